@@ -312,6 +312,169 @@ def gen_encode():
     print("facade:", res, f"{time.time() - t0:.1f}s")
 
 
+# --------------------------------------------------------------------------
+# G4  decode transform chain on seeded random spectra (short / mixed / MS / 3 rates)
+# --------------------------------------------------------------------------
+def header_bytes(sr_code, mode, mode_ext, bitrate_idx=9, pad=0):
+    return [0xFF, 0xFB, (bitrate_idx << 4) | (sr_code << 2) | (pad << 1), (mode << 6) | (mode_ext << 4)]
+
+
+def run_chain(rng, n_frames, sr_code, mode, mode_ext, bt_choices, allow_mixed, max_abs):
+    """Drive the reference's own transform functions the way Frame.init_frame_params
+    does (decoder/Frame.py:265-286) on synthetic Huffman-decoded input."""
+    fr = RF.Frame()
+    fr.init_header_params(header_bytes(sr_code, mode, mode_ext))
+    hdr = fr._Frame__header
+    si = fr.side_info
+    nch = hdr.channels
+    rec = {k: [] for k in ("is", "gg", "sfs", "bt", "mixed", "pre", "sbg", "sfl", "sfsh", "pcm")}
+    for f in range(n_frames):
+        isv = np.zeros((2, 2, 576), dtype=np.int16)
+        for gr in range(2):
+            for ch in range(nch):
+                n_big = int(rng.integers(0, 577))
+                v = np.zeros(576, dtype=np.int64)
+                mag = rng.integers(0, max_abs + 1, size=n_big)
+                small = rng.random(n_big) < 0.8
+                mag = np.where(small, rng.integers(0, 16, size=n_big), mag)
+                v[:n_big] = mag * rng.choice([-1, 1], size=n_big)
+                isv[gr, ch] = v
+                bt = int(rng.choice(bt_choices))
+                si.block_type[gr][ch] = bt
+                si.window_switching[gr][ch] = bt != 0
+                si.mixed_block_flag[gr][ch] = bool(allow_mixed and bt != 0 and rng.random() < 0.5)
+                si.global_gain[gr][ch] = int(rng.integers(90, 200))
+                si.scale_fac_scale[gr][ch] = int(rng.integers(0, 2))
+                si.pre_flag[gr][ch] = int(rng.integers(0, 2))
+                si.sub_block_gain[gr][ch][:] = rng.integers(0, 8, size=3)
+                si.scale_fac_l[gr][ch][:21] = rng.integers(0, 16, size=21)
+                si.scale_fac_l[gr][ch][21] = 0
+                si.scale_fac_s[gr][ch][:, :12] = rng.integers(0, 16, size=(3, 12))
+                si.scale_fac_s[gr][ch][:, 12] = 0
+        fr._Frame__samples[:] = isv.astype(np.float64)
+        fr._Frame__pcm = np.zeros((1152, nch))
+        for k, a in (("gg", si.global_gain), ("sfs", si.scale_fac_scale), ("bt", si.block_type),
+                     ("mixed", si.mixed_block_flag), ("pre", si.pre_flag), ("sbg", si.sub_block_gain),
+                     ("sfl", si.scale_fac_l), ("sfsh", si.scale_fac_s)):
+            rec[k].append(np.asarray(a).astype(np.int32).copy())
+        rec["is"].append(isv)
+        for gr in range(2):
+            for ch in range(nch):
+                RF.re_quantize(gr, ch, si.scale_fac_scale, si.block_type, si.mixed_block_flag,
+                               hdr.band_width.short_win, si.global_gain, si.scale_fac_s, hdr.band_index.long_win,
+                               si.scale_fac_l, si.pre_flag, fr._Frame__samples, si.sub_block_gain)
+            if hdr.channel_mode == RF.ChannelMode.JointStereo and hdr.mode_extension[0]:
+                fr._Frame__ms_stereo(gr)
+            for ch in range(nch):
+                if si.block_type[gr][ch] == 2 or si.mixed_block_flag[gr][ch]:
+                    fr._Frame__reorder(gr, ch)
+                else:
+                    fr._Frame__alias_reduction(gr, ch)
+                RF.imdct(gr, ch, si.block_type, fr._Frame__samples, fr._Frame__sine_block, fr._Frame__prev_samples)
+                fr._Frame__frequency_inversion(gr, ch)
+                RF.synth_filter_bank(gr, ch, fr._Frame__samples, fr._Frame__fifo, fr._Frame__synth_filter_bank_block)
+        fr._Frame__interleave()
+        rec["pcm"].append(fr.pcm.copy())
+    out = {k: np.stack(v) for k, v in rec.items()}
+    out["hdr"] = np.asarray(header_bytes(sr_code, mode, mode_ext), dtype=np.uint8)
+    return out
+
+
+def gen_stages():
+    t0 = time.time()
+    rng = np.random.default_rng(20250523)
+    cases = {
+        # name: (frames, sr_code, mode, mode_ext, block types, mixed?, max |is|)
+        "long_44_stereo": (3, 0, 0, 0, [0], False, 8206),
+        "all_44_ms": (4, 0, 1, 2, [0, 1, 2, 3], True, 2000),
+        "all_48_stereo": (3, 1, 0, 0, [0, 1, 2, 3], True, 300),
+        "all_32_ms": (3, 2, 1, 2, [0, 2, 2, 3], True, 300),
+        "short_44_mono": (3, 0, 3, 0, [2, 0], False, 100),
+        "joint_noms_44": (2, 0, 1, 1, [0, 2], False, 100),
+    }
+    out = {}
+    for name, c in cases.items():
+        r = run_chain(rng, *c)
+        for k, v in r.items():
+            out[f"{name}__{k}"] = v
+    np.savez_compressed(os.path.join(HERE, "g4_decode_chain.npz"), **out)
+    print("stages: decode chain", len(cases), "cases", f"{time.time() - t0:.1f}s")
+    gen_enc_stages(rng)
+
+
+# --------------------------------------------------------------------------
+# G5  encoder stage vectors
+# --------------------------------------------------------------------------
+def gen_enc_stages(rng):
+    t0 = time.time()
+    wav = os.path.join(WORK, "tiny.wav")
+    write_wav(wav, np.zeros((1152, 2), dtype=np.int16), 44100)
+    enc = RE.MP3Encoder(RE.WavReader(wav, 128))
+    out = {}
+    # analysis filterbank: ring x + 32 new samples -> 32 subband values, 6 consecutive slots
+    x = np.zeros((2, 512), dtype=np.int32)
+    off = np.zeros(2, dtype=np.int32)
+    pcm = rng.integers(-32768, 32768, size=(6, 32)).astype(np.int16)
+    pcm[0, :4] = [-32768, 32767, -32768, 32767]
+    sb = np.zeros((6, 32), dtype=np.int32)
+    for k in range(6):
+        for i in range(31, -1, -1):
+            x[0][i + off[0]] = np.int32(pcm[k][31 - i]) << 16
+        sb[k] = RE.window_filter_sub_band(np.zeros(32, dtype=np.int32), 0, x, off, enc._MP3Encoder__sub_band.fl)
+    out["wf_pcm"] = pcm
+    out["wf_sb"] = sb
+    # quantize incl. the ln >= 10000 float path and the early-out
+    l3 = enc._MP3Encoder__l3loop
+    xr = (rng.standard_normal(576) * 10 ** rng.uniform(3, 9.3, size=576)).astype(np.int64)
+    xr = np.clip(xr, -(2 ** 31 - 1), 2 ** 31 - 1).astype(np.int32)
+    xrabs = np.abs(xr.astype(np.int64)).astype(np.int32)
+    xrmax = int(xrabs.max())
+    steps = list(range(-120, 1, 7))
+    qix = np.zeros((len(steps), 576), dtype=np.int32)
+    qmax = np.zeros(len(steps), dtype=np.int32)
+    ix = np.zeros(576, dtype=np.int32)
+    for n, st in enumerate(steps):
+        qmax[n] = RE.quantize(ix, st, l3.steptabi, xrmax, xr, l3.int2idx, l3.steptab, xrabs)
+        qix[n] = ix
+    out["q_xr"] = xr
+    out["q_steps"] = np.asarray(steps, dtype=np.int32)
+    out["q_ix"] = qix
+    out["q_max"] = qmax
+    np.savez_compressed(os.path.join(HERE, "g5_encode_stages.npz"), **out)
+    print("stages: encoder", f"{time.time() - t0:.1f}s")
+
+
+# --------------------------------------------------------------------------
+# G6  synthetic 44.1 kHz stereo stream @128 kbps with a hidden message
+# --------------------------------------------------------------------------
+def gen_synth():
+    sys.path.insert(0, os.path.dirname(HERE))
+    from synth_pcm import synth_pcm
+    n_frames = 48
+    pcm = synth_pcm(n_frames, seed=0x9E3779B97F4A7C15)
+    # make the last 6 frames fade into digital silence: exercises xrmax == 0 and big_values == 0 (E7)
+    fade = np.ones(n_frames * 1152)
+    fade[-6 * 1152:-4 * 1152] = np.linspace(1, 0, 2 * 1152) ** 4
+    fade[-4 * 1152:] = 0
+    pcm = (pcm.astype(np.float64) * fade[:, None]).astype(np.int16)
+    wav = os.path.join(WORK, "synth.wav")
+    write_wav(wav, pcm, 44100)
+    msg = "5#hello"
+    hide = str_to_binary_str(msg)
+    t0 = time.time()
+    out, mp3 = encode_instrumented(wav, os.path.join(WORK, "synth.mp3"), 128, hide, keep_frames=None)
+    out["hide_bits"] = np.frombuffer(hide.encode(), dtype=np.uint8) - ord("0")
+    out["pcm"] = pcm
+    out["mp3"] = np.frombuffer(mp3, dtype=np.uint8)
+    print("synth encode:", len(mp3), f"{time.time() - t0:.1f}s")
+    t0 = time.time()
+    dec, _ = decode_instrumented(os.path.join(WORK, "synth.mp3"), os.path.join(WORK, "synth_dec.wav"), keep_pcm_frames=2)
+    for k in ("bits", "pcm_sha256", "pcm_i16_sha256", "wav_sha256", "pcm_head", "is"):
+        out["dec_" + k] = dec[k]
+    np.savez_compressed(os.path.join(HERE, "g6_synth128.npz"), **out)
+    print("synth decode:", len(dec["bits"]), "bits", f"{time.time() - t0:.1f}s")
+
+
 if __name__ == "__main__":
     what = sys.argv[1:] or ["tables", "decode", "encode"]
     for w in what:
