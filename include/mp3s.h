@@ -1,0 +1,219 @@
+/*
+ * mp3s.h -- C-ABI of the MI355X-native MP3 steganography hot path.
+ *
+ * Drop-in boundary for tomershay100/mp3-steganography-lib (mp3stego-lib 1.1.8).
+ * The reference has no FFI layer: its boundary is the Python API re-exported at
+ * reference mp3stego/__init__.py:1-4 (Decoder, Encoder, Steganography).  The
+ * Python package shipped in mp3-steganography-lib_amd/mp3stego/ keeps that
+ * surface and binds the entry points below with ctypes.
+ * "replaces:" lines name the reference code each entry point stands in for.
+ *
+ * Conventions
+ *   - every function returns MP3S_OK (0) or a negative MP3S_E_* code, never
+ *     exits; mp3s_last_error() gives a message for the calling thread;
+ *   - plain pointers + sizes, no C++/torch types; the caller owns all host
+ *     buffers it passes in; buffers returned through mp3s_buf are owned by the
+ *     library until mp3s_buf_free();
+ *   - a context is bound to ONE HIP device (one process per GPU); calls on one
+ *     context are serialised by the caller;
+ *   - transforms run ONLY on the GPU: without a usable HIP device
+ *     mp3s_ctx_create() fails with MP3S_E_NO_DEVICE and nothing falls back to
+ *     the CPU.  The serial bit parsing / packing stages stay on the host by
+ *     design.
+ */
+#ifndef MP3S_H
+#define MP3S_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MP3S_OK 0
+#define MP3S_E_NO_DEVICE (-1)   /* no HIP device / HIP runtime error at init */
+#define MP3S_E_HIP (-2)         /* HIP runtime error during a call */
+#define MP3S_E_ARG (-3)         /* bad argument (null, size, range) */
+#define MP3S_E_MALFORMED (-4)   /* input the reference raises IndexError/KeyError on */
+#define MP3S_E_UNSUPPORTED (-5) /* input the reference itself cannot process (mono encode, partial frame) */
+#define MP3S_E_STEP_RANGE (-6)  /* quantizer step left the table (reference: IndexError) */
+#define MP3S_E_NOMEM (-7)
+
+#define MP3S_PCM_I16 0 /* (pcm*32767) truncated toward zero, low 16 bits: reference decoder/MP3_Parser.py:91 */
+#define MP3S_PCM_F32 1
+#define MP3S_PCM_F64 2 /* the reference's own float64 samples, bit for bit */
+
+typedef struct mp3s_ctx mp3s_ctx;
+
+/* ---------------------------------------------------------------- records (device + host layout) */
+
+/* per granule*channel side record consumed by the decode transform
+ * replaces: the arguments of re_quantize(), reference decoder/Frame.py:157-176 */
+typedef struct {
+    uint8_t global_gain, scalefac_scale, block_type, mixed_block_flag, preflag;
+    uint8_t sub_block_gain[3];
+    uint8_t scale_fac_l[22];
+    uint8_t scale_fac_s[3][13];
+    uint8_t pad[3];
+} mp3s_granule_si; /* 72 bytes */
+
+/* per frame record.  stream_first = index (in the batch) of the frame that starts the
+ * stream this frame belongs to: overlap/fifo state is zero before it
+ * (reference decoder/Frame.py:234-235, encoder/MP3_Encoder.py:528-534). */
+typedef struct {
+    uint8_t sr_idx;    /* 0 = 44.1 kHz, 1 = 48 kHz, 2 = 32 kHz (header bits) */
+    uint8_t nch;
+    uint8_t ms_stereo; /* JointStereo && (byte3 & 0x20): reference Frame.py:273 */
+    uint8_t flags;
+    uint32_t stream_first;
+} mp3s_frame_hdr; /* 8 bytes */
+
+/* per frame input of the rate loop */
+typedef struct {
+    int32_t max_bits;     /* min(mean_bits // nch, 4095): reference MP3_Encoder.py:894-912 */
+    int32_t sr_idx;
+} mp3s_rate_frame;
+
+/* per granule*channel result of the rate loop
+ * replaces: GrInfo as left by __iteration_loop, reference encoder/MP3_Encoder.py:81-103, 760-815 */
+typedef struct {
+    int32_t part2_3_length; /* WITHOUT stuffing (added by the host back end, MP3_Encoder.py:1097-1145) */
+    int32_t big_values, count1, quantizer_step, region0_count, region1_count, count1table_select;
+    int32_t table_select[3];
+    int32_t address[3];     /* address1/2/3 as left behind (persist per (gr,ch) across frames) */
+    int32_t n_tables;       /* number of non-zero table_select: advance of the hide cursor (:808-809) */
+    int32_t flags;          /* MP3S_RF_* */
+    int32_t reserved0;
+    int32_t xrmax;
+    int32_t reserved;
+} mp3s_gr_out; /* 72 bytes */
+#define MP3S_RF_ACTIVE 1      /* xrmax != 0: outer loop ran */
+#define MP3S_RF_USED_ADDR_IN 2 /* the incoming address1/2/3 were read before being overwritten */
+#define MP3S_RF_STEP_RANGE 4  /* quantizer step left the table */
+#define MP3S_RF_LOG_GUARD 8   /* a log() landed within 1e-9 of an integer: host must recheck scfsi */
+
+/* ---------------------------------------------------------------- context */
+int mp3s_ctx_create(int device, mp3s_ctx **out);
+void mp3s_ctx_destroy(mp3s_ctx *ctx);
+const char *mp3s_last_error(void);
+const char *mp3s_version(void);
+int mp3s_device_name(mp3s_ctx *ctx, char *buf, size_t n);
+int mp3s_sync(mp3s_ctx *ctx);
+
+/* device memory owned by the caller through the context (for resident pipelines / benchmarks) */
+int mp3s_dev_alloc(mp3s_ctx *ctx, size_t bytes, void **dptr);
+int mp3s_dev_free(mp3s_ctx *ctx, void *dptr);
+int mp3s_dev_upload(mp3s_ctx *ctx, void *dptr, const void *host, size_t bytes);
+int mp3s_dev_download(mp3s_ctx *ctx, void *host, const void *dptr, size_t bytes);
+int mp3s_dev_memset(mp3s_ctx *ctx, void *dptr, int value, size_t bytes);
+/* HIP-event timer on the context's stream (the stream every kernel below is launched on) */
+int mp3s_timer_start(mp3s_ctx *ctx);
+int mp3s_timer_stop(mp3s_ctx *ctx, float *ms);
+
+/* ---------------------------------------------------------------- (ii) decode transform batch
+ * replaces: re_quantize, __ms_stereo, __reorder, __alias_reduction, imdct, __frequency_inversion,
+ *           synth_filter_bank, __interleave -- reference decoder/Frame.py:65-218, 561-640 (and the
+ *           (pcm*32767).astype(int16) of MP3_Parser.py:91 for MP3S_PCM_I16).
+ * is  : int16 [n_frames][2 gr][2 ch][576]   (ch 1 ignored when nch == 1)
+ * si  : mp3s_granule_si [n_frames][2][2]
+ * hdr : mp3s_frame_hdr [n_frames]
+ * pcm : [n_frames - n_halo][1152][nch] of the requested format
+ * Frames are consecutive frames of one or more streams; the first n_halo frames only rebuild state
+ * (a 1-frame halo is enough).  *_dev takes device pointers and is asynchronous on
+ * the context's stream; the host variant uploads, runs, downloads and synchronises. */
+int mp3s_decode_transform_dev(mp3s_ctx *ctx, const int16_t *d_is, const mp3s_granule_si *d_si,
+                              const mp3s_frame_hdr *d_hdr, int n_frames, int nch, int n_halo, int out_format,
+                              void *d_pcm);
+int mp3s_decode_transform(mp3s_ctx *ctx, const int16_t *is, const mp3s_granule_si *si, const mp3s_frame_hdr *hdr,
+                          int n_frames, int nch, int n_halo, int out_format, void *pcm);
+
+/* ---------------------------------------------------------------- (iii) encode transform batch
+ * replaces: __replace_samples, window_filter_sub_band, __mdct_sub (MDCT + alias butterflies)
+ *           -- reference encoder/MP3_Encoder.py:321-370, 652-758.
+ * pcm  : int16 [n_frames][1152][2] interleaved (stereo only: mono encode raises in the reference)
+ * mdct : int32 [n_frames][2 ch][2 gr][576]  (the reference's __mdct_freq layout) */
+int mp3s_encode_transform_dev(mp3s_ctx *ctx, const int16_t *d_pcm, const mp3s_frame_hdr *d_hdr, int n_frames,
+                              int32_t *d_mdct);
+int mp3s_encode_transform(mp3s_ctx *ctx, const int16_t *pcm, const mp3s_frame_hdr *hdr, int n_frames,
+                          int32_t *mdct);
+
+/* ---------------------------------------------------------------- (iv) rate-loop batch
+ * replaces: __iteration_loop body per granule*channel: xrsq/xrabs/xrmax, __calc_scfsi energies,
+ *           __bin_search_step_size, quantize, calc_run_len, count1_bit_count, __subdivide,
+ *           __big_v_tab_select/__new_choose_table (+ IDX_TO_TRANSFORM_HUF hide swap), count_bit,
+ *           big_v_bit_count, __inner_loop -- reference encoder/MP3_Encoder.py:171-318, 373-449, 760-1095,
+ *           1147-1264.
+ * Units are indexed u = (frame*2 + ch)*2 + gr, i.e. the reference's processing order (ch outer, gr inner).
+ * mdct      : int32 [n_frames][2][2][576]
+ * frames    : mp3s_rate_frame [n_frames]
+ * hide_bits : n_hide bytes of 0/1 (NULL/0: not hiding)
+ * cursor_in : int32 [n_units] hide-string index at the start of each unit (ignored when not hiding)
+ * state_in  : int32 [n_units][4] address1, address2, address3, quantizerStepSize inherited from the same
+ *             (gr,ch) of the previous frame (NULL = zeros)
+ * unit_list : optional int32 [n_list] subset of units to (re)compute; NULL = all n_frames*4
+ * ix        : int16 [n_frames][2][2][576] signed quantised spectrum (sign from mdct, :1272-1276)
+ * out       : mp3s_gr_out [n_units]
+ * en        : int32 [n_units][22] __calc_scfsi energies: 21 scalefactor bands + the granule total
+ * The serial hide cursor / address chain is resolved by the caller (mp3s_encode_pcm does it):
+ * run, prefix-sum n_tables, re-run the units whose assumed inputs were wrong, until none. */
+int mp3s_rate_loop_dev(mp3s_ctx *ctx, const int32_t *d_mdct, const mp3s_rate_frame *d_frames, int n_frames,
+                       const uint8_t *d_hide_bits, int n_hide, const int32_t *d_cursor_in, const int32_t *d_state_in,
+                       const int32_t *d_unit_list, int n_list, int16_t *d_ix, mp3s_gr_out *d_out, int32_t *d_en);
+
+/* ---------------------------------------------------------------- host stages (no GPU needed) */
+typedef struct mp3s_buf mp3s_buf; /* library-owned result */
+void mp3s_buf_free(mp3s_buf *b);
+
+/* replaces: MP3Parser.parse_file front end: header/side-info parse, reservoir reassembly, scalefactor
+ * and Huffman decode, stego bit extraction -- reference decoder/MP3_Parser.py:25-85, Frame.py:244-263,
+ * 288-559, 676-685, FrameHeader.py, FrameSideInformation.py, util.py:22-81, ID3 skip (ID3_Parser.py:95-131). */
+typedef struct {
+    int32_t n_frames, nch, sampling_rate, bit_rate; /* rate/bitrate of the LAST header */
+    int32_t n_bits;          /* stego bits */
+    int32_t dup_last_frame;  /* reference appends the last PCM frame once more after a bad header (D12) */
+    const int16_t *is;       /* [n_frames][2][2][576] */
+    const mp3s_granule_si *si;
+    const mp3s_frame_hdr *hdr;
+    const uint8_t *bits;     /* 0/1 */
+    const int32_t *table_select; /* [n_frames][2 gr][2 ch][3] as parsed (for tests) */
+    const int32_t *frame_size;   /* [n_frames] */
+} mp3s_parsed;
+int mp3s_parse_stream(const uint8_t *file, size_t len, mp3s_buf **owner, mp3s_parsed *out);
+
+/* replaces: Encoder back end: padding/slot-lag replay, __resv_frame_end, __format_bitstream and the
+ * 32-bit cache writer -- reference encoder/MP3_Encoder.py:623-636, 1097-1145, 1266-1552.
+ * ix/gr/scfsi as produced by the rate loop for n_frames stereo frames. */
+int mp3s_format_stream(int samplerate, int bitrate_kbps, int n_frames, const int16_t *ix, const mp3s_gr_out *gr,
+                       const int32_t *scfsi /*[n_frames][2][4]*/, mp3s_buf **owner, const uint8_t **mp3, size_t *mp3_len);
+/* per-frame padding / max_bits replay (reference MP3_Encoder.py:630-636, 894-912) */
+int mp3s_rate_frames(int samplerate, int bitrate_kbps, int nch, int n_frames, mp3s_rate_frame *out, int32_t *padding);
+
+/* ---------------------------------------------------------------- (v) whole-stream conveniences */
+/* replaces: Decoder.decode up to (not including) the WAV write -- reference decoder/decoder.py:59-84 */
+typedef struct {
+    int32_t n_frames, nch, sampling_rate, bit_rate, n_bits;
+    int64_t n_rows;      /* PCM rows = 1152 * (n_frames + dup_last_frame) */
+    const void *pcm;     /* [n_rows][nch] in out_format */
+    const uint8_t *bits; /* stego bits 0/1 */
+} mp3s_decoded;
+int mp3s_decode_stream(mp3s_ctx *ctx, const uint8_t *file, size_t len, int out_format, mp3s_buf **owner,
+                       mp3s_decoded *out);
+
+/* replaces: Encoder.encode -- reference encoder/encoder.py:33-58, MP3_Encoder.py:596-618 */
+typedef struct {
+    int32_t n_frames;
+    int32_t too_long;      /* hide_str_offset < len(hide_str) - 1 (encoder.py:50) */
+    int64_t hide_offset;
+    const uint8_t *mp3;
+    size_t mp3_len;
+    const mp3s_gr_out *gr; /* [n_frames*4] unit order (frame, ch, gr) */
+    const int32_t *scfsi;  /* [n_frames][2][4] */
+    int32_t rate_passes;   /* launches of the rate loop needed to resolve the serial chain */
+} mp3s_encoded;
+int mp3s_encode_pcm(mp3s_ctx *ctx, const int16_t *pcm, int64_t n_samples_per_ch, int nch, int samplerate,
+                    int bitrate_kbps, const uint8_t *hide_bits, int n_hide, mp3s_buf **owner, mp3s_encoded *out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,126 @@
+// Encode transform kernels (gfx950).  Included by mp3s_device.hip only.
+//
+//   k_enc_analysis : __replace_samples + window_filter_sub_band (reference encoder/MP3_Encoder.py:
+//                    321-370, 751-758) + the odd-slot/odd-band sign flip (:676-679).
+//                    lane = time slot (32 new PCM samples); its 512-sample window is read from an
+//                    LDS tile (rows padded to 80 B so 16-byte reads are conflict free), enwindow and
+//                    the 32x64 matrix fl are scalar operands.
+//   k_enc_mdct     : 36->18 MDCT with the fused sine window + alias butterflies (:681-744).
+//                    lane = (channel, band); cos_l is a scalar operand, the butterfly partner comes
+//                    from the neighbouring lane.
+//
+// Everything is the reference's int32 fixed point: mul = (a*b)>>32 per product (v_mul_hi_i32), then
+// wrapping int32 adds -- integer sums are order independent, each product's floor is not, so every
+// product is floored on its own exactly as the reference does.
+#pragma once
+
+namespace mp3s {
+
+constexpr int ENC_ROW = 40;   // int16 per LDS row: 32 samples + 8 pad (80-byte stride)
+
+// SB layout: int32 [ch][32 bands][Ts] with Ts = n_frames * 36 slots
+__global__ __launch_bounds__(256) void k_enc_analysis(
+    const int16_t *__restrict__ pcm, const mp3s_frame_hdr *__restrict__ hdr, int n_frames,
+    int32_t *__restrict__ SB, long Ts)
+{
+    __shared__ __attribute__((aligned(16))) int16_t tile[4][79 * ENC_ROW];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const long wid = (long)blockIdx.x * 4 + wave;
+    const int ch = (int)(wid & 1);
+    const long t0 = (wid >> 1) * 64;          // first slot of this wave
+    if (t0 >= Ts) return;
+    int16_t *tw = tile[wave];
+    // stage rows t0-15 .. t0+63 of channel ch (zeros outside the batch)
+    for (int e = lane; e < 79 * 32; e += 64) {
+        const int r = e >> 5, s = e & 31;
+        const long row = t0 - 15 + r;
+        int16_t v = 0;
+        if (row >= 0 && row < Ts) v = pcm[(row * 32 + s) * 2 + ch];
+        tw[r * ENC_ROW + s] = v;
+    }
+    __builtin_amdgcn_s_waitcnt(0xc07f);
+    __builtin_amdgcn_wave_barrier();
+    const long t = t0 + lane;
+    const bool valid = t < Ts;
+    long s0 = 0;
+    if (valid) s0 = (long)hdr[t / 36].stream_first * 36;
+
+    int32_t y[64];
+#pragma unroll
+    for (int i = 0; i < 64; i++) y[i] = 0;
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+#pragma unroll
+        for (int h = 0; h < 2; h++) {
+            const int back = 2 * k + h;                  // rows back from the lane's own row
+            const bool in_stream = (t - back) >= s0;     // ring x starts zeroed (MP3_Encoder.py:532-534)
+            const int16_t *rp = tw + (lane + 15 - back) * ENC_ROW;
+#pragma unroll
+            for (int cb = 0; cb < 4; cb++) {
+                uint4 q = *reinterpret_cast<const uint4 *>(rp + cb * 8);
+                if (!in_stream) q = make_uint4(0, 0, 0, 0);
+                const uint32_t d[4] = {q.x, q.y, q.z, q.w};
+#pragma unroll
+                for (int e = 0; e < 4; e++) {
+                    const int col_lo = cb * 8 + 2 * e, col_hi = col_lo + 1;
+                    const int i_lo = h * 32 + 31 - col_lo, i_hi = h * 32 + 31 - col_hi;
+                    const int32_t x_lo = (int32_t)(d[e] << 16), x_hi = (int32_t)(d[e] & 0xffff0000u);
+                    y[i_lo] += __mulhi(x_lo, c_tab.enwindow[i_lo + 64 * k]);
+                    y[i_hi] += __mulhi(x_hi, c_tab.enwindow[i_hi + 64 * k]);
+                }
+            }
+        }
+    }
+    if (!valid) return;
+    const bool odd_slot = (t & 1) != 0;      // slot-in-granule parity == slot parity (18 is even)
+    int32_t *out = SB + (long)ch * 32 * Ts + t;
+    for (int sb = 0; sb < 32; sb++) {
+        int32_t acc = 0;
+#pragma unroll
+        for (int j = 0; j < 64; j++) acc += __mulhi(c_tab.fl[sb][j], y[j]);
+        if (odd_slot && (sb & 1)) acc = (int32_t)(0u - (uint32_t)acc);
+        out[(long)sb * Ts] = acc;
+    }
+}
+
+// mdct layout: int32 [frame][ch][gr][576]  (reference __mdct_freq)
+__global__ __launch_bounds__(256) void k_enc_mdct(
+    const int32_t *__restrict__ SB, long Ts, const mp3s_frame_hdr *__restrict__ hdr, int n_granules,
+    int32_t *__restrict__ mdct)
+{
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int g = blockIdx.x * 4 + wave;
+    if (g >= n_granules) return;
+    const int ch = lane >> 5, band = lane & 31;
+    const bool has_prev = g > (int)hdr[g >> 1].stream_first * 2;   // l3_sb_sample[ch][0] starts zeroed
+    const int32_t *row = SB + ((long)ch * 32 + band) * Ts + (long)g * 18;
+    int32_t in[36];
+#pragma unroll
+    for (int j = 0; j < 18; j++) {
+        in[j] = has_prev ? row[j - 18] : 0;
+        in[18 + j] = row[j];
+    }
+    int32_t X[18];
+#pragma unroll 2
+    for (int k = 0; k < 18; k++) {
+        int32_t acc = 0;
+#pragma unroll
+        for (int j = 0; j < 36; j++) acc += __mulhi(in[j], c_tab.cos_l[k][j]);
+        X[k] = acc;
+    }
+    // alias butterflies (MP3_Encoder.py:704-744, util.cmuls :143-155)
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+        const int32_t lo_nb = __shfl_up(X[17 - i], 1, 64);   // X[band-1][17-i]
+        const int32_t hi_nb = __shfl_down(X[i], 1, 64);      // X[band+1][i]
+        const int64_t cs = c_tab.mdct_cs[i], ca = c_tab.mdct_ca[i];
+        const int32_t a = X[i], b = X[17 - i];
+        if (band >= 1) X[i] = (int32_t)(((int64_t)a * cs - (int64_t)lo_nb * ca) >> 31);
+        if (band <= 30) X[17 - i] = (int32_t)(((int64_t)hi_nb * ca + (int64_t)b * cs) >> 31);
+    }
+    int32_t *o = mdct + ((((long)(g >> 1) * 2 + ch) * 2 + (g & 1)) * 576) + band * 18;
+#pragma unroll
+    for (int k = 0; k < 18; k++) o[k] = X[k];
+}
+
+}  // namespace mp3s

@@ -1,0 +1,390 @@
+// Rate-loop kernel (gfx950).  Included by mp3s_device.hip only.
+//
+// One wavefront per granule*channel ("unit").  The 288 value pairs of the granule are spread over the
+// lanes (pair p = lane + 64*m, m = 0..4); every step of the reference's loop body is a lane-parallel
+// map plus a DPP wave reduction, and all control flow (binary search, inner loop, region split, table
+// choice, hide swap) is wave-uniform scalar code.
+//   reference encoder/MP3_Encoder.py: __iteration_loop :760-815, __calc_scfsi energies :835-859,
+//   __bin_search_step_size :958-996, __inner_loop :1064-1095, quantize :373-415, calc_run_len :266-291,
+//   count1_bit_count :171-211, __subdivide :998-1036, __big_v_tab_select :1147-1168,
+//   __new_choose_table :1170-1264, count_bit :214-263, big_v_bit_count :294-318.
+// Integer work only (bit exact); the two float spots are quantize's ln >= 10000 path (correctly rounded
+// fp64 sqrt) and the scfsi log, which carries a guard flag so the host can recheck near-integer cases.
+#pragma once
+
+namespace mp3s {
+
+__device__ __forceinline__ uint32_t wave_max_u32(uint32_t v)
+{
+    v = max(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, false));  // row_shr:1
+    v = max(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xf, 0xf, false));  // row_shr:2
+    v = max(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xf, 0xf, false));  // row_shr:4
+    v = max(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xf, 0xf, false));  // row_shr:8
+    v = max(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xa, 0xf, false));  // row_bcast:15
+    v = max(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xc, 0xf, false));  // row_bcast:31
+    return (uint32_t)__builtin_amdgcn_readlane((int)v, 63);
+}
+__device__ __forceinline__ uint32_t wave_add_u32(uint32_t v)
+{
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, false);
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xf, 0xf, false);
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xf, 0xf, false);
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xf, 0xf, false);
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xa, 0xf, false);
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xc, 0xf, false);
+    return (uint32_t)__builtin_amdgcn_readlane((int)v, 63);
+}
+
+// encoder/util.py:130-133 mulr for non-negative a: (a*b + 2^31) >> 32
+__device__ __forceinline__ uint32_t mulr_u(uint32_t a, uint32_t b) { return __umulhi(a, b) + ((a * b) >> 31); }
+
+constexpr int RL_WAVES = 4;
+constexpr int RL_NP = 5;   // pair slots per lane (the 5th only for lanes < 32)
+
+struct RlTables {
+    uint16_t int2idx[10000];
+    uint8_t hlen[4][256];   // 13, 15, 16-family, 24-family
+    uint8_t c1a[16];
+};
+
+struct RlState {           // wave-uniform GrInfo fields that live across rate_body calls
+    int big_values, count1, c1sel, r0c, r1c, a1, a2, a3, ts0, ts1, ts2;
+    bool addr_fresh, used_addr_in;
+};
+
+__device__ __forceinline__ int family_of(int t) { return t == 13 ? 0 : (t == 15 ? 1 : (t < 24 ? 2 : 3)); }
+
+// bits of one pair under table t (count_bit, MP3_Encoder.py:234-261)
+__device__ __forceinline__ uint32_t pair_bits(const RlTables &tb, int t, int x, int y)
+{
+    const int xx = x > 14 ? 15 : x, yy = y > 14 ? 15 : y;
+    uint32_t b = tb.hlen[family_of(t)][xx * 16 + yy] + (x != 0) + (y != 0);
+    if (t > 15) b += c_tab.linbits[t] * ((x > 14) + (y > 14));
+    return b;
+}
+
+// quantize (MP3_Encoder.py:389-415); returns the wave-uniform ix_max, 16384 for the early out, -1 when the
+// step leaves steptab (IndexError in the reference)
+__device__ __forceinline__ int rl_quantize(const RlTables &tb, const uint32_t (&xa)[2 * RL_NP], int32_t (&ix)[2 * RL_NP],
+                                           int step, uint32_t xrmax)
+{
+    const int idx = step + 127;
+    if (idx < 0 || idx > 127) return -1;
+    const uint32_t scalei = (uint32_t)c_tab.steptabi[idx];
+    if (mulr_u(xrmax, scalei) > 165140u) return 16384;
+    const double scale = c_tab.steptab[idx];
+    uint32_t mx = 0;
+#pragma unroll
+    for (int e = 0; e < 2 * RL_NP; e++) {
+        const uint32_t ln = mulr_u(xa[e], scalei);
+        int32_t v;
+        if (ln < 10000u) v = tb.int2idx[ln];
+        else {
+            const double dbl = (double)xa[e] * scale * 4.656612875e-10;
+            v = (int32_t)__dsqrt_rn(__dsqrt_rn(dbl) * dbl);
+        }
+        ix[e] = v;
+        mx = max(mx, (uint32_t)v);
+    }
+    return (int)wave_max_u32(mx);
+}
+
+// calc_run_len + count1_bit_count + __subdivide + __big_v_tab_select + big_v_bit_count
+__device__ __forceinline__ int rl_body(const RlTables &tb, uint8_t *pcode, const int32_t (&ix)[2 * RL_NP], int lane,
+                                       int sr, RlState &st, const uint8_t *__restrict__ hide, int n_hide, int cursor)
+{
+    // ---- calc_run_len: highest non-zero pair P0, highest pair holding a value > 1 P1
+    int P0 = -1, P1 = -1;
+#pragma unroll
+    for (int m = RL_NP - 1; m >= 0; m--) {
+        const unsigned long long nzm = __ballot((ix[2 * m] | ix[2 * m + 1]) != 0);
+        const unsigned long long bgm = __ballot(ix[2 * m] > 1 || ix[2 * m + 1] > 1);
+        if (P0 < 0 && nzm) P0 = 64 * m + 63 - __builtin_clzll(nzm);
+        if (P1 < 0 && bgm) P1 = 64 * m + 63 - __builtin_clzll(bgm);
+    }
+    const int count1 = (P0 - P1) >> 1;
+    const int bv = (P0 + 1) - 2 * count1;
+    st.count1 = count1;
+    st.big_values = bv;
+
+    // ---- count1_bit_count: quad k = pairs (bv+2k, bv+2k+1), p = v + 2w + 4x + 8y
+#pragma unroll
+    for (int m = 0; m < RL_NP; m++) pcode[lane + 64 * m] = (uint8_t)((ix[2 * m] & 1) | ((ix[2 * m + 1] & 1) << 1));
+    __builtin_amdgcn_s_waitcnt(0xc07f);
+    __builtin_amdgcn_wave_barrier();
+    uint32_t acc = 0;
+#pragma unroll
+    for (int m = 0; m < RL_NP; m++) {
+        const int p = lane + 64 * m;
+        const int rel = p - bv;
+        if (rel >= 0 && rel < 2 * count1) {
+            const uint32_t c2 = pcode[p];
+            acc += (uint32_t)__popc(c2) << 16;
+            if (!(rel & 1)) acc += tb.c1a[c2 | ((uint32_t)pcode[p + 1] << 2)];
+        }
+    }
+    acc = wave_add_u32(acc);
+    const int signs = (int)(acc >> 16), sum0 = signs + (int)(acc & 0xffff), sum1 = signs + 4 * count1;
+    int bits;
+    if (sum0 < sum1) { st.c1sel = 0; bits = sum0; } else { st.c1sel = 1; bits = sum1; }   // ties -> table B (E10)
+
+    // ---- __subdivide (addresses are left untouched when big_values == 0: E7)
+    const int bvr = 2 * bv;
+    if (bv == 0) {
+        st.r0c = 0; st.r1c = 0;
+        if (!st.addr_fresh) st.used_addr_in = true;
+    } else {
+        const int32_t *sfb = c_tab.sfb_long[sr];
+        int anz = 0;
+        while (sfb[anz] < bvr) anz++;
+        int tc = c_tab.subdv[anz][0];
+        while (tc > 0) { if (sfb[tc + 1] <= bvr) break; tc--; }
+        st.r0c = tc; st.a1 = sfb[tc + 1];
+        const int base = tc + 1;
+        tc = c_tab.subdv[anz][1];
+        while (tc > 0) { if (sfb[base + tc + 1] <= bvr) break; tc--; }
+        st.r1c = tc; st.a2 = sfb[base + tc + 1];
+        st.a3 = bvr;
+        st.addr_fresh = true;
+    }
+
+    // ---- region maxima; a pair starting at line s belongs to r0 if s < a1, r1 if s < a2, r2 if s < 2*bv
+    const int a1 = st.a1, a2 = st.a2;
+    uint32_t mx0 = 0, mx1 = 0, mx2 = 0;
+    int rid[RL_NP];
+#pragma unroll
+    for (int m = 0; m < RL_NP; m++) {
+        const int s = 2 * (lane + 64 * m);
+        const uint32_t pm = (uint32_t)max(ix[2 * m], ix[2 * m + 1]);
+        int r = -1;
+        if (s < a1) { r = 0; mx0 = max(mx0, pm); }
+        else if (s < a2) { r = 1; mx1 = max(mx1, pm); }
+        else if (s < bvr) { r = 2; mx2 = max(mx2, pm); }
+        rid[m] = r;
+    }
+    const int rmax[3] = {(int)wave_max_u32(mx0), (int)wave_max_u32(mx1), (int)wave_max_u32(mx2)};
+
+    // ---- candidates per region (__new_choose_table)
+    int tA[3], tB[3];
+#pragma unroll
+    for (int r = 0; r < 3; r++) {
+        const int mxr = rmax[r];
+        if (mxr == 0) { tA[r] = 0; tB[r] = 0; }
+        else if (mxr < 15) {
+            // reference :1190-1193 scans tables 13..0 for x_len > ix_max; table 13 (x_len 16) always hits first
+            tA[r] = 13; tB[r] = 15;
+        } else {
+            const int need = mxr - 15;
+            int c0 = 15, c1 = 24;
+            while (c0 < 23 && c_tab.linmax[c0] < need) c0++;
+            while (c1 < 31 && c_tab.linmax[c1] < need) c1++;
+            tA[r] = c0; tB[r] = c1;
+        }
+    }
+    uint32_t w[3] = {0, 0, 0};
+#pragma unroll
+    for (int m = 0; m < RL_NP; m++) {
+        const int r = rid[m];
+        if (r >= 0) {
+            const int ta = r == 0 ? tA[0] : (r == 1 ? tA[1] : tA[2]);
+            const int tbb = r == 0 ? tB[0] : (r == 1 ? tB[1] : tB[2]);
+            if (ta) {
+                const uint32_t v = pair_bits(tb, ta, ix[2 * m], ix[2 * m + 1]) |
+                                   (pair_bits(tb, tbb, ix[2 * m], ix[2 * m + 1]) << 16);
+                if (r == 0) w[0] += v; else if (r == 1) w[1] += v; else w[2] += v;
+            }
+        }
+    }
+    int ts[3], rbits[3];
+    bool redo[3];
+    int idx = cursor;
+#pragma unroll
+    for (int r = 0; r < 3; r++) {
+        ts[r] = 0; rbits[r] = 0; redo[r] = false;
+        if (tA[r]) {                                   // uniform
+            const uint32_t s = wave_add_u32(w[r]);
+            const int bA = (int)(s & 0xffff), bB = (int)(s >> 16);
+            int choice;
+            if (tA[r] == 13) choice = (bB <= bA) ? 15 : 13;     // :1227-1231 ties -> 15
+            else choice = (bB < bA) ? tB[r] : tA[r];            // :1254
+            if (n_hide > 0 && idx < n_hide) choice = c_tab.transform[choice][hide[idx] & 1];   // :1257-1263
+            ts[r] = choice;
+            if (choice == tA[r]) rbits[r] = bA;
+            else if (choice == tB[r]) rbits[r] = bB;
+            else redo[r] = true;
+            if (choice > 0) idx += 1;
+        }
+    }
+    if (redo[0] || redo[1] || redo[2]) {               // a hide swap picked a table outside the two candidates
+        uint32_t extra = 0;
+#pragma unroll
+        for (int m = 0; m < RL_NP; m++) {
+            const int r = rid[m];
+            if (r >= 0) {
+                const bool rd = r == 0 ? redo[0] : (r == 1 ? redo[1] : redo[2]);
+                const int t = r == 0 ? ts[0] : (r == 1 ? ts[1] : ts[2]);
+                if (rd) extra += pair_bits(tb, t, ix[2 * m], ix[2 * m + 1]);
+            }
+        }
+        bits += (int)wave_add_u32(extra);
+    }
+    st.ts0 = ts[0]; st.ts1 = ts[1]; st.ts2 = ts[2];
+    return bits + rbits[0] + rbits[1] + rbits[2];
+}
+
+__global__ __launch_bounds__(RL_WAVES * 64) void k_rate_loop(
+    const int32_t *__restrict__ mdct, const mp3s_rate_frame *__restrict__ frames, int n_units,
+    const uint8_t *__restrict__ hide, int n_hide, const int32_t *__restrict__ cursor_in,
+    const int32_t *__restrict__ state_in, const int32_t *__restrict__ unit_list, int n_list,
+    int16_t *__restrict__ ix_out, mp3s_gr_out *__restrict__ out, int32_t *__restrict__ en_out)
+{
+    __shared__ RlTables tb;
+    __shared__ uint8_t pcode_all[RL_WAVES][64 * RL_NP + 4];
+    __shared__ int32_t esq_all[RL_WAVES][576];
+    for (int i = threadIdx.x; i < 10000; i += blockDim.x) tb.int2idx[i] = c_tab.int2idx[i];
+    for (int i = threadIdx.x; i < 256; i += blockDim.x) {
+        tb.hlen[0][i] = c_tab.hlen13[i]; tb.hlen[1][i] = c_tab.hlen15[i];
+        tb.hlen[2][i] = c_tab.hlen16[i]; tb.hlen[3][i] = c_tab.hlen24[i];
+    }
+    if (threadIdx.x < 16) tb.c1a[threadIdx.x] = c_tab.hlen_c1a[threadIdx.x];
+    __syncthreads();
+
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int li = blockIdx.x * RL_WAVES + wave;
+    if (li >= n_list) return;
+    const int u = unit_list ? unit_list[li] : li;
+    if (u < 0 || u >= n_units) return;
+    uint8_t *pcode = pcode_all[wave];
+    int32_t *esq = esq_all[wave];
+    const mp3s_rate_frame fr = frames[u >> 2];
+    const int sr = fr.sr_idx >= 0 && fr.sr_idx < 3 ? fr.sr_idx : 0;
+    const int max_bits = fr.max_bits;
+    const int cursor = (n_hide > 0 && cursor_in) ? cursor_in[u] : 0;
+
+    // ---- load xr, |xr|, xrsq >> 10 (:770-776, :837-838)
+    const int32_t *xr = mdct + (long)u * 576;
+    uint32_t xa[2 * RL_NP];
+    uint32_t negmask = 0, lmax = 0, esum = 0;
+#pragma unroll
+    for (int m = 0; m < RL_NP; m++) {
+        const int p = lane + 64 * m;
+        int2 v = make_int2(0, 0);
+        if (p < 288) v = *reinterpret_cast<const int2 *>(xr + 2 * p);
+        const int32_t vv[2] = {v.x, v.y};
+#pragma unroll
+        for (int e = 0; e < 2; e++) {
+            const uint32_t a = vv[e] < 0 ? (0u - (uint32_t)vv[e]) : (uint32_t)vv[e];
+            xa[2 * m + e] = a;
+            if (vv[e] < 0) negmask |= 1u << (2 * m + e);
+            lmax = max(lmax, a);
+            const int32_t sq = (int32_t)(((uint64_t)a * a + (1ull << 30)) >> 31);   // util.mulsr(xr, xr)
+            const int32_t e10 = sq >> 10;
+            if (p < 288) esq[2 * p + e] = e10;
+            esum += (uint32_t)e10;
+        }
+    }
+    const uint32_t xrmax = wave_max_u32(lmax);
+    const uint32_t etot = wave_add_u32(esum);
+
+    // ---- scalefactor-band energies for __calc_scfsi (:840-857); lane b < 21 sums band b, lane 21 = total
+    __builtin_amdgcn_s_waitcnt(0xc07f);
+    __builtin_amdgcn_wave_barrier();
+    {
+        int32_t temp = 0;
+        if (lane < 21) {
+            const int b0 = c_tab.sfb_long[sr][lane], b1 = c_tab.sfb_long[sr][lane + 1];
+            uint32_t s = 0;
+            for (int i = b0; i < b1; i++) s += (uint32_t)esq[i];
+            temp = (int32_t)s;
+        } else if (lane == 21) temp = (int32_t)etot;
+        int32_t en = 0;
+        bool guard = false;
+        if (lane < 22 && temp) {
+            const double q = log((double)temp * 4.768371584e-7) / 0.69314718;
+            en = (int32_t)q;
+            guard = fabs(q - rint(q)) < 1e-9;
+        }
+        if (lane < 22) en_out[(long)u * 22 + lane] = en;
+        const bool any_guard = __ballot(guard) != 0;
+
+        RlState st;
+        st.big_values = st.count1 = st.c1sel = st.r0c = st.r1c = 0;
+        st.a1 = state_in ? state_in[(long)u * 4 + 0] : 0;
+        st.a2 = state_in ? state_in[(long)u * 4 + 1] : 0;
+        st.a3 = state_in ? state_in[(long)u * 4 + 2] : 0;
+        int qstep = state_in ? state_in[(long)u * 4 + 3] : 0;
+        st.ts0 = st.ts1 = st.ts2 = 0;
+        st.addr_fresh = false; st.used_addr_in = false;
+        int32_t ix[2 * RL_NP];
+#pragma unroll
+        for (int e = 0; e < 2 * RL_NP; e++) ix[e] = 0;
+        int bits = 0, flags = any_guard ? MP3S_RF_LOG_GUARD : 0;
+        bool err = false;
+
+        if (xrmax) {
+            flags |= MP3S_RF_ACTIVE;
+            // ---- __bin_search_step_size (:958-996)
+            int next = -120, count = 120;
+            do {
+                const int half = count / 2;
+                const int q = rl_quantize(tb, xa, ix, next + half, xrmax);
+                int bit;
+                if (q < 0) { err = true; break; }
+                if (q > 8192) bit = 100000;
+                else bit = rl_body(tb, pcode, ix, lane, sr, st, hide, n_hide, cursor);
+                if (bit < max_bits) count = half;
+                else { next += half; count -= half; }
+            } while (count > 1);
+            qstep = next;
+            // ---- __inner_loop (:1064-1095), part2_length == 0
+            if (!err) {
+                if (max_bits < 0) qstep -= 1;
+                do {
+                    int q;
+                    while ((q = rl_quantize(tb, xa, ix, qstep + 1, xrmax)) > 8192) qstep += 1;
+                    if (q < 0) { err = true; break; }
+                    qstep += 1;
+                    bits = rl_body(tb, pcode, ix, lane, sr, st, hide, n_hide, cursor);
+                } while (bits > max_bits);
+            }
+            if (err) flags |= MP3S_RF_STEP_RANGE;
+        }
+        if (st.used_addr_in) flags |= MP3S_RF_USED_ADDR_IN;
+
+        // ---- signed ix (format_bitstream :1272-1276) as int16 pairs
+        int16_t *ixo = ix_out + (long)u * 576;
+#pragma unroll
+        for (int m = 0; m < RL_NP; m++) {
+            const int p = lane + 64 * m;
+            if (p < 288) {
+                int a = xrmax ? ix[2 * m] : 0, b = xrmax ? ix[2 * m + 1] : 0;
+                if ((negmask >> (2 * m)) & 1) a = -a;
+                if ((negmask >> (2 * m + 1)) & 1) b = -b;
+                *reinterpret_cast<uint32_t *>(ixo + 2 * p) = ((uint32_t)(uint16_t)(int16_t)a) | ((uint32_t)(uint16_t)(int16_t)b << 16);
+            }
+        }
+        if (lane == 0) {
+            mp3s_gr_out o;
+            const bool act = xrmax != 0;
+            o.part2_3_length = act ? bits : 0;
+            o.big_values = act ? st.big_values : 0;
+            o.count1 = act ? st.count1 : 0;
+            o.quantizer_step = qstep;
+            o.region0_count = act ? st.r0c : 0;
+            o.region1_count = act ? st.r1c : 0;
+            o.count1table_select = act ? st.c1sel : 0;
+            o.table_select[0] = act ? st.ts0 : 0;
+            o.table_select[1] = act ? st.ts1 : 0;
+            o.table_select[2] = act ? st.ts2 : 0;
+            o.address[0] = st.a1; o.address[1] = st.a2; o.address[2] = st.a3;
+            o.n_tables = act ? (st.ts0 > 0) + (st.ts1 > 0) + (st.ts2 > 0) : 0;
+            o.flags = flags;
+            o.reserved0 = 0;
+            o.xrmax = (int32_t)xrmax;
+            o.reserved = 0;
+            out[u] = o;
+        }
+    }
+}
+
+}  // namespace mp3s

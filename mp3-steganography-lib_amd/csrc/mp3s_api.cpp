@@ -1,0 +1,474 @@
+// C-ABI of the library (include/mp3s.h): context, device memory, the batch entry points and the
+// whole-stream pipelines that glue the host stages to the HIP kernels.  No CPU fallback exists for
+// the transforms: every path that needs them goes through launch_* in mp3s_device.hip.
+#include <hip/hip_runtime_api.h>
+
+#include <algorithm>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/mp3s.h"
+#include "mp3s_device.h"
+#include "mp3s_host.h"
+
+using namespace mp3s;
+
+namespace {
+
+thread_local std::string g_err;
+int fail(int code, const char *fmt, ...)
+{
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    g_err = buf;
+    return code;
+}
+#define HIPCHK(call)                                                                                 \
+    do {                                                                                             \
+        hipError_t e_ = (call);                                                                      \
+        if (e_ != hipSuccess) return fail(MP3S_E_HIP, "%s: %s", #call, hipGetErrorString(e_));       \
+    } while (0)
+
+}  // namespace
+
+struct mp3s_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    void *scratch = nullptr; size_t scratch_bytes = 0;
+    int ensure_scratch(size_t bytes)
+    {
+        if (bytes <= scratch_bytes) return 0;
+        if (scratch) { hipFree(scratch); scratch = nullptr; scratch_bytes = 0; }
+        hipError_t e = hipMalloc(&scratch, bytes);
+        if (e != hipSuccess) return fail(MP3S_E_NOMEM, "hipMalloc(%zu) for scratch: %s", bytes, hipGetErrorString(e));
+        scratch_bytes = bytes;
+        return 0;
+    }
+};
+
+struct mp3s_buf {
+    ParsedStream parsed;
+    std::vector<uint8_t> bytes;      // generic payload (pcm / mp3)
+    std::vector<uint8_t> bits;
+    std::vector<mp3s_gr_out> gr;
+    std::vector<int32_t> scfsi;
+};
+
+extern "C" {
+
+const char *mp3s_last_error(void) { return g_err.c_str(); }
+const char *mp3s_version(void) { return "mp3s-hip 0.1 (gfx950)"; }
+void mp3s_buf_free(mp3s_buf *b) { delete b; }
+
+int mp3s_ctx_create(int device, mp3s_ctx **out)
+{
+    if (!out) return fail(MP3S_E_ARG, "out is null");
+    *out = nullptr;
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n <= 0)
+        return fail(MP3S_E_NO_DEVICE, "no HIP device available (%s); the transforms have no CPU fallback",
+                    e == hipSuccess ? "device count 0" : hipGetErrorString(e));
+    if (device < 0 || device >= n) return fail(MP3S_E_ARG, "device %d out of range (0..%d)", device, n - 1);
+    e = hipSetDevice(device);
+    if (e != hipSuccess) return fail(MP3S_E_NO_DEVICE, "hipSetDevice(%d): %s", device, hipGetErrorString(e));
+    mp3s_ctx *c = new mp3s_ctx();
+    c->device = device;
+    if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess ||
+        hipEventCreate(&c->ev0) != hipSuccess || hipEventCreate(&c->ev1) != hipSuccess) {
+        delete c;
+        return fail(MP3S_E_NO_DEVICE, "stream/event creation failed");
+    }
+    const int rc = dev_upload_tables(c->stream);
+    if (rc) {
+        delete c;
+        return fail(MP3S_E_NO_DEVICE, "constant table upload failed: %s (is this a gfx950 device?)",
+                    hipGetErrorString((hipError_t)rc));
+    }
+    *out = c;
+    return MP3S_OK;
+}
+
+void mp3s_ctx_destroy(mp3s_ctx *c)
+{
+    if (!c) return;
+    hipSetDevice(c->device);
+    if (c->stream) hipStreamSynchronize(c->stream);
+    if (c->scratch) hipFree(c->scratch);
+    if (c->ev0) hipEventDestroy(c->ev0);
+    if (c->ev1) hipEventDestroy(c->ev1);
+    if (c->stream) hipStreamDestroy(c->stream);
+    delete c;
+}
+
+int mp3s_device_name(mp3s_ctx *c, char *buf, size_t n)
+{
+    if (!c || !buf || !n) return fail(MP3S_E_ARG, "bad argument");
+    hipDeviceProp_t p;
+    HIPCHK(hipGetDeviceProperties(&p, c->device));
+    snprintf(buf, n, "%s (%s, %d CUs)", p.name, p.gcnArchName, p.multiProcessorCount);
+    return MP3S_OK;
+}
+
+int mp3s_sync(mp3s_ctx *c)
+{
+    if (!c) return fail(MP3S_E_ARG, "ctx is null");
+    HIPCHK(hipStreamSynchronize(c->stream));
+    return MP3S_OK;
+}
+
+int mp3s_dev_alloc(mp3s_ctx *c, size_t bytes, void **dptr)
+{
+    if (!c || !dptr) return fail(MP3S_E_ARG, "bad argument");
+    HIPCHK(hipSetDevice(c->device));
+    hipError_t e = hipMalloc(dptr, bytes ? bytes : 16);
+    if (e != hipSuccess) return fail(MP3S_E_NOMEM, "hipMalloc(%zu): %s", bytes, hipGetErrorString(e));
+    return MP3S_OK;
+}
+int mp3s_dev_free(mp3s_ctx *c, void *dptr)
+{
+    if (!c) return fail(MP3S_E_ARG, "ctx is null");
+    if (dptr) { HIPCHK(hipStreamSynchronize(c->stream)); HIPCHK(hipFree(dptr)); }
+    return MP3S_OK;
+}
+int mp3s_dev_upload(mp3s_ctx *c, void *dptr, const void *host, size_t bytes)
+{
+    if (!c || (!dptr && bytes) || (!host && bytes)) return fail(MP3S_E_ARG, "bad argument");
+    if (!bytes) return MP3S_OK;
+    HIPCHK(hipMemcpyAsync(dptr, host, bytes, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    return MP3S_OK;
+}
+int mp3s_dev_download(mp3s_ctx *c, void *host, const void *dptr, size_t bytes)
+{
+    if (!c || (!dptr && bytes) || (!host && bytes)) return fail(MP3S_E_ARG, "bad argument");
+    if (!bytes) return MP3S_OK;
+    HIPCHK(hipMemcpyAsync(host, dptr, bytes, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    return MP3S_OK;
+}
+int mp3s_dev_memset(mp3s_ctx *c, void *dptr, int value, size_t bytes)
+{
+    if (!c || !dptr) return fail(MP3S_E_ARG, "bad argument");
+    HIPCHK(hipMemsetAsync(dptr, value, bytes, c->stream));
+    return MP3S_OK;
+}
+int mp3s_timer_start(mp3s_ctx *c)
+{
+    if (!c) return fail(MP3S_E_ARG, "ctx is null");
+    HIPCHK(hipEventRecord(c->ev0, c->stream));
+    return MP3S_OK;
+}
+int mp3s_timer_stop(mp3s_ctx *c, float *ms)
+{
+    if (!c || !ms) return fail(MP3S_E_ARG, "bad argument");
+    HIPCHK(hipEventRecord(c->ev1, c->stream));
+    HIPCHK(hipEventSynchronize(c->ev1));
+    HIPCHK(hipEventElapsedTime(ms, c->ev0, c->ev1));
+    return MP3S_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ batches
+int mp3s_decode_transform_dev(mp3s_ctx *c, const int16_t *d_is, const mp3s_granule_si *d_si, const mp3s_frame_hdr *d_hdr,
+                              int n_frames, int nch, int n_halo, int out_format, void *d_pcm)
+{
+    if (!c || !d_is || !d_si || !d_hdr || !d_pcm) return fail(MP3S_E_ARG, "null pointer");
+    if (n_frames <= 0 || nch < 1 || nch > 2 || n_halo < 0 || n_halo >= n_frames || out_format < 0 || out_format > 2)
+        return fail(MP3S_E_ARG, "bad sizes: n_frames=%d nch=%d n_halo=%d fmt=%d", n_frames, nch, n_halo, out_format);
+    int rc = c->ensure_scratch(dec_scratch_bytes(n_frames, nch));
+    if (rc) return rc;
+    const int e = launch_decode(c->stream, d_is, d_si, d_hdr, n_frames, nch, n_halo, out_format, d_pcm, c->scratch);
+    if (e) return fail(MP3S_E_HIP, "decode launch: %s", hipGetErrorString((hipError_t)e));
+    return MP3S_OK;
+}
+
+static size_t pcm_elem(int fmt) { return fmt == MP3S_PCM_I16 ? 2 : (fmt == MP3S_PCM_F32 ? 4 : 8); }
+
+// frame 0 of a batch always starts from zero state; later frames must not point forward
+static int check_hdr(const mp3s_frame_hdr *hdr, int n)
+{
+    for (int f = 0; f < n; f++) {
+        if (hdr[f].stream_first > (uint32_t)f) return fail(MP3S_E_ARG, "hdr[%d].stream_first=%u points forward", f, hdr[f].stream_first);
+        if (f && hdr[f].stream_first != (uint32_t)f && hdr[f].stream_first != hdr[f - 1].stream_first)
+            return fail(MP3S_E_ARG, "hdr[%d].stream_first is not monotone", f);
+        if (hdr[f].sr_idx > 2) return fail(MP3S_E_ARG, "hdr[%d].sr_idx=%d", f, hdr[f].sr_idx);
+    }
+    if (n && hdr[0].stream_first != 0) return fail(MP3S_E_ARG, "hdr[0].stream_first must be 0");
+    return 0;
+}
+
+int mp3s_decode_transform(mp3s_ctx *c, const int16_t *is, const mp3s_granule_si *si, const mp3s_frame_hdr *hdr,
+                          int n_frames, int nch, int n_halo, int out_format, void *pcm)
+{
+    if (!c || !is || !si || !hdr || !pcm) return fail(MP3S_E_ARG, "null pointer");
+    if (n_frames <= 0 || n_halo < 0 || n_halo >= n_frames) return fail(MP3S_E_ARG, "bad sizes");
+    int rc = check_hdr(hdr, n_frames);
+    if (rc) return rc;
+    for (size_t i = 0; i < (size_t)n_frames * 2304; i++)
+        if (is[i] > 8206 || is[i] < -8206) return fail(MP3S_E_ARG, "is[%zu]=%d outside +-8206", i, is[i]);
+    HIPCHK(hipSetDevice(c->device));
+    void *d_is = nullptr, *d_si = nullptr, *d_hdr = nullptr, *d_pcm = nullptr;
+    const size_t b_is = (size_t)n_frames * 2304 * 2, b_si = (size_t)n_frames * 4 * sizeof(mp3s_granule_si),
+                 b_hdr = (size_t)n_frames * sizeof(mp3s_frame_hdr),
+                 b_pcm = (size_t)(n_frames - n_halo) * 1152 * nch * pcm_elem(out_format);
+    rc = MP3S_OK;
+    if (hipMalloc(&d_is, b_is) != hipSuccess || hipMalloc(&d_si, b_si) != hipSuccess ||
+        hipMalloc(&d_hdr, b_hdr) != hipSuccess || hipMalloc(&d_pcm, b_pcm) != hipSuccess)
+        rc = fail(MP3S_E_NOMEM, "hipMalloc failed for a %d-frame batch", n_frames);
+    if (!rc) rc = mp3s_dev_upload(c, d_is, is, b_is);
+    if (!rc) rc = mp3s_dev_upload(c, d_si, si, b_si);
+    if (!rc) rc = mp3s_dev_upload(c, d_hdr, hdr, b_hdr);
+    if (!rc) rc = mp3s_decode_transform_dev(c, (const int16_t *)d_is, (const mp3s_granule_si *)d_si,
+                                            (const mp3s_frame_hdr *)d_hdr, n_frames, nch, n_halo, out_format, d_pcm);
+    if (!rc) rc = mp3s_dev_download(c, pcm, d_pcm, b_pcm);
+    hipStreamSynchronize(c->stream);
+    hipFree(d_is); hipFree(d_si); hipFree(d_hdr); hipFree(d_pcm);
+    return rc;
+}
+
+int mp3s_encode_transform_dev(mp3s_ctx *c, const int16_t *d_pcm, const mp3s_frame_hdr *d_hdr, int n_frames, int32_t *d_mdct)
+{
+    if (!c || !d_pcm || !d_hdr || !d_mdct) return fail(MP3S_E_ARG, "null pointer");
+    if (n_frames <= 0) return fail(MP3S_E_ARG, "n_frames=%d", n_frames);
+    int rc = c->ensure_scratch(enc_scratch_bytes(n_frames));
+    if (rc) return rc;
+    const int e = launch_encode(c->stream, d_pcm, d_hdr, n_frames, d_mdct, c->scratch);
+    if (e) return fail(MP3S_E_HIP, "encode launch: %s", hipGetErrorString((hipError_t)e));
+    return MP3S_OK;
+}
+
+int mp3s_encode_transform(mp3s_ctx *c, const int16_t *pcm, const mp3s_frame_hdr *hdr, int n_frames, int32_t *mdct)
+{
+    if (!c || !pcm || !hdr || !mdct) return fail(MP3S_E_ARG, "null pointer");
+    if (n_frames <= 0) return fail(MP3S_E_ARG, "n_frames=%d", n_frames);
+    int rc = check_hdr(hdr, n_frames);
+    if (rc) return rc;
+    HIPCHK(hipSetDevice(c->device));
+    void *d_pcm = nullptr, *d_hdr = nullptr, *d_mdct = nullptr;
+    const size_t b_pcm = (size_t)n_frames * 1152 * 2 * 2, b_hdr = (size_t)n_frames * sizeof(mp3s_frame_hdr),
+                 b_mdct = (size_t)n_frames * 2304 * 4;
+    if (hipMalloc(&d_pcm, b_pcm) != hipSuccess || hipMalloc(&d_hdr, b_hdr) != hipSuccess ||
+        hipMalloc(&d_mdct, b_mdct) != hipSuccess)
+        rc = fail(MP3S_E_NOMEM, "hipMalloc failed for a %d-frame batch", n_frames);
+    if (!rc) rc = mp3s_dev_upload(c, d_pcm, pcm, b_pcm);
+    if (!rc) rc = mp3s_dev_upload(c, d_hdr, hdr, b_hdr);
+    if (!rc) rc = mp3s_encode_transform_dev(c, (const int16_t *)d_pcm, (const mp3s_frame_hdr *)d_hdr, n_frames, (int32_t *)d_mdct);
+    if (!rc) rc = mp3s_dev_download(c, mdct, d_mdct, b_mdct);
+    hipStreamSynchronize(c->stream);
+    hipFree(d_pcm); hipFree(d_hdr); hipFree(d_mdct);
+    return rc;
+}
+
+int mp3s_rate_loop_dev(mp3s_ctx *c, const int32_t *d_mdct, const mp3s_rate_frame *d_frames, int n_frames,
+                       const uint8_t *d_hide_bits, int n_hide, const int32_t *d_cursor_in, const int32_t *d_state_in,
+                       const int32_t *d_unit_list, int n_list, int16_t *d_ix, mp3s_gr_out *d_out, int32_t *d_en)
+{
+    if (!c || !d_mdct || !d_frames || !d_ix || !d_out || !d_en) return fail(MP3S_E_ARG, "null pointer");
+    if (n_frames <= 0 || n_hide < 0 || (n_hide > 0 && (!d_hide_bits || !d_cursor_in)))
+        return fail(MP3S_E_ARG, "bad sizes / missing hide inputs");
+    const int e = launch_rate(c->stream, d_mdct, d_frames, n_frames, d_hide_bits, n_hide, d_cursor_in, d_state_in,
+                              d_unit_list, n_list, d_ix, d_out, d_en);
+    if (e) return fail(MP3S_E_HIP, "rate launch: %s", hipGetErrorString((hipError_t)e));
+    return MP3S_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ host stages
+int mp3s_parse_stream(const uint8_t *file, size_t len, mp3s_buf **owner, mp3s_parsed *out)
+{
+    if (!file || !owner || !out) return fail(MP3S_E_ARG, "null pointer");
+    mp3s_buf *b = new mp3s_buf();
+    const int rc = parse_stream(file, len, b->parsed);
+    if (rc) { delete b; return fail(rc, "malformed or unsupported MP3 stream"); }
+    const ParsedStream &p = b->parsed;
+    out->n_frames = p.n_frames; out->nch = p.nch; out->sampling_rate = p.sampling_rate; out->bit_rate = p.bit_rate;
+    out->n_bits = (int32_t)p.bits.size(); out->dup_last_frame = p.dup_last_frame;
+    out->is = p.is.data(); out->si = p.si.data(); out->hdr = p.hdr.data(); out->bits = p.bits.data();
+    out->table_select = p.table_select.data(); out->frame_size = p.frame_size.data();
+    *owner = b;
+    return MP3S_OK;
+}
+
+int mp3s_rate_frames(int samplerate, int bitrate_kbps, int nch, int n_frames, mp3s_rate_frame *out, int32_t *padding)
+{
+    if (!out || n_frames < 0) return fail(MP3S_E_ARG, "bad argument");
+    const int rc = rate_frames(samplerate, bitrate_kbps, nch, n_frames, out, padding);
+    if (rc) return fail(rc, "unsupported samplerate/bitrate %d/%d", samplerate, bitrate_kbps);
+    return MP3S_OK;
+}
+
+int mp3s_format_stream(int samplerate, int bitrate_kbps, int n_frames, const int16_t *ix, const mp3s_gr_out *gr,
+                       const int32_t *scfsi, mp3s_buf **owner, const uint8_t **mp3, size_t *mp3_len)
+{
+    if (!ix || !gr || !scfsi || !owner || !mp3 || !mp3_len) return fail(MP3S_E_ARG, "null pointer");
+    mp3s_buf *b = new mp3s_buf();
+    const int rc = format_stream(samplerate, bitrate_kbps, n_frames, ix, gr, scfsi, b->bytes);
+    if (rc) { delete b; return fail(rc, "format_stream failed"); }
+    *owner = b; *mp3 = b->bytes.data(); *mp3_len = b->bytes.size();
+    return MP3S_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ pipelines
+constexpr int kDecodeChunk = 16384;   // frames per decode launch group (scratch ~0.6 GB); chunks overlap by a 1-frame halo
+
+int mp3s_decode_stream(mp3s_ctx *c, const uint8_t *file, size_t len, int out_format, mp3s_buf **owner, mp3s_decoded *out)
+{
+    if (!c || !file || !owner || !out) return fail(MP3S_E_ARG, "null pointer");
+    if (out_format < 0 || out_format > 2) return fail(MP3S_E_ARG, "out_format=%d", out_format);
+    mp3s_buf *b = new mp3s_buf();
+    int rc = parse_stream(file, len, b->parsed);
+    if (rc) { delete b; return fail(rc, "malformed or unsupported MP3 stream"); }
+    ParsedStream &p = b->parsed;
+    const int n = p.n_frames, nch = p.nch;
+    const size_t esz = pcm_elem(out_format), frame_bytes = (size_t)1152 * nch * esz;
+    b->bytes.assign((size_t)(n + p.dup_last_frame) * frame_bytes, 0);
+    HIPCHK(hipSetDevice(c->device));
+    for (int start = 0; start < n && !rc; start += kDecodeChunk) {
+        const int halo = start ? 1 : 0, first = start - halo, cnt = std::min(kDecodeChunk, n - start) + halo;
+        std::vector<mp3s_frame_hdr> hdr(p.hdr.begin() + first, p.hdr.begin() + first + cnt);
+        for (auto &h : hdr) h.stream_first = 0;   // one stream; the halo frame rebuilds the state
+        rc = mp3s_decode_transform(c, p.is.data() + (size_t)first * 2304, p.si.data() + (size_t)first * 4, hdr.data(), cnt,
+                                   nch, halo, out_format, b->bytes.data() + (size_t)start * frame_bytes);
+    }
+    if (rc) { delete b; return rc; }
+    if (p.dup_last_frame && n > 0)
+        std::memcpy(b->bytes.data() + (size_t)n * frame_bytes, b->bytes.data() + (size_t)(n - 1) * frame_bytes, frame_bytes);
+    out->n_frames = n; out->nch = nch; out->sampling_rate = p.sampling_rate; out->bit_rate = p.bit_rate;
+    out->n_bits = (int32_t)p.bits.size(); out->n_rows = (int64_t)1152 * (n + p.dup_last_frame);
+    out->pcm = b->bytes.data(); out->bits = p.bits.data();
+    *owner = b;
+    return MP3S_OK;
+}
+
+int mp3s_encode_pcm(mp3s_ctx *c, const int16_t *pcm, int64_t n_samples_per_ch, int nch, int samplerate, int bitrate_kbps,
+                    const uint8_t *hide_bits, int n_hide, mp3s_buf **owner, mp3s_encoded *out)
+{
+    if (!c || !pcm || !owner || !out) return fail(MP3S_E_ARG, "null pointer");
+    if (nch != 2) return fail(MP3S_E_UNSUPPORTED, "mono encode raises IndexError in the reference (SURVEY E3)");
+    if (n_samples_per_ch <= 0 || n_samples_per_ch % 1152)
+        return fail(MP3S_E_UNSUPPORTED, "sample count %lld is not a multiple of 1152 (reference over-reads, E3)",
+                    (long long)n_samples_per_ch);
+    if (n_hide < 0 || (n_hide > 0 && !hide_bits)) return fail(MP3S_E_ARG, "bad hide arguments");
+    const int n = (int)(n_samples_per_ch / 1152), units = n * 4;
+    std::vector<mp3s_rate_frame> rf(n);
+    int rc = rate_frames(samplerate, bitrate_kbps, nch, n, rf.data(), nullptr);
+    if (rc) return fail(rc, "unsupported samplerate/bitrate %d/%d", samplerate, bitrate_kbps);
+    HIPCHK(hipSetDevice(c->device));
+
+    std::vector<mp3s_frame_hdr> hdr(n);
+    for (auto &h : hdr) { h.sr_idx = (uint8_t)rf[0].sr_idx; h.nch = 2; h.ms_stereo = 0; h.flags = 0; h.stream_first = 0; }
+    void *d_pcm = nullptr, *d_hdr = nullptr, *d_mdct = nullptr, *d_rf = nullptr, *d_hide = nullptr, *d_cur = nullptr,
+         *d_state = nullptr, *d_list = nullptr, *d_ix = nullptr, *d_out = nullptr, *d_en = nullptr;
+    auto cleanup = [&]() {
+        hipStreamSynchronize(c->stream);
+        for (void *p : {d_pcm, d_hdr, d_mdct, d_rf, d_hide, d_cur, d_state, d_list, d_ix, d_out, d_en}) if (p) hipFree(p);
+    };
+    auto alloc = [&](void **p, size_t bytes) { return hipMalloc(p, bytes ? bytes : 16) == hipSuccess; };
+    if (!alloc(&d_pcm, (size_t)n * 2304 * 2) || !alloc(&d_hdr, (size_t)n * sizeof(mp3s_frame_hdr)) ||
+        !alloc(&d_mdct, (size_t)n * 2304 * 4) || !alloc(&d_rf, (size_t)n * sizeof(mp3s_rate_frame)) ||
+        !alloc(&d_hide, (size_t)n_hide) || !alloc(&d_cur, (size_t)units * 4) || !alloc(&d_state, (size_t)units * 16) ||
+        !alloc(&d_list, (size_t)units * 4) || !alloc(&d_ix, (size_t)n * 2304 * 2) ||
+        !alloc(&d_out, (size_t)units * sizeof(mp3s_gr_out)) || !alloc(&d_en, (size_t)units * 22 * 4)) {
+        cleanup();
+        return fail(MP3S_E_NOMEM, "hipMalloc failed for a %d-frame encode", n);
+    }
+    std::vector<int32_t> cursor(units), state((size_t)units * 4, 0), en((size_t)units * 22);
+    std::vector<mp3s_gr_out> gr(units);
+    for (int u = 0; u < units; u++) cursor[u] = 3 * u;   // first guess: three tables per unit
+    rc = mp3s_dev_upload(c, d_pcm, pcm, (size_t)n * 2304 * 2);
+    if (!rc) rc = mp3s_dev_upload(c, d_hdr, hdr.data(), (size_t)n * sizeof(mp3s_frame_hdr));
+    if (!rc) rc = mp3s_dev_upload(c, d_rf, rf.data(), (size_t)n * sizeof(mp3s_rate_frame));
+    if (!rc && n_hide) rc = mp3s_dev_upload(c, d_hide, hide_bits, (size_t)n_hide);
+    if (!rc) rc = mp3s_dev_upload(c, d_cur, cursor.data(), (size_t)units * 4);
+    if (!rc) rc = mp3s_dev_upload(c, d_state, state.data(), (size_t)units * 16);
+    if (!rc) rc = mp3s_encode_transform_dev(c, (const int16_t *)d_pcm, (const mp3s_frame_hdr *)d_hdr, n, (int32_t *)d_mdct);
+    if (!rc) rc = mp3s_rate_loop_dev(c, (const int32_t *)d_mdct, (const mp3s_rate_frame *)d_rf, n, (const uint8_t *)d_hide,
+                                     n_hide, (const int32_t *)d_cur, (const int32_t *)d_state, nullptr, 0, (int16_t *)d_ix,
+                                     (mp3s_gr_out *)d_out, (int32_t *)d_en);
+    if (!rc) rc = mp3s_dev_download(c, gr.data(), d_out, (size_t)units * sizeof(mp3s_gr_out));
+    int passes = 1;
+    // ---- resolve the serial chain: hide cursor (MP3_Encoder.py:808-809) and the per-(gr,ch) inherited
+    //      address1/2/3 + quantizerStepSize (E7).  Units whose assumed inputs were wrong are re-run.
+    std::vector<int32_t> list;
+    std::vector<mp3s_gr_out> tmp;
+    while (!rc) {
+        list.clear();
+        int64_t cur = 0;
+        int32_t chain[4][4] = {};   // [(ch*2+gr)][a1,a2,a3,step]
+        for (int u = 0; u < units; u++) {
+            const int k = u & 3;
+            mp3s_gr_out &g = gr[u];
+            bool redo = false;
+            const bool active = g.flags & MP3S_RF_ACTIVE;
+            if (n_hide > 0 && active) {
+                const int64_t used = cursor[u];
+                if (used != cur && std::min<int64_t>(used, cur) < n_hide) redo = true;
+            }
+            if ((g.flags & MP3S_RF_USED_ADDR_IN) &&
+                (state[(size_t)u * 4] != chain[k][0] || state[(size_t)u * 4 + 1] != chain[k][1] ||
+                 state[(size_t)u * 4 + 2] != chain[k][2]))
+                redo = true;
+            if (redo) list.push_back(u);
+            cursor[u] = (int32_t)std::min<int64_t>(cur, 0x7fffffff);
+            for (int j = 0; j < 4; j++) state[(size_t)u * 4 + j] = chain[k][j];
+            if (active) {
+                cur += g.n_tables;
+                chain[k][0] = g.address[0]; chain[k][1] = g.address[1]; chain[k][2] = g.address[2];
+                chain[k][3] = g.quantizer_step;
+            } else {   // silent unit: everything is inherited (quantizerStepSize and addresses pass through)
+                g.address[0] = chain[k][0]; g.address[1] = chain[k][1]; g.address[2] = chain[k][2];
+                g.quantizer_step = chain[k][3];
+            }
+            if (g.flags & MP3S_RF_STEP_RANGE) { rc = fail(MP3S_E_STEP_RANGE, "quantizer step left the table in unit %d", u); break; }
+        }
+        out->hide_offset = cur;
+        if (rc || list.empty()) break;
+        if (++passes > units + 2) { rc = fail(MP3S_E_HIP, "rate-loop chain did not converge"); break; }
+        rc = mp3s_dev_upload(c, d_cur, cursor.data(), (size_t)units * 4);
+        if (!rc) rc = mp3s_dev_upload(c, d_state, state.data(), (size_t)units * 16);
+        if (!rc) rc = mp3s_dev_upload(c, d_list, list.data(), list.size() * 4);
+        if (!rc) rc = mp3s_rate_loop_dev(c, (const int32_t *)d_mdct, (const mp3s_rate_frame *)d_rf, n, (const uint8_t *)d_hide,
+                                         n_hide, (const int32_t *)d_cur, (const int32_t *)d_state, (const int32_t *)d_list,
+                                         (int)list.size(), (int16_t *)d_ix, (mp3s_gr_out *)d_out, (int32_t *)d_en);
+        tmp.resize(units);
+        if (!rc) rc = mp3s_dev_download(c, tmp.data(), d_out, (size_t)units * sizeof(mp3s_gr_out));
+        if (!rc) for (int u : list) gr[u] = tmp[u];
+    }
+    mp3s_buf *b = nullptr;
+    if (!rc) {
+        b = new mp3s_buf();
+        std::vector<int16_t> ix((size_t)n * 2304);
+        rc = mp3s_dev_download(c, ix.data(), d_ix, ix.size() * 2);
+        if (!rc) rc = mp3s_dev_download(c, en.data(), d_en, en.size() * 4);
+        if (!rc) {
+            for (int u = 0; u < units && !rc; u++)
+                if (gr[u].flags & MP3S_RF_LOG_GUARD)
+                    rc = fail(MP3S_E_HIP, "scfsi log landed on an integer boundary in unit %d (host recheck not implemented)", u);
+        }
+        if (!rc) {
+            b->scfsi.assign((size_t)n * 8, 0);
+            decide_scfsi(n, en.data(), gr.data(), b->scfsi.data());
+            rc = format_stream(samplerate, bitrate_kbps, n, ix.data(), gr.data(), b->scfsi.data(), b->bytes);
+            if (rc) fail(rc, "format_stream failed");
+        }
+        if (rc) { delete b; b = nullptr; }
+    }
+    cleanup();
+    if (rc) return rc;
+    b->gr = gr;
+    out->n_frames = n;
+    out->too_long = out->hide_offset < (int64_t)n_hide - 1 ? 1 : 0;
+    out->mp3 = b->bytes.data(); out->mp3_len = b->bytes.size();
+    out->gr = b->gr.data(); out->scfsi = b->scfsi.data();
+    out->rate_passes = passes;
+    *owner = b;
+    return MP3S_OK;
+}
+
+}  // extern "C"

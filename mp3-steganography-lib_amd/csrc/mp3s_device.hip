@@ -1,0 +1,83 @@
+// Single device translation unit: the constant-table symbol, the three kernel groups and their
+// launchers.  Compiled for gfx950 only (hipcc --offload-arch=gfx950 -ffp-contract=off).
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/mp3s.h"
+#include "mp3s_device.h"
+#include "mp3s_tables.h"
+
+namespace mp3s {
+__constant__ DevTables c_tab;
+}
+
+#include "k_decode.hpp"
+#include "k_encode.hpp"
+#include "k_rate.hpp"
+
+namespace mp3s {
+
+int dev_upload_tables(hipStream_t stream)
+{
+    const HostTables &h = host_tables();
+    hipError_t e = hipMemcpyToSymbolAsync(HIP_SYMBOL(c_tab), &h.dev, sizeof(DevTables), 0, hipMemcpyHostToDevice, stream);
+    if (e != hipSuccess) return (int)e;
+    return (int)hipStreamSynchronize(stream);
+}
+
+size_t dec_scratch_bytes(int n_frames, int nch)
+{
+    const size_t Tp = (size_t)n_frames * 36 + 18;
+    return 2 * (size_t)nch * 32 * Tp * sizeof(double);
+}
+
+int launch_decode(hipStream_t stream, const int16_t *d_is, const mp3s_granule_si *d_si, const mp3s_frame_hdr *d_hdr,
+                  int n_frames, int nch, int n_halo, int out_format, void *d_pcm, void *d_scratch)
+{
+    const long Tp = (long)n_frames * 36 + 18;
+    double *H = (double *)d_scratch;
+    double *TL = H + (size_t)nch * 32 * Tp;
+    const int n_gran = n_frames * 2;
+    hipLaunchKernelGGL(k_dec_imdct, dim3((n_gran + DEC_A_WAVES - 1) / DEC_A_WAVES), dim3(DEC_A_WAVES * 64), 0, stream,
+                       d_is, d_si, d_hdr, n_gran, nch, H, TL, Tp);
+    constexpr int TW = DEC_SYNTH_TW;
+    const long T = (long)n_frames * 36;
+    const int out_per_tile = TW * 64 - 15;
+    const int tiles = (int)((T + out_per_tile - 1) / out_per_tile);
+    hipLaunchKernelGGL(k_dec_synth<TW>, dim3(tiles), dim3(TW * 64 * nch), 0, stream, (const double *)H,
+                       (const double *)TL, Tp, d_hdr, n_frames, nch, n_halo, out_format, d_pcm);
+    return (int)hipGetLastError();
+}
+
+size_t enc_scratch_bytes(int n_frames)
+{
+    return (size_t)2 * 32 * (size_t)n_frames * 36 * sizeof(int32_t);
+}
+
+int launch_encode(hipStream_t stream, const int16_t *d_pcm, const mp3s_frame_hdr *d_hdr, int n_frames, int32_t *d_mdct,
+                  void *d_scratch)
+{
+    const long Ts = (long)n_frames * 36;
+    int32_t *SB = (int32_t *)d_scratch;
+    const long waves = 2 * ((Ts + 63) / 64);
+    hipLaunchKernelGGL(k_enc_analysis, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, stream, d_pcm, d_hdr, n_frames, SB,
+                       Ts);
+    const int n_gran = n_frames * 2;
+    hipLaunchKernelGGL(k_enc_mdct, dim3((n_gran + 3) / 4), dim3(256), 0, stream, (const int32_t *)SB, Ts, d_hdr, n_gran,
+                       d_mdct);
+    return (int)hipGetLastError();
+}
+
+int launch_rate(hipStream_t stream, const int32_t *d_mdct, const mp3s_rate_frame *d_frames, int n_frames,
+                const uint8_t *d_hide, int n_hide, const int32_t *d_cursor, const int32_t *d_state,
+                const int32_t *d_list, int n_list, int16_t *d_ix, mp3s_gr_out *d_out, int32_t *d_en)
+{
+    const int n_units = n_frames * 4;
+    const int n = d_list ? n_list : n_units;
+    if (n <= 0) return 0;
+    hipLaunchKernelGGL(k_rate_loop, dim3((n + RL_WAVES - 1) / RL_WAVES), dim3(RL_WAVES * 64), 0, stream, d_mdct, d_frames,
+                       n_units, d_hide, n_hide, d_cursor, d_state, d_list, n, d_ix, d_out, d_en);
+    return (int)hipGetLastError();
+}
+
+}  // namespace mp3s

@@ -1,0 +1,34 @@
+// Host stages of the pipeline (serial bit parsing / packing; no GPU involved).
+#pragma once
+#include <stddef.h>
+#include <stdint.h>
+
+#include <vector>
+
+#include "../../include/mp3s.h"
+#include "mp3s_tables.h"
+
+namespace mp3s {
+
+struct ParsedStream {
+    int n_frames = 0, nch = 0, sampling_rate = 0, bit_rate = 0, dup_last_frame = 0;
+    std::vector<int16_t> is;              // [n][2 gr][2 ch][576]
+    std::vector<mp3s_granule_si> si;      // [n][2][2]
+    std::vector<mp3s_frame_hdr> hdr;      // [n]
+    std::vector<uint8_t> bits;            // stego bits
+    std::vector<int32_t> table_select;    // [n][2][2][3]
+    std::vector<int32_t> frame_size;      // [n]
+};
+int parse_stream(const uint8_t *file, size_t len, ParsedStream &out);
+
+// per-frame padding bit and rate-loop budget (reference MP3_Encoder.py:503-513, 630-636, 894-912)
+int rate_frames(int samplerate, int bitrate_kbps, int nch, int n_frames, mp3s_rate_frame *out, int32_t *padding);
+
+// scfsi decision from the per-unit band energies (reference MP3_Encoder.py:861-892); en = [units][22]
+void decide_scfsi(int n_frames, const int32_t *en, const mp3s_gr_out *gr, int32_t *scfsi /*[n][2][4]*/);
+
+// bitstream formatter (reference MP3_Encoder.py:1097-1145, 1266-1552); gr is modified (stuffing) on a copy
+int format_stream(int samplerate, int bitrate_kbps, int n_frames, const int16_t *ix, const mp3s_gr_out *gr,
+                  const int32_t *scfsi, std::vector<uint8_t> &mp3);
+
+}  // namespace mp3s

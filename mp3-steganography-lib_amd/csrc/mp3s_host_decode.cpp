@@ -1,0 +1,400 @@
+// Host front end of the decoder: the serial bit-parsing stage that stays on the CPU by design
+// (SURVEY.md section 8 rows a9/a10).  Turns an MP3 file image into the batch the decode-transform
+// kernels consume: Huffman-decoded spectra `is`, per granule*channel side records and per-frame
+// headers, plus the stego bit string.
+//
+// Behaviour follows the reference, quirks included:
+//   stream loop          decoder/MP3_Parser.py:25-85          (D11, D12)
+//   header               decoder/FrameHeader.py:51-192         (D16)
+//   side info            decoder/FrameSideInformation.py:39-137 (D10: arrays persist across frames)
+//   frame size/reservoir decoder/Frame.py:288-363              (D15, Python slice semantics)
+//   scalefactors         decoder/Frame.py:365-441
+//   Huffman              decoder/Frame.py:443-559              (D1, D2) -- table driven here, the
+//                        reference searches the code book linearly; prefix codes make both agree
+//   stego bits           decoder/Frame.py:676-685, decoder/util.py:67-81 (D14)
+#include "mp3s_host.h"
+
+#include <cmath>
+#include <cstring>
+#include <mutex>
+
+namespace mp3s {
+
+namespace {
+
+// ---------------------------------------------------------------- bit reader (decoder/util.py:22-64)
+struct Bits {
+    const uint8_t *p; long len;
+    uint32_t get(long pos, int n) const   // MSB first, zero padded past the end, n <= 32
+    {
+        uint64_t acc = 0;
+        const long b0 = pos >> 3;
+        for (int k = 0; k < 5; k++) {
+            const long b = b0 + k;
+            acc = (acc << 8) | ((b >= 0 && b < len) ? p[b] : 0);
+        }
+        const int sh = 40 - (int)(pos & 7) - n;
+        return n == 0 ? 0u : (uint32_t)((acc >> sh) & ((n == 32) ? 0xffffffffull : ((1ull << n) - 1)));
+    }
+};
+
+// ---------------------------------------------------------------- Huffman lookup tables
+constexpr int LUT_BITS = 10;
+struct HuffLut {
+    int max = 0;                       // symbols per axis the reference searches (big_value_max)
+    int linbits = 0;
+    std::vector<uint16_t> fast;        // [1<<LUT_BITS]: (len<<8)|(x<<4)|y, 0 = go to the long list
+    std::vector<uint32_t> long_code;   // left-aligned 32-bit codes longer than LUT_BITS
+    std::vector<uint16_t> long_sym;    // (len<<8)|(x<<4)|y
+};
+HuffLut g_lut[32];
+uint16_t g_quad_fast[64];              // count1 table A on 6 bits: (len<<4)|value
+std::once_flag g_lut_once;
+
+void build_luts()
+{
+    const HostTables &H = host_tables();
+    static const int dec_max[32] = {1, 2, 3, 3, 0, 4, 4, 6, 6, 6, 8, 8, 8, 16, 0, 16,
+                                    16, 16, 16, 16, 16, 16, 16, 16, 16, 16, 16, 16, 16, 16, 16, 16};
+    for (int t = 0; t < 32; t++) {
+        HuffLut &L = g_lut[t];
+        L.max = dec_max[t];
+        L.linbits = H.huff[t].linbits;
+        if (t == 0 || L.max == 0) continue;
+        const HostHuff &h = H.huff[t];
+        L.fast.assign(1 << LUT_BITS, 0);
+        // row-major order = the reference's search order; the first match wins there, so keep the first
+        for (int x = 0; x < L.max; x++)
+            for (int y = 0; y < L.max; y++) {
+                const int len = h.hlen[x * h.ylen + y];
+                const uint32_t code = h.hcod[x * h.ylen + y];
+                const uint16_t sym = (uint16_t)((len << 8) | (x << 4) | y);
+                if (len <= LUT_BITS) {
+                    const uint32_t base = code << (LUT_BITS - len);
+                    for (uint32_t f = 0; f < (1u << (LUT_BITS - len)); f++)
+                        if (!L.fast[base + f]) L.fast[base + f] = sym;
+                } else {
+                    L.long_code.push_back(code << (32 - len));
+                    L.long_sym.push_back(sym);
+                }
+            }
+    }
+    const HostHuff &q = H.huff[32];
+    for (int e = 0; e < 16; e++) {
+        const int len = q.hlen[e];
+        const uint32_t base = (uint32_t)q.hcod[e] << (6 - len);
+        for (uint32_t f = 0; f < (1u << (6 - len)); f++)
+            if (!g_quad_fast[base + f]) g_quad_fast[base + f] = (uint16_t)((len << 4) | e);
+    }
+}
+
+inline bool huff_decode(const HuffLut &L, uint32_t window, int &x, int &y, int &len)
+{
+    uint16_t s = L.fast[window >> (32 - LUT_BITS)];
+    if (!s) {
+        for (size_t i = 0; i < L.long_code.size(); i++) {
+            const int l = L.long_sym[i] >> 8;
+            if ((L.long_code[i] >> (32 - l)) == (window >> (32 - l))) { s = L.long_sym[i]; break; }
+        }
+        if (!s) return false;
+    }
+    len = s >> 8; x = (s >> 4) & 15; y = s & 15;
+    return true;
+}
+
+// Python list slicing data[start:stop] appended to dst
+void py_slice_append(std::vector<uint8_t> &dst, const uint8_t *data, long n, long start, long stop)
+{
+    if (start < 0) { start += n; if (start < 0) start = 0; }
+    if (stop < 0) { stop += n; if (stop < 0) stop = 0; }
+    if (start > n) start = n;
+    if (stop > n) stop = n;
+    if (stop > start) dst.insert(dst.end(), data + start, data + stop);
+}
+
+struct Header {            // FrameHeader fields; persist from frame to frame like the Python object
+    double version = 0; int layer = 0, crc = 0, bit_rate = 0, sampling_rate = 0, padding = 0, mode = 0, channels = 0;
+    int mode_ext0 = 0; int sr_idx = -1;
+};
+
+int parse_header(Header &h, const uint8_t *b)
+{
+    const int b1 = b[1], b2 = b[2], b3 = b[3];
+    const bool v10 = b1 & 0x10, v08 = b1 & 0x08;
+    h.version = v10 && v08 ? 1 : (v10 ? 2 : (v08 ? 0 : 2.5));
+    h.layer = 4 - (((b1 << 5) & 0xff) >> 6);
+    h.crc = b1 & 1;
+    static const int rates[3][3] = {{44100, 48000, 32000}, {22050, 24000, 16000}, {11025, 12000, 8000}};
+    int row = (int)std::floor(h.version) - 1; if (row < 0) row += 3;   // Python rates[-1]
+    const int sc = (b2 >> 2) & 3;
+    if (sc != 3) h.sampling_rate = rates[row][sc];
+    if (h.sampling_rate == 44100) h.sr_idx = 0;
+    else if (h.sampling_rate == 48000) h.sr_idx = 1;
+    else if (h.sampling_rate == 32000) h.sr_idx = 2;
+    h.mode = (b3 >> 6) & 3;
+    h.channels = h.mode == 3 ? 1 : 2;
+    if (h.layer == 3) h.mode_ext0 = b3 & 0x20;
+    h.padding = (b2 & 2) ? 1 : 0;
+    static const int r13[14] = {32, 40, 48, 56, 64, 80, 96, 112, 128, 160, 192, 224, 256, 320};
+    static const int r12[14] = {32, 48, 56, 64, 80, 96, 112, 128, 160, 192, 224, 256, 320, 384};
+    static const int r2x[14] = {8, 16, 24, 32, 40, 48, 56, 64, 80, 96, 112, 128, 144, 160};
+    int bi = (b2 >> 4) - 1; if (bi < 0) bi += 14;
+    const int *tab = nullptr;
+    if (h.version == 1) {
+        if (h.layer == 1) { h.bit_rate = b2 * 32; return 0; }
+        tab = h.layer == 2 ? r12 : (h.layer == 3 ? r13 : nullptr);
+    } else {
+        tab = h.layer == 1 ? r13 : (h.layer < 4 ? r2x : nullptr);
+    }
+    if (tab) { if (bi >= 14) return MP3S_E_MALFORMED; h.bit_rate = tab[bi] * 1000; }
+    return 0;
+}
+
+struct SideInfo {          // FrameSideInformation arrays (persist across frames, D10)
+    int main_data_begin = 0;
+    int scfsi[2][4] = {};
+    int part2_3_length[2][2] = {}, big_value[2][2] = {}, global_gain[2][2] = {}, scale_fac_compress[2][2] = {};
+    int window_switching[2][2] = {}, block_type[2][2] = {}, mixed[2][2] = {}, region0[2][2] = {}, region1[2][2] = {};
+    int preflag[2][2] = {}, scalefac_scale[2][2] = {}, count1table[2][2] = {};
+    int table_select[2][2][3] = {}, sub_block_gain[2][2][3] = {};
+    int sf_l[2][2][22] = {}, sf_s[2][2][3][13] = {};
+};
+
+}  // namespace
+
+int parse_stream(const uint8_t *file, size_t flen_, ParsedStream &out)
+{
+    std::call_once(g_lut_once, build_luts);
+    const HostTables &HT = host_tables();
+    const long flen = (long)flen_;
+    out = ParsedStream();
+    // ID3v2 skip (decoder/ID3_Parser.py:95-131): only `offset` and `is_valid` matter to decoding
+    long offset = 0;
+    if (flen >= 10 && file[0] == 'I' && file[1] == 'D' && file[2] == '3' && !(file[5] & 0x0f)) {
+        long size = 0;
+        for (int i = 0; i < 4; i++) size = (size << 7) + file[6 + i];
+        offset = size + ((file[5] >> 4) & 1 ? 20 : 10);
+    }
+    if (flen - offset < 4) return MP3S_E_MALFORMED;
+    Header hd;
+    SideInfo si;
+    double prev_frame_size[9] = {0};
+    int frame_size = 0;
+    std::vector<uint8_t> main_data;
+    auto set_frame_size = [&]() -> int {   // Frame.py:288-316
+        int spf = 0;
+        if (hd.layer == 3) spf = hd.version == 1 ? 1152 : 576;
+        else if (hd.layer == 2) spf = 1152;
+        else if (hd.layer == 1) spf = 384;
+        for (int i = 8; i > 0; i--) prev_frame_size[i] = prev_frame_size[i - 1];
+        prev_frame_size[0] = frame_size;
+        if (hd.sampling_rate == 0) return MP3S_E_MALFORMED;
+        frame_size = (int)((((double)spf / 8) * hd.bit_rate) / hd.sampling_rate);
+        if (hd.padding == 1) frame_size += 1;
+        return 0;
+    };
+    const uint8_t *buffer = file + offset;
+    bool valid = false;
+    if (buffer[0] == 0xFF && buffer[1] >= 0xE0) {
+        valid = true;
+        int rc = parse_header(hd, buffer); if (rc) return rc;
+        rc = set_frame_size(); if (rc) return rc;   // D11
+    }
+    int first_nch = 0;
+    while (valid && flen > offset + 4) {
+        buffer = file + offset;
+        const long buflen = flen - offset;
+        if (buffer[0] == 0xFF && buffer[1] >= 0xE0) { int rc = parse_header(hd, buffer); if (rc) return rc; }
+        else { valid = false; out.dup_last_frame = out.n_frames > 0 ? 1 : 0; break; }   // D12
+        int rc = set_frame_size(); if (rc) return rc;
+        if (frame_size <= 0 || hd.sr_idx < 0 || hd.version != 1 || hd.layer != 3) return MP3S_E_MALFORMED;  // D16
+        if (first_nch == 0) first_nch = hd.channels;
+        else if (hd.channels != first_nch) return MP3S_E_UNSUPPORTED;   // ragged pcm_data in the reference
+        const int nch = hd.channels;
+
+        // ---- side info
+        const long sstart = hd.crc == 0 ? 6 : 4;
+        Bits sb{buffer + (sstart < buflen ? sstart : buflen), buflen - (sstart < buflen ? sstart : buflen)};
+        long off = 0;
+        si.main_data_begin = (int)sb.get(0, 9); off += 9;
+        off += hd.mode == 3 ? 5 : 3;
+        for (int ch = 0; ch < nch; ch++)
+            for (int b = 0; b < 4; b++) { si.scfsi[ch][b] = sb.get(off, 1) != 0; off += 1; }
+        for (int gr = 0; gr < 2; gr++)
+            for (int ch = 0; ch < nch; ch++) {
+                si.part2_3_length[gr][ch] = sb.get(off, 12); off += 12;
+                si.big_value[gr][ch] = sb.get(off, 9); off += 9;
+                si.global_gain[gr][ch] = sb.get(off, 8); off += 8;
+                si.scale_fac_compress[gr][ch] = sb.get(off, 4); off += 4;
+                si.window_switching[gr][ch] = sb.get(off, 1) == 1; off += 1;
+                if (si.window_switching[gr][ch]) {
+                    si.block_type[gr][ch] = sb.get(off, 2); off += 2;
+                    si.mixed[gr][ch] = sb.get(off, 1) == 1; off += 1;
+                    si.region0[gr][ch] = si.block_type[gr][ch] == 2 ? 8 : 7;
+                    si.region1[gr][ch] = 20 - si.region0[gr][ch];
+                    for (int r = 0; r < 2; r++) { si.table_select[gr][ch][r] = sb.get(off, 5); off += 5; }   // [2] stays stale
+                    for (int w = 0; w < 3; w++) { si.sub_block_gain[gr][ch][w] = sb.get(off, 3); off += 3; }
+                } else {
+                    si.block_type[gr][ch] = 0; si.mixed[gr][ch] = 0;
+                    for (int r = 0; r < 3; r++) { si.table_select[gr][ch][r] = sb.get(off, 5); off += 5; }
+                    si.region0[gr][ch] = sb.get(off, 4); off += 4;
+                    si.region1[gr][ch] = sb.get(off, 3); off += 3;
+                }
+                si.preflag[gr][ch] = sb.get(off, 1); off += 1;
+                si.scalefac_scale[gr][ch] = sb.get(off, 1); off += 1;
+                si.count1table[gr][ch] = sb.get(off, 1); off += 1;
+            }
+        // ---- stego bits: ch -> gr -> region, zeros skipped, H0 -> 0
+        for (int ch = 0; ch < nch; ch++)
+            for (int gr = 0; gr < 2; gr++)
+                for (int r = 0; r < 3; r++) {
+                    const int t = si.table_select[gr][ch][r];
+                    if (t) out.bits.push_back(HT.in_h0[t] ? 0 : 1);
+                }
+        // ---- main data (bit reservoir)
+        int constant = hd.mode == 3 ? 21 : 36;
+        if (hd.crc == 0) constant += 2;
+        if (si.main_data_begin == 0) {
+            main_data.clear();
+            py_slice_append(main_data, buffer, buflen, constant, frame_size);
+        } else {
+            double bound = 0;
+            for (int fr = 0; fr < 9; fr++) {
+                bound += prev_frame_size[fr] - constant;
+                if (si.main_data_begin < bound) {
+                    double ptr_offset = si.main_data_begin + fr * constant;
+                    double part[9] = {0};
+                    part[fr] = si.main_data_begin;
+                    for (int i = 0; i < fr; i++) { part[i] = prev_frame_size[i] - constant; part[fr] -= part[i]; }
+                    main_data.clear();
+                    long loc = (long)(offset - ptr_offset);
+                    py_slice_append(main_data, file, flen, loc, loc + (long)part[fr]);
+                    ptr_offset -= (part[fr] + constant);
+                    for (int i = fr - 1; i >= 0; i--) {
+                        loc = (long)(offset - ptr_offset);
+                        py_slice_append(main_data, file, flen, loc, loc + (long)part[i]);
+                        ptr_offset -= (part[i] + constant);
+                    }
+                    py_slice_append(main_data, buffer, buflen, constant, frame_size);
+                    break;
+                }
+            }   // not found: the previous frame's main_data is reused, as in the reference
+        }
+        Bits mb{main_data.data(), (long)main_data.size()};
+
+        // ---- per granule*channel: scalefactors + Huffman
+        const size_t f = (size_t)out.n_frames;
+        out.is.resize((f + 1) * 2304, 0);
+        out.si.resize((f + 1) * 4);
+        out.table_select.resize((f + 1) * 12, 0);
+        std::memset(&out.si[f * 4], 0, 4 * sizeof(mp3s_granule_si));
+        long bit = 0;
+        for (int gr = 0; gr < 2; gr++)
+            for (int ch = 0; ch < nch; ch++) {
+                const long max_bit = bit + si.part2_3_length[gr][ch];
+                const int sl0 = HT.slen[si.scale_fac_compress[gr][ch]][0], sl1 = HT.slen[si.scale_fac_compress[gr][ch]][1];
+                if (si.block_type[gr][ch] == 2 && si.window_switching[gr][ch]) {
+                    if (si.mixed[gr][ch] == 1) {
+                        for (int s = 0; s < 8; s++) { si.sf_l[gr][ch][s] = mb.get(bit, sl0); bit += sl0; }
+                        for (int s = 3; s < 6; s++)
+                            for (int w = 0; w < 3; w++) { si.sf_s[gr][ch][w][s] = mb.get(bit, sl0); bit += sl0; }
+                    } else {
+                        for (int s = 0; s < 6; s++)
+                            for (int w = 0; w < 3; w++) { si.sf_s[gr][ch][w][s] = mb.get(bit, sl0); bit += sl0; }
+                    }
+                    for (int s = 6; s < 12; s++)
+                        for (int w = 0; w < 3; w++) { si.sf_s[gr][ch][w][s] = mb.get(bit, sl1); bit += sl1; }
+                    for (int w = 0; w < 3; w++) si.sf_s[gr][ch][w][12] = 0;
+                } else {
+                    if (gr == 0) {
+                        for (int s = 0; s < 11; s++) { si.sf_l[gr][ch][s] = mb.get(bit, sl0); bit += sl0; }
+                        for (int s = 11; s < 21; s++) { si.sf_l[gr][ch][s] = mb.get(bit, sl1); bit += sl1; }
+                    } else {
+                        static const int SB[5] = {0, 6, 11, 16, 21};
+                        for (int i = 0; i < 4; i++) {
+                            const int sl = i < 2 ? sl0 : sl1;
+                            for (int s = SB[i]; s < SB[i + 1]; s++) {
+                                if (si.scfsi[ch][i]) si.sf_l[gr][ch][s] = si.sf_l[0][ch][s];
+                                else { si.sf_l[gr][ch][s] = mb.get(bit, sl); bit += sl; }
+                            }
+                        }
+                    }
+                    si.sf_l[gr][ch][21] = 0;
+                }
+                // ---- Huffman (Frame.py:443-559)
+                int16_t *smp = &out.is[(f * 4 + gr * 2 + ch) * 576];
+                int region0, region1;
+                if (si.window_switching[gr][ch] && si.block_type[gr][ch] == 2) { region0 = 36; region1 = 576; }
+                else {
+                    const int i0 = si.region0[gr][ch] + 1, i1 = i0 + si.region1[gr][ch] + 1;
+                    if (i0 > 22 || i1 > 22) return MP3S_E_MALFORMED;
+                    region0 = HT.dev.sfb_long[hd.sr_idx][i0]; region1 = HT.dev.sfb_long[hd.sr_idx][i1];
+                }
+                int sample = 0;
+                const int bv2 = si.big_value[gr][ch] * 2;
+                while (sample < bv2) {
+                    if (sample + 1 >= 576) return MP3S_E_MALFORMED;
+                    const int tn = si.table_select[gr][ch][sample < region0 ? 0 : (sample < region1 ? 1 : 2)];
+                    const HuffLut &L = g_lut[tn];
+                    if (tn == 0 || L.max == 0) { sample += 2; continue; }   // tables 0, 4, 14: zeros, no bits (D2)
+                    int v[2], len;
+                    if (huff_decode(L, mb.get(bit, 32), v[0], v[1], len)) {
+                        bit += len;
+                        for (int i = 0; i < 2; i++) {
+                            int lin = 0;
+                            if (L.linbits && v[i] == L.max - 1) { lin = (int)mb.get(bit, L.linbits); bit += L.linbits; }
+                            int sign = 1;
+                            if (v[i] > 0) { sign = mb.get(bit, 1) ? -1 : 1; bit += 1; }
+                            smp[sample + i] = (int16_t)(sign * (v[i] + lin));
+                        }
+                    }
+                    sample += 2;
+                }
+                while (bit < max_bit && sample + 4 < 576) {   // D1
+                    int val[4] = {0, 0, 0, 0};
+                    if (si.count1table[gr][ch] == 1) {
+                        const uint32_t bs = mb.get(bit, 4); bit += 4;
+                        val[0] = (bs & 8) ? 0 : 1; val[1] = (bs & 4) ? 0 : 1; val[2] = (bs & 2) ? 0 : 1; val[3] = (bs & 1) ? 0 : 1;
+                    } else {
+                        const uint16_t s = g_quad_fast[mb.get(bit, 6)];
+                        if (s) {
+                            bit += s >> 4;
+                            const int e = s & 15;
+                            val[0] = (e >> 3) & 1; val[1] = (e >> 2) & 1; val[2] = (e >> 1) & 1; val[3] = e & 1;
+                        }
+                    }
+                    for (int i = 0; i < 4; i++)
+                        if (val[i] > 0) { if (mb.get(bit, 1)) val[i] = -val[i]; bit += 1; }
+                    for (int i = 0; i < 4; i++) smp[sample + i] = (int16_t)val[i];
+                    sample += 4;
+                }
+                bit = max_bit;
+                // ---- side record for the kernels
+                mp3s_granule_si &g = out.si[f * 4 + gr * 2 + ch];
+                g.global_gain = (uint8_t)si.global_gain[gr][ch];
+                g.scalefac_scale = (uint8_t)si.scalefac_scale[gr][ch];
+                g.block_type = (uint8_t)si.block_type[gr][ch];
+                g.mixed_block_flag = (uint8_t)si.mixed[gr][ch];
+                g.preflag = (uint8_t)si.preflag[gr][ch];
+                for (int w = 0; w < 3; w++) g.sub_block_gain[w] = (uint8_t)si.sub_block_gain[gr][ch][w];
+                for (int s = 0; s < 22; s++) g.scale_fac_l[s] = (uint8_t)si.sf_l[gr][ch][s];
+                for (int w = 0; w < 3; w++)
+                    for (int s = 0; s < 13; s++) g.scale_fac_s[w][s] = (uint8_t)si.sf_s[gr][ch][w][s];
+                for (int r = 0; r < 3; r++) out.table_select[(f * 4 + gr * 2 + ch) * 3 + r] = si.table_select[gr][ch][r];
+            }
+        mp3s_frame_hdr fh;
+        fh.sr_idx = (uint8_t)hd.sr_idx; fh.nch = (uint8_t)nch;
+        fh.ms_stereo = (hd.mode == 1 && hd.mode_ext0) ? 1 : 0;
+        fh.flags = 0; fh.stream_first = 0;
+        out.hdr.push_back(fh);
+        out.frame_size.push_back(frame_size);
+        out.n_frames++;
+        offset += frame_size;
+    }
+    out.nch = first_nch ? first_nch : hd.channels;
+    out.sampling_rate = hd.sampling_rate;
+    out.bit_rate = hd.bit_rate;
+    return 0;
+}
+
+}  // namespace mp3s

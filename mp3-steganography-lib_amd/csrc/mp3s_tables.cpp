@@ -1,0 +1,198 @@
+// Host-side construction of the constant tables (see mp3s_tables.h).  Every float table is evaluated
+// with the same libm call and operand order as the reference line cited next to it, so the device
+// sees bit-identical constants; tests/test_tables.py checks them against the reference's dump.
+#include "mp3s_tables.h"
+#include "iso_tables.h"
+
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <mutex>
+
+namespace mp3s {
+
+namespace {
+
+// Python round(x, nd) (correctly rounded decimal, then nearest double)
+double round_decimals(double x, int nd)
+{
+    char buf[64];
+    std::snprintf(buf, sizeof buf, "%.*f", nd, x);
+    return std::strtod(buf, nullptr);
+}
+
+const int kSfbLong[3][23] = {
+    {0, 4, 8, 12, 16, 20, 24, 30, 36, 44, 52, 62, 74, 90, 110, 134, 162, 196, 238, 288, 342, 418, 576},   // 44.1k
+    {0, 4, 8, 12, 16, 20, 24, 30, 36, 42, 50, 60, 72, 88, 106, 128, 156, 190, 230, 276, 330, 384, 576},   // 48k
+    {0, 4, 8, 12, 16, 20, 24, 30, 36, 44, 54, 66, 82, 102, 126, 156, 194, 240, 296, 364, 448, 550, 576}}; // 32k
+const int kSfbShortW[3][12] = {{4, 4, 4, 4, 6, 8, 10, 12, 14, 18, 22, 30},
+                               {4, 4, 4, 4, 6, 6, 10, 12, 14, 16, 20, 26},
+                               {4, 4, 4, 4, 6, 8, 12, 16, 20, 26, 34, 42}};
+const int kPreTab[21] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 1, 1, 1, 1, 2, 2, 3, 3, 3, 2};
+const int kSlen[16][2] = {{0, 0}, {0, 1}, {0, 2}, {0, 3}, {3, 0}, {1, 1}, {1, 2}, {1, 3},
+                          {2, 1}, {2, 2}, {2, 3}, {3, 1}, {3, 2}, {3, 3}, {4, 2}, {4, 3}};
+const int kSubdv[23][2] = {{0, 0}, {0, 0}, {0, 0}, {0, 0}, {0, 0}, {0, 1}, {1, 1}, {1, 1}, {1, 2}, {2, 2}, {2, 3}, {2, 3},
+                           {3, 4}, {3, 4}, {3, 4}, {4, 5}, {4, 5}, {4, 6}, {5, 6}, {5, 6}, {5, 7}, {6, 7}, {6, 7}};
+const double kAliasC[8] = {-0.6, -0.535, -0.33, -0.185, -0.095, -0.041, -0.0142, -0.0037};
+// table-swap steganography: {table -> table for bit 0, table for bit 1}; bit 0 lands in H0
+const uint8_t kTransform[32][2] = {
+    {0, 0},   {3, 1},   {3, 2},   {3, 2},   {0, 0},   {6, 5},   {6, 5},   {8, 7},   {8, 7},   {8, 9},   {11, 10},
+    {11, 10}, {12, 10}, {15, 13}, {0, 0},   {15, 13}, {17, 16}, {17, 18}, {19, 18}, {19, 20}, {21, 20}, {21, 22},
+    {23, 22}, {23, 31}, {24, 25}, {26, 25}, {26, 27}, {28, 27}, {28, 29}, {30, 29}, {30, 31}, {23, 31}};
+const int kH0[14] = {3, 6, 8, 11, 12, 15, 17, 19, 21, 23, 24, 26, 28, 30};
+
+HostTables g_tables;
+std::once_flag g_once;
+
+void set_huff(int n, int xl, int yl, int lb, int lm, const uint16_t *c, const uint8_t *l)
+{
+    g_tables.huff[n] = HostHuff{xl, yl, lb, lm, c, l};
+}
+
+// literal simulation of the sfb/window tracker of reference Frame.py:179-218 for one (sr, case)
+void build_rq_map(int sr, int cse, uint8_t *map)
+{
+    const int *short_win = kSfbShortW[sr];
+    const int *long_win = kSfbLong[sr];
+    const bool bt2 = cse == 1, mixed = cse == 2;
+    int window = 0, sfb = 0, i = 0;
+    for (int sample = 0; sample < 576; sample++, i++) {
+        bool sh;
+        if (bt2 || (mixed && sfb >= 8)) {
+            int swv = sfb < 12 ? short_win[sfb] : 0;
+            if (i == swv) {
+                i = 0;
+                if (window == 2) { window = 0; sfb += 1; } else window += 1;
+            }
+            sh = true;
+        } else {
+            if (sample == long_win[sfb + 1]) sfb += 1;
+            sh = false;
+        }
+        map[sample] = (uint8_t)((sh ? 0x80 : 0) | ((sh ? window : 0) << 5) | sfb);
+    }
+}
+
+void build()
+{
+    HostTables &H = g_tables;
+    DevTables &T = H.dev;
+    std::memset(&H, 0, sizeof H);
+    const double kPi = 3.141592653589793;  // math.pi
+
+    for (int i = 0; i < 512; i++) {
+        T.synth_window[i] = round_decimals((double)ISO_WINDOW_NUM[i] / 65536.0, 9);
+        T.enwindow[i] = (int32_t)(round_decimals((double)ISO_WINDOW_NUM[i] / 2097152.0, 6) * 2147483647.0);
+    }
+    for (int i = 0; i < 64; i++)
+        for (int j = 0; j < 32; j++) T.synth_matrix[i][j] = std::cos((16.0 + i) * (2.0 * j + 1.0) * (kPi / 64.0));
+    for (int i = 0; i < 36; i++)
+        for (int k = 0; k < 18; k++)
+            T.imdct_cos36[i][k] = std::cos(kPi / (double)(2 * 36) * (double)(2 * i + 1 + 18) * (double)(2 * k + 1));
+    for (int i = 0; i < 12; i++)
+        for (int k = 0; k < 6; k++)
+            T.imdct_cos12[i][k] = std::cos(kPi / (double)(2 * 12) * (double)(2 * i + 1 + 6) * (double)(2 * k + 1));
+    for (int i = 0; i < 36; i++) T.sine_block[0][i] = std::sin(kPi / 36.0 * (i + 0.5));
+    for (int i = 0; i < 18; i++) T.sine_block[1][i] = std::sin(kPi / 36.0 * (i + 0.5));
+    for (int i = 18; i < 24; i++) T.sine_block[1][i] = 1.0;
+    for (int i = 24; i < 30; i++) T.sine_block[1][i] = std::sin(kPi / 12.0 * (i - 18.0 + 0.5));
+    for (int i = 30; i < 36; i++) T.sine_block[1][i] = 1.0;   // not 0 as in ISO
+    for (int i = 0; i < 12; i++) T.sine_block[2][i] = std::sin(kPi / 12.0 * (i + 0.5));
+    for (int i = 6; i < 12; i++) T.sine_block[3][i] = std::sin(kPi / 12.0 * (i - 6.0 + 0.5));
+    for (int i = 12; i < 18; i++) T.sine_block[3][i] = 1.0;
+    for (int i = 18; i < 36; i++) T.sine_block[3][i] = std::sin(kPi / 36.0 * (i + 0.5));
+    for (int i = 0; i < 8; i++) {
+        const double c = kAliasC[i];
+        T.alias_cs[i] = round_decimals(1.0 / std::sqrt(1.0 + c * c), 10);
+        T.alias_ca[i] = round_decimals(c / std::sqrt(1.0 + c * c), 10);
+        T.mdct_ca[i] = (int32_t)(c / std::sqrt(1.0 + (c * c)) * 2147483647.0);
+        T.mdct_cs[i] = (int32_t)(1.0 / std::sqrt(1.0 + (c * c)) * 2147483647.0);
+    }
+    for (int i = 0; i < POW43_N; i++) T.pow43[i] = std::pow((double)i, 4.0 / 3.0);
+    for (int i = 0; i < POW2Q_N; i++) T.pow2q[i] = std::pow(2.0, (double)(i + POW2Q_MIN) / 4.0);
+    for (int i = 0; i < POW2H_N; i++) T.pow2h[i] = std::pow(2.0, -((double)i * 0.5));
+    T.sqrt2 = std::sqrt(2.0);
+    for (int sr = 0; sr < 3; sr++) {
+        for (int c = 0; c < 3; c++) build_rq_map(sr, c, T.rq_map[sr][c]);
+        // reference Frame.py:581-602 as a gather map
+        for (int i = 0; i < 576; i++) T.reorder_src[sr][i] = -1;
+        int total = 0, start = 0, block = 0;
+        for (int sb = 0; sb < 12; sb++) {
+            const int w = kSfbShortW[sr][sb];
+            for (int ss = 0; ss < w; ss++) {
+                T.reorder_src[sr][start + block + 0] = (int16_t)(total + ss + w * 0);
+                T.reorder_src[sr][start + block + 6] = (int16_t)(total + ss + w * 1);
+                T.reorder_src[sr][start + block + 12] = (int16_t)(total + ss + w * 2);
+                if (block != 0 && block % 5 == 0) { start += 18; block = 0; } else block += 1;
+            }
+            total += w * 3;
+        }
+        for (int i = 0; i < 23; i++) T.sfb_long[sr][i] = kSfbLong[sr][i];
+        for (int i = 0; i < 12; i++) H.sfb_short_width[sr][i] = kSfbShortW[sr][i];
+    }
+    for (int i = 0; i < 21; i++) T.pre_tab[i] = (uint8_t)kPreTab[i];
+    std::memcpy(H.slen, kSlen, sizeof kSlen);
+    std::memcpy(T.subdv, kSubdv, sizeof kSubdv);
+    std::memcpy(T.transform, kTransform, sizeof kTransform);
+    for (int t : kH0) H.in_h0[t] = 1;
+
+    // encoder fixed-point tables (util.PI64 = 0.049087385212, PI36 = 0.087266462599717, PI = 3.14159265358979)
+    for (int i = 0; i < 32; i++)
+        for (int j = 0; j < 64; j++) {
+            double f = 1e9 * std::cos((double)((2 * i + 1) * (16 - j)) * 0.049087385212), ip;
+            if (f >= 0) std::modf(f + 0.5, &ip); else std::modf(f - 0.5, &ip);
+            T.fl[i][j] = (int32_t)(ip * 2147483647.0 * 1e-9);
+        }
+    for (int m = 0; m < 18; m++)
+        for (int k = 0; k < 36; k++)
+            T.cos_l[m][k] = (int32_t)(std::sin(0.087266462599717 * (k + 0.5)) *
+                                      std::cos((3.14159265358979 / 72) * (double)(2 * k + 19) * (double)(2 * m + 1)) *
+                                      2147483647.0);
+    for (int i = 0; i < 128; i++) {
+        T.steptab[i] = std::pow(2.0, (double)(127 - i) / 4);
+        T.steptabi[i] = (T.steptab[i] * 2 > 2147483647.0) ? 0x7fffffff : (int32_t)(T.steptab[i] * 2 + 0.5);
+    }
+    for (int i = 0; i < 10000; i++)
+        T.int2idx[i] = (uint16_t)(int32_t)(std::sqrt(std::sqrt((double)i) * (double)i) - 0.0946 + 0.5);
+
+    set_huff(0, 0, 0, 0, 0, nullptr, nullptr);
+    set_huff(1, 2, 2, 0, 0, ISO_HCOD_1, ISO_HLEN_1);
+    set_huff(2, 3, 3, 0, 0, ISO_HCOD_2, ISO_HLEN_2);
+    set_huff(3, 3, 3, 0, 0, ISO_HCOD_3, ISO_HLEN_3);
+    set_huff(4, 0, 0, 0, 0, nullptr, nullptr);
+    set_huff(5, 4, 4, 0, 0, ISO_HCOD_5, ISO_HLEN_5);
+    set_huff(6, 4, 4, 0, 0, ISO_HCOD_6, ISO_HLEN_6);
+    set_huff(7, 6, 6, 0, 0, ISO_HCOD_7, ISO_HLEN_7);
+    set_huff(8, 6, 6, 0, 0, ISO_HCOD_8, ISO_HLEN_8);
+    set_huff(9, 6, 6, 0, 0, ISO_HCOD_9, ISO_HLEN_9);
+    set_huff(10, 8, 8, 0, 0, ISO_HCOD_10, ISO_HLEN_10);
+    set_huff(11, 8, 8, 0, 0, ISO_HCOD_11, ISO_HLEN_11);
+    set_huff(12, 8, 8, 0, 0, ISO_HCOD_12, ISO_HLEN_12);
+    set_huff(13, 16, 16, 0, 0, ISO_HCOD_13, ISO_HLEN_13);
+    set_huff(14, 0, 0, 0, 0, nullptr, nullptr);
+    set_huff(15, 16, 16, 0, 0, ISO_HCOD_15, ISO_HLEN_15);
+    static const int lb16[8] = {1, 2, 3, 4, 6, 8, 10, 13}, lb24[8] = {4, 5, 6, 7, 8, 9, 11, 13};
+    for (int k = 0; k < 8; k++) {
+        set_huff(16 + k, 16, 16, lb16[k], (1 << lb16[k]) - 1, ISO_HCOD_16, ISO_HLEN_16);
+        set_huff(24 + k, 16, 16, lb24[k], (1 << lb24[k]) - 1, ISO_HCOD_24, ISO_HLEN_24);
+    }
+    set_huff(32, 1, 16, 0, 0, ISO_HCOD_32, ISO_HLEN_32);
+    set_huff(33, 1, 16, 0, 0, ISO_HCOD_33, ISO_HLEN_33);
+    for (int i = 0; i < 256; i++) {
+        T.hlen13[i] = ISO_HLEN_13[i]; T.hlen15[i] = ISO_HLEN_15[i];
+        T.hlen16[i] = ISO_HLEN_16[i]; T.hlen24[i] = ISO_HLEN_24[i];
+    }
+    for (int i = 0; i < 16; i++) T.hlen_c1a[i] = ISO_HLEN_32[i];
+    for (int i = 0; i < 32; i++) { T.linbits[i] = (uint8_t)H.huff[i].linbits; T.linmax[i] = H.huff[i].linmax; }
+}
+
+}  // namespace
+
+const HostTables &host_tables()
+{
+    std::call_once(g_once, build);
+    return g_tables;
+}
+
+}  // namespace mp3s

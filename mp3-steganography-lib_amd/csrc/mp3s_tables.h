@@ -1,0 +1,65 @@
+// Constant tables of the hot path, built once on the host (glibc libm -- the reference's own float
+// tables come from CPython math.* = the same libm) and uploaded to the device's constant segment.
+// Device cos/sin/pow are never used: they differ from glibc in the last ulp and the decoder must be
+// int16-exact.
+#pragma once
+#include <stdint.h>
+
+namespace mp3s {
+
+constexpr int POW43_N = 8207;       // |is| <= 15 + 8191 (linbits 13)
+constexpr int POW2Q_MIN = -266;     // exp1 = global_gain - 210 - 8*sub_block_gain  in [-266, 45]
+constexpr int POW2Q_N = 312;
+constexpr int POW2H_N = 40;         // 2*exp2 in [0, 36]
+
+// requantisation line map: one byte per spectral line, (is_short << 7) | (window << 5) | sfb
+// case 0 = long path, 1 = block_type 2, 2 = mixed flag with block_type != 2 (reference Frame.py:185-208)
+struct DevTables {
+    // ---- decoder ----
+    double synth_matrix[64][32];   // reference Frame.py:17-29
+    double synth_window[512];      // reference decoder/tables.py:429-514
+    double imdct_cos36[36][18];    // reference Frame.py:130 (n = 36)
+    double imdct_cos12[12][6];     // reference Frame.py:130 (n = 12)
+    double sine_block[4][36];      // reference Frame.py:33-62
+    double alias_cs[8], alias_ca[8];
+    double pow43[POW43_N];         // pow(|is|, 4/3)           Frame.py:211
+    double pow2q[POW2Q_N];         // pow(2, exp1/4)           Frame.py:212
+    double pow2h[POW2H_N];         // pow(2, -(k*0.5))         Frame.py:213
+    double sqrt2;
+    uint8_t rq_map[3][3][576];     // [sr][case][line]
+    int16_t reorder_src[3][576];   // [sr][dst line] -> src line or -1 (zero)  Frame.py:574-602
+    uint8_t pre_tab[24];
+    // ---- encoder ----
+    int32_t enwindow[512];         // reference encoder/tables.py:34
+    int32_t fl[32][64];            // reference MP3_Encoder.py:536-544
+    int32_t cos_l[18][36];         // reference MP3_Encoder.py:551-556
+    int32_t mdct_cs[8], mdct_ca[8];
+    double steptab[128];
+    int32_t steptabi[128];
+    uint16_t int2idx[10000];       // values <= 1000
+    int32_t sfb_long[3][23];
+    int32_t subdv[23][2];
+    uint8_t hlen13[256], hlen15[256], hlen16[256], hlen24[256];
+    uint8_t hlen_c1a[16];
+    uint8_t linbits[32];
+    int32_t linmax[32];
+    uint8_t transform[32][2];      // reference MP3_Encoder.py:419-449
+};
+
+struct HostHuff {
+    int xlen, ylen, linbits, linmax;
+    const uint16_t *hcod;
+    const uint8_t *hlen;
+};
+
+struct HostTables {
+    DevTables dev;
+    HostHuff huff[34];
+    int sfb_short_width[3][12];
+    int slen[16][2];
+    uint8_t in_h0[32];
+};
+
+const HostTables &host_tables();   // built on first use, thread-safe
+
+}  // namespace mp3s

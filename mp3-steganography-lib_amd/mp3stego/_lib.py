@@ -1,0 +1,294 @@
+"""ctypes binding of the C-ABI in include/mp3s.h (libmp3s_hip.so, built in-tree by ../Makefile).
+
+This is the only place the Python side touches native code.  There is no CPU fallback: if the
+shared library is missing, or no MI355X is visible, the first call that needs the transforms raises.
+"""
+import ctypes as C
+import os
+import threading
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libmp3s_hip.so")
+
+MP3S_PCM_I16, MP3S_PCM_F32, MP3S_PCM_F64 = 0, 1, 2
+E_NO_DEVICE, E_HIP, E_ARG, E_MALFORMED, E_UNSUPPORTED, E_STEP_RANGE, E_NOMEM = -1, -2, -3, -4, -5, -6, -7
+RF_ACTIVE, RF_USED_ADDR_IN, RF_STEP_RANGE, RF_LOG_GUARD = 1, 2, 4, 8
+
+
+class Mp3sError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__(f"mp3s error {code}: {msg}")
+        self.code = code
+
+
+class GranuleSI(C.Structure):
+    _fields_ = [("global_gain", C.c_uint8), ("scalefac_scale", C.c_uint8), ("block_type", C.c_uint8),
+                ("mixed_block_flag", C.c_uint8), ("preflag", C.c_uint8), ("sub_block_gain", C.c_uint8 * 3),
+                ("scale_fac_l", C.c_uint8 * 22), ("scale_fac_s", C.c_uint8 * 39), ("pad", C.c_uint8 * 3)]
+
+
+GRANULE_SI_DTYPE = np.dtype([("global_gain", "u1"), ("scalefac_scale", "u1"), ("block_type", "u1"),
+                             ("mixed_block_flag", "u1"), ("preflag", "u1"), ("sub_block_gain", "u1", (3,)),
+                             ("scale_fac_l", "u1", (22,)), ("scale_fac_s", "u1", (3, 13)), ("pad", "u1", (3,))])
+FRAME_HDR_DTYPE = np.dtype([("sr_idx", "u1"), ("nch", "u1"), ("ms_stereo", "u1"), ("flags", "u1"),
+                            ("stream_first", "<u4")])
+RATE_FRAME_DTYPE = np.dtype([("max_bits", "<i4"), ("sr_idx", "<i4")])
+GR_OUT_DTYPE = np.dtype([("part2_3_length", "<i4"), ("big_values", "<i4"), ("count1", "<i4"),
+                         ("quantizer_step", "<i4"), ("region0_count", "<i4"), ("region1_count", "<i4"),
+                         ("count1table_select", "<i4"), ("table_select", "<i4", (3,)), ("address", "<i4", (3,)),
+                         ("n_tables", "<i4"), ("flags", "<i4"), ("reserved0", "<i4"), ("xrmax", "<i4"),
+                         ("reserved", "<i4")])
+assert GRANULE_SI_DTYPE.itemsize == 72 and FRAME_HDR_DTYPE.itemsize == 8 and GR_OUT_DTYPE.itemsize == 72
+
+
+class Parsed(C.Structure):
+    _fields_ = [("n_frames", C.c_int32), ("nch", C.c_int32), ("sampling_rate", C.c_int32), ("bit_rate", C.c_int32),
+                ("n_bits", C.c_int32), ("dup_last_frame", C.c_int32), ("is_", C.c_void_p), ("si", C.c_void_p),
+                ("hdr", C.c_void_p), ("bits", C.c_void_p), ("table_select", C.c_void_p), ("frame_size", C.c_void_p)]
+
+
+class Decoded(C.Structure):
+    _fields_ = [("n_frames", C.c_int32), ("nch", C.c_int32), ("sampling_rate", C.c_int32), ("bit_rate", C.c_int32),
+                ("n_bits", C.c_int32), ("n_rows", C.c_int64), ("pcm", C.c_void_p), ("bits", C.c_void_p)]
+
+
+class Encoded(C.Structure):
+    _fields_ = [("n_frames", C.c_int32), ("too_long", C.c_int32), ("hide_offset", C.c_int64), ("mp3", C.c_void_p),
+                ("mp3_len", C.c_size_t), ("gr", C.c_void_p), ("scfsi", C.c_void_p), ("rate_passes", C.c_int32)]
+
+
+# every symbol include/mp3s.h declares (tests/test_abi.py checks the library exports all of them)
+SYMBOLS = ["mp3s_ctx_create", "mp3s_ctx_destroy", "mp3s_last_error", "mp3s_version", "mp3s_device_name", "mp3s_sync",
+           "mp3s_dev_alloc", "mp3s_dev_free", "mp3s_dev_upload", "mp3s_dev_download", "mp3s_dev_memset",
+           "mp3s_timer_start", "mp3s_timer_stop", "mp3s_decode_transform_dev", "mp3s_decode_transform",
+           "mp3s_encode_transform_dev", "mp3s_encode_transform", "mp3s_rate_loop_dev", "mp3s_buf_free",
+           "mp3s_parse_stream", "mp3s_format_stream", "mp3s_rate_frames", "mp3s_decode_stream", "mp3s_encode_pcm"]
+
+_lib = None
+_lock = threading.Lock()
+
+
+def lib():
+    """Load libmp3s_hip.so (raises if it has not been built: no fallback)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    with _lock:
+        if _lib is not None:
+            return _lib
+        if not os.path.exists(LIB_PATH):
+            raise ImportError(f"{LIB_PATH} is missing: build it with `make -C mp3-steganography-lib_amd` "
+                              "(or `python __graft_entry__.py`); the HIP extension has no CPU fallback")
+        L = C.CDLL(LIB_PATH)
+        vp, i32, i64, sz = C.c_void_p, C.c_int, C.c_int64, C.c_size_t
+        pvp = C.POINTER(C.c_void_p)
+        L.mp3s_last_error.restype = C.c_char_p
+        L.mp3s_version.restype = C.c_char_p
+        L.mp3s_ctx_create.argtypes = [i32, pvp]
+        L.mp3s_ctx_destroy.argtypes = [vp]
+        L.mp3s_ctx_destroy.restype = None
+        L.mp3s_device_name.argtypes = [vp, C.c_char_p, sz]
+        L.mp3s_sync.argtypes = [vp]
+        L.mp3s_dev_alloc.argtypes = [vp, sz, pvp]
+        L.mp3s_dev_free.argtypes = [vp, vp]
+        L.mp3s_dev_upload.argtypes = [vp, vp, vp, sz]
+        L.mp3s_dev_download.argtypes = [vp, vp, vp, sz]
+        L.mp3s_dev_memset.argtypes = [vp, vp, i32, sz]
+        L.mp3s_timer_start.argtypes = [vp]
+        L.mp3s_timer_stop.argtypes = [vp, C.POINTER(C.c_float)]
+        L.mp3s_decode_transform_dev.argtypes = [vp, vp, vp, vp, i32, i32, i32, i32, vp]
+        L.mp3s_decode_transform.argtypes = [vp, vp, vp, vp, i32, i32, i32, i32, vp]
+        L.mp3s_encode_transform_dev.argtypes = [vp, vp, vp, i32, vp]
+        L.mp3s_encode_transform.argtypes = [vp, vp, vp, i32, vp]
+        L.mp3s_rate_loop_dev.argtypes = [vp, vp, vp, i32, vp, i32, vp, vp, vp, i32, vp, vp, vp]
+        L.mp3s_buf_free.argtypes = [vp]
+        L.mp3s_buf_free.restype = None
+        L.mp3s_parse_stream.argtypes = [vp, sz, pvp, C.POINTER(Parsed)]
+        L.mp3s_format_stream.argtypes = [i32, i32, i32, vp, vp, vp, pvp, pvp, C.POINTER(sz)]
+        L.mp3s_rate_frames.argtypes = [i32, i32, i32, i32, vp, vp]
+        L.mp3s_decode_stream.argtypes = [vp, vp, sz, i32, pvp, C.POINTER(Decoded)]
+        L.mp3s_encode_pcm.argtypes = [vp, vp, i64, i32, i32, i32, vp, i32, pvp, C.POINTER(Encoded)]
+        _lib = L
+    return _lib
+
+
+def check(rc):
+    if rc != 0:
+        raise Mp3sError(rc, lib().mp3s_last_error().decode("utf-8", "replace"))
+
+
+def _view(ptr, dtype, shape):
+    n = int(np.prod(shape)) * np.dtype(dtype).itemsize
+    if n == 0 or not ptr:
+        return np.zeros(shape, dtype=dtype)
+    return np.frombuffer((C.c_char * n).from_address(ptr), dtype=dtype).reshape(shape).copy()
+
+
+class Context:
+    """One context = one HIP device + one stream (one process per GPU)."""
+
+    def __init__(self, device=None):
+        if device is None:
+            device = int(os.environ.get("MP3STEGO_DEVICE", os.environ.get("LOCAL_RANK", "0")))
+        h = C.c_void_p()
+        check(lib().mp3s_ctx_create(int(device), C.byref(h)))
+        self.handle = h
+        self.device = int(device)
+
+    def close(self):
+        if self.handle:
+            lib().mp3s_ctx_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def device_name(self):
+        buf = C.create_string_buffer(256)
+        check(lib().mp3s_device_name(self.handle, buf, 256))
+        return buf.value.decode()
+
+    def sync(self):
+        check(lib().mp3s_sync(self.handle))
+
+    # ---- device memory helpers (benchmarks, resident pipelines)
+    def alloc(self, nbytes):
+        p = C.c_void_p()
+        check(lib().mp3s_dev_alloc(self.handle, int(nbytes), C.byref(p)))
+        return p
+
+    def free(self, p):
+        check(lib().mp3s_dev_free(self.handle, p))
+
+    def upload(self, dptr, arr):
+        arr = np.ascontiguousarray(arr)
+        check(lib().mp3s_dev_upload(self.handle, dptr, arr.ctypes.data, arr.nbytes))
+
+    def download(self, dptr, dtype, shape):
+        out = np.empty(shape, dtype=dtype)
+        check(lib().mp3s_dev_download(self.handle, out.ctypes.data, dptr, out.nbytes))
+        return out
+
+    def to_device(self, arr):
+        arr = np.ascontiguousarray(arr)
+        p = self.alloc(arr.nbytes)
+        self.upload(p, arr)
+        return p
+
+    def timer_start(self):
+        check(lib().mp3s_timer_start(self.handle))
+
+    def timer_stop(self):
+        ms = C.c_float()
+        check(lib().mp3s_timer_stop(self.handle, C.byref(ms)))
+        return ms.value
+
+    # ---- batch entry points on host arrays
+    def decode_transform(self, is_, si, hdr, nch, n_halo=0, out_format=MP3S_PCM_F64):
+        is_ = np.ascontiguousarray(is_, dtype=np.int16)
+        si = np.ascontiguousarray(si, dtype=GRANULE_SI_DTYPE)
+        hdr = np.ascontiguousarray(hdr, dtype=FRAME_HDR_DTYPE)
+        n = is_.shape[0]
+        dt = {MP3S_PCM_I16: np.int16, MP3S_PCM_F32: np.float32, MP3S_PCM_F64: np.float64}[out_format]
+        pcm = np.empty(((n - n_halo) * 1152, nch), dtype=dt)
+        check(lib().mp3s_decode_transform(self.handle, is_.ctypes.data, si.ctypes.data, hdr.ctypes.data, n, nch, n_halo,
+                                          out_format, pcm.ctypes.data))
+        return pcm
+
+    def encode_transform(self, pcm_i16, hdr=None):
+        pcm_i16 = np.ascontiguousarray(pcm_i16, dtype=np.int16)
+        n = pcm_i16.shape[0] // 1152
+        if hdr is None:
+            hdr = np.zeros(n, dtype=FRAME_HDR_DTYPE)
+            hdr["nch"] = 2
+        hdr = np.ascontiguousarray(hdr, dtype=FRAME_HDR_DTYPE)
+        mdct = np.empty((n, 2, 2, 576), dtype=np.int32)
+        check(lib().mp3s_encode_transform(self.handle, pcm_i16.ctypes.data, hdr.ctypes.data, n, mdct.ctypes.data))
+        return mdct
+
+    # ---- whole-stream pipelines
+    def decode_stream(self, data: bytes, out_format=MP3S_PCM_I16):
+        buf = np.frombuffer(data, dtype=np.uint8)
+        owner = C.c_void_p()
+        d = Decoded()
+        check(lib().mp3s_decode_stream(self.handle, buf.ctypes.data, len(data), out_format, C.byref(owner), C.byref(d)))
+        try:
+            dt = {MP3S_PCM_I16: np.int16, MP3S_PCM_F32: np.float32, MP3S_PCM_F64: np.float64}[out_format]
+            return {"n_frames": d.n_frames, "channels": d.nch, "sampling_rate": d.sampling_rate, "bit_rate": d.bit_rate,
+                    "pcm": _view(d.pcm, dt, (d.n_rows, d.nch)), "bits": _view(d.bits, np.uint8, (d.n_bits,))}
+        finally:
+            lib().mp3s_buf_free(owner)
+
+    def encode_pcm(self, pcm_i16, samplerate, bitrate, hide_bits=None):
+        pcm_i16 = np.ascontiguousarray(pcm_i16, dtype=np.int16)
+        nch = 1 if pcm_i16.ndim == 1 else pcm_i16.shape[1]
+        hb, nh = None, 0
+        if hide_bits is not None and len(hide_bits):
+            hb = np.ascontiguousarray(hide_bits, dtype=np.uint8)
+            nh = len(hb)
+        owner = C.c_void_p()
+        e = Encoded()
+        check(lib().mp3s_encode_pcm(self.handle, pcm_i16.ctypes.data, pcm_i16.shape[0], nch, samplerate, bitrate,
+                                    hb.ctypes.data if hb is not None else None, nh, C.byref(owner), C.byref(e)))
+        try:
+            return {"n_frames": e.n_frames, "too_long": bool(e.too_long), "hide_offset": e.hide_offset,
+                    "mp3": _view(e.mp3, np.uint8, (e.mp3_len,)).tobytes(),
+                    "gr": _view(e.gr, GR_OUT_DTYPE, (e.n_frames * 4,)),
+                    "scfsi": _view(e.scfsi, np.int32, (e.n_frames, 2, 4)), "rate_passes": e.rate_passes}
+        finally:
+            lib().mp3s_buf_free(owner)
+
+
+def parse_stream(data: bytes):
+    """Host front end only (no GPU): Huffman-decoded spectra, side records, stego bits."""
+    buf = np.frombuffer(data, dtype=np.uint8)
+    owner = C.c_void_p()
+    p = Parsed()
+    check(lib().mp3s_parse_stream(buf.ctypes.data, len(data), C.byref(owner), C.byref(p)))
+    try:
+        n = p.n_frames
+        return {"n_frames": n, "channels": p.nch, "sampling_rate": p.sampling_rate, "bit_rate": p.bit_rate,
+                "dup_last_frame": p.dup_last_frame, "is": _view(p.is_, np.int16, (n, 2, 2, 576)),
+                "si": _view(p.si, GRANULE_SI_DTYPE, (n, 2, 2)), "hdr": _view(p.hdr, FRAME_HDR_DTYPE, (n,)),
+                "bits": _view(p.bits, np.uint8, (p.n_bits,)),
+                "table_select": _view(p.table_select, np.int32, (n, 2, 2, 3)),
+                "frame_size": _view(p.frame_size, np.int32, (n,))}
+    finally:
+        lib().mp3s_buf_free(owner)
+
+
+def rate_frames(samplerate, bitrate, nch, n_frames):
+    out = np.zeros(n_frames, dtype=RATE_FRAME_DTYPE)
+    pad = np.zeros(n_frames, dtype=np.int32)
+    check(lib().mp3s_rate_frames(samplerate, bitrate, nch, n_frames, out.ctypes.data, pad.ctypes.data))
+    return out, pad
+
+
+def format_stream(samplerate, bitrate, ix, gr, scfsi):
+    ix = np.ascontiguousarray(ix, dtype=np.int16)
+    gr = np.ascontiguousarray(gr, dtype=GR_OUT_DTYPE)
+    scfsi = np.ascontiguousarray(scfsi, dtype=np.int32)
+    n = ix.shape[0]
+    owner, mp3, ln = C.c_void_p(), C.c_void_p(), C.c_size_t()
+    check(lib().mp3s_format_stream(samplerate, bitrate, n, ix.ctypes.data, gr.ctypes.data, scfsi.ctypes.data,
+                                   C.byref(owner), C.byref(mp3), C.byref(ln)))
+    try:
+        return _view(mp3.value, np.uint8, (ln.value,)).tobytes()
+    finally:
+        lib().mp3s_buf_free(owner)
+
+
+_default_ctx = None
+
+
+def default_context():
+    """Process-wide context, created on first use (raises without a GPU)."""
+    global _default_ctx
+    if _default_ctx is None:
+        _default_ctx = Context()
+    return _default_ctx

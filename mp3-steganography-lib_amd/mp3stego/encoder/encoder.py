@@ -1,0 +1,67 @@
+"""`Encoder` with the reference's signature and behaviour (reference mp3stego/encoder/encoder.py:8-58,
+MP3_Encoder.py:596-618): WAV in, MP3 out, optional '0'/'1' string hidden in the Huffman-table choice.
+Analysis filterbank, MDCT and the rate loop run on the GPU (mp3s_encode_pcm); bit packing on the host.
+"""
+import os
+import sys
+
+import numpy as np
+
+from mp3stego import _lib
+from mp3stego.encoder.wav_reader import WavReader
+
+
+class Encoder:
+    """
+    Creates an mp3 file from a wav file.
+
+    :param file_path: the wav file path.
+    :param output_file_path: the mp3 output file path.
+    :param bitrate: the bitrate (kbps) of the output
+    :param hide_str: if not empty, a string of '0'/'1' hidden inside the output mp3 file.
+    """
+
+    def __init__(self, file_path: str, output_file_path: str, bitrate: int = 320, hide_str: str = ''):
+        self.__file_path = file_path
+        self.__output_file_path = output_file_path
+        if not os.path.exists(self.__file_path):
+            sys.exit(f'File {self.__file_path} not found.')
+        self.__wav_file = WavReader(self.__file_path, bitrate)
+        self.__hide_str = hide_str
+        self.hide_str_offset = 0
+
+    def encode(self, quiet: bool = True) -> bool:
+        """
+        Encode the wav file into the mp3 file.
+
+        :return: True if the message is too long for this file (it has been trimmed).
+        """
+        w = self.__wav_file
+        nch = w.num_of_channels
+        total = w.num_of_samples * nch
+        per_pass = 1152 * nch
+        count = total // per_pass
+        # the reference steps its cursor by 2 per sample whatever the channel count and reads a partial last
+        # frame past the buffer: both end in IndexError there
+        if nch != 2:
+            raise IndexError("mono input: the reference encoder indexes the sample buffer out of bounds")
+        if total % per_pass or len(w.buffer) < count * per_pass:
+            raise IndexError("sample count is not a multiple of 1152 per channel: the reference encoder reads past "
+                             "the end of the sample buffer")
+        pcm = np.ascontiguousarray(w.buffer[:count * per_pass]).reshape(-1, 2)
+        hide = np.frombuffer(self.__hide_str.encode("ascii"), dtype=np.uint8) - ord("0") if self.__hide_str else None
+        try:
+            res = _lib.default_context().encode_pcm(pcm, w.samplerate, w.bitrate, hide)
+        except _lib.Mp3sError as e:
+            if e.code in (_lib.E_UNSUPPORTED, _lib.E_STEP_RANGE):
+                raise IndexError(str(e)) from None
+            raise
+        self.hide_str_offset = int(res["hide_offset"])
+        with open(self.__output_file_path, "wb") as f:
+            f.write(res["mp3"])
+        too_long = self.hide_str_offset < len(self.__hide_str) - 1
+        if not quiet:
+            if too_long:
+                print("File too short for this message length, your message has been trimmed.")
+            print(f"MP3 file created on {self.__output_file_path}")
+        return too_long
