@@ -99,6 +99,8 @@ const char *mp3s_last_error(void);
 const char *mp3s_version(void);
 int mp3s_device_name(mp3s_ctx *ctx, char *buf, size_t n);
 int mp3s_sync(mp3s_ctx *ctx);
+/* host copy of the constant tables uploaded to the device (struct DevTables of csrc/mp3s_tables.h), for tests */
+const void *mp3s_debug_tables(size_t *bytes);
 
 /* device memory owned by the caller through the context (for resident pipelines / benchmarks) */
 int mp3s_dev_alloc(mp3s_ctx *ctx, size_t bytes, void **dptr);
@@ -109,6 +111,11 @@ int mp3s_dev_memset(mp3s_ctx *ctx, void *dptr, int value, size_t bytes);
 /* HIP-event timer on the context's stream (the stream every kernel below is launched on) */
 int mp3s_timer_start(mp3s_ctx *ctx);
 int mp3s_timer_stop(mp3s_ctx *ctx, float *ms);
+/* per-kernel HIP-event timing on the same stream: enable, run, then collect the summed milliseconds and launch
+ * counts of the five kernels in this order: dec_imdct, dec_synth, enc_analysis, enc_mdct, rate_loop (n >= 5) */
+#define MP3S_N_KERNELS 5
+int mp3s_profile_enable(mp3s_ctx *ctx, int on);
+int mp3s_profile_collect(mp3s_ctx *ctx, double *total_ms, int64_t *launches, int n);
 
 /* ---------------------------------------------------------------- (ii) decode transform batch
  * replaces: re_quantize, __ms_stereo, __reorder, __alias_reduction, imdct, __frequency_inversion,

@@ -42,6 +42,7 @@ struct mp3s_ctx {
     hipStream_t stream = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     void *scratch = nullptr; size_t scratch_bytes = 0;
+    Profiler prof;
     int ensure_scratch(size_t bytes)
     {
         if (bytes <= scratch_bytes) return 0;
@@ -66,6 +67,11 @@ extern "C" {
 const char *mp3s_last_error(void) { return g_err.c_str(); }
 const char *mp3s_version(void) { return "mp3s-hip 0.1 (gfx950)"; }
 void mp3s_buf_free(mp3s_buf *b) { delete b; }
+const void *mp3s_debug_tables(size_t *bytes)
+{
+    if (bytes) *bytes = sizeof(DevTables);
+    return &host_tables().dev;
+}
 
 int mp3s_ctx_create(int device, mp3s_ctx **out)
 {
@@ -175,6 +181,32 @@ int mp3s_timer_stop(mp3s_ctx *c, float *ms)
     return MP3S_OK;
 }
 
+int mp3s_profile_enable(mp3s_ctx *c, int on)
+{
+    if (!c) return fail(MP3S_E_ARG, "ctx is null");
+    HIPCHK(hipStreamSynchronize(c->stream));
+    c->prof.enabled = on != 0;
+    c->prof.n_pairs = 0;
+    for (int k = 0; k < K_COUNT; k++) { c->prof.total_ms[k] = 0; c->prof.count[k] = 0; }
+    return MP3S_OK;
+}
+
+int mp3s_profile_collect(mp3s_ctx *c, double *total_ms, int64_t *launches, int n)
+{
+    if (!c || !total_ms || !launches || n < K_COUNT) return fail(MP3S_E_ARG, "bad argument (need %d slots)", (int)K_COUNT);
+    HIPCHK(hipStreamSynchronize(c->stream));
+    Profiler &p = c->prof;
+    for (int i = 0; i < p.n_pairs; i++) {
+        float ms = 0;
+        HIPCHK(hipEventElapsedTime(&ms, p.ev[2 * i], p.ev[2 * i + 1]));
+        p.total_ms[p.kid[i]] += ms;
+        p.count[p.kid[i]] += 1;
+    }
+    p.n_pairs = 0;
+    for (int k = 0; k < K_COUNT; k++) { total_ms[k] = p.total_ms[k]; launches[k] = p.count[k]; }
+    return MP3S_OK;
+}
+
 // ------------------------------------------------------------------------------------------------ batches
 int mp3s_decode_transform_dev(mp3s_ctx *c, const int16_t *d_is, const mp3s_granule_si *d_si, const mp3s_frame_hdr *d_hdr,
                               int n_frames, int nch, int n_halo, int out_format, void *d_pcm)
@@ -184,7 +216,7 @@ int mp3s_decode_transform_dev(mp3s_ctx *c, const int16_t *d_is, const mp3s_granu
         return fail(MP3S_E_ARG, "bad sizes: n_frames=%d nch=%d n_halo=%d fmt=%d", n_frames, nch, n_halo, out_format);
     int rc = c->ensure_scratch(dec_scratch_bytes(n_frames, nch));
     if (rc) return rc;
-    const int e = launch_decode(c->stream, d_is, d_si, d_hdr, n_frames, nch, n_halo, out_format, d_pcm, c->scratch);
+    const int e = launch_decode(c->stream, d_is, d_si, d_hdr, n_frames, nch, n_halo, out_format, d_pcm, c->scratch, &c->prof);
     if (e) return fail(MP3S_E_HIP, "decode launch: %s", hipGetErrorString((hipError_t)e));
     return MP3S_OK;
 }
@@ -239,7 +271,7 @@ int mp3s_encode_transform_dev(mp3s_ctx *c, const int16_t *d_pcm, const mp3s_fram
     if (n_frames <= 0) return fail(MP3S_E_ARG, "n_frames=%d", n_frames);
     int rc = c->ensure_scratch(enc_scratch_bytes(n_frames));
     if (rc) return rc;
-    const int e = launch_encode(c->stream, d_pcm, d_hdr, n_frames, d_mdct, c->scratch);
+    const int e = launch_encode(c->stream, d_pcm, d_hdr, n_frames, d_mdct, c->scratch, &c->prof);
     if (e) return fail(MP3S_E_HIP, "encode launch: %s", hipGetErrorString((hipError_t)e));
     return MP3S_OK;
 }
@@ -274,7 +306,7 @@ int mp3s_rate_loop_dev(mp3s_ctx *c, const int32_t *d_mdct, const mp3s_rate_frame
     if (n_frames <= 0 || n_hide < 0 || (n_hide > 0 && (!d_hide_bits || !d_cursor_in)))
         return fail(MP3S_E_ARG, "bad sizes / missing hide inputs");
     const int e = launch_rate(c->stream, d_mdct, d_frames, n_frames, d_hide_bits, n_hide, d_cursor_in, d_state_in,
-                              d_unit_list, n_list, d_ix, d_out, d_en);
+                              d_unit_list, n_list, d_ix, d_out, d_en, &c->prof);
     if (e) return fail(MP3S_E_HIP, "rate launch: %s", hipGetErrorString((hipError_t)e));
     return MP3S_OK;
 }

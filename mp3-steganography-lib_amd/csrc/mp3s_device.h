@@ -10,21 +10,36 @@ namespace mp3s {
 
 constexpr int DEC_SYNTH_TW = 4;   // waves per channel in a synthesis tile (tile = TW*64 - 15 output slots)
 
+// optional per-kernel HIP-event timing: when non-null, every kernel launch is bracketed by two events
+// recorded on the launch stream; mp3s_profile_collect() turns the pairs into per-kernel totals.
+enum KernelId { K_DEC_IMDCT = 0, K_DEC_SYNTH, K_ENC_ANALYSIS, K_ENC_MDCT, K_RATE_LOOP, K_COUNT };
+struct Profiler {
+    static constexpr int MAX_PAIRS = 8192;
+    hipEvent_t ev[2 * MAX_PAIRS];
+    int kid[MAX_PAIRS];
+    int n_pairs = 0, n_created = 0;
+    bool enabled = false;
+    double total_ms[K_COUNT] = {0};
+    long count[K_COUNT] = {0};
+    int begin(hipStream_t s, int k);          // returns pair index or -1
+    void end(hipStream_t s, int pair);
+};
+
 int dev_upload_tables(hipStream_t stream);
 
 // scratch: H and TL planes, 2 * nch * 32 * (36 n + 18) doubles
 size_t dec_scratch_bytes(int n_frames, int nch);
 int launch_decode(hipStream_t stream, const int16_t *d_is, const mp3s_granule_si *d_si, const mp3s_frame_hdr *d_hdr,
-                  int n_frames, int nch, int n_halo, int out_format, void *d_pcm, void *d_scratch);
+                  int n_frames, int nch, int n_halo, int out_format, void *d_pcm, void *d_scratch, Profiler *prof);
 
 // scratch: subband samples int32 [2][32][36 n]
 size_t enc_scratch_bytes(int n_frames);
 int launch_encode(hipStream_t stream, const int16_t *d_pcm, const mp3s_frame_hdr *d_hdr, int n_frames, int32_t *d_mdct,
-                  void *d_scratch);
+                  void *d_scratch, Profiler *prof);
 
 // state: int32 [units][4] = address1, address2, address3, quantizerStepSize inherited from the previous frame
 int launch_rate(hipStream_t stream, const int32_t *d_mdct, const mp3s_rate_frame *d_frames, int n_frames,
                 const uint8_t *d_hide, int n_hide, const int32_t *d_cursor, const int32_t *d_state,
-                const int32_t *d_list, int n_list, int16_t *d_ix, mp3s_gr_out *d_out, int32_t *d_en);
+                const int32_t *d_list, int n_list, int16_t *d_ix, mp3s_gr_out *d_out, int32_t *d_en, Profiler *prof);
 
 }  // namespace mp3s

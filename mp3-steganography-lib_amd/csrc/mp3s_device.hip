@@ -17,6 +17,22 @@ __constant__ DevTables c_tab;
 
 namespace mp3s {
 
+int Profiler::begin(hipStream_t s, int k)
+{
+    if (!enabled || n_pairs >= MAX_PAIRS) return -1;
+    while (n_created < 2 * (n_pairs + 1)) {
+        if (hipEventCreate(&ev[n_created]) != hipSuccess) return -1;
+        n_created++;
+    }
+    kid[n_pairs] = k;
+    (void)hipEventRecord(ev[2 * n_pairs], s);
+    return n_pairs++;
+}
+void Profiler::end(hipStream_t s, int pair)
+{
+    if (pair >= 0) (void)hipEventRecord(ev[2 * pair + 1], s);
+}
+
 int dev_upload_tables(hipStream_t stream)
 {
     const HostTables &h = host_tables();
@@ -32,20 +48,24 @@ size_t dec_scratch_bytes(int n_frames, int nch)
 }
 
 int launch_decode(hipStream_t stream, const int16_t *d_is, const mp3s_granule_si *d_si, const mp3s_frame_hdr *d_hdr,
-                  int n_frames, int nch, int n_halo, int out_format, void *d_pcm, void *d_scratch)
+                  int n_frames, int nch, int n_halo, int out_format, void *d_pcm, void *d_scratch, Profiler *prof)
 {
     const long Tp = (long)n_frames * 36 + 18;
     double *H = (double *)d_scratch;
     double *TL = H + (size_t)nch * 32 * Tp;
     const int n_gran = n_frames * 2;
+    int pp = prof ? prof->begin(stream, K_DEC_IMDCT) : -1;
     hipLaunchKernelGGL(k_dec_imdct, dim3((n_gran + DEC_A_WAVES - 1) / DEC_A_WAVES), dim3(DEC_A_WAVES * 64), 0, stream,
                        d_is, d_si, d_hdr, n_gran, nch, H, TL, Tp);
+    if (prof) prof->end(stream, pp);
     constexpr int TW = DEC_SYNTH_TW;
     const long T = (long)n_frames * 36;
     const int out_per_tile = TW * 64 - 15;
     const int tiles = (int)((T + out_per_tile - 1) / out_per_tile);
+    pp = prof ? prof->begin(stream, K_DEC_SYNTH) : -1;
     hipLaunchKernelGGL(k_dec_synth<TW>, dim3(tiles), dim3(TW * 64 * nch), 0, stream, (const double *)H,
                        (const double *)TL, Tp, d_hdr, n_frames, nch, n_halo, out_format, d_pcm);
+    if (prof) prof->end(stream, pp);
     return (int)hipGetLastError();
 }
 
@@ -55,28 +75,34 @@ size_t enc_scratch_bytes(int n_frames)
 }
 
 int launch_encode(hipStream_t stream, const int16_t *d_pcm, const mp3s_frame_hdr *d_hdr, int n_frames, int32_t *d_mdct,
-                  void *d_scratch)
+                  void *d_scratch, Profiler *prof)
 {
     const long Ts = (long)n_frames * 36;
     int32_t *SB = (int32_t *)d_scratch;
     const long waves = 2 * ((Ts + 63) / 64);
+    int pp = prof ? prof->begin(stream, K_ENC_ANALYSIS) : -1;
     hipLaunchKernelGGL(k_enc_analysis, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, stream, d_pcm, d_hdr, n_frames, SB,
                        Ts);
+    if (prof) prof->end(stream, pp);
     const int n_gran = n_frames * 2;
+    pp = prof ? prof->begin(stream, K_ENC_MDCT) : -1;
     hipLaunchKernelGGL(k_enc_mdct, dim3((n_gran + 3) / 4), dim3(256), 0, stream, (const int32_t *)SB, Ts, d_hdr, n_gran,
                        d_mdct);
+    if (prof) prof->end(stream, pp);
     return (int)hipGetLastError();
 }
 
 int launch_rate(hipStream_t stream, const int32_t *d_mdct, const mp3s_rate_frame *d_frames, int n_frames,
                 const uint8_t *d_hide, int n_hide, const int32_t *d_cursor, const int32_t *d_state,
-                const int32_t *d_list, int n_list, int16_t *d_ix, mp3s_gr_out *d_out, int32_t *d_en)
+                const int32_t *d_list, int n_list, int16_t *d_ix, mp3s_gr_out *d_out, int32_t *d_en, Profiler *prof)
 {
     const int n_units = n_frames * 4;
     const int n = d_list ? n_list : n_units;
     if (n <= 0) return 0;
+    const int pp = prof ? prof->begin(stream, K_RATE_LOOP) : -1;
     hipLaunchKernelGGL(k_rate_loop, dim3((n + RL_WAVES - 1) / RL_WAVES), dim3(RL_WAVES * 64), 0, stream, d_mdct, d_frames,
                        n_units, d_hide, n_hide, d_cursor, d_state, d_list, n, d_ix, d_out, d_en);
+    if (prof) prof->end(stream, pp);
     return (int)hipGetLastError();
 }
 

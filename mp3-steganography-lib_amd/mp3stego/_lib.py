@@ -60,9 +60,9 @@ class Encoded(C.Structure):
 
 
 # every symbol include/mp3s.h declares (tests/test_abi.py checks the library exports all of them)
-SYMBOLS = ["mp3s_ctx_create", "mp3s_ctx_destroy", "mp3s_last_error", "mp3s_version", "mp3s_device_name", "mp3s_sync",
+SYMBOLS = ["mp3s_ctx_create", "mp3s_ctx_destroy", "mp3s_last_error", "mp3s_version", "mp3s_device_name", "mp3s_sync", "mp3s_debug_tables",
            "mp3s_dev_alloc", "mp3s_dev_free", "mp3s_dev_upload", "mp3s_dev_download", "mp3s_dev_memset",
-           "mp3s_timer_start", "mp3s_timer_stop", "mp3s_decode_transform_dev", "mp3s_decode_transform",
+           "mp3s_timer_start", "mp3s_timer_stop", "mp3s_profile_enable", "mp3s_profile_collect", "mp3s_decode_transform_dev", "mp3s_decode_transform",
            "mp3s_encode_transform_dev", "mp3s_encode_transform", "mp3s_rate_loop_dev", "mp3s_buf_free",
            "mp3s_parse_stream", "mp3s_format_stream", "mp3s_rate_frames", "mp3s_decode_stream", "mp3s_encode_pcm"]
 
@@ -91,6 +91,8 @@ def lib():
         L.mp3s_ctx_destroy.restype = None
         L.mp3s_device_name.argtypes = [vp, C.c_char_p, sz]
         L.mp3s_sync.argtypes = [vp]
+        L.mp3s_debug_tables.argtypes = [C.POINTER(sz)]
+        L.mp3s_debug_tables.restype = vp
         L.mp3s_dev_alloc.argtypes = [vp, sz, pvp]
         L.mp3s_dev_free.argtypes = [vp, vp]
         L.mp3s_dev_upload.argtypes = [vp, vp, vp, sz]
@@ -98,6 +100,8 @@ def lib():
         L.mp3s_dev_memset.argtypes = [vp, vp, i32, sz]
         L.mp3s_timer_start.argtypes = [vp]
         L.mp3s_timer_stop.argtypes = [vp, C.POINTER(C.c_float)]
+        L.mp3s_profile_enable.argtypes = [vp, i32]
+        L.mp3s_profile_collect.argtypes = [vp, vp, vp, i32]
         L.mp3s_decode_transform_dev.argtypes = [vp, vp, vp, vp, i32, i32, i32, i32, vp]
         L.mp3s_decode_transform.argtypes = [vp, vp, vp, vp, i32, i32, i32, i32, vp]
         L.mp3s_encode_transform_dev.argtypes = [vp, vp, vp, i32, vp]
@@ -187,6 +191,18 @@ class Context:
         ms = C.c_float()
         check(lib().mp3s_timer_stop(self.handle, C.byref(ms)))
         return ms.value
+
+    KERNELS = ("k_dec_imdct", "k_dec_synth", "k_enc_analysis", "k_enc_mdct", "k_rate_loop")
+
+    def profile_enable(self, on=True):
+        check(lib().mp3s_profile_enable(self.handle, 1 if on else 0))
+
+    def profile_collect(self):
+        """{kernel: (total_ms, launches)} since profile_enable()"""
+        ms = np.zeros(5, dtype=np.float64)
+        cnt = np.zeros(5, dtype=np.int64)
+        check(lib().mp3s_profile_collect(self.handle, ms.ctypes.data, cnt.ctypes.data, 5))
+        return {k: (float(ms[i]), int(cnt[i])) for i, k in enumerate(self.KERNELS)}
 
     # ---- batch entry points on host arrays
     def decode_transform(self, is_, si, hdr, nch, n_halo=0, out_format=MP3S_PCM_F64):
@@ -281,6 +297,26 @@ def format_stream(samplerate, bitrate, ix, gr, scfsi):
         return _view(mp3.value, np.uint8, (ln.value,)).tobytes()
     finally:
         lib().mp3s_buf_free(owner)
+
+
+DEV_TABLES_DTYPE = np.dtype([
+    ("synth_matrix", "<f8", (64, 32)), ("synth_window", "<f8", (512,)), ("imdct_cos36", "<f8", (36, 18)),
+    ("imdct_cos12", "<f8", (12, 6)), ("sine_block", "<f8", (4, 36)), ("alias_cs", "<f8", (8,)), ("alias_ca", "<f8", (8,)),
+    ("pow43", "<f8", (8207,)), ("pow2q", "<f8", (312,)), ("pow2h", "<f8", (40,)), ("sqrt2", "<f8"),
+    ("rq_map", "u1", (3, 3, 576)), ("reorder_src", "<i2", (3, 576)), ("pre_tab", "u1", (24,)),
+    ("enwindow", "<i4", (512,)), ("fl", "<i4", (32, 64)), ("cos_l", "<i4", (18, 36)), ("mdct_cs", "<i4", (8,)),
+    ("mdct_ca", "<i4", (8,)), ("steptab", "<f8", (128,)), ("steptabi", "<i4", (128,)), ("int2idx", "<u2", (10000,)),
+    ("sfb_long", "<i4", (3, 23)), ("subdv", "<i4", (23, 2)), ("hlen13", "u1", (256,)), ("hlen15", "u1", (256,)),
+    ("hlen16", "u1", (256,)), ("hlen24", "u1", (256,)), ("hlen_c1a", "u1", (16,)), ("linbits", "u1", (32,)),
+    ("linmax", "<i4", (32,)), ("transform", "u1", (32, 2))], align=True)
+
+
+def debug_tables():
+    """Host copy of the device constant tables as a numpy record (tests only)."""
+    n = C.c_size_t()
+    p = lib().mp3s_debug_tables(C.byref(n))
+    assert n.value == DEV_TABLES_DTYPE.itemsize, (n.value, DEV_TABLES_DTYPE.itemsize)
+    return _view(p, DEV_TABLES_DTYPE, (1,))[0]
 
 
 _default_ctx = None

@@ -1,0 +1,51 @@
+"""The C-ABI library loads and exports every symbol include/mp3s.h declares (no compute without a GPU)."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def declared_symbols():
+    txt = open(os.path.join(ROOT, "include", "mp3s.h")).read()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    return sorted(set(re.findall(r"\b(mp3s_[a-z0-9_]+)\s*\(", txt)))
+
+
+def test_every_declared_symbol_is_exported(mlib):
+    L = mlib.lib()
+    syms = declared_symbols()
+    assert len(syms) >= 24
+    for s in syms:
+        assert hasattr(L, s), f"{s} declared in include/mp3s.h but not exported"
+    assert sorted(mlib.SYMBOLS) == syms
+
+
+def test_record_sizes(mlib):
+    assert C.sizeof(mlib.GranuleSI) == 72
+    assert mlib.GRANULE_SI_DTYPE.itemsize == 72 and mlib.FRAME_HDR_DTYPE.itemsize == 8
+    assert mlib.GR_OUT_DTYPE.itemsize == 72 and mlib.RATE_FRAME_DTYPE.itemsize == 8
+    assert b"gfx950" in mlib.lib().mp3s_version()
+
+
+def test_no_device_fails_loudly(mlib):
+    """Without a GPU the context cannot be created and nothing falls back to the CPU."""
+    import subprocess
+    import sys
+    code = ("import sys; sys.path.insert(0, %r); from mp3stego import _lib\n"
+            "try:\n    _lib.Context(0)\n    print('CREATED')\nexcept _lib.Mp3sError as e:\n    print('ERR', e.code)\n") % (
+        os.path.join(ROOT, "mp3-steganography-lib_amd"),)
+    env = dict(os.environ, HIP_VISIBLE_DEVICES="-1", ROCR_VISIBLE_DEVICES="-1")
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, timeout=120).stdout
+    assert "ERR -1" in out, out
+
+
+def test_argument_checks_do_not_need_a_gpu(mlib):
+    L = mlib.lib()
+    assert L.mp3s_parse_stream(None, 0, None, None) == mlib.E_ARG
+    out = np.zeros(4, dtype=mlib.RATE_FRAME_DTYPE)
+    assert L.mp3s_rate_frames(22050, 128, 2, 4, out.ctypes.data, None) == mlib.E_UNSUPPORTED
+    assert L.mp3s_rate_frames(44100, 100, 2, 4, out.ctypes.data, None) == mlib.E_UNSUPPORTED

@@ -1,0 +1,72 @@
+"""The reference's own five test cases (reference tests/steganography_test.py:15-60), run unchanged in
+spirit against the drop-in package on the GPU, plus the error behaviour of the facade."""
+import os
+import shutil
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture()
+def work(tmp_path, golden_dir, mlib):
+    shutil.copy(os.path.join(golden_dir, "test.mp3"), tmp_path / "test.mp3")
+    os.chmod(tmp_path / "test.mp3", 0o644)
+    return tmp_path
+
+
+def test_decoder_encoder(work):
+    from mp3stego import Steganography
+    st = Steganography(quiet=True)
+    bitrate = st.decode_mp3_to_wav(str(work / "test.mp3"), str(work / "out.wav"))
+    assert bitrate == 320
+    st.encode_wav_to_mp3(str(work / "out.wav"), str(work / "out.mp3"), bitrate)
+    assert os.path.getsize(work / "out.mp3") == 37616 and os.path.getsize(work / "out.wav") == 165932
+
+
+def test_hiding(work):
+    from mp3stego import Steganography
+    assert Steganography(quiet=True).hide_message(str(work / "test.mp3"), str(work / "out.mp3"), message='ddd') is False
+    assert not os.path.exists(work / "test.wav")          # the temporary wav is deleted
+
+
+def test_too_long_hiding(work):
+    from mp3stego import Steganography
+    assert Steganography(quiet=True).hide_message(str(work / "test.mp3"), str(work / "out.mp3"), message='ddd' * 100) is True
+
+
+def test_reveal_hiding(work):
+    from mp3stego import Steganography
+    st = Steganography(quiet=True)
+    st.hide_message(str(work / "test.mp3"), str(work / "out.mp3"), message='ddd')
+    st.reveal_massage(str(work / "out.mp3"), str(work / "reveal.txt"))
+    assert open(work / "reveal.txt").read() == 'ddd'
+
+
+def test_reveal_cleared(work):
+    from mp3stego import Steganography
+    st = Steganography(quiet=True)
+    st.hide_message(str(work / "test.mp3"), str(work / "out.mp3"), message='ddd')
+    st.clear_file(str(work / "out.mp3"), str(work / "cleared.mp3"))
+    st.reveal_massage(str(work / "cleared.mp3"), str(work / "reveal.txt"))
+    assert open(work / "reveal.txt").read() == ''
+
+
+def test_facade_errors(work):
+    from mp3stego import Steganography, Decoder, Encoder
+    st = Steganography()
+    with pytest.raises(SystemExit) as e:
+        st.decode_mp3_to_wav(str(work / "missing.mp3"))
+    assert "not found" in str(e.value)
+    with pytest.raises(SystemExit) as e:
+        st.decode_mp3_to_wav(str(work / "test.mp3"), str(work / "x.txt"))
+    assert str(e.value) == "input_file_path must be mp3 file, wav_file_path must be wav file."
+    with pytest.raises(SystemExit) as e:
+        st.reveal_massage(str(work / "test.mp3"), str(work / "x.wav"))
+    assert str(e.value) == "txt_file_path must be txt file."
+    open(work / "bad.wav", "wb").write(b"not a wave file")
+    with pytest.raises(SystemExit) as e:
+        Encoder(str(work / "bad.wav"), str(work / "o.mp3"))
+    assert str(e.value) == "Bad WAVE file."
+    with pytest.raises(SystemExit):
+        Decoder(str(work / "nope.mp3"), str(work / "o.wav"))

@@ -1,0 +1,217 @@
+"""Parity tests proper: the HIP path (through the C-ABI) against the oracle and the reference goldens.
+Bit-exact everywhere: integer artefacts, MP3 bytes, stego bits AND the float64 PCM (the kernels keep the
+reference's fp64 operation order), so the 1e-5 relative tolerance of the contract is met with margin 0."""
+import hashlib
+import json
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def sha(b):
+    return hashlib.sha256(bytes(b)).hexdigest()
+
+
+def bits_of(s):
+    return np.frombuffer("".join(format(b, "08b") for b in s.encode()).encode(), dtype=np.uint8) - ord("0")
+
+
+# ------------------------------------------------------------------------------------------------ decode
+def _chain_batch(mlib, g, name):
+    hdr_b, isv = g[name + "__hdr"], g[name + "__is"]
+    n = isv.shape[0]
+    mode = int(hdr_b[3] >> 6)
+    nch = 1 if mode == 3 else 2
+    si = np.zeros((n, 2, 2), dtype=mlib.GRANULE_SI_DTYPE)
+    si["global_gain"] = g[name + "__gg"]
+    si["scalefac_scale"] = g[name + "__sfs"]
+    si["block_type"] = g[name + "__bt"]
+    si["mixed_block_flag"] = g[name + "__mixed"]
+    si["preflag"] = g[name + "__pre"]
+    si["sub_block_gain"] = g[name + "__sbg"]
+    si["scale_fac_l"] = g[name + "__sfl"]
+    si["scale_fac_s"] = g[name + "__sfsh"]
+    hdr = np.zeros(n, dtype=mlib.FRAME_HDR_DTYPE)
+    hdr["sr_idx"] = (hdr_b[2] >> 2) & 3
+    hdr["nch"] = nch
+    hdr["ms_stereo"] = 1 if (mode == 1 and (hdr_b[3] & 0x20)) else 0
+    return isv, si, hdr, nch
+
+
+def test_decode_transform_reference_chain(ctx, mlib, golden_dir):
+    """short / start / stop / mixed blocks, MS stereo, mono, 32/44.1/48 kHz: float64 PCM bit for bit"""
+    g = np.load(os.path.join(golden_dir, "g4_decode_chain.npz"))
+    for name in sorted({k.split("__")[0] for k in g.files}):
+        isv, si, hdr, nch = _chain_batch(mlib, g, name)
+        pcm = ctx.decode_transform(isv, si, hdr, nch, 0, mlib.MP3S_PCM_F64)
+        ref = g[name + "__pcm"].reshape(-1, nch)
+        assert pcm.shape == ref.shape
+        assert pcm.tobytes() == ref.tobytes(), name
+        f32 = ctx.decode_transform(isv, si, hdr, nch, 0, mlib.MP3S_PCM_F32)
+        assert np.array_equal(f32, ref.astype(np.float32)), name
+
+
+def test_decode_batch_of_streams_and_halo(ctx, mlib, orc, golden_dir):
+    """several streams in one batch (stream_first) and chunked decoding with a 1-frame halo"""
+    g = np.load(os.path.join(golden_dir, "g4_decode_chain.npz"))
+    a = _chain_batch(mlib, g, "all_44_ms")
+    b = _chain_batch(mlib, g, "long_44_stereo")
+    ra = g["all_44_ms__pcm"].reshape(-1, 2)
+    rb = g["long_44_stereo__pcm"].reshape(-1, 2)
+    isv = np.concatenate([a[0], b[0], a[0]])
+    si = np.concatenate([a[1], b[1], a[1]])
+    hdr = np.concatenate([a[2], b[2], a[2]])
+    na, nb = len(a[2]), len(b[2])
+    hdr["stream_first"] = [0] * na + [na] * nb + [na + nb] * na
+    pcm = ctx.decode_transform(isv, si, hdr, 2, 0, mlib.MP3S_PCM_F64)
+    assert pcm.tobytes() == np.concatenate([ra, rb, ra]).tobytes()
+    # chunked decode: a chunk that starts at frame `start` needs only frame start-1 as halo -- the IMDCT overlap
+    # reaches back one granule and the V fifo 15 slots, both inside the halo frame's second granule
+    p = mlib.parse_stream(open(os.path.join(golden_dir, "test.mp3"), "rb").read())
+    full = ctx.decode_transform(p["is"], p["si"], p["hdr"], 2, 0, mlib.MP3S_PCM_F64)
+    for start in (1, 2, 7, 20, 35):
+        part = ctx.decode_transform(p["is"][start - 1:], p["si"][start - 1:], p["hdr"][start - 1:], 2, 1, mlib.MP3S_PCM_F64)
+        assert part.tobytes() == full[start * 1152:].tobytes(), start
+    i16 = ctx.decode_transform(p["is"][6:], p["si"][6:], p["hdr"][6:], 2, 1, mlib.MP3S_PCM_I16)
+    assert np.array_equal(i16, orc.pcm_to_i16(full[7 * 1152:]))
+
+
+def test_decode_stream_testmp3(ctx, mlib, orc, golden_dir):
+    g = np.load(os.path.join(golden_dir, "g2_decode_testmp3.npz"))
+    data = open(os.path.join(golden_dir, "test.mp3"), "rb").read()
+    r = ctx.decode_stream(data, mlib.MP3S_PCM_F64)
+    assert r["n_frames"] == 36 and r["bit_rate"] == 320000 and r["sampling_rate"] == 44100
+    assert np.array_equal(r["bits"], g["bits"])
+    assert np.array_equal(r["pcm"][:4 * 1152], g["pcm_head"])
+    assert sha(r["pcm"].tobytes()) == bytes(g["pcm_sha256"]).decode()
+    r16 = ctx.decode_stream(data, mlib.MP3S_PCM_I16)
+    assert sha(r16["pcm"].tobytes()) == bytes(g["pcm_i16_sha256"]).decode()
+    assert sha(orc.wav_bytes(r16["pcm"], 44100)) == bytes(g["wav_sha256"]).decode()
+
+
+def test_pcm_i16_wraps_like_numpy(ctx, mlib, orc):
+    """(pcm*32767).astype(int16): truncation toward zero and wrap-around, no clipping"""
+    n = 2
+    isv = np.zeros((n, 2, 2, 576), dtype=np.int16)
+    isv[:, :, :, :40] = 8000
+    si = np.zeros((n, 2, 2), dtype=mlib.GRANULE_SI_DTYPE)
+    si["global_gain"] = 200
+    hdr = np.zeros(n, dtype=mlib.FRAME_HDR_DTYPE)
+    hdr["nch"] = 2
+    f64 = ctx.decode_transform(isv, si, hdr, 2, 0, mlib.MP3S_PCM_F64)
+    i16 = ctx.decode_transform(isv, si, hdr, 2, 0, mlib.MP3S_PCM_I16)
+    assert np.abs(f64).max() > 1.5                       # far outside [-1, 1]
+    assert np.array_equal(i16, orc.pcm_to_i16(f64))
+
+
+# ------------------------------------------------------------------------------------------------ encode
+def test_encode_transform_golden(ctx, mlib, orc, golden_dir):
+    pcm = np.load(os.path.join(golden_dir, "g3_testmp3_wav_pcm.npz"))["pcm"]
+    g = np.load(os.path.join(golden_dir, "g3_encode_plain320.npz"))
+    mdct = ctx.encode_transform(pcm)
+    assert np.array_equal(mdct[:4], g["mdct_freq"])
+    assert np.array_equal(mdct, orc.encode(pcm, 44100, 320)["mdct_freq"])
+    # extreme samples
+    rng = np.random.default_rng(7)
+    hard = rng.choice(np.array([-32768, 32767, 0, 1, -1], dtype=np.int16), size=(8 * 1152, 2))
+    assert np.array_equal(ctx.encode_transform(hard), orc.encode(hard, 44100, 320)["mdct_freq"])
+
+
+@pytest.mark.parametrize("name", ["plain320", "hide_ddd320"])
+def test_encode_pcm_golden(ctx, mlib, golden_dir, name):
+    pcm = np.load(os.path.join(golden_dir, "g3_testmp3_wav_pcm.npz"))["pcm"]
+    g = np.load(os.path.join(golden_dir, f"g3_encode_{name}.npz"))
+    hide = g["hide_bits"] if "hide_bits" in g.files else None
+    r = ctx.encode_pcm(pcm, 44100, 320, hide)
+    assert len(r["mp3"]) == int(g["mp3_len"]) and sha(r["mp3"]) == bytes(g["mp3_sha256"]).decode()
+    _check_gr(r, g)
+    assert r["too_long"] == bool(int(g["too_long"]))
+    assert r["hide_offset"] == int(g["hide_off"][-1])
+
+
+def _check_gr(r, g):
+    """every table index and side-info field of every granule*channel"""
+    fields = bytes(g["gi_fields"]).decode().split(",")
+    gi = g["gi"]                                  # [f][gr][ch][field]
+    n = gi.shape[0]
+    gr = r["gr"].reshape(n, 2, 2)                 # [f][ch][gr]
+    for a, b in (("big_values", "big_values"), ("count1", "count1"), ("quantizer_step", "quantizerStepSize"),
+                 ("region0_count", "region0_count"), ("region1_count", "region1_count"),
+                 ("count1table_select", "count1table_select")):
+        assert np.array_equal(gr[a].transpose(0, 2, 1), gi[..., fields.index(b)]), a
+    assert np.array_equal(gr["table_select"].transpose(0, 2, 1, 3), g["table_select"])
+    for k, fld in enumerate(("address1", "address2", "address3")):
+        assert np.array_equal(gr["address"][..., k].transpose(0, 2, 1), gi[..., fields.index(fld)]), fld
+    assert np.array_equal(r["scfsi"], g["scfsi"])
+
+
+def test_encode_synth128_with_silence(ctx, mlib, golden_dir):
+    """128 kbps synthetic stream ending in digital silence: big_values == 0 units, stale address1/2/3 and
+    quantizerStepSize inheritance, 56-bit message"""
+    g = np.load(os.path.join(golden_dir, "g6_synth128.npz"))
+    r = ctx.encode_pcm(g["pcm"], 44100, 128, g["hide_bits"])
+    assert r["mp3"] == g["mp3"].tobytes()
+    _check_gr(r, g)
+    d = ctx.decode_stream(r["mp3"], mlib.MP3S_PCM_F64)
+    assert np.array_equal(d["bits"], g["dec_bits"])
+    assert np.array_equal(d["bits"][:len(g["hide_bits"])], g["hide_bits"])
+    assert sha(d["pcm"].tobytes()) == bytes(g["dec_pcm_sha256"]).decode()
+
+
+def test_facade_hashes(ctx, mlib, golden_dir):
+    """hide / clear / too-long through the device pipeline equal the reference facade run"""
+    fac = json.load(open(os.path.join(golden_dir, "g3_facade.json")))
+    data = open(os.path.join(golden_dir, "test.mp3"), "rb").read()
+    d = ctx.decode_stream(data, mlib.MP3S_PCM_I16)
+    kbps = d["bit_rate"] // 1000
+    h = ctx.encode_pcm(d["pcm"], d["sampling_rate"], kbps, bits_of("3#ddd"))
+    assert sha(h["mp3"]) == fac["hide_sha256"] and h["too_long"] == fac["too_long"]
+    d2 = ctx.decode_stream(h["mp3"], mlib.MP3S_PCM_I16)
+    c = ctx.encode_pcm(d2["pcm"], d2["sampling_rate"], d2["bit_rate"] // 1000, None)
+    assert sha(c["mp3"]) == fac["cleared_sha256"]
+    lg = ctx.encode_pcm(d["pcm"], d["sampling_rate"], kbps, bits_of("300#" + "ddd" * 100))
+    assert sha(lg["mp3"]) == fac["hide_long_sha256"] and lg["too_long"] == fac["too_long_300"]
+
+
+def test_encode_errors_like_reference(ctx, mlib):
+    with pytest.raises(mlib.Mp3sError) as e:
+        ctx.encode_pcm(np.zeros((1152, 1), dtype=np.int16), 44100, 128)
+    assert e.value.code == mlib.E_UNSUPPORTED
+    with pytest.raises(mlib.Mp3sError) as e:
+        ctx.encode_pcm(np.zeros((1152 + 7, 2), dtype=np.int16), 44100, 128)
+    assert e.value.code == mlib.E_UNSUPPORTED
+    with pytest.raises(mlib.Mp3sError) as e:
+        ctx.encode_pcm(np.zeros((1152, 2), dtype=np.int16), 22050, 128)
+    assert e.value.code == mlib.E_UNSUPPORTED
+    # all-zero input: every unit silent, nothing hidden
+    r = ctx.encode_pcm(np.zeros((3 * 1152, 2), dtype=np.int16), 44100, 128, bits_of("1#x"))
+    assert r["hide_offset"] == 0 and r["too_long"] and (r["gr"]["big_values"] == 0).all()
+
+
+# ------------------------------------------------------------------------------------------------ full size
+@pytest.mark.parametrize("rate,kbps", [(44100, 128), (48000, 320), (32000, 64)])
+def test_full_size_against_oracle(ctx, mlib, orc, rate, kbps):
+    """BASELINE-size batch (10k frames at 44.1k/128k; 2k at the other rates): the whole pipeline against
+    the oracle, byte for byte, plus the size-independent round-trip property"""
+    from synth_pcm import synth_pcm
+    n = 10000 if rate == 44100 else 2000
+    pcm = synth_pcm(n, rate=rate)
+    msg = bits_of("64#" + "The quick brown fox jumps over the lazy dog, again & again, 0123")
+    r = ctx.encode_pcm(pcm, rate, kbps, msg)
+    o = orc.encode(pcm, rate, kbps, msg)
+    assert o["rc"] == 0 and r["mp3"] == o["mp3"]
+    assert r["hide_offset"] == o["hide_offset"] and r["too_long"] == bool(o["too_long"])
+    d = ctx.decode_stream(r["mp3"], mlib.MP3S_PCM_F64)
+    od = orc.decode(r["mp3"])
+    assert d["n_frames"] == od["n_frames"]
+    assert np.array_equal(d["bits"], od["bits"])
+    assert np.array_equal(d["bits"][:len(msg)], msg)                 # encode -> decode recovers the message
+    assert sha(d["pcm"].tobytes()) == sha(np.ascontiguousarray(od["pcm"]).tobytes())
+    d16 = ctx.decode_stream(r["mp3"], mlib.MP3S_PCM_I16)
+    assert np.array_equal(d16["pcm"], orc.pcm_to_i16(od["pcm"]))
+    # decode -> re-encode (clear) -> decode: no message left, same number of frames
+    c = ctx.encode_pcm(d16["pcm"], rate, kbps, None)
+    assert c["mp3"] == orc.encode(d16["pcm"], rate, kbps, None)["mp3"]

@@ -1,0 +1,110 @@
+"""Constant tables (oracle's and the product's) against the reference's evaluated tables (G1).  CPU only."""
+import ctypes as C
+import os
+
+import numpy as np
+
+ALIAS_CS = [.8574929257, .8817419973, .9496286491, .9833145925, .9955178161, .9991605582, .9998991952, .9999931551]
+ALIAS_CA = [-.5144957554, -.4717319686, -.3133774542, -.1819131996, -.0945741925, -.0409655829, -.0141985686,
+            -.0036999747]
+
+
+def test_product_tables_match_reference(mlib, golden_dir):
+    g = np.load(os.path.join(golden_dir, "g1_tables.npz"))
+    t = mlib.debug_tables()
+    assert np.array_equal(t["synth_window"], g["synth_window"])
+    assert np.array_equal(t["synth_matrix"], g["synth_matrix"])
+    assert np.array_equal(t["sine_block"], g["sine_block"])
+    assert np.array_equal(t["alias_cs"], np.array(ALIAS_CS)) and np.array_equal(t["alias_ca"], np.array(ALIAS_CA))
+    assert np.array_equal(t["enwindow"], g["enwindow"])
+    assert np.array_equal(t["fl"], g["enc_fl"])
+    assert np.array_equal(t["cos_l"], g["enc_cos_l"])
+    assert np.array_equal(t["steptab"], g["enc_steptab"]) and np.array_equal(t["steptabi"], g["enc_steptabi"])
+    assert np.array_equal(t["int2idx"].astype(np.int32), g["enc_int2idx"])
+    assert np.array_equal(t["mdct_cs"], g["mdct_cs"]) and np.array_equal(t["mdct_ca"], g["mdct_ca"])
+    assert np.array_equal(t["subdv"], g["subdv_table"])
+    assert np.array_equal(t["sfb_long"], g["enc_sfb_index"][:3])
+    for sr, key in enumerate(("44", "48", "32")):
+        assert np.array_equal(t["sfb_long"][sr], g[f"bi_long_{key}"])
+    assert np.array_equal(t["pre_tab"][:21], g["pre_tab"])
+    assert np.array_equal(t["hlen13"], g["enc_hlen_13"]) and np.array_equal(t["hlen15"], g["enc_hlen_15"])
+    assert np.array_equal(t["hlen16"], g["enc_hlen_16"]) and np.array_equal(t["hlen24"], g["enc_hlen_24"])
+    assert np.array_equal(t["hlen_c1a"], g["enc_hlen_32"])
+    meta = g["enc_huff_meta"]
+    assert np.array_equal(t["linbits"], meta[:32, 2]) and np.array_equal(t["linmax"], meta[:32, 3])
+    tr = g["idx_to_transform_huf"]
+    for tab in range(32):
+        if tab in (0, 4, 14):
+            continue
+        assert tuple(t["transform"][tab]) == tuple(tr[tab]), tab
+    # the float tables the reference evaluates inline
+    i, k = np.meshgrid(np.arange(36), np.arange(18), indexing="ij")
+    import math
+    ref36 = np.array([[math.cos(math.pi / (2 * 36) * (2 * a + 1 + 18) * (2 * b + 1)) for b in range(18)]
+                      for a in range(36)])
+    ref12 = np.array([[math.cos(math.pi / (2 * 12) * (2 * a + 1 + 6) * (2 * b + 1)) for b in range(6)]
+                      for a in range(12)])
+    assert np.array_equal(t["imdct_cos36"], ref36) and np.array_equal(t["imdct_cos12"], ref12)
+    assert np.array_equal(t["pow43"], np.array([pow(float(v), 4.0 / 3.0) for v in range(8207)]))
+    assert np.array_equal(t["pow2q"], np.array([pow(2.0, (v - 266) / 4.0) for v in range(312)]))
+    assert np.array_equal(t["pow2h"], np.array([pow(2.0, -(v * 0.5)) for v in range(40)]))
+    assert t["sqrt2"] == math.sqrt(2)
+
+
+def test_oracle_tables_match_reference(orc, golden_dir):
+    g = np.load(os.path.join(golden_dir, "g1_tables.npz"))
+
+    class H(C.Structure):
+        _fields_ = [("xlen", C.c_int), ("ylen", C.c_int), ("linbits", C.c_int), ("linmax", C.c_int),
+                    ("hcod", C.POINTER(C.c_uint16)), ("hlen", C.POINTER(C.c_uint8))]
+
+    class T(C.Structure):
+        _fields_ = [("synth_window", C.c_double * 512), ("synth_matrix", C.c_double * 2048),
+                    ("sine_block", C.c_double * 144), ("imdct_cos36", C.c_double * 648),
+                    ("imdct_cos12", C.c_double * 72), ("alias_cs", C.c_double * 8), ("alias_ca", C.c_double * 8),
+                    ("sfb_long", C.c_int * 69), ("sfb_short_width", C.c_int * 36), ("pre_tab", C.c_int * 21),
+                    ("slen", C.c_int * 32), ("dec_linbits", C.c_int * 32), ("dec_max", C.c_int * 32),
+                    ("enwindow", C.c_int32 * 512), ("fl", C.c_int32 * 2048), ("cos_l", C.c_int32 * 648),
+                    ("steptab", C.c_double * 128), ("steptabi", C.c_int32 * 128), ("int2idx", C.c_int32 * 10000),
+                    ("mdct_cs", C.c_int32 * 8), ("mdct_ca", C.c_int32 * 8), ("subdv", C.c_int * 46),
+                    ("transform", C.c_int * 64), ("in_h0", C.c_int * 32), ("huff", H * 34)]
+
+    t = T.from_address(orc.lib().orc_tables())
+    a = lambda f: np.ctypeslib.as_array(getattr(t, f))  # noqa: E731
+    assert np.array_equal(a("synth_window"), g["synth_window"])
+    assert np.array_equal(a("synth_matrix").reshape(64, 32), g["synth_matrix"])
+    assert np.array_equal(a("sine_block").reshape(4, 36), g["sine_block"])
+    assert np.array_equal(a("alias_cs"), np.array(ALIAS_CS)) and np.array_equal(a("alias_ca"), np.array(ALIAS_CA))
+    assert np.array_equal(a("enwindow"), g["enwindow"])
+    assert np.array_equal(a("fl").reshape(32, 64), g["enc_fl"])
+    assert np.array_equal(a("cos_l").reshape(18, 36), g["enc_cos_l"])
+    assert np.array_equal(a("steptab"), g["enc_steptab"]) and np.array_equal(a("steptabi"), g["enc_steptabi"])
+    assert np.array_equal(a("int2idx"), g["enc_int2idx"])
+    assert np.array_equal(a("mdct_cs"), g["mdct_cs"]) and np.array_equal(a("mdct_ca"), g["mdct_ca"])
+    assert np.array_equal(a("subdv").reshape(23, 2), g["subdv_table"])
+    assert np.array_equal(a("pre_tab"), g["pre_tab"]) and np.array_equal(a("slen").reshape(16, 2), g["slen"])
+    assert np.array_equal(a("dec_linbits"), g["big_value_linbit"]) and np.array_equal(a("dec_max"), g["big_value_max"])
+    sl = a("sfb_long").reshape(3, 23)
+    sw = a("sfb_short_width").reshape(3, 12)
+    for sr, key in enumerate(("44", "48", "32")):
+        assert np.array_equal(sl[sr], g[f"bi_long_{key}"]) and np.array_equal(sw[sr], g[f"bw_short_{key}"])
+    assert sorted(np.nonzero(a("in_h0"))[0].tolist()) == g["H0"].tolist()
+    tr = a("transform").reshape(32, 2)
+    for tab in range(32):
+        if tab not in (0, 4, 14):
+            assert tuple(tr[tab]) == tuple(g["idx_to_transform_huf"][tab])
+    meta = g["enc_huff_meta"]
+    for n in range(34):
+        h = t.huff[n]
+        assert [h.xlen, h.ylen, h.linbits, h.linmax] == meta[n].tolist()
+        if f"enc_hcod_{n}" in g.files:
+            cnt = len(g[f"enc_hcod_{n}"])
+            assert np.array_equal(np.ctypeslib.as_array(h.hcod, (cnt,)), g[f"enc_hcod_{n}"])
+            assert np.array_equal(np.ctypeslib.as_array(h.hlen, (cnt,)), g[f"enc_hlen_{n}"])
+    # decoder code books are the same books left-aligned: (hcod << (32 - len), len)
+    for n in (1, 2, 3, 5, 6, 7, 8, 9, 10, 11, 12, 13, 15, 16, 24):
+        dec = g[f"dec_hft_{n}"].reshape(-1, 2)
+        code, ln = g[f"enc_hcod_{n}"].astype(np.uint64), g[f"enc_hlen_{n}"].astype(np.uint64)
+        assert np.array_equal(dec[:, 1], ln) and np.array_equal(dec[:, 0].astype(np.uint64), code << (32 - ln))
+    assert np.array_equal(g["quad_hlen"], g["enc_hlen_32"])
+    assert np.array_equal(g["quad_hcod"].astype(np.uint64), g["enc_hcod_32"].astype(np.uint64) << (32 - g["enc_hlen_32"].astype(np.uint64)))
