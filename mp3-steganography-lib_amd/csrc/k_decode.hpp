@@ -1,13 +1,14 @@
 // Decode transform kernels (gfx950).  Included by mp3s_device.hip only.
 //
-//   k_dec_imdct : requantise -> MS stereo -> reorder | alias reduction -> IMDCT + window
+//   k_dec_imdct : requantise -> MS stereo -> reorder | alias reduction -> IMDCT + window + overlap-add
 //                 (reference decoder/Frame.py:157-218, 561-622, 106-154; frequency inversion :624-631
-//                 is folded into the stores).  One wavefront per granule, lane = (channel, subband):
-//                 the 18 lines of a subband live in one lane's registers, the IMDCT twiddle of a
-//                 given (output, term) is the same for every lane, so it is a scalar (SGPR) operand
-//                 fetched through the scalar cache -- no LDS traffic in the inner loop.
-//   k_dec_synth : overlap-add, polyphase matrixing, windowing and PCM conversion
-//                 (reference Frame.py:150-153, 65-103, 633-640, MP3_Parser.py:91).  lane = time slot:
+//                 is folded into the stores).  One wavefront walks DEC_RUN consecutive granules, lane =
+//                 (channel, subband): the 18 lines of a subband and the 18-sample overlap tail live in
+//                 one lane's registers, the IMDCT twiddle of a given (output, term) is the same for every
+//                 lane, so it is a scalar (SGPR) operand fetched through the scalar cache -- no LDS
+//                 traffic in the inner loop.  The run is primed with the tail of the granule before it.
+//   k_dec_synth : polyphase matrixing, windowing and PCM conversion
+//                 (reference Frame.py:65-103, 633-640, MP3_Parser.py:91).  lane = time slot:
 //                 the 32 subband samples of a slot live in registers, the 64x32 matrix and D[] are
 //                 scalar operands; the 16-slot V history is exchanged between lanes through LDS.
 //
@@ -26,39 +27,30 @@ __device__ __forceinline__ double shfl_xor_f64(double v, int mask)
 }
 
 // ---------------------------------------------------------------------------------------------
-// Kernel A.  H / TL layout: [ch][sb][slot] doubles, row stride Tp = n_frames*36 + 18.
-//   H [slot]  (slot = g*18 + i, i < 18)      first half of granule g's windowed IMDCT
-//   TL[slot]  (slot = g*18 + i, i in 18..35) second half, i.e. it lands on granule g+1's slots
-// so that the time-domain subband sample of a slot is simply H[slot] + TL[slot].
+// Kernel A.  S layout: float64 [ch][slot][32 subbands] (slot = granule*18 + i): the time-domain subband
+// samples after overlap-add and frequency inversion -- what synth_filter_bank reads (Frame.py:78-79).
+// A wave stores one 256-byte row per channel per slot: fully coalesced.
 // ---------------------------------------------------------------------------------------------
 constexpr int DEC_A_WAVES = 4;
+constexpr int DEC_RUN = 4;     // granules per wave (+1 priming granule whose second half only is computed)
 
-__global__ __launch_bounds__(DEC_A_WAVES * 64) void k_dec_imdct(
-    const int16_t *__restrict__ is, const mp3s_granule_si *__restrict__ si, const mp3s_frame_hdr *__restrict__ hdr,
-    int n_granules, int nch, double *__restrict__ H, double *__restrict__ TL, long Tp)
+// requantise .. alias/reorder of granule g for this lane's subband; v[18] = IMDCT input
+__device__ __forceinline__ void dec_prepare(double (&v)[18], double *buf, const int16_t *__restrict__ is,
+                                            const mp3s_granule_si *__restrict__ si, int g, int sr, bool ms, int nch,
+                                            int ch, int sb, bool live, int &bt_out)
 {
-    __shared__ double lds[DEC_A_WAVES][2][576];
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int g = blockIdx.x * DEC_A_WAVES + wave;
-    if (g >= n_granules) return;  // whole wave exits together
-    const int ch = lane >> 5, sb = lane & 31;
-    const bool live = ch < nch;
-    const mp3s_frame_hdr fh = hdr[g >> 1];
-    const int sr = fh.sr_idx < 3 ? fh.sr_idx : 0;
     const mp3s_granule_si *gs = &si[(long)g * 2 + (live ? ch : 0)];
     const int gg = gs->global_gain, bt = gs->block_type & 3, mixed = gs->mixed_block_flag ? 1 : 0;
     const int mult2 = gs->scalefac_scale ? 2 : 1, preflag = gs->preflag ? 1 : 0;
     const int cse = bt == 2 ? 1 : (mixed ? 2 : 0);
     const uint8_t *map = c_tab.rq_map[sr][cse];
-
+    bt_out = bt;
     // ---- requantise (Frame.py:210-215): ((sign * |is|^(4/3)) * 2^(exp1/4)) * 2^(-exp2)
-    double v[18];
     const int16_t *isp = is + ((long)g * 2 + (live ? ch : 0)) * 576 + sb * 18;
 #pragma unroll
     for (int k = 0; k < 18; k++) {
-        const int line = sb * 18 + k;
         const int x = live ? (int)isp[k] : 0;
-        const int m = map[line];
+        const int m = map[sb * 18 + k];
         const int sfb = m & 31, win = (m >> 5) & 3;
         int e1, k2;
         if (m & 0x80) {
@@ -74,21 +66,19 @@ __global__ __launch_bounds__(DEC_A_WAVES * 64) void k_dec_imdct(
         const double sa = x < 0 ? -a : a;   // sign * a is exact
         v[k] = (sa * c_tab.pow2q[e1 - POW2Q_MIN]) * c_tab.pow2h[k2 < POW2H_N ? k2 : POW2H_N - 1];
     }
-
     // ---- MS stereo (Frame.py:568-572): L = (M + S) / sqrt2, R = (M - S) / sqrt2
-    if (fh.ms_stereo && nch == 2) {
+    if (ms && nch == 2) {
 #pragma unroll
         for (int k = 0; k < 18; k++) {
             const double o = shfl_xor_f64(v[k], 32);
             v[k] = ch == 0 ? (v[k] + o) / c_tab.sqrt2 : (o - v[k]) / c_tab.sqrt2;
         }
     }
-
     // ---- reorder (short / mixed) or alias reduction (long) through the wave's LDS slice
-    double *buf = lds[wave][ch];
+    __builtin_amdgcn_wave_barrier();
 #pragma unroll
     for (int k = 0; k < 18; k++) buf[sb * 18 + k] = v[k];
-    __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0): own wave's LDS writes landed (single-wave slice)
+    __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0): the wave's own LDS writes have landed
     __builtin_amdgcn_wave_barrier();
     if (cse != 0) {
         const int16_t *src = c_tab.reorder_src[sr];
@@ -112,57 +102,90 @@ __global__ __launch_bounds__(DEC_A_WAVES * 64) void k_dec_imdct(
             }
         }
     }
+    __builtin_amdgcn_s_waitcnt(0xc07f);
+}
 
-    // ---- IMDCT + window (Frame.py:124-148); frequency inversion (:629-631) folded into the sign
-    const long row = ((long)ch * 32 + sb) * Tp + (long)g * 18;
-    double *Hp = H + row, *Tp_ = TL + row;
+__global__ __launch_bounds__(DEC_A_WAVES * 64) void k_dec_imdct(
+    const int16_t *__restrict__ is, const mp3s_granule_si *__restrict__ si, const mp3s_frame_hdr *__restrict__ hdr,
+    int n_granules, int nch, double *__restrict__ S, long T)
+{
+    __shared__ double lds[DEC_A_WAVES][2][576];
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+    const int g0 = (blockIdx.x * DEC_A_WAVES + wave) * DEC_RUN;
+    if (g0 >= n_granules) return;  // whole wave exits together
+    const int ch = lane >> 5, sb = lane & 31;
+    const bool live = ch < nch;
+    double *buf = lds[wave][ch];
     const bool neg_odd = (sb & 1) != 0;
-    if (bt != 2) {
-        const double *win = c_tab.sine_block[bt];
-#pragma unroll 2
-        for (int i = 0; i < 36; i += 2) {
-            double x0 = 0.0, x1 = 0.0;
+    double tail[18];
 #pragma unroll
-            for (int k = 0; k < 18; k++) {
-                x0 += v[k] * c_tab.imdct_cos36[i][k];
-                x1 += v[k] * c_tab.imdct_cos36[i + 1][k];
-            }
-            x0 = x0 * win[i];
-            x1 = x1 * win[i + 1];
-            if (neg_odd) x1 = -x1;   // odd subband, odd slot
-            if (live) {
-                double2 o = make_double2(x0, x1);
-                if (i < 18) *reinterpret_cast<double2 *>(Hp + i) = o;
-                else *reinterpret_cast<double2 *>(Tp_ + i) = o;
-            }
+    for (int i = 0; i < 18; i++) tail[i] = 0.0;
+
+    // gi = -1 primes the overlap with the second half of granule g0-1 (when it belongs to the same stream)
+    for (int gi = -1; gi < DEC_RUN; gi++) {
+        const int g = g0 + gi;
+        if (g >= n_granules) break;
+        if (g < 0) continue;
+        const mp3s_frame_hdr fh = hdr[g >> 1];
+        const int first_gran = (int)fh.stream_first * 2;
+        if (gi < 0 && g0 <= first_gran) continue;          // the run starts a stream: nothing before it
+        if (gi >= 0 && g == first_gran) {
+#pragma unroll
+            for (int i = 0; i < 18; i++) tail[i] = 0.0;    // Frame.py:234 prev_samples starts as zeros
         }
-    } else {
-        double t[36];
+        const int sr = fh.sr_idx < 3 ? fh.sr_idx : 0;
+        double v[18];
+        int bt;
+        dec_prepare(v, buf, is, si, g, sr, fh.ms_stereo != 0, nch, ch, sb, live, bt);
+
+        // ---- IMDCT + window (Frame.py:124-148), overlap (:151-153), frequency inversion (:629-631) in the sign
+        double *row = S + ((long)(live ? ch : 0) * T + (long)g * 18) * 32 + sb;
+        if (bt != 2) {
+            const double *win = c_tab.sine_block[bt];
+            if (gi >= 0) {
+#pragma unroll 2
+                for (int i = 0; i < 18; i++) {
+                    double x = 0.0;
 #pragma unroll
-        for (int w = 0; w < 3; w++)
-#pragma unroll
-            for (int i = 0; i < 12; i++) {
+                    for (int k = 0; k < 18; k++) x += v[k] * c_tab.imdct_cos36[i][k];
+                    x = x * win[i] + tail[i];
+                    if (neg_odd && (i & 1)) x = -x;
+                    if (live) row[(long)i * 32] = x;
+                }
+            }
+#pragma unroll 2
+            for (int i = 18; i < 36; i++) {
                 double x = 0.0;
 #pragma unroll
-                for (int k = 0; k < 6; k++) x += v[6 * w + k] * c_tab.imdct_cos12[i][k];
-                t[w * 12 + i] = x * c_tab.sine_block[2][i];
+                for (int k = 0; k < 18; k++) x += v[k] * c_tab.imdct_cos36[i][k];
+                tail[i - 18] = x * win[i];
             }
-        double o[36];
+        } else {
+            double t[36];
 #pragma unroll
-        for (int i = 0; i < 6; i++) {
-            o[i] = 0.0;
-            o[6 + i] = t[i];
-            o[12 + i] = t[6 + i] + t[12 + i];
-            o[18 + i] = t[18 + i] + t[24 + i];
-            o[24 + i] = t[30 + i];
-            o[30 + i] = 0.0;
-        }
-        if (live) {
+            for (int w = 0; w < 3; w++)
 #pragma unroll
-            for (int i = 0; i < 36; i += 2) {
-                double2 w2 = make_double2(o[i], neg_odd ? -o[i + 1] : o[i + 1]);
-                if (i < 18) *reinterpret_cast<double2 *>(Hp + i) = w2;
-                else *reinterpret_cast<double2 *>(Tp_ + i) = w2;
+                for (int i = 0; i < 12; i++) {
+                    double x = 0.0;
+#pragma unroll
+                    for (int k = 0; k < 6; k++) x += v[6 * w + k] * c_tab.imdct_cos12[i][k];
+                    t[w * 12 + i] = x * c_tab.sine_block[2][i];
+                }
+            if (gi >= 0) {
+#pragma unroll
+                for (int i = 0; i < 18; i++) {
+                    // sample_block[0..5] = 0, [6..11] = t[0..5], [12..17] = t[6..11] + t[12..17]   (:136-142)
+                    const double blk = i < 6 ? 0.0 : (i < 12 ? t[i - 6] : t[i - 6] + t[i]);
+                    double x = blk + tail[i];
+                    if (neg_odd && (i & 1)) x = -x;
+                    if (live) row[(long)i * 32] = x;
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < 6; i++) {
+                tail[i] = t[18 + i] + t[24 + i];           // sample_block[18..23]
+                tail[6 + i] = t[30 + i];                   // sample_block[24..29]
+                tail[12 + i] = 0.0;                        // sample_block[30..35]
             }
         }
     }
@@ -180,45 +203,44 @@ __device__ __forceinline__ int16_t pcm_to_i16(double v)
 }
 
 template <int TW>
-__global__ __launch_bounds__(TW * 64 * 2) void k_dec_synth(
-    const double *__restrict__ H, const double *__restrict__ TL, long Tp, const mp3s_frame_hdr *__restrict__ hdr,
-    int n_frames, int nch, int n_halo, int out_format, void *__restrict__ pcm_out)
+__global__ __launch_bounds__(TW * 64 * 2, (TW * 2 * 2) / 4) void k_dec_synth(
+    const double *__restrict__ S, long T, const mp3s_frame_hdr *__restrict__ hdr, int nch, int n_halo, int out_format,
+    void *__restrict__ pcm_out)
 {
     constexpr int TL_LANES = TW * 64, OUT = TL_LANES - 15;
+    constexpr int OROW = 33;                                   // dwords per staged slot (32 + 1 pad: no bank conflicts)
     __shared__ double ex[2][2][2][TL_LANES];                   // [parity][ch][V half][lane]
-    __shared__ __attribute__((aligned(16))) int16_t otile[OUT * 32 * 2];
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    __shared__ uint32_t otile[OUT * OROW];
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
     const int ch = wave / TW, tl = (wave % TW) * 64 + lane;
-    const long T = (long)n_frames * 36;
     const long tile0 = (long)blockIdx.x * OUT;
     const long t = tile0 - 15 + tl;
     const bool valid = t >= 0 && t < T;
     int lim = -1;            // number of earlier in-stream slots (V history available), -1: slot not valid
-    bool has_tail = false;
     if (valid) {
         const long s0 = (long)hdr[t / 36].stream_first * 36;
         lim = (int)((t - s0) < 64 ? (t - s0) : 64);
-        has_tail = (t / 18) > (s0 / 18);
     }
-    double S[32];
+    double Sv[32];
     {
-        const double *hp = H + (long)ch * 32 * Tp + t, *tp = TL + (long)ch * 32 * Tp + t;
+        const double2 *sp = reinterpret_cast<const double2 *>(S + ((long)ch * T + (valid ? t : 0)) * 32);
 #pragma unroll
-        for (int j = 0; j < 32; j++) {
-            double h = 0.0, tv = 0.0;
-            if (valid) { h = hp[(long)j * Tp]; if (has_tail) tv = tp[(long)j * Tp]; }
-            S[j] = h + tv;   // Frame.py:152  sample_block[i] + prev_samples[ch][block][i]
+        for (int j = 0; j < 16; j++) {
+            double2 q = make_double2(0.0, 0.0);
+            if (valid) q = sp[j];
+            Sv[2 * j] = q.x; Sv[2 * j + 1] = q.y;
         }
     }
     const long halo_slots = (long)n_halo * 36;
     const bool emit = valid && tl >= 15 && t >= halo_slots;
+    uint16_t *ot16 = reinterpret_cast<uint16_t *>(otile);
     int p = 0;
     for (int i = 0; i < 32; i++) {
         double a0 = 0.0, a1 = 0.0;
 #pragma unroll
         for (int j = 0; j < 32; j++) {           // Frame.py:84-87
-            a0 += S[j] * c_tab.synth_matrix[i][j];
-            a1 += S[j] * c_tab.synth_matrix[32 + i][j];
+            a0 += Sv[j] * c_tab.synth_matrix[i][j];
+            a1 += Sv[j] * c_tab.synth_matrix[32 + i][j];
         }
         ex[p][ch][0][tl] = a0;
         ex[p][ch][1][tl] = a1;
@@ -233,7 +255,7 @@ __global__ __launch_bounds__(TW * 64 * 2) void k_dec_synth(
             }
             if (emit) {
                 const long to = t - halo_slots;
-                if (out_format == MP3S_PCM_I16) otile[((tl - 15) * 32 + i) * nch + ch] = pcm_to_i16(sum);
+                if (out_format == MP3S_PCM_I16) ot16[(tl - 15) * OROW * 2 + i * nch + ch] = (uint16_t)pcm_to_i16(sum);
                 else if (out_format == MP3S_PCM_F64) ((double *)pcm_out)[(to * 32 + i) * nch + ch] = sum;
                 else ((float *)pcm_out)[(to * 32 + i) * nch + ch] = (float)sum;
             }
@@ -242,14 +264,14 @@ __global__ __launch_bounds__(TW * 64 * 2) void k_dec_synth(
     }
     if (out_format == MP3S_PCM_I16) {
         __syncthreads();
-        const int chunks_per_slot = (32 * nch * 2) / 16;      // 16-byte chunks per slot
-        const int n_chunks = OUT * chunks_per_slot;
-        int16_t *outp = (int16_t *)pcm_out;
-        for (int c = threadIdx.x; c < n_chunks; c += blockDim.x) {
-            const long slot = tile0 + c / chunks_per_slot;
+        const int dw_per_slot = 16 * nch;                      // 32 samples * nch * 2 bytes / 4
+        const int n_dw = OUT * dw_per_slot;
+        uint32_t *outp = (uint32_t *)pcm_out;
+        for (int c = threadIdx.x; c < n_dw; c += blockDim.x) {
+            const int sl = c / dw_per_slot, w = c - sl * dw_per_slot;
+            const long slot = tile0 + sl;
             if (slot < halo_slots || slot >= T) continue;
-            const uint4 val = reinterpret_cast<const uint4 *>(otile)[c];
-            reinterpret_cast<uint4 *>(outp + (slot - halo_slots) * 32 * nch)[c % chunks_per_slot] = val;
+            outp[(slot - halo_slots) * dw_per_slot + w] = otile[sl * OROW + w];
         }
     }
 }

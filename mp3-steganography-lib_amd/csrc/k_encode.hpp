@@ -19,12 +19,12 @@ namespace mp3s {
 constexpr int ENC_ROW = 40;   // int16 per LDS row: 32 samples + 8 pad (80-byte stride)
 
 // SB layout: int32 [ch][32 bands][Ts] with Ts = n_frames * 36 slots
-__global__ __launch_bounds__(256) void k_enc_analysis(
+__global__ __launch_bounds__(256, 3) void k_enc_analysis(
     const int16_t *__restrict__ pcm, const mp3s_frame_hdr *__restrict__ hdr, int n_frames,
     int32_t *__restrict__ SB, long Ts)
 {
     __shared__ __attribute__((aligned(16))) int16_t tile[4][79 * ENC_ROW];
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
     const long wid = (long)blockIdx.x * 4 + wave;
     const int ch = (int)(wid & 1);
     const long t0 = (wid >> 1) * 64;          // first slot of this wave
@@ -45,11 +45,14 @@ __global__ __launch_bounds__(256) void k_enc_analysis(
     long s0 = 0;
     if (valid) s0 = (long)hdr[t / 36].stream_first * 36;
 
+    // ---- y[i] = sum_k mul(x[(off + i + 64k) & 511], enwindow[i + 64k])   (MP3_Encoder.py:336-354)
+    // sample 32t+31-m sits `m>>5` rows back at column 31-(m&31); one k step = rows 2k and 2k+1 back
     int32_t y[64];
 #pragma unroll
     for (int i = 0; i < 64; i++) y[i] = 0;
-#pragma unroll
+#pragma unroll 1
     for (int k = 0; k < 8; k++) {
+        const int32_t *ew = c_tab.enwindow + 64 * k;
 #pragma unroll
         for (int h = 0; h < 2; h++) {
             const int back = 2 * k + h;                  // rows back from the lane's own row
@@ -65,21 +68,34 @@ __global__ __launch_bounds__(256) void k_enc_analysis(
                     const int col_lo = cb * 8 + 2 * e, col_hi = col_lo + 1;
                     const int i_lo = h * 32 + 31 - col_lo, i_hi = h * 32 + 31 - col_hi;
                     const int32_t x_lo = (int32_t)(d[e] << 16), x_hi = (int32_t)(d[e] & 0xffff0000u);
-                    y[i_lo] += __mulhi(x_lo, c_tab.enwindow[i_lo + 64 * k]);
-                    y[i_hi] += __mulhi(x_hi, c_tab.enwindow[i_hi + 64 * k]);
+                    y[i_lo] += __mulhi(x_lo, ew[i_lo]);
+                    y[i_hi] += __mulhi(x_hi, ew[i_hi]);
                 }
+                __builtin_amdgcn_sched_barrier(0);
             }
         }
     }
     if (!valid) return;
+    // ---- s[sb] = sum_j mul(fl[sb][j], y[j])   (MP3_Encoder.py:358-368); four bands per pass for ILP
     const bool odd_slot = (t & 1) != 0;      // slot-in-granule parity == slot parity (18 is even)
     int32_t *out = SB + (long)ch * 32 * Ts + t;
-    for (int sb = 0; sb < 32; sb++) {
-        int32_t acc = 0;
+#pragma unroll 1
+    for (int sb = 0; sb < 32; sb += 4) {
+        int32_t a0 = 0, a1 = 0, a2 = 0, a3 = 0;
+        const int32_t *f0 = c_tab.fl[sb], *f1 = c_tab.fl[sb + 1], *f2 = c_tab.fl[sb + 2], *f3 = c_tab.fl[sb + 3];
 #pragma unroll
-        for (int j = 0; j < 64; j++) acc += __mulhi(c_tab.fl[sb][j], y[j]);
-        if (odd_slot && (sb & 1)) acc = (int32_t)(0u - (uint32_t)acc);
-        out[(long)sb * Ts] = acc;
+        for (int j = 0; j < 64; j++) {
+            a0 += __mulhi(f0[j], y[j]);
+            a1 += __mulhi(f1[j], y[j]);
+            a2 += __mulhi(f2[j], y[j]);
+            a3 += __mulhi(f3[j], y[j]);
+            if ((j & 7) == 7) __builtin_amdgcn_sched_barrier(0);   // keep the scheduler from hoisting all 256 products
+        }
+        if (odd_slot) { a1 = (int32_t)(0u - (uint32_t)a1); a3 = (int32_t)(0u - (uint32_t)a3); }   // odd bands
+        out[(long)sb * Ts] = a0;
+        out[(long)(sb + 1) * Ts] = a1;
+        out[(long)(sb + 2) * Ts] = a2;
+        out[(long)(sb + 3) * Ts] = a3;
     }
 }
 
@@ -88,7 +104,7 @@ __global__ __launch_bounds__(256) void k_enc_mdct(
     const int32_t *__restrict__ SB, long Ts, const mp3s_frame_hdr *__restrict__ hdr, int n_granules,
     int32_t *__restrict__ mdct)
 {
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
     const int g = blockIdx.x * 4 + wave;
     if (g >= n_granules) return;
     const int ch = lane >> 5, band = lane & 31;

@@ -45,7 +45,15 @@ struct RlTables {
     uint16_t int2idx[10000];
     uint8_t hlen[4][256];   // 13, 15, 16-family, 24-family
     uint8_t c1a[16];
+    uint8_t transform[64];  // [table][bit]
+    uint32_t subdiv[289];   // __subdivide result per big_values for this workgroup's sample rate (see DevTables)
 };
+
+// linbits of table t (encoder/tables.py:287-302) without a memory lookup: nibble k of the packed constants
+__device__ __forceinline__ int lin_bits_of(int t)
+{
+    return t < 16 ? 0 : (int)(((t < 24 ? 0xDA864321u : 0xDB987654u) >> (4 * (t & 7))) & 15u);
+}
 
 struct RlState {           // wave-uniform GrInfo fields that live across rate_body calls
     int big_values, count1, c1sel, r0c, r1c, a1, a2, a3, ts0, ts1, ts2;
@@ -59,7 +67,7 @@ __device__ __forceinline__ uint32_t pair_bits(const RlTables &tb, int t, int x, 
 {
     const int xx = x > 14 ? 15 : x, yy = y > 14 ? 15 : y;
     uint32_t b = tb.hlen[family_of(t)][xx * 16 + yy] + (x != 0) + (y != 0);
-    if (t > 15) b += c_tab.linbits[t] * ((x > 14) + (y > 14));
+    if (t > 15) b += lin_bits_of(t) * ((x > 14) + (y > 14));
     return b;
 }
 
@@ -68,7 +76,7 @@ __device__ __forceinline__ uint32_t pair_bits(const RlTables &tb, int t, int x, 
 __device__ __forceinline__ int rl_quantize(const RlTables &tb, const uint32_t (&xa)[2 * RL_NP], int32_t (&ix)[2 * RL_NP],
                                            int step, uint32_t xrmax)
 {
-    const int idx = step + 127;
+    const int idx = __builtin_amdgcn_readfirstlane(step + 127);
     if (idx < 0 || idx > 127) return -1;
     const uint32_t scalei = (uint32_t)c_tab.steptabi[idx];
     if (mulr_u(xrmax, scalei) > 165140u) return 16384;
@@ -134,16 +142,10 @@ __device__ __forceinline__ int rl_body(const RlTables &tb, uint8_t *pcode, const
         st.r0c = 0; st.r1c = 0;
         if (!st.addr_fresh) st.used_addr_in = true;
     } else {
-        const int32_t *sfb = c_tab.sfb_long[sr];
-        int anz = 0;
-        while (sfb[anz] < bvr) anz++;
-        int tc = c_tab.subdv[anz][0];
-        while (tc > 0) { if (sfb[tc + 1] <= bvr) break; tc--; }
-        st.r0c = tc; st.a1 = sfb[tc + 1];
-        const int base = tc + 1;
-        tc = c_tab.subdv[anz][1];
-        while (tc > 0) { if (sfb[base + tc + 1] <= bvr) break; tc--; }
-        st.r1c = tc; st.a2 = sfb[base + tc + 1];
+        // __subdivide (:1008-1036) depends on big_values only: looked up in the per-rate table built on the host
+        const uint32_t e = tb.subdiv[bv < 289 ? bv : 288];
+        st.r0c = (int)(e & 15); st.r1c = (int)((e >> 4) & 7);
+        st.a1 = (int)((e >> 8) & 1023); st.a2 = (int)((e >> 18) & 1023);
         st.a3 = bvr;
         st.addr_fresh = true;
     }
@@ -174,11 +176,12 @@ __device__ __forceinline__ int rl_body(const RlTables &tb, uint8_t *pcode, const
             // reference :1190-1193 scans tables 13..0 for x_len > ix_max; table 13 (x_len 16) always hits first
             tA[r] = 13; tB[r] = 15;
         } else {
+            // first table of each family whose linmax = 2^linbits - 1 covers ix_max - 15 (:1237-1246);
+            // linbits are {1,2,3,4,6,8,10,13} for 16..23 and {4,5,6,7,8,9,11,13} for 24..31, table 15 has none
             const int need = mxr - 15;
-            int c0 = 15, c1 = 24;
-            while (c0 < 23 && c_tab.linmax[c0] < need) c0++;
-            while (c1 < 31 && c_tab.linmax[c1] < need) c1++;
-            tA[r] = c0; tB[r] = c1;
+            const int nb = need ? 32 - __builtin_clz((unsigned)need) : 0;   // bits of need
+            tA[r] = need == 0 ? 15 : 16 + (nb > 1) + (nb > 2) + (nb > 3) + (nb > 4) + (nb > 6) + (nb > 8) + (nb > 10);
+            tB[r] = 24 + (nb > 4) + (nb > 5) + (nb > 6) + (nb > 7) + (nb > 8) + (nb > 9) + (nb > 11);
         }
     }
     uint32_t w[3] = {0, 0, 0};
@@ -207,7 +210,7 @@ __device__ __forceinline__ int rl_body(const RlTables &tb, uint8_t *pcode, const
             int choice;
             if (tA[r] == 13) choice = (bB <= bA) ? 15 : 13;     // :1227-1231 ties -> 15
             else choice = (bB < bA) ? tB[r] : tA[r];            // :1254
-            if (n_hide > 0 && idx < n_hide) choice = c_tab.transform[choice][hide[idx] & 1];   // :1257-1263
+            if (n_hide > 0 && idx < n_hide) choice = tb.transform[choice * 2 + (hide[idx] & 1)];   // :1257-1263
             ts[r] = choice;
             if (choice == tA[r]) rbits[r] = bA;
             else if (choice == tB[r]) rbits[r] = bB;
@@ -241,23 +244,27 @@ __global__ __launch_bounds__(RL_WAVES * 64) void k_rate_loop(
     __shared__ RlTables tb;
     __shared__ uint8_t pcode_all[RL_WAVES][64 * RL_NP + 4];
     __shared__ int32_t esq_all[RL_WAVES][576];
+    const int sr0 = frames[0].sr_idx;             // one sample rate per launch (the host splits batches otherwise)
+    const int sr_wg = sr0 >= 0 && sr0 < 3 ? sr0 : 0;
     for (int i = threadIdx.x; i < 10000; i += blockDim.x) tb.int2idx[i] = c_tab.int2idx[i];
     for (int i = threadIdx.x; i < 256; i += blockDim.x) {
         tb.hlen[0][i] = c_tab.hlen13[i]; tb.hlen[1][i] = c_tab.hlen15[i];
         tb.hlen[2][i] = c_tab.hlen16[i]; tb.hlen[3][i] = c_tab.hlen24[i];
     }
     if (threadIdx.x < 16) tb.c1a[threadIdx.x] = c_tab.hlen_c1a[threadIdx.x];
+    if (threadIdx.x < 64) tb.transform[threadIdx.x] = c_tab.transform[threadIdx.x >> 1][threadIdx.x & 1];
+    for (int i = threadIdx.x; i < 289; i += blockDim.x) tb.subdiv[i] = c_tab.subdiv_lut[sr_wg][i];
     __syncthreads();
 
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
     const int li = blockIdx.x * RL_WAVES + wave;
     if (li >= n_list) return;
-    const int u = unit_list ? unit_list[li] : li;
+    const int u = __builtin_amdgcn_readfirstlane(unit_list ? unit_list[li] : li);
     if (u < 0 || u >= n_units) return;
     uint8_t *pcode = pcode_all[wave];
     int32_t *esq = esq_all[wave];
     const mp3s_rate_frame fr = frames[u >> 2];
-    const int sr = fr.sr_idx >= 0 && fr.sr_idx < 3 ? fr.sr_idx : 0;
+    const int sr = sr_wg;
     const int max_bits = fr.max_bits;
     const int cursor = (n_hide > 0 && cursor_in) ? cursor_in[u] : 0;
 

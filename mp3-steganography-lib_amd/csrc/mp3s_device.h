@@ -27,7 +27,7 @@ struct Profiler {
 
 int dev_upload_tables(hipStream_t stream);
 
-// scratch: H and TL planes, 2 * nch * 32 * (36 n + 18) doubles
+// scratch: time-domain subband samples, float64 [nch][36 n][32]
 size_t dec_scratch_bytes(int n_frames, int nch);
 int launch_decode(hipStream_t stream, const int16_t *d_is, const mp3s_granule_si *d_si, const mp3s_frame_hdr *d_hdr,
                   int n_frames, int nch, int n_halo, int out_format, void *d_pcm, void *d_scratch, Profiler *prof);

@@ -43,28 +43,26 @@ int dev_upload_tables(hipStream_t stream)
 
 size_t dec_scratch_bytes(int n_frames, int nch)
 {
-    const size_t Tp = (size_t)n_frames * 36 + 18;
-    return 2 * (size_t)nch * 32 * Tp * sizeof(double);
+    return (size_t)nch * (size_t)n_frames * 36 * 32 * sizeof(double);
 }
 
 int launch_decode(hipStream_t stream, const int16_t *d_is, const mp3s_granule_si *d_si, const mp3s_frame_hdr *d_hdr,
                   int n_frames, int nch, int n_halo, int out_format, void *d_pcm, void *d_scratch, Profiler *prof)
 {
-    const long Tp = (long)n_frames * 36 + 18;
-    double *H = (double *)d_scratch;
-    double *TL = H + (size_t)nch * 32 * Tp;
+    const long T = (long)n_frames * 36;
+    double *S = (double *)d_scratch;
     const int n_gran = n_frames * 2;
+    const int runs = (n_gran + DEC_RUN - 1) / DEC_RUN;
     int pp = prof ? prof->begin(stream, K_DEC_IMDCT) : -1;
-    hipLaunchKernelGGL(k_dec_imdct, dim3((n_gran + DEC_A_WAVES - 1) / DEC_A_WAVES), dim3(DEC_A_WAVES * 64), 0, stream,
-                       d_is, d_si, d_hdr, n_gran, nch, H, TL, Tp);
+    hipLaunchKernelGGL(k_dec_imdct, dim3((runs + DEC_A_WAVES - 1) / DEC_A_WAVES), dim3(DEC_A_WAVES * 64), 0, stream,
+                       d_is, d_si, d_hdr, n_gran, nch, S, T);
     if (prof) prof->end(stream, pp);
     constexpr int TW = DEC_SYNTH_TW;
-    const long T = (long)n_frames * 36;
     const int out_per_tile = TW * 64 - 15;
     const int tiles = (int)((T + out_per_tile - 1) / out_per_tile);
     pp = prof ? prof->begin(stream, K_DEC_SYNTH) : -1;
-    hipLaunchKernelGGL(k_dec_synth<TW>, dim3(tiles), dim3(TW * 64 * nch), 0, stream, (const double *)H,
-                       (const double *)TL, Tp, d_hdr, n_frames, nch, n_halo, out_format, d_pcm);
+    hipLaunchKernelGGL(k_dec_synth<TW>, dim3(tiles), dim3(TW * 64 * nch), 0, stream, (const double *)S, T, d_hdr, nch,
+                       n_halo, out_format, d_pcm);
     if (prof) prof->end(stream, pp);
     return (int)hipGetLastError();
 }

@@ -131,6 +131,21 @@ void build()
         for (int i = 0; i < 23; i++) T.sfb_long[sr][i] = kSfbLong[sr][i];
         for (int i = 0; i < 12; i++) H.sfb_short_width[sr][i] = kSfbShortW[sr][i];
     }
+    // __subdivide as a function of big_values (reference MP3_Encoder.py:1008-1036, flattened index walk included)
+    for (int sr = 0; sr < 3; sr++)
+        for (int bv = 1; bv <= 288; bv++) {
+            const int *sfb = kSfbLong[sr];
+            const int bvr = 2 * bv;
+            int anz = 0;
+            while (sfb[anz] < bvr) anz++;
+            int tc = kSubdv[anz][0];
+            while (tc > 0) { if (sfb[tc + 1] <= bvr) break; tc--; }
+            const int r0c = tc, a1 = sfb[tc + 1], base = tc + 1;
+            tc = kSubdv[anz][1];
+            while (tc > 0) { if (sfb[base + tc + 1] <= bvr) break; tc--; }
+            const int r1c = tc, a2 = sfb[base + tc + 1];
+            T.subdiv_lut[sr][bv] = (uint32_t)r0c | ((uint32_t)r1c << 4) | ((uint32_t)a1 << 8) | ((uint32_t)a2 << 18);
+        }
     for (int i = 0; i < 21; i++) T.pre_tab[i] = (uint8_t)kPreTab[i];
     std::memcpy(H.slen, kSlen, sizeof kSlen);
     std::memcpy(T.subdv, kSubdv, sizeof kSubdv);

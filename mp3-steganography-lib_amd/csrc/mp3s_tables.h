@@ -39,6 +39,7 @@ struct DevTables {
     uint16_t int2idx[10000];       // values <= 1000
     int32_t sfb_long[3][23];
     int32_t subdv[23][2];
+    uint32_t subdiv_lut[3][289];   // [sr][big_values] -> r0c | r1c<<4 | address1<<8 | address2<<18 (MP3_Encoder.py:998-1036)
     uint8_t hlen13[256], hlen15[256], hlen16[256], hlen24[256];
     uint8_t hlen_c1a[16];
     uint8_t linbits[32];

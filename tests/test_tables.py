@@ -23,6 +23,26 @@ def test_product_tables_match_reference(mlib, golden_dir):
     assert np.array_equal(t["int2idx"].astype(np.int32), g["enc_int2idx"])
     assert np.array_equal(t["mdct_cs"], g["mdct_cs"]) and np.array_equal(t["mdct_ca"], g["mdct_ca"])
     assert np.array_equal(t["subdv"], g["subdv_table"])
+    # __subdivide (MP3_Encoder.py:998-1036) tabulated per big_values, against a literal evaluation on the
+    # reference's own (flattened) scale_fact_band_index and subdv_table
+    flat = g["enc_sfb_index"].flatten()
+    for sr in range(3):
+        for bv in range(1, 289):
+            tab = flat[sr * 23:]
+            bvr = 2 * bv
+            anz = 0
+            while tab[anz] < bvr:
+                anz += 1
+            tc = int(g["subdv_table"][anz][0])
+            while tc > 0 and not tab[tc + 1] <= bvr:
+                tc -= 1
+            r0c, a1 = tc, int(tab[tc + 1])
+            tab2 = tab[tc + 1:]
+            tc = int(g["subdv_table"][anz][1])
+            while tc > 0 and not tab2[tc + 1] <= bvr:
+                tc -= 1
+            r1c, a2 = tc, int(tab2[tc + 1])
+            assert int(t["subdiv_lut"][sr][bv]) == r0c | (r1c << 4) | (a1 << 8) | (a2 << 18), (sr, bv)
     assert np.array_equal(t["sfb_long"], g["enc_sfb_index"][:3])
     for sr, key in enumerate(("44", "48", "32")):
         assert np.array_equal(t["sfb_long"][sr], g[f"bi_long_{key}"])
