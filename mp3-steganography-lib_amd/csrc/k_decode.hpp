@@ -2,7 +2,7 @@
 //
 //   k_dec_imdct : requantise -> MS stereo -> reorder | alias reduction -> IMDCT + window + overlap-add
 //                 (reference decoder/Frame.py:157-218, 561-622, 106-154; frequency inversion :624-631
-//                 is folded into the stores).  One wavefront walks DEC_RUN consecutive granules, lane =
+//                 is folded into the stores).  One wavefront walks `run` consecutive granules, lane =
 //                 (channel, subband): the 18 lines of a subband and the 18-sample overlap tail live in
 //                 one lane's registers, the IMDCT twiddle of a given (output, term) is the same for every
 //                 lane, so it is a scalar (SGPR) operand fetched through the scalar cache -- no LDS
@@ -32,56 +32,77 @@ __device__ __forceinline__ double shfl_xor_f64(double v, int mask)
 // A wave stores one 256-byte row per channel per slot: fully coalesced.
 // ---------------------------------------------------------------------------------------------
 constexpr int DEC_A_WAVES = 4;
-constexpr int DEC_RUN = 4;     // granules per wave (+1 priming granule whose second half only is computed)
+
+struct DecShared {
+    double pow2q[POW2Q_N];                 // copies of the small exponent tables: random per-lane reads go to LDS
+    double pow2h[POW2H_N];
+    double buf[DEC_A_WAVES][2][576];       // per wave: spectrum exchange for reorder / alias reduction
+    uint32_t side[DEC_A_WAVES][2][18];     // per wave: the two 72-byte side records of the current granule
+};
 
 // requantise .. alias/reorder of granule g for this lane's subband; v[18] = IMDCT input
-__device__ __forceinline__ void dec_prepare(double (&v)[18], double *buf, const int16_t *__restrict__ is,
-                                            const mp3s_granule_si *__restrict__ si, int g, int sr, bool ms, int nch,
-                                            int ch, int sb, bool live, int &bt_out)
+__device__ __forceinline__ void dec_prepare(const DevTables &tab, DecShared &sh, int wave, double (&v)[18],
+                                            const int16_t *__restrict__ is, const mp3s_granule_si *__restrict__ si, int g,
+                                            int sr, bool ms, int nch, int lane, int &bt_out)
 {
-    const mp3s_granule_si *gs = &si[(long)g * 2 + (live ? ch : 0)];
-    const int gg = gs->global_gain, bt = gs->block_type & 3, mixed = gs->mixed_block_flag ? 1 : 0;
-    const int mult2 = gs->scalefac_scale ? 2 : 1, preflag = gs->preflag ? 1 : 0;
+    const int ch = lane >> 5, sb = lane & 31;
+    const bool live = ch < nch;
+    // ---- side records of both channels -> LDS (36 dwords), then byte reads from there
+    __builtin_amdgcn_wave_barrier();
+    if (lane < 36) (&sh.side[wave][0][0])[lane] = reinterpret_cast<const uint32_t *>(si + (long)g * 2)[lane];
+    __builtin_amdgcn_s_waitcnt(0xc07f);
+    __builtin_amdgcn_wave_barrier();
+    const uint8_t *gb = reinterpret_cast<const uint8_t *>(sh.side[wave][live ? ch : 0]);
+    const int gg = gb[0], bt = gb[2] & 3, mixed = gb[3] ? 1 : 0;
+    const int mult2 = gb[1] ? 2 : 1, preflag = gb[4] ? 1 : 0;
     const int cse = bt == 2 ? 1 : (mixed ? 2 : 0);
-    const uint8_t *map = c_tab.rq_map[sr][cse];
     bt_out = bt;
+    // ---- 18 int16 spectrum values (9 dwords) and 18 line-map bytes (5 dwords) of this subband
+    uint32_t xw[9], mw[5];
+    {
+        const uint32_t *xp = reinterpret_cast<const uint32_t *>(is + ((long)g * 2 + (live ? ch : 0)) * 576 + sb * 18);
+#pragma unroll
+        for (int k = 0; k < 9; k++) xw[k] = live ? xp[k] : 0u;
+        const uint32_t *mp = reinterpret_cast<const uint32_t *>(tab.rq_map[sr][cse][sb]);
+#pragma unroll
+        for (int k = 0; k < 5; k++) mw[k] = mp[k];
+    }
     // ---- requantise (Frame.py:210-215): ((sign * |is|^(4/3)) * 2^(exp1/4)) * 2^(-exp2)
-    const int16_t *isp = is + ((long)g * 2 + (live ? ch : 0)) * 576 + sb * 18;
 #pragma unroll
     for (int k = 0; k < 18; k++) {
-        const int x = live ? (int)isp[k] : 0;
-        const int m = map[sb * 18 + k];
+        const int x = (int)(int16_t)(xw[k >> 1] >> ((k & 1) * 16));
+        const int m = (int)((mw[k >> 2] >> ((k & 3) * 8)) & 0xff);
         const int sfb = m & 31, win = (m >> 5) & 3;
-        int e1, k2;
-        if (m & 0x80) {
-            e1 = gg - 210 - 8 * (gs->sub_block_gain[win] & 7);
-            k2 = mult2 * (gs->scale_fac_s[win][sfb < 13 ? sfb : 12] & 15);
-        } else {
-            e1 = gg - 210;
-            k2 = mult2 * ((gs->scale_fac_l[sfb < 22 ? sfb : 21] & 15) + preflag * c_tab.pre_tab[sfb]);
-        }
+        const bool shp = (m & 0x80) != 0;
+        // short path: exp1 = gg-210-8*sbg[win], exp2 = mult*sf_s[win][sfb]; long: exp1 = gg-210,
+        // exp2 = mult*(sf_l[sfb] + preflag*pretab[sfb])
+        const int sf = gb[shp ? 30 + win * 13 + (sfb < 13 ? sfb : 12) : 8 + (sfb < 22 ? sfb : 21)] & 15;
+        const int e1 = gg - 210 - (shp ? 8 * (gb[5 + win] & 7) : 0);
+        const int pt = sfb < 11 ? 0 : (int)((0x2333221111ull >> ((sfb - 11) * 4)) & 15);   // pre_tab[11..20] = 1,1,1,1,2,2,3,3,3,2
+        int k2 = mult2 * (sf + (shp ? 0 : preflag * (sfb < 21 ? pt : 0)));
+        k2 = k2 < POW2H_N ? k2 : POW2H_N - 1;
         int ax = x < 0 ? -x : x;
         ax = ax < POW43_N ? ax : POW43_N - 1;
-        const double a = c_tab.pow43[ax];
+        const double a = tab.pow43[ax];
         const double sa = x < 0 ? -a : a;   // sign * a is exact
-        v[k] = (sa * c_tab.pow2q[e1 - POW2Q_MIN]) * c_tab.pow2h[k2 < POW2H_N ? k2 : POW2H_N - 1];
+        v[k] = (sa * sh.pow2q[e1 - POW2Q_MIN]) * sh.pow2h[k2];
     }
     // ---- MS stereo (Frame.py:568-572): L = (M + S) / sqrt2, R = (M - S) / sqrt2
     if (ms && nch == 2) {
 #pragma unroll
         for (int k = 0; k < 18; k++) {
             const double o = shfl_xor_f64(v[k], 32);
-            v[k] = ch == 0 ? (v[k] + o) / c_tab.sqrt2 : (o - v[k]) / c_tab.sqrt2;
+            v[k] = ch == 0 ? (v[k] + o) / tab.sqrt2 : (o - v[k]) / tab.sqrt2;
         }
     }
     // ---- reorder (short / mixed) or alias reduction (long) through the wave's LDS slice
-    __builtin_amdgcn_wave_barrier();
+    double *buf = sh.buf[wave][ch];
 #pragma unroll
     for (int k = 0; k < 18; k++) buf[sb * 18 + k] = v[k];
     __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0): the wave's own LDS writes have landed
     __builtin_amdgcn_wave_barrier();
     if (cse != 0) {
-        const int16_t *src = c_tab.reorder_src[sr];
+        const int16_t *src = tab.reorder_src[sr];
 #pragma unroll
         for (int k = 0; k < 18; k++) {
             const int s = src[sb * 18 + k];
@@ -90,39 +111,40 @@ __device__ __forceinline__ void dec_prepare(double (&v)[18], double *buf, const 
     } else {
 #pragma unroll
         for (int i = 0; i < 8; i++) {
-            // lower line of the butterfly with subband sb-1:  s2*cs + s1*ca   (Frame.py:622)
-            if (sb >= 1) {
-                const double s1 = buf[18 * sb - 1 - i], s2 = v[i];
-                v[i] = s2 * c_tab.alias_cs[i] + s1 * c_tab.alias_ca[i];
-            }
-            // upper line of the butterfly with subband sb+1:  s1*cs - s2*ca   (Frame.py:621)
-            if (sb <= 30) {
-                const double s1 = v[17 - i], s2 = buf[18 * (sb + 1) + i];
-                v[17 - i] = s1 * c_tab.alias_cs[i] - s2 * c_tab.alias_ca[i];
-            }
+            // butterfly with subband sb-1 (lower line, Frame.py:622: s2*cs + s1*ca) and with subband sb+1 (upper line,
+            // :621: s1*cs - s2*ca); branch-free: every lane evaluates both and the edge subbands keep their value
+            const int ilo = 18 * sb - 1 - i, ihi = 18 * (sb + 1) + i;
+            const double nlo = buf[ilo < 0 ? 0 : ilo], nhi = buf[ihi > 575 ? 575 : ihi];
+            const double cs = tab.alias_cs[i], ca = tab.alias_ca[i];
+            const double lo = v[i] * cs + nlo * ca;
+            const double hi = v[17 - i] * cs - nhi * ca;
+            v[i] = sb >= 1 ? lo : v[i];
+            v[17 - i] = sb <= 30 ? hi : v[17 - i];
         }
     }
     __builtin_amdgcn_s_waitcnt(0xc07f);
 }
 
-__global__ __launch_bounds__(DEC_A_WAVES * 64) void k_dec_imdct(
+__global__ __launch_bounds__(DEC_A_WAVES * 64, 3) void k_dec_imdct(
     const int16_t *__restrict__ is, const mp3s_granule_si *__restrict__ si, const mp3s_frame_hdr *__restrict__ hdr,
-    int n_granules, int nch, double *__restrict__ S, long T)
+    int n_granules, int nch, int run, double *__restrict__ S, long T)
 {
-    __shared__ double lds[DEC_A_WAVES][2][576];
+    __shared__ DecShared sh;
+    for (int i = threadIdx.x; i < POW2Q_N; i += blockDim.x) sh.pow2q[i] = c_tab.pow2q[i];
+    if (threadIdx.x < POW2H_N) sh.pow2h[threadIdx.x] = c_tab.pow2h[threadIdx.x];
+    __syncthreads();
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
-    const int g0 = (blockIdx.x * DEC_A_WAVES + wave) * DEC_RUN;
+    const int g0 = (blockIdx.x * DEC_A_WAVES + wave) * run;
     if (g0 >= n_granules) return;  // whole wave exits together
     const int ch = lane >> 5, sb = lane & 31;
     const bool live = ch < nch;
-    double *buf = lds[wave][ch];
     const bool neg_odd = (sb & 1) != 0;
     double tail[18];
 #pragma unroll
     for (int i = 0; i < 18; i++) tail[i] = 0.0;
 
     // gi = -1 primes the overlap with the second half of granule g0-1 (when it belongs to the same stream)
-    for (int gi = -1; gi < DEC_RUN; gi++) {
+    for (int gi = -1; gi < run; gi++) {
         const int g = g0 + gi;
         if (g >= n_granules) break;
         if (g < 0) continue;
@@ -134,59 +156,81 @@ __global__ __launch_bounds__(DEC_A_WAVES * 64) void k_dec_imdct(
             for (int i = 0; i < 18; i++) tail[i] = 0.0;    // Frame.py:234 prev_samples starts as zeros
         }
         const int sr = fh.sr_idx < 3 ? fh.sr_idx : 0;
+        // The twiddle tables are invariant over this loop; left alone, LICM hoists all 648 scalar loads out of it
+        // and spills the SGPRs.  An opaque zero offset per iteration keeps them streaming through the scalar cache.
+        int zoff = 0;
+        asm volatile("" : "+s"(zoff));
+        const DevTables &tab = *reinterpret_cast<const DevTables *>(reinterpret_cast<const char *>(&c_tab) + zoff);
+        const double(*C36)[18] = tab.imdct_cos36;
+        const double(*C12)[6] = tab.imdct_cos12;
         double v[18];
         int bt;
-        dec_prepare(v, buf, is, si, g, sr, fh.ms_stereo != 0, nch, ch, sb, live, bt);
+        dec_prepare(tab, sh, wave, v, is, si, g, sr, fh.ms_stereo != 0, nch, lane, bt);
+        // window rows of the two channel halves as scalar pointers; lanes pick theirs with a select
+        const int bt0 = __builtin_amdgcn_readlane(bt, 0), bt1 = __builtin_amdgcn_readlane(bt, 32);
+        const double *win0 = tab.sine_block[bt0], *win1 = tab.sine_block[bt1];
 
         // ---- IMDCT + window (Frame.py:124-148), overlap (:151-153), frequency inversion (:629-631) in the sign
         double *row = S + ((long)(live ? ch : 0) * T + (long)g * 18) * 32 + sb;
         if (bt != 2) {
-            const double *win = c_tab.sine_block[bt];
             if (gi >= 0) {
-#pragma unroll 2
+#pragma unroll
                 for (int i = 0; i < 18; i++) {
                     double x = 0.0;
 #pragma unroll
-                    for (int k = 0; k < 18; k++) x += v[k] * c_tab.imdct_cos36[i][k];
-                    x = x * win[i] + tail[i];
+                    for (int k = 0; k < 18; k++) x += v[k] * C36[i][k];
+                    x = x * (ch == 0 ? win0[i] : win1[i]) + tail[i];
                     if (neg_odd && (i & 1)) x = -x;
                     if (live) row[(long)i * 32] = x;
+                    if (i & 1) __builtin_amdgcn_sched_barrier(0);   // at most two rows of twiddles (72 SGPRs) in flight
                 }
             }
-#pragma unroll 2
+#pragma unroll
             for (int i = 18; i < 36; i++) {
                 double x = 0.0;
 #pragma unroll
-                for (int k = 0; k < 18; k++) x += v[k] * c_tab.imdct_cos36[i][k];
-                tail[i - 18] = x * win[i];
+                for (int k = 0; k < 18; k++) x += v[k] * C36[i][k];
+                tail[i - 18] = x * (ch == 0 ? win0[i] : win1[i]);
+                if (i & 1) __builtin_amdgcn_sched_barrier(0);
             }
         } else {
-            double t[36];
+            // three 12-point windows placed at 6/12/18 (Frame.py:135-148); computed one window at a time
+            double w0[12], w1[12];
 #pragma unroll
-            for (int w = 0; w < 3; w++)
+            for (int i = 0; i < 12; i++) {
+                double x = 0.0;
 #pragma unroll
-                for (int i = 0; i < 12; i++) {
-                    double x = 0.0;
+                for (int k = 0; k < 6; k++) x += v[k] * C12[i][k];
+                w0[i] = x * tab.sine_block[2][i];
+            }
 #pragma unroll
-                    for (int k = 0; k < 6; k++) x += v[6 * w + k] * c_tab.imdct_cos12[i][k];
-                    t[w * 12 + i] = x * c_tab.sine_block[2][i];
-                }
+            for (int i = 0; i < 12; i++) {
+                double x = 0.0;
+#pragma unroll
+                for (int k = 0; k < 6; k++) x += v[6 + k] * C12[i][k];
+                w1[i] = x * tab.sine_block[2][i];
+            }
             if (gi >= 0) {
 #pragma unroll
                 for (int i = 0; i < 18; i++) {
-                    // sample_block[0..5] = 0, [6..11] = t[0..5], [12..17] = t[6..11] + t[12..17]   (:136-142)
-                    const double blk = i < 6 ? 0.0 : (i < 12 ? t[i - 6] : t[i - 6] + t[i]);
+                    // sample_block[0..5] = 0, [6..11] = t[0..5], [12..17] = t[6..11] + t[12..17]
+                    const double blk = i < 6 ? 0.0 : (i < 12 ? w0[i - 6] : w0[i - 6] + w1[i - 12]);
                     double x = blk + tail[i];
                     if (neg_odd && (i & 1)) x = -x;
                     if (live) row[(long)i * 32] = x;
                 }
             }
 #pragma unroll
-            for (int i = 0; i < 6; i++) {
-                tail[i] = t[18 + i] + t[24 + i];           // sample_block[18..23]
-                tail[6 + i] = t[30 + i];                   // sample_block[24..29]
-                tail[12 + i] = 0.0;                        // sample_block[30..35]
+            for (int i = 0; i < 12; i++) {
+                double x = 0.0;
+#pragma unroll
+                for (int k = 0; k < 6; k++) x += v[12 + k] * C12[i][k];
+                x = x * tab.sine_block[2][i];
+                if (i < 6) tail[i] = w1[6 + i] + x;        // sample_block[18..23] = t[18..23] + t[24..29]
+                else tail[i] = x;                          // sample_block[24..29] = t[30..35]
             }
+#pragma unroll
+            for (int i = 12; i < 18; i++) tail[i] = 0.0;   // sample_block[30..35]
         }
     }
 }

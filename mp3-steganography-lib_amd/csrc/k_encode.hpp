@@ -17,19 +17,21 @@
 namespace mp3s {
 
 constexpr int ENC_ROW = 40;   // int16 per LDS row: 32 samples + 8 pad (80-byte stride)
+constexpr int ENC_LDS_DW = 64 * 33;   // per-wave LDS in dwords: PCM tile (79 rows * 20 dw) first, then the 64 x 32 output tile (+1 pad)
 
-// SB layout: int32 [ch][32 bands][Ts] with Ts = n_frames * 36 slots
+// SB layout: int32 [ch][Ts][32 bands] with Ts = n_frames * 36 slots (a 128-byte row per slot)
 __global__ __launch_bounds__(256, 3) void k_enc_analysis(
     const int16_t *__restrict__ pcm, const mp3s_frame_hdr *__restrict__ hdr, int n_frames,
     int32_t *__restrict__ SB, long Ts)
 {
-    __shared__ __attribute__((aligned(16))) int16_t tile[4][79 * ENC_ROW];
+    __shared__ __attribute__((aligned(16))) uint32_t lds_all[4][ENC_LDS_DW];
+    static_assert(79 * ENC_ROW * 2 <= ENC_LDS_DW * 4, "PCM tile must fit");
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
     const long wid = (long)blockIdx.x * 4 + wave;
     const int ch = (int)(wid & 1);
     const long t0 = (wid >> 1) * 64;          // first slot of this wave
     if (t0 >= Ts) return;
-    int16_t *tw = tile[wave];
+    int16_t *tw = reinterpret_cast<int16_t *>(lds_all[wave]);
     // stage rows t0-15 .. t0+63 of channel ch (zeros outside the batch)
     for (int e = lane; e < 79 * 32; e += 64) {
         const int r = e >> 5, s = e & 31;
@@ -75,10 +77,11 @@ __global__ __launch_bounds__(256, 3) void k_enc_analysis(
             }
         }
     }
-    if (!valid) return;
-    // ---- s[sb] = sum_j mul(fl[sb][j], y[j])   (MP3_Encoder.py:358-368); four bands per pass for ILP
+    // ---- s[sb] = sum_j mul(fl[sb][j], y[j])   (MP3_Encoder.py:358-368); four bands per pass for ILP.
+    // Results are staged in the wave's LDS region as [slot][band] (33-dword rows) and written out as rows.
     const bool odd_slot = (t & 1) != 0;      // slot-in-granule parity == slot parity (18 is even)
-    int32_t *out = SB + (long)ch * 32 * Ts + t;
+    __builtin_amdgcn_wave_barrier();         // every lane is done reading the PCM tile
+    uint32_t *ot = lds_all[wave];
 #pragma unroll 1
     for (int sb = 0; sb < 32; sb += 4) {
         int32_t a0 = 0, a1 = 0, a2 = 0, a3 = 0;
@@ -92,10 +95,18 @@ __global__ __launch_bounds__(256, 3) void k_enc_analysis(
             if ((j & 7) == 7) __builtin_amdgcn_sched_barrier(0);   // keep the scheduler from hoisting all 256 products
         }
         if (odd_slot) { a1 = (int32_t)(0u - (uint32_t)a1); a3 = (int32_t)(0u - (uint32_t)a3); }   // odd bands
-        out[(long)sb * Ts] = a0;
-        out[(long)(sb + 1) * Ts] = a1;
-        out[(long)(sb + 2) * Ts] = a2;
-        out[(long)(sb + 3) * Ts] = a3;
+        ot[lane * 33 + sb] = (uint32_t)a0;
+        ot[lane * 33 + sb + 1] = (uint32_t)a1;
+        ot[lane * 33 + sb + 2] = (uint32_t)a2;
+        ot[lane * 33 + sb + 3] = (uint32_t)a3;
+    }
+    __builtin_amdgcn_s_waitcnt(0xc07f);
+    __builtin_amdgcn_wave_barrier();
+    uint32_t *out = reinterpret_cast<uint32_t *>(SB) + ((long)ch * Ts + t0) * 32;
+#pragma unroll 4
+    for (int e = lane; e < 64 * 32; e += 64) {
+        const int r = e >> 5, c = e & 31;
+        if (t0 + r < Ts) out[e] = ot[r * 33 + c];
     }
 }
 
@@ -109,12 +120,12 @@ __global__ __launch_bounds__(256) void k_enc_mdct(
     if (g >= n_granules) return;
     const int ch = lane >> 5, band = lane & 31;
     const bool has_prev = g > (int)hdr[g >> 1].stream_first * 2;   // l3_sb_sample[ch][0] starts zeroed
-    const int32_t *row = SB + ((long)ch * 32 + band) * Ts + (long)g * 18;
+    const int32_t *row = SB + ((long)ch * Ts + (long)g * 18) * 32 + band;
     int32_t in[36];
 #pragma unroll
     for (int j = 0; j < 18; j++) {
-        in[j] = has_prev ? row[j - 18] : 0;
-        in[18 + j] = row[j];
+        in[j] = has_prev ? row[(j - 18) * 32] : 0;
+        in[18 + j] = row[j * 32];
     }
     int32_t X[18];
 #pragma unroll 2

@@ -38,7 +38,7 @@ __device__ __forceinline__ uint32_t wave_add_u32(uint32_t v)
 // encoder/util.py:130-133 mulr for non-negative a: (a*b + 2^31) >> 32
 __device__ __forceinline__ uint32_t mulr_u(uint32_t a, uint32_t b) { return __umulhi(a, b) + ((a * b) >> 31); }
 
-constexpr int RL_WAVES = 4;
+constexpr int RL_WAVES = 4;   // 5 waves share one copy of the lookup tables: 35 KB LDS -> 4 workgroups = 20 waves per CU
 constexpr int RL_NP = 5;   // pair slots per lane (the 5th only for lanes < 32)
 
 struct RlTables {
@@ -62,14 +62,14 @@ struct RlState {           // wave-uniform GrInfo fields that live across rate_b
 
 __device__ __forceinline__ int family_of(int t) { return t == 13 ? 0 : (t == 15 ? 1 : (t < 24 ? 2 : 3)); }
 
-// bits of one pair under table t (count_bit, MP3_Encoder.py:234-261)
-__device__ __forceinline__ uint32_t pair_bits(const RlTables &tb, int t, int x, int y)
+// bits of one pair (count_bit, MP3_Encoder.py:234-261) under a table given by its Huffman-length family (0..3 =
+// 13, 15, 16.., 24..) and its linbits; both are wave-uniform per region and selected per lane without branches
+__device__ __forceinline__ uint32_t pair_bits(const RlTables &tb, int fam, int lb, int x, int y)
 {
     const int xx = x > 14 ? 15 : x, yy = y > 14 ? 15 : y;
-    uint32_t b = tb.hlen[family_of(t)][xx * 16 + yy] + (x != 0) + (y != 0);
-    if (t > 15) b += lin_bits_of(t) * ((x > 14) + (y > 14));
-    return b;
+    return tb.hlen[0][fam * 256 + xx * 16 + yy] + (x != 0) + (y != 0) + lb * ((x > 14) + (y > 14));
 }
+__device__ __forceinline__ int sel3(int r, int a, int b, int c) { return r == 0 ? a : (r == 1 ? b : c); }
 
 // quantize (MP3_Encoder.py:389-415); returns the wave-uniform ix_max, 16384 for the early out, -1 when the
 // step leaves steptab (IndexError in the reference)
@@ -82,17 +82,24 @@ __device__ __forceinline__ int rl_quantize(const RlTables &tb, const uint32_t (&
     if (mulr_u(xrmax, scalei) > 165140u) return 16384;
     const double scale = c_tab.steptab[idx];
     uint32_t mx = 0;
+    bool big = false;
 #pragma unroll
     for (int e = 0; e < 2 * RL_NP; e++) {
         const uint32_t ln = mulr_u(xa[e], scalei);
-        int32_t v;
-        if (ln < 10000u) v = tb.int2idx[ln];
-        else {
-            const double dbl = (double)xa[e] * scale * 4.656612875e-10;
-            v = (int32_t)__dsqrt_rn(__dsqrt_rn(dbl) * dbl);
-        }
+        big |= ln >= 10000u;
+        const int32_t v = tb.int2idx[ln < 10000u ? ln : 9999u];   // quick lookup (:403-404)
         ix[e] = v;
         mx = max(mx, (uint32_t)v);
+    }
+    if (__ballot(big)) {   // wave-uniform: some value is outside the table range, redo those with floats (:405-409)
+#pragma unroll
+        for (int e = 0; e < 2 * RL_NP; e++) {
+            const uint32_t ln = mulr_u(xa[e], scalei);
+            const double dbl = (double)xa[e] * scale * 4.656612875e-10;
+            const int32_t v = (int32_t)__dsqrt_rn(__dsqrt_rn(dbl) * dbl);
+            ix[e] = ln >= 10000u ? v : ix[e];
+            mx = max(mx, (uint32_t)ix[e]);
+        }
     }
     return (int)wave_max_u32(mx);
 }
@@ -125,11 +132,10 @@ __device__ __forceinline__ int rl_body(const RlTables &tb, uint8_t *pcode, const
     for (int m = 0; m < RL_NP; m++) {
         const int p = lane + 64 * m;
         const int rel = p - bv;
-        if (rel >= 0 && rel < 2 * count1) {
-            const uint32_t c2 = pcode[p];
-            acc += (uint32_t)__popc(c2) << 16;
-            if (!(rel & 1)) acc += tb.c1a[c2 | ((uint32_t)pcode[p + 1] << 2)];
-        }
+        const bool in_c1 = rel >= 0 && rel < 2 * count1;
+        const uint32_t c2 = (uint32_t)((ix[2 * m] & 1) | ((ix[2 * m + 1] & 1) << 1));
+        const uint32_t quad = tb.c1a[c2 | (((uint32_t)pcode[p + 1] & 3u) << 2)];   // evaluated by every lane, used by few
+        acc += in_c1 ? ((uint32_t)__popc(c2) << 16) + ((rel & 1) ? 0u : quad) : 0u;
     }
     acc = wave_add_u32(acc);
     const int signs = (int)(acc >> 16), sum0 = signs + (int)(acc & 0xffff), sum1 = signs + 4 * count1;
@@ -158,11 +164,11 @@ __device__ __forceinline__ int rl_body(const RlTables &tb, uint8_t *pcode, const
     for (int m = 0; m < RL_NP; m++) {
         const int s = 2 * (lane + 64 * m);
         const uint32_t pm = (uint32_t)max(ix[2 * m], ix[2 * m + 1]);
-        int r = -1;
-        if (s < a1) { r = 0; mx0 = max(mx0, pm); }
-        else if (s < a2) { r = 1; mx1 = max(mx1, pm); }
-        else if (s < bvr) { r = 2; mx2 = max(mx2, pm); }
-        rid[m] = r;
+        const bool in0 = s < a1, in1 = !in0 && s < a2, in2 = !in0 && !in1 && s < bvr;
+        mx0 = max(mx0, in0 ? pm : 0u);
+        mx1 = max(mx1, in1 ? pm : 0u);
+        mx2 = max(mx2, in2 ? pm : 0u);
+        rid[m] = in0 ? 0 : (in1 ? 1 : (in2 ? 2 : -1));
     }
     const int rmax[3] = {(int)wave_max_u32(mx0), (int)wave_max_u32(mx1), (int)wave_max_u32(mx2)};
 
@@ -184,19 +190,23 @@ __device__ __forceinline__ int rl_body(const RlTables &tb, uint8_t *pcode, const
             tB[r] = 24 + (nb > 4) + (nb > 5) + (nb > 6) + (nb > 7) + (nb > 8) + (nb > 9) + (nb > 11);
         }
     }
+    int fA[3], fB[3], lA[3], lB[3];
+#pragma unroll
+    for (int r = 0; r < 3; r++) {
+        fA[r] = family_of(tA[r]); fB[r] = family_of(tB[r]);
+        lA[r] = lin_bits_of(tA[r]); lB[r] = lin_bits_of(tB[r]);
+    }
     uint32_t w[3] = {0, 0, 0};
 #pragma unroll
     for (int m = 0; m < RL_NP; m++) {
         const int r = rid[m];
-        if (r >= 0) {
-            const int ta = r == 0 ? tA[0] : (r == 1 ? tA[1] : tA[2]);
-            const int tbb = r == 0 ? tB[0] : (r == 1 ? tB[1] : tB[2]);
-            if (ta) {
-                const uint32_t v = pair_bits(tb, ta, ix[2 * m], ix[2 * m + 1]) |
-                                   (pair_bits(tb, tbb, ix[2 * m], ix[2 * m + 1]) << 16);
-                if (r == 0) w[0] += v; else if (r == 1) w[1] += v; else w[2] += v;
-            }
-        }
+        const int ta = sel3(r, tA[0], tA[1], tA[2]);
+        uint32_t v = pair_bits(tb, sel3(r, fA[0], fA[1], fA[2]), sel3(r, lA[0], lA[1], lA[2]), ix[2 * m], ix[2 * m + 1]) |
+                     (pair_bits(tb, sel3(r, fB[0], fB[1], fB[2]), sel3(r, lB[0], lB[1], lB[2]), ix[2 * m], ix[2 * m + 1]) << 16);
+        v = (r >= 0 && ta != 0) ? v : 0u;
+        w[0] += r == 0 ? v : 0u;
+        w[1] += r == 1 ? v : 0u;
+        w[2] += r == 2 ? v : 0u;
     }
     int ts[3], rbits[3];
     bool redo[3];
@@ -220,14 +230,14 @@ __device__ __forceinline__ int rl_body(const RlTables &tb, uint8_t *pcode, const
     }
     if (redo[0] || redo[1] || redo[2]) {               // a hide swap picked a table outside the two candidates
         uint32_t extra = 0;
+        const int f0 = family_of(ts[0]), f1 = family_of(ts[1]), f2 = family_of(ts[2]);
+        const int l0 = lin_bits_of(ts[0]), l1 = lin_bits_of(ts[1]), l2 = lin_bits_of(ts[2]);
 #pragma unroll
         for (int m = 0; m < RL_NP; m++) {
             const int r = rid[m];
-            if (r >= 0) {
-                const bool rd = r == 0 ? redo[0] : (r == 1 ? redo[1] : redo[2]);
-                const int t = r == 0 ? ts[0] : (r == 1 ? ts[1] : ts[2]);
-                if (rd) extra += pair_bits(tb, t, ix[2 * m], ix[2 * m + 1]);
-            }
+            const bool rd = r >= 0 && sel3(r, redo[0], redo[1], redo[2]) != 0;
+            const uint32_t v = pair_bits(tb, sel3(r, f0, f1, f2), sel3(r, l0, l1, l2), ix[2 * m], ix[2 * m + 1]);
+            extra += rd ? v : 0u;
         }
         bits += (int)wave_add_u32(extra);
     }
@@ -235,7 +245,7 @@ __device__ __forceinline__ int rl_body(const RlTables &tb, uint8_t *pcode, const
     return bits + rbits[0] + rbits[1] + rbits[2];
 }
 
-__global__ __launch_bounds__(RL_WAVES * 64) void k_rate_loop(
+__global__ __launch_bounds__(RL_WAVES * 64, 4) void k_rate_loop(
     const int32_t *__restrict__ mdct, const mp3s_rate_frame *__restrict__ frames, int n_units,
     const uint8_t *__restrict__ hide, int n_hide, const int32_t *__restrict__ cursor_in,
     const int32_t *__restrict__ state_in, const int32_t *__restrict__ unit_list, int n_list,

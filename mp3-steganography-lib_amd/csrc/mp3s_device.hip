@@ -52,10 +52,22 @@ int launch_decode(hipStream_t stream, const int16_t *d_is, const mp3s_granule_si
     const long T = (long)n_frames * 36;
     double *S = (double *)d_scratch;
     const int n_gran = n_frames * 2;
-    const int runs = (n_gran + DEC_RUN - 1) / DEC_RUN;
+    // granules per wave: each wave also primes itself with half an IMDCT of the granule before its run, so longer
+    // runs waste less; pick the run length (2..8) that fills whole rounds of the chip's 4096 wave slots best
+    int run = 8;
+    {
+        double best = 1e30;
+        for (int r = 2; r <= 8; r++) {
+            const long waves = (n_gran + r - 1) / r;
+            const long rounds = (waves + 4095) / 4096;
+            const double cost = (double)rounds * (r + 0.55);
+            if (cost < best) { best = cost; run = r; }
+        }
+    }
+    const int runs = (n_gran + run - 1) / run;
     int pp = prof ? prof->begin(stream, K_DEC_IMDCT) : -1;
     hipLaunchKernelGGL(k_dec_imdct, dim3((runs + DEC_A_WAVES - 1) / DEC_A_WAVES), dim3(DEC_A_WAVES * 64), 0, stream,
-                       d_is, d_si, d_hdr, n_gran, nch, S, T);
+                       d_is, d_si, d_hdr, n_gran, nch, run, S, T);
     if (prof) prof->end(stream, pp);
     constexpr int TW = DEC_SYNTH_TW;
     const int out_per_tile = TW * 64 - 15;

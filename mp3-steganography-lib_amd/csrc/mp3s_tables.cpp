@@ -114,7 +114,12 @@ void build()
     for (int i = 0; i < POW2H_N; i++) T.pow2h[i] = std::pow(2.0, -((double)i * 0.5));
     T.sqrt2 = std::sqrt(2.0);
     for (int sr = 0; sr < 3; sr++) {
-        for (int c = 0; c < 3; c++) build_rq_map(sr, c, T.rq_map[sr][c]);
+        for (int c = 0; c < 3; c++) {
+            uint8_t flat[576];
+            build_rq_map(sr, c, flat);
+            for (int sb = 0; sb < 32; sb++)
+                for (int k = 0; k < 18; k++) T.rq_map[sr][c][sb][k] = flat[sb * 18 + k];
+        }
         // reference Frame.py:581-602 as a gather map
         for (int i = 0; i < 576; i++) T.reorder_src[sr][i] = -1;
         int total = 0, start = 0, block = 0;
