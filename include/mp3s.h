@@ -101,6 +101,9 @@ int mp3s_device_name(mp3s_ctx *ctx, char *buf, size_t n);
 int mp3s_sync(mp3s_ctx *ctx);
 /* host copy of the constant tables uploaded to the device (struct DevTables of csrc/mp3s_tables.h), for tests */
 const void *mp3s_debug_tables(size_t *bytes);
+/* host (glibc) evaluation of the __calc_scfsi energies of one granule*channel: en[0..20] bands, en[21] total.
+ * The kernel's device log is cross-checked against this; units flagged MP3S_RF_LOG_GUARD are recomputed with it. */
+int mp3s_debug_scfsi_energies(const int32_t *xr576, int sr_idx, int32_t *en22);
 
 /* device memory owned by the caller through the context (for resident pipelines / benchmarks) */
 int mp3s_dev_alloc(mp3s_ctx *ctx, size_t bytes, void **dptr);

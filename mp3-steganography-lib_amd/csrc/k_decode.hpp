@@ -277,6 +277,7 @@ __global__ __launch_bounds__(TW * 64 * 2, (TW * 2 * 2) / 4) void k_dec_synth(
     }
     const long halo_slots = (long)n_halo * 36;
     const bool emit = valid && tl >= 15 && t >= halo_slots;
+    const bool full_hist = __ballot(tl >= 15 && lim < 15) == 0;
     uint16_t *ot16 = reinterpret_cast<uint16_t *>(otile);
     int p = 0;
     for (int i = 0; i < 32; i++) {
@@ -291,11 +292,17 @@ __global__ __launch_bounds__(TW * 64 * 2, (TW * 2 * 2) / 4) void k_dec_synth(
         __syncthreads();
         if (tl >= 15) {
             double sum = 0.0;
+            if (full_hist) {                    // wave-uniform: every lane has 15 in-stream predecessors (the common case)
 #pragma unroll
-            for (int jj = 0; jj < 16; jj++) {   // Frame.py:89-101 (u, w, sum over 16 windowed taps)
-                double u = ex[p][ch][jj & 1][tl - jj];
-                if (jj > lim) u = 0.0;           // before the stream started the fifo holds zeros
-                sum += u * c_tab.synth_window[32 * jj + i];
+                for (int jj = 0; jj < 16; jj++)   // Frame.py:89-101 (u, w, sum over 16 windowed taps)
+                    sum += ex[p][ch][jj & 1][tl - jj] * c_tab.synth_window[32 * jj + i];
+            } else {
+#pragma unroll
+                for (int jj = 0; jj < 16; jj++) {
+                    double u = ex[p][ch][jj & 1][tl - jj];
+                    if (jj > lim) u = 0.0;       // before the stream started the fifo holds zeros
+                    sum += u * c_tab.synth_window[32 * jj + i];
+                }
             }
             if (emit) {
                 const long to = t - halo_slots;

@@ -79,6 +79,28 @@ int rate_frames(int samplerate, int bitrate_kbps, int nch, int n_frames, mp3s_ra
     return 0;
 }
 
+void host_scfsi_energies(const int32_t *xr, int sr_idx, int32_t *en)
+{
+    const int32_t *sfb = host_tables().dev.sfb_long[sr_idx];
+    uint32_t e10[576], tot = 0;
+    for (int i = 0; i < 576; i++) {
+        const int64_t a = xr[i];
+        const int32_t sq = (int32_t)((a * a + (1ll << 30)) >> 31);   // util.mulsr(xr, xr)
+        e10[i] = (uint32_t)(sq >> 10);
+        tot += e10[i];
+    }
+    auto lg = [](uint32_t t) -> int32_t {
+        const int32_t v = (int32_t)t;
+        return v ? (int32_t)(std::log((double)v * 4.768371584e-7) / 0.69314718) : 0;
+    };
+    for (int b = 0; b < 21; b++) {
+        uint32_t t = 0;
+        for (int i = sfb[b]; i < sfb[b + 1]; i++) t += e10[i];
+        en[b] = lg(t);
+    }
+    en[21] = lg(tot);
+}
+
 void decide_scfsi(int n_frames, const int32_t *en, const mp3s_gr_out *gr, int32_t *scfsi)
 {
     static const int band[5] = {0, 6, 11, 16, 21};

@@ -161,6 +161,57 @@ def test_encode_synth128_with_silence(ctx, mlib, golden_dir):
     assert sha(d["pcm"].tobytes()) == bytes(g["dec_pcm_sha256"]).decode()
 
 
+def test_rate_loop_batch_entry_point(ctx, mlib, orc, golden_dir):
+    """mp3s_rate_loop_dev on device buffers: unit lists, inherited state, energies vs the host (glibc) evaluation"""
+    import ctypes as C
+    g = np.load(os.path.join(golden_dir, "g6_synth128.npz"))
+    o = orc.encode(g["pcm"], 44100, 128, None)
+    n = o["n_frames"]
+    units = n * 4
+    L = mlib.lib()
+    mdct = np.ascontiguousarray(o["mdct_freq"], dtype=np.int32)
+    rf, _ = mlib.rate_frames(44100, 128, 2, n)
+    d_mdct, d_rf = ctx.to_device(mdct), ctx.to_device(rf)
+    d_ix, d_out, d_en = ctx.alloc(units * 576 * 2), ctx.alloc(units * 72), ctx.alloc(units * 22 * 4)
+    d_state = ctx.to_device(np.zeros((units, 4), dtype=np.int32))
+    mlib.check(L.mp3s_rate_loop_dev(ctx.handle, d_mdct, d_rf, n, None, 0, None, d_state, None, 0, d_ix, d_out, d_en))
+    ctx.sync()
+    out = ctx.download(d_out, mlib.GR_OUT_DTYPE, (units,))
+    en = ctx.download(d_en, np.int32, (units, 22))
+    ix = ctx.download(d_ix, np.int16, (n, 2, 2, 576))
+    act = (out["flags"] & mlib.RF_ACTIVE) != 0
+    gi = o["frames"]["gi"]
+    ref_bv = gi["big_values"].transpose(0, 2, 1).reshape(-1)
+    ref_ts = gi["table_select"].transpose(0, 2, 1, 3).reshape(-1, 3)
+    # units that did not inherit state are final after one launch
+    clean = act & ((out["flags"] & mlib.RF_USED_ADDR_IN) == 0)
+    assert clean.sum() > 100
+    assert np.array_equal(out["big_values"][clean], ref_bv[clean])
+    assert np.array_equal(out["table_select"][clean], ref_ts[clean])
+    assert np.array_equal(ix.reshape(units, 576)[clean], o["ix"].reshape(units, 576)[clean].astype(np.int16))
+    # device log vs glibc log: identical truncated energies (and the guard flag never fired here)
+    assert not (out["flags"] & mlib.RF_LOG_GUARD).any()
+    host_en = np.zeros(22, dtype=np.int32)
+    for u in list(range(0, units, 7)) + [units - 1]:
+        xr = np.ascontiguousarray(mdct.reshape(units, 576)[u])
+        mlib.check(L.mp3s_debug_scfsi_energies(xr.ctypes.data, 0, host_en.ctypes.data))
+        assert np.array_equal(en[u], host_en), u
+    # a unit list recomputes only the listed units
+    lst = np.array([5, 17, 40], dtype=np.int32)
+    mlib.check(L.mp3s_dev_memset(ctx.handle, d_out, 0, units * 72))
+    d_list = ctx.to_device(lst)
+    mlib.check(L.mp3s_rate_loop_dev(ctx.handle, d_mdct, d_rf, n, None, 0, None, d_state, d_list, 3, d_ix, d_out, d_en))
+    ctx.sync()
+    out2 = ctx.download(d_out, mlib.GR_OUT_DTYPE, (units,))
+    for u in range(units):
+        if u in lst:
+            assert out2[u] == out[u]
+        else:
+            assert out2[u]["flags"] == 0 and out2[u]["xrmax"] == 0
+    for p in (d_mdct, d_rf, d_ix, d_out, d_en, d_state, d_list):
+        ctx.free(p)
+
+
 def test_facade_hashes(ctx, mlib, golden_dir):
     """hide / clear / too-long through the device pipeline equal the reference facade run"""
     fac = json.load(open(os.path.join(golden_dir, "g3_facade.json")))
