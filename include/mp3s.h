@@ -44,6 +44,7 @@ extern "C" {
 #define MP3S_PCM_F64 2 /* the reference's own float64 samples, bit for bit */
 
 typedef struct mp3s_ctx mp3s_ctx;
+typedef struct mp3s_buf mp3s_buf; /* library-owned result, released with mp3s_buf_free() */
 
 /* ---------------------------------------------------------------- records (device + host layout) */
 
@@ -115,8 +116,9 @@ int mp3s_dev_memset(mp3s_ctx *ctx, void *dptr, int value, size_t bytes);
 int mp3s_timer_start(mp3s_ctx *ctx);
 int mp3s_timer_stop(mp3s_ctx *ctx, float *ms);
 /* per-kernel HIP-event timing on the same stream: enable, run, then collect the summed milliseconds and launch
- * counts of the five kernels in this order: dec_imdct, dec_synth, enc_analysis, enc_mdct, rate_loop (n >= 5) */
-#define MP3S_N_KERNELS 5
+ * counts of the kernels in this order: dec_imdct, dec_synth, enc_analysis, enc_mdct, rate_loop, dec_huffman,
+ * enc_pack (n >= MP3S_N_KERNELS) */
+#define MP3S_N_KERNELS 7
 int mp3s_profile_enable(mp3s_ctx *ctx, int on);
 int mp3s_profile_collect(mp3s_ctx *ctx, double *total_ms, int64_t *launches, int n);
 
@@ -170,8 +172,66 @@ int mp3s_rate_loop_dev(mp3s_ctx *ctx, const int32_t *d_mdct, const mp3s_rate_fra
                        const uint8_t *d_hide_bits, int n_hide, const int32_t *d_cursor_in, const int32_t *d_state_in,
                        const int32_t *d_unit_list, int n_list, int16_t *d_ix, mp3s_gr_out *d_out, int32_t *d_en);
 
+/* ---------------------------------------------------------------- (vi) bit-level stages on the device
+ * The serial bit parsing / packing of the reference is serial per granule only: granule boundaries are known from
+ * the side info (decode) or from the rate loop (encode), so granules are decoded / packed in parallel.  The host
+ * keeps the byte-level framing scan (sync, header, 17/32-byte side info, reservoir gather: mp3s_scan_stream). */
+
+/* side info of one granule*channel as parsed from the stream (reference decoder/FrameSideInformation.py:62-137) */
+typedef struct {
+    uint16_t part2_3_length, big_values;
+    uint8_t global_gain, scalefac_compress, window_switching, block_type, mixed_block_flag;
+    uint8_t table_select[3];
+    uint8_t region0_count, region1_count, preflag, scalefac_scale, count1table_select;
+    uint8_t sub_block_gain[3];
+} mp3s_unit_side; /* 20 bytes */
+
+/* one frame for the Huffman kernel: where its main data sits in the blob + the parsed side info */
+typedef struct {
+    uint32_t md_off, md_len;   /* byte offset (multiple of 4) and length of the frame's main data in the blob */
+    uint8_t nch, sr_idx, ms_stereo, flags;
+    uint8_t scfsi[2][4];
+    mp3s_unit_side unit[2][2]; /* [gr][ch] */
+    uint32_t reserved;
+} mp3s_frame_side; /* 104 bytes */
+
+/* replaces: __unpack_scale_fac + __unpack_samples for every granule*channel of the batch -- reference
+ * decoder/Frame.py:365-559 (linear code-book search there, table + trie here; same prefix codes, same quirks D1/D2).
+ * blob: main data of all frames (reservoir already gathered), each frame 4-byte aligned and followed by >= 8 zero
+ * bytes; is / si as consumed by mp3s_decode_transform_dev; status: int32, OR of MP3S_HS_* on malformed input.
+ * Not bit-exact for streams whose scalefactors are inherited across frames (mixed blocks, scfsi after a short
+ * gr0): mp3s_scan_stream reports those (gpu_ok = 0) and the pipelines fall back to the host parser. */
+#define MP3S_HS_BAD_REGION 1
+#define MP3S_HS_BIG_VALUES 2
+int mp3s_huffman_decode_dev(mp3s_ctx *ctx, const uint8_t *d_blob, const mp3s_frame_side *d_side, int n_frames, int nch,
+                            int16_t *d_is, mp3s_granule_si *d_si, int32_t *d_status);
+
+/* replaces: __format_bitstream for every frame of the batch -- reference encoder/MP3_Encoder.py:1097-1145 (stuffing),
+ * 1266-1547; one workgroup per frame, one wavefront per granule*channel, code lengths prefix-summed across lanes.
+ * gr must be final (serial chain resolved, silent units carrying their inherited quantizer_step); en as written by
+ * the rate loop (scfsi is decided here, :861-892); frame_off[f] = byte offset of frame f, padding[f] its padding bit.
+ * Output bytes [frame_off[n_frames]]; the caller truncates the stream to a multiple of 4 bytes (E14). */
+int mp3s_pack_frames_dev(mp3s_ctx *ctx, const int16_t *d_ix, const mp3s_gr_out *d_gr, const int32_t *d_en, int n_frames,
+                         int samplerate, int bitrate_kbps, const uint32_t *d_frame_off, const uint8_t *d_padding,
+                         uint8_t *d_mp3, int32_t *d_scfsi, int32_t *d_status);
+
 /* ---------------------------------------------------------------- host stages (no GPU needed) */
-typedef struct mp3s_buf mp3s_buf; /* library-owned result */
+
+/* replaces: the byte-level part of MP3Parser.parse_file: sync/header/side-info parse, frame sizes, reservoir gather,
+ * stego bits -- reference decoder/MP3_Parser.py:25-85, Frame.py:244-263, 288-363, 676-685, FrameHeader.py,
+ * FrameSideInformation.py.  No scalefactor / Huffman decoding (that is mp3s_huffman_decode_dev or mp3s_parse_stream). */
+typedef struct {
+    int32_t n_frames, nch, sampling_rate, bit_rate, n_bits, dup_last_frame;
+    int32_t gpu_ok;               /* 0: scalefactors are inherited across frames somewhere -> use mp3s_parse_stream */
+    const mp3s_frame_side *side;  /* [n_frames] */
+    const mp3s_frame_hdr *hdr;    /* [n_frames] */
+    const uint8_t *blob;          /* main data of all frames */
+    size_t blob_len;
+    const uint8_t *bits;          /* stego bits 0/1 */
+    const int32_t *frame_size;    /* [n_frames] */
+} mp3s_scanned;
+int mp3s_scan_stream(const uint8_t *file, size_t len, mp3s_buf **owner, mp3s_scanned *out);
+
 void mp3s_buf_free(mp3s_buf *b);
 
 /* replaces: MP3Parser.parse_file front end: header/side-info parse, reservoir reassembly, scalefactor

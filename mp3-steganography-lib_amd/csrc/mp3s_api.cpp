@@ -56,6 +56,7 @@ struct mp3s_ctx {
 
 struct mp3s_buf {
     ParsedStream parsed;
+    ScannedStream scanned;
     std::vector<uint8_t> bytes;      // generic payload (pcm / mp3)
     std::vector<uint8_t> bits;
     std::vector<mp3s_gr_out> gr;
@@ -211,6 +212,7 @@ int mp3s_profile_collect(mp3s_ctx *c, double *total_ms, int64_t *launches, int n
     }
     p.n_pairs = 0;
     for (int k = 0; k < K_COUNT; k++) { total_ms[k] = p.total_ms[k]; launches[k] = p.count[k]; }
+    static_assert(K_COUNT == MP3S_N_KERNELS, "kernel list out of sync with mp3s.h");
     return MP3S_OK;
 }
 
@@ -227,6 +229,8 @@ int mp3s_decode_transform_dev(mp3s_ctx *c, const int16_t *d_is, const mp3s_granu
     if (e) return fail(MP3S_E_HIP, "decode launch: %s", hipGetErrorString((hipError_t)e));
     return MP3S_OK;
 }
+
+constexpr int kDecodeChunk = 16384;   // frames per decode launch group (scratch ~0.6 GB); chunks overlap by a 1-frame halo
 
 static size_t pcm_elem(int fmt) { return fmt == MP3S_PCM_I16 ? 2 : (fmt == MP3S_PCM_F32 ? 4 : 8); }
 
@@ -318,7 +322,49 @@ int mp3s_rate_loop_dev(mp3s_ctx *c, const int32_t *d_mdct, const mp3s_rate_frame
     return MP3S_OK;
 }
 
+int mp3s_huffman_decode_dev(mp3s_ctx *c, const uint8_t *d_blob, const mp3s_frame_side *d_side, int n_frames, int nch,
+                            int16_t *d_is, mp3s_granule_si *d_si, int32_t *d_status)
+{
+    if (!c || !d_blob || !d_side || !d_is || !d_si || !d_status) return fail(MP3S_E_ARG, "null pointer");
+    if (n_frames <= 0 || nch < 1 || nch > 2) return fail(MP3S_E_ARG, "bad sizes");
+    const int e = launch_huffman(c->stream, d_blob, d_side, n_frames, nch, d_is, d_si, d_status, &c->prof);
+    if (e) return fail(MP3S_E_HIP, "huffman launch: %s", hipGetErrorString((hipError_t)e));
+    return MP3S_OK;
+}
+
+int mp3s_pack_frames_dev(mp3s_ctx *c, const int16_t *d_ix, const mp3s_gr_out *d_gr, const int32_t *d_en, int n_frames,
+                         int samplerate, int bitrate_kbps, const uint32_t *d_frame_off, const uint8_t *d_padding,
+                         uint8_t *d_mp3, int32_t *d_scfsi, int32_t *d_status)
+{
+    if (!c || !d_ix || !d_gr || !d_en || !d_frame_off || !d_padding || !d_mp3 || !d_scfsi || !d_status)
+        return fail(MP3S_E_ARG, "null pointer");
+    int sri, bri, whole;
+    if (n_frames <= 0 || stream_params(samplerate, bitrate_kbps, &sri, &bri, &whole))
+        return fail(MP3S_E_UNSUPPORTED, "unsupported samplerate/bitrate %d/%d", samplerate, bitrate_kbps);
+    const int e = launch_pack(c->stream, d_ix, d_gr, d_en, n_frames, sri, bri, whole, d_frame_off, d_padding, d_mp3, d_scfsi,
+                              d_status, &c->prof);
+    if (e) return fail(MP3S_E_HIP, "pack launch: %s", hipGetErrorString((hipError_t)e));
+    return MP3S_OK;
+}
+
 // ------------------------------------------------------------------------------------------------ host stages
+int mp3s_scan_stream(const uint8_t *file, size_t len, mp3s_buf **owner, mp3s_scanned *out)
+{
+    if (!file || !owner || !out) return fail(MP3S_E_ARG, "null pointer");
+    mp3s_buf *b = new mp3s_buf();
+    const int rc = parse_stream(file, len, b->parsed, &b->scanned);
+    if (rc) { delete b; return fail(rc, "malformed or unsupported MP3 stream"); }
+    const ParsedStream &p = b->parsed;
+    out->n_frames = p.n_frames; out->nch = p.nch; out->sampling_rate = p.sampling_rate; out->bit_rate = p.bit_rate;
+    out->n_bits = (int32_t)p.bits.size(); out->dup_last_frame = p.dup_last_frame;
+    out->gpu_ok = b->scanned.gpu_ok ? 1 : 0;
+    out->side = b->scanned.side.data(); out->hdr = p.hdr.data();
+    out->blob = b->scanned.blob.data(); out->blob_len = b->scanned.blob.size();
+    out->bits = p.bits.data(); out->frame_size = p.frame_size.data();
+    *owner = b;
+    return MP3S_OK;
+}
+
 int mp3s_parse_stream(const uint8_t *file, size_t len, mp3s_buf **owner, mp3s_parsed *out)
 {
     if (!file || !owner || !out) return fail(MP3S_E_ARG, "null pointer");
@@ -354,27 +400,61 @@ int mp3s_format_stream(int samplerate, int bitrate_kbps, int n_frames, const int
 }
 
 // ------------------------------------------------------------------------------------------------ pipelines
-constexpr int kDecodeChunk = 16384;   // frames per decode launch group (scratch ~0.6 GB); chunks overlap by a 1-frame halo
-
 int mp3s_decode_stream(mp3s_ctx *c, const uint8_t *file, size_t len, int out_format, mp3s_buf **owner, mp3s_decoded *out)
 {
     if (!c || !file || !owner || !out) return fail(MP3S_E_ARG, "null pointer");
     if (out_format < 0 || out_format > 2) return fail(MP3S_E_ARG, "out_format=%d", out_format);
     mp3s_buf *b = new mp3s_buf();
-    int rc = parse_stream(file, len, b->parsed);
+    // byte-level scan on the host; scalefactors + Huffman on the device unless the stream inherits scalefactors
+    // across frames (mixed blocks ...), in which case the host parser produces the batch
+    int rc = parse_stream(file, len, b->parsed, &b->scanned);
     if (rc) { delete b; return fail(rc, "malformed or unsupported MP3 stream"); }
+    const bool on_device = b->scanned.gpu_ok && b->parsed.n_frames > 0;
+    if (!on_device) {
+        rc = parse_stream(file, len, b->parsed, nullptr);
+        if (rc) { delete b; return fail(rc, "malformed or unsupported MP3 stream"); }
+    }
     ParsedStream &p = b->parsed;
     const int n = p.n_frames, nch = p.nch;
+    if (n <= 0) { delete b; return fail(MP3S_E_MALFORMED, "no MP3 frame found"); }
     const size_t esz = pcm_elem(out_format), frame_bytes = (size_t)1152 * nch * esz;
     b->bytes.assign((size_t)(n + p.dup_last_frame) * frame_bytes, 0);
-    HIPCHK(hipSetDevice(c->device));
+    if (hipSetDevice(c->device) != hipSuccess) { delete b; return fail(MP3S_E_HIP, "hipSetDevice failed"); }
+    for (auto &h : p.hdr) h.stream_first = 0;   // one stream; chunks after the first re-run one halo frame
+    void *d_is = nullptr, *d_si = nullptr, *d_hdr = nullptr, *d_pcm = nullptr, *d_blob = nullptr, *d_side = nullptr,
+         *d_st = nullptr;
+    auto cleanup = [&]() {
+        hipStreamSynchronize(c->stream);
+        for (void *q : {d_is, d_si, d_hdr, d_pcm, d_blob, d_side, d_st}) if (q) hipFree(q);
+    };
+    auto alloc = [&](void **q, size_t bytes) { return hipMalloc(q, bytes ? bytes : 16) == hipSuccess; };
+    const int chunk = std::min(n, kDecodeChunk) + 1;
+    if (!alloc(&d_is, (size_t)n * 2304 * 2) || !alloc(&d_si, (size_t)n * 4 * sizeof(mp3s_granule_si)) ||
+        !alloc(&d_hdr, (size_t)n * sizeof(mp3s_frame_hdr)) || !alloc(&d_pcm, (size_t)chunk * frame_bytes) || !alloc(&d_st, 16) ||
+        (on_device && (!alloc(&d_blob, b->scanned.blob.size()) || !alloc(&d_side, (size_t)n * sizeof(mp3s_frame_side))))) {
+        cleanup(); delete b;
+        return fail(MP3S_E_NOMEM, "hipMalloc failed for a %d-frame decode", n);
+    }
+    rc = mp3s_dev_upload(c, d_hdr, p.hdr.data(), (size_t)n * sizeof(mp3s_frame_hdr));
+    if (on_device) {
+        if (!rc) rc = mp3s_dev_upload(c, d_blob, b->scanned.blob.data(), b->scanned.blob.size());
+        if (!rc) rc = mp3s_dev_upload(c, d_side, b->scanned.side.data(), (size_t)n * sizeof(mp3s_frame_side));
+        if (!rc) rc = mp3s_huffman_decode_dev(c, (const uint8_t *)d_blob, (const mp3s_frame_side *)d_side, n, nch,
+                                              (int16_t *)d_is, (mp3s_granule_si *)d_si, (int32_t *)d_st);
+        int32_t st = 0;
+        if (!rc) rc = mp3s_dev_download(c, &st, d_st, sizeof st);
+        if (!rc && st) rc = fail(MP3S_E_MALFORMED, "malformed main data (status %d)", st);
+    } else {
+        if (!rc) rc = mp3s_dev_upload(c, d_is, p.is.data(), (size_t)n * 2304 * 2);
+        if (!rc) rc = mp3s_dev_upload(c, d_si, p.si.data(), (size_t)n * 4 * sizeof(mp3s_granule_si));
+    }
     for (int start = 0; start < n && !rc; start += kDecodeChunk) {
         const int halo = start ? 1 : 0, first = start - halo, cnt = std::min(kDecodeChunk, n - start) + halo;
-        std::vector<mp3s_frame_hdr> hdr(p.hdr.begin() + first, p.hdr.begin() + first + cnt);
-        for (auto &h : hdr) h.stream_first = 0;   // one stream; the halo frame rebuilds the state
-        rc = mp3s_decode_transform(c, p.is.data() + (size_t)first * 2304, p.si.data() + (size_t)first * 4, hdr.data(), cnt,
-                                   nch, halo, out_format, b->bytes.data() + (size_t)start * frame_bytes);
+        rc = mp3s_decode_transform_dev(c, (const int16_t *)d_is + (size_t)first * 2304, (const mp3s_granule_si *)d_si + (size_t)first * 4,
+                                       (const mp3s_frame_hdr *)d_hdr + first, cnt, nch, halo, out_format, d_pcm);
+        if (!rc) rc = mp3s_dev_download(c, b->bytes.data() + (size_t)start * frame_bytes, d_pcm, (size_t)(cnt - halo) * frame_bytes);
     }
+    cleanup();
     if (rc) { delete b; return rc; }
     if (p.dup_last_frame && n > 0)
         std::memcpy(b->bytes.data() + (size_t)n * frame_bytes, b->bytes.data() + (size_t)(n - 1) * frame_bytes, frame_bytes);
@@ -482,24 +562,44 @@ int mp3s_encode_pcm(mp3s_ctx *c, const int16_t *pcm, int64_t n_samples_per_ch, i
     mp3s_buf *b = nullptr;
     if (!rc) {
         b = new mp3s_buf();
-        std::vector<int16_t> ix((size_t)n * 2304);
-        rc = mp3s_dev_download(c, ix.data(), d_ix, ix.size() * 2);
-        if (!rc) rc = mp3s_dev_download(c, en.data(), d_en, en.size() * 4);
-        if (!rc) {
-            // a device log() that landed within 1e-9 of an integer is re-evaluated with glibc on the host
-            std::vector<int32_t> xr(576);
-            for (int u = 0; u < units && !rc; u++)
-                if (gr[u].flags & MP3S_RF_LOG_GUARD) {
-                    rc = mp3s_dev_download(c, xr.data(), (const int32_t *)d_mdct + (size_t)u * 576, 576 * 4);
-                    if (!rc) host_scfsi_energies(xr.data(), rf[0].sr_idx, en.data() + (size_t)u * 22);
+        // a device log() that landed within 1e-9 of an integer is re-evaluated with glibc on the host
+        std::vector<int32_t> xr(576), en1(22);
+        for (int u = 0; u < units && !rc; u++)
+            if (gr[u].flags & MP3S_RF_LOG_GUARD) {
+                rc = mp3s_dev_download(c, xr.data(), (const int32_t *)d_mdct + (size_t)u * 576, 576 * 4);
+                if (!rc) {
+                    host_scfsi_energies(xr.data(), rf[0].sr_idx, en1.data());
+                    rc = mp3s_dev_upload(c, (int32_t *)d_en + (size_t)u * 22, en1.data(), 22 * 4);
                 }
-        }
-        if (!rc) {
-            b->scfsi.assign((size_t)n * 8, 0);
-            decide_scfsi(n, en.data(), gr.data(), b->scfsi.data());
-            rc = format_stream(samplerate, bitrate_kbps, n, ix.data(), gr.data(), b->scfsi.data(), b->bytes);
-            if (rc) fail(rc, "format_stream failed");
-        }
+            }
+        // ---- bit packing on the device: final GrInfo + frame offsets up, MP3 bytes + scfsi down
+        std::vector<int32_t> padding(n);
+        std::vector<uint32_t> off((size_t)n + 1, 0);
+        std::vector<uint8_t> pad8(n);
+        int sri = 0, bri = 0, whole = 0;
+        if (!rc && stream_params(samplerate, bitrate_kbps, &sri, &bri, &whole)) rc = fail(MP3S_E_UNSUPPORTED, "bad stream parameters");
+        if (!rc) rc = rate_frames(samplerate, bitrate_kbps, nch, n, rf.data(), padding.data());
+        for (int f = 0; f < n; f++) { pad8[f] = (uint8_t)padding[f]; off[f + 1] = off[f] + (uint32_t)(whole + padding[f]); }
+        void *d_off = nullptr, *d_pad = nullptr, *d_mp3 = nullptr, *d_sc = nullptr, *d_st = nullptr;
+        if (!rc && (!alloc(&d_off, ((size_t)n + 1) * 4) || !alloc(&d_pad, (size_t)n) || !alloc(&d_mp3, (size_t)off[n] + 16) ||
+                    !alloc(&d_sc, (size_t)n * 8 * 4) || !alloc(&d_st, 16)))
+            rc = fail(MP3S_E_NOMEM, "hipMalloc failed for the packer");
+        if (!rc) rc = mp3s_dev_upload(c, d_off, off.data(), ((size_t)n + 1) * 4);
+        if (!rc) rc = mp3s_dev_upload(c, d_pad, pad8.data(), (size_t)n);
+        if (!rc) rc = mp3s_dev_upload(c, d_out, gr.data(), (size_t)units * sizeof(mp3s_gr_out));
+        if (!rc) rc = mp3s_pack_frames_dev(c, (const int16_t *)d_ix, (const mp3s_gr_out *)d_out, (const int32_t *)d_en, n, samplerate,
+                                           bitrate_kbps, (const uint32_t *)d_off, (const uint8_t *)d_pad, (uint8_t *)d_mp3,
+                                           (int32_t *)d_sc, (int32_t *)d_st);
+        int32_t st = 0;
+        if (!rc) rc = mp3s_dev_download(c, &st, d_st, sizeof st);
+        if (!rc && st) rc = fail(MP3S_E_HIP, "bit packer reported status %d", st);
+        const size_t keep = ((size_t)off[n] / 4) * 4;   // the reference drops the cached tail (< 32 bits): E14
+        b->bytes.resize(keep);
+        b->scfsi.assign((size_t)n * 8, 0);
+        if (!rc) rc = mp3s_dev_download(c, b->bytes.data(), d_mp3, keep);
+        if (!rc) rc = mp3s_dev_download(c, b->scfsi.data(), d_sc, (size_t)n * 8 * 4);
+        hipStreamSynchronize(c->stream);
+        for (void *q : {d_off, d_pad, d_mp3, d_sc, d_st}) if (q) hipFree(q);
         if (rc) { delete b; b = nullptr; }
     }
     cleanup();

@@ -12,7 +12,7 @@ constexpr int DEC_SYNTH_TW = 4;   // waves per channel in a synthesis tile (tile
 
 // optional per-kernel HIP-event timing: when non-null, every kernel launch is bracketed by two events
 // recorded on the launch stream; mp3s_profile_collect() turns the pairs into per-kernel totals.
-enum KernelId { K_DEC_IMDCT = 0, K_DEC_SYNTH, K_ENC_ANALYSIS, K_ENC_MDCT, K_RATE_LOOP, K_COUNT };
+enum KernelId { K_DEC_IMDCT = 0, K_DEC_SYNTH, K_ENC_ANALYSIS, K_ENC_MDCT, K_RATE_LOOP, K_DEC_HUFFMAN, K_ENC_PACK, K_COUNT };
 struct Profiler {
     static constexpr int MAX_PAIRS = 8192;
     hipEvent_t ev[2 * MAX_PAIRS];
@@ -41,5 +41,12 @@ int launch_encode(hipStream_t stream, const int16_t *d_pcm, const mp3s_frame_hdr
 int launch_rate(hipStream_t stream, const int32_t *d_mdct, const mp3s_rate_frame *d_frames, int n_frames,
                 const uint8_t *d_hide, int n_hide, const int32_t *d_cursor, const int32_t *d_state,
                 const int32_t *d_list, int n_list, int16_t *d_ix, mp3s_gr_out *d_out, int32_t *d_en, Profiler *prof);
+
+// bit-level stages on the device
+int launch_huffman(hipStream_t stream, const uint8_t *d_blob, const mp3s_frame_side *d_side, int n_frames, int nch,
+                   int16_t *d_is, mp3s_granule_si *d_si, int32_t *d_status, Profiler *prof);
+int launch_pack(hipStream_t stream, const int16_t *d_ix, const mp3s_gr_out *d_gr, const int32_t *d_en, int n_frames, int sri,
+                int bri, int whole_slots, const uint32_t *d_frame_off, const uint8_t *d_padding, uint8_t *d_mp3,
+                int32_t *d_scfsi, int32_t *d_status, Profiler *prof);
 
 }  // namespace mp3s

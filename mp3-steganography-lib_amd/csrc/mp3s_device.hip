@@ -14,6 +14,8 @@ __constant__ DevTables c_tab;
 #include "k_decode.hpp"
 #include "k_encode.hpp"
 #include "k_rate.hpp"
+#include "k_huffman.hpp"
+#include "k_pack.hpp"
 
 namespace mp3s {
 
@@ -112,6 +114,34 @@ int launch_rate(hipStream_t stream, const int32_t *d_mdct, const mp3s_rate_frame
     const int pp = prof ? prof->begin(stream, K_RATE_LOOP) : -1;
     hipLaunchKernelGGL(k_rate_loop, dim3((n + RL_WAVES - 1) / RL_WAVES), dim3(RL_WAVES * 64), 0, stream, d_mdct, d_frames,
                        n_units, d_hide, n_hide, d_cursor, d_state, d_list, n, d_ix, d_out, d_en);
+    if (prof) prof->end(stream, pp);
+    return (int)hipGetLastError();
+}
+
+int launch_huffman(hipStream_t stream, const uint8_t *d_blob, const mp3s_frame_side *d_side, int n_frames, int nch,
+                   int16_t *d_is, mp3s_granule_si *d_si, int32_t *d_status, Profiler *prof)
+{
+    hipError_t e = hipMemsetAsync(d_is, 0, (size_t)n_frames * 2304 * sizeof(int16_t), stream);
+    if (e == hipSuccess) e = hipMemsetAsync(d_si, 0, (size_t)n_frames * 4 * sizeof(mp3s_granule_si), stream);
+    if (e == hipSuccess) e = hipMemsetAsync(d_status, 0, sizeof(int32_t), stream);
+    if (e != hipSuccess) return (int)e;
+    const long threads = (long)n_frames * nch;
+    const int pp = prof ? prof->begin(stream, K_DEC_HUFFMAN) : -1;
+    hipLaunchKernelGGL(k_dec_huffman, dim3((unsigned)((threads + HUF_THREADS - 1) / HUF_THREADS)), dim3(HUF_THREADS), 0, stream,
+                       d_blob, d_side, n_frames, nch, d_is, d_si, d_status);
+    if (prof) prof->end(stream, pp);
+    return (int)hipGetLastError();
+}
+
+int launch_pack(hipStream_t stream, const int16_t *d_ix, const mp3s_gr_out *d_gr, const int32_t *d_en, int n_frames, int sri,
+                int bri, int whole_slots, const uint32_t *d_frame_off, const uint8_t *d_padding, uint8_t *d_mp3,
+                int32_t *d_scfsi, int32_t *d_status, Profiler *prof)
+{
+    hipError_t e = hipMemsetAsync(d_status, 0, sizeof(int32_t), stream);
+    if (e != hipSuccess) return (int)e;
+    const int pp = prof ? prof->begin(stream, K_ENC_PACK) : -1;
+    hipLaunchKernelGGL(k_enc_pack, dim3(n_frames), dim3(256), 0, stream, d_ix, d_gr, d_en, n_frames, sri, bri, whole_slots,
+                       d_frame_off, d_padding, d_mp3, d_scfsi, d_status);
     if (prof) prof->end(stream, pp);
     return (int)hipGetLastError();
 }

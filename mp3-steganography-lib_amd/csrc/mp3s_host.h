@@ -19,7 +19,17 @@ struct ParsedStream {
     std::vector<int32_t> table_select;    // [n][2][2][3]
     std::vector<int32_t> frame_size;      // [n]
 };
-int parse_stream(const uint8_t *file, size_t len, ParsedStream &out);
+// byte-level scan only (no scalefactor / Huffman decode): what the device Huffman kernel consumes
+struct ScannedStream {
+    std::vector<mp3s_frame_side> side;    // [n]
+    std::vector<uint8_t> blob;            // main data of all frames, 4-byte aligned, >= 8 zero bytes after each
+    bool gpu_ok = true;                   // false: some granule inherits scalefactors from earlier frames
+};
+// scan == nullptr: full parse (is + si); otherwise is/si stay empty and *scan is filled instead
+int parse_stream(const uint8_t *file, size_t len, ParsedStream &out, ScannedStream *scan = nullptr);
+
+// samplerate / bitrate -> header indices and whole slots per frame; non-zero if unsupported
+int stream_params(int samplerate, int bitrate_kbps, int *sri, int *bri, int *whole_slots);
 
 // per-frame padding bit and rate-loop budget (reference MP3_Encoder.py:503-513, 630-636, 894-912)
 int rate_frames(int samplerate, int bitrate_kbps, int nch, int n_frames, mp3s_rate_frame *out, int32_t *padding);

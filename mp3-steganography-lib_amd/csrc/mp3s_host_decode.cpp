@@ -162,12 +162,13 @@ struct SideInfo {          // FrameSideInformation arrays (persist across frames
 
 }  // namespace
 
-int parse_stream(const uint8_t *file, size_t flen_, ParsedStream &out)
+int parse_stream(const uint8_t *file, size_t flen_, ParsedStream &out, ScannedStream *scan)
 {
     std::call_once(g_lut_once, build_luts);
     const HostTables &HT = host_tables();
     const long flen = (long)flen_;
     out = ParsedStream();
+    if (scan) *scan = ScannedStream();
     // ID3v2 skip (decoder/ID3_Parser.py:95-131): only `offset` and `is_valid` matter to decoding
     long offset = 0;
     if (flen >= 10 && file[0] == 'I' && file[1] == 'D' && file[2] == '3' && !(file[5] & 0x0f)) {
@@ -282,6 +283,47 @@ int parse_stream(const uint8_t *file, size_t flen_, ParsedStream &out)
         }
         Bits mb{main_data.data(), (long)main_data.size()};
 
+        if (scan) {
+            // ---- scan mode: record the side info and append the main data to the blob
+            mp3s_frame_side fs;
+            std::memset(&fs, 0, sizeof fs);
+            out.table_select.resize(((size_t)out.n_frames + 1) * 12, 0);
+            while (scan->blob.size() & 3) scan->blob.push_back(0);
+            fs.md_off = (uint32_t)scan->blob.size();
+            fs.md_len = (uint32_t)main_data.size();
+            scan->blob.insert(scan->blob.end(), main_data.begin(), main_data.end());
+            scan->blob.insert(scan->blob.end(), 8, 0);
+            fs.nch = (uint8_t)nch; fs.sr_idx = (uint8_t)hd.sr_idx;
+            fs.ms_stereo = (hd.mode == 1 && hd.mode_ext0) ? 1 : 0;
+            for (int ch = 0; ch < nch; ch++)
+                for (int b = 0; b < 4; b++) fs.scfsi[ch][b] = (uint8_t)si.scfsi[ch][b];
+            for (int gr = 0; gr < 2; gr++)
+                for (int ch = 0; ch < nch; ch++) {
+                    mp3s_unit_side &u = fs.unit[gr][ch];
+                    u.part2_3_length = (uint16_t)si.part2_3_length[gr][ch]; u.big_values = (uint16_t)si.big_value[gr][ch];
+                    u.global_gain = (uint8_t)si.global_gain[gr][ch]; u.scalefac_compress = (uint8_t)si.scale_fac_compress[gr][ch];
+                    u.window_switching = (uint8_t)si.window_switching[gr][ch]; u.block_type = (uint8_t)si.block_type[gr][ch];
+                    u.mixed_block_flag = (uint8_t)si.mixed[gr][ch];
+                    for (int r = 0; r < 3; r++) u.table_select[r] = (uint8_t)si.table_select[gr][ch][r];
+                    u.region0_count = (uint8_t)si.region0[gr][ch]; u.region1_count = (uint8_t)si.region1[gr][ch];
+                    u.preflag = (uint8_t)si.preflag[gr][ch]; u.scalefac_scale = (uint8_t)si.scalefac_scale[gr][ch];
+                    u.count1table_select = (uint8_t)si.count1table[gr][ch];
+                    for (int w = 0; w < 3; w++) u.sub_block_gain[w] = (uint8_t)si.sub_block_gain[gr][ch][w];
+                    // scalefactors that requantisation would read without this frame having written them (D10):
+                    // mixed blocks, and scfsi reuse when granule 0 carried short-block scalefactors
+                    if (u.window_switching && u.mixed_block_flag) scan->gpu_ok = false;
+                    for (int r = 0; r < 3; r++)
+                        out.table_select[((size_t)out.n_frames * 4 + gr * 2 + ch) * 3 + r] = si.table_select[gr][ch][r];
+                }
+            for (int ch = 0; ch < nch; ch++) {
+                const mp3s_unit_side &g0 = fs.unit[0][ch], &g1 = fs.unit[1][ch];
+                const bool g0_short = g0.window_switching && g0.block_type == 2;
+                const bool g1_short = g1.window_switching && g1.block_type == 2;
+                if (g0_short && !g1_short && (fs.scfsi[ch][0] | fs.scfsi[ch][1] | fs.scfsi[ch][2] | fs.scfsi[ch][3]))
+                    scan->gpu_ok = false;
+            }
+            scan->side.push_back(fs);
+        } else {
         // ---- per granule*channel: scalefactors + Huffman
         const size_t f = (size_t)out.n_frames;
         out.is.resize((f + 1) * 2304, 0);
@@ -382,6 +424,7 @@ int parse_stream(const uint8_t *file, size_t flen_, ParsedStream &out)
                     for (int s = 0; s < 13; s++) g.scale_fac_s[w][s] = (uint8_t)si.sf_s[gr][ch][w][s];
                 for (int r = 0; r < 3; r++) out.table_select[(f * 4 + gr * 2 + ch) * 3 + r] = si.table_select[gr][ch][r];
             }
+        }
         mp3s_frame_hdr fh;
         fh.sr_idx = (uint8_t)hd.sr_idx; fh.nch = (uint8_t)nch;
         fh.ms_stereo = (hd.mode == 1 && hd.mode_ext0) ? 1 : 0;

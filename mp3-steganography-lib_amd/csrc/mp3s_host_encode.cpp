@@ -62,6 +62,15 @@ struct BitWriter {         // reference BitstreamStruct + __put_bits
 
 }  // namespace
 
+int stream_params(int samplerate, int bitrate_kbps, int *sri, int *bri, int *whole_slots)
+{
+    const int s = samplerate_index(samplerate), b = bitrate_index(bitrate_kbps);
+    if (s < 0 || b < 0) return 1;
+    SlotLag sl(samplerate, bitrate_kbps);
+    *sri = s; *bri = b; *whole_slots = sl.whole;
+    return 0;
+}
+
 int rate_frames(int samplerate, int bitrate_kbps, int nch, int n_frames, mp3s_rate_frame *out, int32_t *padding)
 {
     const int sri = samplerate_index(samplerate);

@@ -205,6 +205,61 @@ void build()
     }
     for (int i = 0; i < 16; i++) T.hlen_c1a[i] = ISO_HLEN_32[i];
     for (int i = 0; i < 32; i++) { T.linbits[i] = (uint8_t)H.huff[i].linbits; T.linmax[i] = H.huff[i].linmax; }
+    // ---- device Huffman decode tables
+    static const int kDecMax[32] = {1, 2, 3, 3, 0, 4, 4, 6, 6, 6, 8, 8, 8, 16, 0, 16,
+                                    16, 16, 16, 16, 16, 16, 16, 16, 16, 16, 16, 16, 16, 16, 16, 16};
+    static const int kBooks[15] = {1, 2, 3, 5, 6, 7, 8, 9, 10, 11, 12, 13, 15, 16, 24};
+    for (int t = 0; t < 32; t++) { T.huff_lut_id[t] = 255; T.dec_max[t] = (uint8_t)kDecMax[t]; }
+    for (int b = 0; b < 15; b++) {
+        const int t = kBooks[b];
+        T.huff_lut_id[t] = (uint8_t)b;
+        if (t == 16) for (int k = 16; k < 24; k++) T.huff_lut_id[k] = (uint8_t)b;
+        if (t == 24) for (int k = 24; k < 32; k++) T.huff_lut_id[k] = (uint8_t)b;
+        const HostHuff &h = H.huff[t];
+        uint16_t(*tree)[2] = T.huff_tree[b];
+        int n_nodes = 1;   // node 0 = root
+        for (int x = 0; x < kDecMax[t]; x++)
+            for (int y = 0; y < kDecMax[t]; y++) {
+                const int len = h.hlen[x * h.ylen + y];
+                const uint32_t code = h.hcod[x * h.ylen + y];
+                int node = 0;
+                for (int d = 0; d < len; d++) {
+                    const int bit = (code >> (len - 1 - d)) & 1;
+                    if (d == len - 1) { if (!tree[node][bit]) tree[node][bit] = (uint16_t)(0x8000 | (x << 4) | y); }
+                    else {
+                        if (!tree[node][bit]) tree[node][bit] = (uint16_t)n_nodes++;
+                        node = tree[node][bit];
+                        if (node & 0x8000) break;   // cannot happen for a prefix code
+                    }
+                }
+            }
+        for (uint32_t w = 0; w < 1024; w++) {
+            int node = 0;
+            uint16_t e = 0;
+            for (int d = 0; d < HUFF_FAST_BITS; d++) {
+                const uint16_t nxt = tree[node][(w >> (HUFF_FAST_BITS - 1 - d)) & 1];
+                if (!nxt) { e = 0; node = -1; break; }
+                if (nxt & 0x8000) { e = (uint16_t)(((d + 1) << 8) | (nxt & 0xff)); node = -1; break; }
+                node = nxt;
+            }
+            if (node > 0) e = (uint16_t)(0x8000 | node);
+            T.huff_fast[b][w] = e;
+        }
+    }
+    {
+        const HostHuff &q = H.huff[32];
+        for (int e = 0; e < 16; e++) {
+            const int len = q.hlen[e];
+            const uint32_t base = (uint32_t)q.hcod[e] << (6 - len);
+            for (uint32_t f = 0; f < (1u << (6 - len)); f++)
+                if (!T.quad_fast[base + f]) T.quad_fast[base + f] = (uint16_t)((len << 4) | e);
+            T.hcod_c1a[e] = (uint8_t)q.hcod[e];
+        }
+        for (int i = 0; i < 256; i++) {
+            T.hcod[0][i] = ISO_HCOD_13[i]; T.hcod[1][i] = ISO_HCOD_15[i];
+            T.hcod[2][i] = ISO_HCOD_16[i]; T.hcod[3][i] = ISO_HCOD_24[i];
+        }
+    }
 }
 
 }  // namespace

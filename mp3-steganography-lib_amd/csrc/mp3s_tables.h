@@ -45,6 +45,15 @@ struct DevTables {
     uint8_t linbits[32];
     int32_t linmax[32];
     uint8_t transform[32][2];      // reference MP3_Encoder.py:419-449
+    // ---- Huffman decode on the device (k_dec_huffman): 10-bit first-level table + binary trie for longer codes
+    uint8_t huff_lut_id[32];       // table_select -> 0..14, 255 = no code book (tables 0, 4, 14)
+    uint8_t dec_max[32];           // symbols per axis (reference decoder/tables.py:426)
+    uint16_t huff_fast[15][1024];  // leaf: (len << 8) | (x << 4) | y;  0x8000 | node: continue in the trie;  0: no code
+    uint16_t huff_tree[15][512][2];// child per bit: 0x8000 | (x << 4) | y = leaf, else node index, 0 = no code
+    uint16_t quad_fast[64];        // count1 book A on 6 bits: (len << 4) | value
+    // ---- Huffman code words for the device bit packer (k_enc_pack): books 13, 15, 16.., 24.. and count1 A
+    uint32_t hcod[4][256];
+    uint8_t hcod_c1a[16];
 };
 
 struct HostHuff {
@@ -62,5 +71,6 @@ struct HostTables {
 };
 
 const HostTables &host_tables();   // built on first use, thread-safe
+constexpr int HUFF_FAST_BITS = 10;
 
 }  // namespace mp3s

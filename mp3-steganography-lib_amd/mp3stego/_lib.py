@@ -35,6 +35,15 @@ GRANULE_SI_DTYPE = np.dtype([("global_gain", "u1"), ("scalefac_scale", "u1"), ("
 FRAME_HDR_DTYPE = np.dtype([("sr_idx", "u1"), ("nch", "u1"), ("ms_stereo", "u1"), ("flags", "u1"),
                             ("stream_first", "<u4")])
 RATE_FRAME_DTYPE = np.dtype([("max_bits", "<i4"), ("sr_idx", "<i4")])
+UNIT_SIDE_DTYPE = np.dtype([("part2_3_length", "<u2"), ("big_values", "<u2"), ("global_gain", "u1"),
+                            ("scalefac_compress", "u1"), ("window_switching", "u1"), ("block_type", "u1"),
+                            ("mixed_block_flag", "u1"), ("table_select", "u1", (3,)), ("region0_count", "u1"),
+                            ("region1_count", "u1"), ("preflag", "u1"), ("scalefac_scale", "u1"),
+                            ("count1table_select", "u1"), ("sub_block_gain", "u1", (3,))])
+FRAME_SIDE_DTYPE = np.dtype([("md_off", "<u4"), ("md_len", "<u4"), ("nch", "u1"), ("sr_idx", "u1"), ("ms_stereo", "u1"),
+                             ("flags", "u1"), ("scfsi", "u1", (2, 4)), ("unit", UNIT_SIDE_DTYPE, (2, 2)),
+                             ("reserved", "<u4")])
+assert UNIT_SIDE_DTYPE.itemsize == 20 and FRAME_SIDE_DTYPE.itemsize == 104
 GR_OUT_DTYPE = np.dtype([("part2_3_length", "<i4"), ("big_values", "<i4"), ("count1", "<i4"),
                          ("quantizer_step", "<i4"), ("region0_count", "<i4"), ("region1_count", "<i4"),
                          ("count1table_select", "<i4"), ("table_select", "<i4", (3,)), ("address", "<i4", (3,)),
@@ -47,6 +56,13 @@ class Parsed(C.Structure):
     _fields_ = [("n_frames", C.c_int32), ("nch", C.c_int32), ("sampling_rate", C.c_int32), ("bit_rate", C.c_int32),
                 ("n_bits", C.c_int32), ("dup_last_frame", C.c_int32), ("is_", C.c_void_p), ("si", C.c_void_p),
                 ("hdr", C.c_void_p), ("bits", C.c_void_p), ("table_select", C.c_void_p), ("frame_size", C.c_void_p)]
+
+
+class Scanned(C.Structure):
+    _fields_ = [("n_frames", C.c_int32), ("nch", C.c_int32), ("sampling_rate", C.c_int32), ("bit_rate", C.c_int32),
+                ("n_bits", C.c_int32), ("dup_last_frame", C.c_int32), ("gpu_ok", C.c_int32), ("side", C.c_void_p),
+                ("hdr", C.c_void_p), ("blob", C.c_void_p), ("blob_len", C.c_size_t), ("bits", C.c_void_p),
+                ("frame_size", C.c_void_p)]
 
 
 class Decoded(C.Structure):
@@ -63,7 +79,7 @@ class Encoded(C.Structure):
 SYMBOLS = ["mp3s_ctx_create", "mp3s_ctx_destroy", "mp3s_last_error", "mp3s_version", "mp3s_device_name", "mp3s_sync", "mp3s_debug_tables", "mp3s_debug_scfsi_energies",
            "mp3s_dev_alloc", "mp3s_dev_free", "mp3s_dev_upload", "mp3s_dev_download", "mp3s_dev_memset",
            "mp3s_timer_start", "mp3s_timer_stop", "mp3s_profile_enable", "mp3s_profile_collect", "mp3s_decode_transform_dev", "mp3s_decode_transform",
-           "mp3s_encode_transform_dev", "mp3s_encode_transform", "mp3s_rate_loop_dev", "mp3s_buf_free",
+           "mp3s_encode_transform_dev", "mp3s_encode_transform", "mp3s_rate_loop_dev", "mp3s_huffman_decode_dev", "mp3s_pack_frames_dev", "mp3s_scan_stream", "mp3s_buf_free",
            "mp3s_parse_stream", "mp3s_format_stream", "mp3s_rate_frames", "mp3s_decode_stream", "mp3s_encode_pcm"]
 
 _lib = None
@@ -108,6 +124,9 @@ def lib():
         L.mp3s_encode_transform_dev.argtypes = [vp, vp, vp, i32, vp]
         L.mp3s_encode_transform.argtypes = [vp, vp, vp, i32, vp]
         L.mp3s_rate_loop_dev.argtypes = [vp, vp, vp, i32, vp, i32, vp, vp, vp, i32, vp, vp, vp]
+        L.mp3s_huffman_decode_dev.argtypes = [vp, vp, vp, i32, i32, vp, vp, vp]
+        L.mp3s_pack_frames_dev.argtypes = [vp, vp, vp, vp, i32, i32, i32, vp, vp, vp, vp, vp]
+        L.mp3s_scan_stream.argtypes = [vp, sz, pvp, C.POINTER(Scanned)]
         L.mp3s_buf_free.argtypes = [vp]
         L.mp3s_buf_free.restype = None
         L.mp3s_parse_stream.argtypes = [vp, sz, pvp, C.POINTER(Parsed)]
@@ -193,16 +212,18 @@ class Context:
         check(lib().mp3s_timer_stop(self.handle, C.byref(ms)))
         return ms.value
 
-    KERNELS = ("k_dec_imdct", "k_dec_synth", "k_enc_analysis", "k_enc_mdct", "k_rate_loop")
+    KERNELS = ("k_dec_imdct", "k_dec_synth", "k_enc_analysis", "k_enc_mdct", "k_rate_loop", "k_dec_huffman",
+               "k_enc_pack")
 
     def profile_enable(self, on=True):
         check(lib().mp3s_profile_enable(self.handle, 1 if on else 0))
 
     def profile_collect(self):
         """{kernel: (total_ms, launches)} since profile_enable()"""
-        ms = np.zeros(5, dtype=np.float64)
-        cnt = np.zeros(5, dtype=np.int64)
-        check(lib().mp3s_profile_collect(self.handle, ms.ctypes.data, cnt.ctypes.data, 5))
+        nk = len(self.KERNELS)
+        ms = np.zeros(nk, dtype=np.float64)
+        cnt = np.zeros(nk, dtype=np.int64)
+        check(lib().mp3s_profile_collect(self.handle, ms.ctypes.data, cnt.ctypes.data, nk))
         return {k: (float(ms[i]), int(cnt[i])) for i, k in enumerate(self.KERNELS)}
 
     # ---- batch entry points on host arrays
@@ -279,6 +300,23 @@ def parse_stream(data: bytes):
         lib().mp3s_buf_free(owner)
 
 
+def scan_stream(data: bytes):
+    """Host byte-level scan only (no GPU): frame side info + main-data blob for the device Huffman kernel."""
+    buf = np.frombuffer(data, dtype=np.uint8)
+    owner = C.c_void_p()
+    p = Scanned()
+    check(lib().mp3s_scan_stream(buf.ctypes.data, len(data), C.byref(owner), C.byref(p)))
+    try:
+        n = p.n_frames
+        return {"n_frames": n, "channels": p.nch, "sampling_rate": p.sampling_rate, "bit_rate": p.bit_rate,
+                "dup_last_frame": p.dup_last_frame, "gpu_ok": bool(p.gpu_ok),
+                "side": _view(p.side, FRAME_SIDE_DTYPE, (n,)), "hdr": _view(p.hdr, FRAME_HDR_DTYPE, (n,)),
+                "blob": _view(p.blob, np.uint8, (p.blob_len,)), "bits": _view(p.bits, np.uint8, (p.n_bits,)),
+                "frame_size": _view(p.frame_size, np.int32, (n,))}
+    finally:
+        lib().mp3s_buf_free(owner)
+
+
 def rate_frames(samplerate, bitrate, nch, n_frames):
     out = np.zeros(n_frames, dtype=RATE_FRAME_DTYPE)
     pad = np.zeros(n_frames, dtype=np.int32)
@@ -309,7 +347,9 @@ DEV_TABLES_DTYPE = np.dtype([
     ("mdct_ca", "<i4", (8,)), ("steptab", "<f8", (128,)), ("steptabi", "<i4", (128,)), ("int2idx", "<u2", (10000,)),
     ("sfb_long", "<i4", (3, 23)), ("subdv", "<i4", (23, 2)), ("subdiv_lut", "<u4", (3, 289)), ("hlen13", "u1", (256,)), ("hlen15", "u1", (256,)),
     ("hlen16", "u1", (256,)), ("hlen24", "u1", (256,)), ("hlen_c1a", "u1", (16,)), ("linbits", "u1", (32,)),
-    ("linmax", "<i4", (32,)), ("transform", "u1", (32, 2))], align=True)
+    ("linmax", "<i4", (32,)), ("transform", "u1", (32, 2)), ("huff_lut_id", "u1", (32,)), ("dec_max", "u1", (32,)),
+    ("huff_fast", "<u2", (15, 1024)), ("huff_tree", "<u2", (15, 512, 2)), ("quad_fast", "<u2", (64,)),
+    ("hcod", "<u4", (4, 256)), ("hcod_c1a", "u1", (16,))], align=True)
 
 
 def debug_tables():

@@ -1,0 +1,112 @@
+"""Bit-level stages: host scan on CPU; device Huffman decode / bit packing against the host stages
+and the oracle on the GPU."""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+
+
+def test_scan_stream_cpu(mlib, orc, golden_dir):
+    """byte-level scan = the parse without the Huffman part: same frames, stego bits, table indices; blob holds the
+    main data of every frame, 4-byte aligned and zero padded"""
+    for data in (open(os.path.join(golden_dir, "test.mp3"), "rb").read(),
+                 np.load(os.path.join(golden_dir, "g6_synth128.npz"))["mp3"].tobytes()):
+        p = mlib.parse_stream(data)
+        s = mlib.scan_stream(data)
+        assert s["gpu_ok"] and s["n_frames"] == p["n_frames"] and s["channels"] == p["channels"]
+        assert np.array_equal(s["bits"], p["bits"]) and np.array_equal(s["frame_size"], p["frame_size"])
+        assert np.array_equal(s["hdr"], p["hdr"])
+        side = s["side"]
+        assert np.array_equal(side["unit"]["table_select"], p["table_select"])
+        assert np.array_equal(side["unit"]["global_gain"], p["si"]["global_gain"])
+        assert (side["md_off"] % 4 == 0).all()
+        off = 0
+        for f in range(s["n_frames"]):
+            n = int(p["frame_size"][f]) - 36          # no CRC, stereo, no reservoir: main data = frame - header - side info
+            start = int(side["md_off"][f])
+            assert int(side["md_len"][f]) == min(n, len(data) - off - 36)
+            ln = int(side["md_len"][f])
+            assert bytes(s["blob"][start:start + ln]) == data[off + 36: off + 36 + ln]
+            assert not s["blob"][start + ln:start + ln + 8].any()
+            off += int(p["frame_size"][f])
+
+
+@pytest.mark.gpu
+def test_device_huffman_matches_host_parser(ctx, mlib, orc, golden_dir):
+    L = mlib.lib()
+    from synth_pcm import synth_pcm
+    streams = [open(os.path.join(golden_dir, "test.mp3"), "rb").read(),
+               np.load(os.path.join(golden_dir, "g6_synth128.npz"))["mp3"].tobytes()]
+    for rate, kbps, n in ((44100, 64, 300), (48000, 192, 300), (32000, 320, 200)):
+        streams.append(ctx.encode_pcm(synth_pcm(n, rate=rate), rate, kbps, None)["mp3"])
+    streams.append(streams[1][:-150])                               # truncated last frame: bits past the end read as 0
+    for data in streams:
+        p = mlib.parse_stream(data)
+        s = mlib.scan_stream(data)
+        n, nch = s["n_frames"], s["channels"]
+        d_blob, d_side = ctx.to_device(s["blob"]), ctx.to_device(s["side"])
+        d_is, d_si, d_st = ctx.alloc(n * 2304 * 2), ctx.alloc(n * 4 * 72), ctx.alloc(4)
+        mlib.check(L.mp3s_huffman_decode_dev(ctx.handle, d_blob, d_side, n, nch, d_is, d_si, d_st))
+        ctx.sync()
+        assert int(ctx.download(d_st, np.int32, (1,))[0]) == 0
+        isv = ctx.download(d_is, np.int16, (n, 2, 2, 576))
+        si = ctx.download(d_si, mlib.GRANULE_SI_DTYPE, (n, 2, 2))
+        assert np.array_equal(isv, p["is"])
+        for k in ("global_gain", "scalefac_scale", "block_type", "mixed_block_flag", "preflag", "sub_block_gain",
+                  "scale_fac_l", "scale_fac_s"):
+            assert np.array_equal(si[k], p["si"][k]), k
+        # the decoded batch feeds the transform kernels directly
+        d_hdr, d_pcm = ctx.to_device(s["hdr"]), ctx.alloc(n * 1152 * nch * 8)
+        mlib.check(L.mp3s_decode_transform_dev(ctx.handle, d_is, d_si, d_hdr, n, nch, 0, mlib.MP3S_PCM_F64, d_pcm))
+        ctx.sync()
+        pcm = ctx.download(d_pcm, np.float64, (n * 1152, nch))
+        assert pcm.tobytes() == orc.decode(data)["pcm"][:n * 1152].tobytes()
+        for q in (d_blob, d_side, d_is, d_si, d_st, d_hdr, d_pcm):
+            ctx.free(q)
+
+
+@pytest.mark.gpu
+def test_device_packer_matches_host_formatter(ctx, mlib, orc, golden_dir):
+    L = mlib.lib()
+    from synth_pcm import synth_pcm
+    g6 = np.load(os.path.join(golden_dir, "g6_synth128.npz"))
+    cases = [(g6["pcm"], 44100, 128, g6["hide_bits"]),
+             (np.load(os.path.join(golden_dir, "g3_testmp3_wav_pcm.npz"))["pcm"], 44100, 320, None),
+             (synth_pcm(200, rate=48000), 48000, 96, g6["hide_bits"]),
+             (synth_pcm(120, rate=32000), 32000, 320, None),
+             (np.zeros((5 * 1152, 2), dtype=np.int16), 44100, 128, None)]
+    for pcm, rate, kbps, hide in cases:
+        o = orc.encode(pcm, rate, kbps, hide)
+        n = o["n_frames"]
+        units = n * 4
+        # final GrInfo in unit order (frame, ch, gr) from the oracle; part2_3_length WITHOUT stuffing is not kept by
+        # the reference, so feed the stuffed values minus the stuffing the packer will re-derive: use the raw rate-loop
+        # output of the device instead
+        res = ctx.encode_pcm(pcm, rate, kbps, hide)
+        assert res["mp3"] == o["mp3"]
+        gr = res["gr"]
+        rf, pad = mlib.rate_frames(rate, kbps, 2, n)
+        whole = len(o["mp3"])  # noqa: F841
+        sizes = np.array([int(o["frames"]["written"][f]) for f in range(n)])  # noqa: F841
+        slots = (kbps * 1000 * 1152 // 8) // rate
+        fsz = slots + pad
+        off = np.concatenate([[0], np.cumsum(fsz)]).astype(np.uint32)
+        ix = o["ix"].astype(np.int16)
+        # energies: re-run the rate loop on the device to get them
+        mdct = ctx.encode_transform(pcm)
+        d_mdct, d_rf = ctx.to_device(mdct), ctx.to_device(rf)
+        d_ix, d_out, d_en = ctx.alloc(units * 576 * 2), ctx.alloc(units * 72), ctx.alloc(units * 22 * 4)
+        mlib.check(L.mp3s_rate_loop_dev(ctx.handle, d_mdct, d_rf, n, None, 0, None, None, None, 0, d_ix, d_out, d_en))
+        d_ixf, d_gr = ctx.to_device(ix), ctx.to_device(gr)
+        d_off, d_pad = ctx.to_device(off), ctx.to_device(pad.astype(np.uint8))
+        d_mp3, d_sc, d_st = ctx.alloc(int(off[-1]) + 16), ctx.alloc(n * 8 * 4), ctx.alloc(4)
+        mlib.check(L.mp3s_pack_frames_dev(ctx.handle, d_ixf, d_gr, d_en, n, rate, kbps, d_off, d_pad, d_mp3, d_sc, d_st))
+        ctx.sync()
+        assert int(ctx.download(d_st, np.int32, (1,))[0]) == 0
+        out = ctx.download(d_mp3, np.uint8, (int(off[-1]),)).tobytes()
+        keep = (len(out) // 4) * 4                                   # the reference drops the cached tail (E14)
+        assert out[:keep] == o["mp3"]
+        assert np.array_equal(ctx.download(d_sc, np.int32, (n, 2, 4)), o["frames"]["scfsi"])
+        for q in (d_mdct, d_rf, d_ix, d_out, d_en, d_ixf, d_gr, d_off, d_pad, d_mp3, d_sc, d_st):
+            ctx.free(q)
