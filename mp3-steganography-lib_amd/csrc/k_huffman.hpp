@@ -2,9 +2,9 @@
 //
 //   k_dec_huffman : __unpack_scale_fac + __unpack_samples (reference decoder/Frame.py:365-559) for every
 //                   granule*channel of the batch.  The bit stream of a granule is serial, but granule boundaries
-//                   come from the side info (part2_3_length), so one THREAD decodes one (frame, channel) -- both
-//                   granules, because granule 1 may reuse granule 0's scalefactors (scfsi) -- and a 10 000-frame
-//                   batch gives 20 000 independent threads.  Code books: 10-bit first-level table in LDS, binary
+//                   come from the side info (part2_3_length), so one THREAD decodes one granule*channel (granule 1
+//                   re-reads the scalefactors scfsi lets it share with granule 0 from granule 0's own bits): a
+//                   10 000-frame batch gives 40 000 independent threads.  Code books: 10-bit first-level table in LDS, binary
 //                   trie in global memory for the rare longer codes (same prefix codes the reference searches
 //                   linearly, so the same symbol and length come out).  Quirks kept: D1 (count1 stops at line 572,
 //                   no overrun discard), D2 (books 4/14 read no bits), bits past the buffer read as 0.
@@ -15,7 +15,7 @@ namespace mp3s {
 struct BitReader {
     const uint32_t *w;   // 4-byte aligned main data of the frame
     uint32_t len;        // valid bytes; everything after reads as zero (decoder/util.py:41-43)
-    uint32_t wi, w0, w1; // cached big-endian words wi, wi+1
+    uint32_t wi, w0, w1, w2; // cached big-endian words wi, wi+1 and the prefetched wi+2
     __device__ __forceinline__ uint32_t word(uint32_t i) const
     {
         const uint32_t byte0 = i * 4;
@@ -25,98 +25,124 @@ struct BitReader {
         if (valid < 4) v &= 0xffffffffu << (8 * (4 - valid));
         return v;
     }
-    __device__ __forceinline__ void init(const uint8_t *p, uint32_t n)
+    __device__ __forceinline__ void seek(uint32_t pos)
     {
-        w = reinterpret_cast<const uint32_t *>(p); len = n; wi = 0; w0 = word(0); w1 = word(1);
+        wi = pos >> 5; w0 = word(wi); w1 = word(wi + 1); w2 = word(wi + 2);
+    }
+    __device__ __forceinline__ void init(const uint8_t *p, uint32_t n, uint32_t pos)
+    {
+        w = reinterpret_cast<const uint32_t *>(p); len = n; seek(pos);
     }
     __device__ __forceinline__ uint32_t peek32(uint32_t pos)
     {
         const uint32_t i = pos >> 5, sh = pos & 31;
         if (i != wi) {
-            if (i == wi + 1) { w0 = w1; w1 = word(i + 1); } else { w0 = word(i); w1 = word(i + 1); }
-            wi = i;
+            if (i == wi + 1) { w0 = w1; w1 = w2; w2 = word(i + 2); wi = i; }   // the load of w2 is not needed until
+            else seek(pos);                                                      // 32 more bits have been consumed
         }
         return sh ? (w0 << sh) | (w1 >> (32 - sh)) : w0;
     }
     __device__ __forceinline__ uint32_t get(uint32_t pos, int n) { return n ? peek32(pos) >> (32 - n) : 0u; }
 };
 
-constexpr int HUF_THREADS = 256;
+constexpr int HUF_THREADS = 64;
 
+// one thread per granule*channel; unit index = (frame*2 + gr)*2 + ch (same order as the si / is arrays)
 __global__ __launch_bounds__(HUF_THREADS) void k_dec_huffman(
     const uint8_t *__restrict__ blob, const mp3s_frame_side *__restrict__ side, int n_frames, int nch,
     int16_t *__restrict__ is, mp3s_granule_si *__restrict__ si_out, int32_t *__restrict__ status)
 {
     __shared__ uint16_t fast[15][1024];
-    for (int i = threadIdx.x; i < 15 * 1024; i += blockDim.x) (&fast[0][0])[i] = (&c_tab.huff_fast[0][0])[i];
+    __shared__ uint16_t quad[64];
+    {
+        const uint4 *src = reinterpret_cast<const uint4 *>(&c_tab.huff_fast[0][0]);
+        uint4 *dst = reinterpret_cast<uint4 *>(&fast[0][0]);
+        for (int i = threadIdx.x; i < 15 * 1024 * 2 / 16; i += blockDim.x) dst[i] = src[i];
+        if (threadIdx.x < 64) quad[threadIdx.x] = c_tab.quad_fast[threadIdx.x];
+    }
     __syncthreads();
     const long tid = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (tid >= (long)n_frames * nch) return;
-    const int f = (int)(tid / nch), ch = (int)(tid % nch);
+    if (tid >= (long)n_frames * 4) return;
+    const int f = (int)(tid >> 2), gr = (int)((tid >> 1) & 1), ch = (int)(tid & 1);
+    if (ch >= nch) return;
     const mp3s_frame_side *fs = side + f;
     static const uint8_t kSlen[16][2] = {{0, 0}, {0, 1}, {0, 2}, {0, 3}, {3, 0}, {1, 1}, {1, 2}, {1, 3},
                                          {2, 1}, {2, 2}, {2, 3}, {3, 1}, {3, 2}, {3, 3}, {4, 2}, {4, 3}};
-    BitReader br;
-    br.init(blob + fs->md_off, fs->md_len);
     const int sr = fs->sr_idx < 3 ? fs->sr_idx : 0;
-    uint32_t bit = 0;
-    int err = 0;
-    for (int gr = 0; gr < 2; gr++)
+    // bit offset of this unit and (for scfsi) of granule 0 of the same channel: units are laid out gr-major
+    uint32_t bit = 0, bit_g0 = 0;
+    for (int g2 = 0; g2 < 2; g2++)
         for (int c = 0; c < nch; c++) {
-            const mp3s_unit_side u = fs->unit[gr][c];
-            const uint32_t max_bit = bit + u.part2_3_length;
-            if (c != ch) { bit = max_bit; continue; }
-            uint8_t *g = reinterpret_cast<uint8_t *>(si_out + ((long)f * 2 + gr) * 2 + ch);
-            uint32_t *gw = reinterpret_cast<uint32_t *>(g);
-#pragma unroll
-            for (int k = 0; k < 18; k++) gw[k] = 0;
-            g[0] = u.global_gain; g[1] = u.scalefac_scale; g[2] = u.block_type; g[3] = u.mixed_block_flag; g[4] = u.preflag;
-            g[5] = u.sub_block_gain[0]; g[6] = u.sub_block_gain[1]; g[7] = u.sub_block_gain[2];
-            uint8_t *sf_l = g + 8, *sf_s = g + 30;   // scale_fac_l[22], scale_fac_s[3][13]
-            const int sl0 = kSlen[u.scalefac_compress & 15][0], sl1 = kSlen[u.scalefac_compress & 15][1];
-            // ---- scalefactors (Frame.py:365-441)
-            if (u.block_type == 2 && u.window_switching) {
-                if (u.mixed_block_flag) {
-                    for (int s = 0; s < 8; s++) { sf_l[s] = (uint8_t)br.get(bit, sl0); bit += sl0; }
-                    for (int s = 3; s < 6; s++)
-                        for (int w = 0; w < 3; w++) { sf_s[w * 13 + s] = (uint8_t)br.get(bit, sl0); bit += sl0; }
-                } else {
-                    for (int s = 0; s < 6; s++)
-                        for (int w = 0; w < 3; w++) { sf_s[w * 13 + s] = (uint8_t)br.get(bit, sl0); bit += sl0; }
-                }
-                for (int s = 6; s < 12; s++)
-                    for (int w = 0; w < 3; w++) { sf_s[w * 13 + s] = (uint8_t)br.get(bit, sl1); bit += sl1; }
-            } else if (gr == 0) {
-                for (int s = 0; s < 11; s++) { sf_l[s] = (uint8_t)br.get(bit, sl0); bit += sl0; }
-                for (int s = 11; s < 21; s++) { sf_l[s] = (uint8_t)br.get(bit, sl1); bit += sl1; }
-            } else {
-                const uint8_t *g0 = reinterpret_cast<const uint8_t *>(si_out + ((long)f * 2 + 0) * 2 + ch) + 8;
-                for (int b = 0; b < 4; b++) {
-                    const int lo = b == 0 ? 0 : 1 + 5 * b, hi = 6 + 5 * b, sl = b < 2 ? sl0 : sl1;   // 0-6-11-16-21
-                    for (int s = lo; s < hi; s++) {
-                        if (fs->scfsi[ch][b]) sf_l[s] = g0[s];
-                        else { sf_l[s] = (uint8_t)br.get(bit, sl); bit += sl; }
-                    }
-                }
-            }
-            // ---- big values (Frame.py:458-518)
-            int16_t *smp = is + (((long)f * 2 + gr) * 2 + ch) * 576;
-            int region0, region1;
-            if (u.window_switching && u.block_type == 2) { region0 = 36; region1 = 576; }
-            else {
-                const int i0 = u.region0_count + 1, i1 = i0 + u.region1_count + 1;
-                if (i0 > 22 || i1 > 22) { err |= MP3S_HS_BAD_REGION; bit = max_bit; continue; }
-                region0 = c_tab.sfb_long[sr][i0]; region1 = c_tab.sfb_long[sr][i1];
-            }
-            int sample = 0;
-            const int bv2 = (int)u.big_values * 2;
-            while (sample < bv2) {
+            if (g2 == 0 && c < ch) bit_g0 += fs->unit[0][c].part2_3_length;
+            if (g2 * 2 + c < gr * 2 + ch) bit += fs->unit[g2][c].part2_3_length;
+        }
+    const mp3s_unit_side u = fs->unit[gr][ch];
+    const uint32_t max_bit = bit + u.part2_3_length;
+    int err = 0;
+    BitReader br;
+    uint8_t *g = reinterpret_cast<uint8_t *>(si_out + tid);
+    g[0] = u.global_gain; g[1] = u.scalefac_scale; g[2] = u.block_type; g[3] = u.mixed_block_flag; g[4] = u.preflag;
+    g[5] = u.sub_block_gain[0]; g[6] = u.sub_block_gain[1]; g[7] = u.sub_block_gain[2];
+    uint8_t *sf_l = g + 8, *sf_s = g + 30;   // scale_fac_l[22], scale_fac_s[3][13]; the record was zeroed by the launcher
+    const int sl0 = kSlen[u.scalefac_compress & 15][0], sl1 = kSlen[u.scalefac_compress & 15][1];
+    // ---- scalefactors (Frame.py:365-441)
+    if (gr == 1 && !(u.block_type == 2 && u.window_switching) &&
+        (fs->scfsi[ch][0] | fs->scfsi[ch][1] | fs->scfsi[ch][2] | fs->scfsi[ch][3])) {
+        // bands flagged by scfsi are copied from granule 0 (:423-437): decode them from granule 0's own bits
+        const mp3s_unit_side u0 = fs->unit[0][ch];
+        const int z0 = kSlen[u0.scalefac_compress & 15][0], z1 = kSlen[u0.scalefac_compress & 15][1];
+        br.init(blob + fs->md_off, fs->md_len, bit_g0);
+        uint32_t b0 = bit_g0;
+        for (int s = 0; s < 21; s++) {
+            const int sl = s < 11 ? z0 : z1;
+            const int band = s < 6 ? 0 : (s < 11 ? 1 : (s < 16 ? 2 : 3));
+            const uint32_t v = br.get(b0, sl); b0 += sl;
+            if (fs->scfsi[ch][band]) sf_l[s] = (uint8_t)v;
+        }
+    }
+    br.init(blob + fs->md_off, fs->md_len, bit);
+    if (u.block_type == 2 && u.window_switching) {
+        if (u.mixed_block_flag) {
+            for (int s = 0; s < 8; s++) { sf_l[s] = (uint8_t)br.get(bit, sl0); bit += sl0; }
+            for (int s = 3; s < 6; s++)
+                for (int w = 0; w < 3; w++) { sf_s[w * 13 + s] = (uint8_t)br.get(bit, sl0); bit += sl0; }
+        } else {
+            for (int s = 0; s < 6; s++)
+                for (int w = 0; w < 3; w++) { sf_s[w * 13 + s] = (uint8_t)br.get(bit, sl0); bit += sl0; }
+        }
+        for (int s = 6; s < 12; s++)
+            for (int w = 0; w < 3; w++) { sf_s[w * 13 + s] = (uint8_t)br.get(bit, sl1); bit += sl1; }
+    } else if (gr == 0) {
+        for (int s = 0; s < 11; s++) { sf_l[s] = (uint8_t)br.get(bit, sl0); bit += sl0; }
+        for (int s = 11; s < 21; s++) { sf_l[s] = (uint8_t)br.get(bit, sl1); bit += sl1; }
+    } else {
+        for (int s = 0; s < 21; s++) {
+            const int band = s < 6 ? 0 : (s < 11 ? 1 : (s < 16 ? 2 : 3)), sl = s < 11 ? sl0 : sl1;
+            if (!fs->scfsi[ch][band]) { sf_l[s] = (uint8_t)br.get(bit, sl); bit += sl; }
+        }
+    }
+    // ---- big values (Frame.py:458-518)
+    int16_t *smp = is + tid * 576;
+    int region0, region1;
+    bool ok = true;
+    if (u.window_switching && u.block_type == 2) { region0 = 36; region1 = 576; }
+    else {
+        const int i0 = u.region0_count + 1, i1 = i0 + u.region1_count + 1;
+        if (i0 > 22 || i1 > 22) { err |= MP3S_HS_BAD_REGION; ok = false; region0 = region1 = 0; }
+        else { region0 = c_tab.sfb_long[sr][i0]; region1 = c_tab.sfb_long[sr][i1]; }
+    }
+    if (ok) {
+        int sample = 0;
+        const int bv2 = (int)u.big_values * 2;
+        for (int r = 0; r < 3 && sample < bv2; r++) {
+            const int rend = r == 0 ? region0 : (r == 1 ? region1 : 1 << 30);
+            const int tn = u.table_select[r] & 31;
+            const int lut = c_tab.huff_lut_id[tn], lb = c_tab.linbits[tn];
+            while (sample < bv2 && sample < rend) {
                 if (sample + 1 >= 576) { err |= MP3S_HS_BIG_VALUES; break; }
-                const int tn = u.table_select[sample < region0 ? 0 : (sample < region1 ? 1 : 2)] & 31;
-                const int lut = c_tab.huff_lut_id[tn];
                 if (lut == 255) { sample += 2; continue; }        // books 0, 4, 14: zeros, no bits (D2)
                 const uint32_t window = br.peek32(bit);
-                uint32_t e = fast[lut][window >> 22];
+                const uint32_t e = fast[lut][window >> 22];
                 int len = 0, sym = -1;
                 if (e & 0x8000u) {                                // continue in the trie below the 10-bit prefix
                     uint32_t node = e & 0x7fffu;
@@ -129,7 +155,6 @@ __global__ __launch_bounds__(HUF_THREADS) void k_dec_huffman(
                 } else if (e) { sym = e & 0xff; len = e >> 8; }
                 if (sym >= 0) {
                     bit += len;
-                    const int lb = c_tab.linbits[tn];
                     int v0 = sym >> 4, v1 = sym & 15;
                     if (lb && v0 == 15) { v0 += (int)br.get(bit, lb); bit += lb; }
                     if ((sym >> 4) > 0) { if (br.get(bit, 1)) v0 = -v0; bit += 1; }
@@ -139,29 +164,30 @@ __global__ __launch_bounds__(HUF_THREADS) void k_dec_huffman(
                 }
                 sample += 2;
             }
-            // ---- count1 quadruples (Frame.py:521-554, D1)
-            while (!(err & MP3S_HS_BIG_VALUES) && bit < max_bit && sample + 4 < 576) {
-                int val;
-                if (u.count1table_select) { val = (int)(br.get(bit, 4) ^ 15u); bit += 4; }
-                else {
-                    const uint32_t s = c_tab.quad_fast[br.get(bit, 6)];
-                    val = s ? (int)(s & 15) : 0;
-                    bit += s >> 4;
-                }
-                int q[4];
-#pragma unroll
-                for (int i = 0; i < 4; i++) {
-                    q[i] = (val >> (3 - i)) & 1;
-                    if (q[i]) { if (br.get(bit, 1)) q[i] = -1; bit += 1; }
-                }
-                if (val) {
-                    *reinterpret_cast<uint32_t *>(smp + sample) = (uint32_t)(uint16_t)q[0] | ((uint32_t)(uint16_t)q[1] << 16);
-                    *reinterpret_cast<uint32_t *>(smp + sample + 2) = (uint32_t)(uint16_t)q[2] | ((uint32_t)(uint16_t)q[3] << 16);
-                }
-                sample += 4;
-            }
-            bit = max_bit;
+            if (err) break;
         }
+        // ---- count1 quadruples (Frame.py:521-554, D1)
+        while (!err && bit < max_bit && sample + 4 < 576) {
+            int val;
+            if (u.count1table_select) { val = (int)(br.get(bit, 4) ^ 15u); bit += 4; }
+            else {
+                const uint32_t s = quad[br.get(bit, 6)];
+                val = s ? (int)(s & 15) : 0;
+                bit += s >> 4;
+            }
+            int q[4];
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                q[i] = (val >> (3 - i)) & 1;
+                if (q[i]) { if (br.get(bit, 1)) q[i] = -1; bit += 1; }
+            }
+            if (val) {
+                *reinterpret_cast<uint32_t *>(smp + sample) = (uint32_t)(uint16_t)q[0] | ((uint32_t)(uint16_t)q[1] << 16);
+                *reinterpret_cast<uint32_t *>(smp + sample + 2) = (uint32_t)(uint16_t)q[2] | ((uint32_t)(uint16_t)q[3] << 16);
+            }
+            sample += 4;
+        }
+    }
     if (err) atomicOr(status, err);
 }
 

@@ -125,7 +125,7 @@ int launch_huffman(hipStream_t stream, const uint8_t *d_blob, const mp3s_frame_s
     if (e == hipSuccess) e = hipMemsetAsync(d_si, 0, (size_t)n_frames * 4 * sizeof(mp3s_granule_si), stream);
     if (e == hipSuccess) e = hipMemsetAsync(d_status, 0, sizeof(int32_t), stream);
     if (e != hipSuccess) return (int)e;
-    const long threads = (long)n_frames * nch;
+    const long threads = (long)n_frames * 4;
     const int pp = prof ? prof->begin(stream, K_DEC_HUFFMAN) : -1;
     hipLaunchKernelGGL(k_dec_huffman, dim3((unsigned)((threads + HUF_THREADS - 1) / HUF_THREADS)), dim3(HUF_THREADS), 0, stream,
                        d_blob, d_side, n_frames, nch, d_is, d_si, d_status);
