@@ -194,9 +194,19 @@ __global__ __launch_bounds__(256) void k_enc_pack(
             lds_put(fb, s, n == 32 ? 0xffffffffu : ((1u << n) - 1), (int)n);
         }
     __syncthreads();
+    // ---- LDS image -> global bytes: unaligned head / tail as bytes, the aligned interior as dwords
     const int nbytes = whole_slots + pad;
-    uint8_t *out = mp3 + frame_off[f];
-    for (int k = threadIdx.x; k < nbytes; k += 256) out[k] = (uint8_t)(fb[k >> 2] >> (24 - 8 * (k & 3)));
+    const uint32_t off = frame_off[f];
+    auto byte_at = [&](int k) -> uint32_t { return (fb[k >> 2] >> (24 - 8 * (k & 3))) & 0xffu; };
+    const int head = (int)((4u - (off & 3u)) & 3u) < nbytes ? (int)((4u - (off & 3u)) & 3u) : nbytes;
+    const int n_dw = (nbytes - head) >> 2, tail0 = head + 4 * n_dw;
+    if ((int)threadIdx.x < head) mp3[off + threadIdx.x] = (uint8_t)byte_at(threadIdx.x);
+    uint32_t *outw = reinterpret_cast<uint32_t *>(mp3 + off + head);
+    for (int j = threadIdx.x; j < n_dw; j += 256) {
+        const int k = head + 4 * j;
+        outw[j] = byte_at(k) | (byte_at(k + 1) << 8) | (byte_at(k + 2) << 16) | (byte_at(k + 3) << 24);
+    }
+    if ((int)threadIdx.x < nbytes - tail0) mp3[off + tail0 + threadIdx.x] = (uint8_t)byte_at(tail0 + threadIdx.x);
 }
 
 }  // namespace mp3s
