@@ -12,59 +12,70 @@
 
 namespace mp3s {
 
+constexpr int HUF_THREADS = 64;
+constexpr int HUF_WORDS = 132;   // 4095 bits of part2_3_length + alignment slack, per thread
+
+// global-memory word fetch: big-endian, bytes past `len` read as zero (decoder/util.py:41-43)
+__device__ __forceinline__ uint32_t md_word(const uint32_t *w, uint32_t len, uint32_t i)
+{
+    const uint32_t byte0 = i * 4;
+    if (byte0 >= len) return 0;
+    uint32_t v = __builtin_bswap32(w[i]);
+    const uint32_t valid = len - byte0;          // 1..3: mask the bytes past the end
+    if (valid < 4) v &= 0xffffffffu << (8 * (4 - valid));
+    return v;
+}
+__device__ __forceinline__ uint32_t md_get(const uint32_t *w, uint32_t len, uint32_t pos, int n)
+{
+    if (!n) return 0;
+    const uint32_t i = pos >> 5, sh = pos & 31;
+    const uint32_t w0 = md_word(w, len, i), w1 = md_word(w, len, i + 1);
+    return (sh ? (w0 << sh) | (w1 >> (32 - sh)) : w0) >> (32 - n);
+}
+
+// Bit reader over the lane's column of LDS: the words covering this granule's bits are copied there up front, so the
+// decode loop touches no global memory except its (never waited for) stores.
 struct BitReader {
-    const uint32_t *w;   // 4-byte aligned main data of the frame
-    uint32_t len;        // valid bytes; everything after reads as zero (decoder/util.py:41-43)
-    uint32_t wi, w0, w1, w2; // cached big-endian words wi, wi+1 and the prefetched wi+2
-    __device__ __forceinline__ uint32_t word(uint32_t i) const
+    const uint32_t *lds;   // word j of this lane at lds[j * HUF_THREADS]
+    uint32_t base;         // index of the first staged word
+    __device__ __forceinline__ uint64_t peek64(uint32_t pos) const
     {
-        const uint32_t byte0 = i * 4;
-        if (byte0 >= len) return 0;
-        uint32_t v = __builtin_bswap32(w[i]);
-        const uint32_t valid = len - byte0;          // 1..3: mask the bytes past the end
-        if (valid < 4) v &= 0xffffffffu << (8 * (4 - valid));
-        return v;
+        uint32_t j = (pos >> 5) - base;
+        const uint32_t sh = pos & 31;
+        j = j < HUF_WORDS - 3 ? j : HUF_WORDS - 3;   // malformed streams may run past part2_3_length: stay inside the column
+        const uint32_t w0 = lds[j * HUF_THREADS], w1 = lds[(j + 1) * HUF_THREADS], w2 = lds[(j + 2) * HUF_THREADS];
+        const uint32_t hi = sh ? (w0 << sh) | (w1 >> (32 - sh)) : w0;
+        const uint32_t lo = sh ? (w1 << sh) | (w2 >> (32 - sh)) : w1;
+        return ((uint64_t)hi << 32) | lo;
     }
-    __device__ __forceinline__ void seek(uint32_t pos)
-    {
-        wi = pos >> 5; w0 = word(wi); w1 = word(wi + 1); w2 = word(wi + 2);
-    }
-    __device__ __forceinline__ void init(const uint8_t *p, uint32_t n, uint32_t pos)
-    {
-        w = reinterpret_cast<const uint32_t *>(p); len = n; seek(pos);
-    }
-    __device__ __forceinline__ uint32_t peek32(uint32_t pos)
-    {
-        const uint32_t i = pos >> 5, sh = pos & 31;
-        if (i != wi) {
-            if (i == wi + 1) { w0 = w1; w1 = w2; w2 = word(i + 2); wi = i; }   // the load of w2 is not needed until
-            else seek(pos);                                                      // 32 more bits have been consumed
-        }
-        return sh ? (w0 << sh) | (w1 >> (32 - sh)) : w0;
-    }
-    __device__ __forceinline__ uint32_t get(uint32_t pos, int n) { return n ? peek32(pos) >> (32 - n) : 0u; }
+    __device__ __forceinline__ uint32_t peek32(uint32_t pos) const { return (uint32_t)(peek64(pos) >> 32); }
+    __device__ __forceinline__ uint32_t get(uint32_t pos, int n) const { return n ? peek32(pos) >> (32 - n) : 0u; }
 };
 
-constexpr int HUF_THREADS = 64;
 
 // one thread per granule*channel; unit index = (frame*2 + gr)*2 + ch (same order as the si / is arrays)
 __global__ __launch_bounds__(HUF_THREADS) void k_dec_huffman(
-    const uint8_t *__restrict__ blob, const mp3s_frame_side *__restrict__ side, int n_frames, int nch,
+    const uint8_t *__restrict__ blob, const mp3s_frame_side *__restrict__ side, int n_frames, int nch, int active,
     int16_t *__restrict__ is, mp3s_granule_si *__restrict__ si_out, int32_t *__restrict__ status)
 {
     __shared__ uint16_t fast[15][1024];
     __shared__ uint16_t quad[64];
+    __shared__ uint32_t words[HUF_WORDS * HUF_THREADS];
     {
         const uint4 *src = reinterpret_cast<const uint4 *>(&c_tab.huff_fast[0][0]);
         uint4 *dst = reinterpret_cast<uint4 *>(&fast[0][0]);
-        for (int i = threadIdx.x; i < 15 * 1024 * 2 / 16; i += blockDim.x) dst[i] = src[i];
-        if (threadIdx.x < 64) quad[threadIdx.x] = c_tab.quad_fast[threadIdx.x];
+#pragma unroll 6
+        for (int i = threadIdx.x; i < 15 * 1024 * 2 / 16; i += HUF_THREADS) dst[i] = src[i];
+        quad[threadIdx.x & 63] = c_tab.quad_fast[threadIdx.x & 63];
     }
     __syncthreads();
-    const long tid = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (tid >= (long)n_frames * 4) return;
+    // only `active` lanes of the wave decode: every lane walks its own bit stream, so a wave runs as long as its
+    // slowest lane and pays every lane's branches; with few waves to spare, narrower waves finish sooner
+    const long tid0 = (long)blockIdx.x * active;
+    const long tid = tid0 + threadIdx.x;
+    const bool worker = (int)threadIdx.x < active && tid < (long)n_frames * 4 && (int)(tid & 1) < nch;
+    if (worker) {
     const int f = (int)(tid >> 2), gr = (int)((tid >> 1) & 1), ch = (int)(tid & 1);
-    if (ch >= nch) return;
     const mp3s_frame_side *fs = side + f;
     static const uint8_t kSlen[16][2] = {{0, 0}, {0, 1}, {0, 2}, {0, 3}, {3, 0}, {1, 1}, {1, 2}, {1, 3},
                                          {2, 1}, {2, 2}, {2, 3}, {3, 1}, {3, 2}, {3, 3}, {4, 2}, {4, 3}};
@@ -79,7 +90,15 @@ __global__ __launch_bounds__(HUF_THREADS) void k_dec_huffman(
     const mp3s_unit_side u = fs->unit[gr][ch];
     const uint32_t max_bit = bit + u.part2_3_length;
     int err = 0;
+    const uint32_t *mdw = reinterpret_cast<const uint32_t *>(blob + fs->md_off);
+    const uint32_t md_len = fs->md_len;
     BitReader br;
+    br.lds = words + threadIdx.x;
+    br.base = bit >> 5;
+    {
+        const uint32_t nw = ((max_bit + 63) >> 5) - br.base + 3;
+        for (uint32_t j = 0; j < nw && j < HUF_WORDS; j++) words[j * HUF_THREADS + threadIdx.x] = md_word(mdw, md_len, br.base + j);
+    }
     uint8_t *g = reinterpret_cast<uint8_t *>(si_out + tid);
     g[0] = u.global_gain; g[1] = u.scalefac_scale; g[2] = u.block_type; g[3] = u.mixed_block_flag; g[4] = u.preflag;
     g[5] = u.sub_block_gain[0]; g[6] = u.sub_block_gain[1]; g[7] = u.sub_block_gain[2];
@@ -91,16 +110,14 @@ __global__ __launch_bounds__(HUF_THREADS) void k_dec_huffman(
         // bands flagged by scfsi are copied from granule 0 (:423-437): decode them from granule 0's own bits
         const mp3s_unit_side u0 = fs->unit[0][ch];
         const int z0 = kSlen[u0.scalefac_compress & 15][0], z1 = kSlen[u0.scalefac_compress & 15][1];
-        br.init(blob + fs->md_off, fs->md_len, bit_g0);
         uint32_t b0 = bit_g0;
         for (int s = 0; s < 21; s++) {
             const int sl = s < 11 ? z0 : z1;
             const int band = s < 6 ? 0 : (s < 11 ? 1 : (s < 16 ? 2 : 3));
-            const uint32_t v = br.get(b0, sl); b0 += sl;
+            const uint32_t v = md_get(mdw, md_len, b0, sl); b0 += sl;
             if (fs->scfsi[ch][band]) sf_l[s] = (uint8_t)v;
         }
     }
-    br.init(blob + fs->md_off, fs->md_len, bit);
     if (u.block_type == 2 && u.window_switching) {
         if (u.mixed_block_flag) {
             for (int s = 0; s < 8; s++) { sf_l[s] = (uint8_t)br.get(bit, sl0); bit += sl0; }
@@ -122,7 +139,7 @@ __global__ __launch_bounds__(HUF_THREADS) void k_dec_huffman(
         }
     }
     // ---- big values (Frame.py:458-518)
-    int16_t *smp = is + tid * 576;
+    uint32_t *smp = reinterpret_cast<uint32_t *>(is) + tid * 288;   // pair j; the buffer was zeroed by the launcher
     int region0, region1;
     bool ok = true;
     if (u.window_switching && u.block_type == 2) { region0 = 36; region1 = 576; }
@@ -141,7 +158,8 @@ __global__ __launch_bounds__(HUF_THREADS) void k_dec_huffman(
             while (sample < bv2 && sample < rend) {
                 if (sample + 1 >= 576) { err |= MP3S_HS_BIG_VALUES; break; }
                 if (lut == 255) { sample += 2; continue; }        // books 0, 4, 14: zeros, no bits (D2)
-                const uint32_t window = br.peek32(bit);
+                const uint64_t win64 = br.peek64(bit);
+                const uint32_t window = (uint32_t)(win64 >> 32);
                 const uint32_t e = fast[lut][window >> 22];
                 int len = 0, sym = -1;
                 if (e & 0x8000u) {                                // continue in the trie below the 10-bit prefix
@@ -154,13 +172,16 @@ __global__ __launch_bounds__(HUF_THREADS) void k_dec_huffman(
                     }
                 } else if (e) { sym = e & 0xff; len = e >> 8; }
                 if (sym >= 0) {
-                    bit += len;
+                    // linbits and sign bits follow the code word: x linbits, x sign, y linbits, y sign (:499-513)
+                    uint64_t rest = win64 << len;
+                    int used = len;
                     int v0 = sym >> 4, v1 = sym & 15;
-                    if (lb && v0 == 15) { v0 += (int)br.get(bit, lb); bit += lb; }
-                    if ((sym >> 4) > 0) { if (br.get(bit, 1)) v0 = -v0; bit += 1; }
-                    if (lb && v1 == 15) { v1 += (int)br.get(bit, lb); bit += lb; }
-                    if ((sym & 15) > 0) { if (br.get(bit, 1)) v1 = -v1; bit += 1; }
-                    if (v0 | v1) *reinterpret_cast<uint32_t *>(smp + sample) = (uint32_t)(uint16_t)v0 | ((uint32_t)(uint16_t)v1 << 16);
+                    if (lb && v0 == 15) { v0 += (int)(rest >> (64 - lb)); rest <<= lb; used += lb; }
+                    if ((sym >> 4) > 0) { if (rest >> 63) v0 = -v0; rest <<= 1; used += 1; }
+                    if (lb && v1 == 15) { v1 += (int)(rest >> (64 - lb)); rest <<= lb; used += lb; }
+                    if ((sym & 15) > 0) { if (rest >> 63) v1 = -v1; used += 1; }
+                    bit += used;
+                    if (v0 | v1) smp[sample >> 1] = (uint32_t)(uint16_t)v0 | ((uint32_t)(uint16_t)v1 << 16);
                 }
                 sample += 2;
             }
@@ -168,27 +189,31 @@ __global__ __launch_bounds__(HUF_THREADS) void k_dec_huffman(
         }
         // ---- count1 quadruples (Frame.py:521-554, D1)
         while (!err && bit < max_bit && sample + 4 < 576) {
-            int val;
-            if (u.count1table_select) { val = (int)(br.get(bit, 4) ^ 15u); bit += 4; }
+            uint32_t window = br.peek32(bit);
+            int val, used;
+            if (u.count1table_select) { val = (int)((window >> 28) ^ 15u); used = 4; }
             else {
-                const uint32_t s = quad[br.get(bit, 6)];
+                const uint32_t s = quad[window >> 26];
                 val = s ? (int)(s & 15) : 0;
-                bit += s >> 4;
+                used = (int)(s >> 4);
             }
+            window <<= used;
             int q[4];
 #pragma unroll
             for (int i = 0; i < 4; i++) {
                 q[i] = (val >> (3 - i)) & 1;
-                if (q[i]) { if (br.get(bit, 1)) q[i] = -1; bit += 1; }
+                if (q[i]) { if (window >> 31) q[i] = -1; window <<= 1; used += 1; }
             }
+            bit += used;
             if (val) {
-                *reinterpret_cast<uint32_t *>(smp + sample) = (uint32_t)(uint16_t)q[0] | ((uint32_t)(uint16_t)q[1] << 16);
-                *reinterpret_cast<uint32_t *>(smp + sample + 2) = (uint32_t)(uint16_t)q[2] | ((uint32_t)(uint16_t)q[3] << 16);
+                smp[sample >> 1] = (uint32_t)(uint16_t)q[0] | ((uint32_t)(uint16_t)q[1] << 16);
+                smp[(sample >> 1) + 1] = (uint32_t)(uint16_t)q[2] | ((uint32_t)(uint16_t)q[3] << 16);
             }
             sample += 4;
         }
     }
     if (err) atomicOr(status, err);
+    }   // worker
 }
 
 }  // namespace mp3s

@@ -2,6 +2,7 @@
 // launchers.  Compiled for gfx950 only (hipcc --offload-arch=gfx950 -ffp-contract=off).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 #include "../../include/mp3s.h"
 #include "mp3s_device.h"
@@ -125,10 +126,13 @@ int launch_huffman(hipStream_t stream, const uint8_t *d_blob, const mp3s_frame_s
     if (e == hipSuccess) e = hipMemsetAsync(d_si, 0, (size_t)n_frames * 4 * sizeof(mp3s_granule_si), stream);
     if (e == hipSuccess) e = hipMemsetAsync(d_status, 0, sizeof(int32_t), stream);
     if (e != hipSuccess) return (int)e;
-    const long threads = (long)n_frames * 4;
+    // lanes per wave that decode (see the kernel); narrower waves only paid off before the per-workgroup staging
+    const long units = (long)n_frames * 4;
+    int active = 64;
+    if (const char *e = getenv("MP3S_HUF_ACTIVE")) { const int a = atoi(e); if (a >= 1 && a <= 64) active = a; }
     const int pp = prof ? prof->begin(stream, K_DEC_HUFFMAN) : -1;
-    hipLaunchKernelGGL(k_dec_huffman, dim3((unsigned)((threads + HUF_THREADS - 1) / HUF_THREADS)), dim3(HUF_THREADS), 0, stream,
-                       d_blob, d_side, n_frames, nch, d_is, d_si, d_status);
+    hipLaunchKernelGGL(k_dec_huffman, dim3((unsigned)((units + active - 1) / active)), dim3(HUF_THREADS), 0, stream,
+                       d_blob, d_side, n_frames, nch, active, d_is, d_si, d_status);
     if (prof) prof->end(stream, pp);
     return (int)hipGetLastError();
 }
