@@ -475,6 +475,30 @@ def gen_synth():
     print("synth decode:", len(dec["bits"]), "bits", f"{time.time() - t0:.1f}s")
 
 
+# --------------------------------------------------------------------------
+# G7  synthetic decode-only corpus: short/start/stop/mixed blocks, MS, mono, CRC, reservoir, ID3, books 4/14
+# --------------------------------------------------------------------------
+def gen_corpus():
+    sys.path.insert(0, os.path.dirname(HERE))
+    import frame_synth
+    out = {}
+    for name, data in frame_synth.corpus().items():
+        t0 = time.time()
+        mp3 = os.path.join(WORK, name + ".mp3")
+        with open(mp3, "wb") as f:
+            f.write(data)
+        dec, pcm = decode_instrumented(mp3, os.path.join(WORK, name + ".wav"), keep_pcm_frames=2)
+        out[name + "__mp3"] = np.frombuffer(data, dtype=np.uint8)
+        for k in ("is", "bits", "kbps", "pcm_sha256", "pcm_i16_sha256", "wav_sha256", "pcm_head", "main_data_begin",
+                  "frame_size", "table_select", "si_block_type", "si_mixed_block_flag", "scale_fac_l", "scale_fac_s"):
+            out[name + "__" + k] = dec[k]
+        out[name + "__pcm_rows"] = np.int64(pcm.shape[0])
+        out[name + "__nch"] = np.int64(pcm.shape[1])
+        print("corpus", name, "frames", dec["is"].shape[0], "rows", pcm.shape, "max|pcm|", float(np.abs(pcm).max()),
+              f"{time.time() - t0:.1f}s")
+    np.savez_compressed(os.path.join(HERE, "g7_decode_corpus.npz"), **out)
+
+
 if __name__ == "__main__":
     what = sys.argv[1:] or ["tables", "decode", "encode"]
     for w in what:

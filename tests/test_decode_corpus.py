@@ -1,0 +1,104 @@
+"""Decode-side corpus the reference encoder cannot produce (BASELINE config 5): short / start / stop /
+mixed blocks, MS stereo, mono, CRC, bit reservoir, ID3 tag, code books 4/14, PCM far outside [-1, 1].
+Streams come from tests/frame_synth.py; the expected output is the reference's own decode (gen_golden.py corpus)."""
+import hashlib
+import os
+
+import numpy as np
+import pytest
+
+
+def sha(b):
+    return hashlib.sha256(bytes(b)).hexdigest()
+
+
+@pytest.fixture(scope="module")
+def corpus(golden_dir):
+    g = np.load(os.path.join(golden_dir, "g7_decode_corpus.npz"))
+    names = sorted({k.split("__")[0] for k in g.files})
+    return g, names
+
+
+def test_synthesiser_is_reproducible(corpus):
+    """the committed streams are what tests/frame_synth.py generates (seeded)"""
+    import frame_synth
+    g, names = corpus
+    fresh = frame_synth.corpus()
+    assert sorted(fresh) == names
+    for n in names:
+        assert fresh[n] == g[n + "__mp3"].tobytes(), n
+
+
+def test_oracle_decodes_corpus_like_reference(orc, corpus):
+    g, names = corpus
+    for n in names:
+        r = orc.decode(g[n + "__mp3"].tobytes())
+        assert r["rc"] == 0, n
+        assert np.array_equal(r["is"], g[n + "__is"]), n
+        assert np.array_equal(r["bits"], g[n + "__bits"]), n
+        assert r["pcm"].shape == (int(g[n + "__pcm_rows"]), int(g[n + "__nch"]))
+        assert np.array_equal(r["pcm"][:2 * 1152], g[n + "__pcm_head"]), n
+        assert sha(np.ascontiguousarray(r["pcm"]).tobytes()) == bytes(g[n + "__pcm_sha256"]).decode(), n
+        i16 = orc.pcm_to_i16(r["pcm"])
+        assert sha(i16.tobytes()) == bytes(g[n + "__pcm_i16_sha256"]).decode(), n     # wrap-around, no clipping (D13)
+        assert sha(orc.wav_bytes(i16, r["sampling_rate"])) == bytes(g[n + "__wav_sha256"]).decode(), n
+        assert np.array_equal(r["frames"]["main_data_begin"], g[n + "__main_data_begin"])
+        assert r["bit_rate"] // 1000 == int(g[n + "__kbps"])
+
+
+def test_host_parser_on_corpus(mlib, corpus):
+    g, names = corpus
+    for n in names:
+        data = g[n + "__mp3"].tobytes()
+        p = mlib.parse_stream(data)
+        assert np.array_equal(p["is"], g[n + "__is"]), n
+        assert np.array_equal(p["bits"], g[n + "__bits"]), n
+        assert np.array_equal(p["frame_size"], g[n + "__frame_size"]), n
+        nch = p["channels"]
+        assert np.array_equal(p["si"]["scale_fac_l"][:, :, :nch], g[n + "__scale_fac_l"][:, :, :nch]), n
+        assert np.array_equal(p["si"]["scale_fac_s"][:, :, :nch], g[n + "__scale_fac_s"][:, :, :nch]), n
+        s = mlib.scan_stream(data)
+        # streams with mixed blocks inherit scalefactors across frames: the scan sends them to the host parser
+        assert s["gpu_ok"] == (not g[n + "__si_mixed_block_flag"].any()), n
+        assert np.array_equal(s["bits"], p["bits"]) and s["n_frames"] == p["n_frames"]
+
+
+@pytest.mark.gpu
+def test_device_decode_of_corpus(ctx, mlib, corpus):
+    g, names = corpus
+    for n in names:
+        data = g[n + "__mp3"].tobytes()
+        r = ctx.decode_stream(data, mlib.MP3S_PCM_F64)
+        assert np.array_equal(r["bits"], g[n + "__bits"]), n
+        assert r["pcm"].shape == (int(g[n + "__pcm_rows"]), int(g[n + "__nch"]))
+        assert sha(r["pcm"].tobytes()) == bytes(g[n + "__pcm_sha256"]).decode(), n
+        r16 = ctx.decode_stream(data, mlib.MP3S_PCM_I16)
+        assert sha(r16["pcm"].tobytes()) == bytes(g[n + "__pcm_i16_sha256"]).decode(), n
+
+
+@pytest.mark.gpu
+def test_device_huffman_on_corpus(ctx, mlib, corpus):
+    """the Huffman kernel alone, also on the streams the pipeline would send to the host parser: `is` must match
+    everywhere (only inherited scalefactors can differ there)"""
+    L = mlib.lib()
+    g, names = corpus
+    for n in names:
+        data = g[n + "__mp3"].tobytes()
+        s = mlib.scan_stream(data)
+        nf, nch = s["n_frames"], s["channels"]
+        d_blob, d_side = ctx.to_device(s["blob"]), ctx.to_device(s["side"])
+        d_is, d_si, d_st = ctx.alloc(nf * 2304 * 2), ctx.alloc(nf * 4 * 72), ctx.alloc(4)
+        mlib.check(L.mp3s_huffman_decode_dev(ctx.handle, d_blob, d_side, nf, nch, d_is, d_si, d_st))
+        ctx.sync()
+        assert int(ctx.download(d_st, np.int32, (1,))[0]) == 0
+        isv = ctx.download(d_is, np.int16, (nf, 2, 2, 576))
+        assert np.array_equal(isv[:, :, :nch], g[n + "__is"][:, :, :nch]), n
+        if s["gpu_ok"]:
+            si = ctx.download(d_si, mlib.GRANULE_SI_DTYPE, (nf, 2, 2))
+            p = mlib.parse_stream(data)
+            bt2 = (p["si"]["block_type"] == 2)[:, :, :nch]
+            # entries the requantiser reads: long scalefactors of non-short granules, short ones of short granules
+            assert np.array_equal(si["scale_fac_l"][:, :, :nch][~bt2], p["si"]["scale_fac_l"][:, :, :nch][~bt2]), n
+            assert np.array_equal(si["scale_fac_s"][:, :, :nch][bt2], p["si"]["scale_fac_s"][:, :, :nch][bt2]), n
+        for q in (d_blob, d_side, d_is, d_si, d_st):
+            ctx.free(q)
