@@ -187,6 +187,9 @@ def main():
     value = n * world / max_step
 
     # ---------------------------------------------------------------- roofline of the dominant kernel
+    t_dec0 = time.time()
+    _ = ctx.decode_stream(enc0["mp3"], _lib.MP3S_PCM_I16)
+    t_dec_stream = time.time() - t_dec0
     t_scan0 = time.time()
     _ = _lib.scan_stream(enc0["mp3"])
     t_scan = time.time() - t_scan0
@@ -203,7 +206,12 @@ def main():
     tj = os.path.join(ROOT, "profiles", "traffic_latest.json")
     if os.path.exists(tj):
         try:
-            traffic = json.load(open(tj)).get(dom)
+            tr = json.load(open(tj))
+            # PMC bytes per launch (2 x FETCH_SIZE + WRITE_SIZE, separate rocprofv3 --pmc passes) measured on the
+            # `frames` batch recorded in the file; scaled to this run's batch
+            traffic = tr.get(dom)
+            if traffic is not None:
+                traffic = round(traffic * n / tr.get("frames", 10000))
         except Exception:
             traffic = None
     roofline = {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -233,7 +241,7 @@ def main():
             "metric": METRIC, "value": round(value, 1), "unit": "frames/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(max_step * 1e3, 4), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f64 (decode) / int32 (encode)", "data": "synthetic",
-            "config": {"workload": "10k-frame full decode->stego-embed->re-encode pipeline on 1xMI355X (BASELINE "
+            "config": {"workload": f"{n}-frame full decode->stego-embed->re-encode pipeline on 1xMI355X (BASELINE "
                                    "configs[2]); MP3 main data + side info resident in HBM, MP3 frames out", "frames_per_gpu": n,
                        "sample_rate": 44100, "channels": 2, "bitrate_kbps": 128, "message_bits": int(len(hide)),
                        "rate_loop_rerun_units": int(len(redo_list)), "pipeline_rate_passes": int(final["rate_passes"]),
@@ -248,7 +256,9 @@ def main():
             "e2e": {"note": "single host thread, measured once outside the timed region; the stream pipelines use the "
                             "byte-level scan + device kernels, the full host parser / formatter are the fallback",
                     "host_scan_s": round(t_scan, 3), "host_full_parse_s": round(t_parse, 3),
-                    "host_bit_packing_s": round(t_format, 3), "encode_pcm_pipeline_s": round(t_pipe_host, 3)},
+                    "host_bit_packing_s": round(t_format, 3), "encode_pcm_pipeline_s": round(t_pipe_host, 3),
+                    "decode_stream_pipeline_s": round(t_dec_stream, 3),
+                    "pcie_inclusive_frames_per_s": round(n / (t_dec_stream + t_pipe_host), 1)},
             "device": ctx.device_name(),
         }
         print(json.dumps(out))
