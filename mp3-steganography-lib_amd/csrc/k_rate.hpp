@@ -342,13 +342,14 @@ __global__ __launch_bounds__(RL_WAVES * 64, 4) void k_rate_loop(
             flags |= MP3S_RF_ACTIVE;
             // ---- __bin_search_step_size (:958-996)
             int next = -120, count = 120;
+            int body_step = 1 << 20, body_bits = 0;   // step whose quantisation + rl_body results are still in ix / st
             do {
                 const int half = count / 2;
                 const int q = rl_quantize(tb, xa, ix, next + half, xrmax);
                 int bit;
                 if (q < 0) { err = true; break; }
-                if (q > 8192) bit = 100000;
-                else bit = rl_body(tb, pcode, ix, lane, sr, st, hide, n_hide, cursor);
+                if (q > 8192) { bit = 100000; if (q != 16384) body_step = 1 << 20; }   // 16384 = early out, ix untouched
+                else { bit = rl_body(tb, pcode, ix, lane, sr, st, hide, n_hide, cursor); body_step = next + half; body_bits = bit; }
                 if (bit < max_bits) count = half;
                 else { next += half; count -= half; }
             } while (count > 1);
@@ -357,6 +358,15 @@ __global__ __launch_bounds__(RL_WAVES * 64, 4) void k_rate_loop(
             if (!err) {
                 if (max_bits < 0) qstep -= 1;
                 do {
+                    if (qstep + 1 == body_step) {
+                        // the reference re-quantises the step the binary search probed last and gets the same ix, GrInfo
+                        // and bit count again (rl_body is a pure function of ix, the cursor and -- only when
+                        // big_values == 0 -- the addresses it leaves untouched): reuse them
+                        qstep += 1;
+                        bits = body_bits;
+                        body_step = 1 << 20;
+                        continue;
+                    }
                     int q;
                     while ((q = rl_quantize(tb, xa, ix, qstep + 1, xrmax)) > 8192) qstep += 1;
                     if (q < 0) { err = true; break; }

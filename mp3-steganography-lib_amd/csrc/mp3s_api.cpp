@@ -43,6 +43,20 @@ struct mp3s_ctx {
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     void *scratch = nullptr; size_t scratch_bytes = 0;
     Profiler prof;
+    // device buffers of the stream pipelines, kept between calls (hipMalloc/hipFree cost more than a small file's work)
+    static constexpr int kPoolSlots = 24;
+    void *pool[kPoolSlots] = {nullptr};
+    size_t pool_bytes[kPoolSlots] = {0};
+    void *grab(int slot, size_t bytes)
+    {
+        if (bytes < 16) bytes = 16;
+        if (pool_bytes[slot] >= bytes) return pool[slot];
+        if (pool[slot]) { hipStreamSynchronize(stream); hipFree(pool[slot]); pool[slot] = nullptr; pool_bytes[slot] = 0; }
+        const size_t want = bytes + bytes / 4;   // head room: similar-sized files reuse the buffer
+        if (hipMalloc(&pool[slot], want) != hipSuccess) { pool[slot] = nullptr; return nullptr; }
+        pool_bytes[slot] = want;
+        return pool[slot];
+    }
     int ensure_scratch(size_t bytes)
     {
         if (bytes <= scratch_bytes) return 0;
@@ -116,6 +130,7 @@ void mp3s_ctx_destroy(mp3s_ctx *c)
     hipSetDevice(c->device);
     if (c->stream) hipStreamSynchronize(c->stream);
     if (c->scratch) hipFree(c->scratch);
+    for (void *q : c->pool) if (q) hipFree(q);
     if (c->ev0) hipEventDestroy(c->ev0);
     if (c->ev1) hipEventDestroy(c->ev1);
     if (c->stream) hipStreamDestroy(c->stream);
@@ -423,11 +438,9 @@ int mp3s_decode_stream(mp3s_ctx *c, const uint8_t *file, size_t len, int out_for
     for (auto &h : p.hdr) h.stream_first = 0;   // one stream; chunks after the first re-run one halo frame
     void *d_is = nullptr, *d_si = nullptr, *d_hdr = nullptr, *d_pcm = nullptr, *d_blob = nullptr, *d_side = nullptr,
          *d_st = nullptr;
-    auto cleanup = [&]() {
-        hipStreamSynchronize(c->stream);
-        for (void *q : {d_is, d_si, d_hdr, d_pcm, d_blob, d_side, d_st}) if (q) hipFree(q);
-    };
-    auto alloc = [&](void **q, size_t bytes) { return hipMalloc(q, bytes ? bytes : 16) == hipSuccess; };
+    auto cleanup = [&]() { hipStreamSynchronize(c->stream); };   // the buffers stay in the context's pool
+    int slot = 0;
+    auto alloc = [&](void **q, size_t bytes) { *q = c->grab(slot++, bytes); return *q != nullptr; };
     const int chunk = std::min(n, kDecodeChunk) + 1;
     if (!alloc(&d_is, (size_t)n * 2304 * 2) || !alloc(&d_si, (size_t)n * 4 * sizeof(mp3s_granule_si)) ||
         !alloc(&d_hdr, (size_t)n * sizeof(mp3s_frame_hdr)) || !alloc(&d_pcm, (size_t)chunk * frame_bytes) || !alloc(&d_st, 16) ||
@@ -484,11 +497,9 @@ int mp3s_encode_pcm(mp3s_ctx *c, const int16_t *pcm, int64_t n_samples_per_ch, i
     for (auto &h : hdr) { h.sr_idx = (uint8_t)rf[0].sr_idx; h.nch = 2; h.ms_stereo = 0; h.flags = 0; h.stream_first = 0; }
     void *d_pcm = nullptr, *d_hdr = nullptr, *d_mdct = nullptr, *d_rf = nullptr, *d_hide = nullptr, *d_cur = nullptr,
          *d_state = nullptr, *d_list = nullptr, *d_ix = nullptr, *d_out = nullptr, *d_en = nullptr;
-    auto cleanup = [&]() {
-        hipStreamSynchronize(c->stream);
-        for (void *p : {d_pcm, d_hdr, d_mdct, d_rf, d_hide, d_cur, d_state, d_list, d_ix, d_out, d_en}) if (p) hipFree(p);
-    };
-    auto alloc = [&](void **p, size_t bytes) { return hipMalloc(p, bytes ? bytes : 16) == hipSuccess; };
+    auto cleanup = [&]() { hipStreamSynchronize(c->stream); };   // the buffers stay in the context's pool
+    int slot = 8;
+    auto alloc = [&](void **p, size_t bytes) { *p = c->grab(slot++, bytes); return *p != nullptr; };
     if (!alloc(&d_pcm, (size_t)n * 2304 * 2) || !alloc(&d_hdr, (size_t)n * sizeof(mp3s_frame_hdr)) ||
         !alloc(&d_mdct, (size_t)n * 2304 * 4) || !alloc(&d_rf, (size_t)n * sizeof(mp3s_rate_frame)) ||
         !alloc(&d_hide, (size_t)n_hide) || !alloc(&d_cur, (size_t)units * 4) || !alloc(&d_state, (size_t)units * 16) ||
@@ -599,7 +610,6 @@ int mp3s_encode_pcm(mp3s_ctx *c, const int16_t *pcm, int64_t n_samples_per_ch, i
         if (!rc) rc = mp3s_dev_download(c, b->bytes.data(), d_mp3, keep);
         if (!rc) rc = mp3s_dev_download(c, b->scfsi.data(), d_sc, (size_t)n * 8 * 4);
         hipStreamSynchronize(c->stream);
-        for (void *q : {d_off, d_pad, d_mp3, d_sc, d_st}) if (q) hipFree(q);
         if (rc) { delete b; b = nullptr; }
     }
     cleanup();
