@@ -87,7 +87,7 @@ __global__ __launch_bounds__(HUF_THREADS) void k_dec_huffman(
             if (g2 == 0 && c < ch) bit_g0 += fs->unit[0][c].part2_3_length;
             if (g2 * 2 + c < gr * 2 + ch) bit += fs->unit[g2][c].part2_3_length;
         }
-    const mp3s_unit_side u = fs->unit[gr][ch];
+    const mp3s_unit_side &u = fs->unit[gr][ch];
     const uint32_t max_bit = bit + u.part2_3_length;
     int err = 0;
     const uint32_t *mdw = reinterpret_cast<const uint32_t *>(blob + fs->md_off);
@@ -153,7 +153,7 @@ __global__ __launch_bounds__(HUF_THREADS) void k_dec_huffman(
         const int bv2 = (int)u.big_values * 2;
         for (int r = 0; r < 3 && sample < bv2; r++) {
             const int rend = r == 0 ? region0 : (r == 1 ? region1 : 1 << 30);
-            const int tn = u.table_select[r] & 31;
+            const int tn = (r == 0 ? u.table_select[0] : (r == 1 ? u.table_select[1] : u.table_select[2])) & 31;
             const int lut = c_tab.huff_lut_id[tn], lb = c_tab.linbits[tn];
             while (sample < bv2 && sample < rend) {
                 if (sample + 1 >= 576) { err |= MP3S_HS_BIG_VALUES; break; }

@@ -47,20 +47,25 @@ __global__ __launch_bounds__(256) void k_enc_pack(
         const int bits_per_frame = 8 * (whole_slots + pad);
         const int mean_bits = (bits_per_frame - 288) / 2;
         int p[4], sum = 0;   // emission order e = gr*2 + ch
+#pragma unroll
         for (int e = 0; e < 4; e++) { p[e] = gr[((long)f * 2 + (e & 1)) * 2 + (e >> 1)].part2_3_length; sum += p[e]; }
         int stuffing = 2 * mean_bits - sum + ((mean_bits & 1) ? 1 : 0);
         if (stuffing < 0) stuffing = 0;
         if (stuffing) {
             if (p[0] + stuffing < 4095) p[0] += stuffing;
             else
-                for (int e = 0; e < 4 && stuffing; e++) {
+#pragma unroll
+                for (int e = 0; e < 4; e++) {
+                    if (!stuffing) break;
                     const int extra = 4095 - p[e], now = extra < stuffing ? extra : stuffing;
                     p[e] += now; stuffing -= now;
                 }
         }
+#pragma unroll
         for (int e = 0; e < 4; e++) p23f[e] = p[e];
         // ---- scfsi (:861-892) from the band energies of the two granules of each channel
         int sc[2][4];
+#pragma unroll
         for (int ch = 0; ch < 2; ch++) {
             const long u0 = ((long)f * 2 + ch) * 2, u1 = u0 + 1;
             const int32_t *e0 = en + u0 * 22, *e1 = en + u1 * 22;
@@ -70,6 +75,7 @@ __global__ __launch_bounds__(256) void k_enc_pack(
             int tp = 0;
             for (int s = 0; s < 21; s++) { int a = e0[s] - e1[s]; tp += a < 0 ? -a : a; }
             if (tp < 100) cond++;
+#pragma unroll
             for (int b = 0; b < 4; b++) {
                 int v = 0;
                 if (cond == 6) {
@@ -88,7 +94,11 @@ __global__ __launch_bounds__(256) void k_enc_pack(
         put(0x7ff, 11); put(3, 2); put(1, 2); put(1, 1); put(bri, 4); put(sri % 3, 2); put(pad, 1); put(0, 1);
         put(0, 2); put(0, 2); put(0, 1); put(1, 1); put(0, 2);
         put(0, 9); put(0, 3);
-        for (int ch = 0; ch < 2; ch++) for (int b = 0; b < 4; b++) put(sc[ch][b], 1);
+#pragma unroll
+        for (int ch = 0; ch < 2; ch++)
+#pragma unroll
+            for (int b = 0; b < 4; b++) put(sc[ch][b], 1);
+#pragma unroll
         for (int e = 0; e < 4; e++) {
             const mp3s_gr_out &g = gr[((long)f * 2 + (e & 1)) * 2 + (e >> 1)];
             put(p[e], 12); put(g.big_values, 9); put((uint32_t)(g.quantizer_step + 210) & 0xff, 8); put(0, 4); put(0, 1);
@@ -101,9 +111,11 @@ __global__ __launch_bounds__(256) void k_enc_pack(
     // ---- main data of this wave's granule*channel (:1394-1446)
     const int e = wave, grn = e >> 1, ch = e & 1;
     const long u = ((long)f * 2 + ch) * 2 + grn;
-    const mp3s_gr_out g = gr[u];
+    const mp3s_gr_out &g = gr[u];
+    const int ts0 = g.table_select[0], ts1 = g.table_select[1], ts2 = g.table_select[2], c1sel = g.count1table_select;
     uint32_t ustart = 288;
-    for (int k = 0; k < e; k++) ustart += (uint32_t)p23f[k];
+#pragma unroll
+    for (int k = 0; k < 3; k++) ustart += k < e ? (uint32_t)p23f[k] : 0u;
     const int bv = g.big_values, c1 = g.count1;
     const int32_t *sfb = c_tab.sfb_long[sri];
     const int r1s = sfb[g.region0_count + 1], r2s = sfb[g.region0_count + 1 + g.region1_count + 1];
@@ -135,7 +147,7 @@ __global__ __launch_bounds__(256) void k_enc_pack(
         code0[k] = code1[k] = 0; n0[k] = n1[k] = 0;
         if (p < bv) {
             const int i = 2 * p;
-            const int ti = g.table_select[(i >= r1s) + (i >= r2s)];
+            const int ti = i >= r2s ? ts2 : (i >= r1s ? ts1 : ts0);
             if (ti) {
                 const int fam = ti == 13 ? 0 : (ti == 15 ? 1 : (ti < 16 ? -1 : (ti < 24 ? 2 : 3)));
                 if (fam < 0) bad = 1;
@@ -161,7 +173,7 @@ __global__ __launch_bounds__(256) void k_enc_pack(
             // count1 quadruple = this pair (v, w) + the next one (x, y); code word with the first pair (E13)
             if (!((p - bv) & 1)) {
                 const int q = (x & 1) | ((y & 1) << 1) | (((int)pcw[p + 1] & 3) << 2);
-                if (g.count1table_select) { code0[k] = 15 - q; n0[k] = 4; }
+                if (c1sel) { code0[k] = 15 - q; n0[k] = 4; }
                 else { code0[k] = c_tab.hcod_c1a[q]; n0[k] = c_tab.hlen_c1a[q]; }
             }
             uint32_t s = 0; int nb = 0;
