@@ -268,6 +268,12 @@ typedef struct {
 } mp3s_decoded;
 int mp3s_decode_stream(mp3s_ctx *ctx, const uint8_t *file, size_t len, int out_format, mp3s_buf **owner,
                        mp3s_decoded *out);
+/* many streams in one call: the frames of all files form one batch (stream_first marks the starts), so
+ * a corpus of short files costs one Huffman launch and one transform launch per channel count instead of one per file.
+ * out[i] describes file i; every pointer lives in *owner.  A malformed file fails the whole call (its index is in
+ * mp3s_last_error()). */
+int mp3s_decode_streams(mp3s_ctx *ctx, const uint8_t *const *files, const size_t *lens, int n_files, int out_format,
+                        mp3s_buf **owner, mp3s_decoded *out);
 
 /* replaces: Encoder.encode -- reference encoder/encoder.py:33-58, MP3_Encoder.py:596-618 */
 typedef struct {

@@ -7,6 +7,7 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
+#include <memory>
 #include <string>
 #include <vector>
 
@@ -68,7 +69,9 @@ struct mp3s_ctx {
     }
 };
 
+struct mp3s_multi;
 struct mp3s_buf {
+    std::shared_ptr<mp3s_multi> multi;
     ParsedStream parsed;
     ScannedStream scanned;
     std::vector<uint8_t> bytes;      // generic payload (pcm / mp3)
@@ -415,67 +418,137 @@ int mp3s_format_stream(int samplerate, int bitrate_kbps, int n_frames, const int
 }
 
 // ------------------------------------------------------------------------------------------------ pipelines
-int mp3s_decode_stream(mp3s_ctx *c, const uint8_t *file, size_t len, int out_format, mp3s_buf **owner, mp3s_decoded *out)
+struct mp3s_multi {     // owner payload of mp3s_decode_streams
+    std::vector<ParsedStream> parsed;
+    std::vector<ScannedStream> scanned;
+    std::vector<std::vector<uint8_t>> pcm;
+};
+
+// Decode the streams listed in `idx` (all with the same channel count) as ONE batch.
+static int decode_group(mp3s_ctx *c, mp3s_multi &m, const std::vector<int> &idx, int nch, int out_format)
 {
-    if (!c || !file || !owner || !out) return fail(MP3S_E_ARG, "null pointer");
-    if (out_format < 0 || out_format > 2) return fail(MP3S_E_ARG, "out_format=%d", out_format);
-    mp3s_buf *b = new mp3s_buf();
-    // byte-level scan on the host; scalefactors + Huffman on the device unless the stream inherits scalefactors
-    // across frames (mixed blocks ...), in which case the host parser produces the batch
-    int rc = parse_stream(file, len, b->parsed, &b->scanned);
-    if (rc) { delete b; return fail(rc, "malformed or unsupported MP3 stream"); }
-    const bool on_device = b->scanned.gpu_ok && b->parsed.n_frames > 0;
-    if (!on_device) {
-        rc = parse_stream(file, len, b->parsed, nullptr);
-        if (rc) { delete b; return fail(rc, "malformed or unsupported MP3 stream"); }
-    }
-    ParsedStream &p = b->parsed;
-    const int n = p.n_frames, nch = p.nch;
-    if (n <= 0) { delete b; return fail(MP3S_E_MALFORMED, "no MP3 frame found"); }
     const size_t esz = pcm_elem(out_format), frame_bytes = (size_t)1152 * nch * esz;
-    b->bytes.assign((size_t)(n + p.dup_last_frame) * frame_bytes, 0);
-    if (hipSetDevice(c->device) != hipSuccess) { delete b; return fail(MP3S_E_HIP, "hipSetDevice failed"); }
-    for (auto &h : p.hdr) h.stream_first = 0;   // one stream; chunks after the first re-run one halo frame
-    void *d_is = nullptr, *d_si = nullptr, *d_hdr = nullptr, *d_pcm = nullptr, *d_blob = nullptr, *d_side = nullptr,
-         *d_st = nullptr;
-    auto cleanup = [&]() { hipStreamSynchronize(c->stream); };   // the buffers stay in the context's pool
-    int slot = 0;
-    auto alloc = [&](void **q, size_t bytes) { *q = c->grab(slot++, bytes); return *q != nullptr; };
-    const int chunk = std::min(n, kDecodeChunk) + 1;
-    if (!alloc(&d_is, (size_t)n * 2304 * 2) || !alloc(&d_si, (size_t)n * 4 * sizeof(mp3s_granule_si)) ||
-        !alloc(&d_hdr, (size_t)n * sizeof(mp3s_frame_hdr)) || !alloc(&d_pcm, (size_t)chunk * frame_bytes) || !alloc(&d_st, 16) ||
-        (on_device && (!alloc(&d_blob, b->scanned.blob.size()) || !alloc(&d_side, (size_t)n * sizeof(mp3s_frame_side))))) {
-        cleanup(); delete b;
-        return fail(MP3S_E_NOMEM, "hipMalloc failed for a %d-frame decode", n);
+    long n = 0;
+    for (int i : idx) n += m.parsed[i].n_frames;
+    if (n <= 0) return MP3S_OK;
+    if (n > 0x7fffffff / 8) return fail(MP3S_E_ARG, "batch of %ld frames is too large", n);
+    // ---- concatenate: frame headers (stream_first = first frame of the file), side records, main-data blobs
+    std::vector<mp3s_frame_hdr> hdr((size_t)n);
+    std::vector<mp3s_frame_side> side((size_t)n);
+    std::vector<uint8_t> blob;
+    std::vector<long> first_of(idx.size());
+    bool any_dev = false, any_host = false;
+    long f0 = 0;
+    for (size_t k = 0; k < idx.size(); k++) {
+        const ParsedStream &p = m.parsed[idx[k]];
+        const ScannedStream &sc = m.scanned[idx[k]];
+        first_of[k] = f0;
+        const bool dev = sc.gpu_ok;
+        (dev ? any_dev : any_host) = true;
+        const uint32_t base = (uint32_t)blob.size();
+        if (dev) blob.insert(blob.end(), sc.blob.begin(), sc.blob.end());
+        for (int f = 0; f < p.n_frames; f++) {
+            hdr[(size_t)f0 + f] = p.hdr[f];
+            hdr[(size_t)f0 + f].stream_first = (uint32_t)f0;
+            if (dev) { side[(size_t)f0 + f] = sc.side[f]; side[(size_t)f0 + f].md_off += base; }
+            else std::memset(&side[(size_t)f0 + f], 0, sizeof(mp3s_frame_side));   // filled from the host parse below
+        }
+        f0 += p.n_frames;
     }
-    rc = mp3s_dev_upload(c, d_hdr, p.hdr.data(), (size_t)n * sizeof(mp3s_frame_hdr));
-    if (on_device) {
-        if (!rc) rc = mp3s_dev_upload(c, d_blob, b->scanned.blob.data(), b->scanned.blob.size());
-        if (!rc) rc = mp3s_dev_upload(c, d_side, b->scanned.side.data(), (size_t)n * sizeof(mp3s_frame_side));
-        if (!rc) rc = mp3s_huffman_decode_dev(c, (const uint8_t *)d_blob, (const mp3s_frame_side *)d_side, n, nch,
+    if (blob.empty()) blob.resize(16, 0);
+    if (hipSetDevice(c->device) != hipSuccess) return fail(MP3S_E_HIP, "hipSetDevice failed");
+    const int chunk = (int)std::min<long>(n, kDecodeChunk) + 1;
+    int slot = 0;
+    auto grab = [&](size_t bytes) { return c->grab(slot++, bytes); };
+    void *d_is = grab((size_t)n * 2304 * 2), *d_si = grab((size_t)n * 4 * sizeof(mp3s_granule_si)),
+         *d_hdr = grab((size_t)chunk * sizeof(mp3s_frame_hdr)), *d_pcm = grab((size_t)chunk * frame_bytes), *d_st = grab(16),
+         *d_blob = grab(blob.size()), *d_side = grab((size_t)n * sizeof(mp3s_frame_side));
+    if (!d_is || !d_si || !d_hdr || !d_pcm || !d_st || !d_blob || !d_side)
+        return fail(MP3S_E_NOMEM, "hipMalloc failed for a %ld-frame decode", n);
+    int rc = MP3S_OK;
+    if (any_dev) {
+        rc = mp3s_dev_upload(c, d_blob, blob.data(), blob.size());
+        if (!rc) rc = mp3s_dev_upload(c, d_side, side.data(), (size_t)n * sizeof(mp3s_frame_side));
+        if (!rc) rc = mp3s_huffman_decode_dev(c, (const uint8_t *)d_blob, (const mp3s_frame_side *)d_side, (int)n, nch,
                                               (int16_t *)d_is, (mp3s_granule_si *)d_si, (int32_t *)d_st);
         int32_t st = 0;
         if (!rc) rc = mp3s_dev_download(c, &st, d_st, sizeof st);
         if (!rc && st) rc = fail(MP3S_E_MALFORMED, "malformed main data (status %d)", st);
-    } else {
-        if (!rc) rc = mp3s_dev_upload(c, d_is, p.is.data(), (size_t)n * 2304 * 2);
-        if (!rc) rc = mp3s_dev_upload(c, d_si, p.si.data(), (size_t)n * 4 * sizeof(mp3s_granule_si));
     }
-    for (int start = 0; start < n && !rc; start += kDecodeChunk) {
-        const int halo = start ? 1 : 0, first = start - halo, cnt = std::min(kDecodeChunk, n - start) + halo;
-        rc = mp3s_decode_transform_dev(c, (const int16_t *)d_is + (size_t)first * 2304, (const mp3s_granule_si *)d_si + (size_t)first * 4,
-                                       (const mp3s_frame_hdr *)d_hdr + first, cnt, nch, halo, out_format, d_pcm);
-        if (!rc) rc = mp3s_dev_download(c, b->bytes.data() + (size_t)start * frame_bytes, d_pcm, (size_t)(cnt - halo) * frame_bytes);
+    if (any_host)   // streams that inherit scalefactors across frames were parsed on the host: place their frames
+        for (size_t k = 0; k < idx.size() && !rc; k++) {
+            const ParsedStream &p = m.parsed[idx[k]];
+            if (m.scanned[idx[k]].gpu_ok || !p.n_frames) continue;
+            rc = mp3s_dev_upload(c, (int16_t *)d_is + (size_t)first_of[k] * 2304, p.is.data(), (size_t)p.n_frames * 2304 * 2);
+            if (!rc) rc = mp3s_dev_upload(c, (mp3s_granule_si *)d_si + (size_t)first_of[k] * 4, p.si.data(),
+                                          (size_t)p.n_frames * 4 * sizeof(mp3s_granule_si));
+        }
+    // ---- transforms in chunks of kDecodeChunk frames; a chunk that starts inside a stream re-runs one halo frame
+    std::vector<uint8_t> pcm_all((size_t)n * frame_bytes);
+    std::vector<mp3s_frame_hdr> hc;
+    for (long start = 0; start < n && !rc; start += kDecodeChunk) {
+        const int halo = (start && hdr[(size_t)start].stream_first < (uint32_t)start) ? 1 : 0;
+        const long first = start - halo;
+        const int cnt = (int)std::min<long>(kDecodeChunk, n - start) + halo;
+        hc.assign(hdr.begin() + first, hdr.begin() + first + cnt);
+        for (auto &h : hc) h.stream_first = h.stream_first > (uint32_t)first ? h.stream_first - (uint32_t)first : 0;
+        rc = mp3s_dev_upload(c, d_hdr, hc.data(), (size_t)cnt * sizeof(mp3s_frame_hdr));
+        if (!rc) rc = mp3s_decode_transform_dev(c, (const int16_t *)d_is + (size_t)first * 2304, (const mp3s_granule_si *)d_si + (size_t)first * 4,
+                                                (const mp3s_frame_hdr *)d_hdr, cnt, nch, halo, out_format, d_pcm);
+        if (!rc) rc = mp3s_dev_download(c, pcm_all.data() + (size_t)start * frame_bytes, d_pcm, (size_t)(cnt - halo) * frame_bytes);
     }
-    cleanup();
-    if (rc) { delete b; return rc; }
-    if (p.dup_last_frame && n > 0)
-        std::memcpy(b->bytes.data() + (size_t)n * frame_bytes, b->bytes.data() + (size_t)(n - 1) * frame_bytes, frame_bytes);
-    out->n_frames = n; out->nch = nch; out->sampling_rate = p.sampling_rate; out->bit_rate = p.bit_rate;
-    out->n_bits = (int32_t)p.bits.size(); out->n_rows = (int64_t)1152 * (n + p.dup_last_frame);
-    out->pcm = b->bytes.data(); out->bits = p.bits.data();
+    hipStreamSynchronize(c->stream);
+    if (rc) return rc;
+    for (size_t k = 0; k < idx.size(); k++) {
+        const ParsedStream &p = m.parsed[idx[k]];
+        std::vector<uint8_t> &o = m.pcm[idx[k]];
+        o.assign((size_t)(p.n_frames + p.dup_last_frame) * frame_bytes, 0);
+        std::memcpy(o.data(), pcm_all.data() + (size_t)first_of[k] * frame_bytes, (size_t)p.n_frames * frame_bytes);
+        if (p.dup_last_frame && p.n_frames > 0)   // the reference appends the last PCM frame once more after a bad header (D12)
+            std::memcpy(o.data() + (size_t)p.n_frames * frame_bytes, o.data() + (size_t)(p.n_frames - 1) * frame_bytes, frame_bytes);
+    }
+    return MP3S_OK;
+}
+
+int mp3s_decode_streams(mp3s_ctx *c, const uint8_t *const *files, const size_t *lens, int n_files, int out_format,
+                        mp3s_buf **owner, mp3s_decoded *out)
+{
+    if (!c || !files || !lens || !owner || !out || n_files <= 0) return fail(MP3S_E_ARG, "bad argument");
+    if (out_format < 0 || out_format > 2) return fail(MP3S_E_ARG, "out_format=%d", out_format);
+    mp3s_buf *b = new mp3s_buf();
+    b->multi.reset(new mp3s_multi());
+    mp3s_multi &m = *b->multi;
+    m.parsed.resize(n_files); m.scanned.resize(n_files); m.pcm.resize(n_files);
+    std::vector<int> group[3];
+    for (int i = 0; i < n_files; i++) {
+        if (!files[i]) { delete b; return fail(MP3S_E_ARG, "file %d is null", i); }
+        // byte-level scan on the host; scalefactors + Huffman on the device unless the stream inherits scalefactors
+        // across frames (mixed blocks ...), in which case the host parser produces its frames
+        int rc = parse_stream(files[i], lens[i], m.parsed[i], &m.scanned[i]);
+        if (!rc && !m.scanned[i].gpu_ok) rc = parse_stream(files[i], lens[i], m.parsed[i], nullptr);
+        if (!rc && m.parsed[i].n_frames <= 0) rc = MP3S_E_MALFORMED;
+        if (rc) { delete b; return fail(rc, "file %d: malformed or unsupported MP3 stream", i); }
+        group[m.parsed[i].nch].push_back(i);
+    }
+    for (int nch = 1; nch <= 2; nch++)
+        if (!group[nch].empty()) {
+            const int rc = decode_group(c, m, group[nch], nch, out_format);
+            if (rc) { delete b; return rc; }
+        }
+    for (int i = 0; i < n_files; i++) {
+        const ParsedStream &p = m.parsed[i];
+        out[i].n_frames = p.n_frames; out[i].nch = p.nch; out[i].sampling_rate = p.sampling_rate; out[i].bit_rate = p.bit_rate;
+        out[i].n_bits = (int32_t)p.bits.size(); out[i].n_rows = (int64_t)1152 * (p.n_frames + p.dup_last_frame);
+        out[i].pcm = m.pcm[i].data(); out[i].bits = p.bits.data();
+    }
     *owner = b;
     return MP3S_OK;
+}
+
+int mp3s_decode_stream(mp3s_ctx *c, const uint8_t *file, size_t len, int out_format, mp3s_buf **owner, mp3s_decoded *out)
+{
+    if (!file) return fail(MP3S_E_ARG, "null pointer");
+    return mp3s_decode_streams(c, &file, &len, 1, out_format, owner, out);
 }
 
 int mp3s_encode_pcm(mp3s_ctx *c, const int16_t *pcm, int64_t n_samples_per_ch, int nch, int samplerate, int bitrate_kbps,

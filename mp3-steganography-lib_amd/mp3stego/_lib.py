@@ -80,7 +80,7 @@ SYMBOLS = ["mp3s_ctx_create", "mp3s_ctx_destroy", "mp3s_last_error", "mp3s_versi
            "mp3s_dev_alloc", "mp3s_dev_free", "mp3s_dev_upload", "mp3s_dev_download", "mp3s_dev_memset",
            "mp3s_timer_start", "mp3s_timer_stop", "mp3s_profile_enable", "mp3s_profile_collect", "mp3s_decode_transform_dev", "mp3s_decode_transform",
            "mp3s_encode_transform_dev", "mp3s_encode_transform", "mp3s_rate_loop_dev", "mp3s_huffman_decode_dev", "mp3s_pack_frames_dev", "mp3s_scan_stream", "mp3s_buf_free",
-           "mp3s_parse_stream", "mp3s_format_stream", "mp3s_rate_frames", "mp3s_decode_stream", "mp3s_encode_pcm"]
+           "mp3s_parse_stream", "mp3s_format_stream", "mp3s_rate_frames", "mp3s_decode_stream", "mp3s_decode_streams", "mp3s_encode_pcm"]
 
 _lib = None
 _lock = threading.Lock()
@@ -133,6 +133,7 @@ def lib():
         L.mp3s_format_stream.argtypes = [i32, i32, i32, vp, vp, vp, pvp, pvp, C.POINTER(sz)]
         L.mp3s_rate_frames.argtypes = [i32, i32, i32, i32, vp, vp]
         L.mp3s_decode_stream.argtypes = [vp, vp, sz, i32, pvp, C.POINTER(Decoded)]
+        L.mp3s_decode_streams.argtypes = [vp, pvp, C.POINTER(sz), i32, i32, pvp, C.POINTER(Decoded)]
         L.mp3s_encode_pcm.argtypes = [vp, vp, i64, i32, i32, i32, vp, i32, pvp, C.POINTER(Encoded)]
         _lib = L
     return _lib
@@ -259,6 +260,24 @@ class Context:
             dt = {MP3S_PCM_I16: np.int16, MP3S_PCM_F32: np.float32, MP3S_PCM_F64: np.float64}[out_format]
             return {"n_frames": d.n_frames, "channels": d.nch, "sampling_rate": d.sampling_rate, "bit_rate": d.bit_rate,
                     "pcm": _view(d.pcm, dt, (d.n_rows, d.nch)), "bits": _view(d.bits, np.uint8, (d.n_bits,))}
+        finally:
+            lib().mp3s_buf_free(owner)
+
+    def decode_streams(self, files, out_format=MP3S_PCM_I16):
+        """Decode many MP3 files as one device batch (one Huffman + one transform launch per channel count)."""
+        n = len(files)
+        if n == 0:
+            return []
+        bufs = [np.frombuffer(f, dtype=np.uint8) for f in files]
+        ptrs = (C.c_void_p * n)(*[b.ctypes.data for b in bufs])
+        lens = (C.c_size_t * n)(*[len(f) for f in files])
+        owner = C.c_void_p()
+        d = (Decoded * n)()
+        check(lib().mp3s_decode_streams(self.handle, ptrs, lens, n, out_format, C.byref(owner), d))
+        try:
+            dt = {MP3S_PCM_I16: np.int16, MP3S_PCM_F32: np.float32, MP3S_PCM_F64: np.float64}[out_format]
+            return [{"n_frames": x.n_frames, "channels": x.nch, "sampling_rate": x.sampling_rate, "bit_rate": x.bit_rate,
+                     "pcm": _view(x.pcm, dt, (x.n_rows, x.nch)), "bits": _view(x.bits, np.uint8, (x.n_bits,))} for x in d]
         finally:
             lib().mp3s_buf_free(owner)
 

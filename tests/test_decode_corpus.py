@@ -102,3 +102,37 @@ def test_device_huffman_on_corpus(ctx, mlib, corpus):
             assert np.array_equal(si["scale_fac_s"][:, :, :nch][bt2], p["si"]["scale_fac_s"][:, :, :nch][bt2]), n
         for q in (d_blob, d_side, d_is, d_si, d_st):
             ctx.free(q)
+
+
+@pytest.mark.gpu
+def test_device_decode_of_many_streams_in_one_batch(ctx, mlib, corpus, golden_dir):
+    """a corpus of files as ONE device batch (mono and stereo groups, host-parsed and device-parsed
+    streams side by side) must give, per file, exactly what the single-stream call gives = the reference's decode."""
+    g, names = corpus
+    files = [g[n + "__mp3"].tobytes() for n in names]
+    with open(os.path.join(golden_dir, "test.mp3"), "rb") as fh:
+        files.append(fh.read())
+    order = list(range(len(files))) + [len(files) - 1, 0, 2]          # a file may appear more than once
+    for fmt, key in ((mlib.MP3S_PCM_F64, "__pcm_sha256"), (mlib.MP3S_PCM_I16, "__pcm_i16_sha256")):
+        out = ctx.decode_streams([files[i] for i in order], fmt)
+        assert len(out) == len(order)
+        for i, r in zip(order, out):
+            single = ctx.decode_stream(files[i], fmt)
+            assert r["n_frames"] == single["n_frames"] and r["channels"] == single["channels"]
+            assert r["sampling_rate"] == single["sampling_rate"] and r["bit_rate"] == single["bit_rate"]
+            assert np.array_equal(r["bits"], single["bits"])
+            assert np.array_equal(r["pcm"], single["pcm"]), i
+            if i < len(names):
+                assert sha(r["pcm"].tobytes()) == bytes(g[names[i] + key]).decode(), names[i]
+    w = np.load(os.path.join(golden_dir, "g3_testmp3_wav_pcm.npz"))       # the reference's own WAV of test.mp3
+    assert np.array_equal(out[len(names)]["pcm"], w["pcm"])
+
+
+@pytest.mark.gpu
+def test_many_streams_rejects_a_malformed_member(ctx, mlib, corpus):
+    g, names = corpus
+    good = g[names[0] + "__mp3"].tobytes()
+    with pytest.raises(mlib.Mp3sError) as e:
+        ctx.decode_streams([good, b"\x00" * 64, good])
+    assert "file 1" in str(e.value)
+    assert ctx.decode_streams([]) == []
