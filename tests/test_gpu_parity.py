@@ -266,3 +266,46 @@ def test_full_size_against_oracle(ctx, mlib, orc, rate, kbps):
     # decode -> re-encode (clear) -> decode: no message left, same number of frames
     c = ctx.encode_pcm(d16["pcm"], rate, kbps, None)
     assert c["mp3"] == orc.encode(d16["pcm"], rate, kbps, None)["mp3"]
+
+
+# ------------------------------------------------------------------------------------------------ BASELINE config 5
+@pytest.mark.parametrize("rate", [32000, 44100, 48000])
+def test_encode_matrix_of_rates_and_bitrates(ctx, mlib, orc, rate):
+    """every (sampling rate, bitrate) of BASELINE config 5 in stereo: bytes, cursor and the decode of the result
+    against the oracle (mono encode is a reference crash, test_encode_errors_like_reference)"""
+    from synth_pcm import synth_pcm
+    pcm = synth_pcm(160, rate=rate, seed=0x1234 + rate)
+    pcm[40 * 1152:44 * 1152] = 0                                      # a silent stretch: empty units, reservoir refill
+    pcm[100 * 1152:101 * 1152, 0] = 32767                             # a clipped burst: the quantiser's float path
+    msg = bits_of("20#" + "rates and bitrates..")
+    for kbps in (32, 64, 128, 192, 320):
+        r = ctx.encode_pcm(pcm, rate, kbps, msg)
+        o = orc.encode(pcm, rate, kbps, msg)
+        assert o["rc"] == 0 and r["mp3"] == o["mp3"], (rate, kbps)
+        assert r["hide_offset"] == o["hide_offset"] and r["too_long"] == bool(o["too_long"])
+        d = ctx.decode_stream(r["mp3"], mlib.MP3S_PCM_F64)
+        od = orc.decode(r["mp3"])
+        assert d["bit_rate"] == od["bit_rate"] == kbps * 1000 and d["sampling_rate"] == rate
+        assert np.array_equal(d["bits"], od["bits"])
+        assert np.array_equal(d["pcm"], od["pcm"]), (rate, kbps)
+
+
+# ------------------------------------------------------------------------------------------------ BASELINE config 4 (shape)
+def test_many_seeded_streams_across_chunk_boundaries(ctx, mlib, orc):
+    """config 4 in miniature: several seeded streams as one batch that is larger than the pipeline's transform chunk,
+    so chunk boundaries fall inside streams (halo re-run) and stream starts fall inside chunks (state reset);
+    per stream a CRC of the int16 PCM against the oracle, and the float64 PCM exactly on one of them"""
+    import zlib
+    from synth_pcm import synth_pcm
+    lens = [3000, 5000, 1, 4200, 2, 6100, 700]                        # 19003 frames > 16384
+    files = []
+    for i, n in enumerate(lens):
+        pcm = synth_pcm(n, seed=0x9E3779B97F4A7C15 + i)
+        files.append(ctx.encode_pcm(pcm, 44100, 128, bits_of("3#s%02d" % i))["mp3"])
+    out = ctx.decode_streams(files, mlib.MP3S_PCM_I16)
+    for i, (f, r) in enumerate(zip(files, out)):
+        od = orc.decode(f)
+        assert r["n_frames"] == od["n_frames"] and np.array_equal(r["bits"], od["bits"])
+        assert zlib.crc32(r["pcm"].tobytes()) == zlib.crc32(orc.pcm_to_i16(od["pcm"]).tobytes()), i
+    out64 = ctx.decode_streams(files[4:7], mlib.MP3S_PCM_F64)
+    assert np.array_equal(out64[1]["pcm"], orc.decode(files[5])["pcm"])
