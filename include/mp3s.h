@@ -38,6 +38,7 @@ extern "C" {
 #define MP3S_E_UNSUPPORTED (-5) /* input the reference itself cannot process (mono encode, partial frame) */
 #define MP3S_E_STEP_RANGE (-6)  /* quantizer step left the table (reference: IndexError) */
 #define MP3S_E_NOMEM (-7)
+#define MP3S_E_EXIT (-8)        /* the reference calls sys.exit(text) here; the text is in mp3s_last_error() */
 
 #define MP3S_PCM_I16 0 /* (pcm*32767) truncated toward zero, low 16 bits: reference decoder/MP3_Parser.py:91 */
 #define MP3S_PCM_F32 1
@@ -288,6 +289,52 @@ typedef struct {
 } mp3s_encoded;
 int mp3s_encode_pcm(mp3s_ctx *ctx, const int16_t *pcm, int64_t n_samples_per_ch, int nch, int samplerate,
                     int bitrate_kbps, const uint8_t *hide_bits, int n_hide, mp3s_buf **owner, mp3s_encoded *out);
+
+/* ---------------------------------------------------------------- (vi) files and messages */
+/* Whole files as byte strings in, byte strings out: WAV and MP3 containers, message framing and the facade's three
+ * operations inside the library, so that a binding in any language needs no code of its own for them.  Nothing here
+ * touches the disk.  MP3S_E_EXIT = the reference would sys.exit(text); MP3S_E_UNSUPPORTED / MP3S_E_MALFORMED = it would
+ * raise (IndexError / struct.error ...). */
+
+/* replaces: WavReader.__read_header + check_bitrate_index -- reference encoder/WAV_Reader.py:30-111 */
+typedef struct {
+    int32_t channels, samplerate, bits_per_sample, bitrate;
+    int64_t num_of_samples; /* per channel, from the data chunk size (float arithmetic as in the reference) */
+    int64_t data_offset;    /* byte offset of the first sample */
+    int64_t n_values;       /* int16 values the reference's np.fromfile call yields (up to 2x the declared count) */
+} mp3s_wav_info;
+int mp3s_wav_parse(const uint8_t *file, size_t len, int bitrate_kbps, mp3s_wav_info *out);
+/* replaces: scipy.io.wavfile.write header as used by MP3_Parser.write_to_wav -- reference decoder/MP3_Parser.py:86-93 */
+int mp3s_wav_header(int64_t n_rows, int nch, int rate, uint8_t out44[44]);
+/* replaces: str_to_binary_str(str(len(m)) + "#" + m) -- reference steganography.py:10-24, 42-50.  bits are 0/1 bytes. */
+int mp3s_message_frame(const uint8_t *utf8, size_t n, mp3s_buf **owner, const uint8_t **bits, size_t *n_bits);
+/* replaces: the reveal parse -- reference decoder/decoder.py:90-108.  text is what the reference writes to the .txt. */
+int mp3s_message_reveal(const uint8_t *bits, size_t n_bits, mp3s_buf **owner, const uint8_t **text, size_t *n_text);
+
+typedef struct {
+    const uint8_t *data;  /* the produced file: WAV, MP3 or revealed text */
+    size_t len;
+    int32_t kbps;         /* bitrate of the last frame header / 1000 (decoder.py:110); the bitrate used when encoding */
+    int32_t sampling_rate, channels, n_frames;
+    int32_t too_long;     /* encode/hide: the message did not fit and was trimmed (encoder.py:50) */
+    int32_t n_bits;       /* decode: stego bits found in the stream */
+    int64_t hide_offset;  /* encode/hide: message bits consumed */
+    const uint8_t *bits;  /* decode: the stego bits, 0/1 */
+} mp3s_file;
+/* replaces: Decoder(...).decode() -- reference decoder/decoder.py:59-84: MP3 bytes -> WAV bytes (int16) */
+int mp3s_decode_file(mp3s_ctx *ctx, const uint8_t *mp3, size_t len, mp3s_buf **owner, mp3s_file *out);
+/* replaces: Encoder(...).encode() -- reference encoder/encoder.py:21-58: WAV bytes -> MP3 bytes, hide_bits optional */
+int mp3s_encode_file(mp3s_ctx *ctx, const uint8_t *wav, size_t len, int bitrate_kbps, const uint8_t *hide_bits,
+                     int n_hide, mp3s_buf **owner, mp3s_file *out);
+/* replaces: Steganography.hide_message / clear_file -- reference steganography.py:133-182: decode, then re-encode at
+ * the stream's own bitrate with (hide) or without (clear) "<count>#<message>".  The int16 PCM never leaves HBM between
+ * the two halves; the result is byte-identical to going through the temporary WAV file. */
+int mp3s_hide_message(mp3s_ctx *ctx, const uint8_t *mp3, size_t len, const uint8_t *utf8, size_t n_msg, mp3s_buf **owner,
+                      mp3s_file *out);
+int mp3s_clear_file(mp3s_ctx *ctx, const uint8_t *mp3, size_t len, mp3s_buf **owner, mp3s_file *out);
+/* replaces: Steganography.reveal_massage -- reference steganography.py:103-131: MP3 bytes -> message text.  Only the
+ * byte-level scan runs (table_select lives in the side info), so no device work and no context are needed. */
+int mp3s_reveal_message(const uint8_t *mp3, size_t len, mp3s_buf **owner, mp3s_file *out);
 
 #ifdef __cplusplus
 }

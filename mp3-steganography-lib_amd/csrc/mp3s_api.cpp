@@ -421,11 +421,14 @@ int mp3s_format_stream(int samplerate, int bitrate_kbps, int n_frames, const int
 struct mp3s_multi {     // owner payload of mp3s_decode_streams
     std::vector<ParsedStream> parsed;
     std::vector<ScannedStream> scanned;
-    std::vector<std::vector<uint8_t>> pcm;
+    std::vector<uint8_t> arena[3];        // PCM of all mono / all stereo streams, index = channel count
+    std::vector<const uint8_t *> pcm;     // per stream, into its arena
 };
 
 // Decode the streams listed in `idx` (all with the same channel count) as ONE batch.
-static int decode_group(mp3s_ctx *c, mp3s_multi &m, const std::vector<int> &idx, int nch, int out_format)
+// d_keep != nullptr: the PCM of the group stays on the device there (frames back to back, a duplicated last frame
+// included) and nothing is downloaded -- the re-encode path of mp3s_hide_message / mp3s_clear_file.
+static int decode_group(mp3s_ctx *c, mp3s_multi &m, const std::vector<int> &idx, int nch, int out_format, void *d_keep = nullptr)
 {
     const size_t esz = pcm_elem(out_format), frame_bytes = (size_t)1152 * nch * esz;
     long n = 0;
@@ -483,8 +486,14 @@ static int decode_group(mp3s_ctx *c, mp3s_multi &m, const std::vector<int> &idx,
             if (!rc) rc = mp3s_dev_upload(c, (mp3s_granule_si *)d_si + (size_t)first_of[k] * 4, p.si.data(),
                                           (size_t)p.n_frames * 4 * sizeof(mp3s_granule_si));
         }
-    // ---- transforms in chunks of kDecodeChunk frames; a chunk that starts inside a stream re-runs one halo frame
-    std::vector<uint8_t> pcm_all((size_t)n * frame_bytes);
+    // ---- transforms in chunks of kDecodeChunk frames; a chunk that starts inside a stream re-runs one halo frame.
+    //      Host layout = device layout plus one extra frame after every stream that ends in a bad header (D12): the
+    //      reference appends that stream's last PCM frame once more.
+    std::vector<long> out_first(idx.size());
+    long extra = 0;
+    for (size_t k = 0; k < idx.size(); k++) { out_first[k] = first_of[k] + extra; extra += m.parsed[idx[k]].dup_last_frame ? 1 : 0; }
+    std::vector<uint8_t> &arena = m.arena[nch];
+    if (!d_keep) arena.resize((size_t)(n + extra) * frame_bytes);
     std::vector<mp3s_frame_hdr> hc;
     for (long start = 0; start < n && !rc; start += kDecodeChunk) {
         const int halo = (start && hdr[(size_t)start].stream_first < (uint32_t)start) ? 1 : 0;
@@ -495,19 +504,50 @@ static int decode_group(mp3s_ctx *c, mp3s_multi &m, const std::vector<int> &idx,
         rc = mp3s_dev_upload(c, d_hdr, hc.data(), (size_t)cnt * sizeof(mp3s_frame_hdr));
         if (!rc) rc = mp3s_decode_transform_dev(c, (const int16_t *)d_is + (size_t)first * 2304, (const mp3s_granule_si *)d_si + (size_t)first * 4,
                                                 (const mp3s_frame_hdr *)d_hdr, cnt, nch, halo, out_format, d_pcm);
-        if (!rc) rc = mp3s_dev_download(c, pcm_all.data() + (size_t)start * frame_bytes, d_pcm, (size_t)(cnt - halo) * frame_bytes);
+        // copy out in runs that are contiguous on both sides (a run ends where a duplicated frame is inserted)
+        const long end = start + (cnt - halo);
+        for (long a = start; a < end && !rc;) {
+            size_t k = (size_t)(std::upper_bound(first_of.begin(), first_of.end(), a) - first_of.begin()) - 1;
+            long b = end;
+            for (size_t j = k; j < idx.size() && first_of[j] < end; j++)
+                if (m.parsed[idx[j]].dup_last_frame) { b = std::min<long>(end, first_of[j] + m.parsed[idx[j]].n_frames); break; }
+            if (b <= a) b = std::min<long>(end, a + 1);
+            const size_t dst = (size_t)(out_first[k] + (a - first_of[k])) * frame_bytes, bytes = (size_t)(b - a) * frame_bytes;
+            const uint8_t *src = (const uint8_t *)d_pcm + (size_t)(a - start) * frame_bytes;
+            if (d_keep) {
+                if (hipMemcpyAsync((uint8_t *)d_keep + dst, src, bytes, hipMemcpyDeviceToDevice, c->stream) != hipSuccess)
+                    rc = fail(MP3S_E_HIP, "device copy failed");
+            } else rc = mp3s_dev_download(c, arena.data() + dst, src, bytes);
+            a = b;
+        }
     }
-    hipStreamSynchronize(c->stream);
-    if (rc) return rc;
-    for (size_t k = 0; k < idx.size(); k++) {
+    for (size_t k = 0; k < idx.size() && !rc; k++) {
         const ParsedStream &p = m.parsed[idx[k]];
-        std::vector<uint8_t> &o = m.pcm[idx[k]];
-        o.assign((size_t)(p.n_frames + p.dup_last_frame) * frame_bytes, 0);
-        std::memcpy(o.data(), pcm_all.data() + (size_t)first_of[k] * frame_bytes, (size_t)p.n_frames * frame_bytes);
-        if (p.dup_last_frame && p.n_frames > 0)   // the reference appends the last PCM frame once more after a bad header (D12)
-            std::memcpy(o.data() + (size_t)p.n_frames * frame_bytes, o.data() + (size_t)(p.n_frames - 1) * frame_bytes, frame_bytes);
+        if (p.dup_last_frame && p.n_frames > 0) {
+            const size_t last = (size_t)(out_first[k] + p.n_frames - 1) * frame_bytes;
+            if (d_keep) {
+                if (hipMemcpyAsync((uint8_t *)d_keep + last + frame_bytes, (uint8_t *)d_keep + last, frame_bytes, hipMemcpyDeviceToDevice,
+                                   c->stream) != hipSuccess)
+                    rc = fail(MP3S_E_HIP, "device copy failed");
+            } else {
+                hipStreamSynchronize(c->stream);
+                std::memcpy(arena.data() + last + frame_bytes, arena.data() + last, frame_bytes);
+            }
+        }
+        if (!d_keep) m.pcm[idx[k]] = arena.data() + (size_t)out_first[k] * frame_bytes;
     }
-    return MP3S_OK;
+    if (!d_keep) hipStreamSynchronize(c->stream);
+    return rc;
+}
+
+// host front end of one file: byte-level scan; scalefactors + Huffman run on the device unless the stream inherits
+// scalefactors across frames (mixed blocks ...), in which case the host parser produces its frames
+static int front_end(const uint8_t *file, size_t len, ParsedStream &p, ScannedStream &sc)
+{
+    int rc = parse_stream(file, len, p, &sc);
+    if (!rc && !sc.gpu_ok) rc = parse_stream(file, len, p, nullptr);
+    if (!rc && p.n_frames <= 0) rc = MP3S_E_MALFORMED;
+    return rc;
 }
 
 int mp3s_decode_streams(mp3s_ctx *c, const uint8_t *const *files, const size_t *lens, int n_files, int out_format,
@@ -518,15 +558,11 @@ int mp3s_decode_streams(mp3s_ctx *c, const uint8_t *const *files, const size_t *
     mp3s_buf *b = new mp3s_buf();
     b->multi.reset(new mp3s_multi());
     mp3s_multi &m = *b->multi;
-    m.parsed.resize(n_files); m.scanned.resize(n_files); m.pcm.resize(n_files);
+    m.parsed.resize(n_files); m.scanned.resize(n_files); m.pcm.assign(n_files, nullptr);
     std::vector<int> group[3];
     for (int i = 0; i < n_files; i++) {
         if (!files[i]) { delete b; return fail(MP3S_E_ARG, "file %d is null", i); }
-        // byte-level scan on the host; scalefactors + Huffman on the device unless the stream inherits scalefactors
-        // across frames (mixed blocks ...), in which case the host parser produces its frames
-        int rc = parse_stream(files[i], lens[i], m.parsed[i], &m.scanned[i]);
-        if (!rc && !m.scanned[i].gpu_ok) rc = parse_stream(files[i], lens[i], m.parsed[i], nullptr);
-        if (!rc && m.parsed[i].n_frames <= 0) rc = MP3S_E_MALFORMED;
+        const int rc = front_end(files[i], lens[i], m.parsed[i], m.scanned[i]);
         if (rc) { delete b; return fail(rc, "file %d: malformed or unsupported MP3 stream", i); }
         group[m.parsed[i].nch].push_back(i);
     }
@@ -539,7 +575,7 @@ int mp3s_decode_streams(mp3s_ctx *c, const uint8_t *const *files, const size_t *
         const ParsedStream &p = m.parsed[i];
         out[i].n_frames = p.n_frames; out[i].nch = p.nch; out[i].sampling_rate = p.sampling_rate; out[i].bit_rate = p.bit_rate;
         out[i].n_bits = (int32_t)p.bits.size(); out[i].n_rows = (int64_t)1152 * (p.n_frames + p.dup_last_frame);
-        out[i].pcm = m.pcm[i].data(); out[i].bits = p.bits.data();
+        out[i].pcm = m.pcm[i]; out[i].bits = p.bits.data();
     }
     *owner = b;
     return MP3S_OK;
@@ -551,15 +587,18 @@ int mp3s_decode_stream(mp3s_ctx *c, const uint8_t *file, size_t len, int out_for
     return mp3s_decode_streams(c, &file, &len, 1, out_format, owner, out);
 }
 
-int mp3s_encode_pcm(mp3s_ctx *c, const int16_t *pcm, int64_t n_samples_per_ch, int nch, int samplerate, int bitrate_kbps,
-                    const uint8_t *hide_bits, int n_hide, mp3s_buf **owner, mp3s_encoded *out)
+// pcm_dev != nullptr: the int16 PCM is already in HBM (re-encode after a device decode) and pcm is ignored
+static int encode_core(mp3s_ctx *c, const int16_t *pcm, const int16_t *pcm_dev, int64_t n_samples_per_ch, int nch, int samplerate,
+                       int bitrate_kbps, const uint8_t *hide_bits, int n_hide, mp3s_buf **owner, mp3s_encoded *out)
 {
-    if (!c || !pcm || !owner || !out) return fail(MP3S_E_ARG, "null pointer");
     if (nch != 2) return fail(MP3S_E_UNSUPPORTED, "mono encode raises IndexError in the reference (SURVEY E3)");
     if (n_samples_per_ch <= 0 || n_samples_per_ch % 1152)
         return fail(MP3S_E_UNSUPPORTED, "sample count %lld is not a multiple of 1152 (reference over-reads, E3)",
                     (long long)n_samples_per_ch);
     if (n_hide < 0 || (n_hide > 0 && !hide_bits)) return fail(MP3S_E_ARG, "bad hide arguments");
+    // -1 sits in the reference's bitrate table (encoder/util.py:27,42), so its header check lets it through and the
+    // encoder then runs on negative slot counts; nothing meaningful to reproduce
+    if (bitrate_kbps <= 0) return fail(MP3S_E_UNSUPPORTED, "bitrate %d", bitrate_kbps);
     const int n = (int)(n_samples_per_ch / 1152), units = n * 4;
     std::vector<mp3s_rate_frame> rf(n);
     int rc = rate_frames(samplerate, bitrate_kbps, nch, n, rf.data(), nullptr);
@@ -573,7 +612,9 @@ int mp3s_encode_pcm(mp3s_ctx *c, const int16_t *pcm, int64_t n_samples_per_ch, i
     auto cleanup = [&]() { hipStreamSynchronize(c->stream); };   // the buffers stay in the context's pool
     int slot = 8;
     auto alloc = [&](void **p, size_t bytes) { *p = c->grab(slot++, bytes); return *p != nullptr; };
-    if (!alloc(&d_pcm, (size_t)n * 2304 * 2) || !alloc(&d_hdr, (size_t)n * sizeof(mp3s_frame_hdr)) ||
+    if (pcm_dev) { d_pcm = const_cast<int16_t *>(pcm_dev); slot++; }
+    else if (!alloc(&d_pcm, (size_t)n * 2304 * 2)) d_pcm = nullptr;
+    if (!d_pcm || !alloc(&d_hdr, (size_t)n * sizeof(mp3s_frame_hdr)) ||
         !alloc(&d_mdct, (size_t)n * 2304 * 4) || !alloc(&d_rf, (size_t)n * sizeof(mp3s_rate_frame)) ||
         !alloc(&d_hide, (size_t)n_hide) || !alloc(&d_cur, (size_t)units * 4) || !alloc(&d_state, (size_t)units * 16) ||
         !alloc(&d_list, (size_t)units * 4) || !alloc(&d_ix, (size_t)n * 2304 * 2) ||
@@ -584,7 +625,7 @@ int mp3s_encode_pcm(mp3s_ctx *c, const int16_t *pcm, int64_t n_samples_per_ch, i
     std::vector<int32_t> cursor(units), state((size_t)units * 4, 0), en((size_t)units * 22);
     std::vector<mp3s_gr_out> gr(units);
     for (int u = 0; u < units; u++) cursor[u] = 3 * u;   // first guess: three tables per unit
-    rc = mp3s_dev_upload(c, d_pcm, pcm, (size_t)n * 2304 * 2);
+    if (!pcm_dev) rc = mp3s_dev_upload(c, d_pcm, pcm, (size_t)n * 2304 * 2);
     if (!rc) rc = mp3s_dev_upload(c, d_hdr, hdr.data(), (size_t)n * sizeof(mp3s_frame_hdr));
     if (!rc) rc = mp3s_dev_upload(c, d_rf, rf.data(), (size_t)n * sizeof(mp3s_rate_frame));
     if (!rc && n_hide) rc = mp3s_dev_upload(c, d_hide, hide_bits, (size_t)n_hide);
@@ -693,6 +734,151 @@ int mp3s_encode_pcm(mp3s_ctx *c, const int16_t *pcm, int64_t n_samples_per_ch, i
     out->mp3 = b->bytes.data(); out->mp3_len = b->bytes.size();
     out->gr = b->gr.data(); out->scfsi = b->scfsi.data();
     out->rate_passes = passes;
+    *owner = b;
+    return MP3S_OK;
+}
+
+int mp3s_encode_pcm(mp3s_ctx *c, const int16_t *pcm, int64_t n_samples_per_ch, int nch, int samplerate, int bitrate_kbps,
+                    const uint8_t *hide_bits, int n_hide, mp3s_buf **owner, mp3s_encoded *out)
+{
+    if (!c || !pcm || !owner || !out) return fail(MP3S_E_ARG, "null pointer");
+    return encode_core(c, pcm, nullptr, n_samples_per_ch, nch, samplerate, bitrate_kbps, hide_bits, n_hide, owner, out);
+}
+
+/* ---------------------------------------------------------------- (vi) files and messages */
+int mp3s_wav_parse(const uint8_t *file, size_t len, int bitrate_kbps, mp3s_wav_info *out)
+{
+    if ((!file && len) || !out) return fail(MP3S_E_ARG, "null pointer");
+    const char *msg = "";
+    const int rc = wav_parse(file, len, bitrate_kbps, out, &msg);
+    return rc ? fail(rc, "%s", msg) : MP3S_OK;
+}
+
+int mp3s_wav_header(int64_t n_rows, int nch, int rate, uint8_t *out44)
+{
+    if (!out44 || n_rows < 0 || nch < 1 || nch > 2 || rate <= 0) return fail(MP3S_E_ARG, "bad argument");
+    wav_header(n_rows, nch, rate, out44);
+    return MP3S_OK;
+}
+
+int mp3s_message_frame(const uint8_t *utf8, size_t n, mp3s_buf **owner, const uint8_t **bits, size_t *n_bits)
+{
+    if ((!utf8 && n) || !owner || !bits || !n_bits) return fail(MP3S_E_ARG, "null pointer");
+    mp3s_buf *b = new mp3s_buf();
+    message_frame(utf8, n, b->bits);
+    *bits = b->bits.data(); *n_bits = b->bits.size(); *owner = b;
+    return MP3S_OK;
+}
+
+int mp3s_message_reveal(const uint8_t *bits, size_t n_bits, mp3s_buf **owner, const uint8_t **text, size_t *n_text)
+{
+    if ((!bits && n_bits) || !owner || !text || !n_text) return fail(MP3S_E_ARG, "null pointer");
+    mp3s_buf *b = new mp3s_buf();
+    message_reveal(bits, n_bits, b->bytes);
+    *text = b->bytes.data(); *n_text = b->bytes.size(); *owner = b;
+    return MP3S_OK;
+}
+
+int mp3s_decode_file(mp3s_ctx *c, const uint8_t *mp3, size_t len, mp3s_buf **owner, mp3s_file *out)
+{
+    if (!c || !mp3 || !owner || !out) return fail(MP3S_E_ARG, "null pointer");
+    mp3s_buf *dec = nullptr;
+    mp3s_decoded d;
+    const int rc = mp3s_decode_stream(c, mp3, len, MP3S_PCM_I16, &dec, &d);
+    if (rc) return rc;
+    mp3s_buf *b = new mp3s_buf();
+    const size_t nb = (size_t)d.n_rows * d.nch * 2;
+    b->bytes.resize(44 + nb);
+    wav_header(d.n_rows, d.nch, d.sampling_rate, b->bytes.data());
+    std::memcpy(b->bytes.data() + 44, d.pcm, nb);
+    b->bits.assign(d.bits, d.bits + d.n_bits);
+    std::memset(out, 0, sizeof *out);
+    out->data = b->bytes.data(); out->len = b->bytes.size();
+    out->kbps = d.bit_rate / 1000; out->sampling_rate = d.sampling_rate; out->channels = d.nch; out->n_frames = d.n_frames;
+    out->n_bits = d.n_bits; out->bits = b->bits.data();
+    mp3s_buf_free(dec);
+    *owner = b;
+    return MP3S_OK;
+}
+
+static void file_from_encoded(const mp3s_encoded &e, int kbps, int rate, mp3s_file *out)
+{
+    std::memset(out, 0, sizeof *out);
+    out->data = e.mp3; out->len = e.mp3_len; out->kbps = kbps; out->sampling_rate = rate; out->channels = 2;
+    out->n_frames = e.n_frames; out->too_long = e.too_long; out->hide_offset = e.hide_offset;
+}
+
+int mp3s_encode_file(mp3s_ctx *c, const uint8_t *wav, size_t len, int bitrate_kbps, const uint8_t *hide_bits, int n_hide,
+                     mp3s_buf **owner, mp3s_file *out)
+{
+    if (!c || !wav || !owner || !out) return fail(MP3S_E_ARG, "null pointer");
+    mp3s_wav_info w;
+    int rc = mp3s_wav_parse(wav, len, bitrate_kbps, &w);
+    if (rc) return rc;
+    // MP3_Encoder.py:596-618 walks num_of_samples * channels values in steps of 1152 * channels and indexes the buffer
+    // as if it were stereo: mono input and a partial last frame both end in IndexError there
+    if (w.channels != 2) return fail(MP3S_E_UNSUPPORTED, "mono input: the reference encoder indexes the sample buffer out of bounds");
+    const int64_t total = w.num_of_samples * 2, count = total / 2304;
+    if (total % 2304 || w.n_values < count * 2304)
+        return fail(MP3S_E_UNSUPPORTED, "sample count is not a multiple of 1152 per channel: the reference encoder reads past the end of the sample buffer");
+    std::vector<int16_t> pcm((size_t)count * 2304);   // the data chunk may sit at an odd offset
+    std::memcpy(pcm.data(), wav + w.data_offset, pcm.size() * 2);
+    mp3s_encoded e;
+    rc = encode_core(c, pcm.data(), nullptr, count * 1152, 2, w.samplerate, bitrate_kbps, hide_bits, n_hide, owner, &e);
+    if (!rc) file_from_encoded(e, bitrate_kbps, w.samplerate, out);
+    return rc;
+}
+
+// decode on the device into HBM, encode from there: steganography.py:133-182 without the temporary WAV
+static int reencode(mp3s_ctx *c, const uint8_t *mp3, size_t len, const uint8_t *hide_bits, int n_hide, mp3s_buf **owner, mp3s_file *out)
+{
+    mp3s_multi m;
+    m.parsed.resize(1); m.scanned.resize(1); m.pcm.assign(1, nullptr);
+    int rc = front_end(mp3, len, m.parsed[0], m.scanned[0]);
+    if (rc) return fail(rc, "malformed or unsupported MP3 stream");
+    const ParsedStream &p = m.parsed[0];
+    const int kbps = p.bit_rate / 1000;
+    int sri, bri, whole;
+    if (stream_params(p.sampling_rate, kbps, &sri, &bri, &whole)) return fail(MP3S_E_EXIT, "Unsupported bitrate configuration.");
+    if (p.nch != 2) return fail(MP3S_E_UNSUPPORTED, "mono input: the reference encoder indexes the sample buffer out of bounds");
+    const int64_t rows_frames = (int64_t)p.n_frames + (p.dup_last_frame ? 1 : 0);
+    if (hipSetDevice(c->device) != hipSuccess) return fail(MP3S_E_HIP, "hipSetDevice failed");
+    void *d_keep = c->grab(7, (size_t)rows_frames * 2304 * 2);
+    if (!d_keep) return fail(MP3S_E_NOMEM, "hipMalloc failed for %lld frames of PCM", (long long)rows_frames);
+    rc = decode_group(c, m, std::vector<int>{0}, 2, MP3S_PCM_I16, d_keep);
+    if (rc) return rc;
+    mp3s_encoded e;
+    rc = encode_core(c, nullptr, (const int16_t *)d_keep, rows_frames * 1152, 2, p.sampling_rate, kbps, hide_bits, n_hide, owner, &e);
+    if (!rc) file_from_encoded(e, kbps, p.sampling_rate, out);
+    return rc;
+}
+
+int mp3s_hide_message(mp3s_ctx *c, const uint8_t *mp3, size_t len, const uint8_t *utf8, size_t n_msg, mp3s_buf **owner, mp3s_file *out)
+{
+    if (!c || !mp3 || (!utf8 && n_msg) || !owner || !out) return fail(MP3S_E_ARG, "null pointer");
+    std::vector<uint8_t> bits;
+    message_frame(utf8, n_msg, bits);
+    if (bits.size() > 0x7fffffff) return fail(MP3S_E_ARG, "message too long");
+    return reencode(c, mp3, len, bits.data(), (int)bits.size(), owner, out);
+}
+
+int mp3s_clear_file(mp3s_ctx *c, const uint8_t *mp3, size_t len, mp3s_buf **owner, mp3s_file *out)
+{
+    if (!c || !mp3 || !owner || !out) return fail(MP3S_E_ARG, "null pointer");
+    return reencode(c, mp3, len, nullptr, 0, owner, out);
+}
+
+int mp3s_reveal_message(const uint8_t *mp3, size_t len, mp3s_buf **owner, mp3s_file *out)
+{
+    if (!mp3 || !owner || !out) return fail(MP3S_E_ARG, "null pointer");
+    mp3s_buf *b = new mp3s_buf();
+    const int rc = parse_stream(mp3, len, b->parsed, &b->scanned);
+    if (rc || b->parsed.n_frames <= 0) { delete b; return fail(rc ? rc : MP3S_E_MALFORMED, "malformed or unsupported MP3 stream"); }
+    message_reveal(b->parsed.bits.data(), b->parsed.bits.size(), b->bytes);
+    std::memset(out, 0, sizeof *out);
+    out->data = b->bytes.data(); out->len = b->bytes.size();
+    out->kbps = b->parsed.bit_rate / 1000; out->sampling_rate = b->parsed.sampling_rate; out->channels = b->parsed.nch;
+    out->n_frames = b->parsed.n_frames; out->n_bits = (int32_t)b->parsed.bits.size(); out->bits = b->parsed.bits.data();
     *owner = b;
     return MP3S_OK;
 }

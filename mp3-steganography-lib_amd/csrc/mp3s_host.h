@@ -45,4 +45,14 @@ void host_scfsi_energies(const int32_t *xr576, int sr_idx, int32_t *en22);
 int format_stream(int samplerate, int bitrate_kbps, int n_frames, const int16_t *ix, const mp3s_gr_out *gr,
                   const int32_t *scfsi, std::vector<uint8_t> &mp3);
 
+// ---- container formats and message framing (mp3s_host_files.cpp)
+// reference encoder/WAV_Reader.py:30-111; *msg = the reference's sys.exit text when MP3S_E_EXIT is returned
+int wav_parse(const uint8_t *file, size_t len, int bitrate_kbps, mp3s_wav_info *out, const char **msg);
+// the 44-byte header scipy.io.wavfile.write emits for int16 data
+void wav_header(int64_t n_rows, int nch, int rate, uint8_t *out44);
+// reference steganography.py:10-24, 42-50
+void message_frame(const uint8_t *utf8, size_t n, std::vector<uint8_t> &bits);
+// reference decoder/decoder.py:90-108
+void message_reveal(const uint8_t *bits, size_t n_bits, std::vector<uint8_t> &text);
+
 }  // namespace mp3s

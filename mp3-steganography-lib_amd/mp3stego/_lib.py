@@ -13,7 +13,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libmp3s_hip.so")
 
 MP3S_PCM_I16, MP3S_PCM_F32, MP3S_PCM_F64 = 0, 1, 2
-E_NO_DEVICE, E_HIP, E_ARG, E_MALFORMED, E_UNSUPPORTED, E_STEP_RANGE, E_NOMEM = -1, -2, -3, -4, -5, -6, -7
+E_NO_DEVICE, E_HIP, E_ARG, E_MALFORMED, E_UNSUPPORTED, E_STEP_RANGE, E_NOMEM, E_EXIT = -1, -2, -3, -4, -5, -6, -7, -8
 RF_ACTIVE, RF_USED_ADDR_IN, RF_STEP_RANGE, RF_LOG_GUARD = 1, 2, 4, 8
 
 
@@ -21,6 +21,7 @@ class Mp3sError(RuntimeError):
     def __init__(self, code, msg):
         super().__init__(f"mp3s error {code}: {msg}")
         self.code = code
+        self.text = msg      # for E_EXIT: the exact string the reference passes to sys.exit()
 
 
 class GranuleSI(C.Structure):
@@ -75,12 +76,25 @@ class Encoded(C.Structure):
                 ("mp3_len", C.c_size_t), ("gr", C.c_void_p), ("scfsi", C.c_void_p), ("rate_passes", C.c_int32)]
 
 
+class WavInfo(C.Structure):
+    _fields_ = [("channels", C.c_int32), ("samplerate", C.c_int32), ("bits_per_sample", C.c_int32), ("bitrate", C.c_int32),
+                ("num_of_samples", C.c_int64), ("data_offset", C.c_int64), ("n_values", C.c_int64)]
+
+
+class File(C.Structure):
+    _fields_ = [("data", C.c_void_p), ("len", C.c_size_t), ("kbps", C.c_int32), ("sampling_rate", C.c_int32),
+                ("channels", C.c_int32), ("n_frames", C.c_int32), ("too_long", C.c_int32), ("n_bits", C.c_int32),
+                ("hide_offset", C.c_int64), ("bits", C.c_void_p)]
+
+
 # every symbol include/mp3s.h declares (tests/test_abi.py checks the library exports all of them)
 SYMBOLS = ["mp3s_ctx_create", "mp3s_ctx_destroy", "mp3s_last_error", "mp3s_version", "mp3s_device_name", "mp3s_sync", "mp3s_debug_tables", "mp3s_debug_scfsi_energies",
            "mp3s_dev_alloc", "mp3s_dev_free", "mp3s_dev_upload", "mp3s_dev_download", "mp3s_dev_memset",
            "mp3s_timer_start", "mp3s_timer_stop", "mp3s_profile_enable", "mp3s_profile_collect", "mp3s_decode_transform_dev", "mp3s_decode_transform",
            "mp3s_encode_transform_dev", "mp3s_encode_transform", "mp3s_rate_loop_dev", "mp3s_huffman_decode_dev", "mp3s_pack_frames_dev", "mp3s_scan_stream", "mp3s_buf_free",
-           "mp3s_parse_stream", "mp3s_format_stream", "mp3s_rate_frames", "mp3s_decode_stream", "mp3s_decode_streams", "mp3s_encode_pcm"]
+           "mp3s_parse_stream", "mp3s_format_stream", "mp3s_rate_frames", "mp3s_decode_stream", "mp3s_decode_streams", "mp3s_encode_pcm",
+           "mp3s_wav_parse", "mp3s_wav_header", "mp3s_message_frame", "mp3s_message_reveal", "mp3s_decode_file", "mp3s_encode_file",
+           "mp3s_hide_message", "mp3s_clear_file", "mp3s_reveal_message"]
 
 _lib = None
 _lock = threading.Lock()
@@ -135,6 +149,16 @@ def lib():
         L.mp3s_decode_stream.argtypes = [vp, vp, sz, i32, pvp, C.POINTER(Decoded)]
         L.mp3s_decode_streams.argtypes = [vp, pvp, C.POINTER(sz), i32, i32, pvp, C.POINTER(Decoded)]
         L.mp3s_encode_pcm.argtypes = [vp, vp, i64, i32, i32, i32, vp, i32, pvp, C.POINTER(Encoded)]
+        psz = C.POINTER(sz)
+        L.mp3s_wav_parse.argtypes = [vp, sz, i32, C.POINTER(WavInfo)]
+        L.mp3s_wav_header.argtypes = [i64, i32, i32, vp]
+        L.mp3s_message_frame.argtypes = [vp, sz, pvp, pvp, psz]
+        L.mp3s_message_reveal.argtypes = [vp, sz, pvp, pvp, psz]
+        L.mp3s_decode_file.argtypes = [vp, vp, sz, pvp, C.POINTER(File)]
+        L.mp3s_encode_file.argtypes = [vp, vp, sz, i32, vp, i32, pvp, C.POINTER(File)]
+        L.mp3s_hide_message.argtypes = [vp, vp, sz, vp, sz, pvp, C.POINTER(File)]
+        L.mp3s_clear_file.argtypes = [vp, vp, sz, pvp, C.POINTER(File)]
+        L.mp3s_reveal_message.argtypes = [vp, sz, pvp, C.POINTER(File)]
         _lib = L
     return _lib
 
@@ -299,6 +323,97 @@ class Context:
                     "scfsi": _view(e.scfsi, np.int32, (e.n_frames, 2, 4)), "rate_passes": e.rate_passes}
         finally:
             lib().mp3s_buf_free(owner)
+
+
+    # ---- whole files as byte strings (include/mp3s.h section vi)
+    @staticmethod
+    def _file(f, owner):
+        try:
+            return {"data": _view(f.data, np.uint8, (f.len,)).tobytes(), "kbps": f.kbps, "sampling_rate": f.sampling_rate,
+                    "channels": f.channels, "n_frames": f.n_frames, "too_long": bool(f.too_long),
+                    "hide_offset": f.hide_offset, "bits": _view(f.bits, np.uint8, (f.n_bits,))}
+        finally:
+            lib().mp3s_buf_free(owner)
+
+    def decode_file(self, mp3: bytes):
+        """MP3 bytes -> WAV bytes (+ kbps of the last header and the stego bits)."""
+        buf = np.frombuffer(mp3, dtype=np.uint8)
+        owner, f = C.c_void_p(), File()
+        check(lib().mp3s_decode_file(self.handle, buf.ctypes.data, len(mp3), C.byref(owner), C.byref(f)))
+        return self._file(f, owner)
+
+    def encode_file(self, wav: bytes, bitrate=320, hide_bits=None):
+        """WAV bytes -> MP3 bytes, with the reference's header checks and sample-count rules."""
+        buf = np.frombuffer(wav, dtype=np.uint8)
+        hb, nh = None, 0
+        if hide_bits is not None and len(hide_bits):
+            hb = np.ascontiguousarray(hide_bits, dtype=np.uint8)
+            nh = len(hb)
+        owner, f = C.c_void_p(), File()
+        check(lib().mp3s_encode_file(self.handle, buf.ctypes.data, len(wav), int(bitrate), hb.ctypes.data if hb is not None else None,
+                                     nh, C.byref(owner), C.byref(f)))
+        return self._file(f, owner)
+
+    def hide_message(self, mp3: bytes, message: str):
+        """decode + re-encode with "<count>#<message>" hidden; the PCM stays on the device in between."""
+        buf = np.frombuffer(mp3, dtype=np.uint8)
+        m = message.encode("utf-8")
+        mb = np.frombuffer(m, dtype=np.uint8) if m else None
+        owner, f = C.c_void_p(), File()
+        check(lib().mp3s_hide_message(self.handle, buf.ctypes.data, len(mp3), mb.ctypes.data if mb is not None else None, len(m),
+                                      C.byref(owner), C.byref(f)))
+        return self._file(f, owner)
+
+    def clear_file(self, mp3: bytes):
+        buf = np.frombuffer(mp3, dtype=np.uint8)
+        owner, f = C.c_void_p(), File()
+        check(lib().mp3s_clear_file(self.handle, buf.ctypes.data, len(mp3), C.byref(owner), C.byref(f)))
+        return self._file(f, owner)
+
+
+def reveal_message(mp3: bytes):
+    """MP3 bytes -> the hidden text as the reference writes it to the .txt (host scan only, no GPU)."""
+    buf = np.frombuffer(mp3, dtype=np.uint8)
+    owner, f = C.c_void_p(), File()
+    check(lib().mp3s_reveal_message(buf.ctypes.data, len(mp3), C.byref(owner), C.byref(f)))
+    return Context._file(f, owner)
+
+
+def wav_parse(data: bytes, bitrate=320):
+    """WAV header with the reference's checks (raises Mp3sError; code E_EXIT carries the reference's sys.exit text)."""
+    buf = np.frombuffer(data, dtype=np.uint8)
+    w = WavInfo()
+    check(lib().mp3s_wav_parse(buf.ctypes.data if len(data) else None, len(data), int(bitrate), C.byref(w)))
+    return {k: getattr(w, k) for k, _ in WavInfo._fields_}
+
+
+def wav_header(n_rows, nch, rate):
+    out = (C.c_uint8 * 44)()
+    check(lib().mp3s_wav_header(int(n_rows), int(nch), int(rate), out))
+    return bytes(out)
+
+
+def message_frame(message: str):
+    """'<character count>#<message>' as UTF-8 bits, MSB first (uint8 0/1)."""
+    m = message.encode("utf-8")
+    mb = np.frombuffer(m, dtype=np.uint8) if m else None
+    owner, p, n = C.c_void_p(), C.c_void_p(), C.c_size_t()
+    check(lib().mp3s_message_frame(mb.ctypes.data if mb is not None else None, len(m), C.byref(owner), C.byref(p), C.byref(n)))
+    try:
+        return _view(p.value, np.uint8, (n.value,))
+    finally:
+        lib().mp3s_buf_free(owner)
+
+
+def message_reveal(bits):
+    """The reference's reveal parse of a stego bit string -> the bytes it writes to the .txt."""
+    b = np.ascontiguousarray(bits, dtype=np.uint8)
+    owner, p, n = C.c_void_p(), C.c_void_p(), C.c_size_t()
+    check(lib().mp3s_message_reveal(b.ctypes.data if len(b) else None, len(b), C.byref(owner), C.byref(p), C.byref(n)))
+    try:
+        return _view(p.value, np.uint8, (n.value,)).tobytes()
+    finally:
+        lib().mp3s_buf_free(owner)
 
 
 def parse_stream(data: bytes):

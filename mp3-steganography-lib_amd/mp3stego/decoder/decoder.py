@@ -1,26 +1,14 @@
 """`Decoder` with the reference's signature and side effects (reference mp3stego/decoder/decoder.py:9-117).
 
-The file is parsed on the host, the per-frame transforms run on the GPU (mp3s_decode_stream), the WAV
-is written in the layout scipy.io.wavfile.write produces for int16 data, and the reveal-string parse
-is the reference's (decoder.py:86-108).
+One native call (mp3s_decode_file) turns the MP3 bytes into the WAV bytes scipy.io.wavfile.write would produce
+for the int16 PCM; the reveal-string parse (decoder.py:86-108) is native too (mp3s_message_reveal).
 """
 import os
-import struct
 import sys
 import time
 
-import numpy as np
 
 from mp3stego import _lib
-
-
-def _wav_bytes(pcm_i16: np.ndarray, rate: int) -> bytes:
-    data = np.ascontiguousarray(pcm_i16, dtype="<i2")
-    nch = 1 if data.ndim == 1 else data.shape[1]
-    nb = data.nbytes
-    return (b"RIFF" + struct.pack("<I", 36 + nb) + b"WAVE" + b"fmt " +
-            struct.pack("<IHHIIHH", 16, 1, nch, rate, rate * nch * 2, nch * 2, 16) +
-            b"data" + struct.pack("<I", nb) + data.tobytes())
 
 
 class Decoder:
@@ -48,7 +36,7 @@ class Decoder:
         """
         start = time.time()
         try:
-            res = _lib.default_context().decode_stream(self.__data, _lib.MP3S_PCM_I16)
+            res = _lib.default_context().decode_file(self.__data)
         except _lib.Mp3sError as e:
             if e.code in (_lib.E_MALFORMED, _lib.E_UNSUPPORTED):
                 raise ValueError(str(e)) from None
@@ -57,35 +45,17 @@ class Decoder:
         if not quiet:
             print('\nParsed', res["n_frames"], 'frames in', time.time() - start, 'seconds.')
         with open(self.__output_file_path, "wb") as f:
-            f.write(_wav_bytes(res["pcm"], res["sampling_rate"]))
+            f.write(res["data"])
         if not quiet:
             print(f"Wav file created on {self.__output_file_path}")
 
         if reveal:
             if txt_file_path[-4:] != '.txt':
                 sys.exit("txt_file_path must be txt file.")
-            bits = res["bits"]
-            n = (len(bits) // 8) * 8
-            by = np.packbits(bits[:n]) if n else np.zeros(0, dtype=np.uint8)
-            output_str = ''.join(chr(int(b)) for b in by)
-            message_len_str = ''
-            for ch in output_str:
-                if ch == '#':
-                    break
-                message_len_str += ch
-            try:
-                message_len = int(message_len_str)
-            except Exception:
-                message_len = 0
-                message_len_str = ""
-            if (len(message_len_str) + 1 + message_len) > len(output_str):
-                output_str = output_str[len(message_len_str) + 1:]
-            else:
-                output_str = output_str[len(message_len_str) + 1: len(message_len_str) + 1 + message_len]
             with open(txt_file_path, 'wb') as f:
-                f.write(bytes(output_str, 'utf-8'))
+                f.write(_lib.message_reveal(res["bits"]))
 
-        return res["bit_rate"] // 1000
+        return res["kbps"]
 
     @property
     def output_bits(self) -> str:

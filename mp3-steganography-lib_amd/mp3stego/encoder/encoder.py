@@ -1,6 +1,6 @@
 """`Encoder` with the reference's signature and behaviour (reference mp3stego/encoder/encoder.py:8-58,
 MP3_Encoder.py:596-618): WAV in, MP3 out, optional '0'/'1' string hidden in the Huffman-table choice.
-Analysis filterbank, MDCT and the rate loop run on the GPU (mp3s_encode_pcm); bit packing on the host.
+WAV parsing, analysis filterbank, MDCT, rate loop and bit packing all sit behind one native call (mp3s_encode_file).
 """
 import os
 import sys
@@ -36,29 +36,18 @@ class Encoder:
 
         :return: True if the message is too long for this file (it has been trimmed).
         """
-        w = self.__wav_file
-        nch = w.num_of_channels
-        total = w.num_of_samples * nch
-        per_pass = 1152 * nch
-        count = total // per_pass
-        # the reference steps its cursor by 2 per sample whatever the channel count and reads a partial last
-        # frame past the buffer: both end in IndexError there (SURVEY.md Appendix A, E3)
-        if nch != 2:
-            raise IndexError("mono input: the reference encoder indexes the sample buffer out of bounds")
-        if total % per_pass or len(w.buffer) < count * per_pass:
-            raise IndexError("sample count is not a multiple of 1152 per channel: the reference encoder reads past "
-                             "the end of the sample buffer")
-        pcm = np.ascontiguousarray(w.buffer[:count * per_pass]).reshape(-1, 2)
         hide = np.frombuffer(self.__hide_str.encode("ascii"), dtype=np.uint8) - ord("0") if self.__hide_str else None
         try:
-            res = _lib.default_context().encode_pcm(pcm, w.samplerate, w.bitrate, hide)
+            res = _lib.default_context().encode_file(self.__wav_file.data, self.__wav_file.bitrate, hide)
         except _lib.Mp3sError as e:
+            # mono input, a partial last frame (the reference steps its cursor by 2 per sample whatever the channel count
+            # and reads past the buffer: SURVEY Appendix A, E3) and a quantizer step off its table all end in IndexError
             if e.code in (_lib.E_UNSUPPORTED, _lib.E_STEP_RANGE):
-                raise IndexError(str(e)) from None
+                raise IndexError(e.text) from None
             raise
         self.hide_str_offset = int(res["hide_offset"])
         with open(self.__output_file_path, "wb") as f:
-            f.write(res["mp3"])
+            f.write(res["data"])
         too_long = self.hide_str_offset < len(self.__hide_str) - 1
         if not quiet:
             if too_long:
