@@ -118,7 +118,7 @@ def main():
     prep_s = time.time() - t_prep
 
     def step():
-        _lib.check(L.mp3s_huffman_decode_dev(ctx.handle, d_blob, d_side, n, 2, d_is, d_si, d_hst))
+        _lib.check(L.mp3s_huffman_decode_dev(ctx.handle, d_blob, d_side, n, 2, scanned["max_part2_3_length"], d_is, d_si, d_hst))
         _lib.check(L.mp3s_decode_transform_dev(ctx.handle, d_is, d_si, d_hdr, n, 2, 0, _lib.MP3S_PCM_I16, d_pcm))
         _lib.check(L.mp3s_encode_transform_dev(ctx.handle, d_pcm, d_hdr, n, d_mdct))
         _lib.check(L.mp3s_rate_loop_dev(ctx.handle, d_mdct, d_rf, n, d_hide, len(hide), d_cur1, d_state, None, 0,

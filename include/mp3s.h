@@ -204,8 +204,12 @@ typedef struct {
  * gr0): mp3s_scan_stream reports those (gpu_ok = 0) and the pipelines fall back to the host parser. */
 #define MP3S_HS_BAD_REGION 1
 #define MP3S_HS_BIG_VALUES 2
+#define MP3S_HS_HINT 4 /* some part2_3_length exceeds max_part2_3_length: call again with a larger bound (or 0) */
+/* max_part2_3_length: an upper bound on part2_3_length over the batch (the scan knows it: mp3s_scanned.max_part2_3_length),
+ * or 0 for the format's limit of 4095.  It sizes the per-thread staging of the bit stream in LDS and with it the number of
+ * resident wavefronts: 8 per CU for granules up to 900 bits, 2 at the limit. */
 int mp3s_huffman_decode_dev(mp3s_ctx *ctx, const uint8_t *d_blob, const mp3s_frame_side *d_side, int n_frames, int nch,
-                            int16_t *d_is, mp3s_granule_si *d_si, int32_t *d_status);
+                            int max_part2_3_length, int16_t *d_is, mp3s_granule_si *d_si, int32_t *d_status);
 
 /* replaces: __format_bitstream for every frame of the batch -- reference encoder/MP3_Encoder.py:1097-1145 (stuffing),
  * 1266-1547; one workgroup per frame, one wavefront per granule*channel, code lengths prefix-summed across lanes.
@@ -224,6 +228,7 @@ int mp3s_pack_frames_dev(mp3s_ctx *ctx, const int16_t *d_ix, const mp3s_gr_out *
 typedef struct {
     int32_t n_frames, nch, sampling_rate, bit_rate, n_bits, dup_last_frame;
     int32_t gpu_ok;               /* 0: scalefactors are inherited across frames somewhere -> use mp3s_parse_stream */
+    int32_t max_part2_3_length;   /* over all granules: the bound mp3s_huffman_decode_dev wants */
     const mp3s_frame_side *side;  /* [n_frames] */
     const mp3s_frame_hdr *hdr;    /* [n_frames] */
     const uint8_t *blob;          /* main data of all frames */

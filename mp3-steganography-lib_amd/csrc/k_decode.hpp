@@ -18,6 +18,17 @@
 
 namespace mp3s {
 
+// Workgroup b runs on XCD b % 8 and every XCD has its own L2.  Neighbouring tiles of the transform kernels share
+// halo rows (previous granule, 15 earlier time slots), so each XCD gets a CONTIGUOUS range of tiles: the halo a
+// workgroup needs was just read by the workgroup before it on the same XCD.
+__device__ __forceinline__ int xcd_tile()
+{
+    const int b = blockIdx.x, G = gridDim.x;
+    const int x = b & 7, q = G >> 3, r = G & 7;
+    return x * q + (x < r ? x : r) + (b >> 3);
+}
+
+
 __device__ __forceinline__ double shfl_xor_f64(double v, int mask)
 {
     int lo = __double2loint(v), hi = __double2hiint(v);
@@ -134,7 +145,7 @@ __global__ __launch_bounds__(DEC_A_WAVES * 64, 3) void k_dec_imdct(
     if (threadIdx.x < POW2H_N) sh.pow2h[threadIdx.x] = c_tab.pow2h[threadIdx.x];
     __syncthreads();
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
-    const int g0 = (blockIdx.x * DEC_A_WAVES + wave) * run;
+    const int g0 = (xcd_tile() * DEC_A_WAVES + wave) * run;
     if (g0 >= n_granules) return;  // whole wave exits together
     const int ch = lane >> 5, sb = lane & 31;
     const bool live = ch < nch;
@@ -257,7 +268,7 @@ __global__ __launch_bounds__(TW * 64 * 2, (TW * 2 * 2) / 4) void k_dec_synth(
     __shared__ uint32_t otile[OUT * OROW];
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
     const int ch = wave / TW, tl = (wave % TW) * 64 + lane;
-    const long tile0 = (long)blockIdx.x * OUT;
+    const long tile0 = (long)xcd_tile() * OUT;
     const long t = tile0 - 15 + tl;
     const bool valid = t >= 0 && t < T;
     int lim = -1;            // number of earlier in-stream slots (V history available), -1: slot not valid

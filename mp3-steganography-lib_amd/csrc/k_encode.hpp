@@ -27,7 +27,7 @@ __global__ __launch_bounds__(256, 3) void k_enc_analysis(
     __shared__ __attribute__((aligned(16))) uint32_t lds_all[4][ENC_LDS_DW];
     static_assert(79 * ENC_ROW * 2 <= ENC_LDS_DW * 4, "PCM tile must fit");
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
-    const long wid = (long)blockIdx.x * 4 + wave;
+    const long wid = (long)xcd_tile() * 4 + wave;
     const int ch = (int)(wid & 1);
     const long t0 = (wid >> 1) * 64;          // first slot of this wave
     if (t0 >= Ts) return;
@@ -116,7 +116,7 @@ __global__ __launch_bounds__(256) void k_enc_mdct(
     int32_t *__restrict__ mdct)
 {
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
-    const int g = blockIdx.x * 4 + wave;
+    const int g = xcd_tile() * 4 + wave;
     if (g >= n_granules) return;
     const int ch = lane >> 5, band = lane & 31;
     const bool has_prev = g > (int)hdr[g >> 1].stream_first * 2;   // l3_sb_sample[ch][0] starts zeroed

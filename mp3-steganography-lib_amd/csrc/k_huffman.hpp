@@ -12,8 +12,9 @@
 
 namespace mp3s {
 
-constexpr int HUF_THREADS = 64;
-constexpr int HUF_WORDS = 132;   // 4095 bits of part2_3_length + alignment slack, per thread
+constexpr int HUF_WORDS_MAX = 132;   // 4095 bits of part2_3_length + alignment slack, per thread
+// words of LDS staging a thread needs for granules of at most `bits` bits (any alignment, +64 bits of look-ahead)
+constexpr int huf_words_for(int bits) { return (bits + 94) / 32 + 4 < HUF_WORDS_MAX ? (bits + 94) / 32 + 4 : HUF_WORDS_MAX; }
 
 // global-memory word fetch: big-endian, bytes past `len` read as zero (decoder/util.py:41-43)
 __device__ __forceinline__ uint32_t md_word(const uint32_t *w, uint32_t len, uint32_t i)
@@ -33,165 +34,252 @@ __device__ __forceinline__ uint32_t md_get(const uint32_t *w, uint32_t len, uint
     return (sh ? (w0 << sh) | (w1 >> (32 - sh)) : w0) >> (32 - n);
 }
 
-// Bit reader over the lane's column of LDS: the words covering this granule's bits are copied there up front, so the
-// decode loop touches no global memory except its (never waited for) stores.
-struct BitReader {
-    const uint32_t *lds;   // word j of this lane at lds[j * HUF_THREADS]
-    uint32_t base;         // index of the first staged word
-    __device__ __forceinline__ uint64_t peek64(uint32_t pos) const
+// Bit stream over the lane's column of LDS: the words covering this granule's bits are copied there up front, so the
+// decode loop touches no global memory except its (never waited for) stores.  The next 33..64 bits live in a register
+// window; the word that will be appended next is loaded one refill ahead, so the only LDS access a symbol waits for is
+// its code-book look-up.
+template <int T>
+struct BitStream {
+    const uint32_t *lds;   // word j of this lane at lds[j * T]
+    uint32_t last;         // W - 1: malformed streams may run past part2_3_length, the reader stays inside the column
+    uint32_t idx;          // staged word that `nxt` holds
+    uint32_t nxt;
+    uint64_t win;          // next bit = MSB; bits below `valid` are zero
+    int valid;
+    __device__ __forceinline__ void open(const uint32_t *col, uint32_t W, uint32_t bit)
     {
-        uint32_t j = (pos >> 5) - base;
-        const uint32_t sh = pos & 31;
-        j = j < HUF_WORDS - 3 ? j : HUF_WORDS - 3;   // malformed streams may run past part2_3_length: stay inside the column
-        const uint32_t w0 = lds[j * HUF_THREADS], w1 = lds[(j + 1) * HUF_THREADS], w2 = lds[(j + 2) * HUF_THREADS];
-        const uint32_t hi = sh ? (w0 << sh) | (w1 >> (32 - sh)) : w0;
-        const uint32_t lo = sh ? (w1 << sh) | (w2 >> (32 - sh)) : w1;
-        return ((uint64_t)hi << 32) | lo;
+        lds = col; last = W - 1;
+        const uint32_t sh = bit & 31;
+        win = (((uint64_t)lds[0] << 32) | lds[T]) << sh;
+        valid = 64 - (int)sh;
+        idx = 2; nxt = lds[2 * T];
     }
-    __device__ __forceinline__ uint32_t peek32(uint32_t pos) const { return (uint32_t)(peek64(pos) >> 32); }
-    __device__ __forceinline__ uint32_t get(uint32_t pos, int n) const { return n ? peek32(pos) >> (32 - n) : 0u; }
+    // afterwards more than 32 bits are valid: enough for a code word and two sign bits, or for linbits + sign twice
+    __device__ __forceinline__ void refill()
+    {
+        if (valid <= 32) {
+            win |= (uint64_t)nxt << (32 - valid);
+            valid += 32;
+            idx = idx < last ? idx + 1 : last;
+            nxt = lds[idx * T];
+        }
+    }
+    __device__ __forceinline__ uint32_t top(int n) const { return (uint32_t)(win >> (64 - n)); }   // 1 <= n <= 32
+    __device__ __forceinline__ void skip(int n) { win <<= n; valid -= n; }
+    __device__ __forceinline__ uint32_t get(int n)   // n <= 4 (scalefactors)
+    {
+        if (!n) return 0;
+        refill();
+        const uint32_t v = top(n);
+        skip(n);
+        return v;
+    }
 };
 
+// mp3s_frame_side (104 bytes) in 26 registers: 13 independent 8-byte loads, one wait; fields by constant offsets, the
+// four unit records by select (a struct copy with a run-time index would go through scratch)
+struct SideRegs {
+    uint32_t d[26];
+    __device__ __forceinline__ void load(const mp3s_frame_side *p)
+    {
+        const uint2 *q = reinterpret_cast<const uint2 *>(p);
+#pragma unroll
+        for (int i = 0; i < 13; i++) { const uint2 v = q[i]; d[2 * i] = v.x; d[2 * i + 1] = v.y; }
+    }
+    __device__ __forceinline__ uint32_t unit_dw(int k, int j) const   // dword j of unit[k >> 1][k & 1]
+    {
+        const uint32_t a = k & 1 ? d[10 + j] : d[5 + j], b = k & 1 ? d[20 + j] : d[15 + j];
+        return k & 2 ? b : a;
+    }
+    __device__ __forceinline__ uint32_t p23(int k) const { return d[5 + 5 * k] & 0xffffu; }   // k is a constant here
+};
 
-// one thread per granule*channel; unit index = (frame*2 + gr)*2 + ch (same order as the si / is arrays)
-__global__ __launch_bounds__(HUF_THREADS) void k_dec_huffman(
-    const uint8_t *__restrict__ blob, const mp3s_frame_side *__restrict__ side, int n_frames, int nch, int active,
+// One thread per granule*channel; unit index = (frame*2 + gr)*2 + ch (same order as the si / is arrays).
+// LDS = the shared first-level tables (30.8 KB) + W words of staged bits per thread.  A wave is a chain of dependent LDS
+// look-ups, so throughput comes from resident waves: W is sized by the launcher from the longest granule of the batch
+// (30 words at 128 kbps instead of the worst-case 132), which lets 8 waves share a CU instead of 2.
+template <int T>
+__global__ __launch_bounds__(T) void k_dec_huffman(
+    const uint8_t *__restrict__ blob, const mp3s_frame_side *__restrict__ side, int n_frames, int nch, int W, int max_bits,
     int16_t *__restrict__ is, mp3s_granule_si *__restrict__ si_out, int32_t *__restrict__ status)
 {
     __shared__ uint16_t fast[15][1024];
     __shared__ uint16_t quad[64];
-    __shared__ uint32_t words[HUF_WORDS * HUF_THREADS];
+    __shared__ uint16_t tinfo[32];        // table_select -> first-level table id | linbits << 8
+    extern __shared__ uint32_t words[];   // [W][T]
     {
         const uint4 *src = reinterpret_cast<const uint4 *>(&c_tab.huff_fast[0][0]);
         uint4 *dst = reinterpret_cast<uint4 *>(&fast[0][0]);
+        constexpr int N16 = 15 * 1024 * 2 / 16, ROUNDS = (N16 + T - 1) / T;
+        uint4 v[ROUNDS <= 8 ? ROUNDS : 8];
+        if constexpr (ROUNDS <= 8) {      // every load in flight before the first LDS write
+#pragma unroll
+            for (int r = 0; r < ROUNDS; r++) { const int i = threadIdx.x + r * T; v[r] = src[i < N16 ? i : N16 - 1]; }
+#pragma unroll
+            for (int r = 0; r < ROUNDS; r++) { const int i = threadIdx.x + r * T; if (i < N16) dst[i] = v[r]; }
+        } else {
 #pragma unroll 6
-        for (int i = threadIdx.x; i < 15 * 1024 * 2 / 16; i += HUF_THREADS) dst[i] = src[i];
-        quad[threadIdx.x & 63] = c_tab.quad_fast[threadIdx.x & 63];
+            for (int i = threadIdx.x; i < N16; i += T) dst[i] = src[i];
+        }
+        if (threadIdx.x < 64) quad[threadIdx.x] = c_tab.quad_fast[threadIdx.x];
+        if (threadIdx.x < 32) tinfo[threadIdx.x] = (uint16_t)(c_tab.huff_lut_id[threadIdx.x] | (c_tab.linbits[threadIdx.x] << 8));
     }
     __syncthreads();
-    // only `active` lanes of the wave decode: every lane walks its own bit stream, so a wave runs as long as its
-    // slowest lane and pays every lane's branches; with few waves to spare, narrower waves finish sooner
-    const long tid0 = (long)blockIdx.x * active;
-    const long tid = tid0 + threadIdx.x;
-    const bool worker = (int)threadIdx.x < active && tid < (long)n_frames * 4 && (int)(tid & 1) < nch;
+    const long tid = (long)blockIdx.x * T + threadIdx.x;
+    const bool worker = tid < (long)n_frames * 4 && (int)(tid & 1) < nch;
     if (worker) {
-    const int f = (int)(tid >> 2), gr = (int)((tid >> 1) & 1), ch = (int)(tid & 1);
-    const mp3s_frame_side *fs = side + f;
+    const int f = (int)(tid >> 2), k = (int)(tid & 3), gr = k >> 1, ch = k & 1;
+    SideRegs fs;
+    fs.load(side + f);
     static const uint8_t kSlen[16][2] = {{0, 0}, {0, 1}, {0, 2}, {0, 3}, {3, 0}, {1, 1}, {1, 2}, {1, 3},
                                          {2, 1}, {2, 2}, {2, 3}, {3, 1}, {3, 2}, {3, 3}, {4, 2}, {4, 3}};
-    const int sr = fs->sr_idx < 3 ? fs->sr_idx : 0;
+    const uint32_t md_off = fs.d[0], md_len = fs.d[1];
+    const int sr_raw = (int)((fs.d[2] >> 8) & 0xff), sr = sr_raw < 3 ? sr_raw : 0;
     // bit offset of this unit and (for scfsi) of granule 0 of the same channel: units are laid out gr-major
-    uint32_t bit = 0, bit_g0 = 0;
-    for (int g2 = 0; g2 < 2; g2++)
-        for (int c = 0; c < nch; c++) {
-            if (g2 == 0 && c < ch) bit_g0 += fs->unit[0][c].part2_3_length;
-            if (g2 * 2 + c < gr * 2 + ch) bit += fs->unit[g2][c].part2_3_length;
-        }
-    const mp3s_unit_side &u = fs->unit[gr][ch];
-    const uint32_t max_bit = bit + u.part2_3_length;
+    const uint32_t l0 = fs.p23(0), l1 = nch > 1 ? fs.p23(1) : 0u, l2 = fs.p23(2);
+    const uint32_t bit_g0 = ch ? l0 : 0u;
+    uint32_t bit = (k >= 1 ? l0 : 0u) + (k >= 2 ? l1 : 0u) + (k >= 3 ? l2 : 0u);
+    if (nch == 1) bit = gr ? l0 : 0u;
+    const uint32_t u0 = fs.unit_dw(k, 0), u1 = fs.unit_dw(k, 1), u2 = fs.unit_dw(k, 2), u3 = fs.unit_dw(k, 3), u4 = fs.unit_dw(k, 4);
+    const uint32_t part2_3_length = u0 & 0xffffu, big_values = u0 >> 16;
+    const uint32_t scalefac_compress = (u1 >> 8) & 0xff, window_switching = (u1 >> 16) & 0xff, block_type = u1 >> 24;
+    const uint32_t mixed_block_flag = u2 & 0xff;
+    const uint32_t region0_count = u3 & 0xff, region1_count = (u3 >> 8) & 0xff;
+    const uint32_t count1table_select = u4 & 0xff;
+    const uint32_t scfsi = ch ? fs.d[4] : fs.d[3];   // one byte per band
+    const uint32_t max_bit = bit + part2_3_length;
     int err = 0;
-    const uint32_t *mdw = reinterpret_cast<const uint32_t *>(blob + fs->md_off);
-    const uint32_t md_len = fs->md_len;
-    BitReader br;
-    br.lds = words + threadIdx.x;
-    br.base = bit >> 5;
+    const uint32_t *mdw = reinterpret_cast<const uint32_t *>(blob + md_off);
+    if ((int)part2_3_length > max_bits) err |= MP3S_HS_HINT;   // the caller's bound on part2_3_length does not hold
+    BitStream<T> br;
     {
-        const uint32_t nw = ((max_bit + 63) >> 5) - br.base + 3;
-        for (uint32_t j = 0; j < nw && j < HUF_WORDS; j++) words[j * HUF_THREADS + threadIdx.x] = md_word(mdw, md_len, br.base + j);
+        // stage the words covering this granule: loads first (clamped to a word inside the zero bytes that follow the
+        // frame), then the big-endian swap, the masking of bytes past md_len (decoder/util.py:41-43) and the LDS writes
+        const uint32_t base = bit >> 5, nw0 = ((max_bit + 63) >> 5) - base + 3, nw = nw0 < (uint32_t)W ? nw0 : (uint32_t)W;
+        const uint32_t imax = (md_len + 3) >> 2;
+        for (uint32_t j0 = 0; j0 < nw; j0 += 8) {
+            uint32_t v[8];
+#pragma unroll
+            for (int q = 0; q < 8; q++) { const uint32_t i = base + j0 + q; v[q] = mdw[i < imax ? i : imax]; }
+#pragma unroll
+            for (int q = 0; q < 8; q++) {
+                const uint32_t i = base + j0 + q, byte0 = i * 4;
+                uint32_t x = __builtin_bswap32(v[q]);
+                const uint32_t valid = md_len - byte0;                 // meaningful when byte0 < md_len
+                if (byte0 >= md_len) x = 0;
+                else if (valid < 4) x &= 0xffffffffu << (8 * (4 - valid));
+                if (j0 + q < nw) words[(j0 + q) * T + threadIdx.x] = x;
+            }
+        }
+        br.open(words + threadIdx.x, (uint32_t)W, bit);
     }
-    uint8_t *g = reinterpret_cast<uint8_t *>(si_out + tid);
-    g[0] = u.global_gain; g[1] = u.scalefac_scale; g[2] = u.block_type; g[3] = u.mixed_block_flag; g[4] = u.preflag;
-    g[5] = u.sub_block_gain[0]; g[6] = u.sub_block_gain[1]; g[7] = u.sub_block_gain[2];
+    uint32_t *g32 = reinterpret_cast<uint32_t *>(si_out + tid);
+    // global_gain, scalefac_scale, block_type, mixed_block_flag | preflag, sub_block_gain[3]
+    g32[0] = (u1 & 0xff) | ((u3 >> 24) << 8) | (block_type << 16) | (mixed_block_flag << 24);
+    g32[1] = ((u3 >> 16) & 0xff) | ((u4 >> 8) << 8);
+    uint8_t *g = reinterpret_cast<uint8_t *>(g32);
     uint8_t *sf_l = g + 8, *sf_s = g + 30;   // scale_fac_l[22], scale_fac_s[3][13]; the record was zeroed by the launcher
-    const int sl0 = kSlen[u.scalefac_compress & 15][0], sl1 = kSlen[u.scalefac_compress & 15][1];
+    const int sl0 = kSlen[scalefac_compress & 15][0], sl1 = kSlen[scalefac_compress & 15][1];
+    const bool short_win = block_type == 2 && window_switching;
     // ---- scalefactors (Frame.py:365-441)
-    if (gr == 1 && !(u.block_type == 2 && u.window_switching) &&
-        (fs->scfsi[ch][0] | fs->scfsi[ch][1] | fs->scfsi[ch][2] | fs->scfsi[ch][3])) {
+    if (gr == 1 && !short_win && scfsi) {
         // bands flagged by scfsi are copied from granule 0 (:423-437): decode them from granule 0's own bits
-        const mp3s_unit_side u0 = fs->unit[0][ch];
-        const int z0 = kSlen[u0.scalefac_compress & 15][0], z1 = kSlen[u0.scalefac_compress & 15][1];
+        const uint32_t c0 = ((ch ? fs.d[11] : fs.d[6]) >> 8) & 15;
+        const int z0 = kSlen[c0][0], z1 = kSlen[c0][1];
         uint32_t b0 = bit_g0;
         for (int s = 0; s < 21; s++) {
             const int sl = s < 11 ? z0 : z1;
             const int band = s < 6 ? 0 : (s < 11 ? 1 : (s < 16 ? 2 : 3));
             const uint32_t v = md_get(mdw, md_len, b0, sl); b0 += sl;
-            if (fs->scfsi[ch][band]) sf_l[s] = (uint8_t)v;
+            if ((scfsi >> (8 * band)) & 0xff) sf_l[s] = (uint8_t)v;
         }
     }
-    if (u.block_type == 2 && u.window_switching) {
-        if (u.mixed_block_flag) {
-            for (int s = 0; s < 8; s++) { sf_l[s] = (uint8_t)br.get(bit, sl0); bit += sl0; }
+    if (short_win) {
+        if (mixed_block_flag) {
+            for (int s = 0; s < 8; s++) { sf_l[s] = (uint8_t)br.get(sl0); bit += sl0; }
             for (int s = 3; s < 6; s++)
-                for (int w = 0; w < 3; w++) { sf_s[w * 13 + s] = (uint8_t)br.get(bit, sl0); bit += sl0; }
+                for (int w = 0; w < 3; w++) { sf_s[w * 13 + s] = (uint8_t)br.get(sl0); bit += sl0; }
         } else {
             for (int s = 0; s < 6; s++)
-                for (int w = 0; w < 3; w++) { sf_s[w * 13 + s] = (uint8_t)br.get(bit, sl0); bit += sl0; }
+                for (int w = 0; w < 3; w++) { sf_s[w * 13 + s] = (uint8_t)br.get(sl0); bit += sl0; }
         }
         for (int s = 6; s < 12; s++)
-            for (int w = 0; w < 3; w++) { sf_s[w * 13 + s] = (uint8_t)br.get(bit, sl1); bit += sl1; }
+            for (int w = 0; w < 3; w++) { sf_s[w * 13 + s] = (uint8_t)br.get(sl1); bit += sl1; }
     } else if (gr == 0) {
-        for (int s = 0; s < 11; s++) { sf_l[s] = (uint8_t)br.get(bit, sl0); bit += sl0; }
-        for (int s = 11; s < 21; s++) { sf_l[s] = (uint8_t)br.get(bit, sl1); bit += sl1; }
+        for (int s = 0; s < 11; s++) { sf_l[s] = (uint8_t)br.get(sl0); bit += sl0; }
+        for (int s = 11; s < 21; s++) { sf_l[s] = (uint8_t)br.get(sl1); bit += sl1; }
     } else {
         for (int s = 0; s < 21; s++) {
             const int band = s < 6 ? 0 : (s < 11 ? 1 : (s < 16 ? 2 : 3)), sl = s < 11 ? sl0 : sl1;
-            if (!fs->scfsi[ch][band]) { sf_l[s] = (uint8_t)br.get(bit, sl); bit += sl; }
+            if (!((scfsi >> (8 * band)) & 0xff)) { sf_l[s] = (uint8_t)br.get(sl); bit += sl; }
         }
     }
-    // ---- big values (Frame.py:458-518)
+    // ---- big values (Frame.py:458-518).  One flat loop over the pairs: the region (and with it the code book) is
+    //      looked up per pair, so a wave runs for its longest granule, not for the longest region 0 + region 1 + region 2.
     uint32_t *smp = reinterpret_cast<uint32_t *>(is) + tid * 288;   // pair j; the buffer was zeroed by the launcher
     int region0, region1;
     bool ok = true;
-    if (u.window_switching && u.block_type == 2) { region0 = 36; region1 = 576; }
+    if (short_win) { region0 = 36; region1 = 576; }
     else {
-        const int i0 = u.region0_count + 1, i1 = i0 + u.region1_count + 1;
+        const int i0 = (int)region0_count + 1, i1 = i0 + (int)region1_count + 1;
         if (i0 > 22 || i1 > 22) { err |= MP3S_HS_BAD_REGION; ok = false; region0 = region1 = 0; }
         else { region0 = c_tab.sfb_long[sr][i0]; region1 = c_tab.sfb_long[sr][i1]; }
     }
-    if (ok) {
+    const int bv2 = (int)big_values * 2;
+    if (bv2 > 576) err |= MP3S_HS_BIG_VALUES;                     // the reference runs off its sample array (IndexError)
+    if (ok && !err) {
         int sample = 0;
-        const int bv2 = (int)u.big_values * 2;
-        for (int r = 0; r < 3 && sample < bv2; r++) {
-            const int rend = r == 0 ? region0 : (r == 1 ? region1 : 1 << 30);
-            const int tn = (r == 0 ? u.table_select[0] : (r == 1 ? u.table_select[1] : u.table_select[2])) & 31;
-            const int lut = c_tab.huff_lut_id[tn], lb = c_tab.linbits[tn];
-            while (sample < bv2 && sample < rend) {
-                if (sample + 1 >= 576) { err |= MP3S_HS_BIG_VALUES; break; }
-                if (lut == 255) { sample += 2; continue; }        // books 0, 4, 14: zeros, no bits (D2)
-                const uint64_t win64 = br.peek64(bit);
-                const uint32_t window = (uint32_t)(win64 >> 32);
-                const uint32_t e = fast[lut][window >> 22];
-                int len = 0, sym = -1;
-                if (e & 0x8000u) {                                // continue in the trie below the 10-bit prefix
-                    uint32_t node = e & 0x7fffu;
-                    for (int d = HUFF_FAST_BITS; d < 24; d++) {
-                        const uint32_t nxt = c_tab.huff_tree[lut][node][(window >> (31 - d)) & 1];
-                        if (!nxt) break;
-                        if (nxt & 0x8000u) { sym = nxt & 0xff; len = d + 1; break; }
-                        node = nxt;
-                    }
-                } else if (e) { sym = e & 0xff; len = e >> 8; }
-                if (sym >= 0) {
-                    // linbits and sign bits follow the code word: x linbits, x sign, y linbits, y sign (:499-513)
-                    uint64_t rest = win64 << len;
-                    int used = len;
-                    int v0 = sym >> 4, v1 = sym & 15;
-                    if (lb && v0 == 15) { v0 += (int)(rest >> (64 - lb)); rest <<= lb; used += lb; }
-                    if ((sym >> 4) > 0) { if (rest >> 63) v0 = -v0; rest <<= 1; used += 1; }
-                    if (lb && v1 == 15) { v1 += (int)(rest >> (64 - lb)); rest <<= lb; used += lb; }
-                    if ((sym & 15) > 0) { if (rest >> 63) v1 = -v1; used += 1; }
-                    bit += used;
-                    if (v0 | v1) smp[sample >> 1] = (uint32_t)(uint16_t)v0 | ((uint32_t)(uint16_t)v1 << 16);
-                }
-                sample += 2;
+        const uint32_t ti0 = tinfo[(u2 >> 8) & 31], ti1 = tinfo[(u2 >> 16) & 31], ti2 = tinfo[(u2 >> 24) & 31];
+        while (sample < bv2) {
+            const uint32_t ti = sample < region0 ? ti0 : (sample < region1 ? ti1 : ti2);
+            const int lut = (int)(ti & 0xff), lb = (int)(ti >> 8);
+            if (lut == 255) {                                     // books 0, 4, 14: zeros, no bits (D2): skip the region
+                const int rend = sample < region0 ? region0 : (sample < region1 ? region1 : bv2);
+                sample = rend < bv2 ? rend : bv2;                 // region bounds are even
+                continue;
             }
-            if (err) break;
+            br.refill();
+            const uint32_t window = br.top(32);
+            const uint32_t e = fast[lut][window >> 22];
+            int len = 0, sym = -1;
+            if (e & 0x8000u) {                                    // continue in the trie below the 10-bit prefix
+                uint32_t node = e & 0x7fffu;
+                for (int d = HUFF_FAST_BITS; d < 24; d++) {
+                    const uint32_t nxt = c_tab.huff_tree[lut][node][(window >> (31 - d)) & 1];
+                    if (!nxt) break;
+                    if (nxt & 0x8000u) { sym = nxt & 0xff; len = d + 1; break; }
+                    node = nxt;
+                }
+            } else if (e) { sym = e & 0xff; len = e >> 8; }
+            if (sym >= 0) {
+                // linbits and sign bits follow the code word: x linbits, x sign, y linbits, y sign (:499-513)
+                int v0 = sym >> 4, v1 = sym & 15;
+                br.skip(len);
+                int used = len;
+                if (lb && (v0 == 15 || v1 == 15)) {               // escape values: up to 2 x (13 + 1) more bits
+                    br.refill();
+                    if (v0 == 15) { v0 += (int)br.top(lb); br.skip(lb); used += lb; }
+                    if (v0) { if (br.top(1)) v0 = -v0; br.skip(1); used += 1; }
+                    if (v1 == 15) { v1 += (int)br.top(lb); br.skip(lb); used += lb; }
+                    if (v1) { if (br.top(1)) v1 = -v1; br.skip(1); used += 1; }
+                } else {
+                    const uint32_t sg = br.top(2);
+                    const int n0 = v0 != 0, n1 = v1 != 0;
+                    if (n0 && (sg >> 1)) v0 = -v0;
+                    if (n1 && ((n0 ? sg : sg >> 1) & 1)) v1 = -v1;
+                    br.skip(n0 + n1); used += n0 + n1;
+                }
+                bit += used;
+                if (v0 | v1) smp[sample >> 1] = (uint32_t)(uint16_t)v0 | ((uint32_t)(uint16_t)v1 << 16);
+            }
+            sample += 2;
         }
         // ---- count1 quadruples (Frame.py:521-554, D1)
         while (!err && bit < max_bit && sample + 4 < 576) {
-            uint32_t window = br.peek32(bit);
+            br.refill();
+            uint32_t window = br.top(32);
             int val, used;
-            if (u.count1table_select) { val = (int)((window >> 28) ^ 15u); used = 4; }
+            if (count1table_select) { val = (int)((window >> 28) ^ 15u); used = 4; }
             else {
                 const uint32_t s = quad[window >> 26];
                 val = s ? (int)(s & 15) : 0;
@@ -204,6 +292,7 @@ __global__ __launch_bounds__(HUF_THREADS) void k_dec_huffman(
                 q[i] = (val >> (3 - i)) & 1;
                 if (q[i]) { if (window >> 31) q[i] = -1; window <<= 1; used += 1; }
             }
+            br.skip(used);
             bit += used;
             if (val) {
                 smp[sample >> 1] = (uint32_t)(uint16_t)q[0] | ((uint32_t)(uint16_t)q[1] << 16);

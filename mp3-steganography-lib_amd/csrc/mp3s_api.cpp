@@ -340,12 +340,21 @@ int mp3s_rate_loop_dev(mp3s_ctx *c, const int32_t *d_mdct, const mp3s_rate_frame
     return MP3S_OK;
 }
 
+static int max_part2_3(const mp3s_frame_side *side, long n)
+{
+    int m = 0;
+    for (long f = 0; f < n; f++)
+        for (int k = 0; k < 4; k++) m = std::max<int>(m, side[f].unit[k >> 1][k & 1].part2_3_length);
+    return m;
+}
+
 int mp3s_huffman_decode_dev(mp3s_ctx *c, const uint8_t *d_blob, const mp3s_frame_side *d_side, int n_frames, int nch,
-                            int16_t *d_is, mp3s_granule_si *d_si, int32_t *d_status)
+                            int max_part2_3_length, int16_t *d_is, mp3s_granule_si *d_si, int32_t *d_status)
 {
     if (!c || !d_blob || !d_side || !d_is || !d_si || !d_status) return fail(MP3S_E_ARG, "null pointer");
-    if (n_frames <= 0 || nch < 1 || nch > 2) return fail(MP3S_E_ARG, "bad sizes");
-    const int e = launch_huffman(c->stream, d_blob, d_side, n_frames, nch, d_is, d_si, d_status, &c->prof);
+    if (n_frames <= 0 || nch < 1 || nch > 2 || max_part2_3_length < 0) return fail(MP3S_E_ARG, "bad sizes");
+    if (max_part2_3_length == 0 || max_part2_3_length > 4095) max_part2_3_length = 4095;
+    const int e = launch_huffman(c->stream, d_blob, d_side, n_frames, nch, max_part2_3_length, d_is, d_si, d_status, &c->prof);
     if (e) return fail(MP3S_E_HIP, "huffman launch: %s", hipGetErrorString((hipError_t)e));
     return MP3S_OK;
 }
@@ -376,6 +385,7 @@ int mp3s_scan_stream(const uint8_t *file, size_t len, mp3s_buf **owner, mp3s_sca
     out->n_frames = p.n_frames; out->nch = p.nch; out->sampling_rate = p.sampling_rate; out->bit_rate = p.bit_rate;
     out->n_bits = (int32_t)p.bits.size(); out->dup_last_frame = p.dup_last_frame;
     out->gpu_ok = b->scanned.gpu_ok ? 1 : 0;
+    out->max_part2_3_length = max_part2_3(b->scanned.side.data(), p.n_frames);
     out->side = b->scanned.side.data(); out->hdr = p.hdr.data();
     out->blob = b->scanned.blob.data(); out->blob_len = b->scanned.blob.size();
     out->bits = p.bits.data(); out->frame_size = p.frame_size.data();
@@ -472,7 +482,7 @@ static int decode_group(mp3s_ctx *c, mp3s_multi &m, const std::vector<int> &idx,
     if (any_dev) {
         rc = mp3s_dev_upload(c, d_blob, blob.data(), blob.size());
         if (!rc) rc = mp3s_dev_upload(c, d_side, side.data(), (size_t)n * sizeof(mp3s_frame_side));
-        if (!rc) rc = mp3s_huffman_decode_dev(c, (const uint8_t *)d_blob, (const mp3s_frame_side *)d_side, (int)n, nch,
+        if (!rc) rc = mp3s_huffman_decode_dev(c, (const uint8_t *)d_blob, (const mp3s_frame_side *)d_side, (int)n, nch, max_part2_3(side.data(), n),
                                               (int16_t *)d_is, (mp3s_granule_si *)d_si, (int32_t *)d_st);
         int32_t st = 0;
         if (!rc) rc = mp3s_dev_download(c, &st, d_st, sizeof st);

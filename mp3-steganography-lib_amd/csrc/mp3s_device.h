@@ -43,7 +43,7 @@ int launch_rate(hipStream_t stream, const int32_t *d_mdct, const mp3s_rate_frame
                 const int32_t *d_list, int n_list, int16_t *d_ix, mp3s_gr_out *d_out, int32_t *d_en, Profiler *prof);
 
 // bit-level stages on the device
-int launch_huffman(hipStream_t stream, const uint8_t *d_blob, const mp3s_frame_side *d_side, int n_frames, int nch,
+int launch_huffman(hipStream_t stream, const uint8_t *d_blob, const mp3s_frame_side *d_side, int n_frames, int nch, int max_bits,
                    int16_t *d_is, mp3s_granule_si *d_si, int32_t *d_status, Profiler *prof);
 int launch_pack(hipStream_t stream, const int16_t *d_ix, const mp3s_gr_out *d_gr, const int32_t *d_en, int n_frames, int sri,
                 int bri, int whole_slots, const uint32_t *d_frame_off, const uint8_t *d_padding, uint8_t *d_mp3,

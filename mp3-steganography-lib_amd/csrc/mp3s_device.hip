@@ -119,20 +119,26 @@ int launch_rate(hipStream_t stream, const int32_t *d_mdct, const mp3s_rate_frame
     return (int)hipGetLastError();
 }
 
-int launch_huffman(hipStream_t stream, const uint8_t *d_blob, const mp3s_frame_side *d_side, int n_frames, int nch,
+int launch_huffman(hipStream_t stream, const uint8_t *d_blob, const mp3s_frame_side *d_side, int n_frames, int nch, int max_bits,
                    int16_t *d_is, mp3s_granule_si *d_si, int32_t *d_status, Profiler *prof)
 {
     hipError_t e = hipMemsetAsync(d_is, 0, (size_t)n_frames * 2304 * sizeof(int16_t), stream);
     if (e == hipSuccess) e = hipMemsetAsync(d_si, 0, (size_t)n_frames * 4 * sizeof(mp3s_granule_si), stream);
     if (e == hipSuccess) e = hipMemsetAsync(d_status, 0, sizeof(int32_t), stream);
     if (e != hipSuccess) return (int)e;
-    // lanes per wave that decode (see the kernel); narrower waves only paid off before the per-workgroup staging
+    // LDS per workgroup = 30.8 KB of tables + W words per thread.  256-thread groups share the tables four ways and
+    // fit twice on a CU (8 waves) while W <= 33 (granules up to ~830 bits: 128 kbps without a reservoir needs 762);
+    // longer granules fall back to 64-thread groups, 2..4 of which fit.
     const long units = (long)n_frames * 4;
-    int active = 64;
-    if (const char *e = getenv("MP3S_HUF_ACTIVE")) { const int a = atoi(e); if (a >= 1 && a <= 64) active = a; }
+    const int W = huf_words_for(max_bits);
     const int pp = prof ? prof->begin(stream, K_DEC_HUFFMAN) : -1;
-    hipLaunchKernelGGL(k_dec_huffman, dim3((unsigned)((units + active - 1) / active)), dim3(HUF_THREADS), 0, stream,
-                       d_blob, d_side, n_frames, nch, active, d_is, d_si, d_status);
+    if ((size_t)W * 256 * 4 + 30848 <= 64 * 1024) {
+        hipLaunchKernelGGL(k_dec_huffman<256>, dim3((unsigned)((units + 255) / 256)), dim3(256), (size_t)W * 256 * 4, stream,
+                           d_blob, d_side, n_frames, nch, W, max_bits, d_is, d_si, d_status);
+    } else {
+        hipLaunchKernelGGL(k_dec_huffman<64>, dim3((unsigned)((units + 63) / 64)), dim3(64), (size_t)W * 64 * 4, stream,
+                           d_blob, d_side, n_frames, nch, W, max_bits, d_is, d_si, d_status);
+    }
     if (prof) prof->end(stream, pp);
     return (int)hipGetLastError();
 }

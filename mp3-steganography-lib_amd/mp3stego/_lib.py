@@ -61,7 +61,8 @@ class Parsed(C.Structure):
 
 class Scanned(C.Structure):
     _fields_ = [("n_frames", C.c_int32), ("nch", C.c_int32), ("sampling_rate", C.c_int32), ("bit_rate", C.c_int32),
-                ("n_bits", C.c_int32), ("dup_last_frame", C.c_int32), ("gpu_ok", C.c_int32), ("side", C.c_void_p),
+                ("n_bits", C.c_int32), ("dup_last_frame", C.c_int32), ("gpu_ok", C.c_int32), ("max_part2_3_length", C.c_int32),
+                ("side", C.c_void_p),
                 ("hdr", C.c_void_p), ("blob", C.c_void_p), ("blob_len", C.c_size_t), ("bits", C.c_void_p),
                 ("frame_size", C.c_void_p)]
 
@@ -138,7 +139,7 @@ def lib():
         L.mp3s_encode_transform_dev.argtypes = [vp, vp, vp, i32, vp]
         L.mp3s_encode_transform.argtypes = [vp, vp, vp, i32, vp]
         L.mp3s_rate_loop_dev.argtypes = [vp, vp, vp, i32, vp, i32, vp, vp, vp, i32, vp, vp, vp]
-        L.mp3s_huffman_decode_dev.argtypes = [vp, vp, vp, i32, i32, vp, vp, vp]
+        L.mp3s_huffman_decode_dev.argtypes = [vp, vp, vp, i32, i32, i32, vp, vp, vp]
         L.mp3s_pack_frames_dev.argtypes = [vp, vp, vp, vp, i32, i32, i32, vp, vp, vp, vp, vp]
         L.mp3s_scan_stream.argtypes = [vp, sz, pvp, C.POINTER(Scanned)]
         L.mp3s_buf_free.argtypes = [vp]
@@ -443,7 +444,7 @@ def scan_stream(data: bytes):
     try:
         n = p.n_frames
         return {"n_frames": n, "channels": p.nch, "sampling_rate": p.sampling_rate, "bit_rate": p.bit_rate,
-                "dup_last_frame": p.dup_last_frame, "gpu_ok": bool(p.gpu_ok),
+                "dup_last_frame": p.dup_last_frame, "gpu_ok": bool(p.gpu_ok), "max_part2_3_length": p.max_part2_3_length,
                 "side": _view(p.side, FRAME_SIDE_DTYPE, (n,)), "hdr": _view(p.hdr, FRAME_HDR_DTYPE, (n,)),
                 "blob": _view(p.blob, np.uint8, (p.blob_len,)), "bits": _view(p.bits, np.uint8, (p.n_bits,)),
                 "frame_size": _view(p.frame_size, np.int32, (n,))}

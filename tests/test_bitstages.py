@@ -47,9 +47,19 @@ def test_device_huffman_matches_host_parser(ctx, mlib, orc, golden_dir):
         n, nch = s["n_frames"], s["channels"]
         d_blob, d_side = ctx.to_device(s["blob"]), ctx.to_device(s["side"])
         d_is, d_si, d_st = ctx.alloc(n * 2304 * 2), ctx.alloc(n * 4 * 72), ctx.alloc(4)
-        mlib.check(L.mp3s_huffman_decode_dev(ctx.handle, d_blob, d_side, n, nch, d_is, d_si, d_st))
+        mx = s["max_part2_3_length"]
+        assert mx == int(s["side"]["unit"]["part2_3_length"].max())
+        # a bound that does not hold is reported, not decoded past; then the format's limit (0) and the exact bound:
+        # 64-thread groups with 132 staged words per thread vs 256-thread groups with just enough
+        mlib.check(L.mp3s_huffman_decode_dev(ctx.handle, d_blob, d_side, n, nch, mx - 1, d_is, d_si, d_st))
+        assert int(ctx.download(d_st, np.int32, (1,))[0]) & 4
+        mlib.check(L.mp3s_huffman_decode_dev(ctx.handle, d_blob, d_side, n, nch, 0, d_is, d_si, d_st))
+        assert int(ctx.download(d_st, np.int32, (1,))[0]) == 0
+        is_full = ctx.download(d_is, np.int16, (n, 2, 2, 576))
+        mlib.check(L.mp3s_huffman_decode_dev(ctx.handle, d_blob, d_side, n, nch, mx, d_is, d_si, d_st))
         ctx.sync()
         assert int(ctx.download(d_st, np.int32, (1,))[0]) == 0
+        assert np.array_equal(is_full, ctx.download(d_is, np.int16, (n, 2, 2, 576)))
         isv = ctx.download(d_is, np.int16, (n, 2, 2, 576))
         si = ctx.download(d_si, mlib.GRANULE_SI_DTYPE, (n, 2, 2))
         assert np.array_equal(isv, p["is"])

@@ -88,7 +88,7 @@ def test_device_huffman_on_corpus(ctx, mlib, corpus):
         nf, nch = s["n_frames"], s["channels"]
         d_blob, d_side = ctx.to_device(s["blob"]), ctx.to_device(s["side"])
         d_is, d_si, d_st = ctx.alloc(nf * 2304 * 2), ctx.alloc(nf * 4 * 72), ctx.alloc(4)
-        mlib.check(L.mp3s_huffman_decode_dev(ctx.handle, d_blob, d_side, nf, nch, d_is, d_si, d_st))
+        mlib.check(L.mp3s_huffman_decode_dev(ctx.handle, d_blob, d_side, nf, nch, s["max_part2_3_length"], d_is, d_si, d_st))
         ctx.sync()
         assert int(ctx.download(d_st, np.int32, (1,))[0]) == 0
         isv = ctx.download(d_is, np.int16, (nf, 2, 2, 576))
