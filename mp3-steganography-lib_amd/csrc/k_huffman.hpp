@@ -4,8 +4,8 @@
 //                   granule*channel of the batch.  The bit stream of a granule is serial, but granule boundaries
 //                   come from the side info (part2_3_length), so one THREAD decodes one granule*channel (granule 1
 //                   re-reads the scalefactors scfsi lets it share with granule 0 from granule 0's own bits): a
-//                   10 000-frame batch gives 40 000 independent threads.  Code books: 10-bit first-level table in LDS, binary
-//                   trie in global memory for the rare longer codes (same prefix codes the reference searches
+//                   10 000-frame batch gives 40 000 independent threads.  Code books: 10-bit first-level table and second-level
+//                   tables for the rare longer codes, both in LDS (same prefix codes the reference searches
 //                   linearly, so the same symbol and length come out).  Quirks kept: D1 (count1 stops at line 572,
 //                   no overrun discard), D2 (books 4/14 read no bits), bits past the buffer read as 0.
 #pragma once
@@ -98,15 +98,20 @@ struct SideRegs {
 // LDS = the shared first-level tables (30.8 KB) + W words of staged bits per thread.  A wave is a chain of dependent LDS
 // look-ups, so throughput comes from resident waves: W is sized by the launcher from the longest granule of the batch
 // (30 words at 128 kbps instead of the worst-case 132), which lets 8 waves share a CU instead of 2.
-template <int T>
-__global__ __launch_bounds__(T) void k_dec_huffman(
+// WAVES x 64 threads per workgroup of which LANES per wave decode: every lane walks its own bit stream, so a wave is a
+// latency chain that runs as long as its slowest lane.  Small batches use narrow waves (more waves per SIMD to
+// interleave, less waiting for the slowest lane), large batches full ones (more granules in flight per CU).
+template <int WAVES, int LANES>
+__global__ __launch_bounds__(WAVES * 64) void k_dec_huffman(
     const uint8_t *__restrict__ blob, const mp3s_frame_side *__restrict__ side, int n_frames, int nch, int W, int max_bits,
     int16_t *__restrict__ is, mp3s_granule_si *__restrict__ si_out, int32_t *__restrict__ status)
 {
     __shared__ uint16_t fast[15][1024];
+    __shared__ uint16_t lut2[HUFF_L2_N];    // second-level tables for the codes longer than 10 bits
     __shared__ uint16_t quad[64];
     __shared__ uint16_t tinfo[32];        // table_select -> first-level table id | linbits << 8
-    extern __shared__ uint32_t words[];   // [W][T]
+    extern __shared__ uint32_t words[];   // [W][COLS]
+    constexpr int T = WAVES * 64, COLS = WAVES * LANES;
     {
         const uint4 *src = reinterpret_cast<const uint4 *>(&c_tab.huff_fast[0][0]);
         uint4 *dst = reinterpret_cast<uint4 *>(&fast[0][0]);
@@ -121,12 +126,15 @@ __global__ __launch_bounds__(T) void k_dec_huffman(
 #pragma unroll 6
             for (int i = threadIdx.x; i < N16; i += T) dst[i] = src[i];
         }
+        for (int i = threadIdx.x; i < HUFF_L2_N / 2; i += T)
+            reinterpret_cast<uint32_t *>(lut2)[i] = reinterpret_cast<const uint32_t *>(c_tab.huff_l2)[i];
         if (threadIdx.x < 64) quad[threadIdx.x] = c_tab.quad_fast[threadIdx.x];
         if (threadIdx.x < 32) tinfo[threadIdx.x] = (uint16_t)(c_tab.huff_lut_id[threadIdx.x] | (c_tab.linbits[threadIdx.x] << 8));
     }
     __syncthreads();
-    const long tid = (long)blockIdx.x * T + threadIdx.x;
-    const bool worker = tid < (long)n_frames * 4 && (int)(tid & 1) < nch;
+    const int lane = threadIdx.x & 63, col = (int)(threadIdx.x >> 6) * LANES + lane;
+    const long tid = (long)blockIdx.x * COLS + col;
+    const bool worker = lane < LANES && tid < (long)n_frames * 4 && (int)(tid & 1) < nch;
     if (worker) {
     const int f = (int)(tid >> 2), k = (int)(tid & 3), gr = k >> 1, ch = k & 1;
     SideRegs fs;
@@ -151,7 +159,7 @@ __global__ __launch_bounds__(T) void k_dec_huffman(
     int err = 0;
     const uint32_t *mdw = reinterpret_cast<const uint32_t *>(blob + md_off);
     if ((int)part2_3_length > max_bits) err |= MP3S_HS_HINT;   // the caller's bound on part2_3_length does not hold
-    BitStream<T> br;
+    BitStream<COLS> br;
     {
         // stage the words covering this granule: loads first (clamped to a word inside the zero bytes that follow the
         // frame), then the big-endian swap, the masking of bytes past md_len (decoder/util.py:41-43) and the LDS writes
@@ -168,10 +176,10 @@ __global__ __launch_bounds__(T) void k_dec_huffman(
                 const uint32_t valid = md_len - byte0;                 // meaningful when byte0 < md_len
                 if (byte0 >= md_len) x = 0;
                 else if (valid < 4) x &= 0xffffffffu << (8 * (4 - valid));
-                if (j0 + q < nw) words[(j0 + q) * T + threadIdx.x] = x;
+                if (j0 + q < nw) words[(j0 + q) * COLS + col] = x;
             }
         }
-        br.open(words + threadIdx.x, (uint32_t)W, bit);
+        br.open(words + col, (uint32_t)W, bit);
     }
     uint32_t *g32 = reinterpret_cast<uint32_t *>(si_out + tid);
     // global_gain, scalefac_scale, block_type, mixed_block_flag | preflag, sub_block_gain[3]
@@ -242,15 +250,12 @@ __global__ __launch_bounds__(T) void k_dec_huffman(
             const uint32_t window = br.top(32);
             const uint32_t e = fast[lut][window >> 22];
             int len = 0, sym = -1;
-            if (e & 0x8000u) {                                    // continue in the trie below the 10-bit prefix
-                uint32_t node = e & 0x7fffu;
-                for (int d = HUFF_FAST_BITS; d < 24; d++) {
-                    const uint32_t nxt = c_tab.huff_tree[lut][node][(window >> (31 - d)) & 1];
-                    if (!nxt) break;
-                    if (nxt & 0x8000u) { sym = nxt & 0xff; len = d + 1; break; }
-                    node = nxt;
-                }
-            } else if (e) { sym = e & 0xff; len = e >> 8; }
+            uint32_t leaf = e;
+            if (e & 0x8000u) {                                    // longer than 10 bits: the next k bits pick the leaf
+                const uint32_t k = (e >> 11) & 15;
+                leaf = lut2[(e & 0x7ffu) + ((window << HUFF_FAST_BITS) >> (32 - k))];
+            }
+            if (leaf) { sym = (int)(leaf & 0xff); len = (int)(leaf >> 8); }
             if (sym >= 0) {
                 // linbits and sign bits follow the code word: x linbits, x sign, y linbits, y sign (:499-513)
                 int v0 = sym >> 4, v1 = sym & 15;

@@ -126,19 +126,24 @@ int launch_huffman(hipStream_t stream, const uint8_t *d_blob, const mp3s_frame_s
     if (e == hipSuccess) e = hipMemsetAsync(d_si, 0, (size_t)n_frames * 4 * sizeof(mp3s_granule_si), stream);
     if (e == hipSuccess) e = hipMemsetAsync(d_status, 0, sizeof(int32_t), stream);
     if (e != hipSuccess) return (int)e;
-    // LDS per workgroup = 30.8 KB of tables + W words per thread.  256-thread groups share the tables four ways and
-    // fit twice on a CU (8 waves) while W <= 33 (granules up to ~830 bits: 128 kbps without a reservoir needs 762);
-    // longer granules fall back to 64-thread groups, 2..4 of which fit.
+    // LDS per workgroup = 30.8 KB of tables + W words per decoding lane, at most 64 KB.  Widest waves that still give
+    // every SIMD about three waves to interleave; narrower ones otherwise (and for long granules, whose staging is big).
     const long units = (long)n_frames * 4;
     const int W = huf_words_for(max_bits);
+    auto fits = [&](int cols) { return (size_t)W * cols * 4 + 30720 + HUFF_L2_N * 2 + 256 <= 64 * 1024; };
+    int lanes = 16;
+    if (fits(256) && units / 64 >= 3072) lanes = 64;   // measured: 64 = 32 from 60k frames up, 32 best below (10k: 0.149 vs 0.165 ms)
+    else if (fits(128)) lanes = 32;
+    if (const char *ev = getenv("MP3S_HUF_LANES")) { const int a = atoi(ev); if ((a == 64 && fits(256)) || (a == 32 && fits(128)) || a == 16 || a == 8) lanes = a; }
     const int pp = prof ? prof->begin(stream, K_DEC_HUFFMAN) : -1;
-    if ((size_t)W * 256 * 4 + 30848 <= 64 * 1024) {
-        hipLaunchKernelGGL(k_dec_huffman<256>, dim3((unsigned)((units + 255) / 256)), dim3(256), (size_t)W * 256 * 4, stream,
-                           d_blob, d_side, n_frames, nch, W, max_bits, d_is, d_si, d_status);
-    } else {
-        hipLaunchKernelGGL(k_dec_huffman<64>, dim3((unsigned)((units + 63) / 64)), dim3(64), (size_t)W * 64 * 4, stream,
-                           d_blob, d_side, n_frames, nch, W, max_bits, d_is, d_si, d_status);
-    }
+#define MP3S_HUF_LAUNCH(WV, LN)                                                                                         \
+    hipLaunchKernelGGL((k_dec_huffman<WV, LN>), dim3((unsigned)((units + WV * LN - 1) / (WV * LN))), dim3(WV * 64),    \
+                       (size_t)W * WV * LN * 4, stream, d_blob, d_side, n_frames, nch, W, max_bits, d_is, d_si, d_status)
+    if (lanes == 64) MP3S_HUF_LAUNCH(4, 64);
+    else if (lanes == 32) MP3S_HUF_LAUNCH(4, 32);
+    else if (lanes == 8) MP3S_HUF_LAUNCH(8, 8);
+    else MP3S_HUF_LAUNCH(4, 16);
+#undef MP3S_HUF_LAUNCH
     if (prof) prof->end(stream, pp);
     return (int)hipGetLastError();
 }

@@ -4,10 +4,12 @@
 #include "mp3s_tables.h"
 #include "iso_tables.h"
 
+#include <algorithm>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <functional>
 #include <mutex>
 
 namespace mp3s {
@@ -210,13 +212,16 @@ void build()
                                     16, 16, 16, 16, 16, 16, 16, 16, 16, 16, 16, 16, 16, 16, 16, 16};
     static const int kBooks[15] = {1, 2, 3, 5, 6, 7, 8, 9, 10, 11, 12, 13, 15, 16, 24};
     for (int t = 0; t < 32; t++) { T.huff_lut_id[t] = 255; T.dec_max[t] = (uint8_t)kDecMax[t]; }
+    int l2_used = 0;
     for (int b = 0; b < 15; b++) {
         const int t = kBooks[b];
         T.huff_lut_id[t] = (uint8_t)b;
         if (t == 16) for (int k = 16; k < 24; k++) T.huff_lut_id[k] = (uint8_t)b;
         if (t == 24) for (int k = 24; k < 32; k++) T.huff_lut_id[k] = (uint8_t)b;
         const HostHuff &h = H.huff[t];
-        uint16_t(*tree)[2] = T.huff_tree[b];
+        // binary trie of the book: child per bit, 0x8000 | (x << 4) | y = leaf, else node index, 0 = no code
+        static uint16_t tree[512][2];
+        std::memset(tree, 0, sizeof tree);
         int n_nodes = 1;   // node 0 = root
         for (int x = 0; x < kDecMax[t]; x++)
             for (int y = 0; y < kDecMax[t]; y++) {
@@ -233,6 +238,16 @@ void build()
                     }
                 }
             }
+        // depth of the subtree below a node = bits its second-level table is indexed with
+        std::function<int(int)> depth = [&](int node) {
+            int m = 0;
+            for (int bit = 0; bit < 2; bit++) {
+                const uint16_t nx = tree[node][bit];
+                if (!nx) continue;
+                m = std::max(m, (nx & 0x8000) ? 1 : 1 + depth(nx));
+            }
+            return m;
+        };
         for (uint32_t w = 0; w < 1024; w++) {
             int node = 0;
             uint16_t e = 0;
@@ -242,7 +257,23 @@ void build()
                 if (nxt & 0x8000) { e = (uint16_t)(((d + 1) << 8) | (nxt & 0xff)); node = -1; break; }
                 node = nxt;
             }
-            if (node > 0) e = (uint16_t)(0x8000 | node);
+            if (node > 0) {   // codes longer than 10 bits share this prefix: one second-level table for the subtree
+                const int k = depth(node), off = l2_used;
+                if (k > 15 || off + (1 << k) > HUFF_L2_N || off >= 2048) abort();
+                l2_used += 1 << k;
+                for (uint32_t v = 0; v < (1u << k); v++) {
+                    int nd = node;
+                    uint16_t le = 0;
+                    for (int d = 0; d < k; d++) {
+                        const uint16_t nxt = tree[nd][(v >> (k - 1 - d)) & 1];
+                        if (!nxt) break;
+                        if (nxt & 0x8000) { le = (uint16_t)(((HUFF_FAST_BITS + d + 1) << 8) | (nxt & 0xff)); break; }
+                        nd = nxt;
+                    }
+                    T.huff_l2[off + v] = le;
+                }
+                e = (uint16_t)(0x8000 | (k << 11) | off);
+            }
             T.huff_fast[b][w] = e;
         }
     }

@@ -11,6 +11,7 @@ constexpr int POW43_N = 8207;       // |is| <= 15 + 8191 (linbits 13)
 constexpr int POW2Q_MIN = -266;     // exp1 = global_gain - 210 - 8*sub_block_gain  in [-266, 45]
 constexpr int POW2Q_N = 312;
 constexpr int POW2H_N = 40;         // 2*exp2 in [0, 36]
+constexpr int HUFF_L2_N = 1280;     // second-level Huffman decode entries (1192 used)
 
 // requantisation line map: one byte per spectral line, (is_short << 7) | (window << 5) | sfb
 // case 0 = long path, 1 = block_type 2, 2 = mixed flag with block_type != 2 (reference Frame.py:185-208)
@@ -45,11 +46,12 @@ struct DevTables {
     uint8_t linbits[32];
     int32_t linmax[32];
     uint8_t transform[32][2];      // reference MP3_Encoder.py:419-449
-    // ---- Huffman decode on the device (k_dec_huffman): 10-bit first-level table + binary trie for longer codes
+    // ---- Huffman decode on the device (k_dec_huffman): 10-bit first-level table + second-level tables for longer codes
     uint8_t huff_lut_id[32];       // table_select -> 0..14, 255 = no code book (tables 0, 4, 14)
     uint8_t dec_max[32];           // symbols per axis (reference decoder/tables.py:426)
-    uint16_t huff_fast[15][1024];  // leaf: (len << 8) | (x << 4) | y;  0x8000 | node: continue in the trie;  0: no code
-    uint16_t huff_tree[15][512][2];// child per bit: 0x8000 | (x << 4) | y = leaf, else node index, 0 = no code
+    uint16_t huff_fast[15][1024];  // leaf: (len << 8) | (x << 4) | y;  0x8000 | (k << 11) | off: the next k bits index
+                                   // huff_l2[off ..];  0: no code
+    uint16_t huff_l2[HUFF_L2_N];   // leaf: (total len << 8) | (x << 4) | y;  0: no code
     uint16_t quad_fast[64];        // count1 book A on 6 bits: (len << 4) | value
     // ---- Huffman code words for the device bit packer (k_enc_pack): books 13, 15, 16.., 24.. and count1 A
     uint32_t hcod[4][256];
