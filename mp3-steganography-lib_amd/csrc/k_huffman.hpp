@@ -16,24 +16,6 @@ constexpr int HUF_WORDS_MAX = 132;   // 4095 bits of part2_3_length + alignment 
 // words of LDS staging a thread needs for granules of at most `bits` bits (any alignment, +64 bits of look-ahead)
 constexpr int huf_words_for(int bits) { return (bits + 94) / 32 + 4 < HUF_WORDS_MAX ? (bits + 94) / 32 + 4 : HUF_WORDS_MAX; }
 
-// global-memory word fetch: big-endian, bytes past `len` read as zero (decoder/util.py:41-43)
-__device__ __forceinline__ uint32_t md_word(const uint32_t *w, uint32_t len, uint32_t i)
-{
-    const uint32_t byte0 = i * 4;
-    if (byte0 >= len) return 0;
-    uint32_t v = __builtin_bswap32(w[i]);
-    const uint32_t valid = len - byte0;          // 1..3: mask the bytes past the end
-    if (valid < 4) v &= 0xffffffffu << (8 * (4 - valid));
-    return v;
-}
-__device__ __forceinline__ uint32_t md_get(const uint32_t *w, uint32_t len, uint32_t pos, int n)
-{
-    if (!n) return 0;
-    const uint32_t i = pos >> 5, sh = pos & 31;
-    const uint32_t w0 = md_word(w, len, i), w1 = md_word(w, len, i + 1);
-    return (sh ? (w0 << sh) | (w1 >> (32 - sh)) : w0) >> (32 - n);
-}
-
 // Bit stream over the lane's column of LDS: the words covering this granule's bits are copied there up front, so the
 // decode loop touches no global memory except its (never waited for) stores.  The next 33..64 bits live in a register
 // window; the word that will be appended next is loaded one refill ahead, so the only LDS access a symbol waits for is
@@ -191,14 +173,17 @@ __global__ __launch_bounds__(WAVES * 64) void k_dec_huffman(
     const bool short_win = block_type == 2 && window_switching;
     // ---- scalefactors (Frame.py:365-441)
     if (gr == 1 && !short_win && scfsi) {
-        // bands flagged by scfsi are copied from granule 0 (:423-437): decode them from granule 0's own bits
+        // bands flagged by scfsi are copied from granule 0 (:423-437): decode them from granule 0's own bits, which the
+        // lane two columns to the left (same frame, same wave) has staged
         const uint32_t c0 = ((ch ? fs.d[11] : fs.d[6]) >> 8) & 15;
         const int z0 = kSlen[c0][0], z1 = kSlen[c0][1];
-        uint32_t b0 = bit_g0;
+        __builtin_amdgcn_wave_barrier();
+        BitStream<COLS> b0;
+        b0.open(words + col - 2, (uint32_t)W, bit_g0);
         for (int s = 0; s < 21; s++) {
             const int sl = s < 11 ? z0 : z1;
             const int band = s < 6 ? 0 : (s < 11 ? 1 : (s < 16 ? 2 : 3));
-            const uint32_t v = md_get(mdw, md_len, b0, sl); b0 += sl;
+            const uint32_t v = b0.get(sl);
             if ((scfsi >> (8 * band)) & 0xff) sf_l[s] = (uint8_t)v;
         }
     }
