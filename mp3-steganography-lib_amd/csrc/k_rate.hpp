@@ -43,7 +43,8 @@ constexpr int RL_NP = 5;   // pair slots per lane (the 5th only for lanes < 32)
 
 struct RlTables {
     uint16_t int2idx[10000];
-    uint8_t hlen[4][256];   // 13, 15, 16-family, 24-family
+    uint32_t hl[256];       // per pair (min(x,15), min(y,15)): code length in books 13 | 15 << 5 | 16.. << 10 | 24.. << 15,
+                            // | number of non-zero values << 20 | number of values > 14 << 22
     uint8_t c1a[16];
     uint8_t transform[64];  // [table][bit]
     uint32_t subdiv[289];   // __subdivide result per big_values for this workgroup's sample rate (see DevTables)
@@ -67,7 +68,8 @@ __device__ __forceinline__ int family_of(int t) { return t == 13 ? 0 : (t == 15 
 __device__ __forceinline__ uint32_t pair_bits(const RlTables &tb, int fam, int lb, int x, int y)
 {
     const int xx = x > 14 ? 15 : x, yy = y > 14 ? 15 : y;
-    return tb.hlen[0][fam * 256 + xx * 16 + yy] + (x != 0) + (y != 0) + lb * ((x > 14) + (y > 14));
+    const uint32_t h = tb.hl[xx * 16 + yy];
+    return ((h >> (5 * fam)) & 31u) + ((h >> 20) & 3u) + (uint32_t)lb * ((h >> 22) & 3u);
 }
 __device__ __forceinline__ int sel3(int r, int a, int b, int c) { return r == 0 ? a : (r == 1 ? b : c); }
 
@@ -190,21 +192,26 @@ __device__ __forceinline__ int rl_body(const RlTables &tb, uint8_t *pcode, const
             tB[r] = 24 + (nb > 4) + (nb > 5) + (nb > 6) + (nb > 7) + (nb > 8) + (nb > 9) + (nb > 11);
         }
     }
-    int fA[3], fB[3], lA[3], lB[3];
+    // both candidates of a pair come out of ONE table word; what differs per region is wave-uniform and travels in one
+    // scalar: bit offset of candidate A's length | B's << 8 | A's linbits << 16 | B's << 20 (offset 25 = empty field)
+    uint32_t Kr[3];
 #pragma unroll
-    for (int r = 0; r < 3; r++) {
-        fA[r] = family_of(tA[r]); fB[r] = family_of(tB[r]);
-        lA[r] = lin_bits_of(tA[r]); lB[r] = lin_bits_of(tB[r]);
-    }
+    for (int r = 0; r < 3; r++)
+        Kr[r] = tA[r] ? (uint32_t)(5 * family_of(tA[r])) | ((uint32_t)(5 * family_of(tB[r])) << 8) |
+                            ((uint32_t)lin_bits_of(tA[r]) << 16) | ((uint32_t)lin_bits_of(tB[r]) << 20)
+                      : (25u | (25u << 8));
     uint32_t w[3] = {0, 0, 0};
 #pragma unroll
     for (int m = 0; m < RL_NP; m++) {
         const int r = rid[m];
-        const int ta = sel3(r, tA[0], tA[1], tA[2]);
-        uint32_t v = pair_bits(tb, sel3(r, fA[0], fA[1], fA[2]), sel3(r, lA[0], lA[1], lA[2]), ix[2 * m], ix[2 * m + 1]) |
-                     (pair_bits(tb, sel3(r, fB[0], fB[1], fB[2]), sel3(r, lB[0], lB[1], lB[2]), ix[2 * m], ix[2 * m + 1]) << 16);
-        v = (r >= 0 && ta != 0) ? v : 0u;
-        w[0] += r == 0 ? v : 0u;
+        const uint32_t kp = (uint32_t)sel3(r, (int)Kr[0], (int)Kr[1], (int)Kr[2]);
+        const int x = ix[2 * m], y = ix[2 * m + 1];
+        const uint32_t h = tb.hl[(x > 14 ? 15 : x) * 16 + (y > 14 ? 15 : y)];
+        const uint32_t nz = __builtin_amdgcn_ubfe(h, 20, 2), esc = __builtin_amdgcn_ubfe(h, 22, 2);
+        const uint32_t a = __builtin_amdgcn_ubfe(h, kp & 31u, 5) + nz + __builtin_amdgcn_ubfe(kp, 16, 4) * esc;
+        const uint32_t b = __builtin_amdgcn_ubfe(h, (kp >> 8) & 31u, 5) + nz + __builtin_amdgcn_ubfe(kp, 20, 4) * esc;
+        const uint32_t v = a | (b << 16);
+        w[0] += r == 0 ? v : 0u;   // pairs past big_values (r < 0) match no region
         w[1] += r == 1 ? v : 0u;
         w[2] += r == 2 ? v : 0u;
     }
@@ -258,8 +265,9 @@ __global__ __launch_bounds__(RL_WAVES * 64, 4) void k_rate_loop(
     const int sr_wg = sr0 >= 0 && sr0 < 3 ? sr0 : 0;
     for (int i = threadIdx.x; i < 10000; i += blockDim.x) tb.int2idx[i] = c_tab.int2idx[i];
     for (int i = threadIdx.x; i < 256; i += blockDim.x) {
-        tb.hlen[0][i] = c_tab.hlen13[i]; tb.hlen[1][i] = c_tab.hlen15[i];
-        tb.hlen[2][i] = c_tab.hlen16[i]; tb.hlen[3][i] = c_tab.hlen24[i];
+        const uint32_t x = (uint32_t)i >> 4, y = (uint32_t)i & 15u;
+        tb.hl[i] = (uint32_t)c_tab.hlen13[i] | ((uint32_t)c_tab.hlen15[i] << 5) | ((uint32_t)c_tab.hlen16[i] << 10) |
+                   ((uint32_t)c_tab.hlen24[i] << 15) | (((x != 0) + (y != 0)) << 20) | (((x == 15) + (y == 15)) << 22);
     }
     if (threadIdx.x < 16) tb.c1a[threadIdx.x] = c_tab.hlen_c1a[threadIdx.x];
     if (threadIdx.x < 64) tb.transform[threadIdx.x] = c_tab.transform[threadIdx.x >> 1][threadIdx.x & 1];
