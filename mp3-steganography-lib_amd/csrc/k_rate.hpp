@@ -36,7 +36,7 @@ __device__ __forceinline__ uint32_t wave_add_u32(uint32_t v)
 }
 
 // encoder/util.py:130-133 mulr for non-negative a: (a*b + 2^31) >> 32
-__device__ __forceinline__ uint32_t mulr_u(uint32_t a, uint32_t b) { return __umulhi(a, b) + ((a * b) >> 31); }
+__device__ __forceinline__ uint32_t mulr_u(uint32_t a, uint32_t b) { return (uint32_t)(((uint64_t)a * b + 0x80000000ull) >> 32); }   // one v_mad_u64_u32
 
 constexpr int RL_WAVES = 4;   // 5 waves share one copy of the lookup tables: 35 KB LDS -> 4 workgroups = 20 waves per CU
 constexpr int RL_NP = 5;   // pair slots per lane (the 5th only for lanes < 32)
@@ -83,17 +83,16 @@ __device__ __forceinline__ int rl_quantize(const RlTables &tb, const uint32_t (&
     const uint32_t scalei = (uint32_t)c_tab.steptabi[idx];
     if (mulr_u(xrmax, scalei) > 165140u) return 16384;
     const double scale = c_tab.steptab[idx];
-    uint32_t mx = 0;
-    bool big = false;
+    uint32_t mx = 0, lnmax = 0;
 #pragma unroll
     for (int e = 0; e < 2 * RL_NP; e++) {
         const uint32_t ln = mulr_u(xa[e], scalei);
-        big |= ln >= 10000u;
+        lnmax = max(lnmax, ln);
         const int32_t v = tb.int2idx[ln < 10000u ? ln : 9999u];   // quick lookup (:403-404)
         ix[e] = v;
         mx = max(mx, (uint32_t)v);
     }
-    if (__ballot(big)) {   // wave-uniform: some value is outside the table range, redo those with floats (:405-409)
+    if (__ballot(lnmax >= 10000u)) {   // wave-uniform: some value is outside the table range, redo those with floats (:405-409)
 #pragma unroll
         for (int e = 0; e < 2 * RL_NP; e++) {
             const uint32_t ln = mulr_u(xa[e], scalei);

@@ -56,13 +56,14 @@ int launch_decode(hipStream_t stream, const int16_t *d_is, const mp3s_granule_si
     double *S = (double *)d_scratch;
     const int n_gran = n_frames * 2;
     // granules per wave: each wave also primes itself with half an IMDCT of the granule before its run, so longer
-    // runs waste less; pick the run length (2..8) that fills whole rounds of the chip's 4096 wave slots best
+    // runs waste less; pick the run length (2..8) that fills whole rounds of the chip's wave slots best (168 VGPRs ->
+    // 3 waves per SIMD -> 256 CUs x 12 = 3072 slots)
     int run = 8;
     {
         double best = 1e30;
         for (int r = 2; r <= 8; r++) {
             const long waves = (n_gran + r - 1) / r;
-            const long rounds = (waves + 4095) / 4096;
+            const long rounds = (waves + 3071) / 3072;
             const double cost = (double)rounds * (r + 0.55);
             if (cost < best) { best = cost; run = r; }
         }
