@@ -16,6 +16,15 @@
 
 namespace mp3s {
 
+// (v * s) >> 32 with the wave-uniform factor in an SGPR.  Spelled out because the compiler otherwise widens the vector
+// operands to 64 bits once and keeps the sign words alive (twice the registers) to feed v_mad_i64_i32.
+__device__ __forceinline__ int32_t mulhi_vs(int32_t v, int32_t s)
+{
+    int32_t r;
+    asm("v_mul_hi_i32 %0, %1, %2" : "=v"(r) : "v"(v), "s"(s));
+    return r;
+}
+
 constexpr int ENC_ROW = 40;   // int16 per LDS row: 32 samples + 8 pad (80-byte stride)
 constexpr int ENC_LDS_DW = 64 * 33;   // per-wave LDS in dwords: PCM tile (79 rows * 20 dw) first, then the 64 x 32 output tile (+1 pad)
 
@@ -111,43 +120,69 @@ __global__ __launch_bounds__(256, 3) void k_enc_analysis(
 }
 
 // mdct layout: int32 [frame][ch][gr][576]  (reference __mdct_freq)
-__global__ __launch_bounds__(256) void k_enc_mdct(
-    const int32_t *__restrict__ SB, long Ts, const mp3s_frame_hdr *__restrict__ hdr, int n_granules,
+// One wave per FRAME: lane = (channel, band) transforms both granules, which share 18 of their 36 input rows and every
+// cos_l coefficient (a scalar operand loaded once for two multiply-adds).  Results go to an LDS tile [granule][channel]
+// [line k][band] (rows padded to 33), where the alias butterflies between neighbouring bands are applied
+// (MP3_Encoder.py:704-744, util.cmuls :143-155) and from where the four 576-line blocks leave as full rows.
+constexpr int MD_ROW = 33, MD_BLK = 18 * MD_ROW;
+__global__ __launch_bounds__(256, 4) void k_enc_mdct(
+    const int32_t *__restrict__ SB, long Ts, const mp3s_frame_hdr *__restrict__ hdr, int n_frames,
     int32_t *__restrict__ mdct)
 {
+    __shared__ int32_t xs_all[4][4 * MD_BLK];
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
-    const int g = xcd_tile() * 4 + wave;
-    if (g >= n_granules) return;
+    const int f = xcd_tile() * 4 + wave;
+    if (f >= n_frames) return;
+    int32_t *xs = xs_all[wave];
     const int ch = lane >> 5, band = lane & 31;
-    const bool has_prev = g > (int)hdr[g >> 1].stream_first * 2;   // l3_sb_sample[ch][0] starts zeroed
-    const int32_t *row = SB + ((long)ch * Ts + (long)g * 18) * 32 + band;
-    int32_t in[36];
+    const bool has_prev = f > (int)hdr[f].stream_first;   // l3_sb_sample[ch][0] starts zeroed
+    const int32_t *row = SB + ((long)ch * Ts + (long)f * 36) * 32 + band;
+    int32_t in[54];
 #pragma unroll
     for (int j = 0; j < 18; j++) {
         in[j] = has_prev ? row[(j - 18) * 32] : 0;
         in[18 + j] = row[j * 32];
+        in[36 + j] = row[(18 + j) * 32];
     }
-    int32_t X[18];
+    int32_t *x0 = xs + ch * MD_BLK + band, *x1 = x0 + 2 * MD_BLK;   // block index = granule * 2 + channel
 #pragma unroll 2
     for (int k = 0; k < 18; k++) {
-        int32_t acc = 0;
+        int32_t a0 = 0, a1 = 0;
 #pragma unroll
-        for (int j = 0; j < 36; j++) acc += __mulhi(in[j], c_tab.cos_l[k][j]);
-        X[k] = acc;
+        for (int j = 0; j < 36; j++) {
+            const int32_t c = c_tab.cos_l[k][j];
+            a0 += mulhi_vs(in[j], c);
+            a1 += mulhi_vs(in[18 + j], c);
+        }
+        x0[k * MD_ROW] = a0;
+        x1[k * MD_ROW] = a1;
     }
-    // alias butterflies (MP3_Encoder.py:704-744, util.cmuls :143-155)
+    __builtin_amdgcn_s_waitcnt(0xc07f);
+    __builtin_amdgcn_wave_barrier();
+    if (band >= 1) {
 #pragma unroll
-    for (int i = 0; i < 8; i++) {
-        const int32_t lo_nb = __shfl_up(X[17 - i], 1, 64);   // X[band-1][17-i]
-        const int32_t hi_nb = __shfl_down(X[i], 1, 64);      // X[band+1][i]
-        const int64_t cs = c_tab.mdct_cs[i], ca = c_tab.mdct_ca[i];
-        const int32_t a = X[i], b = X[17 - i];
-        if (band >= 1) X[i] = (int32_t)(((int64_t)a * cs - (int64_t)lo_nb * ca) >> 31);
-        if (band <= 30) X[17 - i] = (int32_t)(((int64_t)hi_nb * ca + (int64_t)b * cs) >> 31);
+        for (int g = 0; g < 2; g++)
+#pragma unroll
+            for (int i = 0; i < 8; i++) {
+                int32_t *pa = x0 + g * 2 * MD_BLK + i * MD_ROW, *pb = x0 + g * 2 * MD_BLK + (17 - i) * MD_ROW - 1;
+                const int64_t cs = c_tab.mdct_cs[i], ca = c_tab.mdct_ca[i];
+                const int64_t a = *pa, b = *pb;          // X[band][i], X[band-1][17-i]
+                *pa = (int32_t)((a * cs - b * ca) >> 31);
+                *pb = (int32_t)((a * ca + b * cs) >> 31);
+            }
     }
-    int32_t *o = mdct + ((((long)(g >> 1) * 2 + ch) * 2 + (g & 1)) * 576) + band * 18;
+    __builtin_amdgcn_s_waitcnt(0xc07f);
+    __builtin_amdgcn_wave_barrier();
+    int32_t *o = mdct + (long)f * 4 * 576;
 #pragma unroll
-    for (int k = 0; k < 18; k++) o[k] = X[k];
+    for (int q = 0; q < 4; q++) {            // output block (channel, granule), tile block (granule, channel)
+        const int32_t *src = xs + ((q & 1) * 2 + (q >> 1)) * MD_BLK;
+#pragma unroll
+        for (int t = 0; t < 9; t++) {
+            const int e = lane + 64 * t, b = (e * 3641) >> 16, k = e - 18 * b;   // e = band * 18 + k
+            o[q * 576 + e] = src[k * MD_ROW + b];
+        }
+    }
 }
 
 }  // namespace mp3s

@@ -98,9 +98,8 @@ int launch_encode(hipStream_t stream, const int16_t *d_pcm, const mp3s_frame_hdr
     hipLaunchKernelGGL(k_enc_analysis, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, stream, d_pcm, d_hdr, n_frames, SB,
                        Ts);
     if (prof) prof->end(stream, pp);
-    const int n_gran = n_frames * 2;
     pp = prof ? prof->begin(stream, K_ENC_MDCT) : -1;
-    hipLaunchKernelGGL(k_enc_mdct, dim3((n_gran + 3) / 4), dim3(256), 0, stream, (const int32_t *)SB, Ts, d_hdr, n_gran,
+    hipLaunchKernelGGL(k_enc_mdct, dim3((n_frames + 3) / 4), dim3(256), 0, stream, (const int32_t *)SB, Ts, d_hdr, n_frames,
                        d_mdct);
     if (prof) prof->end(stream, pp);
     return (int)hipGetLastError();
