@@ -16,14 +16,17 @@
 
 namespace mp3s {
 
-// (v * s) >> 32 with the wave-uniform factor in an SGPR.  Spelled out because the compiler otherwise widens the vector
-// operands to 64 bits once and keeps the sign words alive (twice the registers) to feed v_mad_i64_i32.
+// (v * s) >> 32 with the wave-uniform factor in an SGPR (v_mul_hi_i32 and v_mad_i64_i32 both issue at full rate on
+// gfx950; measured in tools/ubench/valu_rates.hip).  Spelled out where the compiler would otherwise widen the vector
+// operands to 64 bits once and keep their sign words alive (twice the registers).  Feed it from vector-typed scalar
+// loads: single dwords named in an asm operand are each fetched by their own s_load_dword.
 __device__ __forceinline__ int32_t mulhi_vs(int32_t v, int32_t s)
 {
     int32_t r;
     asm("v_mul_hi_i32 %0, %1, %2" : "=v"(r) : "v"(v), "s"(s));
     return r;
 }
+typedef int32_t i32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int ENC_ROW = 40;   // int16 per LDS row: 32 samples + 8 pad (80-byte stride)
 constexpr int ENC_LDS_DW = 64 * 33;   // per-wave LDS in dwords: PCM tile (79 rows * 20 dw) first, then the 64 x 32 output tile (+1 pad)
@@ -148,11 +151,14 @@ __global__ __launch_bounds__(256, 4) void k_enc_mdct(
 #pragma unroll 2
     for (int k = 0; k < 18; k++) {
         int32_t a0 = 0, a1 = 0;
+        const i32x4 *crow = reinterpret_cast<const i32x4 *>(c_tab.cos_l[k]);   // 36 coefficients = 9 x s_load_dwordx4
 #pragma unroll
-        for (int j = 0; j < 36; j++) {
-            const int32_t c = c_tab.cos_l[k][j];
-            a0 += mulhi_vs(in[j], c);
-            a1 += mulhi_vs(in[18 + j], c);
+        for (int q = 0; q < 9; q++) {
+            const i32x4 c = crow[q];
+            a0 += mulhi_vs(in[4 * q], c.x);     a1 += mulhi_vs(in[18 + 4 * q], c.x);
+            a0 += mulhi_vs(in[4 * q + 1], c.y); a1 += mulhi_vs(in[19 + 4 * q], c.y);
+            a0 += mulhi_vs(in[4 * q + 2], c.z); a1 += mulhi_vs(in[20 + 4 * q], c.z);
+            a0 += mulhi_vs(in[4 * q + 3], c.w); a1 += mulhi_vs(in[21 + 4 * q], c.w);
         }
         x0[k * MD_ROW] = a0;
         x1[k * MD_ROW] = a1;

@@ -24,6 +24,10 @@ __global__ void k(uint32_t *out, uint32_t seed, double dseed)
             if (OP == 8) d[i] = d[i] * db + 1.0;                                       // mul + add (no contraction)
             if (OP == 9) { int t; asm("v_mul_hi_i32 %0, %1, %2" : "=v"(t) : "v"(a[i]), "v"(b)); a[i] = (uint32_t)t + a[(i + 1) & 7]; }   // forced mul_hi + add
             if (OP == 10) { a[i] = a[i] + a[(i + 3) & 7]; a[i] ^= it; }                 // add + xor (2 full-rate ops)
+            if (OP == 12) { long long t; asm("v_mad_i64_i32 %0, vcc, %1, %2, 0" : "=v"(t) : "v"(a[i]), "s"(b) : "vcc"); a[i] = (uint32_t)(t >> 32) + a[(i + 1) & 7]; }   // mad_i64_i32 (hi word) + add
+            if (OP == 13) { int t; asm("v_mul_hi_i32 %0, %1, %2" : "=v"(t) : "v"(a[i]), "s"(b)); a[i] = (uint32_t)t; }   // mul_hi alone (sgpr operand)
+            if (OP == 14) { long long t; asm("v_mad_i64_i32 %0, vcc, %1, %2, 0" : "=v"(t) : "v"(a[i]), "s"(b) : "vcc"); a[i] = (uint32_t)(t >> 32); }   // mad_i64_i32 alone
+            if (OP == 15) { unsigned long long t; asm("v_mad_u64_u32 %0, vcc, %1, %2, %3" : "=v"(t) : "v"(a[i]), "s"(b), "v"((unsigned long long)a[(i + 1) & 7]) : "vcc"); a[i] = (uint32_t)(t >> 32); }   // mad_u64_u32 with 64-bit addend
             if (OP == 11) { int t; asm("v_mul_hi_i32 %0, %1, %2" : "=v"(t) : "v"(a[i]), "s"(b)); a[i] = (uint32_t)t + a[(i + 1) & 7]; } // scalar operand
         }
     }
@@ -51,7 +55,7 @@ int main()
 {
     for (int w : {1, 2, 4}) {
         run<0>("mul_hi_i32 + add", w); run<7>("mul_hi_u32", w); run<1>("mul_lo_u32", w); run<2>("add_u32", w);
-        run<6>("mul_i32_i24", w); run<3>("mul_f64", w); run<4>("add_f64", w); run<5>("fma_f64", w); run<8>("mul_f64 + add_f64", w); run<9>("asm mul_hi_i32 + add", w); run<10>("add + xor", w); run<11>("asm mul_hi_i32(sgpr) + add", w);
+        run<6>("mul_i32_i24", w); run<3>("mul_f64", w); run<4>("add_f64", w); run<5>("fma_f64", w); run<8>("mul_f64 + add_f64", w); run<9>("asm mul_hi_i32 + add", w); run<10>("add + xor", w); run<11>("asm mul_hi_i32(sgpr) + add", w); run<12>("asm mad_i64_i32(sgpr) + add", w); run<13>("asm mul_hi_i32(sgpr) alone", w); run<14>("asm mad_i64_i32 alone", w); run<15>("asm mad_u64_u32 + 64b addend", w);
     }
     return 0;
 }
