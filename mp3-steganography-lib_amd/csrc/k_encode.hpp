@@ -27,12 +27,13 @@ __device__ __forceinline__ int32_t mulhi_vs(int32_t v, int32_t s)
     return r;
 }
 typedef int32_t i32x4 __attribute__((ext_vector_type(4)));
+typedef int32_t i32x16 __attribute__((ext_vector_type(16)));
 
 constexpr int ENC_ROW = 40;   // int16 per LDS row: 32 samples + 8 pad (80-byte stride)
 constexpr int ENC_LDS_DW = 64 * 33;   // per-wave LDS in dwords: PCM tile (79 rows * 20 dw) first, then the 64 x 32 output tile (+1 pad)
 
 // SB layout: int32 [ch][Ts][32 bands] with Ts = n_frames * 36 slots (a 128-byte row per slot)
-__global__ __launch_bounds__(256, 3) void k_enc_analysis(
+__global__ __launch_bounds__(256, 4) void k_enc_analysis(
     const int16_t *__restrict__ pcm, const mp3s_frame_hdr *__restrict__ hdr, int n_frames,
     int32_t *__restrict__ SB, long Ts)
 {
@@ -66,9 +67,10 @@ __global__ __launch_bounds__(256, 3) void k_enc_analysis(
     for (int i = 0; i < 64; i++) y[i] = 0;
 #pragma unroll 1
     for (int k = 0; k < 8; k++) {
-        const int32_t *ew = c_tab.enwindow + 64 * k;
+        const i32x16 *ewv = reinterpret_cast<const i32x16 *>(c_tab.enwindow + 64 * k);
 #pragma unroll
         for (int h = 0; h < 2; h++) {
+            const i32x16 e0 = ewv[2 * h], e1 = ewv[2 * h + 1];   // enwindow[64k + 32h .. +31]
             const int back = 2 * k + h;                  // rows back from the lane's own row
             const bool in_stream = (t - back) >= s0;     // ring x starts zeroed (MP3_Encoder.py:532-534)
             const int16_t *rp = tw + (lane + 15 - back) * ENC_ROW;
@@ -80,12 +82,12 @@ __global__ __launch_bounds__(256, 3) void k_enc_analysis(
 #pragma unroll
                 for (int e = 0; e < 4; e++) {
                     const int col_lo = cb * 8 + 2 * e, col_hi = col_lo + 1;
-                    const int i_lo = h * 32 + 31 - col_lo, i_hi = h * 32 + 31 - col_hi;
+                    const int c_lo = 31 - col_lo, c_hi = 31 - col_hi;          // coefficient within this half
                     const int32_t x_lo = (int32_t)(d[e] << 16), x_hi = (int32_t)(d[e] & 0xffff0000u);
-                    y[i_lo] += __mulhi(x_lo, ew[i_lo]);
-                    y[i_hi] += __mulhi(x_hi, ew[i_hi]);
+                    y[h * 32 + c_lo] += mulhi_vs(x_lo, c_lo < 16 ? e0[c_lo & 15] : e1[c_lo & 15]);
+                    y[h * 32 + c_hi] += mulhi_vs(x_hi, c_hi < 16 ? e0[c_hi & 15] : e1[c_hi & 15]);
                 }
-                __builtin_amdgcn_sched_barrier(0);
+                __builtin_amdgcn_sched_barrier(0);   // eight products at a time: bounds the scheduler's hoisting
             }
         }
     }
@@ -97,14 +99,19 @@ __global__ __launch_bounds__(256, 3) void k_enc_analysis(
 #pragma unroll 1
     for (int sb = 0; sb < 32; sb += 4) {
         int32_t a0 = 0, a1 = 0, a2 = 0, a3 = 0;
-        const int32_t *f0 = c_tab.fl[sb], *f1 = c_tab.fl[sb + 1], *f2 = c_tab.fl[sb + 2], *f3 = c_tab.fl[sb + 3];
+        const i32x16 *f0 = reinterpret_cast<const i32x16 *>(c_tab.fl[sb]), *f1 = reinterpret_cast<const i32x16 *>(c_tab.fl[sb + 1]),
+                     *f2 = reinterpret_cast<const i32x16 *>(c_tab.fl[sb + 2]), *f3 = reinterpret_cast<const i32x16 *>(c_tab.fl[sb + 3]);
 #pragma unroll
-        for (int j = 0; j < 64; j++) {
-            a0 += __mulhi(f0[j], y[j]);
-            a1 += __mulhi(f1[j], y[j]);
-            a2 += __mulhi(f2[j], y[j]);
-            a3 += __mulhi(f3[j], y[j]);
-            if ((j & 7) == 7) __builtin_amdgcn_sched_barrier(0);   // keep the scheduler from hoisting all 256 products
+        for (int jb = 0; jb < 4; jb++) {
+            const i32x16 c0 = f0[jb], c1 = f1[jb], c2 = f2[jb], c3 = f3[jb];   // 4 x s_load_dwordx16
+#pragma unroll
+            for (int j = 0; j < 16; j++) {
+                a0 += mulhi_vs(y[jb * 16 + j], c0[j]);
+                a1 += mulhi_vs(y[jb * 16 + j], c1[j]);
+                a2 += mulhi_vs(y[jb * 16 + j], c2[j]);
+                a3 += mulhi_vs(y[jb * 16 + j], c3[j]);
+                if ((j & 3) == 3) __builtin_amdgcn_sched_barrier(0);
+            }
         }
         if (odd_slot) { a1 = (int32_t)(0u - (uint32_t)a1); a3 = (int32_t)(0u - (uint32_t)a3); }   // odd bands
         ot[lane * 33 + sb] = (uint32_t)a0;
