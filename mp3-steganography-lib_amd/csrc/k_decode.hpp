@@ -44,6 +44,20 @@ __device__ __forceinline__ double shfl_xor_f64(double v, int mask)
 // ---------------------------------------------------------------------------------------------
 constexpr int DEC_A_WAVES = 4;
 
+typedef double dvec8 __attribute__((ext_vector_type(8)));
+typedef double dvec2 __attribute__((ext_vector_type(2)));
+struct Row18 { dvec8 a, b; dvec2 c; double w0, w1; };   // IMDCT twiddle row + the window factor of each channel half
+__device__ __forceinline__ Row18 load_row18(const double (*C36)[18], const double *win0, const double *win1, int i)
+{
+    Row18 r;
+    const double *p = C36[i];
+    r.a = *reinterpret_cast<const dvec8 *>(p);
+    r.b = *reinterpret_cast<const dvec8 *>(p + 8);
+    r.c = *reinterpret_cast<const dvec2 *>(p + 16);
+    r.w0 = win0[i]; r.w1 = win1[i];
+    return r;
+}
+
 struct DecShared {
     double pow2q[POW2Q_N];                 // copies of the small exponent tables: random per-lane reads go to LDS
     double pow2h[POW2H_N];
@@ -184,25 +198,35 @@ __global__ __launch_bounds__(DEC_A_WAVES * 64, 3) void k_dec_imdct(
         // ---- IMDCT + window (Frame.py:124-148), overlap (:151-153), frequency inversion (:629-631) in the sign
         double *row = S + ((long)(live ? ch : 0) * T + (long)g * 18) * 32 + sb;
         if (bt != 2) {
+            // One row of twiddles (18 doubles) + its two window factors per scalar batch.  Scalar loads can only be
+            // waited for all at once, so the row after the one being multiplied is requested first: its latency
+            // passes under 18 multiply-adds per lane.
+            Row18 cur = load_row18(C36, win0, win1, gi >= 0 ? 0 : 18);
             if (gi >= 0) {
 #pragma unroll
                 for (int i = 0; i < 18; i++) {
+                    const Row18 nxt = load_row18(C36, win0, win1, i + 1);
+                    __builtin_amdgcn_sched_barrier(0);
                     double x = 0.0;
 #pragma unroll
-                    for (int k = 0; k < 18; k++) x += v[k] * C36[i][k];
-                    x = x * (ch == 0 ? win0[i] : win1[i]) + tail[i];
+                    for (int k = 0; k < 18; k++) x += v[k] * (k < 8 ? cur.a[k & 7] : (k < 16 ? cur.b[k & 7] : cur.c[k & 1]));
+                    x = x * (ch == 0 ? cur.w0 : cur.w1) + tail[i];
                     if (neg_odd && (i & 1)) x = -x;
                     if (live) row[(long)i * 32] = x;
-                    if (i & 1) __builtin_amdgcn_sched_barrier(0);   // at most two rows of twiddles (72 SGPRs) in flight
+                    __builtin_amdgcn_sched_barrier(0);
+                    cur = nxt;
                 }
             }
 #pragma unroll
             for (int i = 18; i < 36; i++) {
+                const Row18 nxt = load_row18(C36, win0, win1, i < 35 ? i + 1 : 35);
+                __builtin_amdgcn_sched_barrier(0);
                 double x = 0.0;
 #pragma unroll
-                for (int k = 0; k < 18; k++) x += v[k] * C36[i][k];
-                tail[i - 18] = x * (ch == 0 ? win0[i] : win1[i]);
-                if (i & 1) __builtin_amdgcn_sched_barrier(0);
+                for (int k = 0; k < 18; k++) x += v[k] * (k < 8 ? cur.a[k & 7] : (k < 16 ? cur.b[k & 7] : cur.c[k & 1]));
+                tail[i - 18] = x * (ch == 0 ? cur.w0 : cur.w1);
+                __builtin_amdgcn_sched_barrier(0);
+                cur = nxt;
             }
         } else {
             // three 12-point windows placed at 6/12/18 (Frame.py:135-148); computed one window at a time
@@ -290,29 +314,49 @@ __global__ __launch_bounds__(TW * 64 * 2, (TW * 2 * 2) / 4) void k_dec_synth(
     const bool emit = valid && tl >= 15 && t >= halo_slots;
     const bool full_hist = __ballot(tl >= 15 && lim < 15) == 0;
     uint16_t *ot16 = reinterpret_cast<uint16_t *>(otile);
+    // The matrix rows and window taps are scalar operands fetched in 8-double batches.  All scalar loads share one
+    // counter that can only be waited to zero, so the loop is software-pipelined by hand: the batch after the one being
+    // multiplied is requested first, and its latency passes under 16 multiply-adds per lane.
+    typedef double d8 __attribute__((ext_vector_type(8)));
+    const d8 *M = reinterpret_cast<const d8 *>(&c_tab.synth_matrix[0][0]);      // row r, batch b: M[r * 4 + b]
+    const d8 *Wt = reinterpret_cast<const d8 *>(&c_tab.synth_window_t[0][0]);   // output i, taps 8h..8h+7: Wt[i * 2 + h]
+    d8 c0 = M[0], c1 = M[32 * 4];
     int p = 0;
+#pragma unroll 1
     for (int i = 0; i < 32; i++) {
         double a0 = 0.0, a1 = 0.0;
 #pragma unroll
-        for (int j = 0; j < 32; j++) {           // Frame.py:84-87
-            a0 += Sv[j] * c_tab.synth_matrix[i][j];
-            a1 += Sv[j] * c_tab.synth_matrix[32 + i][j];
+        for (int b = 0; b < 4; b++) {            // Frame.py:84-87
+            d8 n0, n1;
+            if (b < 3) { n0 = M[i * 4 + b + 1]; n1 = M[(32 + i) * 4 + b + 1]; }
+            else { n0 = Wt[i * 2]; n1 = Wt[i * 2 + 1]; }   // the window taps of this i arrive under the last batch
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int j = 0; j < 8; j++) {
+                a0 += Sv[8 * b + j] * c0[j];
+                a1 += Sv[8 * b + j] * c1[j];
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            c0 = n0; c1 = n1;
         }
         ex[p][ch][0][tl] = a0;
         ex[p][ch][1][tl] = a1;
         __syncthreads();
+        const int inext = i < 31 ? i + 1 : 31;
+        const d8 m0 = M[inext * 4], m1 = M[(32 + inext) * 4];   // first batch of the next output
+        __builtin_amdgcn_sched_barrier(0);
         if (tl >= 15) {
             double sum = 0.0;
             if (full_hist) {                    // wave-uniform: every lane has 15 in-stream predecessors (the common case)
 #pragma unroll
                 for (int jj = 0; jj < 16; jj++)   // Frame.py:89-101 (u, w, sum over 16 windowed taps)
-                    sum += ex[p][ch][jj & 1][tl - jj] * c_tab.synth_window[32 * jj + i];
+                    sum += ex[p][ch][jj & 1][tl - jj] * (jj < 8 ? c0[jj & 7] : c1[jj & 7]);
             } else {
 #pragma unroll
                 for (int jj = 0; jj < 16; jj++) {
                     double u = ex[p][ch][jj & 1][tl - jj];
                     if (jj > lim) u = 0.0;       // before the stream started the fifo holds zeros
-                    sum += u * c_tab.synth_window[32 * jj + i];
+                    sum += u * (jj < 8 ? c0[jj & 7] : c1[jj & 7]);
                 }
             }
             if (emit) {
@@ -322,6 +366,8 @@ __global__ __launch_bounds__(TW * 64 * 2, (TW * 2 * 2) / 4) void k_dec_synth(
                 else ((float *)pcm_out)[(to * 32 + i) * nch + ch] = (float)sum;
             }
         }
+        __builtin_amdgcn_sched_barrier(0);
+        c0 = m0; c1 = m1;
         p ^= 1;
     }
     if (out_format == MP3S_PCM_I16) {

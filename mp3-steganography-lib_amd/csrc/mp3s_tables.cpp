@@ -85,6 +85,7 @@ void build()
 
     for (int i = 0; i < 512; i++) {
         T.synth_window[i] = round_decimals((double)ISO_WINDOW_NUM[i] / 65536.0, 9);
+        T.synth_window_t[i & 31][i >> 5] = T.synth_window[i];
         T.enwindow[i] = (int32_t)(round_decimals((double)ISO_WINDOW_NUM[i] / 2097152.0, 6) * 2147483647.0);
     }
     for (int i = 0; i < 64; i++)

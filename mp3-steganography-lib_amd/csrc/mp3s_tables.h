@@ -19,6 +19,7 @@ struct DevTables {
     // ---- decoder ----
     double synth_matrix[64][32];   // reference Frame.py:17-29
     double synth_window[512];      // reference decoder/tables.py:429-514
+    double synth_window_t[32][16]; // [i][j] = synth_window[32 j + i]: the 16 taps of output i in one scalar load
     double imdct_cos36[36][18];    // reference Frame.py:130 (n = 36)
     double imdct_cos12[12][6];     // reference Frame.py:130 (n = 12)
     double sine_block[4][36];      // reference Frame.py:33-62

@@ -474,7 +474,7 @@ def format_stream(samplerate, bitrate, ix, gr, scfsi):
 
 
 DEV_TABLES_DTYPE = np.dtype([
-    ("synth_matrix", "<f8", (64, 32)), ("synth_window", "<f8", (512,)), ("imdct_cos36", "<f8", (36, 18)),
+    ("synth_matrix", "<f8", (64, 32)), ("synth_window", "<f8", (512,)), ("synth_window_t", "<f8", (32, 16)), ("imdct_cos36", "<f8", (36, 18)),
     ("imdct_cos12", "<f8", (12, 6)), ("sine_block", "<f8", (4, 36)), ("alias_cs", "<f8", (8,)), ("alias_ca", "<f8", (8,)),
     ("pow43", "<f8", (8207,)), ("pow2q", "<f8", (312,)), ("pow2h", "<f8", (40,)), ("sqrt2", "<f8"),
     ("rq_map", "u1", (3, 3, 32, 20)), ("reorder_src", "<i2", (3, 576)), ("pre_tab", "u1", (24,)),
