@@ -23,6 +23,12 @@ __device__ __forceinline__ void lds_put(uint32_t *fb, uint32_t pos, uint32_t val
     if ((uint32_t)w) atomicOr(&fb[d + 1], (uint32_t)w);
 }
 
+// wave sum of a small non-negative value over the lanes selected by `on`
+__device__ __forceinline__ int pack_wave_sum(int v, bool on) { return (int)wave_add_u32(on ? (uint32_t)v : 0u); }
+
+// Persistent workgroups: the code tables are staged in LDS once, then the group walks frames f, f + gridDim.x, ...
+// Everything the four waves need about the frame (part2_3_length after stuffing, start offsets) is wave-uniform
+// scalar work done redundantly by each wave; the header / side info bits are written by the wave they describe.
 __global__ __launch_bounds__(256) void k_enc_pack(
     const int16_t *__restrict__ ix, const mp3s_gr_out *__restrict__ gr, const int32_t *__restrict__ en, int n_frames,
     int sri, int bri, int whole_slots, const uint32_t *__restrict__ frame_off, const uint8_t *__restrict__ padding,
@@ -32,90 +38,89 @@ __global__ __launch_bounds__(256) void k_enc_pack(
     __shared__ uint32_t hc[4][256];
     __shared__ uint8_t hl[4][256];
     __shared__ uint8_t pc[4][324];
-    __shared__ int p23f[4];
-    const int f = blockIdx.x;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
-    for (int i = threadIdx.x; i < PACK_DW; i += 256) fb[i] = 0;
     for (int i = threadIdx.x; i < 1024; i += 256) {
         (&hc[0][0])[i] = (&c_tab.hcod[0][0])[i];
         (&hl[0][0])[i] = i < 256 ? c_tab.hlen13[i] : (i < 512 ? c_tab.hlen15[i - 256] : (i < 768 ? c_tab.hlen16[i - 512] : c_tab.hlen24[i - 768]));
     }
-    __syncthreads();
+    for (int f = blockIdx.x; f < n_frames; f += gridDim.x) {
+    for (int i = threadIdx.x; i < PACK_DW; i += 256) fb[i] = 0;
+    __syncthreads();   // also: the previous frame's image has been copied out, the tables are in place
     const int pad = padding[f];
-    if (threadIdx.x == 0) {
-        // ---- __resv_frame_end (:1097-1145): all slack of the frame becomes stuffing
+    // ---- __resv_frame_end (:1097-1145): all slack of the frame becomes stuffing; emission order e = gr*2 + ch
+    int p23v[4];
+    {
         const int bits_per_frame = 8 * (whole_slots + pad);
         const int mean_bits = (bits_per_frame - 288) / 2;
-        int p[4], sum = 0;   // emission order e = gr*2 + ch
+        int sum = 0;
 #pragma unroll
-        for (int e = 0; e < 4; e++) { p[e] = gr[((long)f * 2 + (e & 1)) * 2 + (e >> 1)].part2_3_length; sum += p[e]; }
+        for (int e = 0; e < 4; e++) {
+            p23v[e] = __builtin_amdgcn_readfirstlane(gr[((long)f * 2 + (e & 1)) * 2 + (e >> 1)].part2_3_length);
+            sum += p23v[e];
+        }
         int stuffing = 2 * mean_bits - sum + ((mean_bits & 1) ? 1 : 0);
         if (stuffing < 0) stuffing = 0;
         if (stuffing) {
-            if (p[0] + stuffing < 4095) p[0] += stuffing;
+            if (p23v[0] + stuffing < 4095) p23v[0] += stuffing;
             else
 #pragma unroll
                 for (int e = 0; e < 4; e++) {
-                    if (!stuffing) break;
-                    const int extra = 4095 - p[e], now = extra < stuffing ? extra : stuffing;
-                    p[e] += now; stuffing -= now;
+                    const int extra = 4095 - p23v[e], now = extra < stuffing ? extra : stuffing;
+                    p23v[e] += now; stuffing -= now;
                 }
-        }
-#pragma unroll
-        for (int e = 0; e < 4; e++) p23f[e] = p[e];
-        // ---- scfsi (:861-892) from the band energies of the two granules of each channel
-        int sc[2][4];
-#pragma unroll
-        for (int ch = 0; ch < 2; ch++) {
-            const long u0 = ((long)f * 2 + ch) * 2, u1 = u0 + 1;
-            const int32_t *e0 = en + u0 * 22, *e1 = en + u1 * 22;
-            int cond = 2 + (gr[u0].xrmax != 0) + (gr[u1].xrmax != 0);
-            int d = e0[21] - e1[21]; if (d < 0) d = -d;
-            if (d < 10) cond++;
-            int tp = 0;
-            for (int s = 0; s < 21; s++) { int a = e0[s] - e1[s]; tp += a < 0 ? -a : a; }
-            if (tp < 100) cond++;
-#pragma unroll
-            for (int b = 0; b < 4; b++) {
-                int v = 0;
-                if (cond == 6) {
-                    const int lo = b == 0 ? 0 : 1 + 5 * b, hi = 6 + 5 * b;
-                    int s0 = 0;
-                    for (int s = lo; s < hi; s++) { int a = e0[s] - e1[s]; s0 += a < 0 ? -a : a; }
-                    v = s0 < 10;
-                }
-                sc[ch][b] = v;
-                scfsi_out[((long)f * 2 + ch) * 4 + b] = v;
-            }
-        }
-        // ---- header + side info (:1281-1337), 288 bits
-        uint32_t pos = 0;
-        auto put = [&](uint32_t v, int n) { lds_put(fb, pos, v, n); pos += n; };
-        put(0x7ff, 11); put(3, 2); put(1, 2); put(1, 1); put(bri, 4); put(sri % 3, 2); put(pad, 1); put(0, 1);
-        put(0, 2); put(0, 2); put(0, 1); put(1, 1); put(0, 2);
-        put(0, 9); put(0, 3);
-#pragma unroll
-        for (int ch = 0; ch < 2; ch++)
-#pragma unroll
-            for (int b = 0; b < 4; b++) put(sc[ch][b], 1);
-#pragma unroll
-        for (int e = 0; e < 4; e++) {
-            const mp3s_gr_out &g = gr[((long)f * 2 + (e & 1)) * 2 + (e >> 1)];
-            put(p[e], 12); put(g.big_values, 9); put((uint32_t)(g.quantizer_step + 210) & 0xff, 8); put(0, 4); put(0, 1);
-            for (int r = 0; r < 3; r++) put(g.table_select[r], 5);
-            put(g.region0_count, 4); put(g.region1_count, 3); put(0, 1); put(0, 1); put(g.count1table_select, 1);
         }
     }
-    __syncthreads();
-
-    // ---- main data of this wave's granule*channel (:1394-1446)
     const int e = wave, grn = e >> 1, ch = e & 1;
     const long u = ((long)f * 2 + ch) * 2 + grn;
     const mp3s_gr_out &g = gr[u];
+    if (wave < 2) {
+        // ---- scfsi of channel `wave` (:861-892) from the band energies of its two granules: lane s holds band s
+        const long u0 = ((long)f * 2 + wave) * 2, u1 = u0 + 1;
+        int a = 0, tot21 = 0;
+        if (lane < 22) {
+            a = en[u0 * 22 + lane] - en[u1 * 22 + lane];
+            a = a < 0 ? -a : a;
+        }
+        tot21 = __builtin_amdgcn_readlane(a, 21);
+        const int tp = pack_wave_sum(a, lane < 21);
+        int cond = 2 + (gr[u0].xrmax != 0) + (gr[u1].xrmax != 0);
+        if (tot21 < 10) cond++;
+        if (tp < 100) cond++;
+        uint32_t scbits = 0;
+#pragma unroll
+        for (int b = 0; b < 4; b++) {
+            const int lo = b == 0 ? 0 : 1 + 5 * b, hi = 6 + 5 * b;
+            const int s0 = pack_wave_sum(a, lane >= lo && lane < hi);
+            const int v = (cond == 6 && s0 < 10) ? 1 : 0;
+            scbits = (scbits << 1) | (uint32_t)v;
+            if (lane == 0) scfsi_out[((long)f * 2 + wave) * 4 + b] = v;
+        }
+        if (lane == 0) {
+            lds_put(fb, 44 + 4 * wave, scbits, 4);
+            if (wave == 0) {
+                // ---- frame header (:1281-1300): sync 11, version 2, layer 2, no CRC 1, bitrate 4, rate 2, padding 1, ext 1,
+                //      mode 2, mode ext 2, copyright 1, original 1, emphasis 2;  main_data_begin 9 + private 3 stay zero
+                const uint32_t h = (0x7ffu << 21) | (3u << 19) | (1u << 17) | (1u << 16) | ((uint32_t)bri << 12) |
+                                   ((uint32_t)(sri % 3) << 10) | ((uint32_t)pad << 9) | (1u << 2);
+                fb[0] = h;     // nothing else writes the first dword
+            }
+        }
+    }
+    if (lane == 0) {
+        // ---- side info of this wave's granule*channel (:1305-1337), 59 bits at 52 + 59 e
+        uint32_t pos = 52 + 59 * (uint32_t)e;
+        auto put = [&](uint32_t v, int n) { lds_put(fb, pos, v, n); pos += n; };
+        put(((uint32_t)p23v[e] << 9) | (uint32_t)g.big_values, 21);
+        put((((uint32_t)(g.quantizer_step + 210) & 0xff) << 5), 13);            // global_gain 8, scalefac_compress 4, window_switching 1
+        put(((uint32_t)g.table_select[0] << 10) | ((uint32_t)g.table_select[1] << 5) | (uint32_t)g.table_select[2], 15);
+        put(((uint32_t)g.region0_count << 6) | ((uint32_t)g.region1_count << 3) | (uint32_t)g.count1table_select, 10);   // + preflag, scalefac_scale = 0
+    }
+
+    // ---- main data of this wave's granule*channel (:1394-1446)
     const int ts0 = g.table_select[0], ts1 = g.table_select[1], ts2 = g.table_select[2], c1sel = g.count1table_select;
     uint32_t ustart = 288;
 #pragma unroll
-    for (int k = 0; k < 3; k++) ustart += k < e ? (uint32_t)p23f[k] : 0u;
+    for (int k = 0; k < 3; k++) ustart += k < e ? (uint32_t)p23v[k] : 0u;
     const int bv = g.big_values, c1 = g.count1;
     const int32_t *sfb = c_tab.sfb_long[sri];
     const int r1s = sfb[g.region0_count + 1], r2s = sfb[g.region0_count + 1 + g.region1_count + 1];
@@ -198,7 +203,7 @@ __global__ __launch_bounds__(256) void k_enc_pack(
         lds_put(fb, pos, code1[k], n1[k]); pos += n1[k];
     }
     // stuffing with ones up to part2_3_length (:1433-1446)
-    const int p23 = p23f[e];
+    const int p23 = e == 0 ? p23v[0] : (e == 1 ? p23v[1] : (e == 2 ? p23v[2] : p23v[3]));
     if (huff_bits > p23 || bad) { if (lane == 0) atomicOr(status, bad ? MP3S_PS_BAD_TABLE : MP3S_PS_OVERFLOW); }
     else
         for (uint32_t s = ustart + huff_bits + 32u * lane; s < ustart + (uint32_t)p23; s += 64u * 32u) {
@@ -219,6 +224,8 @@ __global__ __launch_bounds__(256) void k_enc_pack(
         outw[j] = byte_at(k) | (byte_at(k + 1) << 8) | (byte_at(k + 2) << 16) | (byte_at(k + 3) << 24);
     }
     if ((int)threadIdx.x < nbytes - tail0) mp3[off + tail0 + threadIdx.x] = (uint8_t)byte_at(tail0 + threadIdx.x);
+    __syncthreads();   // the image is free again
+    }   // frames
 }
 
 }  // namespace mp3s

@@ -155,7 +155,8 @@ int launch_pack(hipStream_t stream, const int16_t *d_ix, const mp3s_gr_out *d_gr
     hipError_t e = hipMemsetAsync(d_status, 0, sizeof(int32_t), stream);
     if (e != hipSuccess) return (int)e;
     const int pp = prof ? prof->begin(stream, K_ENC_PACK) : -1;
-    hipLaunchKernelGGL(k_enc_pack, dim3(n_frames), dim3(256), 0, stream, d_ix, d_gr, d_en, n_frames, sri, bri, whole_slots,
+    hipLaunchKernelGGL(k_enc_pack, dim3(n_frames < 2048 ? n_frames : 2048), dim3(256), 0, stream,   // persistent: 8 groups per CU
+                       d_ix, d_gr, d_en, n_frames, sri, bri, whole_slots,
                        d_frame_off, d_padding, d_mp3, d_scfsi, d_status);
     if (prof) prof->end(stream, pp);
     return (int)hipGetLastError();
