@@ -46,7 +46,8 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--frames", type=int, default=10000, help="frames per GPU per step")
-    ap.add_argument("--cpu-frames", type=int, default=6000, help="sample size of the CPU baseline (rank 0, N=1)")
+    ap.add_argument("--cpu-frames", type=int, default=10000, help="frames per pass of the CPU baseline (rank 0, N=1)")
+    ap.add_argument("--cpu-seconds", type=float, default=10.0, help="the CPU baseline repeats its pass until this much time has gone by")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -226,15 +227,19 @@ def main():
         m = min(args.cpu_frames, n)
         sub = enc0["mp3"][:int(parsed["frame_size"][:m].sum())]
         t0 = time.perf_counter()
-        od = O.decode(sub)
-        op = O.pcm_to_i16(od["pcm"])
-        oe = O.encode(op, 44100, 128, hide)
+        passes, done = 0, 0
+        while passes == 0 or time.perf_counter() - t0 < args.cpu_seconds:
+            od = O.decode(sub)
+            op = O.pcm_to_i16(od["pcm"])
+            oe = O.encode(op, 44100, 128, hide)
+            assert oe["rc"] == 0
+            passes += 1
+            done += od["n_frames"]
         dt = time.perf_counter() - t0
-        cpu = {"value": round(od["n_frames"] / dt, 1), "unit": "frames/s", "cores": 1, "kind": "port",
-               "sample": f"first {od['n_frames']} frames of the same stream: oracle decode (incl. Huffman) + "
-                         f"int16 PCM + oracle encode (incl. bit packing), single thread, {dt:.1f} s",
+        cpu = {"value": round(done / dt, 1), "unit": "frames/s", "cores": 1, "kind": "port",
+               "sample": f"{passes} pass(es) over the first {od['n_frames']} frames of the same stream: oracle decode (incl. "
+                         f"Huffman) + int16 PCM + oracle encode (incl. bit packing), single thread, {dt:.1f} s",
                "host_cpus": os.cpu_count()}
-        assert oe["rc"] == 0
 
     if rank == 0:
         out = {
