@@ -45,6 +45,7 @@ struct RlTables {
     uint16_t int2idx[10000];
     uint32_t hl[256];       // per pair (min(x,15), min(y,15)): code length in books 13 | 15 << 5 | 16.. << 10 | 24.. << 15,
                             // | number of non-zero values << 20 | number of values > 14 << 22
+                            // | (shortest of the four lengths + non-zero values, 0 for the pair (0,0)) << 25
     uint8_t c1a[16];
     uint8_t transform[64];  // [table][bit]
     uint32_t subdiv[289];   // __subdivide result per big_values for this workgroup's sample rate (see DevTables)
@@ -106,8 +107,15 @@ __device__ __forceinline__ int rl_quantize(const RlTables &tb, const uint32_t (&
 }
 
 // calc_run_len + count1_bit_count + __subdivide + __big_v_tab_select + big_v_bit_count
+// `limit`: the caller only wants to know whether the bit count reaches it (binary search: max_bits; inner loop:
+// max_bits + 1).  A lower bound -- exact count1 bits + per big-value pair the shortest code any candidate book has for
+// it plus its sign bits -- is one table field per pair and one wave reduction away; when it already reaches the limit
+// (80 % of the probes that do) the region maxima, candidate books and their bit sums are skipped and the bound is
+// returned.  Everything with a side effect the reference's body has (run lengths, count1 table, __subdivide and the
+// stale-address rule) happens before that point.
 __device__ __forceinline__ int rl_body(const RlTables &tb, uint8_t *pcode, const int32_t (&ix)[2 * RL_NP], int lane,
-                                       int sr, RlState &st, const uint8_t *__restrict__ hide, int n_hide, int cursor)
+                                       int sr, RlState &st, const uint8_t *__restrict__ hide, int n_hide, int cursor,
+                                       int limit, bool &full)
 {
     // ---- calc_run_len: highest non-zero pair P0, highest pair holding a value > 1 P1
     int P0 = -1, P1 = -1;
@@ -157,6 +165,21 @@ __device__ __forceinline__ int rl_body(const RlTables &tb, uint8_t *pcode, const
         st.addr_fresh = true;
     }
 
+    // ---- lower bound of the big-value bits
+    uint32_t h[RL_NP];
+    {
+        uint32_t lbv = 0;
+#pragma unroll
+        for (int m = 0; m < RL_NP; m++) {
+            const int x = ix[2 * m], y = ix[2 * m + 1];
+            h[m] = tb.hl[(x > 14 ? 15 : x) * 16 + (y > 14 ? 15 : y)];
+            lbv += (lane + 64 * m) < bv ? __builtin_amdgcn_ubfe(h[m], 25, 5) : 0u;
+        }
+        const int lb = bits + (int)wave_add_u32(lbv);
+        full = lb < limit;
+        if (!full) return lb;
+    }
+
     // ---- region maxima; a pair starting at line s belongs to r0 if s < a1, r1 if s < a2, r2 if s < 2*bv
     const int a1 = st.a1, a2 = st.a2;
     uint32_t mx0 = 0, mx1 = 0, mx2 = 0;
@@ -204,11 +227,9 @@ __device__ __forceinline__ int rl_body(const RlTables &tb, uint8_t *pcode, const
     for (int m = 0; m < RL_NP; m++) {
         const int r = rid[m];
         const uint32_t kp = (uint32_t)sel3(r, (int)Kr[0], (int)Kr[1], (int)Kr[2]);
-        const int x = ix[2 * m], y = ix[2 * m + 1];
-        const uint32_t h = tb.hl[(x > 14 ? 15 : x) * 16 + (y > 14 ? 15 : y)];
-        const uint32_t nz = __builtin_amdgcn_ubfe(h, 20, 2), esc = __builtin_amdgcn_ubfe(h, 22, 2);
-        const uint32_t a = __builtin_amdgcn_ubfe(h, kp & 31u, 5) + nz + __builtin_amdgcn_ubfe(kp, 16, 4) * esc;
-        const uint32_t b = __builtin_amdgcn_ubfe(h, (kp >> 8) & 31u, 5) + nz + __builtin_amdgcn_ubfe(kp, 20, 4) * esc;
+        const uint32_t nz = __builtin_amdgcn_ubfe(h[m], 20, 2), esc = __builtin_amdgcn_ubfe(h[m], 22, 2);
+        const uint32_t a = __builtin_amdgcn_ubfe(h[m], kp & 31u, 5) + nz + __builtin_amdgcn_ubfe(kp, 16, 4) * esc;
+        const uint32_t b = __builtin_amdgcn_ubfe(h[m], (kp >> 8) & 31u, 5) + nz + __builtin_amdgcn_ubfe(kp, 20, 4) * esc;
         const uint32_t v = a | (b << 16);
         w[0] += r == 0 ? v : 0u;   // pairs past big_values (r < 0) match no region
         w[1] += r == 1 ? v : 0u;
@@ -267,6 +288,8 @@ __global__ __launch_bounds__(RL_WAVES * 64, 4) void k_rate_loop(
         const uint32_t x = (uint32_t)i >> 4, y = (uint32_t)i & 15u;
         tb.hl[i] = (uint32_t)c_tab.hlen13[i] | ((uint32_t)c_tab.hlen15[i] << 5) | ((uint32_t)c_tab.hlen16[i] << 10) |
                    ((uint32_t)c_tab.hlen24[i] << 15) | (((x != 0) + (y != 0)) << 20) | (((x == 15) + (y == 15)) << 22);
+        const uint32_t shortest = min(min((uint32_t)c_tab.hlen13[i], (uint32_t)c_tab.hlen15[i]), min((uint32_t)c_tab.hlen16[i], (uint32_t)c_tab.hlen24[i]));
+        if (i) tb.hl[i] |= (shortest + (x != 0) + (y != 0)) << 25;
     }
     if (threadIdx.x < 16) tb.c1a[threadIdx.x] = c_tab.hlen_c1a[threadIdx.x];
     if (threadIdx.x < 64) tb.transform[threadIdx.x] = c_tab.transform[threadIdx.x >> 1][threadIdx.x & 1];
@@ -356,7 +379,11 @@ __global__ __launch_bounds__(RL_WAVES * 64, 4) void k_rate_loop(
                 int bit;
                 if (q < 0) { err = true; break; }
                 if (q > 8192) { bit = 100000; if (q != 16384) body_step = 1 << 20; }   // 16384 = early out, ix untouched
-                else { bit = rl_body(tb, pcode, ix, lane, sr, st, hide, n_hide, cursor); body_step = next + half; body_bits = bit; }
+                else {
+                    bool full;
+                    bit = rl_body(tb, pcode, ix, lane, sr, st, hide, n_hide, cursor, max_bits, full);
+                    if (full) { body_step = next + half; body_bits = bit; } else body_step = 1 << 20;
+                }
                 if (bit < max_bits) count = half;
                 else { next += half; count -= half; }
             } while (count > 1);
@@ -378,7 +405,8 @@ __global__ __launch_bounds__(RL_WAVES * 64, 4) void k_rate_loop(
                     while ((q = rl_quantize(tb, xa, ix, qstep + 1, xrmax)) > 8192) qstep += 1;
                     if (q < 0) { err = true; break; }
                     qstep += 1;
-                    bits = rl_body(tb, pcode, ix, lane, sr, st, hide, n_hide, cursor);
+                    bool full;
+                    bits = rl_body(tb, pcode, ix, lane, sr, st, hide, n_hide, cursor, max_bits + 1, full);
                 } while (bits > max_bits);
             }
             if (err) flags |= MP3S_RF_STEP_RANGE;
