@@ -288,7 +288,7 @@ __global__ __launch_bounds__(TW * 64 * 2, (TW * 2 * 2) / 4) void k_dec_synth(
 {
     constexpr int TL_LANES = TW * 64, OUT = TL_LANES - 15;
     constexpr int OROW = 33;                                   // dwords per staged slot (32 + 1 pad: no bank conflicts)
-    __shared__ double ex[2][2][2][TL_LANES];                   // [parity][ch][V half][lane]
+    __shared__ double ex[2][2][4][TL_LANES];                   // [parity][ch][index of the pair * 2 + V half][lane]
     __shared__ uint32_t otile[OUT * OROW];
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
     const int ch = wave / TW, tl = (wave % TW) * 64 + lane;
@@ -322,52 +322,63 @@ __global__ __launch_bounds__(TW * 64 * 2, (TW * 2 * 2) / 4) void k_dec_synth(
     const d8 *Wt = reinterpret_cast<const d8 *>(&c_tab.synth_window_t[0][0]);   // output i, taps 8h..8h+7: Wt[i * 2 + h]
     d8 c0 = M[0], c1 = M[32 * 4];
     int p = 0;
+    // Two output indices per barrier interval: matrixing of i and i+1, one barrier, then their two window sums.
 #pragma unroll 1
-    for (int i = 0; i < 32; i++) {
-        double a0 = 0.0, a1 = 0.0;
+    for (int i0 = 0; i0 < 32; i0 += 2) {
 #pragma unroll
-        for (int b = 0; b < 4; b++) {            // Frame.py:84-87
+        for (int s = 0; s < 2; s++) {
+            const int i = i0 + s;
+            double a0 = 0.0, a1 = 0.0;
+#pragma unroll
+            for (int b = 0; b < 4; b++) {            // Frame.py:84-87
+                d8 n0, n1;
+                if (b < 3) { n0 = M[i * 4 + b + 1]; n1 = M[(32 + i) * 4 + b + 1]; }
+                else if (s == 0) { n0 = M[(i + 1) * 4]; n1 = M[(32 + i + 1) * 4]; }   // first batch of the second index
+                else { n0 = Wt[i0 * 2]; n1 = Wt[i0 * 2 + 1]; }                         // window taps of the first index
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int j = 0; j < 8; j++) {
+                    a0 += Sv[8 * b + j] * c0[j];
+                    a1 += Sv[8 * b + j] * c1[j];
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                c0 = n0; c1 = n1;
+            }
+            ex[p][ch][2 * s][tl] = a0;
+            ex[p][ch][2 * s + 1][tl] = a1;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int s = 0; s < 2; s++) {
+            const int i = i0 + s;
             d8 n0, n1;
-            if (b < 3) { n0 = M[i * 4 + b + 1]; n1 = M[(32 + i) * 4 + b + 1]; }
-            else { n0 = Wt[i * 2]; n1 = Wt[i * 2 + 1]; }   // the window taps of this i arrive under the last batch
+            if (s == 0) { n0 = Wt[(i0 + 1) * 2]; n1 = Wt[(i0 + 1) * 2 + 1]; }          // taps of the second index
+            else { const int inext = i0 < 30 ? i0 + 2 : 31; n0 = M[inext * 4]; n1 = M[(32 + inext) * 4]; }   // next interval
             __builtin_amdgcn_sched_barrier(0);
+            if (tl >= 15) {
+                double sum = 0.0;
+                if (full_hist) {                    // wave-uniform: every lane has 15 in-stream predecessors (the common case)
 #pragma unroll
-            for (int j = 0; j < 8; j++) {
-                a0 += Sv[8 * b + j] * c0[j];
-                a1 += Sv[8 * b + j] * c1[j];
+                    for (int jj = 0; jj < 16; jj++)   // Frame.py:89-101 (u, w, sum over 16 windowed taps)
+                        sum += ex[p][ch][2 * s + (jj & 1)][tl - jj] * (jj < 8 ? c0[jj & 7] : c1[jj & 7]);
+                } else {
+#pragma unroll
+                    for (int jj = 0; jj < 16; jj++) {
+                        double u = ex[p][ch][2 * s + (jj & 1)][tl - jj];
+                        if (jj > lim) u = 0.0;       // before the stream started the fifo holds zeros
+                        sum += u * (jj < 8 ? c0[jj & 7] : c1[jj & 7]);
+                    }
+                }
+                if (emit) {
+                    const long to = t - halo_slots;
+                    if (out_format == MP3S_PCM_I16) ot16[(tl - 15) * OROW * 2 + i * nch + ch] = (uint16_t)pcm_to_i16(sum);
+                    else if (out_format == MP3S_PCM_F64) ((double *)pcm_out)[(to * 32 + i) * nch + ch] = sum;
+                    else ((float *)pcm_out)[(to * 32 + i) * nch + ch] = (float)sum;
+                }
             }
             __builtin_amdgcn_sched_barrier(0);
             c0 = n0; c1 = n1;
         }
-        ex[p][ch][0][tl] = a0;
-        ex[p][ch][1][tl] = a1;
-        __syncthreads();
-        const int inext = i < 31 ? i + 1 : 31;
-        const d8 m0 = M[inext * 4], m1 = M[(32 + inext) * 4];   // first batch of the next output
-        __builtin_amdgcn_sched_barrier(0);
-        if (tl >= 15) {
-            double sum = 0.0;
-            if (full_hist) {                    // wave-uniform: every lane has 15 in-stream predecessors (the common case)
-#pragma unroll
-                for (int jj = 0; jj < 16; jj++)   // Frame.py:89-101 (u, w, sum over 16 windowed taps)
-                    sum += ex[p][ch][jj & 1][tl - jj] * (jj < 8 ? c0[jj & 7] : c1[jj & 7]);
-            } else {
-#pragma unroll
-                for (int jj = 0; jj < 16; jj++) {
-                    double u = ex[p][ch][jj & 1][tl - jj];
-                    if (jj > lim) u = 0.0;       // before the stream started the fifo holds zeros
-                    sum += u * (jj < 8 ? c0[jj & 7] : c1[jj & 7]);
-                }
-            }
-            if (emit) {
-                const long to = t - halo_slots;
-                if (out_format == MP3S_PCM_I16) ot16[(tl - 15) * OROW * 2 + i * nch + ch] = (uint16_t)pcm_to_i16(sum);
-                else if (out_format == MP3S_PCM_F64) ((double *)pcm_out)[(to * 32 + i) * nch + ch] = sum;
-                else ((float *)pcm_out)[(to * 32 + i) * nch + ch] = (float)sum;
-            }
-        }
-        __builtin_amdgcn_sched_barrier(0);
-        c0 = m0; c1 = m1;
         p ^= 1;
     }
     if (out_format == MP3S_PCM_I16) {
