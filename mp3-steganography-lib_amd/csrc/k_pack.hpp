@@ -34,7 +34,7 @@ __global__ __launch_bounds__(256) void k_enc_pack(
     int sri, int bri, int whole_slots, const uint32_t *__restrict__ frame_off, const uint8_t *__restrict__ padding,
     uint8_t *__restrict__ mp3, int32_t *__restrict__ scfsi_out, int32_t *__restrict__ status)
 {
-    __shared__ uint32_t fb[PACK_DW];
+    __shared__ uint32_t fb3[3][PACK_DW];   // frame images, rotating: written / being copied out / being cleared
     __shared__ uint32_t hc[4][256];
     __shared__ uint8_t hl[4][256];
     __shared__ uint8_t pc[4][324];
@@ -43,9 +43,17 @@ __global__ __launch_bounds__(256) void k_enc_pack(
         (&hc[0][0])[i] = (&c_tab.hcod[0][0])[i];
         (&hl[0][0])[i] = i < 256 ? c_tab.hlen13[i] : (i < 512 ? c_tab.hlen15[i - 256] : (i < 768 ? c_tab.hlen16[i - 512] : c_tab.hlen24[i - 768]));
     }
+    for (int i = threadIdx.x; i < 3 * PACK_DW; i += 256) (&fb3[0][0])[i] = 0;
+    __syncthreads();
+    int rot = 0;
     for (int f = blockIdx.x; f < n_frames; f += gridDim.x) {
-    for (int i = threadIdx.x; i < PACK_DW; i += 256) fb[i] = 0;
-    __syncthreads();   // also: the previous frame's image has been copied out, the tables are in place
+    // One barrier per frame.  This frame's image is fb3[rot]; the image of the frame before last -- every thread
+    // finished copying it out before the previous barrier -- is cleared now and is ready after this frame's barrier.
+    uint32_t *fb = fb3[rot];
+    {
+        uint32_t *cl = fb3[rot == 2 ? 0 : rot + 1];
+        for (int i = threadIdx.x; i < PACK_DW; i += 256) cl[i] = 0;
+    }
     const int pad = padding[f];
     // ---- __resv_frame_end (:1097-1145): all slack of the frame becomes stuffing; emission order e = gr*2 + ch
     int p23v[4];
@@ -224,7 +232,7 @@ __global__ __launch_bounds__(256) void k_enc_pack(
         outw[j] = byte_at(k) | (byte_at(k + 1) << 8) | (byte_at(k + 2) << 16) | (byte_at(k + 3) << 24);
     }
     if ((int)threadIdx.x < nbytes - tail0) mp3[off + tail0 + threadIdx.x] = (uint8_t)byte_at(tail0 + threadIdx.x);
-    __syncthreads();   // the image is free again
+    rot = rot == 2 ? 0 : rot + 1;
     }   // frames
 }
 
