@@ -43,9 +43,10 @@ constexpr int RL_NP = 5;   // pair slots per lane (the 5th only for lanes < 32)
 
 struct RlTables {
     uint16_t int2idx[10000];
-    uint32_t hl[256];       // per pair (min(x,15), min(y,15)): code length in books 13 | 15 << 5 | 16.. << 10 | 24.. << 15,
+    uint2 hl[256];          // .x per pair (min(x,15), min(y,15)): code length in books 13 | 15 << 5 | 16.. << 10 | 24.. << 15,
                             // | number of non-zero values << 20 | number of values > 14 << 22
                             // | (shortest of the four lengths + non-zero values, 0 for the pair (0,0)) << 25
+                            // .y longest of the four lengths + non-zero values + 13 bits per value > 14
     uint8_t c1a[16];
     uint8_t transform[64];  // [table][bit]
     uint32_t subdiv[289];   // __subdivide result per big_values for this workgroup's sample rate (see DevTables)
@@ -69,7 +70,7 @@ __device__ __forceinline__ int family_of(int t) { return t == 13 ? 0 : (t == 15 
 __device__ __forceinline__ uint32_t pair_bits(const RlTables &tb, int fam, int lb, int x, int y)
 {
     const int xx = x > 14 ? 15 : x, yy = y > 14 ? 15 : y;
-    const uint32_t h = tb.hl[xx * 16 + yy];
+    const uint32_t h = tb.hl[xx * 16 + yy].x;
     return ((h >> (5 * fam)) & 31u) + ((h >> 20) & 3u) + (uint32_t)lb * ((h >> 22) & 3u);
 }
 __device__ __forceinline__ int sel3(int r, int a, int b, int c) { return r == 0 ? a : (r == 1 ? b : c); }
@@ -108,14 +109,15 @@ __device__ __forceinline__ int rl_quantize(const RlTables &tb, const uint32_t (&
 
 // calc_run_len + count1_bit_count + __subdivide + __big_v_tab_select + big_v_bit_count
 // `limit`: the caller only wants to know whether the bit count reaches it (binary search: max_bits; inner loop:
-// max_bits + 1).  A lower bound -- exact count1 bits + per big-value pair the shortest code any candidate book has for
+// max_bits + 1).  With `ub_ok` (binary-search probes whose result is not reused) an upper bound that stays below the
+// limit ends the evaluation the same way (another 16 % of the probes).  A lower bound -- exact count1 bits + per big-value pair the shortest code any candidate book has for
 // it plus its sign bits -- is one table field per pair and one wave reduction away; when it already reaches the limit
 // (80 % of the probes that do) the region maxima, candidate books and their bit sums are skipped and the bound is
 // returned.  Everything with a side effect the reference's body has (run lengths, count1 table, __subdivide and the
 // stale-address rule) happens before that point.
 __device__ __forceinline__ int rl_body(const RlTables &tb, uint8_t *pcode, const int32_t (&ix)[2 * RL_NP], int lane,
                                        int sr, RlState &st, const uint8_t *__restrict__ hide, int n_hide, int cursor,
-                                       int limit, bool &full)
+                                       int limit, bool ub_ok, bool &full)
 {
     // ---- calc_run_len: highest non-zero pair P0, highest pair holding a value > 1 P1
     int P0 = -1, P1 = -1;
@@ -165,19 +167,27 @@ __device__ __forceinline__ int rl_body(const RlTables &tb, uint8_t *pcode, const
         st.addr_fresh = true;
     }
 
-    // ---- lower bound of the big-value bits
+    // ---- lower and upper bound of the big-value bits.  Lower: pairs below big_values at their shortest code.  Upper:
+    //      every pair the regions can reach -- with big_values == 0 the stale address2 still delimits regions 0 and 1
+    //      (E7) -- at its longest code with 13 linbits per escape.
     uint32_t h[RL_NP];
     {
-        uint32_t lbv = 0;
+        uint32_t bnd = 0;
+        const int reach = st.a2 > bvr ? st.a2 : bvr;
 #pragma unroll
         for (int m = 0; m < RL_NP; m++) {
             const int x = ix[2 * m], y = ix[2 * m + 1];
-            h[m] = tb.hl[(x > 14 ? 15 : x) * 16 + (y > 14 ? 15 : y)];
-            lbv += (lane + 64 * m) < bv ? __builtin_amdgcn_ubfe(h[m], 25, 5) : 0u;
+            const uint2 hh = tb.hl[(x > 14 ? 15 : x) * 16 + (y > 14 ? 15 : y)];
+            h[m] = hh.x;
+            bnd += (lane + 64 * m) < bv ? __builtin_amdgcn_ubfe(hh.x, 25, 5) : 0u;
+            bnd += 2 * (lane + 64 * m) < reach ? hh.y << 16 : 0u;
         }
-        const int lb = bits + (int)wave_add_u32(lbv);
-        full = lb < limit;
-        if (!full) return lb;
+        bnd = wave_add_u32(bnd);
+        const int lb = bits + (int)(bnd & 0xffffu), ub = bits + (int)(bnd >> 16);
+        full = false;
+        if (lb >= limit) return lb;
+        if (ub_ok && ub < limit) return ub;
+        full = true;
     }
 
     // ---- region maxima; a pair starting at line s belongs to r0 if s < a1, r1 if s < a2, r2 if s < 2*bv
@@ -286,10 +296,12 @@ __global__ __launch_bounds__(RL_WAVES * 64, 4) void k_rate_loop(
     for (int i = threadIdx.x; i < 10000; i += blockDim.x) tb.int2idx[i] = c_tab.int2idx[i];
     for (int i = threadIdx.x; i < 256; i += blockDim.x) {
         const uint32_t x = (uint32_t)i >> 4, y = (uint32_t)i & 15u;
-        tb.hl[i] = (uint32_t)c_tab.hlen13[i] | ((uint32_t)c_tab.hlen15[i] << 5) | ((uint32_t)c_tab.hlen16[i] << 10) |
+        tb.hl[i].x = (uint32_t)c_tab.hlen13[i] | ((uint32_t)c_tab.hlen15[i] << 5) | ((uint32_t)c_tab.hlen16[i] << 10) |
                    ((uint32_t)c_tab.hlen24[i] << 15) | (((x != 0) + (y != 0)) << 20) | (((x == 15) + (y == 15)) << 22);
         const uint32_t shortest = min(min((uint32_t)c_tab.hlen13[i], (uint32_t)c_tab.hlen15[i]), min((uint32_t)c_tab.hlen16[i], (uint32_t)c_tab.hlen24[i]));
-        if (i) tb.hl[i] |= (shortest + (x != 0) + (y != 0)) << 25;
+        if (i) tb.hl[i].x |= (shortest + (x != 0) + (y != 0)) << 25;
+        const uint32_t longest = max(max((uint32_t)c_tab.hlen13[i], (uint32_t)c_tab.hlen15[i]), max((uint32_t)c_tab.hlen16[i], (uint32_t)c_tab.hlen24[i]));
+        tb.hl[i].y = longest + (x != 0) + (y != 0) + 13u * ((x == 15) + (y == 15));
     }
     if (threadIdx.x < 16) tb.c1a[threadIdx.x] = c_tab.hlen_c1a[threadIdx.x];
     if (threadIdx.x < 64) tb.transform[threadIdx.x] = c_tab.transform[threadIdx.x >> 1][threadIdx.x & 1];
@@ -381,7 +393,8 @@ __global__ __launch_bounds__(RL_WAVES * 64, 4) void k_rate_loop(
                 if (q > 8192) { bit = 100000; if (q != 16384) body_step = 1 << 20; }   // 16384 = early out, ix untouched
                 else {
                     bool full;
-                    bit = rl_body(tb, pcode, ix, lane, sr, st, hide, n_hide, cursor, max_bits, full);
+                    // the last probe (half == 1) is the one the inner loop may reuse: it is evaluated in full
+                    bit = rl_body(tb, pcode, ix, lane, sr, st, hide, n_hide, cursor, max_bits, half > 1, full);
                     if (full) { body_step = next + half; body_bits = bit; } else body_step = 1 << 20;
                 }
                 if (bit < max_bits) count = half;
@@ -406,7 +419,7 @@ __global__ __launch_bounds__(RL_WAVES * 64, 4) void k_rate_loop(
                     if (q < 0) { err = true; break; }
                     qstep += 1;
                     bool full;
-                    bits = rl_body(tb, pcode, ix, lane, sr, st, hide, n_hide, cursor, max_bits + 1, full);
+                    bits = rl_body(tb, pcode, ix, lane, sr, st, hide, n_hide, cursor, max_bits + 1, false, full);
                 } while (bits > max_bits);
             }
             if (err) flags |= MP3S_RF_STEP_RANGE;
