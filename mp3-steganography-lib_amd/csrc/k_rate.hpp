@@ -133,6 +133,40 @@ __device__ __forceinline__ int rl_body(const RlTables &tb, uint8_t *pcode, const
     st.count1 = count1;
     st.big_values = bv;
 
+    // ---- __subdivide (addresses are left untouched when big_values == 0: E7)
+    const int bvr = 2 * bv;
+    if (bv == 0) {
+        st.r0c = 0; st.r1c = 0;
+        if (!st.addr_fresh) st.used_addr_in = true;
+    } else {
+        // __subdivide (:1008-1036) depends on big_values only: looked up in the per-rate table built on the host
+        const uint32_t e = tb.subdiv[bv < 289 ? bv : 288];
+        st.r0c = (int)(e & 15); st.r1c = (int)((e >> 4) & 7);
+        st.a1 = (int)((e >> 8) & 1023); st.a2 = (int)((e >> 18) & 1023);
+        st.a3 = bvr;
+        st.addr_fresh = true;
+    }
+
+    // ---- lower and upper bound of the big-value bits.  Lower: pairs below big_values at their shortest code.  Upper:
+    //      every pair the regions can reach -- with big_values == 0 the stale address2 still delimits regions 0 and 1
+    //      (E7) -- at its longest code with 13 linbits per escape.
+    uint32_t h[RL_NP];
+    uint32_t bnd = 0;
+    {
+        const int reach = st.a2 > bvr ? st.a2 : bvr;
+#pragma unroll
+        for (int m = 0; m < RL_NP; m++) {
+            const int x = ix[2 * m], y = ix[2 * m + 1];
+            const uint2 hh = tb.hl[(x > 14 ? 15 : x) * 16 + (y > 14 ? 15 : y)];
+            h[m] = hh.x;
+            bnd += (lane + 64 * m) < bv ? __builtin_amdgcn_ubfe(hh.x, 25, 5) : 0u;
+            bnd += 2 * (lane + 64 * m) < reach ? hh.y << 16 : 0u;
+        }
+        bnd = wave_add_u32(bnd);
+    }
+    full = false;
+    if ((int)(bnd & 0xffffu) >= limit) return (int)(bnd & 0xffffu);   // the big values alone are too many already
+
     // ---- count1_bit_count: quad k = pairs (bv+2k, bv+2k+1), p = v + 2w + 4x + 8y
 #pragma unroll
     for (int m = 0; m < RL_NP; m++) pcode[lane + 64 * m] = (uint8_t)((ix[2 * m] & 1) | ((ix[2 * m + 1] & 1) << 1));
@@ -153,38 +187,8 @@ __device__ __forceinline__ int rl_body(const RlTables &tb, uint8_t *pcode, const
     int bits;
     if (sum0 < sum1) { st.c1sel = 0; bits = sum0; } else { st.c1sel = 1; bits = sum1; }   // ties -> table B (E10)
 
-    // ---- __subdivide (addresses are left untouched when big_values == 0: E7)
-    const int bvr = 2 * bv;
-    if (bv == 0) {
-        st.r0c = 0; st.r1c = 0;
-        if (!st.addr_fresh) st.used_addr_in = true;
-    } else {
-        // __subdivide (:1008-1036) depends on big_values only: looked up in the per-rate table built on the host
-        const uint32_t e = tb.subdiv[bv < 289 ? bv : 288];
-        st.r0c = (int)(e & 15); st.r1c = (int)((e >> 4) & 7);
-        st.a1 = (int)((e >> 8) & 1023); st.a2 = (int)((e >> 18) & 1023);
-        st.a3 = bvr;
-        st.addr_fresh = true;
-    }
-
-    // ---- lower and upper bound of the big-value bits.  Lower: pairs below big_values at their shortest code.  Upper:
-    //      every pair the regions can reach -- with big_values == 0 the stale address2 still delimits regions 0 and 1
-    //      (E7) -- at its longest code with 13 linbits per escape.
-    uint32_t h[RL_NP];
     {
-        uint32_t bnd = 0;
-        const int reach = st.a2 > bvr ? st.a2 : bvr;
-#pragma unroll
-        for (int m = 0; m < RL_NP; m++) {
-            const int x = ix[2 * m], y = ix[2 * m + 1];
-            const uint2 hh = tb.hl[(x > 14 ? 15 : x) * 16 + (y > 14 ? 15 : y)];
-            h[m] = hh.x;
-            bnd += (lane + 64 * m) < bv ? __builtin_amdgcn_ubfe(hh.x, 25, 5) : 0u;
-            bnd += 2 * (lane + 64 * m) < reach ? hh.y << 16 : 0u;
-        }
-        bnd = wave_add_u32(bnd);
         const int lb = bits + (int)(bnd & 0xffffu), ub = bits + (int)(bnd >> 16);
-        full = false;
         if (lb >= limit) return lb;
         if (ub_ok && ub < limit) return ub;
         full = true;
