@@ -101,6 +101,10 @@ const char *mp3s_last_error(void);
 const char *mp3s_version(void);
 int mp3s_device_name(mp3s_ctx *ctx, char *buf, size_t n);
 int mp3s_sync(mp3s_ctx *ctx);
+/* Stream order between two contexts of one device: work submitted to ctx after this call starts only when everything
+ * submitted to other before it has finished.  This is how a second context runs the bit-level front end of the next
+ * batch (mp3s_huffman_decode_dev) under the transform kernels of the current one. */
+int mp3s_ctx_wait(mp3s_ctx *ctx, mp3s_ctx *other);
 /* host copy of the constant tables uploaded to the device (struct DevTables of csrc/mp3s_tables.h), for tests */
 const void *mp3s_debug_tables(size_t *bytes);
 /* host (glibc) evaluation of the __calc_scfsi energies of one granule*channel: en[0..20] bands, en[21] total.

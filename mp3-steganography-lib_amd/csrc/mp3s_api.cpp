@@ -41,7 +41,7 @@ int fail(int code, const char *fmt, ...)
 struct mp3s_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
-    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr, ev_order = nullptr;
     void *scratch = nullptr; size_t scratch_bytes = 0;
     Profiler prof;
     // device buffers of the stream pipelines, kept between calls (hipMalloc/hipFree cost more than a small file's work)
@@ -113,7 +113,8 @@ int mp3s_ctx_create(int device, mp3s_ctx **out)
     mp3s_ctx *c = new mp3s_ctx();
     c->device = device;
     if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess ||
-        hipEventCreate(&c->ev0) != hipSuccess || hipEventCreate(&c->ev1) != hipSuccess) {
+        hipEventCreate(&c->ev0) != hipSuccess || hipEventCreate(&c->ev1) != hipSuccess ||
+        hipEventCreateWithFlags(&c->ev_order, hipEventDisableTiming) != hipSuccess) {
         delete c;
         return fail(MP3S_E_NO_DEVICE, "stream/event creation failed");
     }
@@ -136,6 +137,7 @@ void mp3s_ctx_destroy(mp3s_ctx *c)
     for (void *q : c->pool) if (q) hipFree(q);
     if (c->ev0) hipEventDestroy(c->ev0);
     if (c->ev1) hipEventDestroy(c->ev1);
+    if (c->ev_order) hipEventDestroy(c->ev_order);
     if (c->stream) hipStreamDestroy(c->stream);
     delete c;
 }
@@ -153,6 +155,16 @@ int mp3s_sync(mp3s_ctx *c)
 {
     if (!c) return fail(MP3S_E_ARG, "ctx is null");
     HIPCHK(hipStreamSynchronize(c->stream));
+    return MP3S_OK;
+}
+
+int mp3s_ctx_wait(mp3s_ctx *c, mp3s_ctx *other)
+{
+    if (!c || !other) return fail(MP3S_E_ARG, "ctx is null");
+    if (c == other) return MP3S_OK;
+    if (c->device != other->device) return fail(MP3S_E_ARG, "contexts on different devices");
+    HIPCHK(hipEventRecord(other->ev_order, other->stream));
+    HIPCHK(hipStreamWaitEvent(c->stream, other->ev_order, 0));
     return MP3S_OK;
 }
 

@@ -89,7 +89,7 @@ class File(C.Structure):
 
 
 # every symbol include/mp3s.h declares (tests/test_abi.py checks the library exports all of them)
-SYMBOLS = ["mp3s_ctx_create", "mp3s_ctx_destroy", "mp3s_last_error", "mp3s_version", "mp3s_device_name", "mp3s_sync", "mp3s_debug_tables", "mp3s_debug_scfsi_energies",
+SYMBOLS = ["mp3s_ctx_create", "mp3s_ctx_destroy", "mp3s_ctx_wait", "mp3s_last_error", "mp3s_version", "mp3s_device_name", "mp3s_sync", "mp3s_debug_tables", "mp3s_debug_scfsi_energies",
            "mp3s_dev_alloc", "mp3s_dev_free", "mp3s_dev_upload", "mp3s_dev_download", "mp3s_dev_memset",
            "mp3s_timer_start", "mp3s_timer_stop", "mp3s_profile_enable", "mp3s_profile_collect", "mp3s_decode_transform_dev", "mp3s_decode_transform",
            "mp3s_encode_transform_dev", "mp3s_encode_transform", "mp3s_rate_loop_dev", "mp3s_huffman_decode_dev", "mp3s_pack_frames_dev", "mp3s_scan_stream", "mp3s_buf_free",
@@ -122,6 +122,7 @@ def lib():
         L.mp3s_ctx_destroy.restype = None
         L.mp3s_device_name.argtypes = [vp, C.c_char_p, sz]
         L.mp3s_sync.argtypes = [vp]
+        L.mp3s_ctx_wait.argtypes = [vp, vp]
         L.mp3s_debug_tables.argtypes = [C.POINTER(sz)]
         L.mp3s_debug_tables.restype = vp
         L.mp3s_debug_scfsi_energies.argtypes = [vp, i32, vp]
@@ -229,6 +230,10 @@ class Context:
         p = self.alloc(arr.nbytes)
         self.upload(p, arr)
         return p
+
+    def wait_for(self, other):
+        """work submitted to this context from now on starts after everything submitted to `other` so far"""
+        check(lib().mp3s_ctx_wait(self.handle, other.handle))
 
     def timer_start(self):
         check(lib().mp3s_timer_start(self.handle))
