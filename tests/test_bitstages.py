@@ -120,3 +120,32 @@ def test_device_packer_matches_host_formatter(ctx, mlib, orc, golden_dir):
         assert np.array_equal(ctx.download(d_sc, np.int32, (n, 2, 4)), o["frames"]["scfsi"])
         for q in (d_mdct, d_rf, d_ix, d_out, d_en, d_ixf, d_gr, d_off, d_pad, d_mp3, d_sc, d_st):
             ctx.free(q)
+
+
+@pytest.mark.gpu
+def test_two_contexts_ordered_by_ctx_wait(ctx, mlib, orc, golden_dir):
+    """the front end on a second context of the same device, the transforms on the first, ordered by mp3s_ctx_wait
+    (what bench.py does to run the Huffman decode of the next batch under the rate loop of the current one)"""
+    L = mlib.lib()
+    data = np.load(os.path.join(golden_dir, "g6_synth128.npz"))["mp3"].tobytes()
+    s = mlib.scan_stream(data)
+    n, nch = s["n_frames"], s["channels"]
+    aux = mlib.Context(ctx.device)
+    try:
+        d_blob, d_side, d_hdr = ctx.to_device(s["blob"]), ctx.to_device(s["side"]), ctx.to_device(s["hdr"])
+        d_is, d_si, d_st = ctx.alloc(n * 2304 * 2), ctx.alloc(n * 4 * 72), ctx.alloc(4)
+        d_pcm = ctx.alloc(n * 1152 * nch * 8)
+        expect = orc.decode(data)["pcm"][:n * 1152].tobytes()
+        for _ in range(5):                                           # repeated: the buffers are rewritten every round
+            aux.wait_for(ctx)                                        # the previous round has read is / si
+            mlib.check(L.mp3s_huffman_decode_dev(aux.handle, d_blob, d_side, n, nch, s["max_part2_3_length"], d_is, d_si, d_st))
+            ctx.wait_for(aux)
+            mlib.check(L.mp3s_decode_transform_dev(ctx.handle, d_is, d_si, d_hdr, n, nch, 0, mlib.MP3S_PCM_F64, d_pcm))
+        ctx.sync()
+        assert ctx.download(d_pcm, np.float64, (n * 1152, nch)).tobytes() == expect
+        assert int(ctx.download(d_st, np.int32, (1,))[0]) == 0
+        ctx.wait_for(ctx)                                            # waiting for oneself is a no-op
+        for q in (d_blob, d_side, d_hdr, d_is, d_si, d_st, d_pcm):
+            ctx.free(q)
+    finally:
+        aux.close()
