@@ -209,6 +209,8 @@ typedef struct {
 #define MP3S_HS_BAD_REGION 1
 #define MP3S_HS_BIG_VALUES 2
 #define MP3S_HS_HINT 4 /* some part2_3_length exceeds max_part2_3_length: call again with a larger bound (or 0) */
+#define MP3S_HS_OVERRUN 8 /* the big values of some granule run past its part2_3_length into the bits that follow: the
+                           * reference decodes on (one bit cursor per frame); use mp3s_parse_stream for this stream */
 /* max_part2_3_length: an upper bound on part2_3_length over the batch (the scan knows it: mp3s_scanned.max_part2_3_length),
  * or 0 for the format's limit of 4095.  It sizes the per-thread staging of the bit stream in LDS and with it the number of
  * resident wavefronts: 8 per CU for granules up to 900 bits, 2 at the limit. */

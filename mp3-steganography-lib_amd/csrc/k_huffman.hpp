@@ -224,6 +224,9 @@ __global__ __launch_bounds__(WAVES * 64) void k_dec_huffman(
         int sample = 0;
         const uint32_t ti0 = tinfo[(u2 >> 8) & 31], ti1 = tinfo[(u2 >> 16) & 31], ti2 = tinfo[(u2 >> 24) & 31];
         while (sample < bv2) {
+            // big values that run past part2_3_length read on into the data that follows (the reference has one bit
+            // cursor per frame); the staged window covers one code word of that, a second one is reported
+            if (bit > max_bit) { err |= MP3S_HS_OVERRUN; break; }
             const uint32_t ti = sample < region0 ? ti0 : (sample < region1 ? ti1 : ti2);
             const int lut = (int)(ti & 0xff), lb = (int)(ti >> 8);
             if (lut == 255) {                                     // books 0, 4, 14: zeros, no bits (D2): skip the region

@@ -441,6 +441,7 @@ int mp3s_format_stream(int samplerate, int bitrate_kbps, int n_frames, const int
 
 // ------------------------------------------------------------------------------------------------ pipelines
 struct mp3s_multi {     // owner payload of mp3s_decode_streams
+    std::vector<std::pair<const uint8_t *, size_t>> files;   // borrowed for the duration of the call
     std::vector<ParsedStream> parsed;
     std::vector<ScannedStream> scanned;
     std::vector<uint8_t> arena[3];        // PCM of all mono / all stereo streams, index = channel count
@@ -498,7 +499,21 @@ static int decode_group(mp3s_ctx *c, mp3s_multi &m, const std::vector<int> &idx,
                                               (int16_t *)d_is, (mp3s_granule_si *)d_si, (int32_t *)d_st);
         int32_t st = 0;
         if (!rc) rc = mp3s_dev_download(c, &st, d_st, sizeof st);
-        if (!rc && st) rc = fail(MP3S_E_MALFORMED, "malformed main data (status %d)", st);
+        if (!rc && st) {
+            // Something in the Huffman data is off (region counts, big_values past 576 lines, big values running past
+            // part2_3_length).  The full host parser decides -- it walks the frame with the reference's single bit
+            // cursor -- and its frames replace the device's.
+            for (size_t k = 0; k < idx.size() && !rc; k++) {
+                const int i = idx[k];
+                if (!m.scanned[i].gpu_ok) continue;
+                const int n_before = m.parsed[i].n_frames;
+                rc = parse_stream(m.files[i].first, m.files[i].second, m.parsed[i], nullptr);
+                if (rc) { rc = fail(rc, "file %d: malformed main data", i); break; }
+                if (m.parsed[i].n_frames != n_before) { rc = fail(MP3S_E_MALFORMED, "file %d: inconsistent parse", i); break; }
+                m.scanned[i].gpu_ok = false;
+                any_host = true;
+            }
+        }
     }
     if (any_host)   // streams that inherit scalefactors across frames were parsed on the host: place their frames
         for (size_t k = 0; k < idx.size() && !rc; k++) {
@@ -580,10 +595,11 @@ int mp3s_decode_streams(mp3s_ctx *c, const uint8_t *const *files, const size_t *
     mp3s_buf *b = new mp3s_buf();
     b->multi.reset(new mp3s_multi());
     mp3s_multi &m = *b->multi;
-    m.parsed.resize(n_files); m.scanned.resize(n_files); m.pcm.assign(n_files, nullptr);
+    m.parsed.resize(n_files); m.scanned.resize(n_files); m.pcm.assign(n_files, nullptr); m.files.resize(n_files);
     std::vector<int> group[3];
     for (int i = 0; i < n_files; i++) {
         if (!files[i]) { delete b; return fail(MP3S_E_ARG, "file %d is null", i); }
+        m.files[i] = {files[i], lens[i]};
         const int rc = front_end(files[i], lens[i], m.parsed[i], m.scanned[i]);
         if (rc) { delete b; return fail(rc, "file %d: malformed or unsupported MP3 stream", i); }
         group[m.parsed[i].nch].push_back(i);
@@ -855,12 +871,15 @@ int mp3s_encode_file(mp3s_ctx *c, const uint8_t *wav, size_t len, int bitrate_kb
 static int reencode(mp3s_ctx *c, const uint8_t *mp3, size_t len, const uint8_t *hide_bits, int n_hide, mp3s_buf **owner, mp3s_file *out)
 {
     mp3s_multi m;
-    m.parsed.resize(1); m.scanned.resize(1); m.pcm.assign(1, nullptr);
+    m.parsed.resize(1); m.scanned.resize(1); m.pcm.assign(1, nullptr); m.files.assign(1, {mp3, len});
     int rc = front_end(mp3, len, m.parsed[0], m.scanned[0]);
     if (rc) return fail(rc, "malformed or unsupported MP3 stream");
     const ParsedStream &p = m.parsed[0];
     const int kbps = p.bit_rate / 1000;
     int sri, bri, whole;
+    // the WAV the reference writes carries the last header's sampling rate; its reader checks the rate, then the bitrate
+    if (p.sampling_rate != 32000 && p.sampling_rate != 44100 && p.sampling_rate != 48000)
+        return fail(MP3S_E_EXIT, "Unsupported sampling frequency.");
     if (stream_params(p.sampling_rate, kbps, &sri, &bri, &whole)) return fail(MP3S_E_EXIT, "Unsupported bitrate configuration.");
     if (p.nch != 2) return fail(MP3S_E_UNSUPPORTED, "mono input: the reference encoder indexes the sample buffer out of bounds");
     const int64_t rows_frames = (int64_t)p.n_frames + (p.dup_last_frame ? 1 : 0);

@@ -208,7 +208,11 @@ int parse_stream(const uint8_t *file, size_t flen_, ParsedStream &out, ScannedSt
         if (buffer[0] == 0xFF && buffer[1] >= 0xE0) { int rc = parse_header(hd, buffer); if (rc) return rc; }
         else { valid = false; out.dup_last_frame = out.n_frames > 0 ? 1 : 0; break; }   // D12
         int rc = set_frame_size(); if (rc) return rc;
-        if (frame_size <= 0 || hd.sr_idx < 0 || hd.version != 1 || hd.layer != 3) return MP3S_E_MALFORMED;  // D16
+        // D16: band tables exist for 32 / 44.1 / 48 kHz only and are chosen by the sampling rate alone (FrameHeader.py:125-143);
+        // a header with another rate keeps the tables of the frame before it, a stream that starts with one has none
+        // (IndexError).  Neither the version nor the layer field is checked by the reference: such frames -- reached
+        // through false syncs -- are taken apart as Layer III with that header's frame size and bit-rate rule.
+        if (frame_size <= 0 || hd.sr_idx < 0) return MP3S_E_MALFORMED;
         if (first_nch == 0) first_nch = hd.channels;
         else if (hd.channels != first_nch) return MP3S_E_UNSUPPORTED;   // ragged pcm_data in the reference
         const int nch = hd.channels;
