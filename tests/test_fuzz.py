@@ -88,3 +88,37 @@ def test_device_decode_of_mutants_matches_the_oracle(ctx, mlib, orc, golden_dir)
         assert np.array_equal(r["pcm"].view(np.uint64), np.ascontiguousarray(o["pcm"]).view(np.uint64))   # NaNs compare too
         ok += 1
     assert ok > 100
+
+
+@pytest.mark.gpu
+def test_encoder_on_extreme_signals(ctx, mlib, orc):
+    """full-scale noise, square waves, impulses, DC, near silence -- at the tightest and the widest bit budget: the rate
+    loop's float path (ln >= 10000), the early out, empty granules and the quantizer-step guard all against the oracle"""
+    rng = np.random.default_rng(5)
+    n = 24 * 1152
+    t = np.arange(n)
+    sig = {
+        "noise": rng.integers(-32768, 32768, size=(n, 2)),
+        "square": np.stack([np.where((t // 7) % 2, 32767, -32768), np.where((t // 50) % 2, -32768, 32767)], axis=1),
+        "impulse": np.zeros((n, 2)),
+        "dc": np.full((n, 2), 32767),
+        "quiet": rng.integers(-1, 2, size=(n, 2)),
+        "burst": np.concatenate([np.zeros((n // 2, 2)), rng.integers(-32768, 32768, size=(n - n // 2, 2))]),
+        "left_only": np.stack([rng.integers(-20000, 20000, size=n), np.zeros(n)], axis=1),
+    }
+    sig["impulse"][5000] = (32767, -32768)
+    msg = np.frombuffer(b"1" * 30 + b"0" * 30, dtype=np.uint8) - ord("0")
+    for name, pcm in sig.items():
+        pcm = np.ascontiguousarray(pcm, dtype=np.int16)
+        for rate, kbps in ((44100, 32), (48000, 320), (32000, 128)):
+            o = orc.encode(pcm, rate, kbps, msg)
+            try:
+                r = ctx.encode_pcm(pcm, rate, kbps, msg)
+            except mlib.Mp3sError as e:
+                assert e.code == mlib.E_STEP_RANGE and o["rc"] != 0, (name, rate, kbps)
+                continue
+            assert o["rc"] == 0, (name, rate, kbps)
+            assert r["mp3"] == o["mp3"], (name, rate, kbps)
+            assert r["hide_offset"] == o["hide_offset"]
+            d = ctx.decode_stream(r["mp3"], mlib.MP3S_PCM_F64)
+            assert np.array_equal(d["pcm"], orc.decode(r["mp3"])["pcm"]), (name, rate, kbps)
