@@ -466,4 +466,26 @@ __global__ __launch_bounds__(RL_WAVES * 64, 4) void k_rate_loop(
     }
 }
 
+// Long messages (mp3s_encode_pcm): a unit's result depends on the message only through the <= 3 bits at its cursor, so
+// the rate loop is run once per 3-bit pattern and the host, walking the cursor chain, names the pattern each unit
+// really sees.  One wave per unit copies that variant's ix / GrInfo / energies into the final arrays.
+__global__ __launch_bounds__(256) void k_pick_variant(
+    const uint8_t *__restrict__ sel, int u0, int chunk, const int16_t *__restrict__ ixv, const mp3s_gr_out *__restrict__ outv,
+    const int32_t *__restrict__ env, int16_t *__restrict__ ix, mp3s_gr_out *__restrict__ out, int32_t *__restrict__ en)
+{
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+    const int j = blockIdx.x * 4 + wave;
+    if (j >= chunk) return;
+    const int v = sel[j];
+    if (v >= 8) return;                       // the unit keeps what it has
+    const long src = (long)v * chunk + j, dst = (long)u0 + j;
+    const uint32_t *a = reinterpret_cast<const uint32_t *>(ixv + src * 576);
+    uint32_t *b = reinterpret_cast<uint32_t *>(ix + dst * 576);
+    for (int i = lane; i < 288; i += 64) b[i] = a[i];
+    const uint32_t *ga = reinterpret_cast<const uint32_t *>(outv + src);
+    uint32_t *gb = reinterpret_cast<uint32_t *>(out + dst);
+    if (lane < (int)(sizeof(mp3s_gr_out) / 4)) gb[lane] = ga[lane];
+    if (lane < 22) en[dst * 22 + lane] = env[src * 22 + lane];
+}
+
 }  // namespace mp3s

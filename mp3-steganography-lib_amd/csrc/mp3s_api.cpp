@@ -45,7 +45,7 @@ struct mp3s_ctx {
     void *scratch = nullptr; size_t scratch_bytes = 0;
     Profiler prof;
     // device buffers of the stream pipelines, kept between calls (hipMalloc/hipFree cost more than a small file's work)
-    static constexpr int kPoolSlots = 24;
+    static constexpr int kPoolSlots = 32;
     void *pool[kPoolSlots] = {nullptr};
     size_t pool_bytes[kPoolSlots] = {0};
     void *grab(int slot, size_t bytes)
@@ -626,6 +626,8 @@ int mp3s_decode_stream(mp3s_ctx *c, const uint8_t *file, size_t len, int out_for
 }
 
 // pcm_dev != nullptr: the int16 PCM is already in HBM (re-encode after a device decode) and pcm is ignored
+constexpr int kLongMessageBits = 256;
+
 static int encode_core(mp3s_ctx *c, const int16_t *pcm, const int16_t *pcm_dev, int64_t n_samples_per_ch, int nch, int samplerate,
                        int bitrate_kbps, const uint8_t *hide_bits, int n_hide, mp3s_buf **owner, mp3s_encoded *out)
 {
@@ -662,7 +664,12 @@ static int encode_core(mp3s_ctx *c, const int16_t *pcm, const int16_t *pcm_dev, 
     }
     std::vector<int32_t> cursor(units), state((size_t)units * 4, 0), en((size_t)units * 22);
     std::vector<mp3s_gr_out> gr(units);
-    for (int u = 0; u < units; u++) cursor[u] = 3 * u;   // first guess: three tables per unit
+    // A unit sees the message only through the <= 3 bits at its cursor.  Short messages: guess three tables per unit,
+    // run, prefix-sum the real counts and re-run what the guess got wrong (1-2 launches).  Long messages would need
+    // one launch per unit whose table count differs from the guess (about 1 in 40), so for them the rate loop runs once
+    // per 3-bit pattern over the units the message can reach and the cursor walk below picks each unit's pattern.
+    const bool long_msg = n_hide > kLongMessageBits;
+    for (int u = 0; u < units; u++) cursor[u] = long_msg ? 0x7fffffff : 3 * u;
     if (!pcm_dev) rc = mp3s_dev_upload(c, d_pcm, pcm, (size_t)n * 2304 * 2);
     if (!rc) rc = mp3s_dev_upload(c, d_hdr, hdr.data(), (size_t)n * sizeof(mp3s_frame_hdr));
     if (!rc) rc = mp3s_dev_upload(c, d_rf, rf.data(), (size_t)n * sizeof(mp3s_rate_frame));
@@ -671,10 +678,58 @@ static int encode_core(mp3s_ctx *c, const int16_t *pcm, const int16_t *pcm_dev, 
     if (!rc) rc = mp3s_dev_upload(c, d_state, state.data(), (size_t)units * 16);
     if (!rc) rc = mp3s_encode_transform_dev(c, (const int16_t *)d_pcm, (const mp3s_frame_hdr *)d_hdr, n, (int32_t *)d_mdct);
     if (!rc) rc = mp3s_rate_loop_dev(c, (const int32_t *)d_mdct, (const mp3s_rate_frame *)d_rf, n, (const uint8_t *)d_hide,
-                                     n_hide, (const int32_t *)d_cur, (const int32_t *)d_state, nullptr, 0, (int16_t *)d_ix,
-                                     (mp3s_gr_out *)d_out, (int32_t *)d_en);
+                                     long_msg ? 0 : n_hide, (const int32_t *)d_cur, (const int32_t *)d_state, nullptr, 0,
+                                     (int16_t *)d_ix, (mp3s_gr_out *)d_out, (int32_t *)d_en);
     if (!rc) rc = mp3s_dev_download(c, gr.data(), d_out, (size_t)units * sizeof(mp3s_gr_out));
     int passes = 1;
+    if (!rc && long_msg) {
+        const int kChunk = 8192;   // units per round of eight variant launches
+        void *d_ixv = nullptr, *d_outv = nullptr, *d_env = nullptr, *d_sel = nullptr, *d_h3 = nullptr;
+        if (!alloc(&d_ixv, (size_t)8 * kChunk * 1152) || !alloc(&d_outv, (size_t)8 * kChunk * sizeof(mp3s_gr_out)) ||
+            !alloc(&d_env, (size_t)8 * kChunk * 88) || !alloc(&d_sel, kChunk) || !alloc(&d_h3, 32))
+            rc = fail(MP3S_E_NOMEM, "hipMalloc failed for the message variants");
+        uint8_t h3[32];
+        for (int v = 0; v < 8; v++) { h3[4 * v] = (v >> 2) & 1; h3[4 * v + 1] = (v >> 1) & 1; h3[4 * v + 2] = v & 1; h3[4 * v + 3] = 0; }
+        if (!rc) rc = mp3s_dev_upload(c, d_h3, h3, 32);
+        std::vector<mp3s_gr_out> gv((size_t)8 * kChunk);
+        std::vector<int32_t> lst(kChunk);
+        std::vector<uint8_t> sel(kChunk);
+        int64_t cur = 0;
+        for (int u0 = 0; u0 < units && cur < n_hide && !rc; u0 += kChunk) {
+            const int chunk = std::min(kChunk, units - u0);
+            for (int j = 0; j < chunk; j++) lst[j] = u0 + j;
+            rc = mp3s_dev_upload(c, d_list, lst.data(), (size_t)chunk * 4);
+            for (int v = 0; v < 8 && !rc; v++) {
+                // outputs are indexed by unit: bias the bases so that unit u0 + j lands on element v * chunk + j
+                int16_t *ixb = (int16_t *)d_ixv + ((long)v * chunk - u0) * 576;
+                mp3s_gr_out *ob = (mp3s_gr_out *)d_outv + ((long)v * chunk - u0);
+                int32_t *eb = (int32_t *)d_env + ((long)v * chunk - u0) * 22;
+                const int e = launch_rate(c->stream, (const int32_t *)d_mdct, (const mp3s_rate_frame *)d_rf, n, (const uint8_t *)d_h3 + 4 * v,
+                                          3, nullptr, (const int32_t *)d_state, (const int32_t *)d_list, chunk, ixb, ob, eb, &c->prof);
+                if (e) rc = fail(MP3S_E_HIP, "rate launch: %s", hipGetErrorString((hipError_t)e));
+                passes++;
+            }
+            if (!rc) rc = mp3s_dev_download(c, gv.data(), d_outv, (size_t)8 * chunk * sizeof(mp3s_gr_out));
+            for (int j = 0; j < chunk && !rc; j++) {
+                const int u = u0 + j;
+                sel[j] = 255;
+                if (cur + 3 <= n_hide) {                      // all three bits the unit can ask for exist
+                    const int v = (hide_bits[cur] & 1) * 4 + (hide_bits[cur + 1] & 1) * 2 + (hide_bits[cur + 2] & 1);
+                    sel[j] = (uint8_t)v;
+                    gr[u] = gv[(size_t)v * chunk + j];
+                    cursor[u] = (int32_t)cur;
+                }                                             // else: the message ends inside or before this unit -- the
+                cur += gr[u].n_tables;                        // consistency loop below re-runs it with its real cursor
+            }
+            if (!rc) rc = mp3s_dev_upload(c, d_sel, sel.data(), (size_t)chunk);
+            if (!rc) {
+                const int e = launch_pick(c->stream, (const uint8_t *)d_sel, u0, chunk, (const int16_t *)d_ixv, (const mp3s_gr_out *)d_outv,
+                                          (const int32_t *)d_env, (int16_t *)d_ix, (mp3s_gr_out *)d_out, (int32_t *)d_en);
+                if (e) rc = fail(MP3S_E_HIP, "variant pick: %s", hipGetErrorString((hipError_t)e));
+            }
+            if (!rc && hipStreamSynchronize(c->stream) != hipSuccess) rc = fail(MP3S_E_HIP, "sync failed");   // sel / lst are reused
+        }
+    }
     // ---- resolve the serial chain: hide cursor (MP3_Encoder.py:808-809) and the per-(gr,ch) inherited
     //      address1/2/3 + quantizerStepSize (E7).  Units whose assumed inputs were wrong are re-run.
     std::vector<int32_t> list;

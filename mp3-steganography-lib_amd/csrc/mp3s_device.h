@@ -45,6 +45,9 @@ int launch_rate(hipStream_t stream, const int32_t *d_mdct, const mp3s_rate_frame
 // bit-level stages on the device
 int launch_huffman(hipStream_t stream, const uint8_t *d_blob, const mp3s_frame_side *d_side, int n_frames, int nch, int max_bits,
                    int16_t *d_is, mp3s_granule_si *d_si, int32_t *d_status, Profiler *prof);
+// copy variant sel[j] (0..7, 255 = keep) of units u0 .. u0+chunk-1 from [8][chunk] arrays into the final arrays
+int launch_pick(hipStream_t stream, const uint8_t *d_sel, int u0, int chunk, const int16_t *d_ixv, const mp3s_gr_out *d_outv,
+                const int32_t *d_env, int16_t *d_ix, mp3s_gr_out *d_out, int32_t *d_en);
 int launch_pack(hipStream_t stream, const int16_t *d_ix, const mp3s_gr_out *d_gr, const int32_t *d_en, int n_frames, int sri,
                 int bri, int whole_slots, const uint32_t *d_frame_off, const uint8_t *d_padding, uint8_t *d_mp3,
                 int32_t *d_scfsi, int32_t *d_status, Profiler *prof);

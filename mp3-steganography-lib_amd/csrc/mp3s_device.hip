@@ -119,6 +119,15 @@ int launch_rate(hipStream_t stream, const int32_t *d_mdct, const mp3s_rate_frame
     return (int)hipGetLastError();
 }
 
+int launch_pick(hipStream_t stream, const uint8_t *d_sel, int u0, int chunk, const int16_t *d_ixv, const mp3s_gr_out *d_outv,
+                const int32_t *d_env, int16_t *d_ix, mp3s_gr_out *d_out, int32_t *d_en)
+{
+    if (chunk <= 0) return 0;
+    hipLaunchKernelGGL(k_pick_variant, dim3((chunk + 3) / 4), dim3(256), 0, stream, d_sel, u0, chunk, d_ixv, d_outv, d_env, d_ix,
+                       d_out, d_en);
+    return (int)hipGetLastError();
+}
+
 int launch_huffman(hipStream_t stream, const uint8_t *d_blob, const mp3s_frame_side *d_side, int n_frames, int nch, int max_bits,
                    int16_t *d_is, mp3s_granule_si *d_si, int32_t *d_status, Profiler *prof)
 {

@@ -309,3 +309,28 @@ def test_many_seeded_streams_across_chunk_boundaries(ctx, mlib, orc):
         assert zlib.crc32(r["pcm"].tobytes()) == zlib.crc32(orc.pcm_to_i16(od["pcm"]).tobytes()), i
     out64 = ctx.decode_streams(files[4:7], mlib.MP3S_PCM_F64)
     assert np.array_equal(out64[1]["pcm"], orc.decode(files[5])["pcm"])
+
+
+# ------------------------------------------------------------------------------------------------ long messages
+def test_long_messages_take_the_variant_path(ctx, mlib, orc):
+    """messages above 256 bits: the rate loop runs once per 3-bit pattern and the cursor walk picks each unit's pattern
+    (mp3s_api.cpp encode_core).  Lengths around the threshold, ending mid-stream (the units at the message end fall back
+    to the exact re-run), ending on every offset inside a unit, and longer than the stream can hold."""
+    from synth_pcm import synth_pcm
+    pcm = synth_pcm(700, seed=77)
+    pcm[300 * 1152:330 * 1152] = 0                                   # silent units: no tables, stale addresses (E7)
+    rng = np.random.default_rng(3)
+    for nbits in (256, 257, 258, 259, 300, 1001, 3203, 6000, 24040):
+        msg = rng.integers(0, 2, size=nbits).astype(np.uint8)
+        r = ctx.encode_pcm(pcm, 44100, 128, msg)
+        o = orc.encode(pcm, 44100, 128, msg)
+        assert o["rc"] == 0 and r["mp3"] == o["mp3"], nbits
+        assert r["hide_offset"] == o["hide_offset"] and r["too_long"] == bool(o["too_long"]), nbits
+        d = ctx.decode_stream(r["mp3"], mlib.MP3S_PCM_I16)
+        k = min(nbits, int(r["hide_offset"]))
+        assert np.array_equal(d["bits"][:k], msg[:k]), nbits         # what went in comes out
+    # other rates: the variant launches share the per-rate tables of the batch
+    for rate, kbps in ((48000, 320), (32000, 64)):
+        pcm2 = synth_pcm(300, rate=rate, seed=5)
+        msg = rng.integers(0, 2, size=2500).astype(np.uint8)
+        assert ctx.encode_pcm(pcm2, rate, kbps, msg)["mp3"] == orc.encode(pcm2, rate, kbps, msg)["mp3"], (rate, kbps)
