@@ -695,8 +695,10 @@ static int encode_core(mp3s_ctx *c, const int16_t *pcm, const int16_t *pcm_dev, 
         std::vector<int32_t> lst(kChunk);
         std::vector<uint8_t> sel(kChunk);
         int64_t cur = 0;
-        for (int u0 = 0; u0 < units && cur < n_hide && !rc; u0 += kChunk) {
-            const int chunk = std::min(kChunk, units - u0);
+        for (int u0 = 0, chunk = 0; u0 < units && cur < n_hide && !rc; u0 += chunk) {
+            // as many units as the rest of the message can reach at two tables per unit (silent units take none: the loop
+            // simply goes round again), at most kChunk
+            chunk = (int)std::min<int64_t>(std::min(kChunk, units - u0), (n_hide - cur) / 2 + 64);
             for (int j = 0; j < chunk; j++) lst[j] = u0 + j;
             rc = mp3s_dev_upload(c, d_list, lst.data(), (size_t)chunk * 4);
             for (int v = 0; v < 8 && !rc; v++) {
@@ -773,9 +775,11 @@ static int encode_core(mp3s_ctx *c, const int16_t *pcm, const int16_t *pcm_dev, 
         if (!rc) rc = mp3s_rate_loop_dev(c, (const int32_t *)d_mdct, (const mp3s_rate_frame *)d_rf, n, (const uint8_t *)d_hide,
                                          n_hide, (const int32_t *)d_cur, (const int32_t *)d_state, (const int32_t *)d_list,
                                          (int)list.size(), (int16_t *)d_ix, (mp3s_gr_out *)d_out, (int32_t *)d_en);
-        tmp.resize(units);
-        if (!rc) rc = mp3s_dev_download(c, tmp.data(), d_out, (size_t)units * sizeof(mp3s_gr_out));
-        if (!rc) for (int u : list) gr[u] = tmp[u];
+        // the list is ascending: fetch the span it covers, not all units
+        const int lo = list.front(), span = list.back() - lo + 1;
+        tmp.resize(span);
+        if (!rc) rc = mp3s_dev_download(c, tmp.data(), (const mp3s_gr_out *)d_out + lo, (size_t)span * sizeof(mp3s_gr_out));
+        if (!rc) for (int u : list) gr[u] = tmp[u - lo];
     }
     mp3s_buf *b = nullptr;
     if (!rc) {
