@@ -8,6 +8,7 @@
 #include <cstdio>
 #include <cstring>
 #include <memory>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -67,6 +68,57 @@ struct mp3s_ctx {
         scratch_bytes = bytes;
         return 0;
     }
+};
+
+// Page-locked host memory for large results (decoded PCM): the device writes it at PCIe speed, no bounce buffer, no
+// page faults.  Pinning costs more than the copy it saves, so blocks are kept and reused: process-wide, because a
+// result may outlive the context that produced it.  (Blocks still cached at exit are left to the OS.)
+class PinnedBlock {
+public:
+    PinnedBlock() = default;
+    PinnedBlock(const PinnedBlock &) = delete;
+    PinnedBlock &operator=(const PinnedBlock &) = delete;
+    ~PinnedBlock() { release(); }
+    bool reserve(size_t bytes)
+    {
+        if (bytes <= cap_) return true;
+        release();
+        {
+            std::lock_guard<std::mutex> g(mu());
+            auto &fl = free_list();
+            size_t best = fl.size();
+            for (size_t i = 0; i < fl.size(); i++)
+                if (fl[i].second >= bytes && (best == fl.size() || fl[i].second < fl[best].second)) best = i;
+            if (best < fl.size()) { p_ = fl[best].first; cap_ = fl[best].second; fl.erase(fl.begin() + best); return true; }
+        }
+        const size_t want = bytes + bytes / 8 + (1 << 16);
+        void *q = nullptr;
+        if (hipHostMalloc(&q, want, hipHostMallocDefault) != hipSuccess) return false;
+        p_ = (uint8_t *)q; cap_ = want;
+        return true;
+    }
+    uint8_t *data() const { return p_; }
+
+private:
+    void release()
+    {
+        if (!p_) return;
+        std::lock_guard<std::mutex> g(mu());
+        auto &fl = free_list();
+        size_t held = 0;
+        for (auto &e : fl) held += e.second;
+        if (fl.size() < 4 && held + cap_ <= ((size_t)1 << 30)) fl.emplace_back(p_, cap_);
+        else hipHostFree(p_);
+        p_ = nullptr; cap_ = 0;
+    }
+    static std::mutex &mu() { static std::mutex *m = new std::mutex(); return *m; }
+    static std::vector<std::pair<uint8_t *, size_t>> &free_list()
+    {
+        static auto *v = new std::vector<std::pair<uint8_t *, size_t>>();
+        return *v;
+    }
+    uint8_t *p_ = nullptr;
+    size_t cap_ = 0;
 };
 
 struct mp3s_multi;
@@ -444,7 +496,8 @@ struct mp3s_multi {     // owner payload of mp3s_decode_streams
     std::vector<std::pair<const uint8_t *, size_t>> files;   // borrowed for the duration of the call
     std::vector<ParsedStream> parsed;
     std::vector<ScannedStream> scanned;
-    std::vector<uint8_t> arena[3];        // PCM of all mono / all stereo streams, index = channel count
+    PinnedBlock arena[3];                 // PCM of all mono / all stereo streams, index = channel count
+    size_t head_room = 0;                 // bytes kept free in front of the PCM (mp3s_decode_file puts the WAV header there)
     std::vector<const uint8_t *> pcm;     // per stream, into its arena
 };
 
@@ -529,8 +582,12 @@ static int decode_group(mp3s_ctx *c, mp3s_multi &m, const std::vector<int> &idx,
     std::vector<long> out_first(idx.size());
     long extra = 0;
     for (size_t k = 0; k < idx.size(); k++) { out_first[k] = first_of[k] + extra; extra += m.parsed[idx[k]].dup_last_frame ? 1 : 0; }
-    std::vector<uint8_t> &arena = m.arena[nch];
-    if (!d_keep) arena.resize((size_t)(n + extra) * frame_bytes);
+    uint8_t *arena = nullptr;
+    if (!d_keep) {
+        if (!m.arena[nch].reserve(m.head_room + (size_t)(n + extra) * frame_bytes))
+            return fail(MP3S_E_NOMEM, "hipHostMalloc failed for %ld frames of PCM", n + extra);
+        arena = m.arena[nch].data() + m.head_room;
+    }
     std::vector<mp3s_frame_hdr> hc;
     for (long start = 0; start < n && !rc; start += kDecodeChunk) {
         const int halo = (start && hdr[(size_t)start].stream_first < (uint32_t)start) ? 1 : 0;
@@ -554,7 +611,7 @@ static int decode_group(mp3s_ctx *c, mp3s_multi &m, const std::vector<int> &idx,
             if (d_keep) {
                 if (hipMemcpyAsync((uint8_t *)d_keep + dst, src, bytes, hipMemcpyDeviceToDevice, c->stream) != hipSuccess)
                     rc = fail(MP3S_E_HIP, "device copy failed");
-            } else rc = mp3s_dev_download(c, arena.data() + dst, src, bytes);
+            } else rc = mp3s_dev_download(c, arena + dst, src, bytes);
             a = b;
         }
     }
@@ -568,10 +625,10 @@ static int decode_group(mp3s_ctx *c, mp3s_multi &m, const std::vector<int> &idx,
                     rc = fail(MP3S_E_HIP, "device copy failed");
             } else {
                 hipStreamSynchronize(c->stream);
-                std::memcpy(arena.data() + last + frame_bytes, arena.data() + last, frame_bytes);
+                std::memcpy(arena + last + frame_bytes, arena + last, frame_bytes);
             }
         }
-        if (!d_keep) m.pcm[idx[k]] = arena.data() + (size_t)out_first[k] * frame_bytes;
+        if (!d_keep) m.pcm[idx[k]] = arena + (size_t)out_first[k] * frame_bytes;
     }
     if (!d_keep) hipStreamSynchronize(c->stream);
     return rc;
@@ -587,14 +644,15 @@ static int front_end(const uint8_t *file, size_t len, ParsedStream &p, ScannedSt
     return rc;
 }
 
-int mp3s_decode_streams(mp3s_ctx *c, const uint8_t *const *files, const size_t *lens, int n_files, int out_format,
-                        mp3s_buf **owner, mp3s_decoded *out)
+static int decode_streams_impl(mp3s_ctx *c, const uint8_t *const *files, const size_t *lens, int n_files, int out_format,
+                               size_t head_room, mp3s_buf **owner, mp3s_decoded *out)
 {
     if (!c || !files || !lens || !owner || !out || n_files <= 0) return fail(MP3S_E_ARG, "bad argument");
     if (out_format < 0 || out_format > 2) return fail(MP3S_E_ARG, "out_format=%d", out_format);
     mp3s_buf *b = new mp3s_buf();
     b->multi.reset(new mp3s_multi());
     mp3s_multi &m = *b->multi;
+    m.head_room = head_room;
     m.parsed.resize(n_files); m.scanned.resize(n_files); m.pcm.assign(n_files, nullptr); m.files.resize(n_files);
     std::vector<int> group[3];
     for (int i = 0; i < n_files; i++) {
@@ -617,6 +675,12 @@ int mp3s_decode_streams(mp3s_ctx *c, const uint8_t *const *files, const size_t *
     }
     *owner = b;
     return MP3S_OK;
+}
+
+int mp3s_decode_streams(mp3s_ctx *c, const uint8_t *const *files, const size_t *lens, int n_files, int out_format,
+                        mp3s_buf **owner, mp3s_decoded *out)
+{
+    return decode_streams_impl(c, files, lens, n_files, out_format, 0, owner, out);
 }
 
 int mp3s_decode_stream(mp3s_ctx *c, const uint8_t *file, size_t len, int out_format, mp3s_buf **owner, mp3s_decoded *out)
@@ -879,21 +943,17 @@ int mp3s_message_reveal(const uint8_t *bits, size_t n_bits, mp3s_buf **owner, co
 int mp3s_decode_file(mp3s_ctx *c, const uint8_t *mp3, size_t len, mp3s_buf **owner, mp3s_file *out)
 {
     if (!c || !mp3 || !owner || !out) return fail(MP3S_E_ARG, "null pointer");
-    mp3s_buf *dec = nullptr;
+    // the PCM lands 64 bytes into its buffer; the 44-byte WAV header goes right in front of it: no second copy
+    mp3s_buf *b = nullptr;
     mp3s_decoded d;
-    const int rc = mp3s_decode_stream(c, mp3, len, MP3S_PCM_I16, &dec, &d);
+    const int rc = decode_streams_impl(c, &mp3, &len, 1, MP3S_PCM_I16, 64, &b, &d);
     if (rc) return rc;
-    mp3s_buf *b = new mp3s_buf();
-    const size_t nb = (size_t)d.n_rows * d.nch * 2;
-    b->bytes.resize(44 + nb);
-    wav_header(d.n_rows, d.nch, d.sampling_rate, b->bytes.data());
-    std::memcpy(b->bytes.data() + 44, d.pcm, nb);
-    b->bits.assign(d.bits, d.bits + d.n_bits);
+    uint8_t *wav = const_cast<uint8_t *>(static_cast<const uint8_t *>(d.pcm)) - 44;
+    wav_header(d.n_rows, d.nch, d.sampling_rate, wav);
     std::memset(out, 0, sizeof *out);
-    out->data = b->bytes.data(); out->len = b->bytes.size();
+    out->data = wav; out->len = 44 + (size_t)d.n_rows * d.nch * 2;
     out->kbps = d.bit_rate / 1000; out->sampling_rate = d.sampling_rate; out->channels = d.nch; out->n_frames = d.n_frames;
-    out->n_bits = d.n_bits; out->bits = b->bits.data();
-    mp3s_buf_free(dec);
+    out->n_bits = d.n_bits; out->bits = d.bits;
     *owner = b;
     return MP3S_OK;
 }
