@@ -83,6 +83,13 @@ public:
     {
         if (bytes <= cap_) return true;
         release();
+        if (bytes > kMaxPinned) {   // hours of audio in one call: pinning gigabytes costs seconds, ordinary memory then
+            p_ = (uint8_t *)std::malloc(bytes);
+            if (!p_) return false;
+            cap_ = bytes; pinned_ = false;
+            return true;
+        }
+        pinned_ = true;
         {
             std::lock_guard<std::mutex> g(mu());
             auto &fl = free_list();
@@ -103,11 +110,12 @@ private:
     void release()
     {
         if (!p_) return;
+        if (!pinned_) { std::free(p_); p_ = nullptr; cap_ = 0; return; }
         std::lock_guard<std::mutex> g(mu());
         auto &fl = free_list();
         size_t held = 0;
         for (auto &e : fl) held += e.second;
-        if (fl.size() < 4 && held + cap_ <= ((size_t)1 << 30)) fl.emplace_back(p_, cap_);
+        if (fl.size() < 4 && held + cap_ <= kMaxPinned) fl.emplace_back(p_, cap_);
         else hipHostFree(p_);
         p_ = nullptr; cap_ = 0;
     }
@@ -117,8 +125,10 @@ private:
         static auto *v = new std::vector<std::pair<uint8_t *, size_t>>();
         return *v;
     }
+    static constexpr size_t kMaxPinned = (size_t)1 << 30;
     uint8_t *p_ = nullptr;
     size_t cap_ = 0;
+    bool pinned_ = true;
 };
 
 struct mp3s_multi;
