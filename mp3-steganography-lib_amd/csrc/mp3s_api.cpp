@@ -700,7 +700,7 @@ int mp3s_decode_stream(mp3s_ctx *c, const uint8_t *file, size_t len, int out_for
 }
 
 // pcm_dev != nullptr: the int16 PCM is already in HBM (re-encode after a device decode) and pcm is ignored
-constexpr int kLongMessageBits = 256;
+constexpr int kLongMessageBits = 1024;   // below: a handful of small re-runs is cheaper than eight variant launches
 
 static int encode_core(mp3s_ctx *c, const int16_t *pcm, const int16_t *pcm_dev, int64_t n_samples_per_ch, int nch, int samplerate,
                        int bitrate_kbps, const uint8_t *hide_bits, int n_hide, mp3s_buf **owner, mp3s_encoded *out)

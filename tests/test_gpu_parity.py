@@ -313,14 +313,14 @@ def test_many_seeded_streams_across_chunk_boundaries(ctx, mlib, orc):
 
 # ------------------------------------------------------------------------------------------------ long messages
 def test_long_messages_take_the_variant_path(ctx, mlib, orc):
-    """messages above 256 bits: the rate loop runs once per 3-bit pattern and the cursor walk picks each unit's pattern
+    """messages above 1024 bits: the rate loop runs once per 3-bit pattern and the cursor walk picks each unit's pattern
     (mp3s_api.cpp encode_core).  Lengths around the threshold, ending mid-stream (the units at the message end fall back
     to the exact re-run), ending on every offset inside a unit, and longer than the stream can hold."""
     from synth_pcm import synth_pcm
     pcm = synth_pcm(700, seed=77)
     pcm[300 * 1152:330 * 1152] = 0                                   # silent units: no tables, stale addresses (E7)
     rng = np.random.default_rng(3)
-    for nbits in (256, 257, 258, 259, 300, 1001, 3203, 6000, 24040):
+    for nbits in (300, 1001, 1024, 1025, 1026, 1027, 3203, 6000, 24040):
         msg = rng.integers(0, 2, size=nbits).astype(np.uint8)
         r = ctx.encode_pcm(pcm, 44100, 128, msg)
         o = orc.encode(pcm, 44100, 128, msg)
