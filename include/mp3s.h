@@ -201,7 +201,7 @@ typedef struct {
 } mp3s_frame_side; /* 104 bytes */
 
 /* replaces: __unpack_scale_fac + __unpack_samples for every granule*channel of the batch -- reference
- * decoder/Frame.py:365-559 (linear code-book search there, table + trie here; same prefix codes, same quirks D1/D2).
+ * decoder/Frame.py:365-559 (linear code-book search there, two-level tables here; same prefix codes, same quirks D1/D2).
  * blob: main data of all frames (reservoir already gathered), each frame 4-byte aligned and followed by >= 8 zero
  * bytes; is / si as consumed by mp3s_decode_transform_dev; status: int32, OR of MP3S_HS_* on malformed input.
  * Not bit-exact for streams whose scalefactors are inherited across frames (mixed blocks, scfsi after a short

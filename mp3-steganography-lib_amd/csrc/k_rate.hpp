@@ -38,7 +38,7 @@ __device__ __forceinline__ uint32_t wave_add_u32(uint32_t v)
 // encoder/util.py:130-133 mulr for non-negative a: (a*b + 2^31) >> 32
 __device__ __forceinline__ uint32_t mulr_u(uint32_t a, uint32_t b) { return (uint32_t)(((uint64_t)a * b + 0x80000000ull) >> 32); }   // one v_mad_u64_u32
 
-constexpr int RL_WAVES = 4;   // 5 waves share one copy of the lookup tables: 35 KB LDS -> 4 workgroups = 20 waves per CU
+constexpr int RL_WAVES = 4;   // 4 waves share one copy of the lookup tables: 33 KB LDS -> 4 workgroups = 16 waves per CU
 constexpr int RL_NP = 5;   // pair slots per lane (the 5th only for lanes < 32)
 
 struct RlTables {
