@@ -36,6 +36,12 @@ class Encoder:
 
         :return: True if the message is too long for this file (it has been trimmed).
         """
+        if not quiet:
+            # what MP3Encoder.print_info (reference MP3_Encoder.py:581-594) reports for an MPEG-1 file of this encoder
+            w = self.__wav_file
+            print(f"MPEG-I layer III, {'mono' if w.num_of_channels == 1 else 'stereo'} Psychoacoustic Model: Shine")
+            print(f"Bitrate: {w.bitrate} kbps De-emphasis: none\tOriginal\t")
+            print(f"Encoding \"{w.file_path}\" to \"{w.file_path[:-3]}mp3\"\n")
         hide = np.frombuffer(self.__hide_str.encode("ascii"), dtype=np.uint8) - ord("0") if self.__hide_str else None
         try:
             res = _lib.default_context().encode_file(self.__wav_file.data, self.__wav_file.bitrate, hide)

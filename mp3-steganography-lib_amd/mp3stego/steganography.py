@@ -1,118 +1,119 @@
-"""`Steganography` facade with the reference's surface, messages and file side effects
-(reference mp3stego/steganography.py:10-182)."""
+"""The `Steganography` facade of the drop-in package.
+
+Public surface, console texts, `sys.exit` messages and file side effects (the temporary WAV next to the input that is
+written and removed again) are the reference's (mp3stego/steganography.py:10-182); the work is done by `Decoder` and
+`Encoder`, i.e. by libmp3s_hip.so.  Organised around three private steps -- mp3 -> temporary wav, wav -> mp3, drop
+the wav -- that the five public operations combine.
+"""
+import contextlib
 import os
 import sys
 
-from mp3stego import Decoder
-from mp3stego import Encoder
+from mp3stego.decoder.decoder import Decoder
+from mp3stego.encoder.encoder import Encoder
+
+_RULE = "#" * 18
 
 
 def str_to_binary_str(string: str) -> str:
-    """UTF-8 bytes of `string` as a string of bits, MSB first (reference steganography.py:10-24)."""
-    return "".join(format(b, "08b") for b in string.encode('utf-8'))
+    """'0'/'1' text of the UTF-8 bytes of `string`, most significant bit first."""
+    return "".join(f"{byte:08b}" for byte in string.encode("utf-8"))
+
+
+def _must_exist(path: str):
+    if not os.path.exists(path):
+        sys.exit(f"File {path} not found.")
+
+
+def _ends(path: str, ext: str) -> bool:
+    return path[-4:] == ext
 
 
 class Steganography:
     """
-    Encode and decode mp3/wav files, hide messages in mp3 files, reveal them and clear them.
+    Encode / decode between wav and mp3, hide a message in an mp3 file, reveal it, clear it.
 
-    :param quiet: if False, prints information about the processes and the files.
+    :param quiet: False prints what is going on.
     """
 
     def __init__(self, quiet: bool = True):
         self.quiet = quiet
-        self.__encoder = None
-        self.__decoder = None
-        self.__bitrate = 0
+        self._kbps = 0            # bitrate of the mp3 decoded last: what hide / clear re-encode at
+        self._decoder = None
 
-    def __encode(self, wav_file_path, output_file_path, bitrate=320, quiet=True, hide=False, massage=""):
-        binary_str = ""
-        if hide:
-            massage = str(len(massage)) + "#" + massage   # character count, UTF-8 payload
-            binary_str = str_to_binary_str(massage)
-        self.__encoder = Encoder(wav_file_path, output_file_path, bitrate=bitrate, hide_str=binary_str)
-        return self.__encoder.encode(quiet=quiet)
+    # ---------------------------------------------------------------- console
+    @contextlib.contextmanager
+    def _banner(self, start: str, done: str):
+        if not self.quiet:
+            print(f"\n{_RULE}\n{start}")
+        yield
+        if not self.quiet:
+            print(f"\n{done}\n{_RULE}")
 
-    def __decode(self, input_file_path, wav_file_path, quiet=True, reveal=False, txt_file_path=""):
-        self.__decoder = Decoder(input_file_path, wav_file_path)
-        self.__bitrate = self.__decoder.decode(quiet, reveal=reveal, txt_file_path=txt_file_path)
+    # ---------------------------------------------------------------- the three steps
+    @staticmethod
+    def _wav_beside(mp3_path: str, wav_path: str = "") -> str:
+        """argument checks of every operation that reads an mp3; returns the wav path to use"""
+        _must_exist(mp3_path)
+        wav_path = wav_path or mp3_path[:-4] + ".wav"
+        if not (_ends(mp3_path, ".mp3") and _ends(wav_path, ".wav")):
+            sys.exit("input_file_path must be mp3 file, wav_file_path must be wav file.")
+        return wav_path
 
-    def __delete_wav_file(self, quiet=True):
-        self.__decoder.delete_wav_file()
-        if not quiet:
+    def _to_wav(self, mp3_path: str, wav_path: str, reveal_into: str = ""):
+        self._decoder = Decoder(mp3_path, wav_path)
+        self._kbps = self._decoder.decode(self.quiet, reveal=bool(reveal_into), txt_file_path=reveal_into)
+
+    def _to_mp3(self, wav_path: str, mp3_path: str, kbps: int, message=None) -> bool:
+        _must_exist(wav_path)
+        if not (_ends(mp3_path, ".mp3") and _ends(wav_path, ".wav")):
+            sys.exit("wav_file_path must be wav file, output_file_path must be mp3 file.")
+        payload = ""
+        if message is not None:
+            # "<number of characters>#<message>": the count is in characters, the payload in UTF-8 bytes
+            payload = str_to_binary_str(f"{len(message)}#{message}")
+        return Encoder(wav_path, mp3_path, bitrate=kbps, hide_str=payload).encode(quiet=self.quiet)
+
+    def _drop_wav(self):
+        self._decoder.delete_wav_file()
+        if not self.quiet:
             print("Wav file has been deleted.")
 
-    @staticmethod
-    def __file_existence(file):
-        if not os.path.exists(file):
-            sys.exit(f'File {file} not found.')
-
-    def __check_for_decoder(self, input_file_path, wav_file_path=""):
-        self.__file_existence(input_file_path)
-        if wav_file_path == '':
-            wav_file_path = input_file_path[:-4] + ".wav"
-        if input_file_path[-4:] != '.mp3' or wav_file_path[-4:] != '.wav':
-            sys.exit("input_file_path must be mp3 file, wav_file_path must be wav file.")
-        return wav_file_path
-
-    def __check_for_encoder(self, wav_file_path, output_file_path):
-        self.__file_existence(wav_file_path)
-        if output_file_path[-4:] != '.mp3' or wav_file_path[-4:] != '.wav':
-            sys.exit("wav_file_path must be wav file, output_file_path must be mp3 file.")
-
+    # ---------------------------------------------------------------- public operations
     def encode_wav_to_mp3(self, wav_file_path: str, output_file_path: str, bitrate: int = 320):
-        """Encode a wav file into an mp3 file."""
-        if not self.quiet:
-            print(f"\n##################\nStart Encoding {wav_file_path} to  {output_file_path}.")
-        self.__check_for_encoder(wav_file_path, output_file_path)
-        self.__encode(wav_file_path, output_file_path, hide=False, bitrate=bitrate, quiet=self.quiet)
-        if not self.quiet:
-            print("\nFinished Encoding.\n##################")
+        """wav file -> mp3 file at `bitrate` kbps."""
+        with self._banner(f"Start Encoding {wav_file_path} to  {output_file_path}.", "Finished Encoding."):
+            self._to_mp3(wav_file_path, output_file_path, bitrate)
 
     def decode_mp3_to_wav(self, input_file_path: str, wav_file_path: str = "") -> int:
-        """Decode an mp3 file into a wav file; returns the bitrate (kbps)."""
-        if not self.quiet:
-            print(f"\n##################\nStart Decoding {input_file_path} to  {wav_file_path}.")
-        wav_file_path = self.__check_for_decoder(input_file_path, wav_file_path)
-        self.__decode(input_file_path, wav_file_path, reveal=False, quiet=self.quiet)
-        if not self.quiet:
-            print("\nFinished Decoding.\n##################")
-        return self.__bitrate
+        """mp3 file -> wav file (next to the input unless named); returns the stream's bitrate in kbps."""
+        with self._banner(f"Start Decoding {input_file_path} to  {wav_file_path}.", "Finished Decoding."):
+            self._to_wav(input_file_path, self._wav_beside(input_file_path, wav_file_path))
+        return self._kbps
 
     def reveal_massage(self, input_file_path: str, txt_file_path: str):
-        """Write the string hidden in an mp3 file into a txt file."""
-        if not self.quiet:
-            print(f"\n##################\nStart Revealing hidden message in {input_file_path} to  {txt_file_path}.")
-        wav_file_path = self.__check_for_decoder(input_file_path, "")
-        if txt_file_path[-4:] != '.txt':
-            sys.exit("txt_file_path must be txt file.")
-        self.__decode(input_file_path, wav_file_path, reveal=True, quiet=self.quiet, txt_file_path=txt_file_path)
-        self.__delete_wav_file(quiet=self.quiet)
-        if not self.quiet:
-            print("\nFinished Revealing.\n##################")
+        """write the message hidden in the mp3 file into the txt file."""
+        with self._banner(f"Start Revealing hidden message in {input_file_path} to  {txt_file_path}.", "Finished Revealing."):
+            wav = self._wav_beside(input_file_path)
+            if not _ends(txt_file_path, ".txt"):
+                sys.exit("txt_file_path must be txt file.")
+            self._to_wav(input_file_path, wav, reveal_into=txt_file_path)
+            self._drop_wav()
 
     def hide_message(self, input_file_path: str, output_file_path: str, message: str) -> bool:
-        """Create output_file_path = input mp3 with `message` hidden in it; True if the message was trimmed."""
-        if not self.quiet:
-            print(f"\n##################\nStart Hiding {message} in {output_file_path}.")
-        wav_file_path = self.__check_for_decoder(input_file_path, "")
-        self.__decode(input_file_path, wav_file_path, reveal=False, quiet=self.quiet)
-        self.__check_for_encoder(wav_file_path, output_file_path)
-        too_long = self.__encode(wav_file_path, output_file_path, hide=True, bitrate=self.__bitrate,
-                                 quiet=self.quiet, massage=message)
-        self.__delete_wav_file(quiet=self.quiet)
-        if not self.quiet:
-            print("\nFinished Hiding.\n##################")
-        return too_long
+        """output = input re-encoded with `message` in its Huffman table choices; True if it had to be cut short."""
+        with self._banner(f"Start Hiding {message} in {output_file_path}.", "Finished Hiding."):
+            cut = self._recode(input_file_path, output_file_path, message)
+        return cut
 
     def clear_file(self, input_file_path: str, output_file_path: str):
-        """Create output_file_path = input mp3 re-encoded without any hidden string."""
-        if not self.quiet:
-            print(f"\n##################\nStart Cleaning {input_file_path} into {output_file_path}.")
-        wav_file_path = self.__check_for_decoder(input_file_path, "")
-        self.__decode(input_file_path, wav_file_path, reveal=False, quiet=self.quiet)
-        self.__check_for_encoder(wav_file_path, output_file_path)
-        self.__encode(wav_file_path, output_file_path, hide=False, bitrate=self.__bitrate, quiet=self.quiet)
-        self.__delete_wav_file(quiet=self.quiet)
-        if not self.quiet:
-            print("\nFinished Cleaning.\n##################")
+        """output = input re-encoded with nothing hidden."""
+        with self._banner(f"Start Cleaning {input_file_path} into {output_file_path}.", "Finished Cleaning."):
+            self._recode(input_file_path, output_file_path, None)
+
+    def _recode(self, mp3_in: str, mp3_out: str, message) -> bool:
+        wav = self._wav_beside(mp3_in)
+        self._to_wav(mp3_in, wav)
+        cut = self._to_mp3(wav, mp3_out, self._kbps, message)
+        self._drop_wav()
+        return cut

@@ -1,5 +1,9 @@
+"""Helper the reference package exports beside its classes (reference mp3stego/utils.py); nothing here uses it."""
+
+_U32_MASK = (1 << 32) - 1
+
+
 def safe_uint32(value):
-    """Same helper the reference exports (mp3stego/utils.py:1-6): wrap negative ints into uint32."""
-    if isinstance(value, int) and value < 0:
-        return value & 0xFFFFFFFF
-    return value
+    """Negative Python ints come back as the uint32 with the same low 32 bits; everything else is returned as is."""
+    negative_int = isinstance(value, int) and value < 0
+    return (value & _U32_MASK) if negative_int else value

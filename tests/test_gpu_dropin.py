@@ -70,3 +70,26 @@ def test_facade_errors(work):
     assert str(e.value) == "Bad WAVE file."
     with pytest.raises(SystemExit):
         Decoder(str(work / "nope.mp3"), str(work / "o.wav"))
+
+
+def test_console_texts_when_not_quiet(work, capsys):
+    """quiet=False prints the reference's banners (steganography.py:92-182) around each operation"""
+    from mp3stego import Steganography
+    from mp3stego.utils import safe_uint32
+    st = Steganography(quiet=False)
+    mp3, wav = str(work / "test.mp3"), str(work / "o.wav")
+    st.decode_mp3_to_wav(mp3, wav)
+    out = capsys.readouterr().out
+    assert out.startswith(f"\n##################\nStart Decoding {mp3} to  {wav}.\n")
+    assert "Parsed 36 frames in" in out and f"Wav file created on {wav}" in out
+    assert out.endswith("\nFinished Decoding.\n##################\n")
+    st.hide_message(mp3, str(work / "h.mp3"), "ddd")
+    out = capsys.readouterr().out
+    assert out.startswith(f"\n##################\nStart Hiding ddd in {work / 'h.mp3'}.\n")
+    assert "Wav file has been deleted." in out and out.endswith("\nFinished Hiding.\n##################\n")
+    st.clear_file(str(work / "h.mp3"), str(work / "c.mp3"))
+    assert capsys.readouterr().out.startswith(f"\n##################\nStart Cleaning {work / 'h.mp3'} into {work / 'c.mp3'}.\n")
+    with pytest.raises(SystemExit):
+        st.reveal_massage(str(work / "c.mp3"), str(work / "r.doc"))           # no closing banner after an exit
+    assert "Finished" not in capsys.readouterr().out
+    assert safe_uint32(-1) == 0xFFFFFFFF and safe_uint32(5) == 5 and safe_uint32(-1.5) == -1.5
