@@ -235,7 +235,8 @@ def main():
     value = n * world / max_step
 
     # ---------------------------------------------------------------- roofline of the dominant kernel
-    _ = ctx.decode_stream(enc0["mp3"], _lib.MP3S_PCM_I16)          # warm: the page-locked result block is cached after the first call
+    _ = ctx.decode_stream(enc0["mp3"], _lib.MP3S_PCM_I16)          # warm: the page-locked result block is cached ...
+    del _                                                          # ... once the first result has been released
     t_dec0 = time.time()
     _ = ctx.decode_stream(enc0["mp3"], _lib.MP3S_PCM_I16)
     t_dec_stream = time.time() - t_dec0
