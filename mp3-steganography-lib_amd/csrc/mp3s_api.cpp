@@ -650,7 +650,7 @@ static int front_end(const uint8_t *file, size_t len, ParsedStream &p, ScannedSt
 {
     int rc = parse_stream(file, len, p, &sc);
     if (!rc && !sc.gpu_ok) rc = parse_stream(file, len, p, nullptr);
-    if (!rc && p.n_frames <= 0) rc = MP3S_E_MALFORMED;
+    // no sync where the stream should start: the reference parses nothing and writes an empty WAV (MP3_Parser.py:37-46)
     return rc;
 }
 
@@ -670,7 +670,7 @@ static int decode_streams_impl(mp3s_ctx *c, const uint8_t *const *files, const s
         m.files[i] = {files[i], lens[i]};
         const int rc = front_end(files[i], lens[i], m.parsed[i], m.scanned[i]);
         if (rc) { delete b; return fail(rc, "file %d: malformed or unsupported MP3 stream", i); }
-        group[m.parsed[i].nch].push_back(i);
+        if (m.parsed[i].n_frames > 0) group[m.parsed[i].nch].push_back(i);
     }
     for (int nch = 1; nch <= 2; nch++)
         if (!group[nch].empty()) {
@@ -927,7 +927,7 @@ int mp3s_wav_parse(const uint8_t *file, size_t len, int bitrate_kbps, mp3s_wav_i
 
 int mp3s_wav_header(int64_t n_rows, int nch, int rate, uint8_t *out44)
 {
-    if (!out44 || n_rows < 0 || nch < 1 || nch > 2 || rate <= 0) return fail(MP3S_E_ARG, "bad argument");
+    if (!out44 || n_rows < 0 || nch < 1 || nch > 2 || rate < 0) return fail(MP3S_E_ARG, "bad argument");
     wav_header(n_rows, nch, rate, out44);
     return MP3S_OK;
 }
@@ -958,10 +958,17 @@ int mp3s_decode_file(mp3s_ctx *c, const uint8_t *mp3, size_t len, mp3s_buf **own
     mp3s_decoded d;
     const int rc = decode_streams_impl(c, &mp3, &len, 1, MP3S_PCM_I16, 64, &b, &d);
     if (rc) return rc;
-    uint8_t *wav = const_cast<uint8_t *>(static_cast<const uint8_t *>(d.pcm)) - 44;
-    wav_header(d.n_rows, d.nch, d.sampling_rate, wav);
+    uint8_t *wav;
+    if (d.n_rows == 0) {   // nothing decoded: what scipy writes for an empty 1-d array at the header object's initial rate 0
+        b->bytes.assign(44, 0);
+        wav = b->bytes.data();
+        wav_header(0, 1, d.sampling_rate, wav);
+    } else {
+        wav = const_cast<uint8_t *>(static_cast<const uint8_t *>(d.pcm)) - 44;
+        wav_header(d.n_rows, d.nch, d.sampling_rate, wav);
+    }
     std::memset(out, 0, sizeof *out);
-    out->data = wav; out->len = 44 + (size_t)d.n_rows * d.nch * 2;
+    out->data = wav; out->len = 44 + (size_t)d.n_rows * (size_t)d.nch * 2;
     out->kbps = d.bit_rate / 1000; out->sampling_rate = d.sampling_rate; out->channels = d.nch; out->n_frames = d.n_frames;
     out->n_bits = d.n_bits; out->bits = d.bits;
     *owner = b;
@@ -1011,6 +1018,7 @@ static int reencode(mp3s_ctx *c, const uint8_t *mp3, size_t len, const uint8_t *
         return fail(MP3S_E_EXIT, "Unsupported sampling frequency.");
     if (stream_params(p.sampling_rate, kbps, &sri, &bri, &whole)) return fail(MP3S_E_EXIT, "Unsupported bitrate configuration.");
     if (p.nch != 2) return fail(MP3S_E_UNSUPPORTED, "mono input: the reference encoder indexes the sample buffer out of bounds");
+    if (p.n_frames <= 0) return fail(MP3S_E_UNSUPPORTED, "no frame in the stream");
     const int64_t rows_frames = (int64_t)p.n_frames + (p.dup_last_frame ? 1 : 0);
     if (hipSetDevice(c->device) != hipSuccess) return fail(MP3S_E_HIP, "hipSetDevice failed");
     void *d_keep = c->grab(7, (size_t)rows_frames * 2304 * 2);
@@ -1043,7 +1051,7 @@ int mp3s_reveal_message(const uint8_t *mp3, size_t len, mp3s_buf **owner, mp3s_f
     if (!mp3 || !owner || !out) return fail(MP3S_E_ARG, "null pointer");
     mp3s_buf *b = new mp3s_buf();
     const int rc = parse_stream(mp3, len, b->parsed, &b->scanned);
-    if (rc || b->parsed.n_frames <= 0) { delete b; return fail(rc ? rc : MP3S_E_MALFORMED, "malformed or unsupported MP3 stream"); }
+    if (rc) { delete b; return fail(rc, "malformed or unsupported MP3 stream"); }
     message_reveal(b->parsed.bits.data(), b->parsed.bits.size(), b->bytes);
     std::memset(out, 0, sizeof *out);
     out->data = b->bytes.data(); out->len = b->bytes.size();

@@ -176,7 +176,7 @@ int parse_stream(const uint8_t *file, size_t flen_, ParsedStream &out, ScannedSt
         for (int i = 0; i < 4; i++) size = (size << 7) + file[6 + i];
         offset = size + ((file[5] >> 4) & 1 ? 20 : 10);
     }
-    if (flen - offset < 4) return MP3S_E_MALFORMED;
+    if (flen - offset < 2) return MP3S_E_MALFORMED;   // the reference indexes buffer[0] and buffer[1] (MP3_Parser.py:37)
     Header hd;
     SideInfo si;
     double prev_frame_size[9] = {0};
@@ -198,6 +198,7 @@ int parse_stream(const uint8_t *file, size_t flen_, ParsedStream &out, ScannedSt
     bool valid = false;
     if (buffer[0] == 0xFF && buffer[1] >= 0xE0) {
         valid = true;
+        if (flen - offset < 4) return MP3S_E_MALFORMED;   // a sync with no header behind it: IndexError in the reference
         int rc = parse_header(hd, buffer); if (rc) return rc;
         rc = set_frame_size(); if (rc) return rc;   // D11
     }

@@ -133,6 +133,10 @@ def test_many_streams_rejects_a_malformed_member(ctx, mlib, corpus):
     g, names = corpus
     good = g[names[0] + "__mp3"].tobytes()
     with pytest.raises(mlib.Mp3sError) as e:
-        ctx.decode_streams([good, b"\x00" * 64, good])
+        ctx.decode_streams([good, b"\xff\xfb\x90", good])              # a sync with no header behind it
     assert "file 1" in str(e.value)
     assert ctx.decode_streams([]) == []
+    # no sync where the stream should start: the reference parses nothing and writes an empty WAV; here: an empty member
+    out = ctx.decode_streams([good, b"\x00" * 64, good])
+    assert out[1]["n_frames"] == 0 and out[1]["pcm"].size == 0 and out[1]["bit_rate"] == 0
+    assert np.array_equal(out[0]["pcm"], out[2]["pcm"]) and out[0]["n_frames"] > 0

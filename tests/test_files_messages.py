@@ -154,8 +154,10 @@ def test_reveal_message_needs_no_device(mlib, golden_dir):
     r = mlib.reveal_message(data)
     assert r["data"] == py_reveal(mlib.parse_stream(data)["bits"]) and r["n_frames"] == 36
     with pytest.raises(mlib.Mp3sError) as e:
-        mlib.reveal_message(b"\x00" * 500)
+        mlib.reveal_message(b"\xff\xfb")                                 # a sync and nothing behind it
     assert e.value.code == mlib.E_MALFORMED
+    r = mlib.reveal_message(b"\x00" * 500)                              # no sync at all: nothing parsed, nothing hidden
+    assert r["data"] == b"" and r["n_frames"] == 0 and r["kbps"] == 0
 
 
 # ------------------------------------------------------------------------------------------------ GPU: whole files

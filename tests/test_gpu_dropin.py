@@ -93,3 +93,25 @@ def test_console_texts_when_not_quiet(work, capsys):
         st.reveal_massage(str(work / "c.mp3"), str(work / "r.doc"))           # no closing banner after an exit
     assert "Finished" not in capsys.readouterr().out
     assert safe_uint32(-1) == 0xFFFFFFFF and safe_uint32(5) == 5 and safe_uint32(-1.5) == -1.5
+
+
+def test_a_file_that_does_not_start_with_a_frame(work):
+    """no sync at the expected position: the reference parses nothing, writes the WAV scipy makes of an empty array at
+    the header object's initial rate 0, and reports 0 kbps (MP3_Parser.py:37-46, 86-93); hiding then stops at the WAV
+    reader's sampling-rate check"""
+    import io
+    import numpy as np
+    from scipy.io import wavfile
+    from mp3stego import Steganography
+    junk = work / "junk.mp3"
+    junk.write_bytes(b"\x00" * 1000)
+    st = Steganography()
+    assert st.decode_mp3_to_wav(str(junk), str(work / "junk.wav")) == 0
+    ref = io.BytesIO()
+    wavfile.write(ref, 0, np.zeros(0, dtype=np.int16))
+    assert (work / "junk.wav").read_bytes() == ref.getvalue()
+    st.reveal_massage(str(junk), str(work / "junk.txt"))
+    assert (work / "junk.txt").read_bytes() == b""
+    with pytest.raises(SystemExit) as e:
+        st.hide_message(str(junk), str(work / "o.mp3"), "x")
+    assert str(e.value) == "Unsupported sampling frequency."

@@ -47,8 +47,15 @@ def test_parse_stream_synth_and_edge_cases(mlib, orc, golden_dir):
     p4 = mlib.parse_stream(data[:-100])
     o4 = orc.decode(data[:-100])
     assert p4["n_frames"] == o4["n_frames"] and np.array_equal(p4["is"], o4["is"])
-    with pytest.raises(mlib.Mp3sError):
-        mlib.parse_stream(b"\x00" * 3)
+    for tiny in (b"\x00", b"\xff\xfb", b"\xff\xfb\x90"):            # one byte; a sync with no header behind it
+        with pytest.raises(mlib.Mp3sError):
+            mlib.parse_stream(tiny)
+        assert orc.decode(tiny)["rc"] != 0
+    # no sync at the start: nothing is parsed (the reference then writes an empty WAV), not an error
+    for junk in (b"\x00" * 3, b"\x12\x34", b"\x00" * 5000):
+        pj = mlib.parse_stream(junk)
+        oj = orc.decode(junk)
+        assert oj["rc"] == 0 and pj["n_frames"] == oj["n_frames"] == 0 and len(pj["bits"]) == 0
 
 
 def test_rate_frames_and_format_stream(mlib, orc, golden_dir):
