@@ -125,6 +125,9 @@ int mp3s_timer_stop(mp3s_ctx *ctx, float *ms);
  * enc_pack (n >= MP3S_N_KERNELS) */
 #define MP3S_N_KERNELS 7
 int mp3s_profile_enable(mp3s_ctx *ctx, int on);
+/* An event pair costs a few microseconds of stream time per launch: restrict the timing to the kernels in `mask` (bit k =
+ * kernel k in the order above; all by default).  Takes effect with the next mp3s_profile_enable(ctx, 1). */
+int mp3s_profile_select(mp3s_ctx *ctx, unsigned mask);
 int mp3s_profile_collect(mp3s_ctx *ctx, double *total_ms, int64_t *launches, int n);
 
 /* ---------------------------------------------------------------- (ii) decode transform batch

@@ -291,6 +291,13 @@ int mp3s_profile_enable(mp3s_ctx *c, int on)
     return MP3S_OK;
 }
 
+int mp3s_profile_select(mp3s_ctx *c, unsigned mask)
+{
+    if (!c) return fail(MP3S_E_ARG, "ctx is null");
+    c->prof.mask = mask;
+    return MP3S_OK;
+}
+
 int mp3s_profile_collect(mp3s_ctx *c, double *total_ms, int64_t *launches, int n)
 {
     if (!c || !total_ms || !launches || n < K_COUNT) return fail(MP3S_E_ARG, "bad argument (need %d slots)", (int)K_COUNT);

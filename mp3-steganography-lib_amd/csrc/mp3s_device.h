@@ -19,6 +19,7 @@ struct Profiler {
     int kid[MAX_PAIRS];
     int n_pairs = 0, n_created = 0;
     bool enabled = false;
+    unsigned mask = ~0u;                      // bit k: kernel k gets an event pair
     double total_ms[K_COUNT] = {0};
     long count[K_COUNT] = {0};
     int begin(hipStream_t s, int k);          // returns pair index or -1

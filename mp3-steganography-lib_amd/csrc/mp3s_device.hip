@@ -22,7 +22,7 @@ namespace mp3s {
 
 int Profiler::begin(hipStream_t s, int k)
 {
-    if (!enabled || n_pairs >= MAX_PAIRS) return -1;
+    if (!enabled || !((mask >> k) & 1u) || n_pairs >= MAX_PAIRS) return -1;
     while (n_created < 2 * (n_pairs + 1)) {
         if (hipEventCreate(&ev[n_created]) != hipSuccess) return -1;
         n_created++;

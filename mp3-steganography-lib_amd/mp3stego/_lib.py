@@ -91,7 +91,7 @@ class File(C.Structure):
 # every symbol include/mp3s.h declares (tests/test_abi.py checks the library exports all of them)
 SYMBOLS = ["mp3s_ctx_create", "mp3s_ctx_destroy", "mp3s_ctx_wait", "mp3s_last_error", "mp3s_version", "mp3s_device_name", "mp3s_sync", "mp3s_debug_tables", "mp3s_debug_scfsi_energies",
            "mp3s_dev_alloc", "mp3s_dev_free", "mp3s_dev_upload", "mp3s_dev_download", "mp3s_dev_memset",
-           "mp3s_timer_start", "mp3s_timer_stop", "mp3s_profile_enable", "mp3s_profile_collect", "mp3s_decode_transform_dev", "mp3s_decode_transform",
+           "mp3s_timer_start", "mp3s_timer_stop", "mp3s_profile_enable", "mp3s_profile_select", "mp3s_profile_collect", "mp3s_decode_transform_dev", "mp3s_decode_transform",
            "mp3s_encode_transform_dev", "mp3s_encode_transform", "mp3s_rate_loop_dev", "mp3s_huffman_decode_dev", "mp3s_pack_frames_dev", "mp3s_scan_stream", "mp3s_buf_free",
            "mp3s_parse_stream", "mp3s_format_stream", "mp3s_rate_frames", "mp3s_decode_stream", "mp3s_decode_streams", "mp3s_encode_pcm",
            "mp3s_wav_parse", "mp3s_wav_header", "mp3s_message_frame", "mp3s_message_reveal", "mp3s_decode_file", "mp3s_encode_file",
@@ -134,6 +134,7 @@ def lib():
         L.mp3s_timer_start.argtypes = [vp]
         L.mp3s_timer_stop.argtypes = [vp, C.POINTER(C.c_float)]
         L.mp3s_profile_enable.argtypes = [vp, i32]
+        L.mp3s_profile_select.argtypes = [vp, C.c_uint]
         L.mp3s_profile_collect.argtypes = [vp, vp, vp, i32]
         L.mp3s_decode_transform_dev.argtypes = [vp, vp, vp, vp, i32, i32, i32, i32, vp]
         L.mp3s_decode_transform.argtypes = [vp, vp, vp, vp, i32, i32, i32, i32, vp]
@@ -269,6 +270,11 @@ class Context:
 
     def profile_enable(self, on=True):
         check(lib().mp3s_profile_enable(self.handle, 1 if on else 0))
+
+    def profile_select(self, kernels=None):
+        """time only the named kernels (None = all): every event pair costs stream time"""
+        mask = 0xffffffff if kernels is None else sum(1 << self.KERNELS.index(k) for k in kernels)
+        check(lib().mp3s_profile_select(self.handle, mask))
 
     def profile_collect(self):
         """{kernel: (total_ms, launches)} since profile_enable()"""
