@@ -63,6 +63,8 @@ struct DecShared {
     double pow2h[POW2H_N];
     double buf[DEC_A_WAVES][2][576];       // per wave: spectrum exchange for reorder / alias reduction
     uint32_t side[DEC_A_WAVES][2][18];     // per wave: the two 72-byte side records of the current granule
+    double exp2f[DEC_A_WAVES][2][64];      // per wave and channel: 2^(-exp2) per scalefactor slot of the current granule
+    double exp1f[DEC_A_WAVES][2][4];       // ... and 2^(exp1/4) per gain selector
 };
 
 // requantise .. alias/reorder of granule g for this lane's subband; v[18] = IMDCT input
@@ -92,25 +94,38 @@ __device__ __forceinline__ void dec_prepare(const DevTables &tab, DecShared &sh,
 #pragma unroll
         for (int k = 0; k < 5; k++) mw[k] = mp[k];
     }
-    // ---- requantise (Frame.py:210-215): ((sign * |is|^(4/3)) * 2^(exp1/4)) * 2^(-exp2)
+    // ---- the two exponent factors depend on the line only through its scalefactor band / window: 61 + 4 values per
+    //      granule and channel, worked out once by the wave (two slots per lane) instead of once per line
+    //      long slot s:  exp2 = mult * (sf_l[s] + preflag * pretab[s]);  short slot 22 + 13 w + s:  exp2 = mult * sf_s[w][s]
+    //      selector 0:   exp1 = gg - 210;  selector 1 + w:  exp1 = gg - 210 - 8 * sub_block_gain[w]
+    {
+        double *e2 = sh.exp2f[wave][ch], *e1 = sh.exp1f[wave][ch];
 #pragma unroll
-    for (int k = 0; k < 18; k++) {
-        const int x = (int)(int16_t)(xw[k >> 1] >> ((k & 1) * 16));
-        const int m = (int)((mw[k >> 2] >> ((k & 3) * 8)) & 0xff);
-        const int sfb = m & 31, win = (m >> 5) & 3;
-        const bool shp = (m & 0x80) != 0;
-        // short path: exp1 = gg-210-8*sbg[win], exp2 = mult*sf_s[win][sfb]; long: exp1 = gg-210,
-        // exp2 = mult*(sf_l[sfb] + preflag*pretab[sfb])
-        const int sf = gb[shp ? 30 + win * 13 + (sfb < 13 ? sfb : 12) : 8 + (sfb < 22 ? sfb : 21)] & 15;
-        const int e1 = gg - 210 - (shp ? 8 * (gb[5 + win] & 7) : 0);
-        const int pt = sfb < 11 ? 0 : (int)((0x2333221111ull >> ((sfb - 11) * 4)) & 15);   // pre_tab[11..20] = 1,1,1,1,2,2,3,3,3,2
-        int k2 = mult2 * (sf + (shp ? 0 : preflag * (sfb < 21 ? pt : 0)));
-        k2 = k2 < POW2H_N ? k2 : POW2H_N - 1;
-        int ax = x < 0 ? -x : x;
-        ax = ax < POW43_N ? ax : POW43_N - 1;
-        const double a = tab.pow43[ax];
-        const double sa = x < 0 ? -a : a;   // sign * a is exact
-        v[k] = (sa * sh.pow2q[e1 - POW2Q_MIN]) * sh.pow2h[k2];
+        for (int h = 0; h < 2; h++) {
+            const int slot = sb + 32 * h;
+            if (slot < 61) {
+                int k2;
+                if (slot < 22) {
+                    const int pt = slot < 11 || slot > 20 ? 0 : (int)((0x2333221111ull >> ((slot - 11) * 4)) & 15);   // pre_tab[11..20]
+                    k2 = mult2 * ((gb[8 + slot] & 15) + preflag * pt);
+                } else k2 = mult2 * (gb[30 + (slot - 22)] & 15);
+                e2[slot] = sh.pow2h[k2 < POW2H_N ? k2 : POW2H_N - 1];
+            }
+        }
+        if (sb < 4) e1[sb] = sh.pow2q[gg - 210 - (sb ? 8 * (gb[5 + sb - 1] & 7) : 0) - POW2Q_MIN];
+        __builtin_amdgcn_s_waitcnt(0xc07f);
+        __builtin_amdgcn_wave_barrier();
+        // ---- requantise (Frame.py:210-215): ((sign * |is|^(4/3)) * 2^(exp1/4)) * 2^(-exp2)
+#pragma unroll
+        for (int k = 0; k < 18; k++) {
+            const int x = (int)(int16_t)(xw[k >> 1] >> ((k & 1) * 16));
+            const int m = (int)((mw[k >> 2] >> ((k & 3) * 8)) & 0xff);
+            int ax = x < 0 ? -x : x;
+            ax = ax < POW43_N ? ax : POW43_N - 1;
+            const double a = tab.pow43[ax];
+            const double sa = x < 0 ? -a : a;   // sign * a is exact
+            v[k] = (sa * e1[m >> 6]) * e2[m & 63];
+        }
     }
     // ---- MS stereo (Frame.py:568-572): L = (M + S) / sqrt2, R = (M - S) / sqrt2
     if (ms && nch == 2) {

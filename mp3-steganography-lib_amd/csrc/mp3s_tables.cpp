@@ -72,7 +72,12 @@ void build_rq_map(int sr, int cse, uint8_t *map)
             if (sample == long_win[sfb + 1]) sfb += 1;
             sh = false;
         }
-        map[sample] = (uint8_t)((sh ? 0x80 : 0) | ((sh ? window : 0) << 5) | sfb);
+        // byte = gain selector << 6 | scalefactor slot: the requantiser reads exp1 per selector (0 = global gain, 1 + window =
+        // with that window's sub_block_gain) and exp2 per slot (0..21 = long sfb, 22 + 13 window + sfb = short) from two
+        // small per-granule tables; the clamps are those of the reference's array reads that can happen (sfb past the table
+        // end reads the last entry here, whose pre_tab is 0)
+        const int slot = sh ? 22 + 13 * window + (sfb < 13 ? sfb : 12) : (sfb < 22 ? sfb : 21);
+        map[sample] = (uint8_t)(((sh ? 1 + window : 0) << 6) | slot);
     }
 }
 

@@ -28,7 +28,8 @@ struct DevTables {
     double pow2q[POW2Q_N];         // pow(2, exp1/4)           Frame.py:212
     double pow2h[POW2H_N];         // pow(2, -(k*0.5))         Frame.py:213
     double sqrt2;
-    uint8_t rq_map[3][3][32][20];  // [sr][case][subband][18 lines + 2 pad]: five aligned dwords per lane
+    uint8_t rq_map[3][3][32][20];  // [sr][case][subband][18 lines + 2 pad]: five aligned dwords per lane;
+                                   // byte = gain selector << 6 | scalefactor slot (see build_rq_map)
     int16_t reorder_src[3][576];   // [sr][dst line] -> src line or -1 (zero)  Frame.py:574-602
     uint8_t pre_tab[24];
     // ---- encoder ----
