@@ -13,6 +13,7 @@
 // wrapping int32 adds -- integer sums are order independent, each product's floor is not, so every
 // product is floored on its own exactly as the reference does.
 #pragma once
+#include <type_traits>
 
 namespace mp3s {
 
@@ -65,6 +66,10 @@ __global__ __launch_bounds__(256, 4) void k_enc_analysis(
     int32_t y[64];
 #pragma unroll
     for (int i = 0; i < 64; i++) y[i] = 0;
+    // A stream that starts inside the wave's window (its first slots see zeros where the ring x was still empty) is rare:
+    // the usual case reads the tile without the per-row masks.
+    const bool starts_inside = __ballot(valid && (t - 15) < s0) != 0;
+    auto window_sums = [&](auto masked) {
 #pragma unroll 1
     for (int k = 0; k < 8; k++) {
         const i32x16 *ewv = reinterpret_cast<const i32x16 *>(c_tab.enwindow + 64 * k);
@@ -77,7 +82,7 @@ __global__ __launch_bounds__(256, 4) void k_enc_analysis(
 #pragma unroll
             for (int cb = 0; cb < 4; cb++) {
                 uint4 q = *reinterpret_cast<const uint4 *>(rp + cb * 8);
-                if (!in_stream) q = make_uint4(0, 0, 0, 0);
+                if (decltype(masked)::value && !in_stream) q = make_uint4(0, 0, 0, 0);
                 const uint32_t d[4] = {q.x, q.y, q.z, q.w};
 #pragma unroll
                 for (int e = 0; e < 4; e++) {
@@ -91,6 +96,8 @@ __global__ __launch_bounds__(256, 4) void k_enc_analysis(
             }
         }
     }
+    };
+    if (starts_inside) window_sums(std::true_type{}); else window_sums(std::false_type{});
     // ---- s[sb] = sum_j mul(fl[sb][j], y[j])   (MP3_Encoder.py:358-368); four bands per pass for ILP.
     // Results are staged in the wave's LDS region as [slot][band] (33-dword rows) and written out as rows.
     const bool odd_slot = (t & 1) != 0;      // slot-in-granule parity == slot parity (18 is even)
