@@ -360,15 +360,15 @@ __global__ __launch_bounds__(RL_WAVES * 64, 4) void k_rate_loop(
             for (int i = b0; i < b1; i++) s += (uint32_t)esq[i];
             temp = (int32_t)s;
         } else if (lane == 21) temp = (int32_t)etot;
+        // en = int32(log(temp * 4.768371584e-7) / 0.69314718): tabulated with the host's libm per octave of temp (value at
+        // 2^k, and the argument from which on it is one more), so no device log and nothing to guard
         int32_t en = 0;
-        bool guard = false;
-        if (lane < 22 && temp) {
-            const double q = log((double)temp * 4.768371584e-7) / 0.69314718;
-            en = (int32_t)q;
-            guard = fabs(q - rint(q)) < 1e-9;
+        if (lane < 22 && temp > 0) {
+            const int k = 31 - __builtin_clz((unsigned)temp);
+            en = c_tab.en_base[k] + (temp >= c_tab.en_step[k] ? 1 : 0);
         }
         if (lane < 22) en_out[(long)u * 22 + lane] = en;
-        const bool any_guard = __ballot(guard) != 0;
+        const bool any_guard = false;
 
         RlState st;
         st.big_values = st.count1 = st.c1sel = st.r0c = st.r1c = 0;

@@ -205,6 +205,21 @@ void build()
         set_huff(16 + k, 16, 16, lb16[k], (1 << lb16[k]) - 1, ISO_HCOD_16, ISO_HLEN_16);
         set_huff(24 + k, 16, 16, lb24[k], (1 << lb24[k]) - 1, ISO_HCOD_24, ISO_HLEN_24);
     }
+    {
+        // the scfsi band energies take a log of an integer sum: one value per octave and at most one step inside it
+        auto en_of = [](int64_t e) { return (int32_t)(std::log((double)e * 4.768371584e-7) / 0.69314718); };
+        for (int k = 0; k < 32; k++) { T.en_base[k] = 0; T.en_step[k] = 0x7fffffff; }
+        for (int k = 0; k < 31; k++) {
+            const int64_t lo = (int64_t)1 << k, hi = ((int64_t)1 << (k + 1)) - 1;
+            T.en_base[k] = en_of(lo);
+            if (en_of(hi) == T.en_base[k]) continue;
+            if (en_of(hi) != T.en_base[k] + 1) abort();          // an octave moves the quotient by one
+            int64_t a = lo, b = hi;                                // en_of(a) == base, en_of(b) == base + 1
+            while (b - a > 1) { const int64_t m = (a + b) / 2; (en_of(m) == T.en_base[k] ? a : b) = m; }
+            T.en_step[k] = (int32_t)b;
+        }
+    }
+
     set_huff(32, 1, 16, 0, 0, ISO_HCOD_32, ISO_HLEN_32);
     set_huff(33, 1, 16, 0, 0, ISO_HCOD_33, ISO_HLEN_33);
     for (int i = 0; i < 256; i++) {

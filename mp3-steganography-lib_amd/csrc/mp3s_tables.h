@@ -41,6 +41,9 @@ struct DevTables {
     int32_t steptabi[128];
     uint16_t int2idx[10000];       // values <= 1000
     int32_t sfb_long[3][23];
+    // int32(log(e * 4.768371584e-7) / 0.69314718) of MP3_Encoder.py:841,855 as a step function of the integer e, tabulated
+    // per octave with the host's libm: value at e = 2^k, and the e inside [2^k, 2^(k+1)) from which on it is one more
+    int32_t en_base[32], en_step[32];
     int32_t subdv[23][2];
     uint32_t subdiv_lut[3][289];   // [sr][big_values] -> r0c | r1c<<4 | address1<<8 | address2<<18 (MP3_Encoder.py:998-1036)
     uint8_t hlen13[256], hlen15[256], hlen16[256], hlen24[256];

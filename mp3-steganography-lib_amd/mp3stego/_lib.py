@@ -514,7 +514,7 @@ DEV_TABLES_DTYPE = np.dtype([
     ("rq_map", "u1", (3, 3, 32, 20)), ("reorder_src", "<i2", (3, 576)), ("pre_tab", "u1", (24,)),
     ("enwindow", "<i4", (512,)), ("fl", "<i4", (32, 64)), ("cos_l", "<i4", (18, 36)), ("mdct_cs", "<i4", (8,)),
     ("mdct_ca", "<i4", (8,)), ("steptab", "<f8", (128,)), ("steptabi", "<i4", (128,)), ("int2idx", "<u2", (10000,)),
-    ("sfb_long", "<i4", (3, 23)), ("subdv", "<i4", (23, 2)), ("subdiv_lut", "<u4", (3, 289)), ("hlen13", "u1", (256,)), ("hlen15", "u1", (256,)),
+    ("sfb_long", "<i4", (3, 23)), ("en_base", "<i4", (32,)), ("en_step", "<i4", (32,)), ("subdv", "<i4", (23, 2)), ("subdiv_lut", "<u4", (3, 289)), ("hlen13", "u1", (256,)), ("hlen15", "u1", (256,)),
     ("hlen16", "u1", (256,)), ("hlen24", "u1", (256,)), ("hlen_c1a", "u1", (16,)), ("linbits", "u1", (32,)),
     ("linmax", "<i4", (32,)), ("transform", "u1", (32, 2)), ("huff_lut_id", "u1", (32,)), ("dec_max", "u1", (32,)),
     ("huff_fast", "<u2", (15, 1024)), ("huff_l2", "<u2", (1280,)), ("quad_fast", "<u2", (64,)),
