@@ -92,7 +92,7 @@ typedef struct {
 #define MP3S_RF_ACTIVE 1      /* xrmax != 0: outer loop ran */
 #define MP3S_RF_USED_ADDR_IN 2 /* the incoming address1/2/3 were read before being overwritten */
 #define MP3S_RF_STEP_RANGE 4  /* quantizer step left the table */
-#define MP3S_RF_LOG_GUARD 8   /* a log() landed within 1e-9 of an integer: host must recheck scfsi */
+#define MP3S_RF_LOG_GUARD 8   /* reserved: never set since the band energies come from a table built with the host's libm */
 
 /* ---------------------------------------------------------------- context */
 int mp3s_ctx_create(int device, mp3s_ctx **out);
@@ -108,7 +108,7 @@ int mp3s_ctx_wait(mp3s_ctx *ctx, mp3s_ctx *other);
 /* host copy of the constant tables uploaded to the device (struct DevTables of csrc/mp3s_tables.h), for tests */
 const void *mp3s_debug_tables(size_t *bytes);
 /* host (glibc) evaluation of the __calc_scfsi energies of one granule*channel: en[0..20] bands, en[21] total.
- * The kernel's device log is cross-checked against this; units flagged MP3S_RF_LOG_GUARD are recomputed with it. */
+ * The kernel's tabulated energies are cross-checked against this in the tests. */
 int mp3s_debug_scfsi_energies(const int32_t *xr576, int sr_idx, int32_t *en22);
 
 /* device memory owned by the caller through the context (for resident pipelines / benchmarks) */

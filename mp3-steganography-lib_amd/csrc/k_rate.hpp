@@ -8,8 +8,8 @@
 //   __bin_search_step_size :958-996, __inner_loop :1064-1095, quantize :373-415, calc_run_len :266-291,
 //   count1_bit_count :171-211, __subdivide :998-1036, __big_v_tab_select :1147-1168,
 //   __new_choose_table :1170-1264, count_bit :214-263, big_v_bit_count :294-318.
-// Integer work only (bit exact); the two float spots are quantize's ln >= 10000 path (correctly rounded
-// fp64 sqrt) and the scfsi log, which carries a guard flag so the host can recheck near-integer cases.
+// Integer work only (bit exact); the one float spot is quantize's ln >= 10000 path (correctly rounded fp64 sqrt).  The
+// scfsi log is a table built with the host's libm (DevTables::en_base / en_step).
 #pragma once
 
 namespace mp3s {
@@ -368,8 +368,6 @@ __global__ __launch_bounds__(RL_WAVES * 64, 4) void k_rate_loop(
             en = c_tab.en_base[k] + (temp >= c_tab.en_step[k] ? 1 : 0);
         }
         if (lane < 22) en_out[(long)u * 22 + lane] = en;
-        const bool any_guard = false;
-
         RlState st;
         st.big_values = st.count1 = st.c1sel = st.r0c = st.r1c = 0;
         st.a1 = state_in ? state_in[(long)u * 4 + 0] : 0;
@@ -381,7 +379,7 @@ __global__ __launch_bounds__(RL_WAVES * 64, 4) void k_rate_loop(
         int32_t ix[2 * RL_NP];
 #pragma unroll
         for (int e = 0; e < 2 * RL_NP; e++) ix[e] = 0;
-        int bits = 0, flags = any_guard ? MP3S_RF_LOG_GUARD : 0;
+        int bits = 0, flags = 0;
         bool err = false;
 
         if (xrmax) {

@@ -865,16 +865,6 @@ static int encode_core(mp3s_ctx *c, const int16_t *pcm, const int16_t *pcm_dev, 
     mp3s_buf *b = nullptr;
     if (!rc) {
         b = new mp3s_buf();
-        // a device log() that landed within 1e-9 of an integer is re-evaluated with glibc on the host
-        std::vector<int32_t> xr(576), en1(22);
-        for (int u = 0; u < units && !rc; u++)
-            if (gr[u].flags & MP3S_RF_LOG_GUARD) {
-                rc = mp3s_dev_download(c, xr.data(), (const int32_t *)d_mdct + (size_t)u * 576, 576 * 4);
-                if (!rc) {
-                    host_scfsi_energies(xr.data(), rf[0].sr_idx, en1.data());
-                    rc = mp3s_dev_upload(c, (int32_t *)d_en + (size_t)u * 22, en1.data(), 22 * 4);
-                }
-            }
         // ---- bit packing on the device: final GrInfo + frame offsets up, MP3 bytes + scfsi down
         std::vector<int32_t> padding(n);
         std::vector<uint32_t> off((size_t)n + 1, 0);
