@@ -32,7 +32,7 @@ __device__ __forceinline__ int pack_wave_sum(int v, bool on) { return (int)wave_
 __global__ __launch_bounds__(256) void k_enc_pack(
     const int16_t *__restrict__ ix, const mp3s_gr_out *__restrict__ gr, const int32_t *__restrict__ en, int n_frames,
     int sri, int bri, int whole_slots, const uint32_t *__restrict__ frame_off, const uint8_t *__restrict__ padding,
-    uint8_t *__restrict__ mp3, int32_t *__restrict__ scfsi_out, int32_t *__restrict__ status)
+    uint8_t *__restrict__ mp3, int32_t *__restrict__ scfsi_out, int32_t *__restrict__ status, int32_t *__restrict__ sync)
 {
     __shared__ uint32_t fb3[3][PACK_DW];   // frame images, rotating: written / being copied out / being cleared
     __shared__ uint32_t hc[4][256];
@@ -212,7 +212,8 @@ __global__ __launch_bounds__(256) void k_enc_pack(
     }
     // stuffing with ones up to part2_3_length (:1433-1446)
     const int p23 = e == 0 ? p23v[0] : (e == 1 ? p23v[1] : (e == 2 ? p23v[2] : p23v[3]));
-    if (huff_bits > p23 || bad) { if (lane == 0) atomicOr(status, bad ? MP3S_PS_BAD_TABLE : MP3S_PS_OVERFLOW); }
+    const bool any_bad = __ballot(bad != 0) != 0;
+    if (huff_bits > p23 || any_bad) { if (lane == 0) atomicOr(&sync[1], any_bad ? MP3S_PS_BAD_TABLE : MP3S_PS_OVERFLOW); }
     else
         for (uint32_t s = ustart + huff_bits + 32u * lane; s < ustart + (uint32_t)p23; s += 64u * 32u) {
             const uint32_t n = (ustart + p23 - s) < 32u ? (ustart + p23 - s) : 32u;
@@ -234,6 +235,16 @@ __global__ __launch_bounds__(256) void k_enc_pack(
     if ((int)threadIdx.x < nbytes - tail0) mp3[off + tail0 + threadIdx.x] = (uint8_t)byte_at(tail0 + threadIdx.x);
     rot = rot == 2 ? 0 : rot + 1;
     }   // frames
+    // The caller's status word is written once, by the workgroup that finishes last, from the error bits collected in the
+    // context's scratch pair sync[0] = finished groups, sync[1] = errors; that group also clears the pair for the next
+    // launch on this context.  No fill kernel in front of every launch: one dispatch (and its stream gap) less per step.
+    // (Only device-scope atomics touch the pair, so no cache write-back is needed: the barrier waits for this group's
+    // error atomics to be acknowledged before its arrival is counted.)
+    __syncthreads();
+    if (threadIdx.x == 0 && atomicAdd(&sync[0], 1) == (int)gridDim.x - 1) {
+        *status = atomicExch(&sync[1], 0);
+        atomicExch(&sync[0], 0);
+    }
 }
 
 }  // namespace mp3s

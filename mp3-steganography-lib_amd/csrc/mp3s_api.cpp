@@ -43,6 +43,7 @@ struct mp3s_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr, ev_order = nullptr;
+    int32_t *d_sync = nullptr;        // {finished workgroups, error bits} of the pack kernel in flight: self-clearing
     void *scratch = nullptr; size_t scratch_bytes = 0;
     Profiler prof;
     // device buffers of the stream pipelines, kept between calls (hipMalloc/hipFree cost more than a small file's work)
@@ -180,6 +181,10 @@ int mp3s_ctx_create(int device, mp3s_ctx **out)
         delete c;
         return fail(MP3S_E_NO_DEVICE, "stream/event creation failed");
     }
+    if (hipMalloc((void **)&c->d_sync, 16) != hipSuccess || hipMemsetAsync(c->d_sync, 0, 16, c->stream) != hipSuccess) {
+        delete c;
+        return fail(MP3S_E_NO_DEVICE, "device scratch allocation failed");
+    }
     const int rc = dev_upload_tables(c->stream);
     if (rc) {
         delete c;
@@ -196,6 +201,7 @@ void mp3s_ctx_destroy(mp3s_ctx *c)
     hipSetDevice(c->device);
     if (c->stream) hipStreamSynchronize(c->stream);
     if (c->scratch) hipFree(c->scratch);
+    if (c->d_sync) hipFree(c->d_sync);
     for (void *q : c->pool) if (q) hipFree(q);
     if (c->ev0) hipEventDestroy(c->ev0);
     if (c->ev1) hipEventDestroy(c->ev1);
@@ -450,7 +456,7 @@ int mp3s_pack_frames_dev(mp3s_ctx *c, const int16_t *d_ix, const mp3s_gr_out *d_
     if (n_frames <= 0 || stream_params(samplerate, bitrate_kbps, &sri, &bri, &whole))
         return fail(MP3S_E_UNSUPPORTED, "unsupported samplerate/bitrate %d/%d", samplerate, bitrate_kbps);
     const int e = launch_pack(c->stream, d_ix, d_gr, d_en, n_frames, sri, bri, whole, d_frame_off, d_padding, d_mp3, d_scfsi,
-                              d_status, &c->prof);
+                              d_status, c->d_sync, &c->prof);
     if (e) return fail(MP3S_E_HIP, "pack launch: %s", hipGetErrorString((hipError_t)e));
     return MP3S_OK;
 }

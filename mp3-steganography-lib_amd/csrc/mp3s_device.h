@@ -51,6 +51,6 @@ int launch_pick(hipStream_t stream, const uint8_t *d_sel, int u0, int chunk, con
                 const int32_t *d_env, int16_t *d_ix, mp3s_gr_out *d_out, int32_t *d_en);
 int launch_pack(hipStream_t stream, const int16_t *d_ix, const mp3s_gr_out *d_gr, const int32_t *d_en, int n_frames, int sri,
                 int bri, int whole_slots, const uint32_t *d_frame_off, const uint8_t *d_padding, uint8_t *d_mp3,
-                int32_t *d_scfsi, int32_t *d_status, Profiler *prof);
+                int32_t *d_scfsi, int32_t *d_status, int32_t *d_sync /* 2 zeroed words owned by the context */, Profiler *prof);
 
 }  // namespace mp3s

@@ -159,14 +159,12 @@ int launch_huffman(hipStream_t stream, const uint8_t *d_blob, const mp3s_frame_s
 
 int launch_pack(hipStream_t stream, const int16_t *d_ix, const mp3s_gr_out *d_gr, const int32_t *d_en, int n_frames, int sri,
                 int bri, int whole_slots, const uint32_t *d_frame_off, const uint8_t *d_padding, uint8_t *d_mp3,
-                int32_t *d_scfsi, int32_t *d_status, Profiler *prof)
+                int32_t *d_scfsi, int32_t *d_status, int32_t *d_sync, Profiler *prof)
 {
-    hipError_t e = hipMemsetAsync(d_status, 0, sizeof(int32_t), stream);
-    if (e != hipSuccess) return (int)e;
     const int pp = prof ? prof->begin(stream, K_ENC_PACK) : -1;
     hipLaunchKernelGGL(k_enc_pack, dim3(n_frames < 2048 ? n_frames : 2048), dim3(256), 0, stream,   // persistent: 8 groups per CU
                        d_ix, d_gr, d_en, n_frames, sri, bri, whole_slots,
-                       d_frame_off, d_padding, d_mp3, d_scfsi, d_status);
+                       d_frame_off, d_padding, d_mp3, d_scfsi, d_status, d_sync);
     if (prof) prof->end(stream, pp);
     return (int)hipGetLastError();
 }

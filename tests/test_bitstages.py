@@ -118,6 +118,21 @@ def test_device_packer_matches_host_formatter(ctx, mlib, orc, golden_dir):
         keep = (len(out) // 4) * 4                                   # the reference drops the cached tail (E14)
         assert out[:keep] == o["mp3"]
         assert np.array_equal(ctx.download(d_sc, np.int32, (n, 2, 4)), o["frames"]["scfsi"])
+        # the status word is written by the last workgroup from error bits that clear themselves: a code book the
+        # encoder never selects is reported (2), part2_3_length too small for the codes as well (1), and the launch after
+        # them is clean again
+        if (gr["big_values"] > 20).any():                            # (not the all-silent case)
+            bad = gr.copy()
+            bad["table_select"][int(np.argmax(gr["big_values"] > 20))][0] = 5
+            mlib.check(L.mp3s_pack_frames_dev(ctx.handle, d_ixf, ctx.to_device(bad), d_en, n, rate, kbps, d_off, d_pad, d_mp3, d_sc, d_st))
+            assert int(ctx.download(d_st, np.int32, (1,))[0]) == 2
+            short = gr.copy()
+            short["part2_3_length"][:] = 1
+            mlib.check(L.mp3s_pack_frames_dev(ctx.handle, d_ixf, ctx.to_device(short), d_en, n, rate, kbps, d_off, d_pad, d_mp3, d_sc, d_st))
+            assert int(ctx.download(d_st, np.int32, (1,))[0]) & 1
+        mlib.check(L.mp3s_pack_frames_dev(ctx.handle, d_ixf, d_gr, d_en, n, rate, kbps, d_off, d_pad, d_mp3, d_sc, d_st))
+        assert int(ctx.download(d_st, np.int32, (1,))[0]) == 0
+        assert ctx.download(d_mp3, np.uint8, (int(off[-1]),)).tobytes()[:keep] == o["mp3"]
         for q in (d_mdct, d_rf, d_ix, d_out, d_en, d_ixf, d_gr, d_off, d_pad, d_mp3, d_sc, d_st):
             ctx.free(q)
 
