@@ -4,7 +4,7 @@
 //                   granule*channel of the batch.  The bit stream of a granule is serial, but granule boundaries
 //                   come from the side info (part2_3_length), so one THREAD decodes one granule*channel (granule 1
 //                   re-reads the scalefactors scfsi lets it share with granule 0 from granule 0's own bits): a
-//                   10 000-frame batch gives 40 000 independent threads.  Code books: 10-bit first-level table and second-level
+//                   10 000-frame batch gives 40 000 independent threads.  Code books: 9-bit first-level table and second-level
 //                   tables for the rare longer codes, both in LDS (same prefix codes the reference searches
 //                   linearly, so the same symbol and length come out).  Quirks kept: D1 (count1 stops at line 572,
 //                   no overrun discard), D2 (books 4/14 read no bits), bits past the buffer read as 0.
@@ -88,8 +88,8 @@ __global__ __launch_bounds__(WAVES * 64) void k_dec_huffman(
     const uint8_t *__restrict__ blob, const mp3s_frame_side *__restrict__ side, int n_frames, int nch, int W, int max_bits,
     int16_t *__restrict__ is, mp3s_granule_si *__restrict__ si_out, int32_t *__restrict__ status)
 {
-    __shared__ uint16_t fast[15][1024];
-    __shared__ uint16_t lut2[HUFF_L2_N];    // second-level tables for the codes longer than 10 bits
+    __shared__ uint16_t fast[15][HUFF_L1_N];
+    __shared__ uint16_t lut2[HUFF_L2_N];    // second-level tables for the codes longer than the first-level index
     __shared__ uint16_t quad[64];
     __shared__ uint16_t tinfo[32];        // table_select -> first-level table id | linbits << 8
     extern __shared__ uint32_t words[];   // [W][COLS]
@@ -97,7 +97,7 @@ __global__ __launch_bounds__(WAVES * 64) void k_dec_huffman(
     {
         const uint4 *src = reinterpret_cast<const uint4 *>(&c_tab.huff_fast[0][0]);
         uint4 *dst = reinterpret_cast<uint4 *>(&fast[0][0]);
-        constexpr int N16 = 15 * 1024 * 2 / 16, ROUNDS = (N16 + T - 1) / T;
+        constexpr int N16 = 15 * HUFF_L1_N * 2 / 16, ROUNDS = (N16 + T - 1) / T;
         uint4 v[ROUNDS <= 8 ? ROUNDS : 8];
         if constexpr (ROUNDS <= 8) {      // every load in flight before the first LDS write
 #pragma unroll
@@ -236,12 +236,12 @@ __global__ __launch_bounds__(WAVES * 64) void k_dec_huffman(
             }
             br.refill();
             const uint32_t window = br.top(32);
-            const uint32_t e = fast[lut][window >> 22];
+            const uint32_t e = fast[lut][window >> (32 - HUFF_FAST_BITS)];
             int len = 0, sym = -1;
             uint32_t leaf = e;
-            if (e & 0x8000u) {                                    // longer than 10 bits: the next k bits pick the leaf
+            if (e & 0x8000u) {                                    // longer than the index: the next k bits pick the leaf
                 const uint32_t k = (e >> 11) & 15;
-                leaf = lut2[(e & 0x7ffu) + ((window << HUFF_FAST_BITS) >> (32 - k))];
+                leaf = lut2[2 * (e & 0x7ffu) + ((window << HUFF_FAST_BITS) >> (32 - k))];
             }
             if (leaf) { sym = (int)(leaf & 0xff); len = (int)(leaf >> 8); }
             if (sym >= 0) {

@@ -139,7 +139,7 @@ int launch_huffman(hipStream_t stream, const uint8_t *d_blob, const mp3s_frame_s
     // every SIMD about three waves to interleave; narrower ones otherwise (and for long granules, whose staging is big).
     const long units = (long)n_frames * 4;
     const int W = huf_words_for(max_bits);
-    auto fits = [&](int cols) { return (size_t)W * cols * 4 + 30720 + HUFF_L2_N * 2 + 256 <= 64 * 1024; };
+    auto fits = [&](int cols) { return (size_t)W * cols * 4 + 15 * HUFF_L1_N * 2 + HUFF_L2_N * 2 + 256 <= 64 * 1024; };
     int lanes = 16;
     if (fits(256) && units / 64 >= 3072) lanes = 64;   // measured: 64 = 32 from 60k frames up, 32 best below (10k: 0.149 vs 0.165 ms)
     else if (fits(128)) lanes = 32;

@@ -269,7 +269,7 @@ void build()
             }
             return m;
         };
-        for (uint32_t w = 0; w < 1024; w++) {
+        for (uint32_t w = 0; w < (uint32_t)HUFF_L1_N; w++) {
             int node = 0;
             uint16_t e = 0;
             for (int d = 0; d < HUFF_FAST_BITS; d++) {
@@ -280,8 +280,8 @@ void build()
             }
             if (node > 0) {   // codes longer than 10 bits share this prefix: one second-level table for the subtree
                 const int k = depth(node), off = l2_used;
-                if (k > 15 || off + (1 << k) > HUFF_L2_N || off >= 2048) abort();
-                l2_used += 1 << k;
+                if (k > 15 || (off & 1) || off + (1 << k) > HUFF_L2_N || (off >> 1) >= 2048) abort();
+                l2_used += (1 << k) + ((1 << k) & 1);          // keep the next table on an even offset
                 for (uint32_t v = 0; v < (1u << k); v++) {
                     int nd = node;
                     uint16_t le = 0;
@@ -293,7 +293,7 @@ void build()
                     }
                     T.huff_l2[off + v] = le;
                 }
-                e = (uint16_t)(0x8000 | (k << 11) | off);
+                e = (uint16_t)(0x8000 | (k << 11) | (off >> 1));
             }
             T.huff_fast[b][w] = e;
         }

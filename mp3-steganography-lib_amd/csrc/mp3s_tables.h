@@ -11,7 +11,12 @@ constexpr int POW43_N = 8207;       // |is| <= 15 + 8191 (linbits 13)
 constexpr int POW2Q_MIN = -266;     // exp1 = global_gain - 210 - 8*sub_block_gain  in [-266, 45]
 constexpr int POW2Q_N = 312;
 constexpr int POW2H_N = 40;         // 2*exp2 in [0, 36]
-constexpr int HUFF_L2_N = 1280;     // second-level Huffman decode entries (1192 used)
+// First-level index width of the device Huffman tables.  9 bits: 15.4 KB + 4.4 KB of second-level tables.  With 10 bits
+// (30.7 + 2.4 KB) the kernel alone is 8 % faster, but its workgroups no longer fit into the LDS the rate loop leaves free
+// on a CU, and running under the rate loop is how the pipeline uses it (bench.py: 0.993 -> 0.967 ms per step).
+constexpr int HUFF_FAST_BITS = 9;
+constexpr int HUFF_L1_N = 1 << HUFF_FAST_BITS;
+constexpr int HUFF_L2_N = 2240;     // second-level entries (tables start on even offsets)
 
 // requantisation line map: one byte per spectral line, (is_short << 7) | (window << 5) | sfb
 // case 0 = long path, 1 = block_type 2, 2 = mixed flag with block_type != 2 (reference Frame.py:185-208)
@@ -51,11 +56,11 @@ struct DevTables {
     uint8_t linbits[32];
     int32_t linmax[32];
     uint8_t transform[32][2];      // reference MP3_Encoder.py:419-449
-    // ---- Huffman decode on the device (k_dec_huffman): 10-bit first-level table + second-level tables for longer codes
+    // ---- Huffman decode on the device (k_dec_huffman): first-level table (HUFF_FAST_BITS) + second-level tables for longer codes
     uint8_t huff_lut_id[32];       // table_select -> 0..14, 255 = no code book (tables 0, 4, 14)
     uint8_t dec_max[32];           // symbols per axis (reference decoder/tables.py:426)
-    uint16_t huff_fast[15][1024];  // leaf: (len << 8) | (x << 4) | y;  0x8000 | (k << 11) | off: the next k bits index
-                                   // huff_l2[off ..];  0: no code
+    uint16_t huff_fast[15][HUFF_L1_N];  // leaf: (len << 8) | (x << 4) | y;  0x8000 | (k << 11) | off / 2: the next k bits
+                                        // index huff_l2[off ..];  0: no code
     uint16_t huff_l2[HUFF_L2_N];   // leaf: (total len << 8) | (x << 4) | y;  0: no code
     uint16_t quad_fast[64];        // count1 book A on 6 bits: (len << 4) | value
     // ---- Huffman code words for the device bit packer (k_enc_pack): books 13, 15, 16.., 24.. and count1 A
@@ -78,6 +83,5 @@ struct HostTables {
 };
 
 const HostTables &host_tables();   // built on first use, thread-safe
-constexpr int HUFF_FAST_BITS = 10;
 
 }  // namespace mp3s

@@ -517,7 +517,7 @@ DEV_TABLES_DTYPE = np.dtype([
     ("sfb_long", "<i4", (3, 23)), ("en_base", "<i4", (32,)), ("en_step", "<i4", (32,)), ("subdv", "<i4", (23, 2)), ("subdiv_lut", "<u4", (3, 289)), ("hlen13", "u1", (256,)), ("hlen15", "u1", (256,)),
     ("hlen16", "u1", (256,)), ("hlen24", "u1", (256,)), ("hlen_c1a", "u1", (16,)), ("linbits", "u1", (32,)),
     ("linmax", "<i4", (32,)), ("transform", "u1", (32, 2)), ("huff_lut_id", "u1", (32,)), ("dec_max", "u1", (32,)),
-    ("huff_fast", "<u2", (15, 1024)), ("huff_l2", "<u2", (1280,)), ("quad_fast", "<u2", (64,)),
+    ("huff_fast", "<u2", (15, 512)), ("huff_l2", "<u2", (2240,)), ("quad_fast", "<u2", (64,)),
     ("hcod", "<u4", (4, 256)), ("hcod_c1a", "u1", (16,))], align=True)
 
 
