@@ -8,7 +8,10 @@
 
 namespace mp3s {
 
-constexpr int DEC_SYNTH_TW = 4;   // waves per channel in a synthesis tile (tile = TW*64 - 15 output slots)
+// waves per channel in a synthesis tile (tile = TW*64 - 15 output slots).  2: 31 KB of LDS per workgroup, five groups =
+// five waves per SIMD on a CU; the kernel waits for scalar-cache misses (the 16 KB matrix is streamed once per tile), so
+// the fifth wave buys more (0.217 -> 0.207 ms) than the larger halo share (15/128 instead of 15/256) costs
+constexpr int DEC_SYNTH_TW = 2;
 
 // optional per-kernel HIP-event timing: when non-null, every kernel launch is bracketed by two events
 // recorded on the launch stream; mp3s_profile_collect() turns the pairs into per-kernel totals.
