@@ -290,8 +290,10 @@ __global__ __launch_bounds__(RL_WAVES * 64, 4) void k_rate_loop(
     const int32_t *__restrict__ mdct, const mp3s_rate_frame *__restrict__ frames, int n_units,
     const uint8_t *__restrict__ hide, int n_hide, const int32_t *__restrict__ cursor_in,
     const int32_t *__restrict__ state_in, const int32_t *__restrict__ unit_list, int n_list,
-    int16_t *__restrict__ ix_out, mp3s_gr_out *__restrict__ out, int32_t *__restrict__ en_out)
+    int16_t *__restrict__ ix_out, mp3s_gr_out *__restrict__ out, int32_t *__restrict__ en_out, int out_base)
 {
+    // results of unit u go to element u - out_base of the three output arrays (0 except for the message variants,
+    // whose arrays hold one chunk of units)
     __shared__ RlTables tb;
     __shared__ uint8_t pcode_all[RL_WAVES][64 * RL_NP + 4];
     __shared__ int32_t esq_all[RL_WAVES][576];
@@ -367,7 +369,7 @@ __global__ __launch_bounds__(RL_WAVES * 64, 4) void k_rate_loop(
             const int k = 31 - __builtin_clz((unsigned)temp);
             en = c_tab.en_base[k] + (temp >= c_tab.en_step[k] ? 1 : 0);
         }
-        if (lane < 22) en_out[(long)u * 22 + lane] = en;
+        if (lane < 22) en_out[(long)(u - out_base) * 22 + lane] = en;
         RlState st;
         st.big_values = st.count1 = st.c1sel = st.r0c = st.r1c = 0;
         st.a1 = state_in ? state_in[(long)u * 4 + 0] : 0;
@@ -429,7 +431,7 @@ __global__ __launch_bounds__(RL_WAVES * 64, 4) void k_rate_loop(
         if (st.used_addr_in) flags |= MP3S_RF_USED_ADDR_IN;
 
         // ---- signed ix (format_bitstream :1272-1276) as int16 pairs
-        int16_t *ixo = ix_out + (long)u * 576;
+        int16_t *ixo = ix_out + (long)(u - out_base) * 576;
 #pragma unroll
         for (int m = 0; m < RL_NP; m++) {
             const int p = lane + 64 * m;
@@ -459,7 +461,7 @@ __global__ __launch_bounds__(RL_WAVES * 64, 4) void k_rate_loop(
             o.reserved0 = 0;
             o.xrmax = (int32_t)xrmax;
             o.reserved = 0;
-            out[u] = o;
+            out[u - out_base] = o;
         }
     }
 }

@@ -789,12 +789,12 @@ static int encode_core(mp3s_ctx *c, const int16_t *pcm, const int16_t *pcm_dev, 
             for (int j = 0; j < chunk; j++) lst[j] = u0 + j;
             rc = mp3s_dev_upload(c, d_list, lst.data(), (size_t)chunk * 4);
             for (int v = 0; v < 8 && !rc; v++) {
-                // outputs are indexed by unit: bias the bases so that unit u0 + j lands on element v * chunk + j
-                int16_t *ixb = (int16_t *)d_ixv + ((long)v * chunk - u0) * 576;
-                mp3s_gr_out *ob = (mp3s_gr_out *)d_outv + ((long)v * chunk - u0);
-                int32_t *eb = (int32_t *)d_env + ((long)v * chunk - u0) * 22;
+                // variant v of unit u0 + j lands on element v * chunk + j of the [8][chunk] arrays
+                int16_t *ixb = (int16_t *)d_ixv + (long)v * chunk * 576;
+                mp3s_gr_out *ob = (mp3s_gr_out *)d_outv + (long)v * chunk;
+                int32_t *eb = (int32_t *)d_env + (long)v * chunk * 22;
                 const int e = launch_rate(c->stream, (const int32_t *)d_mdct, (const mp3s_rate_frame *)d_rf, n, (const uint8_t *)d_h3 + 4 * v,
-                                          3, nullptr, (const int32_t *)d_state, (const int32_t *)d_list, chunk, ixb, ob, eb, &c->prof);
+                                          3, nullptr, (const int32_t *)d_state, (const int32_t *)d_list, chunk, ixb, ob, eb, &c->prof, u0);
                 if (e) rc = fail(MP3S_E_HIP, "rate launch: %s", hipGetErrorString((hipError_t)e));
                 passes++;
             }
