@@ -178,16 +178,16 @@ int mp3s_ctx_create(int device, mp3s_ctx **out)
     if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess ||
         hipEventCreate(&c->ev0) != hipSuccess || hipEventCreate(&c->ev1) != hipSuccess ||
         hipEventCreateWithFlags(&c->ev_order, hipEventDisableTiming) != hipSuccess) {
-        delete c;
+        mp3s_ctx_destroy(c);   // releases whatever was created
         return fail(MP3S_E_NO_DEVICE, "stream/event creation failed");
     }
     if (hipMalloc((void **)&c->d_sync, 16) != hipSuccess || hipMemsetAsync(c->d_sync, 0, 16, c->stream) != hipSuccess) {
-        delete c;
+        mp3s_ctx_destroy(c);
         return fail(MP3S_E_NO_DEVICE, "device scratch allocation failed");
     }
     const int rc = dev_upload_tables(c->stream);
     if (rc) {
-        delete c;
+        mp3s_ctx_destroy(c);
         return fail(MP3S_E_NO_DEVICE, "constant table upload failed: %s (is this a gfx950 device?)",
                     hipGetErrorString((hipError_t)rc));
     }
