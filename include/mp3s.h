@@ -74,7 +74,10 @@ typedef struct {
 typedef struct {
     int32_t max_bits;     /* min(mean_bits // nch, 4095): reference MP3_Encoder.py:894-912 */
     int32_t sr_idx;
-} mp3s_rate_frame;
+    int32_t hide_end;     /* the message of this frame's stream ends at hide[hide_end]: a batch of streams keeps their
+                           * messages back to back in one array (mp3s_rate_frames sets INT32_MAX = the array's end) */
+    int32_t reserved;
+} mp3s_rate_frame; /* 16 bytes */
 
 /* per granule*channel result of the rate loop
  * replaces: GrInfo as left by __iteration_loop, reference encoder/MP3_Encoder.py:81-103, 760-815 */
@@ -346,6 +349,15 @@ int mp3s_encode_file(mp3s_ctx *ctx, const uint8_t *wav, size_t len, int bitrate_
 int mp3s_hide_message(mp3s_ctx *ctx, const uint8_t *mp3, size_t len, const uint8_t *utf8, size_t n_msg, mp3s_buf **owner,
                       mp3s_file *out);
 int mp3s_clear_file(mp3s_ctx *ctx, const uint8_t *mp3, size_t len, mp3s_buf **owner, mp3s_file *out);
+/* replaces: a loop of Steganography.hide_message / clear_file over a list of files.  All files with the
+ * same sampling rate and bitrate go through the device as ONE batch (decode, transforms, rate loop, bit packing: the
+ * streams' frames back to back, every serial chain restarting at a stream's first frame), so many short files cost
+ * about what one long file of the same total length costs.  msgs[i] = UTF-8 message of file i, NULL = clear that file
+ * (msgs itself NULL = clear all).  out[i] is byte-identical to what mp3s_hide_message / mp3s_clear_file give for file i
+ * alone.  status[i] = MP3S_OK or the code file i alone would have failed with (its out[i] is zeroed); with status ==
+ * NULL the first such code fails the whole call. */
+int mp3s_hide_messages(mp3s_ctx *ctx, const uint8_t *const *mp3s, const size_t *lens, int n_files, const uint8_t *const *msgs,
+                       const size_t *msg_lens, mp3s_buf **owner, mp3s_file *out, int32_t *status);
 /* replaces: Steganography.reveal_massage -- reference steganography.py:103-131: MP3 bytes -> message text.  Only the
  * byte-level scan runs (table_select lives in the side info), so no device work and no context are needed. */
 int mp3s_reveal_message(const uint8_t *mp3, size_t len, mp3s_buf **owner, mp3s_file *out);

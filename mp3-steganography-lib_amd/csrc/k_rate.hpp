@@ -325,6 +325,7 @@ __global__ __launch_bounds__(RL_WAVES * 64, 4) void k_rate_loop(
     const int sr = sr_wg;
     const int max_bits = fr.max_bits;
     const int cursor = (n_hide > 0 && cursor_in) ? cursor_in[u] : 0;
+    n_hide = min(n_hide, fr.hide_end);            // streams of a batch keep their messages back to back in `hide`
 
     // ---- load xr, |xr|, xrsq >> 10 (:770-776, :837-838)
     const int32_t *xr = mdct + (long)u * 576;

@@ -141,6 +141,7 @@ struct mp3s_buf {
     std::vector<uint8_t> bits;
     std::vector<mp3s_gr_out> gr;
     std::vector<int32_t> scfsi;
+    std::vector<std::unique_ptr<mp3s_buf>> parts;   // results of the batches of a multi-file call
 };
 
 extern "C" {
@@ -712,28 +713,56 @@ int mp3s_decode_stream(mp3s_ctx *c, const uint8_t *file, size_t len, int out_for
     return mp3s_decode_streams(c, &file, &len, 1, out_format, owner, out);
 }
 
-// pcm_dev != nullptr: the int16 PCM is already in HBM (re-encode after a device decode) and pcm is ignored
 constexpr int kLongMessageBits = 1024;   // below: a handful of small re-runs is cheaper than eight variant launches
+constexpr int32_t kNoCursor = 0x3fffffff; // "behind every message": such a unit hides nothing
 
-static int encode_core(mp3s_ctx *c, const int16_t *pcm, const int16_t *pcm_dev, int64_t n_samples_per_ch, int nch, int samplerate,
-                       int bitrate_kbps, const uint8_t *hide_bits, int n_hide, mp3s_buf **owner, mp3s_encoded *out)
+struct EncSeg {             // one stream of an encode batch: frames back to back in the batch's PCM
+    int n_frames = 0;
+    const uint8_t *hide = nullptr;   // 0/1 bytes
+    int n_hide = 0;
+    // filled by encode_batch
+    int first = 0, hide_base = 0;
+    int64_t hide_offset = 0;         // message bits consumed
+    size_t mp3_off = 0, mp3_len = 0; // the stream's bytes inside the batch's output
+};
+
+// Encode the streams of `segs` (stereo, one sampling rate and bitrate) as ONE batch: transforms, rate loop, bit packing.
+// pcm_dev != nullptr: the int16 PCM is already in HBM (re-encode after a device decode) and pcm is ignored.
+// Results: b->bytes = the streams' MP3 bytes (segs[i].mp3_off / mp3_len), b->gr and b->scfsi in batch frame order.
+static int encode_batch(mp3s_ctx *c, const int16_t *pcm, const int16_t *pcm_dev, std::vector<EncSeg> &segs, int samplerate,
+                        int bitrate_kbps, mp3s_buf *b, int *passes_out)
 {
-    if (nch != 2) return fail(MP3S_E_UNSUPPORTED, "mono encode raises IndexError in the reference (SURVEY E3)");
-    if (n_samples_per_ch <= 0 || n_samples_per_ch % 1152)
-        return fail(MP3S_E_UNSUPPORTED, "sample count %lld is not a multiple of 1152 (reference over-reads, E3)",
-                    (long long)n_samples_per_ch);
-    if (n_hide < 0 || (n_hide > 0 && !hide_bits)) return fail(MP3S_E_ARG, "bad hide arguments");
     // -1 sits in the reference's bitrate table (encoder/util.py:27,42), so its header check lets it through and the
     // encoder then runs on negative slot counts; nothing meaningful to reproduce
     if (bitrate_kbps <= 0) return fail(MP3S_E_UNSUPPORTED, "bitrate %d", bitrate_kbps);
-    const int n = (int)(n_samples_per_ch / 1152), units = n * 4;
+    int sri = 0, bri = 0, whole = 0;
+    if (stream_params(samplerate, bitrate_kbps, &sri, &bri, &whole))
+        return fail(MP3S_E_UNSUPPORTED, "unsupported samplerate/bitrate %d/%d", samplerate, bitrate_kbps);
+    int64_t n64 = 0, hide64 = 0;
+    for (auto &s : segs) {
+        if (s.n_frames <= 0 || s.n_hide < 0 || (s.n_hide > 0 && !s.hide)) return fail(MP3S_E_ARG, "bad stream in the encode batch");
+        s.first = (int)n64; s.hide_base = (int)hide64;
+        n64 += s.n_frames; hide64 += s.n_hide;
+        if (n64 > 0x7fffffff / 8 || hide64 >= kNoCursor - 8) return fail(MP3S_E_ARG, "encode batch too large");
+    }
+    if (n64 <= 0) return fail(MP3S_E_ARG, "empty encode batch");
+    const int n = (int)n64, units = n * 4, n_hide = (int)hide64;
     std::vector<mp3s_rate_frame> rf(n);
-    int rc = rate_frames(samplerate, bitrate_kbps, nch, n, rf.data(), nullptr);
-    if (rc) return fail(rc, "unsupported samplerate/bitrate %d/%d", samplerate, bitrate_kbps);
+    std::vector<mp3s_frame_hdr> hdr(n);
+    std::vector<int32_t> padding(n);
+    std::vector<uint8_t> hide_all((size_t)n_hide);
+    for (const auto &s : segs) {
+        // padding / slot lag restart with every stream (MP3_Encoder.py:623-636)
+        const int rc = rate_frames(samplerate, bitrate_kbps, 2, s.n_frames, rf.data() + s.first, padding.data() + s.first);
+        if (rc) return fail(rc, "unsupported samplerate/bitrate %d/%d", samplerate, bitrate_kbps);
+        for (int f = s.first; f < s.first + s.n_frames; f++) {
+            rf[f].hide_end = s.hide_base + s.n_hide;
+            hdr[f].sr_idx = (uint8_t)sri; hdr[f].nch = 2; hdr[f].ms_stereo = 0; hdr[f].flags = 0; hdr[f].stream_first = (uint32_t)s.first;
+        }
+        if (s.n_hide) std::memcpy(hide_all.data() + s.hide_base, s.hide, (size_t)s.n_hide);
+    }
     HIPCHK(hipSetDevice(c->device));
 
-    std::vector<mp3s_frame_hdr> hdr(n);
-    for (auto &h : hdr) { h.sr_idx = (uint8_t)rf[0].sr_idx; h.nch = 2; h.ms_stereo = 0; h.flags = 0; h.stream_first = 0; }
     void *d_pcm = nullptr, *d_hdr = nullptr, *d_mdct = nullptr, *d_rf = nullptr, *d_hide = nullptr, *d_cur = nullptr,
          *d_state = nullptr, *d_list = nullptr, *d_ix = nullptr, *d_out = nullptr, *d_en = nullptr;
     auto cleanup = [&]() { hipStreamSynchronize(c->stream); };   // the buffers stay in the context's pool
@@ -749,27 +778,34 @@ static int encode_core(mp3s_ctx *c, const int16_t *pcm, const int16_t *pcm_dev, 
         cleanup();
         return fail(MP3S_E_NOMEM, "hipMalloc failed for a %d-frame encode", n);
     }
-    std::vector<int32_t> cursor(units), state((size_t)units * 4, 0), en((size_t)units * 22);
-    std::vector<mp3s_gr_out> gr(units);
+    std::vector<int32_t> cursor(units), state((size_t)units * 4, 0);
+    std::vector<mp3s_gr_out> &gr = b->gr;
+    gr.assign(units, mp3s_gr_out());
     // A unit sees the message only through the <= 3 bits at its cursor.  Short messages: guess three tables per unit,
     // run, prefix-sum the real counts and re-run what the guess got wrong (1-2 launches).  Long messages would need
     // one launch per unit whose table count differs from the guess (about 1 in 40), so for them the rate loop runs once
     // per 3-bit pattern over the units the message can reach and the cursor walk below picks each unit's pattern.
-    const bool long_msg = n_hide > kLongMessageBits;
-    for (int u = 0; u < units; u++) cursor[u] = long_msg ? 0x7fffffff : 3 * u;
+    bool any_long = false;
+    for (const auto &s : segs) {
+        const bool long_msg = s.n_hide > kLongMessageBits;
+        any_long |= long_msg;
+        for (int j = 0; j < s.n_frames * 4; j++)
+            cursor[(size_t)s.first * 4 + j] = long_msg ? kNoCursor : (int32_t)std::min<int64_t>((int64_t)s.hide_base + 3 * (int64_t)j, kNoCursor);
+    }
+    int rc = MP3S_OK;
     if (!pcm_dev) rc = mp3s_dev_upload(c, d_pcm, pcm, (size_t)n * 2304 * 2);
     if (!rc) rc = mp3s_dev_upload(c, d_hdr, hdr.data(), (size_t)n * sizeof(mp3s_frame_hdr));
     if (!rc) rc = mp3s_dev_upload(c, d_rf, rf.data(), (size_t)n * sizeof(mp3s_rate_frame));
-    if (!rc && n_hide) rc = mp3s_dev_upload(c, d_hide, hide_bits, (size_t)n_hide);
+    if (!rc && n_hide) rc = mp3s_dev_upload(c, d_hide, hide_all.data(), (size_t)n_hide);
     if (!rc) rc = mp3s_dev_upload(c, d_cur, cursor.data(), (size_t)units * 4);
     if (!rc) rc = mp3s_dev_upload(c, d_state, state.data(), (size_t)units * 16);
     if (!rc) rc = mp3s_encode_transform_dev(c, (const int16_t *)d_pcm, (const mp3s_frame_hdr *)d_hdr, n, (int32_t *)d_mdct);
     if (!rc) rc = mp3s_rate_loop_dev(c, (const int32_t *)d_mdct, (const mp3s_rate_frame *)d_rf, n, (const uint8_t *)d_hide,
-                                     long_msg ? 0 : n_hide, (const int32_t *)d_cur, (const int32_t *)d_state, nullptr, 0,
+                                     n_hide, (const int32_t *)d_cur, (const int32_t *)d_state, nullptr, 0,
                                      (int16_t *)d_ix, (mp3s_gr_out *)d_out, (int32_t *)d_en);
     if (!rc) rc = mp3s_dev_download(c, gr.data(), d_out, (size_t)units * sizeof(mp3s_gr_out));
     int passes = 1;
-    if (!rc && long_msg) {
+    if (!rc && any_long) {
         const int kChunk = 8192;   // units per round of eight variant launches
         void *d_ixv = nullptr, *d_outv = nullptr, *d_env = nullptr, *d_sel = nullptr, *d_h3 = nullptr;
         if (!alloc(&d_ixv, (size_t)8 * kChunk * 1152) || !alloc(&d_outv, (size_t)8 * kChunk * sizeof(mp3s_gr_out)) ||
@@ -781,79 +817,88 @@ static int encode_core(mp3s_ctx *c, const int16_t *pcm, const int16_t *pcm_dev, 
         std::vector<mp3s_gr_out> gv((size_t)8 * kChunk);
         std::vector<int32_t> lst(kChunk);
         std::vector<uint8_t> sel(kChunk);
-        int64_t cur = 0;
-        for (int u0 = 0, chunk = 0; u0 < units && cur < n_hide && !rc; u0 += chunk) {
-            // as many units as the rest of the message can reach at two tables per unit (silent units take none: the loop
-            // simply goes round again), at most kChunk
-            chunk = (int)std::min<int64_t>(std::min(kChunk, units - u0), (n_hide - cur) / 2 + 64);
-            for (int j = 0; j < chunk; j++) lst[j] = u0 + j;
-            rc = mp3s_dev_upload(c, d_list, lst.data(), (size_t)chunk * 4);
-            for (int v = 0; v < 8 && !rc; v++) {
-                // variant v of unit u0 + j lands on element v * chunk + j of the [8][chunk] arrays
-                int16_t *ixb = (int16_t *)d_ixv + (long)v * chunk * 576;
-                mp3s_gr_out *ob = (mp3s_gr_out *)d_outv + (long)v * chunk;
-                int32_t *eb = (int32_t *)d_env + (long)v * chunk * 22;
-                const int e = launch_rate(c->stream, (const int32_t *)d_mdct, (const mp3s_rate_frame *)d_rf, n, (const uint8_t *)d_h3 + 4 * v,
-                                          3, nullptr, (const int32_t *)d_state, (const int32_t *)d_list, chunk, ixb, ob, eb, &c->prof, u0);
-                if (e) rc = fail(MP3S_E_HIP, "rate launch: %s", hipGetErrorString((hipError_t)e));
-                passes++;
+        for (const auto &s : segs) {
+            if (s.n_hide <= kLongMessageBits) continue;
+            const int u_end = (s.first + s.n_frames) * 4;
+            const int64_t end = (int64_t)s.hide_base + s.n_hide;
+            int64_t cur = s.hide_base;
+            for (int u0 = s.first * 4, chunk = 0; u0 < u_end && cur < end && !rc; u0 += chunk) {
+                // as many units as the rest of the message can reach at two tables per unit (silent units take none: the
+                // loop simply goes round again), at most kChunk
+                chunk = (int)std::min<int64_t>(std::min(kChunk, u_end - u0), (end - cur) / 2 + 64);
+                for (int j = 0; j < chunk; j++) lst[j] = u0 + j;
+                rc = mp3s_dev_upload(c, d_list, lst.data(), (size_t)chunk * 4);
+                for (int v = 0; v < 8 && !rc; v++) {
+                    // variant v of unit u0 + j lands on element v * chunk + j of the [8][chunk] arrays
+                    int16_t *ixb = (int16_t *)d_ixv + (long)v * chunk * 576;
+                    mp3s_gr_out *ob = (mp3s_gr_out *)d_outv + (long)v * chunk;
+                    int32_t *eb = (int32_t *)d_env + (long)v * chunk * 22;
+                    const int e = launch_rate(c->stream, (const int32_t *)d_mdct, (const mp3s_rate_frame *)d_rf, n, (const uint8_t *)d_h3 + 4 * v,
+                                              3, nullptr, (const int32_t *)d_state, (const int32_t *)d_list, chunk, ixb, ob, eb, &c->prof, u0);
+                    if (e) rc = fail(MP3S_E_HIP, "rate launch: %s", hipGetErrorString((hipError_t)e));
+                    passes++;
+                }
+                if (!rc) rc = mp3s_dev_download(c, gv.data(), d_outv, (size_t)8 * chunk * sizeof(mp3s_gr_out));
+                for (int j = 0; j < chunk && !rc; j++) {
+                    const int u = u0 + j;
+                    sel[j] = 255;
+                    if (cur + 3 <= end) {                         // all three bits the unit can ask for exist
+                        const int v = (hide_all[cur] & 1) * 4 + (hide_all[cur + 1] & 1) * 2 + (hide_all[cur + 2] & 1);
+                        sel[j] = (uint8_t)v;
+                        gr[u] = gv[(size_t)v * chunk + j];
+                        cursor[u] = (int32_t)cur;
+                    }                                             // else: the message ends inside or before this unit -- the
+                    cur += gr[u].n_tables;                        // consistency loop below re-runs it with its real cursor
+                }
+                if (!rc) rc = mp3s_dev_upload(c, d_sel, sel.data(), (size_t)chunk);
+                if (!rc) {
+                    const int e = launch_pick(c->stream, (const uint8_t *)d_sel, u0, chunk, (const int16_t *)d_ixv, (const mp3s_gr_out *)d_outv,
+                                              (const int32_t *)d_env, (int16_t *)d_ix, (mp3s_gr_out *)d_out, (int32_t *)d_en);
+                    if (e) rc = fail(MP3S_E_HIP, "variant pick: %s", hipGetErrorString((hipError_t)e));
+                }
+                if (!rc && hipStreamSynchronize(c->stream) != hipSuccess) rc = fail(MP3S_E_HIP, "sync failed");   // sel / lst are reused
             }
-            if (!rc) rc = mp3s_dev_download(c, gv.data(), d_outv, (size_t)8 * chunk * sizeof(mp3s_gr_out));
-            for (int j = 0; j < chunk && !rc; j++) {
-                const int u = u0 + j;
-                sel[j] = 255;
-                if (cur + 3 <= n_hide) {                      // all three bits the unit can ask for exist
-                    const int v = (hide_bits[cur] & 1) * 4 + (hide_bits[cur + 1] & 1) * 2 + (hide_bits[cur + 2] & 1);
-                    sel[j] = (uint8_t)v;
-                    gr[u] = gv[(size_t)v * chunk + j];
-                    cursor[u] = (int32_t)cur;
-                }                                             // else: the message ends inside or before this unit -- the
-                cur += gr[u].n_tables;                        // consistency loop below re-runs it with its real cursor
-            }
-            if (!rc) rc = mp3s_dev_upload(c, d_sel, sel.data(), (size_t)chunk);
-            if (!rc) {
-                const int e = launch_pick(c->stream, (const uint8_t *)d_sel, u0, chunk, (const int16_t *)d_ixv, (const mp3s_gr_out *)d_outv,
-                                          (const int32_t *)d_env, (int16_t *)d_ix, (mp3s_gr_out *)d_out, (int32_t *)d_en);
-                if (e) rc = fail(MP3S_E_HIP, "variant pick: %s", hipGetErrorString((hipError_t)e));
-            }
-            if (!rc && hipStreamSynchronize(c->stream) != hipSuccess) rc = fail(MP3S_E_HIP, "sync failed");   // sel / lst are reused
         }
     }
-    // ---- resolve the serial chain: hide cursor (MP3_Encoder.py:808-809) and the per-(gr,ch) inherited
+    // ---- resolve the serial chains, stream by stream: hide cursor (MP3_Encoder.py:808-809) and the per-(gr,ch) inherited
     //      address1/2/3 + quantizerStepSize (E7).  Units whose assumed inputs were wrong are re-run.
     std::vector<int32_t> list;
     std::vector<mp3s_gr_out> tmp;
     while (!rc) {
         list.clear();
-        int64_t cur = 0;
-        int32_t chain[4][4] = {};   // [(ch*2+gr)][a1,a2,a3,step]
-        for (int u = 0; u < units; u++) {
-            const int k = u & 3;
-            mp3s_gr_out &g = gr[u];
-            bool redo = false;
-            const bool active = g.flags & MP3S_RF_ACTIVE;
-            if (n_hide > 0 && active) {
-                const int64_t used = cursor[u];
-                if (used != cur && std::min<int64_t>(used, cur) < n_hide) redo = true;
+        for (auto &s : segs) {
+            int64_t cur = s.hide_base;
+            const int64_t end = (int64_t)s.hide_base + s.n_hide;
+            int32_t chain[4][4] = {};   // [(ch*2+gr)][a1,a2,a3,step]
+            for (int u = s.first * 4; u < (s.first + s.n_frames) * 4; u++) {
+                const int k = u & 3;
+                mp3s_gr_out &g = gr[u];
+                bool redo = false;
+                const bool active = g.flags & MP3S_RF_ACTIVE;
+                if (s.n_hide > 0 && active) {
+                    const int64_t used = cursor[u];
+                    if (used != cur && std::min<int64_t>(used, cur) < end) redo = true;
+                }
+                if ((g.flags & MP3S_RF_USED_ADDR_IN) &&
+                    (state[(size_t)u * 4] != chain[k][0] || state[(size_t)u * 4 + 1] != chain[k][1] ||
+                     state[(size_t)u * 4 + 2] != chain[k][2]))
+                    redo = true;
+                if (redo) list.push_back(u);
+                cursor[u] = (int32_t)std::min<int64_t>(cur, kNoCursor);
+                for (int j = 0; j < 4; j++) state[(size_t)u * 4 + j] = chain[k][j];
+                if (active) {
+                    cur += g.n_tables;
+                    chain[k][0] = g.address[0]; chain[k][1] = g.address[1]; chain[k][2] = g.address[2];
+                    chain[k][3] = g.quantizer_step;
+                } else {   // silent unit: everything is inherited (quantizerStepSize and addresses pass through)
+                    g.address[0] = chain[k][0]; g.address[1] = chain[k][1]; g.address[2] = chain[k][2];
+                    g.quantizer_step = chain[k][3];
+                }
+                if (g.flags & MP3S_RF_STEP_RANGE) { rc = fail(MP3S_E_STEP_RANGE, "quantizer step left the table in unit %d", u); break; }
             }
-            if ((g.flags & MP3S_RF_USED_ADDR_IN) &&
-                (state[(size_t)u * 4] != chain[k][0] || state[(size_t)u * 4 + 1] != chain[k][1] ||
-                 state[(size_t)u * 4 + 2] != chain[k][2]))
-                redo = true;
-            if (redo) list.push_back(u);
-            cursor[u] = (int32_t)std::min<int64_t>(cur, 0x7fffffff);
-            for (int j = 0; j < 4; j++) state[(size_t)u * 4 + j] = chain[k][j];
-            if (active) {
-                cur += g.n_tables;
-                chain[k][0] = g.address[0]; chain[k][1] = g.address[1]; chain[k][2] = g.address[2];
-                chain[k][3] = g.quantizer_step;
-            } else {   // silent unit: everything is inherited (quantizerStepSize and addresses pass through)
-                g.address[0] = chain[k][0]; g.address[1] = chain[k][1]; g.address[2] = chain[k][2];
-                g.quantizer_step = chain[k][3];
-            }
-            if (g.flags & MP3S_RF_STEP_RANGE) { rc = fail(MP3S_E_STEP_RANGE, "quantizer step left the table in unit %d", u); break; }
+            s.hide_offset = cur - s.hide_base;
+            if (rc) break;
         }
-        out->hide_offset = cur;
         if (rc || list.empty()) break;
         if (++passes > units + 2) { rc = fail(MP3S_E_HIP, "rate-loop chain did not converge"); break; }
         rc = mp3s_dev_upload(c, d_cur, cursor.data(), (size_t)units * 4);
@@ -868,20 +913,14 @@ static int encode_core(mp3s_ctx *c, const int16_t *pcm, const int16_t *pcm_dev, 
         if (!rc) rc = mp3s_dev_download(c, tmp.data(), (const mp3s_gr_out *)d_out + lo, (size_t)span * sizeof(mp3s_gr_out));
         if (!rc) for (int u : list) gr[u] = tmp[u - lo];
     }
-    mp3s_buf *b = nullptr;
     if (!rc) {
-        b = new mp3s_buf();
         // ---- bit packing on the device: final GrInfo + frame offsets up, MP3 bytes + scfsi down
-        std::vector<int32_t> padding(n);
         std::vector<uint32_t> off((size_t)n + 1, 0);
         std::vector<uint8_t> pad8(n);
-        int sri = 0, bri = 0, whole = 0;
-        if (!rc && stream_params(samplerate, bitrate_kbps, &sri, &bri, &whole)) rc = fail(MP3S_E_UNSUPPORTED, "bad stream parameters");
-        if (!rc) rc = rate_frames(samplerate, bitrate_kbps, nch, n, rf.data(), padding.data());
         for (int f = 0; f < n; f++) { pad8[f] = (uint8_t)padding[f]; off[f + 1] = off[f] + (uint32_t)(whole + padding[f]); }
         void *d_off = nullptr, *d_pad = nullptr, *d_mp3 = nullptr, *d_sc = nullptr, *d_st = nullptr;
-        if (!rc && (!alloc(&d_off, ((size_t)n + 1) * 4) || !alloc(&d_pad, (size_t)n) || !alloc(&d_mp3, (size_t)off[n] + 16) ||
-                    !alloc(&d_sc, (size_t)n * 8 * 4) || !alloc(&d_st, 16)))
+        if (!alloc(&d_off, ((size_t)n + 1) * 4) || !alloc(&d_pad, (size_t)n) || !alloc(&d_mp3, (size_t)off[n] + 16) ||
+            !alloc(&d_sc, (size_t)n * 8 * 4) || !alloc(&d_st, 16))
             rc = fail(MP3S_E_NOMEM, "hipMalloc failed for the packer");
         if (!rc) rc = mp3s_dev_upload(c, d_off, off.data(), ((size_t)n + 1) * 4);
         if (!rc) rc = mp3s_dev_upload(c, d_pad, pad8.data(), (size_t)n);
@@ -892,23 +931,43 @@ static int encode_core(mp3s_ctx *c, const int16_t *pcm, const int16_t *pcm_dev, 
         int32_t st = 0;
         if (!rc) rc = mp3s_dev_download(c, &st, d_st, sizeof st);
         if (!rc && st) rc = fail(MP3S_E_HIP, "bit packer reported status %d", st);
-        const size_t keep = ((size_t)off[n] / 4) * 4;   // the reference drops the cached tail (< 32 bits): E14
-        b->bytes.resize(keep);
+        for (auto &s : segs) {
+            s.mp3_off = off[s.first];
+            s.mp3_len = ((size_t)(off[s.first + s.n_frames] - off[s.first]) / 4) * 4;   // the reference drops the cached tail (< 32 bits): E14
+        }
+        const size_t total = segs.back().mp3_off + segs.back().mp3_len;
+        b->bytes.resize(total);
         b->scfsi.assign((size_t)n * 8, 0);
-        if (!rc) rc = mp3s_dev_download(c, b->bytes.data(), d_mp3, keep);
+        if (!rc) rc = mp3s_dev_download(c, b->bytes.data(), d_mp3, total);
         if (!rc) rc = mp3s_dev_download(c, b->scfsi.data(), d_sc, (size_t)n * 8 * 4);
-        hipStreamSynchronize(c->stream);
-        if (rc) { delete b; b = nullptr; }
     }
     cleanup();
+    if (passes_out) *passes_out = passes;
+    return rc;
+}
+
+static int encode_core(mp3s_ctx *c, const int16_t *pcm, const int16_t *pcm_dev, int64_t n_samples_per_ch, int nch, int samplerate,
+                       int bitrate_kbps, const uint8_t *hide_bits, int n_hide, mp3s_buf **owner, mp3s_encoded *out)
+{
+    if (nch != 2) return fail(MP3S_E_UNSUPPORTED, "mono encode raises IndexError in the reference (SURVEY E3)");
+    if (n_samples_per_ch <= 0 || n_samples_per_ch % 1152)
+        return fail(MP3S_E_UNSUPPORTED, "sample count %lld is not a multiple of 1152 (reference over-reads, E3)",
+                    (long long)n_samples_per_ch);
+    if (n_hide < 0 || (n_hide > 0 && !hide_bits)) return fail(MP3S_E_ARG, "bad hide arguments");
+    if (n_samples_per_ch / 1152 > 0x7fffffff / 8) return fail(MP3S_E_ARG, "too many frames");
+    std::vector<EncSeg> segs(1);
+    segs[0].n_frames = (int)(n_samples_per_ch / 1152); segs[0].hide = hide_bits; segs[0].n_hide = n_hide;
+    std::unique_ptr<mp3s_buf> b(new mp3s_buf());
+    int passes = 0;
+    const int rc = encode_batch(c, pcm, pcm_dev, segs, samplerate, bitrate_kbps, b.get(), &passes);
     if (rc) return rc;
-    b->gr = gr;
-    out->n_frames = n;
+    out->n_frames = segs[0].n_frames;
+    out->hide_offset = segs[0].hide_offset;
     out->too_long = out->hide_offset < (int64_t)n_hide - 1 ? 1 : 0;
-    out->mp3 = b->bytes.data(); out->mp3_len = b->bytes.size();
+    out->mp3 = b->bytes.data(); out->mp3_len = segs[0].mp3_len;
     out->gr = b->gr.data(); out->scfsi = b->scfsi.data();
     out->rate_passes = passes;
-    *owner = b;
+    *owner = b.release();
     return MP3S_OK;
 }
 
@@ -1006,14 +1065,9 @@ int mp3s_encode_file(mp3s_ctx *c, const uint8_t *wav, size_t len, int bitrate_kb
     return rc;
 }
 
-// decode on the device into HBM, encode from there: steganography.py:133-182 without the temporary WAV
-static int reencode(mp3s_ctx *c, const uint8_t *mp3, size_t len, const uint8_t *hide_bits, int n_hide, mp3s_buf **owner, mp3s_file *out)
+// what the reference's WAV reader / encoder would say to the WAV its decoder writes for this stream
+static int reencode_check(const ParsedStream &p, int *kbps_out)
 {
-    mp3s_multi m;
-    m.parsed.resize(1); m.scanned.resize(1); m.pcm.assign(1, nullptr); m.files.assign(1, {mp3, len});
-    int rc = front_end(mp3, len, m.parsed[0], m.scanned[0]);
-    if (rc) return fail(rc, "malformed or unsupported MP3 stream");
-    const ParsedStream &p = m.parsed[0];
     const int kbps = p.bit_rate / 1000;
     int sri, bri, whole;
     // the WAV the reference writes carries the last header's sampling rate; its reader checks the rate, then the bitrate
@@ -1022,31 +1076,107 @@ static int reencode(mp3s_ctx *c, const uint8_t *mp3, size_t len, const uint8_t *
     if (stream_params(p.sampling_rate, kbps, &sri, &bri, &whole)) return fail(MP3S_E_EXIT, "Unsupported bitrate configuration.");
     if (p.nch != 2) return fail(MP3S_E_UNSUPPORTED, "mono input: the reference encoder indexes the sample buffer out of bounds");
     if (p.n_frames <= 0) return fail(MP3S_E_UNSUPPORTED, "no frame in the stream");
-    const int64_t rows_frames = (int64_t)p.n_frames + (p.dup_last_frame ? 1 : 0);
+    *kbps_out = kbps;
+    return MP3S_OK;
+}
+
+// Decode the streams `idx` of m (stereo, one sampling rate and bitrate) on the device into HBM and encode them from
+// there as one batch: steganography.py:133-182 without the temporary WAV.  bits[i] = framed message of file i (empty:
+// nothing hidden).  The batch's bytes are kept in a new part of `top`; out[i] points into it.
+static int reencode_group(mp3s_ctx *c, mp3s_multi &m, const std::vector<int> &idx, const std::vector<std::vector<uint8_t>> &bits,
+                          int samplerate, int kbps, mp3s_buf *top, mp3s_file *out)
+{
+    std::vector<EncSeg> segs(idx.size());
+    int64_t rows_frames = 0;
+    for (size_t k = 0; k < idx.size(); k++) {
+        const ParsedStream &p = m.parsed[idx[k]];
+        segs[k].n_frames = p.n_frames + (p.dup_last_frame ? 1 : 0);
+        if (bits[idx[k]].size() > 0x7fffffff) return fail(MP3S_E_ARG, "message too long");
+        segs[k].hide = bits[idx[k]].data(); segs[k].n_hide = (int)bits[idx[k]].size();
+        rows_frames += segs[k].n_frames;
+    }
     if (hipSetDevice(c->device) != hipSuccess) return fail(MP3S_E_HIP, "hipSetDevice failed");
     void *d_keep = c->grab(7, (size_t)rows_frames * 2304 * 2);
     if (!d_keep) return fail(MP3S_E_NOMEM, "hipMalloc failed for %lld frames of PCM", (long long)rows_frames);
-    rc = decode_group(c, m, std::vector<int>{0}, 2, MP3S_PCM_I16, d_keep);
+    int rc = decode_group(c, m, idx, 2, MP3S_PCM_I16, d_keep);
     if (rc) return rc;
-    mp3s_encoded e;
-    rc = encode_core(c, nullptr, (const int16_t *)d_keep, rows_frames * 1152, 2, p.sampling_rate, kbps, hide_bits, n_hide, owner, &e);
-    if (!rc) file_from_encoded(e, kbps, p.sampling_rate, out);
-    return rc;
+    std::unique_ptr<mp3s_buf> part(new mp3s_buf());
+    rc = encode_batch(c, nullptr, (const int16_t *)d_keep, segs, samplerate, kbps, part.get(), nullptr);
+    if (rc) return rc;
+    for (size_t k = 0; k < idx.size(); k++) {
+        mp3s_file &o = out[idx[k]];
+        std::memset(&o, 0, sizeof o);
+        o.data = part->bytes.data() + segs[k].mp3_off; o.len = segs[k].mp3_len;
+        o.kbps = kbps; o.sampling_rate = samplerate; o.channels = 2; o.n_frames = segs[k].n_frames;
+        o.hide_offset = segs[k].hide_offset;
+        o.too_long = segs[k].hide_offset < (int64_t)segs[k].n_hide - 1 ? 1 : 0;
+    }
+    top->parts.push_back(std::move(part));
+    return MP3S_OK;
+}
+
+int mp3s_hide_messages(mp3s_ctx *c, const uint8_t *const *mp3s, const size_t *lens, int n_files, const uint8_t *const *msgs,
+                       const size_t *msg_lens, mp3s_buf **owner, mp3s_file *out, int32_t *status)
+{
+    if (!c || !mp3s || !lens || !owner || !out || n_files <= 0 || (msgs && !msg_lens)) return fail(MP3S_E_ARG, "bad argument");
+    std::unique_ptr<mp3s_buf> top(new mp3s_buf());
+    top->multi.reset(new mp3s_multi());
+    mp3s_multi &m = *top->multi;
+    m.parsed.resize(n_files); m.scanned.resize(n_files); m.pcm.assign(n_files, nullptr); m.files.resize(n_files);
+    std::vector<std::vector<uint8_t>> bits(n_files);
+    std::vector<int32_t> st(n_files, MP3S_OK);
+    struct Group { int rate, kbps; std::vector<int> idx; };
+    std::vector<Group> groups;
+    for (int i = 0; i < n_files; i++) {
+        std::memset(&out[i], 0, sizeof out[i]);
+        if (!mp3s[i] || (msgs && msgs[i] == nullptr && msg_lens[i])) { st[i] = fail(MP3S_E_ARG, "file %d: null pointer", i); continue; }
+        m.files[i] = {mp3s[i], lens[i]};
+        int kbps = 0;
+        st[i] = front_end(mp3s[i], lens[i], m.parsed[i], m.scanned[i]);
+        if (st[i]) { fail(st[i], "file %d: malformed or unsupported MP3 stream", i); continue; }
+        st[i] = reencode_check(m.parsed[i], &kbps);
+        if (st[i]) continue;
+        if (msgs && msgs[i]) message_frame(msgs[i], msg_lens[i], bits[i]);
+        const int rate = m.parsed[i].sampling_rate;
+        size_t g = 0;
+        while (g < groups.size() && (groups[g].rate != rate || groups[g].kbps != kbps)) g++;
+        if (g == groups.size()) groups.push_back({rate, kbps, {}});
+        groups[g].idx.push_back(i);
+    }
+    for (const Group &g : groups) {
+        const int rc = reencode_group(c, m, g.idx, bits, g.rate, g.kbps, top.get(), out);
+        if (!rc) continue;
+        // one stream spoils its batch (main data the host parser rejects ...): each file on its own, to name it
+        for (int i : g.idx) st[i] = g.idx.size() == 1 ? rc : reencode_group(c, m, std::vector<int>{i}, bits, g.rate, g.kbps, top.get(), out);
+    }
+    m.files.clear();   // borrowed pointers
+    int first_bad = MP3S_OK;
+    for (int i = 0; i < n_files; i++) {
+        if (status) status[i] = st[i];
+        if (st[i] && !first_bad) first_bad = st[i];
+    }
+    if (!status && first_bad) return first_bad;
+    *owner = top.release();
+    return MP3S_OK;
+}
+
+static int reencode(mp3s_ctx *c, const uint8_t *mp3, size_t len, const uint8_t *msg, size_t n_msg, bool hide, mp3s_buf **owner, mp3s_file *out)
+{
+    const uint8_t *const no_msg = nullptr;
+    return mp3s_hide_messages(c, &mp3, &len, 1, hide ? &msg : &no_msg, &n_msg, owner, out, nullptr);
 }
 
 int mp3s_hide_message(mp3s_ctx *c, const uint8_t *mp3, size_t len, const uint8_t *utf8, size_t n_msg, mp3s_buf **owner, mp3s_file *out)
 {
     if (!c || !mp3 || (!utf8 && n_msg) || !owner || !out) return fail(MP3S_E_ARG, "null pointer");
-    std::vector<uint8_t> bits;
-    message_frame(utf8, n_msg, bits);
-    if (bits.size() > 0x7fffffff) return fail(MP3S_E_ARG, "message too long");
-    return reencode(c, mp3, len, bits.data(), (int)bits.size(), owner, out);
+    static const uint8_t empty = 0;
+    return reencode(c, mp3, len, utf8 ? utf8 : &empty, n_msg, true, owner, out);
 }
 
 int mp3s_clear_file(mp3s_ctx *c, const uint8_t *mp3, size_t len, mp3s_buf **owner, mp3s_file *out)
 {
     if (!c || !mp3 || !owner || !out) return fail(MP3S_E_ARG, "null pointer");
-    return reencode(c, mp3, len, nullptr, 0, owner, out);
+    return reencode(c, mp3, len, nullptr, 0, false, owner, out);
 }
 
 int mp3s_reveal_message(const uint8_t *mp3, size_t len, mp3s_buf **owner, mp3s_file *out)

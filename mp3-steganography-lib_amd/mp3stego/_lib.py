@@ -35,7 +35,7 @@ GRANULE_SI_DTYPE = np.dtype([("global_gain", "u1"), ("scalefac_scale", "u1"), ("
                              ("scale_fac_l", "u1", (22,)), ("scale_fac_s", "u1", (3, 13)), ("pad", "u1", (3,))])
 FRAME_HDR_DTYPE = np.dtype([("sr_idx", "u1"), ("nch", "u1"), ("ms_stereo", "u1"), ("flags", "u1"),
                             ("stream_first", "<u4")])
-RATE_FRAME_DTYPE = np.dtype([("max_bits", "<i4"), ("sr_idx", "<i4")])
+RATE_FRAME_DTYPE = np.dtype([("max_bits", "<i4"), ("sr_idx", "<i4"), ("hide_end", "<i4"), ("reserved", "<i4")])
 UNIT_SIDE_DTYPE = np.dtype([("part2_3_length", "<u2"), ("big_values", "<u2"), ("global_gain", "u1"),
                             ("scalefac_compress", "u1"), ("window_switching", "u1"), ("block_type", "u1"),
                             ("mixed_block_flag", "u1"), ("table_select", "u1", (3,)), ("region0_count", "u1"),
@@ -95,7 +95,7 @@ SYMBOLS = ["mp3s_ctx_create", "mp3s_ctx_destroy", "mp3s_ctx_wait", "mp3s_last_er
            "mp3s_encode_transform_dev", "mp3s_encode_transform", "mp3s_rate_loop_dev", "mp3s_huffman_decode_dev", "mp3s_pack_frames_dev", "mp3s_scan_stream", "mp3s_buf_free",
            "mp3s_parse_stream", "mp3s_format_stream", "mp3s_rate_frames", "mp3s_decode_stream", "mp3s_decode_streams", "mp3s_encode_pcm",
            "mp3s_wav_parse", "mp3s_wav_header", "mp3s_message_frame", "mp3s_message_reveal", "mp3s_decode_file", "mp3s_encode_file",
-           "mp3s_hide_message", "mp3s_clear_file", "mp3s_reveal_message"]
+           "mp3s_hide_message", "mp3s_clear_file", "mp3s_hide_messages", "mp3s_reveal_message"]
 
 _lib = None
 _lock = threading.Lock()
@@ -161,6 +161,7 @@ def lib():
         L.mp3s_encode_file.argtypes = [vp, vp, sz, i32, vp, i32, pvp, C.POINTER(File)]
         L.mp3s_hide_message.argtypes = [vp, vp, sz, vp, sz, pvp, C.POINTER(File)]
         L.mp3s_clear_file.argtypes = [vp, vp, sz, pvp, C.POINTER(File)]
+        L.mp3s_hide_messages.argtypes = [vp, vp, vp, i32, vp, vp, pvp, vp, vp]
         L.mp3s_reveal_message.argtypes = [vp, sz, pvp, C.POINTER(File)]
         _lib = L
     return _lib
@@ -404,6 +405,36 @@ class Context:
         owner, f = C.c_void_p(), File()
         check(lib().mp3s_clear_file(self.handle, buf.ctypes.data, len(mp3), C.byref(owner), C.byref(f)))
         return self._file(f, owner)
+
+    def hide_messages(self, mp3s, messages):
+        """hide_message / clear_file (message None) over a list of files as one device batch per (rate, bitrate).
+        Returns one entry per file: the dict hide_message returns, or the Mp3sError that file alone would raise."""
+        n = len(mp3s)
+        if n != len(messages):
+            raise ValueError("one message (or None) per file")
+        if n == 0:
+            return []
+        bufs = [np.frombuffer(m, dtype=np.uint8) for m in mp3s]
+        msgs = [None if t is None else np.frombuffer(t.encode("utf-8") or b"\0", dtype=np.uint8) for t in messages]
+        files = (C.c_void_p * n)(*[b.ctypes.data for b in bufs])
+        lens = (C.c_size_t * n)(*[len(b) for b in bufs])
+        mptr = (C.c_void_p * n)(*[None if m is None else m.ctypes.data for m in msgs])
+        mlen = (C.c_size_t * n)(*[0 if t is None else len(t.encode("utf-8")) for t in messages])
+        out, status, owner = (File * n)(), (C.c_int32 * n)(), C.c_void_p()
+        check(lib().mp3s_hide_messages(self.handle, files, lens, n, mptr, mlen, C.byref(owner), out, status))
+        try:
+            res = []
+            for i in range(n):
+                f = out[i]
+                if status[i]:
+                    res.append(Mp3sError(status[i], f"file {i}"))
+                else:
+                    res.append({"data": C.string_at(f.data, f.len) if f.len else b"", "kbps": f.kbps, "sampling_rate": f.sampling_rate,
+                                "channels": f.channels, "n_frames": f.n_frames, "too_long": bool(f.too_long),
+                                "hide_offset": f.hide_offset})
+            return res
+        finally:
+            lib().mp3s_buf_free(owner)
 
 
 def reveal_message(mp3: bytes):

@@ -27,7 +27,7 @@ def test_every_declared_symbol_is_exported(mlib):
 def test_record_sizes(mlib):
     assert C.sizeof(mlib.GranuleSI) == 72
     assert mlib.GRANULE_SI_DTYPE.itemsize == 72 and mlib.FRAME_HDR_DTYPE.itemsize == 8
-    assert mlib.GR_OUT_DTYPE.itemsize == 72 and mlib.RATE_FRAME_DTYPE.itemsize == 8
+    assert mlib.GR_OUT_DTYPE.itemsize == 72 and mlib.RATE_FRAME_DTYPE.itemsize == 16
     assert b"gfx950" in mlib.lib().mp3s_version()
 
 
