@@ -57,6 +57,7 @@ def main():
     ap.add_argument("--frames", type=int, default=10000, help="frames per GPU per step")
     ap.add_argument("--cpu-frames", type=int, default=10000, help="frames per pass of the CPU baseline (rank 0, N=1)")
     ap.add_argument("--cpu-seconds", type=float, default=10.0, help="the CPU baseline repeats its pass until this much time has gone by")
+    ap.add_argument("--cpu-seconds-all", type=float, default=6.0, help="duration of the all-cores run of the CPU baseline (0 = skip)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-overlap", action="store_true",
                     help="run the Huffman front end of batch k+1 after, not under, the transform kernels of batch k")
@@ -275,6 +276,19 @@ def main():
     hid = ctx.hide_message(enc0["mp3"], payload)
     t_hide = time.time() - t_h0
     same = same and hid["data"] == final["mp3"]
+    # many short files: the stream cut into 40-frame files, one device batch vs one call per file
+    fs = parsed["frame_size"].astype(np.int64)
+    cuts = np.concatenate([[0], np.cumsum(fs)])
+    shorts = [enc0["mp3"][int(cuts[a]):int(cuts[min(a + 40, n)])] for a in range(0, n, 40)]
+    notes = ["note %d" % i for i in range(len(shorts))]
+    _ = ctx.hide_messages(shorts, notes)
+    t_b0 = time.time()
+    batch_out = ctx.hide_messages(shorts, notes)
+    t_batch = time.time() - t_b0
+    t_l0 = time.time()
+    loop_out = [ctx.hide_message(f, m) for f, m in zip(shorts, notes)]
+    t_loop = time.time() - t_l0
+    same = same and all(not isinstance(b, Exception) and b["data"] == l["data"] for b, l in zip(batch_out, loop_out))
     kern = {k: (ms / max(cnt, 1)) for k, (ms, cnt) in prof.items()}           # avg ms per launch, timed region (dominant kernel)
     # duration of the dominant kernel per batch, from the event pairs of the TIMED region (for the rate loop: the full
     # pass plus, when the message needs it, the small re-run of the units whose cursor guess was wrong)
@@ -317,6 +331,21 @@ def main():
                "sample": f"{passes} pass(es) over the first {od['n_frames']} frames of the same stream: oracle decode (incl. "
                          f"Huffman) + int16 PCM + oracle encode (incl. bit packing), single thread, {dt:.1f} s",
                "host_cpus": os.cpu_count()}
+        # the same port on all host cores -- a child process (this one holds a GPU context and must not
+        # fork) that forks one worker per core, each looping over its own 400-frame cut of the stream
+        if args.cpu_seconds_all > 0 and n > 400:
+            import subprocess
+            import tempfile
+            with tempfile.TemporaryDirectory() as td:
+                open(os.path.join(td, "s.mp3"), "wb").write(enc0["mp3"])
+                np.save(os.path.join(td, "h.npy"), np.asarray(hide, dtype=np.uint8))
+                r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "cpu_all_cores.py"), os.path.join(td, "s.mp3"),
+                                    os.path.join(td, "h.npy"), str(args.cpu_seconds_all)], capture_output=True, text=True, timeout=300)
+            try:
+                cpu["all_cores"] = json.loads(r.stdout.strip().splitlines()[-1])
+                cpu["all_cores"]["x_one_thread"] = round(cpu["all_cores"]["value"] / cpu["value"], 1)
+            except Exception:
+                cpu["all_cores"] = {"error": (r.stderr or r.stdout)[-300:]}
 
     if rank == 0:
         out = {
@@ -345,7 +374,10 @@ def main():
                     "decode_stream_pipeline_s": round(t_dec_stream, 3),
                     "pcie_inclusive_frames_per_s": round(n / (t_dec_stream + t_pipe_host), 1),
                     "hide_message_bytes_to_bytes_s": round(t_hide, 4),
-                    "hide_message_frames_per_s": round(n / t_hide, 1)},
+                    "hide_message_frames_per_s": round(n / t_hide, 1),
+                    "short_files": {"files": len(shorts), "frames_each": 40, "hide_messages_one_batch_s": round(t_batch, 4),
+                                    "hide_message_per_file_loop_s": round(t_loop, 4),
+                                    "batch_files_per_s": round(len(shorts) / t_batch, 1)}},
             "device": ctx.device_name(),
         }
         print(json.dumps(out))

@@ -290,8 +290,10 @@ __global__ __launch_bounds__(RL_WAVES * 64, 4) void k_rate_loop(
     const int32_t *__restrict__ mdct, const mp3s_rate_frame *__restrict__ frames, int n_units,
     const uint8_t *__restrict__ hide, int n_hide, const int32_t *__restrict__ cursor_in,
     const int32_t *__restrict__ state_in, const int32_t *__restrict__ unit_list, int n_list,
-    int16_t *__restrict__ ix_out, mp3s_gr_out *__restrict__ out, int32_t *__restrict__ en_out, int out_base)
+    int16_t *__restrict__ ix_out, mp3s_gr_out *__restrict__ out, int32_t *__restrict__ en_out, int out_base, int compact)
 {
+    // compact (re-runs of a unit list): cursor_in / state_in / out are indexed by the position in the list, so that a
+    // pass moves a few bytes per listed unit over PCIe instead of whole-batch arrays; ix / en still land in place
     // results of unit u go to element u - out_base of the three output arrays (0 except for the message variants,
     // whose arrays hold one chunk of units)
     __shared__ RlTables tb;
@@ -324,7 +326,8 @@ __global__ __launch_bounds__(RL_WAVES * 64, 4) void k_rate_loop(
     const mp3s_rate_frame fr = frames[u >> 2];
     const int sr = sr_wg;
     const int max_bits = fr.max_bits;
-    const int cursor = (n_hide > 0 && cursor_in) ? cursor_in[u] : 0;
+    const int ci = compact ? li : u;
+    const int cursor = (n_hide > 0 && cursor_in) ? cursor_in[ci] : 0;
     n_hide = min(n_hide, fr.hide_end);            // streams of a batch keep their messages back to back in `hide`
 
     // ---- load xr, |xr|, xrsq >> 10 (:770-776, :837-838)
@@ -373,10 +376,10 @@ __global__ __launch_bounds__(RL_WAVES * 64, 4) void k_rate_loop(
         if (lane < 22) en_out[(long)(u - out_base) * 22 + lane] = en;
         RlState st;
         st.big_values = st.count1 = st.c1sel = st.r0c = st.r1c = 0;
-        st.a1 = state_in ? state_in[(long)u * 4 + 0] : 0;
-        st.a2 = state_in ? state_in[(long)u * 4 + 1] : 0;
-        st.a3 = state_in ? state_in[(long)u * 4 + 2] : 0;
-        int qstep = state_in ? state_in[(long)u * 4 + 3] : 0;
+        st.a1 = state_in ? state_in[(long)ci * 4 + 0] : 0;
+        st.a2 = state_in ? state_in[(long)ci * 4 + 1] : 0;
+        st.a3 = state_in ? state_in[(long)ci * 4 + 2] : 0;
+        int qstep = state_in ? state_in[(long)ci * 4 + 3] : 0;
         st.ts0 = st.ts1 = st.ts2 = 0;
         st.addr_fresh = false; st.used_addr_in = false;
         int32_t ix[2 * RL_NP];
@@ -462,7 +465,7 @@ __global__ __launch_bounds__(RL_WAVES * 64, 4) void k_rate_loop(
             o.reserved0 = 0;
             o.xrmax = (int32_t)xrmax;
             o.reserved = 0;
-            out[u - out_base] = o;
+            out[compact ? li : u - out_base] = o;
         }
     }
 }

@@ -4,12 +4,15 @@
 #include <hip/hip_runtime_api.h>
 
 #include <algorithm>
+#include <atomic>
+#include <chrono>
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
 #include <memory>
 #include <mutex>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/mp3s.h"
@@ -143,6 +146,29 @@ struct mp3s_buf {
     std::vector<int32_t> scfsi;
     std::vector<std::unique_ptr<mp3s_buf>> parts;   // results of the batches of a multi-file call
 };
+
+// MP3S_TRACE=1: phase timings of the file pipelines on stderr
+static bool trace_on() { static const bool on = getenv("MP3S_TRACE") != nullptr; return on; }
+static double now_ms() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+
+// f(i) for i in [0, n) on a few host threads: the front ends of the files of a batch are independent.  Small batches
+// (by bytes) stay on the calling thread -- starting a thread costs about what scanning 100 KB does.
+template <class F>
+static void parallel_files(int n, size_t total_bytes, F f)
+{
+    const unsigned hw = std::thread::hardware_concurrency();
+    const int workers = (int)std::min<size_t>({(size_t)n, (size_t)std::min(hw ? hw : 1u, 16u), total_bytes / (256u << 10) + 1});
+    if (workers <= 1) {
+        for (int i = 0; i < n; i++) f(i);
+        return;
+    }
+    std::atomic<int> next{0};
+    auto run = [&]() { for (int i; (i = next.fetch_add(1)) < n;) f(i); };
+    std::vector<std::thread> pool;
+    for (int w = 1; w < workers; w++) pool.emplace_back(run);
+    run();
+    for (auto &t : pool) t.join();
+}
 
 extern "C" {
 
@@ -679,11 +705,16 @@ static int decode_streams_impl(mp3s_ctx *c, const uint8_t *const *files, const s
     m.head_room = head_room;
     m.parsed.resize(n_files); m.scanned.resize(n_files); m.pcm.assign(n_files, nullptr); m.files.resize(n_files);
     std::vector<int> group[3];
+    size_t total = 0;
     for (int i = 0; i < n_files; i++) {
         if (!files[i]) { delete b; return fail(MP3S_E_ARG, "file %d is null", i); }
         m.files[i] = {files[i], lens[i]};
-        const int rc = front_end(files[i], lens[i], m.parsed[i], m.scanned[i]);
-        if (rc) { delete b; return fail(rc, "file %d: malformed or unsupported MP3 stream", i); }
+        total += lens[i];
+    }
+    std::vector<int> frc(n_files, MP3S_OK);
+    parallel_files(n_files, total, [&](int i) { frc[i] = front_end(files[i], lens[i], m.parsed[i], m.scanned[i]); });
+    for (int i = 0; i < n_files; i++) {
+        if (frc[i]) { delete b; return fail(frc[i], "file %d: malformed or unsupported MP3 stream", i); }
         if (m.parsed[i].n_frames > 0) group[m.parsed[i].nch].push_back(i);
     }
     for (int nch = 1; nch <= 2; nch++)
@@ -763,21 +794,27 @@ static int encode_batch(mp3s_ctx *c, const int16_t *pcm, const int16_t *pcm_dev,
     }
     HIPCHK(hipSetDevice(c->device));
 
-    void *d_pcm = nullptr, *d_hdr = nullptr, *d_mdct = nullptr, *d_rf = nullptr, *d_hide = nullptr, *d_cur = nullptr,
-         *d_state = nullptr, *d_list = nullptr, *d_ix = nullptr, *d_out = nullptr, *d_en = nullptr;
+    // every host-made input in one block, one copy: [frame headers | rate frames | cursors | message bits]
+    auto up16 = [](size_t x) { return (x + 15) & ~(size_t)15; };
+    const size_t o_rf = up16((size_t)n * sizeof(mp3s_frame_hdr)), o_cur = o_rf + up16((size_t)n * sizeof(mp3s_rate_frame)),
+                 o_hide = o_cur + up16((size_t)units * 4), in_bytes = o_hide + up16((size_t)n_hide);
+    void *d_pcm = nullptr, *d_in = nullptr, *d_mdct = nullptr, *d_state = nullptr, *d_list = nullptr, *d_redo = nullptr, *d_ix = nullptr,
+         *d_out = nullptr, *d_en = nullptr;
     auto cleanup = [&]() { hipStreamSynchronize(c->stream); };   // the buffers stay in the context's pool
     int slot = 8;
     auto alloc = [&](void **p, size_t bytes) { *p = c->grab(slot++, bytes); return *p != nullptr; };
     if (pcm_dev) { d_pcm = const_cast<int16_t *>(pcm_dev); slot++; }
     else if (!alloc(&d_pcm, (size_t)n * 2304 * 2)) d_pcm = nullptr;
-    if (!d_pcm || !alloc(&d_hdr, (size_t)n * sizeof(mp3s_frame_hdr)) ||
-        !alloc(&d_mdct, (size_t)n * 2304 * 4) || !alloc(&d_rf, (size_t)n * sizeof(mp3s_rate_frame)) ||
-        !alloc(&d_hide, (size_t)n_hide) || !alloc(&d_cur, (size_t)units * 4) || !alloc(&d_state, (size_t)units * 16) ||
-        !alloc(&d_list, (size_t)units * 4) || !alloc(&d_ix, (size_t)n * 2304 * 2) ||
+    if (!d_pcm || !alloc(&d_in, in_bytes) || !alloc(&d_mdct, (size_t)n * 2304 * 4) || !alloc(&d_state, (size_t)units * 16) ||
+        !alloc(&d_list, (size_t)units * 4) || !alloc(&d_redo, (size_t)units * 24) || !alloc(&d_ix, (size_t)n * 2304 * 2) ||
         !alloc(&d_out, (size_t)units * sizeof(mp3s_gr_out)) || !alloc(&d_en, (size_t)units * 22 * 4)) {
         cleanup();
         return fail(MP3S_E_NOMEM, "hipMalloc failed for a %d-frame encode", n);
     }
+    const mp3s_frame_hdr *d_hdr = (const mp3s_frame_hdr *)d_in;
+    const mp3s_rate_frame *d_rf = (const mp3s_rate_frame *)((uint8_t *)d_in + o_rf);
+    const int32_t *d_cur = (const int32_t *)((uint8_t *)d_in + o_cur);
+    const uint8_t *d_hide = (const uint8_t *)d_in + o_hide;
     std::vector<int32_t> cursor(units), state((size_t)units * 4, 0);
     std::vector<mp3s_gr_out> &gr = b->gr;
     gr.assign(units, mp3s_gr_out());
@@ -792,16 +829,17 @@ static int encode_batch(mp3s_ctx *c, const int16_t *pcm, const int16_t *pcm_dev,
         for (int j = 0; j < s.n_frames * 4; j++)
             cursor[(size_t)s.first * 4 + j] = long_msg ? kNoCursor : (int32_t)std::min<int64_t>((int64_t)s.hide_base + 3 * (int64_t)j, kNoCursor);
     }
+    std::vector<uint8_t> in(in_bytes, 0);
+    std::memcpy(in.data(), hdr.data(), (size_t)n * sizeof(mp3s_frame_hdr));
+    std::memcpy(in.data() + o_rf, rf.data(), (size_t)n * sizeof(mp3s_rate_frame));
+    std::memcpy(in.data() + o_cur, cursor.data(), (size_t)units * 4);
+    if (n_hide) std::memcpy(in.data() + o_hide, hide_all.data(), (size_t)n_hide);
     int rc = MP3S_OK;
-    if (!pcm_dev) rc = mp3s_dev_upload(c, d_pcm, pcm, (size_t)n * 2304 * 2);
-    if (!rc) rc = mp3s_dev_upload(c, d_hdr, hdr.data(), (size_t)n * sizeof(mp3s_frame_hdr));
-    if (!rc) rc = mp3s_dev_upload(c, d_rf, rf.data(), (size_t)n * sizeof(mp3s_rate_frame));
-    if (!rc && n_hide) rc = mp3s_dev_upload(c, d_hide, hide_all.data(), (size_t)n_hide);
-    if (!rc) rc = mp3s_dev_upload(c, d_cur, cursor.data(), (size_t)units * 4);
-    if (!rc) rc = mp3s_dev_upload(c, d_state, state.data(), (size_t)units * 16);
-    if (!rc) rc = mp3s_encode_transform_dev(c, (const int16_t *)d_pcm, (const mp3s_frame_hdr *)d_hdr, n, (int32_t *)d_mdct);
-    if (!rc) rc = mp3s_rate_loop_dev(c, (const int32_t *)d_mdct, (const mp3s_rate_frame *)d_rf, n, (const uint8_t *)d_hide,
-                                     n_hide, (const int32_t *)d_cur, (const int32_t *)d_state, nullptr, 0,
+    if (!pcm_dev && hipMemcpyAsync(d_pcm, pcm, (size_t)n * 2304 * 2, hipMemcpyHostToDevice, c->stream) != hipSuccess) rc = fail(MP3S_E_HIP, "PCM upload failed");
+    if (!rc && hipMemsetAsync(d_state, 0, (size_t)units * 16, c->stream) != hipSuccess) rc = fail(MP3S_E_HIP, "memset failed");
+    if (!rc) rc = mp3s_dev_upload(c, d_in, in.data(), in_bytes);
+    if (!rc) rc = mp3s_encode_transform_dev(c, (const int16_t *)d_pcm, d_hdr, n, (int32_t *)d_mdct);
+    if (!rc) rc = mp3s_rate_loop_dev(c, (const int32_t *)d_mdct, d_rf, n, d_hide, n_hide, d_cur, (const int32_t *)d_state, nullptr, 0,
                                      (int16_t *)d_ix, (mp3s_gr_out *)d_out, (int32_t *)d_en);
     if (!rc) rc = mp3s_dev_download(c, gr.data(), d_out, (size_t)units * sizeof(mp3s_gr_out));
     int passes = 1;
@@ -833,7 +871,7 @@ static int encode_batch(mp3s_ctx *c, const int16_t *pcm, const int16_t *pcm_dev,
                     int16_t *ixb = (int16_t *)d_ixv + (long)v * chunk * 576;
                     mp3s_gr_out *ob = (mp3s_gr_out *)d_outv + (long)v * chunk;
                     int32_t *eb = (int32_t *)d_env + (long)v * chunk * 22;
-                    const int e = launch_rate(c->stream, (const int32_t *)d_mdct, (const mp3s_rate_frame *)d_rf, n, (const uint8_t *)d_h3 + 4 * v,
+                    const int e = launch_rate(c->stream, (const int32_t *)d_mdct, d_rf, n, (const uint8_t *)d_h3 + 4 * v,
                                               3, nullptr, (const int32_t *)d_state, (const int32_t *)d_list, chunk, ixb, ob, eb, &c->prof, u0);
                     if (e) rc = fail(MP3S_E_HIP, "rate launch: %s", hipGetErrorString((hipError_t)e));
                     passes++;
@@ -862,7 +900,7 @@ static int encode_batch(mp3s_ctx *c, const int16_t *pcm, const int16_t *pcm_dev,
     }
     // ---- resolve the serial chains, stream by stream: hide cursor (MP3_Encoder.py:808-809) and the per-(gr,ch) inherited
     //      address1/2/3 + quantizerStepSize (E7).  Units whose assumed inputs were wrong are re-run.
-    std::vector<int32_t> list;
+    std::vector<int32_t> list, redo_in;
     std::vector<mp3s_gr_out> tmp;
     while (!rc) {
         list.clear();
@@ -901,17 +939,25 @@ static int encode_batch(mp3s_ctx *c, const int16_t *pcm, const int16_t *pcm_dev,
         }
         if (rc || list.empty()) break;
         if (++passes > units + 2) { rc = fail(MP3S_E_HIP, "rate-loop chain did not converge"); break; }
-        rc = mp3s_dev_upload(c, d_cur, cursor.data(), (size_t)units * 4);
-        if (!rc) rc = mp3s_dev_upload(c, d_state, state.data(), (size_t)units * 16);
-        if (!rc) rc = mp3s_dev_upload(c, d_list, list.data(), list.size() * 4);
-        if (!rc) rc = mp3s_rate_loop_dev(c, (const int32_t *)d_mdct, (const mp3s_rate_frame *)d_rf, n, (const uint8_t *)d_hide,
-                                         n_hide, (const int32_t *)d_cur, (const int32_t *)d_state, (const int32_t *)d_list,
-                                         (int)list.size(), (int16_t *)d_ix, (mp3s_gr_out *)d_out, (int32_t *)d_en);
-        // the list is ascending: fetch the span it covers, not all units
-        const int lo = list.front(), span = list.back() - lo + 1;
-        tmp.resize(span);
-        if (!rc) rc = mp3s_dev_download(c, tmp.data(), (const mp3s_gr_out *)d_out + lo, (size_t)span * sizeof(mp3s_gr_out));
-        if (!rc) for (int u : list) gr[u] = tmp[u - lo];
+        // per listed unit 24 bytes up (unit, cursor, inherited state) and its GrInfo down: [list | cursors | states]
+        const size_t nl = list.size();
+        redo_in.resize(nl * 6);
+        for (size_t i = 0; i < nl; i++) {
+            const int u = list[i];
+            redo_in[i] = u;
+            redo_in[nl + i] = cursor[u];
+            for (int j = 0; j < 4; j++) redo_in[2 * nl + 4 * i + j] = state[(size_t)u * 4 + j];
+        }
+        rc = mp3s_dev_upload(c, d_redo, redo_in.data(), nl * 24);
+        if (!rc) {
+            const int32_t *dr = (const int32_t *)d_redo;
+            const int e = launch_rate(c->stream, (const int32_t *)d_mdct, d_rf, n, d_hide, n_hide, dr + nl, dr + 2 * nl, dr, (int)nl,
+                                      (int16_t *)d_ix, (mp3s_gr_out *)d_out, (int32_t *)d_en, &c->prof, 0, true);
+            if (e) rc = fail(MP3S_E_HIP, "rate launch: %s", hipGetErrorString((hipError_t)e));
+        }
+        tmp.resize(nl);
+        if (!rc) rc = mp3s_dev_download(c, tmp.data(), d_out, nl * sizeof(mp3s_gr_out));
+        if (!rc) for (size_t i = 0; i < nl; i++) gr[list[i]] = tmp[i];
     }
     if (!rc) {
         // ---- bit packing on the device: final GrInfo + frame offsets up, MP3 bytes + scfsi down
@@ -1098,11 +1144,18 @@ static int reencode_group(mp3s_ctx *c, mp3s_multi &m, const std::vector<int> &id
     if (hipSetDevice(c->device) != hipSuccess) return fail(MP3S_E_HIP, "hipSetDevice failed");
     void *d_keep = c->grab(7, (size_t)rows_frames * 2304 * 2);
     if (!d_keep) return fail(MP3S_E_NOMEM, "hipMalloc failed for %lld frames of PCM", (long long)rows_frames);
+    const double t0 = trace_on() ? now_ms() : 0;
     int rc = decode_group(c, m, idx, 2, MP3S_PCM_I16, d_keep);
     if (rc) return rc;
+    if (trace_on()) hipStreamSynchronize(c->stream);
+    const double t1 = trace_on() ? now_ms() : 0;
     std::unique_ptr<mp3s_buf> part(new mp3s_buf());
-    rc = encode_batch(c, nullptr, (const int16_t *)d_keep, segs, samplerate, kbps, part.get(), nullptr);
+    int passes = 0;
+    rc = encode_batch(c, nullptr, (const int16_t *)d_keep, segs, samplerate, kbps, part.get(), &passes);
     if (rc) return rc;
+    if (trace_on())
+        fprintf(stderr, "mp3s:   %zu stream(s), %lld frames: decode %.3f ms, encode %.3f ms (%d rate passes)\n", idx.size(),
+                (long long)rows_frames, t1 - t0, now_ms() - t1, passes);
     for (size_t k = 0; k < idx.size(); k++) {
         mp3s_file &o = out[idx[k]];
         std::memset(&o, 0, sizeof o);
@@ -1127,13 +1180,19 @@ int mp3s_hide_messages(mp3s_ctx *c, const uint8_t *const *mp3s, const size_t *le
     std::vector<int32_t> st(n_files, MP3S_OK);
     struct Group { int rate, kbps; std::vector<int> idx; };
     std::vector<Group> groups;
+    size_t total = 0;
+    const double t0 = trace_on() ? now_ms() : 0;
     for (int i = 0; i < n_files; i++) {
         std::memset(&out[i], 0, sizeof out[i]);
-        if (!mp3s[i] || (msgs && msgs[i] == nullptr && msg_lens[i])) { st[i] = fail(MP3S_E_ARG, "file %d: null pointer", i); continue; }
+        if (!mp3s[i] || (msgs && msgs[i] == nullptr && msg_lens[i])) { st[i] = MP3S_E_ARG; continue; }
         m.files[i] = {mp3s[i], lens[i]};
+        total += lens[i];
+    }
+    parallel_files(n_files, total, [&](int i) { if (!st[i]) st[i] = front_end(mp3s[i], lens[i], m.parsed[i], m.scanned[i]); });
+    const double t1 = trace_on() ? now_ms() : 0;
+    for (int i = 0; i < n_files; i++) {
         int kbps = 0;
-        st[i] = front_end(mp3s[i], lens[i], m.parsed[i], m.scanned[i]);
-        if (st[i]) { fail(st[i], "file %d: malformed or unsupported MP3 stream", i); continue; }
+        if (st[i]) { fail(st[i], st[i] == MP3S_E_ARG ? "file %d: null pointer" : "file %d: malformed or unsupported MP3 stream", i); continue; }
         st[i] = reencode_check(m.parsed[i], &kbps);
         if (st[i]) continue;
         if (msgs && msgs[i]) message_frame(msgs[i], msg_lens[i], bits[i]);
@@ -1143,12 +1202,16 @@ int mp3s_hide_messages(mp3s_ctx *c, const uint8_t *const *mp3s, const size_t *le
         if (g == groups.size()) groups.push_back({rate, kbps, {}});
         groups[g].idx.push_back(i);
     }
+    const double t2 = trace_on() ? now_ms() : 0;
     for (const Group &g : groups) {
         const int rc = reencode_group(c, m, g.idx, bits, g.rate, g.kbps, top.get(), out);
         if (!rc) continue;
         // one stream spoils its batch (main data the host parser rejects ...): each file on its own, to name it
         for (int i : g.idx) st[i] = g.idx.size() == 1 ? rc : reencode_group(c, m, std::vector<int>{i}, bits, g.rate, g.kbps, top.get(), out);
     }
+    if (trace_on())
+        fprintf(stderr, "mp3s: hide_messages, %d file(s): scan %.3f ms, messages + grouping %.3f ms, device batches %.3f ms\n", n_files,
+                t1 - t0, t2 - t1, now_ms() - t2);
     m.files.clear();   // borrowed pointers
     int first_bad = MP3S_OK;
     for (int i = 0; i < n_files; i++) {

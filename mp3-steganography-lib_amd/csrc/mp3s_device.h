@@ -45,7 +45,8 @@ int launch_encode(hipStream_t stream, const int16_t *d_pcm, const mp3s_frame_hdr
 int launch_rate(hipStream_t stream, const int32_t *d_mdct, const mp3s_rate_frame *d_frames, int n_frames,
                 const uint8_t *d_hide, int n_hide, const int32_t *d_cursor, const int32_t *d_state,
                 const int32_t *d_list, int n_list, int16_t *d_ix, mp3s_gr_out *d_out, int32_t *d_en, Profiler *prof,
-                int out_base = 0 /* unit whose results land on element 0 of d_ix / d_out / d_en */);
+                int out_base = 0 /* unit whose results land on element 0 of d_ix / d_out / d_en */,
+                bool compact = false /* d_cursor / d_state / d_out are indexed by the position in d_list */);
 
 // bit-level stages on the device
 int launch_huffman(hipStream_t stream, const uint8_t *d_blob, const mp3s_frame_side *d_side, int n_frames, int nch, int max_bits,

@@ -107,14 +107,15 @@ int launch_encode(hipStream_t stream, const int16_t *d_pcm, const mp3s_frame_hdr
 
 int launch_rate(hipStream_t stream, const int32_t *d_mdct, const mp3s_rate_frame *d_frames, int n_frames,
                 const uint8_t *d_hide, int n_hide, const int32_t *d_cursor, const int32_t *d_state,
-                const int32_t *d_list, int n_list, int16_t *d_ix, mp3s_gr_out *d_out, int32_t *d_en, Profiler *prof, int out_base)
+                const int32_t *d_list, int n_list, int16_t *d_ix, mp3s_gr_out *d_out, int32_t *d_en, Profiler *prof, int out_base, bool compact)
 {
     const int n_units = n_frames * 4;
+    if (compact && !d_list) return (int)hipErrorInvalidValue;
     const int n = d_list ? n_list : n_units;
     if (n <= 0) return 0;
     const int pp = prof ? prof->begin(stream, K_RATE_LOOP) : -1;
     hipLaunchKernelGGL(k_rate_loop, dim3((n + RL_WAVES - 1) / RL_WAVES), dim3(RL_WAVES * 64), 0, stream, d_mdct, d_frames,
-                       n_units, d_hide, n_hide, d_cursor, d_state, d_list, n, d_ix, d_out, d_en, out_base);
+                       n_units, d_hide, n_hide, d_cursor, d_state, d_list, n, d_ix, d_out, d_en, out_base, compact ? 1 : 0);
     if (prof) prof->end(stream, pp);
     return (int)hipGetLastError();
 }
