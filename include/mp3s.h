@@ -293,6 +293,14 @@ int mp3s_decode_stream(mp3s_ctx *ctx, const uint8_t *file, size_t len, int out_f
 int mp3s_decode_streams(mp3s_ctx *ctx, const uint8_t *const *files, const size_t *lens, int n_files, int out_format,
                         mp3s_buf **owner, mp3s_decoded *out);
 
+/* Frames [first_frame, first_frame + n_frames) of the stream (clipped to its end) -- the decode half of sharding one
+ * stream over several GPUs.  The whole file is scanned on the host; only the block's main data plus one frame
+ * in front of it goes to the device (IMDCT overlap and synthesis fifo reach back less than a frame: reference
+ * decoder/Frame.py:151-153, 81-92).  Concatenating the blocks' PCM gives mp3s_decode_stream's.  n_frames / n_rows
+ * describe the block; bits / bit_rate / sampling_rate the whole stream. */
+int mp3s_decode_block(mp3s_ctx *ctx, const uint8_t *file, size_t len, int64_t first_frame, int64_t n_frames, int out_format,
+                      mp3s_buf **owner, mp3s_decoded *out);
+
 /* replaces: Encoder.encode -- reference encoder/encoder.py:33-58, MP3_Encoder.py:596-618 */
 typedef struct {
     int32_t n_frames;
@@ -306,6 +314,27 @@ typedef struct {
 } mp3s_encoded;
 int mp3s_encode_pcm(mp3s_ctx *ctx, const int16_t *pcm, int64_t n_samples_per_ch, int nch, int samplerate,
                     int bitrate_kbps, const uint8_t *hide_bits, int n_hide, mp3s_buf **owner, mp3s_encoded *out);
+
+/* One contiguous block of a longer stream, for a stream sharded over several GPUs.  What crosses a block
+ * boundary in the reference encoder: < 1 frame of filter-bank / MDCT history (MP3_Encoder.py:356,685,747: `lead_frames`
+ * = 1 frame of PCM in front of the block is transformed and dropped), the padding recurrence (:630-636: restarted from
+ * frame 0 by `first_frame`), and two serial chains, passed explicitly: */
+typedef struct {
+    int64_t cursor;        /* message bits consumed by the frames in front of the block (MP3_Encoder.py:808-809) */
+    int32_t chain[4][4];   /* per ch*2+gr: address1, address2, address3, quantizerStepSize as the frame in front left
+                            * them (they are only re-written by granules that carry data: SURVEY E7) */
+} mp3s_carry;
+/* pcm        : int16 [(lead_frames + n) * 1152][2], n = the block's own frames; stereo only
+ * first_frame: index of the block's first own frame in the stream;  last_block: the stream ends with this block
+ * hide_bits  : the WHOLE message (cursors are absolute);  carry_in NULL = the block starts the stream
+ * carry_out  : what the next block needs;  *carry_used = the block's bytes depend on carry_in (a caller that ran the
+ *              block on a guessed carry_in re-runs it only if this is set and the guess was wrong)
+ * out        : mp3 = the block's frames (concatenating the blocks gives the stream mp3s_encode_pcm produces),
+ *              hide_offset counts from the start of the stream; too_long is meaningful for the last block */
+int mp3s_encode_block(mp3s_ctx *ctx, const int16_t *pcm, int64_t n_samples_per_ch, int lead_frames, int64_t first_frame,
+                      int last_block, int samplerate, int bitrate_kbps, const uint8_t *hide_bits, int n_hide,
+                      const mp3s_carry *carry_in, mp3s_carry *carry_out, int32_t *carry_used, mp3s_buf **owner,
+                      mp3s_encoded *out);
 
 /* ---------------------------------------------------------------- (vi) files and messages */
 /* Whole files as byte strings in, byte strings out: WAV and MP3 containers, message framing and the facade's three

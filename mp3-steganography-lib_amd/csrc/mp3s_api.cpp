@@ -549,7 +549,51 @@ struct mp3s_multi {     // owner payload of mp3s_decode_streams
     PinnedBlock arena[3];                 // PCM of all mono / all stereo streams, index = channel count
     size_t head_room = 0;                 // bytes kept free in front of the PCM (mp3s_decode_file puts the WAV header there)
     std::vector<const uint8_t *> pcm;     // per stream, into its arena
+    // mp3s_decode_block: only frames [first, first + count) of stream i are kept after parsing (absent: all of them)
+    std::vector<std::pair<long, long>> window;
+    std::vector<std::vector<uint8_t>> all_bits;   // ... and the stego bits of the whole stream
 };
+
+// keep frames [first, first + count) of a parsed stream (its main data, side records, samples)
+static void cut_window(ParsedStream &p, ScannedStream &sc, long first, long count)
+{
+    const long n = p.n_frames;
+    first = std::min(std::max(first, 0L), n);
+    count = std::min(std::max(count, 0L), n - first);
+    auto cut = [&](auto &v, size_t per) {
+        if (v.size() >= (size_t)n * per) v.assign(v.begin() + (size_t)first * per, v.begin() + (size_t)(first + count) * per);
+    };
+    if (!sc.side.empty()) {
+        const size_t b0 = first < n ? sc.side[first].md_off : sc.blob.size();
+        const size_t b1 = first + count < n ? sc.side[first + count].md_off : sc.blob.size();
+        sc.blob.assign(sc.blob.begin() + b0, sc.blob.begin() + std::max(b0, b1));
+        cut(sc.side, 1);
+        for (auto &fs : sc.side) fs.md_off -= (uint32_t)b0;
+    }
+    cut(p.is, 2304); cut(p.si, 4); cut(p.hdr, 1); cut(p.table_select, 12); cut(p.frame_size, 1);
+    if (first + count < n) p.dup_last_frame = 0;   // the repeated last frame belongs to the block that ends the stream
+    p.n_frames = (int)count;
+}
+
+// host front end of stream i of m: byte-level scan; scalefactors + Huffman run on the device unless the stream inherits
+// scalefactors across frames (mixed blocks ...) or `full` asks for it, in which case the host parser produces its frames
+static int front_end(mp3s_multi &m, int i, bool full = false)
+{
+    ParsedStream &p = m.parsed[i];
+    ScannedStream &sc = m.scanned[i];
+    int rc = full ? MP3S_OK : parse_stream(m.files[i].first, m.files[i].second, p, &sc);
+    if (!rc && (full || !sc.gpu_ok)) {
+        rc = parse_stream(m.files[i].first, m.files[i].second, p, nullptr);
+        sc.gpu_ok = false;
+        sc.side.clear(); sc.blob.clear();   // (possibly cut to a window already; not used for host-parsed streams)
+    }
+    // no sync where the stream should start: the reference parses nothing and writes an empty WAV (MP3_Parser.py:37-46)
+    if (!rc && (size_t)i < m.window.size()) {
+        if ((size_t)i < m.all_bits.size()) m.all_bits[i] = p.bits;
+        cut_window(p, sc, m.window[i].first, m.window[i].second);
+    }
+    return rc;
+}
 
 // Decode the streams listed in `idx` (all with the same channel count) as ONE batch.
 // d_keep != nullptr: the PCM of the group stays on the device there (frames back to back, a duplicated last frame
@@ -610,10 +654,9 @@ static int decode_group(mp3s_ctx *c, mp3s_multi &m, const std::vector<int> &idx,
                 const int i = idx[k];
                 if (!m.scanned[i].gpu_ok) continue;
                 const int n_before = m.parsed[i].n_frames;
-                rc = parse_stream(m.files[i].first, m.files[i].second, m.parsed[i], nullptr);
+                rc = front_end(m, i, true);
                 if (rc) { rc = fail(rc, "file %d: malformed main data", i); break; }
                 if (m.parsed[i].n_frames != n_before) { rc = fail(MP3S_E_MALFORMED, "file %d: inconsistent parse", i); break; }
-                m.scanned[i].gpu_ok = false;
                 any_host = true;
             }
         }
@@ -684,16 +727,6 @@ static int decode_group(mp3s_ctx *c, mp3s_multi &m, const std::vector<int> &idx,
     return rc;
 }
 
-// host front end of one file: byte-level scan; scalefactors + Huffman run on the device unless the stream inherits
-// scalefactors across frames (mixed blocks ...), in which case the host parser produces its frames
-static int front_end(const uint8_t *file, size_t len, ParsedStream &p, ScannedStream &sc)
-{
-    int rc = parse_stream(file, len, p, &sc);
-    if (!rc && !sc.gpu_ok) rc = parse_stream(file, len, p, nullptr);
-    // no sync where the stream should start: the reference parses nothing and writes an empty WAV (MP3_Parser.py:37-46)
-    return rc;
-}
-
 static int decode_streams_impl(mp3s_ctx *c, const uint8_t *const *files, const size_t *lens, int n_files, int out_format,
                                size_t head_room, mp3s_buf **owner, mp3s_decoded *out)
 {
@@ -712,7 +745,7 @@ static int decode_streams_impl(mp3s_ctx *c, const uint8_t *const *files, const s
         total += lens[i];
     }
     std::vector<int> frc(n_files, MP3S_OK);
-    parallel_files(n_files, total, [&](int i) { frc[i] = front_end(files[i], lens[i], m.parsed[i], m.scanned[i]); });
+    parallel_files(n_files, total, [&](int i) { frc[i] = front_end(m, i); });
     for (int i = 0; i < n_files; i++) {
         if (frc[i]) { delete b; return fail(frc[i], "file %d: malformed or unsupported MP3 stream", i); }
         if (m.parsed[i].n_frames > 0) group[m.parsed[i].nch].push_back(i);
@@ -738,6 +771,38 @@ int mp3s_decode_streams(mp3s_ctx *c, const uint8_t *const *files, const size_t *
     return decode_streams_impl(c, files, lens, n_files, out_format, 0, owner, out);
 }
 
+int mp3s_decode_block(mp3s_ctx *c, const uint8_t *file, size_t len, int64_t first_frame, int64_t n_frames, int out_format,
+                      mp3s_buf **owner, mp3s_decoded *out)
+{
+    if (!c || !file || !owner || !out || first_frame < 0 || n_frames <= 0 || first_frame > 0x7fffffff || n_frames > 0x7fffffff)
+        return fail(MP3S_E_ARG, "bad argument");
+    if (out_format < 0 || out_format > 2) return fail(MP3S_E_ARG, "out_format=%d", out_format);
+    // one frame in front of the block is decoded for its state and dropped: the IMDCT overlap and the synthesis fifo
+    // reach back less than a frame (Frame.py:151-153, 81-92)
+    const int halo = first_frame > 0 ? 1 : 0;
+    std::unique_ptr<mp3s_buf> b(new mp3s_buf());
+    b->multi.reset(new mp3s_multi());
+    mp3s_multi &m = *b->multi;
+    m.parsed.resize(1); m.scanned.resize(1); m.pcm.assign(1, nullptr); m.files.assign(1, {file, len});
+    m.window.assign(1, {(long)first_frame - halo, (long)n_frames + halo});
+    m.all_bits.resize(1);
+    int rc = front_end(m, 0);
+    if (rc) return fail(rc, "malformed or unsupported MP3 stream");
+    const ParsedStream &p = m.parsed[0];
+    if (p.n_frames <= halo) return fail(MP3S_E_ARG, "the block starts behind the last frame of the stream");
+    if (p.nch < 1 || p.nch > 2) return fail(MP3S_E_MALFORMED, "channel count");
+    rc = decode_group(c, m, std::vector<int>{0}, p.nch, out_format);
+    if (rc) return rc;
+    m.files.clear();   // borrowed
+    const size_t frame_bytes = (size_t)1152 * p.nch * pcm_elem(out_format);
+    out->n_frames = p.n_frames - halo; out->nch = p.nch; out->sampling_rate = p.sampling_rate; out->bit_rate = p.bit_rate;
+    out->n_rows = (int64_t)1152 * (p.n_frames - halo + p.dup_last_frame);
+    out->pcm = m.pcm[0] + (size_t)halo * frame_bytes;
+    out->n_bits = (int32_t)m.all_bits[0].size(); out->bits = m.all_bits[0].data();
+    *owner = b.release();
+    return MP3S_OK;
+}
+
 int mp3s_decode_stream(mp3s_ctx *c, const uint8_t *file, size_t len, int out_format, mp3s_buf **owner, mp3s_decoded *out)
 {
     if (!file) return fail(MP3S_E_ARG, "null pointer");
@@ -751,10 +816,17 @@ struct EncSeg {             // one stream of an encode batch: frames back to bac
     int n_frames = 0;
     const uint8_t *hide = nullptr;   // 0/1 bytes
     int n_hide = 0;
+    // a block of a longer stream (mp3s_encode_block; only as the single stream of a batch)
+    int lead = 0;                    // frames of PCM in front of the block: transformed for their state, then dropped
+    int64_t first_frame = 0;         // index of the block's first frame in its stream (padding recurrence)
+    bool last = true;                // the stream ends with this block (the reference drops the cached tail there: E14)
+    const mp3s_carry *carry_in = nullptr;
     // filled by encode_batch
     int first = 0, hide_base = 0;
-    int64_t hide_offset = 0;         // message bits consumed
+    int64_t hide_offset = 0;         // message bits consumed (from the start of the stream)
     size_t mp3_off = 0, mp3_len = 0; // the stream's bytes inside the batch's output
+    mp3s_carry carry_out = {};
+    bool carry_used = false;         // the block's bytes depend on carry_in
 };
 
 // Encode the streams of `segs` (stereo, one sampling rate and bitrate) as ONE batch: transforms, rate loop, bit packing.
@@ -777,17 +849,22 @@ static int encode_batch(mp3s_ctx *c, const int16_t *pcm, const int16_t *pcm_dev,
         if (n64 > 0x7fffffff / 8 || hide64 >= kNoCursor - 8) return fail(MP3S_E_ARG, "encode batch too large");
     }
     if (n64 <= 0) return fail(MP3S_E_ARG, "empty encode batch");
-    const int n = (int)n64, units = n * 4, n_hide = (int)hide64;
+    const int lead = segs[0].lead;   // frames that only the transforms see
+    if (lead < 0 || lead > 2 || (segs.size() > 1 && (lead || segs[0].first_frame || segs[0].carry_in)))
+        return fail(MP3S_E_ARG, "a block of a longer stream is encoded on its own");
+    const int n = (int)n64, units = n * 4, n_hide = (int)hide64, n_all = n + lead;
     std::vector<mp3s_rate_frame> rf(n);
-    std::vector<mp3s_frame_hdr> hdr(n);
+    std::vector<mp3s_frame_hdr> hdr(n_all);
     std::vector<int32_t> padding(n);
     std::vector<uint8_t> hide_all((size_t)n_hide);
+    int64_t bytes_before = 0;
     for (const auto &s : segs) {
         // padding / slot lag restart with every stream (MP3_Encoder.py:623-636)
-        const int rc = rate_frames(samplerate, bitrate_kbps, 2, s.n_frames, rf.data() + s.first, padding.data() + s.first);
+        const int rc = rate_frames(samplerate, bitrate_kbps, 2, s.n_frames, rf.data() + s.first, padding.data() + s.first, s.first_frame,
+                                   &bytes_before);
         if (rc) return fail(rc, "unsupported samplerate/bitrate %d/%d", samplerate, bitrate_kbps);
-        for (int f = s.first; f < s.first + s.n_frames; f++) {
-            rf[f].hide_end = s.hide_base + s.n_hide;
+        for (int f = s.first; f < s.first + s.n_frames; f++) rf[f].hide_end = s.hide_base + s.n_hide;
+        for (int f = s.first; f < s.first + s.n_frames + lead; f++) {
             hdr[f].sr_idx = (uint8_t)sri; hdr[f].nch = 2; hdr[f].ms_stereo = 0; hdr[f].flags = 0; hdr[f].stream_first = (uint32_t)s.first;
         }
         if (s.n_hide) std::memcpy(hide_all.data() + s.hide_base, s.hide, (size_t)s.n_hide);
@@ -796,22 +873,23 @@ static int encode_batch(mp3s_ctx *c, const int16_t *pcm, const int16_t *pcm_dev,
 
     // every host-made input in one block, one copy: [frame headers | rate frames | cursors | message bits]
     auto up16 = [](size_t x) { return (x + 15) & ~(size_t)15; };
-    const size_t o_rf = up16((size_t)n * sizeof(mp3s_frame_hdr)), o_cur = o_rf + up16((size_t)n * sizeof(mp3s_rate_frame)),
+    const size_t o_rf = up16((size_t)n_all * sizeof(mp3s_frame_hdr)), o_cur = o_rf + up16((size_t)n * sizeof(mp3s_rate_frame)),
                  o_hide = o_cur + up16((size_t)units * 4), in_bytes = o_hide + up16((size_t)n_hide);
-    void *d_pcm = nullptr, *d_in = nullptr, *d_mdct = nullptr, *d_state = nullptr, *d_list = nullptr, *d_redo = nullptr, *d_ix = nullptr,
+    void *d_pcm = nullptr, *d_in = nullptr, *d_mdct_all = nullptr, *d_state = nullptr, *d_list = nullptr, *d_redo = nullptr, *d_ix = nullptr,
          *d_out = nullptr, *d_en = nullptr;
     auto cleanup = [&]() { hipStreamSynchronize(c->stream); };   // the buffers stay in the context's pool
     int slot = 8;
     auto alloc = [&](void **p, size_t bytes) { *p = c->grab(slot++, bytes); return *p != nullptr; };
     if (pcm_dev) { d_pcm = const_cast<int16_t *>(pcm_dev); slot++; }
-    else if (!alloc(&d_pcm, (size_t)n * 2304 * 2)) d_pcm = nullptr;
-    if (!d_pcm || !alloc(&d_in, in_bytes) || !alloc(&d_mdct, (size_t)n * 2304 * 4) || !alloc(&d_state, (size_t)units * 16) ||
+    else if (!alloc(&d_pcm, (size_t)n_all * 2304 * 2)) d_pcm = nullptr;
+    if (!d_pcm || !alloc(&d_in, in_bytes) || !alloc(&d_mdct_all, (size_t)n_all * 2304 * 4) || !alloc(&d_state, (size_t)units * 16) ||
         !alloc(&d_list, (size_t)units * 4) || !alloc(&d_redo, (size_t)units * 24) || !alloc(&d_ix, (size_t)n * 2304 * 2) ||
         !alloc(&d_out, (size_t)units * sizeof(mp3s_gr_out)) || !alloc(&d_en, (size_t)units * 22 * 4)) {
         cleanup();
         return fail(MP3S_E_NOMEM, "hipMalloc failed for a %d-frame encode", n);
     }
     const mp3s_frame_hdr *d_hdr = (const mp3s_frame_hdr *)d_in;
+    const int32_t *d_mdct = (const int32_t *)d_mdct_all + (size_t)lead * 2304;   // the block's own frames
     const mp3s_rate_frame *d_rf = (const mp3s_rate_frame *)((uint8_t *)d_in + o_rf);
     const int32_t *d_cur = (const int32_t *)((uint8_t *)d_in + o_cur);
     const uint8_t *d_hide = (const uint8_t *)d_in + o_hide;
@@ -823,23 +901,27 @@ static int encode_batch(mp3s_ctx *c, const int16_t *pcm, const int16_t *pcm_dev,
     // one launch per unit whose table count differs from the guess (about 1 in 40), so for them the rate loop runs once
     // per 3-bit pattern over the units the message can reach and the cursor walk below picks each unit's pattern.
     bool any_long = false;
+    auto cursor0 = [](const EncSeg &s) {   // message bits the frames in front of a block have taken
+        return s.carry_in ? std::min<int64_t>(std::max<int64_t>(s.carry_in->cursor, 0), kNoCursor) : 0;
+    };
     for (const auto &s : segs) {
-        const bool long_msg = s.n_hide > kLongMessageBits;
+        const int64_t c0 = cursor0(s);
+        const bool long_msg = s.n_hide - c0 > kLongMessageBits;
         any_long |= long_msg;
         for (int j = 0; j < s.n_frames * 4; j++)
-            cursor[(size_t)s.first * 4 + j] = long_msg ? kNoCursor : (int32_t)std::min<int64_t>((int64_t)s.hide_base + 3 * (int64_t)j, kNoCursor);
+            cursor[(size_t)s.first * 4 + j] = long_msg ? kNoCursor : (int32_t)std::min<int64_t>((int64_t)s.hide_base + c0 + 3 * (int64_t)j, kNoCursor);
     }
     std::vector<uint8_t> in(in_bytes, 0);
-    std::memcpy(in.data(), hdr.data(), (size_t)n * sizeof(mp3s_frame_hdr));
+    std::memcpy(in.data(), hdr.data(), (size_t)n_all * sizeof(mp3s_frame_hdr));
     std::memcpy(in.data() + o_rf, rf.data(), (size_t)n * sizeof(mp3s_rate_frame));
     std::memcpy(in.data() + o_cur, cursor.data(), (size_t)units * 4);
     if (n_hide) std::memcpy(in.data() + o_hide, hide_all.data(), (size_t)n_hide);
     int rc = MP3S_OK;
-    if (!pcm_dev && hipMemcpyAsync(d_pcm, pcm, (size_t)n * 2304 * 2, hipMemcpyHostToDevice, c->stream) != hipSuccess) rc = fail(MP3S_E_HIP, "PCM upload failed");
+    if (!pcm_dev && hipMemcpyAsync(d_pcm, pcm, (size_t)n_all * 2304 * 2, hipMemcpyHostToDevice, c->stream) != hipSuccess) rc = fail(MP3S_E_HIP, "PCM upload failed");
     if (!rc && hipMemsetAsync(d_state, 0, (size_t)units * 16, c->stream) != hipSuccess) rc = fail(MP3S_E_HIP, "memset failed");
     if (!rc) rc = mp3s_dev_upload(c, d_in, in.data(), in_bytes);
-    if (!rc) rc = mp3s_encode_transform_dev(c, (const int16_t *)d_pcm, d_hdr, n, (int32_t *)d_mdct);
-    if (!rc) rc = mp3s_rate_loop_dev(c, (const int32_t *)d_mdct, d_rf, n, d_hide, n_hide, d_cur, (const int32_t *)d_state, nullptr, 0,
+    if (!rc) rc = mp3s_encode_transform_dev(c, (const int16_t *)d_pcm, d_hdr, n_all, (int32_t *)d_mdct_all);
+    if (!rc) rc = mp3s_rate_loop_dev(c, d_mdct, d_rf, n, d_hide, n_hide, d_cur, (const int32_t *)d_state, nullptr, 0,
                                      (int16_t *)d_ix, (mp3s_gr_out *)d_out, (int32_t *)d_en);
     if (!rc) rc = mp3s_dev_download(c, gr.data(), d_out, (size_t)units * sizeof(mp3s_gr_out));
     int passes = 1;
@@ -856,10 +938,10 @@ static int encode_batch(mp3s_ctx *c, const int16_t *pcm, const int16_t *pcm_dev,
         std::vector<int32_t> lst(kChunk);
         std::vector<uint8_t> sel(kChunk);
         for (const auto &s : segs) {
-            if (s.n_hide <= kLongMessageBits) continue;
+            if (s.n_hide - cursor0(s) <= kLongMessageBits) continue;
             const int u_end = (s.first + s.n_frames) * 4;
             const int64_t end = (int64_t)s.hide_base + s.n_hide;
-            int64_t cur = s.hide_base;
+            int64_t cur = s.hide_base + cursor0(s);
             for (int u0 = s.first * 4, chunk = 0; u0 < u_end && cur < end && !rc; u0 += chunk) {
                 // as many units as the rest of the message can reach at two tables per unit (silent units take none: the
                 // loop simply goes round again), at most kChunk
@@ -871,7 +953,7 @@ static int encode_batch(mp3s_ctx *c, const int16_t *pcm, const int16_t *pcm_dev,
                     int16_t *ixb = (int16_t *)d_ixv + (long)v * chunk * 576;
                     mp3s_gr_out *ob = (mp3s_gr_out *)d_outv + (long)v * chunk;
                     int32_t *eb = (int32_t *)d_env + (long)v * chunk * 22;
-                    const int e = launch_rate(c->stream, (const int32_t *)d_mdct, d_rf, n, (const uint8_t *)d_h3 + 4 * v,
+                    const int e = launch_rate(c->stream, d_mdct, d_rf, n, (const uint8_t *)d_h3 + 4 * v,
                                               3, nullptr, (const int32_t *)d_state, (const int32_t *)d_list, chunk, ixb, ob, eb, &c->prof, u0);
                     if (e) rc = fail(MP3S_E_HIP, "rate launch: %s", hipGetErrorString((hipError_t)e));
                     passes++;
@@ -905,14 +987,19 @@ static int encode_batch(mp3s_ctx *c, const int16_t *pcm, const int16_t *pcm_dev,
     while (!rc) {
         list.clear();
         for (auto &s : segs) {
-            int64_t cur = s.hide_base;
+            int64_t cur = s.hide_base + cursor0(s);
             const int64_t end = (int64_t)s.hide_base + s.n_hide;
             int32_t chain[4][4] = {};   // [(ch*2+gr)][a1,a2,a3,step]
+            if (s.carry_in) std::memcpy(chain, s.carry_in->chain, sizeof chain);
+            bool own[4] = {false, false, false, false};   // the block has set chain[k] itself
+            s.carry_used = cur < end;                     // the message is still being hidden when the block starts
             for (int u = s.first * 4; u < (s.first + s.n_frames) * 4; u++) {
                 const int k = u & 3;
                 mp3s_gr_out &g = gr[u];
                 bool redo = false;
                 const bool active = g.flags & MP3S_RF_ACTIVE;
+                if (!own[k] && (!active || (g.flags & MP3S_RF_USED_ADDR_IN))) s.carry_used = true;
+                if (active) own[k] = true;
                 if (s.n_hide > 0 && active) {
                     const int64_t used = cursor[u];
                     if (used != cur && std::min<int64_t>(used, cur) < end) redo = true;
@@ -935,6 +1022,8 @@ static int encode_batch(mp3s_ctx *c, const int16_t *pcm, const int16_t *pcm_dev,
                 if (g.flags & MP3S_RF_STEP_RANGE) { rc = fail(MP3S_E_STEP_RANGE, "quantizer step left the table in unit %d", u); break; }
             }
             s.hide_offset = cur - s.hide_base;
+            s.carry_out.cursor = s.hide_offset;
+            std::memcpy(s.carry_out.chain, chain, sizeof chain);
             if (rc) break;
         }
         if (rc || list.empty()) break;
@@ -951,7 +1040,7 @@ static int encode_batch(mp3s_ctx *c, const int16_t *pcm, const int16_t *pcm_dev,
         rc = mp3s_dev_upload(c, d_redo, redo_in.data(), nl * 24);
         if (!rc) {
             const int32_t *dr = (const int32_t *)d_redo;
-            const int e = launch_rate(c->stream, (const int32_t *)d_mdct, d_rf, n, d_hide, n_hide, dr + nl, dr + 2 * nl, dr, (int)nl,
+            const int e = launch_rate(c->stream, d_mdct, d_rf, n, d_hide, n_hide, dr + nl, dr + 2 * nl, dr, (int)nl,
                                       (int16_t *)d_ix, (mp3s_gr_out *)d_out, (int32_t *)d_en, &c->prof, 0, true);
             if (e) rc = fail(MP3S_E_HIP, "rate launch: %s", hipGetErrorString((hipError_t)e));
         }
@@ -979,7 +1068,9 @@ static int encode_batch(mp3s_ctx *c, const int16_t *pcm, const int16_t *pcm_dev,
         if (!rc && st) rc = fail(MP3S_E_HIP, "bit packer reported status %d", st);
         for (auto &s : segs) {
             s.mp3_off = off[s.first];
-            s.mp3_len = ((size_t)(off[s.first + s.n_frames] - off[s.first]) / 4) * 4;   // the reference drops the cached tail (< 32 bits): E14
+            s.mp3_len = off[s.first + s.n_frames] - off[s.first];
+            // the reference drops the cached tail (< 32 bits) at the end of the stream: E14
+            if (s.last) s.mp3_len -= std::min<size_t>(s.mp3_len, (size_t)((bytes_before + (int64_t)s.mp3_len) % 4));
         }
         const size_t total = segs.back().mp3_off + segs.back().mp3_len;
         b->bytes.resize(total);
@@ -1011,6 +1102,38 @@ static int encode_core(mp3s_ctx *c, const int16_t *pcm, const int16_t *pcm_dev, 
     out->hide_offset = segs[0].hide_offset;
     out->too_long = out->hide_offset < (int64_t)n_hide - 1 ? 1 : 0;
     out->mp3 = b->bytes.data(); out->mp3_len = segs[0].mp3_len;
+    out->gr = b->gr.data(); out->scfsi = b->scfsi.data();
+    out->rate_passes = passes;
+    *owner = b.release();
+    return MP3S_OK;
+}
+
+int mp3s_encode_block(mp3s_ctx *c, const int16_t *pcm, int64_t n_samples_per_ch, int lead_frames, int64_t first_frame, int last_block,
+                      int samplerate, int bitrate_kbps, const uint8_t *hide_bits, int n_hide, const mp3s_carry *carry_in,
+                      mp3s_carry *carry_out, int32_t *carry_used, mp3s_buf **owner, mp3s_encoded *out)
+{
+    if (!c || !pcm || !owner || !out) return fail(MP3S_E_ARG, "null pointer");
+    if (lead_frames < 0 || lead_frames > 2 || first_frame < 0 || (first_frame == 0 && (lead_frames || carry_in)) ||
+        (first_frame > 0 && !carry_in))
+        return fail(MP3S_E_ARG, "block arguments: the first block has no lead and no carry, later blocks have a carry");
+    if (n_samples_per_ch % 1152 || n_samples_per_ch / 1152 <= lead_frames)
+        return fail(MP3S_E_UNSUPPORTED, "sample count %lld is not a multiple of 1152 / holds no frame of its own", (long long)n_samples_per_ch);
+    if (n_hide < 0 || (n_hide > 0 && !hide_bits)) return fail(MP3S_E_ARG, "bad hide arguments");
+    if (n_samples_per_ch / 1152 > 0x7fffffff / 8) return fail(MP3S_E_ARG, "too many frames");
+    std::vector<EncSeg> segs(1);
+    EncSeg &s = segs[0];
+    s.n_frames = (int)(n_samples_per_ch / 1152) - lead_frames; s.hide = hide_bits; s.n_hide = n_hide;
+    s.lead = lead_frames; s.first_frame = first_frame; s.last = last_block != 0; s.carry_in = carry_in;
+    std::unique_ptr<mp3s_buf> b(new mp3s_buf());
+    int passes = 0;
+    const int rc = encode_batch(c, pcm, nullptr, segs, samplerate, bitrate_kbps, b.get(), &passes);
+    if (rc) return rc;
+    if (carry_out) *carry_out = s.carry_out;
+    if (carry_used) *carry_used = s.carry_used ? 1 : 0;
+    out->n_frames = s.n_frames;
+    out->hide_offset = s.hide_offset;
+    out->too_long = out->hide_offset < (int64_t)n_hide - 1 ? 1 : 0;
+    out->mp3 = b->bytes.data(); out->mp3_len = s.mp3_len;
     out->gr = b->gr.data(); out->scfsi = b->scfsi.data();
     out->rate_passes = passes;
     *owner = b.release();
@@ -1188,7 +1311,7 @@ int mp3s_hide_messages(mp3s_ctx *c, const uint8_t *const *mp3s, const size_t *le
         m.files[i] = {mp3s[i], lens[i]};
         total += lens[i];
     }
-    parallel_files(n_files, total, [&](int i) { if (!st[i]) st[i] = front_end(mp3s[i], lens[i], m.parsed[i], m.scanned[i]); });
+    parallel_files(n_files, total, [&](int i) { if (!st[i]) st[i] = front_end(m, i); });
     const double t1 = trace_on() ? now_ms() : 0;
     for (int i = 0; i < n_files; i++) {
         int kbps = 0;

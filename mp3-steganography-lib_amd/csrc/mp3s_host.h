@@ -32,7 +32,9 @@ int parse_stream(const uint8_t *file, size_t len, ParsedStream &out, ScannedStre
 int stream_params(int samplerate, int bitrate_kbps, int *sri, int *bri, int *whole_slots);
 
 // per-frame padding bit and rate-loop budget (reference MP3_Encoder.py:503-513, 630-636, 894-912)
-int rate_frames(int samplerate, int bitrate_kbps, int nch, int n_frames, mp3s_rate_frame *out, int32_t *padding);
+// frames [first_frame, first_frame + n_frames) of a stream; bytes_before = size of the frames in front of them
+int rate_frames(int samplerate, int bitrate_kbps, int nch, int n_frames, mp3s_rate_frame *out, int32_t *padding,
+                int64_t first_frame = 0, int64_t *bytes_before = nullptr);
 
 // scfsi decision from the per-unit band energies (reference MP3_Encoder.py:861-892); en = [units][22]
 void decide_scfsi(int n_frames, const int32_t *en, const mp3s_gr_out *gr, int32_t *scfsi /*[n][2][4]*/);

@@ -71,12 +71,16 @@ int stream_params(int samplerate, int bitrate_kbps, int *sri, int *bri, int *who
     return 0;
 }
 
-int rate_frames(int samplerate, int bitrate_kbps, int nch, int n_frames, mp3s_rate_frame *out, int32_t *padding)
+int rate_frames(int samplerate, int bitrate_kbps, int nch, int n_frames, mp3s_rate_frame *out, int32_t *padding,
+                int64_t first_frame, int64_t *bytes_before)
 {
     const int sri = samplerate_index(samplerate);
-    if (sri < 0 || bitrate_index(bitrate_kbps) < 0 || nch < 1 || nch > 2) return MP3S_E_UNSUPPORTED;
+    if (sri < 0 || bitrate_index(bitrate_kbps) < 0 || nch < 1 || nch > 2 || first_frame < 0) return MP3S_E_UNSUPPORTED;
     SlotLag sl(samplerate, bitrate_kbps);
     const int side_info_len = 8 * (nch == 1 ? 4 + 17 : 4 + 32);
+    int64_t before = 0;
+    for (int64_t f = 0; f < first_frame; f++) before += sl.next() / 8;   // the padding recurrence has no closed form in fp64
+    if (bytes_before) *bytes_before = before;
     for (int f = 0; f < n_frames; f++) {
         const int bits_per_frame = sl.next();
         const int mean_bits = (int)((double)(bits_per_frame - side_info_len) / 2);

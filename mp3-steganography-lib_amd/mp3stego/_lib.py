@@ -77,6 +77,23 @@ class Encoded(C.Structure):
                 ("mp3_len", C.c_size_t), ("gr", C.c_void_p), ("scfsi", C.c_void_p), ("rate_passes", C.c_int32)]
 
 
+class Carry(C.Structure):
+    """what crosses a block boundary in the encoder: message cursor + per (ch*2+gr) address1..3 / quantizerStepSize"""
+    _fields_ = [("cursor", C.c_int64), ("chain", (C.c_int32 * 4) * 4)]
+
+    def to_array(self):
+        return np.array([self.cursor] + [self.chain[k][j] for k in range(4) for j in range(4)], dtype=np.int64)
+
+    @classmethod
+    def from_array(cls, a):
+        c = cls()
+        c.cursor = int(a[0])
+        for k in range(4):
+            for j in range(4):
+                c.chain[k][j] = int(a[1 + 4 * k + j])
+        return c
+
+
 class WavInfo(C.Structure):
     _fields_ = [("channels", C.c_int32), ("samplerate", C.c_int32), ("bits_per_sample", C.c_int32), ("bitrate", C.c_int32),
                 ("num_of_samples", C.c_int64), ("data_offset", C.c_int64), ("n_values", C.c_int64)]
@@ -93,7 +110,7 @@ SYMBOLS = ["mp3s_ctx_create", "mp3s_ctx_destroy", "mp3s_ctx_wait", "mp3s_last_er
            "mp3s_dev_alloc", "mp3s_dev_free", "mp3s_dev_upload", "mp3s_dev_download", "mp3s_dev_memset",
            "mp3s_timer_start", "mp3s_timer_stop", "mp3s_profile_enable", "mp3s_profile_select", "mp3s_profile_collect", "mp3s_decode_transform_dev", "mp3s_decode_transform",
            "mp3s_encode_transform_dev", "mp3s_encode_transform", "mp3s_rate_loop_dev", "mp3s_huffman_decode_dev", "mp3s_pack_frames_dev", "mp3s_scan_stream", "mp3s_buf_free",
-           "mp3s_parse_stream", "mp3s_format_stream", "mp3s_rate_frames", "mp3s_decode_stream", "mp3s_decode_streams", "mp3s_encode_pcm",
+           "mp3s_parse_stream", "mp3s_format_stream", "mp3s_rate_frames", "mp3s_decode_stream", "mp3s_decode_streams", "mp3s_decode_block", "mp3s_encode_pcm", "mp3s_encode_block",
            "mp3s_wav_parse", "mp3s_wav_header", "mp3s_message_frame", "mp3s_message_reveal", "mp3s_decode_file", "mp3s_encode_file",
            "mp3s_hide_message", "mp3s_clear_file", "mp3s_hide_messages", "mp3s_reveal_message"]
 
@@ -161,6 +178,9 @@ def lib():
         L.mp3s_encode_file.argtypes = [vp, vp, sz, i32, vp, i32, pvp, C.POINTER(File)]
         L.mp3s_hide_message.argtypes = [vp, vp, sz, vp, sz, pvp, C.POINTER(File)]
         L.mp3s_clear_file.argtypes = [vp, vp, sz, pvp, C.POINTER(File)]
+        L.mp3s_decode_block.argtypes = [vp, vp, sz, C.c_int64, C.c_int64, i32, pvp, C.POINTER(Decoded)]
+        L.mp3s_encode_block.argtypes = [vp, vp, C.c_int64, i32, C.c_int64, i32, i32, i32, vp, i32, C.POINTER(Carry), C.POINTER(Carry),
+                                        C.POINTER(C.c_int32), pvp, C.POINTER(Encoded)]
         L.mp3s_hide_messages.argtypes = [vp, vp, vp, i32, vp, vp, pvp, vp, vp]
         L.mp3s_reveal_message.argtypes = [vp, sz, pvp, C.POINTER(File)]
         _lib = L
@@ -319,6 +339,19 @@ class Context:
         return {"n_frames": d.n_frames, "channels": d.nch, "sampling_rate": d.sampling_rate, "bit_rate": d.bit_rate,
                 "pcm": _view_owned(d.pcm, dt, (d.n_rows, d.nch), own), "bits": _view(d.bits, np.uint8, (d.n_bits,))}
 
+    def decode_block(self, data: bytes, first_frame, n_frames, out_format=MP3S_PCM_I16):
+        """frames [first_frame, first_frame + n_frames) of the stream (clipped to its end): one shard of a stream that is
+        spread over several GPUs.  "bits", "bit_rate", "sampling_rate" describe the whole stream."""
+        buf = np.frombuffer(data, dtype=np.uint8)
+        owner = C.c_void_p()
+        d = Decoded()
+        check(lib().mp3s_decode_block(self.handle, buf.ctypes.data, len(data), int(first_frame), int(n_frames), out_format,
+                                      C.byref(owner), C.byref(d)))
+        own = _Owner(owner)
+        dt = {MP3S_PCM_I16: np.int16, MP3S_PCM_F32: np.float32, MP3S_PCM_F64: np.float64}[out_format]
+        return {"n_frames": d.n_frames, "channels": d.nch, "sampling_rate": d.sampling_rate, "bit_rate": d.bit_rate,
+                "pcm": _view_owned(d.pcm, dt, (d.n_rows, d.nch), own), "bits": _view(d.bits, np.uint8, (d.n_bits,))}
+
     def decode_streams(self, files, out_format=MP3S_PCM_I16):
         """Decode many MP3 files as one device batch (one Huffman + one transform launch per channel count)."""
         n = len(files)
@@ -354,6 +387,28 @@ class Context:
         finally:
             lib().mp3s_buf_free(owner)
 
+
+    def encode_block(self, pcm_i16, lead_frames, first_frame, last_block, samplerate, bitrate, hide_bits=None, carry_in=None):
+        """one contiguous block of a longer stream (include/mp3s.h mp3s_encode_block).  pcm_i16 holds lead_frames frames
+        in front of the block's own; carry_in / "carry_out" are int64[17] = cursor + 4x4 chain."""
+        pcm_i16 = np.ascontiguousarray(pcm_i16, dtype=np.int16)
+        if pcm_i16.ndim != 2 or pcm_i16.shape[1] != 2:
+            raise Mp3sError(E_UNSUPPORTED, "stereo PCM [rows][2] expected")
+        hb, nh = None, 0
+        if hide_bits is not None and len(hide_bits):
+            hb = np.ascontiguousarray(hide_bits, dtype=np.uint8)
+            nh = len(hb)
+        cin = Carry.from_array(carry_in) if carry_in is not None else None
+        cout, used, owner, e = Carry(), C.c_int32(0), C.c_void_p(), Encoded()
+        check(lib().mp3s_encode_block(self.handle, pcm_i16.ctypes.data, pcm_i16.shape[0], int(lead_frames), int(first_frame),
+                                      1 if last_block else 0, int(samplerate), int(bitrate), hb.ctypes.data if hb is not None else None, nh,
+                                      C.byref(cin) if cin is not None else None, C.byref(cout), C.byref(used), C.byref(owner), C.byref(e)))
+        try:
+            return {"n_frames": e.n_frames, "too_long": bool(e.too_long), "hide_offset": e.hide_offset,
+                    "mp3": _view(e.mp3, np.uint8, (e.mp3_len,)).tobytes(), "gr": _view(e.gr, GR_OUT_DTYPE, (e.n_frames * 4,)),
+                    "carry_out": cout.to_array(), "carry_used": bool(used.value), "rate_passes": e.rate_passes}
+        finally:
+            lib().mp3s_buf_free(owner)
 
     # ---- whole files as byte strings (include/mp3s.h section vi)
     @staticmethod
