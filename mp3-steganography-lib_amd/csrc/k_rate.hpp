@@ -293,7 +293,8 @@ __global__ __launch_bounds__(RL_WAVES * 64, 4) void k_rate_loop(
     int16_t *__restrict__ ix_out, mp3s_gr_out *__restrict__ out, int32_t *__restrict__ en_out, int out_base, int compact)
 {
     // compact (re-runs of a unit list): cursor_in / state_in / out are indexed by the position in the list, so that a
-    // pass moves a few bytes per listed unit over PCIe instead of whole-batch arrays; ix / en still land in place
+    // pass moves a few bytes per listed unit over PCIe instead of whole-batch arrays; ix / en still land in place.
+    // compact == 2 (message variants: the list names a unit once per 3-bit pattern): ix / en go by list position too
     // results of unit u go to element u - out_base of the three output arrays (0 except for the message variants,
     // whose arrays hold one chunk of units)
     __shared__ RlTables tb;
@@ -373,7 +374,7 @@ __global__ __launch_bounds__(RL_WAVES * 64, 4) void k_rate_loop(
             const int k = 31 - __builtin_clz((unsigned)temp);
             en = c_tab.en_base[k] + (temp >= c_tab.en_step[k] ? 1 : 0);
         }
-        if (lane < 22) en_out[(long)(u - out_base) * 22 + lane] = en;
+        if (lane < 22) en_out[(long)(compact == 2 ? li : u - out_base) * 22 + lane] = en;
         RlState st;
         st.big_values = st.count1 = st.c1sel = st.r0c = st.r1c = 0;
         st.a1 = state_in ? state_in[(long)ci * 4 + 0] : 0;
@@ -435,7 +436,7 @@ __global__ __launch_bounds__(RL_WAVES * 64, 4) void k_rate_loop(
         if (st.used_addr_in) flags |= MP3S_RF_USED_ADDR_IN;
 
         // ---- signed ix (format_bitstream :1272-1276) as int16 pairs
-        int16_t *ixo = ix_out + (long)(u - out_base) * 576;
+        int16_t *ixo = ix_out + (long)(compact == 2 ? li : u - out_base) * 576;
 #pragma unroll
         for (int m = 0; m < RL_NP; m++) {
             const int p = lane + 64 * m;
@@ -470,25 +471,22 @@ __global__ __launch_bounds__(RL_WAVES * 64, 4) void k_rate_loop(
     }
 }
 
-// Long messages (mp3s_encode_pcm): a unit's result depends on the message only through the <= 3 bits at its cursor, so
-// the rate loop is run once per 3-bit pattern and the host, walking the cursor chain, names the pattern each unit
-// really sees.  One wave per unit copies that variant's ix / GrInfo / energies into the final arrays.
-__global__ __launch_bounds__(256) void k_pick_variant(
-    const uint8_t *__restrict__ sel, int u0, int chunk, const int16_t *__restrict__ ixv, const mp3s_gr_out *__restrict__ outv,
-    const int32_t *__restrict__ env, int16_t *__restrict__ ix, mp3s_gr_out *__restrict__ out, int32_t *__restrict__ en)
+// Message variants (encode_batch): a unit's result depends on the message only through the <= 3 bits at its cursor, so
+// the units a message reaches are run once per 3-bit pattern (compact == 2 above) and the host, walking the cursor
+// chain, names the entry each unit really sees.  One wave per (entry, unit) pair copies that entry's ix / energies
+// into the unit's place in the final arrays (the GrInfo travels through the host).
+__global__ __launch_bounds__(256) void k_scatter_entries(const int2 *__restrict__ pairs, int n_pairs, const int16_t *__restrict__ ixv,
+                                                         const int32_t *__restrict__ env, int16_t *__restrict__ ix,
+                                                         int32_t *__restrict__ en)
 {
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
     const int j = blockIdx.x * 4 + wave;
-    if (j >= chunk) return;
-    const int v = sel[j];
-    if (v >= 8) return;                       // the unit keeps what it has
-    const long src = (long)v * chunk + j, dst = (long)u0 + j;
+    if (j >= n_pairs) return;
+    const int2 pr = pairs[j];
+    const long src = pr.x, dst = pr.y;
     const uint32_t *a = reinterpret_cast<const uint32_t *>(ixv + src * 576);
     uint32_t *b = reinterpret_cast<uint32_t *>(ix + dst * 576);
     for (int i = lane; i < 288; i += 64) b[i] = a[i];
-    const uint32_t *ga = reinterpret_cast<const uint32_t *>(outv + src);
-    uint32_t *gb = reinterpret_cast<uint32_t *>(out + dst);
-    if (lane < (int)(sizeof(mp3s_gr_out) / 4)) gb[lane] = ga[lane];
     if (lane < 22) en[dst * 22 + lane] = env[src * 22 + lane];
 }
 

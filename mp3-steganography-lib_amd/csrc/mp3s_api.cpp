@@ -809,8 +809,11 @@ int mp3s_decode_stream(mp3s_ctx *c, const uint8_t *file, size_t len, int out_for
     return mp3s_decode_streams(c, &file, &len, 1, out_format, owner, out);
 }
 
-constexpr int kLongMessageBits = 1024;   // below: a handful of small re-runs is cheaper than eight variant launches
+constexpr int kLongMessageBits = 1024;    // above: the first pass does not guess cursors at all
 constexpr int32_t kNoCursor = 0x3fffffff; // "behind every message": such a unit hides nothing
+constexpr int kPatternBytes = 32;         // the eight 3-bit patterns, 4 bytes apart, in front of the messages
+constexpr int kVariantEntries = 65536;    // (unit, pattern) entries per variant launch
+constexpr size_t kFewUnits = 8;           // that few wrong cursors after the first pass: re-run them directly
 
 struct EncSeg {             // one stream of an encode batch: frames back to back in the batch's PCM
     int n_frames = 0;
@@ -841,7 +844,7 @@ static int encode_batch(mp3s_ctx *c, const int16_t *pcm, const int16_t *pcm_dev,
     int sri = 0, bri = 0, whole = 0;
     if (stream_params(samplerate, bitrate_kbps, &sri, &bri, &whole))
         return fail(MP3S_E_UNSUPPORTED, "unsupported samplerate/bitrate %d/%d", samplerate, bitrate_kbps);
-    int64_t n64 = 0, hide64 = 0;
+    int64_t n64 = 0, hide64 = kPatternBytes;
     for (auto &s : segs) {
         if (s.n_frames <= 0 || s.n_hide < 0 || (s.n_hide > 0 && !s.hide)) return fail(MP3S_E_ARG, "bad stream in the encode batch");
         s.first = (int)n64; s.hide_base = (int)hide64;
@@ -856,7 +859,8 @@ static int encode_batch(mp3s_ctx *c, const int16_t *pcm, const int16_t *pcm_dev,
     std::vector<mp3s_rate_frame> rf(n);
     std::vector<mp3s_frame_hdr> hdr(n_all);
     std::vector<int32_t> padding(n);
-    std::vector<uint8_t> hide_all((size_t)n_hide);
+    std::vector<uint8_t> hide_all((size_t)n_hide, 0);   // [patterns | message of stream 0 | message of stream 1 ...]
+    for (int v = 0; v < 8; v++) { hide_all[4 * v] = (v >> 2) & 1; hide_all[4 * v + 1] = (v >> 1) & 1; hide_all[4 * v + 2] = v & 1; }
     int64_t bytes_before = 0;
     for (const auto &s : segs) {
         // padding / slot lag restart with every stream (MP3_Encoder.py:623-636)
@@ -896,18 +900,19 @@ static int encode_batch(mp3s_ctx *c, const int16_t *pcm, const int16_t *pcm_dev,
     std::vector<int32_t> cursor(units), state((size_t)units * 4, 0);
     std::vector<mp3s_gr_out> &gr = b->gr;
     gr.assign(units, mp3s_gr_out());
-    // A unit sees the message only through the <= 3 bits at its cursor.  Short messages: guess three tables per unit,
-    // run, prefix-sum the real counts and re-run what the guess got wrong (1-2 launches).  Long messages would need
-    // one launch per unit whose table count differs from the guess (about 1 in 40), so for them the rate loop runs once
-    // per 3-bit pattern over the units the message can reach and the cursor walk below picks each unit's pattern.
-    bool any_long = false;
+    // A unit sees the message only through the <= 3 bits at its cursor.  First pass: guess three tables per unit (for a
+    // short message in a long stream that is almost always right: one launch).  Where the guess fails, everything behind
+    // the first wrong unit shifts, and re-running shifts it again (hidden bits change bit counts, these the quantiser step,
+    // that the number of tables): pass by pass this converges one unit in fifteen at a time.  Instead the units the rest
+    // of the message can reach are run once per 3-bit pattern (entries = unit x pattern, one launch), the cursor walk
+    // names the entry each unit really sees, and only the message's last unit and the granules that inherit state are
+    // left for exact re-runs.
     auto cursor0 = [](const EncSeg &s) {   // message bits the frames in front of a block have taken
         return s.carry_in ? std::min<int64_t>(std::max<int64_t>(s.carry_in->cursor, 0), kNoCursor) : 0;
     };
     for (const auto &s : segs) {
         const int64_t c0 = cursor0(s);
         const bool long_msg = s.n_hide - c0 > kLongMessageBits;
-        any_long |= long_msg;
         for (int j = 0; j < s.n_frames * 4; j++)
             cursor[(size_t)s.first * 4 + j] = long_msg ? kNoCursor : (int32_t)std::min<int64_t>((int64_t)s.hide_base + c0 + 3 * (int64_t)j, kNoCursor);
     }
@@ -925,68 +930,20 @@ static int encode_batch(mp3s_ctx *c, const int16_t *pcm, const int16_t *pcm_dev,
                                      (int16_t *)d_ix, (mp3s_gr_out *)d_out, (int32_t *)d_en);
     if (!rc) rc = mp3s_dev_download(c, gr.data(), d_out, (size_t)units * sizeof(mp3s_gr_out));
     int passes = 1;
-    if (!rc && any_long) {
-        const int kChunk = 8192;   // units per round of eight variant launches
-        void *d_ixv = nullptr, *d_outv = nullptr, *d_env = nullptr, *d_sel = nullptr, *d_h3 = nullptr;
-        if (!alloc(&d_ixv, (size_t)8 * kChunk * 1152) || !alloc(&d_outv, (size_t)8 * kChunk * sizeof(mp3s_gr_out)) ||
-            !alloc(&d_env, (size_t)8 * kChunk * 88) || !alloc(&d_sel, kChunk) || !alloc(&d_h3, 32))
-            rc = fail(MP3S_E_NOMEM, "hipMalloc failed for the message variants");
-        uint8_t h3[32];
-        for (int v = 0; v < 8; v++) { h3[4 * v] = (v >> 2) & 1; h3[4 * v + 1] = (v >> 1) & 1; h3[4 * v + 2] = v & 1; h3[4 * v + 3] = 0; }
-        if (!rc) rc = mp3s_dev_upload(c, d_h3, h3, 32);
-        std::vector<mp3s_gr_out> gv((size_t)8 * kChunk);
-        std::vector<int32_t> lst(kChunk);
-        std::vector<uint8_t> sel(kChunk);
-        for (const auto &s : segs) {
-            if (s.n_hide - cursor0(s) <= kLongMessageBits) continue;
-            const int u_end = (s.first + s.n_frames) * 4;
-            const int64_t end = (int64_t)s.hide_base + s.n_hide;
-            int64_t cur = s.hide_base + cursor0(s);
-            for (int u0 = s.first * 4, chunk = 0; u0 < u_end && cur < end && !rc; u0 += chunk) {
-                // as many units as the rest of the message can reach at two tables per unit (silent units take none: the
-                // loop simply goes round again), at most kChunk
-                chunk = (int)std::min<int64_t>(std::min(kChunk, u_end - u0), (end - cur) / 2 + 64);
-                for (int j = 0; j < chunk; j++) lst[j] = u0 + j;
-                rc = mp3s_dev_upload(c, d_list, lst.data(), (size_t)chunk * 4);
-                for (int v = 0; v < 8 && !rc; v++) {
-                    // variant v of unit u0 + j lands on element v * chunk + j of the [8][chunk] arrays
-                    int16_t *ixb = (int16_t *)d_ixv + (long)v * chunk * 576;
-                    mp3s_gr_out *ob = (mp3s_gr_out *)d_outv + (long)v * chunk;
-                    int32_t *eb = (int32_t *)d_env + (long)v * chunk * 22;
-                    const int e = launch_rate(c->stream, d_mdct, d_rf, n, (const uint8_t *)d_h3 + 4 * v,
-                                              3, nullptr, (const int32_t *)d_state, (const int32_t *)d_list, chunk, ixb, ob, eb, &c->prof, u0);
-                    if (e) rc = fail(MP3S_E_HIP, "rate launch: %s", hipGetErrorString((hipError_t)e));
-                    passes++;
-                }
-                if (!rc) rc = mp3s_dev_download(c, gv.data(), d_outv, (size_t)8 * chunk * sizeof(mp3s_gr_out));
-                for (int j = 0; j < chunk && !rc; j++) {
-                    const int u = u0 + j;
-                    sel[j] = 255;
-                    if (cur + 3 <= end) {                         // all three bits the unit can ask for exist
-                        const int v = (hide_all[cur] & 1) * 4 + (hide_all[cur + 1] & 1) * 2 + (hide_all[cur + 2] & 1);
-                        sel[j] = (uint8_t)v;
-                        gr[u] = gv[(size_t)v * chunk + j];
-                        cursor[u] = (int32_t)cur;
-                    }                                             // else: the message ends inside or before this unit -- the
-                    cur += gr[u].n_tables;                        // consistency loop below re-runs it with its real cursor
-                }
-                if (!rc) rc = mp3s_dev_upload(c, d_sel, sel.data(), (size_t)chunk);
-                if (!rc) {
-                    const int e = launch_pick(c->stream, (const uint8_t *)d_sel, u0, chunk, (const int16_t *)d_ixv, (const mp3s_gr_out *)d_outv,
-                                              (const int32_t *)d_env, (int16_t *)d_ix, (mp3s_gr_out *)d_out, (int32_t *)d_en);
-                    if (e) rc = fail(MP3S_E_HIP, "variant pick: %s", hipGetErrorString((hipError_t)e));
-                }
-                if (!rc && hipStreamSynchronize(c->stream) != hipSuccess) rc = fail(MP3S_E_HIP, "sync failed");   // sel / lst are reused
-            }
-        }
-    }
     // ---- resolve the serial chains, stream by stream: hide cursor (MP3_Encoder.py:808-809) and the per-(gr,ch) inherited
-    //      address1/2/3 + quantizerStepSize (E7).  Units whose assumed inputs were wrong are re-run.
+    //      address1/2/3 + quantizerStepSize (E7).  walk() lists the units whose assumed inputs were wrong and, per stream,
+    //      where the cursor first went wrong.
     std::vector<int32_t> list, redo_in;
     std::vector<mp3s_gr_out> tmp;
-    while (!rc) {
+    struct Pending { int unit; int64_t cur; };   // first unit of a stream that ran on a wrong cursor, the right cursor there
+    std::vector<Pending> pend(segs.size());
+    // cursor / state: what each unit's current result was computed with; want / state_want: what the walk says it should be
+    std::vector<int32_t> want(units), state_want((size_t)units * 4, 0);
+    auto walk = [&]() {
         list.clear();
-        for (auto &s : segs) {
+        for (size_t si = 0; si < segs.size(); si++) {
+            EncSeg &s = segs[si];
+            pend[si] = {-1, 0};
             int64_t cur = s.hide_base + cursor0(s);
             const int64_t end = (int64_t)s.hide_base + s.n_hide;
             int32_t chain[4][4] = {};   // [(ch*2+gr)][a1,a2,a3,step]
@@ -1002,15 +959,18 @@ static int encode_batch(mp3s_ctx *c, const int16_t *pcm, const int16_t *pcm_dev,
                 if (active) own[k] = true;
                 if (s.n_hide > 0 && active) {
                     const int64_t used = cursor[u];
-                    if (used != cur && std::min<int64_t>(used, cur) < end) redo = true;
+                    if (used != cur && std::min<int64_t>(used, cur) < end) {
+                        redo = true;
+                        if (pend[si].unit < 0) pend[si] = {u, cur};
+                    }
                 }
                 if ((g.flags & MP3S_RF_USED_ADDR_IN) &&
                     (state[(size_t)u * 4] != chain[k][0] || state[(size_t)u * 4 + 1] != chain[k][1] ||
                      state[(size_t)u * 4 + 2] != chain[k][2]))
                     redo = true;
                 if (redo) list.push_back(u);
-                cursor[u] = (int32_t)std::min<int64_t>(cur, kNoCursor);
-                for (int j = 0; j < 4; j++) state[(size_t)u * 4 + j] = chain[k][j];
+                want[u] = (int32_t)std::min<int64_t>(cur, kNoCursor);
+                for (int j = 0; j < 4; j++) state_want[(size_t)u * 4 + j] = chain[k][j];
                 if (active) {
                     cur += g.n_tables;
                     chain[k][0] = g.address[0]; chain[k][1] = g.address[1]; chain[k][2] = g.address[2];
@@ -1019,34 +979,120 @@ static int encode_batch(mp3s_ctx *c, const int16_t *pcm, const int16_t *pcm_dev,
                     g.address[0] = chain[k][0]; g.address[1] = chain[k][1]; g.address[2] = chain[k][2];
                     g.quantizer_step = chain[k][3];
                 }
-                if (g.flags & MP3S_RF_STEP_RANGE) { rc = fail(MP3S_E_STEP_RANGE, "quantizer step left the table in unit %d", u); break; }
+                if (g.flags & MP3S_RF_STEP_RANGE) return fail(MP3S_E_STEP_RANGE, "quantizer step left the table in unit %d", u);
             }
             s.hide_offset = cur - s.hide_base;
             s.carry_out.cursor = s.hide_offset;
             std::memcpy(s.carry_out.chain, chain, sizeof chain);
-            if (rc) break;
         }
-        if (rc || list.empty()) break;
-        if (++passes > units + 2) { rc = fail(MP3S_E_HIP, "rate-loop chain did not converge"); break; }
-        // per listed unit 24 bytes up (unit, cursor, inherited state) and its GrInfo down: [list | cursors | states]
-        const size_t nl = list.size();
+        return (int)MP3S_OK;
+    };
+    // one launch over a list of (unit, cursor, inherited state) entries: 24 bytes per entry up -- [units | cursors | states]
+    // -- and the entries' GrInfo down (into tmp); compact = 1: ix / energies in place, 2: by entry into d_ixv / d_env
+    auto run_entries = [&](const std::vector<int32_t> &units_of, const std::vector<int32_t> &cursor_of, void *d_entries, int compact,
+                           int16_t *ix_to, mp3s_gr_out *out_to, int32_t *en_to) {
+        const size_t nl = units_of.size();
         redo_in.resize(nl * 6);
         for (size_t i = 0; i < nl; i++) {
-            const int u = list[i];
+            const int u = units_of[i];
             redo_in[i] = u;
-            redo_in[nl + i] = cursor[u];
-            for (int j = 0; j < 4; j++) redo_in[2 * nl + 4 * i + j] = state[(size_t)u * 4 + j];
+            redo_in[nl + i] = cursor_of[i];
+            for (int j = 0; j < 4; j++) redo_in[2 * nl + 4 * i + j] = state_want[(size_t)u * 4 + j];
         }
-        rc = mp3s_dev_upload(c, d_redo, redo_in.data(), nl * 24);
-        if (!rc) {
-            const int32_t *dr = (const int32_t *)d_redo;
-            const int e = launch_rate(c->stream, d_mdct, d_rf, n, d_hide, n_hide, dr + nl, dr + 2 * nl, dr, (int)nl,
-                                      (int16_t *)d_ix, (mp3s_gr_out *)d_out, (int32_t *)d_en, &c->prof, 0, true);
-            if (e) rc = fail(MP3S_E_HIP, "rate launch: %s", hipGetErrorString((hipError_t)e));
+        int r = mp3s_dev_upload(c, d_entries, redo_in.data(), nl * 24);
+        if (!r) {
+            const int32_t *dr = (const int32_t *)d_entries;
+            const int e = launch_rate(c->stream, d_mdct, d_rf, n, d_hide, n_hide, dr + nl, dr + 2 * nl, dr, (int)nl, ix_to, out_to, en_to,
+                                      &c->prof, 0, compact);
+            if (e) r = fail(MP3S_E_HIP, "rate launch: %s", hipGetErrorString((hipError_t)e));
         }
         tmp.resize(nl);
-        if (!rc) rc = mp3s_dev_download(c, tmp.data(), d_out, nl * sizeof(mp3s_gr_out));
-        if (!rc) for (size_t i = 0; i < nl; i++) gr[list[i]] = tmp[i];
+        if (!r) r = mp3s_dev_download(c, tmp.data(), out_to, nl * sizeof(mp3s_gr_out));
+        passes++;
+        return r;
+    };
+    if (!rc) rc = walk();
+    if (!rc && list.size() > kFewUnits) {
+        // ---- message variants
+        struct Span { size_t seg; int unit, count; int64_t cur; size_t entry; };
+        std::vector<Span> spans;
+        std::vector<int32_t> ent_unit, ent_cursor, pairs;
+        void *d_ent = nullptr, *d_ixv = nullptr, *d_outv = nullptr, *d_env = nullptr, *d_pairs = nullptr;
+        const int slot_var = slot;
+        for (bool more = true; more && !rc;) {
+            spans.clear(); ent_unit.clear(); ent_cursor.clear(); pairs.clear();
+            for (size_t si = 0; si < segs.size(); si++) {
+                if (pend[si].unit < 0) continue;
+                const EncSeg &s = segs[si];
+                const int64_t end = (int64_t)s.hide_base + s.n_hide;
+                if (pend[si].cur + 3 > end) { pend[si].unit = -1; continue; }   // only the message's last unit is left
+                // as many units as the rest of the message can reach at two tables per unit (silent units take none: the
+                // stream simply comes round again), as many as still fit into this launch
+                const int room = (kVariantEntries - (int)ent_unit.size()) / 8;
+                const int count = (int)std::min<int64_t>({(int64_t)(s.first + s.n_frames) * 4 - pend[si].unit, (end - pend[si].cur) / 2 + 16, (int64_t)room});
+                if (count <= 0) continue;                                       // next launch
+                spans.push_back({si, pend[si].unit, count, pend[si].cur, ent_unit.size()});
+                for (int v = 0; v < 8; v++)
+                    for (int j = 0; j < count; j++) { ent_unit.push_back(pend[si].unit + j); ent_cursor.push_back(4 * v); }
+            }
+            if (spans.empty()) break;
+            const size_t ne = ent_unit.size();
+            slot = slot_var;
+            if (!alloc(&d_ent, ne * 24) || !alloc(&d_ixv, ne * 1152) || !alloc(&d_outv, ne * sizeof(mp3s_gr_out)) ||
+                !alloc(&d_env, ne * 88) || !alloc(&d_pairs, ne))   // at most one pair per unit = ne / 8 pairs of 8 bytes
+                rc = fail(MP3S_E_NOMEM, "hipMalloc failed for the message variants");
+            if (!rc) rc = run_entries(ent_unit, ent_cursor, d_ent, 2, (int16_t *)d_ixv, (mp3s_gr_out *)d_outv, (int32_t *)d_env);
+            more = false;
+            for (const Span &sp : spans) {
+                if (rc) break;
+                const EncSeg &s = segs[sp.seg];
+                const int64_t end = (int64_t)s.hide_base + s.n_hide;
+                int64_t cur = sp.cur;
+                int j = 0;
+                for (; j < sp.count && cur + 3 <= end; j++) {     // all three bits the unit can ask for exist
+                    const int u = sp.unit + j;
+                    const int v = (hide_all[cur] & 1) * 4 + (hide_all[cur + 1] & 1) * 2 + (hide_all[cur + 2] & 1);
+                    const size_t e = sp.entry + (size_t)v * sp.count + j;
+                    gr[u] = tmp[e];
+                    cursor[u] = (int32_t)cur;
+                    for (int q = 0; q < 4; q++) state[(size_t)u * 4 + q] = state_want[(size_t)u * 4 + q];
+                    pairs.push_back((int32_t)e); pairs.push_back(u);
+                    cur += gr[u].n_tables;
+                }
+                // span used up with message left: the stream goes on in the next launch; otherwise the message's last unit
+                // (fewer than three bits left) and whatever lies behind it are the exact re-run's
+                if (j == sp.count && cur < end && sp.unit + sp.count < (s.first + s.n_frames) * 4) { pend[sp.seg] = {sp.unit + sp.count, cur}; more = true; }
+                else pend[sp.seg].unit = -1;
+            }
+            for (size_t si = 0; si < segs.size(); si++) more |= pend[si].unit >= 0;
+            if (!rc && !pairs.empty()) {
+                rc = mp3s_dev_upload(c, d_pairs, pairs.data(), pairs.size() * 4);
+                if (!rc) {
+                    const int e = launch_scatter(c->stream, (const int32_t *)d_pairs, (int)(pairs.size() / 2), (const int16_t *)d_ixv,
+                                                 (const int32_t *)d_env, (int16_t *)d_ix, (int32_t *)d_en);
+                    if (e) rc = fail(MP3S_E_HIP, "scatter: %s", hipGetErrorString((hipError_t)e));
+                }
+                if (!rc && hipStreamSynchronize(c->stream) != hipSuccess) rc = fail(MP3S_E_HIP, "sync failed");   // the entry arrays are reused
+            }
+        }
+        if (!rc) rc = walk();
+    }
+    // ---- exact re-runs of what is left, until nothing changes
+    std::vector<int32_t> cur_of;
+    while (!rc && !list.empty()) {
+        if (passes > units + 16) { rc = fail(MP3S_E_HIP, "rate-loop chain did not converge"); break; }
+        cur_of.resize(list.size());
+        for (size_t i = 0; i < list.size(); i++) cur_of[i] = want[list[i]];
+        const std::vector<int32_t> units_of = list;
+        rc = run_entries(units_of, cur_of, d_redo, 1, (int16_t *)d_ix, (mp3s_gr_out *)d_out, (int32_t *)d_en);
+        if (!rc)
+            for (size_t i = 0; i < units_of.size(); i++) {
+                const int u = units_of[i];
+                gr[u] = tmp[i];
+                cursor[u] = cur_of[i];
+                for (int q = 0; q < 4; q++) state[(size_t)u * 4 + q] = state_want[(size_t)u * 4 + q];
+            }
+        if (!rc) rc = walk();
     }
     if (!rc) {
         // ---- bit packing on the device: final GrInfo + frame offsets up, MP3 bytes + scfsi down

@@ -46,14 +46,14 @@ int launch_rate(hipStream_t stream, const int32_t *d_mdct, const mp3s_rate_frame
                 const uint8_t *d_hide, int n_hide, const int32_t *d_cursor, const int32_t *d_state,
                 const int32_t *d_list, int n_list, int16_t *d_ix, mp3s_gr_out *d_out, int32_t *d_en, Profiler *prof,
                 int out_base = 0 /* unit whose results land on element 0 of d_ix / d_out / d_en */,
-                bool compact = false /* d_cursor / d_state / d_out are indexed by the position in d_list */);
+                int compact = 0 /* 1: d_cursor / d_state / d_out are indexed by the position in d_list; 2: d_ix / d_en too */);
 
 // bit-level stages on the device
 int launch_huffman(hipStream_t stream, const uint8_t *d_blob, const mp3s_frame_side *d_side, int n_frames, int nch, int max_bits,
                    int16_t *d_is, mp3s_granule_si *d_si, int32_t *d_status, Profiler *prof);
-// copy variant sel[j] (0..7, 255 = keep) of units u0 .. u0+chunk-1 from [8][chunk] arrays into the final arrays
-int launch_pick(hipStream_t stream, const uint8_t *d_sel, int u0, int chunk, const int16_t *d_ixv, const mp3s_gr_out *d_outv,
-                const int32_t *d_env, int16_t *d_ix, mp3s_gr_out *d_out, int32_t *d_en);
+// pairs: int32 [n][2] = (entry, unit): entry's ix / energies (compact == 2 arrays) -> the unit's place
+int launch_scatter(hipStream_t stream, const int32_t *d_pairs, int n_pairs, const int16_t *d_ixv, const int32_t *d_env, int16_t *d_ix,
+                   int32_t *d_en);
 int launch_pack(hipStream_t stream, const int16_t *d_ix, const mp3s_gr_out *d_gr, const int32_t *d_en, int n_frames, int sri,
                 int bri, int whole_slots, const uint32_t *d_frame_off, const uint8_t *d_padding, uint8_t *d_mp3,
                 int32_t *d_scfsi, int32_t *d_status, int32_t *d_sync /* 2 zeroed words owned by the context */, Profiler *prof);

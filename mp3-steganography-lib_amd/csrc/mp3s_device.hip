@@ -107,7 +107,7 @@ int launch_encode(hipStream_t stream, const int16_t *d_pcm, const mp3s_frame_hdr
 
 int launch_rate(hipStream_t stream, const int32_t *d_mdct, const mp3s_rate_frame *d_frames, int n_frames,
                 const uint8_t *d_hide, int n_hide, const int32_t *d_cursor, const int32_t *d_state,
-                const int32_t *d_list, int n_list, int16_t *d_ix, mp3s_gr_out *d_out, int32_t *d_en, Profiler *prof, int out_base, bool compact)
+                const int32_t *d_list, int n_list, int16_t *d_ix, mp3s_gr_out *d_out, int32_t *d_en, Profiler *prof, int out_base, int compact)
 {
     const int n_units = n_frames * 4;
     if (compact && !d_list) return (int)hipErrorInvalidValue;
@@ -115,17 +115,17 @@ int launch_rate(hipStream_t stream, const int32_t *d_mdct, const mp3s_rate_frame
     if (n <= 0) return 0;
     const int pp = prof ? prof->begin(stream, K_RATE_LOOP) : -1;
     hipLaunchKernelGGL(k_rate_loop, dim3((n + RL_WAVES - 1) / RL_WAVES), dim3(RL_WAVES * 64), 0, stream, d_mdct, d_frames,
-                       n_units, d_hide, n_hide, d_cursor, d_state, d_list, n, d_ix, d_out, d_en, out_base, compact ? 1 : 0);
+                       n_units, d_hide, n_hide, d_cursor, d_state, d_list, n, d_ix, d_out, d_en, out_base, compact);
     if (prof) prof->end(stream, pp);
     return (int)hipGetLastError();
 }
 
-int launch_pick(hipStream_t stream, const uint8_t *d_sel, int u0, int chunk, const int16_t *d_ixv, const mp3s_gr_out *d_outv,
-                const int32_t *d_env, int16_t *d_ix, mp3s_gr_out *d_out, int32_t *d_en)
+int launch_scatter(hipStream_t stream, const int32_t *d_pairs, int n_pairs, const int16_t *d_ixv, const int32_t *d_env, int16_t *d_ix,
+                   int32_t *d_en)
 {
-    if (chunk <= 0) return 0;
-    hipLaunchKernelGGL(k_pick_variant, dim3((chunk + 3) / 4), dim3(256), 0, stream, d_sel, u0, chunk, d_ixv, d_outv, d_env, d_ix,
-                       d_out, d_en);
+    if (n_pairs <= 0) return 0;
+    hipLaunchKernelGGL(k_scatter_entries, dim3((n_pairs + 3) / 4), dim3(256), 0, stream, (const int2 *)d_pairs, n_pairs, d_ixv, d_env,
+                       d_ix, d_en);
     return (int)hipGetLastError();
 }
 

@@ -132,7 +132,8 @@ def reencode_sharded(ctx, mp3: bytes, message=None, comm=None):
     if count > 0:                                                    # (ranks beyond the last frame only take part in the gather)
         lead = 1 if first > 0 else 0
         blk = ctx.decode_block(mp3, first - lead, count + lead, _lib.MP3S_PCM_I16)
-        pcm = blk["pcm"]
+        # (a block that ends on the stream's last frame also gets the repeated frame of D12, which belongs to the next block)
+        pcm = blk["pcm"][:(count + lead) * 1152]
         assert pcm.shape[0] == (count + lead) * 1152, (pcm.shape, first, count, lead)
         is_last = comm.rank == last_rank
         if first == 0:

@@ -63,7 +63,10 @@ def test_reencode_blocks_equal_whole_stream(ctx, mlib, orc):
     pcm[88 * 1152:93 * 1152, 0] = 0                                  # one channel silent around frame 90 = world 2
     cases = [(ctx.encode_pcm(pcm, 44100, 128, None)["mp3"], [None, "short", "m" * 150, "".join(chr(int(c)) for c in rng.integers(32, 127, size=700))]),
              (ctx.encode_pcm(synth_pcm(50, rate=48000, seed=3), 48000, 192, None)["mp3"], ["x" * 40]),
-             (ctx.encode_pcm(synth_pcm(31, rate=32000, seed=4), 32000, 64, None)["mp3"][:-300], [None, "tail"])]
+             (ctx.encode_pcm(synth_pcm(31, rate=32000, seed=4), 32000, 64, None)["mp3"][:-300], [None, "tail"]),
+             # 2 whole frames + a cut one: the decoder repeats the last PCM frame (D12); with 3 and 6 ranks one block ends
+             # on the stream's last frame and the next one is the repeated frame alone
+             (ctx.encode_pcm(synth_pcm(3, seed=9), 44100, 128, None)["mp3"][:-200], [None, "x"])]
     for mp3, msgs in cases:
         for msg in msgs:
             whole = ctx.clear_file(mp3) if msg is None else ctx.hide_message(mp3, msg)
