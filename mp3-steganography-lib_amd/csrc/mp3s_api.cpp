@@ -63,6 +63,10 @@ struct mp3s_ctx {
         pool_bytes[slot] = want;
         return pool[slot];
     }
+    // host-side work arrays of the encoder, kept between calls: beyond a few MB a fresh vector means fresh pages from
+    // the kernel on every call (page faults cost more than the work done in them)
+    std::vector<int32_t> h_cursor, h_state, h_want, h_state_want;
+    std::vector<uint8_t> h_in;
     int ensure_scratch(size_t bytes)
     {
         if (bytes <= scratch_bytes) return 0;
@@ -119,7 +123,7 @@ private:
         auto &fl = free_list();
         size_t held = 0;
         for (auto &e : fl) held += e.second;
-        if (fl.size() < 4 && held + cap_ <= kMaxPinned) fl.emplace_back(p_, cap_);
+        if (fl.size() < 8 && held + cap_ <= kMaxPinned) fl.emplace_back(p_, cap_);
         else hipHostFree(p_);
         p_ = nullptr; cap_ = 0;
     }
@@ -145,6 +149,10 @@ struct mp3s_buf {
     std::vector<mp3s_gr_out> gr;
     std::vector<int32_t> scfsi;
     std::vector<std::unique_ptr<mp3s_buf>> parts;   // results of the batches of a multi-file call
+    // encoder results: MP3 bytes and GrInfo records land in page-locked blocks and are handed out from there
+    PinnedBlock big[2];
+    uint8_t *mp3 = nullptr;
+    mp3s_gr_out *gr_out = nullptr;
 };
 
 // MP3S_TRACE=1: phase timings of the file pipelines on stderr
@@ -834,7 +842,7 @@ struct EncSeg {             // one stream of an encode batch: frames back to bac
 
 // Encode the streams of `segs` (stereo, one sampling rate and bitrate) as ONE batch: transforms, rate loop, bit packing.
 // pcm_dev != nullptr: the int16 PCM is already in HBM (re-encode after a device decode) and pcm is ignored.
-// Results: b->bytes = the streams' MP3 bytes (segs[i].mp3_off / mp3_len), b->gr and b->scfsi in batch frame order.
+// Results: b->mp3 = the streams' MP3 bytes (segs[i].mp3_off / mp3_len), b->gr_out and b->scfsi in batch frame order.
 static int encode_batch(mp3s_ctx *c, const int16_t *pcm, const int16_t *pcm_dev, std::vector<EncSeg> &segs, int samplerate,
                         int bitrate_kbps, mp3s_buf *b, int *passes_out)
 {
@@ -897,9 +905,10 @@ static int encode_batch(mp3s_ctx *c, const int16_t *pcm, const int16_t *pcm_dev,
     const mp3s_rate_frame *d_rf = (const mp3s_rate_frame *)((uint8_t *)d_in + o_rf);
     const int32_t *d_cur = (const int32_t *)((uint8_t *)d_in + o_cur);
     const uint8_t *d_hide = (const uint8_t *)d_in + o_hide;
-    std::vector<int32_t> cursor(units), state((size_t)units * 4, 0);
-    std::vector<mp3s_gr_out> &gr = b->gr;
-    gr.assign(units, mp3s_gr_out());
+    std::vector<int32_t> &cursor = c->h_cursor, &state = c->h_state;
+    cursor.assign(units, 0); state.assign((size_t)units * 4, 0);
+    if (!b->big[1].reserve((size_t)units * sizeof(mp3s_gr_out))) { cleanup(); return fail(MP3S_E_NOMEM, "host memory for %d units", units); }
+    mp3s_gr_out *const gr = b->gr_out = (mp3s_gr_out *)b->big[1].data();   // filled by the first pass's download
     // A unit sees the message only through the <= 3 bits at its cursor.  First pass: guess three tables per unit (for a
     // short message in a long stream that is almost always right: one launch).  Where the guess fails, everything behind
     // the first wrong unit shifts, and re-running shifts it again (hidden bits change bit counts, these the quantiser step,
@@ -916,7 +925,8 @@ static int encode_batch(mp3s_ctx *c, const int16_t *pcm, const int16_t *pcm_dev,
         for (int j = 0; j < s.n_frames * 4; j++)
             cursor[(size_t)s.first * 4 + j] = long_msg ? kNoCursor : (int32_t)std::min<int64_t>((int64_t)s.hide_base + c0 + 3 * (int64_t)j, kNoCursor);
     }
-    std::vector<uint8_t> in(in_bytes, 0);
+    std::vector<uint8_t> &in = c->h_in;
+    in.assign(in_bytes, 0);
     std::memcpy(in.data(), hdr.data(), (size_t)n_all * sizeof(mp3s_frame_hdr));
     std::memcpy(in.data() + o_rf, rf.data(), (size_t)n * sizeof(mp3s_rate_frame));
     std::memcpy(in.data() + o_cur, cursor.data(), (size_t)units * 4);
@@ -928,7 +938,7 @@ static int encode_batch(mp3s_ctx *c, const int16_t *pcm, const int16_t *pcm_dev,
     if (!rc) rc = mp3s_encode_transform_dev(c, (const int16_t *)d_pcm, d_hdr, n_all, (int32_t *)d_mdct_all);
     if (!rc) rc = mp3s_rate_loop_dev(c, d_mdct, d_rf, n, d_hide, n_hide, d_cur, (const int32_t *)d_state, nullptr, 0,
                                      (int16_t *)d_ix, (mp3s_gr_out *)d_out, (int32_t *)d_en);
-    if (!rc) rc = mp3s_dev_download(c, gr.data(), d_out, (size_t)units * sizeof(mp3s_gr_out));
+    if (!rc) rc = mp3s_dev_download(c, gr, d_out, (size_t)units * sizeof(mp3s_gr_out));
     int passes = 1;
     // ---- resolve the serial chains, stream by stream: hide cursor (MP3_Encoder.py:808-809) and the per-(gr,ch) inherited
     //      address1/2/3 + quantizerStepSize (E7).  walk() lists the units whose assumed inputs were wrong and, per stream,
@@ -938,7 +948,8 @@ static int encode_batch(mp3s_ctx *c, const int16_t *pcm, const int16_t *pcm_dev,
     struct Pending { int unit; int64_t cur; };   // first unit of a stream that ran on a wrong cursor, the right cursor there
     std::vector<Pending> pend(segs.size());
     // cursor / state: what each unit's current result was computed with; want / state_want: what the walk says it should be
-    std::vector<int32_t> want(units), state_want((size_t)units * 4, 0);
+    std::vector<int32_t> &want = c->h_want, &state_want = c->h_state_want;
+    want.assign(units, 0); state_want.assign((size_t)units * 4, 0);
     auto walk = [&]() {
         list.clear();
         for (size_t si = 0; si < segs.size(); si++) {
@@ -1105,7 +1116,7 @@ static int encode_batch(mp3s_ctx *c, const int16_t *pcm, const int16_t *pcm_dev,
             rc = fail(MP3S_E_NOMEM, "hipMalloc failed for the packer");
         if (!rc) rc = mp3s_dev_upload(c, d_off, off.data(), ((size_t)n + 1) * 4);
         if (!rc) rc = mp3s_dev_upload(c, d_pad, pad8.data(), (size_t)n);
-        if (!rc) rc = mp3s_dev_upload(c, d_out, gr.data(), (size_t)units * sizeof(mp3s_gr_out));
+        if (!rc) rc = mp3s_dev_upload(c, d_out, gr, (size_t)units * sizeof(mp3s_gr_out));
         if (!rc) rc = mp3s_pack_frames_dev(c, (const int16_t *)d_ix, (const mp3s_gr_out *)d_out, (const int32_t *)d_en, n, samplerate,
                                            bitrate_kbps, (const uint32_t *)d_off, (const uint8_t *)d_pad, (uint8_t *)d_mp3,
                                            (int32_t *)d_sc, (int32_t *)d_st);
@@ -1119,9 +1130,10 @@ static int encode_batch(mp3s_ctx *c, const int16_t *pcm, const int16_t *pcm_dev,
             if (s.last) s.mp3_len -= std::min<size_t>(s.mp3_len, (size_t)((bytes_before + (int64_t)s.mp3_len) % 4));
         }
         const size_t total = segs.back().mp3_off + segs.back().mp3_len;
-        b->bytes.resize(total);
+        if (!rc && !b->big[0].reserve(total)) rc = fail(MP3S_E_NOMEM, "host memory for %zu bytes of MP3", total);
+        b->mp3 = b->big[0].data();
         b->scfsi.assign((size_t)n * 8, 0);
-        if (!rc) rc = mp3s_dev_download(c, b->bytes.data(), d_mp3, total);
+        if (!rc) rc = mp3s_dev_download(c, b->mp3, d_mp3, total);
         if (!rc) rc = mp3s_dev_download(c, b->scfsi.data(), d_sc, (size_t)n * 8 * 4);
     }
     cleanup();
@@ -1147,8 +1159,8 @@ static int encode_core(mp3s_ctx *c, const int16_t *pcm, const int16_t *pcm_dev, 
     out->n_frames = segs[0].n_frames;
     out->hide_offset = segs[0].hide_offset;
     out->too_long = out->hide_offset < (int64_t)n_hide - 1 ? 1 : 0;
-    out->mp3 = b->bytes.data(); out->mp3_len = segs[0].mp3_len;
-    out->gr = b->gr.data(); out->scfsi = b->scfsi.data();
+    out->mp3 = b->mp3; out->mp3_len = segs[0].mp3_len;
+    out->gr = b->gr_out; out->scfsi = b->scfsi.data();
     out->rate_passes = passes;
     *owner = b.release();
     return MP3S_OK;
@@ -1179,8 +1191,8 @@ int mp3s_encode_block(mp3s_ctx *c, const int16_t *pcm, int64_t n_samples_per_ch,
     out->n_frames = s.n_frames;
     out->hide_offset = s.hide_offset;
     out->too_long = out->hide_offset < (int64_t)n_hide - 1 ? 1 : 0;
-    out->mp3 = b->bytes.data(); out->mp3_len = s.mp3_len;
-    out->gr = b->gr.data(); out->scfsi = b->scfsi.data();
+    out->mp3 = b->mp3; out->mp3_len = s.mp3_len;
+    out->gr = b->gr_out; out->scfsi = b->scfsi.data();
     out->rate_passes = passes;
     *owner = b.release();
     return MP3S_OK;
@@ -1328,7 +1340,7 @@ static int reencode_group(mp3s_ctx *c, mp3s_multi &m, const std::vector<int> &id
     for (size_t k = 0; k < idx.size(); k++) {
         mp3s_file &o = out[idx[k]];
         std::memset(&o, 0, sizeof o);
-        o.data = part->bytes.data() + segs[k].mp3_off; o.len = segs[k].mp3_len;
+        o.data = part->mp3 + segs[k].mp3_off; o.len = segs[k].mp3_len;
         o.kbps = kbps; o.sampling_rate = samplerate; o.channels = 2; o.n_frames = segs[k].n_frames;
         o.hide_offset = segs[k].hide_offset;
         o.too_long = segs[k].hide_offset < (int64_t)segs[k].n_hide - 1 ? 1 : 0;

@@ -168,7 +168,12 @@ int parse_stream(const uint8_t *file, size_t flen_, ParsedStream &out, ScannedSt
     const HostTables &HT = host_tables();
     const long flen = (long)flen_;
     out = ParsedStream();
-    if (scan) *scan = ScannedStream();
+    if (scan) {
+        *scan = ScannedStream();
+        // main data is the file minus headers and side info, plus padding: one allocation instead of doubling through 40 MB
+        scan->blob.reserve(flen_ + flen_ / 32 + 64);
+        scan->side.reserve(flen_ / 96 + 1);
+    }
     // ID3v2 skip (decoder/ID3_Parser.py:95-131): only `offset` and `is_valid` matter to decoding
     long offset = 0;
     if (flen >= 10 && file[0] == 'I' && file[1] == 'D' && file[2] == '3' && !(file[5] & 0x0f)) {
