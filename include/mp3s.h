@@ -387,6 +387,22 @@ int mp3s_clear_file(mp3s_ctx *ctx, const uint8_t *mp3, size_t len, mp3s_buf **ow
  * NULL the first such code fails the whole call. */
 int mp3s_hide_messages(mp3s_ctx *ctx, const uint8_t *const *mp3s, const size_t *lens, int n_files, const uint8_t *const *msgs,
                        const size_t *msg_lens, mp3s_buf **owner, mp3s_file *out, int32_t *status);
+/* The share of one rank in hiding a message in (utf8 != NULL) or clearing (NULL) ONE stream that is spread over `world`
+ * ranks: the stream's PCM frames (repeated last frame included) are cut into `world` contiguous blocks, sizes
+ * differing by at most one; this call decodes block `rank` -- one frame of decoder state and one frame of PCM in front of
+ * it -- and re-encodes it without the PCM leaving HBM: mp3s_decode_block + mp3s_encode_block in one, with one host scan.
+ * carry_in NULL is only valid for rank 0; the other ranks pass the carry_out of the rank before them -- or a guess, and
+ * call again with the real one if carry_used says the block depended on it (see mp3s_encode_block).  file.data = the
+ * block's frames; concatenated over the ranks they are the file mp3s_hide_message / mp3s_clear_file produce.  A rank
+ * beyond the last frame gets n_frames = 0 and no data. */
+typedef struct {
+    int64_t total_frames, first_frame, n_frames; /* of the stream / of this rank's block */
+    int32_t is_last, carry_used;
+    mp3s_carry carry_out;
+    mp3s_file file;                              /* too_long / hide_offset count from the start of the stream */
+} mp3s_block;
+int mp3s_reencode_block(mp3s_ctx *ctx, const uint8_t *mp3, size_t len, const uint8_t *utf8, size_t n_msg, int rank, int world,
+                        const mp3s_carry *carry_in, mp3s_buf **owner, mp3s_block *out);
 /* replaces: Steganography.reveal_massage -- reference steganography.py:103-131: MP3 bytes -> message text.  Only the
  * byte-level scan runs (table_select lives in the side info), so no device work and no context are needed. */
 int mp3s_reveal_message(const uint8_t *mp3, size_t len, mp3s_buf **owner, mp3s_file *out);

@@ -1404,6 +1404,62 @@ int mp3s_hide_messages(mp3s_ctx *c, const uint8_t *const *mp3s, const size_t *le
     return MP3S_OK;
 }
 
+int mp3s_reencode_block(mp3s_ctx *c, const uint8_t *mp3, size_t len, const uint8_t *utf8, size_t n_msg, int rank, int world,
+                        const mp3s_carry *carry_in, mp3s_buf **owner, mp3s_block *out)
+{
+    if (!c || !mp3 || !owner || !out || world <= 0 || rank < 0 || rank >= world || (rank == 0 && carry_in) || (rank > 0 && !carry_in))
+        return fail(MP3S_E_ARG, "bad argument (rank 0 has no carry, every other rank has one)");
+    std::unique_ptr<mp3s_buf> top(new mp3s_buf());
+    top->multi.reset(new mp3s_multi());
+    mp3s_multi &m = *top->multi;
+    m.parsed.resize(1); m.scanned.resize(1); m.pcm.assign(1, nullptr); m.files.assign(1, {mp3, len});
+    int rc = front_end(m, 0);
+    if (rc) return fail(rc, "malformed or unsupported MP3 stream");
+    ParsedStream &p = m.parsed[0];
+    int kbps = 0;
+    rc = reencode_check(p, &kbps);
+    if (rc) return rc;
+    const int samplerate = p.sampling_rate;
+    std::vector<uint8_t> bits;
+    if (utf8) message_frame(utf8, n_msg, bits);
+    if (bits.size() > 0x7fffffff) return fail(MP3S_E_ARG, "message too long");
+    // blocks of PCM frames; the frame the decoder repeats after a bad header (D12) is the stream's last PCM frame
+    const long n = p.n_frames, total = n + (p.dup_last_frame ? 1 : 0);
+    const long base = total / world, rem = total % world;
+    const long first = rank * base + std::min<long>(rank, rem), count = base + (rank < rem ? 1 : 0);
+    std::memset(out, 0, sizeof *out);
+    out->total_frames = total; out->first_frame = first; out->n_frames = count; out->is_last = first + count == total;
+    out->file.kbps = kbps; out->file.sampling_rate = samplerate; out->file.channels = 2;
+    if (count == 0) { m.files.clear(); *owner = top.release(); return MP3S_OK; }
+    const int lead = first > 0 ? 1 : 0;                   // PCM in front of the block, for the encoder's filter state
+    const int halo = first - lead > 0 ? 1 : 0;            // a frame in front of that, for the decoder's
+    const long w0 = first - lead - halo, w1 = std::min(first + count, n);
+    const bool with_dup = first + count == total && p.dup_last_frame;
+    cut_window(p, m.scanned[0], w0, w1 - w0);
+    p.dup_last_frame = with_dup ? 1 : 0;
+    const int64_t rows_frames = (w1 - w0) + (with_dup ? 1 : 0);
+    if (hipSetDevice(c->device) != hipSuccess) return fail(MP3S_E_HIP, "hipSetDevice failed");
+    void *d_keep = c->grab(7, (size_t)rows_frames * 2304 * 2);
+    if (!d_keep) return fail(MP3S_E_NOMEM, "hipMalloc failed for %lld frames of PCM", (long long)rows_frames);
+    rc = decode_group(c, m, std::vector<int>{0}, 2, MP3S_PCM_I16, d_keep);
+    if (rc) return rc;
+    std::vector<EncSeg> segs(1);
+    EncSeg &s = segs[0];
+    s.n_frames = (int)count; s.hide = bits.data(); s.n_hide = (int)bits.size();
+    s.lead = lead; s.first_frame = first; s.last = out->is_last != 0; s.carry_in = carry_in;
+    std::unique_ptr<mp3s_buf> part(new mp3s_buf());
+    rc = encode_batch(c, nullptr, (const int16_t *)d_keep + (size_t)halo * 2304, segs, samplerate, kbps, part.get(), nullptr);
+    if (rc) return rc;
+    out->carry_out = s.carry_out; out->carry_used = s.carry_used ? 1 : 0;
+    out->file.data = part->mp3 + s.mp3_off; out->file.len = s.mp3_len; out->file.n_frames = (int32_t)count;
+    out->file.hide_offset = s.hide_offset;
+    out->file.too_long = s.hide_offset < (int64_t)s.n_hide - 1 ? 1 : 0;
+    top->parts.push_back(std::move(part));
+    m.files.clear();
+    *owner = top.release();
+    return MP3S_OK;
+}
+
 static int reencode(mp3s_ctx *c, const uint8_t *mp3, size_t len, const uint8_t *msg, size_t n_msg, bool hide, mp3s_buf **owner, mp3s_file *out)
 {
     const uint8_t *const no_msg = nullptr;

@@ -105,6 +105,11 @@ class File(C.Structure):
                 ("hide_offset", C.c_int64), ("bits", C.c_void_p)]
 
 
+class Block(C.Structure):
+    _fields_ = [("total_frames", C.c_int64), ("first_frame", C.c_int64), ("n_frames", C.c_int64), ("is_last", C.c_int32),
+                ("carry_used", C.c_int32), ("carry_out", Carry), ("file", File)]
+
+
 # every symbol include/mp3s.h declares (tests/test_abi.py checks the library exports all of them)
 SYMBOLS = ["mp3s_ctx_create", "mp3s_ctx_destroy", "mp3s_ctx_wait", "mp3s_last_error", "mp3s_version", "mp3s_device_name", "mp3s_sync", "mp3s_debug_tables", "mp3s_debug_scfsi_energies",
            "mp3s_dev_alloc", "mp3s_dev_free", "mp3s_dev_upload", "mp3s_dev_download", "mp3s_dev_memset",
@@ -112,7 +117,7 @@ SYMBOLS = ["mp3s_ctx_create", "mp3s_ctx_destroy", "mp3s_ctx_wait", "mp3s_last_er
            "mp3s_encode_transform_dev", "mp3s_encode_transform", "mp3s_rate_loop_dev", "mp3s_huffman_decode_dev", "mp3s_pack_frames_dev", "mp3s_scan_stream", "mp3s_buf_free",
            "mp3s_parse_stream", "mp3s_format_stream", "mp3s_rate_frames", "mp3s_decode_stream", "mp3s_decode_streams", "mp3s_decode_block", "mp3s_encode_pcm", "mp3s_encode_block",
            "mp3s_wav_parse", "mp3s_wav_header", "mp3s_message_frame", "mp3s_message_reveal", "mp3s_decode_file", "mp3s_encode_file",
-           "mp3s_hide_message", "mp3s_clear_file", "mp3s_hide_messages", "mp3s_reveal_message"]
+           "mp3s_hide_message", "mp3s_clear_file", "mp3s_hide_messages", "mp3s_reencode_block", "mp3s_reveal_message"]
 
 _lib = None
 _lock = threading.Lock()
@@ -181,6 +186,7 @@ def lib():
         L.mp3s_decode_block.argtypes = [vp, vp, sz, C.c_int64, C.c_int64, i32, pvp, C.POINTER(Decoded)]
         L.mp3s_encode_block.argtypes = [vp, vp, C.c_int64, i32, C.c_int64, i32, i32, i32, vp, i32, C.POINTER(Carry), C.POINTER(Carry),
                                         C.POINTER(C.c_int32), pvp, C.POINTER(Encoded)]
+        L.mp3s_reencode_block.argtypes = [vp, vp, sz, vp, sz, i32, i32, C.POINTER(Carry), pvp, C.POINTER(Block)]
         L.mp3s_hide_messages.argtypes = [vp, vp, vp, i32, vp, vp, pvp, vp, vp]
         L.mp3s_reveal_message.argtypes = [vp, sz, pvp, C.POINTER(File)]
         _lib = L
@@ -460,6 +466,26 @@ class Context:
         owner, f = C.c_void_p(), File()
         check(lib().mp3s_clear_file(self.handle, buf.ctypes.data, len(mp3), C.byref(owner), C.byref(f)))
         return self._file(f, owner)
+
+    def reencode_block(self, mp3: bytes, message, rank, world, carry_in=None):
+        """this rank's block of hide_message (message: str) / clear_file (None) on one stream spread over `world` ranks:
+        decode + re-encode of the block on the device (include/mp3s.h mp3s_reencode_block).  carry_in: int64[17], None
+        for rank 0."""
+        buf = np.frombuffer(mp3, dtype=np.uint8)
+        mb = None if message is None else np.frombuffer(message.encode("utf-8") or b"\0", dtype=np.uint8)
+        nm = 0 if message is None else len(message.encode("utf-8"))
+        cin = Carry.from_array(carry_in) if carry_in is not None else None
+        owner, b = C.c_void_p(), Block()
+        check(lib().mp3s_reencode_block(self.handle, buf.ctypes.data, len(mp3), None if mb is None else mb.ctypes.data, nm, int(rank),
+                                        int(world), C.byref(cin) if cin is not None else None, C.byref(owner), C.byref(b)))
+        try:
+            f = b.file
+            return {"total_frames": b.total_frames, "first_frame": b.first_frame, "n_frames": b.n_frames, "is_last": bool(b.is_last),
+                    "carry_used": bool(b.carry_used), "carry_out": b.carry_out.to_array(),
+                    "mp3": C.string_at(f.data, f.len) if f.len else b"", "kbps": f.kbps, "sampling_rate": f.sampling_rate,
+                    "too_long": bool(f.too_long), "hide_offset": f.hide_offset}
+        finally:
+            lib().mp3s_buf_free(owner)
 
     def hide_messages(self, mp3s, messages):
         """hide_message / clear_file (message None) over a list of files as one device batch per (rate, bitrate).

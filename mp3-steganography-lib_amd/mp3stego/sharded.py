@@ -7,6 +7,7 @@ decode -> re-encode path.  What crosses a block boundary:
   81-92), so a rank decodes one extra frame in front of its block and drops it (mp3s_decode_block);
 * encode: analysis filter bank + MDCT need 1056 earlier PCM samples (encoder/MP3_Encoder.py:356, 685, 747): one frame
   of PCM in front of the block; the padding bit is a recurrence on the frame index (:630-636), replayed on the host;
+  (both halves in one call, the PCM staying in HBM: mp3s_reencode_block);
 * two serial chains of the rate loop -- the message cursor (:808-809) and the address1/2/3 + quantizerStepSize a silent
   granule inherits.  They are 17 integers.  A rank encodes its block on a guess (message already hidden,
   no inherited state), receives the real values from the rank before it, re-encodes only if the library says the
@@ -119,48 +120,33 @@ def reencode_sharded(ctx, mp3: bytes, message=None, comm=None):
     `comm`.  Rank 0 returns {"data": mp3 bytes, "too_long", "hide_offset", ...} exactly as Context.hide_message /
     clear_file do for the whole file on one GPU; the other ranks return None."""
     comm = comm or SoloComm()
-    info = _lib.scan_stream(mp3)
-    rate, kbps = info["sampling_rate"], info["bit_rate"] // 1000
-    if info["channels"] != 2 or info["n_frames"] <= 0:
-        raise _lib.Mp3sError(_lib.E_UNSUPPORTED, "stereo stream with at least one frame expected")
-    total = info["n_frames"] + info["dup_last_frame"]                # PCM frames the encoder sees (D12)
-    hide = np.array(_lib.message_frame(message)) if message is not None else None
-    n_hide = 0 if hide is None else len(hide)
-    first, count = shard_frames(total, comm.rank, comm.world)
-    last_rank = max(r for r in range(comm.world) if shard_frames(total, r, comm.world)[1] > 0)
-    result = None
-    if count > 0:                                                    # (ranks beyond the last frame only take part in the gather)
-        lead = 1 if first > 0 else 0
-        blk = ctx.decode_block(mp3, first - lead, count + lead, _lib.MP3S_PCM_I16)
-        # (a block that ends on the stream's last frame also gets the repeated frame of D12, which belongs to the next block)
-        pcm = blk["pcm"][:(count + lead) * 1152]
-        assert pcm.shape[0] == (count + lead) * 1152, (pcm.shape, first, count, lead)
-        is_last = comm.rank == last_rank
-        if first == 0:
-            result = ctx.encode_block(pcm, 0, 0, is_last, rate, kbps, hide, None)
+    n_hide = 0 if message is None else len(_lib.message_frame(message))
+    if comm.rank == 0:
+        blk = ctx.reencode_block(mp3, message, 0, comm.world, None)
+    else:
+        guess = np.zeros(CARRY_WORDS, dtype=np.int64)
+        guess[0] = _PAST_MESSAGE
+        blk = ctx.reencode_block(mp3, message, comm.rank, comm.world, guess)      # overlaps the ranks in front
+    last_rank = min(comm.world, int(blk["total_frames"])) - 1                     # ranks behind it hold no frame
+    if 0 < comm.rank <= last_rank:
+        real = comm.recv(comm.rank - 1)
+        live = min(int(real[0]), n_hide) < n_hide                    # the message is still being hidden at this boundary
+        if not _same_effect(real, guess, n_hide) and (blk["carry_used"] or live):
+            blk = ctx.reencode_block(mp3, message, comm.rank, comm.world, real)
         else:
-            guess = np.zeros(CARRY_WORDS, dtype=np.int64)
-            guess[0] = _PAST_MESSAGE
-            result = ctx.encode_block(pcm, lead, first, is_last, rate, kbps, hide, guess)   # overlaps the ranks in front
-            real = comm.recv(comm.rank - 1)
-            live = min(int(real[0]), n_hide) < n_hide                # the message is still being hidden at this boundary
-            if not _same_effect(real, guess, n_hide) and (result["carry_used"] or live):
-                result = ctx.encode_block(pcm, lead, first, is_last, rate, kbps, hide, real)
-            else:
-                # nothing in the block looked at the carry, so every chain entry it hands on is its own (a granule that
-                # inherits would have set carry_used); only the count of tables seen so far moves with the real cursor
-                out = result["carry_out"].copy()
-                out[0] = int(real[0]) + (int(out[0]) - int(guess[0]))
-                result["carry_out"] = out
-                result["hide_offset"] = int(out[0])
-        if comm.rank < last_rank:
-            comm.send(comm.rank + 1, result["carry_out"])
-    payload = None if result is None else (result["mp3"], int(result["hide_offset"]), comm.rank == last_rank)
+            # nothing in the block looked at the carry, so every chain entry it hands on is its own (a granule that
+            # inherits would have set carry_used); only the count of tables seen so far moves with the real cursor
+            out = blk["carry_out"].copy()
+            out[0] = int(real[0]) + (int(out[0]) - int(guess[0]))
+            blk["carry_out"] = out
+            blk["hide_offset"] = int(out[0])
+    if comm.rank < last_rank:
+        comm.send(comm.rank + 1, blk["carry_out"])
+    payload = None if comm.rank > last_rank else (blk["mp3"], int(blk["hide_offset"]), comm.rank == last_rank)
     parts = comm.gather(payload)
     if parts is None:
         return None
     parts = [p for p in parts if p is not None]
-    data = b"".join(p[0] for p in parts)
     hide_offset = [p[1] for p in parts if p[2]][0]
-    return {"data": data, "kbps": kbps, "sampling_rate": rate, "channels": 2, "n_frames": total,
-            "too_long": hide_offset < n_hide - 1, "hide_offset": hide_offset}
+    return {"data": b"".join(p[0] for p in parts), "kbps": blk["kbps"], "sampling_rate": blk["sampling_rate"], "channels": 2,
+            "n_frames": int(blk["total_frames"]), "too_long": hide_offset < n_hide - 1, "hide_offset": hide_offset}

@@ -87,19 +87,22 @@ SHARD_WORKER = textwrap.dedent("""
     class StubCtx:
         # stands in for the GPU context: a block that starts at frame 30 or later "inherits" (its bytes show the carry it got)
         calls = 0
-        def decode_block(self, data, first, count, fmt=0):
-            return {"pcm": np.zeros((count * 1152, 2), dtype=np.int16)}
-        def encode_block(self, pcm, lead, first, last, rate, kbps, hide, carry_in):
+        def reencode_block(self, mp3, message, rank, world, carry_in):
+            from mp3stego import _lib
             StubCtx.calls += 1
-            n = pcm.shape[0] // 1152 - lead
+            total = _lib.scan_stream(mp3)["n_frames"]
+            first, n = sharded.shard_frames(total, rank, world)
             c = np.zeros(17, dtype=np.int64) if carry_in is None else np.array(carry_in, dtype=np.int64)
             used = first >= 30
             out = c.copy()
             out[0] = c[0] + 12 * n
             if not used:
                 out[1:] = first + 1
-            text = "<%%d,%%d,%%s,%%d>" %% (first, n, ",".join(map(str, c)) if used else "-", int(bool(last)))
-            return {"mp3": text.encode(), "hide_offset": int(out[0]), "too_long": False, "carry_out": out, "carry_used": used}
+            last = first + n == total
+            text = "<%%d,%%d,%%s,%%d>" %% (first, n, ",".join(map(str, c)) if used else "-", int(last))
+            return {"total_frames": total, "first_frame": first, "n_frames": n, "is_last": last, "carry_used": used,
+                    "carry_out": out, "mp3": text.encode(), "kbps": 128, "sampling_rate": 44100, "too_long": False,
+                    "hide_offset": int(out[0])}
 
     comm = sharded.TorchComm()
     mp3 = open(sys.argv[1], "rb").read()

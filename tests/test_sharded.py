@@ -104,6 +104,35 @@ def test_encode_block_carry_contract(ctx, mlib):
             ctx.encode_block(pcm[:10 * 1152], bad["lead"], bad["first"], True, 44100, 128, None, bad["carry"])
 
 
+@pytest.mark.gpu
+def test_reencode_block_entry_point(ctx, mlib):
+    """mp3s_reencode_block on its own: blocks partition the PCM frames, ranks beyond the last frame get nothing, the
+    blocks run on their real carries concatenate to the single-GPU file, argument errors are reported"""
+    from synth_pcm import synth_pcm
+    pcm = synth_pcm(23, seed=12)
+    pcm[9 * 1152:14 * 1152] = 0
+    mp3 = ctx.encode_pcm(pcm, 44100, 128, None)["mp3"][:-100]       # 22 whole frames + the repeated one = 23 PCM frames
+    whole = ctx.hide_message(mp3, "block by block")
+    for world in (1, 2, 5, 23, 30):
+        carry, data, covered = None, b"", 0
+        for rank in range(world):
+            b = ctx.reencode_block(mp3, "block by block", rank, world, carry)
+            assert b["total_frames"] == 23 and b["first_frame"] == covered
+            covered += b["n_frames"]
+            if b["n_frames"] == 0:
+                assert rank >= 23 and b["mp3"] == b""
+                carry = np.zeros(17, dtype=np.int64) if carry is None else carry
+                continue
+            data += b["mp3"]
+            carry = b["carry_out"]
+            assert b["is_last"] == (covered == 23)
+        assert covered == 23 and data == whole["data"], world
+        assert b["hide_offset"] == whole["hide_offset"] or b["n_frames"] == 0
+    for rank, world, carry in ((0, 0, None), (2, 2, None), (-1, 2, None), (1, 2, None), (0, 2, np.zeros(17, dtype=np.int64))):
+        with pytest.raises(mlib.Mp3sError):
+            ctx.reencode_block(mp3, None, rank, world, carry)
+
+
 WORKER = textwrap.dedent("""
     import os, sys, json, hashlib
     sys.path.insert(0, os.path.join(%r, "mp3-steganography-lib_amd")); sys.path.insert(0, os.path.join(%r, "tests"))
