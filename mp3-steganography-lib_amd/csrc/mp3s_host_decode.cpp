@@ -38,6 +38,18 @@ struct Bits {
     }
 };
 
+// the same on a buffer that is known to be long enough (zero padded by the caller): 1 <= n <= 32
+struct FastBits {
+    const uint8_t *p;
+    uint32_t get(long pos, int n) const
+    {
+        uint64_t w;
+        std::memcpy(&w, p + (pos >> 3), 8);
+        w = __builtin_bswap64(w);
+        return (uint32_t)((w << (pos & 7)) >> (64 - n));
+    }
+};
+
 // ---------------------------------------------------------------- Huffman lookup tables
 constexpr int LUT_BITS = 10;
 struct HuffLut {
@@ -223,9 +235,12 @@ int parse_stream(const uint8_t *file, size_t flen_, ParsedStream &out, ScannedSt
         else if (hd.channels != first_nch) return MP3S_E_UNSUPPORTED;   // ragged pcm_data in the reference
         const int nch = hd.channels;
 
-        // ---- side info
+        // ---- side info: at most 32 bytes, read field by field from a zero-padded copy (bits past the end of the file
+        //      read as 0, as in the reference's reader)
         const long sstart = hd.crc == 0 ? 6 : 4;
-        Bits sb{buffer + (sstart < buflen ? sstart : buflen), buflen - (sstart < buflen ? sstart : buflen)};
+        uint8_t sbuf[48] = {0};
+        if (buflen > sstart) std::memcpy(sbuf, buffer + sstart, (size_t)std::min<long>(buflen - sstart, 40));
+        const FastBits sb{sbuf};
         long off = 0;
         si.main_data_begin = (int)sb.get(0, 9); off += 9;
         off += hd.mode == 3 ? 5 : 3;
@@ -262,12 +277,20 @@ int parse_stream(const uint8_t *file, size_t flen_, ParsedStream &out, ScannedSt
                     const int t = si.table_select[gr][ch][r];
                     if (t) out.bits.push_back(HT.in_h0[t] ? 0 : 1);
                 }
-        // ---- main data (bit reservoir)
+        // ---- main data (bit reservoir); in scan mode it is assembled in the blob directly
         int constant = hd.mode == 3 ? 21 : 36;
         if (hd.crc == 0) constant += 2;
+        std::vector<uint8_t> &md = scan ? scan->blob : main_data;
+        size_t md_start = 0;
+        if (scan) {
+            while (scan->blob.size() & 3) scan->blob.push_back(0);
+            md_start = scan->blob.size();
+        }
+        bool rebuilt = false;
         if (si.main_data_begin == 0) {
-            main_data.clear();
-            py_slice_append(main_data, buffer, buflen, constant, frame_size);
+            if (!scan) main_data.clear();
+            py_slice_append(md, buffer, buflen, constant, frame_size);
+            rebuilt = true;
         } else {
             double bound = 0;
             for (int fr = 0; fr < 9; fr++) {
@@ -277,16 +300,17 @@ int parse_stream(const uint8_t *file, size_t flen_, ParsedStream &out, ScannedSt
                     double part[9] = {0};
                     part[fr] = si.main_data_begin;
                     for (int i = 0; i < fr; i++) { part[i] = prev_frame_size[i] - constant; part[fr] -= part[i]; }
-                    main_data.clear();
+                    if (!scan) main_data.clear();
                     long loc = (long)(offset - ptr_offset);
-                    py_slice_append(main_data, file, flen, loc, loc + (long)part[fr]);
+                    py_slice_append(md, file, flen, loc, loc + (long)part[fr]);
                     ptr_offset -= (part[fr] + constant);
                     for (int i = fr - 1; i >= 0; i--) {
                         loc = (long)(offset - ptr_offset);
-                        py_slice_append(main_data, file, flen, loc, loc + (long)part[i]);
+                        py_slice_append(md, file, flen, loc, loc + (long)part[i]);
                         ptr_offset -= (part[i] + constant);
                     }
-                    py_slice_append(main_data, buffer, buflen, constant, frame_size);
+                    py_slice_append(md, buffer, buflen, constant, frame_size);
+                    rebuilt = true;
                     break;
                 }
             }   // not found: the previous frame's main_data is reused, as in the reference
@@ -294,14 +318,17 @@ int parse_stream(const uint8_t *file, size_t flen_, ParsedStream &out, ScannedSt
         Bits mb{main_data.data(), (long)main_data.size()};
 
         if (scan) {
-            // ---- scan mode: record the side info and append the main data to the blob
+            // ---- scan mode: record the side info; the main data sits in the blob already
             mp3s_frame_side fs;
             std::memset(&fs, 0, sizeof fs);
             out.table_select.resize(((size_t)out.n_frames + 1) * 12, 0);
-            while (scan->blob.size() & 3) scan->blob.push_back(0);
-            fs.md_off = (uint32_t)scan->blob.size();
-            fs.md_len = (uint32_t)main_data.size();
-            scan->blob.insert(scan->blob.end(), main_data.begin(), main_data.end());
+            if (!rebuilt && !scan->side.empty()) {
+                const mp3s_frame_side &pv = scan->side.back();
+                const std::vector<uint8_t> again(scan->blob.begin() + pv.md_off, scan->blob.begin() + pv.md_off + pv.md_len);
+                scan->blob.insert(scan->blob.end(), again.begin(), again.end());
+            }
+            fs.md_off = (uint32_t)md_start;
+            fs.md_len = (uint32_t)(scan->blob.size() - md_start);
             scan->blob.insert(scan->blob.end(), 8, 0);
             fs.nch = (uint8_t)nch; fs.sr_idx = (uint8_t)hd.sr_idx;
             fs.ms_stereo = (hd.mode == 1 && hd.mode_ext0) ? 1 : 0;
