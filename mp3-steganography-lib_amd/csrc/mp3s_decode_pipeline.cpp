@@ -1,0 +1,287 @@
+// C-ABI of the library (include/mp3s.h), part 2: MP3 streams in, PCM out -- the host front end, the device batch
+// (Huffman decode + transforms, chunked with a one-frame halo) and the entry points built on them.
+#include "mp3s_internal.h"
+
+// keep frames [first, first + count) of a parsed stream (its main data, side records, samples)
+void cut_window(ParsedStream &p, ScannedStream &sc, long first, long count)
+{
+    const long n = p.n_frames;
+    first = std::min(std::max(first, 0L), n);
+    count = std::min(std::max(count, 0L), n - first);
+    auto cut = [&](auto &v, size_t per) {
+        if (v.size() >= (size_t)n * per) v.assign(v.begin() + (size_t)first * per, v.begin() + (size_t)(first + count) * per);
+    };
+    if (!sc.side.empty()) {
+        const size_t b0 = first < n ? sc.side[first].md_off : sc.blob.size();
+        const size_t b1 = first + count < n ? sc.side[first + count].md_off : sc.blob.size();
+        sc.blob.assign(sc.blob.begin() + b0, sc.blob.begin() + std::max(b0, b1));
+        cut(sc.side, 1);
+        for (auto &fs : sc.side) fs.md_off -= (uint32_t)b0;
+    }
+    cut(p.is, 2304); cut(p.si, 4); cut(p.hdr, 1); cut(p.table_select, 12); cut(p.frame_size, 1);
+    if (first + count < n) p.dup_last_frame = 0;   // the repeated last frame belongs to the block that ends the stream
+    p.n_frames = (int)count;
+}
+
+// host front end of stream i of m: byte-level scan; scalefactors + Huffman run on the device unless the stream inherits
+// scalefactors across frames (mixed blocks ...) or `full` asks for it, in which case the host parser produces its frames
+int front_end(mp3s_multi &m, int i, bool full)
+{
+    ParsedStream &p = m.parsed[i];
+    ScannedStream &sc = m.scanned[i];
+    int rc = full ? MP3S_OK : parse_stream(m.files[i].first, m.files[i].second, p, &sc);
+    if (!rc && (full || !sc.gpu_ok)) {
+        rc = parse_stream(m.files[i].first, m.files[i].second, p, nullptr);
+        sc.gpu_ok = false;
+        sc.side.clear(); sc.blob.clear();   // (possibly cut to a window already; not used for host-parsed streams)
+    }
+    // no sync where the stream should start: the reference parses nothing and writes an empty WAV (MP3_Parser.py:37-46)
+    if (!rc && (size_t)i < m.window.size()) {
+        if ((size_t)i < m.all_bits.size()) m.all_bits[i] = p.bits;
+        cut_window(p, sc, m.window[i].first, m.window[i].second);
+    }
+    return rc;
+}
+
+// Decode the streams listed in `idx` (all with the same channel count) as ONE batch.
+// d_keep != nullptr: the PCM of the group stays on the device there (frames back to back, a duplicated last frame
+// included) and nothing is downloaded -- the re-encode path of mp3s_hide_message / mp3s_clear_file.
+int decode_group(mp3s_ctx *c, mp3s_multi &m, const std::vector<int> &idx, int nch, int out_format, void *d_keep)
+{
+    const size_t esz = pcm_elem(out_format), frame_bytes = (size_t)1152 * nch * esz;
+    long n = 0;
+    for (int i : idx) n += m.parsed[i].n_frames;
+    if (n <= 0) return MP3S_OK;
+    if (n > 0x7fffffff / 8) return fail(MP3S_E_ARG, "batch of %ld frames is too large", n);
+    // ---- concatenate: frame headers (stream_first = first frame of the file), side records, main-data blobs
+    std::vector<mp3s_frame_hdr> hdr((size_t)n);
+    std::vector<mp3s_frame_side> side((size_t)n);
+    std::vector<uint8_t> blob;
+    std::vector<long> first_of(idx.size());
+    bool any_dev = false, any_host = false;
+    long f0 = 0;
+    for (size_t k = 0; k < idx.size(); k++) {
+        const ParsedStream &p = m.parsed[idx[k]];
+        const ScannedStream &sc = m.scanned[idx[k]];
+        first_of[k] = f0;
+        const bool dev = sc.gpu_ok;
+        (dev ? any_dev : any_host) = true;
+        const uint32_t base = (uint32_t)blob.size();
+        if (dev) blob.insert(blob.end(), sc.blob.begin(), sc.blob.end());
+        for (int f = 0; f < p.n_frames; f++) {
+            hdr[(size_t)f0 + f] = p.hdr[f];
+            hdr[(size_t)f0 + f].stream_first = (uint32_t)f0;
+            if (dev) { side[(size_t)f0 + f] = sc.side[f]; side[(size_t)f0 + f].md_off += base; }
+            else std::memset(&side[(size_t)f0 + f], 0, sizeof(mp3s_frame_side));   // filled from the host parse below
+        }
+        f0 += p.n_frames;
+    }
+    if (blob.empty()) blob.resize(16, 0);
+    if (hipSetDevice(c->device) != hipSuccess) return fail(MP3S_E_HIP, "hipSetDevice failed");
+    const int chunk = (int)std::min<long>(n, kDecodeChunk) + 1;
+    int slot = 0;
+    auto grab = [&](size_t bytes) { return c->grab(slot++, bytes); };
+    void *d_is = grab((size_t)n * 2304 * 2), *d_si = grab((size_t)n * 4 * sizeof(mp3s_granule_si)),
+         *d_hdr = grab((size_t)chunk * sizeof(mp3s_frame_hdr)), *d_pcm = grab((size_t)chunk * frame_bytes), *d_st = grab(16),
+         *d_blob = grab(blob.size()), *d_side = grab((size_t)n * sizeof(mp3s_frame_side));
+    if (!d_is || !d_si || !d_hdr || !d_pcm || !d_st || !d_blob || !d_side)
+        return fail(MP3S_E_NOMEM, "hipMalloc failed for a %ld-frame decode", n);
+    int rc = MP3S_OK;
+    if (any_dev) {
+        rc = mp3s_dev_upload(c, d_blob, blob.data(), blob.size());
+        if (!rc) rc = mp3s_dev_upload(c, d_side, side.data(), (size_t)n * sizeof(mp3s_frame_side));
+        if (!rc) rc = mp3s_huffman_decode_dev(c, (const uint8_t *)d_blob, (const mp3s_frame_side *)d_side, (int)n, nch, max_part2_3(side.data(), n),
+                                              (int16_t *)d_is, (mp3s_granule_si *)d_si, (int32_t *)d_st);
+        int32_t st = 0;
+        if (!rc) rc = mp3s_dev_download(c, &st, d_st, sizeof st);
+        if (!rc && st) {
+            // Something in the Huffman data is off (region counts, big_values past 576 lines, big values running past
+            // part2_3_length).  The full host parser decides -- it walks the frame with the reference's single bit
+            // cursor -- and its frames replace the device's.
+            for (size_t k = 0; k < idx.size() && !rc; k++) {
+                const int i = idx[k];
+                if (!m.scanned[i].gpu_ok) continue;
+                const int n_before = m.parsed[i].n_frames;
+                rc = front_end(m, i, true);
+                if (rc) { rc = fail(rc, "file %d: malformed main data", i); break; }
+                if (m.parsed[i].n_frames != n_before) { rc = fail(MP3S_E_MALFORMED, "file %d: inconsistent parse", i); break; }
+                any_host = true;
+            }
+        }
+    }
+    if (any_host)   // streams that inherit scalefactors across frames were parsed on the host: place their frames
+        for (size_t k = 0; k < idx.size() && !rc; k++) {
+            const ParsedStream &p = m.parsed[idx[k]];
+            if (m.scanned[idx[k]].gpu_ok || !p.n_frames) continue;
+            rc = mp3s_dev_upload(c, (int16_t *)d_is + (size_t)first_of[k] * 2304, p.is.data(), (size_t)p.n_frames * 2304 * 2);
+            if (!rc) rc = mp3s_dev_upload(c, (mp3s_granule_si *)d_si + (size_t)first_of[k] * 4, p.si.data(),
+                                          (size_t)p.n_frames * 4 * sizeof(mp3s_granule_si));
+        }
+    // ---- transforms in chunks of kDecodeChunk frames; a chunk that starts inside a stream re-runs one halo frame.
+    //      Host layout = device layout plus one extra frame after every stream that ends in a bad header (D12): the
+    //      reference appends that stream's last PCM frame once more.
+    std::vector<long> out_first(idx.size());
+    long extra = 0;
+    for (size_t k = 0; k < idx.size(); k++) { out_first[k] = first_of[k] + extra; extra += m.parsed[idx[k]].dup_last_frame ? 1 : 0; }
+    uint8_t *arena = nullptr;
+    if (!d_keep) {
+        if (!m.arena[nch].reserve(m.head_room + (size_t)(n + extra) * frame_bytes))
+            return fail(MP3S_E_NOMEM, "hipHostMalloc failed for %ld frames of PCM", n + extra);
+        arena = m.arena[nch].data() + m.head_room;
+    }
+    std::vector<mp3s_frame_hdr> hc;
+    for (long start = 0; start < n && !rc; start += kDecodeChunk) {
+        const int halo = (start && hdr[(size_t)start].stream_first < (uint32_t)start) ? 1 : 0;
+        const long first = start - halo;
+        const int cnt = (int)std::min<long>(kDecodeChunk, n - start) + halo;
+        hc.assign(hdr.begin() + first, hdr.begin() + first + cnt);
+        for (auto &h : hc) h.stream_first = h.stream_first > (uint32_t)first ? h.stream_first - (uint32_t)first : 0;
+        rc = mp3s_dev_upload(c, d_hdr, hc.data(), (size_t)cnt * sizeof(mp3s_frame_hdr));
+        if (!rc) rc = mp3s_decode_transform_dev(c, (const int16_t *)d_is + (size_t)first * 2304, (const mp3s_granule_si *)d_si + (size_t)first * 4,
+                                                (const mp3s_frame_hdr *)d_hdr, cnt, nch, halo, out_format, d_pcm);
+        // copy out in runs that are contiguous on both sides (a run ends where a duplicated frame is inserted)
+        const long end = start + (cnt - halo);
+        for (long a = start; a < end && !rc;) {
+            size_t k = (size_t)(std::upper_bound(first_of.begin(), first_of.end(), a) - first_of.begin()) - 1;
+            long b = end;
+            for (size_t j = k; j < idx.size() && first_of[j] < end; j++)
+                if (m.parsed[idx[j]].dup_last_frame) { b = std::min<long>(end, first_of[j] + m.parsed[idx[j]].n_frames); break; }
+            if (b <= a) b = std::min<long>(end, a + 1);
+            const size_t dst = (size_t)(out_first[k] + (a - first_of[k])) * frame_bytes, bytes = (size_t)(b - a) * frame_bytes;
+            const uint8_t *src = (const uint8_t *)d_pcm + (size_t)(a - start) * frame_bytes;
+            if (d_keep) {
+                if (hipMemcpyAsync((uint8_t *)d_keep + dst, src, bytes, hipMemcpyDeviceToDevice, c->stream) != hipSuccess)
+                    rc = fail(MP3S_E_HIP, "device copy failed");
+            } else rc = mp3s_dev_download(c, arena + dst, src, bytes);
+            a = b;
+        }
+    }
+    for (size_t k = 0; k < idx.size() && !rc; k++) {
+        const ParsedStream &p = m.parsed[idx[k]];
+        if (p.dup_last_frame && p.n_frames > 0) {
+            const size_t last = (size_t)(out_first[k] + p.n_frames - 1) * frame_bytes;
+            if (d_keep) {
+                if (hipMemcpyAsync((uint8_t *)d_keep + last + frame_bytes, (uint8_t *)d_keep + last, frame_bytes, hipMemcpyDeviceToDevice,
+                                   c->stream) != hipSuccess)
+                    rc = fail(MP3S_E_HIP, "device copy failed");
+            } else {
+                hipStreamSynchronize(c->stream);
+                std::memcpy(arena + last + frame_bytes, arena + last, frame_bytes);
+            }
+        }
+        if (!d_keep) m.pcm[idx[k]] = arena + (size_t)out_first[k] * frame_bytes;
+    }
+    if (!d_keep) hipStreamSynchronize(c->stream);
+    return rc;
+}
+
+extern "C" {
+
+static int decode_streams_impl(mp3s_ctx *c, const uint8_t *const *files, const size_t *lens, int n_files, int out_format,
+                               size_t head_room, mp3s_buf **owner, mp3s_decoded *out)
+{
+    if (!c || !files || !lens || !owner || !out || n_files <= 0) return fail(MP3S_E_ARG, "bad argument");
+    if (out_format < 0 || out_format > 2) return fail(MP3S_E_ARG, "out_format=%d", out_format);
+    mp3s_buf *b = new mp3s_buf();
+    b->multi.reset(new mp3s_multi());
+    mp3s_multi &m = *b->multi;
+    m.head_room = head_room;
+    m.parsed.resize(n_files); m.scanned.resize(n_files); m.pcm.assign(n_files, nullptr); m.files.resize(n_files);
+    std::vector<int> group[3];
+    size_t total = 0;
+    for (int i = 0; i < n_files; i++) {
+        if (!files[i]) { delete b; return fail(MP3S_E_ARG, "file %d is null", i); }
+        m.files[i] = {files[i], lens[i]};
+        total += lens[i];
+    }
+    std::vector<int> frc(n_files, MP3S_OK);
+    parallel_files(n_files, total, [&](int i) { frc[i] = front_end(m, i); });
+    for (int i = 0; i < n_files; i++) {
+        if (frc[i]) { delete b; return fail(frc[i], "file %d: malformed or unsupported MP3 stream", i); }
+        if (m.parsed[i].n_frames > 0) group[m.parsed[i].nch].push_back(i);
+    }
+    for (int nch = 1; nch <= 2; nch++)
+        if (!group[nch].empty()) {
+            const int rc = decode_group(c, m, group[nch], nch, out_format);
+            if (rc) { delete b; return rc; }
+        }
+    for (int i = 0; i < n_files; i++) {
+        const ParsedStream &p = m.parsed[i];
+        out[i].n_frames = p.n_frames; out[i].nch = p.nch; out[i].sampling_rate = p.sampling_rate; out[i].bit_rate = p.bit_rate;
+        out[i].n_bits = (int32_t)p.bits.size(); out[i].n_rows = (int64_t)1152 * (p.n_frames + p.dup_last_frame);
+        out[i].pcm = m.pcm[i]; out[i].bits = p.bits.data();
+    }
+    *owner = b;
+    return MP3S_OK;
+}
+
+int mp3s_decode_streams(mp3s_ctx *c, const uint8_t *const *files, const size_t *lens, int n_files, int out_format,
+                        mp3s_buf **owner, mp3s_decoded *out)
+{
+    return decode_streams_impl(c, files, lens, n_files, out_format, 0, owner, out);
+}
+
+int mp3s_decode_block(mp3s_ctx *c, const uint8_t *file, size_t len, int64_t first_frame, int64_t n_frames, int out_format,
+                      mp3s_buf **owner, mp3s_decoded *out)
+{
+    if (!c || !file || !owner || !out || first_frame < 0 || n_frames <= 0 || first_frame > 0x7fffffff || n_frames > 0x7fffffff)
+        return fail(MP3S_E_ARG, "bad argument");
+    if (out_format < 0 || out_format > 2) return fail(MP3S_E_ARG, "out_format=%d", out_format);
+    // one frame in front of the block is decoded for its state and dropped: the IMDCT overlap and the synthesis fifo
+    // reach back less than a frame (Frame.py:151-153, 81-92)
+    const int halo = first_frame > 0 ? 1 : 0;
+    std::unique_ptr<mp3s_buf> b(new mp3s_buf());
+    b->multi.reset(new mp3s_multi());
+    mp3s_multi &m = *b->multi;
+    m.parsed.resize(1); m.scanned.resize(1); m.pcm.assign(1, nullptr); m.files.assign(1, {file, len});
+    m.window.assign(1, {(long)first_frame - halo, (long)n_frames + halo});
+    m.all_bits.resize(1);
+    int rc = front_end(m, 0);
+    if (rc) return fail(rc, "malformed or unsupported MP3 stream");
+    const ParsedStream &p = m.parsed[0];
+    if (p.n_frames <= halo) return fail(MP3S_E_ARG, "the block starts behind the last frame of the stream");
+    if (p.nch < 1 || p.nch > 2) return fail(MP3S_E_MALFORMED, "channel count");
+    rc = decode_group(c, m, std::vector<int>{0}, p.nch, out_format);
+    if (rc) return rc;
+    m.files.clear();   // borrowed
+    const size_t frame_bytes = (size_t)1152 * p.nch * pcm_elem(out_format);
+    out->n_frames = p.n_frames - halo; out->nch = p.nch; out->sampling_rate = p.sampling_rate; out->bit_rate = p.bit_rate;
+    out->n_rows = (int64_t)1152 * (p.n_frames - halo + p.dup_last_frame);
+    out->pcm = m.pcm[0] + (size_t)halo * frame_bytes;
+    out->n_bits = (int32_t)m.all_bits[0].size(); out->bits = m.all_bits[0].data();
+    *owner = b.release();
+    return MP3S_OK;
+}
+
+int mp3s_decode_stream(mp3s_ctx *c, const uint8_t *file, size_t len, int out_format, mp3s_buf **owner, mp3s_decoded *out)
+{
+    if (!file) return fail(MP3S_E_ARG, "null pointer");
+    return mp3s_decode_streams(c, &file, &len, 1, out_format, owner, out);
+}
+
+int mp3s_decode_file(mp3s_ctx *c, const uint8_t *mp3, size_t len, mp3s_buf **owner, mp3s_file *out)
+{
+    if (!c || !mp3 || !owner || !out) return fail(MP3S_E_ARG, "null pointer");
+    // the PCM lands 64 bytes into its buffer; the 44-byte WAV header goes right in front of it: no second copy
+    mp3s_buf *b = nullptr;
+    mp3s_decoded d;
+    const int rc = decode_streams_impl(c, &mp3, &len, 1, MP3S_PCM_I16, 64, &b, &d);
+    if (rc) return rc;
+    uint8_t *wav;
+    if (d.n_rows == 0) {   // nothing decoded: what scipy writes for an empty 1-d array at the header object's initial rate 0
+        b->bytes.assign(44, 0);
+        wav = b->bytes.data();
+        wav_header(0, 1, d.sampling_rate, wav);
+    } else {
+        wav = const_cast<uint8_t *>(static_cast<const uint8_t *>(d.pcm)) - 44;
+        wav_header(d.n_rows, d.nch, d.sampling_rate, wav);
+    }
+    std::memset(out, 0, sizeof *out);
+    out->data = wav; out->len = 44 + (size_t)d.n_rows * (size_t)d.nch * 2;
+    out->kbps = d.bit_rate / 1000; out->sampling_rate = d.sampling_rate; out->channels = d.nch; out->n_frames = d.n_frames;
+    out->n_bits = d.n_bits; out->bits = d.bits;
+    *owner = b;
+    return MP3S_OK;
+}
+
+}  // extern "C"

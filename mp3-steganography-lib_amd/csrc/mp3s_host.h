@@ -40,7 +40,7 @@ int rate_frames(int samplerate, int bitrate_kbps, int nch, int n_frames, mp3s_ra
 void decide_scfsi(int n_frames, const int32_t *en, const mp3s_gr_out *gr, int32_t *scfsi /*[n][2][4]*/);
 
 // __calc_scfsi energies of one granule*channel on the host with glibc log (reference MP3_Encoder.py:835-857);
-// used to recheck units the kernel flagged MP3S_RF_LOG_GUARD
+// the device takes these from a table instead; kept as the table's cross-check (mp3s_debug_scfsi_energies, tests)
 void host_scfsi_energies(const int32_t *xr576, int sr_idx, int32_t *en22);
 
 // bitstream formatter (reference MP3_Encoder.py:1097-1145, 1266-1552); gr is modified (stuffing) on a copy

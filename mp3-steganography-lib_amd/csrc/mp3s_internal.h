@@ -1,0 +1,216 @@
+// Shared by the translation units behind include/mp3s.h (mp3s_api.cpp, mp3s_decode_pipeline.cpp,
+// mp3s_encode_pipeline.cpp): the context, result owners, page-locked blocks and the pipeline helpers.  Nothing here is
+// part of the C-ABI.
+#pragma once
+#include <hip/hip_runtime_api.h>
+
+#include <algorithm>
+#include <atomic>
+#include <chrono>
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <memory>
+#include <mutex>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include "../../include/mp3s.h"
+#include "mp3s_device.h"
+#include "mp3s_host.h"
+
+using namespace mp3s;
+
+// records the text mp3s_last_error() returns on this thread; returns `code`
+int mp3s_fail(int code, const char *fmt, ...);
+#define fail mp3s_fail
+#define HIPCHK(call)                                                                                 \
+    do {                                                                                             \
+        hipError_t e_ = (call);                                                                      \
+        if (e_ != hipSuccess) return fail(MP3S_E_HIP, "%s: %s", #call, hipGetErrorString(e_));       \
+    } while (0)
+
+struct mp3s_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr, ev_order = nullptr;
+    int32_t *d_sync = nullptr;        // {finished workgroups, error bits} of the pack kernel in flight: self-clearing
+    void *scratch = nullptr; size_t scratch_bytes = 0;
+    Profiler prof;
+    // device buffers of the stream pipelines, kept between calls (hipMalloc/hipFree cost more than a small file's work)
+    static constexpr int kPoolSlots = 32;
+    void *pool[kPoolSlots] = {nullptr};
+    size_t pool_bytes[kPoolSlots] = {0};
+    void *grab(int slot, size_t bytes)
+    {
+        if (bytes < 16) bytes = 16;
+        if (pool_bytes[slot] >= bytes) return pool[slot];
+        if (pool[slot]) { hipStreamSynchronize(stream); hipFree(pool[slot]); pool[slot] = nullptr; pool_bytes[slot] = 0; }
+        const size_t want = bytes + bytes / 4;   // head room: similar-sized files reuse the buffer
+        if (hipMalloc(&pool[slot], want) != hipSuccess) { pool[slot] = nullptr; return nullptr; }
+        pool_bytes[slot] = want;
+        return pool[slot];
+    }
+    // host-side work arrays of the encoder, kept between calls: beyond a few MB a fresh vector means fresh pages from
+    // the kernel on every call (page faults cost more than the work done in them)
+    std::vector<int32_t> h_cursor, h_state, h_want, h_state_want;
+    std::vector<uint8_t> h_in;
+    int ensure_scratch(size_t bytes)
+    {
+        if (bytes <= scratch_bytes) return 0;
+        if (scratch) { hipFree(scratch); scratch = nullptr; scratch_bytes = 0; }
+        hipError_t e = hipMalloc(&scratch, bytes);
+        if (e != hipSuccess) return fail(MP3S_E_NOMEM, "hipMalloc(%zu) for scratch: %s", bytes, hipGetErrorString(e));
+        scratch_bytes = bytes;
+        return 0;
+    }
+};
+
+// Page-locked host memory for large results (decoded PCM): the device writes it at PCIe speed, no bounce buffer, no
+// page faults.  Pinning costs more than the copy it saves, so blocks are kept and reused: process-wide, because a
+// result may outlive the context that produced it.  (Blocks still cached at exit are left to the OS.)
+class PinnedBlock {
+public:
+    PinnedBlock() = default;
+    PinnedBlock(const PinnedBlock &) = delete;
+    PinnedBlock &operator=(const PinnedBlock &) = delete;
+    ~PinnedBlock() { release(); }
+    bool reserve(size_t bytes)
+    {
+        if (bytes <= cap_) return true;
+        release();
+        if (bytes > kMaxPinned) {   // hours of audio in one call: pinning gigabytes costs seconds, ordinary memory then
+            p_ = (uint8_t *)std::malloc(bytes);
+            if (!p_) return false;
+            cap_ = bytes; pinned_ = false;
+            return true;
+        }
+        pinned_ = true;
+        {
+            std::lock_guard<std::mutex> g(mu());
+            auto &fl = free_list();
+            size_t best = fl.size();
+            for (size_t i = 0; i < fl.size(); i++)
+                if (fl[i].second >= bytes && (best == fl.size() || fl[i].second < fl[best].second)) best = i;
+            if (best < fl.size()) { p_ = fl[best].first; cap_ = fl[best].second; fl.erase(fl.begin() + best); return true; }
+        }
+        const size_t want = bytes + bytes / 8 + (1 << 16);
+        void *q = nullptr;
+        if (hipHostMalloc(&q, want, hipHostMallocDefault) != hipSuccess) return false;
+        p_ = (uint8_t *)q; cap_ = want;
+        return true;
+    }
+    uint8_t *data() const { return p_; }
+
+private:
+    void release()
+    {
+        if (!p_) return;
+        if (!pinned_) { std::free(p_); p_ = nullptr; cap_ = 0; return; }
+        std::lock_guard<std::mutex> g(mu());
+        auto &fl = free_list();
+        size_t held = 0;
+        for (auto &e : fl) held += e.second;
+        if (fl.size() < 8 && held + cap_ <= kMaxPinned) fl.emplace_back(p_, cap_);
+        else hipHostFree(p_);
+        p_ = nullptr; cap_ = 0;
+    }
+    static std::mutex &mu() { static std::mutex *m = new std::mutex(); return *m; }
+    static std::vector<std::pair<uint8_t *, size_t>> &free_list()
+    {
+        static auto *v = new std::vector<std::pair<uint8_t *, size_t>>();
+        return *v;
+    }
+    static constexpr size_t kMaxPinned = (size_t)1 << 30;
+    uint8_t *p_ = nullptr;
+    size_t cap_ = 0;
+    bool pinned_ = true;
+};
+
+struct mp3s_multi {     // owner payload of mp3s_decode_streams
+    std::vector<std::pair<const uint8_t *, size_t>> files;   // borrowed for the duration of the call
+    std::vector<ParsedStream> parsed;
+    std::vector<ScannedStream> scanned;
+    PinnedBlock arena[3];                 // PCM of all mono / all stereo streams, index = channel count
+    size_t head_room = 0;                 // bytes kept free in front of the PCM (mp3s_decode_file puts the WAV header there)
+    std::vector<const uint8_t *> pcm;     // per stream, into its arena
+    // mp3s_decode_block: only frames [first, first + count) of stream i are kept after parsing (absent: all of them)
+    std::vector<std::pair<long, long>> window;
+    std::vector<std::vector<uint8_t>> all_bits;   // ... and the stego bits of the whole stream
+};
+
+struct mp3s_buf {
+    std::shared_ptr<mp3s_multi> multi;
+    ParsedStream parsed;
+    ScannedStream scanned;
+    std::vector<uint8_t> bytes;      // generic payload (pcm / mp3)
+    std::vector<uint8_t> bits;
+    std::vector<int32_t> scfsi;
+    std::vector<std::unique_ptr<mp3s_buf>> parts;   // results of the batches of a multi-file call
+    // encoder results: MP3 bytes and GrInfo records land in page-locked blocks and are handed out from there
+    PinnedBlock big[2];
+    uint8_t *mp3 = nullptr;
+    mp3s_gr_out *gr_out = nullptr;
+};
+
+// MP3S_TRACE=1: phase timings of the file pipelines on stderr
+inline bool trace_on() { static const bool on = getenv("MP3S_TRACE") != nullptr; return on; }
+inline double now_ms() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+
+// f(i) for i in [0, n) on a few host threads: the front ends of the files of a batch are independent.  Small batches
+// (by bytes) stay on the calling thread -- starting a thread costs about what scanning 100 KB does.
+template <class F>
+void parallel_files(int n, size_t total_bytes, F f)
+{
+    const unsigned hw = std::thread::hardware_concurrency();
+    const int workers = (int)std::min<size_t>({(size_t)n, (size_t)std::min(hw ? hw : 1u, 16u), total_bytes / (256u << 10) + 1});
+    if (workers <= 1) {
+        for (int i = 0; i < n; i++) f(i);
+        return;
+    }
+    std::atomic<int> next{0};
+    auto run = [&]() { for (int i; (i = next.fetch_add(1)) < n;) f(i); };
+    std::vector<std::thread> pool;
+    for (int w = 1; w < workers; w++) pool.emplace_back(run);
+    run();
+    for (auto &t : pool) t.join();
+}
+
+// ---------------------------------------------------------------- decode pipeline (mp3s_decode_pipeline.cpp)
+constexpr int kDecodeChunk = 16384;   // frames per decode launch group (scratch ~0.6 GB); chunks overlap by a 1-frame halo
+inline size_t pcm_elem(int fmt) { return fmt == MP3S_PCM_I16 ? 2 : (fmt == MP3S_PCM_F32 ? 4 : 8); }
+int max_part2_3(const mp3s_frame_side *side, long n);
+// keep frames [first, first + count) of a parsed stream (its main data, side records, samples)
+void cut_window(ParsedStream &p, ScannedStream &sc, long first, long count);
+// host front end of stream i of m (scan; full host parse where the device cannot decode, or when `full`)
+int front_end(mp3s_multi &m, int i, bool full = false);
+// decode the streams `idx` of m (one channel count) as one batch; d_keep: int16 PCM stays on the device there
+int decode_group(mp3s_ctx *c, mp3s_multi &m, const std::vector<int> &idx, int nch, int out_format, void *d_keep = nullptr);
+
+// ---------------------------------------------------------------- encode pipeline (mp3s_encode_pipeline.cpp)
+constexpr int kLongMessageBits = 1024;    // above: the first pass does not guess cursors at all
+constexpr int32_t kNoCursor = 0x3fffffff; // "behind every message": such a unit hides nothing
+constexpr int kPatternBytes = 32;         // the eight 3-bit patterns, 4 bytes apart, in front of the messages
+constexpr int kVariantEntries = 65536;    // (unit, pattern) entries per variant launch
+constexpr size_t kFewUnits = 8;           // that few wrong cursors after the first pass: re-run them directly
+
+struct EncSeg {             // one stream of an encode batch: frames back to back in the batch's PCM
+    int n_frames = 0;
+    const uint8_t *hide = nullptr;   // 0/1 bytes
+    int n_hide = 0;
+    // a block of a longer stream (mp3s_encode_block; only as the single stream of a batch)
+    int lead = 0;                    // frames of PCM in front of the block: transformed for their state, then dropped
+    int64_t first_frame = 0;         // index of the block's first frame in its stream (padding recurrence)
+    bool last = true;                // the stream ends with this block (the reference drops the cached tail there: E14)
+    const mp3s_carry *carry_in = nullptr;
+    // filled by encode_batch
+    int first = 0, hide_base = 0;
+    int64_t hide_offset = 0;         // message bits consumed (from the start of the stream)
+    size_t mp3_off = 0, mp3_len = 0; // the stream's bytes inside the batch's output
+    mp3s_carry carry_out = {};
+    bool carry_used = false;         // the block's bytes depend on carry_in
+};
+int encode_batch(mp3s_ctx *c, const int16_t *pcm, const int16_t *pcm_dev, std::vector<EncSeg> &segs, int samplerate, int bitrate_kbps,
+                 mp3s_buf *b, int *passes_out);

@@ -314,7 +314,7 @@ def test_many_seeded_streams_across_chunk_boundaries(ctx, mlib, orc):
 # ------------------------------------------------------------------------------------------------ long messages
 def test_long_messages_take_the_variant_path(ctx, mlib, orc):
     """messages above 1024 bits: the rate loop runs once per 3-bit pattern and the cursor walk picks each unit's pattern
-    (mp3s_api.cpp encode_core).  Lengths around the threshold, ending mid-stream (the units at the message end fall back
+    (mp3s_encode_pipeline.cpp encode_batch).  Lengths around the threshold, ending mid-stream (the units at the message end fall back
     to the exact re-run), ending on every offset inside a unit, and longer than the stream can hold."""
     from synth_pcm import synth_pcm
     pcm = synth_pcm(700, seed=77)
