@@ -78,7 +78,8 @@ def main():
     from mp3stego import _lib
     from synth_pcm import synth_pcm
     L = _lib.lib()
-    ctx = _lib.Context(local_rank)
+    # one rank per GPU; MP3STEGO_DEVICE pins every rank to one device (launch-path checks on a 1-GPU box)
+    ctx = _lib.Context(int(os.environ.get("MP3STEGO_DEVICE", local_rank)))
     n = args.frames
 
     # ---------------------------------------------------------------- build the resident batch (untimed)
@@ -98,7 +99,7 @@ def main():
     d_is2 = [ctx.alloc(n * 2304 * 2), ctx.alloc(n * 2304 * 2)]
     d_si2 = [ctx.alloc(n * 4 * 72), ctx.alloc(n * 4 * 72)]
     d_hst2 = [ctx.alloc(16), ctx.alloc(16)]
-    aux = None if args.no_overlap else _lib.Context(local_rank)   # second stream on the same device
+    aux = None if args.no_overlap else _lib.Context(ctx.device)   # second stream on the same device
     d_hdr = ctx.to_device(parsed["hdr"])
     rf, _pad = _lib.rate_frames(44100, 128, 2, n)
     d_rf = ctx.to_device(rf)
@@ -359,7 +360,7 @@ def main():
             "metric": METRIC, "value": round(value, 1), "unit": "frames/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(max_step * 1e3, 4), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f64 (decode) / int32 (encode)", "data": "synthetic",
-            "config": {"workload": f"{n}-frame full decode->stego-embed->re-encode pipeline on 1xMI355X (BASELINE "
+            "config": {"workload": f"{n}-frame full decode->stego-embed->re-encode pipeline per MI355X (BASELINE "
                                    "configs[2]); MP3 main data + side info resident in HBM, MP3 frames out", "frames_per_gpu": n,
                        "sample_rate": 44100, "channels": 2, "bitrate_kbps": 128, "message_bits": int(len(hide)),
                        "rate_loop_rerun_units": int(len(redo_list)), "pipeline_rate_passes": int(final["rate_passes"]),
