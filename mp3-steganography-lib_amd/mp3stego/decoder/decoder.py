@@ -1,7 +1,8 @@
 """`Decoder` with the reference's signature and side effects (reference mp3stego/decoder/decoder.py:9-117).
 
 One native call (mp3s_decode_file) turns the MP3 bytes into the WAV bytes scipy.io.wavfile.write would produce
-for the int16 PCM; the reveal-string parse (decoder.py:86-108) is native too (mp3s_message_reveal).
+for the int16 PCM; the reveal-string parse (decoder.py:86-108) is native too (mp3s_message_reveal).  The ID3v2
+listing a non-quiet decode leaves in METADATA.txt (decoder.py:37-57) is host bookkeeping: mp3stego/decoder/id3.py.
 """
 import os
 import sys
@@ -9,6 +10,7 @@ import time
 
 
 from mp3stego import _lib
+from mp3stego.decoder import id3
 
 
 class Decoder:
@@ -26,6 +28,7 @@ class Decoder:
             sys.exit(f'File {self.__file_path} not found.')
         with open(self.__file_path, 'rb') as f:
             self.__data = f.read()
+        self.__tag = id3.read_tag(self.__data)     # IndexError for a file that ends inside its tag, as in the reference
         self.__result = None
 
     def decode(self, quiet: bool = True, reveal: bool = False, txt_file_path: str = "") -> int:
@@ -34,6 +37,9 @@ class Decoder:
 
         :return: the bitrate (kbps) of the last frame header, as the reference does.
         """
+        if not quiet and self.__tag is not None:
+            with open('METADATA.txt', 'w') as f:   # in the working directory, like the reference
+                f.write(id3.listing(self.__file_path, self.__tag))
         start = time.time()
         try:
             res = _lib.default_context().decode_file(self.__data)

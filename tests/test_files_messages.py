@@ -229,3 +229,42 @@ def test_encode_file_sample_count_rules(ctx, mlib):
     with pytest.raises(mlib.Mp3sError) as e:
         ctx.encode_file(ok, -1)
     assert e.value.code == mlib.E_UNSUPPORTED
+
+
+def test_id3_listing_matches_reference(golden_dir):
+    """METADATA.txt of a non-quiet decode (reference decoder/ID3_Parser.py, decoder.py:37-57): validity, audio offset and
+    the listing text for hand-made tags, against what the reference made of them (tests/golden/gen_id3_golden.py)"""
+    import json
+    from mp3stego.decoder import id3
+    cases = json.load(open(os.path.join(golden_dir, "g8_id3.json")))
+    assert len(cases) >= 30
+    for r in cases:
+        data = bytes.fromhex(r["file_hex"])
+        if r["raises"] and r["name"] == "id_cut_by_eof":             # the reference's ID3 constructor dies on it
+            with pytest.raises(IndexError):
+                id3.read_tag(data)
+            continue
+        tag = id3.read_tag(data)
+        if r["raises"]:                                              # (dies later, in the frame parser: offset past the file)
+            assert tag is not None and tag.offset > len(data)
+            continue
+        assert (tag is not None) == r["valid"], r["name"]
+        if tag is not None:
+            assert tag.offset == r["offset"], r["name"]
+            assert id3.listing("case.mp3", tag) == r["metadata"], r["name"]
+    with pytest.raises(IndexError):
+        id3.read_tag(b"ID")
+
+
+def test_scan_skips_the_tag_the_listing_describes(mlib, golden_dir):
+    """the library's own tag skip and the listing agree on where the audio starts"""
+    import json
+    from mp3stego.decoder import id3
+    for r in json.load(open(os.path.join(golden_dir, "g8_id3.json"))):
+        if r["raises"] or not r["valid"]:
+            continue
+        data = bytes.fromhex(r["file_hex"])
+        tag = id3.read_tag(data)
+        s = mlib.scan_stream(data)
+        plain = mlib.scan_stream(data[tag.offset:])
+        assert s["n_frames"] == plain["n_frames"] and np.array_equal(s["frame_size"], plain["frame_size"]), r["name"]

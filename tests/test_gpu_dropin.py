@@ -115,3 +115,22 @@ def test_a_file_that_does_not_start_with_a_frame(work):
     with pytest.raises(SystemExit) as e:
         st.hide_message(str(junk), str(work / "o.mp3"), "x")
     assert str(e.value) == "Unsupported sampling frequency."
+
+
+def test_metadata_listing_of_a_tagged_file(work, golden_dir, monkeypatch):
+    """a non-quiet decode of a file with an ID3v2 tag leaves METADATA.txt in the working directory (reference
+    decoder/decoder.py:37-57, 73-74); a quiet one, or a file without a tag, does not; the audio decodes the same"""
+    import json
+    from mp3stego import Decoder
+    monkeypatch.chdir(work)
+    case = [r for r in json.load(open(os.path.join(golden_dir, "g8_id3.json"))) if r["name"] == "frame_flags_6"][0]
+    data = bytes.fromhex(case["file_hex"])
+    (work / "case.mp3").write_bytes(data)
+    assert Decoder("case.mp3", "quiet.wav").decode(quiet=True) == 128 and not os.path.exists("METADATA.txt")
+    assert Decoder("case.mp3", "loud.wav").decode(quiet=False) == 128
+    assert open("METADATA.txt").read() == case["metadata"]
+    assert (work / "loud.wav").read_bytes() == (work / "quiet.wav").read_bytes()
+    os.remove("METADATA.txt")
+    (work / "bare.mp3").write_bytes(data[case["offset"]:])
+    assert Decoder("bare.mp3", "bare.wav").decode(quiet=False) == 128 and not os.path.exists("METADATA.txt")
+    assert (work / "bare.wav").read_bytes() == (work / "loud.wav").read_bytes()
