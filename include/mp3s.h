@@ -169,7 +169,8 @@ int mp3s_encode_transform(mp3s_ctx *ctx, const int16_t *pcm, const mp3s_frame_hd
  * Units are indexed u = (frame*2 + ch)*2 + gr, i.e. the reference's processing order (ch outer, gr inner).
  * mdct      : int32 [n_frames][2][2][576]
  * frames    : mp3s_rate_frame [n_frames]
- * hide_bits : n_hide bytes of 0/1 (NULL/0: not hiding)
+ * hide_bits : n_hide bytes of 0/1 (NULL/0: not hiding); a unit reads hide_bits[i] only for i < min(n_hide,
+ *             frames[frame].hide_end), so the messages of several streams can sit back to back in one array
  * cursor_in : int32 [n_units] hide-string index at the start of each unit (ignored when not hiding)
  * state_in  : int32 [n_units][4] address1, address2, address3, quantizerStepSize inherited from the same
  *             (gr,ch) of the previous frame (NULL = zeros)
