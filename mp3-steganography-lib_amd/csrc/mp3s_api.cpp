@@ -7,7 +7,7 @@ namespace {
 thread_local std::string g_err;
 }
 
-int mp3s_fail(int code, const char *fmt, ...)
+int mp3s::fail(int code, const char *fmt, ...)
 {
     char buf[512];
     va_list ap;

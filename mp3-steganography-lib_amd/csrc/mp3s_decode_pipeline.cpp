@@ -38,7 +38,8 @@ int front_end(mp3s_multi &m, int i, bool full)
     // no sync where the stream should start: the reference parses nothing and writes an empty WAV (MP3_Parser.py:37-46)
     if (!rc && (size_t)i < m.window.size()) {
         if ((size_t)i < m.all_bits.size()) m.all_bits[i] = p.bits;
-        cut_window(p, sc, m.window[i].first, m.window[i].second);
+        cut_window(p, sc, m.window[i].first, m.window[i].count);
+        if (!m.window[i].keep_dup) p.dup_last_frame = 0;
     }
     return rc;
 }
@@ -234,7 +235,7 @@ int mp3s_decode_block(mp3s_ctx *c, const uint8_t *file, size_t len, int64_t firs
     b->multi.reset(new mp3s_multi());
     mp3s_multi &m = *b->multi;
     m.parsed.resize(1); m.scanned.resize(1); m.pcm.assign(1, nullptr); m.files.assign(1, {file, len});
-    m.window.assign(1, {(long)first_frame - halo, (long)n_frames + halo});
+    m.window.assign(1, {(long)first_frame - halo, (long)n_frames + halo, true});
     m.all_bits.resize(1);
     int rc = front_end(m, 0);
     if (rc) return fail(rc, "malformed or unsupported MP3 stream");

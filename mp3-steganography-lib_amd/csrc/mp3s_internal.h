@@ -21,11 +21,13 @@
 #include "mp3s_device.h"
 #include "mp3s_host.h"
 
+namespace mp3s {
+// records the text mp3s_last_error() returns on this thread; returns `code`
+int fail(int code, const char *fmt, ...) __attribute__((format(printf, 2, 3)));
+}  // namespace mp3s
+
 using namespace mp3s;
 
-// records the text mp3s_last_error() returns on this thread; returns `code`
-int mp3s_fail(int code, const char *fmt, ...);
-#define fail mp3s_fail
 #define HIPCHK(call)                                                                                 \
     do {                                                                                             \
         hipError_t e_ = (call);                                                                      \
@@ -136,8 +138,10 @@ struct mp3s_multi {     // owner payload of mp3s_decode_streams
     PinnedBlock arena[3];                 // PCM of all mono / all stereo streams, index = channel count
     size_t head_room = 0;                 // bytes kept free in front of the PCM (mp3s_decode_file puts the WAV header there)
     std::vector<const uint8_t *> pcm;     // per stream, into its arena
-    // mp3s_decode_block: only frames [first, first + count) of stream i are kept after parsing (absent: all of them)
-    std::vector<std::pair<long, long>> window;
+    // blocks of a stream: only frames [first, first + count) of stream i are kept after parsing (absent: all of them);
+    // keep_dup = the frame the reference repeats after a bad header (D12) still belongs to a window that ends the stream
+    struct Window { long first, count; bool keep_dup; };
+    std::vector<Window> window;
     std::vector<std::vector<uint8_t>> all_bits;   // ... and the stego bits of the whole stream
 };
 

@@ -104,6 +104,47 @@ def test_encode_block_carry_contract(ctx, mlib):
             ctx.encode_block(pcm[:10 * 1152], bad["lead"], bad["first"], True, 44100, 128, None, bad["carry"])
 
 
+def _shrink_part2_3(mp3, frame_sizes, frame, to):
+    """part2_3_length of granule 0 / channel 0 of `frame` set to `to` bits: its big values then run past the end of the
+    granule, which the device Huffman kernel reports and the host parser -- one bit cursor per frame, as the reference --
+    decodes.  (stereo, no CRC: the 12-bit field starts 20 bits into the side info)"""
+    at = int(np.sum(frame_sizes[:frame])) + 4
+    b = bytearray(mp3)
+    word = int.from_bytes(b[at:at + 4], "big")
+    assert (word & 0xfff) > to
+    word = (word & ~0xfff) | to
+    b[at:at + 4] = word.to_bytes(4, "big")
+    return bytes(b)
+
+
+@pytest.mark.gpu
+def test_blocks_of_a_stream_that_needs_the_host_parser(ctx, mlib, orc):
+    """a frame the device Huffman decoder hands back to the host parser, sitting in the middle of a block: the block
+    paths cut the host parser's frames to the same window (found by the soak: the fallback used to see the whole file)"""
+    from mp3stego import sharded
+    from synth_pcm import synth_pcm
+    mp3 = ctx.encode_pcm(synth_pcm(30, seed=44), 44100, 128, None)["mp3"]
+    sizes = mlib.scan_stream(mp3)["frame_size"]
+    for frame in (7, 19, 29):
+        bad = _shrink_part2_3(mp3, sizes, frame, 40)
+        sc = mlib.scan_stream(bad)                                   # the device decoder does flag this stream
+        d_blob, d_side = ctx.to_device(sc["blob"]), ctx.to_device(sc["side"])
+        d_is, d_si, d_st = ctx.alloc(30 * 2304 * 2), ctx.alloc(30 * 4 * 72), ctx.alloc(4)
+        mlib.check(mlib.lib().mp3s_huffman_decode_dev(ctx.handle, d_blob, d_side, 30, 2, sc["max_part2_3_length"], d_is, d_si, d_st))
+        assert int(ctx.download(d_st, np.int32, (1,))[0]) != 0
+        for q in (d_blob, d_side, d_is, d_si, d_st):
+            ctx.free(q)
+        whole = ctx.decode_stream(bad, mlib.MP3S_PCM_F64)
+        o = orc.decode(bad)
+        assert o["rc"] == 0 and whole["pcm"].tobytes() == o["pcm"].tobytes()
+        for world in (2, 3, 5):
+            got = _play(world, lambda comm: sharded.decode_sharded(ctx, bad, comm, mlib.MP3S_PCM_F64))
+            assert got["pcm"].tobytes() == whole["pcm"].tobytes(), (frame, world)
+            again = ctx.hide_message(bad, "through the fallback")
+            got = _play(world, lambda comm: sharded.reencode_sharded(ctx, bad, "through the fallback", comm))
+            assert got["data"] == again["data"], (frame, world)
+
+
 @pytest.mark.gpu
 def test_reencode_block_entry_point(ctx, mlib):
     """mp3s_reencode_block on its own: blocks partition the PCM frames, ranks beyond the last frame get nothing, the
