@@ -86,7 +86,7 @@ struct SideRegs {
 template <int WAVES, int LANES>
 __global__ __launch_bounds__(WAVES * 64) void k_dec_huffman(
     const uint8_t *__restrict__ blob, const mp3s_frame_side *__restrict__ side, int n_frames, int nch, int W, int max_bits,
-    int16_t *__restrict__ is, mp3s_granule_si *__restrict__ si_out, int32_t *__restrict__ status)
+    int16_t *__restrict__ is, mp3s_granule_si *__restrict__ si_out, int32_t *__restrict__ status, int per_frame)
 {
     __shared__ uint16_t fast[15][HUFF_L1_N];
     __shared__ uint16_t lut2[HUFF_L2_N];    // second-level tables for the codes longer than the first-level index
@@ -294,7 +294,10 @@ __global__ __launch_bounds__(WAVES * 64) void k_dec_huffman(
             sample += 4;
         }
     }
-    if (err) atomicOr(status, err);
+    if (err) {
+        atomicOr(status, err);
+        if (per_frame) atomicOr(status + 1 + f, err);   // which frame: the caller re-parses only the streams that hold one
+    }
     }   // worker
 }
 

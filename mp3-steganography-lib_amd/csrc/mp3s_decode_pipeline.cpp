@@ -83,7 +83,7 @@ int decode_group(mp3s_ctx *c, mp3s_multi &m, const std::vector<int> &idx, int nc
     int slot = 0;
     auto grab = [&](size_t bytes) { return c->grab(slot++, bytes); };
     void *d_is = grab((size_t)n * 2304 * 2), *d_si = grab((size_t)n * 4 * sizeof(mp3s_granule_si)),
-         *d_hdr = grab((size_t)chunk * sizeof(mp3s_frame_hdr)), *d_pcm = grab((size_t)chunk * frame_bytes), *d_st = grab(16),
+         *d_hdr = grab((size_t)chunk * sizeof(mp3s_frame_hdr)), *d_pcm = grab((size_t)chunk * frame_bytes), *d_st = grab(((size_t)n + 1) * 4),
          *d_blob = grab(blob.size()), *d_side = grab((size_t)n * sizeof(mp3s_frame_side));
     if (!d_is || !d_si || !d_hdr || !d_pcm || !d_st || !d_blob || !d_side)
         return fail(MP3S_E_NOMEM, "hipMalloc failed for a %ld-frame decode", n);
@@ -91,18 +91,26 @@ int decode_group(mp3s_ctx *c, mp3s_multi &m, const std::vector<int> &idx, int nc
     if (any_dev) {
         rc = mp3s_dev_upload(c, d_blob, blob.data(), blob.size());
         if (!rc) rc = mp3s_dev_upload(c, d_side, side.data(), (size_t)n * sizeof(mp3s_frame_side));
-        if (!rc) rc = mp3s_huffman_decode_dev(c, (const uint8_t *)d_blob, (const mp3s_frame_side *)d_side, (int)n, nch, max_part2_3(side.data(), n),
-                                              (int16_t *)d_is, (mp3s_granule_si *)d_si, (int32_t *)d_st);
+        if (!rc) {
+            const int e = launch_huffman(c->stream, (const uint8_t *)d_blob, (const mp3s_frame_side *)d_side, (int)n, nch,
+                                         max_part2_3(side.data(), n), (int16_t *)d_is, (mp3s_granule_si *)d_si, (int32_t *)d_st, &c->prof, true);
+            if (e) rc = fail(MP3S_E_HIP, "huffman launch: %s", hipGetErrorString((hipError_t)e));
+        }
         int32_t st = 0;
         if (!rc) rc = mp3s_dev_download(c, &st, d_st, sizeof st);
         if (!rc && st) {
             // Something in the Huffman data is off (region counts, big_values past 576 lines, big values running past
             // part2_3_length).  The full host parser decides -- it walks the frame with the reference's single bit
-            // cursor -- and its frames replace the device's.
+            // cursor -- and its frames replace the device's, for the streams that hold a flagged frame.
+            std::vector<int32_t> fst((size_t)n);
+            rc = mp3s_dev_download(c, fst.data(), (const int32_t *)d_st + 1, (size_t)n * 4);
             for (size_t k = 0; k < idx.size() && !rc; k++) {
                 const int i = idx[k];
                 if (!m.scanned[i].gpu_ok) continue;
                 const int n_before = m.parsed[i].n_frames;
+                bool flagged = false;
+                for (long f = first_of[k]; f < first_of[k] + n_before && !flagged; f++) flagged = fst[(size_t)f] != 0;
+                if (!flagged) continue;
                 rc = front_end(m, i, true);
                 if (rc) { rc = fail(rc, "file %d: malformed main data", i); break; }
                 if (m.parsed[i].n_frames != n_before) { rc = fail(MP3S_E_MALFORMED, "file %d: inconsistent parse", i); break; }

@@ -137,6 +137,11 @@ def test_blocks_of_a_stream_that_needs_the_host_parser(ctx, mlib, orc):
         whole = ctx.decode_stream(bad, mlib.MP3S_PCM_F64)
         o = orc.decode(bad)
         assert o["rc"] == 0 and whole["pcm"].tobytes() == o["pcm"].tobytes()
+        # in a batch only the stream that holds the flagged frame goes back to the host parser; all come out right
+        trio = ctx.decode_streams([mp3, bad, mp3[:418 * 9]], mlib.MP3S_PCM_F64)
+        assert trio[1]["pcm"].tobytes() == o["pcm"].tobytes()
+        assert trio[0]["pcm"].tobytes() == orc.decode(mp3)["pcm"].tobytes()
+        assert trio[2]["pcm"].tobytes() == orc.decode(mp3[:418 * 9])["pcm"].tobytes()
         for world in (2, 3, 5):
             got = _play(world, lambda comm: sharded.decode_sharded(ctx, bad, comm, mlib.MP3S_PCM_F64))
             assert got["pcm"].tobytes() == whole["pcm"].tobytes(), (frame, world)
