@@ -24,16 +24,15 @@ void cut_window(ParsedStream &p, ScannedStream &sc, long first, long count)
 }
 
 // host front end of stream i of m: byte-level scan; scalefactors + Huffman run on the device unless the stream inherits
-// scalefactors across frames (mixed blocks ...) or `full` asks for it, in which case the host parser produces its frames
-int front_end(mp3s_multi &m, int i, bool full)
+// scalefactors across frames (mixed blocks ...), in which case the host parser produces its frames
+int front_end(mp3s_multi &m, int i)
 {
     ParsedStream &p = m.parsed[i];
     ScannedStream &sc = m.scanned[i];
-    int rc = full ? MP3S_OK : parse_stream(m.files[i].first, m.files[i].second, p, &sc);
-    if (!rc && (full || !sc.gpu_ok)) {
+    int rc = parse_stream(m.files[i].first, m.files[i].second, p, &sc);
+    if (!rc && !sc.gpu_ok) {
         rc = parse_stream(m.files[i].first, m.files[i].second, p, nullptr);
-        sc.gpu_ok = false;
-        sc.side.clear(); sc.blob.clear();   // (possibly cut to a window already; not used for host-parsed streams)
+        sc.side.clear(); sc.blob.clear();   // not used for host-parsed streams
     }
     // no sync where the stream should start: the reference parses nothing and writes an empty WAV (MP3_Parser.py:37-46)
     if (!rc && (size_t)i < m.window.size()) {
@@ -99,23 +98,33 @@ int decode_group(mp3s_ctx *c, mp3s_multi &m, const std::vector<int> &idx, int nc
         int32_t st = 0;
         if (!rc) rc = mp3s_dev_download(c, &st, d_st, sizeof st);
         if (!rc && st) {
-            // Something in the Huffman data is off (region counts, big_values past 576 lines, big values running past
-            // part2_3_length).  The full host parser decides -- it walks the frame with the reference's single bit
-            // cursor -- and its frames replace the device's, for the streams that hold a flagged frame.
+            // Something in the Huffman data of some frames is off (region counts, big_values past 576 lines, big values
+            // running past part2_3_length -- which is what the cut tail of this library's own output looks like in one file
+            // out of eight).  The host parser decides those frames -- it walks a frame with the reference's single bit
+            // cursor -- and its samples replace the device's.  Frames of a device-decoded stream inherit nothing from one
+            // another, so only the flagged ones are redone.
             std::vector<int32_t> fst((size_t)n);
             rc = mp3s_dev_download(c, fst.data(), (const int32_t *)d_st + 1, (size_t)n * 4);
-            for (size_t k = 0; k < idx.size() && !rc; k++) {
+            std::vector<long> flagged;
+            for (long f = 0; f < n; f++)
+                if (fst[(size_t)f]) flagged.push_back(f);
+            std::vector<int16_t> his(flagged.size() * 2304);          // staged here until the copies have been issued and waited for
+            std::vector<mp3s_granule_si> hsi(flagged.size() * 4);
+            int redone = 0;
+            for (size_t q = 0; q < flagged.size() && !rc; q++) {
+                const long f = flagged[q];
+                const size_t k = (size_t)(std::upper_bound(first_of.begin(), first_of.end(), f) - first_of.begin()) - 1;
                 const int i = idx[k];
                 if (!m.scanned[i].gpu_ok) continue;
-                const int n_before = m.parsed[i].n_frames;
-                bool flagged = false;
-                for (long f = first_of[k]; f < first_of[k] + n_before && !flagged; f++) flagged = fst[(size_t)f] != 0;
-                if (!flagged) continue;
-                rc = front_end(m, i, true);
-                if (rc) { rc = fail(rc, "file %d: malformed main data", i); break; }
-                if (m.parsed[i].n_frames != n_before) { rc = fail(MP3S_E_MALFORMED, "file %d: inconsistent parse", i); break; }
-                any_host = true;
+                const int prc = parse_scanned_frame(m.scanned[i].side[(size_t)(f - first_of[k])], m.scanned[i].blob.data(), &his[q * 2304], &hsi[q * 4]);
+                if (prc) { rc = fail(prc, "file %d: malformed main data", i); break; }
+                if (hipMemcpyAsync((int16_t *)d_is + (size_t)f * 2304, &his[q * 2304], 2304 * sizeof(int16_t), hipMemcpyHostToDevice, c->stream) != hipSuccess ||
+                    hipMemcpyAsync((mp3s_granule_si *)d_si + (size_t)f * 4, &hsi[q * 4], 4 * sizeof(mp3s_granule_si), hipMemcpyHostToDevice, c->stream) != hipSuccess)
+                    rc = fail(MP3S_E_HIP, "upload of a host-decoded frame failed");
+                redone++;
             }
+            if (hipStreamSynchronize(c->stream) != hipSuccess && !rc) rc = fail(MP3S_E_HIP, "sync failed");
+            if (trace_on()) fprintf(stderr, "mp3s:   device Huffman status 0x%x: %d frame(s) decoded on the host instead\n", st, redone);
         }
     }
     if (any_host)   // streams that inherit scalefactors across frames were parsed on the host: place their frames

@@ -540,7 +540,7 @@ int mp3s_reencode_block(mp3s_ctx *c, const uint8_t *mp3, size_t len, const uint8
     const int halo = first - lead > 0 ? 1 : 0;            // a frame in front of that, for the decoder's
     const long w0 = first - lead - halo, w1 = std::min(first + count, n);
     const bool with_dup = first + count == total && p.dup_last_frame;
-    m.window.assign(1, {w0, w1 - w0, with_dup});   // registered: a fallback to the host parser inside decode_group cuts again
+    m.window.assign(1, {w0, w1 - w0, with_dup});
     cut_window(p, m.scanned[0], w0, w1 - w0);
     if (!with_dup) p.dup_last_frame = 0;
     const int64_t rows_frames = (w1 - w0) + (with_dup ? 1 : 0);

@@ -28,6 +28,10 @@ struct ScannedStream {
 // scan == nullptr: full parse (is + si); otherwise is/si stay empty and *scan is filled instead
 int parse_stream(const uint8_t *file, size_t len, ParsedStream &out, ScannedStream *scan = nullptr);
 
+// scalefactors + Huffman of ONE frame of a scanned stream (side record + its main data in the blob): the host's answer for
+// a frame the device Huffman kernel flags; exact for gpu_ok streams (no frame inherits anything from another)
+int parse_scanned_frame(const mp3s_frame_side &fs, const uint8_t *blob, int16_t *is2304, mp3s_granule_si *si4);
+
 // samplerate / bitrate -> header indices and whole slots per frame; non-zero if unsupported
 int stream_params(int samplerate, int bitrate_kbps, int *sri, int *bri, int *whole_slots);
 

@@ -172,6 +172,109 @@ struct SideInfo {          // FrameSideInformation arrays (persist across frames
     int sf_l[2][2][22] = {}, sf_s[2][2][3][13] = {};
 };
 
+// Scalefactors + Huffman data of one frame (Frame.py:365-559).  `si` brings the frame's side info and keeps the
+// scalefactors, which persist from frame to frame in the reference (D10); is / gsi / table_select receive the frame's
+// 2304 samples, 4 side records and 12 table indices (is and gsi zeroed by the caller).
+int decode_main_data(const HostTables &HT, SideInfo &si, int nch, int sr_idx, const Bits &mb, int16_t *is, mp3s_granule_si *gsi,
+                     int32_t *table_select)
+{
+    long bit = 0;
+    for (int gr = 0; gr < 2; gr++)
+        for (int ch = 0; ch < nch; ch++) {
+            const long max_bit = bit + si.part2_3_length[gr][ch];
+            const int sl0 = HT.slen[si.scale_fac_compress[gr][ch]][0], sl1 = HT.slen[si.scale_fac_compress[gr][ch]][1];
+            if (si.block_type[gr][ch] == 2 && si.window_switching[gr][ch]) {
+                if (si.mixed[gr][ch] == 1) {
+                    for (int s = 0; s < 8; s++) { si.sf_l[gr][ch][s] = mb.get(bit, sl0); bit += sl0; }
+                    for (int s = 3; s < 6; s++)
+                        for (int w = 0; w < 3; w++) { si.sf_s[gr][ch][w][s] = mb.get(bit, sl0); bit += sl0; }
+                } else {
+                    for (int s = 0; s < 6; s++)
+                        for (int w = 0; w < 3; w++) { si.sf_s[gr][ch][w][s] = mb.get(bit, sl0); bit += sl0; }
+                }
+                for (int s = 6; s < 12; s++)
+                    for (int w = 0; w < 3; w++) { si.sf_s[gr][ch][w][s] = mb.get(bit, sl1); bit += sl1; }
+                for (int w = 0; w < 3; w++) si.sf_s[gr][ch][w][12] = 0;
+            } else {
+                if (gr == 0) {
+                    for (int s = 0; s < 11; s++) { si.sf_l[gr][ch][s] = mb.get(bit, sl0); bit += sl0; }
+                    for (int s = 11; s < 21; s++) { si.sf_l[gr][ch][s] = mb.get(bit, sl1); bit += sl1; }
+                } else {
+                    static const int SB[5] = {0, 6, 11, 16, 21};
+                    for (int i = 0; i < 4; i++) {
+                        const int sl = i < 2 ? sl0 : sl1;
+                        for (int s = SB[i]; s < SB[i + 1]; s++) {
+                            if (si.scfsi[ch][i]) si.sf_l[gr][ch][s] = si.sf_l[0][ch][s];
+                            else { si.sf_l[gr][ch][s] = mb.get(bit, sl); bit += sl; }
+                        }
+                    }
+                }
+                si.sf_l[gr][ch][21] = 0;
+            }
+            // ---- Huffman (Frame.py:443-559)
+            int16_t *smp = &is[(gr * 2 + ch) * 576];
+            int region0, region1;
+            if (si.window_switching[gr][ch] && si.block_type[gr][ch] == 2) { region0 = 36; region1 = 576; }
+            else {
+                const int i0 = si.region0[gr][ch] + 1, i1 = i0 + si.region1[gr][ch] + 1;
+                if (i0 > 22 || i1 > 22) return MP3S_E_MALFORMED;
+                region0 = HT.dev.sfb_long[sr_idx][i0]; region1 = HT.dev.sfb_long[sr_idx][i1];
+            }
+            int sample = 0;
+            const int bv2 = si.big_value[gr][ch] * 2;
+            while (sample < bv2) {
+                if (sample + 1 >= 576) return MP3S_E_MALFORMED;
+                const int tn = si.table_select[gr][ch][sample < region0 ? 0 : (sample < region1 ? 1 : 2)];
+                const HuffLut &L = g_lut[tn];
+                if (tn == 0 || L.max == 0) { sample += 2; continue; }   // tables 0, 4, 14: zeros, no bits (D2)
+                int v[2], len;
+                if (huff_decode(L, mb.get(bit, 32), v[0], v[1], len)) {
+                    bit += len;
+                    for (int i = 0; i < 2; i++) {
+                        int lin = 0;
+                        if (L.linbits && v[i] == L.max - 1) { lin = (int)mb.get(bit, L.linbits); bit += L.linbits; }
+                        int sign = 1;
+                        if (v[i] > 0) { sign = mb.get(bit, 1) ? -1 : 1; bit += 1; }
+                        smp[sample + i] = (int16_t)(sign * (v[i] + lin));
+                    }
+                }
+                sample += 2;
+            }
+            while (bit < max_bit && sample + 4 < 576) {   // D1
+                int val[4] = {0, 0, 0, 0};
+                if (si.count1table[gr][ch] == 1) {
+                    const uint32_t bs = mb.get(bit, 4); bit += 4;
+                    val[0] = (bs & 8) ? 0 : 1; val[1] = (bs & 4) ? 0 : 1; val[2] = (bs & 2) ? 0 : 1; val[3] = (bs & 1) ? 0 : 1;
+                } else {
+                    const uint16_t s = g_quad_fast[mb.get(bit, 6)];
+                    if (s) {
+                        bit += s >> 4;
+                        const int e = s & 15;
+                        val[0] = (e >> 3) & 1; val[1] = (e >> 2) & 1; val[2] = (e >> 1) & 1; val[3] = e & 1;
+                    }
+                }
+                for (int i = 0; i < 4; i++)
+                    if (val[i] > 0) { if (mb.get(bit, 1)) val[i] = -val[i]; bit += 1; }
+                for (int i = 0; i < 4; i++) smp[sample + i] = (int16_t)val[i];
+                sample += 4;
+            }
+            bit = max_bit;
+            // ---- side record for the kernels
+            mp3s_granule_si &g = gsi[gr * 2 + ch];
+            g.global_gain = (uint8_t)si.global_gain[gr][ch];
+            g.scalefac_scale = (uint8_t)si.scalefac_scale[gr][ch];
+            g.block_type = (uint8_t)si.block_type[gr][ch];
+            g.mixed_block_flag = (uint8_t)si.mixed[gr][ch];
+            g.preflag = (uint8_t)si.preflag[gr][ch];
+            for (int w = 0; w < 3; w++) g.sub_block_gain[w] = (uint8_t)si.sub_block_gain[gr][ch][w];
+            for (int s = 0; s < 22; s++) g.scale_fac_l[s] = (uint8_t)si.sf_l[gr][ch][s];
+            for (int w = 0; w < 3; w++)
+                for (int s = 0; s < 13; s++) g.scale_fac_s[w][s] = (uint8_t)si.sf_s[gr][ch][w][s];
+            for (int r = 0; r < 3; r++) table_select[(gr * 2 + ch) * 3 + r] = si.table_select[gr][ch][r];
+        }
+    return 0;
+}
+
 }  // namespace
 
 int parse_stream(const uint8_t *file, size_t flen_, ParsedStream &out, ScannedStream *scan)
@@ -367,100 +470,8 @@ int parse_stream(const uint8_t *file, size_t flen_, ParsedStream &out, ScannedSt
         out.si.resize((f + 1) * 4);
         out.table_select.resize((f + 1) * 12, 0);
         std::memset(&out.si[f * 4], 0, 4 * sizeof(mp3s_granule_si));
-        long bit = 0;
-        for (int gr = 0; gr < 2; gr++)
-            for (int ch = 0; ch < nch; ch++) {
-                const long max_bit = bit + si.part2_3_length[gr][ch];
-                const int sl0 = HT.slen[si.scale_fac_compress[gr][ch]][0], sl1 = HT.slen[si.scale_fac_compress[gr][ch]][1];
-                if (si.block_type[gr][ch] == 2 && si.window_switching[gr][ch]) {
-                    if (si.mixed[gr][ch] == 1) {
-                        for (int s = 0; s < 8; s++) { si.sf_l[gr][ch][s] = mb.get(bit, sl0); bit += sl0; }
-                        for (int s = 3; s < 6; s++)
-                            for (int w = 0; w < 3; w++) { si.sf_s[gr][ch][w][s] = mb.get(bit, sl0); bit += sl0; }
-                    } else {
-                        for (int s = 0; s < 6; s++)
-                            for (int w = 0; w < 3; w++) { si.sf_s[gr][ch][w][s] = mb.get(bit, sl0); bit += sl0; }
-                    }
-                    for (int s = 6; s < 12; s++)
-                        for (int w = 0; w < 3; w++) { si.sf_s[gr][ch][w][s] = mb.get(bit, sl1); bit += sl1; }
-                    for (int w = 0; w < 3; w++) si.sf_s[gr][ch][w][12] = 0;
-                } else {
-                    if (gr == 0) {
-                        for (int s = 0; s < 11; s++) { si.sf_l[gr][ch][s] = mb.get(bit, sl0); bit += sl0; }
-                        for (int s = 11; s < 21; s++) { si.sf_l[gr][ch][s] = mb.get(bit, sl1); bit += sl1; }
-                    } else {
-                        static const int SB[5] = {0, 6, 11, 16, 21};
-                        for (int i = 0; i < 4; i++) {
-                            const int sl = i < 2 ? sl0 : sl1;
-                            for (int s = SB[i]; s < SB[i + 1]; s++) {
-                                if (si.scfsi[ch][i]) si.sf_l[gr][ch][s] = si.sf_l[0][ch][s];
-                                else { si.sf_l[gr][ch][s] = mb.get(bit, sl); bit += sl; }
-                            }
-                        }
-                    }
-                    si.sf_l[gr][ch][21] = 0;
-                }
-                // ---- Huffman (Frame.py:443-559)
-                int16_t *smp = &out.is[(f * 4 + gr * 2 + ch) * 576];
-                int region0, region1;
-                if (si.window_switching[gr][ch] && si.block_type[gr][ch] == 2) { region0 = 36; region1 = 576; }
-                else {
-                    const int i0 = si.region0[gr][ch] + 1, i1 = i0 + si.region1[gr][ch] + 1;
-                    if (i0 > 22 || i1 > 22) return MP3S_E_MALFORMED;
-                    region0 = HT.dev.sfb_long[hd.sr_idx][i0]; region1 = HT.dev.sfb_long[hd.sr_idx][i1];
-                }
-                int sample = 0;
-                const int bv2 = si.big_value[gr][ch] * 2;
-                while (sample < bv2) {
-                    if (sample + 1 >= 576) return MP3S_E_MALFORMED;
-                    const int tn = si.table_select[gr][ch][sample < region0 ? 0 : (sample < region1 ? 1 : 2)];
-                    const HuffLut &L = g_lut[tn];
-                    if (tn == 0 || L.max == 0) { sample += 2; continue; }   // tables 0, 4, 14: zeros, no bits (D2)
-                    int v[2], len;
-                    if (huff_decode(L, mb.get(bit, 32), v[0], v[1], len)) {
-                        bit += len;
-                        for (int i = 0; i < 2; i++) {
-                            int lin = 0;
-                            if (L.linbits && v[i] == L.max - 1) { lin = (int)mb.get(bit, L.linbits); bit += L.linbits; }
-                            int sign = 1;
-                            if (v[i] > 0) { sign = mb.get(bit, 1) ? -1 : 1; bit += 1; }
-                            smp[sample + i] = (int16_t)(sign * (v[i] + lin));
-                        }
-                    }
-                    sample += 2;
-                }
-                while (bit < max_bit && sample + 4 < 576) {   // D1
-                    int val[4] = {0, 0, 0, 0};
-                    if (si.count1table[gr][ch] == 1) {
-                        const uint32_t bs = mb.get(bit, 4); bit += 4;
-                        val[0] = (bs & 8) ? 0 : 1; val[1] = (bs & 4) ? 0 : 1; val[2] = (bs & 2) ? 0 : 1; val[3] = (bs & 1) ? 0 : 1;
-                    } else {
-                        const uint16_t s = g_quad_fast[mb.get(bit, 6)];
-                        if (s) {
-                            bit += s >> 4;
-                            const int e = s & 15;
-                            val[0] = (e >> 3) & 1; val[1] = (e >> 2) & 1; val[2] = (e >> 1) & 1; val[3] = e & 1;
-                        }
-                    }
-                    for (int i = 0; i < 4; i++)
-                        if (val[i] > 0) { if (mb.get(bit, 1)) val[i] = -val[i]; bit += 1; }
-                    for (int i = 0; i < 4; i++) smp[sample + i] = (int16_t)val[i];
-                    sample += 4;
-                }
-                bit = max_bit;
-                // ---- side record for the kernels
-                mp3s_granule_si &g = out.si[f * 4 + gr * 2 + ch];
-                g.global_gain = (uint8_t)si.global_gain[gr][ch];
-                g.scalefac_scale = (uint8_t)si.scalefac_scale[gr][ch];
-                g.block_type = (uint8_t)si.block_type[gr][ch];
-                g.mixed_block_flag = (uint8_t)si.mixed[gr][ch];
-                g.preflag = (uint8_t)si.preflag[gr][ch];
-                for (int w = 0; w < 3; w++) g.sub_block_gain[w] = (uint8_t)si.sub_block_gain[gr][ch][w];
-                for (int s = 0; s < 22; s++) g.scale_fac_l[s] = (uint8_t)si.sf_l[gr][ch][s];
-                for (int w = 0; w < 3; w++)
-                    for (int s = 0; s < 13; s++) g.scale_fac_s[w][s] = (uint8_t)si.sf_s[gr][ch][w][s];
-                for (int r = 0; r < 3; r++) out.table_select[(f * 4 + gr * 2 + ch) * 3 + r] = si.table_select[gr][ch][r];
-            }
+        const int rc2 = decode_main_data(HT, si, nch, hd.sr_idx, mb, &out.is[f * 2304], &out.si[f * 4], &out.table_select[f * 12]);
+        if (rc2) return rc2;
         }
         mp3s_frame_hdr fh;
         fh.sr_idx = (uint8_t)hd.sr_idx; fh.nch = (uint8_t)nch;
@@ -475,6 +486,36 @@ int parse_stream(const uint8_t *file, size_t flen_, ParsedStream &out, ScannedSt
     out.sampling_rate = hd.sampling_rate;
     out.bit_rate = hd.bit_rate;
     return 0;
+}
+
+// One frame of a scanned stream on the host: what decode_group does with the frames the device Huffman kernel flags.
+// Valid for streams the scan marked gpu_ok -- nothing in such a frame is inherited from another one.
+int parse_scanned_frame(const mp3s_frame_side &fs, const uint8_t *blob, int16_t *is2304, mp3s_granule_si *si4)
+{
+    std::call_once(g_lut_once, build_luts);
+    const HostTables &HT = host_tables();
+    if (fs.nch < 1 || fs.nch > 2 || fs.sr_idx > 2) return MP3S_E_MALFORMED;
+    SideInfo si;
+    for (int ch = 0; ch < fs.nch; ch++)
+        for (int b = 0; b < 4; b++) si.scfsi[ch][b] = fs.scfsi[ch][b];
+    for (int gr = 0; gr < 2; gr++)
+        for (int ch = 0; ch < fs.nch; ch++) {
+            const mp3s_unit_side &u = fs.unit[gr][ch];
+            si.part2_3_length[gr][ch] = u.part2_3_length; si.big_value[gr][ch] = u.big_values;
+            si.global_gain[gr][ch] = u.global_gain; si.scale_fac_compress[gr][ch] = u.scalefac_compress;
+            si.window_switching[gr][ch] = u.window_switching; si.block_type[gr][ch] = u.block_type;
+            si.mixed[gr][ch] = u.mixed_block_flag;
+            for (int r = 0; r < 3; r++) si.table_select[gr][ch][r] = u.table_select[r];
+            si.region0[gr][ch] = u.region0_count; si.region1[gr][ch] = u.region1_count;
+            si.preflag[gr][ch] = u.preflag; si.scalefac_scale[gr][ch] = u.scalefac_scale;
+            si.count1table[gr][ch] = u.count1table_select;
+            for (int w = 0; w < 3; w++) si.sub_block_gain[gr][ch][w] = u.sub_block_gain[w];
+        }
+    std::memset(is2304, 0, 2304 * sizeof(int16_t));
+    std::memset(si4, 0, 4 * sizeof(mp3s_granule_si));
+    int32_t table_select[12];
+    const Bits mb{blob + fs.md_off, (long)fs.md_len};
+    return decode_main_data(HT, si, fs.nch, fs.sr_idx, mb, is2304, si4, table_select);
 }
 
 }  // namespace mp3s

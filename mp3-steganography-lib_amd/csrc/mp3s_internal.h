@@ -188,8 +188,8 @@ inline size_t pcm_elem(int fmt) { return fmt == MP3S_PCM_I16 ? 2 : (fmt == MP3S_
 int max_part2_3(const mp3s_frame_side *side, long n);
 // keep frames [first, first + count) of a parsed stream (its main data, side records, samples)
 void cut_window(ParsedStream &p, ScannedStream &sc, long first, long count);
-// host front end of stream i of m (scan; full host parse where the device cannot decode, or when `full`)
-int front_end(mp3s_multi &m, int i, bool full = false);
+// host front end of stream i of m (scan; full host parse where the device cannot decode), cut to the stream's window
+int front_end(mp3s_multi &m, int i);
 // decode the streams `idx` of m (one channel count) as one batch; d_keep: int16 PCM stays on the device there
 int decode_group(mp3s_ctx *c, mp3s_multi &m, const std::vector<int> &idx, int nch, int out_format, void *d_keep = nullptr);
 
