@@ -105,7 +105,7 @@ def decode_sharded(ctx, mp3: bytes, comm=None, out_format=_lib.MP3S_PCM_I16):
         return None
     parts = [p for p in parts if p is not None]
     dt = {_lib.MP3S_PCM_I16: np.int16, _lib.MP3S_PCM_F32: np.float32, _lib.MP3S_PCM_F64: np.float64}[out_format]
-    pcm = np.concatenate(parts) if parts else np.zeros((0, max(info["channels"], 1)), dtype=dt)
+    pcm = np.concatenate(parts) if parts else np.zeros((0, info["channels"]), dtype=dt)   # (a stream without a frame)
     return {"n_frames": info["n_frames"], "channels": info["channels"], "sampling_rate": info["sampling_rate"],
             "bit_rate": info["bit_rate"], "pcm": pcm, "bits": np.array(info["bits"])}
 
