@@ -1,0 +1,31 @@
+"""The bench line's contract, checked on the latest line committed under profiles/ (bench.py itself needs the GPU):
+metric and unit are BASELINE.json's, every field the driver reads is there, roofline and cpu_baseline are complete and
+consistent with each other."""
+import glob
+import json
+import os
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_latest_bench_line_has_the_contract_fields():
+    base = json.load(open(os.path.join(ROOT, "BASELINE.json")))
+    latest = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_bench.json")))[-1]
+    line = json.loads(open(latest).read().strip().splitlines()[-1])
+    assert line["metric"] == base["metric"]
+    if base.get("unit"):
+        assert line["unit"] in base["unit"] or base["unit"] in line["unit"]
+    for key, typ in (("value", (int, float)), ("n_gpus", int), ("steps", int), ("warmup", int), ("ms_per_step", (int, float)),
+                     ("higher_is_better", bool), ("scaling", str), ("dtype", str), ("data", str), ("config", dict)):
+        assert isinstance(line[key], typ), key
+    assert "vs_baseline" in line and line["scaling"] == "weak" and "workload" in line["config"] and "model" not in line["config"]
+    r = line["roofline"]
+    assert r["bound"] in ("hbm", "mfma") and r["unit"] in ("GB/s", "TFLOP/s")
+    assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3 and (r["traffic"] is None or r["traffic"] > 0)
+    # achieved = algorithmic bytes per launch / the dominant kernel's duration
+    assert abs(r["achieved"] - r["algorithmic_bytes_per_launch"] / (r["kernel_ms_per_launch"] * 1e-3) / 1e9) / r["achieved"] < 0.01
+    c = line["cpu_baseline"]
+    assert c["kind"] in ("reference", "port") and c["cores"] >= 1 and c["value"] > 0 and c["sample"]
+    # whole-job value = frames of all ranks / step time
+    assert abs(line["value"] - line["config"]["frames_per_gpu"] * line["n_gpus"] / (line["ms_per_step"] * 1e-3)) / line["value"] < 0.01
+    assert line["parity_checked"] is True
