@@ -53,12 +53,16 @@ int decode_group(mp3s_ctx *c, mp3s_multi &m, const std::vector<int> &idx, int nc
     for (int i : idx) n += m.parsed[i].n_frames;
     if (n <= 0) return MP3S_OK;
     if (n > 0x7fffffff / 8) return fail(MP3S_E_ARG, "batch of %ld frames is too large", n);
-    // ---- concatenate: frame headers (stream_first = first frame of the file), side records, main-data blobs
-    std::vector<mp3s_frame_hdr> hdr((size_t)n);
-    std::vector<mp3s_frame_side> side((size_t)n);
-    std::vector<uint8_t> blob;
+    const double t_cat0 = trace_on() ? now_ms() : 0;
+    // ---- one batch: frame headers (stream_first = first frame of the file), side records, main-data blobs.  A single
+    //      device-decoded stream is used where it lies; several are laid end to end in work arrays the context keeps
+    //      (tens of MB of fresh vectors per call cost more in page faults than the copy itself).
+    std::vector<mp3s_frame_hdr> &hdr = c->h_hdr;
+    hdr.resize((size_t)n);
     std::vector<long> first_of(idx.size());
     bool any_dev = false, any_host = false;
+    const bool in_place = idx.size() == 1 && m.scanned[idx[0]].gpu_ok;
+    if (!in_place) { c->h_side.resize((size_t)n); c->h_blob.clear(); }
     long f0 = 0;
     for (size_t k = 0; k < idx.size(); k++) {
         const ParsedStream &p = m.parsed[idx[k]];
@@ -66,37 +70,44 @@ int decode_group(mp3s_ctx *c, mp3s_multi &m, const std::vector<int> &idx, int nc
         first_of[k] = f0;
         const bool dev = sc.gpu_ok;
         (dev ? any_dev : any_host) = true;
-        const uint32_t base = (uint32_t)blob.size();
-        if (dev) blob.insert(blob.end(), sc.blob.begin(), sc.blob.end());
+        const uint32_t base = (uint32_t)c->h_blob.size();
+        if (dev && !in_place) c->h_blob.insert(c->h_blob.end(), sc.blob.begin(), sc.blob.end());
         for (int f = 0; f < p.n_frames; f++) {
             hdr[(size_t)f0 + f] = p.hdr[f];
             hdr[(size_t)f0 + f].stream_first = (uint32_t)f0;
-            if (dev) { side[(size_t)f0 + f] = sc.side[f]; side[(size_t)f0 + f].md_off += base; }
-            else std::memset(&side[(size_t)f0 + f], 0, sizeof(mp3s_frame_side));   // filled from the host parse below
+            if (in_place) continue;
+            if (dev) { c->h_side[(size_t)f0 + f] = sc.side[f]; c->h_side[(size_t)f0 + f].md_off += base; }
+            else std::memset(&c->h_side[(size_t)f0 + f], 0, sizeof(mp3s_frame_side));   // filled from the host parse below
         }
         f0 += p.n_frames;
     }
-    if (blob.empty()) blob.resize(16, 0);
+    if (!in_place && c->h_blob.empty()) c->h_blob.resize(16, 0);
+    const mp3s_frame_side *side = in_place ? m.scanned[idx[0]].side.data() : c->h_side.data();
+    const uint8_t *blob = in_place ? m.scanned[idx[0]].blob.data() : c->h_blob.data();
+    const size_t blob_bytes = in_place ? m.scanned[idx[0]].blob.size() : c->h_blob.size();
     if (hipSetDevice(c->device) != hipSuccess) return fail(MP3S_E_HIP, "hipSetDevice failed");
     const int chunk = (int)std::min<long>(n, kDecodeChunk) + 1;
     int slot = 0;
     auto grab = [&](size_t bytes) { return c->grab(slot++, bytes); };
     void *d_is = grab((size_t)n * 2304 * 2), *d_si = grab((size_t)n * 4 * sizeof(mp3s_granule_si)),
          *d_hdr = grab((size_t)chunk * sizeof(mp3s_frame_hdr)), *d_pcm = grab((size_t)chunk * frame_bytes), *d_st = grab(((size_t)n + 1) * 4),
-         *d_blob = grab(blob.size()), *d_side = grab((size_t)n * sizeof(mp3s_frame_side));
+         *d_blob = grab(blob_bytes), *d_side = grab((size_t)n * sizeof(mp3s_frame_side));
     if (!d_is || !d_si || !d_hdr || !d_pcm || !d_st || !d_blob || !d_side)
         return fail(MP3S_E_NOMEM, "hipMalloc failed for a %ld-frame decode", n);
     int rc = MP3S_OK;
+    const double t_up0 = trace_on() ? now_ms() : 0;
     if (any_dev) {
-        rc = mp3s_dev_upload(c, d_blob, blob.data(), blob.size());
-        if (!rc) rc = mp3s_dev_upload(c, d_side, side.data(), (size_t)n * sizeof(mp3s_frame_side));
+        rc = mp3s_dev_upload(c, d_blob, blob, blob_bytes);
+        if (!rc) rc = mp3s_dev_upload(c, d_side, side, (size_t)n * sizeof(mp3s_frame_side));
         if (!rc) {
             const int e = launch_huffman(c->stream, (const uint8_t *)d_blob, (const mp3s_frame_side *)d_side, (int)n, nch,
-                                         max_part2_3(side.data(), n), (int16_t *)d_is, (mp3s_granule_si *)d_si, (int32_t *)d_st, &c->prof, true);
+                                         max_part2_3(side, n), (int16_t *)d_is, (mp3s_granule_si *)d_si, (int32_t *)d_st, &c->prof, true);
             if (e) rc = fail(MP3S_E_HIP, "huffman launch: %s", hipGetErrorString((hipError_t)e));
         }
+        const double t_up1 = trace_on() ? now_ms() : 0;
         int32_t st = 0;
         if (!rc) rc = mp3s_dev_download(c, &st, d_st, sizeof st);
+        if (trace_on()) fprintf(stderr, "mp3s:   decode batch of %ld frames: concatenate %.3f ms, upload %.3f ms, Huffman %.3f ms\n", n, t_up0 - t_cat0, t_up1 - t_up0, now_ms() - t_up1);
         if (!rc && st) {
             // Something in the Huffman data of some frames is off (region counts, big_values past 576 lines, big values
             // running past part2_3_length -- which is what the cut tail of this library's own output looks like in one file

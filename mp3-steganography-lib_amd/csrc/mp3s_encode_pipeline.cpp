@@ -474,6 +474,7 @@ int mp3s_hide_messages(mp3s_ctx *c, const uint8_t *const *mp3s, const size_t *le
         m.files[i] = {mp3s[i], lens[i]};
         total += lens[i];
     }
+    if (n_files == 1) m.scanned[0] = std::move(c->spare_scan);   // its capacity: no fresh pages for the blob of a long file
     parallel_files(n_files, total, [&](int i) { if (!st[i]) st[i] = front_end(m, i); });
     const double t1 = trace_on() ? now_ms() : 0;
     for (int i = 0; i < n_files; i++) {
@@ -499,6 +500,7 @@ int mp3s_hide_messages(mp3s_ctx *c, const uint8_t *const *mp3s, const size_t *le
         fprintf(stderr, "mp3s: hide_messages, %d file(s): scan %.3f ms, messages + grouping %.3f ms, device batches %.3f ms\n", n_files,
                 t1 - t0, t2 - t1, now_ms() - t2);
     m.files.clear();   // borrowed pointers
+    if (n_files == 1) c->spare_scan = std::move(m.scanned[0]);
     int first_bad = MP3S_OK;
     for (int i = 0; i < n_files; i++) {
         if (status) status[i] = st[i];

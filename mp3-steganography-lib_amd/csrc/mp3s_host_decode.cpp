@@ -284,7 +284,7 @@ int parse_stream(const uint8_t *file, size_t flen_, ParsedStream &out, ScannedSt
     const long flen = (long)flen_;
     out = ParsedStream();
     if (scan) {
-        *scan = ScannedStream();
+        scan->side.clear(); scan->blob.clear(); scan->gpu_ok = true;   // (capacity a caller lends is kept)
         // main data is the file minus headers and side info, plus padding: one allocation instead of doubling through 40 MB
         scan->blob.reserve(flen_ + flen_ / 32 + 64);
         scan->side.reserve(flen_ / 96 + 1);

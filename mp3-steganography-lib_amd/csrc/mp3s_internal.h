@@ -59,6 +59,12 @@ struct mp3s_ctx {
     // the kernel on every call (page faults cost more than the work done in them)
     std::vector<int32_t> h_cursor, h_state, h_want, h_state_want;
     std::vector<uint8_t> h_in;
+    // ... and of the decoder: the concatenated batch
+    std::vector<mp3s_frame_hdr> h_hdr;
+    std::vector<mp3s_frame_side> h_side;
+    std::vector<uint8_t> h_blob;
+    // ... and the scan result of the last single-file call, lent to the next one for its capacity
+    ScannedStream spare_scan;
     int ensure_scratch(size_t bytes)
     {
         if (bytes <= scratch_bytes) return 0;

@@ -418,13 +418,21 @@ class Context:
 
     # ---- whole files as byte strings (include/mp3s.h section vi)
     @staticmethod
+    def _owned_bytes(ptr, n, own):
+        """read-only bytes-like view (compare, hash, write, len, slice) of n bytes of a library buffer that `own` keeps
+        alive: a 40 MB file is handed over, not copied"""
+        if not n:
+            return b""
+        raw = (C.c_char * n).from_address(ptr)
+        raw._mp3s_owner = own
+        return memoryview(raw).cast("B").toreadonly()
+
+    @staticmethod
     def _file(f, owner):
-        try:
-            return {"data": C.string_at(f.data, f.len) if f.len else b"", "kbps": f.kbps, "sampling_rate": f.sampling_rate,
-                    "channels": f.channels, "n_frames": f.n_frames, "too_long": bool(f.too_long),
-                    "hide_offset": f.hide_offset, "bits": _view(f.bits, np.uint8, (f.n_bits,))}
-        finally:
-            lib().mp3s_buf_free(owner)
+        own = _Owner(owner)
+        return {"data": Context._owned_bytes(f.data, f.len, own), "kbps": f.kbps, "sampling_rate": f.sampling_rate,
+                "channels": f.channels, "n_frames": f.n_frames, "too_long": bool(f.too_long),
+                "hide_offset": f.hide_offset, "bits": _view_owned(f.bits, np.uint8, (f.n_bits,), own)}
 
     def decode_file(self, mp3: bytes):
         """MP3 bytes -> WAV bytes (+ kbps of the last header and the stego bits).  "data" is a read-only view of the
@@ -433,9 +441,7 @@ class Context:
         owner, f = C.c_void_p(), File()
         check(lib().mp3s_decode_file(self.handle, buf.ctypes.data, len(mp3), C.byref(owner), C.byref(f)))
         own = _Owner(owner)
-        raw = (C.c_char * f.len).from_address(f.data)
-        raw._mp3s_owner = own
-        return {"data": memoryview(raw).cast("B").toreadonly(), "kbps": f.kbps, "sampling_rate": f.sampling_rate,
+        return {"data": self._owned_bytes(f.data, f.len, own), "kbps": f.kbps, "sampling_rate": f.sampling_rate,
                 "channels": f.channels, "n_frames": f.n_frames, "too_long": False, "hide_offset": 0,
                 "bits": _view(f.bits, np.uint8, (f.n_bits,))}
 
@@ -523,7 +529,9 @@ def reveal_message(mp3: bytes):
     buf = np.frombuffer(mp3, dtype=np.uint8)
     owner, f = C.c_void_p(), File()
     check(lib().mp3s_reveal_message(buf.ctypes.data, len(mp3), C.byref(owner), C.byref(f)))
-    return Context._file(f, owner)
+    r = Context._file(f, owner)
+    r["data"] = bytes(r["data"])               # a message, not a file: plain bytes
+    return r
 
 
 def wav_parse(data: bytes, bitrate=320):
