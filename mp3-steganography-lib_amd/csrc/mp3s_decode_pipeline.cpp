@@ -224,6 +224,7 @@ static int decode_streams_impl(mp3s_ctx *c, const uint8_t *const *files, const s
         total += lens[i];
     }
     std::vector<int> frc(n_files, MP3S_OK);
+    if (n_files == 1) m.scanned[0] = std::move(c->spare_scan);   // its capacity: no fresh pages for the blob of a long file
     parallel_files(n_files, total, [&](int i) { frc[i] = front_end(m, i); });
     for (int i = 0; i < n_files; i++) {
         if (frc[i]) { delete b; return fail(frc[i], "file %d: malformed or unsupported MP3 stream", i); }
@@ -240,6 +241,7 @@ static int decode_streams_impl(mp3s_ctx *c, const uint8_t *const *files, const s
         out[i].n_bits = (int32_t)p.bits.size(); out[i].n_rows = (int64_t)1152 * (p.n_frames + p.dup_last_frame);
         out[i].pcm = m.pcm[i]; out[i].bits = p.bits.data();
     }
+    if (n_files == 1) c->spare_scan = std::move(m.scanned[0]);   // (the result refers to the parse and the PCM only)
     *owner = b;
     return MP3S_OK;
 }
