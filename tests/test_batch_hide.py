@@ -111,3 +111,45 @@ def test_many_short_files_one_batch(ctx, mlib, orc):
             assert bytes(mlib.reveal_message(r["data"])["data"])[:k] == m.encode()[:k], i
             fitted += not r["too_long"]
     assert crc_batch == crc_single and fitted > 60
+
+
+def test_two_threads_two_contexts(mlib, orc):
+    """calls on one context are serialised by the caller, different contexts run concurrently (ctypes
+    releases the GIL): two threads, each with its own context on the same device, must not disturb each other (shared
+    state = the page-locked block cache, the constant tables, the per-thread error text)"""
+    import threading
+    from synth_pcm import synth_pcm
+    streams = []
+    boot = mlib.Context(0)
+    for i in range(6):
+        streams.append(boot.encode_pcm(synth_pcm(20 + 7 * i, seed=600 + i), 44100, 128, None)["mp3"])
+    want = [bytes(boot.hide_message(s, "thread %d" % i)["data"]) for i, s in enumerate(streams)]
+    boot.close()
+    errors = []
+
+    def work(tid):
+        try:
+            ctx = mlib.Context(0)
+            for rnd in range(15):
+                for i, s in enumerate(streams):
+                    if (i + tid) % 2:
+                        continue
+                    if bytes(ctx.hide_message(s, "thread %d" % i)["data"]) != want[i]:
+                        errors.append((tid, rnd, i))
+                    try:
+                        ctx.hide_message(b"\x00" * 64, "x")          # an error text per thread
+                    except mlib.Mp3sError:
+                        pass
+                d = ctx.decode_stream(streams[tid], mlib.MP3S_PCM_I16)
+                if d["n_frames"] != 20 + 7 * tid:
+                    errors.append((tid, rnd, "decode"))
+            ctx.close()
+        except Exception as e:                                       # noqa: BLE001
+            errors.append((tid, repr(e)))
+
+    threads = [threading.Thread(target=work, args=(t,)) for t in range(2)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errors, errors[:5]
