@@ -114,6 +114,11 @@ const void *mp3s_debug_tables(size_t *bytes);
  * The kernel's tabulated energies are cross-checked against this in the tests. */
 int mp3s_debug_scfsi_energies(const int32_t *xr576, int sr_idx, int32_t *en22);
 
+/* host decode (scalefactors + Huffman) of ONE frame of a scanned stream: what the stream pipelines do with the frames the
+ * device Huffman kernel flags (exact for streams the scan marks gpu_ok); exposed for the tests.  side = that frame's
+ * record, blob = the stream's blob; is2304 = int16 [2][2][576], si4 = mp3s_granule_si [2][2] */
+int mp3s_debug_parse_scanned_frame(const void *frame_side, const uint8_t *blob, int16_t *is2304, mp3s_granule_si *si4);
+
 /* device memory owned by the caller through the context (for resident pipelines / benchmarks) */
 int mp3s_dev_alloc(mp3s_ctx *ctx, size_t bytes, void **dptr);
 int mp3s_dev_free(mp3s_ctx *ctx, void *dptr);

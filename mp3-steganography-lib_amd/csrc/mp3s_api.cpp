@@ -44,6 +44,13 @@ int mp3s_debug_scfsi_energies(const int32_t *xr576, int sr_idx, int32_t *en22)
     return MP3S_OK;
 }
 
+int mp3s_debug_parse_scanned_frame(const void *frame_side, const uint8_t *blob, int16_t *is2304, mp3s_granule_si *si4)
+{
+    if (!frame_side || !blob || !is2304 || !si4) return fail(MP3S_E_ARG, "null pointer");
+    const int rc = parse_scanned_frame(*static_cast<const mp3s_frame_side *>(frame_side), blob, is2304, si4);
+    return rc ? fail(rc, "malformed main data") : MP3S_OK;
+}
+
 int mp3s_ctx_create(int device, mp3s_ctx **out)
 {
     if (!out) return fail(MP3S_E_ARG, "out is null");

@@ -111,7 +111,7 @@ class Block(C.Structure):
 
 
 # every symbol include/mp3s.h declares (tests/test_abi.py checks the library exports all of them)
-SYMBOLS = ["mp3s_ctx_create", "mp3s_ctx_destroy", "mp3s_ctx_wait", "mp3s_last_error", "mp3s_version", "mp3s_device_name", "mp3s_sync", "mp3s_debug_tables", "mp3s_debug_scfsi_energies",
+SYMBOLS = ["mp3s_ctx_create", "mp3s_ctx_destroy", "mp3s_ctx_wait", "mp3s_last_error", "mp3s_version", "mp3s_device_name", "mp3s_sync", "mp3s_debug_tables", "mp3s_debug_scfsi_energies", "mp3s_debug_parse_scanned_frame",
            "mp3s_dev_alloc", "mp3s_dev_free", "mp3s_dev_upload", "mp3s_dev_download", "mp3s_dev_memset",
            "mp3s_timer_start", "mp3s_timer_stop", "mp3s_profile_enable", "mp3s_profile_select", "mp3s_profile_collect", "mp3s_decode_transform_dev", "mp3s_decode_transform",
            "mp3s_encode_transform_dev", "mp3s_encode_transform", "mp3s_rate_loop_dev", "mp3s_huffman_decode_dev", "mp3s_pack_frames_dev", "mp3s_scan_stream", "mp3s_buf_free",
@@ -170,6 +170,7 @@ def lib():
         L.mp3s_buf_free.restype = None
         L.mp3s_parse_stream.argtypes = [vp, sz, pvp, C.POINTER(Parsed)]
         L.mp3s_format_stream.argtypes = [i32, i32, i32, vp, vp, vp, pvp, pvp, C.POINTER(sz)]
+        L.mp3s_debug_parse_scanned_frame.argtypes = [vp, vp, vp, vp]
         L.mp3s_rate_frames.argtypes = [i32, i32, i32, i32, vp, vp]
         L.mp3s_decode_stream.argtypes = [vp, vp, sz, i32, pvp, C.POINTER(Decoded)]
         L.mp3s_decode_streams.argtypes = [vp, pvp, C.POINTER(sz), i32, i32, pvp, C.POINTER(Decoded)]

@@ -85,3 +85,38 @@ def test_rate_frames_and_format_stream(mlib, orc, golden_dir):
         assert tot == 2 * mean_bits            # every frame is filled completely (E6)
     mp3 = mlib.format_stream(44100, 128, o["ix"].astype(np.int16), gr, o["frames"]["scfsi"])
     assert mp3 == o["mp3"] == g["mp3"].tobytes()
+
+
+def test_one_frame_host_decode_equals_the_stream_parser(mlib, golden_dir):
+    """parse_scanned_frame (the host's answer for frames the device Huffman kernel flags) against the full stream parser,
+    frame by frame, on every stream of the corpus the device would decode itself: same samples, same scalefactors the
+    transforms read"""
+    L = mlib.lib()
+    g = np.load(os.path.join(golden_dir, "g7_decode_corpus.npz"))
+    names = sorted({k.split("__")[0] for k in g.files})
+    streams = [open(os.path.join(golden_dir, "test.mp3"), "rb").read(), np.load(os.path.join(golden_dir, "g6_synth128.npz"))["mp3"].tobytes()]
+    streams += [g[n + "__mp3"].tobytes() for n in names]
+    checked = 0
+    for data in streams:
+        s = mlib.scan_stream(data)
+        if not s["gpu_ok"]:
+            continue
+        p = mlib.parse_stream(data)
+        side, blob = np.ascontiguousarray(s["side"]), np.ascontiguousarray(s["blob"])
+        nch = s["channels"]
+        for f in range(s["n_frames"]):
+            isv = np.zeros((2, 2, 576), dtype=np.int16)
+            si = np.zeros((2, 2), dtype=mlib.GRANULE_SI_DTYPE)
+            mlib.check(L.mp3s_debug_parse_scanned_frame(side[f:f + 1].ctypes.data, blob.ctypes.data, isv.ctypes.data, si.ctypes.data))
+            assert np.array_equal(isv[:, :nch], p["is"][f][:, :nch]), f
+            for gr in range(2):
+                for ch in range(nch):
+                    a, b = si[gr, ch], p["si"][f, gr, ch]
+                    for k in ("global_gain", "scalefac_scale", "block_type", "mixed_block_flag", "preflag", "sub_block_gain"):
+                        assert np.array_equal(a[k], b[k]), (f, gr, ch, k)
+                    if b["block_type"] == 2:
+                        assert np.array_equal(a["scale_fac_s"], b["scale_fac_s"]), (f, gr, ch)
+                    else:
+                        assert np.array_equal(a["scale_fac_l"], b["scale_fac_l"]), (f, gr, ch)
+            checked += 1
+    assert checked > 100
