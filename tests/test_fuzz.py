@@ -49,6 +49,22 @@ def check_host(mlib, orc, m):
     return o
 
 
+def check_frame_by_frame(mlib, m, o):
+    """the one-frame host decode (what the device pipeline falls back to for frames its Huffman kernel flags) on every
+    frame of a stream the device would decode itself: the oracle's samples"""
+    s = mlib.scan_stream(m)
+    if not s["gpu_ok"] or s["n_frames"] == 0:
+        return 0
+    side, blob, L = np.ascontiguousarray(s["side"]), np.ascontiguousarray(s["blob"]), mlib.lib()
+    isv = np.zeros((2, 2, 576), dtype=np.int16)
+    si = np.zeros((2, 2), dtype=mlib.GRANULE_SI_DTYPE)
+    nch = s["channels"]
+    for f in range(s["n_frames"]):
+        mlib.check(L.mp3s_debug_parse_scanned_frame(side[f:f + 1].ctypes.data, blob.ctypes.data, isv.ctypes.data, si.ctypes.data))
+        assert np.array_equal(isv[:, :nch], o["is"][f][:, :nch]), f
+    return s["n_frames"]
+
+
 def test_host_parser_reaches_the_oracles_verdict(mlib, orc, golden_dir):
     with open(os.path.join(golden_dir, "test.mp3"), "rb") as f:
         data = f.read()
@@ -58,11 +74,15 @@ def test_host_parser_reaches_the_oracles_verdict(mlib, orc, golden_dir):
     cases = list(header_mutants(mlib, data, 250, 1)) + list(mutants(data, 100, 2))
     for n in names[:3]:
         cases += list(header_mutants(mlib, g[n + "__mp3"].tobytes(), 40, 3)) + list(mutants(g[n + "__mp3"].tobytes(), 20, 4))
+    frames = 0
     for m in cases:
         o = check_host(mlib, orc, m)
         ok += o is not None
         bad += o is None
+        if o is not None:
+            frames += check_frame_by_frame(mlib, m, o)
     assert ok > 300 and bad > 5                   # both outcomes are exercised
+    assert frames > 5000                          # ... and the one-frame host decode on most frames of the accepted ones
 
 
 @pytest.mark.gpu
