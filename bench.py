@@ -344,16 +344,20 @@ def main():
         if args.cpu_seconds_all > 0 and n > 400:
             import subprocess
             import tempfile
-            with tempfile.TemporaryDirectory() as td:
-                open(os.path.join(td, "s.mp3"), "wb").write(enc0["mp3"])
-                np.save(os.path.join(td, "h.npy"), np.asarray(hide, dtype=np.uint8))
-                r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "cpu_all_cores.py"), os.path.join(td, "s.mp3"),
-                                    os.path.join(td, "h.npy"), str(args.cpu_seconds_all)], capture_output=True, text=True, timeout=300)
+            # optional extra: whatever goes wrong in the child (timeout, a box that cannot fork that many workers) must
+            # not cost the bench line, whose timed region is already over
+            r = None
             try:
+                with tempfile.TemporaryDirectory() as td:
+                    open(os.path.join(td, "s.mp3"), "wb").write(enc0["mp3"])
+                    np.save(os.path.join(td, "h.npy"), np.asarray(hide, dtype=np.uint8))
+                    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "cpu_all_cores.py"), os.path.join(td, "s.mp3"),
+                                        os.path.join(td, "h.npy"), str(args.cpu_seconds_all)], capture_output=True, text=True, timeout=300)
                 cpu["all_cores"] = json.loads(r.stdout.strip().splitlines()[-1])
                 cpu["all_cores"]["x_one_thread"] = round(cpu["all_cores"]["value"] / cpu["value"], 1)
-            except Exception:
-                cpu["all_cores"] = {"error": (r.stderr or r.stdout)[-300:]}
+            except Exception as e:                                   # noqa: BLE001
+                tail = ((r.stderr or r.stdout) if r is not None else "")[-300:]
+                cpu["all_cores"] = {"error": f"{type(e).__name__}: {e}"[:200], "child_output": tail}
 
     if rank == 0:
         out = {
