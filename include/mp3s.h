@@ -39,6 +39,7 @@ extern "C" {
 #define MP3S_E_STEP_RANGE (-6)  /* quantizer step left the table (reference: IndexError) */
 #define MP3S_E_NOMEM (-7)
 #define MP3S_E_EXIT (-8)        /* the reference calls sys.exit(text) here; the text is in mp3s_last_error() */
+#define MP3S_E_BUSY (-9)        /* mp3s_pipe_submit: every slot is taken, collect a result first; mp3s_pipe_collect: nothing pending */
 
 #define MP3S_PCM_I16 0 /* (pcm*32767) truncated toward zero, low 16 bits: reference decoder/MP3_Parser.py:91 */
 #define MP3S_PCM_F32 1
@@ -76,7 +77,7 @@ typedef struct {
     int32_t sr_idx;
     int32_t hide_end;     /* the message of this frame's stream ends at hide[hide_end]: a batch of streams keeps their
                            * messages back to back in one array (mp3s_rate_frames sets INT32_MAX = the array's end) */
-    int32_t reserved;
+    int32_t stream;       /* index of the frame's stream in the batch (into mp3s_chain_seg[]); mp3s_rate_frames sets 0 */
 } mp3s_rate_frame; /* 16 bytes */
 
 /* per granule*channel result of the rate loop
@@ -128,10 +129,13 @@ int mp3s_dev_memset(mp3s_ctx *ctx, void *dptr, int value, size_t bytes);
 /* HIP-event timer on the context's stream (the stream every kernel below is launched on) */
 int mp3s_timer_start(mp3s_ctx *ctx);
 int mp3s_timer_stop(mp3s_ctx *ctx, float *ms);
+/* a plain device-to-device copy kernel over `bytes` (read + write counted), `iters` launches timed with HIP events on the
+ * context's stream: the HBM bandwidth a streaming kernel achieves on this device, to set beside the data-sheet peak */
+int mp3s_bench_copy(mp3s_ctx *ctx, size_t bytes, int iters, double *gb_per_s);
 /* per-kernel HIP-event timing on the same stream: enable, run, then collect the summed milliseconds and launch
  * counts of the kernels in this order: dec_imdct, dec_synth, enc_analysis, enc_mdct, rate_loop, dec_huffman,
- * enc_pack (n >= MP3S_N_KERNELS) */
-#define MP3S_N_KERNELS 7
+ * enc_pack, chain (the pair of mp3s_chain_resolve_dev counts as one) (n >= MP3S_N_KERNELS) */
+#define MP3S_N_KERNELS 8
 int mp3s_profile_enable(mp3s_ctx *ctx, int on);
 /* An event pair costs a few microseconds of stream time per launch: restrict the timing to the kernels in `mask` (bit k =
  * kernel k in the order above; all by default).  Takes effect with the next mp3s_profile_enable(ctx, 1). */
@@ -188,6 +192,34 @@ int mp3s_encode_transform(mp3s_ctx *ctx, const int16_t *pcm, const mp3s_frame_hd
 int mp3s_rate_loop_dev(mp3s_ctx *ctx, const int32_t *d_mdct, const mp3s_rate_frame *d_frames, int n_frames,
                        const uint8_t *d_hide_bits, int n_hide, const int32_t *d_cursor_in, const int32_t *d_state_in,
                        const int32_t *d_unit_list, int n_list, int16_t *d_ix, mp3s_gr_out *d_out, int32_t *d_en);
+
+/* ---------------------------------------------------------------- (iv-b) the serial chains of the rate loop, on the device
+ * replaces: the two values the reference carries from unit to unit -- __hide_str_offset (reference
+ *           encoder/MP3_Encoder.py:808-809, read at :1154-1168) and the address1/2/3 + quantizerStepSize a granule
+ *           without big values inherits from the same (gr, ch) of the frame before (:1004-1006, :788-803).
+ * mp3s_rate_loop_dev runs every unit on ASSUMED inputs (cursor_in, state_in).  This call scans the batch (segments =
+ * streams), compares every unit's assumptions with the true chain, gives silent units the values they inherit (the
+ * bit packer writes them into the side info) and leaves one verdict: verdict[0] = number of units that ran on wrong
+ * assumptions that mattered (0: d_gr is final, mp3s_pack_frames_dev may run), verdict[1] = 1 if some quantizer step
+ * left its table.  The host then reads 8 bytes instead of 72 per unit. */
+typedef struct {
+    int32_t first_frame, n_frames;   /* the stream's frames in the batch */
+    int32_t hide_base;               /* its message is hide[hide_base .. hide_end) of the batch's message array */
+    int32_t hide_begin;              /* cursor at its first unit: hide_base + the bits taken by the frames in front of a block */
+    int32_t hide_end;
+    int32_t reserved;
+    int32_t chain_in[4][4];          /* per ch*2+gr: address1..3, quantizerStepSize the frames in front left (zeros: stream start) */
+} mp3s_chain_seg; /* 88 bytes */
+typedef struct {
+    int64_t cursor;                  /* behind the stream's last unit, as an index into the batch's message array */
+    int32_t chain[4][4];             /* the four chains as the stream leaves them */
+    int32_t carry_used;              /* some unit looked at chain_in / the message was live at the first unit */
+    int32_t reserved;
+} mp3s_chain_seg_out; /* 80 bytes */
+/* d_state_in NULL = zeros (as for mp3s_rate_loop_dev); d_verdict: 2 words; d_seg_out: [n_segs]; both written by the call */
+int mp3s_chain_resolve_dev(mp3s_ctx *ctx, mp3s_gr_out *d_gr, const mp3s_rate_frame *d_frames, int n_frames,
+                           const mp3s_chain_seg *d_segs, int n_segs, const int32_t *d_cursor_in, const int32_t *d_state_in,
+                           int32_t *d_verdict, mp3s_chain_seg_out *d_seg_out);
 
 /* ---------------------------------------------------------------- (vi) bit-level stages on the device
  * The serial bit parsing / packing of the reference is serial per granule only: granule boundaries are known from
@@ -412,6 +444,37 @@ int mp3s_reencode_block(mp3s_ctx *ctx, const uint8_t *mp3, size_t len, const uin
 /* replaces: Steganography.reveal_massage -- reference steganography.py:103-131: MP3 bytes -> message text.  Only the
  * byte-level scan runs (table_select lives in the side info), so no device work and no context are needed. */
 int mp3s_reveal_message(const uint8_t *mp3, size_t len, mp3s_buf **owner, mp3s_file *out);
+
+/* ---------------------------------------------------------------- (vii) asynchronous host-fed pipeline
+ * replaces: a loop of Steganography.hide_message / clear_file over many files or batches of files -- reference
+ *           steganography.py:133-182, whose two serial frame loops (decoder/MP3_Parser.py:68-80, encoder/MP3_Encoder.py:
+ *           607-609) become four overlapping stages: host scan on worker threads (straight into page-locked staging) ||
+ *           hipMemcpyAsync up || kernels || hipMemcpyAsync down, `depth` jobs in flight, nothing waited for until a result
+ *           is collected.
+ * A job = the files of one mp3s_hide_messages call (same arguments, same results byte for byte: jobs the device cannot
+ * take in one batch, or whose on-device verdict says a guess failed, are redone by that very function).
+ * While a pipe exists its context belongs to it: no other call may use the context until mp3s_pipe_destroy().
+ * The submitted file and message buffers are borrowed until the job has been collected. */
+typedef struct mp3s_pipe mp3s_pipe;
+typedef struct {
+    int64_t submitted, collected;
+    int64_t fast, slow;               /* collected jobs that went through the overlapped stages / through mp3s_hide_messages */
+    double scan_ms, issue_ms;         /* summed over jobs: host scan + input layout; queueing the job's device work */
+    double last_device_span_ms;       /* first upload byte to last download byte of the job collected last (HIP events) */
+} mp3s_pipe_stats;
+/* depth: jobs in flight (= staging slots); max_job_bytes: MP3 bytes per job the staging is sized for (larger jobs still
+ * work, through the synchronous path); scan_threads: host workers */
+int mp3s_pipe_create(mp3s_ctx *ctx, int depth, size_t max_job_bytes, int scan_threads, mp3s_pipe **out);
+void mp3s_pipe_destroy(mp3s_pipe *pipe);
+/* arguments as for mp3s_hide_messages (msgs NULL = clear all, msgs[i] NULL = clear file i); MP3S_E_BUSY when `depth`
+ * jobs are in flight (collect one first) */
+int mp3s_pipe_submit(mp3s_pipe *pipe, const uint8_t *const *mp3s, const size_t *lens, int n_files, const uint8_t *const *msgs,
+                     const size_t *msg_lens, int64_t *ticket);
+/* waits for the OLDEST job in flight and hands out its results: out[i] / status[i] as mp3s_hide_messages fills them
+ * (max_files = room in both arrays), *n_files = files of that job.  MP3S_E_BUSY: nothing in flight. */
+int mp3s_pipe_collect(mp3s_pipe *pipe, int64_t *ticket, mp3s_buf **owner, mp3s_file *out, int32_t *status, int max_files,
+                      int *n_files);
+int mp3s_pipe_get_stats(mp3s_pipe *pipe, mp3s_pipe_stats *out);
 
 #ifdef __cplusplus
 }

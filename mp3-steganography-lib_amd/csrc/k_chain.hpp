@@ -1,0 +1,198 @@
+// Serial chains of the rate loop, checked on the device (gfx950).  Included by mp3s_device.hip only.
+//
+// The reference encoder carries two things from one granule*channel ("unit") to the next:
+//   * the message cursor __hide_str_offset: every unit adds the number of its non-zero table_select
+//     (reference encoder/MP3_Encoder.py:808-809), and __new_choose_table reads the message at that cursor (:1154-1168);
+//   * address1/2/3 and quantizerStepSize of the same (gr, ch) of the frame before, which a unit without big values
+//     (or without any signal) does not overwrite (:1004-1006, :788-803).
+// k_rate_loop runs every unit on assumed inputs (cursor_in, state_in).  These two kernels do what the host walk of
+// round 1 did after downloading 72 bytes per unit: a segmented scan over the frames of the batch (segments = streams)
+// gives every frame the true cursor and the last values its four (gr, ch) classes were left with, every unit's
+// assumptions are compared with them, silent units get the values they inherit (the bit packer writes them into the
+// side info), and the host reads back ONE verdict: the number of units that ran on wrong assumptions that mattered.
+// Zero is the common case (a short message in a long stream, guess = 3 tables per unit); otherwise the host resolves
+// the chain as before (csrc/mp3s_encode_pipeline.cpp).
+//
+// Scan element per frame: (reset, tables, last[4]) -- reset: the frame starts a stream; tables: non-zero tables of its
+// active units; last[k]: index of its active unit of class k = ch*2+gr, or -1.  The operator takes the right operand's
+// reset, adds tables unless the right operand resets, and keeps the right-most last[k].
+#pragma once
+
+namespace mp3s {
+
+constexpr int CH_THREADS = 256;   // frames per workgroup
+
+struct ChainEl { int reset, tables, last[4]; };
+
+__device__ __forceinline__ ChainEl chain_identity() { return ChainEl{0, 0, {-1, -1, -1, -1}}; }
+__device__ __forceinline__ ChainEl chain_combine(const ChainEl &l, const ChainEl &r)
+{
+    if (r.reset) return r;
+    ChainEl o;
+    o.reset = l.reset;
+    o.tables = l.tables + r.tables;
+#pragma unroll
+    for (int k = 0; k < 4; k++) o.last[k] = r.last[k] >= 0 ? r.last[k] : l.last[k];
+    return o;
+}
+__device__ __forceinline__ ChainEl chain_shfl_up(const ChainEl &x, int d)
+{
+    ChainEl o;
+    o.reset = __shfl_up(x.reset, d, 64);
+    o.tables = __shfl_up(x.tables, d, 64);
+#pragma unroll
+    for (int k = 0; k < 4; k++) o.last[k] = __shfl_up(x.last[k], d, 64);
+    return o;
+}
+
+// inclusive scan over the 256 threads of the workgroup; *total = the combination of all 256 elements
+__device__ __forceinline__ ChainEl chain_block_scan(ChainEl x, ChainEl (&wave_tot)[CH_THREADS / 64], ChainEl *total)
+{
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const ChainEl o = chain_shfl_up(x, d);
+        if (lane >= d) x = chain_combine(o, x);
+    }
+    __syncthreads();                       // the previous use of wave_tot is over
+    if (lane == 63) wave_tot[wave] = x;
+    __syncthreads();
+    ChainEl pre = chain_identity();
+#pragma unroll
+    for (int w = 0; w < CH_THREADS / 64; w++) {
+        if (w < wave) pre = chain_combine(pre, wave_tot[w]);
+    }
+    x = chain_combine(pre, x);
+    if (total) {
+        ChainEl t = wave_tot[0];
+#pragma unroll
+        for (int w = 1; w < CH_THREADS / 64; w++) t = chain_combine(t, wave_tot[w]);
+        *total = t;
+    }
+    return x;
+}
+
+__device__ __forceinline__ ChainEl chain_element(const mp3s_gr_out *__restrict__ gr, const mp3s_rate_frame *__restrict__ rf,
+                                                 const mp3s_chain_seg *__restrict__ segs, int f, int n_frames)
+{
+    ChainEl e = chain_identity();
+    if (f >= n_frames) return e;
+    e.reset = segs[rf[f].stream].first_frame == f ? 1 : 0;
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        const mp3s_gr_out &g = gr[(long)f * 4 + k];
+        if (g.flags & MP3S_RF_ACTIVE) { e.tables += g.n_tables; e.last[k] = f * 4 + k; }
+    }
+    return e;
+}
+
+// pass 1: one aggregate per workgroup of 256 frames
+__global__ __launch_bounds__(CH_THREADS) void k_chain_sum(const mp3s_gr_out *__restrict__ gr, const mp3s_rate_frame *__restrict__ rf,
+                                                          const mp3s_chain_seg *__restrict__ segs, int n_frames,
+                                                          ChainEl *__restrict__ agg, int32_t *__restrict__ verdict,
+                                                          mp3s_chain_seg_out *__restrict__ seg_out)
+{
+    __shared__ ChainEl wave_tot[CH_THREADS / 64];
+    const int f = blockIdx.x * CH_THREADS + threadIdx.x;
+    // what pass 2 accumulates into starts from zero (no fill launches in front of the pair)
+    if (f == 0) { verdict[0] = 0; verdict[1] = 0; }
+    if (f < n_frames && segs[rf[f].stream].first_frame == f) seg_out[rf[f].stream].carry_used = 0;
+    ChainEl total;
+    chain_block_scan(chain_element(gr, rf, segs, f, n_frames), wave_tot, &total);
+    if (threadIdx.x == 0) agg[blockIdx.x] = total;
+}
+
+// pass 2: every frame walks its four units with the true inputs in hand
+//   verdict[0] += units whose assumed cursor / inherited addresses were wrong and mattered; verdict[1] |= 1: a
+//   quantizer step left the table;  seg_out[s]: cursor behind the stream's last unit (index into the batch's message
+//   array), the four chains as the stream leaves them, carry_used (see mp3s_encode_block)
+__global__ __launch_bounds__(CH_THREADS) void k_chain_apply(mp3s_gr_out *__restrict__ gr, const mp3s_rate_frame *__restrict__ rf,
+                                                            const mp3s_chain_seg *__restrict__ segs, int n_frames,
+                                                            const ChainEl *__restrict__ agg, const int32_t *__restrict__ cursor_in,
+                                                            const int32_t *__restrict__ state_in, int32_t *__restrict__ verdict,
+                                                            mp3s_chain_seg_out *__restrict__ seg_out)
+{
+    __shared__ ChainEl wave_tot[CH_THREADS / 64];
+    const int f = blockIdx.x * CH_THREADS + threadIdx.x;
+    // what the workgroups in front of this one add up to
+    ChainEl before = chain_identity();
+    for (int c0 = 0; c0 < (int)blockIdx.x; c0 += CH_THREADS) {
+        const int j = c0 + (int)threadIdx.x;
+        ChainEl total;
+        chain_block_scan(j < (int)blockIdx.x ? agg[j] : chain_identity(), wave_tot, &total);
+        before = chain_combine(before, total);
+    }
+    const ChainEl own_el = chain_element(gr, rf, segs, f, n_frames);
+    const ChainEl incl = chain_block_scan(own_el, wave_tot, nullptr);
+    // exclusive prefix: the element of the thread before (wave_tot of the wave before for lane 0)
+    ChainEl excl = chain_shfl_up(incl, 1);
+    if ((threadIdx.x & 63) == 0) {
+        excl = chain_identity();
+        for (int w = 0; w < (int)(threadIdx.x >> 6); w++) excl = chain_combine(excl, wave_tot[w]);
+    }
+    excl = chain_combine(before, excl);
+    int redo_here = 0, err_here = 0;
+    if (f < n_frames) {
+        const int s = rf[f].stream;
+        const mp3s_chain_seg sg = segs[s];
+        const bool first = sg.first_frame == f;
+        if (first) excl = chain_identity();          // whatever lies in front belongs to another stream
+        long cur = (long)sg.hide_begin + excl.tables;
+        const long end = sg.hide_end;
+        const bool hiding = sg.hide_end > sg.hide_base;
+        int carry_used = first && cur < end ? 1 : 0; // the message is still being hidden when the stream (block) starts
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const long u = (long)f * 4 + k;
+            mp3s_gr_out &g = gr[u];
+            int32_t ch[4];
+            const bool own = excl.last[k] >= 0;      // the stream has set chain k itself by now
+            if (own) {
+                const mp3s_gr_out &p = gr[excl.last[k]];
+                ch[0] = p.address[0]; ch[1] = p.address[1]; ch[2] = p.address[2]; ch[3] = p.quantizer_step;
+            } else {
+#pragma unroll
+                for (int j = 0; j < 4; j++) ch[j] = sg.chain_in[k][j];
+            }
+            const int flags = g.flags;
+            const bool active = flags & MP3S_RF_ACTIVE;
+            if (!own && (!active || (flags & MP3S_RF_USED_ADDR_IN))) carry_used = 1;
+            bool redo = false;
+            if (hiding && active) {
+                const long used = cursor_in[u];
+                if (used != cur && (used < cur ? used : cur) < end) redo = true;
+            }
+            if (flags & MP3S_RF_USED_ADDR_IN) {
+                const int32_t s0 = state_in ? state_in[u * 4] : 0, s1 = state_in ? state_in[u * 4 + 1] : 0,
+                              s2 = state_in ? state_in[u * 4 + 2] : 0;
+                if (s0 != ch[0] || s1 != ch[1] || s2 != ch[2]) redo = true;
+            }
+            redo_here += redo ? 1 : 0;
+            if (flags & MP3S_RF_STEP_RANGE) err_here = 1;
+            if (active) cur += g.n_tables;
+            else {   // silent unit: everything is inherited (quantizerStepSize and addresses pass through)
+                g.address[0] = ch[0]; g.address[1] = ch[1]; g.address[2] = ch[2];
+                g.quantizer_step = ch[3];
+            }
+        }
+        if (carry_used) atomicOr(&seg_out[s].carry_used, 1);
+        if (f == sg.first_frame + sg.n_frames - 1) {
+            // the chains behind the stream's last frame: this frame's active units, else what it inherited
+            seg_out[s].cursor = cur;
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                const mp3s_gr_out &g = gr[(long)f * 4 + k];   // (silent units carry their inherited values by now)
+                seg_out[s].chain[k][0] = g.address[0]; seg_out[s].chain[k][1] = g.address[1];
+                seg_out[s].chain[k][2] = g.address[2]; seg_out[s].chain[k][3] = g.quantizer_step;
+            }
+        }
+    }
+    const int n_redo = (int)wave_add_u32((uint32_t)redo_here);
+    const bool any_err = __ballot(err_here != 0) != 0;
+    if ((threadIdx.x & 63) == 0) {
+        if (n_redo) atomicAdd(&verdict[0], n_redo);
+        if (any_err) atomicOr(&verdict[1], 1);
+    }
+}
+
+}  // namespace mp3s

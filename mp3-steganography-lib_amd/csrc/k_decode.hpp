@@ -167,7 +167,7 @@ __device__ __forceinline__ void dec_prepare(const DevTables &tab, DecShared &sh,
 
 __global__ __launch_bounds__(DEC_A_WAVES * 64, 3) void k_dec_imdct(
     const int16_t *__restrict__ is, const mp3s_granule_si *__restrict__ si, const mp3s_frame_hdr *__restrict__ hdr,
-    int n_granules, int nch, int run, double *__restrict__ S, long T)
+    int n_granules, int nch, int run, double *__restrict__ S, long T, int sf_base)
 {
     __shared__ DecShared sh;
     for (int i = threadIdx.x; i < POW2Q_N; i += blockDim.x) sh.pow2q[i] = c_tab.pow2q[i];
@@ -189,7 +189,8 @@ __global__ __launch_bounds__(DEC_A_WAVES * 64, 3) void k_dec_imdct(
         if (g >= n_granules) break;
         if (g < 0) continue;
         const mp3s_frame_hdr fh = hdr[g >> 1];
-        const int first_gran = (int)fh.stream_first * 2;
+        // stream_first counts from frame sf_base of the batch; this launch starts there (a chunk of a longer batch)
+        const int first_gran = fh.stream_first > (uint32_t)sf_base ? (int)(fh.stream_first - (uint32_t)sf_base) * 2 : 0;
         if (gi < 0 && g0 <= first_gran) continue;          // the run starts a stream: nothing before it
         if (gi >= 0 && g == first_gran) {
 #pragma unroll
@@ -299,7 +300,7 @@ __device__ __forceinline__ int16_t pcm_to_i16(double v)
 template <int TW>
 __global__ __launch_bounds__(TW * 64 * 2, 5) void k_dec_synth(
     const double *__restrict__ S, long T, const mp3s_frame_hdr *__restrict__ hdr, int nch, int n_halo, int out_format,
-    void *__restrict__ pcm_out)
+    void *__restrict__ pcm_out, int sf_base)
 {
     constexpr int TL_LANES = TW * 64, OUT = TL_LANES - 15;
     constexpr int OROW = 33;                                   // dwords per staged slot (32 + 1 pad: no bank conflicts)
@@ -312,7 +313,8 @@ __global__ __launch_bounds__(TW * 64 * 2, 5) void k_dec_synth(
     const bool valid = t >= 0 && t < T;
     int lim = -1;            // number of earlier in-stream slots (V history available), -1: slot not valid
     if (valid) {
-        const long s0 = (long)hdr[t / 36].stream_first * 36;
+        const uint32_t sf = hdr[t / 36].stream_first;
+        const long s0 = sf > (uint32_t)sf_base ? (long)(sf - (uint32_t)sf_base) * 36 : 0;
         lim = (int)((t - s0) < 64 ? (t - s0) : 64);
     }
     double Sv[32];

@@ -177,6 +177,26 @@ int mp3s_timer_stop(mp3s_ctx *c, float *ms)
     return MP3S_OK;
 }
 
+int mp3s_bench_copy(mp3s_ctx *c, size_t bytes, int iters, double *gb_per_s)
+{
+    if (!c || !gb_per_s || bytes < 4096 || iters < 1) return fail(MP3S_E_ARG, "bad argument");
+    HIPCHK(hipSetDevice(c->device));
+    bytes &= ~(size_t)15;
+    void *a = nullptr, *b = nullptr;
+    if (hipMalloc(&a, bytes) != hipSuccess || hipMalloc(&b, bytes) != hipSuccess) { if (a) hipFree(a); return fail(MP3S_E_NOMEM, "hipMalloc(%zu) x 2", bytes); }
+    int rc = MP3S_OK;
+    float ms = 0;
+    if (hipMemsetAsync(a, 1, bytes, c->stream) != hipSuccess || launch_copy(c->stream, a, b, bytes) != 0) rc = fail(MP3S_E_HIP, "copy launch failed");   // warm
+    if (!rc && hipEventRecord(c->ev0, c->stream) != hipSuccess) rc = fail(MP3S_E_HIP, "event");
+    for (int i = 0; i < iters && !rc; i++) if (launch_copy(c->stream, i & 1 ? b : a, i & 1 ? a : b, bytes) != 0) rc = fail(MP3S_E_HIP, "copy launch failed");
+    if (!rc && (hipEventRecord(c->ev1, c->stream) != hipSuccess || hipEventSynchronize(c->ev1) != hipSuccess ||
+                hipEventElapsedTime(&ms, c->ev0, c->ev1) != hipSuccess)) rc = fail(MP3S_E_HIP, "event");
+    hipStreamSynchronize(c->stream);
+    hipFree(a); hipFree(b);
+    if (!rc) *gb_per_s = 2.0 * (double)bytes * iters / (ms * 1e-3) / 1e9;   // read + write
+    return rc;
+}
+
 int mp3s_profile_enable(mp3s_ctx *c, int on)
 {
     if (!c) return fail(MP3S_E_ARG, "ctx is null");
@@ -316,6 +336,19 @@ int mp3s_rate_loop_dev(mp3s_ctx *c, const int32_t *d_mdct, const mp3s_rate_frame
 }
 
 
+
+int mp3s_chain_resolve_dev(mp3s_ctx *c, mp3s_gr_out *d_gr, const mp3s_rate_frame *d_frames, int n_frames, const mp3s_chain_seg *d_segs,
+                           int n_segs, const int32_t *d_cursor_in, const int32_t *d_state_in, int32_t *d_verdict,
+                           mp3s_chain_seg_out *d_seg_out)
+{
+    if (!c || !d_gr || !d_frames || !d_segs || !d_verdict || !d_seg_out) return fail(MP3S_E_ARG, "null pointer");
+    if (n_frames <= 0 || n_segs <= 0) return fail(MP3S_E_ARG, "bad sizes");
+    void *d_agg = c->grab(30, chain_agg_bytes(n_frames));
+    if (!d_agg) return fail(MP3S_E_NOMEM, "hipMalloc failed for the chain scratch");
+    const int e = launch_chain(c->stream, d_gr, d_frames, n_frames, d_segs, d_cursor_in, d_state_in, d_agg, d_verdict, d_seg_out, &c->prof);
+    if (e) return fail(MP3S_E_HIP, "chain launch: %s", hipGetErrorString((hipError_t)e));
+    return MP3S_OK;
+}
 
 int mp3s_huffman_decode_dev(mp3s_ctx *c, const uint8_t *d_blob, const mp3s_frame_side *d_side, int n_frames, int nch,
                             int max_part2_3_length, int16_t *d_is, mp3s_granule_si *d_si, int32_t *d_status)

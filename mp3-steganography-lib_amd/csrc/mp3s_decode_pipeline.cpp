@@ -43,6 +43,19 @@ int front_end(mp3s_multi &m, int i)
     return rc;
 }
 
+// transforms of frames [first, first + cnt) of a resident batch (arrays indexed by batch frame; stream_first counts from
+// frame 0 of the batch); the PCM of all but the first `halo` of them goes to d_pcm
+int decode_transform_chunk(mp3s_ctx *c, const int16_t *d_is, const mp3s_granule_si *d_si, const mp3s_frame_hdr *d_hdr, long first, int cnt,
+                           int nch, int halo, int out_format, void *d_pcm)
+{
+    int rc = c->ensure_scratch(dec_scratch_bytes(cnt, nch));
+    if (rc) return rc;
+    const int e = launch_decode(c->stream, d_is + (size_t)first * 2304, d_si + (size_t)first * 4, d_hdr + first, cnt, nch, halo, out_format,
+                                d_pcm, c->scratch, &c->prof, (int)first);
+    if (e) return fail(MP3S_E_HIP, "decode launch: %s", hipGetErrorString((hipError_t)e));
+    return MP3S_OK;
+}
+
 // Decode the streams listed in `idx` (all with the same channel count) as ONE batch.
 // d_keep != nullptr: the PCM of the group stays on the device there (frames back to back, a duplicated last frame
 // included) and nothing is downloaded -- the re-encode path of mp3s_hide_message / mp3s_clear_file.
@@ -70,6 +83,7 @@ int decode_group(mp3s_ctx *c, mp3s_multi &m, const std::vector<int> &idx, int nc
         first_of[k] = f0;
         const bool dev = sc.gpu_ok;
         (dev ? any_dev : any_host) = true;
+        if (dev && !in_place) c->h_blob.resize((c->h_blob.size() + 3) & ~(size_t)3, 0);   // md_off stays a multiple of 4 (mp3s.h)
         const uint32_t base = (uint32_t)c->h_blob.size();
         if (dev && !in_place) c->h_blob.insert(c->h_blob.end(), sc.blob.begin(), sc.blob.end());
         for (int f = 0; f < p.n_frames; f++) {
@@ -90,7 +104,7 @@ int decode_group(mp3s_ctx *c, mp3s_multi &m, const std::vector<int> &idx, int nc
     int slot = 0;
     auto grab = [&](size_t bytes) { return c->grab(slot++, bytes); };
     void *d_is = grab((size_t)n * 2304 * 2), *d_si = grab((size_t)n * 4 * sizeof(mp3s_granule_si)),
-         *d_hdr = grab((size_t)chunk * sizeof(mp3s_frame_hdr)), *d_pcm = grab((size_t)chunk * frame_bytes), *d_st = grab(((size_t)n + 1) * 4),
+         *d_hdr = grab((size_t)n * sizeof(mp3s_frame_hdr)), *d_pcm = grab((size_t)chunk * frame_bytes), *d_st = grab(((size_t)n + 1) * 4),
          *d_blob = grab(blob_bytes), *d_side = grab((size_t)n * sizeof(mp3s_frame_side));
     if (!d_is || !d_si || !d_hdr || !d_pcm || !d_st || !d_blob || !d_side)
         return fail(MP3S_E_NOMEM, "hipMalloc failed for a %ld-frame decode", n);
@@ -158,16 +172,13 @@ int decode_group(mp3s_ctx *c, mp3s_multi &m, const std::vector<int> &idx, int nc
             return fail(MP3S_E_NOMEM, "hipHostMalloc failed for %ld frames of PCM", n + extra);
         arena = m.arena[nch].data() + m.head_room;
     }
-    std::vector<mp3s_frame_hdr> hc;
+    if (!rc) rc = mp3s_dev_upload(c, d_hdr, hdr.data(), (size_t)n * sizeof(mp3s_frame_hdr));
     for (long start = 0; start < n && !rc; start += kDecodeChunk) {
         const int halo = (start && hdr[(size_t)start].stream_first < (uint32_t)start) ? 1 : 0;
         const long first = start - halo;
         const int cnt = (int)std::min<long>(kDecodeChunk, n - start) + halo;
-        hc.assign(hdr.begin() + first, hdr.begin() + first + cnt);
-        for (auto &h : hc) h.stream_first = h.stream_first > (uint32_t)first ? h.stream_first - (uint32_t)first : 0;
-        rc = mp3s_dev_upload(c, d_hdr, hc.data(), (size_t)cnt * sizeof(mp3s_frame_hdr));
-        if (!rc) rc = mp3s_decode_transform_dev(c, (const int16_t *)d_is + (size_t)first * 2304, (const mp3s_granule_si *)d_si + (size_t)first * 4,
-                                                (const mp3s_frame_hdr *)d_hdr, cnt, nch, halo, out_format, d_pcm);
+        rc = decode_transform_chunk(c, (const int16_t *)d_is, (const mp3s_granule_si *)d_si, (const mp3s_frame_hdr *)d_hdr, first, cnt, nch,
+                                    halo, out_format, d_pcm);
         // copy out in runs that are contiguous on both sides (a run ends where a duplicated frame is inserted)
         const long end = start + (cnt - halo);
         for (long a = start; a < end && !rc;) {

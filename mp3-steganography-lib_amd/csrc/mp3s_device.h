@@ -15,7 +15,7 @@ constexpr int DEC_SYNTH_TW = 2;
 
 // optional per-kernel HIP-event timing: when non-null, every kernel launch is bracketed by two events
 // recorded on the launch stream; mp3s_profile_collect() turns the pairs into per-kernel totals.
-enum KernelId { K_DEC_IMDCT = 0, K_DEC_SYNTH, K_ENC_ANALYSIS, K_ENC_MDCT, K_RATE_LOOP, K_DEC_HUFFMAN, K_ENC_PACK, K_COUNT };
+enum KernelId { K_DEC_IMDCT = 0, K_DEC_SYNTH, K_ENC_ANALYSIS, K_ENC_MDCT, K_RATE_LOOP, K_DEC_HUFFMAN, K_ENC_PACK, K_CHAIN, K_COUNT };
 struct Profiler {
     static constexpr int MAX_PAIRS = 8192;
     hipEvent_t ev[2 * MAX_PAIRS];
@@ -34,7 +34,8 @@ int dev_upload_tables(hipStream_t stream);
 // scratch: time-domain subband samples, float64 [nch][36 n][32]
 size_t dec_scratch_bytes(int n_frames, int nch);
 int launch_decode(hipStream_t stream, const int16_t *d_is, const mp3s_granule_si *d_si, const mp3s_frame_hdr *d_hdr,
-                  int n_frames, int nch, int n_halo, int out_format, void *d_pcm, void *d_scratch, Profiler *prof);
+                  int n_frames, int nch, int n_halo, int out_format, void *d_pcm, void *d_scratch, Profiler *prof,
+                  int sf_base = 0 /* hdr[].stream_first counts from this frame of the batch; d_is / d_si / d_hdr start there */);
 
 // scratch: subband samples int32 [2][32][36 n]
 size_t enc_scratch_bytes(int n_frames);
@@ -47,6 +48,14 @@ int launch_rate(hipStream_t stream, const int32_t *d_mdct, const mp3s_rate_frame
                 const int32_t *d_list, int n_list, int16_t *d_ix, mp3s_gr_out *d_out, int32_t *d_en, Profiler *prof,
                 int out_base = 0 /* unit whose results land on element 0 of d_ix / d_out / d_en */,
                 int compact = 0 /* 1: d_cursor / d_state / d_out are indexed by the position in d_list; 2: d_ix / d_en too */);
+
+// the serial chains of the rate loop (k_chain.hpp): two small launches; d_agg: chain_agg_bytes(n_frames) of scratch
+size_t chain_agg_bytes(int n_frames);
+int launch_chain(hipStream_t stream, mp3s_gr_out *d_gr, const mp3s_rate_frame *d_frames, int n_frames, const mp3s_chain_seg *d_segs,
+                 const int32_t *d_cursor, const int32_t *d_state, void *d_agg, int32_t *d_verdict, mp3s_chain_seg_out *d_seg_out,
+                 Profiler *prof);
+
+int launch_copy(hipStream_t stream, const void *d_src, void *d_dst, size_t bytes);
 
 // bit-level stages on the device
 int launch_huffman(hipStream_t stream, const uint8_t *d_blob, const mp3s_frame_side *d_side, int n_frames, int nch, int max_bits,

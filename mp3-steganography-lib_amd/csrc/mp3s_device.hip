@@ -17,6 +17,7 @@ __constant__ DevTables c_tab;
 #include "k_rate.hpp"
 #include "k_huffman.hpp"
 #include "k_pack.hpp"
+#include "k_chain.hpp"
 
 namespace mp3s {
 
@@ -50,7 +51,7 @@ size_t dec_scratch_bytes(int n_frames, int nch)
 }
 
 int launch_decode(hipStream_t stream, const int16_t *d_is, const mp3s_granule_si *d_si, const mp3s_frame_hdr *d_hdr,
-                  int n_frames, int nch, int n_halo, int out_format, void *d_pcm, void *d_scratch, Profiler *prof)
+                  int n_frames, int nch, int n_halo, int out_format, void *d_pcm, void *d_scratch, Profiler *prof, int sf_base)
 {
     const long T = (long)n_frames * 36;
     double *S = (double *)d_scratch;
@@ -71,14 +72,14 @@ int launch_decode(hipStream_t stream, const int16_t *d_is, const mp3s_granule_si
     const int runs = (n_gran + run - 1) / run;
     int pp = prof ? prof->begin(stream, K_DEC_IMDCT) : -1;
     hipLaunchKernelGGL(k_dec_imdct, dim3((runs + DEC_A_WAVES - 1) / DEC_A_WAVES), dim3(DEC_A_WAVES * 64), 0, stream,
-                       d_is, d_si, d_hdr, n_gran, nch, run, S, T);
+                       d_is, d_si, d_hdr, n_gran, nch, run, S, T, sf_base);
     if (prof) prof->end(stream, pp);
     constexpr int TW = DEC_SYNTH_TW;
     const int out_per_tile = TW * 64 - 15;
     const int tiles = (int)((T + out_per_tile - 1) / out_per_tile);
     pp = prof ? prof->begin(stream, K_DEC_SYNTH) : -1;
     hipLaunchKernelGGL(k_dec_synth<TW>, dim3(tiles), dim3(TW * 64 * nch), 0, stream, (const double *)S, T, d_hdr, nch,
-                       n_halo, out_format, d_pcm);
+                       n_halo, out_format, d_pcm, sf_base);
     if (prof) prof->end(stream, pp);
     return (int)hipGetLastError();
 }
@@ -120,6 +121,23 @@ int launch_rate(hipStream_t stream, const int32_t *d_mdct, const mp3s_rate_frame
     return (int)hipGetLastError();
 }
 
+size_t chain_agg_bytes(int n_frames) { return (size_t)((n_frames + CH_THREADS - 1) / CH_THREADS) * sizeof(ChainEl) + 16; }
+
+int launch_chain(hipStream_t stream, mp3s_gr_out *d_gr, const mp3s_rate_frame *d_frames, int n_frames, const mp3s_chain_seg *d_segs,
+                 const int32_t *d_cursor, const int32_t *d_state, void *d_agg, int32_t *d_verdict, mp3s_chain_seg_out *d_seg_out,
+                 Profiler *prof)
+{
+    if (n_frames <= 0) return 0;
+    const int blocks = (n_frames + CH_THREADS - 1) / CH_THREADS;
+    const int pp = prof ? prof->begin(stream, K_CHAIN) : -1;
+    hipLaunchKernelGGL(k_chain_sum, dim3(blocks), dim3(CH_THREADS), 0, stream, (const mp3s_gr_out *)d_gr, d_frames, d_segs, n_frames,
+                       (ChainEl *)d_agg, d_verdict, d_seg_out);
+    hipLaunchKernelGGL(k_chain_apply, dim3(blocks), dim3(CH_THREADS), 0, stream, d_gr, d_frames, d_segs, n_frames,
+                       (const ChainEl *)d_agg, d_cursor, d_state, d_verdict, d_seg_out);
+    if (prof) prof->end(stream, pp);
+    return (int)hipGetLastError();
+}
+
 int launch_scatter(hipStream_t stream, const int32_t *d_pairs, int n_pairs, const int16_t *d_ixv, const int32_t *d_env, int16_t *d_ix,
                    int32_t *d_en)
 {
@@ -155,6 +173,19 @@ int launch_huffman(hipStream_t stream, const uint8_t *d_blob, const mp3s_frame_s
     else MP3S_HUF_LAUNCH(4, 16);
 #undef MP3S_HUF_LAUNCH
     if (prof) prof->end(stream, pp);
+    return (int)hipGetLastError();
+}
+
+// plain device copy, 16 bytes per lane and step: what HBM gives a streaming kernel on this box (BASELINE.md section 4 asks
+// for the achievable figure beside the 8 TB/s of the data sheet)
+__global__ __launch_bounds__(256) void k_copy16(const uint4 *__restrict__ src, uint4 *__restrict__ dst, size_t n16)
+{
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n16; i += stride) dst[i] = src[i];
+}
+int launch_copy(hipStream_t stream, const void *d_src, void *d_dst, size_t bytes)
+{
+    hipLaunchKernelGGL(k_copy16, dim3(256 * 16), dim3(256), 0, stream, (const uint4 *)d_src, (uint4 *)d_dst, bytes / 16);
     return (int)hipGetLastError();
 }
 

@@ -2,18 +2,16 @@
 // -- the encoder's device batch with its serial chains, and the file / message / block entry points built on it.
 #include "mp3s_internal.h"
 
-// Encode the streams of `segs` (stereo, one sampling rate and bitrate) as ONE batch: transforms, rate loop, bit packing.
-// pcm_dev != nullptr: the int16 PCM is already in HBM (re-encode after a device decode) and pcm is ignored.
-// Results: b->mp3 = the streams' MP3 bytes (segs[i].mp3_off / mp3_len), b->gr_out and b->scfsi in batch frame order.
-int encode_batch(mp3s_ctx *c, const int16_t *pcm, const int16_t *pcm_dev, std::vector<EncSeg> &segs, int samplerate, int bitrate_kbps,
-                 mp3s_buf *b, int *passes_out)
+static inline size_t up16(size_t x) { return (x + 15) & ~(size_t)15; }
+
+int enc_layout(std::vector<EncSeg> &segs, int samplerate, int bitrate_kbps, EncLayout &L)
 {
     // -1 sits in the reference's bitrate table (encoder/util.py:27,42), so its header check lets it through and the
     // encoder then runs on negative slot counts; nothing meaningful to reproduce
     if (bitrate_kbps <= 0) return fail(MP3S_E_UNSUPPORTED, "bitrate %d", bitrate_kbps);
-    int sri = 0, bri = 0, whole = 0;
-    if (stream_params(samplerate, bitrate_kbps, &sri, &bri, &whole))
+    if (stream_params(samplerate, bitrate_kbps, &L.sri, &L.bri, &L.whole))
         return fail(MP3S_E_UNSUPPORTED, "unsupported samplerate/bitrate %d/%d", samplerate, bitrate_kbps);
+    L.samplerate = samplerate; L.kbps = bitrate_kbps;
     int64_t n64 = 0, hide64 = kPatternBytes;
     for (auto &s : segs) {
         if (s.n_frames <= 0 || s.n_hide < 0 || (s.n_hide > 0 && !s.hide)) return fail(MP3S_E_ARG, "bad stream in the encode batch");
@@ -22,85 +20,184 @@ int encode_batch(mp3s_ctx *c, const int16_t *pcm, const int16_t *pcm_dev, std::v
         if (n64 > 0x7fffffff / 8 || hide64 >= kNoCursor - 8) return fail(MP3S_E_ARG, "encode batch too large");
     }
     if (n64 <= 0) return fail(MP3S_E_ARG, "empty encode batch");
-    const int lead = segs[0].lead;   // frames that only the transforms see
-    if (lead < 0 || lead > 2 || (segs.size() > 1 && (lead || segs[0].first_frame || segs[0].carry_in)))
+    L.lead = segs[0].lead;   // frames that only the transforms see
+    if (L.lead < 0 || L.lead > 2 || (segs.size() > 1 && (L.lead || segs[0].first_frame || segs[0].carry_in)))
         return fail(MP3S_E_ARG, "a block of a longer stream is encoded on its own");
-    const int n = (int)n64, units = n * 4, n_hide = (int)hide64, n_all = n + lead;
-    std::vector<mp3s_rate_frame> rf(n);
-    std::vector<mp3s_frame_hdr> hdr(n_all);
-    std::vector<int32_t> padding(n);
-    std::vector<uint8_t> hide_all((size_t)n_hide, 0);   // [patterns | message of stream 0 | message of stream 1 ...]
-    for (int v = 0; v < 8; v++) { hide_all[4 * v] = (v >> 2) & 1; hide_all[4 * v + 1] = (v >> 1) & 1; hide_all[4 * v + 2] = v & 1; }
-    int64_t bytes_before = 0;
-    for (const auto &s : segs) {
-        // padding / slot lag restart with every stream (MP3_Encoder.py:623-636)
-        const int rc = rate_frames(samplerate, bitrate_kbps, 2, s.n_frames, rf.data() + s.first, padding.data() + s.first, s.first_frame,
-                                   &bytes_before);
-        if (rc) return fail(rc, "unsupported samplerate/bitrate %d/%d", samplerate, bitrate_kbps);
-        for (int f = s.first; f < s.first + s.n_frames; f++) rf[f].hide_end = s.hide_base + s.n_hide;
-        for (int f = s.first; f < s.first + s.n_frames + lead; f++) {
-            hdr[f].sr_idx = (uint8_t)sri; hdr[f].nch = 2; hdr[f].ms_stereo = 0; hdr[f].flags = 0; hdr[f].stream_first = (uint32_t)s.first;
-        }
-        if (s.n_hide) std::memcpy(hide_all.data() + s.hide_base, s.hide, (size_t)s.n_hide);
-    }
-    HIPCHK(hipSetDevice(c->device));
+    L.n = (int)n64; L.units = L.n * 4; L.n_hide = (int)hide64; L.n_all = L.n + L.lead; L.n_segs = (int)segs.size();
+    L.o_rf = up16((size_t)L.n_all * sizeof(mp3s_frame_hdr));
+    L.o_cur = L.o_rf + up16((size_t)L.n * sizeof(mp3s_rate_frame));
+    L.o_hide = L.o_cur + up16((size_t)L.units * 4);
+    L.o_segs = L.o_hide + up16((size_t)L.n_hide);
+    L.o_off = L.o_segs + up16((size_t)L.n_segs * sizeof(mp3s_chain_seg));
+    L.o_pad = L.o_off + up16(((size_t)L.n + 1) * 4);
+    L.bytes = L.o_pad + up16((size_t)L.n);
+    return MP3S_OK;
+}
 
-    // every host-made input in one block, one copy: [frame headers | rate frames | cursors | message bits]
-    auto up16 = [](size_t x) { return (x + 15) & ~(size_t)15; };
-    const size_t o_rf = up16((size_t)n_all * sizeof(mp3s_frame_hdr)), o_cur = o_rf + up16((size_t)n * sizeof(mp3s_rate_frame)),
-                 o_hide = o_cur + up16((size_t)units * 4), in_bytes = o_hide + up16((size_t)n_hide);
-    void *d_pcm = nullptr, *d_in = nullptr, *d_mdct_all = nullptr, *d_state = nullptr, *d_list = nullptr, *d_redo = nullptr, *d_ix = nullptr,
-         *d_out = nullptr, *d_en = nullptr;
+// message bits the frames in front of a block have taken
+static int64_t cursor0(const EncSeg &s)
+{
+    return s.carry_in ? std::min<int64_t>(std::max<int64_t>(s.carry_in->cursor, 0), kNoCursor) : 0;
+}
+
+int enc_fill(std::vector<EncSeg> &segs, EncLayout &L, uint8_t *dst)
+{
+    std::memset(dst, 0, L.bytes);
+    mp3s_frame_hdr *hdr = (mp3s_frame_hdr *)dst;
+    mp3s_rate_frame *rf = (mp3s_rate_frame *)(dst + L.o_rf);
+    int32_t *cursor = (int32_t *)(dst + L.o_cur);
+    uint8_t *hide_all = dst + L.o_hide;          // [patterns | message of stream 0 | message of stream 1 ...]
+    mp3s_chain_seg *cs = (mp3s_chain_seg *)(dst + L.o_segs);
+    uint32_t *off = (uint32_t *)(dst + L.o_off);
+    uint8_t *pad8 = dst + L.o_pad;
+    for (int v = 0; v < 8; v++) { hide_all[4 * v] = (v >> 2) & 1; hide_all[4 * v + 1] = (v >> 1) & 1; hide_all[4 * v + 2] = v & 1; }
+    std::vector<int32_t> padding;
+    L.bytes_before = 0;
+    for (size_t si = 0; si < segs.size(); si++) {
+        EncSeg &s = segs[si];
+        // padding / slot lag restart with every stream (MP3_Encoder.py:623-636)
+        padding.resize((size_t)s.n_frames);
+        const int rc = rate_frames(L.samplerate, L.kbps, 2, s.n_frames, rf + s.first, padding.data(), s.first_frame, &L.bytes_before);
+        if (rc) return fail(rc, "unsupported samplerate/bitrate %d/%d", L.samplerate, L.kbps);
+        for (int f = s.first; f < s.first + s.n_frames; f++) {
+            rf[f].hide_end = s.hide_base + s.n_hide;
+            rf[f].stream = (int32_t)si;
+            pad8[f] = (uint8_t)padding[(size_t)(f - s.first)];
+        }
+        for (int f = s.first; f < s.first + s.n_frames + L.lead; f++) {
+            hdr[f].sr_idx = (uint8_t)L.sri; hdr[f].nch = 2; hdr[f].ms_stereo = 0; hdr[f].flags = 0; hdr[f].stream_first = (uint32_t)s.first;
+        }
+        if (s.n_hide) std::memcpy(hide_all + s.hide_base, s.hide, (size_t)s.n_hide);
+        // A unit sees the message only through the <= 3 bits at its cursor.  First pass: guess three tables per unit (for
+        // a short message in a long stream that is almost always right); a long message is left to the variants.
+        const int64_t c0 = cursor0(s);
+        const bool long_msg = s.n_hide - c0 > kLongMessageBits;
+        for (int j = 0; j < s.n_frames * 4; j++)
+            cursor[(size_t)s.first * 4 + j] = long_msg ? kNoCursor : (int32_t)std::min<int64_t>((int64_t)s.hide_base + c0 + 3 * (int64_t)j, kNoCursor);
+        cs[si].first_frame = s.first; cs[si].n_frames = s.n_frames;
+        cs[si].hide_base = s.hide_base; cs[si].hide_begin = (int32_t)std::min<int64_t>((int64_t)s.hide_base + c0, kNoCursor);
+        cs[si].hide_end = s.hide_base + s.n_hide;
+        if (s.carry_in) std::memcpy(cs[si].chain_in, s.carry_in->chain, sizeof cs[si].chain_in);
+    }
+    off[0] = 0;
+    for (int f = 0; f < L.n; f++) off[f + 1] = off[f] + (uint32_t)(L.whole + pad8[f]);
+    L.mp3_bytes = off[L.n];
+    for (auto &s : segs) {
+        s.mp3_off = off[s.first];
+        s.mp3_len = off[s.first + s.n_frames] - off[s.first];
+        // the reference drops the cached tail (< 32 bits) at the end of the stream: E14
+        if (s.last) s.mp3_len -= std::min<size_t>(s.mp3_len, (size_t)((L.bytes_before + (int64_t)s.mp3_len) % 4));
+    }
+    return MP3S_OK;
+}
+
+int enc_issue(mp3s_ctx *c, const EncLayout &L, const EncDev &d)
+{
+    const mp3s_frame_hdr *d_hdr = (const mp3s_frame_hdr *)d.d_in;
+    const mp3s_rate_frame *d_rf = (const mp3s_rate_frame *)(d.d_in + L.o_rf);
+    const int32_t *d_cur = (const int32_t *)(d.d_in + L.o_cur);
+    const uint8_t *d_hide = d.d_in + L.o_hide;
+    const mp3s_chain_seg *d_segs = (const mp3s_chain_seg *)(d.d_in + L.o_segs);
+    const int32_t *d_mdct = d.d_mdct_all + (size_t)L.lead * 2304;   // the block's own frames
+    int rc = mp3s_encode_transform_dev(c, d.d_pcm, d_hdr, L.n_all, d.d_mdct_all);
+    if (!rc) rc = mp3s_rate_loop_dev(c, d_mdct, d_rf, L.n, d_hide, L.n_hide, d_cur, nullptr, nullptr, 0, d.d_ix, d.d_out, d.d_en);
+    if (!rc) {
+        const int e = launch_chain(c->stream, d.d_out, d_rf, L.n, d_segs, d_cur, nullptr, d.d_agg, d.d_small,
+                                   (mp3s_chain_seg_out *)((uint8_t *)d.d_small + kSmallHead), &c->prof);
+        if (e) rc = fail(MP3S_E_HIP, "chain launch: %s", hipGetErrorString((hipError_t)e));
+    }
+    // packed on the assumption that the verdict is "nothing to redo" (the common case); the caller discards it otherwise
+    if (!rc) rc = mp3s_pack_frames_dev(c, d.d_ix, d.d_out, d.d_en, L.n, L.samplerate, L.kbps, (const uint32_t *)(d.d_in + L.o_off),
+                                       d.d_in + L.o_pad, d.d_mp3, d.d_sc, d.d_small + 2);
+    return rc;
+}
+
+// Encode the streams of `segs` (stereo, one sampling rate and bitrate) as ONE batch: transforms, rate loop, bit packing.
+// pcm_dev != nullptr: the int16 PCM is already in HBM (re-encode after a device decode) and pcm is ignored.
+// Results: b->mp3 = the streams' MP3 bytes (segs[i].mp3_off / mp3_len); with want_gr also b->gr_out and b->scfsi in
+// batch frame order.
+int encode_batch(mp3s_ctx *c, const int16_t *pcm, const int16_t *pcm_dev, std::vector<EncSeg> &segs, int samplerate, int bitrate_kbps,
+                 mp3s_buf *b, int *passes_out, bool want_gr)
+{
+    EncLayout L;
+    int rc = enc_layout(segs, samplerate, bitrate_kbps, L);
+    if (rc) return rc;
+    const int lead = L.lead, n = L.n, units = L.units, n_hide = L.n_hide, n_all = L.n_all;
+    HIPCHK(hipSetDevice(c->device));
+    std::vector<uint8_t> &in = c->h_in;
+    in.resize(L.bytes);
+    rc = enc_fill(segs, L, in.data());
+    if (rc) return rc;
+    const uint8_t *hide_all = in.data() + L.o_hide;
+
+    void *d_pcm = nullptr, *d_in = nullptr, *d_mdct_all = nullptr, *d_redo = nullptr, *d_ix = nullptr, *d_out = nullptr, *d_en = nullptr,
+         *d_agg = nullptr, *d_mp3 = nullptr, *d_sc = nullptr, *d_small = nullptr;
     auto cleanup = [&]() { hipStreamSynchronize(c->stream); };   // the buffers stay in the context's pool
     int slot = 8;
     auto alloc = [&](void **p, size_t bytes) { *p = c->grab(slot++, bytes); return *p != nullptr; };
     if (pcm_dev) { d_pcm = const_cast<int16_t *>(pcm_dev); slot++; }
     else if (!alloc(&d_pcm, (size_t)n_all * 2304 * 2)) d_pcm = nullptr;
-    if (!d_pcm || !alloc(&d_in, in_bytes) || !alloc(&d_mdct_all, (size_t)n_all * 2304 * 4) || !alloc(&d_state, (size_t)units * 16) ||
-        !alloc(&d_list, (size_t)units * 4) || !alloc(&d_redo, (size_t)units * 24) || !alloc(&d_ix, (size_t)n * 2304 * 2) ||
-        !alloc(&d_out, (size_t)units * sizeof(mp3s_gr_out)) || !alloc(&d_en, (size_t)units * 22 * 4)) {
+    if (!d_pcm || !alloc(&d_in, L.bytes) || !alloc(&d_mdct_all, (size_t)n_all * 2304 * 4) || !alloc(&d_redo, (size_t)units * 24) ||
+        !alloc(&d_ix, (size_t)n * 2304 * 2) || !alloc(&d_out, (size_t)units * sizeof(mp3s_gr_out)) || !alloc(&d_en, (size_t)units * 22 * 4) ||
+        !alloc(&d_agg, chain_agg_bytes(n)) || !alloc(&d_mp3, L.mp3_bytes + 16) || !alloc(&d_sc, (size_t)n * 8 * 4) ||
+        !alloc(&d_small, small_bytes(L.n_segs))) {
         cleanup();
         return fail(MP3S_E_NOMEM, "hipMalloc failed for a %d-frame encode", n);
     }
-    const mp3s_frame_hdr *d_hdr = (const mp3s_frame_hdr *)d_in;
     const int32_t *d_mdct = (const int32_t *)d_mdct_all + (size_t)lead * 2304;   // the block's own frames
-    const mp3s_rate_frame *d_rf = (const mp3s_rate_frame *)((uint8_t *)d_in + o_rf);
-    const int32_t *d_cur = (const int32_t *)((uint8_t *)d_in + o_cur);
-    const uint8_t *d_hide = (const uint8_t *)d_in + o_hide;
-    std::vector<int32_t> &cursor = c->h_cursor, &state = c->h_state;
-    cursor.assign(units, 0); state.assign((size_t)units * 4, 0);
-    if (!b->big[1].reserve((size_t)units * sizeof(mp3s_gr_out))) { cleanup(); return fail(MP3S_E_NOMEM, "host memory for %d units", units); }
-    mp3s_gr_out *const gr = b->gr_out = (mp3s_gr_out *)b->big[1].data();   // filled by the first pass's download
-    // A unit sees the message only through the <= 3 bits at its cursor.  First pass: guess three tables per unit (for a
-    // short message in a long stream that is almost always right: one launch).  Where the guess fails, everything behind
-    // the first wrong unit shifts, and re-running shifts it again (hidden bits change bit counts, these the quantiser step,
-    // that the number of tables): pass by pass this converges one unit in fifteen at a time.  Instead the units the rest
-    // of the message can reach are run once per 3-bit pattern (entries = unit x pattern, one launch), the cursor walk
-    // names the entry each unit really sees, and only the message's last unit and the granules that inherit state are
-    // left for exact re-runs.
-    auto cursor0 = [](const EncSeg &s) {   // message bits the frames in front of a block have taken
-        return s.carry_in ? std::min<int64_t>(std::max<int64_t>(s.carry_in->cursor, 0), kNoCursor) : 0;
-    };
-    for (const auto &s : segs) {
-        const int64_t c0 = cursor0(s);
-        const bool long_msg = s.n_hide - c0 > kLongMessageBits;
-        for (int j = 0; j < s.n_frames * 4; j++)
-            cursor[(size_t)s.first * 4 + j] = long_msg ? kNoCursor : (int32_t)std::min<int64_t>((int64_t)s.hide_base + c0 + 3 * (int64_t)j, kNoCursor);
+    const mp3s_rate_frame *d_rf = (const mp3s_rate_frame *)((uint8_t *)d_in + L.o_rf);
+    const uint8_t *d_hide = (const uint8_t *)d_in + L.o_hide;
+    const size_t total = segs.back().mp3_off + segs.back().mp3_len;
+    if (!b->big[0].reserve(L.mp3_bytes) || !b->big[2].reserve(small_bytes(L.n_segs)) ||
+        (want_gr && !b->big[1].reserve((size_t)units * sizeof(mp3s_gr_out)))) {
+        cleanup();
+        return fail(MP3S_E_NOMEM, "host memory for a %d-frame encode", n);
     }
-    std::vector<uint8_t> &in = c->h_in;
-    in.assign(in_bytes, 0);
-    std::memcpy(in.data(), hdr.data(), (size_t)n_all * sizeof(mp3s_frame_hdr));
-    std::memcpy(in.data() + o_rf, rf.data(), (size_t)n * sizeof(mp3s_rate_frame));
-    std::memcpy(in.data() + o_cur, cursor.data(), (size_t)units * 4);
-    if (n_hide) std::memcpy(in.data() + o_hide, hide_all.data(), (size_t)n_hide);
-    int rc = MP3S_OK;
+    b->mp3 = b->big[0].data();
+    int32_t *const small = (int32_t *)b->big[2].data();
+    const mp3s_chain_seg_out *const seg_out = (const mp3s_chain_seg_out *)(b->big[2].data() + kSmallHead);
+    if (want_gr) b->scfsi.assign((size_t)n * 8, 0);
+    // ---- one pass, nothing waited for in between: inputs up, transforms, rate loop on the guessed cursors, the chain
+    //      check on the device, bit packing, results down.  The verdict says whether the guesses held.
     if (!pcm_dev && hipMemcpyAsync(d_pcm, pcm, (size_t)n_all * 2304 * 2, hipMemcpyHostToDevice, c->stream) != hipSuccess) rc = fail(MP3S_E_HIP, "PCM upload failed");
-    if (!rc && hipMemsetAsync(d_state, 0, (size_t)units * 16, c->stream) != hipSuccess) rc = fail(MP3S_E_HIP, "memset failed");
-    if (!rc) rc = mp3s_dev_upload(c, d_in, in.data(), in_bytes);
-    if (!rc) rc = mp3s_encode_transform_dev(c, (const int16_t *)d_pcm, d_hdr, n_all, (int32_t *)d_mdct_all);
-    if (!rc) rc = mp3s_rate_loop_dev(c, d_mdct, d_rf, n, d_hide, n_hide, d_cur, (const int32_t *)d_state, nullptr, 0,
-                                     (int16_t *)d_ix, (mp3s_gr_out *)d_out, (int32_t *)d_en);
-    if (!rc) rc = mp3s_dev_download(c, gr, d_out, (size_t)units * sizeof(mp3s_gr_out));
+    if (!rc && hipMemcpyAsync(d_in, in.data(), L.bytes, hipMemcpyHostToDevice, c->stream) != hipSuccess) rc = fail(MP3S_E_HIP, "input upload failed");
+    EncDev dev;
+    dev.d_pcm = (const int16_t *)d_pcm; dev.d_in = (const uint8_t *)d_in; dev.d_mdct_all = (int32_t *)d_mdct_all; dev.d_ix = (int16_t *)d_ix;
+    dev.d_out = (mp3s_gr_out *)d_out; dev.d_en = (int32_t *)d_en; dev.d_agg = d_agg; dev.d_mp3 = (uint8_t *)d_mp3; dev.d_sc = (int32_t *)d_sc;
+    dev.d_small = (int32_t *)d_small;
+    if (!rc) rc = enc_issue(c, L, dev);
+    auto down = [&](void *dst, const void *src, size_t bytes) {
+        if (!rc && bytes && hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, c->stream) != hipSuccess) rc = fail(MP3S_E_HIP, "download failed");
+    };
+    down(small, d_small, small_bytes(L.n_segs));
+    down(b->mp3, d_mp3, total);
+    if (want_gr) {
+        down(b->big[1].data(), d_out, (size_t)units * sizeof(mp3s_gr_out));
+        down(b->scfsi.data(), d_sc, (size_t)n * 8 * 4);
+    }
+    if (!rc && hipStreamSynchronize(c->stream) != hipSuccess) rc = fail(MP3S_E_HIP, "sync failed");
+    if (rc) { cleanup(); return rc; }
+    if (want_gr) b->gr_out = (mp3s_gr_out *)b->big[1].data();
+    if (small[0] == 0 && small[1] == 0) {
+        if (small[2]) { cleanup(); return fail(MP3S_E_HIP, "bit packer reported status %d", small[2]); }
+        for (size_t si = 0; si < segs.size(); si++) {
+            EncSeg &s = segs[si];
+            s.hide_offset = seg_out[si].cursor - s.hide_base;
+            s.carry_out.cursor = s.hide_offset;
+            std::memcpy(s.carry_out.chain, seg_out[si].chain, sizeof s.carry_out.chain);
+            s.carry_used = seg_out[si].carry_used != 0;
+        }
+        if (passes_out) *passes_out = 1;
+        return MP3S_OK;
+    }
+    // ---- the guesses did not hold: resolve the chains on the host, as round 1 did
+    if (!b->big[1].reserve((size_t)units * sizeof(mp3s_gr_out))) { cleanup(); return fail(MP3S_E_NOMEM, "host memory for %d units", units); }
+    mp3s_gr_out *const gr = b->gr_out = (mp3s_gr_out *)b->big[1].data();
+    if (!want_gr) rc = mp3s_dev_download(c, gr, d_out, (size_t)units * sizeof(mp3s_gr_out));
+    b->scfsi.assign((size_t)n * 8, 0);
+    std::vector<int32_t> &cursor = c->h_cursor, &state = c->h_state;
+    cursor.assign((const int32_t *)(in.data() + L.o_cur), (const int32_t *)(in.data() + L.o_cur) + units);
+    state.assign((size_t)units * 4, 0);
     int passes = 1;
     // ---- resolve the serial chains, stream by stream: hide cursor (MP3_Encoder.py:808-809) and the per-(gr,ch) inherited
     //      address1/2/3 + quantizerStepSize (E7).  walk() lists the units whose assumed inputs were wrong and, per stream,
@@ -268,33 +365,14 @@ int encode_batch(mp3s_ctx *c, const int16_t *pcm, const int16_t *pcm_dev, std::v
         if (!rc) rc = walk();
     }
     if (!rc) {
-        // ---- bit packing on the device: final GrInfo + frame offsets up, MP3 bytes + scfsi down
-        std::vector<uint32_t> off((size_t)n + 1, 0);
-        std::vector<uint8_t> pad8(n);
-        for (int f = 0; f < n; f++) { pad8[f] = (uint8_t)padding[f]; off[f + 1] = off[f] + (uint32_t)(whole + padding[f]); }
-        void *d_off = nullptr, *d_pad = nullptr, *d_mp3 = nullptr, *d_sc = nullptr, *d_st = nullptr;
-        if (!alloc(&d_off, ((size_t)n + 1) * 4) || !alloc(&d_pad, (size_t)n) || !alloc(&d_mp3, (size_t)off[n] + 16) ||
-            !alloc(&d_sc, (size_t)n * 8 * 4) || !alloc(&d_st, 16))
-            rc = fail(MP3S_E_NOMEM, "hipMalloc failed for the packer");
-        if (!rc) rc = mp3s_dev_upload(c, d_off, off.data(), ((size_t)n + 1) * 4);
-        if (!rc) rc = mp3s_dev_upload(c, d_pad, pad8.data(), (size_t)n);
-        if (!rc) rc = mp3s_dev_upload(c, d_out, gr, (size_t)units * sizeof(mp3s_gr_out));
+        // ---- bit packing again, on the final GrInfo
+        rc = mp3s_dev_upload(c, d_out, gr, (size_t)units * sizeof(mp3s_gr_out));
         if (!rc) rc = mp3s_pack_frames_dev(c, (const int16_t *)d_ix, (const mp3s_gr_out *)d_out, (const int32_t *)d_en, n, samplerate,
-                                           bitrate_kbps, (const uint32_t *)d_off, (const uint8_t *)d_pad, (uint8_t *)d_mp3,
-                                           (int32_t *)d_sc, (int32_t *)d_st);
+                                           bitrate_kbps, (const uint32_t *)((uint8_t *)d_in + L.o_off), (const uint8_t *)d_in + L.o_pad,
+                                           (uint8_t *)d_mp3, (int32_t *)d_sc, (int32_t *)d_small + 2);
         int32_t st = 0;
-        if (!rc) rc = mp3s_dev_download(c, &st, d_st, sizeof st);
+        if (!rc) rc = mp3s_dev_download(c, &st, (int32_t *)d_small + 2, sizeof st);
         if (!rc && st) rc = fail(MP3S_E_HIP, "bit packer reported status %d", st);
-        for (auto &s : segs) {
-            s.mp3_off = off[s.first];
-            s.mp3_len = off[s.first + s.n_frames] - off[s.first];
-            // the reference drops the cached tail (< 32 bits) at the end of the stream: E14
-            if (s.last) s.mp3_len -= std::min<size_t>(s.mp3_len, (size_t)((bytes_before + (int64_t)s.mp3_len) % 4));
-        }
-        const size_t total = segs.back().mp3_off + segs.back().mp3_len;
-        if (!rc && !b->big[0].reserve(total)) rc = fail(MP3S_E_NOMEM, "host memory for %zu bytes of MP3", total);
-        b->mp3 = b->big[0].data();
-        b->scfsi.assign((size_t)n * 8, 0);
         if (!rc) rc = mp3s_dev_download(c, b->mp3, d_mp3, total);
         if (!rc) rc = mp3s_dev_download(c, b->scfsi.data(), d_sc, (size_t)n * 8 * 4);
     }
@@ -437,7 +515,7 @@ static int reencode_group(mp3s_ctx *c, mp3s_multi &m, const std::vector<int> &id
     const double t1 = trace_on() ? now_ms() : 0;
     std::unique_ptr<mp3s_buf> part(new mp3s_buf());
     int passes = 0;
-    rc = encode_batch(c, nullptr, (const int16_t *)d_keep, segs, samplerate, kbps, part.get(), &passes);
+    rc = encode_batch(c, nullptr, (const int16_t *)d_keep, segs, samplerate, kbps, part.get(), &passes, false);
     if (rc) return rc;
     if (trace_on())
         fprintf(stderr, "mp3s:   %zu stream(s), %lld frames: decode %.3f ms, encode %.3f ms (%d rate passes)\n", idx.size(),
@@ -556,7 +634,7 @@ int mp3s_reencode_block(mp3s_ctx *c, const uint8_t *mp3, size_t len, const uint8
     s.n_frames = (int)count; s.hide = bits.data(); s.n_hide = (int)bits.size();
     s.lead = lead; s.first_frame = first; s.last = out->is_last != 0; s.carry_in = carry_in;
     std::unique_ptr<mp3s_buf> part(new mp3s_buf());
-    rc = encode_batch(c, nullptr, (const int16_t *)d_keep + (size_t)halo * 2304, segs, samplerate, kbps, part.get(), nullptr);
+    rc = encode_batch(c, nullptr, (const int16_t *)d_keep + (size_t)halo * 2304, segs, samplerate, kbps, part.get(), nullptr, false);
     if (rc) return rc;
     out->carry_out = s.carry_out; out->carry_used = s.carry_used ? 1 : 0;
     out->file.data = part->mp3 + s.mp3_off; out->file.len = s.mp3_len; out->file.n_frames = (int32_t)count;

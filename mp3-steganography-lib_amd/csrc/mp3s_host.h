@@ -3,6 +3,8 @@
 #include <stddef.h>
 #include <stdint.h>
 
+#include <memory>
+#include <utility>
 #include <vector>
 
 #include "../../include/mp3s.h"
@@ -20,13 +22,33 @@ struct ParsedStream {
     std::vector<int32_t> frame_size;      // [n]
 };
 // byte-level scan only (no scalefactor / Huffman decode): what the device Huffman kernel consumes
+// vectors whose resize() leaves new elements uninitialised: the scan sizes them to their capacity up front and writes
+// every byte it later counts, so zero-filling tens of megabytes first would only touch the pages twice
+template <class T>
+struct NoInitAlloc : std::allocator<T> {
+    template <class U> struct rebind { using other = NoInitAlloc<U>; };
+    template <class U> void construct(U *p) noexcept { ::new (static_cast<void *>(p)) U; }
+    template <class U, class... A> void construct(U *p, A &&...a) { ::new (static_cast<void *>(p)) U(std::forward<A>(a)...); }
+};
 struct ScannedStream {
-    std::vector<mp3s_frame_side> side;    // [n]
-    std::vector<uint8_t> blob;            // main data of all frames, 4-byte aligned, >= 8 zero bytes after each
+    std::vector<mp3s_frame_side, NoInitAlloc<mp3s_frame_side>> side;    // [n]
+    std::vector<uint8_t, NoInitAlloc<uint8_t>> blob;   // main data of all frames, 4-byte aligned, >= 8 zero bytes after each
     bool gpu_ok = true;                   // false: some granule inherits scalefactors from earlier frames
 };
 // scan == nullptr: full parse (is + si); otherwise is/si stay empty and *scan is filled instead
 int parse_stream(const uint8_t *file, size_t len, ParsedStream &out, ScannedStream *scan = nullptr);
+// The same scan writing where the caller says: growable arrays (what parse_stream does with a ScannedStream) or arrays
+// of fixed capacity -- page-locked staging of the asynchronous pipeline, which the copy engine reads directly.  A fixed
+// sink that runs out of room ends the scan with MP3S_E_NOMEM.
+struct ScanSink {
+    uint8_t *blob = nullptr; size_t blob_len = 0, blob_cap = 0;
+    mp3s_frame_side *side = nullptr; size_t n_side = 0, side_cap = 0;
+    bool gpu_ok = true;
+    bool lean = false;                 // the caller wants neither stego bits nor table indices nor frame sizes
+    void *user = nullptr;
+    bool (*grow)(ScanSink *, size_t blob_need, size_t side_need) = nullptr;   // null: fixed capacity
+};
+int parse_stream_sink(const uint8_t *file, size_t len, ParsedStream &out, ScanSink *sink);
 
 // scalefactors + Huffman of ONE frame of a scanned stream (side record + its main data in the blob): the host's answer for
 // a frame the device Huffman kernel flags; exact for gpu_ok streams (no frame inherits anything from another)

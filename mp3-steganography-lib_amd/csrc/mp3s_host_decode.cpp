@@ -277,18 +277,47 @@ int decode_main_data(const HostTables &HT, SideInfo &si, int nch, int sr_idx, co
 
 }  // namespace
 
-int parse_stream(const uint8_t *file, size_t flen_, ParsedStream &out, ScannedStream *scan)
+static bool grow_vectors(ScanSink *k, size_t blob_need, size_t side_need)
+{
+    ScannedStream *sc = static_cast<ScannedStream *>(k->user);
+    if (blob_need > k->blob_cap) { sc->blob.resize(std::max(blob_need, 2 * k->blob_cap)); k->blob = sc->blob.data(); k->blob_cap = sc->blob.size(); }
+    if (side_need > k->side_cap) { sc->side.resize(std::max(side_need, 2 * k->side_cap)); k->side = sc->side.data(); k->side_cap = sc->side.size(); }
+    return true;
+}
+
+int parse_stream(const uint8_t *file, size_t flen, ParsedStream &out, ScannedStream *scan)
+{
+    if (!scan) return parse_stream_sink(file, flen, out, nullptr);
+    // main data is the file minus headers and side info, plus padding: one allocation instead of doubling through 40 MB
+    // (capacity a caller lends is kept)
+    scan->blob.resize(std::max(scan->blob.capacity(), flen + flen / 32 + 64));
+    scan->side.resize(std::max(scan->side.capacity(), flen / 96 + 1));
+    ScanSink k;
+    k.blob = scan->blob.data(); k.blob_cap = scan->blob.size();
+    k.side = scan->side.data(); k.side_cap = scan->side.size();
+    k.user = scan; k.grow = grow_vectors;
+    const int rc = parse_stream_sink(file, flen, out, &k);
+    scan->blob.resize(k.blob_len); scan->side.resize(k.n_side);
+    scan->gpu_ok = k.gpu_ok;
+    return rc;
+}
+
+int parse_stream_sink(const uint8_t *file, size_t flen_, ParsedStream &out, ScanSink *scan)
 {
     std::call_once(g_lut_once, build_luts);
     const HostTables &HT = host_tables();
     const long flen = (long)flen_;
     out = ParsedStream();
     if (scan) {
-        scan->side.clear(); scan->blob.clear(); scan->gpu_ok = true;   // (capacity a caller lends is kept)
-        // main data is the file minus headers and side info, plus padding: one allocation instead of doubling through 40 MB
-        scan->blob.reserve(flen_ + flen_ / 32 + 64);
-        scan->side.reserve(flen_ / 96 + 1);
+        scan->blob_len = 0; scan->n_side = 0; scan->gpu_ok = true;
+        out.hdr.reserve(flen_ / 96 + 1);
+        if (!scan->lean) { out.frame_size.reserve(flen_ / 96 + 1); out.bits.reserve(flen_ / 8 + 16); out.table_select.reserve((flen_ / 96 + 1) * 12); }
     }
+    // blob bytes of the sink: room for `extra` more, or (fixed capacity) give up
+    auto blob_room = [&](size_t extra) -> bool {
+        if (scan->blob_len + extra <= scan->blob_cap) return true;
+        return scan->grow && scan->grow(scan, scan->blob_len + extra, 0);
+    };
     // ID3v2 skip (decoder/ID3_Parser.py:95-131): only `offset` and `is_valid` matter to decoding
     long offset = 0;
     if (flen >= 10 && file[0] == 'I' && file[1] == 'D' && file[2] == '3' && !(file[5] & 0x0f)) {
@@ -374,6 +403,7 @@ int parse_stream(const uint8_t *file, size_t flen_, ParsedStream &out, ScannedSt
                 si.count1table[gr][ch] = sb.get(off, 1); off += 1;
             }
         // ---- stego bits: ch -> gr -> region, zeros skipped, H0 -> 0
+        if (!(scan && scan->lean))
         for (int ch = 0; ch < nch; ch++)
             for (int gr = 0; gr < 2; gr++)
                 for (int r = 0; r < 3; r++) {
@@ -383,16 +413,29 @@ int parse_stream(const uint8_t *file, size_t flen_, ParsedStream &out, ScannedSt
         // ---- main data (bit reservoir); in scan mode it is assembled in the blob directly
         int constant = hd.mode == 3 ? 21 : 36;
         if (hd.crc == 0) constant += 2;
-        std::vector<uint8_t> &md = scan ? scan->blob : main_data;
         size_t md_start = 0;
+        bool full = false;                       // a sink of fixed capacity ran out of room
         if (scan) {
-            while (scan->blob.size() & 3) scan->blob.push_back(0);
-            md_start = scan->blob.size();
+            if (!blob_room(4)) return MP3S_E_NOMEM;
+            while (scan->blob_len & 3) scan->blob[scan->blob_len++] = 0;
+            md_start = scan->blob_len;
         }
+        // Python list slicing data[start:stop] appended to the frame's main data (the blob in scan mode)
+        auto md_append = [&](const uint8_t *data, long n, long start, long stop) {
+            if (!scan) { py_slice_append(main_data, data, n, start, stop); return; }
+            if (start < 0) { start += n; if (start < 0) start = 0; }
+            if (stop < 0) { stop += n; if (stop < 0) stop = 0; }
+            if (start > n) start = n;
+            if (stop > n) stop = n;
+            if (stop <= start || full) return;
+            if (!blob_room((size_t)(stop - start))) { full = true; return; }
+            std::memcpy(scan->blob + scan->blob_len, data + start, (size_t)(stop - start));
+            scan->blob_len += (size_t)(stop - start);
+        };
         bool rebuilt = false;
         if (si.main_data_begin == 0) {
             if (!scan) main_data.clear();
-            py_slice_append(md, buffer, buflen, constant, frame_size);
+            md_append(buffer, buflen, constant, frame_size);
             rebuilt = true;
         } else {
             double bound = 0;
@@ -405,14 +448,14 @@ int parse_stream(const uint8_t *file, size_t flen_, ParsedStream &out, ScannedSt
                     for (int i = 0; i < fr; i++) { part[i] = prev_frame_size[i] - constant; part[fr] -= part[i]; }
                     if (!scan) main_data.clear();
                     long loc = (long)(offset - ptr_offset);
-                    py_slice_append(md, file, flen, loc, loc + (long)part[fr]);
+                    md_append(file, flen, loc, loc + (long)part[fr]);
                     ptr_offset -= (part[fr] + constant);
                     for (int i = fr - 1; i >= 0; i--) {
                         loc = (long)(offset - ptr_offset);
-                        py_slice_append(md, file, flen, loc, loc + (long)part[i]);
+                        md_append(file, flen, loc, loc + (long)part[i]);
                         ptr_offset -= (part[i] + constant);
                     }
-                    py_slice_append(md, buffer, buflen, constant, frame_size);
+                    md_append(buffer, buflen, constant, frame_size);
                     rebuilt = true;
                     break;
                 }
@@ -424,15 +467,18 @@ int parse_stream(const uint8_t *file, size_t flen_, ParsedStream &out, ScannedSt
             // ---- scan mode: record the side info; the main data sits in the blob already
             mp3s_frame_side fs;
             std::memset(&fs, 0, sizeof fs);
-            out.table_select.resize(((size_t)out.n_frames + 1) * 12, 0);
-            if (!rebuilt && !scan->side.empty()) {
-                const mp3s_frame_side &pv = scan->side.back();
-                const std::vector<uint8_t> again(scan->blob.begin() + pv.md_off, scan->blob.begin() + pv.md_off + pv.md_len);
-                scan->blob.insert(scan->blob.end(), again.begin(), again.end());
+            if (!scan->lean) out.table_select.resize(((size_t)out.n_frames + 1) * 12, 0);
+            if (!rebuilt && scan->n_side) {
+                const mp3s_frame_side pv = scan->side[scan->n_side - 1];
+                if (!blob_room(pv.md_len)) return MP3S_E_NOMEM;
+                std::memmove(scan->blob + scan->blob_len, scan->blob + pv.md_off, pv.md_len);   // (the room may have moved the blob)
+                scan->blob_len += pv.md_len;
             }
+            if (full || !blob_room(8)) return MP3S_E_NOMEM;
             fs.md_off = (uint32_t)md_start;
-            fs.md_len = (uint32_t)(scan->blob.size() - md_start);
-            scan->blob.insert(scan->blob.end(), 8, 0);
+            fs.md_len = (uint32_t)(scan->blob_len - md_start);
+            std::memset(scan->blob + scan->blob_len, 0, 8);
+            scan->blob_len += 8;
             fs.nch = (uint8_t)nch; fs.sr_idx = (uint8_t)hd.sr_idx;
             fs.ms_stereo = (hd.mode == 1 && hd.mode_ext0) ? 1 : 0;
             for (int ch = 0; ch < nch; ch++)
@@ -452,8 +498,9 @@ int parse_stream(const uint8_t *file, size_t flen_, ParsedStream &out, ScannedSt
                     // scalefactors that requantisation would read without this frame having written them (D10):
                     // mixed blocks, and scfsi reuse when granule 0 carried short-block scalefactors
                     if (u.window_switching && u.mixed_block_flag) scan->gpu_ok = false;
-                    for (int r = 0; r < 3; r++)
-                        out.table_select[((size_t)out.n_frames * 4 + gr * 2 + ch) * 3 + r] = si.table_select[gr][ch][r];
+                    if (!scan->lean)
+                        for (int r = 0; r < 3; r++)
+                            out.table_select[((size_t)out.n_frames * 4 + gr * 2 + ch) * 3 + r] = si.table_select[gr][ch][r];
                 }
             for (int ch = 0; ch < nch; ch++) {
                 const mp3s_unit_side &g0 = fs.unit[0][ch], &g1 = fs.unit[1][ch];
@@ -462,7 +509,8 @@ int parse_stream(const uint8_t *file, size_t flen_, ParsedStream &out, ScannedSt
                 if (g0_short && !g1_short && (fs.scfsi[ch][0] | fs.scfsi[ch][1] | fs.scfsi[ch][2] | fs.scfsi[ch][3]))
                     scan->gpu_ok = false;
             }
-            scan->side.push_back(fs);
+            if (scan->n_side >= scan->side_cap && !(scan->grow && scan->grow(scan, 0, scan->n_side + 1))) return MP3S_E_NOMEM;
+            scan->side[scan->n_side++] = fs;
         } else {
         // ---- per granule*channel: scalefactors + Huffman
         const size_t f = (size_t)out.n_frames;
@@ -478,7 +526,7 @@ int parse_stream(const uint8_t *file, size_t flen_, ParsedStream &out, ScannedSt
         fh.ms_stereo = (hd.mode == 1 && hd.mode_ext0) ? 1 : 0;
         fh.flags = 0; fh.stream_first = 0;
         out.hdr.push_back(fh);
-        out.frame_size.push_back(frame_size);
+        if (!(scan && scan->lean)) out.frame_size.push_back(frame_size);
         out.n_frames++;
         offset += frame_size;
     }

@@ -86,7 +86,7 @@ int rate_frames(int samplerate, int bitrate_kbps, int nch, int n_frames, mp3s_ra
         const int mean_bits = (int)((double)(bits_per_frame - side_info_len) / 2);
         int mb = mean_bits / nch;                     // resv_max == 0: MP3_Encoder.py:904-912
         if (mb > 4095) mb = 4095;
-        out[f].max_bits = mb; out[f].sr_idx = sri; out[f].hide_end = 0x7fffffff; out[f].reserved = 0;
+        out[f].max_bits = mb; out[f].sr_idx = sri; out[f].hide_end = 0x7fffffff; out[f].stream = 0;
         if (padding) padding[f] = sl.padding;
     }
     return 0;

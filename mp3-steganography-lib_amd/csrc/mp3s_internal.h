@@ -160,7 +160,7 @@ struct mp3s_buf {
     std::vector<int32_t> scfsi;
     std::vector<std::unique_ptr<mp3s_buf>> parts;   // results of the batches of a multi-file call
     // encoder results: MP3 bytes and GrInfo records land in page-locked blocks and are handed out from there
-    PinnedBlock big[2];
+    PinnedBlock big[3];              // MP3 bytes, GrInfo records, the small results (verdict, per-stream chain ends)
     uint8_t *mp3 = nullptr;
     mp3s_gr_out *gr_out = nullptr;
 };
@@ -196,6 +196,8 @@ int max_part2_3(const mp3s_frame_side *side, long n);
 void cut_window(ParsedStream &p, ScannedStream &sc, long first, long count);
 // host front end of stream i of m (scan; full host parse where the device cannot decode), cut to the stream's window
 int front_end(mp3s_multi &m, int i);
+int decode_transform_chunk(mp3s_ctx *c, const int16_t *d_is, const mp3s_granule_si *d_si, const mp3s_frame_hdr *d_hdr, long first, int cnt,
+                           int nch, int halo, int out_format, void *d_pcm);
 // decode the streams `idx` of m (one channel count) as one batch; d_keep: int16 PCM stays on the device there
 int decode_group(mp3s_ctx *c, mp3s_multi &m, const std::vector<int> &idx, int nch, int out_format, void *d_keep = nullptr);
 
@@ -222,5 +224,33 @@ struct EncSeg {             // one stream of an encode batch: frames back to bac
     mp3s_carry carry_out = {};
     bool carry_used = false;         // the block's bytes depend on carry_in
 };
+// The host-made inputs of an encode batch travel as ONE block (one copy):
+//   [frame headers (n_all) | rate frames (n) | assumed cursors (units) | message bits | chain segments | frame offsets (n+1) | padding (n)]
+struct EncLayout {
+    int n = 0, n_all = 0, lead = 0, units = 0, n_hide = 0, n_segs = 0;
+    int sri = 0, bri = 0, whole = 0, samplerate = 0, kbps = 0;
+    size_t o_rf = 0, o_cur = 0, o_hide = 0, o_segs = 0, o_off = 0, o_pad = 0, bytes = 0;   // (headers at offset 0)
+    size_t mp3_bytes = 0;          // all frames of the batch
+    int64_t bytes_before = 0;      // size of the frames in front of a block (E14: the tail cut depends on it)
+};
+// small results of a batch, in one block: verdict[2] (mp3s_chain_resolve_dev), pack status, Huffman status, then seg_out[n_segs]
+constexpr size_t kSmallHead = 16;
+inline size_t small_bytes(int n_segs) { return kSmallHead + (size_t)n_segs * sizeof(mp3s_chain_seg_out); }
+// checks the streams and fills first / hide_base of each
+int enc_layout(std::vector<EncSeg> &segs, int samplerate, int bitrate_kbps, EncLayout &L);
+// writes the block (L.bytes at dst); *mp3_off_len: per stream {offset, length} of its bytes in the batch's output
+int enc_fill(std::vector<EncSeg> &segs, EncLayout &L, uint8_t *dst);
+struct EncDev {
+    const int16_t *d_pcm = nullptr;      // [n_all][1152][2]
+    const uint8_t *d_in = nullptr;       // the block above
+    int32_t *d_mdct_all = nullptr;       // [n_all][2][2][576]
+    int16_t *d_ix = nullptr; mp3s_gr_out *d_out = nullptr; int32_t *d_en = nullptr;
+    void *d_agg = nullptr;               // chain_agg_bytes(n)
+    uint8_t *d_mp3 = nullptr; int32_t *d_sc = nullptr;
+    int32_t *d_small = nullptr;          // small_bytes(n_segs)
+};
+// transforms -> rate loop on the guessed cursors -> chain check -> bit packing, all on c->stream, nothing waited for.
+// The packed bytes are final iff verdict[0] == 0 and verdict[1] == 0 (d_small[0], d_small[1]).
+int enc_issue(mp3s_ctx *c, const EncLayout &L, const EncDev &d);
 int encode_batch(mp3s_ctx *c, const int16_t *pcm, const int16_t *pcm_dev, std::vector<EncSeg> &segs, int samplerate, int bitrate_kbps,
-                 mp3s_buf *b, int *passes_out);
+                 mp3s_buf *b, int *passes_out, bool want_gr = true);

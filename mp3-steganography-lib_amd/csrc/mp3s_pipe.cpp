@@ -1,0 +1,420 @@
+// C-ABI of the library (include/mp3s.h), part 4: the asynchronous host-fed pipeline.
+//
+// The reference runs one file at a time through two serial frame loops (decoder/MP3_Parser.py:68-80,
+// encoder/MP3_Encoder.py:607-609, glued by steganography.py:153-159).  Here a job (one file, or a list of files that
+// form one device batch) passes through four stages that overlap with those of the jobs around it:
+//
+//   scan      a host worker thread walks the frames (sync, header, side info, reservoir) and writes main data and side
+//             records straight into the job slot's page-locked staging -- no intermediate vectors, no second copy
+//   upload    hipMemcpyAsync on the copy-up stream: staging -> the slot's device inputs
+//   compute   the context's stream: Huffman decode -> decode transforms -> encode transforms -> rate loop -> chain check ->
+//             bit packing; the scratch between the kernels is shared by all slots (one stream = one job at a time)
+//   download  hipMemcpyAsync on the copy-down stream: MP3 bytes + the 16-byte verdict -> a page-locked result block
+//
+// Events order the three streams; the host waits for nothing until the caller collects a result.  A job whose streams
+// the device cannot take alone (mono, mixed blocks, a repeated last frame, unsupported rates, staging too small), or
+// whose verdict says the cursor guess failed or the Huffman data is damaged, is redone by the synchronous path
+// (mp3s_hide_messages) -- same bytes, by construction of that path; the fast path is an optimisation, never a
+// different answer.
+#include <condition_variable>
+#include <deque>
+
+#include "mp3s_internal.h"
+
+namespace {
+
+constexpr int kMaxFastFiles = 1024;
+
+struct Slot {
+    uint8_t *h_stage = nullptr;          // page-locked: [blob | side records | input block]
+    uint8_t *d_stage = nullptr;          // the same layout on the device
+    size_t blob_cap = 0, side_cap = 0 /* frames */, in_cap = 0, o_side = 0, o_in = 0, stage_bytes = 0;
+    uint8_t *d_mp3 = nullptr; size_t mp3_cap = 0;
+    int32_t *d_small = nullptr;
+    hipEvent_t e_start = nullptr, e_up = nullptr, e_comp = nullptr, e_down = nullptr;
+    bool busy = false;
+};
+
+struct Job {
+    int64_t ticket = 0;
+    int slot = -1;
+    std::vector<std::pair<const uint8_t *, size_t>> files, msgs;   // borrowed until the job is collected
+    bool clear_all = false;
+    enum State { QUEUED, ISSUED, SLOW_DONE } state = QUEUED;
+    // fast path
+    std::vector<std::vector<uint8_t>> bits;
+    std::vector<EncSeg> segs;
+    EncLayout L;
+    int rate = 0, kbps = 0;
+    std::unique_ptr<mp3s_buf> res;
+    // synchronous path
+    mp3s_buf *slow_owner = nullptr;
+    std::vector<mp3s_file> slow_out;
+    std::vector<int32_t> slow_st;
+    int slow_rc = 0;
+    std::string slow_err;
+    double scan_ms = 0, issue_ms = 0;
+};
+
+}  // namespace
+
+struct mp3s_pipe {
+    mp3s_ctx *c = nullptr;
+    int depth = 0;
+    std::vector<Slot> slots;
+    hipStream_t s_up = nullptr, s_down = nullptr;
+    std::mutex mu;                       // queue, job states, slots
+    std::condition_variable cv_work, cv_done;
+    std::mutex mu_issue;                 // everything that touches the context (its stream, pool, profiler)
+    std::deque<std::unique_ptr<Job>> inflight;   // ticket order; front = next to collect
+    std::deque<Job *> todo;
+    std::vector<std::thread> workers;
+    bool stop = false;
+    int64_t next_ticket = 0;
+    mp3s_pipe_stats st = {};
+};
+
+namespace {
+
+int reencode_params(const ParsedStream &p, int *kbps_out)
+{
+    const int kbps = p.bit_rate / 1000;
+    int sri, bri, whole;
+    if (p.sampling_rate != 32000 && p.sampling_rate != 44100 && p.sampling_rate != 48000) return 1;
+    if (kbps <= 0 || stream_params(p.sampling_rate, kbps, &sri, &bri, &whole)) return 1;
+    if (p.nch != 2 || p.n_frames <= 0 || p.dup_last_frame) return 1;
+    *kbps_out = kbps;
+    return 0;
+}
+
+// scan the job's files into the slot's staging and lay out the encoder's inputs; false = this job takes the synchronous path
+bool prepare_fast(mp3s_pipe *P, Job &j, Slot &s, size_t *blob_len, int *max_p23)
+{
+    const int nf = (int)j.files.size();
+    if (nf > kMaxFastFiles) return false;
+    mp3s_frame_side *side = (mp3s_frame_side *)(s.h_stage + s.o_side);
+    uint8_t *in = s.h_stage + s.o_in;
+    size_t base = 0;
+    long n = 0;
+    j.segs.assign((size_t)nf, EncSeg());
+    j.bits.assign((size_t)nf, {});
+    std::vector<mp3s_frame_hdr> dechdr;
+    ParsedStream p;
+    for (int i = 0; i < nf; i++) {
+        if (!j.files[i].first) return false;
+        ScanSink k;
+        k.blob = s.h_stage + base; k.blob_cap = s.blob_cap - base;
+        k.side = side + n; k.side_cap = s.side_cap - (size_t)n;
+        k.lean = true;
+        if (parse_stream_sink(j.files[i].first, j.files[i].second, p, &k) || !k.gpu_ok) return false;
+        int kbps = 0;
+        if (reencode_params(p, &kbps)) return false;
+        if (i == 0) { j.rate = p.sampling_rate; j.kbps = kbps; }
+        else if (p.sampling_rate != j.rate || kbps != j.kbps) return false;   // more than one device batch
+        for (int f = 0; f < p.n_frames; f++) {
+            side[n + f].md_off += (uint32_t)base;
+            mp3s_frame_hdr h = p.hdr[(size_t)f];
+            h.stream_first = (uint32_t)n;
+            dechdr.push_back(h);
+        }
+        *max_p23 = std::max(*max_p23, max_part2_3(side + n, p.n_frames));
+        j.segs[i].n_frames = p.n_frames;
+        if (!j.clear_all && j.msgs[i].first) {
+            message_frame(j.msgs[i].first, j.msgs[i].second, j.bits[i]);
+            if (j.bits[i].size() > 0x7fffffff) return false;
+            j.segs[i].hide = j.bits[i].data(); j.segs[i].n_hide = (int)j.bits[i].size();
+        }
+        n += p.n_frames;
+        base = (base + k.blob_len + 3) & ~(size_t)3;
+        if (base + 16 > s.blob_cap) return false;
+    }
+    *blob_len = base;
+    if (enc_layout(j.segs, j.rate, j.kbps, j.L)) return false;
+    const size_t o_dechdr = (j.L.bytes + 15) & ~(size_t)15;
+    if (o_dechdr + (size_t)n * sizeof(mp3s_frame_hdr) > s.in_cap) return false;
+    if (enc_fill(j.segs, j.L, in)) return false;
+    if (j.L.mp3_bytes + 16 > s.mp3_cap) return false;
+    std::memcpy(in + o_dechdr, dechdr.data(), (size_t)n * sizeof(mp3s_frame_hdr));
+    j.res.reset(new mp3s_buf());
+    if (!j.res->big[0].reserve(j.L.mp3_bytes) || !j.res->big[2].reserve(small_bytes(j.L.n_segs))) return false;
+    j.res->mp3 = j.res->big[0].data();
+    return true;
+}
+
+// everything a fast job does on the device, queued on the three streams; nothing is waited for
+int issue_fast(mp3s_pipe *P, Job &j, Slot &s, size_t blob_len, int max_p23)
+{
+    mp3s_ctx *c = P->c;
+    const EncLayout &L = j.L;
+    const int n = L.n, units = L.units;
+    const size_t o_dechdr = (L.bytes + 15) & ~(size_t)15, in_bytes = o_dechdr + (size_t)n * sizeof(mp3s_frame_hdr);
+    void *d_is = c->grab(0, (size_t)n * 2304 * 2), *d_si = c->grab(1, (size_t)n * 4 * sizeof(mp3s_granule_si)),
+         *d_keep = c->grab(7, (size_t)n * 2304 * 2), *d_mdct = c->grab(10, (size_t)n * 2304 * 4), *d_ix = c->grab(12, (size_t)n * 2304 * 2),
+         *d_out = c->grab(13, (size_t)units * sizeof(mp3s_gr_out)), *d_en = c->grab(14, (size_t)units * 22 * 4),
+         *d_agg = c->grab(15, chain_agg_bytes(n)), *d_sc = c->grab(17, (size_t)n * 8 * 4);
+    if (!d_is || !d_si || !d_keep || !d_mdct || !d_ix || !d_out || !d_en || !d_agg || !d_sc)
+        return fail(MP3S_E_NOMEM, "hipMalloc failed for a %d-frame job", n);
+    uint8_t *d_blob = s.d_stage, *d_side = s.d_stage + s.o_side, *d_in = s.d_stage + s.o_in;
+    HIPCHK(hipEventRecord(s.e_start, P->s_up));
+    HIPCHK(hipMemcpyAsync(d_blob, s.h_stage, blob_len, hipMemcpyHostToDevice, P->s_up));
+    HIPCHK(hipMemcpyAsync(d_side, s.h_stage + s.o_side, (size_t)n * sizeof(mp3s_frame_side), hipMemcpyHostToDevice, P->s_up));
+    HIPCHK(hipMemcpyAsync(d_in, s.h_stage + s.o_in, in_bytes, hipMemcpyHostToDevice, P->s_up));
+    HIPCHK(hipEventRecord(s.e_up, P->s_up));
+    HIPCHK(hipStreamWaitEvent(c->stream, s.e_up, 0));
+    const int e = launch_huffman(c->stream, d_blob, (const mp3s_frame_side *)d_side, n, 2, max_p23, (int16_t *)d_is, (mp3s_granule_si *)d_si,
+                                 s.d_small + 3, &c->prof, false);
+    if (e) return fail(MP3S_E_HIP, "huffman launch: %s", hipGetErrorString((hipError_t)e));
+    const mp3s_frame_hdr *d_dechdr = (const mp3s_frame_hdr *)(d_in + o_dechdr);
+    const mp3s_frame_hdr *h_dechdr = (const mp3s_frame_hdr *)(s.h_stage + s.o_in + o_dechdr);
+    for (long start = 0; start < n; start += kDecodeChunk) {
+        const int halo = (start && h_dechdr[start].stream_first < (uint32_t)start) ? 1 : 0;
+        const int cnt = (int)std::min<long>(kDecodeChunk, n - start) + halo;
+        const int rc = decode_transform_chunk(c, (const int16_t *)d_is, (const mp3s_granule_si *)d_si, d_dechdr, start - halo, cnt, 2, halo,
+                                              MP3S_PCM_I16, (int16_t *)d_keep + (size_t)start * 2304);
+        if (rc) return rc;
+    }
+    EncDev dev;
+    dev.d_pcm = (const int16_t *)d_keep; dev.d_in = d_in; dev.d_mdct_all = (int32_t *)d_mdct; dev.d_ix = (int16_t *)d_ix;
+    dev.d_out = (mp3s_gr_out *)d_out; dev.d_en = (int32_t *)d_en; dev.d_agg = d_agg; dev.d_mp3 = s.d_mp3; dev.d_sc = (int32_t *)d_sc;
+    dev.d_small = s.d_small;
+    const int rc = enc_issue(c, L, dev);
+    if (rc) return rc;
+    HIPCHK(hipEventRecord(s.e_comp, c->stream));
+    HIPCHK(hipStreamWaitEvent(P->s_down, s.e_comp, 0));
+    const size_t total = j.segs.back().mp3_off + j.segs.back().mp3_len;
+    HIPCHK(hipMemcpyAsync(j.res->big[2].data(), s.d_small, small_bytes(L.n_segs), hipMemcpyDeviceToHost, P->s_down));
+    if (total) HIPCHK(hipMemcpyAsync(j.res->mp3, s.d_mp3, total, hipMemcpyDeviceToHost, P->s_down));
+    HIPCHK(hipEventRecord(s.e_down, P->s_down));
+    return MP3S_OK;
+}
+
+void run_slow(mp3s_pipe *P, Job &j)   // mu_issue held
+{
+    const int nf = (int)j.files.size();
+    std::vector<const uint8_t *> fp(nf), mp(nf);
+    std::vector<size_t> fl(nf), ml(nf);
+    for (int i = 0; i < nf; i++) {
+        fp[i] = j.files[i].first; fl[i] = j.files[i].second;
+        mp[i] = j.clear_all ? nullptr : j.msgs[i].first; ml[i] = j.clear_all ? 0 : j.msgs[i].second;
+    }
+    j.slow_out.assign((size_t)nf, mp3s_file());
+    j.slow_st.assign((size_t)nf, 0);
+    j.res.reset();
+    j.slow_rc = mp3s_hide_messages(P->c, fp.data(), fl.data(), nf, j.clear_all ? nullptr : mp.data(), ml.data(), &j.slow_owner, j.slow_out.data(),
+                                   j.slow_st.data());
+    j.slow_err = mp3s_last_error();
+}
+
+void worker(mp3s_pipe *P)
+{
+    (void)hipSetDevice(P->c->device);
+    for (;;) {
+        Job *j = nullptr;
+        {
+            std::unique_lock<std::mutex> g(P->mu);
+            P->cv_work.wait(g, [&] { return P->stop || !P->todo.empty(); });
+            if (P->todo.empty()) return;       // stop
+            j = P->todo.front(); P->todo.pop_front();
+        }
+        Slot &s = P->slots[(size_t)j->slot];
+        const double t0 = now_ms();
+        size_t blob_len = 0;
+        int max_p23 = 0;
+        bool fast = prepare_fast(P, *j, s, &blob_len, &max_p23);
+        const double t1 = now_ms();
+        Job::State st;
+        {
+            std::lock_guard<std::mutex> gi(P->mu_issue);
+            if (fast && issue_fast(P, *j, s, blob_len, max_p23) != MP3S_OK) {
+                (void)hipStreamSynchronize(P->s_up); (void)hipStreamSynchronize(P->c->stream); (void)hipStreamSynchronize(P->s_down);
+                fast = false;
+            }
+            if (!fast) run_slow(P, *j);
+            st = fast ? Job::ISSUED : Job::SLOW_DONE;
+        }
+        const double t2 = now_ms();
+        {
+            std::lock_guard<std::mutex> g(P->mu);
+            j->scan_ms = t1 - t0; j->issue_ms = t2 - t1;
+            j->state = st;
+            P->st.scan_ms += t1 - t0; P->st.issue_ms += t2 - t1;
+        }
+        P->cv_done.notify_all();
+    }
+}
+
+void free_slot(Slot &s)
+{
+    if (s.h_stage) (void)hipHostFree(s.h_stage);
+    if (s.d_stage) (void)hipFree(s.d_stage);
+    if (s.d_mp3) (void)hipFree(s.d_mp3);
+    if (s.d_small) (void)hipFree(s.d_small);
+    for (hipEvent_t e : {s.e_start, s.e_up, s.e_comp, s.e_down}) if (e) (void)hipEventDestroy(e);
+    s = Slot();
+}
+
+}  // namespace
+
+extern "C" {
+
+int mp3s_pipe_create(mp3s_ctx *c, int depth, size_t max_job_bytes, int scan_threads, mp3s_pipe **out)
+{
+    if (!c || !out || depth < 1 || depth > 64 || scan_threads < 1 || scan_threads > 64 || max_job_bytes < 4096)
+        return fail(MP3S_E_ARG, "bad argument (1 <= depth, scan_threads <= 64; max_job_bytes >= 4096)");
+    *out = nullptr;
+    HIPCHK(hipSetDevice(c->device));
+    std::unique_ptr<mp3s_pipe> P(new mp3s_pipe());
+    P->c = c; P->depth = depth;
+    auto destroy = [&](int code, const char *what) {
+        for (auto &s : P->slots) free_slot(s);
+        if (P->s_up) (void)hipStreamDestroy(P->s_up);
+        if (P->s_down) (void)hipStreamDestroy(P->s_down);
+        return fail(code, "%s", what);
+    };
+    if (hipStreamCreateWithFlags(&P->s_up, hipStreamNonBlocking) != hipSuccess ||
+        hipStreamCreateWithFlags(&P->s_down, hipStreamNonBlocking) != hipSuccess)
+        return destroy(MP3S_E_HIP, "stream creation failed");
+    P->slots.resize((size_t)depth);
+    for (auto &s : P->slots) {
+        // main data: the file minus headers plus alignment and 8 zero bytes per frame; frames: 96 bytes is the smallest
+        // Layer III frame (32 kbit/s at 48 kHz); anything denser (false syncs) overflows the sink and takes the other path
+        s.blob_cap = (max_job_bytes + max_job_bytes / 8 + 4096 + 15) & ~(size_t)15;
+        s.side_cap = max_job_bytes / 96 + 16;
+        s.in_cap = (s.side_cap * 64 + max_job_bytes / 4 + (size_t)kMaxFastFiles * sizeof(mp3s_chain_seg) + 4096 + 15) & ~(size_t)15;
+        s.o_side = s.blob_cap;
+        s.o_in = (s.o_side + s.side_cap * sizeof(mp3s_frame_side) + 15) & ~(size_t)15;
+        s.stage_bytes = s.o_in + s.in_cap;
+        s.mp3_cap = max_job_bytes + s.side_cap + 4096;
+        if (hipHostMalloc((void **)&s.h_stage, s.stage_bytes, hipHostMallocDefault) != hipSuccess || hipMalloc((void **)&s.d_stage, s.stage_bytes) != hipSuccess ||
+            hipMalloc((void **)&s.d_mp3, s.mp3_cap) != hipSuccess || hipMalloc((void **)&s.d_small, small_bytes(kMaxFastFiles)) != hipSuccess ||
+            hipEventCreate(&s.e_start) != hipSuccess || hipEventCreate(&s.e_up) != hipSuccess || hipEventCreate(&s.e_comp) != hipSuccess ||
+            hipEventCreate(&s.e_down) != hipSuccess)
+            return destroy(MP3S_E_NOMEM, "slot allocation failed");
+    }
+    for (int t = 0; t < scan_threads; t++) P->workers.emplace_back(worker, P.get());
+    *out = P.release();
+    return MP3S_OK;
+}
+
+void mp3s_pipe_destroy(mp3s_pipe *P)
+{
+    if (!P) return;
+    {
+        std::lock_guard<std::mutex> g(P->mu);
+        P->stop = true;
+        P->todo.clear();
+    }
+    P->cv_work.notify_all();
+    for (auto &t : P->workers) t.join();
+    (void)hipSetDevice(P->c->device);
+    (void)hipStreamSynchronize(P->s_up); (void)hipStreamSynchronize(P->c->stream); (void)hipStreamSynchronize(P->s_down);
+    for (auto &j : P->inflight) if (j->slow_owner) mp3s_buf_free(j->slow_owner);
+    for (auto &s : P->slots) free_slot(s);
+    (void)hipStreamDestroy(P->s_up); (void)hipStreamDestroy(P->s_down);
+    delete P;
+}
+
+int mp3s_pipe_submit(mp3s_pipe *P, const uint8_t *const *mp3s, const size_t *lens, int n_files, const uint8_t *const *msgs,
+                     const size_t *msg_lens, int64_t *ticket)
+{
+    if (!P || !mp3s || !lens || n_files <= 0 || (msgs && !msg_lens)) return fail(MP3S_E_ARG, "bad argument");
+    std::unique_ptr<Job> j(new Job());
+    j->files.resize((size_t)n_files); j->msgs.assign((size_t)n_files, {nullptr, 0});
+    j->clear_all = msgs == nullptr;
+    for (int i = 0; i < n_files; i++) {
+        j->files[i] = {mp3s[i], lens[i]};
+        if (msgs) {
+            if (!msgs[i] && msg_lens[i]) return fail(MP3S_E_ARG, "file %d: null message of non-zero length", i);
+            j->msgs[i] = {msgs[i], msg_lens[i]};
+        }
+    }
+    {
+        std::lock_guard<std::mutex> g(P->mu);
+        int slot = -1;
+        for (int k = 0; k < P->depth; k++) if (!P->slots[(size_t)k].busy) { slot = k; break; }
+        if (slot < 0) return fail(MP3S_E_BUSY, "all %d slots are taken: collect a result first", P->depth);
+        P->slots[(size_t)slot].busy = true;
+        j->slot = slot; j->ticket = P->next_ticket++;
+        if (ticket) *ticket = j->ticket;
+        P->todo.push_back(j.get());
+        P->inflight.push_back(std::move(j));
+        P->st.submitted++;
+    }
+    P->cv_work.notify_one();
+    return MP3S_OK;
+}
+
+int mp3s_pipe_collect(mp3s_pipe *P, int64_t *ticket, mp3s_buf **owner, mp3s_file *out, int32_t *status, int max_files, int *n_files)
+{
+    if (!P || !owner || !out || !status) return fail(MP3S_E_ARG, "null pointer");
+    Job *j = nullptr;
+    {
+        std::unique_lock<std::mutex> g(P->mu);
+        if (P->inflight.empty()) return fail(MP3S_E_BUSY, "nothing in flight");
+        j = P->inflight.front().get();
+        if ((int)j->files.size() > max_files) return fail(MP3S_E_ARG, "the next job has %zu files, room for %d", j->files.size(), max_files);
+        P->cv_done.wait(g, [&] { return j->state != Job::QUEUED; });
+    }
+    Slot &s = P->slots[(size_t)j->slot];
+    const int nf = (int)j->files.size();
+    int rc = MP3S_OK;
+    bool fast_ok = false;
+    if (j->state == Job::ISSUED) {
+        (void)hipSetDevice(P->c->device);
+        if (hipEventSynchronize(s.e_down) != hipSuccess) rc = fail(MP3S_E_HIP, "waiting for the job's results failed");
+        else {
+            const int32_t *small = (const int32_t *)j->res->big[2].data();
+            fast_ok = small[0] == 0 && small[1] == 0 && small[2] == 0 && small[3] == 0;
+            float ms = 0;
+            if (hipEventElapsedTime(&ms, s.e_start, s.e_down) == hipSuccess) P->st.last_device_span_ms = ms;
+            if (!fast_ok) {
+                // the cursor guess failed (long message), or damaged Huffman data: the synchronous path decides
+                std::lock_guard<std::mutex> gi(P->mu_issue);
+                run_slow(P, *j);
+            }
+        }
+    }
+    if (!rc) {
+        if (fast_ok) {
+            const mp3s_chain_seg_out *so = (const mp3s_chain_seg_out *)(j->res->big[2].data() + kSmallHead);
+            for (int i = 0; i < nf; i++) {
+                const EncSeg &sg = j->segs[(size_t)i];
+                std::memset(&out[i], 0, sizeof out[i]);
+                out[i].data = j->res->mp3 + sg.mp3_off; out[i].len = sg.mp3_len;
+                out[i].kbps = j->kbps; out[i].sampling_rate = j->rate; out[i].channels = 2; out[i].n_frames = sg.n_frames;
+                out[i].hide_offset = so[i].cursor - sg.hide_base;
+                out[i].too_long = out[i].hide_offset < (int64_t)sg.n_hide - 1 ? 1 : 0;
+                status[i] = MP3S_OK;
+            }
+            *owner = j->res.release();
+        } else {
+            rc = j->slow_rc;
+            if (rc) fail(rc, "%s", j->slow_err.c_str());
+            for (int i = 0; i < nf; i++) { out[i] = j->slow_out[(size_t)i]; status[i] = j->slow_st[(size_t)i]; }
+            if (!rc) {
+                for (int i = 0; i < nf; i++) if (status[i]) { fail(status[i], "%s", j->slow_err.c_str()); break; }
+                *owner = j->slow_owner; j->slow_owner = nullptr;
+            }
+        }
+    }
+    if (ticket) *ticket = j->ticket;
+    if (n_files) *n_files = nf;
+    {
+        std::lock_guard<std::mutex> g(P->mu);
+        P->st.collected++;
+        if (fast_ok) P->st.fast++; else P->st.slow++;
+        s.busy = false;
+        P->inflight.pop_front();
+    }
+    return rc;
+}
+
+int mp3s_pipe_get_stats(mp3s_pipe *P, mp3s_pipe_stats *out)
+{
+    if (!P || !out) return fail(MP3S_E_ARG, "null pointer");
+    std::lock_guard<std::mutex> g(P->mu);
+    *out = P->st;
+    return MP3S_OK;
+}
+
+}  // extern "C"

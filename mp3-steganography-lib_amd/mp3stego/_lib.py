@@ -13,7 +13,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libmp3s_hip.so")
 
 MP3S_PCM_I16, MP3S_PCM_F32, MP3S_PCM_F64 = 0, 1, 2
-E_NO_DEVICE, E_HIP, E_ARG, E_MALFORMED, E_UNSUPPORTED, E_STEP_RANGE, E_NOMEM, E_EXIT = -1, -2, -3, -4, -5, -6, -7, -8
+E_NO_DEVICE, E_HIP, E_ARG, E_MALFORMED, E_UNSUPPORTED, E_STEP_RANGE, E_NOMEM, E_EXIT, E_BUSY = -1, -2, -3, -4, -5, -6, -7, -8, -9
 RF_ACTIVE, RF_USED_ADDR_IN, RF_STEP_RANGE, RF_LOG_GUARD = 1, 2, 4, 8
 
 
@@ -35,7 +35,7 @@ GRANULE_SI_DTYPE = np.dtype([("global_gain", "u1"), ("scalefac_scale", "u1"), ("
                              ("scale_fac_l", "u1", (22,)), ("scale_fac_s", "u1", (3, 13)), ("pad", "u1", (3,))])
 FRAME_HDR_DTYPE = np.dtype([("sr_idx", "u1"), ("nch", "u1"), ("ms_stereo", "u1"), ("flags", "u1"),
                             ("stream_first", "<u4")])
-RATE_FRAME_DTYPE = np.dtype([("max_bits", "<i4"), ("sr_idx", "<i4"), ("hide_end", "<i4"), ("reserved", "<i4")])
+RATE_FRAME_DTYPE = np.dtype([("max_bits", "<i4"), ("sr_idx", "<i4"), ("hide_end", "<i4"), ("stream", "<i4")])
 UNIT_SIDE_DTYPE = np.dtype([("part2_3_length", "<u2"), ("big_values", "<u2"), ("global_gain", "u1"),
                             ("scalefac_compress", "u1"), ("window_switching", "u1"), ("block_type", "u1"),
                             ("mixed_block_flag", "u1"), ("table_select", "u1", (3,)), ("region0_count", "u1"),
@@ -51,6 +51,10 @@ GR_OUT_DTYPE = np.dtype([("part2_3_length", "<i4"), ("big_values", "<i4"), ("cou
                          ("n_tables", "<i4"), ("flags", "<i4"), ("reserved0", "<i4"), ("xrmax", "<i4"),
                          ("reserved", "<i4")])
 assert GRANULE_SI_DTYPE.itemsize == 72 and FRAME_HDR_DTYPE.itemsize == 8 and GR_OUT_DTYPE.itemsize == 72
+CHAIN_SEG_DTYPE = np.dtype([("first_frame", "<i4"), ("n_frames", "<i4"), ("hide_base", "<i4"), ("hide_begin", "<i4"),
+                            ("hide_end", "<i4"), ("reserved", "<i4"), ("chain_in", "<i4", (4, 4))])
+CHAIN_SEG_OUT_DTYPE = np.dtype([("cursor", "<i8"), ("chain", "<i4", (4, 4)), ("carry_used", "<i4"), ("reserved", "<i4")])
+assert CHAIN_SEG_DTYPE.itemsize == 88 and CHAIN_SEG_OUT_DTYPE.itemsize == 80
 
 
 class Parsed(C.Structure):
@@ -105,6 +109,11 @@ class File(C.Structure):
                 ("hide_offset", C.c_int64), ("bits", C.c_void_p)]
 
 
+class PipeStats(C.Structure):
+    _fields_ = [("submitted", C.c_int64), ("collected", C.c_int64), ("fast", C.c_int64), ("slow", C.c_int64),
+                ("scan_ms", C.c_double), ("issue_ms", C.c_double), ("last_device_span_ms", C.c_double)]
+
+
 class Block(C.Structure):
     _fields_ = [("total_frames", C.c_int64), ("first_frame", C.c_int64), ("n_frames", C.c_int64), ("is_last", C.c_int32),
                 ("carry_used", C.c_int32), ("carry_out", Carry), ("file", File)]
@@ -113,11 +122,12 @@ class Block(C.Structure):
 # every symbol include/mp3s.h declares (tests/test_abi.py checks the library exports all of them)
 SYMBOLS = ["mp3s_ctx_create", "mp3s_ctx_destroy", "mp3s_ctx_wait", "mp3s_last_error", "mp3s_version", "mp3s_device_name", "mp3s_sync", "mp3s_debug_tables", "mp3s_debug_scfsi_energies", "mp3s_debug_parse_scanned_frame",
            "mp3s_dev_alloc", "mp3s_dev_free", "mp3s_dev_upload", "mp3s_dev_download", "mp3s_dev_memset",
-           "mp3s_timer_start", "mp3s_timer_stop", "mp3s_profile_enable", "mp3s_profile_select", "mp3s_profile_collect", "mp3s_decode_transform_dev", "mp3s_decode_transform",
-           "mp3s_encode_transform_dev", "mp3s_encode_transform", "mp3s_rate_loop_dev", "mp3s_huffman_decode_dev", "mp3s_pack_frames_dev", "mp3s_scan_stream", "mp3s_buf_free",
+           "mp3s_timer_start", "mp3s_timer_stop", "mp3s_bench_copy", "mp3s_profile_enable", "mp3s_profile_select", "mp3s_profile_collect", "mp3s_decode_transform_dev", "mp3s_decode_transform",
+           "mp3s_encode_transform_dev", "mp3s_encode_transform", "mp3s_rate_loop_dev", "mp3s_chain_resolve_dev", "mp3s_huffman_decode_dev", "mp3s_pack_frames_dev", "mp3s_scan_stream", "mp3s_buf_free",
            "mp3s_parse_stream", "mp3s_format_stream", "mp3s_rate_frames", "mp3s_decode_stream", "mp3s_decode_streams", "mp3s_decode_block", "mp3s_encode_pcm", "mp3s_encode_block",
            "mp3s_wav_parse", "mp3s_wav_header", "mp3s_message_frame", "mp3s_message_reveal", "mp3s_decode_file", "mp3s_encode_file",
-           "mp3s_hide_message", "mp3s_clear_file", "mp3s_hide_messages", "mp3s_reencode_block", "mp3s_reveal_message"]
+           "mp3s_hide_message", "mp3s_clear_file", "mp3s_hide_messages", "mp3s_reencode_block", "mp3s_reveal_message",
+           "mp3s_pipe_create", "mp3s_pipe_destroy", "mp3s_pipe_submit", "mp3s_pipe_collect", "mp3s_pipe_get_stats"]
 
 _lib = None
 _lock = threading.Lock()
@@ -155,6 +165,7 @@ def lib():
         L.mp3s_dev_memset.argtypes = [vp, vp, i32, sz]
         L.mp3s_timer_start.argtypes = [vp]
         L.mp3s_timer_stop.argtypes = [vp, C.POINTER(C.c_float)]
+        L.mp3s_bench_copy.argtypes = [vp, sz, i32, C.POINTER(C.c_double)]
         L.mp3s_profile_enable.argtypes = [vp, i32]
         L.mp3s_profile_select.argtypes = [vp, C.c_uint]
         L.mp3s_profile_collect.argtypes = [vp, vp, vp, i32]
@@ -163,6 +174,7 @@ def lib():
         L.mp3s_encode_transform_dev.argtypes = [vp, vp, vp, i32, vp]
         L.mp3s_encode_transform.argtypes = [vp, vp, vp, i32, vp]
         L.mp3s_rate_loop_dev.argtypes = [vp, vp, vp, i32, vp, i32, vp, vp, vp, i32, vp, vp, vp]
+        L.mp3s_chain_resolve_dev.argtypes = [vp, vp, vp, i32, vp, i32, vp, vp, vp, vp]
         L.mp3s_huffman_decode_dev.argtypes = [vp, vp, vp, i32, i32, i32, vp, vp, vp]
         L.mp3s_pack_frames_dev.argtypes = [vp, vp, vp, vp, i32, i32, i32, vp, vp, vp, vp, vp]
         L.mp3s_scan_stream.argtypes = [vp, sz, pvp, C.POINTER(Scanned)]
@@ -190,6 +202,12 @@ def lib():
         L.mp3s_reencode_block.argtypes = [vp, vp, sz, vp, sz, i32, i32, C.POINTER(Carry), pvp, C.POINTER(Block)]
         L.mp3s_hide_messages.argtypes = [vp, vp, vp, i32, vp, vp, pvp, vp, vp]
         L.mp3s_reveal_message.argtypes = [vp, sz, pvp, C.POINTER(File)]
+        L.mp3s_pipe_create.argtypes = [vp, i32, sz, i32, pvp]
+        L.mp3s_pipe_destroy.argtypes = [vp]
+        L.mp3s_pipe_destroy.restype = None
+        L.mp3s_pipe_submit.argtypes = [vp, vp, vp, i32, vp, vp, C.POINTER(C.c_int64)]
+        L.mp3s_pipe_collect.argtypes = [vp, C.POINTER(C.c_int64), pvp, vp, vp, i32, C.POINTER(C.c_int32)]
+        L.mp3s_pipe_get_stats.argtypes = [vp, C.POINTER(PipeStats)]
         _lib = L
     return _lib
 
@@ -293,8 +311,14 @@ class Context:
         check(lib().mp3s_timer_stop(self.handle, C.byref(ms)))
         return ms.value
 
+    def bench_copy(self, nbytes=1 << 30, iters=20):
+        """GB/s (read + write) of a plain device copy kernel"""
+        g = C.c_double()
+        check(lib().mp3s_bench_copy(self.handle, int(nbytes), int(iters), C.byref(g)))
+        return g.value
+
     KERNELS = ("k_dec_imdct", "k_dec_synth", "k_enc_analysis", "k_enc_mdct", "k_rate_loop", "k_dec_huffman",
-               "k_enc_pack")
+               "k_enc_pack", "k_chain")
 
     def profile_enable(self, on=True):
         check(lib().mp3s_profile_enable(self.handle, 1 if on else 0))
@@ -523,6 +547,80 @@ class Context:
             return res
         finally:
             lib().mp3s_buf_free(owner)
+
+
+class Pipe:
+    """Asynchronous host-fed pipeline (include/mp3s.h section vii): `depth` jobs in flight, host scan || upload || kernels ||
+    download.  A job is the argument list of Context.hide_messages; results come back in submission order and are byte
+    for byte what hide_messages returns.  The context belongs to the pipe until close()."""
+
+    def __init__(self, ctx, depth=4, max_job_bytes=8 << 20, scan_threads=3, max_files=1024):
+        h = C.c_void_p()
+        check(lib().mp3s_pipe_create(ctx.handle, int(depth), int(max_job_bytes), int(scan_threads), C.byref(h)))
+        self.handle, self.ctx, self.depth = h, ctx, int(depth)
+        self._keep = {}                         # ticket -> the buffers the job borrows
+        self._out, self._status, self._cap = (File * max_files)(), (C.c_int32 * max_files)(), max_files
+
+    def submit(self, mp3s, messages):
+        """-> ticket, or None when `depth` jobs are in flight (collect one first).  messages: one str (or None = clear)
+        per file, or None = clear all."""
+        n = len(mp3s)
+        if messages is not None and n != len(messages):
+            raise ValueError("one message (or None) per file")
+        bufs = [np.frombuffer(m, dtype=np.uint8) for m in mp3s]
+        files = (C.c_void_p * n)(*[b.ctypes.data for b in bufs])
+        lens = (C.c_size_t * n)(*[len(b) for b in bufs])
+        msgs = mptr = mlen = None
+        if messages is not None:
+            enc = [None if t is None else t.encode("utf-8") for t in messages]
+            msgs = [None if e is None else np.frombuffer(e or b"\0", dtype=np.uint8) for e in enc]
+            mptr = (C.c_void_p * n)(*[None if m is None else m.ctypes.data for m in msgs])
+            mlen = (C.c_size_t * n)(*[0 if e is None else len(e) for e in enc])
+        t = C.c_int64()
+        rc = lib().mp3s_pipe_submit(self.handle, files, lens, n, mptr, mlen, C.byref(t))
+        if rc == E_BUSY:
+            return None
+        check(rc)
+        self._keep[t.value] = (mp3s, bufs, msgs, files, lens, mptr, mlen)
+        return t.value
+
+    def collect(self):
+        """-> (ticket, [per file: the dict Context.hide_message returns, or the Mp3sError that file alone would raise]);
+        None when nothing is in flight.  "data" is a read-only view of the library's page-locked result block."""
+        t, owner, nf = C.c_int64(), C.c_void_p(), C.c_int32()
+        rc = lib().mp3s_pipe_collect(self.handle, C.byref(t), C.byref(owner), self._out, self._status, self._cap, C.byref(nf))
+        if rc == E_BUSY:
+            return None
+        self._keep.pop(t.value, None)
+        check(rc)
+        own = _Owner(owner)
+        res = []
+        for i in range(nf.value):
+            f = self._out[i]
+            if self._status[i]:
+                res.append(Mp3sError(self._status[i], f"file {i}"))
+            else:
+                res.append({"data": Context._owned_bytes(f.data, f.len, own), "kbps": f.kbps, "sampling_rate": f.sampling_rate,
+                            "channels": f.channels, "n_frames": f.n_frames, "too_long": bool(f.too_long),
+                            "hide_offset": f.hide_offset})
+        return t.value, res
+
+    def stats(self):
+        s = PipeStats()
+        check(lib().mp3s_pipe_get_stats(self.handle, C.byref(s)))
+        return {k: getattr(s, k) for k, _ in PipeStats._fields_}
+
+    def close(self):
+        if self.handle:
+            lib().mp3s_pipe_destroy(self.handle)
+            self.handle = None
+            self._keep.clear()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
 def reveal_message(mp3: bytes):

@@ -1,0 +1,200 @@
+"""The asynchronous host-fed pipeline (include/mp3s.h section vii) and the on-device chain check it relies on
+(mp3s_chain_resolve_dev): results are byte for byte those of the synchronous calls, which are pinned to the oracle
+elsewhere (tests/test_batch_hide.py, tests/test_gpu_dropin.py) -- and against the oracle directly here."""
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _expect(orc, mlib, mp3, message):
+    d = orc.decode(mp3)
+    pcm = orc.pcm_to_i16(d["pcm"])
+    bits = None if message is None else np.array(mlib.message_frame(message))
+    return orc.encode(pcm, int(d["sampling_rate"]), int(d["bit_rate"]) // 1000, bits)
+
+
+def _drain(pipe, jobs):
+    """keep the pipe full, collect in order; -> results per job"""
+    out, nxt = [], 0
+    while len(out) < len(jobs):
+        while nxt < len(jobs):
+            t = pipe.submit(*jobs[nxt])
+            if t is None:
+                break
+            assert t == nxt
+            nxt += 1
+        t, res = pipe.collect()
+        assert t == len(out)
+        out.append(res)
+    assert pipe.collect() is None
+    return out
+
+
+def test_pipe_matches_the_synchronous_calls_and_the_oracle(mlib, orc, golden_dir):
+    from synth_pcm import synth_pcm
+    ctx = mlib.Context(0)
+    try:
+        # the inputs: streams of several sizes and rates, one with silence (inherited addresses, E7)
+        streams = []
+        for i, (rate, kbps, n) in enumerate([(44100, 128, 300), (44100, 128, 41), (48000, 192, 60), (32000, 64, 25), (44100, 128, 120)]):
+            pcm = synth_pcm(n, rate=rate, seed=77 + i)
+            if i == 4:
+                pcm[: 30 * 1152] = 0
+                pcm[60 * 1152:80 * 1152] = 0
+            streams.append(bytes(ctx.encode_pcm(pcm, rate, kbps, None)["mp3"]))
+        g = np.load(os.path.join(golden_dir, "g7_decode_corpus.npz"))
+        names = sorted({k.split("__")[0] for k in g.files})
+        corpus = [g[n + "__mp3"].tobytes() for n in names]           # mono, MS, reservoir, mixed blocks, CRC ...
+        test_mp3 = open(os.path.join(golden_dir, "test.mp3"), "rb").read()
+        long_msg = "long " * 60                                       # > 1024 bits: the first pass cannot guess the cursors
+        jobs = [
+            ([streams[0]], ["a short message"]),
+            ([streams[1]], None),                                     # clear
+            ([streams[0], streams[1], streams[4]], ["one", None, "three"]),   # one device batch of three streams
+            ([streams[2]], ["x"]),
+            ([streams[0], streams[2]], ["two groups", "in one job"]), # two (rate, bitrate) groups: the synchronous path
+            ([streams[4]], [long_msg]),                               # verdict != 0: redone by the synchronous path
+            ([test_mp3], ["ddd"]),
+            ([streams[3]], [""]),
+            (corpus, ["m%d" % i for i in range(len(corpus))]),        # per-file status
+            ([streams[0][:-700]], ["cut"]),                           # truncated last frame
+            ([b"garbage" * 50], ["nope"]),
+        ]
+        want = []
+        for files, msgs in jobs:
+            want.append(ctx.hide_messages(files, [None] * len(files) if msgs is None else msgs))
+        for depth, threads in ((3, 2), (1, 1), (5, 4)):
+            pipe = mlib.Pipe(ctx, depth=depth, max_job_bytes=1 << 20, scan_threads=threads)
+            try:
+                got = _drain(pipe, jobs * 2)
+                st = pipe.stats()
+            finally:
+                pipe.close()
+            for k, res in enumerate(got):
+                w = want[k % len(jobs)]
+                assert len(res) == len(w)
+                for a, b in zip(res, w):
+                    if isinstance(b, Exception):
+                        assert isinstance(a, mlib.Mp3sError) and a.code == b.code, (k, a, b)
+                    else:
+                        assert not isinstance(a, Exception), (k, a)
+                        assert bytes(a["data"]) == bytes(b["data"]), k
+                        assert a["too_long"] == b["too_long"] and a["hide_offset"] == b["hide_offset"], k
+                        assert (a["kbps"], a["sampling_rate"], a["n_frames"]) == (b["kbps"], b["sampling_rate"], b["n_frames"]), k
+            assert st["collected"] == 2 * len(jobs) and st["fast"] >= 2 * 5, st      # the plain jobs took the overlapped stages
+            assert st["slow"] >= 2 * 3, st
+        # ... and the oracle on the jobs the device took alone
+        for k in (0, 1, 3, 6, 7):
+            files, msgs = jobs[k]
+            o = _expect(orc, mlib, files[0], None if msgs is None else msgs[0])
+            assert o["rc"] == 0 and bytes(want[k][0]["data"]) == o["mp3"], k
+        for i in range(3):
+            o = _expect(orc, mlib, jobs[2][0][i], jobs[2][1][i])
+            assert bytes(want[2][i]["data"]) == o["mp3"], i
+    finally:
+        ctx.close()
+
+
+def test_pipe_staging_too_small_takes_the_other_path(mlib):
+    from synth_pcm import synth_pcm
+    ctx = mlib.Context(0)
+    try:
+        mp3 = bytes(ctx.encode_pcm(synth_pcm(200, seed=3), 44100, 128, None)["mp3"])
+        want = ctx.hide_message(mp3, "fits nowhere")
+        pipe = mlib.Pipe(ctx, depth=2, max_job_bytes=8192, scan_threads=1)
+        try:
+            assert pipe.submit([mp3], ["fits nowhere"]) == 0
+            assert pipe.submit([mp3], ["fits nowhere"]) == 1
+            assert pipe.submit([mp3], ["fits nowhere"]) is None      # both slots taken
+            for t in range(2):
+                tk, res = pipe.collect()
+                assert tk == t and bytes(res[0]["data"]) == bytes(want["data"])
+            assert pipe.stats()["slow"] == 2
+        finally:
+            pipe.close()
+        # the context is usable again after the pipe is gone
+        assert bytes(ctx.hide_message(mp3, "fits nowhere")["data"]) == bytes(want["data"])
+    finally:
+        ctx.close()
+
+
+def test_chain_check_on_the_device(ctx, mlib):
+    """mp3s_chain_resolve_dev against a host walk of the same GrInfo records: cursor, inherited addresses of silent units,
+    verdict, per-stream chain ends -- two streams in one batch, silence at a stream start and in the middle"""
+    from synth_pcm import synth_pcm
+    L = mlib.lib()
+    n0, n1 = 300, 53                                   # > 256 frames: more than one workgroup of the scan
+    n = n0 + n1
+    pcm = np.concatenate([synth_pcm(n0, seed=21), synth_pcm(n1, seed=22)])
+    pcm[:5 * 1152] = 0
+    pcm[100 * 1152:140 * 1152] = 0
+    pcm[n0 * 1152:(n0 + 3) * 1152] = 0                 # the second stream starts in silence
+    hdr = np.zeros(n, dtype=mlib.FRAME_HDR_DTYPE)
+    hdr["nch"] = 2
+    hdr["stream_first"][n0:] = n0
+    mdct = ctx.encode_transform(pcm, hdr)
+    rf, _ = mlib.rate_frames(44100, 128, 2, n)
+    rf["stream"][n0:] = 1
+    msg = np.array(mlib.message_frame("the device walks the chain"), dtype=np.uint8)
+    hide = np.concatenate([msg, msg])
+    rf["hide_end"][:n0] = len(msg)
+    rf["hide_end"][n0:] = 2 * len(msg)
+    units = n * 4
+    segs = np.zeros(2, dtype=mlib.CHAIN_SEG_DTYPE)
+    segs["first_frame"], segs["n_frames"] = [0, n0], [n0, n1]
+    segs["hide_base"], segs["hide_begin"], segs["hide_end"] = [0, len(msg)], [0, len(msg)], [len(msg), 2 * len(msg)]
+    segs["chain_in"][1] = np.arange(16).reshape(4, 4) + 7          # as if the second stream were a block with a carry
+    cur = np.zeros(units, dtype=np.int32)
+    cur[:n0 * 4] = 3 * np.arange(n0 * 4)
+    cur[n0 * 4:] = len(msg) + 3 * np.arange(n1 * 4)
+    d_mdct, d_rf, d_hide, d_cur, d_segs = (ctx.to_device(a) for a in (mdct, rf, hide, cur, segs))
+    d_ix, d_out, d_en = ctx.alloc(n * 2304 * 2), ctx.alloc(units * 72), ctx.alloc(units * 88)
+    d_ver, d_so = ctx.alloc(16), ctx.alloc(2 * 80)
+    try:
+        mlib.check(L.mp3s_rate_loop_dev(ctx.handle, d_mdct, d_rf, n, d_hide, len(hide), d_cur, None, None, 0, d_ix, d_out, d_en))
+        before = ctx.download(d_out, mlib.GR_OUT_DTYPE, (units,))
+        mlib.check(L.mp3s_chain_resolve_dev(ctx.handle, d_out, d_rf, n, d_segs, 2, d_cur, None, d_ver, d_so))
+        after = ctx.download(d_out, mlib.GR_OUT_DTYPE, (units,))
+        ver = ctx.download(d_ver, np.int32, (2,))
+        so = ctx.download(d_so, mlib.CHAIN_SEG_OUT_DTYPE, (2,))
+    finally:
+        for p in (d_mdct, d_rf, d_hide, d_cur, d_segs, d_ix, d_out, d_en, d_ver, d_so):
+            ctx.free(p)
+    # the host walk (what csrc/mp3s_encode_pipeline.cpp's walk() does)
+    exp = before.copy()
+    n_redo = 0
+    for s in range(2):
+        f0, nf = int(segs["first_frame"][s]), int(segs["n_frames"][s])
+        c, end = int(segs["hide_begin"][s]), int(segs["hide_end"][s])
+        chain = segs["chain_in"][s].copy()
+        own = [False] * 4
+        used_carry = c < end
+        for u in range(f0 * 4, (f0 + nf) * 4):
+            k = u & 3
+            g = exp[u]
+            active = bool(g["flags"] & mlib.RF_ACTIVE)
+            used_addr = bool(g["flags"] & mlib.RF_USED_ADDR_IN)
+            if not own[k] and (not active or used_addr):
+                used_carry = True
+            if active:
+                own[k] = True
+            redo = active and int(cur[u]) != c and min(int(cur[u]), c) < end
+            if used_addr and tuple(chain[k][:3]) != (0, 0, 0):
+                redo = True
+            n_redo += int(redo)
+            if active:
+                c += int(g["n_tables"])
+                chain[k] = list(g["address"]) + [g["quantizer_step"]]
+            else:
+                exp["address"][u] = chain[k][:3]
+                exp["quantizer_step"][u] = chain[k][3]
+        assert int(so["cursor"][s]) == c, s
+        assert np.array_equal(so["chain"][s], chain), s
+        assert bool(so["carry_used"][s]) == used_carry, s
+    assert np.array_equal(after, exp)
+    assert (before["flags"] & mlib.RF_ACTIVE == 0).sum() >= 40 * 4   # the silent stretches are really silent
+    assert int(ver[0]) == n_redo and int(ver[1]) == 0
+    assert n_redo > 0                                                  # silence shifts the cursor: the guess 3 per unit fails
