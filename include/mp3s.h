@@ -235,7 +235,10 @@ typedef struct {
     uint8_t sub_block_gain[3];
 } mp3s_unit_side; /* 20 bytes */
 
-/* one frame for the Huffman kernel: where its main data sits in the blob + the parsed side info */
+/* one frame for the Huffman kernel: where its main data sits in the blob + the parsed side info
+ * flags & MP3S_FS_HOST_DECODED: the kernel skips the frame (the caller places host-decoded samples there afterwards: the
+ * last frame of a stream written by the reference's encoder can lack up to 3 bytes of its main data) */
+#define MP3S_FS_HOST_DECODED 1
 typedef struct {
     uint32_t md_off, md_len;   /* byte offset (multiple of 4) and length of the frame's main data in the blob */
     uint8_t nch, sr_idx, ms_stereo, flags;
@@ -461,6 +464,7 @@ typedef struct {
     int64_t fast, slow;               /* collected jobs that went through the overlapped stages / through mp3s_hide_messages */
     double scan_ms, issue_ms;         /* summed over jobs: host scan + input layout; queueing the job's device work */
     double last_device_span_ms;       /* first upload byte to last download byte of the job collected last (HIP events) */
+    double scan_cpu_ms;               /* CPU time of the scan threads inside scan_ms (less than scan_ms: the threads were not running) */
 } mp3s_pipe_stats;
 /* depth: jobs in flight (= staging slots); max_job_bytes: MP3 bytes per job the staging is sized for (larger jobs still
  * work, through the synchronous path); scan_threads: host workers */

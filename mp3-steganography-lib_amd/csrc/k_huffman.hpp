@@ -116,7 +116,9 @@ __global__ __launch_bounds__(WAVES * 64) void k_dec_huffman(
     __syncthreads();
     const int lane = threadIdx.x & 63, col = (int)(threadIdx.x >> 6) * LANES + lane;
     const long tid = (long)blockIdx.x * COLS + col;
-    const bool worker = lane < LANES && tid < (long)n_frames * 4 && (int)(tid & 1) < nch;
+    bool worker = lane < LANES && tid < (long)n_frames * 4 && (int)(tid & 1) < nch;
+    // a frame the host has decoded itself (MP3S_FS_HOST_DECODED: its samples are placed behind this kernel) is left alone
+    if (worker && (reinterpret_cast<const uint32_t *>(side + (tid >> 2))[2] >> 24) & MP3S_FS_HOST_DECODED) worker = false;
     if (worker) {
     const int f = (int)(tid >> 2), k = (int)(tid & 3), gr = k >> 1, ch = k & 1;
     SideRegs fs;

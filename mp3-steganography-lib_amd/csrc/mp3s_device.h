@@ -55,6 +55,8 @@ int launch_chain(hipStream_t stream, mp3s_gr_out *d_gr, const mp3s_rate_frame *d
                  const int32_t *d_cursor, const int32_t *d_state, void *d_agg, int32_t *d_verdict, mp3s_chain_seg_out *d_seg_out,
                  Profiler *prof);
 
+constexpr size_t kPlaceEntry = 4912;   // [int32 frame, pad to 16 | int16 is[2304] | mp3s_granule_si si[4]]
+int launch_place_frames(hipStream_t stream, const uint8_t *d_entries, int n_entries, int16_t *d_is, mp3s_granule_si *d_si);
 int launch_copy(hipStream_t stream, const void *d_src, void *d_dst, size_t bytes);
 
 // bit-level stages on the device

@@ -176,6 +176,25 @@ int launch_huffman(hipStream_t stream, const uint8_t *d_blob, const mp3s_frame_s
     return (int)hipGetLastError();
 }
 
+// host-decoded frames (the asynchronous pipe decodes the last frame of every stream on the host: E14) into their places:
+// entry = [int32 frame, 12 bytes pad | int16 is[2304] | mp3s_granule_si si[4]] = 4912 bytes, one workgroup per entry
+__global__ __launch_bounds__(256) void k_place_frames(const uint8_t *__restrict__ entries, int n_entries, int16_t *__restrict__ is,
+                                                      mp3s_granule_si *__restrict__ si)
+{
+    const uint8_t *e = entries + (size_t)blockIdx.x * 4912;
+    const int f = *reinterpret_cast<const int32_t *>(e);
+    const uint32_t *src = reinterpret_cast<const uint32_t *>(e + 16);
+    uint32_t *d_is = reinterpret_cast<uint32_t *>(is + (size_t)f * 2304), *d_si = reinterpret_cast<uint32_t *>(si + (size_t)f * 4);
+    for (int i = threadIdx.x; i < 1152; i += 256) d_is[i] = src[i];
+    for (int i = threadIdx.x; i < 72; i += 256) d_si[i] = src[1152 + i];
+}
+int launch_place_frames(hipStream_t stream, const uint8_t *d_entries, int n_entries, int16_t *d_is, mp3s_granule_si *d_si)
+{
+    if (n_entries <= 0) return 0;
+    hipLaunchKernelGGL(k_place_frames, dim3(n_entries), dim3(256), 0, stream, d_entries, n_entries, d_is, d_si);
+    return (int)hipGetLastError();
+}
+
 // plain device copy, 16 bytes per lane and step: what HBM gives a streaming kernel on this box (BASELINE.md section 4 asks
 // for the achievable figure beside the 8 TB/s of the data sheet)
 __global__ __launch_bounds__(256) void k_copy16(const uint4 *__restrict__ src, uint4 *__restrict__ dst, size_t n16)

@@ -43,6 +43,7 @@ int parse_stream(const uint8_t *file, size_t len, ParsedStream &out, ScannedStre
 struct ScanSink {
     uint8_t *blob = nullptr; size_t blob_len = 0, blob_cap = 0;
     mp3s_frame_side *side = nullptr; size_t n_side = 0, side_cap = 0;
+    mp3s_frame_hdr *hdr = nullptr;     // optional, side_cap entries: the frame headers go here instead of ParsedStream::hdr
     bool gpu_ok = true;
     bool lean = false;                 // the caller wants neither stego bits nor table indices nor frame sizes
     void *user = nullptr;

@@ -307,10 +307,14 @@ int parse_stream_sink(const uint8_t *file, size_t flen_, ParsedStream &out, Scan
     std::call_once(g_lut_once, build_luts);
     const HostTables &HT = host_tables();
     const long flen = (long)flen_;
-    out = ParsedStream();
+    // (the vectors keep their capacity: a caller that scans file after file with one ParsedStream allocates nothing here --
+    // fresh blocks of this size come from mmap, and page faults / unmaps of several scanning threads queue up on the
+    // process's memory-map lock)
+    out.n_frames = out.nch = out.sampling_rate = out.bit_rate = out.dup_last_frame = 0;
+    out.is.clear(); out.si.clear(); out.hdr.clear(); out.bits.clear(); out.table_select.clear(); out.frame_size.clear();
     if (scan) {
         scan->blob_len = 0; scan->n_side = 0; scan->gpu_ok = true;
-        out.hdr.reserve(flen_ / 96 + 1);
+        if (!scan->hdr) out.hdr.reserve(flen_ / 96 + 1);
         if (!scan->lean) { out.frame_size.reserve(flen_ / 96 + 1); out.bits.reserve(flen_ / 8 + 16); out.table_select.reserve((flen_ / 96 + 1) * 12); }
     }
     // blob bytes of the sink: room for `extra` more, or (fixed capacity) give up
@@ -525,7 +529,8 @@ int parse_stream_sink(const uint8_t *file, size_t flen_, ParsedStream &out, Scan
         fh.sr_idx = (uint8_t)hd.sr_idx; fh.nch = (uint8_t)nch;
         fh.ms_stereo = (hd.mode == 1 && hd.mode_ext0) ? 1 : 0;
         fh.flags = 0; fh.stream_first = 0;
-        out.hdr.push_back(fh);
+        if (scan && scan->hdr) scan->hdr[out.n_frames] = fh;   // (room for as many headers as side records)
+        else out.hdr.push_back(fh);
         if (!(scan && scan->lean)) out.frame_size.push_back(frame_size);
         out.n_frames++;
         offset += frame_size;

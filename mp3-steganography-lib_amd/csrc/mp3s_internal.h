@@ -100,8 +100,11 @@ public:
             std::lock_guard<std::mutex> g(mu());
             auto &fl = free_list();
             size_t best = fl.size();
+            // best fit, but a small request does not take a large block away from the next large request (which would
+            // then have to pin fresh pages: about a millisecond per 4 MB)
+            const size_t too_big = std::max(4 * bytes, bytes + ((size_t)1 << 20));
             for (size_t i = 0; i < fl.size(); i++)
-                if (fl[i].second >= bytes && (best == fl.size() || fl[i].second < fl[best].second)) best = i;
+                if (fl[i].second >= bytes && fl[i].second <= too_big && (best == fl.size() || fl[i].second < fl[best].second)) best = i;
             if (best < fl.size()) { p_ = fl[best].first; cap_ = fl[best].second; fl.erase(fl.begin() + best); return true; }
         }
         const size_t want = bytes + bytes / 8 + (1 << 16);
@@ -121,7 +124,7 @@ private:
         auto &fl = free_list();
         size_t held = 0;
         for (auto &e : fl) held += e.second;
-        if (fl.size() < 8 && held + cap_ <= kMaxPinned) fl.emplace_back(p_, cap_);
+        if (fl.size() < 48 && held + cap_ <= kMaxPinned) fl.emplace_back(p_, cap_);
         else hipHostFree(p_);
         p_ = nullptr; cap_ = 0;
     }
