@@ -75,7 +75,7 @@ int enc_fill(std::vector<EncSeg> &segs, EncLayout &L, uint8_t *dst)
         for (int j = 0; j < s.n_frames * 4; j++)
             cursor[(size_t)s.first * 4 + j] = long_msg ? kNoCursor : (int32_t)std::min<int64_t>((int64_t)s.hide_base + c0 + 3 * (int64_t)j, kNoCursor);
         cs[si].first_frame = s.first; cs[si].n_frames = s.n_frames;
-        cs[si].hide_base = s.hide_base; cs[si].hide_begin = (int32_t)std::min<int64_t>((int64_t)s.hide_base + c0, kNoCursor);
+        cs[si].hide_base = s.hide_base; cs[si].hide_begin = (int32_t)((int64_t)s.hide_base + c0);   // (both below 2^30)
         cs[si].hide_end = s.hide_base + s.n_hide;
         if (s.carry_in) std::memcpy(cs[si].chain_in, s.carry_in->chain, sizeof cs[si].chain_in);
     }

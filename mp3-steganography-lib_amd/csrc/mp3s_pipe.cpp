@@ -305,8 +305,14 @@ int mp3s_pipe_create(mp3s_ctx *c, int depth, size_t max_job_bytes, int scan_thre
         if (P->s_down) (void)hipStreamDestroy(P->s_down);
         return fail(code, "%s", what);
     };
-    if (hipStreamCreateWithFlags(&P->s_up, hipStreamNonBlocking) != hipSuccess ||
-        hipStreamCreateWithFlags(&P->s_down, hipStreamNonBlocking) != hipSuccess)
+    // The runtime multiplexes streams onto a few hardware queues (round robin, four by default), and work of two streams
+    // that share a queue runs in order: a copy stream that lands on the compute stream's queue stops overlapping with the
+    // kernels (measured: every second pipe of a process, 1.35 instead of 1.10 ms per 10 000-frame batch).  Streams of
+    // another priority come from another set of queues, so the copy streams are created with the highest one.
+    int prio_low = 0, prio_high = 0;
+    (void)hipDeviceGetStreamPriorityRange(&prio_low, &prio_high);
+    if (hipStreamCreateWithPriority(&P->s_up, hipStreamNonBlocking, prio_high) != hipSuccess ||
+        hipStreamCreateWithPriority(&P->s_down, hipStreamNonBlocking, prio_high) != hipSuccess)
         return destroy(MP3S_E_HIP, "stream creation failed");
     P->slots.resize((size_t)depth);
     for (auto &s : P->slots) {
