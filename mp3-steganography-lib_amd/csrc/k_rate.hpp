@@ -38,7 +38,8 @@ __device__ __forceinline__ uint32_t wave_add_u32(uint32_t v)
 // encoder/util.py:130-133 mulr for non-negative a: (a*b + 2^31) >> 32
 __device__ __forceinline__ uint32_t mulr_u(uint32_t a, uint32_t b) { return (uint32_t)(((uint64_t)a * b + 0x80000000ull) >> 32); }   // one v_mad_u64_u32
 
-constexpr int RL_WAVES = 4;   // 4 waves share one copy of the lookup tables: 33 KB LDS -> 4 workgroups = 16 waves per CU
+constexpr int RL_WAVES = 4;   // 4 waves share one copy of the lookup tables: 33 KB LDS -> 4 workgroups = 16 waves per CU (a fifth wave
+                              // per SIMD at 96 VGPRs was measured: 0.351 instead of 0.305 ms, and the Huffman kernel no longer fits beside it)
 constexpr int RL_NP = 5;   // pair slots per lane (the 5th only for lanes < 32)
 
 struct RlTables {
@@ -75,36 +76,35 @@ __device__ __forceinline__ uint32_t pair_bits(const RlTables &tb, int fam, int l
 }
 __device__ __forceinline__ int sel3(int r, int a, int b, int c) { return r == 0 ? a : (r == 1 ? b : c); }
 
-// quantize (MP3_Encoder.py:389-415); returns the wave-uniform ix_max, 16384 for the early out, -1 when the
-// step leaves steptab (IndexError in the reference)
+// quantize (MP3_Encoder.py:389-415); returns 0, or 8193 when some quantised value exceeds 8192, 16384 for the early out,
+// -1 when the step leaves steptab (IndexError in the reference).  (The callers only ask "more than 8192?".)
+// mulr is monotone in its first argument, so the largest ln of the granule is the one of xrmax: whether the float path
+// is needed at all is a scalar question, and the table path cannot exceed 1000 -- no wave reduction in the common case.
 __device__ __forceinline__ int rl_quantize(const RlTables &tb, const uint32_t (&xa)[2 * RL_NP], int32_t (&ix)[2 * RL_NP],
                                            int step, uint32_t xrmax)
 {
     const int idx = __builtin_amdgcn_readfirstlane(step + 127);
     if (idx < 0 || idx > 127) return -1;
     const uint32_t scalei = (uint32_t)c_tab.steptabi[idx];
-    if (mulr_u(xrmax, scalei) > 165140u) return 16384;
+    const uint32_t lnmax = mulr_u(xrmax, scalei);
+    if (lnmax > 165140u) return 16384;
+    if (lnmax < 10000u) {
+#pragma unroll
+        for (int e = 0; e < 2 * RL_NP; e++) ix[e] = tb.int2idx[mulr_u(xa[e], scalei)];   // quick lookup (:403-404)
+        return 0;
+    }
+    // some value is outside the table range: those go through floats (:405-409)
     const double scale = c_tab.steptab[idx];
-    uint32_t mx = 0, lnmax = 0;
+    bool big = false;
 #pragma unroll
     for (int e = 0; e < 2 * RL_NP; e++) {
         const uint32_t ln = mulr_u(xa[e], scalei);
-        lnmax = max(lnmax, ln);
-        const int32_t v = tb.int2idx[ln < 10000u ? ln : 9999u];   // quick lookup (:403-404)
-        ix[e] = v;
-        mx = max(mx, (uint32_t)v);
+        const double dbl = (double)xa[e] * scale * 4.656612875e-10;
+        const int32_t v = (int32_t)__dsqrt_rn(__dsqrt_rn(dbl) * dbl);
+        ix[e] = ln >= 10000u ? v : (int32_t)tb.int2idx[ln < 10000u ? ln : 9999u];
+        big |= ix[e] > 8192;
     }
-    if (__ballot(lnmax >= 10000u)) {   // wave-uniform: some value is outside the table range, redo those with floats (:405-409)
-#pragma unroll
-        for (int e = 0; e < 2 * RL_NP; e++) {
-            const uint32_t ln = mulr_u(xa[e], scalei);
-            const double dbl = (double)xa[e] * scale * 4.656612875e-10;
-            const int32_t v = (int32_t)__dsqrt_rn(__dsqrt_rn(dbl) * dbl);
-            ix[e] = ln >= 10000u ? v : ix[e];
-            mx = max(mx, (uint32_t)ix[e]);
-        }
-    }
-    return (int)wave_max_u32(mx);
+    return __ballot(big) ? 8193 : 0;
 }
 
 // calc_run_len + count1_bit_count + __subdivide + __big_v_tab_select + big_v_bit_count

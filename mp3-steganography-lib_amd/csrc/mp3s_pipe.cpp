@@ -34,7 +34,7 @@ struct Slot {
     size_t blob_cap = 0, side_cap = 0 /* frames */, in_cap = 0, fix_cap = 0 /* entries */, o_side = 0, o_in = 0, o_fix = 0, stage_bytes = 0;
     uint8_t *d_mp3 = nullptr; size_t mp3_cap = 0;
     int32_t *d_small = nullptr;
-    hipEvent_t e_start = nullptr, e_up = nullptr, e_comp = nullptr, e_down = nullptr;
+    hipEvent_t e_start = nullptr, e_up = nullptr, e_huff = nullptr, e_comp = nullptr, e_down = nullptr;
     bool busy = false;
 };
 
@@ -67,6 +67,13 @@ struct mp3s_pipe {
     int depth = 0;
     std::vector<Slot> slots;
     hipStream_t s_up = nullptr, s_down = nullptr;
+    // The Huffman kernel is a latency chain that leaves the vector units mostly idle; the rate loop is bound by them.  The
+    // front end of job k+1 therefore runs on a stream of its own, under the encode half of job k, with two sets of
+    // Huffman outputs (is / side records) taken in turn; e_dec[x] = the decode transforms that read set x last are done.
+    hipStream_t s_huff = nullptr;
+    hipEvent_t e_dec[2] = {nullptr, nullptr};
+    bool dec_used[2] = {false, false};
+    unsigned issued = 0;
     std::mutex mu;                       // queue, job states, slots
     std::condition_variable cv_work, cv_done;
     std::mutex mu_issue;                 // everything that touches the context (its stream, pool, profiler)
@@ -176,7 +183,8 @@ int issue_fast(mp3s_pipe *P, Job &j, Slot &s, size_t blob_len, int max_p23)
     const EncLayout &L = j.L;
     const int n = L.n, units = L.units;
     const size_t o_enc = ((size_t)n * sizeof(mp3s_frame_hdr) + 15) & ~(size_t)15, in_bytes = o_enc + L.bytes;
-    void *d_is = c->grab(0, (size_t)n * 2304 * 2), *d_si = c->grab(1, (size_t)n * 4 * sizeof(mp3s_granule_si)),
+    const int set = (int)(P->issued++ & 1u);
+    void *d_is = c->grab(set ? 24 : 0, (size_t)n * 2304 * 2), *d_si = c->grab(set ? 25 : 1, (size_t)n * 4 * sizeof(mp3s_granule_si)),
          *d_keep = c->grab(7, (size_t)n * 2304 * 2), *d_mdct = c->grab(10, (size_t)n * 2304 * 4), *d_ix = c->grab(12, (size_t)n * 2304 * 2),
          *d_out = c->grab(13, (size_t)units * sizeof(mp3s_gr_out)), *d_en = c->grab(14, (size_t)units * 22 * 4),
          *d_agg = c->grab(15, chain_agg_bytes(n)), *d_sc = c->grab(17, (size_t)n * 8 * 4);
@@ -189,12 +197,15 @@ int issue_fast(mp3s_pipe *P, Job &j, Slot &s, size_t blob_len, int max_p23)
     HIPCHK(hipMemcpyAsync(d_in, s.h_stage + s.o_in, in_bytes, hipMemcpyHostToDevice, P->s_up));
     HIPCHK(hipMemcpyAsync(s.d_stage + s.o_fix, s.h_stage + s.o_fix, (size_t)j.n_fix * kPlaceEntry, hipMemcpyHostToDevice, P->s_up));
     HIPCHK(hipEventRecord(s.e_up, P->s_up));
-    HIPCHK(hipStreamWaitEvent(c->stream, s.e_up, 0));
-    const int e = launch_huffman(c->stream, d_blob, (const mp3s_frame_side *)d_side, n, 2, max_p23, (int16_t *)d_is, (mp3s_granule_si *)d_si,
+    HIPCHK(hipStreamWaitEvent(P->s_huff, s.e_up, 0));
+    if (P->dec_used[set]) HIPCHK(hipStreamWaitEvent(P->s_huff, P->e_dec[set], 0));
+    const int e = launch_huffman(P->s_huff, d_blob, (const mp3s_frame_side *)d_side, n, 2, max_p23, (int16_t *)d_is, (mp3s_granule_si *)d_si,
                                  s.d_small + 3, &c->prof, false);
     if (e) return fail(MP3S_E_HIP, "huffman launch: %s", hipGetErrorString((hipError_t)e));
-    if (launch_place_frames(c->stream, s.d_stage + s.o_fix, j.n_fix, (int16_t *)d_is, (mp3s_granule_si *)d_si))
+    if (launch_place_frames(P->s_huff, s.d_stage + s.o_fix, j.n_fix, (int16_t *)d_is, (mp3s_granule_si *)d_si))
         return fail(MP3S_E_HIP, "placing the host-decoded frames failed");
+    HIPCHK(hipEventRecord(s.e_huff, P->s_huff));
+    HIPCHK(hipStreamWaitEvent(c->stream, s.e_huff, 0));
     const mp3s_frame_hdr *d_dechdr = (const mp3s_frame_hdr *)d_in;
     const mp3s_frame_hdr *h_dechdr = (const mp3s_frame_hdr *)(s.h_stage + s.o_in);
     for (long start = 0; start < n; start += kDecodeChunk) {
@@ -204,6 +215,8 @@ int issue_fast(mp3s_pipe *P, Job &j, Slot &s, size_t blob_len, int max_p23)
                                               MP3S_PCM_I16, (int16_t *)d_keep + (size_t)start * 2304);
         if (rc) return rc;
     }
+    HIPCHK(hipEventRecord(P->e_dec[set], c->stream));
+    P->dec_used[set] = true;
     EncDev dev;
     dev.d_pcm = (const int16_t *)d_keep; dev.d_in = d_in + o_enc; dev.d_mdct_all = (int32_t *)d_mdct; dev.d_ix = (int16_t *)d_ix;
     dev.d_out = (mp3s_gr_out *)d_out; dev.d_en = (int32_t *)d_en; dev.d_agg = d_agg; dev.d_mp3 = s.d_mp3; dev.d_sc = (int32_t *)d_sc;
@@ -228,6 +241,7 @@ void run_slow(mp3s_pipe *P, Job &j)   // mu_issue held
         fp[i] = j.files[i].first; fl[i] = j.files[i].second;
         mp[i] = j.clear_all ? nullptr : j.msgs[i].first; ml[i] = j.clear_all ? 0 : j.msgs[i].second;
     }
+    (void)hipStreamSynchronize(P->s_huff);   // the synchronous path uses the same Huffman output buffers
     j.slow_out.assign((size_t)nf, mp3s_file());
     j.slow_st.assign((size_t)nf, 0);
     j.res.reset();
@@ -260,7 +274,8 @@ void worker(mp3s_pipe *P, int me)
         {
             std::lock_guard<std::mutex> gi(P->mu_issue);
             if (fast && issue_fast(P, *j, s, blob_len, max_p23) != MP3S_OK) {
-                (void)hipStreamSynchronize(P->s_up); (void)hipStreamSynchronize(P->c->stream); (void)hipStreamSynchronize(P->s_down);
+                (void)hipStreamSynchronize(P->s_up); (void)hipStreamSynchronize(P->s_huff); (void)hipStreamSynchronize(P->c->stream);
+                (void)hipStreamSynchronize(P->s_down);
                 fast = false;
             }
             if (!fast) run_slow(P, *j);
@@ -283,7 +298,7 @@ void free_slot(Slot &s)
     if (s.d_stage) (void)hipFree(s.d_stage);
     if (s.d_mp3) (void)hipFree(s.d_mp3);
     if (s.d_small) (void)hipFree(s.d_small);
-    for (hipEvent_t e : {s.e_start, s.e_up, s.e_comp, s.e_down}) if (e) (void)hipEventDestroy(e);
+    for (hipEvent_t e : {s.e_start, s.e_up, s.e_huff, s.e_comp, s.e_down}) if (e) (void)hipEventDestroy(e);
     s = Slot();
 }
 
@@ -303,6 +318,8 @@ int mp3s_pipe_create(mp3s_ctx *c, int depth, size_t max_job_bytes, int scan_thre
         for (auto &s : P->slots) free_slot(s);
         if (P->s_up) (void)hipStreamDestroy(P->s_up);
         if (P->s_down) (void)hipStreamDestroy(P->s_down);
+        if (P->s_huff) (void)hipStreamDestroy(P->s_huff);
+        for (hipEvent_t e : P->e_dec) if (e) (void)hipEventDestroy(e);
         return fail(code, "%s", what);
     };
     // The runtime multiplexes streams onto a few hardware queues (round robin, four by default), and work of two streams
@@ -313,6 +330,14 @@ int mp3s_pipe_create(mp3s_ctx *c, int depth, size_t max_job_bytes, int scan_thre
     (void)hipDeviceGetStreamPriorityRange(&prio_low, &prio_high);
     if (hipStreamCreateWithPriority(&P->s_up, hipStreamNonBlocking, prio_high) != hipSuccess ||
         hipStreamCreateWithPriority(&P->s_down, hipStreamNonBlocking, prio_high) != hipSuccess)
+        return destroy(MP3S_E_HIP, "stream creation failed");
+    // the front-end stream takes the lowest priority: another set of queues again, and its workgroups fill in beside the
+    // compute stream's instead of competing with them
+    const char *hp = getenv("MP3S_PIPE_HUFF_PRIO");
+    const int huff_prio = hp ? atoi(hp) : prio_low;
+    if (hipStreamCreateWithPriority(&P->s_huff, hipStreamNonBlocking, huff_prio) != hipSuccess ||
+        hipEventCreateWithFlags(&P->e_dec[0], hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&P->e_dec[1], hipEventDisableTiming) != hipSuccess)
         return destroy(MP3S_E_HIP, "stream creation failed");
     P->slots.resize((size_t)depth);
     for (auto &s : P->slots) {
@@ -329,7 +354,8 @@ int mp3s_pipe_create(mp3s_ctx *c, int depth, size_t max_job_bytes, int scan_thre
         s.mp3_cap = max_job_bytes + s.side_cap + 4096;
         if (hipHostMalloc((void **)&s.h_stage, s.stage_bytes, hipHostMallocDefault) != hipSuccess || hipMalloc((void **)&s.d_stage, s.stage_bytes) != hipSuccess ||
             hipMalloc((void **)&s.d_mp3, s.mp3_cap) != hipSuccess || hipMalloc((void **)&s.d_small, small_bytes(kMaxFastFiles)) != hipSuccess ||
-            hipEventCreate(&s.e_start) != hipSuccess || hipEventCreate(&s.e_up) != hipSuccess || hipEventCreate(&s.e_comp) != hipSuccess ||
+            hipEventCreate(&s.e_start) != hipSuccess || hipEventCreate(&s.e_up) != hipSuccess || hipEventCreate(&s.e_huff) != hipSuccess ||
+            hipEventCreate(&s.e_comp) != hipSuccess ||
             hipEventCreate(&s.e_down) != hipSuccess)
             return destroy(MP3S_E_NOMEM, "slot allocation failed");
     }
@@ -350,10 +376,12 @@ void mp3s_pipe_destroy(mp3s_pipe *P)
     P->cv_work.notify_all();
     for (auto &t : P->workers) t.join();
     (void)hipSetDevice(P->c->device);
-    (void)hipStreamSynchronize(P->s_up); (void)hipStreamSynchronize(P->c->stream); (void)hipStreamSynchronize(P->s_down);
+    (void)hipStreamSynchronize(P->s_up); (void)hipStreamSynchronize(P->s_huff); (void)hipStreamSynchronize(P->c->stream);
+    (void)hipStreamSynchronize(P->s_down);
     for (auto &j : P->inflight) if (j->slow_owner) mp3s_buf_free(j->slow_owner);
     for (auto &s : P->slots) free_slot(s);
-    (void)hipStreamDestroy(P->s_up); (void)hipStreamDestroy(P->s_down);
+    (void)hipStreamDestroy(P->s_up); (void)hipStreamDestroy(P->s_down); (void)hipStreamDestroy(P->s_huff);
+    for (hipEvent_t e : P->e_dec) (void)hipEventDestroy(e);
     delete P;
 }
 
