@@ -3,7 +3,8 @@
 Public surface, console texts, `sys.exit` messages and file side effects (the temporary WAV next to the input that is
 written and removed again) are the reference's (mp3stego/steganography.py:10-182); the work is done by `Decoder` and
 `Encoder`, i.e. by libmp3s_hip.so.  Organised around three private steps -- mp3 -> temporary wav, wav -> mp3, drop
-the wav -- that the five public operations combine.
+the wav -- that the five public operations combine; hide_message / clear_file take the fused native call (PCM kept in
+device memory) whenever nothing of the detour would be observable.
 """
 import contextlib
 import os
@@ -112,7 +113,29 @@ class Steganography:
             self._recode(input_file_path, output_file_path, None)
 
     def _recode(self, mp3_in: str, mp3_out: str, message) -> bool:
+        """decode + re-encode (reference steganography.py:153-159 / 178-181).  The quiet case is ONE native call
+        (mp3s_hide_message / mp3s_clear_file): the PCM stays in device memory instead of travelling through a temporary
+        WAV file -- byte-identical output.  What the reference's detour leaves behind is reproduced: a file that happened
+        to sit at the temporary WAV's path is gone afterwards (it was overwritten, then deleted).  Whatever is observable
+        beyond that -- the console texts and METADATA.txt of a non-quiet run, the WAV a failing encode leaves on disk,
+        which exception a stream the reference cannot re-encode raises -- comes from the step-by-step path below."""
         wav = self._wav_beside(mp3_in)
+        if self.quiet and _ends(mp3_out, ".mp3"):
+            from mp3stego import _lib
+            with open(mp3_in, "rb") as f:
+                data = f.read()
+            try:
+                ctx = _lib.default_context()
+                res = ctx.clear_file(data) if message is None else ctx.hide_message(data, message)
+            except _lib.Mp3sError:
+                res = None                       # the step-by-step path decides what this looks like to the caller
+            if res is not None:
+                self._kbps = res["kbps"]
+                with open(mp3_out, "wb") as f:
+                    f.write(res["data"])
+                if os.path.exists(wav):
+                    os.remove(wav)
+                return bool(res["too_long"])
         self._to_wav(mp3_in, wav)
         cut = self._to_mp3(wav, mp3_out, self._kbps, message)
         self._drop_wav()

@@ -134,3 +134,30 @@ def test_metadata_listing_of_a_tagged_file(work, golden_dir, monkeypatch):
     (work / "bare.mp3").write_bytes(data[case["offset"]:])
     assert Decoder("bare.mp3", "bare.wav").decode(quiet=False) == 128 and not os.path.exists("METADATA.txt")
     assert (work / "bare.wav").read_bytes() == (work / "loud.wav").read_bytes()
+
+
+def test_fused_hide_equals_the_detour_through_the_wav(work, capsys):
+    """quiet hide_message / clear_file are one native call (PCM stays in device memory); the non-quiet ones go decode ->
+    WAV file -> encode as the reference does.  Same bytes, same return value, same files left behind."""
+    from mp3stego import Steganography
+    src = str(work / "test.mp3")
+    for message in ("ddd", "d" * 400, None):
+        (work / "test.wav").write_bytes(b"something that happened to lie at the temporary path")
+        if message is None:
+            Steganography(quiet=True).clear_file(src, str(work / "a.mp3"))
+            cut_a = None
+        else:
+            cut_a = Steganography(quiet=True).hide_message(src, str(work / "a.mp3"), message)
+        assert not os.path.exists(work / "test.wav")                  # overwritten and deleted by the reference, gone here too
+        if message is None:
+            Steganography(quiet=False).clear_file(src, str(work / "b.mp3"))
+            cut_b = None
+        else:
+            cut_b = Steganography(quiet=False).hide_message(src, str(work / "b.mp3"), message)
+        capsys.readouterr()
+        assert cut_a == cut_b
+        assert (work / "a.mp3").read_bytes() == (work / "b.mp3").read_bytes()
+    # an output path the reference rejects only after it has decoded: the WAV stays behind, as there
+    with pytest.raises(SystemExit):
+        Steganography(quiet=True).hide_message(src, str(work / "out.xyz"), "ddd")
+    assert os.path.exists(work / "test.wav")
