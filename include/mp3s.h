@@ -329,10 +329,11 @@ int mp3s_decode_stream(mp3s_ctx *ctx, const uint8_t *file, size_t len, int out_f
                        mp3s_decoded *out);
 /* many streams in one call: the frames of all files form one batch (stream_first marks the starts), so
  * a corpus of short files costs one Huffman launch and one transform launch per channel count instead of one per file.
- * out[i] describes file i; every pointer lives in *owner.  A malformed file fails the whole call (its index is in
- * mp3s_last_error()). */
+ * out[i] describes file i; every pointer lives in *owner.  status[i] = MP3S_OK or the code file i alone would have
+ * failed with (its out[i] is zeroed, the other files are unaffected); with status == NULL the first such file fails the
+ * whole call (its index is in mp3s_last_error()) -- the same rule as mp3s_hide_messages. */
 int mp3s_decode_streams(mp3s_ctx *ctx, const uint8_t *const *files, const size_t *lens, int n_files, int out_format,
-                        mp3s_buf **owner, mp3s_decoded *out);
+                        mp3s_buf **owner, mp3s_decoded *out, int32_t *status);
 
 /* Frames [first_frame, first_frame + n_frames) of the stream (clipped to its end) -- the decode half of sharding one
  * stream over several GPUs.  The whole file is scanned on the host; only the block's main data plus one frame

@@ -218,7 +218,7 @@ int decode_group(mp3s_ctx *c, mp3s_multi &m, const std::vector<int> &idx, int nc
 extern "C" {
 
 static int decode_streams_impl(mp3s_ctx *c, const uint8_t *const *files, const size_t *lens, int n_files, int out_format,
-                               size_t head_room, mp3s_buf **owner, mp3s_decoded *out)
+                               size_t head_room, mp3s_buf **owner, mp3s_decoded *out, int32_t *status)
 {
     if (!c || !files || !lens || !owner || !out || n_files <= 0) return fail(MP3S_E_ARG, "bad argument");
     if (out_format < 0 || out_format > 2) return fail(MP3S_E_ARG, "out_format=%d", out_format);
@@ -229,38 +229,65 @@ static int decode_streams_impl(mp3s_ctx *c, const uint8_t *const *files, const s
     m.parsed.resize(n_files); m.scanned.resize(n_files); m.pcm.assign(n_files, nullptr); m.files.resize(n_files);
     std::vector<int> group[3];
     size_t total = 0;
+    std::vector<int> frc(n_files, MP3S_OK);
     for (int i = 0; i < n_files; i++) {
-        if (!files[i]) { delete b; return fail(MP3S_E_ARG, "file %d is null", i); }
+        if (!files[i]) {
+            if (!status) { delete b; return fail(MP3S_E_ARG, "file %d is null", i); }
+            frc[i] = MP3S_E_ARG;
+            continue;
+        }
         m.files[i] = {files[i], lens[i]};
         total += lens[i];
     }
-    std::vector<int> frc(n_files, MP3S_OK);
     if (n_files == 1) m.scanned[0] = std::move(c->spare_scan);   // its capacity: no fresh pages for the blob of a long file
-    parallel_files(n_files, total, [&](int i) { frc[i] = front_end(m, i); });
+    parallel_files(n_files, total, [&](int i) { if (!frc[i]) frc[i] = front_end(m, i); });
     for (int i = 0; i < n_files; i++) {
-        if (frc[i]) { delete b; return fail(frc[i], "file %d: malformed or unsupported MP3 stream", i); }
+        if (frc[i]) {
+            if (!status) { delete b; return fail(frc[i], "file %d: malformed or unsupported MP3 stream", i); }
+            m.parsed[i] = ParsedStream();        // nothing of it goes into a batch
+            continue;
+        }
         if (m.parsed[i].n_frames > 0) group[m.parsed[i].nch].push_back(i);
     }
     for (int nch = 1; nch <= 2; nch++)
         if (!group[nch].empty()) {
-            const int rc = decode_group(c, m, group[nch], nch, out_format);
+            int rc = decode_group(c, m, group[nch], nch, out_format);
+            if (rc && status && group[nch].size() > 1) {
+                // one stream spoils its batch (main data the host parser rejects): each file on its own, to name it.
+                // (The arena of this channel count is re-used per file, so the good files are decoded a second time as a
+                // batch once the bad ones are known.)
+                std::vector<int> good;
+                for (int i : group[nch]) {
+                    const int r1 = decode_group(c, m, std::vector<int>{i}, nch, out_format);
+                    if (r1) { frc[i] = r1; m.parsed[i] = ParsedStream(); m.pcm[i] = nullptr; }
+                    else good.push_back(i);
+                }
+                rc = good.empty() ? MP3S_OK : decode_group(c, m, good, nch, out_format);
+            } else if (rc && status) {
+                frc[group[nch][0]] = rc; m.parsed[group[nch][0]] = ParsedStream(); m.pcm[group[nch][0]] = nullptr;
+                rc = MP3S_OK;
+            }
             if (rc) { delete b; return rc; }
         }
     for (int i = 0; i < n_files; i++) {
         const ParsedStream &p = m.parsed[i];
+        std::memset(&out[i], 0, sizeof out[i]);
+        if (status) status[i] = frc[i];
+        if (frc[i]) continue;
         out[i].n_frames = p.n_frames; out[i].nch = p.nch; out[i].sampling_rate = p.sampling_rate; out[i].bit_rate = p.bit_rate;
         out[i].n_bits = (int32_t)p.bits.size(); out[i].n_rows = (int64_t)1152 * (p.n_frames + p.dup_last_frame);
         out[i].pcm = m.pcm[i]; out[i].bits = p.bits.data();
     }
     if (n_files == 1) c->spare_scan = std::move(m.scanned[0]);   // (the result refers to the parse and the PCM only)
+    m.files.clear();   // borrowed
     *owner = b;
     return MP3S_OK;
 }
 
 int mp3s_decode_streams(mp3s_ctx *c, const uint8_t *const *files, const size_t *lens, int n_files, int out_format,
-                        mp3s_buf **owner, mp3s_decoded *out)
+                        mp3s_buf **owner, mp3s_decoded *out, int32_t *status)
 {
-    return decode_streams_impl(c, files, lens, n_files, out_format, 0, owner, out);
+    return decode_streams_impl(c, files, lens, n_files, out_format, 0, owner, out, status);
 }
 
 int mp3s_decode_block(mp3s_ctx *c, const uint8_t *file, size_t len, int64_t first_frame, int64_t n_frames, int out_format,
@@ -298,7 +325,7 @@ int mp3s_decode_block(mp3s_ctx *c, const uint8_t *file, size_t len, int64_t firs
 int mp3s_decode_stream(mp3s_ctx *c, const uint8_t *file, size_t len, int out_format, mp3s_buf **owner, mp3s_decoded *out)
 {
     if (!file) return fail(MP3S_E_ARG, "null pointer");
-    return mp3s_decode_streams(c, &file, &len, 1, out_format, owner, out);
+    return mp3s_decode_streams(c, &file, &len, 1, out_format, owner, out, nullptr);
 }
 
 int mp3s_decode_file(mp3s_ctx *c, const uint8_t *mp3, size_t len, mp3s_buf **owner, mp3s_file *out)
@@ -307,7 +334,7 @@ int mp3s_decode_file(mp3s_ctx *c, const uint8_t *mp3, size_t len, mp3s_buf **own
     // the PCM lands 64 bytes into its buffer; the 44-byte WAV header goes right in front of it: no second copy
     mp3s_buf *b = nullptr;
     mp3s_decoded d;
-    const int rc = decode_streams_impl(c, &mp3, &len, 1, MP3S_PCM_I16, 64, &b, &d);
+    const int rc = decode_streams_impl(c, &mp3, &len, 1, MP3S_PCM_I16, 64, &b, &d, nullptr);
     if (rc) return rc;
     uint8_t *wav;
     if (d.n_rows == 0) {   // nothing decoded: what scipy writes for an empty 1-d array at the header object's initial rate 0

@@ -185,7 +185,7 @@ def lib():
         L.mp3s_debug_parse_scanned_frame.argtypes = [vp, vp, vp, vp]
         L.mp3s_rate_frames.argtypes = [i32, i32, i32, i32, vp, vp]
         L.mp3s_decode_stream.argtypes = [vp, vp, sz, i32, pvp, C.POINTER(Decoded)]
-        L.mp3s_decode_streams.argtypes = [vp, pvp, C.POINTER(sz), i32, i32, pvp, C.POINTER(Decoded)]
+        L.mp3s_decode_streams.argtypes = [vp, pvp, C.POINTER(sz), i32, i32, pvp, C.POINTER(Decoded), vp]
         L.mp3s_encode_pcm.argtypes = [vp, vp, i64, i32, i32, i32, vp, i32, pvp, C.POINTER(Encoded)]
         psz = C.POINTER(sz)
         L.mp3s_wav_parse.argtypes = [vp, sz, i32, C.POINTER(WavInfo)]
@@ -383,8 +383,10 @@ class Context:
         return {"n_frames": d.n_frames, "channels": d.nch, "sampling_rate": d.sampling_rate, "bit_rate": d.bit_rate,
                 "pcm": _view_owned(d.pcm, dt, (d.n_rows, d.nch), own), "bits": _view(d.bits, np.uint8, (d.n_bits,))}
 
-    def decode_streams(self, files, out_format=MP3S_PCM_I16):
-        """Decode many MP3 files as one device batch (one Huffman + one transform launch per channel count)."""
+    def decode_streams(self, files, out_format=MP3S_PCM_I16, per_file=False):
+        """Decode many MP3 files as one device batch (one Huffman + one transform launch per channel count).
+        per_file=True: a file that cannot be decoded yields the Mp3sError it alone would raise, the others are unaffected;
+        otherwise the first such file fails the call."""
         n = len(files)
         if n == 0:
             return []
@@ -393,11 +395,13 @@ class Context:
         lens = (C.c_size_t * n)(*[len(f) for f in files])
         owner = C.c_void_p()
         d = (Decoded * n)()
-        check(lib().mp3s_decode_streams(self.handle, ptrs, lens, n, out_format, C.byref(owner), d))
+        status = (C.c_int32 * n)()
+        check(lib().mp3s_decode_streams(self.handle, ptrs, lens, n, out_format, C.byref(owner), d, status if per_file else None))
         own = _Owner(owner)
         dt = {MP3S_PCM_I16: np.int16, MP3S_PCM_F32: np.float32, MP3S_PCM_F64: np.float64}[out_format]
-        return [{"n_frames": x.n_frames, "channels": x.nch, "sampling_rate": x.sampling_rate, "bit_rate": x.bit_rate,
-                 "pcm": _view_owned(x.pcm, dt, (x.n_rows, x.nch), own), "bits": _view(x.bits, np.uint8, (x.n_bits,))} for x in d]
+        return [Mp3sError(status[i], f"file {i}") if per_file and status[i] else
+                {"n_frames": x.n_frames, "channels": x.nch, "sampling_rate": x.sampling_rate, "bit_rate": x.bit_rate,
+                 "pcm": _view_owned(x.pcm, dt, (x.n_rows, x.nch), own), "bits": _view(x.bits, np.uint8, (x.n_bits,))} for i, x in enumerate(d)]
 
     def encode_pcm(self, pcm_i16, samplerate, bitrate, hide_bits=None):
         pcm_i16 = np.ascontiguousarray(pcm_i16, dtype=np.int16)

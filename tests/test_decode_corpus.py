@@ -140,3 +140,24 @@ def test_many_streams_rejects_a_malformed_member(ctx, mlib, corpus):
     out = ctx.decode_streams([good, b"\x00" * 64, good])
     assert out[1]["n_frames"] == 0 and out[1]["pcm"].size == 0 and out[1]["bit_rate"] == 0
     assert np.array_equal(out[0]["pcm"], out[2]["pcm"]) and out[0]["n_frames"] > 0
+
+
+@pytest.mark.gpu
+def test_many_streams_per_file_status(ctx, mlib, corpus):
+    """per_file=True: every member gets its own status (what the single-file call fails with), the others decode as in a
+    batch of their own -- the rule mp3s_hide_messages already follows"""
+    g, names = corpus
+    files = [g[n + "__mp3"].tobytes() for n in names]
+    bad = [b"\xff\xfb\x90", b"", b"\xff\xfb\x90\x64" + b"\x00" * 10]
+    mixed = [files[0], bad[0], files[1], bad[1], files[2], bad[2]] + files[3:]
+    out = ctx.decode_streams(mixed, mlib.MP3S_PCM_F64, per_file=True)
+    assert len(out) == len(mixed)
+    for i, (f, r) in enumerate(zip(mixed, out)):
+        try:
+            single = ctx.decode_stream(f, mlib.MP3S_PCM_F64)
+        except mlib.Mp3sError as e:
+            assert isinstance(r, mlib.Mp3sError) and r.code == e.code, (i, r, e)
+            continue
+        assert not isinstance(r, Exception), (i, r)
+        assert r["pcm"].tobytes() == single["pcm"].tobytes() and np.array_equal(r["bits"], single["bits"]), i
+    assert sum(isinstance(r, Exception) for r in out) >= 2
