@@ -343,6 +343,30 @@ int mp3s_decode_streams(mp3s_ctx *ctx, const uint8_t *const *files, const size_t
 int mp3s_decode_block(mp3s_ctx *ctx, const uint8_t *file, size_t len, int64_t first_frame, int64_t n_frames, int out_format,
                       mp3s_buf **owner, mp3s_decoded *out);
 
+/* Index of a stream: ONE walk over its frames (headers, side info, reservoir pointers; no main data is copied) that leaves
+ * a resume point every 256 frames.  With it a block of the stream is scanned on its own -- the ranks of a sharded stream
+ * and the chunks of a streamed file pay for their own frames (plus at most 255 skipped ones), not for the whole file again
+ * (reference: none -- it reads the whole file into memory, decoder/decoder.py:26-27, and loops over it once,
+ * decoder/MP3_Parser.py:68-80).  The index is plain host data, bound to the file bytes it was made from. */
+typedef struct mp3s_index mp3s_index;
+typedef struct {
+    int64_t n_frames;
+    int32_t nch, sampling_rate, bit_rate;   /* of the LAST frame header, as mp3s_scan_stream reports them */
+    int32_t dup_last_frame;
+    int32_t gpu_ok;                         /* 0: a stream the host parser has to take (mp3s_scanned.gpu_ok): block calls then scan the whole file */
+    int32_t reserved;
+} mp3s_index_info;
+int mp3s_index_stream(const uint8_t *file, size_t len, mp3s_index **index, mp3s_index_info *info);
+void mp3s_index_free(mp3s_index *index);
+/* mp3s_scan_stream for frames [first_frame, first_frame + n_frames) only (clipped to the stream): side records, main-data
+ * blob, headers, frame sizes and the stego bits OF THESE FRAMES, identical to the corresponding part of the full scan */
+int mp3s_scan_range(const uint8_t *file, size_t len, const mp3s_index *index, int64_t first_frame, int64_t n_frames, mp3s_buf **owner,
+                    mp3s_scanned *out);
+/* mp3s_decode_block with the block scanned on its own; out->bits / n_bits then describe the block's frames (the halo frame in
+ * front included), not the whole stream.  index == NULL: exactly mp3s_decode_block. */
+int mp3s_decode_block_indexed(mp3s_ctx *ctx, const uint8_t *file, size_t len, const mp3s_index *index, int64_t first_frame,
+                              int64_t n_frames, int out_format, mp3s_buf **owner, mp3s_decoded *out);
+
 /* replaces: Encoder.encode -- reference encoder/encoder.py:33-58, MP3_Encoder.py:596-618 */
 typedef struct {
     int32_t n_frames;
@@ -445,6 +469,15 @@ typedef struct {
 } mp3s_block;
 int mp3s_reencode_block(mp3s_ctx *ctx, const uint8_t *mp3, size_t len, const uint8_t *utf8, size_t n_msg, int rank, int world,
                         const mp3s_carry *carry_in, mp3s_buf **owner, mp3s_block *out);
+/* mp3s_reencode_block with the block scanned on its own (index == NULL: exactly mp3s_reencode_block) */
+int mp3s_reencode_block_indexed(mp3s_ctx *ctx, const uint8_t *mp3, size_t len, const mp3s_index *index, const uint8_t *utf8, size_t n_msg,
+                                int rank, int world, const mp3s_carry *carry_in, mp3s_buf **owner, mp3s_block *out);
+/* mp3s_hide_message (utf8 != NULL) / mp3s_clear_file (NULL) on a file of any length in chunks of at most chunk_frames frames:
+ * one index walk, then chunk after chunk through the device, each scanned on its own and run on the real carry of the one in
+ * front of it (streaming for files larger than the device / page-locked buffers should take at once).  The
+ * device and staging memory in use is that of one chunk; the result is byte-identical to the one-call functions. */
+int mp3s_hide_message_chunked(mp3s_ctx *ctx, const uint8_t *mp3, size_t len, const uint8_t *utf8, size_t n_msg, int64_t chunk_frames,
+                              mp3s_buf **owner, mp3s_file *out);
 /* replaces: Steganography.reveal_massage -- reference steganography.py:103-131: MP3 bytes -> message text.  Only the
  * byte-level scan runs (table_select lives in the side info), so no device work and no context are needed. */
 int mp3s_reveal_message(const uint8_t *mp3, size_t len, mp3s_buf **owner, mp3s_file *out);

@@ -29,6 +29,18 @@ int front_end(mp3s_multi &m, int i)
 {
     ParsedStream &p = m.parsed[i];
     ScannedStream &sc = m.scanned[i];
+    if (m.index && index_info(m.index).gpu_ok && (size_t)i < m.window.size()) {
+        // the window alone, from the resume point in front of it
+        const StreamIndexInfo &info = index_info(m.index);
+        const long first = std::min(std::max(m.window[i].first, 0L), info.n_frames);
+        const long count = std::min(std::max(m.window[i].count, 0L), info.n_frames - first);
+        const int rc = parse_stream_range(m.files[i].first, m.files[i].second, m.index, first, count, p, sc);
+        if (rc) return rc;
+        p.nch = info.nch; p.sampling_rate = info.sampling_rate; p.bit_rate = info.bit_rate;
+        p.dup_last_frame = (first + count >= info.n_frames && m.window[i].keep_dup) ? info.dup_last_frame : 0;
+        if ((size_t)i < m.all_bits.size()) m.all_bits[i] = p.bits;
+        return MP3S_OK;
+    }
     int rc = parse_stream(m.files[i].first, m.files[i].second, p, &sc);
     if (!rc && !sc.gpu_ok) {
         rc = parse_stream(m.files[i].first, m.files[i].second, p, nullptr);
@@ -293,6 +305,49 @@ int mp3s_decode_streams(mp3s_ctx *c, const uint8_t *const *files, const size_t *
 int mp3s_decode_block(mp3s_ctx *c, const uint8_t *file, size_t len, int64_t first_frame, int64_t n_frames, int out_format,
                       mp3s_buf **owner, mp3s_decoded *out)
 {
+    return mp3s_decode_block_indexed(c, file, len, nullptr, first_frame, n_frames, out_format, owner, out);
+}
+
+int mp3s_index_stream(const uint8_t *file, size_t len, mp3s_index **index, mp3s_index_info *info)
+{
+    if (!file || !index) return fail(MP3S_E_ARG, "null pointer");
+    int rc = 0;
+    StreamIndexInfo si;
+    StreamIndex *ix = index_stream(file, len, &si, &rc);
+    if (!ix) return fail(rc ? rc : MP3S_E_NOMEM, "malformed or unsupported MP3 stream");
+    *index = reinterpret_cast<mp3s_index *>(ix);
+    if (info) {
+        info->n_frames = si.n_frames; info->nch = si.nch; info->sampling_rate = si.sampling_rate; info->bit_rate = si.bit_rate;
+        info->dup_last_frame = si.dup_last_frame; info->gpu_ok = si.gpu_ok ? 1 : 0;
+    }
+    return MP3S_OK;
+}
+
+void mp3s_index_free(mp3s_index *index) { index_free(reinterpret_cast<StreamIndex *>(index)); }
+
+int mp3s_scan_range(const uint8_t *file, size_t len, const mp3s_index *index, int64_t first_frame, int64_t n_frames, mp3s_buf **owner,
+                    mp3s_scanned *out)
+{
+    if (!file || !index || !owner || !out || first_frame < 0 || n_frames < 0) return fail(MP3S_E_ARG, "bad argument");
+    mp3s_buf *b = new mp3s_buf();
+    const int rc = parse_stream_range(file, len, reinterpret_cast<const StreamIndex *>(index), (long)first_frame, (long)n_frames, b->parsed, b->scanned);
+    if (rc) { delete b; return fail(rc, "malformed or unsupported MP3 stream"); }
+    const ParsedStream &p = b->parsed;
+    const StreamIndexInfo &info = index_info(reinterpret_cast<const StreamIndex *>(index));
+    out->n_frames = p.n_frames; out->nch = info.nch; out->sampling_rate = info.sampling_rate; out->bit_rate = info.bit_rate;
+    out->n_bits = (int32_t)p.bits.size(); out->dup_last_frame = first_frame + p.n_frames >= info.n_frames ? info.dup_last_frame : 0;
+    out->gpu_ok = b->scanned.gpu_ok ? 1 : 0;
+    out->max_part2_3_length = max_part2_3(b->scanned.side.data(), p.n_frames);
+    out->side = b->scanned.side.data(); out->hdr = p.hdr.data();
+    out->blob = b->scanned.blob.data(); out->blob_len = b->scanned.blob.size();
+    out->bits = p.bits.data(); out->frame_size = p.frame_size.data();
+    *owner = b;
+    return MP3S_OK;
+}
+
+int mp3s_decode_block_indexed(mp3s_ctx *c, const uint8_t *file, size_t len, const mp3s_index *index, int64_t first_frame, int64_t n_frames,
+                              int out_format, mp3s_buf **owner, mp3s_decoded *out)
+{
     if (!c || !file || !owner || !out || first_frame < 0 || n_frames <= 0 || first_frame > 0x7fffffff || n_frames > 0x7fffffff)
         return fail(MP3S_E_ARG, "bad argument");
     if (out_format < 0 || out_format > 2) return fail(MP3S_E_ARG, "out_format=%d", out_format);
@@ -305,7 +360,9 @@ int mp3s_decode_block(mp3s_ctx *c, const uint8_t *file, size_t len, int64_t firs
     m.parsed.resize(1); m.scanned.resize(1); m.pcm.assign(1, nullptr); m.files.assign(1, {file, len});
     m.window.assign(1, {(long)first_frame - halo, (long)n_frames + halo, true});
     m.all_bits.resize(1);
+    m.index = reinterpret_cast<const StreamIndex *>(index);
     int rc = front_end(m, 0);
+    m.index = nullptr;
     if (rc) return fail(rc, "malformed or unsupported MP3 stream");
     const ParsedStream &p = m.parsed[0];
     if (p.n_frames <= halo) return fail(MP3S_E_ARG, "the block starts behind the last frame of the stream");

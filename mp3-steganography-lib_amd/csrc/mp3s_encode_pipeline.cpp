@@ -592,15 +592,28 @@ int mp3s_hide_messages(mp3s_ctx *c, const uint8_t *const *mp3s, const size_t *le
 int mp3s_reencode_block(mp3s_ctx *c, const uint8_t *mp3, size_t len, const uint8_t *utf8, size_t n_msg, int rank, int world,
                         const mp3s_carry *carry_in, mp3s_buf **owner, mp3s_block *out)
 {
+    return mp3s_reencode_block_indexed(c, mp3, len, nullptr, utf8, n_msg, rank, world, carry_in, owner, out);
+}
+
+int mp3s_reencode_block_indexed(mp3s_ctx *c, const uint8_t *mp3, size_t len, const mp3s_index *index, const uint8_t *utf8, size_t n_msg,
+                                int rank, int world, const mp3s_carry *carry_in, mp3s_buf **owner, mp3s_block *out)
+{
     if (!c || !mp3 || !owner || !out || world <= 0 || rank < 0 || rank >= world || (rank == 0 && carry_in) || (rank > 0 && !carry_in))
         return fail(MP3S_E_ARG, "bad argument (rank 0 has no carry, every other rank has one)");
     std::unique_ptr<mp3s_buf> top(new mp3s_buf());
     top->multi.reset(new mp3s_multi());
     mp3s_multi &m = *top->multi;
     m.parsed.resize(1); m.scanned.resize(1); m.pcm.assign(1, nullptr); m.files.assign(1, {mp3, len});
-    int rc = front_end(m, 0);
-    if (rc) return fail(rc, "malformed or unsupported MP3 stream");
+    const StreamIndex *ix = reinterpret_cast<const StreamIndex *>(index);
+    const bool ranged = ix && index_info(ix).gpu_ok;      // scan the block alone; otherwise the whole file, then cut
+    int rc = MP3S_OK;
     ParsedStream &p = m.parsed[0];
+    if (ranged) {
+        const StreamIndexInfo &info = index_info(ix);
+        p.n_frames = (int)info.n_frames; p.nch = info.nch; p.sampling_rate = info.sampling_rate; p.bit_rate = info.bit_rate;
+        p.dup_last_frame = info.dup_last_frame;
+    } else rc = front_end(m, 0);
+    if (rc) return fail(rc, "malformed or unsupported MP3 stream");
     int kbps = 0;
     rc = reencode_check(p, &kbps);
     if (rc) return rc;
@@ -621,7 +634,12 @@ int mp3s_reencode_block(mp3s_ctx *c, const uint8_t *mp3, size_t len, const uint8
     const long w0 = first - lead - halo, w1 = std::min(first + count, n);
     const bool with_dup = first + count == total && p.dup_last_frame;
     m.window.assign(1, {w0, w1 - w0, with_dup});
-    cut_window(p, m.scanned[0], w0, w1 - w0);
+    if (ranged) {
+        m.index = ix;
+        rc = front_end(m, 0);
+        m.index = nullptr;
+        if (rc) return fail(rc, "malformed or unsupported MP3 stream");
+    } else cut_window(p, m.scanned[0], w0, w1 - w0);
     if (!with_dup) p.dup_last_frame = 0;
     const int64_t rows_frames = (w1 - w0) + (with_dup ? 1 : 0);
     if (hipSetDevice(c->device) != hipSuccess) return fail(MP3S_E_HIP, "hipSetDevice failed");
@@ -642,6 +660,41 @@ int mp3s_reencode_block(mp3s_ctx *c, const uint8_t *mp3, size_t len, const uint8
     out->file.too_long = s.hide_offset < (int64_t)s.n_hide - 1 ? 1 : 0;
     top->parts.push_back(std::move(part));
     m.files.clear();
+    *owner = top.release();
+    return MP3S_OK;
+}
+
+int mp3s_hide_message_chunked(mp3s_ctx *c, const uint8_t *mp3, size_t len, const uint8_t *utf8, size_t n_msg, int64_t chunk_frames,
+                              mp3s_buf **owner, mp3s_file *out)
+{
+    if (!c || !mp3 || !owner || !out || chunk_frames < 2) return fail(MP3S_E_ARG, "bad argument (chunks of at least 2 frames)");
+    mp3s_index *index = nullptr;
+    mp3s_index_info info;
+    int rc = mp3s_index_stream(mp3, len, &index, &info);
+    if (rc) return rc;
+    const int64_t total = info.n_frames + (info.dup_last_frame ? 1 : 0);
+    const int64_t world64 = std::max<int64_t>(1, (total + chunk_frames - 1) / chunk_frames);
+    if (world64 > 0x7fffffff) { mp3s_index_free(index); return fail(MP3S_E_ARG, "too many chunks"); }
+    const int world = (int)world64;
+    std::unique_ptr<mp3s_buf> top(new mp3s_buf());
+    mp3s_carry carry;
+    std::memset(out, 0, sizeof *out);
+    for (int r = 0; r < world && !rc; r++) {
+        mp3s_buf *part = nullptr;
+        mp3s_block blk;
+        rc = mp3s_reencode_block_indexed(c, mp3, len, index, utf8, n_msg, r, world, r ? &carry : nullptr, &part, &blk);
+        if (rc) break;
+        // every chunk runs on the real carry of the one in front of it: nothing is guessed, nothing re-run
+        carry = blk.carry_out;
+        if (blk.file.len) top->bytes.insert(top->bytes.end(), blk.file.data, blk.file.data + blk.file.len);
+        out->kbps = blk.file.kbps; out->sampling_rate = blk.file.sampling_rate; out->channels = blk.file.channels;
+        out->n_frames += (int32_t)blk.n_frames;
+        if (blk.n_frames) { out->too_long = blk.file.too_long; out->hide_offset = blk.file.hide_offset; }
+        mp3s_buf_free(part);
+    }
+    mp3s_index_free(index);
+    if (rc) return rc;
+    out->data = top->bytes.data(); out->len = top->bytes.size();
     *owner = top.release();
     return MP3S_OK;
 }

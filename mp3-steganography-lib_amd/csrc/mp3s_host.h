@@ -51,6 +51,25 @@ struct ScanSink {
 };
 int parse_stream_sink(const uint8_t *file, size_t len, ParsedStream &out, ScanSink *sink);
 
+// Index of a stream: one walk over its frames (headers, side info, reservoir pointers -- no main data copied, nothing
+// stored per frame) that leaves a resume point every 256 frames.  With it a block of the stream is scanned on its own:
+// parse_stream_range starts at the resume point in front of the block, so a rank of a sharded stream or a chunk of a
+// streamed file pays for its own frames only (plus at most 255 skipped ones), not for the whole file again.
+struct StreamIndex;
+struct StreamIndexInfo {
+    long n_frames = 0;
+    int nch = 0, sampling_rate = 0, bit_rate = 0;   // rate / bitrate of the LAST header, as parse_stream reports them
+    int dup_last_frame = 0;
+    bool gpu_ok = true;
+};
+StreamIndex *index_stream(const uint8_t *file, size_t len, StreamIndexInfo *info, int *rc);
+void index_free(StreamIndex *ix);
+const StreamIndexInfo &index_info(const StreamIndex *ix);
+// frames [first, first + count) (clipped to the stream) into the sink, exactly as parse_stream_sink would have stored them
+// (out.bits = the stego bits of these frames; out.dup_last_frame is not set: the index knows it)
+int parse_stream_range(const uint8_t *file, size_t len, const StreamIndex *ix, long first, long count, ParsedStream &out, ScanSink *sink);
+int parse_stream_range(const uint8_t *file, size_t len, const StreamIndex *ix, long first, long count, ParsedStream &out, ScannedStream &scan);
+
 // scalefactors + Huffman of ONE frame of a scanned stream (side record + its main data in the blob): the host's answer for
 // a frame the device Huffman kernel flags; exact for gpu_ok streams (no frame inherits anything from another)
 int parse_scanned_frame(const mp3s_frame_side &fs, const uint8_t *blob, int16_t *is2304, mp3s_granule_si *si4);

@@ -302,7 +302,81 @@ int parse_stream(const uint8_t *file, size_t flen, ParsedStream &out, ScannedStr
     return rc;
 }
 
-int parse_stream_sink(const uint8_t *file, size_t flen_, ParsedStream &out, ScanSink *scan)
+namespace {
+// where the frame loop stands in front of a frame: everything the reference's parser objects carry from frame to frame
+struct ScanState {
+    Header hd;
+    SideInfo si;
+    double prev_frame_size[9] = {0};
+    int frame_size = 0, first_nch = 0;
+    long offset = 0;
+    std::vector<uint8_t> main_data;     // of the frame before (reused when the reservoir pointer finds nothing: Frame.py:336-356)
+};
+}  // namespace
+
+// resume points of a stream, one every kIndexStep frames (the state in FRONT of frame k * kIndexStep)
+constexpr long kIndexStep = 256;
+struct StreamIndex {
+    std::vector<ScanState> at;
+    StreamIndexInfo info;
+};
+
+static int scan_core(const uint8_t *file, size_t flen_, ParsedStream &out, ScanSink *scan, const ScanState *resume, long skip,
+                     long max_frames, StreamIndex *record);
+
+int parse_stream_sink(const uint8_t *file, size_t flen, ParsedStream &out, ScanSink *scan)
+{
+    return scan_core(file, flen, out, scan, nullptr, 0, -1, nullptr);
+}
+
+StreamIndex *index_stream(const uint8_t *file, size_t len, StreamIndexInfo *info, int *rc_out)
+{
+    std::unique_ptr<StreamIndex> ix(new StreamIndex());
+    ParsedStream p;
+    ScanSink dry;                        // nothing is stored: every frame is "skipped", the state is recorded on the way
+    dry.lean = true;
+    const int rc = scan_core(file, len, p, &dry, nullptr, -1, -1, ix.get());
+    if (rc_out) *rc_out = rc;
+    if (rc) return nullptr;
+    ix->info.gpu_ok = dry.gpu_ok;
+    if (info) *info = ix->info;
+    return ix.release();
+}
+void index_free(StreamIndex *ix) { delete ix; }
+const StreamIndexInfo &index_info(const StreamIndex *ix) { return ix->info; }
+
+int parse_stream_range(const uint8_t *file, size_t len, const StreamIndex *ix, long first, long count, ParsedStream &out, ScanSink *sink)
+{
+    if (!ix || !sink || first < 0 || count < 0) return MP3S_E_ARG;
+    first = std::min(first, ix->info.n_frames);
+    count = std::min(count, ix->info.n_frames - first);
+    const size_t k = std::min<size_t>((size_t)(first / kIndexStep), ix->at.empty() ? 0 : ix->at.size() - 1);
+    if (ix->at.empty()) {               // a stream without a frame
+        out = ParsedStream(); sink->blob_len = 0; sink->n_side = 0;
+        return 0;
+    }
+    return scan_core(file, len, out, sink, &ix->at[k], first - (long)k * kIndexStep, count, nullptr);
+}
+
+int parse_stream_range(const uint8_t *file, size_t len, const StreamIndex *ix, long first, long count, ParsedStream &out, ScannedStream &scan)
+{
+    const size_t guess = (size_t)std::max<long>(count, 1) * 1500 + 4096;   // grows if the frames are larger
+    scan.blob.resize(std::max(scan.blob.capacity(), std::min(guess, len + len / 32 + 64)));
+    scan.side.resize(std::max<size_t>(scan.side.capacity(), (size_t)count + 1));
+    ScanSink k;
+    k.blob = scan.blob.data(); k.blob_cap = scan.blob.size();
+    k.side = scan.side.data(); k.side_cap = scan.side.size();
+    k.user = &scan; k.grow = grow_vectors;
+    const int rc = parse_stream_range(file, len, ix, first, count, out, &k);
+    scan.blob.resize(k.blob_len); scan.side.resize(k.n_side);
+    scan.gpu_ok = k.gpu_ok;
+    return rc;
+}
+
+// skip: frames in front of the first one to emit (state only, nothing stored; -1 = all of them); max_frames: frames to emit
+// (-1 = to the end of the stream); record: resume points + the stream's summary go there
+static int scan_core(const uint8_t *file, size_t flen_, ParsedStream &out, ScanSink *scan, const ScanState *resume, long skip,
+                     long max_frames, StreamIndex *record)
 {
     std::call_once(g_lut_once, build_luts);
     const HostTables &HT = host_tables();
@@ -322,19 +396,25 @@ int parse_stream_sink(const uint8_t *file, size_t flen_, ParsedStream &out, Scan
         if (scan->blob_len + extra <= scan->blob_cap) return true;
         return scan->grow && scan->grow(scan, scan->blob_len + extra, 0);
     };
+    ScanState st;
+    if (resume) st = *resume;
+    Header &hd = st.hd;
+    SideInfo &si = st.si;
+    double (&prev_frame_size)[9] = st.prev_frame_size;
+    int &frame_size = st.frame_size, &first_nch = st.first_nch;
+    long &offset = st.offset;
+    std::vector<uint8_t> &main_data = st.main_data;
+    long seen = 0;                       // frames passed since the start of this call (skipped ones included)
+    bool all_gpu_ok = true;
     // ID3v2 skip (decoder/ID3_Parser.py:95-131): only `offset` and `is_valid` matter to decoding
-    long offset = 0;
+    if (!resume) {
     if (flen >= 10 && file[0] == 'I' && file[1] == 'D' && file[2] == '3' && !(file[5] & 0x0f)) {
         long size = 0;
         for (int i = 0; i < 4; i++) size = (size << 7) + file[6 + i];
         offset = size + ((file[5] >> 4) & 1 ? 20 : 10);
     }
     if (flen - offset < 2) return MP3S_E_MALFORMED;   // the reference indexes buffer[0] and buffer[1] (MP3_Parser.py:37)
-    Header hd;
-    SideInfo si;
-    double prev_frame_size[9] = {0};
-    int frame_size = 0;
-    std::vector<uint8_t> main_data;
+    }
     auto set_frame_size = [&]() -> int {   // Frame.py:288-316
         int spf = 0;
         if (hd.layer == 3) spf = hd.version == 1 ? 1152 : 576;
@@ -348,19 +428,22 @@ int parse_stream_sink(const uint8_t *file, size_t flen_, ParsedStream &out, Scan
         return 0;
     };
     const uint8_t *buffer = file + offset;
-    bool valid = false;
-    if (buffer[0] == 0xFF && buffer[1] >= 0xE0) {
+    bool valid = resume != nullptr;
+    if (!resume && buffer[0] == 0xFF && buffer[1] >= 0xE0) {
         valid = true;
         if (flen - offset < 4) return MP3S_E_MALFORMED;   // a sync with no header behind it: IndexError in the reference
         int rc = parse_header(hd, buffer); if (rc) return rc;
         rc = set_frame_size(); if (rc) return rc;   // D11
     }
-    int first_nch = 0;
+    bool dup_last = false;
     while (valid && flen > offset + 4) {
+        if (max_frames >= 0 && out.n_frames >= max_frames) break;        // the caller's range ends here
+        const bool dry = skip < 0 || seen < skip;                        // state only: nothing of this frame is stored
+        if (record && seen % kIndexStep == 0) record->at.push_back(st);
         buffer = file + offset;
         const long buflen = flen - offset;
         if (buffer[0] == 0xFF && buffer[1] >= 0xE0) { int rc = parse_header(hd, buffer); if (rc) return rc; }
-        else { valid = false; out.dup_last_frame = out.n_frames > 0 ? 1 : 0; break; }   // D12
+        else { valid = false; dup_last = seen > 0 || resume; out.dup_last_frame = out.n_frames > 0 ? 1 : 0; break; }   // D12
         int rc = set_frame_size(); if (rc) return rc;
         // D16: band tables exist for 32 / 44.1 / 48 kHz only and are chosen by the sampling rate alone (FrameHeader.py:125-143);
         // a header with another rate keeps the tables of the frame before it, a stream that starts with one has none
@@ -406,8 +489,17 @@ int parse_stream_sink(const uint8_t *file, size_t flen_, ParsedStream &out, Scan
                 si.scalefac_scale[gr][ch] = sb.get(off, 1); off += 1;
                 si.count1table[gr][ch] = sb.get(off, 1); off += 1;
             }
+        // scalefactors that requantisation would read without this frame having written them (D10): mixed blocks, and
+        // scfsi reuse when granule 0 carried short-block scalefactors -- such a stream is parsed on the host
+        for (int ch = 0; ch < nch; ch++) {
+            const bool g0_short = si.window_switching[0][ch] && si.block_type[0][ch] == 2;
+            const bool g1_short = si.window_switching[1][ch] && si.block_type[1][ch] == 2;
+            if ((si.window_switching[0][ch] && si.mixed[0][ch]) || (si.window_switching[1][ch] && si.mixed[1][ch]) ||
+                (g0_short && !g1_short && (si.scfsi[ch][0] | si.scfsi[ch][1] | si.scfsi[ch][2] | si.scfsi[ch][3])))
+                all_gpu_ok = false;
+        }
         // ---- stego bits: ch -> gr -> region, zeros skipped, H0 -> 0
-        if (!(scan && scan->lean))
+        if (!dry && !(scan && scan->lean))
         for (int ch = 0; ch < nch; ch++)
             for (int gr = 0; gr < 2; gr++)
                 for (int r = 0; r < 3; r++) {
@@ -419,14 +511,15 @@ int parse_stream_sink(const uint8_t *file, size_t flen_, ParsedStream &out, Scan
         if (hd.crc == 0) constant += 2;
         size_t md_start = 0;
         bool full = false;                       // a sink of fixed capacity ran out of room
-        if (scan) {
+        const bool to_blob = scan && !dry;
+        if (to_blob) {
             if (!blob_room(4)) return MP3S_E_NOMEM;
             while (scan->blob_len & 3) scan->blob[scan->blob_len++] = 0;
             md_start = scan->blob_len;
         }
         // Python list slicing data[start:stop] appended to the frame's main data (the blob in scan mode)
         auto md_append = [&](const uint8_t *data, long n, long start, long stop) {
-            if (!scan) { py_slice_append(main_data, data, n, start, stop); return; }
+            if (!to_blob) { py_slice_append(main_data, data, n, start, stop); return; }
             if (start < 0) { start += n; if (start < 0) start = 0; }
             if (stop < 0) { stop += n; if (stop < 0) stop = 0; }
             if (start > n) start = n;
@@ -438,7 +531,7 @@ int parse_stream_sink(const uint8_t *file, size_t flen_, ParsedStream &out, Scan
         };
         bool rebuilt = false;
         if (si.main_data_begin == 0) {
-            if (!scan) main_data.clear();
+            if (!to_blob) main_data.clear();
             md_append(buffer, buflen, constant, frame_size);
             rebuilt = true;
         } else {
@@ -450,7 +543,7 @@ int parse_stream_sink(const uint8_t *file, size_t flen_, ParsedStream &out, Scan
                     double part[9] = {0};
                     part[fr] = si.main_data_begin;
                     for (int i = 0; i < fr; i++) { part[i] = prev_frame_size[i] - constant; part[fr] -= part[i]; }
-                    if (!scan) main_data.clear();
+                    if (!to_blob) main_data.clear();
                     long loc = (long)(offset - ptr_offset);
                     md_append(file, flen, loc, loc + (long)part[fr]);
                     ptr_offset -= (part[fr] + constant);
@@ -467,6 +560,7 @@ int parse_stream_sink(const uint8_t *file, size_t flen_, ParsedStream &out, Scan
         }
         Bits mb{main_data.data(), (long)main_data.size()};
 
+        if (dry) { seen++; offset += frame_size; continue; }
         if (scan) {
             // ---- scan mode: record the side info; the main data sits in the blob already
             mp3s_frame_side fs;
@@ -477,7 +571,12 @@ int parse_stream_sink(const uint8_t *file, size_t flen_, ParsedStream &out, Scan
                 if (!blob_room(pv.md_len)) return MP3S_E_NOMEM;
                 std::memmove(scan->blob + scan->blob_len, scan->blob + pv.md_off, pv.md_len);   // (the room may have moved the blob)
                 scan->blob_len += pv.md_len;
+            } else if (!rebuilt && !main_data.empty()) {   // the frame before was skipped: its main data is in the state
+                if (!blob_room(main_data.size())) return MP3S_E_NOMEM;
+                std::memcpy(scan->blob + scan->blob_len, main_data.data(), main_data.size());
+                scan->blob_len += main_data.size();
             }
+            // (a skipped frame that follows an emitted one does not occur: the skipped frames come first)
             if (full || !blob_room(8)) return MP3S_E_NOMEM;
             fs.md_off = (uint32_t)md_start;
             fs.md_len = (uint32_t)(scan->blob_len - md_start);
@@ -499,20 +598,10 @@ int parse_stream_sink(const uint8_t *file, size_t flen_, ParsedStream &out, Scan
                     u.preflag = (uint8_t)si.preflag[gr][ch]; u.scalefac_scale = (uint8_t)si.scalefac_scale[gr][ch];
                     u.count1table_select = (uint8_t)si.count1table[gr][ch];
                     for (int w = 0; w < 3; w++) u.sub_block_gain[w] = (uint8_t)si.sub_block_gain[gr][ch][w];
-                    // scalefactors that requantisation would read without this frame having written them (D10):
-                    // mixed blocks, and scfsi reuse when granule 0 carried short-block scalefactors
-                    if (u.window_switching && u.mixed_block_flag) scan->gpu_ok = false;
                     if (!scan->lean)
                         for (int r = 0; r < 3; r++)
                             out.table_select[((size_t)out.n_frames * 4 + gr * 2 + ch) * 3 + r] = si.table_select[gr][ch][r];
                 }
-            for (int ch = 0; ch < nch; ch++) {
-                const mp3s_unit_side &g0 = fs.unit[0][ch], &g1 = fs.unit[1][ch];
-                const bool g0_short = g0.window_switching && g0.block_type == 2;
-                const bool g1_short = g1.window_switching && g1.block_type == 2;
-                if (g0_short && !g1_short && (fs.scfsi[ch][0] | fs.scfsi[ch][1] | fs.scfsi[ch][2] | fs.scfsi[ch][3]))
-                    scan->gpu_ok = false;
-            }
             if (scan->n_side >= scan->side_cap && !(scan->grow && scan->grow(scan, 0, scan->n_side + 1))) return MP3S_E_NOMEM;
             scan->side[scan->n_side++] = fs;
         } else {
@@ -533,11 +622,17 @@ int parse_stream_sink(const uint8_t *file, size_t flen_, ParsedStream &out, Scan
         else out.hdr.push_back(fh);
         if (!(scan && scan->lean)) out.frame_size.push_back(frame_size);
         out.n_frames++;
+        seen++;
         offset += frame_size;
     }
     out.nch = first_nch ? first_nch : hd.channels;
     out.sampling_rate = hd.sampling_rate;
     out.bit_rate = hd.bit_rate;
+    if (scan) scan->gpu_ok = all_gpu_ok;
+    if (record) {
+        record->info.n_frames = seen; record->info.nch = out.nch; record->info.sampling_rate = hd.sampling_rate;
+        record->info.bit_rate = hd.bit_rate; record->info.dup_last_frame = dup_last && seen > 0 ? 1 : 0;
+    }
     return 0;
 }
 

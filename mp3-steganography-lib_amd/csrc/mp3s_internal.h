@@ -152,6 +152,9 @@ struct mp3s_multi {     // owner payload of mp3s_decode_streams
     struct Window { long first, count; bool keep_dup; };
     std::vector<Window> window;
     std::vector<std::vector<uint8_t>> all_bits;   // ... and the stego bits of the whole stream
+    // an index of the (single) stream: its window is scanned on its own, from the resume point in front of it, instead of
+    // the whole file (then all_bits holds the bits of the window's frames only)
+    const StreamIndex *index = nullptr;
 };
 
 struct mp3s_buf {

@@ -109,6 +109,11 @@ class File(C.Structure):
                 ("hide_offset", C.c_int64), ("bits", C.c_void_p)]
 
 
+class IndexInfo(C.Structure):
+    _fields_ = [("n_frames", C.c_int64), ("nch", C.c_int32), ("sampling_rate", C.c_int32), ("bit_rate", C.c_int32),
+                ("dup_last_frame", C.c_int32), ("gpu_ok", C.c_int32), ("reserved", C.c_int32)]
+
+
 class PipeStats(C.Structure):
     _fields_ = [("submitted", C.c_int64), ("collected", C.c_int64), ("fast", C.c_int64), ("slow", C.c_int64),
                 ("scan_ms", C.c_double), ("issue_ms", C.c_double), ("last_device_span_ms", C.c_double), ("scan_cpu_ms", C.c_double)]
@@ -127,7 +132,9 @@ SYMBOLS = ["mp3s_ctx_create", "mp3s_ctx_destroy", "mp3s_ctx_wait", "mp3s_last_er
            "mp3s_parse_stream", "mp3s_format_stream", "mp3s_rate_frames", "mp3s_decode_stream", "mp3s_decode_streams", "mp3s_decode_block", "mp3s_encode_pcm", "mp3s_encode_block",
            "mp3s_wav_parse", "mp3s_wav_header", "mp3s_message_frame", "mp3s_message_reveal", "mp3s_decode_file", "mp3s_encode_file",
            "mp3s_hide_message", "mp3s_clear_file", "mp3s_hide_messages", "mp3s_reencode_block", "mp3s_reveal_message",
-           "mp3s_pipe_create", "mp3s_pipe_destroy", "mp3s_pipe_submit", "mp3s_pipe_collect", "mp3s_pipe_get_stats"]
+           "mp3s_pipe_create", "mp3s_pipe_destroy", "mp3s_pipe_submit", "mp3s_pipe_collect", "mp3s_pipe_get_stats",
+           "mp3s_index_stream", "mp3s_index_free", "mp3s_scan_range", "mp3s_decode_block_indexed", "mp3s_reencode_block_indexed",
+           "mp3s_hide_message_chunked"]
 
 _lib = None
 _lock = threading.Lock()
@@ -202,6 +209,13 @@ def lib():
         L.mp3s_reencode_block.argtypes = [vp, vp, sz, vp, sz, i32, i32, C.POINTER(Carry), pvp, C.POINTER(Block)]
         L.mp3s_hide_messages.argtypes = [vp, vp, vp, i32, vp, vp, pvp, vp, vp]
         L.mp3s_reveal_message.argtypes = [vp, sz, pvp, C.POINTER(File)]
+        L.mp3s_index_stream.argtypes = [vp, sz, pvp, C.POINTER(IndexInfo)]
+        L.mp3s_index_free.argtypes = [vp]
+        L.mp3s_index_free.restype = None
+        L.mp3s_scan_range.argtypes = [vp, sz, vp, C.c_int64, C.c_int64, pvp, C.POINTER(Scanned)]
+        L.mp3s_decode_block_indexed.argtypes = [vp, vp, sz, vp, C.c_int64, C.c_int64, i32, pvp, C.POINTER(Decoded)]
+        L.mp3s_reencode_block_indexed.argtypes = [vp, vp, sz, vp, vp, sz, i32, i32, C.POINTER(Carry), pvp, C.POINTER(Block)]
+        L.mp3s_hide_message_chunked.argtypes = [vp, vp, sz, vp, sz, C.c_int64, pvp, C.POINTER(File)]
         L.mp3s_pipe_create.argtypes = [vp, i32, sz, i32, pvp]
         L.mp3s_pipe_destroy.argtypes = [vp]
         L.mp3s_pipe_destroy.restype = None
@@ -370,14 +384,15 @@ class Context:
         return {"n_frames": d.n_frames, "channels": d.nch, "sampling_rate": d.sampling_rate, "bit_rate": d.bit_rate,
                 "pcm": _view_owned(d.pcm, dt, (d.n_rows, d.nch), own), "bits": _view(d.bits, np.uint8, (d.n_bits,))}
 
-    def decode_block(self, data: bytes, first_frame, n_frames, out_format=MP3S_PCM_I16):
+    def decode_block(self, data: bytes, first_frame, n_frames, out_format=MP3S_PCM_I16, index=None):
         """frames [first_frame, first_frame + n_frames) of the stream (clipped to its end): one shard of a stream that is
-        spread over several GPUs.  "bits", "bit_rate", "sampling_rate" describe the whole stream."""
+        spread over several GPUs.  "bits", "bit_rate", "sampling_rate" describe the whole stream.  With an `index`
+        (StreamIndex) only the block is scanned, and "bits" are those of the block's frames."""
         buf = np.frombuffer(data, dtype=np.uint8)
         owner = C.c_void_p()
         d = Decoded()
-        check(lib().mp3s_decode_block(self.handle, buf.ctypes.data, len(data), int(first_frame), int(n_frames), out_format,
-                                      C.byref(owner), C.byref(d)))
+        check(lib().mp3s_decode_block_indexed(self.handle, buf.ctypes.data, len(data), index.handle if index is not None else None,
+                                              int(first_frame), int(n_frames), out_format, C.byref(owner), C.byref(d)))
         own = _Owner(owner)
         dt = {MP3S_PCM_I16: np.int16, MP3S_PCM_F32: np.float32, MP3S_PCM_F64: np.float64}[out_format]
         return {"n_frames": d.n_frames, "channels": d.nch, "sampling_rate": d.sampling_rate, "bit_rate": d.bit_rate,
@@ -502,7 +517,7 @@ class Context:
         check(lib().mp3s_clear_file(self.handle, buf.ctypes.data, len(mp3), C.byref(owner), C.byref(f)))
         return self._file(f, owner)
 
-    def reencode_block(self, mp3: bytes, message, rank, world, carry_in=None):
+    def reencode_block(self, mp3: bytes, message, rank, world, carry_in=None, index=None):
         """this rank's block of hide_message (message: str) / clear_file (None) on one stream spread over `world` ranks:
         decode + re-encode of the block on the device (include/mp3s.h mp3s_reencode_block).  carry_in: int64[17], None
         for rank 0."""
@@ -511,8 +526,9 @@ class Context:
         nm = 0 if message is None else len(message.encode("utf-8"))
         cin = Carry.from_array(carry_in) if carry_in is not None else None
         owner, b = C.c_void_p(), Block()
-        check(lib().mp3s_reencode_block(self.handle, buf.ctypes.data, len(mp3), None if mb is None else mb.ctypes.data, nm, int(rank),
-                                        int(world), C.byref(cin) if cin is not None else None, C.byref(owner), C.byref(b)))
+        check(lib().mp3s_reencode_block_indexed(self.handle, buf.ctypes.data, len(mp3), index.handle if index is not None else None,
+                                                None if mb is None else mb.ctypes.data, nm, int(rank), int(world),
+                                                C.byref(cin) if cin is not None else None, C.byref(owner), C.byref(b)))
         try:
             f = b.file
             return {"total_frames": b.total_frames, "first_frame": b.first_frame, "n_frames": b.n_frames, "is_last": bool(b.is_last),
@@ -521,6 +537,29 @@ class Context:
                     "too_long": bool(f.too_long), "hide_offset": f.hide_offset}
         finally:
             lib().mp3s_buf_free(owner)
+
+    def hide_message_chunked(self, mp3: bytes, message, chunk_frames):
+        """hide_message (message: str) / clear_file (None) on a file of any length, chunk_frames frames at a time through the
+        device: one index walk, every chunk scanned on its own and run on the real carry of the one in front of it"""
+        buf = np.frombuffer(mp3, dtype=np.uint8)
+        mb = None if message is None else np.frombuffer(message.encode("utf-8") or b"\0", dtype=np.uint8)
+        nm = 0 if message is None else len(message.encode("utf-8"))
+        owner, f = C.c_void_p(), File()
+        check(lib().mp3s_hide_message_chunked(self.handle, buf.ctypes.data, len(mp3), None if mb is None else mb.ctypes.data, nm,
+                                              int(chunk_frames), C.byref(owner), C.byref(f)))
+        return self._file(f, owner)
+
+    def decode_chunks(self, mp3: bytes, chunk_frames, out_format=MP3S_PCM_I16):
+        """generator over the PCM of the stream, chunk_frames frames at a time: one index walk, then every chunk is scanned
+        and decoded on its own (the repeated last frame of a stream that ends in a bad header comes with the last chunk)"""
+        ix = StreamIndex(mp3)
+        first = 0
+        while first < max(ix.n_frames, 1):
+            blk = self.decode_block(mp3, first, chunk_frames, out_format, index=ix)
+            yield blk["pcm"]
+            first += chunk_frames
+            if ix.n_frames == 0:
+                break
 
     def hide_messages(self, mp3s, messages):
         """hide_message / clear_file (message None) over a list of files as one device batch per (rate, bitrate).
@@ -619,6 +658,45 @@ class Pipe:
             lib().mp3s_pipe_destroy(self.handle)
             self.handle = None
             self._keep.clear()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class StreamIndex:
+    """resume points of a stream (mp3s_index_stream): blocks of it are then scanned on their own"""
+
+    def __init__(self, data: bytes):
+        self._data = data
+        buf = np.frombuffer(data, dtype=np.uint8)
+        h, info = C.c_void_p(), IndexInfo()
+        check(lib().mp3s_index_stream(buf.ctypes.data, len(data), C.byref(h), C.byref(info)))
+        self.handle = h
+        self.n_frames, self.channels, self.sampling_rate, self.bit_rate = info.n_frames, info.nch, info.sampling_rate, info.bit_rate
+        self.dup_last_frame, self.gpu_ok = info.dup_last_frame, bool(info.gpu_ok)
+
+    def scan_range(self, first_frame, n_frames):
+        """scan_stream for these frames only"""
+        buf = np.frombuffer(self._data, dtype=np.uint8)
+        owner, p = C.c_void_p(), Scanned()
+        check(lib().mp3s_scan_range(buf.ctypes.data, len(self._data), self.handle, int(first_frame), int(n_frames), C.byref(owner), C.byref(p)))
+        try:
+            n = p.n_frames
+            return {"n_frames": n, "channels": p.nch, "sampling_rate": p.sampling_rate, "bit_rate": p.bit_rate,
+                    "dup_last_frame": p.dup_last_frame, "gpu_ok": bool(p.gpu_ok), "max_part2_3_length": p.max_part2_3_length,
+                    "side": _view(p.side, FRAME_SIDE_DTYPE, (n,)), "hdr": _view(p.hdr, FRAME_HDR_DTYPE, (n,)),
+                    "blob": _view(p.blob, np.uint8, (p.blob_len,)), "bits": _view(p.bits, np.uint8, (p.n_bits,)),
+                    "frame_size": _view(p.frame_size, np.int32, (n,))}
+        finally:
+            lib().mp3s_buf_free(owner)
+
+    def close(self):
+        if self.handle:
+            lib().mp3s_index_free(self.handle)
+            self.handle = None
 
     def __del__(self):
         try:

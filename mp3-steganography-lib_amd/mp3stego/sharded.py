@@ -94,20 +94,27 @@ class TorchComm:
 def decode_sharded(ctx, mp3: bytes, comm=None, out_format=_lib.MP3S_PCM_I16):
     """every rank decodes its block; rank 0 returns the dict Context.decode_stream returns, the others None"""
     comm = comm or SoloComm()
-    info = _lib.scan_stream(mp3)
-    first, count = shard_frames(info["n_frames"], comm.rank, comm.world)
+    # one walk over the frame headers (no main data copied); the rank then scans its own block only
+    ix = _lib.StreamIndex(mp3)
+    first, count = shard_frames(ix.n_frames, comm.rank, comm.world)
     part = None
     if count > 0:
-        blk = ctx.decode_block(mp3, first, count, out_format)
-        part = np.array(blk["pcm"])
+        blk = ctx.decode_block(mp3, first, count, out_format, index=ix)
+        # the block's stego bits without those of the halo frame decoded in front of it
+        halo_bits = len(ix.scan_range(first - 1, 1)["bits"]) if first > 0 and ix.gpu_ok else 0
+        part = (np.array(blk["pcm"]), np.array(blk["bits"][halo_bits:]) if ix.gpu_ok else None, np.array(blk["bits"]))
     parts = comm.gather(part)
     if parts is None:
         return None
     parts = [p for p in parts if p is not None]
     dt = {_lib.MP3S_PCM_I16: np.int16, _lib.MP3S_PCM_F32: np.float32, _lib.MP3S_PCM_F64: np.float64}[out_format]
-    pcm = np.concatenate(parts) if parts else np.zeros((0, info["channels"]), dtype=dt)   # (a stream without a frame)
-    return {"n_frames": info["n_frames"], "channels": info["channels"], "sampling_rate": info["sampling_rate"],
-            "bit_rate": info["bit_rate"], "pcm": pcm, "bits": np.array(info["bits"])}
+    pcm = np.concatenate([p[0] for p in parts]) if parts else np.zeros((0, ix.channels), dtype=dt)   # (a stream without a frame)
+    if parts and parts[0][1] is not None:
+        bits = np.concatenate([p[1] for p in parts])
+    else:                                            # host-parsed stream: every block call returned the whole stream's bits
+        bits = parts[0][2] if parts else np.zeros(0, dtype=np.uint8)
+    return {"n_frames": ix.n_frames, "channels": ix.channels, "sampling_rate": ix.sampling_rate,
+            "bit_rate": ix.bit_rate, "pcm": pcm, "bits": bits}
 
 
 def _same_effect(a, b, n_hide):
@@ -121,18 +128,19 @@ def reencode_sharded(ctx, mp3: bytes, message=None, comm=None):
     clear_file do for the whole file on one GPU; the other ranks return None."""
     comm = comm or SoloComm()
     n_hide = 0 if message is None else len(_lib.message_frame(message))
+    ix = _lib.StreamIndex(mp3)         # the block is scanned on its own, also when it has to be encoded a second time
     if comm.rank == 0:
-        blk = ctx.reencode_block(mp3, message, 0, comm.world, None)
+        blk = ctx.reencode_block(mp3, message, 0, comm.world, None, index=ix)
     else:
         guess = np.zeros(CARRY_WORDS, dtype=np.int64)
         guess[0] = _PAST_MESSAGE
-        blk = ctx.reencode_block(mp3, message, comm.rank, comm.world, guess)      # overlaps the ranks in front
+        blk = ctx.reencode_block(mp3, message, comm.rank, comm.world, guess, index=ix)      # overlaps the ranks in front
     last_rank = min(comm.world, int(blk["total_frames"])) - 1                     # ranks behind it hold no frame
     if 0 < comm.rank <= last_rank:
         real = comm.recv(comm.rank - 1)
         live = min(int(real[0]), n_hide) < n_hide                    # the message is still being hidden at this boundary
         if not _same_effect(real, guess, n_hide) and (blk["carry_used"] or live):
-            blk = ctx.reencode_block(mp3, message, comm.rank, comm.world, real)
+            blk = ctx.reencode_block(mp3, message, comm.rank, comm.world, real, index=ix)
         else:
             # nothing in the block looked at the carry, so every chain entry it hands on is its own (a granule that
             # inherits would have set carry_used); only the count of tables seen so far moves with the real cursor

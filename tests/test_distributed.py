@@ -87,7 +87,7 @@ SHARD_WORKER = textwrap.dedent("""
     class StubCtx:
         # stands in for the GPU context: a block that starts at frame 30 or later "inherits" (its bytes show the carry it got)
         calls = 0
-        def reencode_block(self, mp3, message, rank, world, carry_in):
+        def reencode_block(self, mp3, message, rank, world, carry_in, index=None):
             from mp3stego import _lib
             StubCtx.calls += 1
             total = _lib.scan_stream(mp3)["n_frames"]
