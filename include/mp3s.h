@@ -479,7 +479,11 @@ int mp3s_reencode_block_indexed(mp3s_ctx *ctx, const uint8_t *mp3, size_t len, c
 int mp3s_hide_message_chunked(mp3s_ctx *ctx, const uint8_t *mp3, size_t len, const uint8_t *utf8, size_t n_msg, int64_t chunk_frames,
                               mp3s_buf **owner, mp3s_file *out);
 /* replaces: Steganography.reveal_massage -- reference steganography.py:103-131: MP3 bytes -> message text.  Only the
- * byte-level scan runs (table_select lives in the side info), so no device work and no context are needed. */
+ * byte-level scan runs (table_select lives in the side info), so no device work and no context are needed.
+ * More lenient than the reference in one respect: reveal_massage decodes every frame before it looks at the bits, so a
+ * stream whose main data makes that decode raise (big_values > 288, region counts past the band table, ragged channel
+ * counts are caught here too, Huffman-level damage is not) raises there and yields a message here.  The Python facade is
+ * unaffected (Steganography.reveal_massage goes through mp3s_decode_file). */
 int mp3s_reveal_message(const uint8_t *mp3, size_t len, mp3s_buf **owner, mp3s_file *out);
 
 /* ---------------------------------------------------------------- (vii) asynchronous host-fed pipeline

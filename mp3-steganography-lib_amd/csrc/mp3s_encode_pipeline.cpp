@@ -464,9 +464,14 @@ int mp3s_encode_file(mp3s_ctx *c, const uint8_t *wav, size_t len, int bitrate_kb
     // MP3_Encoder.py:596-618 walks num_of_samples * channels values in steps of 1152 * channels and indexes the buffer
     // as if it were stereo: mono input and a partial last frame both end in IndexError there
     if (w.channels != 2) return fail(MP3S_E_UNSUPPORTED, "mono input: the reference encoder indexes the sample buffer out of bounds");
-    const int64_t total = w.num_of_samples * 2, count = total / 2304;
-    if (total % 2304 || w.n_values < count * 2304)
-        return fail(MP3S_E_UNSUPPORTED, "sample count is not a multiple of 1152 per channel: the reference encoder reads past the end of the sample buffer");
+    // count whole frames, plus one more when samples are left over (:611-614): that frame is read from whatever follows in
+    // the buffer -- np.fromfile was asked for twice the declared count (WAV_Reader.py:108), so a chunk behind the data
+    // chunk, or the second half of samples that are not 16 bits wide, is taken for audio; only a buffer that ends inside
+    // the frame raises (IndexError)
+    const int64_t total = w.num_of_samples * 2;
+    const int64_t count = total / 2304 + (total % 2304 ? 1 : 0);
+    if (count <= 0 || w.n_values < count * 2304)
+        return fail(MP3S_E_UNSUPPORTED, "sample count is not a multiple of 1152 per channel and the file ends inside the last frame: the reference encoder reads past the end of the sample buffer");
     std::vector<int16_t> pcm((size_t)count * 2304);   // the data chunk may sit at an odd offset
     std::memcpy(pcm.data(), wav + w.data_offset, pcm.size() * 2);
     mp3s_encoded e;

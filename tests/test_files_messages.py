@@ -268,3 +268,17 @@ def test_scan_skips_the_tag_the_listing_describes(mlib, golden_dir):
         s = mlib.scan_stream(data)
         plain = mlib.scan_stream(data[tag.offset:])
         assert s["n_frames"] == plain["n_frames"] and np.array_equal(s["frame_size"], plain["frame_size"]), r["name"]
+
+
+@pytest.mark.gpu
+def test_encode_file_takes_the_frame_behind_a_partial_one_like_the_reference(ctx, mlib, golden_dir):
+    """a WAV whose declared sample count is not a multiple of 1152 per channel: the reference encodes one more frame from
+    whatever follows in its buffer (here a LIST chunk behind the data chunk), and raises IndexError when the file ends
+    inside that frame (tests/golden/gen_wav_tail_golden.py ran the reference on both files)"""
+    g = np.load(os.path.join(golden_dir, "g9_wav_tail.npz"))
+    assert str(g["tail_error"]) == "" and str(g["short_error"]) == "IndexError"
+    r = ctx.encode_file(g["tail_wav"].tobytes(), 128)
+    assert r["n_frames"] == 3 and bytes(r["data"]) == g["tail_mp3"].tobytes()
+    with pytest.raises(mlib.Mp3sError) as e:
+        ctx.encode_file(g["short_wav"].tobytes(), 128)
+    assert e.value.code == mlib.E_UNSUPPORTED

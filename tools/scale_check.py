@@ -24,6 +24,35 @@ for r in range(3):
     comm.rank = r
     res = sharded.reencode_sharded(ctx, enc, msg, comm)
 print("sharded x3 (sequential in one process): %.4f s, equal %s" % (time.time() - t0, res["data"] == whole["data"]))
+# host scan cost: the whole file, the index walk, and blocks scanned from the index (time should follow the block size)
+import ctypes as C
+L = mlib.lib()
+buf = np.frombuffer(enc, dtype=np.uint8)
+def best(f, k=5):
+    b = 1e9
+    for _ in range(k):
+        t0 = time.perf_counter(); f(); b = min(b, time.perf_counter() - t0)
+    return b * 1e3
+def full_scan():
+    o, sc = C.c_void_p(), mlib.Scanned()
+    mlib.check(L.mp3s_scan_stream(buf.ctypes.data, len(enc), C.byref(o), C.byref(sc))); L.mp3s_buf_free(o)
+print("host scan of the whole file: %.3f ms" % best(full_scan))
+print("index walk of the whole file: %.3f ms" % best(lambda: mlib.StreamIndex(enc).close()))
+ix = mlib.StreamIndex(enc)
+for cnt in (N // 100, N // 10, N // 3, N):
+    def rng():
+        o, sc = C.c_void_p(), mlib.Scanned()
+        mlib.check(L.mp3s_scan_range(buf.ctypes.data, len(enc), ix.handle, N // 2 - cnt // 2, cnt, C.byref(o), C.byref(sc))); L.mp3s_buf_free(o)
+    print("scan of a block of %d frames in the middle of the file: %.3f ms" % (cnt, best(rng)))
+comm = sharded.LocalComm(3)
+t0 = time.time()
+for r in range(3):
+    comm.rank = r
+    got = b"".join(bytes(c.tobytes()) for c in [np.concatenate(list(ctx.decode_chunks(enc, 16384)))]) if r == 0 else None
+print("decode in chunks of 16384 frames (each scanned on its own): %.4f s" % (time.time() - t0))
+for chunk in (16384, 50000):
+    t0 = time.time(); ch = ctx.hide_message_chunked(enc, msg, chunk); t3 = time.time() - t0
+    print("hide_message_chunked %d: %.4f s, equal %s" % (chunk, t3, bytes(ch["data"]) == bytes(whole["data"])))
 p = mlib.scan_stream(enc)
 cuts = np.concatenate([[0], np.cumsum(p["frame_size"].astype(np.int64))])
 k = 50
