@@ -244,15 +244,18 @@ typedef struct {
     uint8_t nch, sr_idx, ms_stereo, flags;
     uint8_t scfsi[2][4];
     mp3s_unit_side unit[2][2]; /* [gr][ch] */
-    uint32_t reserved;
+    uint32_t reserved;         /* index (in the batch) of the first frame of this frame's stream; the scan writes 0 */
 } mp3s_frame_side; /* 104 bytes */
 
 /* replaces: __unpack_scale_fac + __unpack_samples for every granule*channel of the batch -- reference
  * decoder/Frame.py:365-559 (linear code-book search there, two-level tables here; same prefix codes, same quirks D1/D2).
  * blob: main data of all frames (reservoir already gathered), each frame 4-byte aligned and followed by >= 8 zero
  * bytes; is / si as consumed by mp3s_decode_transform_dev; status: int32, OR of MP3S_HS_* on malformed input.
- * Not bit-exact for streams whose scalefactors are inherited across frames (mixed blocks, scfsi after a short
- * gr0): mp3s_scan_stream reports those (gpu_ok = 0) and the pipelines fall back to the host parser. */
+ * Streams whose scalefactors are inherited across frames (mixed blocks, scfsi behind a short granule 0: SURVEY D10;
+ * mp3s_scan_stream reports them with gpu_ok = 0): the kernel walks back through the stream's side records to the granule
+ * that wrote the entry last and reads it from that granule's bits, so the batch must hold such a stream from its first
+ * frame on and frame_side.reserved must name that frame's index in the batch (0 for a single stream).  Blocks of such a
+ * stream are parsed on the host. */
 #define MP3S_HS_BAD_REGION 1
 #define MP3S_HS_BIG_VALUES 2
 #define MP3S_HS_HINT 4 /* some part2_3_length exceeds max_part2_3_length: call again with a larger bound (or 0) */

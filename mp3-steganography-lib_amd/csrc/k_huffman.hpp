@@ -58,6 +58,76 @@ struct BitStream {
     }
 };
 
+// Scalefactors a granule reads without having written them: the reference keeps every scalefactor array from frame to
+// frame (decoder/FrameSideInformation.py:11-37), and two kinds of granules look at entries their own bits do
+// not set -- mixed short blocks (the three lowest short bands: Frame.py:392-397 writes sf_s[w][3..11] only) and granule 1
+// behind a short granule 0 with scfsi set (Frame.py:423-437 copies sf_l[0][ch][s], which a short granule 0 did not
+// write).  What they see is what the last granule of the same (gr, ch) that DID write the entry left there, possibly many
+// frames back.  These helpers walk back through the side records of the stream (frame_side.reserved = the stream's first
+// frame in the batch) and read the value straight from that granule's bits in the blob.  Rare: global loads, no staging.
+__device__ __forceinline__ uint32_t huf_global_bits(const uint8_t *__restrict__ blob, uint32_t md_off, uint32_t md_len, uint32_t bit, int n)
+{
+    if (!n) return 0;
+    uint32_t acc = 0;                                   // three bytes cover n <= 4 bits at any alignment
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+        const uint32_t b = (bit >> 3) + k;
+        acc = (acc << 8) | (b < md_len ? blob[md_off + b] : 0u);   // bits past the main data read as 0 (decoder/util.py:41-43)
+    }
+    return (acc >> (24 - (bit & 7) - n)) & ((1u << n) - 1);
+}
+struct HufUnitAt {               // what the walk needs of unit (gr, ch) of frame f
+    uint32_t md_off, md_len, bit, slen0, slen1;
+    bool short_win, mixed;
+};
+__device__ __forceinline__ HufUnitAt huf_unit_at(const mp3s_frame_side *__restrict__ side, long f, int gr, int ch, int nch)
+{
+    const uint32_t *d = reinterpret_cast<const uint32_t *>(side + f);
+    const int k = gr * 2 + ch;
+    HufUnitAt u;
+    u.md_off = d[0]; u.md_len = d[1];
+    uint32_t bit = 0;
+    for (int q = 0; q < k; q++)
+        if ((q & 1) < nch) bit += d[5 + 5 * q] & 0xffffu;          // part2_3_length of the units in front (gr-major, ch inner)
+    u.bit = bit;
+    const uint32_t u1 = d[5 + 5 * k + 1], u2 = d[5 + 5 * k + 2];
+    const uint32_t sc = (u1 >> 8) & 15;
+    const uint8_t sl[16][2] = {{0, 0}, {0, 1}, {0, 2}, {0, 3}, {3, 0}, {1, 1}, {1, 2}, {1, 3},
+                               {2, 1}, {2, 2}, {2, 3}, {3, 1}, {3, 2}, {3, 3}, {4, 2}, {4, 3}};
+    u.slen0 = sl[sc][0]; u.slen1 = sl[sc][1];
+    u.short_win = ((u1 >> 16) & 0xff) && (u1 >> 24) == 2;
+    u.mixed = u.short_win && (u2 & 0xff);
+    return u;
+}
+// sf_s[w][s] as a granule (gr, ch) of frame f finds it when its own bits do not set it: written last by a short granule
+// of the same (gr, ch) -- a mixed one only writes bands 3..11 (Frame.py:392-405)
+__device__ __noinline__ uint32_t huf_inherit_short(const uint8_t *__restrict__ blob, const mp3s_frame_side *__restrict__ side, long f, long first,
+                                                   int gr, int ch, int nch, int w, int s)
+{
+    for (long fb = f - 1; fb >= first; fb--) {
+        const HufUnitAt u = huf_unit_at(side, fb, gr, ch, nch);
+        if (!u.short_win || (u.mixed && s < 3)) continue;
+        uint32_t off;
+        if (s >= 6) off = (u.mixed ? 17u : 18u) * u.slen0 + (uint32_t)((s - 6) * 3 + w) * u.slen1;
+        else off = u.mixed ? (8u + (uint32_t)((s - 3) * 3 + w)) * u.slen0 : (uint32_t)(s * 3 + w) * u.slen0;
+        return huf_global_bits(blob, u.md_off, u.md_len, u.bit + off, (int)(s >= 6 ? u.slen1 : u.slen0));
+    }
+    return 0;
+}
+// sf_l[0][ch][s] as granule 1 finds it when granule 0 of frame f did not write it (granule 0 short; mixed: s >= 8)
+__device__ __noinline__ uint32_t huf_inherit_long(const uint8_t *__restrict__ blob, const mp3s_frame_side *__restrict__ side, long f, long first,
+                                                  int ch, int nch, int s)
+{
+    for (long fb = f - 1; fb >= first; fb--) {
+        const HufUnitAt u = huf_unit_at(side, fb, 0, ch, nch);
+        if (!u.short_win)
+            return huf_global_bits(blob, u.md_off, u.md_len, u.bit + (s < 11 ? (uint32_t)s * u.slen0 : 11 * u.slen0 + (uint32_t)(s - 11) * u.slen1),
+                                   (int)(s < 11 ? u.slen0 : u.slen1));
+        if (u.mixed && s < 8) return huf_global_bits(blob, u.md_off, u.md_len, u.bit + (uint32_t)s * u.slen0, (int)u.slen0);
+    }
+    return 0;
+}
+
 // mp3s_frame_side (104 bytes) in 26 registers: 13 independent 8-byte loads, one wait; fields by constant offsets, the
 // four unit records by select (a struct copy with a run-time index would go through scratch)
 struct SideRegs {
@@ -174,19 +244,33 @@ __global__ __launch_bounds__(WAVES * 64) void k_dec_huffman(
     const int sl0 = kSlen[scalefac_compress & 15][0], sl1 = kSlen[scalefac_compress & 15][1];
     const bool short_win = block_type == 2 && window_switching;
     // ---- scalefactors (Frame.py:365-441)
+    const long stream_first = (long)fs.d[25];           // frame_side.reserved: first frame of this stream in the batch
     if (gr == 1 && !short_win && scfsi) {
         // bands flagged by scfsi are copied from granule 0 (:423-437): decode them from granule 0's own bits, which the
         // lane two columns to the left (same frame, same wave) has staged
-        const uint32_t c0 = ((ch ? fs.d[11] : fs.d[6]) >> 8) & 15;
+        const uint32_t g0u1 = ch ? fs.d[11] : fs.d[6], g0u2 = ch ? fs.d[12] : fs.d[7];
+        const uint32_t c0 = (g0u1 >> 8) & 15;
         const int z0 = kSlen[c0][0], z1 = kSlen[c0][1];
+        const bool g0_short = ((g0u1 >> 16) & 0xff) && (g0u1 >> 24) == 2, g0_mixed = g0_short && (g0u2 & 0xff);
         __builtin_amdgcn_wave_barrier();
-        BitStream<COLS> b0;
-        b0.open(words + col - 2, (uint32_t)W, bit_g0);
-        for (int s = 0; s < 21; s++) {
-            const int sl = s < 11 ? z0 : z1;
-            const int band = s < 6 ? 0 : (s < 11 ? 1 : (s < 16 ? 2 : 3));
-            const uint32_t v = b0.get(sl);
-            if ((scfsi >> (8 * band)) & 0xff) sf_l[s] = (uint8_t)v;
+        if (!g0_short) {
+            BitStream<COLS> b0;
+            b0.open(words + col - 2, (uint32_t)W, bit_g0);
+            for (int s = 0; s < 21; s++) {
+                const int sl = s < 11 ? z0 : z1;
+                const int band = s < 6 ? 0 : (s < 11 ? 1 : (s < 16 ? 2 : 3));
+                const uint32_t v = b0.get(sl);
+                if ((scfsi >> (8 * band)) & 0xff) sf_l[s] = (uint8_t)v;
+            }
+        } else {
+            // granule 0 is short: it wrote sf_l[0..7] if mixed (first in its bits), nothing of sf_l otherwise; the rest is
+            // what earlier frames left in the array
+            for (int s = 0; s < 21; s++) {
+                const int band = s < 6 ? 0 : (s < 11 ? 1 : (s < 16 ? 2 : 3));
+                if (!((scfsi >> (8 * band)) & 0xff)) continue;
+                if (g0_mixed && s < 8) sf_l[s] = (uint8_t)huf_global_bits(blob, md_off, md_len, bit_g0 + (uint32_t)(s * z0), z0);
+                else sf_l[s] = (uint8_t)huf_inherit_long(blob, side, f, stream_first, ch, nch, s);
+            }
         }
     }
     if (short_win) {
@@ -194,6 +278,8 @@ __global__ __launch_bounds__(WAVES * 64) void k_dec_huffman(
             for (int s = 0; s < 8; s++) { sf_l[s] = (uint8_t)br.get(sl0); bit += sl0; }
             for (int s = 3; s < 6; s++)
                 for (int w = 0; w < 3; w++) { sf_s[w * 13 + s] = (uint8_t)br.get(sl0); bit += sl0; }
+            for (int s = 0; s < 3; s++)                 // not in this granule's bits: what the array still holds
+                for (int w = 0; w < 3; w++) sf_s[w * 13 + s] = (uint8_t)huf_inherit_short(blob, side, f, stream_first, gr, ch, nch, w, s);
         } else {
             for (int s = 0; s < 6; s++)
                 for (int w = 0; w < 3; w++) { sf_s[w * 13 + s] = (uint8_t)br.get(sl0); bit += sl0; }
@@ -208,6 +294,12 @@ __global__ __launch_bounds__(WAVES * 64) void k_dec_huffman(
             const int band = s < 6 ? 0 : (s < 11 ? 1 : (s < 16 ? 2 : 3)), sl = s < 11 ? sl0 : sl1;
             if (!((scfsi >> (8 * band)) & 0xff)) { sf_l[s] = (uint8_t)br.get(sl); bit += sl; }
         }
+    }
+    if (!short_win && window_switching && mixed_block_flag) {
+        // a start / stop block with the mixed flag: its scalefactors are the long ones (:406-441), but re_quantize switches
+        // to the short bands from sfb 8 on (Frame.py:186) and reads sf_s[w][8..], which only short granules write
+        for (int s = 8; s < 12; s++)
+            for (int w = 0; w < 3; w++) sf_s[w * 13 + s] = (uint8_t)huf_inherit_short(blob, side, f, stream_first, gr, ch, nch, w, s);
     }
     // ---- big values (Frame.py:458-518).  One flat loop over the pairs: the region (and with it the code book) is
     //      looked up per pair, so a wave runs for its longest granule, not for the longest region 0 + region 1 + region 2.

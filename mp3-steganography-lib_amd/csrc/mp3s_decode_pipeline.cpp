@@ -42,9 +42,13 @@ int front_end(mp3s_multi &m, int i)
         return MP3S_OK;
     }
     int rc = parse_stream(m.files[i].first, m.files[i].second, p, &sc);
-    if (!rc && !sc.gpu_ok) {
+    sc.host_parsed = false;
+    // scalefactors inherited across frames (mixed blocks, scfsi behind a short granule 0): the device kernel walks back
+    // through the stream for them, so it needs the stream from its first frame on; a window of such a stream is parsed here
+    if (!rc && !sc.gpu_ok && (size_t)i < m.window.size()) {
         rc = parse_stream(m.files[i].first, m.files[i].second, p, nullptr);
         sc.side.clear(); sc.blob.clear();   // not used for host-parsed streams
+        sc.host_parsed = true;
     }
     // no sync where the stream should start: the reference parses nothing and writes an empty WAV (MP3_Parser.py:37-46)
     if (!rc && (size_t)i < m.window.size()) {
@@ -86,14 +90,14 @@ int decode_group(mp3s_ctx *c, mp3s_multi &m, const std::vector<int> &idx, int nc
     hdr.resize((size_t)n);
     std::vector<long> first_of(idx.size());
     bool any_dev = false, any_host = false;
-    const bool in_place = idx.size() == 1 && m.scanned[idx[0]].gpu_ok;
+    const bool in_place = idx.size() == 1 && !m.scanned[idx[0]].host_parsed;
     if (!in_place) { c->h_side.resize((size_t)n); c->h_blob.clear(); }
     long f0 = 0;
     for (size_t k = 0; k < idx.size(); k++) {
         const ParsedStream &p = m.parsed[idx[k]];
         const ScannedStream &sc = m.scanned[idx[k]];
         first_of[k] = f0;
-        const bool dev = sc.gpu_ok;
+        const bool dev = !sc.host_parsed;
         (dev ? any_dev : any_host) = true;
         if (dev && !in_place) c->h_blob.resize((c->h_blob.size() + 3) & ~(size_t)3, 0);   // md_off stays a multiple of 4 (mp3s.h)
         const uint32_t base = (uint32_t)c->h_blob.size();
@@ -102,7 +106,7 @@ int decode_group(mp3s_ctx *c, mp3s_multi &m, const std::vector<int> &idx, int nc
             hdr[(size_t)f0 + f] = p.hdr[f];
             hdr[(size_t)f0 + f].stream_first = (uint32_t)f0;
             if (in_place) continue;
-            if (dev) { c->h_side[(size_t)f0 + f] = sc.side[f]; c->h_side[(size_t)f0 + f].md_off += base; }
+            if (dev) { c->h_side[(size_t)f0 + f] = sc.side[f]; c->h_side[(size_t)f0 + f].md_off += base; c->h_side[(size_t)f0 + f].reserved = (uint32_t)f0; }
             else std::memset(&c->h_side[(size_t)f0 + f], 0, sizeof(mp3s_frame_side));   // filled from the host parse below
         }
         f0 += p.n_frames;
@@ -148,11 +152,13 @@ int decode_group(mp3s_ctx *c, mp3s_multi &m, const std::vector<int> &idx, int nc
             std::vector<int16_t> his(flagged.size() * 2304);          // staged here until the copies have been issued and waited for
             std::vector<mp3s_granule_si> hsi(flagged.size() * 4);
             int redone = 0;
+            std::vector<char> whole(idx.size(), 0);                   // streams that go to the host parser as a whole
             for (size_t q = 0; q < flagged.size() && !rc; q++) {
                 const long f = flagged[q];
                 const size_t k = (size_t)(std::upper_bound(first_of.begin(), first_of.end(), f) - first_of.begin()) - 1;
                 const int i = idx[k];
-                if (!m.scanned[i].gpu_ok) continue;
+                if (m.scanned[i].host_parsed) continue;
+                if (!m.scanned[i].gpu_ok) { whole[k] = 1; continue; }   // its frames inherit from one another: one frame cannot be redone alone
                 const int prc = parse_scanned_frame(m.scanned[i].side[(size_t)(f - first_of[k])], m.scanned[i].blob.data(), &his[q * 2304], &hsi[q * 4]);
                 if (prc) { rc = fail(prc, "file %d: malformed main data", i); break; }
                 if (hipMemcpyAsync((int16_t *)d_is + (size_t)f * 2304, &his[q * 2304], 2304 * sizeof(int16_t), hipMemcpyHostToDevice, c->stream) != hipSuccess ||
@@ -161,13 +167,24 @@ int decode_group(mp3s_ctx *c, mp3s_multi &m, const std::vector<int> &idx, int nc
                 redone++;
             }
             if (hipStreamSynchronize(c->stream) != hipSuccess && !rc) rc = fail(MP3S_E_HIP, "sync failed");
+            for (size_t k = 0; k < idx.size() && !rc; k++) {
+                if (!whole[k]) continue;
+                ParsedStream &p = m.parsed[idx[k]];
+                const std::vector<uint8_t> bits = p.bits;
+                const int prc = parse_stream(m.files[idx[k]].first, m.files[idx[k]].second, p, nullptr);
+                if (prc) { rc = fail(prc, "file %d: malformed main data", idx[k]); break; }
+                p.bits = bits;
+                m.scanned[idx[k]].host_parsed = true;
+                any_host = true;
+                redone += p.n_frames;
+            }
             if (trace_on()) fprintf(stderr, "mp3s:   device Huffman status 0x%x: %d frame(s) decoded on the host instead\n", st, redone);
         }
     }
     if (any_host)   // streams that inherit scalefactors across frames were parsed on the host: place their frames
         for (size_t k = 0; k < idx.size() && !rc; k++) {
             const ParsedStream &p = m.parsed[idx[k]];
-            if (m.scanned[idx[k]].gpu_ok || !p.n_frames) continue;
+            if (!m.scanned[idx[k]].host_parsed || !p.n_frames) continue;
             rc = mp3s_dev_upload(c, (int16_t *)d_is + (size_t)first_of[k] * 2304, p.is.data(), (size_t)p.n_frames * 2304 * 2);
             if (!rc) rc = mp3s_dev_upload(c, (mp3s_granule_si *)d_si + (size_t)first_of[k] * 4, p.si.data(),
                                           (size_t)p.n_frames * 4 * sizeof(mp3s_granule_si));

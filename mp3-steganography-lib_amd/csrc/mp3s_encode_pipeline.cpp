@@ -617,7 +617,15 @@ int mp3s_reencode_block_indexed(mp3s_ctx *c, const uint8_t *mp3, size_t len, con
         const StreamIndexInfo &info = index_info(ix);
         p.n_frames = (int)info.n_frames; p.nch = info.nch; p.sampling_rate = info.sampling_rate; p.bit_rate = info.bit_rate;
         p.dup_last_frame = info.dup_last_frame;
-    } else rc = front_end(m, 0);
+    } else {
+        rc = front_end(m, 0);
+        if (!rc && !m.scanned[0].gpu_ok && !m.scanned[0].host_parsed && world > 1) {
+            // scalefactors inherited across frames: a block of such a stream cannot look back on the device
+            rc = parse_stream(mp3, len, p, nullptr);
+            m.scanned[0].side.clear(); m.scanned[0].blob.clear();
+            m.scanned[0].host_parsed = true;
+        }
+    }
     if (rc) return fail(rc, "malformed or unsupported MP3 stream");
     int kbps = 0;
     rc = reencode_check(p, &kbps);

@@ -33,7 +33,10 @@ struct NoInitAlloc : std::allocator<T> {
 struct ScannedStream {
     std::vector<mp3s_frame_side, NoInitAlloc<mp3s_frame_side>> side;    // [n]
     std::vector<uint8_t, NoInitAlloc<uint8_t>> blob;   // main data of all frames, 4-byte aligned, >= 8 zero bytes after each
-    bool gpu_ok = true;                   // false: some granule inherits scalefactors from earlier frames
+    bool gpu_ok = true;                   // false: some granule inherits scalefactors from earlier frames: the device
+                                          // kernel resolves that by walking back through the stream's side records, which
+                                          // needs the WHOLE stream in the batch (a block of such a stream is parsed on the host)
+    bool host_parsed = false;             // the pipelines' front end took the host parser for this stream (side / blob unused)
 };
 // scan == nullptr: full parse (is + si); otherwise is/si stay empty and *scan is filled instead
 int parse_stream(const uint8_t *file, size_t len, ParsedStream &out, ScannedStream *scan = nullptr);

@@ -128,17 +128,18 @@ bool prepare_fast(mp3s_pipe *P, Job &j, Slot &s, ParsedStream &p, size_t *blob_l
         k.side = side + n; k.side_cap = s.side_cap - (size_t)n;
         k.hdr = dechdr + n;
         k.lean = true;
-        if (parse_stream_sink(j.files[i].first, j.files[i].second, p, &k) || !k.gpu_ok) return false;
+        if (parse_stream_sink(j.files[i].first, j.files[i].second, p, &k)) return false;
         int kbps = 0;
         if (reencode_params(p, &kbps)) return false;
         if (i == 0) { j.rate = p.sampling_rate; j.kbps = kbps; }
         else if (p.sampling_rate != j.rate || kbps != j.kbps) return false;   // more than one device batch
         for (int f = 0; f < p.n_frames; f++) {
             side[n + f].md_off += (uint32_t)base;
+            side[n + f].reserved = (uint32_t)n;           // where the stream starts in the batch (scalefactor inheritance walks back to it)
             dechdr[n + f].stream_first = (uint32_t)n;
         }
         *max_p23 = std::max(*max_p23, max_part2_3(side + n, p.n_frames));
-        {
+        if (k.gpu_ok) {   // (a frame of a stream with inherited scalefactors cannot be decoded on its own)
             // The last frame of a stream the reference's encoder wrote lacks the 0-3 bytes its writer drops (E14), and in one
             // file out of eight the Huffman data reaches into them: the device kernel would flag it.  One frame per stream is
             // cheap on the host, so it is decoded here, the kernel skips it, and its samples are placed behind the kernel.

@@ -93,13 +93,19 @@ def test_device_huffman_on_corpus(ctx, mlib, corpus):
         assert int(ctx.download(d_st, np.int32, (1,))[0]) == 0
         isv = ctx.download(d_is, np.int16, (nf, 2, 2, 576))
         assert np.array_equal(isv[:, :, :nch], g[n + "__is"][:, :, :nch]), n
-        if s["gpu_ok"]:
-            si = ctx.download(d_si, mlib.GRANULE_SI_DTYPE, (nf, 2, 2))
-            p = mlib.parse_stream(data)
-            bt2 = (p["si"]["block_type"] == 2)[:, :, :nch]
-            # entries the requantiser reads: long scalefactors of non-short granules, short ones of short granules
-            assert np.array_equal(si["scale_fac_l"][:, :, :nch][~bt2], p["si"]["scale_fac_l"][:, :, :nch][~bt2]), n
-            assert np.array_equal(si["scale_fac_s"][:, :, :nch][bt2], p["si"]["scale_fac_s"][:, :, :nch][bt2]), n
+        # every entry the requantiser reads -- long scalefactors of non-short granules, short ones of short granules --
+        # including those a granule inherits from earlier frames (mixed blocks, scfsi behind a short granule 0: the kernel
+        # walks back through the stream for them); and every other field of the record
+        si = ctx.download(d_si, mlib.GRANULE_SI_DTYPE, (nf, 2, 2))
+        p = mlib.parse_stream(data)
+        bt2 = (p["si"]["block_type"] == 2)[:, :, :nch]
+        assert np.array_equal(si["scale_fac_l"][:, :, :nch][~bt2], p["si"]["scale_fac_l"][:, :, :nch][~bt2]), n
+        assert np.array_equal(si["scale_fac_s"][:, :, :nch][bt2], p["si"]["scale_fac_s"][:, :, :nch][bt2]), n
+        # a start / stop block with the mixed flag is requantised with the SHORT scalefactors from band 8 on (Frame.py:186)
+        mx = ((p["si"]["mixed_block_flag"] != 0) & (p["si"]["block_type"] != 2))[:, :, :nch]
+        assert np.array_equal(si["scale_fac_s"][:, :, :nch][mx][..., 8:12], p["si"]["scale_fac_s"][:, :, :nch][mx][..., 8:12]), n
+        for k in ("global_gain", "scalefac_scale", "block_type", "mixed_block_flag", "preflag", "sub_block_gain"):
+            assert np.array_equal(si[k][:, :, :nch], p["si"][k][:, :, :nch]), (n, k)
         for q in (d_blob, d_side, d_is, d_si, d_st):
             ctx.free(q)
 
@@ -161,3 +167,28 @@ def test_many_streams_per_file_status(ctx, mlib, corpus):
         assert not isinstance(r, Exception), (i, r)
         assert r["pcm"].tobytes() == single["pcm"].tobytes() and np.array_equal(r["bits"], single["bits"]), i
     assert sum(isinstance(r, Exception) for r in out) >= 2
+
+
+@pytest.mark.gpu
+def test_inherited_scalefactors_far_back_and_in_a_batch(ctx, mlib, orc):
+    """long streams full of mixed blocks and short / long switches: the entries a granule inherits were written many frames
+    earlier; several such streams in one batch (the walk stops at the stream's own first frame); against the host parser's
+    samples and against the oracle's PCM"""
+    import frame_synth
+    files = [frame_synth.make_stream(20 + i, 90 + 17 * i, block_types=(0, 1, 2, 3), allow_mixed=True, mode=(0, 1, 3)[i % 3],
+                                     mode_ext=2 if i % 3 == 1 else 0) for i in range(5)]
+    files.append(frame_synth.make_stream(40, 60, block_types=(0,)))             # a plain one in between
+    assert sum(not mlib.scan_stream(f)["gpu_ok"] for f in files) >= 4
+    for f in files:
+        o = orc.decode(f)
+        got = ctx.decode_stream(f, mlib.MP3S_PCM_F64)
+        assert got["pcm"].tobytes() == o["pcm"].tobytes()
+    order = [3, 0, 5, 1, 4, 2]
+    batch = ctx.decode_streams([files[i] for i in order], mlib.MP3S_PCM_F64)
+    for i, r in zip(order, batch):
+        assert r["pcm"].tobytes() == orc.decode(files[i])["pcm"].tobytes(), i
+    # blocks of such a stream still go through the host parser: same samples
+    f = files[0]
+    whole = ctx.decode_stream(f, mlib.MP3S_PCM_F64)["pcm"]
+    blk = ctx.decode_block(f, 40, 30, mlib.MP3S_PCM_F64)
+    assert blk["pcm"].tobytes() == whole[40 * 1152:70 * 1152].tobytes()
