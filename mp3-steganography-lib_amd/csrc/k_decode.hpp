@@ -412,4 +412,254 @@ __global__ __launch_bounds__(TW * 64 * 2, 5) void k_dec_synth(
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Kernel BC, fast variant for int16 output.  Same tiling and V exchange as k_dec_synth; the 64 x 32 matrixing is replaced
+// by X[k] = sum_j S[j] cos((2j+1) k pi/64), k < 32, evaluated by even / odd splitting (341 multiplications instead of
+// 2048; every factor is a cosine, nothing is amplified), from which V[i] = X[16+i] (i <= 16, X[32] = 0), -X[48-i]
+// (17 <= i <= 47), -X[i-48] (i >= 48).  The result is NOT the reference's float64 bit pattern: it differs from it by a few
+// 1e-14 of the slot's sum |S| (mostly because the reference's own matrix is that far from the true cosines).  What the
+// int16 format promises -- (pcm * 32767) truncated exactly as the reference truncates it -- is kept by a guard: a sample
+// whose scaled value lies closer to an integer than the proven bound on that difference (DevTables::synth_eps_a / _x,
+// derivation in mp3s_tables.cpp and DESIGN.md) is computed again in the reference's order from the subband samples in S.
+// About one sample in 3e7 takes that path.  eps_scale (tests): inflates the guard so that the exact path is exercised.
+// ---------------------------------------------------------------------------------------------
+__device__ __noinline__ double synth_exact_sample(const double *__restrict__ S, long T, int ch, long t, int i, int lim)
+{
+    // Frame.py:84-101 for one output sample: 16 taps, each a 32-term matrixing sum of an earlier slot
+    double sum = 0.0;
+    for (int jj = 0; jj < 16; jj++) {
+        double u = 0.0;
+        if (jj <= lim) {
+            const double *row = S + ((long)ch * T + (t - jj)) * 32;
+            const double *nrow = c_tab.synth_matrix[(jj & 1) ? 32 + i : i];
+            double a = 0.0;
+            for (int j = 0; j < 32; j++) a += row[j] * nrow[j];
+            u = a;
+        }
+        sum += u * c_tab.synth_window_t[i][jj];
+    }
+    return sum;
+}
+
+// One output of the even / odd splitting: sum_j d[j] * row[j].  The row is wave-uniform and arrives through the scalar
+// cache; its address is a run-time value (so the unrolled code around it cannot pull every row of the table to the front),
+// and it is REQUESTED one stage before it is used: all scalar loads of a wave share one counter that can only be waited
+// to zero, so a stage first asks for the operands of the stage after it, then multiplies with its own.
+template <int N> struct SynthRow { typedef double vec __attribute__((ext_vector_type(N >= 8 ? 8 : N))); vec c[N >= 8 ? N / 8 : 1]; };
+template <int N>
+__device__ __forceinline__ SynthRow<N> synth_row(const double *__restrict__ row)
+{
+    SynthRow<N> r;
+    const typename SynthRow<N>::vec *q = reinterpret_cast<const typename SynthRow<N>::vec *>(row);
+#pragma unroll
+    for (int k = 0; k < (N >= 8 ? N / 8 : 1); k++) r.c[k] = q[k];
+    return r;
+}
+template <int N>
+__device__ __forceinline__ double synth_dot(const double (&d)[N], const SynthRow<N> &r)
+{
+    constexpr int V = N >= 8 ? 8 : N;
+    double a = 0.0;
+#pragma unroll
+    for (int j = 0; j < N; j++) a += d[j] * r.c[j / V][j % V];
+    return a;
+}
+
+template <int TW>
+__global__ __launch_bounds__(TW * 64 * 2, TW == 4 ? 2 : 4) void k_dec_synth_fast(
+    const double *__restrict__ S, long T, const mp3s_frame_hdr *__restrict__ hdr, int nch, int n_halo,
+    int16_t *__restrict__ pcm_out, int sf_base, double eps_scale, int32_t *__restrict__ n_exact)
+{
+    constexpr int TL_LANES = TW * 64, OUT = TL_LANES - 15;
+    constexpr int OROW = 33;
+    __shared__ double ex[2][2][4][TL_LANES];
+    __shared__ uint32_t otile[OUT * OROW];
+    __shared__ double amax_w[TW * 2];
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+    const int ch = wave / TW, tl = (wave % TW) * 64 + lane;
+    const long tile0 = (long)xcd_tile() * OUT;
+    const long t = tile0 - 15 + tl;
+    const bool valid = t >= 0 && t < T;
+    int lim = -1;
+    if (valid) {
+        const uint32_t sf = hdr[t / 36].stream_first;
+        const long s0 = sf > (uint32_t)sf_base ? (long)(sf - (uint32_t)sf_base) * 36 : 0;
+        lim = (int)((t - s0) < 64 ? (t - s0) : 64);
+    }
+    // ---- the differences of the splitting, level by level: X[k] of odd k is a 16-term sum over d16, of k = 2 mod 4 an
+    //      8-term sum over d8, k = 4 mod 8: d4, k = 8 mod 16: d2, and X[16] = (u2[0] - u2[1]) cos(pi/4), X[0] = u2[0] + u2[1]
+    double d16[16], d8v[8], d4[4], d2[2], x0, x16;
+    double asum = 0.0;
+    {
+        double Sv[32];
+        const double2 *sp = reinterpret_cast<const double2 *>(S + ((long)ch * T + (valid ? t : 0)) * 32);
+#pragma unroll
+        for (int j = 0; j < 16; j++) {
+            double2 q = make_double2(0.0, 0.0);
+            if (valid) q = sp[j];
+            Sv[2 * j] = q.x; Sv[2 * j + 1] = q.y;
+        }
+#pragma unroll
+        for (int j = 0; j < 32; j++) asum += fabs(Sv[j]);
+        double u16[16], u8[8], u4[4], u2[2];
+#pragma unroll
+        for (int j = 0; j < 16; j++) { u16[j] = Sv[j] + Sv[31 - j]; d16[j] = Sv[j] - Sv[31 - j]; }
+#pragma unroll
+        for (int j = 0; j < 8; j++) { u8[j] = u16[j] + u16[15 - j]; d8v[j] = u16[j] - u16[15 - j]; }
+#pragma unroll
+        for (int j = 0; j < 4; j++) { u4[j] = u8[j] + u8[7 - j]; d4[j] = u8[j] - u8[7 - j]; }
+#pragma unroll
+        for (int j = 0; j < 2; j++) { u2[j] = u4[j] + u4[3 - j]; d2[j] = u4[j] - u4[3 - j]; }
+        x0 = u2[0] + u2[1];
+        x16 = (u2[0] - u2[1]) * c_tab.synth_fast[340];
+    }
+    // ---- the largest sum |S| of a slot in this tile (both channels): the scale of the guard
+    {
+        double a = asum;
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) { const double o = shfl_xor_f64(a, d); a = a > o ? a : o; }
+        if (lane == 0) amax_w[wave] = a;
+    }
+    __syncthreads();
+    double amax = amax_w[0];
+#pragma unroll
+    for (int w = 1; w < TW * 2; w++) if (w < TW * nch) amax = amax > amax_w[w] ? amax : amax_w[w];
+    const double eps_a = c_tab.synth_eps_a * amax * eps_scale, eps_x = c_tab.synth_eps_x * eps_scale;
+    const long halo_slots = (long)n_halo * 36;
+    const bool emit = valid && tl >= 15 && t >= halo_slots;
+    const bool full_hist = __ballot(tl >= 15 && lim < 15) == 0;
+    uint16_t *ot16 = reinterpret_cast<uint16_t *>(otile);
+    const double *C32 = c_tab.synth_fast, *C16 = c_tab.synth_fast + 256, *C8 = c_tab.synth_fast + 320, *C4 = c_tab.synth_fast + 336;
+    uint32_t redo = 0;
+    int p = 0;
+    // Outputs i = 16 h + 2 t and i + 1 per barrier interval.  V[i] = X[16+i] (h = 0) or -X[48-i] (h = 1), V[32+i] = -X[16-i]
+    // or -X[i-16]: in both halves the k of V[i] and of V[32+i] have the same number of trailing zero bits as 2t, so the
+    // code of an interval (which level, how many terms) is the same for h = 0 and h = 1 and only the table row differs.
+    // Stages of an interval: odd-k sums A1, B1 (16 terms), even-k sums A0, B0 (8 / 4 / 2 terms), barrier, the two window
+    // sums W0, W1 (16 taps); each stage requests the scalar operands of the next one before it computes.
+    auto window = [&](int io, int s, const SynthRow<16> &w) {
+        if (tl < 15) return;
+        double sum = 0.0;
+        if (full_hist) {
+#pragma unroll
+            for (int jj = 0; jj < 16; jj++) sum += ex[p][ch][2 * s + (jj & 1)][tl - jj] * w.c[jj >> 3][jj & 7];
+        } else {
+#pragma unroll
+            for (int jj = 0; jj < 16; jj++) {
+                double u = ex[p][ch][2 * s + (jj & 1)][tl - jj];
+                if (jj > lim) u = 0.0;
+                sum += u * w.c[jj >> 3][jj & 7];
+            }
+        }
+        if (emit) {
+            // the guard: is the truncation of sum * 32767 beyond doubt?  (Truncation is toward zero: every x in (-1, 1) gives
+            // 0, so the integer 0 is not a boundary.)
+            const double x = sum * 32767, xi = rint(x);
+            const double r = fabs(x - xi);
+            if ((xi != 0.0 && !(r > eps_a + eps_x * fabs(x))) || !(fabs(x) < 2147483000.0)) redo |= 1u << io;
+            ot16[(tl - 15) * OROW * 2 + io * nch + ch] = (uint16_t)pcm_to_i16(sum);
+        }
+    };
+    const double *Wtab = &c_tab.synth_window_t[0][0];
+    SynthRow<16> rA1 = synth_row<16>(C32 + (17 >> 1) * 16);          // interval (h = 0, t = 0): k = 17
+#pragma unroll 1
+    for (int h = 0; h < 2; h++) {
+#pragma unroll
+        for (int tt = 0; tt < 8; tt++) {
+            const int i = 16 * h + 2 * tt;
+            // odd k: V[i+1] = X[17+2t] | -X[31-2t],  V[32+i+1] = -X[15-2t] | -X[2t+1];  row of odd k: (k-1)/2
+            const int kb1 = h ? 2 * tt + 1 : 15 - 2 * tt;
+            // even k: V[i] = X[16+2t] | -X[32-2t],  V[32+i] = -X[16-2t] | -X[2t]
+            const int ka0 = h ? 32 - 2 * tt : 16 + 2 * tt, kb0 = h ? 2 * tt : 16 - 2 * tt;
+            constexpr int dummy = 0; (void)dummy;
+            const SynthRow<16> rB1 = synth_row<16>(C32 + (kb1 >> 1) * 16);
+            __builtin_amdgcn_sched_barrier(0);
+            double va1 = synth_dot<16>(d16, rA1);
+            if (h) va1 = -va1;
+            __builtin_amdgcn_sched_barrier(0);
+            double va0, vb0, vb1;
+            SynthRow<16> w0;
+            if (tt == 0) {                              // k = 16 | 32 (X[32] = 0) and k = 16 | 0: nothing to multiply
+                w0 = synth_row<16>(Wtab + i * 16);
+                __builtin_amdgcn_sched_barrier(0);
+                vb1 = -synth_dot<16>(d16, rB1);
+                va0 = h ? 0.0 : x16; vb0 = h ? -x0 : -x16;
+                __builtin_amdgcn_sched_barrier(0);
+            } else if (tt & 1) {
+                const SynthRow<8> rA0 = synth_row<8>(C16 + ((ka0 - 2) >> 2) * 8);
+                __builtin_amdgcn_sched_barrier(0);
+                vb1 = -synth_dot<16>(d16, rB1);
+                __builtin_amdgcn_sched_barrier(0);
+                const SynthRow<8> rB0 = synth_row<8>(C16 + ((kb0 - 2) >> 2) * 8);
+                __builtin_amdgcn_sched_barrier(0);
+                va0 = synth_dot<8>(d8v, rA0);
+                __builtin_amdgcn_sched_barrier(0);
+                w0 = synth_row<16>(Wtab + i * 16);
+                __builtin_amdgcn_sched_barrier(0);
+                vb0 = -synth_dot<8>(d8v, rB0);
+                __builtin_amdgcn_sched_barrier(0);
+            } else if (tt & 2) {
+                const SynthRow<4> rA0 = synth_row<4>(C8 + ((ka0 - 4) >> 3) * 4), rB0 = synth_row<4>(C8 + ((kb0 - 4) >> 3) * 4);
+                __builtin_amdgcn_sched_barrier(0);
+                vb1 = -synth_dot<16>(d16, rB1);
+                __builtin_amdgcn_sched_barrier(0);
+                w0 = synth_row<16>(Wtab + i * 16);
+                __builtin_amdgcn_sched_barrier(0);
+                va0 = synth_dot<4>(d4, rA0); vb0 = -synth_dot<4>(d4, rB0);
+                __builtin_amdgcn_sched_barrier(0);
+            } else {
+                const SynthRow<2> rA0 = synth_row<2>(C4 + ((ka0 - 8) >> 4) * 2), rB0 = synth_row<2>(C4 + ((kb0 - 8) >> 4) * 2);
+                __builtin_amdgcn_sched_barrier(0);
+                vb1 = -synth_dot<16>(d16, rB1);
+                __builtin_amdgcn_sched_barrier(0);
+                w0 = synth_row<16>(Wtab + i * 16);
+                __builtin_amdgcn_sched_barrier(0);
+                va0 = synth_dot<2>(d2, rA0); vb0 = -synth_dot<2>(d2, rB0);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            if (h && tt) va0 = -va0;
+            ex[p][ch][0][tl] = va0;
+            ex[p][ch][1][tl] = vb0;
+            ex[p][ch][2][tl] = va1;
+            ex[p][ch][3][tl] = vb1;
+            __syncthreads();
+            const SynthRow<16> w1 = synth_row<16>(Wtab + (i + 1) * 16);
+            __builtin_amdgcn_sched_barrier(0);
+            window(i, 0, w0);
+            __builtin_amdgcn_sched_barrier(0);
+            {
+                // the first row of the next interval: (h, t + 1), or (1, 0) behind (0, 7); behind the last one: any row
+                const int hn = tt == 7 ? 1 : h, tn = tt == 7 ? 0 : tt + 1;
+                const int kn = hn ? 31 - 2 * tn : 17 + 2 * tn;
+                rA1 = synth_row<16>(C32 + (kn >> 1) * 16);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            window(i + 1, 1, w1);
+            __builtin_amdgcn_sched_barrier(0);
+            p ^= 1;
+        }
+    }
+    // ---- the samples the guard could not vouch for, in the reference's order (outside the loop above: a call inside it
+    //      would make the compiler save its scalar operands around every call site)
+    if (redo) {
+        int n_redo = 0;
+        for (int i = 0; i < 32; i++)
+            if ((redo >> i) & 1u) {
+                ot16[(tl - 15) * OROW * 2 + i * nch + ch] = (uint16_t)pcm_to_i16(synth_exact_sample(S, T, ch, t, i, lim));
+                n_redo++;
+            }
+        if (n_exact) atomicAdd(n_exact, n_redo);
+    }
+    __syncthreads();
+    const int dw_per_slot = 16 * nch;
+    const int n_dw = OUT * dw_per_slot;
+    uint32_t *outp = (uint32_t *)pcm_out;
+    for (int c = threadIdx.x; c < n_dw; c += blockDim.x) {
+        const int sl = c / dw_per_slot, w = c - sl * dw_per_slot;
+        const long slot = tile0 + sl;
+        if (slot < halo_slots || slot >= T) continue;
+        outp[(slot - halo_slots) * dw_per_slot + w] = otile[sl * OROW + w];
+    }
+}
+
 }  // namespace mp3s

@@ -177,6 +177,18 @@ int mp3s_timer_stop(mp3s_ctx *c, float *ms)
     return MP3S_OK;
 }
 
+int mp3s_synth_mode(mp3s_ctx *c, double eps_scale, int64_t *exact_samples)
+{
+    if (!c || eps_scale < 0) return fail(MP3S_E_ARG, "bad argument");
+    HIPCHK(hipStreamSynchronize(c->stream));
+    int32_t n = 0;
+    HIPCHK(hipMemcpy(&n, c->d_sync + 2, 4, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemset(c->d_sync + 2, 0, 4));
+    if (exact_samples) *exact_samples = n;
+    c->synth_eps_scale = eps_scale;
+    return MP3S_OK;
+}
+
 int mp3s_bench_copy(mp3s_ctx *c, size_t bytes, int iters, double *gb_per_s)
 {
     if (!c || !gb_per_s || bytes < 4096 || iters < 1) return fail(MP3S_E_ARG, "bad argument");
@@ -240,7 +252,8 @@ int mp3s_decode_transform_dev(mp3s_ctx *c, const int16_t *d_is, const mp3s_granu
         return fail(MP3S_E_ARG, "bad sizes: n_frames=%d nch=%d n_halo=%d fmt=%d", n_frames, nch, n_halo, out_format);
     int rc = c->ensure_scratch(dec_scratch_bytes(n_frames, nch));
     if (rc) return rc;
-    const int e = launch_decode(c->stream, d_is, d_si, d_hdr, n_frames, nch, n_halo, out_format, d_pcm, c->scratch, &c->prof);
+    const int e = launch_decode(c->stream, d_is, d_si, d_hdr, n_frames, nch, n_halo, out_format, d_pcm, c->scratch, &c->prof, 0,
+                                c->synth_eps_scale, c->d_sync + 2);
     if (e) return fail(MP3S_E_HIP, "decode launch: %s", hipGetErrorString((hipError_t)e));
     return MP3S_OK;
 }

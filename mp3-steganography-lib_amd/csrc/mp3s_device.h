@@ -12,6 +12,7 @@ namespace mp3s {
 // five waves per SIMD on a CU; the kernel waits for scalar-cache misses (the 16 KB matrix is streamed once per tile), so
 // the fifth wave buys more (0.217 -> 0.207 ms) than the larger halo share (15/128 instead of 15/256) costs
 constexpr int DEC_SYNTH_TW = 2;
+constexpr int DEC_SYNTH_FAST_TW = 2;   // the fast int16 variant (k_dec_synth_fast)
 
 // optional per-kernel HIP-event timing: when non-null, every kernel launch is bracketed by two events
 // recorded on the launch stream; mp3s_profile_collect() turns the pairs into per-kernel totals.
@@ -35,7 +36,10 @@ int dev_upload_tables(hipStream_t stream);
 size_t dec_scratch_bytes(int n_frames, int nch);
 int launch_decode(hipStream_t stream, const int16_t *d_is, const mp3s_granule_si *d_si, const mp3s_frame_hdr *d_hdr,
                   int n_frames, int nch, int n_halo, int out_format, void *d_pcm, void *d_scratch, Profiler *prof,
-                  int sf_base = 0 /* hdr[].stream_first counts from this frame of the batch; d_is / d_si / d_hdr start there */);
+                  int sf_base = 0 /* hdr[].stream_first counts from this frame of the batch; d_is / d_si / d_hdr start there */,
+                  double synth_eps_scale = 1.0 /* int16 output: guard of the fast synthesis (k_dec_synth_fast); 0 = the exact
+                                                  kernel */,
+                  int32_t *d_n_exact = nullptr /* counts the samples the guard sent through the exact order */);
 
 // scratch: subband samples int32 [2][32][36 n]
 size_t enc_scratch_bytes(int n_frames);

@@ -51,7 +51,8 @@ size_t dec_scratch_bytes(int n_frames, int nch)
 }
 
 int launch_decode(hipStream_t stream, const int16_t *d_is, const mp3s_granule_si *d_si, const mp3s_frame_hdr *d_hdr,
-                  int n_frames, int nch, int n_halo, int out_format, void *d_pcm, void *d_scratch, Profiler *prof, int sf_base)
+                  int n_frames, int nch, int n_halo, int out_format, void *d_pcm, void *d_scratch, Profiler *prof, int sf_base,
+                  double synth_eps_scale, int32_t *d_n_exact)
 {
     const long T = (long)n_frames * 36;
     double *S = (double *)d_scratch;
@@ -75,11 +76,22 @@ int launch_decode(hipStream_t stream, const int16_t *d_is, const mp3s_granule_si
                        d_is, d_si, d_hdr, n_gran, nch, run, S, T, sf_base);
     if (prof) prof->end(stream, pp);
     constexpr int TW = DEC_SYNTH_TW;
-    const int out_per_tile = TW * 64 - 15;
-    const int tiles = (int)((T + out_per_tile - 1) / out_per_tile);
     pp = prof ? prof->begin(stream, K_DEC_SYNTH) : -1;
-    hipLaunchKernelGGL(k_dec_synth<TW>, dim3(tiles), dim3(TW * 64 * nch), 0, stream, (const double *)S, T, d_hdr, nch,
-                       n_halo, out_format, d_pcm, sf_base);
+    if (out_format == MP3S_PCM_I16 && synth_eps_scale > 0) {
+        static const int ftw = getenv("MP3S_FAST_TW") ? atoi(getenv("MP3S_FAST_TW")) : DEC_SYNTH_FAST_TW;
+#define MP3S_FAST_LAUNCH(W)                                                                                                        \
+        hipLaunchKernelGGL(k_dec_synth_fast<W>, dim3((unsigned)((T + (W * 64 - 15) - 1) / (W * 64 - 15))), dim3(W * 64 * nch), 0, stream, \
+                           (const double *)S, T, d_hdr, nch, n_halo, (int16_t *)d_pcm, sf_base, synth_eps_scale, d_n_exact)
+        if (ftw == 1) MP3S_FAST_LAUNCH(1);
+        else if (ftw == 4) MP3S_FAST_LAUNCH(4);
+        else MP3S_FAST_LAUNCH(2);
+#undef MP3S_FAST_LAUNCH
+    } else {
+        const int out_per_tile = TW * 64 - 15;
+        const int tiles = (int)((T + out_per_tile - 1) / out_per_tile);
+        hipLaunchKernelGGL(k_dec_synth<TW>, dim3(tiles), dim3(TW * 64 * nch), 0, stream, (const double *)S, T, d_hdr, nch,
+                           n_halo, out_format, d_pcm, sf_base);
+    }
     if (prof) prof->end(stream, pp);
     return (int)hipGetLastError();
 }

@@ -38,7 +38,9 @@ struct mp3s_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr, ev_order = nullptr;
-    int32_t *d_sync = nullptr;        // {finished workgroups, error bits} of the pack kernel in flight: self-clearing
+    int32_t *d_sync = nullptr;        // {finished workgroups, error bits} of the pack kernel in flight: self-clearing;
+                                      // [2] counts the samples the fast synthesis computed again in the exact order
+    double synth_eps_scale = 1.0;     // int16 decode: scale of the fast synthesis guard (0 = always the exact kernel)
     void *scratch = nullptr; size_t scratch_bytes = 0;
     Profiler prof;
     // device buffers of the stream pipelines, kept between calls (hipMalloc/hipFree cost more than a small file's work)

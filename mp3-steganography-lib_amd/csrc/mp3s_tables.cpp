@@ -121,6 +121,43 @@ void build()
     for (int i = 0; i < POW2Q_N; i++) T.pow2q[i] = std::pow(2.0, (double)(i + POW2Q_MIN) / 4.0);
     for (int i = 0; i < POW2H_N; i++) T.pow2h[i] = std::pow(2.0, -((double)i * 0.5));
     T.sqrt2 = std::sqrt(2.0);
+    {
+        // fast synthesis: factors of the odd outputs per level (true cosines, rounded once by libm)
+        int o = 0;
+        for (int n = 32; n >= 2; n >>= 1)
+            for (int m = 0; m < n / 2; m++)
+                for (int j = 0; j < n / 2; j++)
+                    T.synth_fast[o++] = std::cos((double)((2 * j + 1) * (2 * m + 1)) * (kPi / (2.0 * n)));
+        // The guard.  u = 2^-53.  With A = sum_j |S[j]| of a slot:
+        //   reference:  |V_ref - V_true| <= (dN + g33) A,   dN = max |N[i][j] - cos((16+i)(2j+1) pi/64)| of the reference's
+        //               own table (its arguments are rounded before the cosine is taken: measured below in long double),
+        //               g33 = 33u/(1-33u): 32 products summed one after the other
+        //   fast:       |V_fast - V_true| <= g24 A:  at most 5 additions in front of a product, a factor that is off by at
+        //               most 2u, 16 products summed one after the other
+        //   window:     both paths run the same 16-tap sum on their V; the results differ by at most
+        //               Dsum (dV + 2 g17 (1 + dV)) Amax,  Dsum = max_i sum_taps |D|,  dV = dN + g33 + g24
+        //   * 32767:    two roundings of one multiplication: 2u |x|
+        // and twice that, against slips in the algebra above.
+        const double u = 1.1102230246251565e-16;
+        long double dN = 0;
+        const long double pil = 3.14159265358979323846264338327950288L;
+        for (int i = 0; i < 64; i++)
+            for (int j = 0; j < 32; j++) {
+                const long double c = cosl((long double)((16 + i) * (2 * j + 1)) * pil / 64.0L);
+                const long double d = fabsl((long double)T.synth_matrix[i][j] - c);
+                if (d > dN) dN = d;
+            }
+        double dsum = 0;
+        for (int i = 0; i < 32; i++) {
+            double a = 0;
+            for (int k = 0; k < 16; k++) a += std::fabs(T.synth_window[32 * k + i]);
+            if (a > dsum) dsum = a;
+        }
+        const double g33 = 33 * u / (1 - 33 * u), g24 = 24 * u / (1 - 24 * u), g17 = 17 * u / (1 - 17 * u);
+        const double dV = (double)dN + 1e-19 + g33 + g24;
+        T.synth_eps_a = 2.0 * 32767.0 * dsum * (dV + 2 * g17 * (1 + dV));
+        T.synth_eps_x = 2.0 * 2 * u;
+    }
     for (int sr = 0; sr < 3; sr++) {
         for (int c = 0; c < 3; c++) {
             uint8_t flat[576];

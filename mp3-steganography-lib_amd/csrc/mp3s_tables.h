@@ -33,6 +33,13 @@ struct DevTables {
     double pow2q[POW2Q_N];         // pow(2, exp1/4)           Frame.py:212
     double pow2h[POW2H_N];         // pow(2, -(k*0.5))         Frame.py:213
     double sqrt2;
+    // ---- fast synthesis for int16 output (k_dec_synth_fast): X[k] = sum_j S[j] cos((2j+1) k pi/64), k < 32, by splitting
+    //      the sum into its even / odd halves level by level (341 multiplications instead of 2048).  Per level n = 32, 16,
+    //      8, 4, 2 the factors of the odd outputs, cos((2j+1)(2m+1) pi/(2n)), rows m, columns j: 256 + 64 + 16 + 4 + 1
+    double synth_fast[344];
+    // the guard of that path: a sample whose value * 32767 lies within  synth_eps_a * (largest sum |S| of a time slot in
+    // the tile) + synth_eps_x * |value * 32767|  of an integer is computed again in the reference's order
+    double synth_eps_a, synth_eps_x;
     uint8_t rq_map[3][3][32][20];  // [sr][case][subband][18 lines + 2 pad]: five aligned dwords per lane;
                                    // byte = gain selector << 6 | scalefactor slot (see build_rq_map)
     int16_t reorder_src[3][576];   // [sr][dst line] -> src line or -1 (zero)  Frame.py:574-602

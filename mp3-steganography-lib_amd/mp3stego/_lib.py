@@ -127,7 +127,7 @@ class Block(C.Structure):
 # every symbol include/mp3s.h declares (tests/test_abi.py checks the library exports all of them)
 SYMBOLS = ["mp3s_ctx_create", "mp3s_ctx_destroy", "mp3s_ctx_wait", "mp3s_last_error", "mp3s_version", "mp3s_device_name", "mp3s_sync", "mp3s_debug_tables", "mp3s_debug_scfsi_energies", "mp3s_debug_parse_scanned_frame",
            "mp3s_dev_alloc", "mp3s_dev_free", "mp3s_dev_upload", "mp3s_dev_download", "mp3s_dev_memset",
-           "mp3s_timer_start", "mp3s_timer_stop", "mp3s_bench_copy", "mp3s_profile_enable", "mp3s_profile_select", "mp3s_profile_collect", "mp3s_decode_transform_dev", "mp3s_decode_transform",
+           "mp3s_timer_start", "mp3s_timer_stop", "mp3s_bench_copy", "mp3s_synth_mode", "mp3s_profile_enable", "mp3s_profile_select", "mp3s_profile_collect", "mp3s_decode_transform_dev", "mp3s_decode_transform",
            "mp3s_encode_transform_dev", "mp3s_encode_transform", "mp3s_rate_loop_dev", "mp3s_chain_resolve_dev", "mp3s_huffman_decode_dev", "mp3s_pack_frames_dev", "mp3s_scan_stream", "mp3s_buf_free",
            "mp3s_parse_stream", "mp3s_format_stream", "mp3s_rate_frames", "mp3s_decode_stream", "mp3s_decode_streams", "mp3s_decode_block", "mp3s_encode_pcm", "mp3s_encode_block",
            "mp3s_wav_parse", "mp3s_wav_header", "mp3s_message_frame", "mp3s_message_reveal", "mp3s_decode_file", "mp3s_encode_file",
@@ -173,6 +173,7 @@ def lib():
         L.mp3s_timer_start.argtypes = [vp]
         L.mp3s_timer_stop.argtypes = [vp, C.POINTER(C.c_float)]
         L.mp3s_bench_copy.argtypes = [vp, sz, i32, C.POINTER(C.c_double)]
+        L.mp3s_synth_mode.argtypes = [vp, C.c_double, C.POINTER(C.c_int64)]
         L.mp3s_profile_enable.argtypes = [vp, i32]
         L.mp3s_profile_select.argtypes = [vp, C.c_uint]
         L.mp3s_profile_collect.argtypes = [vp, vp, vp, i32]
@@ -324,6 +325,13 @@ class Context:
         ms = C.c_float()
         check(lib().mp3s_timer_stop(self.handle, C.byref(ms)))
         return ms.value
+
+    def synth_mode(self, eps_scale=1.0):
+        """guard of the fast int16 synthesis: 1 = proven bound, 0 = always the exact kernel, > 1 = wider (tests);
+        returns the number of samples the guard has sent through the exact order since the last call"""
+        n = C.c_int64()
+        check(lib().mp3s_synth_mode(self.handle, float(eps_scale), C.byref(n)))
+        return n.value
 
     def bench_copy(self, nbytes=1 << 30, iters=20):
         """GB/s (read + write) of a plain device copy kernel"""
@@ -812,6 +820,7 @@ DEV_TABLES_DTYPE = np.dtype([
     ("synth_matrix", "<f8", (64, 32)), ("synth_window", "<f8", (512,)), ("synth_window_t", "<f8", (32, 16)), ("imdct_cos36", "<f8", (36, 18)),
     ("imdct_cos12", "<f8", (12, 6)), ("sine_block", "<f8", (4, 36)), ("alias_cs", "<f8", (8,)), ("alias_ca", "<f8", (8,)),
     ("pow43", "<f8", (8207,)), ("pow2q", "<f8", (312,)), ("pow2h", "<f8", (40,)), ("sqrt2", "<f8"),
+    ("synth_fast", "<f8", (344,)), ("synth_eps_a", "<f8"), ("synth_eps_x", "<f8"),
     ("rq_map", "u1", (3, 3, 32, 20)), ("reorder_src", "<i2", (3, 576)), ("pre_tab", "u1", (24,)),
     ("enwindow", "<i4", (512,)), ("fl", "<i4", (32, 64)), ("cos_l", "<i4", (18, 36)), ("mdct_cs", "<i4", (8,)),
     ("mdct_ca", "<i4", (8,)), ("steptab", "<f8", (128,)), ("steptabi", "<i4", (128,)), ("int2idx", "<u2", (10000,)),

@@ -1,0 +1,47 @@
+"""The fast int16 synthesis (k_dec_synth_fast) behind its guard: int16 PCM equal to the exact kernel's -- which is the
+reference's, bit for bit (tests/test_gpu_parity.py, tests/test_decode_corpus.py) -- also when the guard is made so wide that
+most samples take the exact path, and on streams that start and stop inside a tile."""
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def test_fast_synthesis_equals_exact_kernel(mlib, golden_dir, orc):
+    from synth_pcm import synth_pcm
+    import frame_synth
+    ctx = mlib.Context(0)
+    try:
+        rng = np.random.default_rng(8)
+        pcm = synth_pcm(400, seed=51)
+        pcm[100 * 1152:120 * 1152] = 0
+        loud = (rng.integers(-32768, 32767, size=(200 * 1152, 2))).astype(np.int16)          # full-scale noise: large |S|
+        streams = [bytes(ctx.encode_pcm(pcm, 44100, 128, None)["mp3"]), bytes(ctx.encode_pcm(loud, 48000, 320, None)["mp3"]),
+                   frame_synth.make_stream(31, 150, block_types=(0, 1, 2, 3), allow_mixed=True, mode=1, mode_ext=2),
+                   frame_synth.make_stream(32, 90, mode=3, max_lin=8191),                      # mono, values up to +-8206
+                   open(os.path.join(golden_dir, "test.mp3"), "rb").read()]
+        ctx.synth_mode(0.0)
+        exact = [np.array(ctx.decode_stream(s, mlib.MP3S_PCM_I16)["pcm"]) for s in streams]
+        exact_batch = [np.array(r["pcm"]) for r in ctx.decode_streams(streams, mlib.MP3S_PCM_I16)]
+        assert np.array_equal(exact[4], orc.pcm_to_i16(orc.decode(streams[4])["pcm"]))
+        counts = {}
+        for scale in (1.0, 1e3, 1e6, 1e9):
+            ctx.synth_mode(scale)
+            fast = [np.array(ctx.decode_stream(s, mlib.MP3S_PCM_I16)["pcm"]) for s in streams]
+            batch = [np.array(r["pcm"]) for r in ctx.decode_streams(streams, mlib.MP3S_PCM_I16)]
+            counts[scale] = ctx.synth_mode(scale)
+            for k in range(len(streams)):
+                assert np.array_equal(fast[k], exact[k]), (scale, k)
+                assert np.array_equal(batch[k], exact_batch[k]), (scale, k)
+        # the guard's share: next to nothing at the proven bound, a large share when inflated a billion times
+        total = 2 * sum(e.size for e in exact)
+        assert counts[1.0] < total * 1e-5 and counts[1e9] > total * 0.5, counts
+        assert counts[1.0] <= counts[1e3] <= counts[1e6] <= counts[1e9]
+        # the float formats do not take the fast path
+        ctx.synth_mode(1.0)
+        f64 = ctx.decode_stream(streams[4], mlib.MP3S_PCM_F64)["pcm"]
+        assert f64.tobytes() == orc.decode(streams[4])["pcm"].tobytes()
+    finally:
+        ctx.close()
