@@ -156,7 +156,8 @@ struct SideRegs {
 template <int WAVES, int LANES>
 __global__ __launch_bounds__(WAVES * 64) void k_dec_huffman(
     const uint8_t *__restrict__ blob, const mp3s_frame_side *__restrict__ side, int n_frames, int nch, int W, int max_bits,
-    int16_t *__restrict__ is, mp3s_granule_si *__restrict__ si_out, int32_t *__restrict__ status, int per_frame)
+    int16_t *__restrict__ is, mp3s_granule_si *__restrict__ si_out, int32_t *__restrict__ status, int per_frame,
+    int32_t *__restrict__ sync /* {finished workgroups, error bits}: zero between launches, owned by the context */)
 {
     __shared__ uint16_t fast[15][HUFF_L1_N];
     __shared__ uint16_t lut2[HUFF_L2_N];    // second-level tables for the codes longer than the first-level index
@@ -188,7 +189,17 @@ __global__ __launch_bounds__(WAVES * 64) void k_dec_huffman(
     const long tid = (long)blockIdx.x * COLS + col;
     bool worker = lane < LANES && tid < (long)n_frames * 4 && (int)(tid & 1) < nch;
     // a frame the host has decoded itself (MP3S_FS_HOST_DECODED: its samples are placed behind this kernel) is left alone
-    if (worker && (reinterpret_cast<const uint32_t *>(side + (tid >> 2))[2] >> 24) & MP3S_FS_HOST_DECODED) worker = false;
+    const bool host_frame = tid < (long)n_frames * 4 && ((reinterpret_cast<const uint32_t *>(side + (tid >> 2))[2] >> 24) & MP3S_FS_HOST_DECODED);
+    if (host_frame) worker = false;
+    int err = 0;
+    // Nothing is cleared in front of this kernel: every unit writes all of its 288 sample pairs and its whole side record
+    // (the second channel's unit of a mono stream: zeros), and the status words are plain stores.
+    if (!worker && !host_frame && lane < LANES && tid < (long)n_frames * 4) {
+        uint32_t *z = reinterpret_cast<uint32_t *>(is) + tid * 288;
+        for (int j = 0; j < 288; j++) z[j] = 0;
+        uint32_t *zr = reinterpret_cast<uint32_t *>(si_out + tid);
+        for (int j = 0; j < 18; j++) zr[j] = 0;
+    }
     if (worker) {
     const int f = (int)(tid >> 2), k = (int)(tid & 3), gr = k >> 1, ch = k & 1;
     SideRegs fs;
@@ -210,7 +221,6 @@ __global__ __launch_bounds__(WAVES * 64) void k_dec_huffman(
     const uint32_t count1table_select = u4 & 0xff;
     const uint32_t scfsi = ch ? fs.d[4] : fs.d[3];   // one byte per band
     const uint32_t max_bit = bit + part2_3_length;
-    int err = 0;
     const uint32_t *mdw = reinterpret_cast<const uint32_t *>(blob + md_off);
     if ((int)part2_3_length > max_bits) err |= MP3S_HS_HINT;   // the caller's bound on part2_3_length does not hold
     BitStream<COLS> br;
@@ -236,11 +246,13 @@ __global__ __launch_bounds__(WAVES * 64) void k_dec_huffman(
         br.open(words + col, (uint32_t)W, bit);
     }
     uint32_t *g32 = reinterpret_cast<uint32_t *>(si_out + tid);
+#pragma unroll
+    for (int q = 2; q < 18; q++) g32[q] = 0;   // the scalefactor bytes are stored one by one below, the rest stays zero
     // global_gain, scalefac_scale, block_type, mixed_block_flag | preflag, sub_block_gain[3]
     g32[0] = (u1 & 0xff) | ((u3 >> 24) << 8) | (block_type << 16) | (mixed_block_flag << 24);
     g32[1] = ((u3 >> 16) & 0xff) | ((u4 >> 8) << 8);
     uint8_t *g = reinterpret_cast<uint8_t *>(g32);
-    uint8_t *sf_l = g + 8, *sf_s = g + 30;   // scale_fac_l[22], scale_fac_s[3][13]; the record was zeroed by the launcher
+    uint8_t *sf_l = g + 8, *sf_s = g + 30;   // scale_fac_l[22], scale_fac_s[3][13]
     const int sl0 = kSlen[scalefac_compress & 15][0], sl1 = kSlen[scalefac_compress & 15][1];
     const bool short_win = block_type == 2 && window_switching;
     // ---- scalefactors (Frame.py:365-441)
@@ -303,7 +315,7 @@ __global__ __launch_bounds__(WAVES * 64) void k_dec_huffman(
     }
     // ---- big values (Frame.py:458-518).  One flat loop over the pairs: the region (and with it the code book) is
     //      looked up per pair, so a wave runs for its longest granule, not for the longest region 0 + region 1 + region 2.
-    uint32_t *smp = reinterpret_cast<uint32_t *>(is) + tid * 288;   // pair j; the buffer was zeroed by the launcher
+    uint32_t *smp = reinterpret_cast<uint32_t *>(is) + tid * 288;   // pair j
     int region0, region1;
     bool ok = true;
     if (short_win) { region0 = 36; region1 = 576; }
@@ -314,8 +326,8 @@ __global__ __launch_bounds__(WAVES * 64) void k_dec_huffman(
     }
     const int bv2 = (int)big_values * 2;
     if (bv2 > 576) err |= MP3S_HS_BIG_VALUES;                     // the reference runs off its sample array (IndexError)
+    int sample = 0;
     if (ok && !err) {
-        int sample = 0;
         const uint32_t ti0 = tinfo[(u2 >> 8) & 31], ti1 = tinfo[(u2 >> 16) & 31], ti2 = tinfo[(u2 >> 24) & 31];
         while (sample < bv2) {
             // big values that run past part2_3_length read on into the data that follows (the reference has one bit
@@ -325,7 +337,9 @@ __global__ __launch_bounds__(WAVES * 64) void k_dec_huffman(
             const int lut = (int)(ti & 0xff), lb = (int)(ti >> 8);
             if (lut == 255) {                                     // books 0, 4, 14: zeros, no bits (D2): skip the region
                 const int rend = sample < region0 ? region0 : (sample < region1 ? region1 : bv2);
-                sample = rend < bv2 ? rend : bv2;                 // region bounds are even
+                const int to = rend < bv2 ? rend : bv2;           // region bounds are even
+                for (int j = sample >> 1; j < (to >> 1); j++) smp[j] = 0;
+                sample = to;
                 continue;
             }
             br.refill();
@@ -357,8 +371,8 @@ __global__ __launch_bounds__(WAVES * 64) void k_dec_huffman(
                     br.skip(n0 + n1); used += n0 + n1;
                 }
                 bit += used;
-                if (v0 | v1) smp[sample >> 1] = (uint32_t)(uint16_t)v0 | ((uint32_t)(uint16_t)v1 << 16);
-            }
+                smp[sample >> 1] = (uint32_t)(uint16_t)v0 | ((uint32_t)(uint16_t)v1 << 16);
+            } else smp[sample >> 1] = 0;                          // no code word matches: the reference leaves the pair at zero
             sample += 2;
         }
         // ---- count1 quadruples (Frame.py:521-554, D1)
@@ -381,18 +395,27 @@ __global__ __launch_bounds__(WAVES * 64) void k_dec_huffman(
             }
             br.skip(used);
             bit += used;
-            if (val) {
-                smp[sample >> 1] = (uint32_t)(uint16_t)q[0] | ((uint32_t)(uint16_t)q[1] << 16);
-                smp[(sample >> 1) + 1] = (uint32_t)(uint16_t)q[2] | ((uint32_t)(uint16_t)q[3] << 16);
-            }
+            smp[sample >> 1] = (uint32_t)(uint16_t)q[0] | ((uint32_t)(uint16_t)q[1] << 16);
+            smp[(sample >> 1) + 1] = (uint32_t)(uint16_t)q[2] | ((uint32_t)(uint16_t)q[3] << 16);
             sample += 4;
         }
     }
-    if (err) {
-        atomicOr(status, err);
-        if (per_frame) atomicOr(status + 1 + f, err);   // which frame: the caller re-parses only the streams that hold one
-    }
+    for (int j = sample >> 1; j < 288; j++) smp[j] = 0;   // what no code word reached (everything, when the unit was rejected)
     }   // worker
+    // ---- status: the four units of a frame sit in four neighbouring lanes; the first of them stores the frame's word
+    //      (which frame: the caller re-parses only the streams that hold one), errors of the whole launch are collected
+    //      in the context's pair and handed out by the workgroup that finishes last (no fill launch in front of the kernel)
+    int e4 = err | __shfl_xor(err, 1, 64);
+    e4 |= __shfl_xor(e4, 2, 64);
+    if (lane < LANES && tid < (long)n_frames * 4 && (tid & 3) == 0) {
+        if (per_frame) status[1 + (tid >> 2)] = e4;
+        if (e4) atomicOr(&sync[1], e4);
+    }
+    __syncthreads();
+    if (threadIdx.x == 0 && atomicAdd(&sync[0], 1) == (int)gridDim.x - 1) {
+        status[0] = atomicExch(&sync[1], 0);
+        atomicExch(&sync[0], 0);
+    }
 }
 
 }  // namespace mp3s

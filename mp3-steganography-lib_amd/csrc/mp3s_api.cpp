@@ -71,7 +71,8 @@ int mp3s_ctx_create(int device, mp3s_ctx **out)
         mp3s_ctx_destroy(c);   // releases whatever was created
         return fail(MP3S_E_NO_DEVICE, "stream/event creation failed");
     }
-    if (hipMalloc((void **)&c->d_sync, 16) != hipSuccess || hipMemsetAsync(c->d_sync, 0, 16, c->stream) != hipSuccess) {
+    // self-clearing words of kernels in flight: [0..1] bit packer, [2] fast synthesis counter, [4..5] Huffman kernel
+    if (hipMalloc((void **)&c->d_sync, 32) != hipSuccess || hipMemsetAsync(c->d_sync, 0, 32, c->stream) != hipSuccess) {
         mp3s_ctx_destroy(c);
         return fail(MP3S_E_NO_DEVICE, "device scratch allocation failed");
     }
@@ -369,7 +370,7 @@ int mp3s_huffman_decode_dev(mp3s_ctx *c, const uint8_t *d_blob, const mp3s_frame
     if (!c || !d_blob || !d_side || !d_is || !d_si || !d_status) return fail(MP3S_E_ARG, "null pointer");
     if (n_frames <= 0 || nch < 1 || nch > 2 || max_part2_3_length < 0) return fail(MP3S_E_ARG, "bad sizes");
     if (max_part2_3_length == 0 || max_part2_3_length > 4095) max_part2_3_length = 4095;
-    const int e = launch_huffman(c->stream, d_blob, d_side, n_frames, nch, max_part2_3_length, d_is, d_si, d_status, &c->prof);
+    const int e = launch_huffman(c->stream, d_blob, d_side, n_frames, nch, max_part2_3_length, d_is, d_si, d_status, c->d_sync + 4, &c->prof);
     if (e) return fail(MP3S_E_HIP, "huffman launch: %s", hipGetErrorString((hipError_t)e));
     return MP3S_OK;
 }

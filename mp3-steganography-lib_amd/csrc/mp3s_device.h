@@ -65,7 +65,8 @@ int launch_copy(hipStream_t stream, const void *d_src, void *d_dst, size_t bytes
 
 // bit-level stages on the device
 int launch_huffman(hipStream_t stream, const uint8_t *d_blob, const mp3s_frame_side *d_side, int n_frames, int nch, int max_bits,
-                   int16_t *d_is, mp3s_granule_si *d_si, int32_t *d_status, Profiler *prof,
+                   int16_t *d_is, mp3s_granule_si *d_si, int32_t *d_status, int32_t *d_sync /* 2 zeroed words owned by the context */,
+                   Profiler *prof,
                    bool per_frame = false /* d_status holds 1 + n_frames words: [0] = all, [1 + f] = frame f */);
 // pairs: int32 [n][2] = (entry, unit): entry's ix / energies (compact == 2 arrays) -> the unit's place
 int launch_scatter(hipStream_t stream, const int32_t *d_pairs, int n_pairs, const int16_t *d_ixv, const int32_t *d_env, int16_t *d_ix,

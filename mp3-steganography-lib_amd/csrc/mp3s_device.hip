@@ -160,12 +160,9 @@ int launch_scatter(hipStream_t stream, const int32_t *d_pairs, int n_pairs, cons
 }
 
 int launch_huffman(hipStream_t stream, const uint8_t *d_blob, const mp3s_frame_side *d_side, int n_frames, int nch, int max_bits,
-                   int16_t *d_is, mp3s_granule_si *d_si, int32_t *d_status, Profiler *prof, bool per_frame)
+                   int16_t *d_is, mp3s_granule_si *d_si, int32_t *d_status, int32_t *d_sync, Profiler *prof, bool per_frame)
 {
-    hipError_t e = hipMemsetAsync(d_is, 0, (size_t)n_frames * 2304 * sizeof(int16_t), stream);
-    if (e == hipSuccess) e = hipMemsetAsync(d_si, 0, (size_t)n_frames * 4 * sizeof(mp3s_granule_si), stream);
-    if (e == hipSuccess) e = hipMemsetAsync(d_status, 0, sizeof(int32_t) * (per_frame ? (size_t)n_frames + 1 : 1), stream);
-    if (e != hipSuccess) return (int)e;
+    // (no fills in front of the kernel: it writes every sample pair, every side record and every status word itself)
     // LDS per workgroup = 30.8 KB of tables + W words per decoding lane, at most 64 KB.  Widest waves that still give
     // every SIMD about three waves to interleave; narrower ones otherwise (and for long granules, whose staging is big).
     const long units = (long)n_frames * 4;
@@ -178,7 +175,7 @@ int launch_huffman(hipStream_t stream, const uint8_t *d_blob, const mp3s_frame_s
     const int pp = prof ? prof->begin(stream, K_DEC_HUFFMAN) : -1;
 #define MP3S_HUF_LAUNCH(WV, LN)                                                                                         \
     hipLaunchKernelGGL((k_dec_huffman<WV, LN>), dim3((unsigned)((units + WV * LN - 1) / (WV * LN))), dim3(WV * 64),    \
-                       (size_t)W * WV * LN * 4, stream, d_blob, d_side, n_frames, nch, W, max_bits, d_is, d_si, d_status, per_frame ? 1 : 0)
+                       (size_t)W * WV * LN * 4, stream, d_blob, d_side, n_frames, nch, W, max_bits, d_is, d_si, d_status, per_frame ? 1 : 0, d_sync)
     if (lanes == 64) MP3S_HUF_LAUNCH(4, 64);
     else if (lanes == 32) MP3S_HUF_LAUNCH(4, 32);
     else if (lanes == 8) MP3S_HUF_LAUNCH(8, 8);

@@ -201,7 +201,7 @@ int issue_fast(mp3s_pipe *P, Job &j, Slot &s, size_t blob_len, int max_p23)
     HIPCHK(hipStreamWaitEvent(P->s_huff, s.e_up, 0));
     if (P->dec_used[set]) HIPCHK(hipStreamWaitEvent(P->s_huff, P->e_dec[set], 0));
     const int e = launch_huffman(P->s_huff, d_blob, (const mp3s_frame_side *)d_side, n, 2, max_p23, (int16_t *)d_is, (mp3s_granule_si *)d_si,
-                                 s.d_small + 3, &c->prof, false);
+                                 s.d_small + 3, c->d_sync + 4, &c->prof, false);
     if (e) return fail(MP3S_E_HIP, "huffman launch: %s", hipGetErrorString((hipError_t)e));
     if (launch_place_frames(P->s_huff, s.d_stage + s.o_fix, j.n_fix, (int16_t *)d_is, (mp3s_granule_si *)d_si))
         return fail(MP3S_E_HIP, "placing the host-decoded frames failed");
