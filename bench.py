@@ -74,6 +74,7 @@ def main():
                          "runs pass this so that the per-kernel averages of the trace describe the full-size launches)")
     ap.add_argument("--no-overlap", action="store_true",
                     help="run the Huffman front end of batch k+1 after, not under, the transform kernels of batch k")
+    ap.add_argument("--pack-overlap", action="store_true", help="bit packing of batch k on a third stream, under the decode of batch k+1")
     ap.add_argument("--resident-only", action="store_true", help="region (i) only (profiling runs)")
     args = ap.parse_args()
 
@@ -128,6 +129,10 @@ def main():
     d_si2 = [ctx.alloc(n * 4 * 72), ctx.alloc(n * 4 * 72)]
     d_hst2 = [ctx.alloc(16), ctx.alloc(16)]
     aux = None if args.no_overlap else _lib.Context(ctx.device)   # second stream on the same device
+    # third stream: the bit packer (LDS atomics, vector units mostly idle) of batch k runs under the decode transforms of
+    # batch k+1
+    # (measured: 0.923 against 0.915 ms per step without it -- packer and IMDCT stretch each other -- so it is off by default)
+    aux2 = _lib.Context(ctx.device) if (args.pack_overlap and not args.no_overlap) else None
     d_hdr = ctx.to_device(parsed["hdr"])
     rf, _pad = _lib.rate_frames(44100, 128, 2, n)
     rf["hide_end"] = len(hide)
@@ -187,14 +192,22 @@ def main():
         if aux is not None and not state.get("last"):
             aux.wait_for(ctx)                       # decode(k-1) has read its inputs; start under the rate loop, the longest kernel
             front_end(aux, k + 1)
+        if aux2 is not None:
+            ctx.wait_for(aux2)                      # the packer of batch k-1 has read what the rate loop is about to overwrite
         _lib.check(L.mp3s_rate_loop_dev(ctx.handle, d_mdct, d_rf, n, d_hide, len(hide), d_cur, None, None, 0, d_ix, d_out, d_en))
         _lib.check(L.mp3s_chain_resolve_dev(ctx.handle, d_out, d_rf, n, d_seg, 1, d_cur, None, d_verdict, d_segout))
-        _lib.check(L.mp3s_pack_frames_dev(ctx.handle, d_ix, d_out, d_en, n, 44100, 128, d_off, d_pad, d_mp3, d_sc, d_pst))
+        pk = ctx
+        if aux2 is not None:
+            aux2.wait_for(ctx)
+            pk = aux2
+        _lib.check(L.mp3s_pack_frames_dev(pk.handle, d_ix, d_out, d_en, n, 44100, 128, d_off, d_pad, d_mp3, d_sc, d_pst))
 
     def barrier():
         ctx.sync()
         if aux is not None:
             aux.sync()
+        if aux2 is not None:
+            aux2.sync()
         if dist is not None:
             dist.barrier()
 
@@ -210,15 +223,16 @@ def main():
     def collect():
         pr = ctx.profile_collect()
         on_main = {kname for kname, (ms, cnt) in pr.items() if cnt}          # launched on the main stream
-        if aux is not None:
-            for kname, (ms, cnt) in aux.profile_collect().items():
-                pr[kname] = (pr[kname][0] + ms, pr[kname][1] + cnt)
+        for c in (aux, aux2):
+            if c is not None:
+                for kname, (ms, cnt) in c.profile_collect().items():
+                    pr[kname] = (pr[kname][0] + ms, pr[kname][1] + cnt)
         return pr, on_main
 
     # ---- untimed pass with an event pair around every kernel: the per-kernel table and the choice of the dominant one.
     #      (An event pair costs stream time -- about 0.05 ms per step for all kernels -- so the timed region below
     #      carries them only around the dominant kernel, whose duration the roofline is computed from.)
-    for c in (ctx, aux):
+    for c in (ctx, aux, aux2):
         if c is not None:
             c.profile_select(None)
             c.profile_enable(True)
@@ -231,7 +245,7 @@ def main():
     # them (its own duration is stretched by sharing the CUs and is not what bounds the step)
     dom = max((kname for kname in per_step if kname in main_kernels), key=per_step.get)
     # ---- timed region (i): K steps, HIP events around the dominant kernel only
-    for c in (ctx, aux):
+    for c in (ctx, aux, aux2):
         if c is not None:
             c.profile_select([dom])
             c.profile_enable(True)
@@ -243,7 +257,7 @@ def main():
     barrier()
     wall = time.perf_counter() - t0
     prof, _ = collect()
-    for c in (ctx, aux):
+    for c in (ctx, aux, aux2):
         if c is not None:
             c.profile_enable(False)
             c.profile_select(None)
@@ -532,8 +546,9 @@ def main():
             "device": ctx.device_name(),
         }
         print(json.dumps(out))
-    if aux is not None:
-        aux.close()
+    for c in (aux, aux2):
+        if c is not None:
+            c.close()
     ctx.close()
     if dist is not None:
         dist.destroy_process_group()

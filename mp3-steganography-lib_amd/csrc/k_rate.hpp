@@ -298,7 +298,7 @@ __global__ __launch_bounds__(RL_WAVES * 64, 4) void k_rate_loop(
     // results of unit u go to element u - out_base of the three output arrays (0 except for the message variants,
     // whose arrays hold one chunk of units)
     __shared__ RlTables tb;
-    __shared__ uint8_t pcode_all[RL_WAVES][64 * RL_NP + 4];
+    __shared__ __attribute__((aligned(16))) uint8_t pcode_all[RL_WAVES][64 * RL_NP + 4];
     __shared__ int32_t esq_all[RL_WAVES][576];
     const int sr0 = frames[0].sr_idx;             // one sample rate per launch (the host splits batches otherwise)
     const int sr_wg = sr0 >= 0 && sr0 < 3 ? sr0 : 0;
@@ -360,13 +360,35 @@ __global__ __launch_bounds__(RL_WAVES * 64, 4) void k_rate_loop(
     __builtin_amdgcn_s_waitcnt(0xc07f);
     __builtin_amdgcn_wave_barrier();
     {
+        // Band sums through prefix sums: lane l adds up lines 9l .. 9l+8, a wave scan turns the 64 chunk sums into the
+        // sums of everything in front of each chunk, and a band lane completes its two bounds with at most 8 lines each
+        // (instead of walking bands of up to 76 lines with 21 of the 64 lanes).  Sums stay below 2^31 (576 x 2^21).
+        uint32_t chunk = 0;
+#pragma unroll
+        for (int k = 0; k < 9; k++) chunk += (uint32_t)esq[9 * lane + k];
+        uint32_t incl = chunk;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const uint32_t o = (uint32_t)__shfl_up((int)incl, d, 64);
+            if (lane >= d) incl += o;
+        }
+        __builtin_amdgcn_wave_barrier();       // every lane has read its chunk: the first 64 words now hold the prefixes
+        const uint32_t excl = incl - chunk;
+        uint32_t *pre = reinterpret_cast<uint32_t *>(pcode);   // (the pair codes are written later, by rl_body)
+        pre[lane] = excl;
+        __builtin_amdgcn_s_waitcnt(0xc07f);
+        __builtin_amdgcn_wave_barrier();
         int32_t temp = 0;
         if (lane < 21) {
             const int b0 = c_tab.sfb_long[sr][lane], b1 = c_tab.sfb_long[sr][lane + 1];
-            uint32_t s = 0;
-            for (int i = b0; i < b1; i++) s += (uint32_t)esq[i];
-            temp = (int32_t)s;
+            const int q0 = (b0 * 7282) >> 16, q1 = (b1 * 7282) >> 16;        // x / 9 for x <= 576
+            uint32_t p0 = pre[q0], p1 = pre[q1 < 64 ? q1 : 63];
+            if (q1 >= 64) p1 += __builtin_amdgcn_readlane((int)chunk, 63);   // (a bound of 576: everything)
+            for (int i = 9 * q0; i < b0; i++) p0 += (uint32_t)esq[i];
+            for (int i = 9 * q1; i < b1; i++) p1 += (uint32_t)esq[i];
+            temp = (int32_t)(p1 - p0);
         } else if (lane == 21) temp = (int32_t)etot;
+        __builtin_amdgcn_wave_barrier();
         // en = int32(log(temp * 4.768371584e-7) / 0.69314718): tabulated with the host's libm per octave of temp (value at
         // 2^k, and the argument from which on it is one more), so no device log and nothing to guard
         int32_t en = 0;
