@@ -522,6 +522,9 @@ void mp3s_pipe_destroy(mp3s_pipe *pipe);
  * jobs are in flight (collect one first) */
 int mp3s_pipe_submit(mp3s_pipe *pipe, const uint8_t *const *mp3s, const size_t *lens, int n_files, const uint8_t *const *msgs,
                      const size_t *msg_lens, int64_t *ticket);
+/* a decode job: the files of one mp3s_decode_file loop, MP3 bytes -> WAV bytes (int16) + stego bits per file; results
+ * through mp3s_pipe_collect like those of the other jobs (out[i].data = the WAV image, bits / n_bits set) */
+int mp3s_pipe_submit_decode(mp3s_pipe *pipe, const uint8_t *const *mp3s, const size_t *lens, int n_files, int64_t *ticket);
 /* waits for the OLDEST job in flight and hands out its results: out[i] / status[i] as mp3s_hide_messages fills them
  * (max_files = room in both arrays), *n_files = files of that job.  MP3S_E_BUSY: nothing in flight. */
 int mp3s_pipe_collect(mp3s_pipe *pipe, int64_t *ticket, mp3s_buf **owner, mp3s_file *out, int32_t *status, int max_files,

@@ -43,6 +43,7 @@ struct Job {
     int slot = -1;
     std::vector<std::pair<const uint8_t *, size_t>> files, msgs;   // borrowed until the job is collected
     bool clear_all = false;
+    bool decode = false;                 // MP3 -> WAV (int16) instead of hide / clear
     enum State { QUEUED, ISSUED, SLOW_DONE } state = QUEUED;
     // fast path
     std::vector<std::vector<uint8_t>> bits;
@@ -58,6 +59,11 @@ struct Job {
     std::string slow_err;
     double scan_ms = 0, issue_ms = 0;
     int n_fix = 0;
+    // decode jobs: per file the frames, rows, header fields, where its WAV starts in the result block, its stego bits
+    struct DecFile { int n_frames, nch, rate, bit_rate; size_t wav_off, bits_off, n_bits; };
+    std::vector<DecFile> dec;
+    std::vector<uint8_t> res_bits;
+    int nch = 2, n_total = 0, keep_set = 0;
 };
 
 }  // namespace
@@ -74,6 +80,9 @@ struct mp3s_pipe {
     hipEvent_t e_dec[2] = {nullptr, nullptr};
     bool dec_used[2] = {false, false};
     unsigned issued = 0;
+    // the int16 PCM of a batch lives in one of two device buffers taken in turn; a decode job downloads from it while the
+    // next job computes: keep_slot[x] = slot of the job whose download reads buffer x last (-1: none)
+    int keep_slot[2] = {-1, -1};
     std::mutex mu;                       // queue, job states, slots
     std::condition_variable cv_work, cv_done;
     std::mutex mu_issue;                 // everything that touches the context (its stream, pool, profiler)
@@ -120,6 +129,7 @@ bool prepare_fast(mp3s_pipe *P, Job &j, Slot &s, ParsedStream &p, size_t *blob_l
     j.segs.assign((size_t)nf, EncSeg());
     j.bits.assign((size_t)nf, {});
     j.n_fix = 0;
+    j.dec.clear(); j.res_bits.clear();
     mp3s_frame_hdr *dechdr = (mp3s_frame_hdr *)in;      // the input block starts with the decoder's frame headers
     for (int i = 0; i < nf; i++) {
         if (!j.files[i].first) return false;
@@ -127,12 +137,20 @@ bool prepare_fast(mp3s_pipe *P, Job &j, Slot &s, ParsedStream &p, size_t *blob_l
         k.blob = s.h_stage + base; k.blob_cap = s.blob_cap - base;
         k.side = side + n; k.side_cap = s.side_cap - (size_t)n;
         k.hdr = dechdr + n;
-        k.lean = true;
+        k.lean = !j.decode;                              // a decode job hands out the stego bits too
         if (parse_stream_sink(j.files[i].first, j.files[i].second, p, &k)) return false;
-        int kbps = 0;
-        if (reencode_params(p, &kbps)) return false;
-        if (i == 0) { j.rate = p.sampling_rate; j.kbps = kbps; }
-        else if (p.sampling_rate != j.rate || kbps != j.kbps) return false;   // more than one device batch
+        if (j.decode) {
+            if (p.n_frames <= 0 || p.dup_last_frame || p.nch < 1 || p.nch > 2) return false;
+            if (i == 0) j.nch = p.nch;
+            else if (p.nch != j.nch) return false;        // one device batch per channel count
+            j.dec.push_back({p.n_frames, p.nch, p.sampling_rate, p.bit_rate, 0, j.res_bits.size(), p.bits.size()});
+            j.res_bits.insert(j.res_bits.end(), p.bits.begin(), p.bits.end());
+        } else {
+            int kbps = 0;
+            if (reencode_params(p, &kbps)) return false;
+            if (i == 0) { j.rate = p.sampling_rate; j.kbps = kbps; }
+            else if (p.sampling_rate != j.rate || kbps != j.kbps) return false;   // more than one device batch
+        }
         for (int f = 0; f < p.n_frames; f++) {
             side[n + f].md_off += (uint32_t)base;
             side[n + f].reserved = (uint32_t)n;           // where the stream starts in the batch (scalefactor inheritance walks back to it)
@@ -153,7 +171,7 @@ bool prepare_fast(mp3s_pipe *P, Job &j, Slot &s, ParsedStream &p, size_t *blob_l
             j.n_fix++;
         }
         j.segs[i].n_frames = p.n_frames;
-        if (!j.clear_all && j.msgs[i].first) {
+        if (!j.decode && !j.clear_all && j.msgs[i].first) {
             message_frame(j.msgs[i].first, j.msgs[i].second, j.bits[i]);
             if (j.bits[i].size() > 0x7fffffff) return false;
             j.segs[i].hide = j.bits[i].data(); j.segs[i].n_hide = (int)j.bits[i].size();
@@ -163,6 +181,22 @@ bool prepare_fast(mp3s_pipe *P, Job &j, Slot &s, ParsedStream &p, size_t *blob_l
         if (base + 16 > s.blob_cap) return false;
     }
     *blob_len = base;
+    j.n_total = (int)n;
+    if (j.decode) {
+        // the result block: per file a WAV image, its PCM 64 bytes into an aligned region, the 44-byte header right in
+        // front of it (what mp3s_decode_file hands out)
+        size_t off = 0;
+        for (auto &d : j.dec) {
+            d.wav_off = off + 64 - 44;
+            off += 64 + (((size_t)d.n_frames * 1152 * d.nch * 2 + 63) & ~(size_t)63);
+        }
+        j.res.reset(new mp3s_buf());
+        if (!j.res->big[0].reserve(off) || !j.res->big[2].reserve(small_bytes(1))) return false;
+        j.res->mp3 = j.res->big[0].data();
+        for (const auto &d : j.dec) wav_header((int64_t)d.n_frames * 1152, d.nch, d.rate, j.res->mp3 + d.wav_off);
+        j.res->bits = std::move(j.res_bits);
+        return true;
+    }
     const double tA = trace_on() ? now_ms() : 0;
     if (enc_layout(j.segs, j.rate, j.kbps, j.L)) return false;
     const size_t o_enc = ((size_t)n * sizeof(mp3s_frame_hdr) + 15) & ~(size_t)15;
@@ -177,20 +211,17 @@ bool prepare_fast(mp3s_pipe *P, Job &j, Slot &s, ParsedStream &p, size_t *blob_l
     return true;
 }
 
-// everything a fast job does on the device, queued on the three streams; nothing is waited for
+// everything a fast job does on the device, queued on the streams; nothing is waited for
 int issue_fast(mp3s_pipe *P, Job &j, Slot &s, size_t blob_len, int max_p23)
 {
     mp3s_ctx *c = P->c;
     const EncLayout &L = j.L;
-    const int n = L.n, units = L.units;
-    const size_t o_enc = ((size_t)n * sizeof(mp3s_frame_hdr) + 15) & ~(size_t)15, in_bytes = o_enc + L.bytes;
+    const int n = j.n_total, units = n * 4, nch = j.decode ? j.nch : 2;
+    const size_t o_enc = ((size_t)n * sizeof(mp3s_frame_hdr) + 15) & ~(size_t)15, in_bytes = j.decode ? o_enc : o_enc + L.bytes;
     const int set = (int)(P->issued++ & 1u);
     void *d_is = c->grab(set ? 24 : 0, (size_t)n * 2304 * 2), *d_si = c->grab(set ? 25 : 1, (size_t)n * 4 * sizeof(mp3s_granule_si)),
-         *d_keep = c->grab(7, (size_t)n * 2304 * 2), *d_mdct = c->grab(10, (size_t)n * 2304 * 4), *d_ix = c->grab(12, (size_t)n * 2304 * 2),
-         *d_out = c->grab(13, (size_t)units * sizeof(mp3s_gr_out)), *d_en = c->grab(14, (size_t)units * 22 * 4),
-         *d_agg = c->grab(15, chain_agg_bytes(n)), *d_sc = c->grab(17, (size_t)n * 8 * 4);
-    if (!d_is || !d_si || !d_keep || !d_mdct || !d_ix || !d_out || !d_en || !d_agg || !d_sc)
-        return fail(MP3S_E_NOMEM, "hipMalloc failed for a %d-frame job", n);
+         *d_keep = c->grab(set ? 26 : 7, (size_t)n * 2304 * 2);
+    if (!d_is || !d_si || !d_keep) return fail(MP3S_E_NOMEM, "hipMalloc failed for a %d-frame job", n);
     uint8_t *d_blob = s.d_stage, *d_side = s.d_stage + s.o_side, *d_in = s.d_stage + s.o_in;
     HIPCHK(hipEventRecord(s.e_start, P->s_up));
     HIPCHK(hipMemcpyAsync(d_blob, s.h_stage, blob_len, hipMemcpyHostToDevice, P->s_up));
@@ -200,24 +231,45 @@ int issue_fast(mp3s_pipe *P, Job &j, Slot &s, size_t blob_len, int max_p23)
     HIPCHK(hipEventRecord(s.e_up, P->s_up));
     HIPCHK(hipStreamWaitEvent(P->s_huff, s.e_up, 0));
     if (P->dec_used[set]) HIPCHK(hipStreamWaitEvent(P->s_huff, P->e_dec[set], 0));
-    const int e = launch_huffman(P->s_huff, d_blob, (const mp3s_frame_side *)d_side, n, 2, max_p23, (int16_t *)d_is, (mp3s_granule_si *)d_si,
+    const int e = launch_huffman(P->s_huff, d_blob, (const mp3s_frame_side *)d_side, n, nch, max_p23, (int16_t *)d_is, (mp3s_granule_si *)d_si,
                                  s.d_small + 3, c->d_sync + 4, &c->prof, false);
     if (e) return fail(MP3S_E_HIP, "huffman launch: %s", hipGetErrorString((hipError_t)e));
     if (launch_place_frames(P->s_huff, s.d_stage + s.o_fix, j.n_fix, (int16_t *)d_is, (mp3s_granule_si *)d_si))
         return fail(MP3S_E_HIP, "placing the host-decoded frames failed");
     HIPCHK(hipEventRecord(s.e_huff, P->s_huff));
     HIPCHK(hipStreamWaitEvent(c->stream, s.e_huff, 0));
+    // the PCM buffer of this set may still be read by the download of the decode job that used it last
+    if (P->keep_slot[set] >= 0) HIPCHK(hipStreamWaitEvent(c->stream, P->slots[(size_t)P->keep_slot[set]].e_down, 0));
+    P->keep_slot[set] = j.decode ? j.slot : -1;
     const mp3s_frame_hdr *d_dechdr = (const mp3s_frame_hdr *)d_in;
     const mp3s_frame_hdr *h_dechdr = (const mp3s_frame_hdr *)(s.h_stage + s.o_in);
+    const size_t frame_elems = (size_t)1152 * nch;
     for (long start = 0; start < n; start += kDecodeChunk) {
         const int halo = (start && h_dechdr[start].stream_first < (uint32_t)start) ? 1 : 0;
         const int cnt = (int)std::min<long>(kDecodeChunk, n - start) + halo;
-        const int rc = decode_transform_chunk(c, (const int16_t *)d_is, (const mp3s_granule_si *)d_si, d_dechdr, start - halo, cnt, 2, halo,
-                                              MP3S_PCM_I16, (int16_t *)d_keep + (size_t)start * 2304);
+        const int rc = decode_transform_chunk(c, (const int16_t *)d_is, (const mp3s_granule_si *)d_si, d_dechdr, start - halo, cnt, nch, halo,
+                                              MP3S_PCM_I16, (int16_t *)d_keep + (size_t)start * frame_elems);
         if (rc) return rc;
     }
     HIPCHK(hipEventRecord(P->e_dec[set], c->stream));
     P->dec_used[set] = true;
+    if (j.decode) {
+        HIPCHK(hipEventRecord(s.e_comp, c->stream));
+        HIPCHK(hipStreamWaitEvent(P->s_down, s.e_comp, 0));
+        HIPCHK(hipMemcpyAsync(j.res->big[2].data(), s.d_small, kSmallHead, hipMemcpyDeviceToHost, P->s_down));
+        size_t first = 0;
+        for (const auto &d : j.dec) {
+            const size_t bytes = (size_t)d.n_frames * frame_elems * 2;
+            HIPCHK(hipMemcpyAsync(j.res->mp3 + d.wav_off + 44, (const int16_t *)d_keep + first * frame_elems, bytes, hipMemcpyDeviceToHost, P->s_down));
+            first += (size_t)d.n_frames;
+        }
+        HIPCHK(hipEventRecord(s.e_down, P->s_down));
+        return MP3S_OK;
+    }
+    void *d_mdct = c->grab(10, (size_t)n * 2304 * 4), *d_ix = c->grab(12, (size_t)n * 2304 * 2),
+         *d_out = c->grab(13, (size_t)units * sizeof(mp3s_gr_out)), *d_en = c->grab(14, (size_t)units * 22 * 4),
+         *d_agg = c->grab(15, chain_agg_bytes(n)), *d_sc = c->grab(17, (size_t)n * 8 * 4);
+    if (!d_mdct || !d_ix || !d_out || !d_en || !d_agg || !d_sc) return fail(MP3S_E_NOMEM, "hipMalloc failed for a %d-frame job", n);
     EncDev dev;
     dev.d_pcm = (const int16_t *)d_keep; dev.d_in = d_in + o_enc; dev.d_mdct_all = (int32_t *)d_mdct; dev.d_ix = (int16_t *)d_ix;
     dev.d_out = (mp3s_gr_out *)d_out; dev.d_en = (int32_t *)d_en; dev.d_agg = d_agg; dev.d_mp3 = s.d_mp3; dev.d_sc = (int32_t *)d_sc;
@@ -243,9 +295,23 @@ void run_slow(mp3s_pipe *P, Job &j)   // mu_issue held
         mp[i] = j.clear_all ? nullptr : j.msgs[i].first; ml[i] = j.clear_all ? 0 : j.msgs[i].second;
     }
     (void)hipStreamSynchronize(P->s_huff);   // the synchronous path uses the same Huffman output buffers
+    (void)hipStreamSynchronize(P->s_down);   // ... and the PCM buffer a download may still be reading
     j.slow_out.assign((size_t)nf, mp3s_file());
     j.slow_st.assign((size_t)nf, 0);
     j.res.reset();
+    if (j.decode) {
+        // file by file through mp3s_decode_file; the owners travel in one
+        std::unique_ptr<mp3s_buf> top(new mp3s_buf());
+        for (int i = 0; i < nf; i++) {
+            mp3s_buf *part = nullptr;
+            j.slow_st[(size_t)i] = j.files[i].first ? mp3s_decode_file(P->c, j.files[i].first, j.files[i].second, &part, &j.slow_out[(size_t)i]) : MP3S_E_ARG;
+            if (j.slow_st[(size_t)i]) { j.slow_err = mp3s_last_error(); std::memset(&j.slow_out[(size_t)i], 0, sizeof(mp3s_file)); }
+            else top->parts.emplace_back(part);
+        }
+        j.slow_rc = MP3S_OK;
+        j.slow_owner = top.release();
+        return;
+    }
     j.slow_rc = mp3s_hide_messages(P->c, fp.data(), fl.data(), nf, j.clear_all ? nullptr : mp.data(), ml.data(), &j.slow_owner, j.slow_out.data(),
                                    j.slow_st.data());
     j.slow_err = mp3s_last_error();
@@ -416,6 +482,29 @@ int mp3s_pipe_submit(mp3s_pipe *P, const uint8_t *const *mp3s, const size_t *len
     return MP3S_OK;
 }
 
+int mp3s_pipe_submit_decode(mp3s_pipe *P, const uint8_t *const *mp3s, const size_t *lens, int n_files, int64_t *ticket)
+{
+    if (!P || !mp3s || !lens || n_files <= 0) return fail(MP3S_E_ARG, "bad argument");
+    std::unique_ptr<Job> j(new Job());
+    j->decode = true; j->clear_all = true;
+    j->files.resize((size_t)n_files); j->msgs.assign((size_t)n_files, {nullptr, 0});
+    for (int i = 0; i < n_files; i++) j->files[i] = {mp3s[i], lens[i]};
+    {
+        std::lock_guard<std::mutex> g(P->mu);
+        int slot = -1;
+        for (int k = 0; k < P->depth; k++) if (!P->slots[(size_t)k].busy) { slot = k; break; }
+        if (slot < 0) return fail(MP3S_E_BUSY, "all %d slots are taken: collect a result first", P->depth);
+        P->slots[(size_t)slot].busy = true;
+        j->slot = slot; j->ticket = P->next_ticket++;
+        if (ticket) *ticket = j->ticket;
+        P->todo[(size_t)slot % P->todo.size()].push_back(j.get());
+        P->inflight.push_back(std::move(j));
+        P->st.submitted++;
+    }
+    P->cv_work.notify_all();
+    return MP3S_OK;
+}
+
 int mp3s_pipe_collect(mp3s_pipe *P, int64_t *ticket, mp3s_buf **owner, mp3s_file *out, int32_t *status, int max_files, int *n_files)
 {
     if (!P || !owner || !out || !status) return fail(MP3S_E_ARG, "null pointer");
@@ -436,7 +525,7 @@ int mp3s_pipe_collect(mp3s_pipe *P, int64_t *ticket, mp3s_buf **owner, mp3s_file
         if (hipEventSynchronize(s.e_down) != hipSuccess) rc = fail(MP3S_E_HIP, "waiting for the job's results failed");
         else {
             const int32_t *small = (const int32_t *)j->res->big[2].data();
-            fast_ok = small[0] == 0 && small[1] == 0 && small[2] == 0 && small[3] == 0;
+            fast_ok = j->decode ? small[3] == 0 : (small[0] == 0 && small[1] == 0 && small[2] == 0 && small[3] == 0);
             float ms = 0;
             if (hipEventElapsedTime(&ms, s.e_start, s.e_down) == hipSuccess) P->st.last_device_span_ms = ms;
             if (!fast_ok) {
@@ -447,7 +536,17 @@ int mp3s_pipe_collect(mp3s_pipe *P, int64_t *ticket, mp3s_buf **owner, mp3s_file
         }
     }
     if (!rc) {
-        if (fast_ok) {
+        if (fast_ok && j->decode) {
+            for (int i = 0; i < nf; i++) {
+                const Job::DecFile &d = j->dec[(size_t)i];
+                std::memset(&out[i], 0, sizeof out[i]);
+                out[i].data = j->res->mp3 + d.wav_off; out[i].len = 44 + (size_t)d.n_frames * 1152 * d.nch * 2;
+                out[i].kbps = d.bit_rate / 1000; out[i].sampling_rate = d.rate; out[i].channels = d.nch; out[i].n_frames = d.n_frames;
+                out[i].n_bits = (int32_t)d.n_bits; out[i].bits = j->res->bits.data() + d.bits_off;
+                status[i] = MP3S_OK;
+            }
+            *owner = j->res.release();
+        } else if (fast_ok) {
             const mp3s_chain_seg_out *so = (const mp3s_chain_seg_out *)(j->res->big[2].data() + kSmallHead);
             for (int i = 0; i < nf; i++) {
                 const EncSeg &sg = j->segs[(size_t)i];

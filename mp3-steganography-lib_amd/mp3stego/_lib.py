@@ -132,7 +132,7 @@ SYMBOLS = ["mp3s_ctx_create", "mp3s_ctx_destroy", "mp3s_ctx_wait", "mp3s_last_er
            "mp3s_parse_stream", "mp3s_format_stream", "mp3s_rate_frames", "mp3s_decode_stream", "mp3s_decode_streams", "mp3s_decode_block", "mp3s_encode_pcm", "mp3s_encode_block",
            "mp3s_wav_parse", "mp3s_wav_header", "mp3s_message_frame", "mp3s_message_reveal", "mp3s_decode_file", "mp3s_encode_file",
            "mp3s_hide_message", "mp3s_clear_file", "mp3s_hide_messages", "mp3s_reencode_block", "mp3s_reveal_message",
-           "mp3s_pipe_create", "mp3s_pipe_destroy", "mp3s_pipe_submit", "mp3s_pipe_collect", "mp3s_pipe_get_stats",
+           "mp3s_pipe_create", "mp3s_pipe_destroy", "mp3s_pipe_submit", "mp3s_pipe_submit_decode", "mp3s_pipe_collect", "mp3s_pipe_get_stats",
            "mp3s_index_stream", "mp3s_index_free", "mp3s_scan_range", "mp3s_decode_block_indexed", "mp3s_reencode_block_indexed",
            "mp3s_hide_message_chunked"]
 
@@ -221,6 +221,7 @@ def lib():
         L.mp3s_pipe_destroy.argtypes = [vp]
         L.mp3s_pipe_destroy.restype = None
         L.mp3s_pipe_submit.argtypes = [vp, vp, vp, i32, vp, vp, C.POINTER(C.c_int64)]
+        L.mp3s_pipe_submit_decode.argtypes = [vp, vp, vp, i32, C.POINTER(C.c_int64)]
         L.mp3s_pipe_collect.argtypes = [vp, C.POINTER(C.c_int64), pvp, vp, vp, i32, C.POINTER(C.c_int32)]
         L.mp3s_pipe_get_stats.argtypes = [vp, C.POINTER(PipeStats)]
         _lib = L
@@ -635,6 +636,20 @@ class Pipe:
         self._keep[t.value] = (mp3s, bufs, msgs, files, lens, mptr, mlen)
         return t.value
 
+    def submit_decode(self, mp3s):
+        """a decode job (MP3 -> WAV bytes + stego bits per file) -> ticket, or None when every slot is taken"""
+        n = len(mp3s)
+        bufs = [np.frombuffer(m, dtype=np.uint8) for m in mp3s]
+        files = (C.c_void_p * n)(*[b.ctypes.data for b in bufs])
+        lens = (C.c_size_t * n)(*[len(b) for b in bufs])
+        t = C.c_int64()
+        rc = lib().mp3s_pipe_submit_decode(self.handle, files, lens, n, C.byref(t))
+        if rc == E_BUSY:
+            return None
+        check(rc)
+        self._keep[t.value] = (mp3s, bufs, files, lens)
+        return t.value
+
     def collect(self):
         """-> (ticket, [per file: the dict Context.hide_message returns, or the Mp3sError that file alone would raise]);
         None when nothing is in flight.  "data" is a read-only view of the library's page-locked result block."""
@@ -653,7 +668,7 @@ class Pipe:
             else:
                 res.append({"data": Context._owned_bytes(f.data, f.len, own), "kbps": f.kbps, "sampling_rate": f.sampling_rate,
                             "channels": f.channels, "n_frames": f.n_frames, "too_long": bool(f.too_long),
-                            "hide_offset": f.hide_offset})
+                            "hide_offset": f.hide_offset, "bits": _view(f.bits, np.uint8, (f.n_bits,))})
         return t.value, res
 
     def stats(self):

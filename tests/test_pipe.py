@@ -198,3 +198,63 @@ def test_chain_check_on_the_device(ctx, mlib):
     assert (before["flags"] & mlib.RF_ACTIVE == 0).sum() >= 40 * 4   # the silent stretches are really silent
     assert int(ver[0]) == n_redo and int(ver[1]) == 0
     assert n_redo > 0                                                  # silence shifts the cursor: the guess 3 per unit fails
+
+
+def test_pipe_decode_jobs(mlib, golden_dir):
+    """decode jobs (MP3 -> WAV bytes + stego bits) interleaved with hide jobs: what mp3s_decode_file gives, file by file"""
+    from synth_pcm import synth_pcm
+    import frame_synth
+    ctx = mlib.Context(0)
+    try:
+        a = bytes(ctx.encode_pcm(synth_pcm(300, seed=5), 44100, 128, None)["mp3"])
+        b = bytes(ctx.encode_pcm(synth_pcm(70, rate=48000, seed=6), 48000, 192, None)["mp3"])
+        mono = frame_synth.make_stream(12, 80, mode=3)
+        mixed = frame_synth.make_stream(13, 50, block_types=(0, 2), allow_mixed=True)
+        test_mp3 = open(os.path.join(golden_dir, "test.mp3"), "rb").read()
+        g = np.load(os.path.join(golden_dir, "g7_decode_corpus.npz"))
+        corpus = [g[n + "__mp3"].tobytes() for n in sorted({k.split("__")[0] for k in g.files})]
+        jobs = [("d", [a]), ("d", [b, a]), ("h", [a], ["hello"]), ("d", [mono]), ("d", [mixed, test_mp3]), ("d", [a[:-500]]),   # cut: repeated last frame
+                ("d", [mono, a]), ("h", [b], None), ("d", corpus), ("d", [b"junk" * 40, a]), ("d", [test_mp3])]
+
+        def want_of(job):
+            if job[0] == "h":
+                return ctx.hide_messages(job[1], [None] * len(job[1]) if job[2] is None else job[2])
+            out = []
+            for f in job[1]:
+                try:
+                    out.append(ctx.decode_file(f))
+                except mlib.Mp3sError as e:
+                    out.append(e)
+            return out
+        want = [want_of(j) for j in jobs]
+        for depth, threads in ((3, 2), (1, 1), (4, 4)):
+            pipe = mlib.Pipe(ctx, depth=depth, max_job_bytes=1 << 20, scan_threads=threads)
+            try:
+                got, nxt = [], 0
+                seq = jobs * 2
+                while len(got) < len(seq):
+                    while nxt < len(seq):
+                        j = seq[nxt]
+                        t = pipe.submit_decode(j[1]) if j[0] == "d" else pipe.submit(j[1], j[2])
+                        if t is None:
+                            break
+                        nxt += 1
+                    got.append(pipe.collect()[1])
+                st = pipe.stats()
+            finally:
+                pipe.close()
+            for k, res in enumerate(got):
+                w = want[k % len(jobs)]
+                assert len(res) == len(w), k
+                for x, y in zip(res, w):
+                    if isinstance(y, Exception):
+                        assert isinstance(x, mlib.Mp3sError) and x.code == y.code, (k, x, y)
+                        continue
+                    assert not isinstance(x, Exception), (k, x)
+                    assert bytes(x["data"]) == bytes(y["data"]), k
+                    assert (x["kbps"], x["sampling_rate"], x["channels"], x["n_frames"]) == (y["kbps"], y["sampling_rate"], y["channels"], y["n_frames"]), k
+                    if jobs[k % len(jobs)][0] == "d":
+                        assert np.array_equal(x["bits"], y["bits"]), k
+            assert st["fast"] >= 2 * 7, st
+    finally:
+        ctx.close()
