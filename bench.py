@@ -52,6 +52,12 @@ N_SIMD, CLOCK_GHZ, CLK_PER_VALU = 1024, 2.4, 4.0   # 256 CUs x 4 SIMDs; fp64 / 3
 MESSAGE = "64#" + "The quick brown fox jumps over the lazy dog, again & again, 0123"
 
 
+def same_bytes(view, ref):
+    """compare a result (a view of the library's page-locked block) with reference bytes without copying it"""
+    a, b = np.frombuffer(view, dtype=np.uint8), np.frombuffer(ref, dtype=np.uint8)
+    return a.size == b.size and bool(np.array_equal(a, b))
+
+
 def bits_of(s):
     return np.frombuffer("".join(format(b, "08b") for b in s.encode()).encode(), dtype=np.uint8) - ord("0")
 
@@ -384,7 +390,7 @@ def main():
                         sub += 1
                     _t, res = pipe.collect()
                     if got % check_every == 0 or got == batches - 1:
-                        ok = ok and bytes(res[0]["data"]) == ref_out
+                        ok = ok and same_bytes(res[0]["data"], ref_out)
                     del res
                     got += 1
                 return ok
@@ -407,6 +413,34 @@ def main():
                           "bytes_in_per_batch": len(mp3_in), "bytes_out_per_batch": len(ref_out),
                           "what": "MP3 bytes -> MP3 bytes with the message hidden, mp3s_pipe_*: host scan (worker threads, into page-locked "
                                   "staging) || hipMemcpyAsync up || kernels || hipMemcpyAsync down; every 16th result compared with the one-shot call"}
+        # config 2 host-fed: MP3 bytes -> WAV bytes (46 MB of int16 PCM down per batch), steady state
+        if args.e2e_batches > 0:
+            wav_ref = bytes(ctx.decode_file(mp3_in)["data"])
+            pipe = _lib.Pipe(pctx, depth=args.pipe_depth, max_job_bytes=max_job, scan_threads=args.scan_threads)
+            nbd = max(40, args.e2e_batches // 4)
+
+            def pump_dec(batches, check_every):
+                ok, sub, got = True, 0, 0
+                while got < batches:
+                    while sub < batches and pipe.submit_decode([mp3_in]) is not None:
+                        sub += 1
+                    _t, res = pipe.collect()
+                    if got % check_every == 0 or got == batches - 1:
+                        ok = ok and same_bytes(res[0]["data"], wav_ref)
+                    del res
+                    got += 1
+                return ok
+            same = pump_dec(8, 1) and same
+            t0 = time.perf_counter()
+            ok = pump_dec(nbd, 64)
+            t_dec_steady = reduce_max(time.perf_counter() - t0)
+            sd = pipe.stats()
+            pipe.close()
+            same = same and ok and sd["slow"] == 0
+            regions["decode_steady"] = {"frames_per_s": round(n * nbd * world / t_dec_steady, 1), "ms_per_batch": round(t_dec_steady / nbd * 1e3, 4), "batches": nbd,
+                                        "pcm_mb_down_per_batch": round(n * 2304 * 2 / 1e6, 1), "pcie_gbs_down": round(n * 2304 * 2 * nbd / t_dec_steady / 1e9, 1),
+                                        "what": "BASELINE configs[1] host-fed: MP3 bytes -> WAV bytes (int16) through mp3s_pipe_submit_decode, several batches in "
+                                                "flight; the download of one batch's PCM runs under the kernels of the next"}
         pctx.close()
         # many short files: the stream cut into 40-frame files, one device batch vs one call per file
         if not args.no_short_files:
