@@ -423,7 +423,9 @@ int mp3s_pipe_create(mp3s_ctx *c, int depth, size_t max_job_bytes, int scan_thre
             hipMalloc((void **)&s.d_mp3, s.mp3_cap) != hipSuccess || hipMalloc((void **)&s.d_small, small_bytes(kMaxFastFiles)) != hipSuccess ||
             hipEventCreate(&s.e_start) != hipSuccess || hipEventCreate(&s.e_up) != hipSuccess || hipEventCreate(&s.e_huff) != hipSuccess ||
             hipEventCreate(&s.e_comp) != hipSuccess ||
-            hipEventCreate(&s.e_down) != hipSuccess)
+            // the collecting thread sleeps on this one instead of spinning: with one process per GPU on a shared host the
+            // cores are needed by the scan workers (the wake-up latency disappears behind the jobs in flight)
+            hipEventCreateWithFlags(&s.e_down, getenv("MP3S_PIPE_SPIN") ? hipEventDefault : hipEventBlockingSync) != hipSuccess)
             return destroy(MP3S_E_NOMEM, "slot allocation failed");
     }
     P->todo.resize((size_t)scan_threads);
