@@ -6,6 +6,7 @@ import json
 import os
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HBM_PEAK = 8000.0
 
 
 def test_latest_bench_line_has_the_contract_fields():
@@ -29,3 +30,15 @@ def test_latest_bench_line_has_the_contract_fields():
     # whole-job value = frames of all ranks / step time
     assert abs(line["value"] - line["config"]["frames_per_gpu"] * line["n_gpus"] / (line["ms_per_step"] * 1e-3)) / line["value"] < 0.01
     assert line["parity_checked"] is True
+    # round 2 and later: the binding roofline, the copy kernel, and the host-fed regions, steps-averaged
+    if "e2e_steady" in line:
+        a = line["roofline_alu"]
+        assert a["bound"] == "valu_issue" and 0 < a["frac"] < 1 and abs(a["frac"] - a["achieved"] / a["peak"]) < 1e-3
+        assert a["kernel"] == r["kernel"] and a["valu_wave_instructions_per_launch"] > 0
+        assert r["copy_kernel_gbs"] and 1000 < r["copy_kernel_gbs"] < HBM_PEAK
+        e = line["e2e_steady"]
+        assert e["steps"] >= 200 and e["frames_per_s"] > 0
+        assert abs(e["frames_per_s"] - line["config"]["frames_per_gpu"] * line["n_gpus"] / (e["ms_per_batch"] * 1e-3)) / e["frames_per_s"] < 0.01
+        for k in ("h2d_kernels_d2h", "bytes_to_bytes_one_at_a_time", "decode_steady"):
+            assert line["regions"][k]["batches"] >= 10 and line["regions"][k]["ms_per_batch"] > 0, k
+        assert line["decode_only"]["steps"] >= 10 and line["config"]["chain_verdict_units_to_redo"] == 0
