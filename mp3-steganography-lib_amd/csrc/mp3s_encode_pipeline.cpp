@@ -72,8 +72,11 @@ int enc_fill(std::vector<EncSeg> &segs, EncLayout &L, uint8_t *dst)
         // a short message in a long stream that is almost always right); a long message is left to the variants.
         const int64_t c0 = cursor0(s);
         const bool long_msg = s.n_hide - c0 > kLongMessageBits;
-        for (int j = 0; j < s.n_frames * 4; j++)
-            cursor[(size_t)s.first * 4 + j] = long_msg ? kNoCursor : (int32_t)std::min<int64_t>((int64_t)s.hide_base + c0 + 3 * (int64_t)j, kNoCursor);
+        int64_t ahead = 0;               // tables the units in front are expected to take
+        for (int j = 0; j < s.n_frames * 4; j++) {
+            cursor[(size_t)s.first * 4 + j] = long_msg ? kNoCursor : (int32_t)std::min<int64_t>((int64_t)s.hide_base + c0 + ahead, kNoCursor);
+            ahead += s.tables_guess ? s.tables_guess[j] : 3;
+        }
         cs[si].first_frame = s.first; cs[si].n_frames = s.n_frames;
         cs[si].hide_base = s.hide_base; cs[si].hide_begin = (int32_t)((int64_t)s.hide_base + c0);   // (both below 2^30)
         cs[si].hide_end = s.hide_base + s.n_hide;
@@ -89,6 +92,23 @@ int enc_fill(std::vector<EncSeg> &segs, EncLayout &L, uint8_t *dst)
         if (s.last) s.mp3_len -= std::min<size_t>(s.mp3_len, (size_t)((L.bytes_before + (int64_t)s.mp3_len) % 4));
     }
     return MP3S_OK;
+}
+
+void tables_guess_of(const mp3s_frame_side *side, long n_frames, int extra, std::vector<uint8_t> &out)
+{
+    out.resize((size_t)(n_frames + extra) * 4);
+    for (long f = 0; f < n_frames + extra; f++) {
+        const mp3s_frame_side &fs = side[f < n_frames ? f : n_frames - 1];
+        for (int ch = 0; ch < 2; ch++)
+            for (int gr = 0; gr < 2; gr++) {
+                const mp3s_unit_side &u = fs.unit[gr][ch];
+                // (a granule without big values has no table of its own in this encoder's output; a window-switching one
+                // of a foreign stream carries two)
+                int n = 0;
+                if (u.big_values) for (int r = 0; r < (u.window_switching ? 2 : 3); r++) n += u.table_select[r] != 0;
+                out[(size_t)f * 4 + ch * 2 + gr] = (uint8_t)n;
+            }
+    }
 }
 
 int enc_issue(mp3s_ctx *c, const EncLayout &L, const EncDev &d)
@@ -502,10 +522,16 @@ static int reencode_group(mp3s_ctx *c, mp3s_multi &m, const std::vector<int> &id
                           int samplerate, int kbps, mp3s_buf *top, mp3s_file *out)
 {
     std::vector<EncSeg> segs(idx.size());
+    std::vector<std::vector<uint8_t>> guess(idx.size());
     int64_t rows_frames = 0;
     for (size_t k = 0; k < idx.size(); k++) {
         const ParsedStream &p = m.parsed[idx[k]];
         segs[k].n_frames = p.n_frames + (p.dup_last_frame ? 1 : 0);
+        const ScannedStream &sc = m.scanned[idx[k]];
+        if (!sc.host_parsed && (long)sc.side.size() == p.n_frames && p.n_frames > 0 && !bits[idx[k]].empty()) {
+            tables_guess_of(sc.side.data(), p.n_frames, p.dup_last_frame ? 1 : 0, guess[k]);
+            segs[k].tables_guess = guess[k].data();
+        }
         if (bits[idx[k]].size() > 0x7fffffff) return fail(MP3S_E_ARG, "message too long");
         segs[k].hide = bits[idx[k]].data(); segs[k].n_hide = (int)bits[idx[k]].size();
         rows_frames += segs[k].n_frames;

@@ -225,6 +225,11 @@ struct EncSeg {             // one stream of an encode batch: frames back to bac
     int64_t first_frame = 0;         // index of the block's first frame in its stream (padding recurrence)
     bool last = true;                // the stream ends with this block (the reference drops the cached tail there: E14)
     const mp3s_carry *carry_in = nullptr;
+    // The first pass of the rate loop runs every unit on a GUESSED message cursor: the tables the units in front of it will
+    // take.  Without better knowledge that is three per unit.  A stream that is being re-encoded brings better knowledge:
+    // the non-zero table indices of the SAME audio in the stream it was decoded from (side info of the input, unit order
+    // frame / channel / granule; silence has none).  n_frames * 4 entries, or null.
+    const uint8_t *tables_guess = nullptr;
     // filled by encode_batch
     int first = 0, hide_base = 0;
     int64_t hide_offset = 0;         // message bits consumed (from the start of the stream)
@@ -262,3 +267,6 @@ struct EncDev {
 int enc_issue(mp3s_ctx *c, const EncLayout &L, const EncDev &d);
 int encode_batch(mp3s_ctx *c, const int16_t *pcm, const int16_t *pcm_dev, std::vector<EncSeg> &segs, int samplerate, int bitrate_kbps,
                  mp3s_buf *b, int *passes_out, bool want_gr = true);
+// non-zero table indices per unit of a scanned stream, in the encoder's unit order (frame, channel, granule): see
+// EncSeg::tables_guess; `extra` more frames (the repeated last frame of a stream that ends in a bad header) repeat the last
+void tables_guess_of(const mp3s_frame_side *side, long n_frames, int extra, std::vector<uint8_t> &out);

@@ -46,7 +46,7 @@ struct Job {
     bool decode = false;                 // MP3 -> WAV (int16) instead of hide / clear
     enum State { QUEUED, ISSUED, SLOW_DONE } state = QUEUED;
     // fast path
-    std::vector<std::vector<uint8_t>> bits;
+    std::vector<std::vector<uint8_t>> bits, guess;
     std::vector<EncSeg> segs;
     EncLayout L;
     int rate = 0, kbps = 0;
@@ -128,6 +128,7 @@ bool prepare_fast(mp3s_pipe *P, Job &j, Slot &s, ParsedStream &p, size_t *blob_l
     long n = 0;
     j.segs.assign((size_t)nf, EncSeg());
     j.bits.assign((size_t)nf, {});
+    j.guess.assign((size_t)nf, {});
     j.n_fix = 0;
     j.dec.clear(); j.res_bits.clear();
     mp3s_frame_hdr *dechdr = (mp3s_frame_hdr *)in;      // the input block starts with the decoder's frame headers
@@ -175,6 +176,8 @@ bool prepare_fast(mp3s_pipe *P, Job &j, Slot &s, ParsedStream &p, size_t *blob_l
             message_frame(j.msgs[i].first, j.msgs[i].second, j.bits[i]);
             if (j.bits[i].size() > 0x7fffffff) return false;
             j.segs[i].hide = j.bits[i].data(); j.segs[i].n_hide = (int)j.bits[i].size();
+            tables_guess_of(side + n, p.n_frames, 0, j.guess[i]);        // the cursor guess of the first pass: the input's own tables
+            j.segs[i].tables_guess = j.guess[i].data();
         }
         n += p.n_frames;
         base = (base + k.blob_len + 3) & ~(size_t)3;
@@ -531,6 +534,8 @@ int mp3s_pipe_collect(mp3s_pipe *P, int64_t *ticket, mp3s_buf **owner, mp3s_file
             float ms = 0;
             if (hipEventElapsedTime(&ms, s.e_start, s.e_down) == hipSuccess) P->st.last_device_span_ms = ms;
             if (!fast_ok) {
+                if (trace_on()) fprintf(stderr, "mp3s: pipe job %lld: verdict %d units to redo, step range %d, packer %d, Huffman status 0x%x -> synchronous path\n",
+                                        (long long)j->ticket, small[0], small[1], small[2], small[3]);
                 // the cursor guess failed (long message), or damaged Huffman data: the synchronous path decides
                 std::lock_guard<std::mutex> gi(P->mu_issue);
                 run_slow(P, *j);
