@@ -68,3 +68,33 @@ def test_ranges_of_damaged_streams(mlib, golden_dir):
     _check(mlib, tag + bytes(mp3), [(0, 36), (30, 10)])
     with pytest.raises(mlib.Mp3sError):
         mlib.StreamIndex(b"\xff\xfb\x90")
+
+
+def test_ranges_of_mutants(mlib, golden_dir):
+    """bit flips in headers, side info and main data (false syncs, frame sizes that change, reservoir pointers into nowhere):
+    whatever the whole-file scan makes of a mutant, the index and the range scans make the same of it"""
+    import frame_synth
+    rng = np.random.default_rng(77)
+    bases = [open(os.path.join(golden_dir, "test.mp3"), "rb").read(),
+             frame_synth.make_stream(5, 300, block_types=(0, 1, 2, 3), use_reservoir=True, allow_mixed=True),
+             frame_synth.make_stream(6, 280, mode=3, use_reservoir=True, crc=True)]
+    checked = rejected = 0
+    for base in bases:
+        for _ in range(60):
+            b = bytearray(base)
+            for _ in range(int(rng.integers(1, 5))):
+                b[int(rng.integers(0, len(b)))] ^= 1 << int(rng.integers(0, 8))
+            m = bytes(b)
+            try:
+                full = mlib.scan_stream(m)
+            except mlib.Mp3sError as e:
+                with pytest.raises(mlib.Mp3sError) as e2:
+                    mlib.StreamIndex(m)
+                assert e2.value.code == e.code
+                rejected += 1
+                continue
+            n = full["n_frames"]
+            ranges = [(0, n + 3), (max(0, n - 2), 5)] + [(int(a), int(c)) for a, c in zip(rng.integers(0, max(n, 1), 4), rng.integers(1, 280, 4))]
+            _check(mlib, m, ranges)
+            checked += 1
+    assert checked > 100
