@@ -503,7 +503,8 @@ int mp3s_reveal_message(const uint8_t *mp3, size_t len, mp3s_buf **owner, mp3s_f
  *           hipMemcpyAsync up || kernels || hipMemcpyAsync down, `depth` jobs in flight, nothing waited for until a result
  *           is collected.
  * A job = the files of one mp3s_hide_messages call (same arguments, same results byte for byte: jobs the device cannot
- * take in one batch, or whose on-device verdict says a guess failed, are redone by that very function).
+ * take in one batch, or whose Huffman data is damaged, are redone by that very function; a job whose on-device verdict says
+ * a guess failed keeps its device buffers and has its chains resolved at collect time).
  * While a pipe exists its context belongs to it: no other call may use the context until mp3s_pipe_destroy().
  * The submitted file and message buffers are borrowed until the job has been collected. */
 typedef struct mp3s_pipe mp3s_pipe;
@@ -513,6 +514,8 @@ typedef struct {
     double scan_ms, issue_ms;         /* summed over jobs: host scan + input layout; queueing the job's device work */
     double last_device_span_ms;       /* first upload byte to last download byte of the job collected last (HIP events) */
     double scan_cpu_ms;               /* CPU time of the scan threads inside scan_ms (less than scan_ms: the threads were not running) */
+    int64_t resolved;                 /* collected jobs whose cursor / address guess failed and whose chains the host resolved on the job's
+                                       * own device buffers (scan, decode and transforms kept); fast + resolved + slow = collected */
 } mp3s_pipe_stats;
 /* depth: jobs in flight (= staging slots); max_job_bytes: MP3 bytes per job the staging is sized for (larger jobs still
  * work, through the synchronous path); scan_threads: host workers */

@@ -493,13 +493,20 @@ __global__ __launch_bounds__(RL_WAVES * 64, 4) void k_rate_loop(
     }
 }
 
-// Message variants (encode_batch): a unit's result depends on the message only through the <= 3 bits at its cursor, so
+// Message variants (enc_resolve): a unit's result depends on the message only through the <= 3 bits at its cursor, so
 // the units a message reaches are run once per 3-bit pattern (compact == 2 above) and the host, walking the cursor
-// chain, names the entry each unit really sees.  One wave per (entry, unit) pair copies that entry's ix / energies
-// into the unit's place in the final arrays (the GrInfo travels through the host).
+// chain, names the entry each unit really sees.  The walk needs one number per entry -- the tables it took -- so those
+// come down as a byte array (k_gather_tables), and one wave per (entry, unit) pair then copies that entry's ix, energies
+// and GrInfo into the unit's place in the final arrays.
+__global__ __launch_bounds__(256) void k_gather_tables(const mp3s_gr_out *__restrict__ outv, int n, uint8_t *__restrict__ tables)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < n) tables[i] = (uint8_t)outv[i].n_tables;
+}
+
 __global__ __launch_bounds__(256) void k_scatter_entries(const int2 *__restrict__ pairs, int n_pairs, const int16_t *__restrict__ ixv,
-                                                         const int32_t *__restrict__ env, int16_t *__restrict__ ix,
-                                                         int32_t *__restrict__ en)
+                                                         const int32_t *__restrict__ env, const mp3s_gr_out *__restrict__ outv,
+                                                         int16_t *__restrict__ ix, int32_t *__restrict__ en, mp3s_gr_out *__restrict__ out)
 {
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
     const int j = blockIdx.x * 4 + wave;
@@ -510,6 +517,9 @@ __global__ __launch_bounds__(256) void k_scatter_entries(const int2 *__restrict_
     uint32_t *b = reinterpret_cast<uint32_t *>(ix + dst * 576);
     for (int i = lane; i < 288; i += 64) b[i] = a[i];
     if (lane < 22) en[dst * 22 + lane] = env[src * 22 + lane];
+    static_assert(sizeof(mp3s_gr_out) % 4 == 0, "GrInfo is copied by words");
+    if (lane < (int)(sizeof(mp3s_gr_out) / 4))
+        reinterpret_cast<uint32_t *>(out + dst)[lane] = reinterpret_cast<const uint32_t *>(outv + src)[lane];
 }
 
 }  // namespace mp3s

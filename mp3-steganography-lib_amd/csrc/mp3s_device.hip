@@ -150,12 +150,19 @@ int launch_chain(hipStream_t stream, mp3s_gr_out *d_gr, const mp3s_rate_frame *d
     return (int)hipGetLastError();
 }
 
-int launch_scatter(hipStream_t stream, const int32_t *d_pairs, int n_pairs, const int16_t *d_ixv, const int32_t *d_env, int16_t *d_ix,
-                   int32_t *d_en)
+int launch_gather_tables(hipStream_t stream, const mp3s_gr_out *d_outv, int n, uint8_t *d_tables)
+{
+    if (n <= 0) return 0;
+    hipLaunchKernelGGL(k_gather_tables, dim3((n + 255) / 256), dim3(256), 0, stream, d_outv, n, d_tables);
+    return (int)hipGetLastError();
+}
+
+int launch_scatter(hipStream_t stream, const int32_t *d_pairs, int n_pairs, const int16_t *d_ixv, const int32_t *d_env,
+                   const mp3s_gr_out *d_outv, int16_t *d_ix, int32_t *d_en, mp3s_gr_out *d_out)
 {
     if (n_pairs <= 0) return 0;
     hipLaunchKernelGGL(k_scatter_entries, dim3((n_pairs + 3) / 4), dim3(256), 0, stream, (const int2 *)d_pairs, n_pairs, d_ixv, d_env,
-                       d_ix, d_en);
+                       d_outv, d_ix, d_en, d_out);
     return (int)hipGetLastError();
 }
 

@@ -132,91 +132,39 @@ int enc_issue(mp3s_ctx *c, const EncLayout &L, const EncDev &d)
     return rc;
 }
 
-// Encode the streams of `segs` (stereo, one sampling rate and bitrate) as ONE batch: transforms, rate loop, bit packing.
-// pcm_dev != nullptr: the int16 PCM is already in HBM (re-encode after a device decode) and pcm is ignored.
-// Results: b->mp3 = the streams' MP3 bytes (segs[i].mp3_off / mp3_len); with want_gr also b->gr_out and b->scfsi in
-// batch frame order.
-int encode_batch(mp3s_ctx *c, const int16_t *pcm, const int16_t *pcm_dev, std::vector<EncSeg> &segs, int samplerate, int bitrate_kbps,
-                 mp3s_buf *b, int *passes_out, bool want_gr)
+// The guesses of the first pass did not hold (verdict != 0): resolve the serial chains on the host -- the GrInfo of the
+// first pass comes down, walk() finds the units that ran on wrong inputs, message variants and exact re-runs replace them,
+// and the frames are packed again.  `in` = the host copy of the input block enc_fill wrote, `d` = the device buffers of
+// the first pass (its mdct / ix / GrInfo / energies must still be there).  Results as encode_batch's.
+int enc_resolve(mp3s_ctx *c, const EncLayout &L, std::vector<EncSeg> &segs, const uint8_t *in, const EncDev &d, mp3s_buf *b, bool have_gr,
+                int *passes_out)
 {
-    EncLayout L;
-    int rc = enc_layout(segs, samplerate, bitrate_kbps, L);
-    if (rc) return rc;
-    const int lead = L.lead, n = L.n, units = L.units, n_hide = L.n_hide, n_all = L.n_all;
-    HIPCHK(hipSetDevice(c->device));
-    std::vector<uint8_t> &in = c->h_in;
-    in.resize(L.bytes);
-    rc = enc_fill(segs, L, in.data());
-    if (rc) return rc;
-    const uint8_t *hide_all = in.data() + L.o_hide;
-
-    void *d_pcm = nullptr, *d_in = nullptr, *d_mdct_all = nullptr, *d_redo = nullptr, *d_ix = nullptr, *d_out = nullptr, *d_en = nullptr,
-         *d_agg = nullptr, *d_mp3 = nullptr, *d_sc = nullptr, *d_small = nullptr;
-    auto cleanup = [&]() { hipStreamSynchronize(c->stream); };   // the buffers stay in the context's pool
-    int slot = 8;
-    auto alloc = [&](void **p, size_t bytes) { *p = c->grab(slot++, bytes); return *p != nullptr; };
-    if (pcm_dev) { d_pcm = const_cast<int16_t *>(pcm_dev); slot++; }
-    else if (!alloc(&d_pcm, (size_t)n_all * 2304 * 2)) d_pcm = nullptr;
-    if (!d_pcm || !alloc(&d_in, L.bytes) || !alloc(&d_mdct_all, (size_t)n_all * 2304 * 4) || !alloc(&d_redo, (size_t)units * 24) ||
-        !alloc(&d_ix, (size_t)n * 2304 * 2) || !alloc(&d_out, (size_t)units * sizeof(mp3s_gr_out)) || !alloc(&d_en, (size_t)units * 22 * 4) ||
-        !alloc(&d_agg, chain_agg_bytes(n)) || !alloc(&d_mp3, L.mp3_bytes + 16) || !alloc(&d_sc, (size_t)n * 8 * 4) ||
-        !alloc(&d_small, small_bytes(L.n_segs))) {
-        cleanup();
-        return fail(MP3S_E_NOMEM, "hipMalloc failed for a %d-frame encode", n);
-    }
-    const int32_t *d_mdct = (const int32_t *)d_mdct_all + (size_t)lead * 2304;   // the block's own frames
-    const mp3s_rate_frame *d_rf = (const mp3s_rate_frame *)((uint8_t *)d_in + L.o_rf);
-    const uint8_t *d_hide = (const uint8_t *)d_in + L.o_hide;
+    const int n = L.n, units = L.units, n_hide = L.n_hide, samplerate = L.samplerate, bitrate_kbps = L.kbps;
+    const uint8_t *hide_all = in + L.o_hide;
+    const uint8_t *const d_in = d.d_in;
+    int16_t *const d_ix = d.d_ix; mp3s_gr_out *const d_out = d.d_out; int32_t *const d_en = d.d_en; uint8_t *const d_mp3 = d.d_mp3;
+    int32_t *const d_sc = d.d_sc, *const d_small = d.d_small;
+    const int32_t *d_mdct = d.d_mdct_all + (size_t)L.lead * 2304;   // the block's own frames
+    const mp3s_rate_frame *d_rf = (const mp3s_rate_frame *)(d_in + L.o_rf);
+    const uint8_t *d_hide = d_in + L.o_hide;
     const size_t total = segs.back().mp3_off + segs.back().mp3_len;
-    if (!b->big[0].reserve(L.mp3_bytes) || !b->big[2].reserve(small_bytes(L.n_segs)) ||
-        (want_gr && !b->big[1].reserve((size_t)units * sizeof(mp3s_gr_out)))) {
-        cleanup();
-        return fail(MP3S_E_NOMEM, "host memory for a %d-frame encode", n);
-    }
+    void *d_redo = c->grab(kSlotRedo, (size_t)units * 24);
+    if (!d_redo || !b->big[0].reserve(L.mp3_bytes)) return fail(MP3S_E_NOMEM, "memory for resolving %d units", units);
     b->mp3 = b->big[0].data();
-    int32_t *const small = (int32_t *)b->big[2].data();
-    const mp3s_chain_seg_out *const seg_out = (const mp3s_chain_seg_out *)(b->big[2].data() + kSmallHead);
-    if (want_gr) b->scfsi.assign((size_t)n * 8, 0);
-    // ---- one pass, nothing waited for in between: inputs up, transforms, rate loop on the guessed cursors, the chain
-    //      check on the device, bit packing, results down.  The verdict says whether the guesses held.
-    if (!pcm_dev && hipMemcpyAsync(d_pcm, pcm, (size_t)n_all * 2304 * 2, hipMemcpyHostToDevice, c->stream) != hipSuccess) rc = fail(MP3S_E_HIP, "PCM upload failed");
-    if (!rc && hipMemcpyAsync(d_in, in.data(), L.bytes, hipMemcpyHostToDevice, c->stream) != hipSuccess) rc = fail(MP3S_E_HIP, "input upload failed");
-    EncDev dev;
-    dev.d_pcm = (const int16_t *)d_pcm; dev.d_in = (const uint8_t *)d_in; dev.d_mdct_all = (int32_t *)d_mdct_all; dev.d_ix = (int16_t *)d_ix;
-    dev.d_out = (mp3s_gr_out *)d_out; dev.d_en = (int32_t *)d_en; dev.d_agg = d_agg; dev.d_mp3 = (uint8_t *)d_mp3; dev.d_sc = (int32_t *)d_sc;
-    dev.d_small = (int32_t *)d_small;
-    if (!rc) rc = enc_issue(c, L, dev);
-    auto down = [&](void *dst, const void *src, size_t bytes) {
-        if (!rc && bytes && hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, c->stream) != hipSuccess) rc = fail(MP3S_E_HIP, "download failed");
+    int rc = MP3S_OK;
+    double t_mark = trace_on() ? now_ms() : 0;
+    auto mark = [&](const char *what) {
+        if (!trace_on()) return;
+        const double t = now_ms();
+        fprintf(stderr, "mp3s:   resolve: %-28s %.3f ms\n", what, t - t_mark);
+        t_mark = t;
     };
-    down(small, d_small, small_bytes(L.n_segs));
-    down(b->mp3, d_mp3, total);
-    if (want_gr) {
-        down(b->big[1].data(), d_out, (size_t)units * sizeof(mp3s_gr_out));
-        down(b->scfsi.data(), d_sc, (size_t)n * 8 * 4);
-    }
-    if (!rc && hipStreamSynchronize(c->stream) != hipSuccess) rc = fail(MP3S_E_HIP, "sync failed");
-    if (rc) { cleanup(); return rc; }
-    if (want_gr) b->gr_out = (mp3s_gr_out *)b->big[1].data();
-    if (small[0] == 0 && small[1] == 0) {
-        if (small[2]) { cleanup(); return fail(MP3S_E_HIP, "bit packer reported status %d", small[2]); }
-        for (size_t si = 0; si < segs.size(); si++) {
-            EncSeg &s = segs[si];
-            s.hide_offset = seg_out[si].cursor - s.hide_base;
-            s.carry_out.cursor = s.hide_offset;
-            std::memcpy(s.carry_out.chain, seg_out[si].chain, sizeof s.carry_out.chain);
-            s.carry_used = seg_out[si].carry_used != 0;
-        }
-        if (passes_out) *passes_out = 1;
-        return MP3S_OK;
-    }
-    // ---- the guesses did not hold: resolve the chains on the host, as round 1 did
-    if (!b->big[1].reserve((size_t)units * sizeof(mp3s_gr_out))) { cleanup(); return fail(MP3S_E_NOMEM, "host memory for %d units", units); }
+    if (!b->big[1].reserve((size_t)units * sizeof(mp3s_gr_out))) return fail(MP3S_E_NOMEM, "host memory for %d units", units);
     mp3s_gr_out *const gr = b->gr_out = (mp3s_gr_out *)b->big[1].data();
-    if (!want_gr) rc = mp3s_dev_download(c, gr, d_out, (size_t)units * sizeof(mp3s_gr_out));
+    if (!have_gr) rc = mp3s_dev_download(c, gr, d_out, (size_t)units * sizeof(mp3s_gr_out));
     b->scfsi.assign((size_t)n * 8, 0);
     std::vector<int32_t> &cursor = c->h_cursor, &state = c->h_state;
-    cursor.assign((const int32_t *)(in.data() + L.o_cur), (const int32_t *)(in.data() + L.o_cur) + units);
+    cursor.assign((const int32_t *)(in + L.o_cur), (const int32_t *)(in + L.o_cur) + units);
     state.assign((size_t)units * 4, 0);
     int passes = 1;
     // ---- resolve the serial chains, stream by stream: hide cursor (MP3_Encoder.py:808-809) and the per-(gr,ch) inherited
@@ -278,9 +226,11 @@ int encode_batch(mp3s_ctx *c, const int16_t *pcm, const int16_t *pcm_dev, std::v
         return (int)MP3S_OK;
     };
     // one launch over a list of (unit, cursor, inherited state) entries: 24 bytes per entry up -- [units | cursors | states]
-    // -- and the entries' GrInfo down (into tmp); compact = 1: ix / energies in place, 2: by entry into d_ixv / d_env
+    // -- and the entries' GrInfo down (into tmp); compact = 1: ix / energies in place, 2: by entry into d_ixv / d_env, and only
+    // the table count of every entry comes down (one byte each, into tables_of, through d_tables)
+    std::vector<uint8_t> tables_of;
     auto run_entries = [&](const std::vector<int32_t> &units_of, const std::vector<int32_t> &cursor_of, void *d_entries, int compact,
-                           int16_t *ix_to, mp3s_gr_out *out_to, int32_t *en_to) {
+                           int16_t *ix_to, mp3s_gr_out *out_to, int32_t *en_to, uint8_t *d_tables) {
         const size_t nl = units_of.size();
         redo_in.resize(nl * 6);
         for (size_t i = 0; i < nl; i++) {
@@ -296,19 +246,26 @@ int encode_batch(mp3s_ctx *c, const int16_t *pcm, const int16_t *pcm_dev, std::v
                                       &c->prof, 0, compact);
             if (e) r = fail(MP3S_E_HIP, "rate launch: %s", hipGetErrorString((hipError_t)e));
         }
-        tmp.resize(nl);
-        if (!r) r = mp3s_dev_download(c, tmp.data(), out_to, nl * sizeof(mp3s_gr_out));
+        if (d_tables) {
+            if (!r && launch_gather_tables(c->stream, out_to, (int)nl, d_tables)) r = fail(MP3S_E_HIP, "gathering the table counts failed");
+            tables_of.resize(nl);
+            if (!r) r = mp3s_dev_download(c, tables_of.data(), d_tables, nl);
+        } else {
+            tmp.resize(nl);
+            if (!r) r = mp3s_dev_download(c, tmp.data(), out_to, nl * sizeof(mp3s_gr_out));
+        }
         passes++;
         return r;
     };
+    mark("GrInfo down");
     if (!rc) rc = walk();
+    mark("walk");
     if (!rc && list.size() > kFewUnits) {
         // ---- message variants
         struct Span { size_t seg; int unit, count; int64_t cur; size_t entry; };
         std::vector<Span> spans;
         std::vector<int32_t> ent_unit, ent_cursor, pairs;
         void *d_ent = nullptr, *d_ixv = nullptr, *d_outv = nullptr, *d_env = nullptr, *d_pairs = nullptr;
-        const int slot_var = slot;
         for (bool more = true; more && !rc;) {
             spans.clear(); ent_unit.clear(); ent_cursor.clear(); pairs.clear();
             for (size_t si = 0; si < segs.size(); si++) {
@@ -316,10 +273,10 @@ int encode_batch(mp3s_ctx *c, const int16_t *pcm, const int16_t *pcm_dev, std::v
                 const EncSeg &s = segs[si];
                 const int64_t end = (int64_t)s.hide_base + s.n_hide;
                 if (pend[si].cur + 3 > end) { pend[si].unit = -1; continue; }   // only the message's last unit is left
-                // as many units as the rest of the message can reach at two tables per unit (silent units take none: the
-                // stream simply comes round again), as many as still fit into this launch
+                // as many units as the rest of the message can reach at 2.8 tables per unit (measured on music: 2.96; a stream
+                // that takes fewer -- silent units take none -- simply comes round again), as many as still fit into this launch
                 const int room = (kVariantEntries - (int)ent_unit.size()) / 8;
-                const int count = (int)std::min<int64_t>({(int64_t)(s.first + s.n_frames) * 4 - pend[si].unit, (end - pend[si].cur) / 2 + 16, (int64_t)room});
+                const int count = (int)std::min<int64_t>({(int64_t)(s.first + s.n_frames) * 4 - pend[si].unit, (end - pend[si].cur) * 5 / 14 + 32, (int64_t)room});
                 if (count <= 0) continue;                                       // next launch
                 spans.push_back({si, pend[si].unit, count, pend[si].cur, ent_unit.size()});
                 for (int v = 0; v < 8; v++)
@@ -327,11 +284,15 @@ int encode_batch(mp3s_ctx *c, const int16_t *pcm, const int16_t *pcm_dev, std::v
             }
             if (spans.empty()) break;
             const size_t ne = ent_unit.size();
-            slot = slot_var;
+            int slot = kSlotVariants;
+            auto alloc = [&](void **p, size_t bytes) { *p = c->grab(slot++, bytes); return *p != nullptr; };
             if (!alloc(&d_ent, ne * 24) || !alloc(&d_ixv, ne * 1152) || !alloc(&d_outv, ne * sizeof(mp3s_gr_out)) ||
                 !alloc(&d_env, ne * 88) || !alloc(&d_pairs, ne))   // at most one pair per unit = ne / 8 pairs of 8 bytes
                 rc = fail(MP3S_E_NOMEM, "hipMalloc failed for the message variants");
-            if (!rc) rc = run_entries(ent_unit, ent_cursor, d_ent, 2, (int16_t *)d_ixv, (mp3s_gr_out *)d_outv, (int32_t *)d_env);
+            mark("variant entries listed");
+            // (d_pairs holds the table counts first, the chosen pairs afterwards: ne bytes either way)
+            if (!rc) rc = run_entries(ent_unit, ent_cursor, d_ent, 2, (int16_t *)d_ixv, (mp3s_gr_out *)d_outv, (int32_t *)d_env, (uint8_t *)d_pairs);
+            mark("variants: up, launch, down");
             more = false;
             for (const Span &sp : spans) {
                 if (rc) break;
@@ -343,11 +304,10 @@ int encode_batch(mp3s_ctx *c, const int16_t *pcm, const int16_t *pcm_dev, std::v
                     const int u = sp.unit + j;
                     const int v = (hide_all[cur] & 1) * 4 + (hide_all[cur + 1] & 1) * 2 + (hide_all[cur + 2] & 1);
                     const size_t e = sp.entry + (size_t)v * sp.count + j;
-                    gr[u] = tmp[e];
                     cursor[u] = (int32_t)cur;
                     for (int q = 0; q < 4; q++) state[(size_t)u * 4 + q] = state_want[(size_t)u * 4 + q];
                     pairs.push_back((int32_t)e); pairs.push_back(u);
-                    cur += gr[u].n_tables;
+                    cur += tables_of[e];                           // (the entry's GrInfo goes to the unit's place on the device)
                 }
                 // span used up with message left: the stream goes on in the next launch; otherwise the message's last unit
                 // (fewer than three bits left) and whatever lies behind it are the exact re-run's
@@ -355,17 +315,24 @@ int encode_batch(mp3s_ctx *c, const int16_t *pcm, const int16_t *pcm_dev, std::v
                 else pend[sp.seg].unit = -1;
             }
             for (size_t si = 0; si < segs.size(); si++) more |= pend[si].unit >= 0;
+            mark("variants: select");
             if (!rc && !pairs.empty()) {
                 rc = mp3s_dev_upload(c, d_pairs, pairs.data(), pairs.size() * 4);
+                mark("variants: pairs up");
                 if (!rc) {
                     const int e = launch_scatter(c->stream, (const int32_t *)d_pairs, (int)(pairs.size() / 2), (const int16_t *)d_ixv,
-                                                 (const int32_t *)d_env, (int16_t *)d_ix, (int32_t *)d_en);
+                                                 (const int32_t *)d_env, (const mp3s_gr_out *)d_outv, (int16_t *)d_ix, (int32_t *)d_en, d_out);
                     if (e) rc = fail(MP3S_E_HIP, "scatter: %s", hipGetErrorString((hipError_t)e));
                 }
                 if (!rc && hipStreamSynchronize(c->stream) != hipSuccess) rc = fail(MP3S_E_HIP, "sync failed");   // the entry arrays are reused
             }
+            mark("variants: select, scatter");
         }
+        // the GrInfo with the chosen entries in place
+        if (!rc) rc = mp3s_dev_download(c, gr, d_out, (size_t)units * sizeof(mp3s_gr_out));
+        mark("GrInfo down");
         if (!rc) rc = walk();
+        mark("walk");
     }
     // ---- exact re-runs of what is left, until nothing changes
     std::vector<int32_t> cur_of;
@@ -374,7 +341,7 @@ int encode_batch(mp3s_ctx *c, const int16_t *pcm, const int16_t *pcm_dev, std::v
         cur_of.resize(list.size());
         for (size_t i = 0; i < list.size(); i++) cur_of[i] = want[list[i]];
         const std::vector<int32_t> units_of = list;
-        rc = run_entries(units_of, cur_of, d_redo, 1, (int16_t *)d_ix, (mp3s_gr_out *)d_out, (int32_t *)d_en);
+        rc = run_entries(units_of, cur_of, d_redo, 1, (int16_t *)d_ix, (mp3s_gr_out *)d_out, (int32_t *)d_en, nullptr);
         if (!rc)
             for (size_t i = 0; i < units_of.size(); i++) {
                 const int u = units_of[i];
@@ -384,6 +351,7 @@ int encode_batch(mp3s_ctx *c, const int16_t *pcm, const int16_t *pcm_dev, std::v
             }
         if (!rc) rc = walk();
     }
+    mark("exact re-runs");
     if (!rc) {
         // ---- bit packing again, on the final GrInfo
         rc = mp3s_dev_upload(c, d_out, gr, (size_t)units * sizeof(mp3s_gr_out));
@@ -396,8 +364,89 @@ int encode_batch(mp3s_ctx *c, const int16_t *pcm, const int16_t *pcm_dev, std::v
         if (!rc) rc = mp3s_dev_download(c, b->mp3, d_mp3, total);
         if (!rc) rc = mp3s_dev_download(c, b->scfsi.data(), d_sc, (size_t)n * 8 * 4);
     }
-    cleanup();
+    mark("GrInfo up, pack, bytes down");
     if (passes_out) *passes_out = passes;
+    return rc;
+}
+
+
+// Encode the streams of `segs` (stereo, one sampling rate and bitrate) as ONE batch: transforms, rate loop, bit packing.
+// pcm_dev != nullptr: the int16 PCM is already in HBM (re-encode after a device decode) and pcm is ignored.
+// Results: b->mp3 = the streams' MP3 bytes (segs[i].mp3_off / mp3_len); with want_gr also b->gr_out and b->scfsi in
+// batch frame order.
+int encode_batch(mp3s_ctx *c, const int16_t *pcm, const int16_t *pcm_dev, std::vector<EncSeg> &segs, int samplerate, int bitrate_kbps,
+                 mp3s_buf *b, int *passes_out, bool want_gr)
+{
+    EncLayout L;
+    int rc = enc_layout(segs, samplerate, bitrate_kbps, L);
+    if (rc) return rc;
+    const int n = L.n, units = L.units, n_all = L.n_all;
+    HIPCHK(hipSetDevice(c->device));
+    std::vector<uint8_t> &in = c->h_in;
+    in.resize(L.bytes);
+    rc = enc_fill(segs, L, in.data());
+    if (rc) return rc;
+    void *d_pcm = nullptr, *d_in = nullptr, *d_mdct_all = nullptr, *d_ix = nullptr, *d_out = nullptr, *d_en = nullptr,
+         *d_agg = nullptr, *d_mp3 = nullptr, *d_sc = nullptr, *d_small = nullptr;
+    auto cleanup = [&]() { hipStreamSynchronize(c->stream); };   // the buffers stay in the context's pool
+    int slot = 8;
+    auto alloc = [&](void **p, size_t bytes) { *p = c->grab(slot++, bytes); return *p != nullptr; };
+    if (pcm_dev) { d_pcm = const_cast<int16_t *>(pcm_dev); slot++; }
+    else if (!alloc(&d_pcm, (size_t)n_all * 2304 * 2)) d_pcm = nullptr;
+    if (!d_pcm || !alloc(&d_in, L.bytes) || !alloc(&d_mdct_all, (size_t)n_all * 2304 * 4) || (slot++ /* kSlotRedo */, false) ||
+        !alloc(&d_ix, (size_t)n * 2304 * 2) || !alloc(&d_out, (size_t)units * sizeof(mp3s_gr_out)) || !alloc(&d_en, (size_t)units * 22 * 4) ||
+        !alloc(&d_agg, chain_agg_bytes(n)) || !alloc(&d_mp3, L.mp3_bytes + 16) || !alloc(&d_sc, (size_t)n * 8 * 4) ||
+        !alloc(&d_small, small_bytes(L.n_segs))) {
+        cleanup();
+        return fail(MP3S_E_NOMEM, "hipMalloc failed for a %d-frame encode", n);
+    }
+    const size_t total = segs.back().mp3_off + segs.back().mp3_len;
+    if (!b->big[0].reserve(L.mp3_bytes) || !b->big[2].reserve(small_bytes(L.n_segs)) ||
+        (want_gr && !b->big[1].reserve((size_t)units * sizeof(mp3s_gr_out)))) {
+        cleanup();
+        return fail(MP3S_E_NOMEM, "host memory for a %d-frame encode", n);
+    }
+    b->mp3 = b->big[0].data();
+    int32_t *const small = (int32_t *)b->big[2].data();
+    const mp3s_chain_seg_out *const seg_out = (const mp3s_chain_seg_out *)(b->big[2].data() + kSmallHead);
+    if (want_gr) b->scfsi.assign((size_t)n * 8, 0);
+    // ---- one pass, nothing waited for in between: inputs up, transforms, rate loop on the guessed cursors, the chain
+    //      check on the device, bit packing, results down.  The verdict says whether the guesses held.
+    if (!pcm_dev && hipMemcpyAsync(d_pcm, pcm, (size_t)n_all * 2304 * 2, hipMemcpyHostToDevice, c->stream) != hipSuccess) rc = fail(MP3S_E_HIP, "PCM upload failed");
+    if (!rc && hipMemcpyAsync(d_in, in.data(), L.bytes, hipMemcpyHostToDevice, c->stream) != hipSuccess) rc = fail(MP3S_E_HIP, "input upload failed");
+    EncDev dev;
+    dev.d_pcm = (const int16_t *)d_pcm; dev.d_in = (const uint8_t *)d_in; dev.d_mdct_all = (int32_t *)d_mdct_all; dev.d_ix = (int16_t *)d_ix;
+    dev.d_out = (mp3s_gr_out *)d_out; dev.d_en = (int32_t *)d_en; dev.d_agg = d_agg; dev.d_mp3 = (uint8_t *)d_mp3; dev.d_sc = (int32_t *)d_sc;
+    dev.d_small = (int32_t *)d_small;
+    if (!rc) rc = enc_issue(c, L, dev);
+    auto down = [&](void *dst, const void *src, size_t bytes) {
+        if (!rc && bytes && hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, c->stream) != hipSuccess) rc = fail(MP3S_E_HIP, "download failed");
+    };
+    down(small, d_small, small_bytes(L.n_segs));
+    down(b->mp3, d_mp3, total);
+    if (want_gr) {
+        down(b->big[1].data(), d_out, (size_t)units * sizeof(mp3s_gr_out));
+        down(b->scfsi.data(), d_sc, (size_t)n * 8 * 4);
+    }
+    if (!rc && hipStreamSynchronize(c->stream) != hipSuccess) rc = fail(MP3S_E_HIP, "sync failed");
+    if (rc) { cleanup(); return rc; }
+    if (want_gr) b->gr_out = (mp3s_gr_out *)b->big[1].data();
+    if (small[0] == 0 && small[1] == 0) {
+        if (small[2]) { cleanup(); return fail(MP3S_E_HIP, "bit packer reported status %d", small[2]); }
+        for (size_t si = 0; si < segs.size(); si++) {
+            EncSeg &s = segs[si];
+            s.hide_offset = seg_out[si].cursor - s.hide_base;
+            s.carry_out.cursor = s.hide_offset;
+            std::memcpy(s.carry_out.chain, seg_out[si].chain, sizeof s.carry_out.chain);
+            s.carry_used = seg_out[si].carry_used != 0;
+        }
+        if (passes_out) *passes_out = 1;
+        return MP3S_OK;
+    }
+    // ---- the guesses did not hold: resolve the chains on the host, as round 1 did
+    EncDev devr = dev;
+    rc = enc_resolve(c, L, segs, in.data(), devr, b, want_gr, passes_out);
+    cleanup();
     return rc;
 }
 

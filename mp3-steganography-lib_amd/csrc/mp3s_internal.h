@@ -265,6 +265,11 @@ struct EncDev {
 // transforms -> rate loop on the guessed cursors -> chain check -> bit packing, all on c->stream, nothing waited for.
 // The packed bytes are final iff verdict[0] == 0 and verdict[1] == 0 (d_small[0], d_small[1]).
 int enc_issue(mp3s_ctx *c, const EncLayout &L, const EncDev &d);
+// verdict != 0: the host resolves the chains on the first pass's device buffers (walk, message variants, exact re-runs,
+// packing again); `in` = the host copy of the block.  Pool slots of its own: the entries of the exact re-runs, the variants.
+constexpr int kSlotRedo = 11, kSlotVariants = 19;
+int enc_resolve(mp3s_ctx *c, const EncLayout &L, std::vector<EncSeg> &segs, const uint8_t *in, const EncDev &d, mp3s_buf *b, bool have_gr,
+                int *passes_out);
 int encode_batch(mp3s_ctx *c, const int16_t *pcm, const int16_t *pcm_dev, std::vector<EncSeg> &segs, int samplerate, int bitrate_kbps,
                  mp3s_buf *b, int *passes_out, bool want_gr = true);
 // non-zero table indices per unit of a scanned stream, in the encoder's unit order (frame, channel, granule): see

@@ -34,6 +34,9 @@ struct Slot {
     size_t blob_cap = 0, side_cap = 0 /* frames */, in_cap = 0, fix_cap = 0 /* entries */, o_side = 0, o_in = 0, o_fix = 0, stage_bytes = 0;
     uint8_t *d_mp3 = nullptr; size_t mp3_cap = 0;
     int32_t *d_small = nullptr;
+    // the encoder's intermediates of the slot's job (mdct, quantised lines, GrInfo, energies, scfsi): the slot's own, so
+    // that a job whose cursor guess failed is resolved on them at collect time while later jobs have long been issued
+    uint8_t *d_enc = nullptr; size_t enc_cap = 0;
     hipEvent_t e_start = nullptr, e_up = nullptr, e_huff = nullptr, e_comp = nullptr, e_down = nullptr;
     bool busy = false;
 };
@@ -49,6 +52,7 @@ struct Job {
     std::vector<std::vector<uint8_t>> bits, guess;
     std::vector<EncSeg> segs;
     EncLayout L;
+    EncDev dev;
     int rate = 0, kbps = 0;
     std::unique_ptr<mp3s_buf> res;
     // synchronous path
@@ -269,13 +273,21 @@ int issue_fast(mp3s_pipe *P, Job &j, Slot &s, size_t blob_len, int max_p23)
         HIPCHK(hipEventRecord(s.e_down, P->s_down));
         return MP3S_OK;
     }
-    void *d_mdct = c->grab(10, (size_t)n * 2304 * 4), *d_ix = c->grab(12, (size_t)n * 2304 * 2),
-         *d_out = c->grab(13, (size_t)units * sizeof(mp3s_gr_out)), *d_en = c->grab(14, (size_t)units * 22 * 4),
-         *d_agg = c->grab(15, chain_agg_bytes(n)), *d_sc = c->grab(17, (size_t)n * 8 * 4);
-    if (!d_mdct || !d_ix || !d_out || !d_en || !d_agg || !d_sc) return fail(MP3S_E_NOMEM, "hipMalloc failed for a %d-frame job", n);
-    EncDev dev;
-    dev.d_pcm = (const int16_t *)d_keep; dev.d_in = d_in + o_enc; dev.d_mdct_all = (int32_t *)d_mdct; dev.d_ix = (int16_t *)d_ix;
-    dev.d_out = (mp3s_gr_out *)d_out; dev.d_en = (int32_t *)d_en; dev.d_agg = d_agg; dev.d_mp3 = s.d_mp3; dev.d_sc = (int32_t *)d_sc;
+    const size_t b_mdct = (size_t)n * 2304 * 4, b_ix = (size_t)n * 2304 * 2, b_out = (size_t)units * sizeof(mp3s_gr_out),
+                 b_en = ((size_t)units * 22 * 4 + 255) & ~(size_t)255, b_sc = (size_t)n * 8 * 4;
+    const size_t need = b_mdct + b_ix + b_out + b_en + b_sc;
+    if (need > s.enc_cap) {   // (hipFree waits for the device; only while the slot is growing to its job size)
+        if (s.d_enc) (void)hipFree(s.d_enc);
+        s.d_enc = nullptr; s.enc_cap = 0;
+        if (hipMalloc((void **)&s.d_enc, need + need / 8) != hipSuccess) return fail(MP3S_E_NOMEM, "hipMalloc failed for a %d-frame job", n);
+        s.enc_cap = need + need / 8;
+    }
+    void *d_agg = c->grab(15, chain_agg_bytes(n));
+    if (!d_agg) return fail(MP3S_E_NOMEM, "hipMalloc failed for a %d-frame job", n);
+    EncDev &dev = j.dev;
+    dev.d_pcm = (const int16_t *)d_keep; dev.d_in = d_in + o_enc; dev.d_mdct_all = (int32_t *)s.d_enc; dev.d_ix = (int16_t *)(s.d_enc + b_mdct);
+    dev.d_out = (mp3s_gr_out *)(s.d_enc + b_mdct + b_ix); dev.d_en = (int32_t *)(s.d_enc + b_mdct + b_ix + b_out); dev.d_agg = d_agg;
+    dev.d_mp3 = s.d_mp3; dev.d_sc = (int32_t *)(s.d_enc + b_mdct + b_ix + b_out + b_en);
     dev.d_small = s.d_small;
     const int rc = enc_issue(c, L, dev);
     if (rc) return rc;
@@ -368,6 +380,7 @@ void free_slot(Slot &s)
     if (s.d_stage) (void)hipFree(s.d_stage);
     if (s.d_mp3) (void)hipFree(s.d_mp3);
     if (s.d_small) (void)hipFree(s.d_small);
+    if (s.d_enc) (void)hipFree(s.d_enc);
     for (hipEvent_t e : {s.e_start, s.e_up, s.e_huff, s.e_comp, s.e_down}) if (e) (void)hipEventDestroy(e);
     s = Slot();
 }
@@ -524,7 +537,7 @@ int mp3s_pipe_collect(mp3s_pipe *P, int64_t *ticket, mp3s_buf **owner, mp3s_file
     Slot &s = P->slots[(size_t)j->slot];
     const int nf = (int)j->files.size();
     int rc = MP3S_OK;
-    bool fast_ok = false;
+    bool fast_ok = false, resolved = false;
     if (j->state == Job::ISSUED) {
         (void)hipSetDevice(P->c->device);
         if (hipEventSynchronize(s.e_down) != hipSuccess) rc = fail(MP3S_E_HIP, "waiting for the job's results failed");
@@ -534,11 +547,19 @@ int mp3s_pipe_collect(mp3s_pipe *P, int64_t *ticket, mp3s_buf **owner, mp3s_file
             float ms = 0;
             if (hipEventElapsedTime(&ms, s.e_start, s.e_down) == hipSuccess) P->st.last_device_span_ms = ms;
             if (!fast_ok) {
-                if (trace_on()) fprintf(stderr, "mp3s: pipe job %lld: verdict %d units to redo, step range %d, packer %d, Huffman status 0x%x -> synchronous path\n",
+                if (trace_on()) fprintf(stderr, "mp3s: pipe job %lld: verdict %d units to redo, step range %d, packer %d, Huffman status 0x%x\n",
                                         (long long)j->ticket, small[0], small[1], small[2], small[3]);
-                // the cursor guess failed (long message), or damaged Huffman data: the synchronous path decides
                 std::lock_guard<std::mutex> gi(P->mu_issue);
-                run_slow(P, *j);
+                // only the cursor / address guesses failed (a long message, a start the input's tables did not predict):
+                // the host resolves the chains on the job's own device buffers -- scan, decode and transforms stand
+                if (!j->decode && small[0] != 0 && small[1] == 0 && small[3] == 0) {
+                    int passes = 0;
+                    resolved = enc_resolve(P->c, j->L, j->segs, s.h_stage + s.o_in + (((size_t)j->n_total * sizeof(mp3s_frame_hdr) + 15) & ~(size_t)15),
+                                           j->dev, j->res.get(), false, &passes) == MP3S_OK;
+                    if (hipStreamSynchronize(P->c->stream) != hipSuccess) resolved = false;
+                }
+                // damaged Huffman data, a quantiser step out of range, a failed resolve: the synchronous path decides, file by file
+                if (!resolved) run_slow(P, *j);
             }
         }
     }
@@ -553,14 +574,14 @@ int mp3s_pipe_collect(mp3s_pipe *P, int64_t *ticket, mp3s_buf **owner, mp3s_file
                 status[i] = MP3S_OK;
             }
             *owner = j->res.release();
-        } else if (fast_ok) {
+        } else if (fast_ok || resolved) {
             const mp3s_chain_seg_out *so = (const mp3s_chain_seg_out *)(j->res->big[2].data() + kSmallHead);
             for (int i = 0; i < nf; i++) {
                 const EncSeg &sg = j->segs[(size_t)i];
                 std::memset(&out[i], 0, sizeof out[i]);
                 out[i].data = j->res->mp3 + sg.mp3_off; out[i].len = sg.mp3_len;
                 out[i].kbps = j->kbps; out[i].sampling_rate = j->rate; out[i].channels = 2; out[i].n_frames = sg.n_frames;
-                out[i].hide_offset = so[i].cursor - sg.hide_base;
+                out[i].hide_offset = resolved ? sg.hide_offset : so[i].cursor - sg.hide_base;
                 out[i].too_long = out[i].hide_offset < (int64_t)sg.n_hide - 1 ? 1 : 0;
                 status[i] = MP3S_OK;
             }
@@ -580,7 +601,7 @@ int mp3s_pipe_collect(mp3s_pipe *P, int64_t *ticket, mp3s_buf **owner, mp3s_file
     {
         std::lock_guard<std::mutex> g(P->mu);
         P->st.collected++;
-        if (fast_ok) P->st.fast++; else P->st.slow++;
+        if (fast_ok) P->st.fast++; else if (resolved) P->st.resolved++; else P->st.slow++;
         s.busy = false;
         P->inflight.pop_front();
     }

@@ -116,7 +116,8 @@ class IndexInfo(C.Structure):
 
 class PipeStats(C.Structure):
     _fields_ = [("submitted", C.c_int64), ("collected", C.c_int64), ("fast", C.c_int64), ("slow", C.c_int64),
-                ("scan_ms", C.c_double), ("issue_ms", C.c_double), ("last_device_span_ms", C.c_double), ("scan_cpu_ms", C.c_double)]
+                ("scan_ms", C.c_double), ("issue_ms", C.c_double), ("last_device_span_ms", C.c_double), ("scan_cpu_ms", C.c_double),
+                ("resolved", C.c_int64)]
 
 
 class Block(C.Structure):

@@ -56,7 +56,7 @@ def test_pipe_matches_the_synchronous_calls_and_the_oracle(mlib, orc, golden_dir
             ([streams[0], streams[1], streams[4]], ["one", None, "three"]),   # one device batch of three streams
             ([streams[2]], ["x"]),
             ([streams[0], streams[2]], ["two groups", "in one job"]), # two (rate, bitrate) groups: the synchronous path
-            ([streams[4]], [long_msg]),                               # verdict != 0: redone by the synchronous path
+            ([streams[4]], [long_msg]),                               # verdict != 0: the chains are resolved at collect time
             ([test_mp3], ["ddd"]),
             ([streams[3]], [""]),
             (corpus, ["m%d" % i for i in range(len(corpus))]),        # per-file status
@@ -85,7 +85,8 @@ def test_pipe_matches_the_synchronous_calls_and_the_oracle(mlib, orc, golden_dir
                         assert a["too_long"] == b["too_long"] and a["hide_offset"] == b["hide_offset"], k
                         assert (a["kbps"], a["sampling_rate"], a["n_frames"]) == (b["kbps"], b["sampling_rate"], b["n_frames"]), k
             assert st["collected"] == 2 * len(jobs) and st["fast"] >= 2 * 5, st      # the plain jobs took the overlapped stages
-            assert st["slow"] >= 2 * 3, st
+            assert st["slow"] >= 2 * 2 and st["resolved"] >= 2 * 1, st   # ... the long message was resolved on its own buffers
+            assert st["fast"] + st["resolved"] + st["slow"] == st["collected"], st
         # ... and the oracle on the jobs the device took alone
         for k in (0, 1, 3, 6, 7):
             files, msgs = jobs[k]

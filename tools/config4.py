@@ -130,7 +130,7 @@ def main():
            "slowest_rank_ms": max(rank_ms), "frames_per_s_if_ranks_ran_side_by_side": round(total / (max(rank_ms) / 1e3), 1),
            "streams_equal_to_single_call": same, "streams": n_streams, "single_call_loop_s": round(t_single, 3),
            "oracle_sample_frames": oracle_frames, "oracle_sample_streams_equal": oracle_same, "oracle_sample_streams": ranks,
-           "pipe": {"fast": st["fast"], "slow": st["slow"]}, "inputs_s": round(t_inputs, 1), "total_s": round(time.time() - t_all, 1),
+           "pipe": {"fast": st["fast"], "resolved": st["resolved"], "slow": st["slow"]}, "inputs_s": round(t_inputs, 1), "total_s": round(time.time() - t_all, 1),
            "ok": same == n_streams and oracle_same == ranks}
     print(json.dumps(res))
     sys.exit(0 if res["ok"] else 3)

@@ -49,7 +49,7 @@ def same(a, b):
 
 t0 = time.time()
 jobs_done = files_done = bad = pipes = 0
-stats = {"fast": 0, "slow": 0}
+stats = {"fast": 0, "resolved": 0, "slow": 0}
 while time.time() - t0 < budget:
     depth, threads = int(rng.integers(1, 6)), int(rng.integers(1, 5))
     pipe = _lib.Pipe(ctx, depth=depth, max_job_bytes=int(rng.choice([1 << 16, 1 << 19, 1 << 21])), scan_threads=threads)
@@ -70,7 +70,7 @@ while time.time() - t0 < budget:
         got.append(pipe.collect()[1])
     st = pipe.stats()
     pipe.close()
-    stats["fast"] += st["fast"]; stats["slow"] += st["slow"]
+    stats["fast"] += st["fast"]; stats["slow"] += st["slow"]; stats["resolved"] += st["resolved"]
     for (k, files, msgs), res in zip(jobs, got):
         if k == "d":
             want = []
