@@ -8,8 +8,9 @@ Three timed regions, all on the same 10 000-frame stream
 
   (i)   `value`: one step = one batch through the whole DEVICE pipeline, inputs resident in HBM (MP3 main data + parsed
         side info, what the host scan uploads): Huffman decode -> decode transforms -> int16 PCM -> encode transforms ->
-        rate loop on the guessed message cursors -> chain check on the device (mp3s_chain_resolve_dev: nothing about the
-        serial chains is precomputed outside the timed region) -> bit packing.  K steps, wall clock between barriers.
+        rate loop with the message's variants in the same launch -> cursor chain decided on the device (mp3s_rate_select_dev)
+        -> chain check on the device (mp3s_chain_resolve_dev: nothing about the serial chains is precomputed outside the
+        timed region, nothing is guessed) -> bit packing.  K steps, wall clock between barriers.
   (ii)  `regions.h2d_kernels_d2h`: the same batch from page-locked host staging: upload + kernels + download, one batch at
         a time (pipe of depth 1; HIP events from the first uploaded byte to the last downloaded one), averaged.
   (iii) `e2e_steady`: MP3 bytes -> MP3 bytes through the asynchronous host-fed pipeline (mp3s_pipe_*: host scan on worker
@@ -141,9 +142,11 @@ def main():
     aux2 = _lib.Context(ctx.device) if (args.pack_overlap and not args.no_overlap) else None
     d_hdr = ctx.to_device(parsed["hdr"])
     rf, _pad = _lib.rate_frames(44100, 128, 2, n)
-    rf["hide_end"] = len(hide)
+    # the message array of a batch: the eight 3-bit patterns the variants read, then the message
+    hide_all = np.concatenate([_lib.select_patterns(), np.asarray(hide, dtype=np.uint8)])
+    rf["hide_end"] = len(hide_all)
     d_rf = ctx.to_device(rf)
-    d_hide = ctx.to_device(hide)
+    d_hide = ctx.to_device(hide_all)
     units = n * 4
     d_pcm = ctx.alloc(n * 2304 * 2)
     d_pcm32 = ctx.alloc(n * 2304 * 4)
@@ -158,12 +161,18 @@ def main():
     d_mp3 = ctx.alloc(int(frame_off[-1]) + 16)
     d_sc = ctx.alloc(n * 8 * 4)
     d_pst = ctx.alloc(16)
-    # the serial chains: every unit is run on the guess "three tables per unit in front of me"; the device checks it
-    guess = np.minimum(3 * np.arange(units, dtype=np.int64), 2**30).astype(np.int32)
-    d_cur = ctx.to_device(guess)
+    # the serial chains.  The message cursor is decided on the device (what the library's own pipeline does for a short
+    # message): the units the message can reach run once per possibility as extra entries of the rate-loop launch, a
+    # small kernel walks the chain and puts the entry each unit really sees in its place, and the chain check confirms.
     seg = np.zeros(1, dtype=_lib.CHAIN_SEG_DTYPE)
-    seg["n_frames"], seg["hide_end"] = n, len(hide)
+    seg["n_frames"], seg["hide_base"], seg["hide_begin"], seg["hide_end"] = n, 32, 32, len(hide_all)
     d_seg = ctx.to_device(seg)
+    spans, ent_unit, ent_cursor = _lib.select_plan(seg, max(units // 2, 8192))
+    n_ent, max_reach = len(ent_unit), int(spans["reach"].max())
+    assert n_ent > 0, "the bench payload is a short message: the device decides its cursor chain"
+    d_spans, d_eu, d_ec = ctx.to_device(spans), ctx.to_device(ent_unit), ctx.to_device(ent_cursor)
+    d_ixv, d_outv, d_env = ctx.alloc(n_ent * 1152), ctx.alloc(n_ent * 72 + ((n_ent + 15) & ~15)), ctx.alloc(n_ent * 88)
+    d_cur = ctx.to_device(np.full(units, _lib.NO_CURSOR, dtype=np.int32))
     d_verdict = ctx.alloc(16)
     d_segout = ctx.alloc(80)
 
@@ -200,7 +209,8 @@ def main():
             front_end(aux, k + 1)
         if aux2 is not None:
             ctx.wait_for(aux2)                      # the packer of batch k-1 has read what the rate loop is about to overwrite
-        _lib.check(L.mp3s_rate_loop_dev(ctx.handle, d_mdct, d_rf, n, d_hide, len(hide), d_cur, None, None, 0, d_ix, d_out, d_en))
+        _lib.check(L.mp3s_rate_select_dev(ctx.handle, d_mdct, d_rf, n, d_hide, len(hide_all), d_cur, d_seg, d_spans, 1, max_reach,
+                                          d_eu, d_ec, n_ent, d_ix, d_out, d_en, d_ixv, d_outv, d_env))
         _lib.check(L.mp3s_chain_resolve_dev(ctx.handle, d_out, d_rf, n, d_seg, 1, d_cur, None, d_verdict, d_segout))
         pk = ctx
         if aux2 is not None:
@@ -276,8 +286,8 @@ def main():
     got_ix = ctx.download(d_ix, np.int16, (n, 2, 2, 576))
     got_pcm = ctx.download(d_pcm, np.int16, (n * 1152, 2))
     got_mp3 = ctx.download(d_mp3, np.uint8, (int(frame_off[-1]),)).tobytes()
-    same = int(verdict[0]) == 0 and int(verdict[1]) == 0          # the guessed cursors held: the step was the whole job
-    same = same and int(segout["cursor"][0]) == int(final["hide_offset"])
+    same = int(verdict[0]) == 0 and int(verdict[1]) == 0          # the chain check agrees: the step was the whole job
+    same = same and int(segout["cursor"][0]) - 32 == int(final["hide_offset"])
     same = same and bool(np.array_equal(got_pcm, pcm16)) and got_mp3[:(len(got_mp3) // 4) * 4] == final["mp3"]
     same = same and bool(np.array_equal(ctx.download(d_is, np.int16, (n, 2, 2, 576)), parsed["is"]))
     same = same and int(ctx.download(d_hst, np.int32, (1,))[0]) == 0 and int(ctx.download(d_pst, np.int32, (1,))[0]) == 0
@@ -579,10 +589,10 @@ def main():
             "warmup": args.warmup, "ms_per_step": round(max_step * 1e3, 4), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f64 (decode) / int32 (encode)", "data": "synthetic",
             "config": {"workload": f"{n}-frame full decode->stego-embed->re-encode pipeline per MI355X (BASELINE "
-                                   "configs[2]); MP3 main data + side info resident in HBM, MP3 frames out; the serial chains of the "
-                                   "rate loop are checked on the device inside every step", "frames_per_gpu": n,
+                                   "configs[2]); MP3 main data + side info resident in HBM, MP3 frames out; the message cursor chain is "
+                                   "decided and the serial chains of the rate loop are checked on the device inside every step", "frames_per_gpu": n,
                        "sample_rate": 44100, "channels": 2, "bitrate_kbps": 128, "message_bits": int(len(hide)),
-                       "chain_verdict_units_to_redo": int(verdict[0]), "pipeline_rate_passes": int(final["rate_passes"]),
+                       "chain_verdict_units_to_redo": int(verdict[0]), "message_variant_entries": n_ent, "pipeline_rate_passes": int(final["rate_passes"]),
                        "parallelism": f"frames sharded over {world} GPU(s), no collective"},
             "roofline": roofline,
             "roofline_alu": roofline_alu,

@@ -228,6 +228,40 @@ int mp3s_chain_resolve_dev(mp3s_ctx *ctx, mp3s_gr_out *d_gr, const mp3s_rate_fra
                            const mp3s_chain_seg *d_segs, int n_segs, const int32_t *d_cursor_in, const int32_t *d_state_in,
                            int32_t *d_verdict, mp3s_chain_seg_out *d_seg_out);
 
+/* ---------------------------------------------------------------- (iv-c) the message cursor, decided on the device
+ * replaces: the same __hide_str_offset chain (reference encoder/MP3_Encoder.py:808-809, :1154-1168) for the usual case
+ *           of a short message in a long stream, without guessing: a unit sees the message only through the <= 3 bits at
+ *           its cursor (__new_choose_table reads hide_str[offset] once per non-zero table, :1257-1263), so the first
+ *           `reach` units of a hiding stream are run once per possibility -- the 8 three-bit patterns, "two bits left",
+ *           "one bit left" -- as extra entries of the SAME rate-loop launch, every unit's own run (cursor behind every
+ *           message) being the eleventh, and a small kernel walks the chain and copies the entry each unit really sees
+ *           into its place.  mp3s_chain_resolve_dev still checks the result; a stream whose message reaches further than
+ *           the plan covered fails that check and is resolved by the host as before.
+ * The message array must start with the 32 pattern bytes of mp3s_select_patterns() (so hide_base >= 32), and d_cursor
+ * must hold MP3S_NO_CURSOR for every unit of a planned stream before the call; the call overwrites the cursors of the
+ * units it replaced with what they really saw (a later call with the same plan may find those there: they are exact). */
+#define MP3S_SELECT_VARIANTS 10
+#define MP3S_SELECT_MAX_REACH 2048
+#define MP3S_NO_CURSOR 0x3fffffff     /* "behind every message": such a unit hides nothing */
+typedef struct {
+    int32_t first_entry;             /* entry (v, j) of the stream = first_entry + v * reach + j */
+    int32_t reach;                   /* its first `reach` units are planned (0: the stream is left to cursor_in as it is) */
+} mp3s_select_span; /* 8 bytes */
+void mp3s_select_patterns(uint8_t out[32]);
+/* host only: spans[n_segs] and the entries (unit, cursor; capacity `cap` each) for the streams of segs.  A stream that does
+ * not hide, or whose message could reach more than MP3S_SELECT_MAX_REACH units, or that does not fit into cap any more
+ * gets reach 0.  Returns the number of entries. */
+int mp3s_select_plan(const mp3s_chain_seg *segs, int n_segs, mp3s_select_span *spans, int32_t *ent_unit, int32_t *ent_cursor, int cap);
+/* mp3s_rate_loop_dev over all units of the batch (no inherited state) with the entries behind them in the same launch, then
+ * the selection.  d_ixv / d_env: int16 [n_entries][576], int32 [n_entries][22]; d_outv: MP3S_VARIANT_OUT_BYTES(n_entries) --
+ * mp3s_gr_out [n_entries] followed by the entries' table counts, one byte each. */
+#define MP3S_VARIANT_OUT_BYTES(n) ((size_t)(n) * sizeof(mp3s_gr_out) + (((size_t)(n) + 15) & ~(size_t)15))
+int mp3s_rate_select_dev(mp3s_ctx *ctx, const int32_t *d_mdct, const mp3s_rate_frame *d_frames, int n_frames,
+                         const uint8_t *d_hide_bits, int n_hide, int32_t *d_cursor, const mp3s_chain_seg *d_segs,
+                         const mp3s_select_span *d_spans, int n_segs, int max_reach, const int32_t *d_ent_unit,
+                         const int32_t *d_ent_cursor, int n_entries, int16_t *d_ix, mp3s_gr_out *d_out, int32_t *d_en,
+                         int16_t *d_ixv, mp3s_gr_out *d_outv, int32_t *d_env);
+
 /* ---------------------------------------------------------------- (vi) bit-level stages on the device
  * The serial bit parsing / packing of the reference is serial per granule only: granule boundaries are known from
  * the side info (decode) or from the rate loop (encode), so granules are decoded / packed in parallel.  The host

@@ -195,4 +195,105 @@ __global__ __launch_bounds__(CH_THREADS) void k_chain_apply(mp3s_gr_out *__restr
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// The message cursor, decided on the device.  A unit sees the message only through the <= 3 bits at its cursor, so the
+// units a (short) message can reach are run once per possibility inside the rate-loop launch itself (RateVariants:
+// the 8 three-bit patterns, "two bits left", "one bit left"; the launch's own run of the unit, with the cursor behind
+// every message, is the eleventh: "nothing left").  What remains is the serial part -- which possibility does unit j
+// see? -- and that is a composition of small maps: with d = 3j - (cursor - start) (the tables the units so far fell
+// short of three each, 0 <= d < 128), unit j maps d to d + 3 - tables(j, possibility at that cursor).  One workgroup
+// per stream keeps two byte arrays in LDS -- the possibility at every cursor position, the table count of every
+// (possibility, unit) -- and its 16 waves compose a chunk of units each (a lane carries d = lane and d = lane + 64
+// through the chunk: two LDS reads per unit and state); the chunk totals give every chunk its starting d, a second walk
+// gives every unit its d, and the entry each unit takes goes into a list that k_scatter_entries (many workgroups: one
+// compute unit alone copies too slowly) works off.  cursor[] receives what each unit really saw, for the check in
+// k_chain_apply, which stays the judge: a stream the plan did not cover (the message reached further, d left its
+// range) is simply left as it was and fails that check.
+constexpr int SEL_THREADS = 1024, SEL_WAVES = SEL_THREADS / 64, SEL_D = 128;
+constexpr int SEL_NONE = MP3S_SELECT_VARIANTS;   // index of "the unit's own run" in the per-unit table counts
+
+__host__ __device__ inline size_t select_lds_bytes(int reach)
+{
+    return (size_t)reach * (SEL_NONE + 1) + (size_t)(3 * reach + 8) + (size_t)reach + SEL_WAVES * SEL_D + 64;
+}
+
+// pairs: int2 [n_segs][max_reach] = (entry or -1, unit) for k_scatter_entries
+__global__ __launch_bounds__(SEL_THREADS) void k_chain_select(const mp3s_chain_seg *__restrict__ segs, const mp3s_select_span *__restrict__ spans,
+                                                              int max_reach, const uint8_t *__restrict__ hide,
+                                                              const uint8_t *__restrict__ tabv, const mp3s_gr_out *__restrict__ out,
+                                                              int32_t *__restrict__ cursor, int2 *__restrict__ pairs)
+{
+    extern __shared__ uint8_t sel_lds[];
+    __shared__ int overflow;
+    const int s = blockIdx.x;
+    const mp3s_select_span sp = spans[s];
+    const int R = sp.reach;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    int2 *my_pairs = pairs + (long)s * max_reach;
+    if (R <= 0) {
+        for (int j = tid; j < max_reach; j += SEL_THREADS) my_pairs[j] = make_int2(-1, 0);
+        return;
+    }
+    const mp3s_chain_seg sg = segs[s];
+    const long c0 = sg.hide_begin, end = sg.hide_end;
+    const long u0 = (long)sg.first_frame * 4;
+    uint8_t *tabs = sel_lds;                                  // [11][R]: table counts of the entries, [10] = the unit's own run
+    uint8_t *code = tabs + (size_t)R * (SEL_NONE + 1);        // [3R + 8]: the possibility a unit sees with its cursor at start + p
+    uint8_t *delta = code + 3 * R + 8;                        // [R]
+    uint8_t *tot = delta + R;                                 // [16][128]
+    if (tid == 0) overflow = 0;
+    for (int i = tid; i < R * SEL_NONE; i += SEL_THREADS) tabs[i] = tabv[sp.first_entry + i];
+    for (int j = tid; j < R; j += SEL_THREADS) tabs[SEL_NONE * R + j] = (uint8_t)out[u0 + j].n_tables;
+    for (int p = tid; p < 3 * R + 8; p += SEL_THREADS) {
+        const long cur = c0 + p;
+        int v = SEL_NONE;
+        if (cur + 3 <= end) v = (hide[cur] & 1) * 4 + (hide[cur + 1] & 1) * 2 + (hide[cur + 2] & 1);
+        else if (cur == end - 2) v = 8;
+        else if (cur == end - 1) v = 9;
+        code[p] = (uint8_t)v;
+    }
+    __syncthreads();
+    // unit j, state d -> the next state (d stays once the cursor is behind the message: it no longer matters there, and
+    // the cursor 3j - d only moves on); states the chain cannot be in (cursor in front of the start) stay too
+    auto step = [&](int j, int d) -> int {
+        const int rel = 3 * j - d;
+        if (rel < 0) return d;
+        const int v = code[rel];
+        return v == SEL_NONE ? d : min(d + 3 - (int)tabs[v * R + j], SEL_D - 1);
+    };
+    const int chunk = (R + SEL_WAVES - 1) / SEL_WAVES, j0 = wave * chunk, j1 = min(R, j0 + chunk);
+    {
+        int m0 = lane, m1 = lane + 64;
+        for (int j = j0; j < j1; j++) { m0 = step(j, m0); m1 = step(j, m1); }
+        tot[wave * SEL_D + lane] = (uint8_t)m0;
+        tot[wave * SEL_D + 64 + lane] = (uint8_t)m1;
+    }
+    __syncthreads();
+    {
+        int d = 0;
+        for (int w = 0; w < wave; w++) d = tot[w * SEL_D + d];
+        bool sat = false;
+        for (int j = j0; j < j1; j++) {
+            if (lane == 0) delta[j] = (uint8_t)d;
+            sat |= d >= SEL_D - 1;
+            d = step(j, d);
+        }
+        if (sat && lane == 0) overflow = 1;
+    }
+    __syncthreads();
+    const bool bad = overflow != 0;
+    for (int j = tid; j < max_reach; j += SEL_THREADS) {
+        int src = -1;
+        if (j < R && !bad) {
+            const int rel = 3 * j - (int)delta[j];
+            const int v = rel < 0 ? SEL_NONE : (int)code[rel];
+            if (v != SEL_NONE) {
+                src = sp.first_entry + v * R + j;
+                cursor[u0 + j] = (int32_t)(c0 + rel);
+            }
+        }
+        my_pairs[j] = make_int2(src, (int)(u0 + j));
+    }
+}
+
 }  // namespace mp3s

@@ -286,11 +286,21 @@ __device__ __forceinline__ int rl_body(const RlTables &tb, uint8_t *pcode, const
     return bits + rbits[0] + rbits[1] + rbits[2];
 }
 
+// Entries behind the launch's own units (message variants decided on the device, k_chain_select): entry e re-runs unit
+// unit[e] with the message cursor cursor[e] and no inherited state; its results go to element e of ix / out / en.
+struct RateVariants {
+    const int32_t *unit, *cursor;
+    int n;
+    int16_t *ix; mp3s_gr_out *out; int32_t *en;
+    uint8_t *tables;   // the entries' table counts once more, one byte each (what the selection's walk reads)
+};
+
 __global__ __launch_bounds__(RL_WAVES * 64, 4) void k_rate_loop(
     const int32_t *__restrict__ mdct, const mp3s_rate_frame *__restrict__ frames, int n_units,
     const uint8_t *__restrict__ hide, int n_hide, const int32_t *__restrict__ cursor_in,
     const int32_t *__restrict__ state_in, const int32_t *__restrict__ unit_list, int n_list,
-    int16_t *__restrict__ ix_out, mp3s_gr_out *__restrict__ out, int32_t *__restrict__ en_out, int out_base, int compact)
+    int16_t *__restrict__ ix_out, mp3s_gr_out *__restrict__ out, int32_t *__restrict__ en_out, int out_base, int compact,
+    RateVariants var)
 {
     // compact (re-runs of a unit list): cursor_in / state_in / out are indexed by the position in the list, so that a
     // pass moves a few bytes per listed unit over PCIe instead of whole-batch arrays; ix / en still land in place.
@@ -318,8 +328,16 @@ __global__ __launch_bounds__(RL_WAVES * 64, 4) void k_rate_loop(
     __syncthreads();
 
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
-    const int li = blockIdx.x * RL_WAVES + wave;
-    if (li >= n_list) return;
+    int li = blockIdx.x * RL_WAVES + wave;
+    if (li >= n_list + var.n) return;
+    uint8_t *tables_out = nullptr;
+    if (li >= n_list) {                           // a variant entry: by entry position throughout (as compact == 2)
+        li -= n_list;
+        tables_out = var.tables;
+        unit_list = var.unit; cursor_in = var.cursor; state_in = nullptr;
+        ix_out = var.ix; out = var.out; en_out = var.en;
+        compact = 2;
+    }
     const int u = __builtin_amdgcn_readfirstlane(unit_list ? unit_list[li] : li);
     if (u < 0 || u >= n_units) return;
     uint8_t *pcode = pcode_all[wave];
@@ -489,6 +507,7 @@ __global__ __launch_bounds__(RL_WAVES * 64, 4) void k_rate_loop(
             o.xrmax = (int32_t)xrmax;
             o.reserved = 0;
             out[compact ? li : u - out_base] = o;
+            if (tables_out) tables_out[li] = (uint8_t)o.n_tables;
         }
     }
 }
@@ -512,6 +531,7 @@ __global__ __launch_bounds__(256) void k_scatter_entries(const int2 *__restrict_
     const int j = blockIdx.x * 4 + wave;
     if (j >= n_pairs) return;
     const int2 pr = pairs[j];
+    if (pr.x < 0) return;                                     // (k_chain_select: the unit's own run stands)
     const long src = pr.x, dst = pr.y;
     const uint32_t *a = reinterpret_cast<const uint32_t *>(ixv + src * 576);
     uint32_t *b = reinterpret_cast<uint32_t *>(ix + dst * 576);

@@ -26,6 +26,18 @@ int max_part2_3(const mp3s_frame_side *side, long n)
     return m;
 }
 
+void select_entries(int first_unit, int reach, int first_entry, int hide_end, int32_t *ent_unit, int32_t *ent_cursor)
+{
+    for (int v = 0; v < MP3S_SELECT_VARIANTS; v++) {
+        // 0..7: the three-bit patterns in front of the messages; 8 / 9: the message's own last two bits / last bit
+        const int32_t cur = v < 8 ? 4 * v : hide_end - (10 - v);
+        for (int j = 0; j < reach; j++) {
+            ent_unit[first_entry + v * reach + j] = first_unit + j;
+            ent_cursor[first_entry + v * reach + j] = cur;
+        }
+    }
+}
+
 extern "C" {
 
 const char *mp3s_last_error(void) { return g_err.c_str(); }
@@ -350,6 +362,50 @@ int mp3s_rate_loop_dev(mp3s_ctx *c, const int32_t *d_mdct, const mp3s_rate_frame
 }
 
 
+
+void mp3s_select_patterns(uint8_t out[32])
+{
+    for (int v = 0; v < 8; v++) { out[4 * v] = (v >> 2) & 1; out[4 * v + 1] = (v >> 1) & 1; out[4 * v + 2] = v & 1; out[4 * v + 3] = 0; }
+}
+
+int mp3s_select_plan(const mp3s_chain_seg *segs, int n_segs, mp3s_select_span *spans, int32_t *ent_unit, int32_t *ent_cursor, int cap)
+{
+    if (!segs || !spans || n_segs <= 0 || cap < 0 || ((ent_unit == nullptr) != (ent_cursor == nullptr))) return fail(MP3S_E_ARG, "bad argument");
+    int used = 0;
+    for (int i = 0; i < n_segs; i++) {
+        const mp3s_chain_seg &g = segs[i];
+        spans[i].first_entry = used; spans[i].reach = 0;
+        const int64_t left = (int64_t)g.hide_end - g.hide_begin;
+        if (left <= 0 || g.n_frames <= 0 || g.hide_base < 32) continue;
+        // units the rest of the message can reach at 2.8 tables per unit (measured on music: 2.96), and some
+        const int64_t reach = std::min<int64_t>((int64_t)g.n_frames * 4, left * 5 / 14 + 32);
+        if (reach > MP3S_SELECT_MAX_REACH || used + reach * MP3S_SELECT_VARIANTS > cap) continue;
+        spans[i].reach = (int32_t)reach;
+        if (ent_unit) select_entries(g.first_frame * 4, (int)reach, used, g.hide_end, ent_unit, ent_cursor);
+        used += (int)reach * MP3S_SELECT_VARIANTS;
+    }
+    return used;
+}
+
+int mp3s_rate_select_dev(mp3s_ctx *c, const int32_t *d_mdct, const mp3s_rate_frame *d_frames, int n_frames, const uint8_t *d_hide_bits,
+                         int n_hide, int32_t *d_cursor, const mp3s_chain_seg *d_segs, const mp3s_select_span *d_spans, int n_segs,
+                         int max_reach, const int32_t *d_ent_unit, const int32_t *d_ent_cursor, int n_entries, int16_t *d_ix,
+                         mp3s_gr_out *d_out, int32_t *d_en, int16_t *d_ixv, mp3s_gr_out *d_outv, int32_t *d_env)
+{
+    if (!c || !d_mdct || !d_frames || !d_ix || !d_out || !d_en || !d_hide_bits || !d_cursor || !d_segs || !d_spans || !d_ent_unit ||
+        !d_ent_cursor || !d_ixv || !d_outv || !d_env)
+        return fail(MP3S_E_ARG, "null pointer");
+    if (n_frames <= 0 || n_hide < 32 || n_segs <= 0 || n_entries <= 0 || max_reach <= 0 || max_reach > MP3S_SELECT_MAX_REACH)
+        return fail(MP3S_E_ARG, "bad sizes");
+    const RateVariantArgs va = {d_ent_unit, d_ent_cursor, n_entries, d_ixv, d_outv, d_env, (uint8_t *)(d_outv + n_entries)};
+    int e = launch_rate(c->stream, d_mdct, d_frames, n_frames, d_hide_bits, n_hide, d_cursor, nullptr, nullptr, 0, d_ix, d_out, d_en,
+                        &c->prof, 0, 0, &va);
+    void *d_pairs = c->grab(29, (size_t)n_segs * max_reach * 8);
+    if (!d_pairs) return fail(MP3S_E_NOMEM, "hipMalloc failed for the selection scratch");
+    if (!e) e = launch_select(c->stream, d_segs, d_spans, n_segs, max_reach, d_hide_bits, va, d_ix, d_en, d_out, d_cursor, d_pairs, &c->prof);
+    if (e) return fail(MP3S_E_HIP, "rate / select launch: %s", hipGetErrorString((hipError_t)e));
+    return MP3S_OK;
+}
 
 int mp3s_chain_resolve_dev(mp3s_ctx *c, mp3s_gr_out *d_gr, const mp3s_rate_frame *d_frames, int n_frames, const mp3s_chain_seg *d_segs,
                            int n_segs, const int32_t *d_cursor_in, const int32_t *d_state_in, int32_t *d_verdict,

@@ -46,18 +46,34 @@ size_t enc_scratch_bytes(int n_frames);
 int launch_encode(hipStream_t stream, const int16_t *d_pcm, const mp3s_frame_hdr *d_hdr, int n_frames, int32_t *d_mdct,
                   void *d_scratch, Profiler *prof);
 
+// entries behind the launch's own units: unit d_unit[e] once more with cursor d_cursor[e] and no inherited state, results
+// to element e of d_ix / d_out / d_en (the message variants the device chooses from, launch_select)
+struct RateVariantArgs {
+    const int32_t *d_unit, *d_cursor;
+    int n;
+    int16_t *d_ix; mp3s_gr_out *d_out; int32_t *d_en;
+    uint8_t *d_tables;   // n bytes: the entries' table counts (kept behind the GrInfo records: variant_out_bytes)
+};
+// the GrInfo array of n variant entries is followed by their table counts, one byte each
+inline size_t variant_out_bytes(int n) { return (size_t)n * sizeof(mp3s_gr_out) + (((size_t)n + 15) & ~(size_t)15); }
 // state: int32 [units][4] = address1, address2, address3, quantizerStepSize inherited from the previous frame
 int launch_rate(hipStream_t stream, const int32_t *d_mdct, const mp3s_rate_frame *d_frames, int n_frames,
                 const uint8_t *d_hide, int n_hide, const int32_t *d_cursor, const int32_t *d_state,
                 const int32_t *d_list, int n_list, int16_t *d_ix, mp3s_gr_out *d_out, int32_t *d_en, Profiler *prof,
                 int out_base = 0 /* unit whose results land on element 0 of d_ix / d_out / d_en */,
-                int compact = 0 /* 1: d_cursor / d_state / d_out are indexed by the position in d_list; 2: d_ix / d_en too */);
+                int compact = 0 /* 1: d_cursor / d_state / d_out are indexed by the position in d_list; 2: d_ix / d_en too */,
+                const RateVariantArgs *variants = nullptr);
 
 // the serial chains of the rate loop (k_chain.hpp): two small launches; d_agg: chain_agg_bytes(n_frames) of scratch
 size_t chain_agg_bytes(int n_frames);
 int launch_chain(hipStream_t stream, mp3s_gr_out *d_gr, const mp3s_rate_frame *d_frames, int n_frames, const mp3s_chain_seg *d_segs,
                  const int32_t *d_cursor, const int32_t *d_state, void *d_agg, int32_t *d_verdict, mp3s_chain_seg_out *d_seg_out,
                  Profiler *prof);
+
+// the message cursor decided on the device (k_chain_select): one workgroup per stream, after a launch_rate with variants
+int launch_select(hipStream_t stream, const mp3s_chain_seg *d_segs, const mp3s_select_span *d_spans, int n_segs, int max_reach,
+                  const uint8_t *d_hide, const RateVariantArgs &v, int16_t *d_ix, int32_t *d_en, mp3s_gr_out *d_out, int32_t *d_cursor,
+                  void *d_pairs /* n_segs * max_reach * 8 bytes of scratch */, Profiler *prof);
 
 constexpr size_t kPlaceEntry = 4912;   // [int32 frame, pad to 16 | int16 is[2304] | mp3s_granule_si si[4]]
 int launch_place_frames(hipStream_t stream, const uint8_t *d_entries, int n_entries, int16_t *d_is, mp3s_granule_si *d_si);

@@ -120,15 +120,18 @@ int launch_encode(hipStream_t stream, const int16_t *d_pcm, const mp3s_frame_hdr
 
 int launch_rate(hipStream_t stream, const int32_t *d_mdct, const mp3s_rate_frame *d_frames, int n_frames,
                 const uint8_t *d_hide, int n_hide, const int32_t *d_cursor, const int32_t *d_state,
-                const int32_t *d_list, int n_list, int16_t *d_ix, mp3s_gr_out *d_out, int32_t *d_en, Profiler *prof, int out_base, int compact)
+                const int32_t *d_list, int n_list, int16_t *d_ix, mp3s_gr_out *d_out, int32_t *d_en, Profiler *prof, int out_base, int compact,
+                const RateVariantArgs *variants)
 {
     const int n_units = n_frames * 4;
     if (compact && !d_list) return (int)hipErrorInvalidValue;
     const int n = d_list ? n_list : n_units;
-    if (n <= 0) return 0;
+    RateVariants var = {nullptr, nullptr, 0, nullptr, nullptr, nullptr, nullptr};
+    if (variants && variants->n > 0) var = RateVariants{variants->d_unit, variants->d_cursor, variants->n, variants->d_ix, variants->d_out, variants->d_en, variants->d_tables};
+    if (n + var.n <= 0) return 0;
     const int pp = prof ? prof->begin(stream, K_RATE_LOOP) : -1;
-    hipLaunchKernelGGL(k_rate_loop, dim3((n + RL_WAVES - 1) / RL_WAVES), dim3(RL_WAVES * 64), 0, stream, d_mdct, d_frames,
-                       n_units, d_hide, n_hide, d_cursor, d_state, d_list, n, d_ix, d_out, d_en, out_base, compact);
+    hipLaunchKernelGGL(k_rate_loop, dim3((n + var.n + RL_WAVES - 1) / RL_WAVES), dim3(RL_WAVES * 64), 0, stream, d_mdct, d_frames,
+                       n_units, d_hide, n_hide, d_cursor, d_state, d_list, n, d_ix, d_out, d_en, out_base, compact, var);
     if (prof) prof->end(stream, pp);
     return (int)hipGetLastError();
 }
@@ -146,6 +149,22 @@ int launch_chain(hipStream_t stream, mp3s_gr_out *d_gr, const mp3s_rate_frame *d
                        (ChainEl *)d_agg, d_verdict, d_seg_out);
     hipLaunchKernelGGL(k_chain_apply, dim3(blocks), dim3(CH_THREADS), 0, stream, d_gr, d_frames, d_segs, n_frames,
                        (const ChainEl *)d_agg, d_cursor, d_state, d_verdict, d_seg_out);
+    if (prof) prof->end(stream, pp);
+    return (int)hipGetLastError();
+}
+
+int launch_select(hipStream_t stream, const mp3s_chain_seg *d_segs, const mp3s_select_span *d_spans, int n_segs, int max_reach,
+                  const uint8_t *d_hide, const RateVariantArgs &v, int16_t *d_ix, int32_t *d_en, mp3s_gr_out *d_out, int32_t *d_cursor,
+                  void *d_pairs, Profiler *prof)
+{
+    if (n_segs <= 0 || max_reach <= 0 || v.n <= 0) return 0;
+    if (max_reach > MP3S_SELECT_MAX_REACH) return (int)hipErrorInvalidValue;
+    const int pp = prof ? prof->begin(stream, K_CHAIN) : -1;
+    hipLaunchKernelGGL(k_chain_select, dim3(n_segs), dim3(SEL_THREADS), select_lds_bytes(max_reach), stream, d_segs, d_spans, max_reach,
+                       d_hide, (const uint8_t *)v.d_tables, (const mp3s_gr_out *)d_out, d_cursor, (int2 *)d_pairs);
+    const int n_pairs = n_segs * max_reach;
+    hipLaunchKernelGGL(k_scatter_entries, dim3((n_pairs + 3) / 4), dim3(256), 0, stream, (const int2 *)d_pairs, n_pairs,
+                       (const int16_t *)v.d_ix, (const int32_t *)v.d_en, (const mp3s_gr_out *)v.d_out, d_ix, d_en, d_out);
     if (prof) prof->end(stream, pp);
     return (int)hipGetLastError();
 }

@@ -4,6 +4,14 @@
 
 static inline size_t up16(size_t x) { return (x + 15) & ~(size_t)15; }
 
+// message bits the frames in front of a block have taken
+static int64_t cursor0(const EncSeg &s)
+{
+    return s.carry_in ? std::min<int64_t>(std::max<int64_t>(s.carry_in->cursor, 0), kNoCursor) : 0;
+}
+
+static bool select_disabled() { static const bool off = getenv("MP3S_NO_SELECT") != nullptr; return off; }
+
 int enc_layout(std::vector<EncSeg> &segs, int samplerate, int bitrate_kbps, EncLayout &L)
 {
     // -1 sits in the reference's bitrate table (encoder/util.py:27,42), so its header check lets it through and the
@@ -30,14 +38,35 @@ int enc_layout(std::vector<EncSeg> &segs, int samplerate, int bitrate_kbps, EncL
     L.o_segs = L.o_hide + up16((size_t)L.n_hide);
     L.o_off = L.o_segs + up16((size_t)L.n_segs * sizeof(mp3s_chain_seg));
     L.o_pad = L.o_off + up16(((size_t)L.n + 1) * 4);
-    L.bytes = L.o_pad + up16((size_t)L.n);
+    // ---- the streams whose message cursor the device decides (mp3s_select_plan's rule)
+    std::vector<mp3s_chain_seg> cs(segs.size());
+    std::vector<mp3s_select_span> spans(segs.size());
+    for (size_t si = 0; si < segs.size(); si++) {
+        const EncSeg &s = segs[si];
+        cs[si] = mp3s_chain_seg();
+        cs[si].first_frame = s.first; cs[si].n_frames = s.n_frames; cs[si].hide_base = s.hide_base;
+        cs[si].hide_begin = (int32_t)((int64_t)s.hide_base + cursor0(s)); cs[si].hide_end = s.hide_base + s.n_hide;
+    }
+    const int budget = select_disabled() ? 0 : std::max(L.units / 2, 8192);
+    L.n_entries = mp3s_select_plan(cs.data(), L.n_segs, spans.data(), nullptr, nullptr, budget);
+    L.max_reach = 0;
+    for (size_t si = 0; si < segs.size(); si++) {
+        segs[si].reach = spans[si].reach; segs[si].first_entry = spans[si].first_entry;
+        L.max_reach = std::max(L.max_reach, spans[si].reach);
+    }
+    L.o_spans = L.o_pad + up16((size_t)L.n);
+    L.o_ent = L.o_spans + up16((size_t)L.n_segs * sizeof(mp3s_select_span));
+    L.bytes = L.o_ent + up16((size_t)L.n_entries * 8);
     return MP3S_OK;
 }
 
-// message bits the frames in front of a block have taken
-static int64_t cursor0(const EncSeg &s)
+bool enc_variant_buffers(mp3s_ctx *c, const EncLayout &L, EncDev &d)
 {
-    return s.carry_in ? std::min<int64_t>(std::max<int64_t>(s.carry_in->cursor, 0), kNoCursor) : 0;
+    if (L.n_entries <= 0) { d.d_ixv = nullptr; d.d_outv = nullptr; d.d_env = nullptr; return true; }
+    d.d_ixv = (int16_t *)c->grab(kSlotVariants + 1, (size_t)L.n_entries * 1152);
+    d.d_outv = (mp3s_gr_out *)c->grab(kSlotVariants + 2, variant_out_bytes(L.n_entries));
+    d.d_env = (int32_t *)c->grab(kSlotVariants + 3, (size_t)L.n_entries * 88);
+    return d.d_ixv && d.d_outv && d.d_env;
 }
 
 int enc_fill(std::vector<EncSeg> &segs, EncLayout &L, uint8_t *dst)
@@ -50,7 +79,8 @@ int enc_fill(std::vector<EncSeg> &segs, EncLayout &L, uint8_t *dst)
     mp3s_chain_seg *cs = (mp3s_chain_seg *)(dst + L.o_segs);
     uint32_t *off = (uint32_t *)(dst + L.o_off);
     uint8_t *pad8 = dst + L.o_pad;
-    for (int v = 0; v < 8; v++) { hide_all[4 * v] = (v >> 2) & 1; hide_all[4 * v + 1] = (v >> 1) & 1; hide_all[4 * v + 2] = v & 1; }
+    mp3s_select_span *spans = (mp3s_select_span *)(dst + L.o_spans);
+    mp3s_select_patterns(hide_all);
     std::vector<int32_t> padding;
     L.bytes_before = 0;
     for (size_t si = 0; si < segs.size(); si++) {
@@ -70,17 +100,25 @@ int enc_fill(std::vector<EncSeg> &segs, EncLayout &L, uint8_t *dst)
         if (s.n_hide) std::memcpy(hide_all + s.hide_base, s.hide, (size_t)s.n_hide);
         // A unit sees the message only through the <= 3 bits at its cursor.  First pass: guess three tables per unit (for
         // a short message in a long stream that is almost always right); a long message is left to the variants.
+        // A stream with a plan (reach > 0) needs no guess: its units run "behind every message" and the variants, in the
+        // same launch, cover what the message can reach; the selection writes the cursors the units really saw.
         const int64_t c0 = cursor0(s);
-        const bool long_msg = s.n_hide - c0 > kLongMessageBits;
+        const bool long_msg = s.reach > 0 || s.n_hide - c0 > kLongMessageBits;
         int64_t ahead = 0;               // tables the units in front are expected to take
         for (int j = 0; j < s.n_frames * 4; j++) {
             cursor[(size_t)s.first * 4 + j] = long_msg ? kNoCursor : (int32_t)std::min<int64_t>((int64_t)s.hide_base + c0 + ahead, kNoCursor);
             ahead += s.tables_guess ? s.tables_guess[j] : 3;
         }
+        spans[si].first_entry = s.first_entry; spans[si].reach = s.reach;
         cs[si].first_frame = s.first; cs[si].n_frames = s.n_frames;
         cs[si].hide_base = s.hide_base; cs[si].hide_begin = (int32_t)((int64_t)s.hide_base + c0);   // (both below 2^30)
         cs[si].hide_end = s.hide_base + s.n_hide;
         if (s.carry_in) std::memcpy(cs[si].chain_in, s.carry_in->chain, sizeof cs[si].chain_in);
+    }
+    if (L.n_entries > 0) {
+        int32_t *ent = (int32_t *)(dst + L.o_ent);
+        for (const auto &s : segs)
+            if (s.reach > 0) select_entries(s.first * 4, s.reach, s.first_entry, s.hide_base + s.n_hide, ent, ent + L.n_entries);
     }
     off[0] = 0;
     for (int f = 0; f < L.n; f++) off[f + 1] = off[f] + (uint32_t)(L.whole + pad8[f]);
@@ -120,7 +158,14 @@ int enc_issue(mp3s_ctx *c, const EncLayout &L, const EncDev &d)
     const mp3s_chain_seg *d_segs = (const mp3s_chain_seg *)(d.d_in + L.o_segs);
     const int32_t *d_mdct = d.d_mdct_all + (size_t)L.lead * 2304;   // the block's own frames
     int rc = mp3s_encode_transform_dev(c, d.d_pcm, d_hdr, L.n_all, d.d_mdct_all);
-    if (!rc) rc = mp3s_rate_loop_dev(c, d_mdct, d_rf, L.n, d_hide, L.n_hide, d_cur, nullptr, nullptr, 0, d.d_ix, d.d_out, d.d_en);
+    if (!rc && L.n_entries > 0) {
+        // short messages: their variants run in the same launch and the device decides the cursor chain (no guess)
+        const int32_t *d_ent = (const int32_t *)(d.d_in + L.o_ent);
+        rc = mp3s_rate_select_dev(c, d_mdct, d_rf, L.n, d_hide, L.n_hide, const_cast<int32_t *>(d_cur), d_segs,
+                                  (const mp3s_select_span *)(d.d_in + L.o_spans), L.n_segs, L.max_reach, d_ent, d_ent + L.n_entries,
+                                  L.n_entries, d.d_ix, d.d_out, d.d_en, d.d_ixv, d.d_outv, d.d_env);
+    } else if (!rc)
+        rc = mp3s_rate_loop_dev(c, d_mdct, d_rf, L.n, d_hide, L.n_hide, d_cur, nullptr, nullptr, 0, d.d_ix, d.d_out, d.d_en);
     if (!rc) {
         const int e = launch_chain(c->stream, d.d_out, d_rf, L.n, d_segs, d_cur, nullptr, d.d_agg, d.d_small,
                                    (mp3s_chain_seg_out *)((uint8_t *)d.d_small + kSmallHead), &c->prof);
@@ -165,6 +210,8 @@ int enc_resolve(mp3s_ctx *c, const EncLayout &L, std::vector<EncSeg> &segs, cons
     b->scfsi.assign((size_t)n * 8, 0);
     std::vector<int32_t> &cursor = c->h_cursor, &state = c->h_state;
     cursor.assign((const int32_t *)(in + L.o_cur), (const int32_t *)(in + L.o_cur) + units);
+    // (the selection on the device has written the cursors of the units it replaced)
+    if (!rc && L.n_entries > 0) rc = mp3s_dev_download(c, cursor.data(), d_in + L.o_cur, (size_t)units * 4);
     state.assign((size_t)units * 4, 0);
     int passes = 1;
     // ---- resolve the serial chains, stream by stream: hide cursor (MP3_Encoder.py:808-809) and the per-(gr,ch) inherited
@@ -418,6 +465,7 @@ int encode_batch(mp3s_ctx *c, const int16_t *pcm, const int16_t *pcm_dev, std::v
     dev.d_pcm = (const int16_t *)d_pcm; dev.d_in = (const uint8_t *)d_in; dev.d_mdct_all = (int32_t *)d_mdct_all; dev.d_ix = (int16_t *)d_ix;
     dev.d_out = (mp3s_gr_out *)d_out; dev.d_en = (int32_t *)d_en; dev.d_agg = d_agg; dev.d_mp3 = (uint8_t *)d_mp3; dev.d_sc = (int32_t *)d_sc;
     dev.d_small = (int32_t *)d_small;
+    if (!rc && !enc_variant_buffers(c, L, dev)) rc = fail(MP3S_E_NOMEM, "hipMalloc failed for %d variant entries", L.n_entries);
     if (!rc) rc = enc_issue(c, L, dev);
     auto down = [&](void *dst, const void *src, size_t bytes) {
         if (!rc && bytes && hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, c->stream) != hipSuccess) rc = fail(MP3S_E_HIP, "download failed");

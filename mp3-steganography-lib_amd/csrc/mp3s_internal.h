@@ -211,7 +211,7 @@ int decode_group(mp3s_ctx *c, mp3s_multi &m, const std::vector<int> &idx, int nc
 
 // ---------------------------------------------------------------- encode pipeline (mp3s_encode_pipeline.cpp)
 constexpr int kLongMessageBits = 1024;    // above: the first pass does not guess cursors at all
-constexpr int32_t kNoCursor = 0x3fffffff; // "behind every message": such a unit hides nothing
+constexpr int32_t kNoCursor = MP3S_NO_CURSOR; // "behind every message": such a unit hides nothing
 constexpr int kPatternBytes = 32;         // the eight 3-bit patterns, 4 bytes apart, in front of the messages
 constexpr int kVariantEntries = 65536;    // (unit, pattern) entries per variant launch
 constexpr size_t kFewUnits = 8;           // that few wrong cursors after the first pass: re-run them directly
@@ -232,17 +232,20 @@ struct EncSeg {             // one stream of an encode batch: frames back to bac
     const uint8_t *tables_guess = nullptr;
     // filled by encode_batch
     int first = 0, hide_base = 0;
+    int reach = 0, first_entry = 0;  // the message cursor is decided on the device over the stream's first `reach` units (0: guessed)
     int64_t hide_offset = 0;         // message bits consumed (from the start of the stream)
     size_t mp3_off = 0, mp3_len = 0; // the stream's bytes inside the batch's output
     mp3s_carry carry_out = {};
     bool carry_used = false;         // the block's bytes depend on carry_in
 };
 // The host-made inputs of an encode batch travel as ONE block (one copy):
-//   [frame headers (n_all) | rate frames (n) | assumed cursors (units) | message bits | chain segments | frame offsets (n+1) | padding (n)]
+//   [frame headers (n_all) | rate frames (n) | assumed cursors (units) | message bits | chain segments | frame offsets (n+1) | padding (n)
+//    | selection spans (n_segs) | variant entries: units (n_entries), cursors (n_entries)]
 struct EncLayout {
     int n = 0, n_all = 0, lead = 0, units = 0, n_hide = 0, n_segs = 0;
+    int n_entries = 0, max_reach = 0;   // message variants run inside the first rate-loop launch (mp3s_rate_select_dev)
     int sri = 0, bri = 0, whole = 0, samplerate = 0, kbps = 0;
-    size_t o_rf = 0, o_cur = 0, o_hide = 0, o_segs = 0, o_off = 0, o_pad = 0, bytes = 0;   // (headers at offset 0)
+    size_t o_rf = 0, o_cur = 0, o_hide = 0, o_segs = 0, o_off = 0, o_pad = 0, o_spans = 0, o_ent = 0, bytes = 0;   // (headers at offset 0)
     size_t mp3_bytes = 0;          // all frames of the batch
     int64_t bytes_before = 0;      // size of the frames in front of a block (E14: the tail cut depends on it)
 };
@@ -261,7 +264,13 @@ struct EncDev {
     void *d_agg = nullptr;               // chain_agg_bytes(n)
     uint8_t *d_mp3 = nullptr; int32_t *d_sc = nullptr;
     int32_t *d_small = nullptr;          // small_bytes(n_segs)
+    // results of the variant entries (L.n_entries of them; read by the selection right behind the rate loop)
+    int16_t *d_ixv = nullptr; mp3s_gr_out *d_outv = nullptr; int32_t *d_env = nullptr;
 };
+// the MP3S_SELECT_VARIANTS entries of each of a stream's first `reach` units (variant-major: entry (v, j) = first_entry + v * reach + j)
+void select_entries(int first_unit, int reach, int first_entry, int hide_end, int32_t *ent_unit, int32_t *ent_cursor);
+// device buffers for L.n_entries variant entries from the context's pool (slots of the host's variants, free at that point)
+bool enc_variant_buffers(mp3s_ctx *c, const EncLayout &L, EncDev &d);
 // transforms -> rate loop on the guessed cursors -> chain check -> bit packing, all on c->stream, nothing waited for.
 // The packed bytes are final iff verdict[0] == 0 and verdict[1] == 0 (d_small[0], d_small[1]).
 int enc_issue(mp3s_ctx *c, const EncLayout &L, const EncDev &d);

@@ -289,6 +289,7 @@ int issue_fast(mp3s_pipe *P, Job &j, Slot &s, size_t blob_len, int max_p23)
     dev.d_out = (mp3s_gr_out *)(s.d_enc + b_mdct + b_ix); dev.d_en = (int32_t *)(s.d_enc + b_mdct + b_ix + b_out); dev.d_agg = d_agg;
     dev.d_mp3 = s.d_mp3; dev.d_sc = (int32_t *)(s.d_enc + b_mdct + b_ix + b_out + b_en);
     dev.d_small = s.d_small;
+    if (!enc_variant_buffers(c, L, dev)) return fail(MP3S_E_NOMEM, "hipMalloc failed for %d variant entries", L.n_entries);
     const int rc = enc_issue(c, L, dev);
     if (rc) return rc;
     HIPCHK(hipEventRecord(s.e_comp, c->stream));
@@ -428,7 +429,7 @@ int mp3s_pipe_create(mp3s_ctx *c, int depth, size_t max_job_bytes, int scan_thre
         // Layer III frame (32 kbit/s at 48 kHz); anything denser (false syncs) overflows the sink and takes the other path
         s.blob_cap = (max_job_bytes + max_job_bytes / 8 + 4096 + 15) & ~(size_t)15;
         s.side_cap = max_job_bytes / 96 + 16;
-        s.in_cap = (s.side_cap * 72 + max_job_bytes / 4 + (size_t)kMaxFastFiles * sizeof(mp3s_chain_seg) + 4096 + 15) & ~(size_t)15;
+        s.in_cap = (s.side_cap * (72 + 16) + max_job_bytes / 4 + (size_t)kMaxFastFiles * (sizeof(mp3s_chain_seg) + sizeof(mp3s_select_span)) + 8192 * 8 + 4096 + 15) & ~(size_t)15;   // (+ variant entries: at most 2 per frame or 8192, 8 bytes each)
         s.o_side = s.blob_cap;
         s.o_in = (s.o_side + s.side_cap * sizeof(mp3s_frame_side) + 15) & ~(size_t)15;
         s.fix_cap = std::min<size_t>(kMaxFastFiles, s.side_cap);

@@ -1,0 +1,181 @@
+"""The message cursor decided on the device (include/mp3s.h (iv-c): mp3s_select_plan, mp3s_rate_select_dev; csrc/k_chain.hpp
+k_chain_select).  The plan is host arithmetic (CPU tests); the selection is checked against the oracle encoder -- reference
+encoder/MP3_Encoder.py:808-809 (the cursor), :1154-1168 and :1257-1263 (where the message is read) -- on the cases the walk
+has to get right: messages of one, two, three bits (the "bits left" variants), messages ending on every offset inside a unit,
+silence inside the reach (units that take no tables), a start in silence that the plan does not cover (the chain check fails
+and the host resolves it), several streams in one batch, blocks that continue a message."""
+import numpy as np
+import pytest
+
+
+# ------------------------------------------------------------------------------------------------ the plan (host only)
+def test_plan_layout_and_limits(mlib):
+    pat = mlib.select_patterns()
+    assert pat.tolist() == [b for v in range(8) for b in ((v >> 2) & 1, (v >> 1) & 1, v & 1, 0)]
+    segs = np.zeros(5, dtype=mlib.CHAIN_SEG_DTYPE)
+    #          plain         not hiding      message too long for a plan   short stream      continuing block, 5 bits left
+    segs["first_frame"] = [0, 100, 150, 9000, 9010]
+    segs["n_frames"] = [100, 50, 8850, 10, 40]
+    segs["hide_base"] = [32, 132, 132, 100132, 100232]
+    segs["hide_begin"] = [32, 132, 132, 100132, 100232 + 995]
+    segs["hide_end"] = [132, 132, 100132, 100232, 100232 + 1000]
+    spans, unit, cursor = mlib.select_plan(segs, 1 << 20)
+    reach0 = 100 * 5 // 14 + 32
+    assert spans["reach"].tolist() == [reach0, 0, 0, 40, 5 * 5 // 14 + 32]
+    assert spans["first_entry"].tolist()[:1] == [0] and spans["first_entry"][3] == reach0 * 10
+    assert len(unit) == (reach0 + 40 + 33) * 10
+    # variant-major: entry (v, j) = first_entry + v * reach + j; patterns at 4v, then the message's own last two bits / last bit
+    e0 = unit[:reach0 * 10].reshape(10, reach0)
+    assert (e0 == np.arange(reach0)[None, :]).all()
+    c0 = cursor[:reach0 * 10].reshape(10, reach0)
+    assert c0[:, 0].tolist() == [0, 4, 8, 12, 16, 20, 24, 28, 130, 131]
+    e3 = unit[reach0 * 10:(reach0 + 40) * 10].reshape(10, 40)
+    assert (e3 == 9000 * 4 + np.arange(40)[None, :]).all()          # the whole 10-frame stream: 40 units < the message's reach
+    # capacity: what does not fit any more is left out, later streams that fit are still planned
+    spans2, unit2, _ = mlib.select_plan(segs, reach0 * 10 + 400)
+    assert spans2["reach"].tolist() == [reach0, 0, 0, 40, 0] and len(unit2) == (reach0 + 40) * 10
+    # a message array without the patterns in front cannot be planned
+    segs["hide_base"][0] = 0
+    assert mlib.select_plan(segs, 1 << 20)[0]["reach"][0] == 0
+
+
+def test_plan_reach_limit(mlib):
+    segs = np.zeros(1, dtype=mlib.CHAIN_SEG_DTYPE)
+    segs["n_frames"], segs["hide_base"], segs["hide_begin"] = 100000, 32, 32
+    for bits, planned in ((5000, True), (5647, True), (5648, False), (50000, False)):   # bits * 5 // 14 + 32 <= 2048
+        segs["hide_end"] = 32 + bits
+        reach = int(mlib.select_plan(segs, 1 << 22)[0]["reach"][0])
+        assert (reach > 0) == planned and reach <= 2048, (bits, reach)
+
+
+# ------------------------------------------------------------------------------------------------ the selection (GPU)
+@pytest.mark.gpu
+def test_short_messages_every_ending(ctx, mlib, orc):
+    """one to a few bits (only the "bits left" variants and the start), and messages ending on every offset inside a unit"""
+    from synth_pcm import synth_pcm
+    pcm = synth_pcm(60, seed=31)
+    rng = np.random.default_rng(8)
+    for nbits in list(range(1, 14)) + [31, 32, 33, 95, 96, 97, 200, 201, 202, 203, 204, 205]:
+        msg = rng.integers(0, 2, size=nbits).astype(np.uint8)
+        r = ctx.encode_pcm(pcm, 44100, 128, msg)
+        o = orc.encode(pcm, 44100, 128, msg)
+        assert o["rc"] == 0 and r["mp3"] == o["mp3"], nbits
+        assert r["hide_offset"] == o["hide_offset"] and r["too_long"] == bool(o["too_long"]), nbits
+        assert r["rate_passes"] == 1, nbits                          # decided on the device: the first pass was final
+
+
+@pytest.mark.gpu
+def test_silence_inside_the_reach_and_uncovered_start(ctx, mlib, orc):
+    from synth_pcm import synth_pcm
+    rng = np.random.default_rng(9)
+    msg = rng.integers(0, 2, size=900).astype(np.uint8)
+    # silent frames in the middle of the message: those units take no tables, d grows by three per unit
+    pcm = synth_pcm(200, seed=32)
+    pcm[20 * 1152:27 * 1152] = 0
+    r, o = ctx.encode_pcm(pcm, 44100, 128, msg), orc.encode(pcm, 44100, 128, msg)
+    assert r["mp3"] == o["mp3"] and r["hide_offset"] == o["hide_offset"]
+    # a long silent start: d leaves its range / the message reaches further than planned; the chain check on the device
+    # says so and the host resolves the chains (more than one pass), same bytes
+    pcm = synth_pcm(300, seed=33)
+    pcm[:120 * 1152] = 0
+    r, o = ctx.encode_pcm(pcm, 44100, 128, msg), orc.encode(pcm, 44100, 128, msg)
+    assert r["mp3"] == o["mp3"] and r["hide_offset"] == o["hide_offset"]
+    assert r["rate_passes"] > 1
+    # a stream shorter than the message's reach, message longer than the stream can hold
+    pcm = synth_pcm(9, seed=34)
+    r, o = ctx.encode_pcm(pcm, 44100, 128, msg), orc.encode(pcm, 44100, 128, msg)
+    assert r["mp3"] == o["mp3"] and r["too_long"] and bool(o["too_long"]) and r["hide_offset"] == o["hide_offset"]
+
+
+@pytest.mark.gpu
+def test_batch_of_streams_and_blocks(ctx, mlib, orc):
+    """several streams with their own plans in one batch (one workgroup per stream), and a message carried across blocks
+    (the plan starts at the carried cursor)"""
+    from synth_pcm import synth_pcm
+    files, msgs = [], []
+    for i, n in enumerate((90, 40, 300, 55)):
+        pcm = synth_pcm(n, seed=50 + i)
+        if i == 2:
+            pcm[10 * 1152:14 * 1152] = 0
+        files.append(bytes(ctx.encode_pcm(pcm, 44100, 128, None)["mp3"]))
+        msgs.append("stream %d " % i * (1 + 3 * i))
+    msgs[1] = None                                                    # one of them is cleared
+    got = ctx.hide_messages(files, msgs)
+    for i, (f, m) in enumerate(zip(files, msgs)):
+        one = ctx.hide_message(f, m) if m is not None else ctx.clear_file(f)
+        assert bytes(got[i]["data"]) == bytes(one["data"]) and got[i]["hide_offset"] == one["hide_offset"], i
+        d = orc.decode(f)
+        o = orc.encode(orc.pcm_to_i16(d["pcm"]), 44100, 128, np.array(mlib.message_frame(m), dtype=np.uint8) if m is not None else None)
+        assert bytes(got[i]["data"]) == o["mp3"], i
+    # blocks: 3 x 50 frames, a message that runs from the first block into the second
+    pcm = synth_pcm(150, seed=60)
+    msg = np.random.default_rng(10).integers(0, 2, size=700).astype(np.uint8)
+    whole = ctx.encode_pcm(pcm, 44100, 128, msg)
+    out, carry = b"", None
+    for b in range(3):
+        lead = 0 if b == 0 else 2
+        blk = ctx.encode_block(pcm[(b * 50 - lead) * 1152:(b + 1) * 50 * 1152], lead, b * 50, b == 2, 44100, 128, msg, carry)
+        out += bytes(blk["mp3"])
+        carry = blk["carry_out"]
+    assert out == whole["mp3"] == orc.encode(pcm, 44100, 128, msg)["mp3"]
+
+
+@pytest.mark.gpu
+def test_rate_select_entry_point(ctx, mlib):
+    """mp3s_rate_select_dev + mp3s_chain_resolve_dev on device buffers, two streams: GrInfo, quantised lines and the
+    cursors equal what the library's own encoder (pinned to the oracle above) leaves for the same streams"""
+    from synth_pcm import synth_pcm
+    L = mlib.lib()
+    n0, n1 = 120, 70
+    n, units = n0 + n1, (n0 + n1) * 4
+    pcm0, pcm1 = synth_pcm(n0, seed=71), synth_pcm(n1, seed=72)
+    pcm1[5 * 1152:7 * 1152] = 0
+    rng = np.random.default_rng(11)
+    m0, m1 = rng.integers(0, 2, size=333).astype(np.uint8), rng.integers(0, 2, size=64).astype(np.uint8)
+    want = [ctx.encode_pcm(pcm0, 44100, 128, m0), ctx.encode_pcm(pcm1, 44100, 128, m1)]
+    hdr = np.zeros(n, dtype=mlib.FRAME_HDR_DTYPE)
+    hdr["nch"] = 2
+    hdr["stream_first"][n0:] = n0
+    mdct = ctx.encode_transform(np.concatenate([pcm0, pcm1]), hdr)
+    rf = np.concatenate([mlib.rate_frames(44100, 128, 2, n0)[0], mlib.rate_frames(44100, 128, 2, n1)[0]])
+    hide = np.concatenate([mlib.select_patterns(), m0, m1])
+    rf["stream"][n0:] = 1
+    rf["hide_end"][:n0] = 32 + len(m0)
+    rf["hide_end"][n0:] = 32 + len(m0) + len(m1)
+    segs = np.zeros(2, dtype=mlib.CHAIN_SEG_DTYPE)
+    segs["first_frame"], segs["n_frames"] = [0, n0], [n0, n1]
+    segs["hide_base"] = segs["hide_begin"] = [32, 32 + len(m0)]
+    segs["hide_end"] = [32 + len(m0), 32 + len(m0) + len(m1)]
+    spans, eu, ec = mlib.select_plan(segs, 1 << 20)
+    ne, max_reach = len(eu), int(spans["reach"].max())
+    assert spans["reach"].min() > 0
+    cur = np.full(units, mlib.NO_CURSOR, dtype=np.int32)
+    dev = [ctx.to_device(a) for a in (mdct, rf, hide, cur, segs, spans, eu, ec)]
+    d_mdct, d_rf, d_hide, d_cur, d_segs, d_spans, d_eu, d_ec = dev
+    outs = [ctx.alloc(n * 2304 * 2), ctx.alloc(units * 72), ctx.alloc(units * 88), ctx.alloc(ne * 1152),
+            ctx.alloc(ne * 72 + ((ne + 15) & ~15)), ctx.alloc(ne * 88), ctx.alloc(16), ctx.alloc(2 * 80)]
+    d_ix, d_out, d_en, d_ixv, d_outv, d_env, d_ver, d_so = outs
+    try:
+        for _ in range(2):   # the second call finds the cursors the first one wrote (exact ones): same result
+            mlib.check(L.mp3s_rate_select_dev(ctx.handle, d_mdct, d_rf, n, d_hide, len(hide), d_cur, d_segs, d_spans, 2, max_reach,
+                                              d_eu, d_ec, ne, d_ix, d_out, d_en, d_ixv, d_outv, d_env))
+            mlib.check(L.mp3s_chain_resolve_dev(ctx.handle, d_out, d_rf, n, d_segs, 2, d_cur, None, d_ver, d_so))
+            gr = ctx.download(d_out, mlib.GR_OUT_DTYPE, (units,))
+            ver = ctx.download(d_ver, np.int32, (2,))
+            so = ctx.download(d_so, mlib.CHAIN_SEG_OUT_DTYPE, (2,))
+            used = ctx.download(d_cur, np.int32, (units,))
+            assert ver.tolist() == [0, 0]
+            for s, (a, b) in enumerate(((0, n0 * 4), (n0 * 4, units))):
+                w = want[s]["gr"]
+                for k in ("part2_3_length", "big_values", "count1", "table_select", "count1table_select", "region0_count",
+                          "region1_count", "n_tables", "quantizer_step", "address"):
+                    assert np.array_equal(gr[k][a:b], w[k]), (s, k)
+                base = int(segs["hide_base"][s])
+                assert int(so["cursor"][s]) - base == want[s]["hide_offset"]
+                # the cursors the units really saw: the running sum of the tables, up to the end of the message
+                true = base + np.concatenate([[0], np.cumsum(w["n_tables"])[:-1]])
+                hiding = true < int(segs["hide_end"][s])
+                assert np.array_equal(used[a:b][hiding], true[hiding]) and (used[a:b][~hiding] == mlib.NO_CURSOR).all(), s
+    finally:
+        for p in dev + outs:
+            ctx.free(p)
