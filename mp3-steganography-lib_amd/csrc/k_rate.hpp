@@ -14,25 +14,55 @@
 
 namespace mp3s {
 
+#define RL_DPP(v, ctrl, rm) ((uint32_t)__builtin_amdgcn_update_dpp(0, (int)(v), ctrl, rm, 0xf, false))
+
 __device__ __forceinline__ uint32_t wave_max_u32(uint32_t v)
 {
-    v = max(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, false));  // row_shr:1
-    v = max(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xf, 0xf, false));  // row_shr:2
-    v = max(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xf, 0xf, false));  // row_shr:4
-    v = max(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xf, 0xf, false));  // row_shr:8
-    v = max(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xa, 0xf, false));  // row_bcast:15
-    v = max(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xc, 0xf, false));  // row_bcast:31
+    v = max(v, RL_DPP(v, 0x111, 0xf));  // row_shr:1
+    v = max(v, RL_DPP(v, 0x112, 0xf));  // row_shr:2
+    v = max(v, RL_DPP(v, 0x114, 0xf));  // row_shr:4
+    v = max(v, RL_DPP(v, 0x118, 0xf));  // row_shr:8
+    v = max(v, RL_DPP(v, 0x142, 0xa));  // row_bcast:15
+    v = max(v, RL_DPP(v, 0x143, 0xc));  // row_bcast:31
     return (uint32_t)__builtin_amdgcn_readlane((int)v, 63);
 }
 __device__ __forceinline__ uint32_t wave_add_u32(uint32_t v)
 {
-    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, false);
-    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xf, 0xf, false);
-    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xf, 0xf, false);
-    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xf, 0xf, false);
-    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xa, 0xf, false);
-    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xc, 0xf, false);
+    v += RL_DPP(v, 0x111, 0xf);
+    v += RL_DPP(v, 0x112, 0xf);
+    v += RL_DPP(v, 0x114, 0xf);
+    v += RL_DPP(v, 0x118, 0xf);
+    v += RL_DPP(v, 0x142, 0xa);
+    v += RL_DPP(v, 0x143, 0xc);
     return (uint32_t)__builtin_amdgcn_readlane((int)v, 63);
+}
+// Several reductions at once: a DPP step has to wait two issue slots for the VALU write in front of it, so independent
+// chains are written step by step side by side -- the second and third fill the slots the first would idle in.
+__device__ __forceinline__ void wave_add2(uint32_t &a, uint32_t &b)
+{
+#define RL_STEP(ctrl, rm) { const uint32_t ta = RL_DPP(a, ctrl, rm), tb = RL_DPP(b, ctrl, rm); a += ta; b += tb; }
+    RL_STEP(0x111, 0xf) RL_STEP(0x112, 0xf) RL_STEP(0x114, 0xf) RL_STEP(0x118, 0xf) RL_STEP(0x142, 0xa) RL_STEP(0x143, 0xc)
+#undef RL_STEP
+    a = (uint32_t)__builtin_amdgcn_readlane((int)a, 63);
+    b = (uint32_t)__builtin_amdgcn_readlane((int)b, 63);
+}
+__device__ __forceinline__ void wave_add3(uint32_t &a, uint32_t &b, uint32_t &c)
+{
+#define RL_STEP(ctrl, rm) { const uint32_t ta = RL_DPP(a, ctrl, rm), tb = RL_DPP(b, ctrl, rm), tc = RL_DPP(c, ctrl, rm); a += ta; b += tb; c += tc; }
+    RL_STEP(0x111, 0xf) RL_STEP(0x112, 0xf) RL_STEP(0x114, 0xf) RL_STEP(0x118, 0xf) RL_STEP(0x142, 0xa) RL_STEP(0x143, 0xc)
+#undef RL_STEP
+    a = (uint32_t)__builtin_amdgcn_readlane((int)a, 63);
+    b = (uint32_t)__builtin_amdgcn_readlane((int)b, 63);
+    c = (uint32_t)__builtin_amdgcn_readlane((int)c, 63);
+}
+__device__ __forceinline__ void wave_max3(uint32_t &a, uint32_t &b, uint32_t &c)
+{
+#define RL_STEP(ctrl, rm) { const uint32_t ta = RL_DPP(a, ctrl, rm), tb = RL_DPP(b, ctrl, rm), tc = RL_DPP(c, ctrl, rm); a = max(a, ta); b = max(b, tb); c = max(c, tc); }
+    RL_STEP(0x111, 0xf) RL_STEP(0x112, 0xf) RL_STEP(0x114, 0xf) RL_STEP(0x118, 0xf) RL_STEP(0x142, 0xa) RL_STEP(0x143, 0xc)
+#undef RL_STEP
+    a = (uint32_t)__builtin_amdgcn_readlane((int)a, 63);
+    b = (uint32_t)__builtin_amdgcn_readlane((int)b, 63);
+    c = (uint32_t)__builtin_amdgcn_readlane((int)c, 63);
 }
 
 // encoder/util.py:130-133 mulr for non-negative a: (a*b + 2^31) >> 32
@@ -40,7 +70,11 @@ __device__ __forceinline__ uint32_t mulr_u(uint32_t a, uint32_t b) { return (uin
 
 constexpr int RL_WAVES = 4;   // 4 waves share one copy of the lookup tables: 33 KB LDS -> 4 workgroups = 16 waves per CU (a fifth wave
                               // per SIMD at 96 VGPRs was measured: 0.351 instead of 0.305 ms, and the Huffman kernel no longer fits beside it)
-constexpr int RL_NP = 5;   // pair slots per lane (the 5th only for lanes < 32)
+constexpr int RL_NP = 5;      // pairs per lane: lane l holds the CONSECUTIVE pairs 5l .. 5l+4 (lines 10l .. 10l+9); lanes 0..57 hold
+                              // the granule's 288 pairs (lane 57 three of them), what lies beyond is zero throughout.  (Until r02c
+                              // pair p sat in lane p % 64: the highest non-zero pair then was a chain of ten ballots and ~90 scalar
+                              // selects per evaluation, and the neighbour pair of a count1 quad came through LDS, one round trip per
+                              // slot.  Now the run lengths are two ballots and two readlanes, the neighbour is the next register.)
 
 struct RlTables {
     uint16_t int2idx[10000];
@@ -76,16 +110,23 @@ __device__ __forceinline__ uint32_t pair_bits(const RlTables &tb, int fam, int l
 }
 __device__ __forceinline__ int sel3(int r, int a, int b, int c) { return r == 0 ? a : (r == 1 ? b : c); }
 
+// steptabi[step + 127]: the binary search asks for the scale of both steps it may probe next while it still works on
+// the current one (a scalar load takes longer than a wave has other work between probes).  The index is wrapped into the
+// table; rl_quantize rejects a step that lies outside it before the scale is used.
+__device__ __forceinline__ uint32_t rl_scale_of(int step)
+{
+    return (uint32_t)c_tab.steptabi[(step + 127) & 127];
+}
+
 // quantize (MP3_Encoder.py:389-415); returns 0, or 8193 when some quantised value exceeds 8192, 16384 for the early out,
 // -1 when the step leaves steptab (IndexError in the reference).  (The callers only ask "more than 8192?".)
 // mulr is monotone in its first argument, so the largest ln of the granule is the one of xrmax: whether the float path
 // is needed at all is a scalar question, and the table path cannot exceed 1000 -- no wave reduction in the common case.
 __device__ __forceinline__ int rl_quantize(const RlTables &tb, const uint32_t (&xa)[2 * RL_NP], int32_t (&ix)[2 * RL_NP],
-                                           int step, uint32_t xrmax)
+                                           int step, uint32_t scalei, uint32_t xrmax)
 {
-    const int idx = __builtin_amdgcn_readfirstlane(step + 127);
+    const int idx = step + 127;
     if (idx < 0 || idx > 127) return -1;
-    const uint32_t scalei = (uint32_t)c_tab.steptabi[idx];
     const uint32_t lnmax = mulr_u(xrmax, scalei);
     if (lnmax > 165140u) return 16384;
     if (lnmax < 10000u) {
@@ -98,8 +139,10 @@ __device__ __forceinline__ int rl_quantize(const RlTables &tb, const uint32_t (&
     bool big = false;
 #pragma unroll
     for (int e = 0; e < 2 * RL_NP; e++) {
-        const uint32_t ln = mulr_u(xa[e], scalei);
-        const double dbl = (double)xa[e] * scale * 4.656612875e-10;
+        uint32_t a = xa[e];
+        asm volatile("" : "+v"(a));        // (keeps the ten conversions to double out of the loop's live registers: this path is rare)
+        const uint32_t ln = mulr_u(a, scalei);
+        const double dbl = (double)a * scale * 4.656612875e-10;
         const int32_t v = (int32_t)__dsqrt_rn(__dsqrt_rn(dbl) * dbl);
         ix[e] = ln >= 10000u ? v : (int32_t)tb.int2idx[ln < 10000u ? ln : 9999u];
         big |= ix[e] > 8192;
@@ -109,25 +152,30 @@ __device__ __forceinline__ int rl_quantize(const RlTables &tb, const uint32_t (&
 
 // calc_run_len + count1_bit_count + __subdivide + __big_v_tab_select + big_v_bit_count
 // `limit`: the caller only wants to know whether the bit count reaches it (binary search: max_bits; inner loop:
-// max_bits + 1).  With `ub_ok` (binary-search probes whose result is not reused) an upper bound that stays below the
-// limit ends the evaluation the same way (another 16 % of the probes).  A lower bound -- exact count1 bits + per big-value pair the shortest code any candidate book has for
-// it plus its sign bits -- is one table field per pair and one wave reduction away; when it already reaches the limit
-// (80 % of the probes that do) the region maxima, candidate books and their bit sums are skipped and the bound is
-// returned.  Everything with a side effect the reference's body has (run lengths, count1 table, __subdivide and the
-// stale-address rule) happens before that point.
-__device__ __forceinline__ int rl_body(const RlTables &tb, uint8_t *pcode, const int32_t (&ix)[2 * RL_NP], int lane,
-                                       int sr, RlState &st, const uint8_t *__restrict__ hide, int n_hide, int cursor,
+// max_bits + 1).  A lower bound -- exact count1 bits + per big-value pair the shortest code any candidate book has for it
+// plus its sign bits -- and an upper bound (longest code, 13 linbits per escape) come out of one table word per pair and
+// ONE pair of wave reductions; when the lower bound reaches the limit (most probes that do), or -- with `ub_ok`, for
+// binary-search probes whose result is not reused -- the upper bound stays below it, the region maxima, candidate books
+// and their bit sums are skipped and the bound is returned.  Everything with a side effect the reference's body has (run
+// lengths, count1 table, __subdivide and the stale-address rule) happens before that point.
+__device__ __forceinline__ int rl_body(const RlTables &tb, const int32_t (&ix)[2 * RL_NP], int p0,
+                                       RlState &st, const uint8_t *__restrict__ hide, int n_hide, int cursor,
                                        int limit, bool ub_ok, bool &full)
 {
-    // ---- calc_run_len: highest non-zero pair P0, highest pair holding a value > 1 P1
-    int P0 = -1, P1 = -1;
+    // ---- calc_run_len: highest non-zero pair P0, highest pair holding a value > 1 P1.  Values are >= 0 here, so "some value
+    //      of the pair > 1" is (x | y) > 1.  Per lane the highest slot (+1), then the highest lane.
+    uint32_t o[RL_NP];
+    int k0 = 0, k1 = 0;
 #pragma unroll
-    for (int m = RL_NP - 1; m >= 0; m--) {
-        const unsigned long long nzm = __ballot((ix[2 * m] | ix[2 * m + 1]) != 0);
-        const unsigned long long bgm = __ballot(ix[2 * m] > 1 || ix[2 * m + 1] > 1);
-        if (P0 < 0 && nzm) P0 = 64 * m + 63 - __builtin_clzll(nzm);
-        if (P1 < 0 && bgm) P1 = 64 * m + 63 - __builtin_clzll(bgm);
+    for (int m = 0; m < RL_NP; m++) {
+        o[m] = (uint32_t)(ix[2 * m] | ix[2 * m + 1]);
+        k0 = o[m] != 0 ? m + 1 : k0;
+        k1 = o[m] > 1 ? m + 1 : k1;
     }
+    const unsigned long long nzm = __ballot(k0 != 0), bgm = __ballot(k1 != 0);
+    const int L0 = 63 - (nzm ? __builtin_clzll(nzm) : 0), L1 = 63 - (bgm ? __builtin_clzll(bgm) : 0);
+    const int r0 = __builtin_amdgcn_readlane(k0, L0), r1 = __builtin_amdgcn_readlane(k1, L1);
+    const int P0 = nzm ? 5 * L0 + r0 - 1 : -1, P1 = bgm ? 5 * L1 + r1 - 1 : -1;
     const int count1 = (P0 - P1) >> 1;
     const int bv = (P0 + 1) - 2 * count1;
     st.count1 = count1;
@@ -147,46 +195,36 @@ __device__ __forceinline__ int rl_body(const RlTables &tb, uint8_t *pcode, const
         st.addr_fresh = true;
     }
 
-    // ---- lower and upper bound of the big-value bits.  Lower: pairs below big_values at their shortest code.  Upper:
-    //      every pair the regions can reach -- with big_values == 0 the stale address2 still delimits regions 0 and 1
-    //      (E7) -- at its longest code with 13 linbits per escape.
-    uint32_t h[RL_NP];
-    uint32_t bnd = 0;
+    // ---- one pass over the lane's pairs: table word of the pair (lower / upper bound of the big-value bits: pairs below
+    //      big_values at their shortest code; every pair the regions can reach -- with big_values == 0 the stale address2
+    //      still delimits regions 0 and 1 (E7) -- at its longest code with 13 linbits per escape) and count1_bit_count:
+    //      quad k = pairs (bv+2k, bv+2k+1), p = v + 2w + 4x + 8y; the second pair of a quad is the lane's next slot, or
+    //      the first slot of the lane above
+    uint32_t h[RL_NP], c2[RL_NP + 1];
+    uint32_t bnd = 0, acc = 0;
     {
         const int reach = st.a2 > bvr ? st.a2 : bvr;
+#pragma unroll
+        for (int m = 0; m < RL_NP; m++) c2[m] = (uint32_t)((ix[2 * m] & 1) | ((ix[2 * m + 1] & 1) << 1));
+        c2[RL_NP] = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)c2[0], 0x130, 0xf, 0xf, false);   // wave_shl:1 = lane + 1's
+        const uint32_t c1n = (uint32_t)(2 * count1);
 #pragma unroll
         for (int m = 0; m < RL_NP; m++) {
             const int x = ix[2 * m], y = ix[2 * m + 1];
             const uint2 hh = tb.hl[(x > 14 ? 15 : x) * 16 + (y > 14 ? 15 : y)];
+            const uint32_t quad = tb.c1a[c2[m] | (c2[m + 1] << 2)];
             h[m] = hh.x;
-            bnd += (lane + 64 * m) < bv ? __builtin_amdgcn_ubfe(hh.x, 25, 5) : 0u;
-            bnd += 2 * (lane + 64 * m) < reach ? hh.y << 16 : 0u;
+            bnd += (p0 + m) < bv ? __builtin_amdgcn_ubfe(hh.x, 25, 5) : 0u;
+            bnd += 2 * (p0 + m) < reach ? hh.y << 16 : 0u;
+            const uint32_t rel = (uint32_t)(p0 + m - bv);
+            acc += rel < c1n ? ((uint32_t)__popc(c2[m]) << 16) + ((rel & 1u) ? 0u : quad) : 0u;
         }
-        bnd = wave_add_u32(bnd);
+        wave_add2(bnd, acc);
     }
-    full = false;
-    if ((int)(bnd & 0xffffu) >= limit) return (int)(bnd & 0xffffu);   // the big values alone are too many already
-
-    // ---- count1_bit_count: quad k = pairs (bv+2k, bv+2k+1), p = v + 2w + 4x + 8y
-#pragma unroll
-    for (int m = 0; m < RL_NP; m++) pcode[lane + 64 * m] = (uint8_t)((ix[2 * m] & 1) | ((ix[2 * m + 1] & 1) << 1));
-    __builtin_amdgcn_s_waitcnt(0xc07f);
-    __builtin_amdgcn_wave_barrier();
-    uint32_t acc = 0;
-#pragma unroll
-    for (int m = 0; m < RL_NP; m++) {
-        const int p = lane + 64 * m;
-        const int rel = p - bv;
-        const bool in_c1 = rel >= 0 && rel < 2 * count1;
-        const uint32_t c2 = (uint32_t)((ix[2 * m] & 1) | ((ix[2 * m + 1] & 1) << 1));
-        const uint32_t quad = tb.c1a[c2 | (((uint32_t)pcode[p + 1] & 3u) << 2)];   // evaluated by every lane, used by few
-        acc += in_c1 ? ((uint32_t)__popc(c2) << 16) + ((rel & 1) ? 0u : quad) : 0u;
-    }
-    acc = wave_add_u32(acc);
     const int signs = (int)(acc >> 16), sum0 = signs + (int)(acc & 0xffff), sum1 = signs + 4 * count1;
     int bits;
     if (sum0 < sum1) { st.c1sel = 0; bits = sum0; } else { st.c1sel = 1; bits = sum1; }   // ties -> table B (E10)
-
+    full = false;
     {
         const int lb = bits + (int)(bnd & 0xffffu), ub = bits + (int)(bnd >> 16);
         if (lb >= limit) return lb;
@@ -200,7 +238,7 @@ __device__ __forceinline__ int rl_body(const RlTables &tb, uint8_t *pcode, const
     int rid[RL_NP];
 #pragma unroll
     for (int m = 0; m < RL_NP; m++) {
-        const int s = 2 * (lane + 64 * m);
+        const int s = 2 * (p0 + m);
         const uint32_t pm = (uint32_t)max(ix[2 * m], ix[2 * m + 1]);
         const bool in0 = s < a1, in1 = !in0 && s < a2, in2 = !in0 && !in1 && s < bvr;
         mx0 = max(mx0, in0 ? pm : 0u);
@@ -208,35 +246,32 @@ __device__ __forceinline__ int rl_body(const RlTables &tb, uint8_t *pcode, const
         mx2 = max(mx2, in2 ? pm : 0u);
         rid[m] = in0 ? 0 : (in1 ? 1 : (in2 ? 2 : -1));
     }
-    const int rmax[3] = {(int)wave_max_u32(mx0), (int)wave_max_u32(mx1), (int)wave_max_u32(mx2)};
+    wave_max3(mx0, mx1, mx2);
+    const int rmax[3] = {(int)mx0, (int)mx1, (int)mx2};
 
     // ---- candidates per region (__new_choose_table)
     int tA[3], tB[3];
-#pragma unroll
-    for (int r = 0; r < 3; r++) {
-        const int mxr = rmax[r];
-        if (mxr == 0) { tA[r] = 0; tB[r] = 0; }
-        else if (mxr < 15) {
-            // reference :1190-1193 scans tables 13..0 for x_len > ix_max; table 13 (x_len 16) always hits first
-            tA[r] = 13; tB[r] = 15;
-        } else {
-            // first table of each family whose linmax = 2^linbits - 1 covers ix_max - 15 (:1237-1246);
-            // linbits are {1,2,3,4,6,8,10,13} for 16..23 and {4,5,6,7,8,9,11,13} for 24..31, table 15 has none
-            const int need = mxr - 15;
-            const int nb = need ? 32 - __builtin_clz((unsigned)need) : 0;   // bits of need
-            tA[r] = need == 0 ? 15 : 16 + (nb > 1) + (nb > 2) + (nb > 3) + (nb > 4) + (nb > 6) + (nb > 8) + (nb > 10);
-            tB[r] = 24 + (nb > 4) + (nb > 5) + (nb > 6) + (nb > 7) + (nb > 8) + (nb > 9) + (nb > 11);
-        }
-    }
     // both candidates of a pair come out of ONE table word; what differs per region is wave-uniform and travels in one
     // scalar: bit offset of candidate A's length | B's << 8 | A's linbits << 16 | B's << 20 (offset 25 = empty field)
     uint32_t Kr[3];
 #pragma unroll
-    for (int r = 0; r < 3; r++)
-        Kr[r] = tA[r] ? (uint32_t)(5 * family_of(tA[r])) | ((uint32_t)(5 * family_of(tB[r])) << 8) |
-                            ((uint32_t)lin_bits_of(tA[r]) << 16) | ((uint32_t)lin_bits_of(tB[r]) << 20)
-                      : (25u | (25u << 8));
-    uint32_t w[3] = {0, 0, 0};
+    for (int r = 0; r < 3; r++) {
+        const int mxr = rmax[r];
+        // mxr < 15: reference :1190-1193 scans tables 13..0 for x_len > ix_max; table 13 (x_len 16) always hits first
+        // else: first table of each family whose linmax = 2^linbits - 1 covers ix_max - 15 (:1237-1246);
+        // linbits are {1,2,3,4,6,8,10,13} for 16..23 and {4,5,6,7,8,9,11,13} for 24..31, table 15 has none
+        const int need = mxr - 15;
+        const int nb = need > 0 ? 32 - __builtin_clz((unsigned)need) : 0;   // bits of need
+        const int kA = (nb > 1) + (nb > 2) + (nb > 3) + (nb > 4) + (nb > 6) + (nb > 8) + (nb > 10);
+        const int kB = (nb > 4) + (nb > 5) + (nb > 6) + (nb > 7) + (nb > 8) + (nb > 9) + (nb > 11);
+        const bool none = mxr == 0, small = mxr < 15, esc0 = need == 0;
+        tA[r] = none ? 0 : (small ? 13 : (esc0 ? 15 : 16 + kA));
+        tB[r] = none ? 0 : (small ? 15 : 24 + kB);
+        const uint32_t lbA = (0xDA864321u >> (4 * kA)) & 15u, lbB = (0xDB987654u >> (4 * kB)) & 15u;
+        const uint32_t big = (esc0 ? 5u : (10u | (lbA << 16))) | (15u << 8) | (lbB << 20);
+        Kr[r] = none ? (25u | (25u << 8)) : (small ? (0u | (5u << 8)) : big);
+    }
+    uint32_t w0 = 0, w1 = 0, w2 = 0;
 #pragma unroll
     for (int m = 0; m < RL_NP; m++) {
         const int r = rid[m];
@@ -245,10 +280,12 @@ __device__ __forceinline__ int rl_body(const RlTables &tb, uint8_t *pcode, const
         const uint32_t a = __builtin_amdgcn_ubfe(h[m], kp & 31u, 5) + nz + __builtin_amdgcn_ubfe(kp, 16, 4) * esc;
         const uint32_t b = __builtin_amdgcn_ubfe(h[m], (kp >> 8) & 31u, 5) + nz + __builtin_amdgcn_ubfe(kp, 20, 4) * esc;
         const uint32_t v = a | (b << 16);
-        w[0] += r == 0 ? v : 0u;   // pairs past big_values (r < 0) match no region
-        w[1] += r == 1 ? v : 0u;
-        w[2] += r == 2 ? v : 0u;
+        w0 += r == 0 ? v : 0u;   // pairs past big_values (r < 0) match no region
+        w1 += r == 1 ? v : 0u;
+        w2 += r == 2 ? v : 0u;
     }
+    wave_add3(w0, w1, w2);
+    const uint32_t wsum[3] = {w0, w1, w2};
     int ts[3], rbits[3];
     bool redo[3];
     int idx = cursor;
@@ -256,7 +293,7 @@ __device__ __forceinline__ int rl_body(const RlTables &tb, uint8_t *pcode, const
     for (int r = 0; r < 3; r++) {
         ts[r] = 0; rbits[r] = 0; redo[r] = false;
         if (tA[r]) {                                   // uniform
-            const uint32_t s = wave_add_u32(w[r]);
+            const uint32_t s = wsum[r];
             const int bA = (int)(s & 0xffff), bB = (int)(s >> 16);
             int choice;
             if (tA[r] == 13) choice = (bB <= bA) ? 15 : 13;     // :1227-1231 ties -> 15
@@ -307,12 +344,17 @@ __global__ __launch_bounds__(RL_WAVES * 64, 4) void k_rate_loop(
     // compact == 2 (message variants: the list names a unit once per 3-bit pattern): ix / en go by list position too
     // results of unit u go to element u - out_base of the three output arrays (0 except for the message variants,
     // whose arrays hold one chunk of units)
-    __shared__ RlTables tb;
-    __shared__ __attribute__((aligned(16))) uint8_t pcode_all[RL_WAVES][64 * RL_NP + 4];
-    __shared__ int32_t esq_all[RL_WAVES][576];
+    __shared__ __attribute__((aligned(16))) RlTables tb;
+    __shared__ uint32_t pre_all[RL_WAVES][64];
+    __shared__ int32_t esq_all[RL_WAVES][580];
     const int sr0 = frames[0].sr_idx;             // one sample rate per launch (the host splits batches otherwise)
     const int sr_wg = sr0 >= 0 && sr0 < 3 ? sr0 : 0;
-    for (int i = threadIdx.x; i < 10000; i += blockDim.x) tb.int2idx[i] = c_tab.int2idx[i];
+    {
+        static_assert(sizeof(tb.int2idx) % 16 == 0 && sizeof(c_tab.int2idx) == sizeof(tb.int2idx), "int2idx is staged 16 bytes at a time");
+        const uint4 *src = reinterpret_cast<const uint4 *>(c_tab.int2idx);
+        uint4 *dst = reinterpret_cast<uint4 *>(tb.int2idx);
+        for (int i = threadIdx.x; i < (int)(sizeof(tb.int2idx) / 16); i += blockDim.x) dst[i] = src[i];
+    }
     for (int i = threadIdx.x; i < 256; i += blockDim.x) {
         const uint32_t x = (uint32_t)i >> 4, y = (uint32_t)i & 15u;
         tb.hl[i].x = (uint32_t)c_tab.hlen13[i] | ((uint32_t)c_tab.hlen15[i] << 5) | ((uint32_t)c_tab.hlen16[i] << 10) |
@@ -340,7 +382,7 @@ __global__ __launch_bounds__(RL_WAVES * 64, 4) void k_rate_loop(
     }
     const int u = __builtin_amdgcn_readfirstlane(unit_list ? unit_list[li] : li);
     if (u < 0 || u >= n_units) return;
-    uint8_t *pcode = pcode_all[wave];
+    uint32_t *pre = pre_all[wave];
     int32_t *esq = esq_all[wave];
     const mp3s_rate_frame fr = frames[u >> 2];
     const int sr = sr_wg;
@@ -348,6 +390,7 @@ __global__ __launch_bounds__(RL_WAVES * 64, 4) void k_rate_loop(
     const int ci = compact ? li : u;
     const int cursor = (n_hide > 0 && cursor_in) ? cursor_in[ci] : 0;
     n_hide = min(n_hide, fr.hide_end);            // streams of a batch keep their messages back to back in `hide`
+    const int p0 = 5 * lane;                      // the lane's first pair
 
     // ---- load xr, |xr|, xrsq >> 10 (:770-776, :837-838)
     const int32_t *xr = mdct + (long)u * 576;
@@ -355,7 +398,7 @@ __global__ __launch_bounds__(RL_WAVES * 64, 4) void k_rate_loop(
     uint32_t negmask = 0, lmax = 0, esum = 0;
 #pragma unroll
     for (int m = 0; m < RL_NP; m++) {
-        const int p = lane + 64 * m;
+        const int p = p0 + m;
         int2 v = make_int2(0, 0);
         if (p < 288) v = *reinterpret_cast<const int2 *>(xr + 2 * p);
         const int32_t vv[2] = {v.x, v.y};
@@ -371,40 +414,31 @@ __global__ __launch_bounds__(RL_WAVES * 64, 4) void k_rate_loop(
             esum += (uint32_t)e10;
         }
     }
-    const uint32_t xrmax = wave_max_u32(lmax);
-    const uint32_t etot = wave_add_u32(esum);
-
+    uint32_t xrmax = lmax, etot = 0;
     // ---- scalefactor-band energies for __calc_scfsi (:840-857); lane b < 21 sums band b, lane 21 = total
-    __builtin_amdgcn_s_waitcnt(0xc07f);
-    __builtin_amdgcn_wave_barrier();
     {
-        // Band sums through prefix sums: lane l adds up lines 9l .. 9l+8, a wave scan turns the 64 chunk sums into the
-        // sums of everything in front of each chunk, and a band lane completes its two bounds with at most 8 lines each
-        // (instead of walking bands of up to 76 lines with 21 of the 64 lanes).  Sums stay below 2^31 (576 x 2^21).
-        uint32_t chunk = 0;
-#pragma unroll
-        for (int k = 0; k < 9; k++) chunk += (uint32_t)esq[9 * lane + k];
-        uint32_t incl = chunk;
+        // Band sums through prefix sums: lane l holds the sum of lines 10l .. 10l+9 already; a wave scan turns the lane sums
+        // into the sums of everything in front of each lane, and a band lane completes its two bounds with at most 9 lines
+        // each.  Sums stay below 2^31 (576 x 2^21).
+        uint32_t incl = esum;
 #pragma unroll
         for (int d = 1; d < 64; d <<= 1) {
             const uint32_t o = (uint32_t)__shfl_up((int)incl, d, 64);
             if (lane >= d) incl += o;
         }
-        __builtin_amdgcn_wave_barrier();       // every lane has read its chunk: the first 64 words now hold the prefixes
-        const uint32_t excl = incl - chunk;
-        uint32_t *pre = reinterpret_cast<uint32_t *>(pcode);   // (the pair codes are written later, by rl_body)
-        pre[lane] = excl;
+        etot = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+        xrmax = wave_max_u32(lmax);
+        pre[lane] = incl - esum;
         __builtin_amdgcn_s_waitcnt(0xc07f);
         __builtin_amdgcn_wave_barrier();
         int32_t temp = 0;
         if (lane < 21) {
             const int b0 = c_tab.sfb_long[sr][lane], b1 = c_tab.sfb_long[sr][lane + 1];
-            const int q0 = (b0 * 7282) >> 16, q1 = (b1 * 7282) >> 16;        // x / 9 for x <= 576
-            uint32_t p0 = pre[q0], p1 = pre[q1 < 64 ? q1 : 63];
-            if (q1 >= 64) p1 += __builtin_amdgcn_readlane((int)chunk, 63);   // (a bound of 576: everything)
-            for (int i = 9 * q0; i < b0; i++) p0 += (uint32_t)esq[i];
-            for (int i = 9 * q1; i < b1; i++) p1 += (uint32_t)esq[i];
-            temp = (int32_t)(p1 - p0);
+            const int q0 = (b0 * 6554) >> 16, q1 = (b1 * 6554) >> 16;        // x / 10 for x <= 576
+            uint32_t s0 = pre[q0], s1 = pre[q1];                             // (q <= 57)
+            for (int i = 10 * q0; i < b0; i++) s0 += (uint32_t)esq[i];
+            for (int i = 10 * q1; i < b1; i++) s1 += (uint32_t)esq[i];
+            temp = (int32_t)(s1 - s0);
         } else if (lane == 21) temp = (int32_t)etot;
         __builtin_amdgcn_wave_barrier();
         // en = int32(log(temp * 4.768371584e-7) / 0.69314718): tabulated with the host's libm per octave of temp (value at
@@ -434,20 +468,24 @@ __global__ __launch_bounds__(RL_WAVES * 64, 4) void k_rate_loop(
             // ---- __bin_search_step_size (:958-996)
             int next = -120, count = 120;
             int body_step = 1 << 20, body_bits = 0;   // step whose quantisation + rl_body results are still in ix / st
+            uint32_t sc = rl_scale_of(next + count / 2);
+            asm volatile("s_mov_b32 %0, %0" : "+s"(sc));   // arrived before the loop: inside it no use of `sc` has to wait for the loads issued at its top
             do {
                 const int half = count / 2;
-                const int q = rl_quantize(tb, xa, ix, next + half, xrmax);
+                // the scales of the two steps the search may probe next, asked for now
+                const uint32_t sc_lo = rl_scale_of(next + half / 2), sc_hi = rl_scale_of(next + half + (count - half) / 2);
+                const int q = rl_quantize(tb, xa, ix, next + half, sc, xrmax);
                 int bit;
                 if (q < 0) { err = true; break; }
                 if (q > 8192) { bit = 100000; if (q != 16384) body_step = 1 << 20; }   // 16384 = early out, ix untouched
                 else {
                     bool full;
                     // the last probe (half == 1) is the one the inner loop may reuse: it is evaluated in full
-                    bit = rl_body(tb, pcode, ix, lane, sr, st, hide, n_hide, cursor, max_bits, half > 1, full);
+                    bit = rl_body(tb, ix, p0, st, hide, n_hide, cursor, max_bits, half > 1, full);
                     if (full) { body_step = next + half; body_bits = bit; } else body_step = 1 << 20;
                 }
-                if (bit < max_bits) count = half;
-                else { next += half; count -= half; }
+                if (bit < max_bits) { count = half; sc = sc_lo; }
+                else { next += half; count -= half; sc = sc_hi; }
             } while (count > 1);
             qstep = next;
             // ---- __inner_loop (:1064-1095), part2_length == 0
@@ -464,11 +502,11 @@ __global__ __launch_bounds__(RL_WAVES * 64, 4) void k_rate_loop(
                         continue;
                     }
                     int q;
-                    while ((q = rl_quantize(tb, xa, ix, qstep + 1, xrmax)) > 8192) qstep += 1;
+                    while ((q = rl_quantize(tb, xa, ix, qstep + 1, rl_scale_of(qstep + 1), xrmax)) > 8192) qstep += 1;
                     if (q < 0) { err = true; break; }
                     qstep += 1;
                     bool full;
-                    bits = rl_body(tb, pcode, ix, lane, sr, st, hide, n_hide, cursor, max_bits + 1, false, full);
+                    bits = rl_body(tb, ix, p0, st, hide, n_hide, cursor, max_bits + 1, false, full);
                 } while (bits > max_bits);
             }
             if (err) flags |= MP3S_RF_STEP_RANGE;
@@ -479,7 +517,7 @@ __global__ __launch_bounds__(RL_WAVES * 64, 4) void k_rate_loop(
         int16_t *ixo = ix_out + (long)(compact == 2 ? li : u - out_base) * 576;
 #pragma unroll
         for (int m = 0; m < RL_NP; m++) {
-            const int p = lane + 64 * m;
+            const int p = p0 + m;
             if (p < 288) {
                 int a = xrmax ? ix[2 * m] : 0, b = xrmax ? ix[2 * m + 1] : 0;
                 if ((negmask >> (2 * m)) & 1) a = -a;

@@ -51,7 +51,7 @@ struct DevTables {
     int32_t mdct_cs[8], mdct_ca[8];
     double steptab[128];
     int32_t steptabi[128];
-    uint16_t int2idx[10000];       // values <= 1000
+    alignas(16) uint16_t int2idx[10000];   // values <= 1000 (k_rate_loop stages it 16 bytes at a time)
     int32_t sfb_long[3][23];
     // int32(log(e * 4.768371584e-7) / 0.69314718) of MP3_Encoder.py:841,855 as a step function of the integer e, tabulated
     // per octave with the host's libm: value at e = 2^k, and the e inside [2^k, 2^(k+1)) from which on it is one more
