@@ -81,8 +81,9 @@ struct RlTables {
     uint2 hl[256];          // .x per pair (min(x,15), min(y,15)): code length in books 13 | 15 << 5 | 16.. << 10 | 24.. << 15,
                             // | number of non-zero values << 20 | number of values > 14 << 22
                             // | (shortest of the four lengths + non-zero values, 0 for the pair (0,0)) << 25
-                            // .y longest of the four lengths + non-zero values + 13 bits per value > 14
-    uint8_t c1a[16];
+                            // .y bounds of the pair's bits under any candidate book: the shortest field once more
+                            // | (longest of the four lengths + non-zero values + 13 bits per value > 14) << 16
+    uint32_t c1w[16];       // count1 book A: code length of the quad | number of ones in its first pair << 16
     uint8_t transform[64];  // [table][bit]
     uint32_t subdiv[289];   // __subdivide result per big_values for this workgroup's sample rate (see DevTables)
 };
@@ -204,20 +205,23 @@ __device__ __forceinline__ int rl_body(const RlTables &tb, const int32_t (&ix)[2
     uint32_t bnd = 0, acc = 0;
     {
         const int reach = st.a2 > bvr ? st.a2 : bvr;
+        // inside the count1 region every value is 0 or 1, so x + 2y is the pair's code there; elsewhere the sum is only
+        // kept inside the table (& 15) and its result dropped
 #pragma unroll
-        for (int m = 0; m < RL_NP; m++) c2[m] = (uint32_t)((ix[2 * m] & 1) | ((ix[2 * m + 1] & 1) << 1));
+        for (int m = 0; m < RL_NP; m++) c2[m] = (uint32_t)(ix[2 * m] + 2 * ix[2 * m + 1]);
         c2[RL_NP] = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)c2[0], 0x130, 0xf, 0xf, false);   // wave_shl:1 = lane + 1's
         const uint32_t c1n = (uint32_t)(2 * count1);
+        const uint32_t rel0 = (uint32_t)(p0 - bv);
+        // a pair at an even distance from big_values starts a quad (code length + its ones), the others add their ones only
+        const uint32_t keep_even = (rel0 & 1u) ? 0xffff0000u : 0xffffffffu, keep_odd = (rel0 & 1u) ? 0xffffffffu : 0xffff0000u;
 #pragma unroll
         for (int m = 0; m < RL_NP; m++) {
             const int x = ix[2 * m], y = ix[2 * m + 1];
             const uint2 hh = tb.hl[(x > 14 ? 15 : x) * 16 + (y > 14 ? 15 : y)];
-            const uint32_t quad = tb.c1a[c2[m] | (c2[m + 1] << 2)];
+            const uint32_t quad = tb.c1w[(c2[m] | (c2[m + 1] << 2)) & 15u];
             h[m] = hh.x;
-            bnd += (p0 + m) < bv ? __builtin_amdgcn_ubfe(hh.x, 25, 5) : 0u;
-            bnd += 2 * (p0 + m) < reach ? hh.y << 16 : 0u;
-            const uint32_t rel = (uint32_t)(p0 + m - bv);
-            acc += rel < c1n ? ((uint32_t)__popc(c2[m]) << 16) + ((rel & 1u) ? 0u : quad) : 0u;
+            bnd += (p0 + m) < bv ? hh.y : (2 * (p0 + m) < reach ? hh.y & 0xffff0000u : 0u);
+            acc += rel0 + (uint32_t)m < c1n ? quad & ((m & 1) ? keep_odd : keep_even) : 0u;
         }
         wave_add2(bnd, acc);
     }
@@ -262,8 +266,10 @@ __device__ __forceinline__ int rl_body(const RlTables &tb, const int32_t (&ix)[2
         // linbits are {1,2,3,4,6,8,10,13} for 16..23 and {4,5,6,7,8,9,11,13} for 24..31, table 15 has none
         const int need = mxr - 15;
         const int nb = need > 0 ? 32 - __builtin_clz((unsigned)need) : 0;   // bits of need
-        const int kA = (nb > 1) + (nb > 2) + (nb > 3) + (nb > 4) + (nb > 6) + (nb > 8) + (nb > 10);
-        const int kB = (nb > 4) + (nb > 5) + (nb > 6) + (nb > 7) + (nb > 8) + (nb > 9) + (nb > 11);
+        // (nb > 1) + (nb > 2) + (nb > 3) + (nb > 4) + (nb > 6) + (nb > 8) + (nb > 10) and (nb > 4) + ... + (nb > 9) + (nb > 11)
+        // as nibbles of two constants (nb <= 13): one scalar shift each
+        const int kA = (int)((0x77766554432100ull >> (4 * nb)) & 15ull);
+        const int kB = (int)((0x77665432100000ull >> (4 * nb)) & 15ull);
         const bool none = mxr == 0, small = mxr < 15, esc0 = need == 0;
         tA[r] = none ? 0 : (small ? 13 : (esc0 ? 15 : 16 + kA));
         tB[r] = none ? 0 : (small ? 15 : 24 + kB);
@@ -362,9 +368,9 @@ __global__ __launch_bounds__(RL_WAVES * 64, 4) void k_rate_loop(
         const uint32_t shortest = min(min((uint32_t)c_tab.hlen13[i], (uint32_t)c_tab.hlen15[i]), min((uint32_t)c_tab.hlen16[i], (uint32_t)c_tab.hlen24[i]));
         if (i) tb.hl[i].x |= (shortest + (x != 0) + (y != 0)) << 25;
         const uint32_t longest = max(max((uint32_t)c_tab.hlen13[i], (uint32_t)c_tab.hlen15[i]), max((uint32_t)c_tab.hlen16[i], (uint32_t)c_tab.hlen24[i]));
-        tb.hl[i].y = longest + (x != 0) + (y != 0) + 13u * ((x == 15) + (y == 15));
+        tb.hl[i].y = (i ? shortest + (x != 0) + (y != 0) : 0u) | ((longest + (x != 0) + (y != 0) + 13u * ((x == 15) + (y == 15))) << 16);
     }
-    if (threadIdx.x < 16) tb.c1a[threadIdx.x] = c_tab.hlen_c1a[threadIdx.x];
+    if (threadIdx.x < 16) tb.c1w[threadIdx.x] = (uint32_t)c_tab.hlen_c1a[threadIdx.x] | ((uint32_t)__popc(threadIdx.x & 3u) << 16);
     if (threadIdx.x < 64) tb.transform[threadIdx.x] = c_tab.transform[threadIdx.x >> 1][threadIdx.x & 1];
     for (int i = threadIdx.x; i < 289; i += blockDim.x) tb.subdiv[i] = c_tab.subdiv_lut[sr_wg][i];
     __syncthreads();
