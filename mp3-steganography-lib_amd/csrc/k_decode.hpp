@@ -461,8 +461,8 @@ __device__ __forceinline__ double synth_dot(const double (&d)[N], const SynthRow
     constexpr int V = N >= 8 ? 8 : N;
     double a = 0.0;
 #pragma unroll
-    for (int j = 0; j < N; j++) a += d[j] * r.c[j / V][j % V];
-    return a;
+    for (int j = 0; j < N; j++) a = __builtin_fma(d[j], r.c[j / V][j % V], a);   // fused: one rounding per term instead of two
+    return a;                                                                      // (the guard's bound covers either; half the instructions)
 }
 
 template <int TW>
@@ -542,13 +542,13 @@ __global__ __launch_bounds__(TW * 64 * 2, TW == 4 ? 2 : 4) void k_dec_synth_fast
         double sum = 0.0;
         if (full_hist) {
 #pragma unroll
-            for (int jj = 0; jj < 16; jj++) sum += ex[p][ch][2 * s + (jj & 1)][tl - jj] * w.c[jj >> 3][jj & 7];
+            for (int jj = 0; jj < 16; jj++) sum = __builtin_fma(ex[p][ch][2 * s + (jj & 1)][tl - jj], w.c[jj >> 3][jj & 7], sum);
         } else {
 #pragma unroll
             for (int jj = 0; jj < 16; jj++) {
                 double u = ex[p][ch][2 * s + (jj & 1)][tl - jj];
                 if (jj > lim) u = 0.0;
-                sum += u * w.c[jj >> 3][jj & 7];
+                sum = __builtin_fma(u, w.c[jj >> 3][jj & 7], sum);
             }
         }
         if (emit) {
