@@ -37,7 +37,6 @@ __global__ __launch_bounds__(256) void k_enc_pack(
     __shared__ uint32_t fb3[3][PACK_DW];   // frame images, rotating: written / being copied out / being cleared
     __shared__ uint32_t hc[4][256];
     __shared__ uint8_t hl[4][256];
-    __shared__ uint8_t pc[4][324];
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
     for (int i = threadIdx.x; i < 1024; i += 256) {
         (&hc[0][0])[i] = (&c_tab.hcod[0][0])[i];
@@ -141,14 +140,12 @@ __global__ __launch_bounds__(256) void k_enc_pack(
             xv[2 * k] = (int)(int16_t)(w & 0xffff); xv[2 * k + 1] = (int)(int16_t)(w >> 16);
         }
     }
-    uint8_t *pcw = pc[wave];
+    // the low bits of the lane's pairs and of the pair behind them (the first pair of the lane above): a count1 quadruple
+    // is this pair + the next one
+    uint32_t c2[6];
 #pragma unroll
-    for (int k = 0; k < 5; k++) {
-        const int a = xv[2 * k] < 0 ? -xv[2 * k] : xv[2 * k], b = xv[2 * k + 1] < 0 ? -xv[2 * k + 1] : xv[2 * k + 1];
-        pcw[lane * 5 + k] = (uint8_t)((a & 1) | ((b & 1) << 1));
-    }
-    __builtin_amdgcn_s_waitcnt(0xc07f);
-    __builtin_amdgcn_wave_barrier();
+    for (int k = 0; k < 5; k++) c2[k] = (uint32_t)((xv[2 * k] & 1) | ((xv[2 * k + 1] & 1) << 1));   // (two's complement: the low bit of |v| is the low bit of v)
+    c2[5] = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)c2[0], 0x130, 0xf, 0xf, false);              // wave_shl:1
     uint32_t code0[5], code1[5]; int n0[5], n1[5];
     int tot = 0, bad = 0;
 #pragma unroll
@@ -185,7 +182,7 @@ __global__ __launch_bounds__(256) void k_enc_pack(
         } else if (p < bv + 2 * c1) {
             // count1 quadruple = this pair (v, w) + the next one (x, y); code word with the first pair (E13)
             if (!((p - bv) & 1)) {
-                const int q = (x & 1) | ((y & 1) << 1) | (((int)pcw[p + 1] & 3) << 2);
+                const int q = (int)(c2[k] | (c2[k + 1] << 2));
                 if (c1sel) { code0[k] = 15 - q; n0[k] = 4; }
                 else { code0[k] = c_tab.hcod_c1a[q]; n0[k] = c_tab.hlen_c1a[q]; }
             }
@@ -204,11 +201,22 @@ __global__ __launch_bounds__(256) void k_enc_pack(
         if (lane >= d) incl += o;
     }
     const int huff_bits = __shfl(incl, 63, 64);
-    uint32_t pos = ustart + (uint32_t)(incl - tot);
+    // The lane's code words are consecutive in the stream: they are gathered in a 64-bit register (in front of them as many
+    // zero bits as the lane's start lies behind a dword boundary) and leave as whole dwords of the frame image -- two or
+    // three LDS atomics per lane instead of one or two per code word.  A word has at most 28 bits and fewer than 32 are
+    // pending in front of it, so one flush per word suffices.
+    {
+        const uint32_t pos0 = ustart + (uint32_t)(incl - tot);
+        uint32_t d = pos0 >> 5;
+        int cnt = (int)(pos0 & 31u);
+        uint64_t acc = 0;
+        auto append = [&](uint32_t v, int n) {
+            acc = (acc << n) | v; cnt += n;
+            if (cnt >= 32) { atomicOr(&fb[d], (uint32_t)(acc >> (cnt - 32))); d++; cnt -= 32; }
+        };
 #pragma unroll
-    for (int k = 0; k < 5; k++) {
-        lds_put(fb, pos, code0[k], n0[k]); pos += n0[k];
-        lds_put(fb, pos, code1[k], n1[k]); pos += n1[k];
+        for (int k = 0; k < 5; k++) { append(code0[k], n0[k]); append(code1[k], n1[k]); }
+        if (cnt > 0) atomicOr(&fb[d], (uint32_t)(acc << (32 - cnt)));
     }
     // stuffing with ones up to part2_3_length (:1433-1446)
     const int p23 = e == 0 ? p23v[0] : (e == 1 ? p23v[1] : (e == 2 ? p23v[2] : p23v[3]));
