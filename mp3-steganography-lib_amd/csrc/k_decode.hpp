@@ -165,19 +165,39 @@ __device__ __forceinline__ void dec_prepare(const DevTables &tab, DecShared &sh,
     __builtin_amdgcn_s_waitcnt(0xc07f);
 }
 
-__global__ __launch_bounds__(DEC_A_WAVES * 64, 3) void k_dec_imdct(
-    const int16_t *__restrict__ is, const mp3s_granule_si *__restrict__ si, const mp3s_frame_hdr *__restrict__ hdr,
-    int n_granules, int nch, int run, double *__restrict__ S, long T, int sf_base)
+// twiddle row i + the window factors of rows i and im (the row that mirrors it) for each channel half
+struct Row18m { dvec8 a, b; dvec2 c; double w0, w1, w0m, w1m; };
+__device__ __forceinline__ Row18m load_row18m(const double (*C36)[18], const double *win0, const double *win1, int i, int im)
 {
-    __shared__ DecShared sh;
-    for (int i = threadIdx.x; i < POW2Q_N; i += blockDim.x) sh.pow2q[i] = c_tab.pow2q[i];
-    if (threadIdx.x < POW2H_N) sh.pow2h[threadIdx.x] = c_tab.pow2h[threadIdx.x];
-    __syncthreads();
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
-    const int g0 = (xcd_tile() * DEC_A_WAVES + wave) * run;
-    if (g0 >= n_granules) return;  // whole wave exits together
+    Row18m r;
+    const double *p = C36[i];
+    r.a = *reinterpret_cast<const dvec8 *>(p);
+    r.b = *reinterpret_cast<const dvec8 *>(p + 8);
+    r.c = *reinterpret_cast<const dvec2 *>(p + 16);
+    r.w0 = win0[i]; r.w1 = win1[i]; r.w0m = win0[im]; r.w1m = win1[im];
+    return r;
+}
+
+// One wave walks granules g0 .. g0 + run - 1 (lane = channel, subband), primed with the second half of granule g0 - 1.
+// Rows go to S + ((ch * T) + g * 18 + i - slot0) * 32 (slot0 = 0 for the batch's scratch; the fix-up kernel writes a
+// private window of slots).
+//
+// FAST (int16 output only, see k_dec_synth_fast): the 36 outputs of a long-block IMDCT are 18 sums and their mirror
+// images -- x[17-i] = -x[i], x[53-i] = x[i] -- and the sums are fused multiply-adds: 324 instead of 1296 instructions per
+// subband.  The result is NOT the reference's bit pattern: it differs from it by at most kappa * (B + B') with B, B' the
+// sums of |input| of this subband in this and the previous granule (DevTables::imdct_kappa, derivation in
+// mp3s_tables.cpp); the wave leaves G = sum of B over the subbands of each channel behind, the synthesis guard adds
+// kappa-scaled G to its bound, and a sample the guard cannot vouch for is recomputed from `is` in the reference's order
+// (k_dec_fixup, which runs this function with FAST = false).  Short blocks keep the reference's order in both modes.
+template <bool FAST>
+__device__ __forceinline__ void imdct_run(DecShared &sh, int wave, int lane, const int16_t *__restrict__ is,
+                                          const mp3s_granule_si *__restrict__ si, const mp3s_frame_hdr *__restrict__ hdr,
+                                          int n_granules, int nch, int g0, int run, double *S, long T, long slot0,
+                                          int sf_base, double *__restrict__ G, int only_ch = -1)
+{
     const int ch = lane >> 5, sb = lane & 31;
     const bool live = ch < nch;
+    const bool wr = live && (only_ch < 0 || ch == only_ch);   // (the fix-up kernel keeps one channel's rows)
     const bool neg_odd = (sb & 1) != 0;
     double tail[18];
 #pragma unroll
@@ -207,13 +227,55 @@ __global__ __launch_bounds__(DEC_A_WAVES * 64, 3) void k_dec_imdct(
         double v[18];
         int bt;
         dec_prepare(tab, sh, wave, v, is, si, g, sr, fh.ms_stereo != 0, nch, lane, bt);
+        if (FAST && gi >= 0 && G) {
+            // G[g][ch] = sum over the channel's 32 subbands of sum_k |v[k]| (what the guard of the synthesis scales kappa with)
+            double b = 0.0;
+#pragma unroll
+            for (int k = 0; k < 18; k++) b += fabs(v[k]);
+#pragma unroll
+            for (int d = 16; d >= 1; d >>= 1) b += shfl_xor_f64(b, d);
+            if (sb == 0 && live) G[(long)g * 2 + ch] = b;
+        }
         // window rows of the two channel halves as scalar pointers; lanes pick theirs with a select
         const int bt0 = __builtin_amdgcn_readlane(bt, 0), bt1 = __builtin_amdgcn_readlane(bt, 32);
         const double *win0 = tab.sine_block[bt0], *win1 = tab.sine_block[bt1];
 
         // ---- IMDCT + window (Frame.py:124-148), overlap (:151-153), frequency inversion (:629-631) in the sign
-        double *row = S + ((long)(live ? ch : 0) * T + (long)g * 18) * 32 + sb;
+        double *row = S + ((long)(live ? ch : 0) * T + ((long)g * 18 - slot0)) * 32 + sb;
         if (bt != 2) {
+            if (FAST) {
+                // rows 0..8 and their mirrors 17..9, then rows 18..26 and their mirrors 35..27
+                Row18m cur = gi >= 0 ? load_row18m(C36, win0, win1, 0, 17) : load_row18m(C36, win0, win1, 18, 35);
+                if (gi >= 0) {
+#pragma unroll
+                    for (int i = 0; i < 9; i++) {
+                        const Row18m nxt = i < 8 ? load_row18m(C36, win0, win1, i + 1, 16 - i) : load_row18m(C36, win0, win1, 18, 35);
+                        __builtin_amdgcn_sched_barrier(0);
+                        double y = 0.0;
+#pragma unroll
+                        for (int k = 0; k < 18; k++) y = __builtin_fma(v[k], k < 8 ? cur.a[k & 7] : (k < 16 ? cur.b[k & 7] : cur.c[k & 1]), y);
+                        double xa = y * (ch == 0 ? cur.w0 : cur.w1) + tail[i];
+                        double xb = -y * (ch == 0 ? cur.w0m : cur.w1m) + tail[17 - i];
+                        if (neg_odd && (i & 1)) xa = -xa;
+                        if (neg_odd && ((17 - i) & 1)) xb = -xb;
+                        if (wr) { row[(long)i * 32] = xa; row[(long)(17 - i) * 32] = xb; }
+                        __builtin_amdgcn_sched_barrier(0);
+                        cur = nxt;
+                    }
+                }
+#pragma unroll
+                for (int i = 18; i < 27; i++) {
+                    const Row18m nxt = load_row18m(C36, win0, win1, i < 26 ? i + 1 : 26, i < 26 ? 52 - i : 27);
+                    __builtin_amdgcn_sched_barrier(0);
+                    double y = 0.0;
+#pragma unroll
+                    for (int k = 0; k < 18; k++) y = __builtin_fma(v[k], k < 8 ? cur.a[k & 7] : (k < 16 ? cur.b[k & 7] : cur.c[k & 1]), y);
+                    tail[i - 18] = y * (ch == 0 ? cur.w0 : cur.w1);
+                    tail[35 - i] = y * (ch == 0 ? cur.w0m : cur.w1m);
+                    __builtin_amdgcn_sched_barrier(0);
+                    cur = nxt;
+                }
+            } else {
             // One row of twiddles (18 doubles) + its two window factors per scalar batch.  Scalar loads can only be
             // waited for all at once, so the row after the one being multiplied is requested first: its latency
             // passes under 18 multiply-adds per lane.
@@ -228,7 +290,7 @@ __global__ __launch_bounds__(DEC_A_WAVES * 64, 3) void k_dec_imdct(
                     for (int k = 0; k < 18; k++) x += v[k] * (k < 8 ? cur.a[k & 7] : (k < 16 ? cur.b[k & 7] : cur.c[k & 1]));
                     x = x * (ch == 0 ? cur.w0 : cur.w1) + tail[i];
                     if (neg_odd && (i & 1)) x = -x;
-                    if (live) row[(long)i * 32] = x;
+                    if (wr) row[(long)i * 32] = x;
                     __builtin_amdgcn_sched_barrier(0);
                     cur = nxt;
                 }
@@ -243,6 +305,7 @@ __global__ __launch_bounds__(DEC_A_WAVES * 64, 3) void k_dec_imdct(
                 tail[i - 18] = x * (ch == 0 ? cur.w0 : cur.w1);
                 __builtin_amdgcn_sched_barrier(0);
                 cur = nxt;
+            }
             }
         } else {
             // three 12-point windows placed at 6/12/18 (Frame.py:135-148); computed one window at a time
@@ -268,7 +331,7 @@ __global__ __launch_bounds__(DEC_A_WAVES * 64, 3) void k_dec_imdct(
                     const double blk = i < 6 ? 0.0 : (i < 12 ? w0[i - 6] : w0[i - 6] + w1[i - 12]);
                     double x = blk + tail[i];
                     if (neg_odd && (i & 1)) x = -x;
-                    if (live) row[(long)i * 32] = x;
+                    if (wr) row[(long)i * 32] = x;
                 }
             }
 #pragma unroll
@@ -284,6 +347,21 @@ __global__ __launch_bounds__(DEC_A_WAVES * 64, 3) void k_dec_imdct(
             for (int i = 12; i < 18; i++) tail[i] = 0.0;   // sample_block[30..35]
         }
     }
+}
+
+template <bool FAST>
+__global__ __launch_bounds__(DEC_A_WAVES * 64, 3) void k_dec_imdct(
+    const int16_t *__restrict__ is, const mp3s_granule_si *__restrict__ si, const mp3s_frame_hdr *__restrict__ hdr,
+    int n_granules, int nch, int run, double *__restrict__ S, long T, int sf_base, double *__restrict__ G)
+{
+    __shared__ DecShared sh;
+    for (int i = threadIdx.x; i < POW2Q_N; i += blockDim.x) sh.pow2q[i] = c_tab.pow2q[i];
+    if (threadIdx.x < POW2H_N) sh.pow2h[threadIdx.x] = c_tab.pow2h[threadIdx.x];
+    __syncthreads();
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+    const int g0 = (xcd_tile() * DEC_A_WAVES + wave) * run;
+    if (g0 >= n_granules) return;  // whole wave exits together
+    imdct_run<FAST>(sh, wave, lane, is, si, hdr, n_granules, nch, g0, run, S, T, 0, sf_base, G);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -423,7 +501,7 @@ __global__ __launch_bounds__(TW * 64 * 2, 5) void k_dec_synth(
 // derivation in mp3s_tables.cpp and DESIGN.md) is computed again in the reference's order from the subband samples in S.
 // About one sample in 3e7 takes that path.  eps_scale (tests): inflates the guard so that the exact path is exercised.
 // ---------------------------------------------------------------------------------------------
-__device__ __noinline__ double synth_exact_sample(const double *__restrict__ S, long T, int ch, long t, int i, int lim)
+__device__ __noinline__ double synth_exact_sample(const double *S, long T, int ch, long t, int i, int lim)
 {
     // Frame.py:84-101 for one output sample: 16 taps, each a 32-term matrixing sum of an earlier slot
     double sum = 0.0;
@@ -468,16 +546,31 @@ __device__ __forceinline__ double synth_dot(const double (&d)[N], const SynthRow
 template <int TW>
 __global__ __launch_bounds__(TW * 64 * 2, TW == 4 ? 2 : 4) void k_dec_synth_fast(
     const double *__restrict__ S, long T, const mp3s_frame_hdr *__restrict__ hdr, int nch, int n_halo,
-    int16_t *__restrict__ pcm_out, int sf_base, double eps_scale, int32_t *__restrict__ n_exact)
+    int16_t *__restrict__ pcm_out, int sf_base, double eps_scale, const double *__restrict__ G, int n_granules,
+    uint2 *__restrict__ fix_list, int32_t *__restrict__ fix_count)
 {
     constexpr int TL_LANES = TW * 64, OUT = TL_LANES - 15;
     constexpr int OROW = 33;
     __shared__ double ex[2][2][4][TL_LANES];
     __shared__ uint32_t otile[OUT * OROW];
     __shared__ double amax_w[TW * 2];
+    __shared__ double gmax_s;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
     const int ch = wave / TW, tl = (wave % TW) * 64 + lane;
     const long tile0 = (long)xcd_tile() * OUT;
+    if (wave == 0) {
+        // the largest G (sum of |IMDCT input| of a granule and channel, left behind by the fast IMDCT) among the granules
+        // whose rows this tile reads and the granule in front of them (its overlap tail is part of their rows)
+        const long tlo = tile0 - 15 > 0 ? tile0 - 15 : 0, thi = tile0 + OUT - 1 < T - 1 ? tile0 + OUT - 1 : T - 1;
+        const int ga = (int)(tlo / 18) > 0 ? (int)(tlo / 18) - 1 : 0, gb = (int)(thi / 18);
+        static_assert((TW * 64 + 17) / 18 + 2 <= 32, "one lane pair per granule of the tile");
+        const int g = ga + (lane >> 1), c = lane & 1;
+        double gm = 0.0;
+        if (G && g <= gb && g < n_granules && c < nch) gm = G[(long)g * 2 + c];
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) { const double o = shfl_xor_f64(gm, d); gm = gm > o ? gm : o; }
+        if (lane == 0) gmax_s = gm;
+    }
     const long t = tile0 - 15 + tl;
     const bool valid = t >= 0 && t < T;
     int lim = -1;
@@ -524,7 +617,7 @@ __global__ __launch_bounds__(TW * 64 * 2, TW == 4 ? 2 : 4) void k_dec_synth_fast
     double amax = amax_w[0];
 #pragma unroll
     for (int w = 1; w < TW * 2; w++) if (w < TW * nch) amax = amax > amax_w[w] ? amax : amax_w[w];
-    const double eps_a = c_tab.synth_eps_a * amax * eps_scale, eps_x = c_tab.synth_eps_x * eps_scale;
+    const double eps_a = (c_tab.synth_eps_a * amax + c_tab.synth_eps_g * gmax_s) * eps_scale, eps_x = c_tab.synth_eps_x * eps_scale;
     const long halo_slots = (long)n_halo * 36;
     const bool emit = valid && tl >= 15 && t >= halo_slots;
     const bool full_hist = __ballot(tl >= 15 && lim < 15) == 0;
@@ -639,16 +732,11 @@ __global__ __launch_bounds__(TW * 64 * 2, TW == 4 ? 2 : 4) void k_dec_synth_fast
             p ^= 1;
         }
     }
-    // ---- the samples the guard could not vouch for, in the reference's order (outside the loop above: a call inside it
-    //      would make the compiler save its scalar operands around every call site)
+    // ---- the samples the guard could not vouch for go on the fix-up list: slot | channel << 31, mask of output indices
+    //      (k_dec_fixup recomputes them from `is` in the reference's order and overwrites what is stored below)
     if (redo) {
-        int n_redo = 0;
-        for (int i = 0; i < 32; i++)
-            if ((redo >> i) & 1u) {
-                ot16[(tl - 15) * OROW * 2 + i * nch + ch] = (uint16_t)pcm_to_i16(synth_exact_sample(S, T, ch, t, i, lim));
-                n_redo++;
-            }
-        if (n_exact) atomicAdd(n_exact, n_redo);
+        const int at = atomicAdd(fix_count, 1);
+        fix_list[at] = make_uint2((uint32_t)t | ((uint32_t)ch << 31), redo);
     }
     __syncthreads();
     const int dw_per_slot = 16 * nch;
@@ -659,6 +747,70 @@ __global__ __launch_bounds__(TW * 64 * 2, TW == 4 ? 2 : 4) void k_dec_synth_fast
         const long slot = tile0 + sl;
         if (slot < halo_slots || slot >= T) continue;
         outp[(slot - halo_slots) * dw_per_slot + w] = otile[sl * OROW + w];
+    }
+}
+
+
+// ---------------------------------------------------------------------------------------------
+// Fix-up of the fast int16 path.  Entry = a time slot of one channel + the mask of its output samples whose truncation
+// the guard of k_dec_synth_fast could not vouch for.  One wave per entry: the rows of the 16 slots the samples read are
+// computed again from `is` in the reference's order (imdct_run<false>, one or two granules primed with the granule in
+// front of them) into a window in LDS, then lane j computes the j-th flagged sample exactly as k_dec_synth would and
+// overwrites it in the PCM.  About one sample in a million comes here; with the guard inflated (tests) all of them do.
+// counters: [0] entries (written by k_dec_synth_fast), [1] workgroups through; the last one clears both.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(DEC_A_WAVES * 64, 2) void k_dec_fixup(
+    const int16_t *__restrict__ is, const mp3s_granule_si *__restrict__ si, const mp3s_frame_hdr *__restrict__ hdr,
+    int n_granules, int nch, long T, int n_halo, int sf_base, int16_t *__restrict__ pcm_out,
+    const uint2 *__restrict__ fix_list, int32_t *counters, int32_t *__restrict__ n_exact)
+{
+    __shared__ DecShared sh;
+    __shared__ double win[DEC_A_WAVES][36 * 32];
+    for (int i = threadIdx.x; i < POW2Q_N; i += blockDim.x) sh.pow2q[i] = c_tab.pow2q[i];
+    if (threadIdx.x < POW2H_N) sh.pow2h[threadIdx.x] = c_tab.pow2h[threadIdx.x];
+    __syncthreads();
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+    const int n = __builtin_amdgcn_readfirstlane(__hip_atomic_load(&counters[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+    const long halo_slots = (long)n_halo * 36;
+    double *Sp = win[wave];
+    for (int e = blockIdx.x * DEC_A_WAVES + wave; e < n; e += gridDim.x * DEC_A_WAVES) {
+        const uint2 en = fix_list[e];
+        const long t = (long)(en.x & 0x7fffffffu);
+        const int ch = (int)(en.x >> 31);
+        const uint32_t mask = en.y;
+        if (t >= T || ch >= nch) continue;                                  // (never: the list is the synthesis kernel's)
+        const uint32_t sf = hdr[t / 36].stream_first;
+        const long s0 = sf > (uint32_t)sf_base ? (long)(sf - (uint32_t)sf_base) * 36 : 0;
+        const int lim = (int)((t - s0) < 64 ? (t - s0) : 64);
+        const long tlo = t - 15 > s0 ? t - 15 : s0;
+        const int ga = (int)(tlo / 18), gb = (int)(t / 18);
+        __builtin_amdgcn_wave_barrier();
+        imdct_run<false>(sh, wave, lane, is, si, hdr, n_granules, nch, ga, gb - ga + 1, Sp, 0, (long)ga * 18, sf_base, nullptr, ch);
+        __builtin_amdgcn_s_waitcnt(0);                                      // the wave's rows are in LDS
+        __builtin_amdgcn_wave_barrier();
+        // lane j takes the j-th flagged sample
+        int i = -1;
+        {
+            uint32_t m = mask;
+            for (int j = 0; j < 32; j++) {
+                if (!m) break;
+                const int b = __builtin_ctz(m);
+                if (j == lane) i = b;
+                m &= m - 1;
+            }
+        }
+        if (i >= 0 && t >= halo_slots) {
+            const double v = synth_exact_sample(Sp, 0, 0, t - (long)ga * 18, i, lim);
+            pcm_out[((t - halo_slots) * 32 + i) * nch + ch] = pcm_to_i16(v);
+        }
+        if (lane == 0 && n_exact) atomicAdd(n_exact, __popc(mask));
+        __builtin_amdgcn_s_waitcnt(0);
+        __builtin_amdgcn_wave_barrier();
+    }
+    __syncthreads();
+    if (threadIdx.x == 0 && atomicAdd(&counters[1], 1) == (int)gridDim.x - 1) {
+        atomicExch(&counters[0], 0);
+        atomicExch(&counters[1], 0);
     }
 }
 

@@ -83,7 +83,7 @@ int mp3s_ctx_create(int device, mp3s_ctx **out)
         mp3s_ctx_destroy(c);   // releases whatever was created
         return fail(MP3S_E_NO_DEVICE, "stream/event creation failed");
     }
-    // self-clearing words of kernels in flight: [0..1] bit packer, [2] fast synthesis counter, [4..5] Huffman kernel
+    // self-clearing words of kernels in flight: [0..1] bit packer, [2] fast synthesis counter, [4..5] Huffman kernel, [6..7] fix-up list of the fast int16 decode
     if (hipMalloc((void **)&c->d_sync, 32) != hipSuccess || hipMemsetAsync(c->d_sync, 0, 32, c->stream) != hipSuccess) {
         mp3s_ctx_destroy(c);
         return fail(MP3S_E_NO_DEVICE, "device scratch allocation failed");
@@ -266,7 +266,7 @@ int mp3s_decode_transform_dev(mp3s_ctx *c, const int16_t *d_is, const mp3s_granu
     int rc = c->ensure_scratch(dec_scratch_bytes(n_frames, nch));
     if (rc) return rc;
     const int e = launch_decode(c->stream, d_is, d_si, d_hdr, n_frames, nch, n_halo, out_format, d_pcm, c->scratch, &c->prof, 0,
-                                c->synth_eps_scale, c->d_sync + 2);
+                                c->synth_eps_scale, c->d_sync);
     if (e) return fail(MP3S_E_HIP, "decode launch: %s", hipGetErrorString((hipError_t)e));
     return MP3S_OK;
 }

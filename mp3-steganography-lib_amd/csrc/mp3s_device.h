@@ -32,14 +32,16 @@ struct Profiler {
 
 int dev_upload_tables(hipStream_t stream);
 
-// scratch: time-domain subband samples, float64 [nch][36 n][32]
+// scratch: time-domain subband samples, float64 [nch][36 n][32], + what the fast int16 path keeps beside them
 size_t dec_scratch_bytes(int n_frames, int nch);
 int launch_decode(hipStream_t stream, const int16_t *d_is, const mp3s_granule_si *d_si, const mp3s_frame_hdr *d_hdr,
                   int n_frames, int nch, int n_halo, int out_format, void *d_pcm, void *d_scratch, Profiler *prof,
                   int sf_base = 0 /* hdr[].stream_first counts from this frame of the batch; d_is / d_si / d_hdr start there */,
-                  double synth_eps_scale = 1.0 /* int16 output: guard of the fast synthesis (k_dec_synth_fast); 0 = the exact
-                                                  kernel */,
-                  int32_t *d_n_exact = nullptr /* counts the samples the guard sent through the exact order */);
+                  double synth_eps_scale = 1.0 /* int16 output: guard of the fast kernels (imdct_run<true>, k_dec_synth_fast);
+                                                  0 = the exact kernels */,
+                  int32_t *d_sync = nullptr /* the context's self-clearing words (8): [2] counts the samples the guard sent
+                                               through the exact order, [6..7] belong to the fix-up list; without them the
+                                               exact kernels run */);
 
 // scratch: subband samples int32 [2][32][36 n]
 size_t enc_scratch_bytes(int n_frames);

@@ -45,18 +45,27 @@ int dev_upload_tables(hipStream_t stream)
     return (int)hipStreamSynchronize(stream);
 }
 
+// decode scratch: S (float64 [ch][slot][32]) | G (float64 [granule][2], left by the fast IMDCT for the guard of the
+// fast synthesis) | fix-up list (one entry per slot and channel at most)
+static size_t dec_S_bytes(int n_frames, int nch) { return (size_t)nch * (size_t)n_frames * 36 * 32 * sizeof(double); }
+static size_t dec_G_bytes(int n_frames) { return (size_t)n_frames * 2 * 2 * sizeof(double); }
 size_t dec_scratch_bytes(int n_frames, int nch)
 {
-    return (size_t)nch * (size_t)n_frames * 36 * 32 * sizeof(double);
+    return dec_S_bytes(n_frames, nch) + dec_G_bytes(n_frames) + (size_t)nch * (size_t)n_frames * 36 * sizeof(uint2);
 }
 
 int launch_decode(hipStream_t stream, const int16_t *d_is, const mp3s_granule_si *d_si, const mp3s_frame_hdr *d_hdr,
                   int n_frames, int nch, int n_halo, int out_format, void *d_pcm, void *d_scratch, Profiler *prof, int sf_base,
-                  double synth_eps_scale, int32_t *d_n_exact)
+                  double synth_eps_scale, int32_t *d_sync)
 {
     const long T = (long)n_frames * 36;
     double *S = (double *)d_scratch;
+    double *G = (double *)((char *)d_scratch + dec_S_bytes(n_frames, nch));
+    uint2 *fix_list = (uint2 *)((char *)G + dec_G_bytes(n_frames));
     const int n_gran = n_frames * 2;
+    // int16 output through the fast kernels (guarded; needs the context's counters), everything else in the reference's order
+    const bool fast = out_format == MP3S_PCM_I16 && synth_eps_scale > 0 && d_sync;
+    static const bool fast_imdct = !(getenv("MP3S_FAST_IMDCT") && atoi(getenv("MP3S_FAST_IMDCT")) == 0);
     // granules per wave: each wave also primes itself with half an IMDCT of the granule before its run, so longer
     // runs waste less; pick the run length (2..8) that fills whole rounds of the chip's wave slots best (168 VGPRs ->
     // 3 waves per SIMD -> 256 CUs x 12 = 3072 slots)
@@ -72,20 +81,29 @@ int launch_decode(hipStream_t stream, const int16_t *d_is, const mp3s_granule_si
     }
     const int runs = (n_gran + run - 1) / run;
     int pp = prof ? prof->begin(stream, K_DEC_IMDCT) : -1;
-    hipLaunchKernelGGL(k_dec_imdct, dim3((runs + DEC_A_WAVES - 1) / DEC_A_WAVES), dim3(DEC_A_WAVES * 64), 0, stream,
-                       d_is, d_si, d_hdr, n_gran, nch, run, S, T, sf_base);
+    if (fast && fast_imdct)
+        hipLaunchKernelGGL(k_dec_imdct<true>, dim3((runs + DEC_A_WAVES - 1) / DEC_A_WAVES), dim3(DEC_A_WAVES * 64), 0, stream,
+                           d_is, d_si, d_hdr, n_gran, nch, run, S, T, sf_base, G);
+    else
+        hipLaunchKernelGGL(k_dec_imdct<false>, dim3((runs + DEC_A_WAVES - 1) / DEC_A_WAVES), dim3(DEC_A_WAVES * 64), 0, stream,
+                           d_is, d_si, d_hdr, n_gran, nch, run, S, T, sf_base, (double *)nullptr);
     if (prof) prof->end(stream, pp);
     constexpr int TW = DEC_SYNTH_TW;
     pp = prof ? prof->begin(stream, K_DEC_SYNTH) : -1;
-    if (out_format == MP3S_PCM_I16 && synth_eps_scale > 0) {
+    if (fast) {
         static const int ftw = getenv("MP3S_FAST_TW") ? atoi(getenv("MP3S_FAST_TW")) : DEC_SYNTH_FAST_TW;
+        const double *Gk = fast_imdct ? G : nullptr;
 #define MP3S_FAST_LAUNCH(W)                                                                                                        \
         hipLaunchKernelGGL(k_dec_synth_fast<W>, dim3((unsigned)((T + (W * 64 - 15) - 1) / (W * 64 - 15))), dim3(W * 64 * nch), 0, stream, \
-                           (const double *)S, T, d_hdr, nch, n_halo, (int16_t *)d_pcm, sf_base, synth_eps_scale, d_n_exact)
+                           (const double *)S, T, d_hdr, nch, n_halo, (int16_t *)d_pcm, sf_base, synth_eps_scale, Gk, n_gran, fix_list, d_sync + 6)
         if (ftw == 1) MP3S_FAST_LAUNCH(1);
         else if (ftw == 4) MP3S_FAST_LAUNCH(4);
         else MP3S_FAST_LAUNCH(2);
 #undef MP3S_FAST_LAUNCH
+        // the samples the guard could not vouch for, again from `is` in the reference's order (a handful per batch)
+        const int fix_groups = (int)((T * nch + DEC_A_WAVES - 1) / DEC_A_WAVES) < 128 ? (int)((T * nch + DEC_A_WAVES - 1) / DEC_A_WAVES) : 128;
+        hipLaunchKernelGGL(k_dec_fixup, dim3(fix_groups), dim3(DEC_A_WAVES * 64), 0, stream, d_is, d_si, d_hdr, n_gran, nch, T, n_halo,
+                           sf_base, (int16_t *)d_pcm, (const uint2 *)fix_list, d_sync + 6, d_sync + 2);
     } else {
         const int out_per_tile = TW * 64 - 15;
         const int tiles = (int)((T + out_per_tile - 1) / out_per_tile);

@@ -156,6 +156,34 @@ void build()
         const double g33 = 33 * u / (1 - 33 * u), g24 = 24 * u / (1 - 24 * u), g17 = 17 * u / (1 - 17 * u);
         const double dV = (double)dN + 1e-19 + g33 + g24;
         T.synth_eps_a = 2.0 * 32767.0 * dsum * (dV + 2 * g17 * (1 + dV));
+        // The fast IMDCT (imdct_run<true>).  Inputs v[k] of a subband are the same in both paths (requantisation .. alias
+        // reduction are not touched); B = sum_k |v[k]|, |C| <= 1, |window| <= 1.
+        //   reference:  X[i] = the 18 products summed one after the other:            |X[i] - sum v C[i]| <= g18 B
+        //   fast:       Y[i], i = 0..8 and 18..26, fused multiply-adds:              |Y[i] - sum v C[i]| <= g18 B
+        //               Y[17-i] = -Y[i], Y[53-i] = Y[i]; the reference's table is only symmetric up to dT =
+        //               max |C[i][k] + C[17-i][k]|, |C[i][k] - C[53-i][k]| (arguments rounded before the cosine: measured
+        //               below in long double against the table itself):               |Y[i'] - sum v C[i']| <= (g18 + dT) B
+        //   so |Y - X| <= (2 g18 + dT) B for every row; the window factor adds one rounding on each side (2.1 u B), the
+        //   overlap-add another on each side and the previous granule's share with its own B':
+        //               |S_fast - S_ref| <= kappa (B + B'),  kappa = 2 g18 + dT + 4.2 u
+        //   (short blocks keep the reference's order in both paths.)
+        // Through the synthesis: the matrixing is a sum over the 32 subbands with factors <= 1, so V moves by at most
+        // kappa * sum_subbands (B + B') <= 2 kappa Gmax (G = sum of B over the subbands of a granule and channel, Gmax
+        // over the granules whose rows a window sum reads and the granule in front of them); the sum |S| of a slot, which
+        // scales the other terms, moves by the same amount (second order, covered by the factor 2 below); the 16-tap
+        // window sum multiplies by Dsum as above.  G itself is a float sum of 576 non-negative terms (relative error
+        // < 600 u): nothing against the factor 2.
+        long double dT = 0;
+        for (int i = 0; i < 9; i++)
+            for (int k = 0; k < 18; k++) {
+                const long double a = fabsl((long double)T.imdct_cos36[i][k] + (long double)T.imdct_cos36[17 - i][k]);
+                const long double b = fabsl((long double)T.imdct_cos36[18 + i][k] - (long double)T.imdct_cos36[35 - i][k]);
+                if (a > dT) dT = a;
+                if (b > dT) dT = b;
+            }
+        const double g18 = 18 * u / (1 - 18 * u);
+        T.imdct_kappa = 2 * g18 + (double)dT + 4.2 * u;
+        T.synth_eps_g = 2.0 * 32767.0 * dsum * 2.0002 * T.imdct_kappa;
         T.synth_eps_x = 2.0 * 2 * u;
     }
     for (int sr = 0; sr < 3; sr++) {

@@ -40,6 +40,10 @@ struct DevTables {
     // the guard of that path: a sample whose value * 32767 lies within  synth_eps_a * (largest sum |S| of a time slot in
     // the tile) + synth_eps_x * |value * 32767|  of an integer is computed again in the reference's order
     double synth_eps_a, synth_eps_x;
+    // ... plus synth_eps_g * (largest G of a granule the tile reads): the fast IMDCT (mirrored sums, fused multiply-adds)
+    // leaves rows that differ from the reference's by at most imdct_kappa * (sum of |IMDCT input| of the subband in this
+    // and the previous granule); G is that sum over the 32 subbands of a granule and channel
+    double synth_eps_g, imdct_kappa;
     uint8_t rq_map[3][3][32][20];  // [sr][case][subband][18 lines + 2 pad]: five aligned dwords per lane;
                                    // byte = gain selector << 6 | scalefactor slot (see build_rq_map)
     int16_t reorder_src[3][576];   // [sr][dst line] -> src line or -1 (zero)  Frame.py:574-602
