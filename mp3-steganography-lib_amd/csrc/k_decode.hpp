@@ -65,7 +65,16 @@ struct DecShared {
     uint32_t side[DEC_A_WAVES][2][18];     // per wave: the two 72-byte side records of the current granule
     double exp2f[DEC_A_WAVES][2][64];      // per wave and channel: 2^(-exp2) per scalefactor slot of the current granule
     double exp1f[DEC_A_WAVES][2][4];       // ... and 2^(exp1/4) per gain selector
+    double win[4][36];                     // sine_block: the fast IMDCT reads its window factors per lane (the channels may differ
+                                           // in block type) instead of carrying both channels' factors in scalar registers
 };
+__device__ __forceinline__ void dec_stage_tables(DecShared &sh)
+{
+    for (int i = threadIdx.x; i < POW2Q_N; i += blockDim.x) sh.pow2q[i] = c_tab.pow2q[i];
+    if (threadIdx.x < POW2H_N) sh.pow2h[threadIdx.x] = c_tab.pow2h[threadIdx.x];
+    if (threadIdx.x < 144) (&sh.win[0][0])[threadIdx.x] = (&c_tab.sine_block[0][0])[threadIdx.x];
+    __syncthreads();
+}
 
 // requantise .. alias/reorder of granule g for this lane's subband; v[18] = IMDCT input
 __device__ __forceinline__ void dec_prepare(const DevTables &tab, DecShared &sh, int wave, double (&v)[18],
@@ -165,16 +174,15 @@ __device__ __forceinline__ void dec_prepare(const DevTables &tab, DecShared &sh,
     __builtin_amdgcn_s_waitcnt(0xc07f);
 }
 
-// twiddle row i + the window factors of rows i and im (the row that mirrors it) for each channel half
-struct Row18m { dvec8 a, b; dvec2 c; double w0, w1, w0m, w1m; };
-__device__ __forceinline__ Row18m load_row18m(const double (*C36)[18], const double *win0, const double *win1, int i, int im)
+// twiddle row i alone (the fast IMDCT takes its window factors from LDS)
+struct Row18s { dvec8 a, b; dvec2 c; };
+__device__ __forceinline__ Row18s load_row18s(const double (*C36)[18], int i)
 {
-    Row18m r;
+    Row18s r;
     const double *p = C36[i];
     r.a = *reinterpret_cast<const dvec8 *>(p);
     r.b = *reinterpret_cast<const dvec8 *>(p + 8);
     r.c = *reinterpret_cast<const dvec2 *>(p + 16);
-    r.w0 = win0[i]; r.w1 = win1[i]; r.w0m = win0[im]; r.w1m = win1[im];
     return r;
 }
 
@@ -244,18 +252,20 @@ __device__ __forceinline__ void imdct_run(DecShared &sh, int wave, int lane, con
         double *row = S + ((long)(live ? ch : 0) * T + ((long)g * 18 - slot0)) * 32 + sb;
         if (bt != 2) {
             if (FAST) {
-                // rows 0..8 and their mirrors 17..9, then rows 18..26 and their mirrors 35..27
-                Row18m cur = gi >= 0 ? load_row18m(C36, win0, win1, 0, 17) : load_row18m(C36, win0, win1, 18, 35);
+                // rows 0..8 and their mirrors 17..9, then rows 18..26 and their mirrors 35..27; window factors from LDS
+                const double *wl = sh.win[bt];
+                Row18s cur = load_row18s(C36, gi >= 0 ? 0 : 18);
                 if (gi >= 0) {
 #pragma unroll
                     for (int i = 0; i < 9; i++) {
-                        const Row18m nxt = i < 8 ? load_row18m(C36, win0, win1, i + 1, 16 - i) : load_row18m(C36, win0, win1, 18, 35);
+                        const Row18s nxt = load_row18s(C36, i < 8 ? i + 1 : 18);
+                        const double wa = wl[i], wb = wl[17 - i];
                         __builtin_amdgcn_sched_barrier(0);
                         double y = 0.0;
 #pragma unroll
                         for (int k = 0; k < 18; k++) y = __builtin_fma(v[k], k < 8 ? cur.a[k & 7] : (k < 16 ? cur.b[k & 7] : cur.c[k & 1]), y);
-                        double xa = y * (ch == 0 ? cur.w0 : cur.w1) + tail[i];
-                        double xb = -y * (ch == 0 ? cur.w0m : cur.w1m) + tail[17 - i];
+                        double xa = y * wa + tail[i];
+                        double xb = -y * wb + tail[17 - i];
                         if (neg_odd && (i & 1)) xa = -xa;
                         if (neg_odd && ((17 - i) & 1)) xb = -xb;
                         if (wr) { row[(long)i * 32] = xa; row[(long)(17 - i) * 32] = xb; }
@@ -265,13 +275,14 @@ __device__ __forceinline__ void imdct_run(DecShared &sh, int wave, int lane, con
                 }
 #pragma unroll
                 for (int i = 18; i < 27; i++) {
-                    const Row18m nxt = load_row18m(C36, win0, win1, i < 26 ? i + 1 : 26, i < 26 ? 52 - i : 27);
+                    const Row18s nxt = load_row18s(C36, i < 26 ? i + 1 : 26);
+                    const double wa = wl[i], wb = wl[53 - i];
                     __builtin_amdgcn_sched_barrier(0);
                     double y = 0.0;
 #pragma unroll
                     for (int k = 0; k < 18; k++) y = __builtin_fma(v[k], k < 8 ? cur.a[k & 7] : (k < 16 ? cur.b[k & 7] : cur.c[k & 1]), y);
-                    tail[i - 18] = y * (ch == 0 ? cur.w0 : cur.w1);
-                    tail[35 - i] = y * (ch == 0 ? cur.w0m : cur.w1m);
+                    tail[i - 18] = y * wa;
+                    tail[35 - i] = y * wb;
                     __builtin_amdgcn_sched_barrier(0);
                     cur = nxt;
                 }
@@ -355,9 +366,7 @@ __global__ __launch_bounds__(DEC_A_WAVES * 64, 3) void k_dec_imdct(
     int n_granules, int nch, int run, double *__restrict__ S, long T, int sf_base, double *__restrict__ G)
 {
     __shared__ DecShared sh;
-    for (int i = threadIdx.x; i < POW2Q_N; i += blockDim.x) sh.pow2q[i] = c_tab.pow2q[i];
-    if (threadIdx.x < POW2H_N) sh.pow2h[threadIdx.x] = c_tab.pow2h[threadIdx.x];
-    __syncthreads();
+    dec_stage_tables(sh);
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
     const int g0 = (xcd_tile() * DEC_A_WAVES + wave) * run;
     if (g0 >= n_granules) return;  // whole wave exits together
@@ -759,18 +768,16 @@ __global__ __launch_bounds__(TW * 64 * 2, TW == 4 ? 2 : 4) void k_dec_synth_fast
 // overwrites it in the PCM.  About one sample in a million comes here; with the guard inflated (tests) all of them do.
 // counters: [0] entries (written by k_dec_synth_fast), [1] workgroups through; the last one clears both.
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(DEC_A_WAVES * 64, 2) void k_dec_fixup(
+__global__ __launch_bounds__(DEC_A_WAVES * 64, 1) void k_dec_fixup(
     const int16_t *__restrict__ is, const mp3s_granule_si *__restrict__ si, const mp3s_frame_hdr *__restrict__ hdr,
     int n_granules, int nch, long T, int n_halo, int sf_base, int16_t *__restrict__ pcm_out,
     const uint2 *__restrict__ fix_list, int32_t *counters, int32_t *__restrict__ n_exact)
 {
     __shared__ DecShared sh;
     __shared__ double win[DEC_A_WAVES][36 * 32];
-    for (int i = threadIdx.x; i < POW2Q_N; i += blockDim.x) sh.pow2q[i] = c_tab.pow2q[i];
-    if (threadIdx.x < POW2H_N) sh.pow2h[threadIdx.x] = c_tab.pow2h[threadIdx.x];
-    __syncthreads();
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
     const int n = __builtin_amdgcn_readfirstlane(__hip_atomic_load(&counters[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+    if ((int)(blockIdx.x * DEC_A_WAVES) < n) dec_stage_tables(sh);     // (uniform per workgroup; most launches find an empty or short list)
     const long halo_slots = (long)n_halo * 36;
     double *Sp = win[wave];
     for (int e = blockIdx.x * DEC_A_WAVES + wave; e < n; e += gridDim.x * DEC_A_WAVES) {
