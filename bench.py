@@ -81,6 +81,8 @@ def main():
                          "runs pass this so that the per-kernel averages of the trace describe the full-size launches)")
     ap.add_argument("--no-overlap", action="store_true",
                     help="run the Huffman front end of batch k+1 after, not under, the transform kernels of batch k")
+    ap.add_argument("--huffman-under", choices=("rate", "decode"), default="rate",
+                    help="where the Huffman decode of batch k+1 starts: under the rate loop of batch k, or under its decode transforms")
     ap.add_argument("--pack-overlap", action="store_true", help="bit packing of batch k on a third stream, under the decode of batch k+1")
     ap.add_argument("--resident-only", action="store_true", help="region (i) only (profiling runs)")
     args = ap.parse_args()
@@ -202,9 +204,12 @@ def main():
             if k == 0 or state.get("restart"):
                 front_end(aux, k); state["restart"] = False
             ctx.wait_for(aux)                       # Huffman(k) done
+        if aux is not None and not state.get("last") and args.huffman_under == "decode":
+            aux.wait_for(ctx)                       # batch k-1 is through: its Huffman outputs may be overwritten
+            front_end(aux, k + 1)
         _lib.check(L.mp3s_decode_transform_dev(ctx.handle, d_is2[b], d_si2[b], d_hdr, n, 2, 0, _lib.MP3S_PCM_I16, d_pcm))
         _lib.check(L.mp3s_encode_transform_dev(ctx.handle, d_pcm, d_hdr, n, d_mdct))
-        if aux is not None and not state.get("last"):
+        if aux is not None and not state.get("last") and args.huffman_under == "rate":
             aux.wait_for(ctx)                       # decode(k-1) has read its inputs; start under the rate loop, the longest kernel
             front_end(aux, k + 1)
         if aux2 is not None:

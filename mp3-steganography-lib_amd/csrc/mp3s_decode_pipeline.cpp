@@ -170,10 +170,14 @@ int decode_group(mp3s_ctx *c, mp3s_multi &m, const std::vector<int> &idx, int nc
             for (size_t k = 0; k < idx.size() && !rc; k++) {
                 if (!whole[k]) continue;
                 ParsedStream &p = m.parsed[idx[k]];
-                const std::vector<uint8_t> bits = p.bits;
-                const int prc = parse_stream(m.files[idx[k]].first, m.files[idx[k]].second, p, nullptr);
+                // into a stream of its own: a parse that fails half way must leave the scan's record as it was (the batch
+                // entry points run a failing group's files again one by one: a record cut down to the frames in front of the
+                // damage let such a file through as a shorter one)
+                ParsedStream whole_parse;
+                const int prc = parse_stream(m.files[idx[k]].first, m.files[idx[k]].second, whole_parse, nullptr);
                 if (prc) { rc = fail(prc, "file %d: malformed main data", idx[k]); break; }
-                p.bits = bits;
+                whole_parse.bits = std::move(p.bits);
+                p = std::move(whole_parse);
                 m.scanned[idx[k]].host_parsed = true;
                 any_host = true;
                 redone += p.n_frames;

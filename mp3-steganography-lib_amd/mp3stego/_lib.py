@@ -865,15 +865,15 @@ DEV_TABLES_DTYPE = np.dtype([
     ("synth_matrix", "<f8", (64, 32)), ("synth_window", "<f8", (512,)), ("synth_window_t", "<f8", (32, 16)), ("imdct_cos36", "<f8", (36, 18)),
     ("imdct_cos12", "<f8", (12, 6)), ("sine_block", "<f8", (4, 36)), ("alias_cs", "<f8", (8,)), ("alias_ca", "<f8", (8,)),
     ("pow43", "<f8", (8207,)), ("pow2q", "<f8", (312,)), ("pow2h", "<f8", (40,)), ("sqrt2", "<f8"),
-    ("synth_fast", "<f8", (344,)), ("synth_eps_a", "<f8"), ("synth_eps_x", "<f8"),
+    ("synth_fast", "<f8", (344,)), ("synth_eps_a", "<f8"), ("synth_eps_x", "<f8"), ("synth_eps_g", "<f8"), ("imdct_kappa", "<f8"),
     ("rq_map", "u1", (3, 3, 32, 20)), ("reorder_src", "<i2", (3, 576)), ("pre_tab", "u1", (24,)),
     ("enwindow", "<i4", (512,)), ("fl", "<i4", (32, 64)), ("cos_l", "<i4", (18, 36)), ("mdct_cs", "<i4", (8,)),
-    ("mdct_ca", "<i4", (8,)), ("steptab", "<f8", (128,)), ("steptabi", "<i4", (128,)), ("int2idx", "<u2", (10000,)),
+    ("mdct_ca", "<i4", (8,)), ("steptab", "<f8", (128,)), ("steptabi", "<i4", (128,)), ("_pad_int2idx", "u1", (8,)), ("int2idx", "<u2", (10000,)),   # (int2idx is alignas(16))
     ("sfb_long", "<i4", (3, 23)), ("en_base", "<i4", (32,)), ("en_step", "<i4", (32,)), ("subdv", "<i4", (23, 2)), ("subdiv_lut", "<u4", (3, 289)), ("hlen13", "u1", (256,)), ("hlen15", "u1", (256,)),
     ("hlen16", "u1", (256,)), ("hlen24", "u1", (256,)), ("hlen_c1a", "u1", (16,)), ("linbits", "u1", (32,)),
     ("linmax", "<i4", (32,)), ("transform", "u1", (32, 2)), ("huff_lut_id", "u1", (32,)), ("dec_max", "u1", (32,)),
     ("huff_fast", "<u2", (15, 512)), ("huff_l2", "<u2", (2240,)), ("quad_fast", "<u2", (64,)),
-    ("hcod", "<u4", (4, 256)), ("hcod_c1a", "u1", (16,))], align=True)
+    ("hcod", "<u4", (4, 256)), ("hcod_c1a", "u1", (16,)), ("_pad_end", "u1", (8,))], align=True)   # (the struct is 16-byte aligned)
 
 
 def debug_tables():

@@ -128,3 +128,21 @@ def test_oracle_tables_match_reference(orc, golden_dir):
         assert np.array_equal(dec[:, 1], ln) and np.array_equal(dec[:, 0].astype(np.uint64), code << (32 - ln))
     assert np.array_equal(g["quad_hlen"], g["enc_hlen_32"])
     assert np.array_equal(g["quad_hcod"].astype(np.uint64), g["enc_hcod_32"].astype(np.uint64) << (32 - g["enc_hlen_32"].astype(np.uint64)))
+
+
+def test_guard_constants_of_the_fast_int16_decode(mlib):
+    """The bounds the fast IMDCT / synthesis are guarded with, recomputed from the tables themselves:
+    the table asymmetry the mirrored IMDCT sums rely on, kappa, and the G term of the synthesis guard."""
+    t = mlib.debug_tables()
+    c = t["imdct_cos36"].astype(np.longdouble)
+    d_t = max(float(np.abs(c[:9] + c[17:8:-1]).max()), float(np.abs(c[18:27] - c[35:26:-1]).max()))
+    # the true cosines are exactly (anti)symmetric: what is left is the rounding of the arguments, a few 1e-14
+    assert 0 < d_t < 1e-13
+    u = 2.0 ** -53
+    g18 = 18 * u / (1 - 18 * u)
+    kappa = 2 * g18 + d_t + 4.2 * u
+    assert abs(float(t["imdct_kappa"]) - kappa) <= 1e-18
+    dsum = max(float(np.abs(t["synth_window"][i::32]).sum()) for i in range(32))
+    assert abs(float(t["synth_eps_g"]) / (2.0 * 32767.0 * dsum * 2.0002 * kappa) - 1) < 1e-12
+    # the older terms stay what they were: eps_a scales with the slot's sum |S|, eps_x with the sample itself
+    assert 1e-9 < float(t["synth_eps_a"]) < 1e-8 and float(t["synth_eps_x"]) == 4 * u
