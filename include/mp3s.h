@@ -129,11 +129,13 @@ int mp3s_dev_memset(mp3s_ctx *ctx, void *dptr, int value, size_t bytes);
 /* HIP-event timer on the context's stream (the stream every kernel below is launched on) */
 int mp3s_timer_start(mp3s_ctx *ctx);
 int mp3s_timer_stop(mp3s_ctx *ctx, float *ms);
-/* The int16 decode format takes a FAST synthesis (even / odd splitting of the 32-point cosine sums, a sixth of the
- * multiplications) behind a guard: a sample whose value * 32767 lies within a proven bound of an integer is computed
- * again in the reference's operation order, so the int16 PCM is the reference's, sample for sample (derivation of the
- * bound: DESIGN.md; the float formats always run the exact kernel and are bit-identical to the reference).
- * eps_scale: 1 = the proven bound (default), 0 = always the exact kernel, > 1 = a wider guard (tests: forces samples
+/* The int16 decode format takes FAST kernels -- an IMDCT of 18 sums and their mirror images, a synthesis by even / odd
+ * splitting of the 32-point cosine sums (a sixth of the multiplications), both with fused multiply-adds -- behind a guard: a
+ * sample whose value * 32767 lies within a proven bound of an integer is computed again from the Huffman output in the
+ * reference's operation order (a fix-up kernel behind the synthesis), so the int16 PCM is the reference's, sample for sample
+ * (derivation of the bound: DESIGN.md section 2; the float formats always run the exact kernels and are bit-identical to
+ * the reference).
+ * eps_scale: 1 = the proven bound (default), 0 = always the exact kernels, > 1 = a wider guard (tests: forces samples
  * through the exact path).  *exact_samples (optional) = samples the guard has sent there since the last call. */
 int mp3s_synth_mode(mp3s_ctx *ctx, double eps_scale, int64_t *exact_samples);
 /* a plain device-to-device copy kernel over `bytes` (read + write counted), `iters` launches timed with HIP events on the
