@@ -83,7 +83,8 @@ def main():
                     help="run the Huffman front end of batch k+1 after, not under, the transform kernels of batch k")
     ap.add_argument("--huffman-under", choices=("rate", "decode"), default="rate",
                     help="where the Huffman decode of batch k+1 starts: under the rate loop of batch k, or under its decode transforms")
-    ap.add_argument("--pack-overlap", action="store_true", help="bit packing of batch k on a third stream, under the decode of batch k+1")
+    ap.add_argument("--pack-overlap", action="store_true", help="(default since r02e; kept for old command lines)")
+    ap.add_argument("--no-tail-stream", action="store_true", help="chain check and bit packing of batch k on the main stream instead of a third one")
     ap.add_argument("--resident-only", action="store_true", help="region (i) only (profiling runs)")
     args = ap.parse_args()
 
@@ -138,10 +139,10 @@ def main():
     d_si2 = [ctx.alloc(n * 4 * 72), ctx.alloc(n * 4 * 72)]
     d_hst2 = [ctx.alloc(16), ctx.alloc(16)]
     aux = None if args.no_overlap else _lib.Context(ctx.device)   # second stream on the same device
-    # third stream: the bit packer (LDS atomics, vector units mostly idle) of batch k runs under the decode transforms of
-    # batch k+1
-    # (measured: 0.923 against 0.915 ms per step without it -- packer and IMDCT stretch each other -- so it is off by default)
-    aux2 = _lib.Context(ctx.device) if (args.pack_overlap and not args.no_overlap) else None
+    # third stream: the tail of batch k (chain check: two small launches, and the bit packer) runs under the decode
+    # transforms of batch k+1, as in the library's pipe (mp3s_pipe.cpp: s_tail) -- the small launches and their gaps are 5 %
+    # of a step when they sit in front of the next batch (0.829 -> 0.785 ms per step)
+    aux2 = _lib.Context(ctx.device) if not (args.no_tail_stream or args.no_overlap) else None
     d_hdr = ctx.to_device(parsed["hdr"])
     rf, _pad = _lib.rate_frames(44100, 128, 2, n)
     # the message array of a batch: the eight 3-bit patterns the variants read, then the message
@@ -216,11 +217,11 @@ def main():
             ctx.wait_for(aux2)                      # the packer of batch k-1 has read what the rate loop is about to overwrite
         _lib.check(L.mp3s_rate_select_dev(ctx.handle, d_mdct, d_rf, n, d_hide, len(hide_all), d_cur, d_seg, d_spans, 1, max_reach,
                                           d_eu, d_ec, n_ent, d_ix, d_out, d_en, d_ixv, d_outv, d_env))
-        _lib.check(L.mp3s_chain_resolve_dev(ctx.handle, d_out, d_rf, n, d_seg, 1, d_cur, None, d_verdict, d_segout))
         pk = ctx
         if aux2 is not None:
-            aux2.wait_for(ctx)
+            aux2.wait_for(ctx)                      # rate loop + selection of batch k are through: its tail goes on the third stream
             pk = aux2
+        _lib.check(L.mp3s_chain_resolve_dev(pk.handle, d_out, d_rf, n, d_seg, 1, d_cur, None, d_verdict, d_segout))
         _lib.check(L.mp3s_pack_frames_dev(pk.handle, d_ix, d_out, d_en, n, 44100, 128, d_off, d_pad, d_mp3, d_sc, d_pst))
 
     def barrier():
@@ -613,7 +614,7 @@ def main():
                                                        if k not in ("k_dec_huffman", "k_enc_pack")) * 1e-3), 1),
             "gpu_event_ms_per_step": round(gpu_ms / args.steps, 4),
             "timed_region_s": round(wall, 4),
-            "front_end_overlap": aux is not None,
+            "front_end_overlap": aux is not None, "tail_stream": aux2 is not None,
             "parity_checked": bool(same),
             "short_files": short_files,
             "prep_s": round(prep_s, 2),

@@ -149,7 +149,7 @@ void tables_guess_of(const mp3s_frame_side *side, long n_frames, int extra, std:
     }
 }
 
-int enc_issue(mp3s_ctx *c, const EncLayout &L, const EncDev &d)
+int enc_issue(mp3s_ctx *c, const EncLayout &L, const EncDev &d, hipStream_t tail, hipEvent_t tail_from, hipEvent_t rate_after)
 {
     const mp3s_frame_hdr *d_hdr = (const mp3s_frame_hdr *)d.d_in;
     const mp3s_rate_frame *d_rf = (const mp3s_rate_frame *)(d.d_in + L.o_rf);
@@ -158,6 +158,8 @@ int enc_issue(mp3s_ctx *c, const EncLayout &L, const EncDev &d)
     const mp3s_chain_seg *d_segs = (const mp3s_chain_seg *)(d.d_in + L.o_segs);
     const int32_t *d_mdct = d.d_mdct_all + (size_t)L.lead * 2304;   // the block's own frames
     int rc = mp3s_encode_transform_dev(c, d.d_pcm, d_hdr, L.n_all, d.d_mdct_all);
+    // (the tail of the job in front is through before this job's rate loop starts: tails do not queue up behind one another)
+    if (!rc && rate_after && hipStreamWaitEvent(c->stream, rate_after, 0) != hipSuccess) rc = fail(MP3S_E_HIP, "ordering behind the previous tail failed");
     if (!rc && L.n_entries > 0) {
         // short messages: their variants run in the same launch and the device decides the cursor chain (no guess)
         const int32_t *d_ent = (const int32_t *)(d.d_in + L.o_ent);
@@ -166,14 +168,27 @@ int enc_issue(mp3s_ctx *c, const EncLayout &L, const EncDev &d)
                                   L.n_entries, d.d_ix, d.d_out, d.d_en, d.d_ixv, d.d_outv, d.d_env);
     } else if (!rc)
         rc = mp3s_rate_loop_dev(c, d_mdct, d_rf, L.n, d_hide, L.n_hide, d_cur, nullptr, nullptr, 0, d.d_ix, d.d_out, d.d_en);
+    // The tail of a job -- chain check (two small launches) and bit packing -- reads only the job's own buffers: the pipe
+    // gives it a stream of its own, so that the small launches and their gaps lie under the decode transforms of the next
+    // job instead of in front of them (bench.py --pack-overlap: 0.829 -> 0.785 ms per step).  Every tail goes through the
+    // same stream, so the context's chain scratch and the packer's sync words are still used by one launch at a time.
+    hipStream_t ts = c->stream;
+    if (!rc && tail) {
+        if (hipEventRecord(tail_from, c->stream) != hipSuccess || hipStreamWaitEvent(tail, tail_from, 0) != hipSuccess)
+            rc = fail(MP3S_E_HIP, "ordering the tail stream failed");
+        ts = tail;
+    }
     if (!rc) {
-        const int e = launch_chain(c->stream, d.d_out, d_rf, L.n, d_segs, d_cur, nullptr, d.d_agg, d.d_small,
+        const int e = launch_chain(ts, d.d_out, d_rf, L.n, d_segs, d_cur, nullptr, d.d_agg, d.d_small,
                                    (mp3s_chain_seg_out *)((uint8_t *)d.d_small + kSmallHead), &c->prof);
         if (e) rc = fail(MP3S_E_HIP, "chain launch: %s", hipGetErrorString((hipError_t)e));
     }
     // packed on the assumption that the verdict is "nothing to redo" (the common case); the caller discards it otherwise
-    if (!rc) rc = mp3s_pack_frames_dev(c, d.d_ix, d.d_out, d.d_en, L.n, L.samplerate, L.kbps, (const uint32_t *)(d.d_in + L.o_off),
-                                       d.d_in + L.o_pad, d.d_mp3, d.d_sc, d.d_small + 2);
+    if (!rc) {
+        const int e = launch_pack(ts, d.d_ix, d.d_out, d.d_en, L.n, L.sri, L.bri, L.whole, (const uint32_t *)(d.d_in + L.o_off), d.d_in + L.o_pad, d.d_mp3,
+                                  d.d_sc, d.d_small + 2, c->d_sync, &c->prof);
+        if (e) rc = fail(MP3S_E_HIP, "pack launch: %s", hipGetErrorString((hipError_t)e));
+    }
     return rc;
 }
 

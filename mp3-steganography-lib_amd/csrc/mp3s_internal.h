@@ -273,7 +273,8 @@ void select_entries(int first_unit, int reach, int first_entry, int hide_end, in
 bool enc_variant_buffers(mp3s_ctx *c, const EncLayout &L, EncDev &d);
 // transforms -> rate loop on the guessed cursors -> chain check -> bit packing, all on c->stream, nothing waited for.
 // The packed bytes are final iff verdict[0] == 0 and verdict[1] == 0 (d_small[0], d_small[1]).
-int enc_issue(mp3s_ctx *c, const EncLayout &L, const EncDev &d);
+int enc_issue(mp3s_ctx *c, const EncLayout &L, const EncDev &d, hipStream_t tail = nullptr /* chain check + packing on this stream, ordered behind the rate loop through tail_from */,
+              hipEvent_t tail_from = nullptr, hipEvent_t rate_after = nullptr /* the rate loop waits for this event (the previous job's tail) */);
 // verdict != 0: the host resolves the chains on the first pass's device buffers (walk, message variants, exact re-runs,
 // packing again); `in` = the host copy of the block.  Pool slots of its own: the entries of the exact re-runs, the variants.
 constexpr int kSlotRedo = 11, kSlotVariants = 19;

@@ -37,7 +37,7 @@ struct Slot {
     // the encoder's intermediates of the slot's job (mdct, quantised lines, GrInfo, energies, scfsi): the slot's own, so
     // that a job whose cursor guess failed is resolved on them at collect time while later jobs have long been issued
     uint8_t *d_enc = nullptr; size_t enc_cap = 0;
-    hipEvent_t e_start = nullptr, e_up = nullptr, e_huff = nullptr, e_comp = nullptr, e_down = nullptr;
+    hipEvent_t e_start = nullptr, e_up = nullptr, e_huff = nullptr, e_rate = nullptr, e_comp = nullptr, e_down = nullptr;
     bool busy = false;
 };
 
@@ -81,6 +81,10 @@ struct mp3s_pipe {
     // front end of job k+1 therefore runs on a stream of its own, under the encode half of job k, with two sets of
     // Huffman outputs (is / side records) taken in turn; e_dec[x] = the decode transforms that read set x last are done.
     hipStream_t s_huff = nullptr;
+    // ... and, optionally (MP3S_PIPE_TAIL=1; measured slower here, see mp3s_pipe_create), the tail of a job (chain check +
+    // bit packing) on another one, under the decode transforms of the next job; e_rate orders it behind the job's rate loop
+    hipStream_t s_tail = nullptr;
+    int last_tail = -1;                  // slot of the job whose tail was issued last
     hipEvent_t e_dec[2] = {nullptr, nullptr};
     bool dec_used[2] = {false, false};
     unsigned issued = 0;
@@ -290,9 +294,10 @@ int issue_fast(mp3s_pipe *P, Job &j, Slot &s, size_t blob_len, int max_p23)
     dev.d_mp3 = s.d_mp3; dev.d_sc = (int32_t *)(s.d_enc + b_mdct + b_ix + b_out + b_en);
     dev.d_small = s.d_small;
     if (!enc_variant_buffers(c, L, dev)) return fail(MP3S_E_NOMEM, "hipMalloc failed for %d variant entries", L.n_entries);
-    const int rc = enc_issue(c, L, dev);
+    const int rc = enc_issue(c, L, dev, P->s_tail, s.e_rate, P->s_tail && P->last_tail >= 0 && getenv("MP3S_PIPE_TAIL_THROTTLE") ? P->slots[(size_t)P->last_tail].e_comp : nullptr);
     if (rc) return rc;
-    HIPCHK(hipEventRecord(s.e_comp, c->stream));
+    HIPCHK(hipEventRecord(s.e_comp, P->s_tail ? P->s_tail : c->stream));
+    P->last_tail = (int)(&s - P->slots.data());
     HIPCHK(hipStreamWaitEvent(P->s_down, s.e_comp, 0));
     const size_t total = j.segs.back().mp3_off + j.segs.back().mp3_len;
     HIPCHK(hipMemcpyAsync(j.res->big[2].data(), s.d_small, small_bytes(L.n_segs), hipMemcpyDeviceToHost, P->s_down));
@@ -312,6 +317,7 @@ void run_slow(mp3s_pipe *P, Job &j)   // mu_issue held
     }
     (void)hipStreamSynchronize(P->s_huff);   // the synchronous path uses the same Huffman output buffers
     (void)hipStreamSynchronize(P->s_down);   // ... and the PCM buffer a download may still be reading
+    if (P->s_tail) (void)hipStreamSynchronize(P->s_tail);   // ... and the context's chain scratch and packer words
     j.slow_out.assign((size_t)nf, mp3s_file());
     j.slow_st.assign((size_t)nf, 0);
     j.res.reset();
@@ -358,6 +364,7 @@ void worker(mp3s_pipe *P, int me)
             std::lock_guard<std::mutex> gi(P->mu_issue);
             if (fast && issue_fast(P, *j, s, blob_len, max_p23) != MP3S_OK) {
                 (void)hipStreamSynchronize(P->s_up); (void)hipStreamSynchronize(P->s_huff); (void)hipStreamSynchronize(P->c->stream);
+                if (P->s_tail) (void)hipStreamSynchronize(P->s_tail);
                 (void)hipStreamSynchronize(P->s_down);
                 fast = false;
             }
@@ -382,7 +389,7 @@ void free_slot(Slot &s)
     if (s.d_mp3) (void)hipFree(s.d_mp3);
     if (s.d_small) (void)hipFree(s.d_small);
     if (s.d_enc) (void)hipFree(s.d_enc);
-    for (hipEvent_t e : {s.e_start, s.e_up, s.e_huff, s.e_comp, s.e_down}) if (e) (void)hipEventDestroy(e);
+    for (hipEvent_t e : {s.e_start, s.e_up, s.e_huff, s.e_rate, s.e_comp, s.e_down}) if (e) (void)hipEventDestroy(e);
     s = Slot();
 }
 
@@ -403,6 +410,7 @@ int mp3s_pipe_create(mp3s_ctx *c, int depth, size_t max_job_bytes, int scan_thre
         if (P->s_up) (void)hipStreamDestroy(P->s_up);
         if (P->s_down) (void)hipStreamDestroy(P->s_down);
         if (P->s_huff) (void)hipStreamDestroy(P->s_huff);
+        if (P->s_tail) (void)hipStreamDestroy(P->s_tail);
         for (hipEvent_t e : P->e_dec) if (e) (void)hipEventDestroy(e);
         return fail(code, "%s", what);
     };
@@ -423,6 +431,16 @@ int mp3s_pipe_create(mp3s_ctx *c, int depth, size_t max_job_bytes, int scan_thre
         hipEventCreateWithFlags(&P->e_dec[0], hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&P->e_dec[1], hipEventDisableTiming) != hipSuccess)
         return destroy(MP3S_E_HIP, "stream creation failed");
+    // The tail stream is OFF unless MP3S_PIPE_TAIL=1.  On a resident batch fed through three contexts the arrangement is
+    // worth 5 % (bench.py, region (i): 0.829 -> 0.787 ms per step); in this pipe it measured slower at every priority, with
+    // and without making the next rate loop wait for the tail in front of it (0.89 - 1.25 against 0.83 ms per batch: with
+    // the copy streams and the front end there are then five streams at work, and every kernel of the two overlapping jobs
+    // stretches by half; tools/two_pipes_probe.py with MP3S_PIPE_TAIL / MP3S_PIPE_TAIL_PRIO / MP3S_PIPE_TAIL_THROTTLE).
+    const char *tp = getenv("MP3S_PIPE_TAIL_PRIO");
+    const int tail_prio = tp ? atoi(tp) : 0;
+    if (getenv("MP3S_PIPE_TAIL") && atoi(getenv("MP3S_PIPE_TAIL")) == 1 &&
+        hipStreamCreateWithPriority(&P->s_tail, hipStreamNonBlocking, tail_prio) != hipSuccess)
+        return destroy(MP3S_E_HIP, "stream creation failed");
     P->slots.resize((size_t)depth);
     for (auto &s : P->slots) {
         // main data: the file minus headers plus alignment and 8 zero bytes per frame; frames: 96 bytes is the smallest
@@ -439,7 +457,7 @@ int mp3s_pipe_create(mp3s_ctx *c, int depth, size_t max_job_bytes, int scan_thre
         if (hipHostMalloc((void **)&s.h_stage, s.stage_bytes, hipHostMallocDefault) != hipSuccess || hipMalloc((void **)&s.d_stage, s.stage_bytes) != hipSuccess ||
             hipMalloc((void **)&s.d_mp3, s.mp3_cap) != hipSuccess || hipMalloc((void **)&s.d_small, small_bytes(kMaxFastFiles)) != hipSuccess ||
             hipEventCreate(&s.e_start) != hipSuccess || hipEventCreate(&s.e_up) != hipSuccess || hipEventCreate(&s.e_huff) != hipSuccess ||
-            hipEventCreate(&s.e_comp) != hipSuccess ||
+            hipEventCreate(&s.e_comp) != hipSuccess || hipEventCreateWithFlags(&s.e_rate, hipEventDisableTiming) != hipSuccess ||
             // the collecting thread sleeps on this one instead of spinning: with one process per GPU on a shared host the
             // cores are needed by the scan workers (the wake-up latency disappears behind the jobs in flight)
             hipEventCreateWithFlags(&s.e_down, getenv("MP3S_PIPE_SPIN") ? hipEventDefault : hipEventBlockingSync) != hipSuccess)
@@ -463,10 +481,12 @@ void mp3s_pipe_destroy(mp3s_pipe *P)
     for (auto &t : P->workers) t.join();
     (void)hipSetDevice(P->c->device);
     (void)hipStreamSynchronize(P->s_up); (void)hipStreamSynchronize(P->s_huff); (void)hipStreamSynchronize(P->c->stream);
+    if (P->s_tail) (void)hipStreamSynchronize(P->s_tail);
     (void)hipStreamSynchronize(P->s_down);
     for (auto &j : P->inflight) if (j->slow_owner) mp3s_buf_free(j->slow_owner);
     for (auto &s : P->slots) free_slot(s);
     (void)hipStreamDestroy(P->s_up); (void)hipStreamDestroy(P->s_down); (void)hipStreamDestroy(P->s_huff);
+    if (P->s_tail) (void)hipStreamDestroy(P->s_tail);
     for (hipEvent_t e : P->e_dec) (void)hipEventDestroy(e);
     delete P;
 }
@@ -553,6 +573,7 @@ int mp3s_pipe_collect(mp3s_pipe *P, int64_t *ticket, mp3s_buf **owner, mp3s_file
                 std::lock_guard<std::mutex> gi(P->mu_issue);
                 // only the cursor / address guesses failed (a long message, a start the input's tables did not predict):
                 // the host resolves the chains on the job's own device buffers -- scan, decode and transforms stand
+                if (P->s_tail) (void)hipStreamSynchronize(P->s_tail);   // (later jobs' tails: the resolve below packs through the same context)
                 if (!j->decode && small[0] != 0 && small[1] == 0 && small[3] == 0) {
                     int passes = 0;
                     resolved = enc_resolve(P->c, j->L, j->segs, s.h_stage + s.o_in + (((size_t)j->n_total * sizeof(mp3s_frame_hdr) + 15) & ~(size_t)15),

@@ -27,7 +27,7 @@ def pump(pipe, k, out):
     out.append(ok)
 
 
-for n_pipes, depth, threads in ((1, 4, 3), (2, 3, 2), (2, 4, 3), (3, 3, 2)):
+for n_pipes, depth, threads in ((1, 4, 3), (2, 4, 3), (2, 3, 2), (3, 3, 2))[:int(os.environ.get("PROBE_CASES", "4"))]:
     ctxs = [_lib.Context(0) for _ in range(n_pipes)]
     pipes = [_lib.Pipe(c, depth=depth, max_job_bytes=len(mp3) + 65536, scan_threads=threads) for c in ctxs]
     for p in pipes:
