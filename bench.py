@@ -139,7 +139,7 @@ def main():
     d_si2 = [ctx.alloc(n * 4 * 72), ctx.alloc(n * 4 * 72)]
     d_hst2 = [ctx.alloc(16), ctx.alloc(16)]
     aux = None if args.no_overlap else _lib.Context(ctx.device)   # second stream on the same device
-    # third stream: the tail of batch k (chain check: two small launches, and the bit packer) runs under the decode
+    # third stream: the tail of batch k (selection, scatter, chain check: four small launches, and the bit packer) runs under the decode
     # transforms of batch k+1, as in the library's pipe (mp3s_pipe.cpp: s_tail) -- the small launches and their gaps are 5 %
     # of a step when they sit in front of the next batch (0.829 -> 0.785 ms per step)
     aux2 = _lib.Context(ctx.device) if not (args.no_tail_stream or args.no_overlap) else None
@@ -215,12 +215,13 @@ def main():
             front_end(aux, k + 1)
         if aux2 is not None:
             ctx.wait_for(aux2)                      # the packer of batch k-1 has read what the rate loop is about to overwrite
-        _lib.check(L.mp3s_rate_select_dev(ctx.handle, d_mdct, d_rf, n, d_hide, len(hide_all), d_cur, d_seg, d_spans, 1, max_reach,
-                                          d_eu, d_ec, n_ent, d_ix, d_out, d_en, d_ixv, d_outv, d_env))
+        _lib.check(L.mp3s_rate_variants_dev(ctx.handle, d_mdct, d_rf, n, d_hide, len(hide_all), d_cur, d_eu, d_ec, n_ent, d_ix, d_out, d_en,
+                                            d_ixv, d_outv, d_env))
         pk = ctx
         if aux2 is not None:
-            aux2.wait_for(ctx)                      # rate loop + selection of batch k are through: its tail goes on the third stream
+            aux2.wait_for(ctx)                      # the rate loop of batch k is through: its tail goes on the third stream
             pk = aux2
+        _lib.check(L.mp3s_select_dev(pk.handle, d_hide, d_cur, d_seg, d_spans, 1, max_reach, d_eu, d_ec, n_ent, d_ix, d_out, d_en, d_ixv, d_outv, d_env))
         _lib.check(L.mp3s_chain_resolve_dev(pk.handle, d_out, d_rf, n, d_seg, 1, d_cur, None, d_verdict, d_segout))
         _lib.check(L.mp3s_pack_frames_dev(pk.handle, d_ix, d_out, d_en, n, 44100, 128, d_off, d_pad, d_mp3, d_sc, d_pst))
 

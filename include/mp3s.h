@@ -263,6 +263,17 @@ int mp3s_rate_select_dev(mp3s_ctx *ctx, const int32_t *d_mdct, const mp3s_rate_f
                          const mp3s_select_span *d_spans, int n_segs, int max_reach, const int32_t *d_ent_unit,
                          const int32_t *d_ent_cursor, int n_entries, int16_t *d_ix, mp3s_gr_out *d_out, int32_t *d_en,
                          int16_t *d_ixv, mp3s_gr_out *d_outv, int32_t *d_env);
+/* The two halves of mp3s_rate_select_dev on their own, for callers that put the selection (two small launches) on another
+ * context's stream than the rate loop -- e.g. with the chain check and the bit packing under the decode transforms of the
+ * next batch (bench.py).  The caller orders the streams (mp3s_ctx_wait). */
+int mp3s_rate_variants_dev(mp3s_ctx *ctx, const int32_t *d_mdct, const mp3s_rate_frame *d_frames, int n_frames,
+                           const uint8_t *d_hide_bits, int n_hide, const int32_t *d_cursor, const int32_t *d_ent_unit,
+                           const int32_t *d_ent_cursor, int n_entries, int16_t *d_ix, mp3s_gr_out *d_out, int32_t *d_en,
+                           int16_t *d_ixv, mp3s_gr_out *d_outv, int32_t *d_env);
+int mp3s_select_dev(mp3s_ctx *ctx, const uint8_t *d_hide_bits, int32_t *d_cursor, const mp3s_chain_seg *d_segs,
+                    const mp3s_select_span *d_spans, int n_segs, int max_reach, const int32_t *d_ent_unit,
+                    const int32_t *d_ent_cursor, int n_entries, int16_t *d_ix, mp3s_gr_out *d_out, int32_t *d_en,
+                    int16_t *d_ixv, mp3s_gr_out *d_outv, int32_t *d_env);
 
 /* ---------------------------------------------------------------- (vi) bit-level stages on the device
  * The serial bit parsing / packing of the reference is serial per granule only: granule boundaries are known from

@@ -387,24 +387,49 @@ int mp3s_select_plan(const mp3s_chain_seg *segs, int n_segs, mp3s_select_span *s
     return used;
 }
 
+int mp3s_rate_variants_dev(mp3s_ctx *c, const int32_t *d_mdct, const mp3s_rate_frame *d_frames, int n_frames, const uint8_t *d_hide_bits,
+                           int n_hide, const int32_t *d_cursor, const int32_t *d_ent_unit, const int32_t *d_ent_cursor, int n_entries,
+                           int16_t *d_ix, mp3s_gr_out *d_out, int32_t *d_en, int16_t *d_ixv, mp3s_gr_out *d_outv, int32_t *d_env)
+{
+    if (!c || !d_mdct || !d_frames || !d_ix || !d_out || !d_en || !d_hide_bits || !d_cursor || !d_ent_unit || !d_ent_cursor || !d_ixv ||
+        !d_outv || !d_env)
+        return fail(MP3S_E_ARG, "null pointer");
+    if (n_frames <= 0 || n_hide < 32 || n_entries <= 0) return fail(MP3S_E_ARG, "bad sizes");
+    const RateVariantArgs va = {d_ent_unit, d_ent_cursor, n_entries, d_ixv, d_outv, d_env, (uint8_t *)(d_outv + n_entries)};
+    const int e = launch_rate(c->stream, d_mdct, d_frames, n_frames, d_hide_bits, n_hide, d_cursor, nullptr, nullptr, 0, d_ix, d_out, d_en,
+                              &c->prof, 0, 0, &va);
+    if (e) return fail(MP3S_E_HIP, "rate launch: %s", hipGetErrorString((hipError_t)e));
+    return MP3S_OK;
+}
+
+int mp3s_select_dev(mp3s_ctx *c, const uint8_t *d_hide_bits, int32_t *d_cursor, const mp3s_chain_seg *d_segs, const mp3s_select_span *d_spans,
+                    int n_segs, int max_reach, const int32_t *d_ent_unit, const int32_t *d_ent_cursor, int n_entries, int16_t *d_ix,
+                    mp3s_gr_out *d_out, int32_t *d_en, int16_t *d_ixv, mp3s_gr_out *d_outv, int32_t *d_env)
+{
+    if (!c || !d_ix || !d_out || !d_en || !d_hide_bits || !d_cursor || !d_segs || !d_spans || !d_ent_unit || !d_ent_cursor || !d_ixv ||
+        !d_outv || !d_env)
+        return fail(MP3S_E_ARG, "null pointer");
+    if (n_segs <= 0 || n_entries <= 0 || max_reach <= 0 || max_reach > MP3S_SELECT_MAX_REACH) return fail(MP3S_E_ARG, "bad sizes");
+    const RateVariantArgs va = {d_ent_unit, d_ent_cursor, n_entries, d_ixv, d_outv, d_env, (uint8_t *)(d_outv + n_entries)};
+    void *d_pairs = c->grab(29, (size_t)n_segs * max_reach * 8);
+    if (!d_pairs) return fail(MP3S_E_NOMEM, "hipMalloc failed for the selection scratch");
+    const int e = launch_select(c->stream, d_segs, d_spans, n_segs, max_reach, d_hide_bits, va, d_ix, d_en, d_out, d_cursor, d_pairs, &c->prof);
+    if (e) return fail(MP3S_E_HIP, "select launch: %s", hipGetErrorString((hipError_t)e));
+    return MP3S_OK;
+}
+
 int mp3s_rate_select_dev(mp3s_ctx *c, const int32_t *d_mdct, const mp3s_rate_frame *d_frames, int n_frames, const uint8_t *d_hide_bits,
                          int n_hide, int32_t *d_cursor, const mp3s_chain_seg *d_segs, const mp3s_select_span *d_spans, int n_segs,
                          int max_reach, const int32_t *d_ent_unit, const int32_t *d_ent_cursor, int n_entries, int16_t *d_ix,
                          mp3s_gr_out *d_out, int32_t *d_en, int16_t *d_ixv, mp3s_gr_out *d_outv, int32_t *d_env)
 {
-    if (!c || !d_mdct || !d_frames || !d_ix || !d_out || !d_en || !d_hide_bits || !d_cursor || !d_segs || !d_spans || !d_ent_unit ||
-        !d_ent_cursor || !d_ixv || !d_outv || !d_env)
-        return fail(MP3S_E_ARG, "null pointer");
-    if (n_frames <= 0 || n_hide < 32 || n_segs <= 0 || n_entries <= 0 || max_reach <= 0 || max_reach > MP3S_SELECT_MAX_REACH)
-        return fail(MP3S_E_ARG, "bad sizes");
-    const RateVariantArgs va = {d_ent_unit, d_ent_cursor, n_entries, d_ixv, d_outv, d_env, (uint8_t *)(d_outv + n_entries)};
-    int e = launch_rate(c->stream, d_mdct, d_frames, n_frames, d_hide_bits, n_hide, d_cursor, nullptr, nullptr, 0, d_ix, d_out, d_en,
-                        &c->prof, 0, 0, &va);
-    void *d_pairs = c->grab(29, (size_t)n_segs * max_reach * 8);
-    if (!d_pairs) return fail(MP3S_E_NOMEM, "hipMalloc failed for the selection scratch");
-    if (!e) e = launch_select(c->stream, d_segs, d_spans, n_segs, max_reach, d_hide_bits, va, d_ix, d_en, d_out, d_cursor, d_pairs, &c->prof);
-    if (e) return fail(MP3S_E_HIP, "rate / select launch: %s", hipGetErrorString((hipError_t)e));
-    return MP3S_OK;
+    if (!d_segs || !d_spans) return fail(MP3S_E_ARG, "null pointer");
+    if (n_segs <= 0 || max_reach <= 0 || max_reach > MP3S_SELECT_MAX_REACH) return fail(MP3S_E_ARG, "bad sizes");
+    const int rc = mp3s_rate_variants_dev(c, d_mdct, d_frames, n_frames, d_hide_bits, n_hide, d_cursor, d_ent_unit, d_ent_cursor, n_entries, d_ix,
+                                          d_out, d_en, d_ixv, d_outv, d_env);
+    if (rc) return rc;
+    return mp3s_select_dev(c, d_hide_bits, d_cursor, d_segs, d_spans, n_segs, max_reach, d_ent_unit, d_ent_cursor, n_entries, d_ix, d_out, d_en,
+                           d_ixv, d_outv, d_env);
 }
 
 int mp3s_chain_resolve_dev(mp3s_ctx *c, mp3s_gr_out *d_gr, const mp3s_rate_frame *d_frames, int n_frames, const mp3s_chain_seg *d_segs,
