@@ -1,9 +1,9 @@
 // Rate-loop kernel (gfx950).  Included by mp3s_device.hip only.
 //
 // One wavefront per granule*channel ("unit").  The 288 value pairs of the granule are spread over the
-// lanes (pair p = lane + 64*m, m = 0..4); every step of the reference's loop body is a lane-parallel
-// map plus a DPP wave reduction, and all control flow (binary search, inner loop, region split, table
-// choice, hide swap) is wave-uniform scalar code.
+// lanes (lane l holds the consecutive pairs 5l .. 5l+4); every step of the reference's loop body is a
+// lane-parallel map plus DPP wave reductions (independent ones written side by side), and all control
+// flow (binary search, inner loop, region split, table choice, hide swap) is wave-uniform scalar code.
 //   reference encoder/MP3_Encoder.py: __iteration_loop :760-815, __calc_scfsi energies :835-859,
 //   __bin_search_step_size :958-996, __inner_loop :1064-1095, quantize :373-415, calc_run_len :266-291,
 //   count1_bit_count :171-211, __subdivide :998-1036, __big_v_tab_select :1147-1168,
@@ -14,6 +14,7 @@
 
 namespace mp3s {
 
+// one DPP step of a wave reduction: lanes without a source read 0 (ctrl and row mask must be literals)
 #define RL_DPP(v, ctrl, rm) ((uint32_t)__builtin_amdgcn_update_dpp(0, (int)(v), ctrl, rm, 0xf, false))
 
 __device__ __forceinline__ uint32_t wave_max_u32(uint32_t v)
