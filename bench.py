@@ -81,8 +81,10 @@ def main():
                          "runs pass this so that the per-kernel averages of the trace describe the full-size launches)")
     ap.add_argument("--no-overlap", action="store_true",
                     help="run the Huffman front end of batch k+1 after, not under, the transform kernels of batch k")
-    ap.add_argument("--huffman-under", choices=("rate", "decode"), default="rate",
-                    help="where the Huffman decode of batch k+1 starts: under the rate loop of batch k, or under its decode transforms")
+    ap.add_argument("--huffman-under", choices=("rate", "decode"), default="decode",
+                    help="where the Huffman decode of batch k+1 starts: under the decode transforms of batch k (default since r02e: with the "
+                         "tail of batch k-1 on the third stream the step takes the same time either way, and the rate loop -- the kernel the "
+                         "roofline is computed from -- runs undisturbed), or under its rate loop (r02d and before)")
     ap.add_argument("--pack-overlap", action="store_true", help="(default since r02e; kept for old command lines)")
     ap.add_argument("--no-tail-stream", action="store_true", help="chain check and bit packing of batch k on the main stream instead of a third one")
     ap.add_argument("--resident-only", action="store_true", help="region (i) only (profiling runs)")
