@@ -37,12 +37,14 @@ __global__ __launch_bounds__(256) void k_enc_pack(
     __shared__ uint32_t fb3[3][PACK_DW];   // frame images, rotating: written / being copied out / being cleared
     __shared__ uint32_t hc[4][256];
     __shared__ uint8_t hl[4][256];
+    __shared__ uint8_t c1code[16], c1len[16];
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
     for (int i = threadIdx.x; i < 1024; i += 256) {
         (&hc[0][0])[i] = (&c_tab.hcod[0][0])[i];
         (&hl[0][0])[i] = i < 256 ? c_tab.hlen13[i] : (i < 512 ? c_tab.hlen15[i - 256] : (i < 768 ? c_tab.hlen16[i - 512] : c_tab.hlen24[i - 768]));
     }
     for (int i = threadIdx.x; i < 3 * PACK_DW; i += 256) (&fb3[0][0])[i] = 0;
+    if (threadIdx.x < 16) { c1code[threadIdx.x] = c_tab.hcod_c1a[threadIdx.x]; c1len[threadIdx.x] = c_tab.hlen_c1a[threadIdx.x]; }
     __syncthreads();
     int rot = 0;
     for (int f = blockIdx.x; f < n_frames; f += gridDim.x) {
@@ -147,50 +149,56 @@ __global__ __launch_bounds__(256) void k_enc_pack(
     for (int k = 0; k < 5; k++) c2[k] = (uint32_t)((xv[2 * k] & 1) | ((xv[2 * k + 1] & 1) << 1));   // (two's complement: the low bit of |v| is the low bit of v)
     c2[5] = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)c2[0], 0x130, 0xf, 0xf, false);              // wave_shl:1
     uint32_t code0[5], code1[5]; int n0[5], n1[5];
-    int tot = 0, bad = 0;
+    int tot = 0;
+    // What differs between the regions is wave-uniform: one scalar word per region -- Huffman-length family (books 13, 15,
+    // 16.., 24..) | linbits << 2 | "book in use" << 6 -- picked per lane; everything else is the same arithmetic for every
+    // pair, without a branch: the table word of (min(x,15), min(y,15)), the escape and sign bits (MP3_Encoder.py:1452-1500;
+    // books 13 and 15 have no linbits, so their value 15 emits none), and for a count1 pair the quadruple's code with its first
+    // pair (E13) and the signs of its own two values (:1502-1547).
+    uint32_t Kr[3];
+    bool any_bad = false;
+    {
+        const int tsr[3] = {ts0, ts1, ts2};
+#pragma unroll
+        for (int r = 0; r < 3; r++) {
+            const int ti = tsr[r];
+            const int fam = ti == 13 ? 0 : (ti == 15 ? 1 : (ti < 24 ? 2 : 3));
+            Kr[r] = ti ? (uint32_t)fam | ((uint32_t)lin_bits_of(ti) << 2) | (1u << 6) : 0u;
+            // a book this encoder never selects, in a region that holds pairs
+            const int lo = r == 0 ? 0 : (r == 1 ? r1s : r2s), hi = r == 0 ? r1s : (r == 1 ? r2s : 576);
+            any_bad |= ti != 0 && ti != 13 && ti != 15 && ti < 16 && lo < 2 * bv && lo < hi;
+        }
+    }
 #pragma unroll
     for (int k = 0; k < 5; k++) {
         const int p = lane * 5 + k;
         int x = xv[2 * k], y = xv[2 * k + 1];
         const uint32_t sx = x > 0 ? 0 : 1, sy = y > 0 ? 0 : 1;     // util.abs_and_sign: "sign" of 0 is 1, never emitted
         x = x < 0 ? -x : x; y = y < 0 ? -y : y;
-        code0[k] = code1[k] = 0; n0[k] = n1[k] = 0;
-        if (p < bv) {
-            const int i = 2 * p;
-            const int ti = i >= r2s ? ts2 : (i >= r1s ? ts1 : ts0);
-            if (ti) {
-                const int fam = ti == 13 ? 0 : (ti == 15 ? 1 : (ti < 16 ? -1 : (ti < 24 ? 2 : 3)));
-                if (fam < 0) bad = 1;
-                else if (ti > 15) {
-                    const int lb = lin_bits_of(ti);
-                    const int lbx = x > 14 ? x - 15 : 0, lby = y > 14 ? y - 15 : 0;
-                    const int xx = x > 14 ? 15 : x, yy = y > 14 ? 15 : y;
-                    code0[k] = hc[fam][xx * 16 + yy]; n0[k] = hl[fam][xx * 16 + yy];
-                    uint32_t ext = 0; int xb = 0;
-                    if (xx > 14) { ext |= (uint32_t)lbx; xb += lb; }
-                    if (xx != 0) { ext = (ext << 1) | sx; xb += 1; }
-                    if (yy > 14) { ext = (ext << lb) | (uint32_t)lby; xb += lb; }
-                    if (yy != 0) { ext = (ext << 1) | sy; xb += 1; }
-                    code1[k] = ext; n1[k] = xb;
-                } else {
-                    uint32_t c = hc[fam][x * 16 + y]; int nb = hl[fam][x * 16 + y];
-                    if (x != 0) { c = (c << 1) | sx; nb += 1; }
-                    if (y != 0) { c = (c << 1) | sy; nb += 1; }
-                    code0[k] = c; n0[k] = nb;
-                }
-            }
-        } else if (p < bv + 2 * c1) {
-            // count1 quadruple = this pair (v, w) + the next one (x, y); code word with the first pair (E13)
-            if (!((p - bv) & 1)) {
-                const int q = (int)(c2[k] | (c2[k + 1] << 2));
-                if (c1sel) { code0[k] = 15 - q; n0[k] = 4; }
-                else { code0[k] = c_tab.hcod_c1a[q]; n0[k] = c_tab.hlen_c1a[q]; }
-            }
-            uint32_t s = 0; int nb = 0;
-            if (x) { s = sx; nb = 1; }
-            if (y) { s = (s << 1) | sy; nb += 1; }
-            code1[k] = s; n1[k] = nb;
-        }
+        const int i = 2 * p;
+        const uint32_t K = i >= r2s ? Kr[2] : (i >= r1s ? Kr[1] : Kr[0]);
+        const bool in_bv = p < bv && (K >> 6) != 0;
+        const bool in_c1 = p >= bv && p < bv + 2 * c1;
+        const int lb = in_bv ? (int)((K >> 2) & 15u) : 0;
+        // escape and sign bits: [x - 15 in lb bits] [sign of x] [y - 15 in lb bits] [sign of y]
+        const bool ex = x > 14 && lb > 0, ey = y > 14 && lb > 0;
+        uint32_t ext = ex ? (uint32_t)(x - 15) : 0u;
+        int xb = ex ? lb : 0;
+        ext = x != 0 ? (ext << 1) | sx : ext; xb += x != 0 ? 1 : 0;
+        ext = ey ? (ext << lb) | (uint32_t)(y - 15) : ext; xb += ey ? lb : 0;
+        ext = y != 0 ? (ext << 1) | sy : ext; xb += y != 0 ? 1 : 0;
+        // the pair's own code word: big-value book, or the quadruple's code with the first pair of a quad
+        const int xx = x > 14 ? 15 : x, yy = y > 14 ? 15 : y;
+        const uint32_t tix = ((K & 3u) << 8) + (uint32_t)(xx * 16 + yy);
+        const uint32_t bc = (&hc[0][0])[tix]; const int bn = (&hl[0][0])[tix];
+        const int q = (int)((c2[k] | (c2[k + 1] << 2)) & 15u);
+        const uint32_t qc = c1sel ? (uint32_t)(15 - q) : (uint32_t)c1code[q];
+        const int qn = c1sel ? 4 : (int)c1len[q];
+        const bool quad = in_c1 && !((p - bv) & 1);
+        code0[k] = in_bv ? bc : (quad ? qc : 0u);
+        n0[k] = in_bv ? bn : (quad ? qn : 0);
+        code1[k] = (in_bv || in_c1) ? ext : 0u;
+        n1[k] = (in_bv || in_c1) ? xb : 0;
         tot += n0[k] + n1[k];
     }
     // exclusive prefix of the lanes' bit counts
@@ -220,7 +228,6 @@ __global__ __launch_bounds__(256) void k_enc_pack(
     }
     // stuffing with ones up to part2_3_length (:1433-1446)
     const int p23 = e == 0 ? p23v[0] : (e == 1 ? p23v[1] : (e == 2 ? p23v[2] : p23v[3]));
-    const bool any_bad = __ballot(bad != 0) != 0;
     if (huff_bits > p23 || any_bad) { if (lane == 0) atomicOr(&sync[1], any_bad ? MP3S_PS_BAD_TABLE : MP3S_PS_OVERFLOW); }
     else
         for (uint32_t s = ustart + huff_bits + 32u * lane; s < ustart + (uint32_t)p23; s += 64u * 32u) {
