@@ -45,3 +45,25 @@ def test_fast_synthesis_equals_exact_kernel(mlib, golden_dir, orc):
         assert f64.tobytes() == orc.decode(streams[4])["pcm"].tobytes()
     finally:
         ctx.close()
+
+
+def test_fast_decode_across_transform_chunks(mlib):
+    """A stream longer than one transform chunk (16 384 frames, one frame of halo in front of the second chunk) with the
+    guard inflated: the fix-up kernel recomputes flagged samples of both chunks from `is`, with the halo frame as priming."""
+    from synth_pcm import synth_pcm
+    ctx = mlib.Context(0)
+    try:
+        pcm = synth_pcm(17000, seed=77)
+        mp3 = bytes(ctx.encode_pcm(pcm, 44100, 128, None)["mp3"])
+        ctx.synth_mode(0.0)
+        exact = np.array(ctx.decode_stream(mp3, mlib.MP3S_PCM_I16)["pcm"])
+        for scale in (1.0, 1e5):
+            ctx.synth_mode(scale)
+            fast = np.array(ctx.decode_stream(mp3, mlib.MP3S_PCM_I16)["pcm"])
+            n_exact = ctx.synth_mode(1.0)
+            assert np.array_equal(fast, exact), scale
+            if scale > 1:
+                assert n_exact > 100000, n_exact          # a flood through the fix-up kernel, second chunk included
+        del exact, fast
+    finally:
+        ctx.close()
