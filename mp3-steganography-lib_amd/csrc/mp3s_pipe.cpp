@@ -456,8 +456,9 @@ int mp3s_pipe_create(mp3s_ctx *c, int depth, size_t max_job_bytes, int scan_thre
         s.mp3_cap = max_job_bytes + s.side_cap + 4096;
         if (hipHostMalloc((void **)&s.h_stage, s.stage_bytes, hipHostMallocDefault) != hipSuccess || hipMalloc((void **)&s.d_stage, s.stage_bytes) != hipSuccess ||
             hipMalloc((void **)&s.d_mp3, s.mp3_cap) != hipSuccess || hipMalloc((void **)&s.d_small, small_bytes(kMaxFastFiles)) != hipSuccess ||
-            hipEventCreate(&s.e_start) != hipSuccess || hipEventCreate(&s.e_up) != hipSuccess || hipEventCreate(&s.e_huff) != hipSuccess ||
-            hipEventCreate(&s.e_comp) != hipSuccess || hipEventCreateWithFlags(&s.e_rate, hipEventDisableTiming) != hipSuccess ||
+            // (only e_start and e_down are read as times; the ordering events carry no time stamps: 1 % per job)
+            hipEventCreate(&s.e_start) != hipSuccess || hipEventCreateWithFlags(&s.e_up, hipEventDisableTiming) != hipSuccess ||
+            hipEventCreateWithFlags(&s.e_huff, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&s.e_comp, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&s.e_rate, hipEventDisableTiming) != hipSuccess ||
             // the collecting thread sleeps on this one instead of spinning: with one process per GPU on a shared host the
             // cores are needed by the scan workers (the wake-up latency disappears behind the jobs in flight)
             hipEventCreateWithFlags(&s.e_down, getenv("MP3S_PIPE_SPIN") ? hipEventDefault : hipEventBlockingSync) != hipSuccess)
