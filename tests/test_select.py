@@ -156,10 +156,22 @@ def test_rate_select_entry_point(ctx, mlib):
             ctx.alloc(ne * 72 + ((ne + 15) & ~15)), ctx.alloc(ne * 88), ctx.alloc(16), ctx.alloc(2 * 80)]
     d_ix, d_out, d_en, d_ixv, d_outv, d_env, d_ver, d_so = outs
     try:
-        for _ in range(2):   # the second call finds the cursors the first one wrote (exact ones): same result
-            mlib.check(L.mp3s_rate_select_dev(ctx.handle, d_mdct, d_rf, n, d_hide, len(hide), d_cur, d_segs, d_spans, 2, max_reach,
-                                              d_eu, d_ec, ne, d_ix, d_out, d_en, d_ixv, d_outv, d_env))
-            mlib.check(L.mp3s_chain_resolve_dev(ctx.handle, d_out, d_rf, n, d_segs, 2, d_cur, None, d_ver, d_so))
+        ctx2 = mlib.Context(ctx.device)
+        for it in range(3):  # the second call finds the cursors the first one wrote (exact ones): same result
+            if it < 2:
+                mlib.check(L.mp3s_rate_select_dev(ctx.handle, d_mdct, d_rf, n, d_hide, len(hide), d_cur, d_segs, d_spans, 2, max_reach,
+                                                  d_eu, d_ec, ne, d_ix, d_out, d_en, d_ixv, d_outv, d_env))
+                mlib.check(L.mp3s_chain_resolve_dev(ctx.handle, d_out, d_rf, n, d_segs, 2, d_cur, None, d_ver, d_so))
+            else:
+                # the third time in two halves: the rate loop on this context, selection and chain check on another one's
+                # stream (what bench.py does with the tail of a batch)
+                mlib.check(L.mp3s_rate_variants_dev(ctx.handle, d_mdct, d_rf, n, d_hide, len(hide), d_cur, d_eu, d_ec, ne, d_ix, d_out,
+                                                    d_en, d_ixv, d_outv, d_env))
+                ctx2.wait_for(ctx)
+                mlib.check(L.mp3s_select_dev(ctx2.handle, d_hide, d_cur, d_segs, d_spans, 2, max_reach, d_eu, d_ec, ne, d_ix, d_out, d_en,
+                                             d_ixv, d_outv, d_env))
+                mlib.check(L.mp3s_chain_resolve_dev(ctx2.handle, d_out, d_rf, n, d_segs, 2, d_cur, None, d_ver, d_so))
+                ctx.wait_for(ctx2)
             gr = ctx.download(d_out, mlib.GR_OUT_DTYPE, (units,))
             ver = ctx.download(d_ver, np.int32, (2,))
             so = ctx.download(d_so, mlib.CHAIN_SEG_OUT_DTYPE, (2,))
@@ -179,3 +191,5 @@ def test_rate_select_entry_point(ctx, mlib):
     finally:
         for p in dev + outs:
             ctx.free(p)
+        if "ctx2" in locals():
+            ctx2.close()
