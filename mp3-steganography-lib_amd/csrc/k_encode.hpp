@@ -162,13 +162,29 @@ __global__ __launch_bounds__(256, 4) void k_enc_mdct(
         in[36 + j] = row[(18 + j) * 32];
     }
     int32_t *x0 = xs + ch * MD_BLK + band, *x1 = x0 + 2 * MD_BLK;   // block index = granule * 2 + channel
+    // The 36 coefficients of output k are one scalar batch (9 x s_load_dwordx4).  All scalar loads of a wave share one counter
+    // that can only be waited to zero, and the compiler waits where a value is first used: the batch of output k + 1 is
+    // therefore requested AFTER the first coefficient of batch k has been named (the wait: that batch was requested a whole
+    // output ago) and before its 72 multiply-adds, which then run with the next batch in flight.
+    struct Coef { i32x4 q[9]; };
+    auto load_coef = [&](int k) {
+        Coef c;
+        const i32x4 *crow = reinterpret_cast<const i32x4 *>(c_tab.cos_l[k]);
+#pragma unroll
+        for (int q = 0; q < 9; q++) c.q[q] = crow[q];
+        return c;
+    };
+    Coef cur = load_coef(0);
 #pragma unroll 2
     for (int k = 0; k < 18; k++) {
+        asm volatile("" ::"s"(cur.q[0].x));
+        __builtin_amdgcn_sched_barrier(0);
+        const Coef nxt = load_coef(k < 17 ? k + 1 : 17);
+        __builtin_amdgcn_sched_barrier(0);
         int32_t a0 = 0, a1 = 0;
-        const i32x4 *crow = reinterpret_cast<const i32x4 *>(c_tab.cos_l[k]);   // 36 coefficients = 9 x s_load_dwordx4
 #pragma unroll
         for (int q = 0; q < 9; q++) {
-            const i32x4 c = crow[q];
+            const i32x4 c = cur.q[q];
             a0 += mulhi_vs(in[4 * q], c.x);     a1 += mulhi_vs(in[18 + 4 * q], c.x);
             a0 += mulhi_vs(in[4 * q + 1], c.y); a1 += mulhi_vs(in[19 + 4 * q], c.y);
             a0 += mulhi_vs(in[4 * q + 2], c.z); a1 += mulhi_vs(in[20 + 4 * q], c.z);
@@ -176,6 +192,8 @@ __global__ __launch_bounds__(256, 4) void k_enc_mdct(
         }
         x0[k * MD_ROW] = a0;
         x1[k * MD_ROW] = a1;
+        __builtin_amdgcn_sched_barrier(0);
+        cur = nxt;
     }
     __builtin_amdgcn_s_waitcnt(0xc07f);
     __builtin_amdgcn_wave_barrier();
