@@ -231,19 +231,20 @@ int mp3s_chain_resolve_dev(mp3s_ctx *ctx, mp3s_gr_out *d_gr, const mp3s_rate_fra
                            int32_t *d_verdict, mp3s_chain_seg_out *d_seg_out);
 
 /* ---------------------------------------------------------------- (iv-c) the message cursor, decided on the device
- * replaces: the same __hide_str_offset chain (reference encoder/MP3_Encoder.py:808-809, :1154-1168) for the usual case
- *           of a short message in a long stream, without guessing: a unit sees the message only through the <= 3 bits at
- *           its cursor (__new_choose_table reads hide_str[offset] once per non-zero table, :1257-1263), so the first
+ * replaces: the same __hide_str_offset chain (reference encoder/MP3_Encoder.py:808-809, :1154-1168), without guessing:
+ *           a unit sees the message only through the <= 3 bits at its cursor (__new_choose_table reads hide_str[offset] once per non-zero table, :1257-1263), so the first
  *           `reach` units of a hiding stream are run once per possibility -- the 8 three-bit patterns, "two bits left",
  *           "one bit left" -- as extra entries of the SAME rate-loop launch, every unit's own run (cursor behind every
  *           message) being the eleventh, and a small kernel walks the chain and copies the entry each unit really sees
  *           into its place.  mp3s_chain_resolve_dev still checks the result; a stream whose message reaches further than
- *           the plan covered fails that check and is resolved by the host as before.
+ *           the plan covered fails that check and is resolved by the host as before.  The walk goes in rounds of 1 024
+ *           units with the state carried from round to round, so a plan may cover any length of message (r02f; until
+ *           then 2 048 units, about 700 message bytes).
  * The message array must start with the 32 pattern bytes of mp3s_select_patterns() (so hide_base >= 32), and d_cursor
  * must hold MP3S_NO_CURSOR for every unit of a planned stream before the call; the call overwrites the cursors of the
  * units it replaced with what they really saw (a later call with the same plan may find those there: they are exact). */
 #define MP3S_SELECT_VARIANTS 10
-#define MP3S_SELECT_MAX_REACH 2048
+#define MP3S_SELECT_MAX_REACH (1 << 18)
 #define MP3S_NO_CURSOR 0x3fffffff     /* "behind every message": such a unit hides nothing */
 typedef struct {
     int32_t first_entry;             /* entry (v, j) of the stream = first_entry + v * reach + j */

@@ -197,24 +197,32 @@ __global__ __launch_bounds__(CH_THREADS) void k_chain_apply(mp3s_gr_out *__restr
 
 // ---------------------------------------------------------------------------------------------------------------
 // The message cursor, decided on the device.  A unit sees the message only through the <= 3 bits at its cursor, so the
-// units a (short) message can reach are run once per possibility inside the rate-loop launch itself (RateVariants:
+// units a message can reach are run once per possibility inside the rate-loop launch itself (RateVariants:
 // the 8 three-bit patterns, "two bits left", "one bit left"; the launch's own run of the unit, with the cursor behind
 // every message, is the eleventh: "nothing left").  What remains is the serial part -- which possibility does unit j
 // see? -- and that is a composition of small maps: with d = 3j - (cursor - start) (the tables the units so far fell
-// short of three each, 0 <= d < 128), unit j maps d to d + 3 - tables(j, possibility at that cursor).  One workgroup
-// per stream keeps two byte arrays in LDS -- the possibility at every cursor position, the table count of every
-// (possibility, unit) -- and its 16 waves compose a chunk of units each (a lane carries d = lane and d = lane + 64
-// through the chunk: two LDS reads per unit and state); the chunk totals give every chunk its starting d, a second walk
-// gives every unit its d, and the entry each unit takes goes into a list that k_scatter_entries (many workgroups: one
-// compute unit alone copies too slowly) works off.  cursor[] receives what each unit really saw, for the check in
-// k_chain_apply, which stays the judge: a stream the plan did not cover (the message reached further, d left its
-// range) is simply left as it was and fails that check.
+// short of three each), unit j maps d to d + 3 - tables(j, possibility at that cursor).  One workgroup
+// per stream works through the planned units in rounds of SEL_ROUND: it keeps two byte arrays of the round in LDS -- the
+// possibility at every cursor position the round can see, the table count of every (possibility, unit) -- and its 16
+// waves compose a chunk of units each (a lane carries the states lane and lane + 64 through the chunk: two LDS reads per
+// unit and state); the chunk totals give every chunk its starting state, a second walk gives every unit its own, and the
+// last chunk's end is the exact d the next round starts from: the states of a round are d RELATIVE to that (0 <= d - d0 <
+// 128), so the reach of a plan is not limited by LDS or by the total the chain falls short of (until r02e: one round of
+// at most 2 048 units, absolute d).  A round whose chain leaves that range all the same -- a silence: such units take no
+// table and d grows by three with each -- is done again in rounds of SEL_SAFE units, which cannot leave it (3 x 32 < 128),
+// up to the next multiple of SEL_ROUND.  The entry each unit takes goes into
+// a list that k_scatter_entries (many workgroups: one compute unit alone copies too slowly) works off.  cursor[] receives
+// what each unit really saw, for the check in k_chain_apply, which stays the judge: a stream the plan did not cover (the
+// message reached further than the planned units) fails that check.
 constexpr int SEL_THREADS = 1024, SEL_WAVES = SEL_THREADS / 64, SEL_D = 128;
+constexpr int SEL_ROUND = SEL_THREADS;           // units per round
+constexpr int SEL_SAFE = 32;                     // ... of a stretch where d grows faster than a round of SEL_ROUND can follow
 constexpr int SEL_NONE = MP3S_SELECT_VARIANTS;   // index of "the unit's own run" in the per-unit table counts
 
 __host__ __device__ inline size_t select_lds_bytes(int reach)
 {
-    return (size_t)reach * (SEL_NONE + 1) + (size_t)(3 * reach + 8) + (size_t)reach + SEL_WAVES * SEL_D + 64;
+    const int rs = reach < SEL_ROUND ? reach : SEL_ROUND;
+    return (size_t)rs * (SEL_NONE + 1) + (size_t)(3 * rs + SEL_D + 8) + (size_t)rs + SEL_WAVES * SEL_D + 64;
 }
 
 // pairs: int2 [n_segs][max_reach] = (entry or -1, unit) for k_scatter_entries
@@ -224,7 +232,7 @@ __global__ __launch_bounds__(SEL_THREADS) void k_chain_select(const mp3s_chain_s
                                                               int32_t *__restrict__ cursor, int2 *__restrict__ pairs)
 {
     extern __shared__ uint8_t sel_lds[];
-    __shared__ int overflow;
+    __shared__ int overflow, d_next, d_try, sat_round;
     const int s = blockIdx.x;
     const mp3s_select_span sp = spans[s];
     const int R = sp.reach;
@@ -237,60 +245,87 @@ __global__ __launch_bounds__(SEL_THREADS) void k_chain_select(const mp3s_chain_s
     const mp3s_chain_seg sg = segs[s];
     const long c0 = sg.hide_begin, end = sg.hide_end;
     const long u0 = (long)sg.first_frame * 4;
-    uint8_t *tabs = sel_lds;                                  // [11][R]: table counts of the entries, [10] = the unit's own run
-    uint8_t *code = tabs + (size_t)R * (SEL_NONE + 1);        // [3R + 8]: the possibility a unit sees with its cursor at start + p
-    uint8_t *delta = code + 3 * R + 8;                        // [R]
-    uint8_t *tot = delta + R;                                 // [16][128]
-    if (tid == 0) overflow = 0;
-    for (int i = tid; i < R * SEL_NONE; i += SEL_THREADS) tabs[i] = tabv[sp.first_entry + i];
-    for (int j = tid; j < R; j += SEL_THREADS) tabs[SEL_NONE * R + j] = (uint8_t)out[u0 + j].n_tables;
-    for (int p = tid; p < 3 * R + 8; p += SEL_THREADS) {
-        const long cur = c0 + p;
-        int v = SEL_NONE;
-        if (cur + 3 <= end) v = (hide[cur] & 1) * 4 + (hide[cur + 1] & 1) * 2 + (hide[cur + 2] & 1);
-        else if (cur == end - 2) v = 8;
-        else if (cur == end - 1) v = 9;
-        code[p] = (uint8_t)v;
-    }
-    __syncthreads();
-    // unit j, state d -> the next state (d stays once the cursor is behind the message: it no longer matters there, and
-    // the cursor 3j - d only moves on); states the chain cannot be in (cursor in front of the start) stay too
-    auto step = [&](int j, int d) -> int {
-        const int rel = 3 * j - d;
-        if (rel < 0) return d;
-        const int v = code[rel];
-        return v == SEL_NONE ? d : min(d + 3 - (int)tabs[v * R + j], SEL_D - 1);
-    };
-    const int chunk = (R + SEL_WAVES - 1) / SEL_WAVES, j0 = wave * chunk, j1 = min(R, j0 + chunk);
-    {
-        int m0 = lane, m1 = lane + 64;
-        for (int j = j0; j < j1; j++) { m0 = step(j, m0); m1 = step(j, m1); }
-        tot[wave * SEL_D + lane] = (uint8_t)m0;
-        tot[wave * SEL_D + 64 + lane] = (uint8_t)m1;
-    }
-    __syncthreads();
-    {
-        int d = 0;
-        for (int w = 0; w < wave; w++) d = tot[w * SEL_D + d];
-        bool sat = false;
-        for (int j = j0; j < j1; j++) {
-            if (lane == 0) delta[j] = (uint8_t)d;
-            sat |= d >= SEL_D - 1;
-            d = step(j, d);
+    const int RS = min(R, SEL_ROUND);                         // row length of the LDS arrays
+    uint8_t *tabs = sel_lds;                                  // [11][RS]: table counts of the entries, [10] = the unit's own run
+    uint8_t *code = tabs + (size_t)RS * (SEL_NONE + 1);       // [3RS + 128 + 8]: the possibility a unit sees with its cursor at start + rel0 + p
+    uint8_t *delta = code + 3 * RS + SEL_D + 8;               // [RS]: d - d0 in front of every unit
+    uint8_t *tot = delta + RS;                                // [16][128]
+    if (tid == 0) { overflow = 0; d_next = 0; }
+    int size = SEL_ROUND;
+    for (int J = 0; J < R;) {
+        __syncthreads();                                      // (the round before is through with the arrays; d_next is there)
+        if (tid == 0) sat_round = 0;
+        const int Rs = min(size, R - J);
+        const int d0 = d_next;
+        const long rel0 = 3L * J - d0 - (SEL_D - 1);          // the lowest cursor position (from the start) a state of this round can be at
+        if (c0 + rel0 >= end) {                               // the chain is behind the message: nothing to replace from here on
+            for (int jj = tid; jj < Rs; jj += SEL_THREADS) my_pairs[J + jj] = make_int2(-1, 0);
+            J += Rs;
+            continue;
         }
-        if (sat && lane == 0) overflow = 1;
+        for (int v = 0; v < SEL_NONE; v++)
+            for (int jj = tid; jj < Rs; jj += SEL_THREADS) tabs[v * RS + jj] = tabv[sp.first_entry + (long)v * R + J + jj];
+        for (int jj = tid; jj < Rs; jj += SEL_THREADS) tabs[SEL_NONE * RS + jj] = (uint8_t)out[u0 + J + jj].n_tables;
+        for (int p = tid; p < 3 * Rs + SEL_D + 8; p += SEL_THREADS) {
+            const long rel = rel0 + p, cur = c0 + rel;
+            int v = SEL_NONE;                                 // (also: in front of the start, where the chain cannot be)
+            if (rel >= 0) {
+                if (cur + 3 <= end) v = (hide[cur] & 1) * 4 + (hide[cur + 1] & 1) * 2 + (hide[cur + 2] & 1);
+                else if (cur == end - 2) v = 8;
+                else if (cur == end - 1) v = 9;
+            }
+            code[p] = (uint8_t)v;
+        }
+        __syncthreads();
+        // unit J + jj, state d (relative) -> the next state (d stays once the cursor is behind the message: it no longer
+        // matters there, and the cursor only moves on); states the chain cannot be in stay too
+        auto step = [&](int jj, int d) -> int {
+            const int v = code[3 * jj + (SEL_D - 1) - d];
+            return v == SEL_NONE ? d : min(d + 3 - (int)tabs[v * RS + jj], SEL_D - 1);
+        };
+        const int chunk = (Rs + SEL_WAVES - 1) / SEL_WAVES, j0 = wave * chunk, j1 = min(Rs, j0 + chunk);
+        {
+            int m0 = lane, m1 = lane + 64;
+            for (int jj = j0; jj < j1; jj++) { m0 = step(jj, m0); m1 = step(jj, m1); }
+            tot[wave * SEL_D + lane] = (uint8_t)m0;
+            tot[wave * SEL_D + 64 + lane] = (uint8_t)m1;
+        }
+        __syncthreads();
+        {
+            int d = 0;
+            for (int w = 0; w < wave; w++) d = tot[w * SEL_D + d];
+            bool sat = false;
+            for (int jj = j0; jj < j1; jj++) {
+                if (lane == 0) delta[jj] = (uint8_t)d;
+                sat |= d >= SEL_D - 1;
+                d = step(jj, d);
+            }
+            if (sat && lane == 0) sat_round = 1;
+            if (wave == SEL_WAVES - 1 && lane == 0) d_try = d0 + d;   // (a wave without units of its own walks nothing)
+        }
+        __syncthreads();
+        if (sat_round) {
+            if (size > SEL_SAFE) { size = SEL_SAFE; continue; }   // the same units again, a few at a time
+            if (tid == 0) overflow = 1;                           // (cannot happen: 3 x SEL_SAFE < SEL_D)
+        }
+        for (int jj = tid; jj < Rs; jj += SEL_THREADS) {
+            const int p = 3 * jj + (SEL_D - 1) - (int)delta[jj];
+            const int v = code[p];
+            // (entry, cursor position from the start) for now: the unit number goes in once the whole plan held
+            my_pairs[J + jj] = v == SEL_NONE ? make_int2(-1, 0) : make_int2(sp.first_entry + v * R + J + jj, (int)(rel0 + p));
+        }
+        if (tid == 0) d_next = d_try;
+        J += Rs;
+        if (size == SEL_SAFE && J % SEL_ROUND == 0) size = SEL_ROUND;
     }
     __syncthreads();
     const bool bad = overflow != 0;
     for (int j = tid; j < max_reach; j += SEL_THREADS) {
         int src = -1;
         if (j < R && !bad) {
-            const int rel = 3 * j - (int)delta[j];
-            const int v = rel < 0 ? SEL_NONE : (int)code[rel];
-            if (v != SEL_NONE) {
-                src = sp.first_entry + v * R + j;
-                cursor[u0 + j] = (int32_t)(c0 + rel);
-            }
+            const int2 pr = my_pairs[j];
+            src = pr.x;
+            if (src >= 0) cursor[u0 + j] = (int32_t)(c0 + pr.y);
         }
         my_pairs[j] = make_int2(src, (int)(u0 + j));
     }

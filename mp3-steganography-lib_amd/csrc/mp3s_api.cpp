@@ -370,6 +370,14 @@ void mp3s_select_patterns(uint8_t out[32])
 
 int mp3s_select_plan(const mp3s_chain_seg *segs, int n_segs, mp3s_select_span *spans, int32_t *ent_unit, int32_t *ent_cursor, int cap)
 {
+    return select_plan(segs, n_segs, spans, ent_unit, ent_cursor, cap, nullptr);
+}
+
+}  // extern "C"
+
+int select_plan(const mp3s_chain_seg *segs, int n_segs, mp3s_select_span *spans, int32_t *ent_unit, int32_t *ent_cursor, int cap,
+                const int32_t *min_reach)
+{
     if (!segs || !spans || n_segs <= 0 || cap < 0 || ((ent_unit == nullptr) != (ent_cursor == nullptr))) return fail(MP3S_E_ARG, "bad argument");
     int used = 0;
     for (int i = 0; i < n_segs; i++) {
@@ -378,14 +386,17 @@ int mp3s_select_plan(const mp3s_chain_seg *segs, int n_segs, mp3s_select_span *s
         const int64_t left = (int64_t)g.hide_end - g.hide_begin;
         if (left <= 0 || g.n_frames <= 0 || g.hide_base < 32) continue;
         // units the rest of the message can reach at 2.8 tables per unit (measured on music: 2.96), and some
-        const int64_t reach = std::min<int64_t>((int64_t)g.n_frames * 4, left * 5 / 14 + 32);
-        if (reach > MP3S_SELECT_MAX_REACH || used + reach * MP3S_SELECT_VARIANTS > cap) continue;
+        // ... or as far as the caller expects it to get (a stream that starts in silence offers no tables for a while)
+        const int64_t reach = std::min<int64_t>((int64_t)g.n_frames * 4, std::max<int64_t>(left * 5 / 14 + 32, min_reach ? min_reach[i] : 0));
+        if (reach > MP3S_SELECT_MAX_REACH || (int64_t)used + reach * MP3S_SELECT_VARIANTS > cap) continue;
         spans[i].reach = (int32_t)reach;
         if (ent_unit) select_entries(g.first_frame * 4, (int)reach, used, g.hide_end, ent_unit, ent_cursor);
         used += (int)reach * MP3S_SELECT_VARIANTS;
     }
     return used;
 }
+
+extern "C" {
 
 int mp3s_rate_variants_dev(mp3s_ctx *c, const int32_t *d_mdct, const mp3s_rate_frame *d_frames, int n_frames, const uint8_t *d_hide_bits,
                            int n_hide, const int32_t *d_cursor, const int32_t *d_ent_unit, const int32_t *d_ent_cursor, int n_entries,

@@ -176,7 +176,7 @@ int launch_select(hipStream_t stream, const mp3s_chain_seg *d_segs, const mp3s_s
                   void *d_pairs, Profiler *prof)
 {
     if (n_segs <= 0 || max_reach <= 0 || v.n <= 0) return 0;
-    if (max_reach > MP3S_SELECT_MAX_REACH) return (int)hipErrorInvalidValue;
+    if (max_reach > MP3S_SELECT_MAX_REACH || (int64_t)n_segs * max_reach > 0x3fffffff) return (int)hipErrorInvalidValue;
     const int pp = prof ? prof->begin(stream, K_CHAIN) : -1;
     hipLaunchKernelGGL(k_chain_select, dim3(n_segs), dim3(SEL_THREADS), select_lds_bytes(max_reach), stream, d_segs, d_spans, max_reach,
                        d_hide, (const uint8_t *)v.d_tables, (const mp3s_gr_out *)d_out, d_cursor, (int2 *)d_pairs);

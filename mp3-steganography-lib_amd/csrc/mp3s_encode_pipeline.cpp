@@ -10,7 +10,7 @@ static int64_t cursor0(const EncSeg &s)
     return s.carry_in ? std::min<int64_t>(std::max<int64_t>(s.carry_in->cursor, 0), kNoCursor) : 0;
 }
 
-static bool select_disabled() { static const bool off = getenv("MP3S_NO_SELECT") != nullptr; return off; }
+static bool select_disabled() { return getenv("MP3S_NO_SELECT") != nullptr; }   // (read per batch: tests switch it)
 
 int enc_layout(std::vector<EncSeg> &segs, int samplerate, int bitrate_kbps, EncLayout &L)
 {
@@ -47,8 +47,25 @@ int enc_layout(std::vector<EncSeg> &segs, int samplerate, int bitrate_kbps, EncL
         cs[si].first_frame = s.first; cs[si].n_frames = s.n_frames; cs[si].hide_base = s.hide_base;
         cs[si].hide_begin = (int32_t)((int64_t)s.hide_base + cursor0(s)); cs[si].hide_end = s.hide_base + s.n_hide;
     }
-    const int budget = select_disabled() ? 0 : std::max(L.units / 2, 8192);
-    L.n_entries = mp3s_select_plan(cs.data(), L.n_segs, spans.data(), nullptr, nullptr, budget);
+    // every unit a message can reach costs MP3S_SELECT_VARIANTS entries (1.3 KB each in HBM, one more wave of the rate
+    // loop); the alternative for a stream left out is the host walking its chains pass by pass, which costs more at any
+    // length, so the only limit is memory: 8 GB of entries
+    const int budget = select_disabled() ? 0 : (int)std::min<int64_t>((int64_t)L.units * MP3S_SELECT_VARIANTS, 6000000);
+    // how far the message gets is a question of the tables the units in front offer: 2.8 per unit on music, none in silence
+    // (the first seconds of many a file).  Where the stream being re-encoded is known, its own table counts say how many
+    // units that takes (hiding takes a table away here and there: 1/16 more, and some)
+    std::vector<int32_t> min_reach(segs.size(), 0);
+    for (size_t si = 0; si < segs.size(); si++) {
+        const EncSeg &s = segs[si];
+        const int64_t left = (int64_t)cs[si].hide_end - cs[si].hide_begin;
+        if (!s.tables_guess || left <= 0) continue;
+        const int64_t need = left + left / 16 + 48;
+        int64_t offered = 0;
+        int j = 0;
+        while (j < s.n_frames * 4 && offered < need) offered += s.tables_guess[j++];
+        min_reach[si] = (int32_t)std::min<int64_t>((int64_t)s.n_frames * 4, (int64_t)j + 32);
+    }
+    L.n_entries = select_plan(cs.data(), L.n_segs, spans.data(), nullptr, nullptr, budget, min_reach.data());
     L.max_reach = 0;
     for (size_t si = 0; si < segs.size(); si++) {
         segs[si].reach = spans[si].reach; segs[si].first_entry = spans[si].first_entry;

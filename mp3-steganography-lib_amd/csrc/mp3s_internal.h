@@ -284,4 +284,7 @@ int encode_batch(mp3s_ctx *c, const int16_t *pcm, const int16_t *pcm_dev, std::v
                  mp3s_buf *b, int *passes_out, bool want_gr = true);
 // non-zero table indices per unit of a scanned stream, in the encoder's unit order (frame, channel, granule): see
 // EncSeg::tables_guess; `extra` more frames (the repeated last frame of a stream that ends in a bad header) repeat the last
+// mp3s_select_plan with a lower limit for each stream's reach (nullptr: none)
+int select_plan(const mp3s_chain_seg *segs, int n_segs, mp3s_select_span *spans, int32_t *ent_unit, int32_t *ent_cursor, int cap,
+                const int32_t *min_reach);
 void tables_guess_of(const mp3s_frame_side *side, long n_frames, int extra, std::vector<uint8_t> &out);

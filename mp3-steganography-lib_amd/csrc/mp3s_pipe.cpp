@@ -447,7 +447,7 @@ int mp3s_pipe_create(mp3s_ctx *c, int depth, size_t max_job_bytes, int scan_thre
         // Layer III frame (32 kbit/s at 48 kHz); anything denser (false syncs) overflows the sink and takes the other path
         s.blob_cap = (max_job_bytes + max_job_bytes / 8 + 4096 + 15) & ~(size_t)15;
         s.side_cap = max_job_bytes / 96 + 16;
-        s.in_cap = (s.side_cap * (72 + 16) + max_job_bytes / 4 + (size_t)kMaxFastFiles * (sizeof(mp3s_chain_seg) + sizeof(mp3s_select_span)) + 8192 * 8 + 4096 + 15) & ~(size_t)15;   // (+ variant entries: at most 2 per frame or 8192, 8 bytes each)
+        s.in_cap = (s.side_cap * (72 + 16) + max_job_bytes / 4 + (size_t)kMaxFastFiles * (sizeof(mp3s_chain_seg) + sizeof(mp3s_select_span)) + s.side_cap * 4 * MP3S_SELECT_VARIANTS * 8 + 4096 + 15) & ~(size_t)15;   // (+ variant entries: at most 10 per unit, 8 bytes each)
         s.o_side = s.blob_cap;
         s.o_in = (s.o_side + s.side_cap * sizeof(mp3s_frame_side) + 15) & ~(size_t)15;
         s.fix_cap = std::min<size_t>(kMaxFastFiles, s.side_cap);

@@ -13,15 +13,16 @@ def test_plan_layout_and_limits(mlib):
     pat = mlib.select_patterns()
     assert pat.tolist() == [b for v in range(8) for b in ((v >> 2) & 1, (v >> 1) & 1, v & 1, 0)]
     segs = np.zeros(5, dtype=mlib.CHAIN_SEG_DTYPE)
-    #          plain         not hiding      message too long for a plan   short stream      continuing block, 5 bits left
+    #          plain         not hiding      too many entries for the capacity   short stream      continuing block, 5 bits left
     segs["first_frame"] = [0, 100, 150, 9000, 9010]
     segs["n_frames"] = [100, 50, 8850, 10, 40]
     segs["hide_base"] = [32, 132, 132, 100132, 100232]
     segs["hide_begin"] = [32, 132, 132, 100132, 100232 + 995]
     segs["hide_end"] = [132, 132, 100132, 100232, 100232 + 1000]
-    spans, unit, cursor = mlib.select_plan(segs, 1 << 20)
+    spans, unit, cursor = mlib.select_plan(segs, 1 << 18)            # (stream 2 would take 35 400 units x 10 entries)
     reach0 = 100 * 5 // 14 + 32
     assert spans["reach"].tolist() == [reach0, 0, 0, 40, 5 * 5 // 14 + 32]
+    assert mlib.select_plan(segs, 1 << 20)[0]["reach"].tolist() == [reach0, 0, 35400, 40, 5 * 5 // 14 + 32]
     assert spans["first_entry"].tolist()[:1] == [0] and spans["first_entry"][3] == reach0 * 10
     assert len(unit) == (reach0 + 40 + 33) * 10
     # variant-major: entry (v, j) = first_entry + v * reach + j; patterns at 4v, then the message's own last two bits / last bit
@@ -42,10 +43,16 @@ def test_plan_layout_and_limits(mlib):
 def test_plan_reach_limit(mlib):
     segs = np.zeros(1, dtype=mlib.CHAIN_SEG_DTYPE)
     segs["n_frames"], segs["hide_base"], segs["hide_begin"] = 100000, 32, 32
-    for bits, planned in ((5000, True), (5647, True), (5648, False), (50000, False)):   # bits * 5 // 14 + 32 <= 2048
+    # bits * 5 // 14 + 32 <= MP3S_SELECT_MAX_REACH = 1 << 18 (the selection works in rounds: LDS does not limit the reach)
+    for bits, planned in ((5000, True), (5648, True), (50000, True), (733916, True), (733919, False)):
         segs["hide_end"] = 32 + bits
         reach = int(mlib.select_plan(segs, 1 << 22)[0]["reach"][0])
-        assert (reach > 0) == planned and reach <= 2048, (bits, reach)
+        assert (reach > 0) == planned and reach <= 1 << 18, (bits, reach)
+        if planned:
+            assert reach == bits * 5 // 14 + 32
+    # ... and never past the end of the stream
+    segs["n_frames"], segs["hide_end"] = 1000, 32 + 50000
+    assert int(mlib.select_plan(segs, 1 << 22)[0]["reach"][0]) == 4000
 
 
 # ------------------------------------------------------------------------------------------------ the selection (GPU)
@@ -62,6 +69,23 @@ def test_short_messages_every_ending(ctx, mlib, orc):
         assert o["rc"] == 0 and r["mp3"] == o["mp3"], nbits
         assert r["hide_offset"] == o["hide_offset"] and r["too_long"] == bool(o["too_long"]), nbits
         assert r["rate_passes"] == 1, nbits                          # decided on the device: the first pass was final
+
+
+@pytest.mark.gpu
+def test_long_messages_in_rounds(ctx, mlib, orc):
+    """messages whose reach takes several rounds of the selection (1 024 units each, the state carried from round to
+    round): final after the first pass; silences that one round can absorb; a message that fills the stream"""
+    from synth_pcm import synth_pcm
+    pcm = synth_pcm(900, seed=35)
+    pcm[150 * 1152:155 * 1152] = 0                                    # 20 silent units in round 0, 24 in round 2
+    pcm[600 * 1152:606 * 1152] = 0
+    rng = np.random.default_rng(12)
+    for nbits in (2900, 3100, 6000, 9001, 20000):
+        msg = rng.integers(0, 2, size=nbits).astype(np.uint8)
+        r, o = ctx.encode_pcm(pcm, 44100, 128, msg), orc.encode(pcm, 44100, 128, msg)
+        assert o["rc"] == 0 and r["mp3"] == o["mp3"], nbits
+        assert r["hide_offset"] == o["hide_offset"] and r["too_long"] == bool(o["too_long"]), nbits
+        assert r["rate_passes"] == 1, nbits
 
 
 @pytest.mark.gpu
