@@ -9,8 +9,9 @@ Three timed regions, all on the same 10 000-frame stream
   (i)   `value`: one step = one batch through the whole DEVICE pipeline, inputs resident in HBM (MP3 main data + parsed
         side info, what the host scan uploads): Huffman decode -> decode transforms -> int16 PCM -> encode transforms ->
         rate loop with the message's variants in the same launch -> cursor chain decided on the device (mp3s_rate_select_dev)
-        -> chain check on the device (mp3s_chain_resolve_dev: nothing about the serial chains is precomputed outside the
-        timed region, nothing is guessed) -> bit packing.  K steps, wall clock between barriers.
+        -> chain check on the device, with the re-runs it asks for and the check behind them (mp3s_chain_redo_dev, as the
+        library's own encoder issues it: nothing about the serial chains is precomputed outside the timed region, nothing is
+        guessed) -> bit packing.  K steps, wall clock between barriers.
   (ii)  `regions.h2d_kernels_d2h`: the same batch from page-locked host staging: upload + kernels + download, one batch at
         a time (pipe of depth 1; HIP events from the first uploaded byte to the last downloaded one), averaged.
   (iii) `e2e_steady`: MP3 bytes -> MP3 bytes through the asynchronous host-fed pipeline (mp3s_pipe_*: host scan on worker
@@ -155,7 +156,8 @@ def main():
     units = n * 4
     d_pcm = ctx.alloc(n * 2304 * 2)
     d_pcm32 = ctx.alloc(n * 2304 * 4)
-    d_mdct = ctx.alloc(n * 2304 * 4)
+    d_mdct2 = [ctx.alloc(n * 2304 * 4), ctx.alloc(n * 2304 * 4)]   # (the tail of batch k may read its spectra while batch k + 1 writes its own)
+    d_mdct = d_mdct2[0]
     d_ix = ctx.alloc(n * 2304 * 2)
     d_out = ctx.alloc(units * 72)
     d_en = ctx.alloc(units * 22 * 4)
@@ -211,6 +213,7 @@ def main():
             aux.wait_for(ctx)                       # batch k-1 is through: its Huffman outputs may be overwritten
             front_end(aux, k + 1)
         _lib.check(L.mp3s_decode_transform_dev(ctx.handle, d_is2[b], d_si2[b], d_hdr, n, 2, 0, _lib.MP3S_PCM_I16, d_pcm))
+        d_mdct = d_mdct2[b]
         _lib.check(L.mp3s_encode_transform_dev(ctx.handle, d_pcm, d_hdr, n, d_mdct))
         if aux is not None and not state.get("last") and args.huffman_under == "rate":
             aux.wait_for(ctx)                       # decode(k-1) has read its inputs; start under the rate loop, the longest kernel
@@ -224,7 +227,7 @@ def main():
             aux2.wait_for(ctx)                      # the rate loop of batch k is through: its tail goes on the third stream
             pk = aux2
         _lib.check(L.mp3s_select_dev(pk.handle, d_hide, d_cur, d_seg, d_spans, 1, max_reach, d_eu, d_ec, n_ent, d_ix, d_out, d_en, d_ixv, d_outv, d_env))
-        _lib.check(L.mp3s_chain_resolve_dev(pk.handle, d_out, d_rf, n, d_seg, 1, d_cur, None, d_verdict, d_segout))
+        _lib.check(L.mp3s_chain_redo_dev(pk.handle, d_mdct, d_rf, n, d_hide, len(hide_all), d_cur, d_seg, 1, d_ix, d_out, d_en, d_verdict, d_segout))
         _lib.check(L.mp3s_pack_frames_dev(pk.handle, d_ix, d_out, d_en, n, 44100, 128, d_off, d_pad, d_mp3, d_sc, d_pst))
 
     def barrier():

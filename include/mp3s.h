@@ -89,7 +89,7 @@ typedef struct {
     int32_t address[3];     /* address1/2/3 as left behind (persist per (gr,ch) across frames) */
     int32_t n_tables;       /* number of non-zero table_select: advance of the hide cursor (:808-809) */
     int32_t flags;          /* MP3S_RF_* */
-    int32_t reserved0;
+    int32_t reserved0;      /* the address1/2/3 the unit was given, a1 | a2 << 10 | a3 << 20 (0 without d_state_in) */
     int32_t xrmax;
     int32_t reserved;
 } mp3s_gr_out; /* 72 bytes */
@@ -229,6 +229,17 @@ typedef struct {
 int mp3s_chain_resolve_dev(mp3s_ctx *ctx, mp3s_gr_out *d_gr, const mp3s_rate_frame *d_frames, int n_frames,
                            const mp3s_chain_seg *d_segs, int n_segs, const int32_t *d_cursor_in, const int32_t *d_state_in,
                            int32_t *d_verdict, mp3s_chain_seg_out *d_seg_out);
+
+/* The same check, and what it finds wrong put right on the device where that takes one more run: the units that read
+ * inherited addresses other than the chain really holds (the first pass gives every unit zeros: SURVEY E7 -- the first
+ * quiet granules behind a silence), or ran on another cursor, are listed on the device, run again on the cursor and
+ * addresses the check found (results in place, d_cursor updated for them) and everything is checked once more.  The
+ * verdict is the second check's: 0 = final.  What it still finds (a re-run changed what later units inherit, more than
+ * 1 024 units listed) is left to the host as before.  Operands as for mp3s_rate_loop_dev / mp3s_chain_resolve_dev; every
+ * unit must have run without d_state_in (the records carry what they were given). */
+int mp3s_chain_redo_dev(mp3s_ctx *ctx, const int32_t *d_mdct, const mp3s_rate_frame *d_frames, int n_frames,
+                        const uint8_t *d_hide_bits, int n_hide, int32_t *d_cursor, const mp3s_chain_seg *d_segs, int n_segs,
+                        int16_t *d_ix, mp3s_gr_out *d_gr, int32_t *d_en, int32_t *d_verdict, mp3s_chain_seg_out *d_seg_out);
 
 /* ---------------------------------------------------------------- (iv-c) the message cursor, decided on the device
  * replaces: the same __hide_str_offset chain (reference encoder/MP3_Encoder.py:808-809, :1154-1168), without guessing:

@@ -90,12 +90,18 @@ __device__ __forceinline__ ChainEl chain_element(const mp3s_gr_out *__restrict__
 __global__ __launch_bounds__(CH_THREADS) void k_chain_sum(const mp3s_gr_out *__restrict__ gr, const mp3s_rate_frame *__restrict__ rf,
                                                           const mp3s_chain_seg *__restrict__ segs, int n_frames,
                                                           ChainEl *__restrict__ agg, int32_t *__restrict__ verdict,
-                                                          mp3s_chain_seg_out *__restrict__ seg_out)
+                                                          mp3s_chain_seg_out *__restrict__ seg_out, int32_t *__restrict__ redo,
+                                                          const int32_t *__restrict__ only_after)
 {
     __shared__ ChainEl wave_tot[CH_THREADS / 64];
+    if (only_after && only_after[0] == 0) return;   // the check behind the re-runs: nothing was run again, the first verdict stands
     const int f = blockIdx.x * CH_THREADS + threadIdx.x;
     // what pass 2 accumulates into starts from zero (no fill launches in front of the pair)
     if (f == 0) { verdict[0] = 0; verdict[1] = 0; }
+    if (redo) {
+        if (f == 0) redo[0] = 0;
+        for (int i = f; i < REDO_CAP; i += (int)gridDim.x * CH_THREADS) redo[REDO_HEAD + i] = -1;
+    }
     if (f < n_frames && segs[rf[f].stream].first_frame == f) seg_out[rf[f].stream].carry_used = 0;
     ChainEl total;
     chain_block_scan(chain_element(gr, rf, segs, f, n_frames), wave_tot, &total);
@@ -108,10 +114,12 @@ __global__ __launch_bounds__(CH_THREADS) void k_chain_sum(const mp3s_gr_out *__r
 //   array), the four chains as the stream leaves them, carry_used (see mp3s_encode_block)
 __global__ __launch_bounds__(CH_THREADS) void k_chain_apply(mp3s_gr_out *__restrict__ gr, const mp3s_rate_frame *__restrict__ rf,
                                                             const mp3s_chain_seg *__restrict__ segs, int n_frames,
-                                                            const ChainEl *__restrict__ agg, const int32_t *__restrict__ cursor_in,
+                                                            const ChainEl *__restrict__ agg, int32_t *__restrict__ cursor_in,
                                                             const int32_t *__restrict__ state_in, int32_t *__restrict__ verdict,
-                                                            mp3s_chain_seg_out *__restrict__ seg_out)
+                                                            mp3s_chain_seg_out *__restrict__ seg_out, int32_t *__restrict__ redo_list,
+                                                            const int32_t *__restrict__ only_after)
 {
+    if (only_after && only_after[0] == 0) return;
     __shared__ ChainEl wave_tot[CH_THREADS / 64];
     const int f = blockIdx.x * CH_THREADS + threadIdx.x;
     // what the workgroups in front of this one add up to
@@ -163,11 +171,24 @@ __global__ __launch_bounds__(CH_THREADS) void k_chain_apply(mp3s_gr_out *__restr
                 if (used != cur && (used < cur ? used : cur) < end) redo = true;
             }
             if (flags & MP3S_RF_USED_ADDR_IN) {
-                const int32_t s0 = state_in ? state_in[u * 4] : 0, s1 = state_in ? state_in[u * 4 + 1] : 0,
-                              s2 = state_in ? state_in[u * 4 + 2] : 0;
-                if (s0 != ch[0] || s1 != ch[1] || s2 != ch[2]) redo = true;
+                // (what the unit was given: the caller's array, else the unit's own record of it)
+                const int32_t given = state_in ? state_in[u * 4] | (state_in[u * 4 + 1] << 10) | (state_in[u * 4 + 2] << 20) : g.reserved0;
+                if (given != (ch[0] | (ch[1] << 10) | (ch[2] << 20))) redo = true;
             }
             redo_here += redo ? 1 : 0;
+            if (redo && redo_list) {
+                // for k_rate_redo: the unit once more, on the cursor and the addresses found here (which hold if the units
+                // in front keep their results; the check after the re-runs says whether they did)
+                const int at = atomicAdd(&redo_list[0], 1);
+                if (at < REDO_CAP) {
+                    const int32_t c = (int32_t)(cur < (long)MP3S_NO_CURSOR ? cur : (long)MP3S_NO_CURSOR);
+                    redo_list[REDO_HEAD + at] = (int32_t)u;
+                    redo_list[REDO_HEAD + REDO_CAP + at] = hiding ? c : (cursor_in ? cursor_in[u] : 0);
+                    if (hiding) cursor_in[u] = c;
+#pragma unroll
+                    for (int j = 0; j < 4; j++) redo_list[REDO_HEAD + 2 * REDO_CAP + 4 * at + j] = ch[j];
+                }
+            }
             if (flags & MP3S_RF_STEP_RANGE) err_here = 1;
             if (active) cur += g.n_tables;
             else {   // silent unit: everything is inherited (quantizerStepSize and addresses pass through)

@@ -69,6 +69,9 @@ __device__ __forceinline__ void wave_max3(uint32_t &a, uint32_t &b, uint32_t &c)
 // encoder/util.py:130-133 mulr for non-negative a: (a*b + 2^31) >> 32
 __device__ __forceinline__ uint32_t mulr_u(uint32_t a, uint32_t b) { return (uint32_t)(((uint64_t)a * b + 0x80000000ull) >> 32); }   // one v_mad_u64_u32
 
+// the device's list of units to run again (written by k_chain_apply, read by k_rate_redo), int32: [0] = entries wanted,
+// then from REDO_HEAD: unit[REDO_CAP] (-1 behind the end), cursor[REDO_CAP], inherited state[REDO_CAP][4]
+constexpr int REDO_CAP = 1024, REDO_HEAD = 4, REDO_WORDS = REDO_HEAD + 6 * REDO_CAP;
 constexpr int RL_WAVES = 4;   // 4 waves share one copy of the lookup tables: 33 KB LDS -> 4 workgroups = 16 waves per CU (a fifth wave
                               // per SIMD at 96 VGPRs was measured: 0.351 instead of 0.305 ms, and the Huffman kernel no longer fits beside it)
 constexpr int RL_NP = 5;      // pairs per lane: lane l holds the CONSECUTIVE pairs 5l .. 5l+4 (lines 10l .. 10l+9); lanes 0..57 hold
@@ -339,7 +342,7 @@ struct RateVariants {
     uint8_t *tables;   // the entries' table counts once more, one byte each (what the selection's walk reads)
 };
 
-__global__ __launch_bounds__(RL_WAVES * 64, 4) void k_rate_loop(
+__device__ __forceinline__ void rate_units(
     const int32_t *__restrict__ mdct, const mp3s_rate_frame *__restrict__ frames, int n_units,
     const uint8_t *__restrict__ hide, int n_hide, const int32_t *__restrict__ cursor_in,
     const int32_t *__restrict__ state_in, const int32_t *__restrict__ unit_list, int n_list,
@@ -349,6 +352,7 @@ __global__ __launch_bounds__(RL_WAVES * 64, 4) void k_rate_loop(
     // compact (re-runs of a unit list): cursor_in / state_in / out are indexed by the position in the list, so that a
     // pass moves a few bytes per listed unit over PCIe instead of whole-batch arrays; ix / en still land in place.
     // compact == 2 (message variants: the list names a unit once per 3-bit pattern): ix / en go by list position too
+    // compact == 3 (the device's own re-runs, k_rate_redo): only cursor_in / state_in by list position, results in place
     // results of unit u go to element u - out_base of the three output arrays (0 except for the message variants,
     // whose arrays hold one chunk of units)
     __shared__ __attribute__((aligned(16))) RlTables tb;
@@ -548,13 +552,40 @@ __global__ __launch_bounds__(RL_WAVES * 64, 4) void k_rate_loop(
             o.address[0] = st.a1; o.address[1] = st.a2; o.address[2] = st.a3;
             o.n_tables = act ? (st.ts0 > 0) + (st.ts1 > 0) + (st.ts2 > 0) : 0;
             o.flags = flags;
-            o.reserved0 = 0;
+            // the inherited addresses the unit was given (each < 1024): what k_chain_apply compares with the true chain
+            o.reserved0 = state_in ? state_in[(long)ci * 4 + 0] | (state_in[(long)ci * 4 + 1] << 10) | (state_in[(long)ci * 4 + 2] << 20) : 0;
             o.xrmax = (int32_t)xrmax;
             o.reserved = 0;
-            out[compact ? li : u - out_base] = o;
+            out[compact == 1 || compact == 2 ? li : u - out_base] = o;
             if (tables_out) tables_out[li] = (uint8_t)o.n_tables;
         }
     }
+}
+
+__global__ __launch_bounds__(RL_WAVES * 64, 4) void k_rate_loop(
+    const int32_t *__restrict__ mdct, const mp3s_rate_frame *__restrict__ frames, int n_units,
+    const uint8_t *__restrict__ hide, int n_hide, const int32_t *__restrict__ cursor_in,
+    const int32_t *__restrict__ state_in, const int32_t *__restrict__ unit_list, int n_list,
+    int16_t *__restrict__ ix_out, mp3s_gr_out *__restrict__ out, int32_t *__restrict__ en_out, int out_base, int compact,
+    RateVariants var)
+{
+    rate_units(mdct, frames, n_units, hide, n_hide, cursor_in, state_in, unit_list, n_list, ix_out, out, en_out, out_base, compact, var);
+}
+
+// The units k_chain_apply listed (they ran on inherited addresses or a cursor that turned out different: k_chain.hpp) once
+// more, on what it found, results in place.  The list lives on the device and is short or empty: its length is not a
+// launch parameter, entries behind its end hold -1 (it is filled from the front, so a workgroup whose first entry is
+// empty has nothing to do).
+__global__ __launch_bounds__(RL_WAVES * 64, 4) void k_rate_redo(
+    const int32_t *__restrict__ mdct, const mp3s_rate_frame *__restrict__ frames, int n_units,
+    const uint8_t *__restrict__ hide, int n_hide, const int32_t *__restrict__ redo, int16_t *__restrict__ ix_out,
+    mp3s_gr_out *__restrict__ out, int32_t *__restrict__ en_out)
+{
+    const int32_t *unit_list = redo + REDO_HEAD;
+    if (unit_list[blockIdx.x * RL_WAVES] < 0) return;
+    const RateVariants none = {nullptr, nullptr, 0, nullptr, nullptr, nullptr, nullptr};
+    rate_units(mdct, frames, n_units, hide, n_hide, unit_list + REDO_CAP, unit_list + 2 * REDO_CAP, unit_list, REDO_CAP, ix_out, out, en_out,
+               0, 3, none);
 }
 
 // Message variants (enc_resolve): a unit's result depends on the message only through the <= 3 bits at its cursor, so

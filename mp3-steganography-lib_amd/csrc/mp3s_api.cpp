@@ -456,6 +456,20 @@ int mp3s_chain_resolve_dev(mp3s_ctx *c, mp3s_gr_out *d_gr, const mp3s_rate_frame
     return MP3S_OK;
 }
 
+int mp3s_chain_redo_dev(mp3s_ctx *c, const int32_t *d_mdct, const mp3s_rate_frame *d_frames, int n_frames, const uint8_t *d_hide_bits, int n_hide,
+                        int32_t *d_cursor, const mp3s_chain_seg *d_segs, int n_segs, int16_t *d_ix, mp3s_gr_out *d_gr, int32_t *d_en,
+                        int32_t *d_verdict, mp3s_chain_seg_out *d_seg_out)
+{
+    if (!c || !d_mdct || !d_gr || !d_frames || !d_segs || !d_verdict || !d_seg_out || !d_ix || !d_en) return fail(MP3S_E_ARG, "null pointer");
+    if (n_frames <= 0 || n_segs <= 0 || n_hide < 0 || (n_hide > 0 && (!d_hide_bits || !d_cursor))) return fail(MP3S_E_ARG, "bad sizes");
+    void *d_agg = c->grab(30, chain_agg_bytes(n_frames));
+    if (!d_agg) return fail(MP3S_E_NOMEM, "hipMalloc failed for the chain scratch");
+    const ChainRedoArgs redo = {d_mdct, d_hide_bits, n_hide, d_ix, d_en};
+    const int e = launch_chain(c->stream, d_gr, d_frames, n_frames, d_segs, d_cursor, nullptr, d_agg, d_verdict, d_seg_out, &c->prof, &redo);
+    if (e) return fail(MP3S_E_HIP, "chain launch: %s", hipGetErrorString((hipError_t)e));
+    return MP3S_OK;
+}
+
 int mp3s_huffman_decode_dev(mp3s_ctx *c, const uint8_t *d_blob, const mp3s_frame_side *d_side, int n_frames, int nch,
                             int max_part2_3_length, int16_t *d_is, mp3s_granule_si *d_si, int32_t *d_status)
 {

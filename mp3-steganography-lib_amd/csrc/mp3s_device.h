@@ -66,11 +66,16 @@ int launch_rate(hipStream_t stream, const int32_t *d_mdct, const mp3s_rate_frame
                 int compact = 0 /* 1: d_cursor / d_state / d_out are indexed by the position in d_list; 2: d_ix / d_en too */,
                 const RateVariantArgs *variants = nullptr);
 
-// the serial chains of the rate loop (k_chain.hpp): two small launches; d_agg: chain_agg_bytes(n_frames) of scratch
+// the serial chains of the rate loop (k_chain.hpp): two small launches; d_agg: chain_agg_bytes(n_frames) of scratch.
+// With `redo` (the rate loop's other operands) the units the check finds wrong -- they read inherited addresses that were
+// not what the chain holds, or ran on another cursor -- are listed on the device, run again on what the check found
+// (k_rate_redo, results in place, d_cursor updated for them: it is written then) and everything is checked once more:
+// five launches, the verdict is the second check's.
+struct ChainRedoArgs { const int32_t *d_mdct; const uint8_t *d_hide; int n_hide; int16_t *d_ix; int32_t *d_en; };
 size_t chain_agg_bytes(int n_frames);
 int launch_chain(hipStream_t stream, mp3s_gr_out *d_gr, const mp3s_rate_frame *d_frames, int n_frames, const mp3s_chain_seg *d_segs,
                  const int32_t *d_cursor, const int32_t *d_state, void *d_agg, int32_t *d_verdict, mp3s_chain_seg_out *d_seg_out,
-                 Profiler *prof);
+                 Profiler *prof, const ChainRedoArgs *redo = nullptr);
 
 // the message cursor decided on the device (k_chain_select): one workgroup per stream, after a launch_rate with variants
 int launch_select(hipStream_t stream, const mp3s_chain_seg *d_segs, const mp3s_select_span *d_spans, int n_segs, int max_reach,

@@ -154,19 +154,30 @@ int launch_rate(hipStream_t stream, const int32_t *d_mdct, const mp3s_rate_frame
     return (int)hipGetLastError();
 }
 
-size_t chain_agg_bytes(int n_frames) { return (size_t)((n_frames + CH_THREADS - 1) / CH_THREADS) * sizeof(ChainEl) + 16; }
+static size_t chain_scan_bytes(int n_frames) { return ((size_t)((n_frames + CH_THREADS - 1) / CH_THREADS) * sizeof(ChainEl) + 31) & ~(size_t)15; }
+size_t chain_agg_bytes(int n_frames) { return chain_scan_bytes(n_frames) + (size_t)REDO_WORDS * 4; }   // (+ the list of units to run again)
 
 int launch_chain(hipStream_t stream, mp3s_gr_out *d_gr, const mp3s_rate_frame *d_frames, int n_frames, const mp3s_chain_seg *d_segs,
                  const int32_t *d_cursor, const int32_t *d_state, void *d_agg, int32_t *d_verdict, mp3s_chain_seg_out *d_seg_out,
-                 Profiler *prof)
+                 Profiler *prof, const ChainRedoArgs *redo)
 {
     if (n_frames <= 0) return 0;
     const int blocks = (n_frames + CH_THREADS - 1) / CH_THREADS;
+    int32_t *d_redo = redo ? (int32_t *)((uint8_t *)d_agg + chain_scan_bytes(n_frames)) : nullptr;
+    int32_t *cursor = const_cast<int32_t *>(d_cursor);   // (written only with `redo`)
     const int pp = prof ? prof->begin(stream, K_CHAIN) : -1;
     hipLaunchKernelGGL(k_chain_sum, dim3(blocks), dim3(CH_THREADS), 0, stream, (const mp3s_gr_out *)d_gr, d_frames, d_segs, n_frames,
-                       (ChainEl *)d_agg, d_verdict, d_seg_out);
+                       (ChainEl *)d_agg, d_verdict, d_seg_out, d_redo, (const int32_t *)nullptr);
     hipLaunchKernelGGL(k_chain_apply, dim3(blocks), dim3(CH_THREADS), 0, stream, d_gr, d_frames, d_segs, n_frames,
-                       (const ChainEl *)d_agg, d_cursor, d_state, d_verdict, d_seg_out);
+                       (const ChainEl *)d_agg, cursor, d_state, d_verdict, d_seg_out, d_redo, (const int32_t *)nullptr);
+    if (redo) {
+        hipLaunchKernelGGL(k_rate_redo, dim3(REDO_CAP / RL_WAVES), dim3(RL_WAVES * 64), 0, stream, redo->d_mdct, d_frames, n_frames * 4,
+                           redo->d_hide, redo->n_hide, (const int32_t *)d_redo, redo->d_ix, d_gr, redo->d_en);
+        hipLaunchKernelGGL(k_chain_sum, dim3(blocks), dim3(CH_THREADS), 0, stream, (const mp3s_gr_out *)d_gr, d_frames, d_segs, n_frames,
+                           (ChainEl *)d_agg, d_verdict, d_seg_out, (int32_t *)nullptr, (const int32_t *)d_redo);
+        hipLaunchKernelGGL(k_chain_apply, dim3(blocks), dim3(CH_THREADS), 0, stream, d_gr, d_frames, d_segs, n_frames,
+                           (const ChainEl *)d_agg, cursor, d_state, d_verdict, d_seg_out, (int32_t *)nullptr, (const int32_t *)d_redo);
+    }
     if (prof) prof->end(stream, pp);
     return (int)hipGetLastError();
 }

@@ -10,6 +10,7 @@ static int64_t cursor0(const EncSeg &s)
     return s.carry_in ? std::min<int64_t>(std::max<int64_t>(s.carry_in->cursor, 0), kNoCursor) : 0;
 }
 
+static bool redo_disabled() { return getenv("MP3S_NO_REDO") != nullptr; }
 static bool select_disabled() { return getenv("MP3S_NO_SELECT") != nullptr; }   // (read per batch: tests switch it)
 
 int enc_layout(std::vector<EncSeg> &segs, int samplerate, int bitrate_kbps, EncLayout &L)
@@ -196,8 +197,10 @@ int enc_issue(mp3s_ctx *c, const EncLayout &L, const EncDev &d, hipStream_t tail
         ts = tail;
     }
     if (!rc) {
+        // (with the device's own re-runs of the units that inherited other addresses than the zeros they were given)
+        const ChainRedoArgs redo = {d_mdct, d_hide, L.n_hide, d.d_ix, d.d_en};
         const int e = launch_chain(ts, d.d_out, d_rf, L.n, d_segs, d_cur, nullptr, d.d_agg, d.d_small,
-                                   (mp3s_chain_seg_out *)((uint8_t *)d.d_small + kSmallHead), &c->prof);
+                                   (mp3s_chain_seg_out *)((uint8_t *)d.d_small + kSmallHead), &c->prof, redo_disabled() ? nullptr : &redo);
         if (e) rc = fail(MP3S_E_HIP, "chain launch: %s", hipGetErrorString((hipError_t)e));
     }
     // packed on the assumption that the verdict is "nothing to redo" (the common case); the caller discards it otherwise

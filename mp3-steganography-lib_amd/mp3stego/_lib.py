@@ -154,7 +154,7 @@ class Block(C.Structure):
 SYMBOLS = ["mp3s_ctx_create", "mp3s_ctx_destroy", "mp3s_ctx_wait", "mp3s_last_error", "mp3s_version", "mp3s_device_name", "mp3s_sync", "mp3s_debug_tables", "mp3s_debug_scfsi_energies", "mp3s_debug_parse_scanned_frame",
            "mp3s_dev_alloc", "mp3s_dev_free", "mp3s_dev_upload", "mp3s_dev_download", "mp3s_dev_memset",
            "mp3s_timer_start", "mp3s_timer_stop", "mp3s_bench_copy", "mp3s_synth_mode", "mp3s_profile_enable", "mp3s_profile_select", "mp3s_profile_collect", "mp3s_decode_transform_dev", "mp3s_decode_transform",
-           "mp3s_encode_transform_dev", "mp3s_encode_transform", "mp3s_rate_loop_dev", "mp3s_chain_resolve_dev", "mp3s_select_patterns", "mp3s_select_plan", "mp3s_rate_select_dev", "mp3s_rate_variants_dev", "mp3s_select_dev", "mp3s_huffman_decode_dev", "mp3s_pack_frames_dev", "mp3s_scan_stream", "mp3s_buf_free",
+           "mp3s_encode_transform_dev", "mp3s_encode_transform", "mp3s_rate_loop_dev", "mp3s_chain_resolve_dev", "mp3s_chain_redo_dev", "mp3s_select_patterns", "mp3s_select_plan", "mp3s_rate_select_dev", "mp3s_rate_variants_dev", "mp3s_select_dev", "mp3s_huffman_decode_dev", "mp3s_pack_frames_dev", "mp3s_scan_stream", "mp3s_buf_free",
            "mp3s_parse_stream", "mp3s_format_stream", "mp3s_rate_frames", "mp3s_decode_stream", "mp3s_decode_streams", "mp3s_decode_block", "mp3s_encode_pcm", "mp3s_encode_block",
            "mp3s_wav_parse", "mp3s_wav_header", "mp3s_message_frame", "mp3s_message_reveal", "mp3s_decode_file", "mp3s_encode_file",
            "mp3s_hide_message", "mp3s_clear_file", "mp3s_hide_messages", "mp3s_reencode_block", "mp3s_reveal_message",
@@ -209,6 +209,7 @@ def lib():
         L.mp3s_encode_transform.argtypes = [vp, vp, vp, i32, vp]
         L.mp3s_rate_loop_dev.argtypes = [vp, vp, vp, i32, vp, i32, vp, vp, vp, i32, vp, vp, vp]
         L.mp3s_chain_resolve_dev.argtypes = [vp, vp, vp, i32, vp, i32, vp, vp, vp, vp]
+        L.mp3s_chain_redo_dev.argtypes = [vp, vp, vp, i32, vp, i32, vp, vp, i32, vp, vp, vp, vp, vp]
         L.mp3s_select_patterns.argtypes = [vp]
         L.mp3s_select_patterns.restype = None
         L.mp3s_select_plan.argtypes = [vp, i32, vp, vp, vp, i32]

@@ -4,6 +4,8 @@ encoder/MP3_Encoder.py:808-809 (the cursor), :1154-1168 and :1257-1263 (where th
 has to get right: messages of one, two, three bits (the "bits left" variants), messages ending on every offset inside a unit,
 silence inside the reach (units that take no tables), a start in silence that the plan does not cover (the chain check fails
 and the host resolves it), several streams in one batch, blocks that continue a message."""
+import os
+
 import numpy as np
 import pytest
 
@@ -89,6 +91,25 @@ def test_long_messages_in_rounds(ctx, mlib, orc):
 
 
 @pytest.mark.gpu
+def test_inherited_addresses_are_put_right_on_the_device(ctx, mlib, orc):
+    """silences in the middle of a stream: the granules behind them read address1/2/3 inherited across the silence
+    (SURVEY E7); the first pass gives every unit zeros, the chain check lists the units for which that was wrong and they
+    run again on the device -- final without the host, same bytes as the oracle"""
+    from synth_pcm import synth_pcm
+    rng = np.random.default_rng(14)
+    for seed, cuts in ((41, [(60, 90)]), (42, [(10, 12), (100, 140), (200, 201)]), (43, [(0, 30), (150, 155)])):
+        pcm = synth_pcm(260, seed=seed)
+        for a, b in cuts:
+            pcm[a * 1152:b * 1152] = 0
+        pcm[220 * 1152:230 * 1152, 0] = 0                             # one channel only
+        for nbits in (0, 40, 1500):
+            msg = rng.integers(0, 2, size=nbits).astype(np.uint8) if nbits else None
+            r, o = ctx.encode_pcm(pcm, 44100, 128, msg), orc.encode(pcm, 44100, 128, msg)
+            assert o["rc"] == 0 and r["mp3"] == o["mp3"] and r["hide_offset"] == o["hide_offset"], (seed, nbits)
+            assert r["rate_passes"] == 1, (seed, nbits)
+
+
+@pytest.mark.gpu
 def test_silence_inside_the_reach_and_uncovered_start(ctx, mlib, orc):
     from synth_pcm import synth_pcm
     rng = np.random.default_rng(9)
@@ -98,13 +119,27 @@ def test_silence_inside_the_reach_and_uncovered_start(ctx, mlib, orc):
     pcm[20 * 1152:27 * 1152] = 0
     r, o = ctx.encode_pcm(pcm, 44100, 128, msg), orc.encode(pcm, 44100, 128, msg)
     assert r["mp3"] == o["mp3"] and r["hide_offset"] == o["hide_offset"]
-    # a long silent start: d leaves its range / the message reaches further than planned; the chain check on the device
-    # says so and the host resolves the chains (more than one pass), same bytes
+    # a long silent start (raw PCM: no input stream whose tables could tell): the message reaches further than planned;
+    # the chain check on the device says so, the units behind the plan run again on the cursors it found (300 of them:
+    # the list holds 1 024) and the second check passes; without the device's re-runs the host resolves the chains
+    # (more than one pass); same bytes every time
     pcm = synth_pcm(300, seed=33)
     pcm[:120 * 1152] = 0
     r, o = ctx.encode_pcm(pcm, 44100, 128, msg), orc.encode(pcm, 44100, 128, msg)
     assert r["mp3"] == o["mp3"] and r["hide_offset"] == o["hide_offset"]
-    assert r["rate_passes"] > 1
+    assert r["rate_passes"] == 1
+    os.environ["MP3S_NO_REDO"] = "1"
+    try:
+        r = ctx.encode_pcm(pcm, 44100, 128, msg)
+    finally:
+        del os.environ["MP3S_NO_REDO"]
+    assert r["mp3"] == o["mp3"] and r["hide_offset"] == o["hide_offset"] and r["rate_passes"] > 1
+    # ... and a message far behind the plan, more units than the list holds: the host again
+    long_msg = rng.integers(0, 2, size=6000).astype(np.uint8)
+    pcm = synth_pcm(1500, seed=36)
+    pcm[:700 * 1152] = 0
+    r, o = ctx.encode_pcm(pcm, 44100, 128, long_msg), orc.encode(pcm, 44100, 128, long_msg)
+    assert r["mp3"] == o["mp3"] and r["hide_offset"] == o["hide_offset"] and r["rate_passes"] > 1
     # a stream shorter than the message's reach, message longer than the stream can hold
     pcm = synth_pcm(9, seed=34)
     r, o = ctx.encode_pcm(pcm, 44100, 128, msg), orc.encode(pcm, 44100, 128, msg)
