@@ -49,8 +49,10 @@ int enc_layout(std::vector<EncSeg> &segs, int samplerate, int bitrate_kbps, EncL
         cs[si].hide_begin = (int32_t)((int64_t)s.hide_base + cursor0(s)); cs[si].hide_end = s.hide_base + s.n_hide;
     }
     // every unit a message can reach costs MP3S_SELECT_VARIANTS entries (1.3 KB each in HBM, one more wave of the rate
-    // loop); the alternative for a stream left out is the host walking its chains pass by pass, which costs more at any
-    // length, so the only limit is memory: 8 GB of entries
+    // loop); the alternative for a stream left out is the host resolving its chains, which runs 8 variants per unit as
+    // well and needs the host in the middle of the job (a 14 KB message in 10 000 frames: 6.0 ms here, 5.3 ms there for
+    // the synchronous call; through the pipe the host's turn is what stalls: DESIGN 4a), so the only limit is memory:
+    // 8 GB of entries
     const int budget = select_disabled() ? 0 : (int)std::min<int64_t>((int64_t)L.units * MP3S_SELECT_VARIANTS, 6000000);
     // how far the message gets is a question of the tables the units in front offer: 2.8 per unit on music, none in silence
     // (the first seconds of many a file).  Where the stream being re-encoded is known, its own table counts say how many
