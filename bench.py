@@ -380,7 +380,7 @@ def main():
         t_long = (time.perf_counter() - t0) / 5
         long_message = {"message_bytes": len(long_text), "ms_per_batch": round(t_long * 1e3, 3), "frames_per_s": round(n / t_long, 1),
                         "too_long": bool(r["too_long"]),
-                        "what": "a 1 700-byte message (reach 4 889 units: 48 890 variant entries behind the 40 000 units of the rate-loop launch, five rounds of the selection), mp3s_hide_message one call at a time, nothing overlapped"}
+                        "what": "a 1 700-byte message (reach 4 889 units: 39 826 variant entries behind the 40 000 units of the rate-loop launch, five rounds of the selection), mp3s_hide_message one call at a time, nothing overlapped"}
         del r
         # the pipe owns its context
         pctx = _lib.Context(dev)

@@ -255,10 +255,18 @@ int mp3s_chain_redo_dev(mp3s_ctx *ctx, const int32_t *d_mdct, const mp3s_rate_fr
  * must hold MP3S_NO_CURSOR for every unit of a planned stream before the call; the call overwrites the cursors of the
  * units it replaced with what they really saw (a later call with the same plan may find those there: they are exact). */
 #define MP3S_SELECT_VARIANTS 10
+/* The two "bits left" possibilities can only meet the units around the message's end: a unit never takes more than three
+ * tables, so unit j's cursor is at most 3j bits behind the start, and "two bits left" needs 3j >= bits_left - 2.  A stream's
+ * entries are therefore 8 rows of `reach` units (the patterns) and 2 rows of the units from MP3S_SELECT_TAIL_FIRST on:
+ *   entry (v < 8, j) = first_entry + v * reach + j
+ *   entry (v >= 8, j >= t) = first_entry + 8 * reach + (v - 8) * (reach - t) + (j - t),  t = MP3S_SELECT_TAIL_FIRST(bits left, reach)
+ * with bits left = hide_end - hide_begin of the stream's mp3s_chain_seg. */
+#define MP3S_SELECT_TAIL_FIRST(bits_left, reach) ((bits_left) < 2 ? 0 : (((bits_left) - 2) / 3 < (reach) ? ((bits_left) - 2) / 3 : (reach)))
+#define MP3S_SELECT_ENTRIES(bits_left, reach) (8 * (reach) + 2 * ((reach) - MP3S_SELECT_TAIL_FIRST(bits_left, reach)))
 #define MP3S_SELECT_MAX_REACH (1 << 18)
 #define MP3S_NO_CURSOR 0x3fffffff     /* "behind every message": such a unit hides nothing */
 typedef struct {
-    int32_t first_entry;             /* entry (v, j) of the stream = first_entry + v * reach + j */
+    int32_t first_entry;             /* the stream's first entry (layout: MP3S_SELECT_TAIL_FIRST above) */
     int32_t reach;                   /* its first `reach` units are planned (0: the stream is left to cursor_in as it is) */
 } mp3s_select_span; /* 8 bytes */
 void mp3s_select_patterns(uint8_t out[32]);

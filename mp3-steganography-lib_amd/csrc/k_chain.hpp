@@ -267,6 +267,10 @@ __global__ __launch_bounds__(SEL_THREADS) void k_chain_select(const mp3s_chain_s
     const long c0 = sg.hide_begin, end = sg.hide_end;
     const long u0 = (long)sg.first_frame * 4;
     const int RS = min(R, SEL_ROUND);                         // row length of the LDS arrays
+    // the two "bits left" rows of the entries start at unit `tail` (MP3S_SELECT_TAIL_FIRST: no unit in front can meet them)
+    const long left = end - c0;
+    const int tail = (int)MP3S_SELECT_TAIL_FIRST(left, (long)R), R2 = R - tail;
+    const long row8 = (long)sp.first_entry + 8L * R - tail;    // entry (v >= 8, j) = row8 + (v - 8) * R2 + j
     uint8_t *tabs = sel_lds;                                  // [11][RS]: table counts of the entries, [10] = the unit's own run
     uint8_t *code = tabs + (size_t)RS * (SEL_NONE + 1);       // [3RS + 128 + 8]: the possibility a unit sees with its cursor at start + rel0 + p
     uint8_t *delta = code + 3 * RS + SEL_D + 8;               // [RS]: d - d0 in front of every unit
@@ -284,8 +288,10 @@ __global__ __launch_bounds__(SEL_THREADS) void k_chain_select(const mp3s_chain_s
             J += Rs;
             continue;
         }
-        for (int v = 0; v < SEL_NONE; v++)
+        for (int v = 0; v < 8; v++)
             for (int jj = tid; jj < Rs; jj += SEL_THREADS) tabs[v * RS + jj] = tabv[sp.first_entry + (long)v * R + J + jj];
+        for (int v = 8; v < SEL_NONE; v++)
+            for (int jj = tid; jj < Rs; jj += SEL_THREADS) tabs[v * RS + jj] = J + jj >= tail ? tabv[row8 + (long)(v - 8) * R2 + J + jj] : (uint8_t)0;
         for (int jj = tid; jj < Rs; jj += SEL_THREADS) tabs[SEL_NONE * RS + jj] = (uint8_t)out[u0 + J + jj].n_tables;
         for (int p = tid; p < 3 * Rs + SEL_D + 8; p += SEL_THREADS) {
             const long rel = rel0 + p, cur = c0 + rel;
@@ -333,7 +339,10 @@ __global__ __launch_bounds__(SEL_THREADS) void k_chain_select(const mp3s_chain_s
             const int p = 3 * jj + (SEL_D - 1) - (int)delta[jj];
             const int v = code[p];
             // (entry, cursor position from the start) for now: the unit number goes in once the whole plan held
-            my_pairs[J + jj] = v == SEL_NONE ? make_int2(-1, 0) : make_int2(sp.first_entry + v * R + J + jj, (int)(rel0 + p));
+            const int j = J + jj;
+            if (v >= 8 && v != SEL_NONE && j < tail) overflow = 1;        // (cannot happen: see MP3S_SELECT_TAIL_FIRST)
+            my_pairs[j] = v == SEL_NONE ? make_int2(-1, 0)
+                                        : make_int2(v < 8 ? sp.first_entry + v * R + j : (int)(row8 + (long)(v - 8) * R2 + j), (int)(rel0 + p));
         }
         if (tid == 0) d_next = d_try;
         J += Rs;

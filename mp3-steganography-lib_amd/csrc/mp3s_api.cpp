@@ -26,14 +26,17 @@ int max_part2_3(const mp3s_frame_side *side, long n)
     return m;
 }
 
-void select_entries(int first_unit, int reach, int first_entry, int hide_end, int32_t *ent_unit, int32_t *ent_cursor)
+void select_entries(int first_unit, int reach, int first_entry, int hide_end, int64_t bits_left, int32_t *ent_unit, int32_t *ent_cursor)
 {
+    const int tail = (int)MP3S_SELECT_TAIL_FIRST(bits_left, (int64_t)reach);
+    int at = first_entry;
     for (int v = 0; v < MP3S_SELECT_VARIANTS; v++) {
-        // 0..7: the three-bit patterns in front of the messages; 8 / 9: the message's own last two bits / last bit
+        // 0..7: the three-bit patterns in front of the messages; 8 / 9: the message's own last two bits / last bit, which
+        // only the units from `tail` on can meet
         const int32_t cur = v < 8 ? 4 * v : hide_end - (10 - v);
-        for (int j = 0; j < reach; j++) {
-            ent_unit[first_entry + v * reach + j] = first_unit + j;
-            ent_cursor[first_entry + v * reach + j] = cur;
+        for (int j = v < 8 ? 0 : tail; j < reach; j++) {
+            ent_unit[at] = first_unit + j;
+            ent_cursor[at++] = cur;
         }
     }
 }
@@ -388,10 +391,10 @@ int select_plan(const mp3s_chain_seg *segs, int n_segs, mp3s_select_span *spans,
         // units the rest of the message can reach at 2.8 tables per unit (measured on music: 2.96), and some
         // ... or as far as the caller expects it to get (a stream that starts in silence offers no tables for a while)
         const int64_t reach = std::min<int64_t>((int64_t)g.n_frames * 4, std::max<int64_t>(left * 5 / 14 + 32, min_reach ? min_reach[i] : 0));
-        if (reach > MP3S_SELECT_MAX_REACH || (int64_t)used + reach * MP3S_SELECT_VARIANTS > cap) continue;
+        if (reach > MP3S_SELECT_MAX_REACH || (int64_t)used + MP3S_SELECT_ENTRIES(left, reach) > cap) continue;
         spans[i].reach = (int32_t)reach;
-        if (ent_unit) select_entries(g.first_frame * 4, (int)reach, used, g.hide_end, ent_unit, ent_cursor);
-        used += (int)reach * MP3S_SELECT_VARIANTS;
+        if (ent_unit) select_entries(g.first_frame * 4, (int)reach, used, g.hide_end, left, ent_unit, ent_cursor);
+        used += (int)MP3S_SELECT_ENTRIES(left, reach);
     }
     return used;
 }

@@ -48,11 +48,11 @@ int enc_layout(std::vector<EncSeg> &segs, int samplerate, int bitrate_kbps, EncL
         cs[si].first_frame = s.first; cs[si].n_frames = s.n_frames; cs[si].hide_base = s.hide_base;
         cs[si].hide_begin = (int32_t)((int64_t)s.hide_base + cursor0(s)); cs[si].hide_end = s.hide_base + s.n_hide;
     }
-    // every unit a message can reach costs MP3S_SELECT_VARIANTS entries (1.3 KB each in HBM, one more wave of the rate
-    // loop); the alternative for a stream left out is the host resolving its chains, which runs 8 variants per unit as
-    // well and needs the host in the middle of the job (a 14 KB message in 10 000 frames: 6.0 ms here, 5.3 ms there for
-    // the synchronous call; through the pipe the host's turn is what stalls: DESIGN 4a), so the only limit is memory:
-    // 8 GB of entries
+    // every unit a message can reach costs 8 to MP3S_SELECT_VARIANTS entries (1.3 KB each in HBM, one more wave of the
+    // rate loop); the alternative for a stream left out is the host resolving its chains, which runs 8 variants per unit
+    // as well and needs the host in the middle of the job (a 14 KB message in 10 000 frames: 5.7 ms here, 5.6 ms and more
+    // there for the synchronous call; through the pipe the host's turn is what stalls: DESIGN 4a), so the only limit is
+    // memory: 8 GB of entries
     const int budget = select_disabled() ? 0 : (int)std::min<int64_t>((int64_t)L.units * MP3S_SELECT_VARIANTS, 6000000);
     // how far the message gets is a question of the tables the units in front offer: 2.8 per unit on music, none in silence
     // (the first seconds of many a file).  Where the stream being re-encoded is known, its own table counts say how many
@@ -138,7 +138,7 @@ int enc_fill(std::vector<EncSeg> &segs, EncLayout &L, uint8_t *dst)
     if (L.n_entries > 0) {
         int32_t *ent = (int32_t *)(dst + L.o_ent);
         for (const auto &s : segs)
-            if (s.reach > 0) select_entries(s.first * 4, s.reach, s.first_entry, s.hide_base + s.n_hide, ent, ent + L.n_entries);
+            if (s.reach > 0) select_entries(s.first * 4, s.reach, s.first_entry, s.hide_base + s.n_hide, (int64_t)s.n_hide - cursor0(s), ent, ent + L.n_entries);
     }
     off[0] = 0;
     for (int f = 0; f < L.n; f++) off[f + 1] = off[f] + (uint32_t)(L.whole + pad8[f]);

@@ -267,8 +267,8 @@ struct EncDev {
     // results of the variant entries (L.n_entries of them; read by the selection right behind the rate loop)
     int16_t *d_ixv = nullptr; mp3s_gr_out *d_outv = nullptr; int32_t *d_env = nullptr;
 };
-// the MP3S_SELECT_VARIANTS entries of each of a stream's first `reach` units (variant-major: entry (v, j) = first_entry + v * reach + j)
-void select_entries(int first_unit, int reach, int first_entry, int hide_end, int32_t *ent_unit, int32_t *ent_cursor);
+// the entries of a stream's first `reach` units (variant-major, the two "bits left" rows from MP3S_SELECT_TAIL_FIRST on: mp3s.h)
+void select_entries(int first_unit, int reach, int first_entry, int hide_end, int64_t bits_left, int32_t *ent_unit, int32_t *ent_cursor);
 // device buffers for L.n_entries variant entries from the context's pool (slots of the host's variants, free at that point)
 bool enc_variant_buffers(mp3s_ctx *c, const EncLayout &L, EncDev &d);
 // transforms -> rate loop on the guessed cursors -> chain check -> bit packing, all on c->stream, nothing waited for.

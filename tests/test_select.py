@@ -21,22 +21,35 @@ def test_plan_layout_and_limits(mlib):
     segs["hide_base"] = [32, 132, 132, 100132, 100232]
     segs["hide_begin"] = [32, 132, 132, 100132, 100232 + 995]
     segs["hide_end"] = [132, 132, 100132, 100232, 100232 + 1000]
-    spans, unit, cursor = mlib.select_plan(segs, 1 << 18)            # (stream 2 would take 35 400 units x 10 entries)
+    spans, unit, cursor = mlib.select_plan(segs, 1 << 18)            # (stream 2 would take 35 400 units x 8 to 10 entries)
     reach0 = 100 * 5 // 14 + 32
+
+    def tail_first(bits_left, reach):                                 # MP3S_SELECT_TAIL_FIRST
+        return 0 if bits_left < 2 else min((bits_left - 2) // 3, reach)
+
+    def entries(bits_left, reach):                                    # MP3S_SELECT_ENTRIES
+        return 8 * reach + 2 * (reach - tail_first(bits_left, reach))
+    t0 = tail_first(100, reach0)
+    assert t0 == 32 and entries(100, reach0) == 8 * reach0 + 2 * (reach0 - 32)
     assert spans["reach"].tolist() == [reach0, 0, 0, 40, 5 * 5 // 14 + 32]
     assert mlib.select_plan(segs, 1 << 20)[0]["reach"].tolist() == [reach0, 0, 35400, 40, 5 * 5 // 14 + 32]
-    assert spans["first_entry"].tolist()[:1] == [0] and spans["first_entry"][3] == reach0 * 10
-    assert len(unit) == (reach0 + 40 + 33) * 10
-    # variant-major: entry (v, j) = first_entry + v * reach + j; patterns at 4v, then the message's own last two bits / last bit
-    e0 = unit[:reach0 * 10].reshape(10, reach0)
+    n0, n3, n4 = entries(100, reach0), entries(100, 40), entries(5, 33)
+    assert n3 == 8 * 40 + 2 * 8 and n4 == 8 * 33 + 2 * 32
+    assert spans["first_entry"].tolist()[:1] == [0] and spans["first_entry"][3] == n0 and spans["first_entry"][4] == n0 + n3
+    assert len(unit) == n0 + n3 + n4
+    # variant-major: 8 rows of patterns (cursors 4v into the pattern table) over all planned units, then the message's own
+    # last two bits / last bit over the units from tail_first on (no unit in front of them can get that far)
+    e0 = unit[:8 * reach0].reshape(8, reach0)
     assert (e0 == np.arange(reach0)[None, :]).all()
-    c0 = cursor[:reach0 * 10].reshape(10, reach0)
-    assert c0[:, 0].tolist() == [0, 4, 8, 12, 16, 20, 24, 28, 130, 131]
-    e3 = unit[reach0 * 10:(reach0 + 40) * 10].reshape(10, 40)
+    assert cursor[:8 * reach0].reshape(8, reach0)[:, 0].tolist() == [0, 4, 8, 12, 16, 20, 24, 28]
+    e0t = unit[8 * reach0:n0].reshape(2, reach0 - t0)
+    assert (e0t == np.arange(t0, reach0)[None, :]).all()
+    assert cursor[8 * reach0:n0].reshape(2, reach0 - t0)[:, 0].tolist() == [130, 131]
+    e3 = unit[n0:n0 + 8 * 40].reshape(8, 40)
     assert (e3 == 9000 * 4 + np.arange(40)[None, :]).all()          # the whole 10-frame stream: 40 units < the message's reach
     # capacity: what does not fit any more is left out, later streams that fit are still planned
-    spans2, unit2, _ = mlib.select_plan(segs, reach0 * 10 + 400)
-    assert spans2["reach"].tolist() == [reach0, 0, 0, 40, 0] and len(unit2) == (reach0 + 40) * 10
+    spans2, unit2, _ = mlib.select_plan(segs, n0 + n3 + 10)
+    assert spans2["reach"].tolist() == [reach0, 0, 0, 40, 0] and len(unit2) == n0 + n3
     # a message array without the patterns in front cannot be planned
     segs["hide_base"][0] = 0
     assert mlib.select_plan(segs, 1 << 20)[0]["reach"][0] == 0
