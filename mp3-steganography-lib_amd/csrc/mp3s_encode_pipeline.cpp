@@ -57,6 +57,14 @@ int enc_layout(std::vector<EncSeg> &segs, int samplerate, int bitrate_kbps, EncL
     // how far the message gets is a question of the tables the units in front offer: 2.8 per unit on music, none in silence
     // (the first seconds of many a file).  Where the stream being re-encoded is known, its own table counts say how many
     // units that takes (hiding takes a table away here and there: 1/16 more, and some)
+    // The device's re-runs (launch_chain's `redo`: three more launches, which return at once when nothing is listed but
+    // still take their 15 us of a stream's time) are issued where they can be needed: what they put right are units that
+    // read inherited addresses -- quiet granules, behind a silence -- or ran behind the end of a plan, behind a silence
+    // again.  A stream whose own units all carry tables has neither; raw PCM (no stream to ask) gets them always.  A wrong
+    // guess costs time only: the check's verdict then sends the job to the host as before.
+    L.redo = false;
+    for (const EncSeg &s : segs)
+        if (!s.tables_guess || std::memchr(s.tables_guess, 0, (size_t)s.n_frames * 4)) L.redo = true;
     std::vector<int32_t> min_reach(segs.size(), 0);
     for (size_t si = 0; si < segs.size(); si++) {
         const EncSeg &s = segs[si];
@@ -202,7 +210,7 @@ int enc_issue(mp3s_ctx *c, const EncLayout &L, const EncDev &d, hipStream_t tail
         // (with the device's own re-runs of the units that inherited other addresses than the zeros they were given)
         const ChainRedoArgs redo = {d_mdct, d_hide, L.n_hide, d.d_ix, d.d_en};
         const int e = launch_chain(ts, d.d_out, d_rf, L.n, d_segs, d_cur, nullptr, d.d_agg, d.d_small,
-                                   (mp3s_chain_seg_out *)((uint8_t *)d.d_small + kSmallHead), &c->prof, redo_disabled() ? nullptr : &redo);
+                                   (mp3s_chain_seg_out *)((uint8_t *)d.d_small + kSmallHead), &c->prof, redo_disabled() || !L.redo ? nullptr : &redo);
         if (e) rc = fail(MP3S_E_HIP, "chain launch: %s", hipGetErrorString((hipError_t)e));
     }
     // packed on the assumption that the verdict is "nothing to redo" (the common case); the caller discards it otherwise

@@ -244,6 +244,7 @@ struct EncSeg {             // one stream of an encode batch: frames back to bac
 struct EncLayout {
     int n = 0, n_all = 0, lead = 0, units = 0, n_hide = 0, n_segs = 0;
     int n_entries = 0, max_reach = 0;   // message variants run inside the first rate-loop launch (mp3s_rate_select_dev)
+    bool redo = true;              // the chain check is issued with the device's re-runs behind it (launch_chain's `redo`)
     int sri = 0, bri = 0, whole = 0, samplerate = 0, kbps = 0;
     size_t o_rf = 0, o_cur = 0, o_hide = 0, o_segs = 0, o_off = 0, o_pad = 0, o_spans = 0, o_ent = 0, bytes = 0;   // (headers at offset 0)
     size_t mp3_bytes = 0;          // all frames of the batch
