@@ -341,6 +341,56 @@ typedef struct {
 int mp3s_huffman_decode_dev(mp3s_ctx *ctx, const uint8_t *d_blob, const mp3s_frame_side *d_side, int n_frames, int nch,
                             int max_part2_3_length, int16_t *d_is, mp3s_granule_si *d_si, int32_t *d_status);
 
+/* ---- the byte-level scan split in two: a walk from header to header on the host, everything else on the device
+ * replaces: the same lines as mp3s_scan_stream -- reference decoder/MP3_Parser.py:68-80 and Frame.py:288-316 (the walk: frame
+ *           sizes are a recurrence on the headers), decoder/FrameSideInformation.py:39-137 and Frame.py:318-363 (side info
+ *           taken apart field by field, main data collected from where the bit reservoir left it: on the device, one
+ *           wavefront per frame, from the file image as it is).
+ * The walk takes REGULAR streams -- MPEG-1 Layer III frames whose reservoir pointers stay inside the file -- and reports
+ * anything else (regular = 0: false syncs parsed as other layers, free-format headers that inherit fields, pointers in front
+ * of the file): such a stream goes through mp3s_scan_stream, which follows the reference through every oddity. */
+typedef struct {
+    uint32_t file_off;         /* offset of the frame header in the byte image the device holds */
+    uint32_t md_off;           /* where the frame's main data goes in the blob (multiple of 4) */
+    uint16_t md_len;           /* ... and how long it is (reservoir bytes included) */
+    uint16_t frame_size;       /* bytes the frame loop steps over (Frame.py:311-316) */
+    uint16_t stream;           /* index into the batch's mp3s_stream_ref array */
+    uint16_t flags;            /* MP3S_FS_HOST_DECODED: the Huffman kernel leaves the frame alone */
+} mp3s_frame_ref; /* 16 bytes */
+typedef struct {
+    uint32_t base, end;        /* the stream's file image inside the batch's byte image: [base, end); bytes behind `end` read
+                                * as zero (reference decoder/util.py:41-43) */
+    uint32_t first_frame;      /* its first frame in the batch (mp3s_frame_side.reserved, mp3s_frame_hdr.stream_first) */
+    uint32_t n_frames;
+    uint16_t prev_size[9];     /* what Frame.__prev_frame_size holds in front of first_frame's gather (SURVEY D11 at a stream's start) */
+    uint16_t reserved[3];
+} mp3s_stream_ref; /* 40 bytes */
+typedef struct {
+    int32_t regular;              /* 0: use mp3s_scan_stream for this stream (nothing else below is meaningful) */
+    int32_t n_frames, nch, sampling_rate, bit_rate, dup_last_frame;
+    int32_t max_part2_3_length;   /* over all granules: the bound mp3s_huffman_decode_dev wants */
+    int32_t any_silent;           /* some granule has no big values */
+    size_t blob_len;              /* bytes of blob the frames take */
+    const mp3s_frame_ref *refs;   /* [n_frames]: file_off counted from the start of the file, md_off from 0, stream 0 */
+    mp3s_stream_ref stream;       /* base 0, end = len, first_frame 0 */
+    const uint8_t *tables;        /* [n_frames][4]: code books in use per granule in the encoder's unit order (frame, ch, gr); stereo only */
+} mp3s_walked;
+int mp3s_walk_stream(const uint8_t *file, size_t len, mp3s_buf **owner, mp3s_walked *out);
+/* d_image[0] / d_blob[0] are byte image_base / md_base of what the references count in (a chunk of a long file brings its own
+ * piece of both); d_tsel optional: per frame the twelve table indices, five bits each in the order the stego bits walk them
+ * (channel, granule, region), the four window-switching flags above them -- mp3s_stego_bits turns them into the bits;
+ * d_status: one zeroed word, MP3S_PS_* are OR-ed in.  Records as mp3s_scan_stream writes them, except table_select[2] of
+ * window-switching granules and sub_block_gain of the others: a granule keeps those from the frame before,
+ * nothing on the device reads them, they are zero here. */
+#define MP3S_PS_INHERITS 1   /* scalefactors are inherited across frames somewhere (mp3s_scanned.gpu_ok == 0) */
+#define MP3S_PS_MISMATCH 2   /* a frame's main data came out another length than its reference says */
+int mp3s_parse_frames_dev(mp3s_ctx *ctx, const uint8_t *d_image, uint32_t image_base, const mp3s_frame_ref *d_refs,
+                          const mp3s_stream_ref *d_streams, int n_frames, uint32_t md_base, mp3s_frame_side *d_side,
+                          mp3s_frame_hdr *d_hdr, uint8_t *d_blob, uint64_t *d_tsel, int32_t *d_status);
+/* replaces: __get_frame_huffman_tables + bit_from_huffman_tables -- reference decoder/Frame.py:676-685, decoder/util.py:67-81.
+ * carry[4]: the third table index each (channel, granule) was left with by the frames in front (zeros at a stream's start), updated */
+int mp3s_stego_bits(const uint64_t *tsel, int64_t n_frames, int nch, uint8_t carry[4], mp3s_buf **owner, const uint8_t **bits, size_t *n_bits);
+
 /* replaces: __format_bitstream for every frame of the batch -- reference encoder/MP3_Encoder.py:1097-1145 (stuffing),
  * 1266-1547; one workgroup per frame, one wavefront per granule*channel, code lengths prefix-summed across lanes.
  * gr must be final (serial chain resolved, silent units carrying their inherited quantizer_step); en as written by

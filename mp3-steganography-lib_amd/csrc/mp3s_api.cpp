@@ -518,6 +518,54 @@ int mp3s_scan_stream(const uint8_t *file, size_t len, mp3s_buf **owner, mp3s_sca
     return MP3S_OK;
 }
 
+int mp3s_walk_stream(const uint8_t *file, size_t len, mp3s_buf **owner, mp3s_walked *out)
+{
+    if (!file || !owner || !out) return fail(MP3S_E_ARG, "null pointer");
+    std::memset(out, 0, sizeof *out);
+    std::unique_ptr<mp3s_buf> b(new mp3s_buf());
+    FrameWalker w;
+    const int rc = w.open(file, len);
+    if (rc) return fail(rc, "malformed or unsupported MP3 stream");
+    // refs and table counts live in the generic payload: [refs (16 bytes each) | tables (4 bytes each)]
+    const size_t cap = len / 24 + 16;          // no Layer III frame is shorter than 24 bytes
+    b->bytes.resize(cap * 20);
+    FrameRef *refs = reinterpret_cast<FrameRef *>(b->bytes.data());
+    uint8_t *tables = b->bytes.data() + cap * 16;
+    std::memset(tables, 0, cap * 4);
+    w.tables_wanted = 0x7fffffffffffffffL;
+    long n = 0;
+    while (!w.ended && !w.irregular && (size_t)n < cap) n += w.next(refs + n, (long)(cap - (size_t)n), tables + (size_t)n * 4, 0, 0);
+    *owner = b.release();
+    if (w.irregular || !w.ended) return MP3S_OK;   // regular = 0
+    out->regular = 1;
+    out->n_frames = (int32_t)n; out->nch = w.nch; out->sampling_rate = w.sampling_rate; out->bit_rate = w.bit_rate;
+    out->dup_last_frame = w.dup_last ? 1 : 0; out->max_part2_3_length = w.max_p23; out->any_silent = w.any_silent ? 1 : 0;
+    out->blob_len = n > 0 ? (size_t)refs[n - 1].md_off + refs[n - 1].md_len + 8 : 0; out->refs = refs; out->tables = tables;
+    out->stream.base = 0; out->stream.end = (uint32_t)len; out->stream.first_frame = 0; out->stream.n_frames = (uint32_t)n;
+    if (n > 0) FrameWalker::history(refs, 0, out->stream.prev_size);
+    return MP3S_OK;
+}
+
+int mp3s_parse_frames_dev(mp3s_ctx *c, const uint8_t *d_image, uint32_t image_base, const mp3s_frame_ref *d_refs, const mp3s_stream_ref *d_streams,
+                          int n_frames, uint32_t md_base, mp3s_frame_side *d_side, mp3s_frame_hdr *d_hdr, uint8_t *d_blob, uint64_t *d_tsel,
+                          int32_t *d_status)
+{
+    if (!c || !d_image || !d_refs || !d_streams || !d_side || !d_hdr || !d_blob || !d_status) return fail(MP3S_E_ARG, "null pointer");
+    if (n_frames <= 0) return fail(MP3S_E_ARG, "n_frames=%d", n_frames);
+    const int e = launch_parse(c->stream, d_image, image_base, d_refs, d_streams, n_frames, md_base, d_side, d_hdr, d_blob, d_tsel, d_status);
+    if (e) return fail(MP3S_E_HIP, "parse launch: %s", hipGetErrorString((hipError_t)e));
+    return MP3S_OK;
+}
+
+int mp3s_stego_bits(const uint64_t *tsel, int64_t n_frames, int nch, uint8_t carry[4], mp3s_buf **owner, const uint8_t **bits, size_t *n_bits)
+{
+    if ((!tsel && n_frames) || n_frames < 0 || nch < 1 || nch > 2 || !carry || !owner || !bits || !n_bits) return fail(MP3S_E_ARG, "bad argument");
+    mp3s_buf *b = new mp3s_buf();
+    stego_bits_from_tsel(tsel, (long)n_frames, nch, carry, b->bits);
+    *bits = b->bits.data(); *n_bits = b->bits.size(); *owner = b;
+    return MP3S_OK;
+}
+
 int mp3s_parse_stream(const uint8_t *file, size_t len, mp3s_buf **owner, mp3s_parsed *out)
 {
     if (!file || !owner || !out) return fail(MP3S_E_ARG, "null pointer");

@@ -82,6 +82,17 @@ int launch_select(hipStream_t stream, const mp3s_chain_seg *d_segs, const mp3s_s
                   const uint8_t *d_hide, const RateVariantArgs &v, int16_t *d_ix, int32_t *d_en, mp3s_gr_out *d_out, int32_t *d_cursor,
                   void *d_pairs /* n_segs * max_reach * 8 bytes of scratch */, Profiler *prof);
 
+// side-info parse + main-data gather on the device (k_parse.hpp) from the file image and the host's frame walk (FrameRef /
+// StreamRef of mp3s_host.h, 16 / 40 bytes): side records, frame headers and the blob as the host scan would have written
+// them.  image_base / md_base: what d_image[0] and d_blob[0] are in the offsets the references hold (a chunk of a long
+// file brings its own piece of both).  d_tsel optional (decode jobs: the stego bits are put together from it on the host);
+// d_status: one word the caller has zeroed, PARSE_* bits are OR-ed in.
+using FrameRef = mp3s_frame_ref;
+using StreamRef = mp3s_stream_ref;
+constexpr int kParseInherits = 1, kParseMismatch = 2;
+int launch_parse(hipStream_t stream, const uint8_t *d_image, uint32_t image_base, const FrameRef *d_refs, const StreamRef *d_streams, int n_frames,
+                 uint32_t md_base, mp3s_frame_side *d_side, mp3s_frame_hdr *d_hdr, uint8_t *d_blob, uint64_t *d_tsel, int32_t *d_status);
+
 constexpr size_t kPlaceEntry = 4912;   // [int32 frame, pad to 16 | int16 is[2304] | mp3s_granule_si si[4]]
 int launch_place_frames(hipStream_t stream, const uint8_t *d_entries, int n_entries, int16_t *d_is, mp3s_granule_si *d_si);
 int launch_copy(hipStream_t stream, const void *d_src, void *d_dst, size_t bytes);

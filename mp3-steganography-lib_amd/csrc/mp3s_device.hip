@@ -6,6 +6,7 @@
 
 #include "../../include/mp3s.h"
 #include "mp3s_device.h"
+#include "mp3s_host.h"
 #include "mp3s_tables.h"
 
 namespace mp3s {
@@ -16,6 +17,7 @@ __constant__ DevTables c_tab;
 #include "k_encode.hpp"
 #include "k_rate.hpp"
 #include "k_huffman.hpp"
+#include "k_parse.hpp"
 #include "k_pack.hpp"
 #include "k_chain.hpp"
 
@@ -237,6 +239,18 @@ int launch_huffman(hipStream_t stream, const uint8_t *d_blob, const mp3s_frame_s
     else MP3S_HUF_LAUNCH(4, 16);
 #undef MP3S_HUF_LAUNCH
     if (prof) prof->end(stream, pp);
+    return (int)hipGetLastError();
+}
+
+static_assert(sizeof(ParseFrameRef) == sizeof(FrameRef) && sizeof(ParseStreamRef) == sizeof(StreamRef), "frame / stream references out of sync with mp3s_host.h");
+
+int launch_parse(hipStream_t stream, const uint8_t *d_image, uint32_t image_base, const FrameRef *d_refs, const StreamRef *d_streams, int n_frames,
+                 uint32_t md_base, mp3s_frame_side *d_side, mp3s_frame_hdr *d_hdr, uint8_t *d_blob, uint64_t *d_tsel, int32_t *d_status)
+{
+    if (n_frames <= 0) return 0;
+    hipLaunchKernelGGL(k_dec_parse, dim3((n_frames + PARSE_WAVES - 1) / PARSE_WAVES), dim3(PARSE_WAVES * 64), 0, stream, d_image, image_base,
+                       reinterpret_cast<const ParseFrameRef *>(d_refs), reinterpret_cast<const ParseStreamRef *>(d_streams), n_frames, md_base, d_side,
+                       d_hdr, d_blob, d_tsel, d_status);
     return (int)hipGetLastError();
 }
 

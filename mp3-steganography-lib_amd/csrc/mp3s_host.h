@@ -73,6 +73,59 @@ const StreamIndexInfo &index_info(const StreamIndex *ix);
 int parse_stream_range(const uint8_t *file, size_t len, const StreamIndex *ix, long first, long count, ParsedStream &out, ScanSink *sink);
 int parse_stream_range(const uint8_t *file, size_t len, const StreamIndex *ix, long first, long count, ParsedStream &out, ScannedStream &scan);
 
+// ---- the frame walk: all the host still does per frame when the side info is parsed and the main data gathered on the
+//      device (launch_parse, k_parse.hpp).  The walk steps from header to header exactly as the reference's frame loop does
+//      (decoder/MP3_Parser.py:68-80, Frame.py:288-316) and reads three things of every frame's side info: main_data_begin
+//      (where the frame's main data starts: Frame.py:318-363), the part2_3_length fields (the longest granule sizes the
+//      Huffman kernel's staging) and, for a re-encode, how many code books each granule uses (the cursor plan of the rate
+//      loop).  It handles REGULAR streams -- MPEG-1 Layer III frames whose reservoir pointers stay inside the file -- and
+//      says so when a stream is anything else (`irregular`): such a stream takes the byte-level scan above, which follows
+//      the reference through every oddity.
+using FrameRef = mp3s_frame_ref;     // one frame for the device parser, 16 bytes (include/mp3s.h)
+using StreamRef = mp3s_stream_ref;   // one stream (or one chunk of a stream) of a batch, 40 bytes
+struct WalkHeader {            // FrameHeader fields; they persist from frame to frame like the Python object's
+    double version = 0; int layer = 0, crc = 0, bit_rate = 0, sampling_rate = 0, padding = 0, mode = 0, channels = 0;
+    int mode_ext0 = 0; int sr_idx = -1;
+};
+struct FrameWalker {
+    // 0, or the code parse_stream fails with before it reaches a frame
+    int open(const uint8_t *file, size_t len);
+    // up to `cap` more frames: refs[i] with file_off counted from the start of the file plus `image_base`, md_off running on
+    // from md_cursor, stream = `stream`; tables4 (optional, [cap][4]): code books in use per granule in the ENCODER's unit
+    // order (frame, channel, granule) for as long as `tables_wanted` says.  Returns the number of frames written; 0 once the
+    // stream has ended (`ended`) or cannot be walked (`irregular` / `error`).
+    long next(FrameRef *refs, long cap, uint8_t *tables4, uint32_t image_base, uint16_t stream);
+    // Frame.__prev_frame_size as the gather of frame `f` sees it, from the refs of the stream's frames [0, f)
+    static void history(const FrameRef *stream_refs, long f, uint16_t out[9]);
+    // scalefactors + Huffman of the frame emitted LAST, on the host (the asynchronous paths decode a stream's last frame
+    // here: SURVEY E14); *alone = nothing in it is inherited from another frame (otherwise the result must not be used)
+    int decode_last(int16_t *is2304, mp3s_granule_si *si4, bool *alone);
+
+    bool ended = false, dup_last = false, irregular = false;
+    int error = 0;                       // the code parse_stream returns for this stream (set together with irregular)
+    int nch = 0, sampling_rate = 0, bit_rate = 0;   // channel count of the first frame; rate / bitrate of the LAST header walked
+    int max_p23 = 0;                     // largest part2_3_length so far
+    bool any_silent = false;             // some granule without big values so far
+    long n_frames = 0;                   // frames emitted so far
+    uint32_t md_cursor = 0;              // the next frame's md_off
+    long tables_wanted = 0;              // tables4 is filled until this many code books have been counted (0: never)
+    long tables_frames = 0, tables_seen = 0;   // frames whose tables4 entries are valid; code books counted in them
+
+    // ---- the frame loop's state (MP3_Parser / Frame / FrameHeader objects)
+    const uint8_t *file = nullptr; long flen = 0;
+    WalkHeader hd;
+    int frame_size = 0, prev[9] = {0}, first_nch = 0;
+    long offset = 0;
+    // ... and the same in front of the frame emitted last
+    WalkHeader last_hd; int last_frame_size = 0, last_prev[9] = {0}; long last_offset = 0; int last_first_nch = 0;
+};
+// stego bits of a stream from what the device parser leaves per frame (tsel[f]: the twelve table indices of the frame, five
+// bits each in the order the reference walks them -- channel, granule, region -- and above them the four window-switching
+// flags): a window-switching granule parses two regions only and keeps the third index of the frame before,
+// which is serial and stays here.  `carry` = the four stale indices in front of the first frame (zeros at a stream's start),
+// updated.  reference: decoder/Frame.py:676-685, decoder/util.py:67-81
+void stego_bits_from_tsel(const uint64_t *tsel, long n_frames, int nch, uint8_t carry[4], std::vector<uint8_t> &bits);
+
 // scalefactors + Huffman of ONE frame of a scanned stream (side record + its main data in the blob): the host's answer for
 // a frame the device Huffman kernel flags; exact for gpu_ok streams (no frame inherits anything from another)
 int parse_scanned_frame(const mp3s_frame_side &fs, const uint8_t *blob, int16_t *is2304, mp3s_granule_si *si4);

@@ -124,10 +124,7 @@ void py_slice_append(std::vector<uint8_t> &dst, const uint8_t *data, long n, lon
     if (stop > start) dst.insert(dst.end(), data + start, data + stop);
 }
 
-struct Header {            // FrameHeader fields; persist from frame to frame like the Python object
-    double version = 0; int layer = 0, crc = 0, bit_rate = 0, sampling_rate = 0, padding = 0, mode = 0, channels = 0;
-    int mode_ext0 = 0; int sr_idx = -1;
-};
+using Header = WalkHeader;   // FrameHeader fields; persist from frame to frame like the Python object (mp3s_host.h)
 
 int parse_header(Header &h, const uint8_t *b)
 {
@@ -664,6 +661,179 @@ int parse_scanned_frame(const mp3s_frame_side &fs, const uint8_t *blob, int16_t 
     int32_t table_select[12];
     const Bits mb{blob + fs.md_off, (long)fs.md_len};
     return decode_main_data(HT, si, fs.nch, fs.sr_idx, mb, is2304, si4, table_select);
+}
+
+
+// ---------------------------------------------------------------- the frame walk (device-side parse: k_parse.hpp)
+namespace {
+// n <= 25 bits at bit `pos` of a byte string that is readable for 8 bytes from (pos >> 3)
+inline uint32_t bits_at(const uint8_t *p, int pos, int n)
+{
+    uint64_t w;
+    std::memcpy(&w, p + (pos >> 3), 8);
+    w = __builtin_bswap64(w);
+    return (uint32_t)((w << (pos & 7)) >> (64 - n));
+}
+}  // namespace
+
+int FrameWalker::open(const uint8_t *f, size_t len)
+{
+    *this = FrameWalker();
+    file = f; flen = (long)len;
+    // ID3v2 skip (decoder/ID3_Parser.py:95-131), as scan_core
+    if (flen >= 10 && file[0] == 'I' && file[1] == 'D' && file[2] == '3' && !(file[5] & 0x0f)) {
+        long size = 0;
+        for (int i = 0; i < 4; i++) size = (size << 7) + file[6 + i];
+        offset = size + ((file[5] >> 4) & 1 ? 20 : 10);
+    }
+    if (flen - offset < 2) return MP3S_E_MALFORMED;
+    const uint8_t *buffer = file + offset;
+    if (!(buffer[0] == 0xFF && buffer[1] >= 0xE0)) { ended = true; return 0; }   // nothing is parsed: an empty WAV at rate 0
+    if (flen - offset < 4) return MP3S_E_MALFORMED;
+    int rc = parse_header(hd, buffer);
+    if (rc) return rc;
+    // D11: set_frame_size runs once before the loop
+    if (hd.sampling_rate == 0) return MP3S_E_MALFORMED;
+    {
+        int spf = 0;
+        if (hd.layer == 3) spf = hd.version == 1 ? 1152 : 576;
+        else if (hd.layer == 2) spf = 1152;
+        else if (hd.layer == 1) spf = 384;
+        frame_size = (int)((((double)spf / 8) * hd.bit_rate) / hd.sampling_rate);
+        if (hd.padding == 1) frame_size += 1;
+    }
+    if (!(flen > offset + 4)) ended = true;
+    return 0;
+}
+
+long FrameWalker::next(FrameRef *refs, long cap, uint8_t *tables4, uint32_t image_base, uint16_t stream)
+{
+    long n = 0;
+    while (n < cap && !ended && !irregular) {
+        const uint8_t *buffer = file + offset;
+        const long buflen = flen - offset;
+        // the state in front of this frame (decode_last resumes the byte-level scan from it)
+        last_hd = hd; last_frame_size = frame_size; std::memcpy(last_prev, prev, sizeof prev); last_offset = offset; last_first_nch = first_nch;
+        int rc = parse_header(hd, buffer);   // (the sync was checked when the frame before was passed)
+        if (rc) { irregular = true; error = rc; break; }
+        // anything but MPEG-1 Layer III with a sampling rate of its own: header fields would carry over from earlier
+        // frames (FrameHeader.py:125-143), false syncs are taken apart as whatever they claim -- the byte-level scan's business
+        if (hd.version != 1 || hd.layer != 3 || ((buffer[2] >> 2) & 3) == 3 || hd.sr_idx < 0) { irregular = true; break; }
+        for (int i = 8; i > 0; i--) prev[i] = prev[i - 1];
+        prev[0] = frame_size;
+        frame_size = (int)(((1152.0 / 8) * hd.bit_rate) / hd.sampling_rate);
+        if (hd.padding == 1) frame_size += 1;
+        if (frame_size <= 0) { irregular = true; error = MP3S_E_MALFORMED; break; }
+        if (first_nch == 0) first_nch = hd.channels;
+        else if (hd.channels != first_nch) { irregular = true; error = MP3S_E_UNSUPPORTED; break; }
+        const int nch_f = hd.channels;
+        // ---- side info: the fields the host needs, read where they lie (fixed positions: both layouts of a granule take 59 bits)
+        const long sstart = hd.crc == 0 ? 6 : 4;
+        uint8_t sbuf[48];
+        const uint8_t *sb = buffer + sstart;
+        if (buflen < sstart + 40) {          // the stream ends inside the side info: bits past the end read as 0
+            std::memset(sbuf, 0, sizeof sbuf);
+            if (buflen > sstart) std::memcpy(sbuf, buffer + sstart, (size_t)std::min<long>(buflen - sstart, 40));
+            sb = sbuf;
+        }
+        const int mdb = (int)bits_at(sb, 0, 9);
+        const int ubase = nch_f == 2 ? 20 : 18;
+        for (int u = 0; u < 2 * nch_f; u++) {
+            const int b = ubase + 59 * u;
+            max_p23 = std::max(max_p23, (int)bits_at(sb, b, 12));
+            if (bits_at(sb, b + 12, 9) == 0) any_silent = true;
+        }
+        if (tables4 && nch_f == 2 && tables_frames == n_frames && tables_seen < tables_wanted) {
+            for (int gr = 0; gr < 2; gr++)
+                for (int ch = 0; ch < 2; ch++) {
+                    const int b = ubase + 59 * (gr * 2 + ch);
+                    int t = 0;
+                    if (bits_at(sb, b + 12, 9)) {
+                        if (bits_at(sb, b + 33, 1)) t = (bits_at(sb, b + 37, 5) != 0) + (bits_at(sb, b + 42, 5) != 0);
+                        else t = (bits_at(sb, b + 34, 5) != 0) + (bits_at(sb, b + 39, 5) != 0) + (bits_at(sb, b + 44, 5) != 0);
+                    }
+                    tables4[(size_t)n * 4 + ch * 2 + gr] = (uint8_t)t;
+                    tables_seen += t;
+                }
+            tables_frames++;
+        }
+        // ---- main data: how long it is (Frame.py:318-363); every part must lie inside the file where the pointers say
+        const int constant = (hd.mode == 3 ? 21 : 36) + (hd.crc == 0 ? 2 : 0);
+        long md_len = std::max<long>(0, std::min<long>(frame_size, buflen) - constant);
+        if (mdb != 0) {
+            long bound = 0;
+            int fr = 0;
+            for (; fr < 9; fr++) {
+                const long part = (long)prev[fr] - constant;
+                if (mdb < bound + part) break;
+                if (part < 0) { fr = 9; break; }
+                bound += part;
+            }
+            // not found: the reference goes on with the main data of the frame before; a pointer in front of the file wraps
+            // around (Python slices) -- both are the byte-level scan's business
+            if (fr >= 9 || offset - mdb - (long)fr * constant < 0) { irregular = true; break; }
+            md_len += mdb;
+        }
+        if (md_len > 0xffff || frame_size > 0xffff || (uint64_t)offset + image_base > 0xffffffffull || (uint64_t)md_cursor + (uint64_t)md_len + 16 > 0xffffffffull) {
+            irregular = true; break;
+        }
+        FrameRef &r = refs[n];
+        r.file_off = (uint32_t)offset + image_base; r.md_off = md_cursor; r.md_len = (uint16_t)md_len; r.frame_size = (uint16_t)frame_size;
+        r.stream = stream; r.flags = 0;
+        md_cursor = (uint32_t)((md_cursor + md_len + 8 + 3) & ~(uint32_t)3);
+        n++; n_frames++;
+        offset += frame_size;
+        if (!(flen > offset + 4)) ended = true;
+        else if (!(file[offset] == 0xFF && file[offset + 1] >= 0xE0)) { ended = true; dup_last = true; }   // D12
+    }
+    nch = first_nch ? first_nch : hd.channels;
+    sampling_rate = hd.sampling_rate; bit_rate = hd.bit_rate;
+    return n;
+}
+
+void FrameWalker::history(const FrameRef *stream_refs, long f, uint16_t out[9])
+{
+    // prev[i] at frame f = the size of frame f - 1 - i; in front of frame 0 stands frame 0's own size once (D11), zeros before it
+    for (int i = 0; i < 9; i++) {
+        const long g = f - 1 - i;
+        out[i] = g >= 0 ? stream_refs[g].frame_size : (g == -1 && f >= 0 ? stream_refs[0].frame_size : 0);
+    }
+}
+
+int FrameWalker::decode_last(int16_t *is2304, mp3s_granule_si *si4, bool *alone)
+{
+    if (n_frames <= 0) return MP3S_E_ARG;
+    ScanState st;
+    st.hd = last_hd; st.frame_size = last_frame_size; st.first_nch = last_first_nch; st.offset = last_offset;
+    for (int i = 0; i < 9; i++) st.prev_frame_size[i] = last_prev[i];
+    uint8_t blob[4096];
+    mp3s_frame_side side[1];
+    ScanSink k;
+    k.blob = blob; k.blob_cap = sizeof blob; k.side = side; k.side_cap = 1; k.lean = true;
+    ParsedStream tmp;
+    const int rc = scan_core(file, (size_t)flen, tmp, &k, &st, 0, 1, nullptr);
+    if (rc) return rc;
+    if (k.n_side != 1) return MP3S_E_MALFORMED;
+    if (alone) *alone = k.gpu_ok;
+    return parse_scanned_frame(side[0], blob, is2304, si4);
+}
+
+void stego_bits_from_tsel(const uint64_t *tsel, long n_frames, int nch, uint8_t carry[4], std::vector<uint8_t> &bits)
+{
+    const HostTables &HT = host_tables();
+    for (long f = 0; f < n_frames; f++) {
+        const uint64_t w = tsel[f];
+        for (int ch = 0; ch < nch; ch++)
+            for (int gr = 0; gr < 2; gr++) {
+                const int cls = ch * 2 + gr;
+                const bool ws = (w >> (60 + cls)) & 1;
+                for (int r = 0; r < 3; r++) {
+                    int t = (int)((w >> (5 * (cls * 3 + r))) & 31);
+                    if (r == 2) { if (ws) t = carry[cls]; else carry[cls] = (uint8_t)t; }
+                    if (t) bits.push_back(HT.in_h0[t] ? 0 : 1);
+                }
+            }
+    }
 }
 
 }  // namespace mp3s

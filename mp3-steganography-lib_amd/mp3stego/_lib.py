@@ -71,6 +71,24 @@ class Scanned(C.Structure):
                 ("frame_size", C.c_void_p)]
 
 
+FRAME_REF_DTYPE = np.dtype([("file_off", "<u4"), ("md_off", "<u4"), ("md_len", "<u2"), ("frame_size", "<u2"), ("stream", "<u2"), ("flags", "<u2")])
+STREAM_REF_DTYPE = np.dtype([("base", "<u4"), ("end", "<u4"), ("first_frame", "<u4"), ("n_frames", "<u4"), ("prev_size", "<u2", (9,)),
+                             ("reserved", "<u2", (3,))])
+assert FRAME_REF_DTYPE.itemsize == 16 and STREAM_REF_DTYPE.itemsize == 40
+PS_INHERITS, PS_MISMATCH = 1, 2
+
+
+class StreamRef(C.Structure):
+    _fields_ = [("base", C.c_uint32), ("end", C.c_uint32), ("first_frame", C.c_uint32), ("n_frames", C.c_uint32),
+                ("prev_size", C.c_uint16 * 9), ("reserved", C.c_uint16 * 3)]
+
+
+class Walked(C.Structure):
+    _fields_ = [("regular", C.c_int32), ("n_frames", C.c_int32), ("nch", C.c_int32), ("sampling_rate", C.c_int32), ("bit_rate", C.c_int32),
+                ("dup_last_frame", C.c_int32), ("max_part2_3_length", C.c_int32), ("any_silent", C.c_int32), ("blob_len", C.c_size_t),
+                ("refs", C.c_void_p), ("stream", StreamRef), ("tables", C.c_void_p)]
+
+
 class Decoded(C.Structure):
     _fields_ = [("n_frames", C.c_int32), ("nch", C.c_int32), ("sampling_rate", C.c_int32), ("bit_rate", C.c_int32),
                 ("n_bits", C.c_int32), ("n_rows", C.c_int64), ("pcm", C.c_void_p), ("bits", C.c_void_p)]
@@ -250,6 +268,9 @@ def lib():
         L.mp3s_decode_block_indexed.argtypes = [vp, vp, sz, vp, C.c_int64, C.c_int64, i32, pvp, C.POINTER(Decoded)]
         L.mp3s_reencode_block_indexed.argtypes = [vp, vp, sz, vp, vp, sz, i32, i32, C.POINTER(Carry), pvp, C.POINTER(Block)]
         L.mp3s_hide_message_chunked.argtypes = [vp, vp, sz, vp, sz, C.c_int64, pvp, C.POINTER(File)]
+        L.mp3s_walk_stream.argtypes = [vp, sz, pvp, C.POINTER(Walked)]
+        L.mp3s_parse_frames_dev.argtypes = [vp, vp, C.c_uint32, vp, vp, i32, C.c_uint32, vp, vp, vp, vp, vp]
+        L.mp3s_stego_bits.argtypes = [vp, i64, i32, vp, pvp, pvp, psz]
         L.mp3s_pipe_create.argtypes = [vp, i32, sz, i32, pvp]
         L.mp3s_pipe_destroy.argtypes = [vp]
         L.mp3s_pipe_destroy.restype = None
@@ -347,6 +368,25 @@ class Context:
         p = self.alloc(arr.nbytes)
         self.upload(p, arr)
         return p
+
+    def parse_frames(self, data: bytes, walked, want_tsel=True):
+        """side info + main-data gather of a walked stream on the device: -> dict(side, hdr, blob, tsel, status)"""
+        n = walked["n_frames"]
+        d_img = self.to_device(np.frombuffer(data, dtype=np.uint8))
+        d_refs, d_streams = self.to_device(walked["refs"]), self.to_device(walked["stream"])
+        d_side, d_hdr, d_blob = self.alloc(n * 104), self.alloc(n * 8), self.alloc(walked["blob_len"] + 16)
+        d_tsel = self.alloc(n * 8) if want_tsel else None
+        d_st = self.to_device(np.zeros(4, dtype=np.int32))
+        try:
+            check(lib().mp3s_parse_frames_dev(self.handle, d_img, 0, d_refs, d_streams, n, 0, d_side, d_hdr, d_blob, d_tsel, d_st))
+            return {"side": self.download(d_side, FRAME_SIDE_DTYPE, (n,)), "hdr": self.download(d_hdr, FRAME_HDR_DTYPE, (n,)),
+                    "blob": self.download(d_blob, np.uint8, (walked["blob_len"],)),
+                    "tsel": self.download(d_tsel, np.uint64, (n,)) if want_tsel else None,
+                    "status": int(self.download(d_st, np.int32, (4,))[0])}
+        finally:
+            for p in (d_img, d_refs, d_streams, d_side, d_hdr, d_blob, d_tsel, d_st):
+                if p is not None:
+                    self.free(p)
 
     def wait_for(self, other):
         """work submitted to this context from now on starts after everything submitted to `other` so far"""
@@ -839,6 +879,39 @@ def scan_stream(data: bytes):
                 "side": _view(p.side, FRAME_SIDE_DTYPE, (n,)), "hdr": _view(p.hdr, FRAME_HDR_DTYPE, (n,)),
                 "blob": _view(p.blob, np.uint8, (p.blob_len,)), "bits": _view(p.bits, np.uint8, (p.n_bits,)),
                 "frame_size": _view(p.frame_size, np.int32, (n,))}
+    finally:
+        lib().mp3s_buf_free(owner)
+
+
+def walk_stream(data: bytes):
+    """Host walk from frame header to frame header (no GPU): what the device-side parser (Context.parse_frames_dev) needs.
+    regular == False: the stream needs scan_stream (false syncs, inherited header fields, pointers in front of the file)."""
+    buf = np.frombuffer(data, dtype=np.uint8)
+    owner = C.c_void_p()
+    w = Walked()
+    check(lib().mp3s_walk_stream(buf.ctypes.data, len(data), C.byref(owner), C.byref(w)))
+    try:
+        if not w.regular:
+            return {"regular": False}
+        n = w.n_frames
+        stream = np.zeros(1, dtype=STREAM_REF_DTYPE)
+        C.memmove(stream.ctypes.data, C.byref(w.stream), 40)
+        return {"regular": True, "n_frames": n, "channels": w.nch, "sampling_rate": w.sampling_rate, "bit_rate": w.bit_rate,
+                "dup_last_frame": w.dup_last_frame, "max_part2_3_length": w.max_part2_3_length, "any_silent": bool(w.any_silent),
+                "blob_len": w.blob_len, "refs": _view(w.refs, FRAME_REF_DTYPE, (n,)), "stream": stream,
+                "tables": _view(w.tables, np.uint8, (n, 4))}
+    finally:
+        lib().mp3s_buf_free(owner)
+
+
+def stego_bits(tsel, nch, carry=None):
+    """stego bits from the per-frame table-index words the device parser leaves (mp3s_stego_bits); -> (bits, carry)"""
+    tsel = np.ascontiguousarray(tsel, dtype=np.uint64)
+    carry = np.zeros(4, dtype=np.uint8) if carry is None else np.ascontiguousarray(carry, dtype=np.uint8).copy()
+    owner, bits, n = C.c_void_p(), C.c_void_p(), C.c_size_t()
+    check(lib().mp3s_stego_bits(tsel.ctypes.data, len(tsel), nch, carry.ctypes.data, C.byref(owner), C.byref(bits), C.byref(n)))
+    try:
+        return _view(bits.value, np.uint8, (n.value,)), carry
     finally:
         lib().mp3s_buf_free(owner)
 
