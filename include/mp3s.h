@@ -109,6 +109,31 @@ int mp3s_sync(mp3s_ctx *ctx);
  * submitted to other before it has finished.  This is how a second context runs the bit-level front end of the next
  * batch (mp3s_huffman_decode_dev) under the transform kernels of the current one. */
 int mp3s_ctx_wait(mp3s_ctx *ctx, mp3s_ctx *other);
+/* Options of a context (what used to be MP3S_* environment switches read in the middle of a job: the environment now only
+ * provides the DEFAULTS, read once by mp3s_ctx_create -- the names in brackets -- so two contexts of one process can differ
+ * and no job path calls getenv).  Set them while nothing is in flight on the context. */
+#define MP3S_OPT_SELECT 1          /* 1: the message cursor is decided on the device (mp3s_rate_select_dev); 0: guessed cursors,
+                                    * checked and resolved afterwards [MP3S_NO_SELECT=1 -> 0] */
+#define MP3S_OPT_REDO 2            /* 1: the chain check's re-runs on the device (mp3s_chain_redo_dev) [MP3S_NO_REDO=1 -> 0] */
+#define MP3S_OPT_FAST_IMDCT 3      /* 1: int16 decode through the mirrored, fused IMDCT behind the guard [MP3S_FAST_IMDCT=0 -> 0] */
+#define MP3S_OPT_PIPE_TAIL 4       /* 1: a pipe created on this context puts a job's tail on a stream of its own [MP3S_PIPE_TAIL=1] */
+#define MP3S_OPT_CHUNK_FRAMES 5    /* frames per chunk when ONE file goes through the overlapped stages (mp3s_hide_message, mp3s_clear_file,
+                                    * mp3s_decode_file, mp3s_decode_stream); 0 = chosen from the file's length [MP3S_CHUNK_FRAMES] */
+#define MP3S_OPT_DEVICE_PARSE 6    /* 1: side info and main-data gather on the device (mp3s_parse_frames_dev) wherever the stream is
+                                    * regular; 0: the host's byte-level scan everywhere [MP3S_DEVICE_PARSE=0 -> 0] */
+#define MP3S_OPT_FILE_PIPELINE 7   /* 1: the one-file calls above run as chunks through overlapped stages; 0: scan, upload, kernels,
+                                    * download one after the other as in round 2 [MP3S_FILE_PIPELINE=0 -> 0] */
+#define MP3S_OPT_SCAN_THREADS 8    /* host threads a multi-file call may use for its front end; 0 = from the CPUs this process may
+                                    * run on (sched_getaffinity, cgroup quota) divided by the ranks on this host [MP3S_SCAN_THREADS] */
+#define MP3S_OPT_COUNT 9
+/* what became of the one-file calls of this context (mp3s_hide_message, mp3s_clear_file, mp3s_decode_file, mp3s_decode_stream,
+ * mp3s_hide_message_chunked): files that went through the overlapped stages as chunks, their chunks, chunks that were run
+ * again because they depended on a carry the guess got wrong, chunks whose chains the host resolved, and files that took
+ * the stages one after the other instead (streams the frame walk does not take, mono re-encodes, ...) */
+typedef struct { int64_t files, chunks, reruns, resolved, fallbacks; } mp3s_run_stats;
+int mp3s_ctx_run_stats(mp3s_ctx *ctx, mp3s_run_stats *out);
+int mp3s_ctx_set_option(mp3s_ctx *ctx, int option, int64_t value);
+int mp3s_ctx_get_option(mp3s_ctx *ctx, int option, int64_t *value);
 /* host copy of the constant tables uploaded to the device (struct DevTables of csrc/mp3s_tables.h), for tests */
 const void *mp3s_debug_tables(size_t *bytes);
 /* host (glibc) evaluation of the __calc_scfsi energies of one granule*channel: en[0..20] bands, en[21] total.

@@ -412,6 +412,7 @@ __global__ __launch_bounds__(WAVES * 64) void k_dec_huffman(
         if (e4) atomicOr(&sync[1], e4);
     }
     __syncthreads();
+    __threadfence();   // the group's error atomics (other lanes, possibly another L2 channel) are visible device-wide before its arrival is counted
     if (threadIdx.x == 0 && atomicAdd(&sync[0], 1) == (int)gridDim.x - 1) {
         status[0] = atomicExch(&sync[1], 0);
         atomicExch(&sync[0], 0);

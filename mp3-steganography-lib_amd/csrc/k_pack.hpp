@@ -256,6 +256,7 @@ __global__ __launch_bounds__(256) void k_enc_pack(
     // (Only device-scope atomics touch the pair, so no cache write-back is needed: the barrier waits for this group's
     // error atomics to be acknowledged before its arrival is counted.)
     __syncthreads();
+    __threadfence();   // the group's error atomics (other lanes, possibly another L2 channel) are visible device-wide before its arrival is counted
     if (threadIdx.x == 0 && atomicAdd(&sync[0], 1) == (int)gridDim.x - 1) {
         *status = atomicExch(&sync[1], 0);
         atomicExch(&sync[0], 0);

@@ -80,6 +80,18 @@ int mp3s_ctx_create(int device, mp3s_ctx **out)
     if (e != hipSuccess) return fail(MP3S_E_NO_DEVICE, "hipSetDevice(%d): %s", device, hipGetErrorString(e));
     mp3s_ctx *c = new mp3s_ctx();
     c->device = device;
+    {
+        // the environment provides the defaults, once
+        auto env = [](const char *name, int64_t dflt) { const char *v = getenv(name); return v && *v ? (int64_t)atoll(v) : dflt; };
+        c->opt[MP3S_OPT_SELECT] = getenv("MP3S_NO_SELECT") ? 0 : 1;
+        c->opt[MP3S_OPT_REDO] = getenv("MP3S_NO_REDO") ? 0 : 1;
+        c->opt[MP3S_OPT_FAST_IMDCT] = env("MP3S_FAST_IMDCT", 1) != 0;
+        c->opt[MP3S_OPT_PIPE_TAIL] = env("MP3S_PIPE_TAIL", 0) == 1;
+        c->opt[MP3S_OPT_CHUNK_FRAMES] = std::max<int64_t>(0, env("MP3S_CHUNK_FRAMES", 0));
+        c->opt[MP3S_OPT_DEVICE_PARSE] = env("MP3S_DEVICE_PARSE", 1) != 0;
+        c->opt[MP3S_OPT_FILE_PIPELINE] = env("MP3S_FILE_PIPELINE", 1) != 0;
+        c->opt[MP3S_OPT_SCAN_THREADS] = std::max<int64_t>(0, env("MP3S_SCAN_THREADS", 0));
+    }
     if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess ||
         hipEventCreate(&c->ev0) != hipSuccess || hipEventCreate(&c->ev1) != hipSuccess ||
         hipEventCreateWithFlags(&c->ev_order, hipEventDisableTiming) != hipSuccess) {
@@ -105,6 +117,7 @@ void mp3s_ctx_destroy(mp3s_ctx *c)
 {
     if (!c) return;
     hipSetDevice(c->device);
+    destroy_own_pipe(c);
     if (c->stream) hipStreamSynchronize(c->stream);
     if (c->scratch) hipFree(c->scratch);
     if (c->d_sync) hipFree(c->d_sync);
@@ -114,6 +127,29 @@ void mp3s_ctx_destroy(mp3s_ctx *c)
     if (c->ev_order) hipEventDestroy(c->ev_order);
     if (c->stream) hipStreamDestroy(c->stream);
     delete c;
+}
+
+int mp3s_ctx_set_option(mp3s_ctx *c, int option, int64_t value)
+{
+    if (!c || option <= 0 || option >= MP3S_OPT_COUNT) return fail(MP3S_E_ARG, "unknown option %d", option);
+    if (value < 0 || (option == MP3S_OPT_CHUNK_FRAMES && value != 0 && value < 4) || (option == MP3S_OPT_SCAN_THREADS && value > 64))
+        return fail(MP3S_E_ARG, "option %d: value %lld out of range", option, (long long)value);
+    c->opt[option] = option == MP3S_OPT_CHUNK_FRAMES || option == MP3S_OPT_SCAN_THREADS ? value : (value != 0);
+    return MP3S_OK;
+}
+
+int mp3s_ctx_run_stats(mp3s_ctx *c, mp3s_run_stats *out)
+{
+    if (!c || !out) return fail(MP3S_E_ARG, "null pointer");
+    *out = c->run_stats;
+    return MP3S_OK;
+}
+
+int mp3s_ctx_get_option(mp3s_ctx *c, int option, int64_t *value)
+{
+    if (!c || !value || option <= 0 || option >= MP3S_OPT_COUNT) return fail(MP3S_E_ARG, "unknown option %d", option);
+    *value = c->opt[option];
+    return MP3S_OK;
 }
 
 int mp3s_device_name(mp3s_ctx *c, char *buf, size_t n)
@@ -269,7 +305,7 @@ int mp3s_decode_transform_dev(mp3s_ctx *c, const int16_t *d_is, const mp3s_granu
     int rc = c->ensure_scratch(dec_scratch_bytes(n_frames, nch));
     if (rc) return rc;
     const int e = launch_decode(c->stream, d_is, d_si, d_hdr, n_frames, nch, n_halo, out_format, d_pcm, c->scratch, &c->prof, 0,
-                                c->synth_eps_scale, c->d_sync);
+                                c->synth_eps_scale, c->d_sync, c->opt[MP3S_OPT_FAST_IMDCT] != 0);
     if (e) return fail(MP3S_E_HIP, "decode launch: %s", hipGetErrorString((hipError_t)e));
     return MP3S_OK;
 }

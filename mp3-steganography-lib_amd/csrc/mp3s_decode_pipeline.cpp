@@ -67,7 +67,7 @@ int decode_transform_chunk(mp3s_ctx *c, const int16_t *d_is, const mp3s_granule_
     int rc = c->ensure_scratch(dec_scratch_bytes(cnt, nch));
     if (rc) return rc;
     const int e = launch_decode(c->stream, d_is + (size_t)first * 2304, d_si + (size_t)first * 4, d_hdr + first, cnt, nch, halo, out_format,
-                                d_pcm, c->scratch, &c->prof, (int)first, c->synth_eps_scale, c->d_sync);
+                                d_pcm, c->scratch, &c->prof, (int)first, c->synth_eps_scale, c->d_sync, c->opt[MP3S_OPT_FAST_IMDCT] != 0);
     if (e) return fail(MP3S_E_HIP, "decode launch: %s", hipGetErrorString((hipError_t)e));
     return MP3S_OK;
 }
@@ -403,6 +403,17 @@ int mp3s_decode_block_indexed(mp3s_ctx *c, const uint8_t *file, size_t len, cons
 int mp3s_decode_stream(mp3s_ctx *c, const uint8_t *file, size_t len, int out_format, mp3s_buf **owner, mp3s_decoded *out)
 {
     if (!file) return fail(MP3S_E_ARG, "null pointer");
+    if (c && owner && out && out_format >= 0 && out_format <= 2) {
+        // the file as chunks through the overlapped stages; kRunFallback: one stage after the other below (same samples)
+        RunResult r;
+        const int rc = run_file(c, file, len, kRunDecode, nullptr, 0, out_format, owner, &r);
+        if (rc != kRunFallback) {
+            if (rc) return rc;
+            out->n_frames = (int32_t)r.n_frames; out->nch = r.nch; out->sampling_rate = r.sampling_rate; out->bit_rate = r.bit_rate;
+            out->n_bits = (int32_t)r.n_bits; out->n_rows = r.n_rows; out->pcm = r.pcm; out->bits = r.bits;
+            return MP3S_OK;
+        }
+    }
     return mp3s_decode_streams(c, &file, &len, 1, out_format, owner, out, nullptr);
 }
 
@@ -412,7 +423,13 @@ int mp3s_decode_file(mp3s_ctx *c, const uint8_t *mp3, size_t len, mp3s_buf **own
     // the PCM lands 64 bytes into its buffer; the 44-byte WAV header goes right in front of it: no second copy
     mp3s_buf *b = nullptr;
     mp3s_decoded d;
-    const int rc = decode_streams_impl(c, &mp3, &len, 1, MP3S_PCM_I16, 64, &b, &d, nullptr);
+    RunResult r;
+    int rc = run_file(c, mp3, len, kRunDecode, nullptr, 0, MP3S_PCM_I16, &b, &r);   // chunks through the overlapped stages ...
+    if (rc == MP3S_OK) {
+        d.n_frames = (int32_t)r.n_frames; d.nch = r.nch; d.sampling_rate = r.sampling_rate; d.bit_rate = r.bit_rate;
+        d.n_bits = (int32_t)r.n_bits; d.n_rows = r.n_rows; d.pcm = r.pcm; d.bits = r.bits;
+    } else if (rc == kRunFallback)                                                    // ... or one stage after the other
+        rc = decode_streams_impl(c, &mp3, &len, 1, MP3S_PCM_I16, 64, &b, &d, nullptr);
     if (rc) return rc;
     uint8_t *wav;
     if (d.n_rows == 0) {   // nothing decoded: what scipy writes for an empty 1-d array at the header object's initial rate 0

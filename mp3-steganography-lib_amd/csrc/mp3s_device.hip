@@ -58,7 +58,7 @@ size_t dec_scratch_bytes(int n_frames, int nch)
 
 int launch_decode(hipStream_t stream, const int16_t *d_is, const mp3s_granule_si *d_si, const mp3s_frame_hdr *d_hdr,
                   int n_frames, int nch, int n_halo, int out_format, void *d_pcm, void *d_scratch, Profiler *prof, int sf_base,
-                  double synth_eps_scale, int32_t *d_sync)
+                  double synth_eps_scale, int32_t *d_sync, bool fast_imdct)
 {
     const long T = (long)n_frames * 36;
     double *S = (double *)d_scratch;
@@ -67,7 +67,6 @@ int launch_decode(hipStream_t stream, const int16_t *d_is, const mp3s_granule_si
     const int n_gran = n_frames * 2;
     // int16 output through the fast kernels (guarded; needs the context's counters), everything else in the reference's order
     const bool fast = out_format == MP3S_PCM_I16 && synth_eps_scale > 0 && d_sync;
-    static const bool fast_imdct = !(getenv("MP3S_FAST_IMDCT") && atoi(getenv("MP3S_FAST_IMDCT")) == 0);
     // granules per wave: each wave also primes itself with half an IMDCT of the granule before its run, so longer
     // runs waste less; pick the run length (2..8) that fills whole rounds of the chip's wave slots best (168 VGPRs ->
     // 3 waves per SIMD -> 256 CUs x 12 = 3072 slots)

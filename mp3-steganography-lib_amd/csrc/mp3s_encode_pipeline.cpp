@@ -10,10 +10,7 @@ static int64_t cursor0(const EncSeg &s)
     return s.carry_in ? std::min<int64_t>(std::max<int64_t>(s.carry_in->cursor, 0), kNoCursor) : 0;
 }
 
-static bool redo_disabled() { return getenv("MP3S_NO_REDO") != nullptr; }
-static bool select_disabled() { return getenv("MP3S_NO_SELECT") != nullptr; }   // (read per batch: tests switch it)
-
-int enc_layout(std::vector<EncSeg> &segs, int samplerate, int bitrate_kbps, EncLayout &L)
+int enc_layout(std::vector<EncSeg> &segs, int samplerate, int bitrate_kbps, EncLayout &L, bool select)
 {
     // -1 sits in the reference's bitrate table (encoder/util.py:27,42), so its header check lets it through and the
     // encoder then runs on negative slot counts; nothing meaningful to reproduce
@@ -53,7 +50,7 @@ int enc_layout(std::vector<EncSeg> &segs, int samplerate, int bitrate_kbps, EncL
     // as well and needs the host in the middle of the job (a 14 KB message in 10 000 frames: 5.7 ms here, 5.6 ms and more
     // there for the synchronous call; through the pipe the host's turn is what stalls: DESIGN 4a), so the only limit is
     // memory: 8 GB of entries
-    const int budget = select_disabled() ? 0 : (int)std::min<int64_t>((int64_t)L.units * MP3S_SELECT_VARIANTS, 6000000);
+    const int budget = !select ? 0 : (int)std::min<int64_t>((int64_t)L.units * MP3S_SELECT_VARIANTS, 6000000);
     // how far the message gets is a question of the tables the units in front offer: 2.8 per unit on music, none in silence
     // (the first seconds of many a file).  Where the stream being re-encoded is known, its own table counts say how many
     // units that takes (hiding takes a table away here and there: 1/16 more, and some)
@@ -63,18 +60,21 @@ int enc_layout(std::vector<EncSeg> &segs, int samplerate, int bitrate_kbps, EncL
     // again.  A stream whose own units all carry tables has neither; raw PCM (no stream to ask) gets them always.  A wrong
     // guess costs time only: the check's verdict then sends the job to the host as before.
     L.redo = false;
-    for (const EncSeg &s : segs)
-        if (!s.tables_guess || std::memchr(s.tables_guess, 0, (size_t)s.n_frames * 4)) L.redo = true;
+    for (const EncSeg &s : segs) {
+        const size_t known = s.n_guess < 0 ? (size_t)s.n_frames * 4 : (size_t)std::min(s.n_guess, s.n_frames * 4);
+        if (s.any_silent >= 0 ? s.any_silent != 0 : (!s.tables_guess || known < (size_t)s.n_frames * 4 || std::memchr(s.tables_guess, 0, known))) L.redo = true;
+    }
     std::vector<int32_t> min_reach(segs.size(), 0);
     for (size_t si = 0; si < segs.size(); si++) {
         const EncSeg &s = segs[si];
         const int64_t left = (int64_t)cs[si].hide_end - cs[si].hide_begin;
         if (!s.tables_guess || left <= 0) continue;
         const int64_t need = left + left / 16 + 48;
-        int64_t offered = 0;
-        int j = 0;
-        while (j < s.n_frames * 4 && offered < need) offered += s.tables_guess[j++];
-        min_reach[si] = (int32_t)std::min<int64_t>((int64_t)s.n_frames * 4, (int64_t)j + 32);
+        int64_t offered = 0, j = 0;
+        const int64_t known = s.n_guess < 0 ? (int64_t)s.n_frames * 4 : std::min<int64_t>(s.n_guess, (int64_t)s.n_frames * 4);
+        while (j < known && offered < need) offered += s.tables_guess[j++];
+        if (offered < need) j += (need - offered) * 5 / 14;   // behind what is known of the stream: 2.8 tables per unit
+        min_reach[si] = (int32_t)std::min<int64_t>((int64_t)s.n_frames * 4, j + 32);
     }
     L.n_entries = select_plan(cs.data(), L.n_segs, spans.data(), nullptr, nullptr, budget, min_reach.data());
     L.max_reach = 0;
@@ -135,7 +135,7 @@ int enc_fill(std::vector<EncSeg> &segs, EncLayout &L, uint8_t *dst)
         int64_t ahead = 0;               // tables the units in front are expected to take
         for (int j = 0; j < s.n_frames * 4; j++) {
             cursor[(size_t)s.first * 4 + j] = long_msg ? kNoCursor : (int32_t)std::min<int64_t>((int64_t)s.hide_base + c0 + ahead, kNoCursor);
-            ahead += s.tables_guess ? s.tables_guess[j] : 3;
+            ahead += s.tables_guess && (s.n_guess < 0 || j < s.n_guess) ? s.tables_guess[j] : 3;
         }
         spans[si].first_entry = s.first_entry; spans[si].reach = s.reach;
         cs[si].first_frame = s.first; cs[si].n_frames = s.n_frames;
@@ -210,7 +210,7 @@ int enc_issue(mp3s_ctx *c, const EncLayout &L, const EncDev &d, hipStream_t tail
         // (with the device's own re-runs of the units that inherited other addresses than the zeros they were given)
         const ChainRedoArgs redo = {d_mdct, d_hide, L.n_hide, d.d_ix, d.d_en};
         const int e = launch_chain(ts, d.d_out, d_rf, L.n, d_segs, d_cur, nullptr, d.d_agg, d.d_small,
-                                   (mp3s_chain_seg_out *)((uint8_t *)d.d_small + kSmallHead), &c->prof, redo_disabled() || !L.redo ? nullptr : &redo);
+                                   (mp3s_chain_seg_out *)((uint8_t *)d.d_small + kSmallHead), &c->prof, !c->opt[MP3S_OPT_REDO] || !L.redo ? nullptr : &redo);
         if (e) rc = fail(MP3S_E_HIP, "chain launch: %s", hipGetErrorString((hipError_t)e));
     }
     // packed on the assumption that the verdict is "nothing to redo" (the common case); the caller discards it otherwise
@@ -255,8 +255,9 @@ int enc_resolve(mp3s_ctx *c, const EncLayout &L, std::vector<EncSeg> &segs, cons
     b->scfsi.assign((size_t)n * 8, 0);
     std::vector<int32_t> &cursor = c->h_cursor, &state = c->h_state;
     cursor.assign((const int32_t *)(in + L.o_cur), (const int32_t *)(in + L.o_cur) + units);
-    // (the selection on the device has written the cursors of the units it replaced)
-    if (!rc && L.n_entries > 0) rc = mp3s_dev_download(c, cursor.data(), d_in + L.o_cur, (size_t)units * 4);
+    // (the selection on the device has written the cursors of the units it replaced, and the chain check's re-runs those
+    // of the units they ran again -- also in a batch without a plan)
+    if (!rc && (L.n_entries > 0 || (L.redo && c->opt[MP3S_OPT_REDO]))) rc = mp3s_dev_download(c, cursor.data(), d_in + L.o_cur, (size_t)units * 4);
     state.assign((size_t)units * 4, 0);
     int passes = 1;
     // ---- resolve the serial chains, stream by stream: hide cursor (MP3_Encoder.py:808-809) and the per-(gr,ch) inherited
@@ -470,7 +471,7 @@ int encode_batch(mp3s_ctx *c, const int16_t *pcm, const int16_t *pcm_dev, std::v
                  mp3s_buf *b, int *passes_out, bool want_gr)
 {
     EncLayout L;
-    int rc = enc_layout(segs, samplerate, bitrate_kbps, L);
+    int rc = enc_layout(segs, samplerate, bitrate_kbps, L, c->opt[MP3S_OPT_SELECT] != 0);
     if (rc) return rc;
     const int n = L.n, units = L.units, n_all = L.n_all;
     HIPCHK(hipSetDevice(c->device));
@@ -849,6 +850,22 @@ int mp3s_hide_message_chunked(mp3s_ctx *c, const uint8_t *mp3, size_t len, const
                               mp3s_buf **owner, mp3s_file *out)
 {
     if (!c || !mp3 || !owner || !out || chunk_frames < 2) return fail(MP3S_E_ARG, "bad argument (chunks of at least 2 frames)");
+    if (chunk_frames >= 4) {
+        // the chunks through the overlapped stages, several in flight; a stream that path does not take: chunk after chunk below
+        const int64_t keep = c->opt[MP3S_OPT_CHUNK_FRAMES];
+        c->opt[MP3S_OPT_CHUNK_FRAMES] = chunk_frames;
+        RunResult r;
+        static const uint8_t empty = 0;
+        const int rr = run_file(c, mp3, len, utf8 ? kRunHide : kRunClear, utf8 ? utf8 : &empty, utf8 ? n_msg : 0, MP3S_PCM_I16, owner, &r);
+        c->opt[MP3S_OPT_CHUNK_FRAMES] = keep;
+        if (rr != kRunFallback) {
+            if (rr) return rr;
+            std::memset(out, 0, sizeof *out);
+            out->data = r.mp3; out->len = r.mp3_len; out->kbps = r.kbps; out->sampling_rate = r.sampling_rate; out->channels = 2;
+            out->n_frames = (int32_t)r.n_frames; out->too_long = r.too_long; out->hide_offset = r.hide_offset;
+            return MP3S_OK;
+        }
+    }
     mp3s_index *index = nullptr;
     mp3s_index_info info;
     int rc = mp3s_index_stream(mp3, len, &index, &info);
@@ -882,6 +899,18 @@ int mp3s_hide_message_chunked(mp3s_ctx *c, const uint8_t *mp3, size_t len, const
 
 static int reencode(mp3s_ctx *c, const uint8_t *mp3, size_t len, const uint8_t *msg, size_t n_msg, bool hide, mp3s_buf **owner, mp3s_file *out)
 {
+    // the file as chunks through the overlapped stages (walk || upload || kernels || download); what that path does not take
+    // (irregular streams, mono, a repeated last frame, a message that reaches further than a chunk ...) comes back as
+    // kRunFallback and goes through the stages one after the other below -- the same bytes either way
+    RunResult r;
+    const int rc = run_file(c, mp3, len, hide ? kRunHide : kRunClear, msg, n_msg, MP3S_PCM_I16, owner, &r);
+    if (rc != kRunFallback) {
+        if (rc) return rc;
+        std::memset(out, 0, sizeof *out);
+        out->data = r.mp3; out->len = r.mp3_len; out->kbps = r.kbps; out->sampling_rate = r.sampling_rate; out->channels = 2;
+        out->n_frames = (int32_t)r.n_frames; out->too_long = r.too_long; out->hide_offset = r.hide_offset;
+        return MP3S_OK;
+    }
     const uint8_t *const no_msg = nullptr;
     return mp3s_hide_messages(c, &mp3, &len, 1, hide ? &msg : &no_msg, &n_msg, owner, out, nullptr);
 }

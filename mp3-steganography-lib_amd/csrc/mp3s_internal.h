@@ -34,8 +34,12 @@ using namespace mp3s;
         if (e_ != hipSuccess) return fail(MP3S_E_HIP, "%s: %s", #call, hipGetErrorString(e_));       \
     } while (0)
 
+struct mp3s_pipe;
 struct mp3s_ctx {
     int device = 0;
+    int64_t opt[MP3S_OPT_COUNT] = {0};   // MP3S_OPT_*: defaults from the environment at creation, then mp3s_ctx_set_option
+    mp3s_run_stats run_stats = {0, 0, 0, 0, 0};
+    mp3s_pipe *own_pipe = nullptr;       // the overlapped stages the one-file calls run their chunks through (made on first use)
     hipStream_t stream = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr, ev_order = nullptr;
     int32_t *d_sync = nullptr;        // {finished workgroups, error bits} of the pack kernel in flight: self-clearing;
@@ -67,6 +71,9 @@ struct mp3s_ctx {
     std::vector<uint8_t> h_blob;
     // ... and the scan result of the last single-file call, lent to the next one for its capacity
     ScannedStream spare_scan;
+    // ... and the frame table / table counts of the file run_file is working on
+    std::vector<FrameRef> h_refs;
+    std::vector<uint8_t> h_tables;
     int ensure_scratch(size_t bytes)
     {
         if (bytes <= scratch_bytes) return 0;
@@ -230,6 +237,8 @@ struct EncSeg {             // one stream of an encode batch: frames back to bac
     // the non-zero table indices of the SAME audio in the stream it was decoded from (side info of the input, unit order
     // frame / channel / granule; silence has none).  n_frames * 4 entries, or null.
     const uint8_t *tables_guess = nullptr;
+    int n_guess = -1;                // units tables_guess covers (-1: all n_frames * 4); behind them the guess is 3 per unit
+    int any_silent = -1;             // 1 / 0: some / no unit of the stream is without tables; -1: look into tables_guess
     // filled by encode_batch
     int first = 0, hide_base = 0;
     int reach = 0, first_entry = 0;  // the message cursor is decided on the device over the stream's first `reach` units (0: guessed)
@@ -250,11 +259,11 @@ struct EncLayout {
     size_t mp3_bytes = 0;          // all frames of the batch
     int64_t bytes_before = 0;      // size of the frames in front of a block (E14: the tail cut depends on it)
 };
-// small results of a batch, in one block: verdict[2] (mp3s_chain_resolve_dev), pack status, Huffman status, then seg_out[n_segs]
-constexpr size_t kSmallHead = 16;
+// small results of a batch, in one block: verdict[2] (mp3s_chain_resolve_dev), pack status, Huffman status, parse status, then seg_out[n_segs]
+constexpr size_t kSmallHead = 32;          // (word 4: status of the device-side parse, MP3S_PS_*; 5..7 spare)
 inline size_t small_bytes(int n_segs) { return kSmallHead + (size_t)n_segs * sizeof(mp3s_chain_seg_out); }
 // checks the streams and fills first / hide_base of each
-int enc_layout(std::vector<EncSeg> &segs, int samplerate, int bitrate_kbps, EncLayout &L);
+int enc_layout(std::vector<EncSeg> &segs, int samplerate, int bitrate_kbps, EncLayout &L, bool select = true /* MP3S_OPT_SELECT */);
 // writes the block (L.bytes at dst); *mp3_off_len: per stream {offset, length} of its bytes in the batch's output
 int enc_fill(std::vector<EncSeg> &segs, EncLayout &L, uint8_t *dst);
 struct EncDev {
@@ -289,3 +298,29 @@ int encode_batch(mp3s_ctx *c, const int16_t *pcm, const int16_t *pcm_dev, std::v
 int select_plan(const mp3s_chain_seg *segs, int n_segs, mp3s_select_span *spans, int32_t *ent_unit, int32_t *ent_cursor, int cap,
                 const int32_t *min_reach);
 void tables_guess_of(const mp3s_frame_side *side, long n_frames, int extra, std::vector<uint8_t> &out);
+
+// ---------------------------------------------------------------- one file as chunks through the overlapped stages (mp3s_pipe.cpp)
+constexpr int kRunFallback = 1;          // run_file: not for this path -- the caller takes the synchronous one (same bytes)
+constexpr int kRunHide = 0, kRunClear = 1, kRunDecode = 2;
+struct RunResult {
+    int64_t n_frames = 0, n_rows = 0;
+    int nch = 0, sampling_rate = 0, bit_rate = 0, kbps = 0;
+    const uint8_t *mp3 = nullptr; size_t mp3_len = 0;        // hide / clear
+    int64_t hide_offset = 0; int too_long = 0;
+    const uint8_t *pcm = nullptr;                            // decode: [n_rows][nch] in the format asked for, 64 bytes into its block
+    const uint8_t *bits = nullptr; size_t n_bits = 0;
+};
+// mode: kRunHide (utf8 / n_msg = the message) / kRunClear / kRunDecode (out_format).  MP3S_OK, kRunFallback, or an error.
+int run_file(mp3s_ctx *c, const uint8_t *mp3, size_t len, int mode, const uint8_t *utf8, size_t n_msg, int out_format, mp3s_buf **owner, RunResult *out);
+void destroy_own_pipe(mp3s_ctx *c);
+
+// ---------------------------------------------------------------- what this process may use of the host (mp3s_hostinfo.cpp)
+// CPUs the process may run on: sched_getaffinity, cut down to the cgroup's CPU quota
+int host_cpus_allowed();
+// ranks sharing this host: LOCAL_WORLD_SIZE of the launcher, 1 without one
+int local_world_size();
+// host threads a rank should scan / walk with: MP3S_OPT_SCAN_THREADS, or its share of the allowed CPUs (one is kept for the
+// thread that issues and collects), between 1 and 3
+int default_scan_threads(const mp3s_ctx *c);
+// the CPUs of the GPU's NUMA node that this process may run on (sysfs numa_node of the PCI device); empty: unknown, no binding
+std::vector<int> gpu_node_cpus(int device);

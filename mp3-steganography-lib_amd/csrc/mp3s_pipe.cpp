@@ -1,21 +1,24 @@
-// C-ABI of the library (include/mp3s.h), part 4: the asynchronous host-fed pipeline.
+// C-ABI of the library (include/mp3s.h), part 4: the overlapped stages -- the asynchronous host-fed pipeline (mp3s_pipe_*)
+// and, on the same machinery, ONE file as a sequence of chunks (run_file: what mp3s_hide_message, mp3s_clear_file,
+// mp3s_decode_file and mp3s_decode_stream are made of since round 3).
 //
 // The reference runs one file at a time through two serial frame loops (decoder/MP3_Parser.py:68-80,
-// encoder/MP3_Encoder.py:607-609, glued by steganography.py:153-159).  Here a job (one file, or a list of files that
-// form one device batch) passes through four stages that overlap with those of the jobs around it:
+// encoder/MP3_Encoder.py:607-609, glued by steganography.py:153-159).  Here a job (one file, a list of files that form one
+// device batch, or a chunk of a long file) passes through stages that overlap with those of the jobs around it:
 //
-//   scan      a host worker thread walks the frames (sync, header, side info, reservoir) and writes main data and side
-//             records straight into the job slot's page-locked staging -- no intermediate vectors, no second copy
-//   upload    hipMemcpyAsync on the copy-up stream: staging -> the slot's device inputs
-//   compute   the context's stream: Huffman decode -> decode transforms -> encode transforms -> rate loop -> chain check ->
-//             bit packing; the scratch between the kernels is shared by all slots (one stream = one job at a time)
-//   download  hipMemcpyAsync on the copy-down stream: MP3 bytes + the 16-byte verdict -> a page-locked result block
+//   walk      a host thread steps from frame header to frame header (FrameWalker: frame sizes, reservoir pointers -> where
+//             each frame's main data goes; 16 bytes per frame) -- or, for a stream the walk does not take (false syncs,
+//             inherited header fields ...), the byte-level scan of round 2 (parse_stream_sink straight into the staging)
+//   upload    hipMemcpyAsync on the copy-up stream: the file bytes as they are, from the caller's memory, + the frame table
+//   front end the Huffman stream: side-info parse + main-data gather (k_dec_parse) -> Huffman decode (k_dec_huffman)
+//   compute   the context's stream: decode transforms -> encode transforms -> rate loop -> chain check -> bit packing; the
+//             scratch between the kernels is shared by all slots (one stream = one job at a time)
+//   download  hipMemcpyAsync on the copy-down stream: MP3 bytes + the small verdict block (or PCM) -> page-locked results
 //
-// Events order the three streams; the host waits for nothing until the caller collects a result.  A job whose streams
-// the device cannot take alone (mono, mixed blocks, a repeated last frame, unsupported rates, staging too small), or
-// whose verdict says the cursor guess failed or the Huffman data is damaged, is redone by the synchronous path
-// (mp3s_hide_messages) -- same bytes, by construction of that path; the fast path is an optimisation, never a
-// different answer.
+// Events order the streams; the host waits for nothing until a result is collected.  A job the device cannot take alone
+// (mono re-encode, a repeated last frame, unsupported rates, staging too small), or whose verdict says the Huffman data is
+// damaged, is redone by the synchronous path -- same bytes, by construction of that path; the fast path is an
+// optimisation, never a different answer.
 #include <sched.h>
 #include <time.h>
 
@@ -27,11 +30,17 @@
 namespace {
 
 constexpr int kMaxFastFiles = 1024;
+constexpr size_t kDirectUpload = (size_t)256 << 10;   // a file at least this long goes up from the caller's memory in a copy of its own
+constexpr uint32_t kImageLead = 1024;                 // bytes in front of a chunk's first frame its reservoir pointers can name (511 + 8 x 38)
+constexpr int kRunDepth = 3;                          // chunks of one file in flight
 
 struct Slot {
-    uint8_t *h_stage = nullptr;          // page-locked: [blob | side records | input block]
-    uint8_t *d_stage = nullptr;          // the same layout on the device
-    size_t blob_cap = 0, side_cap = 0 /* frames */, in_cap = 0, fix_cap = 0 /* entries */, o_side = 0, o_in = 0, o_fix = 0, stage_bytes = 0;
+    uint8_t *h_stage = nullptr;          // page-locked: [blob | side records | packed inputs]; the walk uses the last part only
+    uint8_t *d_stage = nullptr;          // the same layout on the device, + [decoder frame headers | table-index words]
+    size_t blob_cap = 0, side_cap = 0 /* frames */, in_cap = 0, fix_cap = 0 /* entries */, pack_cap = 0, o_side = 0, o_in = 0, o_dechdr = 0, o_tsel = 0,
+           stage_bytes = 0;
+    uint8_t *d_image = nullptr; size_t image_cap = 0;   // the file bytes of a walked job
+    uint8_t *h_image = nullptr;                          // page-locked, made on first need: short files are laid end to end here first
     uint8_t *d_mp3 = nullptr; size_t mp3_cap = 0;
     int32_t *d_small = nullptr;
     // the encoder's intermediates of the slot's job (mdct, quantised lines, GrInfo, energies, scfsi): the slot's own, so
@@ -39,6 +48,29 @@ struct Slot {
     uint8_t *d_enc = nullptr; size_t enc_cap = 0;
     hipEvent_t e_start = nullptr, e_up = nullptr, e_huff = nullptr, e_rate = nullptr, e_comp = nullptr, e_down = nullptr;
     bool busy = false;
+};
+
+struct Upload { size_t dst; const uint8_t *src; size_t bytes; };   // into the slot's d_image
+
+// a chunk of one file (run_file): frames [w0, w0 + n_win) of the stream go to the device, of which the first `halo` only
+// rebuild decoder state (IMDCT overlap, synthesis fifo: < 1 frame, Frame.py:151-153, 81-92) and the next `lead` only
+// encoder state (filter bank + MDCT history: 1 056 samples, MP3_Encoder.py:356, 685, 747)
+struct Chunk {
+    bool on = false;
+    const FrameRef *refs = nullptr;      // the stream's frames as walked (file / blob offsets of the whole stream)
+    long w0 = 0, n_win = 0, first = 0, count = 0;
+    int halo = 0, lead = 0;
+    bool last = false;
+    bool has_carry = false; mp3s_carry carry_in = {};
+    int out_format = MP3S_PCM_I16;
+    uint8_t *dst = nullptr;              // where the chunk's bytes go on the host (MP3 frames; PCM of a decode)
+    const uint8_t *file = nullptr; size_t file_len = 0;
+    uint32_t image_lo = 0, image_hi = 0; // the piece of the file that goes up
+    const uint8_t *fix = nullptr;        // kPlaceEntry bytes: the stream's last frame decoded on the host (index in the window filled in here), or null
+    const uint8_t *tables = nullptr; int n_tables = 0; int any_silent = -1;   // the walk's table counts for the chunk's own units
+    const uint8_t *hide = nullptr; int n_hide = 0;
+    int rate = 0, kbps = 0, nch = 2;
+    bool decode = false;
 };
 
 struct Job {
@@ -49,6 +81,11 @@ struct Job {
     bool decode = false;                 // MP3 -> WAV (int16) instead of hide / clear
     enum State { QUEUED, ISSUED, SLOW_DONE } state = QUEUED;
     // fast path
+    bool walked = false;                 // side info and main data are taken apart on the device (k_dec_parse)
+    std::vector<Upload> ups;
+    size_t o_encblk = 0, o_fix = 0, o_refs = 0, o_streams = 0, pack_end = 0;   // packed inputs inside the slot's stage (from its start)
+    uint32_t image_base = 0, md_base = 0;
+    std::vector<uint32_t> stream_first;  // first frame of every stream of the batch
     std::vector<std::vector<uint8_t>> bits, guess;
     std::vector<EncSeg> segs;
     EncLayout L;
@@ -64,10 +101,11 @@ struct Job {
     double scan_ms = 0, issue_ms = 0;
     int n_fix = 0;
     // decode jobs: per file the frames, rows, header fields, where its WAV starts in the result block, its stego bits
-    struct DecFile { int n_frames, nch, rate, bit_rate; size_t wav_off, bits_off, n_bits; };
+    struct DecFile { int n_frames, nch, rate, bit_rate; size_t wav_off, bits_off, n_bits; long first; };
     std::vector<DecFile> dec;
     std::vector<uint8_t> res_bits;
-    int nch = 2, n_total = 0, keep_set = 0;
+    int nch = 2, n_total = 0, max_p23 = 0;
+    Chunk ck;
 };
 
 }  // namespace
@@ -75,23 +113,26 @@ struct Job {
 struct mp3s_pipe {
     mp3s_ctx *c = nullptr;
     int depth = 0;
+    bool internal = false;               // the context's own (run_file): no worker threads, jobs issued by the caller
+    size_t max_job_bytes = 0;
     std::vector<Slot> slots;
     hipStream_t s_up = nullptr, s_down = nullptr;
     // The Huffman kernel is a latency chain that leaves the vector units mostly idle; the rate loop is bound by them.  The
     // front end of job k+1 therefore runs on a stream of its own, under the encode half of job k, with two sets of
     // Huffman outputs (is / side records) taken in turn; e_dec[x] = the decode transforms that read set x last are done.
     hipStream_t s_huff = nullptr;
-    // ... and, optionally (MP3S_PIPE_TAIL=1; measured slower here, see mp3s_pipe_create), the tail of a job (chain check +
+    // ... and, optionally (MP3S_OPT_PIPE_TAIL; measured slower here, see mp3s_pipe_create), the tail of a job (chain check +
     // bit packing) on another one, under the decode transforms of the next job; e_rate orders it behind the job's rate loop
     hipStream_t s_tail = nullptr;
     int last_tail = -1;                  // slot of the job whose tail was issued last
+    bool tail_throttle = false;
     hipEvent_t e_dec[2] = {nullptr, nullptr};
     bool dec_used[2] = {false, false};
     unsigned issued = 0;
-    // the int16 PCM of a batch lives in one of two device buffers taken in turn; a decode job downloads from it while the
+    // the PCM of a batch lives in one of two device buffers taken in turn; a decode job downloads from it while the
     // next job computes: keep_slot[x] = slot of the job whose download reads buffer x last (-1: none)
     int keep_slot[2] = {-1, -1};
-    std::mutex mu;                       // queue, job states, slots
+    std::mutex mu;                       // queue, job states, slots, statistics
     std::condition_variable cv_work, cv_done;
     std::mutex mu_issue;                 // everything that touches the context (its stream, pool, profiler)
     std::deque<std::unique_ptr<Job>> inflight;   // ticket order; front = next to collect
@@ -100,6 +141,7 @@ struct mp3s_pipe {
     // overwrites from there (measured: 0.75 ms per 10 000 frames on the slot's own worker, 2.5 ms on changing ones).
     std::vector<std::deque<Job *>> todo;
     std::vector<std::thread> workers;
+    std::vector<int> node_cpus;          // CPUs of the GPU's NUMA node this process may run on (empty: unknown / no binding)
     bool stop = false;
     int64_t next_ticket = 0;
     mp3s_pipe_stats st = {};
@@ -114,22 +156,228 @@ double thread_cpu_ms()
     return ts.tv_sec * 1e3 + ts.tv_nsec * 1e-6;
 }
 
-int reencode_params(const ParsedStream &p, int *kbps_out)
+int reencode_params(int sampling_rate, int bit_rate, int nch, long n_frames, int dup_last, int *kbps_out)
 {
-    const int kbps = p.bit_rate / 1000;
+    const int kbps = bit_rate / 1000;
     int sri, bri, whole;
-    if (p.sampling_rate != 32000 && p.sampling_rate != 44100 && p.sampling_rate != 48000) return 1;
-    if (kbps <= 0 || stream_params(p.sampling_rate, kbps, &sri, &bri, &whole)) return 1;
-    if (p.nch != 2 || p.n_frames <= 0 || p.dup_last_frame) return 1;
+    if (sampling_rate != 32000 && sampling_rate != 44100 && sampling_rate != 48000) return 1;
+    if (kbps <= 0 || stream_params(sampling_rate, kbps, &sri, &bri, &whole)) return 1;
+    if (nch != 2 || n_frames <= 0 || dup_last) return 1;
     *kbps_out = kbps;
     return 0;
 }
 
-// scan the job's files into the slot's staging and lay out the encoder's inputs; false = this job takes the synchronous path
+// the result block of a decode job: per file a WAV image, its PCM 64 bytes into an aligned region, the 44-byte header right
+// in front of it (what mp3s_decode_file hands out)
+bool decode_result(Job &j)
+{
+    size_t off = 0;
+    for (auto &d : j.dec) {
+        d.wav_off = off + 64 - 44;
+        off += 64 + (((size_t)d.n_frames * 1152 * d.nch * 2 + 63) & ~(size_t)63);
+    }
+    j.res.reset(new mp3s_buf());
+    if (!j.res->big[0].reserve(off) || !j.res->big[2].reserve(small_bytes(1))) return false;
+    if (j.walked && !j.res->big[1].reserve((size_t)j.n_total * 8 + 16)) return false;   // the table-index words the stego bits are made of
+    j.res->mp3 = j.res->big[0].data();
+    for (const auto &d : j.dec) wav_header((int64_t)d.n_frames * 1152, d.nch, d.rate, j.res->mp3 + d.wav_off);
+    return true;
+}
+
+bool encode_inputs(Job &j, Slot &s, uint8_t *encblk, size_t room, bool select)
+{
+    if (enc_layout(j.segs, j.rate, j.kbps, j.L, select)) return false;
+    if (j.L.bytes > room) return false;
+    if (enc_fill(j.segs, j.L, encblk)) return false;
+    if (j.L.mp3_bytes + 16 > s.mp3_cap) return false;
+    return true;
+}
+
+// ---- the walk: frame table + what the encoder needs of every stream, packed [encoder inputs | host-decoded frames | refs |
+//      streams] behind o_in; false = not for this path (the byte-level scan, or the synchronous path, takes the job)
+bool prepare_walk(mp3s_pipe *P, Job &j, Slot &s)
+{
+    const int nf = (int)j.files.size();
+    if (nf > kMaxFastFiles) return false;
+    j.walked = true;
+    j.segs.assign((size_t)nf, EncSeg());
+    j.bits.assign((size_t)nf, {});
+    j.guess.assign((size_t)nf, {});
+    j.dec.clear(); j.res_bits.clear(); j.ups.clear(); j.stream_first.assign((size_t)nf, 0);
+    j.n_fix = 0; j.image_base = 0; j.md_base = 0;
+    // refs and streams are written at the END of the packed area first (their place depends on the encoder block's size) and
+    // moved down once that is known; room for them is what the packed area has behind in_cap
+    FrameRef *refs = reinterpret_cast<FrameRef *>(s.h_stage + s.o_in + s.in_cap + s.fix_cap * kPlaceEntry);
+    StreamRef *streams = reinterpret_cast<StreamRef *>(reinterpret_cast<uint8_t *>(refs) + s.side_cap * sizeof(FrameRef));
+    uint8_t *fix = s.h_stage + s.o_in + s.in_cap;
+    long n = 0;
+    size_t img = 0;                  // bytes of d_image in use
+    size_t run_lo = 0, run_hi = 0;   // short files collected in h_image since the last flush
+    uint32_t md = 0;
+    int max_p23 = 0;
+    for (int i = 0; i < nf; i++) {
+        const uint8_t *file = j.files[i].first;
+        const size_t len = j.files[i].second;
+        if (!file) return false;
+        img = (img + 15) & ~(size_t)15;
+        if (img + len + 64 > s.image_cap || img + len > 0xfffffff0ull) return false;
+        FrameWalker w;
+        if (w.open(file, len)) return false;
+        w.md_cursor = md;
+        const bool hiding = !j.decode && !j.clear_all && j.msgs[i].first;
+        if (hiding) {
+            message_frame(j.msgs[i].first, j.msgs[i].second, j.bits[i]);
+            if (j.bits[i].size() > 0x7fffffff) return false;
+            w.tables_wanted = (long)j.bits[i].size() + (long)j.bits[i].size() / 16 + 64;
+            j.guess[i].resize((size_t)std::min<long>((long)(len / 96 + 16), w.tables_wanted + 8) * 4);
+        }
+        long got = 0;
+        while (!w.ended && !w.irregular) {
+            const long room = (long)s.side_cap - n - got;
+            if (room <= 0) return false;
+            uint8_t *tb = hiding && (size_t)(got + 1) * 4 <= j.guess[i].size() && w.tables_frames == got ? j.guess[i].data() + (size_t)got * 4 : nullptr;
+            const long cap = tb ? std::min<long>(room, (long)(j.guess[i].size() / 4) - got) : room;
+            got += w.next(refs + n + got, cap, tb, (uint32_t)img, (uint16_t)i);
+        }
+        if (w.irregular || got <= 0) return false;
+        if (j.decode) {
+            if (w.dup_last || w.nch < 1 || w.nch > 2) return false;
+            if (i == 0) j.nch = w.nch;
+            else if (w.nch != j.nch) return false;        // one device batch per channel count
+            j.dec.push_back({(int)got, w.nch, w.sampling_rate, w.bit_rate, 0, 0, 0, n});
+        } else {
+            int kbps = 0;
+            if (reencode_params(w.sampling_rate, w.bit_rate, w.nch, got, w.dup_last ? 1 : 0, &kbps)) return false;
+            if (i == 0) { j.rate = w.sampling_rate; j.kbps = kbps; }
+            else if (w.sampling_rate != j.rate || kbps != j.kbps) return false;   // more than one device batch
+        }
+        StreamRef &sr = streams[i];
+        std::memset(&sr, 0, sizeof sr);
+        sr.base = (uint32_t)img; sr.end = (uint32_t)(img + len); sr.first_frame = (uint32_t)n; sr.n_frames = (uint32_t)got;
+        FrameWalker::history(refs + n, 0, sr.prev_size);
+        j.stream_first[(size_t)i] = (uint32_t)n;
+        max_p23 = std::max(max_p23, w.max_p23);
+        // The last frame of a stream the reference's encoder wrote lacks the 0-3 bytes its writer drops (E14), and in one
+        // file out of eight the Huffman data reaches into them: the device kernel would flag it.  One frame per stream is
+        // cheap on the host, so it is decoded here, the kernel skips it, and its samples are placed behind the kernel --
+        // unless it inherits scalefactors from earlier frames (then the kernel's walk back through the stream has the answer).
+        if ((size_t)j.n_fix >= s.fix_cap) return false;
+        {
+            uint8_t *e = fix + (size_t)j.n_fix * kPlaceEntry;
+            bool alone = false;
+            std::memset(e, 0, 16);
+            *reinterpret_cast<int32_t *>(e) = (int32_t)(n + got - 1);
+            if (w.decode_last(reinterpret_cast<int16_t *>(e + 16), reinterpret_cast<mp3s_granule_si *>(e + 16 + 4608), &alone) == 0 && alone) {
+                refs[n + got - 1].flags |= MP3S_FS_HOST_DECODED;
+                j.n_fix++;
+            }
+        }
+        j.segs[i].n_frames = (int)got;
+        if (hiding) {
+            j.segs[i].hide = j.bits[i].data(); j.segs[i].n_hide = (int)j.bits[i].size();
+            j.segs[i].tables_guess = j.guess[i].data(); j.segs[i].n_guess = (int)std::min<long>(w.tables_frames, got) * 4;
+            j.segs[i].any_silent = w.any_silent ? 1 : 0;
+        }
+        // the file's bytes: long files go up from where they lie, short ones are laid end to end in page-locked staging first
+        if (len >= kDirectUpload) {
+            if (run_hi > run_lo) { j.ups.push_back({run_lo, s.h_image + run_lo, run_hi - run_lo}); run_lo = run_hi = 0; }
+            j.ups.push_back({img, file, len});
+        } else {
+            if (!s.h_image && hipHostMalloc((void **)&s.h_image, s.image_cap, hipHostMallocDefault) != hipSuccess) { s.h_image = nullptr; return false; }
+            if (run_hi == run_lo) run_lo = img;
+            std::memcpy(s.h_image + img, file, len);
+            run_hi = img + len;
+        }
+        img += len;
+        n += got;
+        md = w.md_cursor;
+        if ((size_t)md + 64 > s.blob_cap) return false;
+    }
+    if (run_hi > run_lo) j.ups.push_back({run_lo, s.h_image + run_lo, run_hi - run_lo});
+    j.n_total = (int)n;
+    j.L = EncLayout();
+    j.max_p23 = max_p23;
+    size_t enc_bytes = 0;
+    if (j.decode) {
+        if (!decode_result(j)) return false;
+    } else {
+        if (!encode_inputs(j, s, s.h_stage + s.o_in, s.in_cap, P->c->opt[MP3S_OPT_SELECT] != 0)) return false;
+        enc_bytes = j.L.bytes;
+        j.res.reset(new mp3s_buf());
+        if (!j.res->big[0].reserve(j.L.mp3_bytes) || !j.res->big[2].reserve(small_bytes(j.L.n_segs))) return false;
+        j.res->mp3 = j.res->big[0].data();
+    }
+    // pack: [encoder inputs | host-decoded frames | refs | streams], one copy up
+    j.o_encblk = s.o_in;
+    j.o_fix = (j.o_encblk + enc_bytes + 15) & ~(size_t)15;
+    if (j.o_fix != s.o_in + s.in_cap) std::memmove(s.h_stage + j.o_fix, fix, (size_t)j.n_fix * kPlaceEntry);
+    j.o_refs = (j.o_fix + (size_t)j.n_fix * kPlaceEntry + 15) & ~(size_t)15;
+    std::memmove(s.h_stage + j.o_refs, refs, (size_t)n * sizeof(FrameRef));
+    j.o_streams = (j.o_refs + (size_t)n * sizeof(FrameRef) + 15) & ~(size_t)15;
+    std::memmove(s.h_stage + j.o_streams, streams, (size_t)nf * sizeof(StreamRef));
+    j.pack_end = j.o_streams + (size_t)nf * sizeof(StreamRef);
+    j.ck.on = false;
+    return true;
+}
+
+// ---- a chunk of one file: the same packed inputs for frames [w0, w0 + n_win) of a stream that run_file has walked
+bool prepare_chunk(mp3s_pipe *P, Job &j, Slot &s, int max_p23)
+{
+    Chunk &k = j.ck;
+    j.walked = true; j.decode = k.decode; j.clear_all = k.n_hide == 0;
+    j.segs.assign(1, EncSeg());
+    j.dec.clear(); j.ups.clear(); j.stream_first.assign(1, 0);
+    j.n_fix = 0;
+    j.n_total = (int)k.n_win; j.nch = k.nch; j.rate = k.rate; j.kbps = k.kbps;
+    if ((size_t)k.n_win > s.side_cap || k.image_hi - k.image_lo + 64 > s.image_cap) return false;
+    j.image_base = k.image_lo; j.md_base = k.refs[k.w0].md_off;
+    const FrameRef &lastr = k.refs[k.w0 + k.n_win - 1];
+    if ((size_t)lastr.md_off - j.md_base + lastr.md_len + 64 > s.blob_cap) return false;
+    j.ups.push_back({0, k.file + k.image_lo, (size_t)(k.image_hi - k.image_lo)});
+    size_t enc_bytes = 0;
+    j.L = EncLayout();
+    if (!k.decode) {
+        EncSeg &sg = j.segs[0];
+        sg.n_frames = (int)k.count; sg.hide = k.hide; sg.n_hide = k.n_hide;
+        sg.lead = k.lead; sg.first_frame = k.first; sg.last = k.last; sg.carry_in = k.has_carry ? &k.carry_in : nullptr;
+        sg.tables_guess = k.tables; sg.n_guess = k.tables ? k.n_tables : -1; sg.any_silent = k.any_silent;
+        if (!encode_inputs(j, s, s.h_stage + s.o_in, s.in_cap, P->c->opt[MP3S_OPT_SELECT] != 0)) return false;
+        enc_bytes = j.L.bytes;
+    }
+    j.res.reset(new mp3s_buf());
+    if (!j.res->big[2].reserve(small_bytes(1))) return false;
+    if (k.decode && !j.res->big[1].reserve((size_t)k.n_win * 8 + 16)) return false;
+    j.o_encblk = s.o_in;
+    j.o_fix = (j.o_encblk + enc_bytes + 15) & ~(size_t)15;
+    if (k.fix) {
+        if (s.fix_cap < 1) return false;
+        std::memcpy(s.h_stage + j.o_fix, k.fix, kPlaceEntry);
+        *reinterpret_cast<int32_t *>(s.h_stage + j.o_fix) = (int32_t)(k.n_win - 1);
+        j.n_fix = 1;
+    }
+    j.o_refs = (j.o_fix + (size_t)j.n_fix * kPlaceEntry + 15) & ~(size_t)15;
+    FrameRef *refs = reinterpret_cast<FrameRef *>(s.h_stage + j.o_refs);
+    std::memcpy(refs, k.refs + k.w0, (size_t)k.n_win * sizeof(FrameRef));
+    for (long f = 0; f < k.n_win; f++) { refs[f].stream = 0; refs[f].flags = 0; }
+    if (k.fix) refs[k.n_win - 1].flags = MP3S_FS_HOST_DECODED;
+    j.o_streams = (j.o_refs + (size_t)k.n_win * sizeof(FrameRef) + 15) & ~(size_t)15;
+    StreamRef *sr = reinterpret_cast<StreamRef *>(s.h_stage + j.o_streams);
+    std::memset(sr, 0, sizeof *sr);
+    sr->base = 0; sr->end = (uint32_t)k.file_len; sr->first_frame = 0; sr->n_frames = (uint32_t)k.n_win;
+    FrameWalker::history(k.refs, k.w0, sr->prev_size);
+    j.pack_end = j.o_streams + sizeof(StreamRef);
+    if (j.pack_end > s.o_in + s.pack_cap) return false;
+    j.max_p23 = max_p23;
+    return true;
+}
+
+// scan the job's files into the slot's staging (round 2's byte-level scan) and lay out the encoder's inputs; false = this
+// job takes the synchronous path
 bool prepare_fast(mp3s_pipe *P, Job &j, Slot &s, ParsedStream &p, size_t *blob_len, int *max_p23)
 {
     const int nf = (int)j.files.size();
     if (nf > kMaxFastFiles) return false;
+    j.walked = false; j.ck.on = false;
     mp3s_frame_side *side = (mp3s_frame_side *)(s.h_stage + s.o_side);
     uint8_t *in = s.h_stage + s.o_in;
     size_t base = 0;
@@ -137,8 +385,9 @@ bool prepare_fast(mp3s_pipe *P, Job &j, Slot &s, ParsedStream &p, size_t *blob_l
     j.segs.assign((size_t)nf, EncSeg());
     j.bits.assign((size_t)nf, {});
     j.guess.assign((size_t)nf, {});
+    j.stream_first.assign((size_t)nf, 0);
     j.n_fix = 0;
-    j.dec.clear(); j.res_bits.clear();
+    j.dec.clear(); j.res_bits.clear(); j.ups.clear();
     mp3s_frame_hdr *dechdr = (mp3s_frame_hdr *)in;      // the input block starts with the decoder's frame headers
     for (int i = 0; i < nf; i++) {
         if (!j.files[i].first) return false;
@@ -152,26 +401,24 @@ bool prepare_fast(mp3s_pipe *P, Job &j, Slot &s, ParsedStream &p, size_t *blob_l
             if (p.n_frames <= 0 || p.dup_last_frame || p.nch < 1 || p.nch > 2) return false;
             if (i == 0) j.nch = p.nch;
             else if (p.nch != j.nch) return false;        // one device batch per channel count
-            j.dec.push_back({p.n_frames, p.nch, p.sampling_rate, p.bit_rate, 0, j.res_bits.size(), p.bits.size()});
+            j.dec.push_back({p.n_frames, p.nch, p.sampling_rate, p.bit_rate, 0, j.res_bits.size(), p.bits.size(), n});
             j.res_bits.insert(j.res_bits.end(), p.bits.begin(), p.bits.end());
         } else {
             int kbps = 0;
-            if (reencode_params(p, &kbps)) return false;
+            if (reencode_params(p.sampling_rate, p.bit_rate, p.nch, p.n_frames, p.dup_last_frame, &kbps)) return false;
             if (i == 0) { j.rate = p.sampling_rate; j.kbps = kbps; }
             else if (p.sampling_rate != j.rate || kbps != j.kbps) return false;   // more than one device batch
         }
+        j.stream_first[(size_t)i] = (uint32_t)n;
         for (int f = 0; f < p.n_frames; f++) {
             side[n + f].md_off += (uint32_t)base;
             side[n + f].reserved = (uint32_t)n;           // where the stream starts in the batch (scalefactor inheritance walks back to it)
             dechdr[n + f].stream_first = (uint32_t)n;
         }
         *max_p23 = std::max(*max_p23, max_part2_3(side + n, p.n_frames));
-        if (k.gpu_ok) {   // (a frame of a stream with inherited scalefactors cannot be decoded on its own)
-            // The last frame of a stream the reference's encoder wrote lacks the 0-3 bytes its writer drops (E14), and in one
-            // file out of eight the Huffman data reaches into them: the device kernel would flag it.  One frame per stream is
-            // cheap on the host, so it is decoded here, the kernel skips it, and its samples are placed behind the kernel.
+        if (k.gpu_ok) {   // (a frame of a stream with inherited scalefactors cannot be decoded on its own; E14: see prepare_walk)
             if ((size_t)j.n_fix >= s.fix_cap) return false;
-            uint8_t *e = s.h_stage + s.o_fix + (size_t)j.n_fix * kPlaceEntry;
+            uint8_t *e = s.h_stage + s.o_in + s.in_cap + (size_t)j.n_fix * kPlaceEntry;
             mp3s_frame_side &last = side[n + p.n_frames - 1];
             std::memset(e, 0, 16);
             *reinterpret_cast<int32_t *>(e) = (int32_t)(n + p.n_frames - 1);
@@ -193,32 +440,18 @@ bool prepare_fast(mp3s_pipe *P, Job &j, Slot &s, ParsedStream &p, size_t *blob_l
     }
     *blob_len = base;
     j.n_total = (int)n;
+    j.o_fix = s.o_in + s.in_cap;
     if (j.decode) {
-        // the result block: per file a WAV image, its PCM 64 bytes into an aligned region, the 44-byte header right in
-        // front of it (what mp3s_decode_file hands out)
-        size_t off = 0;
-        for (auto &d : j.dec) {
-            d.wav_off = off + 64 - 44;
-            off += 64 + (((size_t)d.n_frames * 1152 * d.nch * 2 + 63) & ~(size_t)63);
-        }
-        j.res.reset(new mp3s_buf());
-        if (!j.res->big[0].reserve(off) || !j.res->big[2].reserve(small_bytes(1))) return false;
-        j.res->mp3 = j.res->big[0].data();
-        for (const auto &d : j.dec) wav_header((int64_t)d.n_frames * 1152, d.nch, d.rate, j.res->mp3 + d.wav_off);
+        if (!decode_result(j)) return false;
         j.res->bits = std::move(j.res_bits);
         return true;
     }
-    const double tA = trace_on() ? now_ms() : 0;
-    if (enc_layout(j.segs, j.rate, j.kbps, j.L)) return false;
     const size_t o_enc = ((size_t)n * sizeof(mp3s_frame_hdr) + 15) & ~(size_t)15;
-    if (o_enc + j.L.bytes > s.in_cap) return false;
-    if (enc_fill(j.segs, j.L, in + o_enc)) return false;
-    if (j.L.mp3_bytes + 16 > s.mp3_cap) return false;
-    const double tB = trace_on() ? now_ms() : 0;
+    if (o_enc > s.in_cap || !encode_inputs(j, s, in + o_enc, s.in_cap - o_enc, P->c->opt[MP3S_OPT_SELECT] != 0)) return false;
+    j.o_encblk = s.o_in + o_enc;
     j.res.reset(new mp3s_buf());
     if (!j.res->big[0].reserve(j.L.mp3_bytes) || !j.res->big[2].reserve(small_bytes(j.L.n_segs))) return false;
     j.res->mp3 = j.res->big[0].data();
-    if (trace_on()) fprintf(stderr, "mp3s:   job %lld: input layout %.3f ms, result blocks %.3f ms\n", (long long)j.ticket, tB - tA, now_ms() - tB);
     return true;
 }
 
@@ -227,39 +460,60 @@ int issue_fast(mp3s_pipe *P, Job &j, Slot &s, size_t blob_len, int max_p23)
 {
     mp3s_ctx *c = P->c;
     const EncLayout &L = j.L;
-    const int n = j.n_total, units = n * 4, nch = j.decode ? j.nch : 2;
-    const size_t o_enc = ((size_t)n * sizeof(mp3s_frame_hdr) + 15) & ~(size_t)15, in_bytes = j.decode ? o_enc : o_enc + L.bytes;
+    const Chunk &ck = j.ck;
+    const int n = j.n_total, nch = j.decode ? j.nch : 2;
+    const int out_format = ck.on && j.decode ? ck.out_format : MP3S_PCM_I16;
+    const size_t esz = pcm_elem(out_format), frame_elems = (size_t)1152 * nch;
     const int set = (int)(P->issued++ & 1u);
     void *d_is = c->grab(set ? 24 : 0, (size_t)n * 2304 * 2), *d_si = c->grab(set ? 25 : 1, (size_t)n * 4 * sizeof(mp3s_granule_si)),
-         *d_keep = c->grab(set ? 26 : 7, (size_t)n * 2304 * 2);
+         *d_keep = c->grab(set ? 26 : 7, (size_t)n * frame_elems * esz);
     if (!d_is || !d_si || !d_keep) return fail(MP3S_E_NOMEM, "hipMalloc failed for a %d-frame job", n);
-    uint8_t *d_blob = s.d_stage, *d_side = s.d_stage + s.o_side, *d_in = s.d_stage + s.o_in;
+    uint8_t *d_blob = s.d_stage, *d_side = s.d_stage + s.o_side;
+    const mp3s_frame_hdr *d_dechdr;
     HIPCHK(hipEventRecord(s.e_start, P->s_up));
-    HIPCHK(hipMemcpyAsync(d_blob, s.h_stage, blob_len, hipMemcpyHostToDevice, P->s_up));
-    HIPCHK(hipMemcpyAsync(d_side, s.h_stage + s.o_side, (size_t)n * sizeof(mp3s_frame_side), hipMemcpyHostToDevice, P->s_up));
-    HIPCHK(hipMemcpyAsync(d_in, s.h_stage + s.o_in, in_bytes, hipMemcpyHostToDevice, P->s_up));
-    HIPCHK(hipMemcpyAsync(s.d_stage + s.o_fix, s.h_stage + s.o_fix, (size_t)j.n_fix * kPlaceEntry, hipMemcpyHostToDevice, P->s_up));
+    if (j.walked) {
+        for (const Upload &u : j.ups) HIPCHK(hipMemcpyAsync(s.d_image + u.dst, u.src, u.bytes, hipMemcpyHostToDevice, P->s_up));
+        HIPCHK(hipMemcpyAsync(s.d_stage + j.o_encblk, s.h_stage + j.o_encblk, j.pack_end - j.o_encblk, hipMemcpyHostToDevice, P->s_up));
+        d_dechdr = (const mp3s_frame_hdr *)(s.d_stage + s.o_dechdr);
+    } else {
+        const size_t o_enc = j.o_encblk - s.o_in, in_bytes = j.decode ? ((size_t)n * sizeof(mp3s_frame_hdr) + 15) & ~(size_t)15 : o_enc + L.bytes;
+        HIPCHK(hipMemcpyAsync(d_blob, s.h_stage, blob_len, hipMemcpyHostToDevice, P->s_up));
+        HIPCHK(hipMemcpyAsync(d_side, s.h_stage + s.o_side, (size_t)n * sizeof(mp3s_frame_side), hipMemcpyHostToDevice, P->s_up));
+        HIPCHK(hipMemcpyAsync(s.d_stage + s.o_in, s.h_stage + s.o_in, in_bytes, hipMemcpyHostToDevice, P->s_up));
+        HIPCHK(hipMemcpyAsync(s.d_stage + j.o_fix, s.h_stage + j.o_fix, (size_t)j.n_fix * kPlaceEntry, hipMemcpyHostToDevice, P->s_up));
+        d_dechdr = (const mp3s_frame_hdr *)(s.d_stage + s.o_in);
+    }
     HIPCHK(hipEventRecord(s.e_up, P->s_up));
     HIPCHK(hipStreamWaitEvent(P->s_huff, s.e_up, 0));
     if (P->dec_used[set]) HIPCHK(hipStreamWaitEvent(P->s_huff, P->e_dec[set], 0));
+    HIPCHK(hipMemsetAsync(s.d_small + 4, 0, 4, P->s_huff));
+    if (j.walked) {
+        uint64_t *d_tsel = j.decode ? (uint64_t *)(s.d_stage + s.o_tsel) : nullptr;
+        const int e = launch_parse(P->s_huff, s.d_image, j.image_base, (const FrameRef *)(s.d_stage + j.o_refs), (const StreamRef *)(s.d_stage + j.o_streams), n,
+                                   j.md_base, (mp3s_frame_side *)d_side, (mp3s_frame_hdr *)(s.d_stage + s.o_dechdr), d_blob, d_tsel, s.d_small + 4);
+        if (e) return fail(MP3S_E_HIP, "parse launch: %s", hipGetErrorString((hipError_t)e));
+    }
     const int e = launch_huffman(P->s_huff, d_blob, (const mp3s_frame_side *)d_side, n, nch, max_p23, (int16_t *)d_is, (mp3s_granule_si *)d_si,
                                  s.d_small + 3, c->d_sync + 4, &c->prof, false);
     if (e) return fail(MP3S_E_HIP, "huffman launch: %s", hipGetErrorString((hipError_t)e));
-    if (launch_place_frames(P->s_huff, s.d_stage + s.o_fix, j.n_fix, (int16_t *)d_is, (mp3s_granule_si *)d_si))
+    if (launch_place_frames(P->s_huff, s.d_stage + j.o_fix, j.n_fix, (int16_t *)d_is, (mp3s_granule_si *)d_si))
         return fail(MP3S_E_HIP, "placing the host-decoded frames failed");
     HIPCHK(hipEventRecord(s.e_huff, P->s_huff));
     HIPCHK(hipStreamWaitEvent(c->stream, s.e_huff, 0));
     // the PCM buffer of this set may still be read by the download of the decode job that used it last
     if (P->keep_slot[set] >= 0) HIPCHK(hipStreamWaitEvent(c->stream, P->slots[(size_t)P->keep_slot[set]].e_down, 0));
     P->keep_slot[set] = j.decode ? j.slot : -1;
-    const mp3s_frame_hdr *d_dechdr = (const mp3s_frame_hdr *)d_in;
-    const mp3s_frame_hdr *h_dechdr = (const mp3s_frame_hdr *)(s.h_stage + s.o_in);
-    const size_t frame_elems = (size_t)1152 * nch;
-    for (long start = 0; start < n; start += kDecodeChunk) {
-        const int halo = (start && h_dechdr[start].stream_first < (uint32_t)start) ? 1 : 0;
+    // a transform group that starts inside a stream re-runs one frame of it for the state (the chunk's own halo comes first)
+    auto inside_stream = [&](long f) {
+        size_t k = std::upper_bound(j.stream_first.begin(), j.stream_first.end(), (uint32_t)f) - j.stream_first.begin();
+        return k > 0 && j.stream_first[k - 1] < (uint32_t)f;
+    };
+    const int halo0 = ck.on ? ck.halo : 0;
+    for (long start = halo0; start < n; start += kDecodeChunk) {
+        const int halo = start == halo0 ? halo0 : (inside_stream(start) ? 1 : 0);
         const int cnt = (int)std::min<long>(kDecodeChunk, n - start) + halo;
         const int rc = decode_transform_chunk(c, (const int16_t *)d_is, (const mp3s_granule_si *)d_si, d_dechdr, start - halo, cnt, nch, halo,
-                                              MP3S_PCM_I16, (int16_t *)d_keep + (size_t)start * frame_elems);
+                                              out_format, (uint8_t *)d_keep + (size_t)(start - halo0) * frame_elems * esz);
         if (rc) return rc;
     }
     HIPCHK(hipEventRecord(P->e_dec[set], c->stream));
@@ -268,17 +522,23 @@ int issue_fast(mp3s_pipe *P, Job &j, Slot &s, size_t blob_len, int max_p23)
         HIPCHK(hipEventRecord(s.e_comp, c->stream));
         HIPCHK(hipStreamWaitEvent(P->s_down, s.e_comp, 0));
         HIPCHK(hipMemcpyAsync(j.res->big[2].data(), s.d_small, kSmallHead, hipMemcpyDeviceToHost, P->s_down));
-        size_t first = 0;
-        for (const auto &d : j.dec) {
-            const size_t bytes = (size_t)d.n_frames * frame_elems * 2;
-            HIPCHK(hipMemcpyAsync(j.res->mp3 + d.wav_off + 44, (const int16_t *)d_keep + first * frame_elems, bytes, hipMemcpyDeviceToHost, P->s_down));
-            first += (size_t)d.n_frames;
+        if (j.walked) HIPCHK(hipMemcpyAsync(j.res->big[1].data(), s.d_stage + s.o_tsel, (size_t)n * 8, hipMemcpyDeviceToHost, P->s_down));
+        if (ck.on) {
+            HIPCHK(hipMemcpyAsync(ck.dst, d_keep, (size_t)ck.count * frame_elems * esz, hipMemcpyDeviceToHost, P->s_down));
+        } else {
+            size_t first = 0;
+            for (const auto &d : j.dec) {
+                const size_t bytes = (size_t)d.n_frames * frame_elems * 2;
+                HIPCHK(hipMemcpyAsync(j.res->mp3 + d.wav_off + 44, (const int16_t *)d_keep + first * frame_elems, bytes, hipMemcpyDeviceToHost, P->s_down));
+                first += (size_t)d.n_frames;
+            }
         }
         HIPCHK(hipEventRecord(s.e_down, P->s_down));
         return MP3S_OK;
     }
-    const size_t b_mdct = (size_t)n * 2304 * 4, b_ix = (size_t)n * 2304 * 2, b_out = (size_t)units * sizeof(mp3s_gr_out),
-                 b_en = ((size_t)units * 22 * 4 + 255) & ~(size_t)255, b_sc = (size_t)n * 8 * 4;
+    const int units = L.units;
+    const size_t b_mdct = (size_t)L.n_all * 2304 * 4, b_ix = (size_t)L.n * 2304 * 2, b_out = (size_t)units * sizeof(mp3s_gr_out),
+                 b_en = ((size_t)units * 22 * 4 + 255) & ~(size_t)255, b_sc = (size_t)L.n * 8 * 4;
     const size_t need = b_mdct + b_ix + b_out + b_en + b_sc;
     if (need > s.enc_cap) {   // (hipFree waits for the device; only while the slot is growing to its job size)
         if (s.d_enc) (void)hipFree(s.d_enc);
@@ -286,24 +546,31 @@ int issue_fast(mp3s_pipe *P, Job &j, Slot &s, size_t blob_len, int max_p23)
         if (hipMalloc((void **)&s.d_enc, need + need / 8) != hipSuccess) return fail(MP3S_E_NOMEM, "hipMalloc failed for a %d-frame job", n);
         s.enc_cap = need + need / 8;
     }
-    void *d_agg = c->grab(15, chain_agg_bytes(n));
+    void *d_agg = c->grab(15, chain_agg_bytes(L.n));
     if (!d_agg) return fail(MP3S_E_NOMEM, "hipMalloc failed for a %d-frame job", n);
     EncDev &dev = j.dev;
-    dev.d_pcm = (const int16_t *)d_keep; dev.d_in = d_in + o_enc; dev.d_mdct_all = (int32_t *)s.d_enc; dev.d_ix = (int16_t *)(s.d_enc + b_mdct);
+    dev.d_pcm = (const int16_t *)d_keep; dev.d_in = s.d_stage + j.o_encblk; dev.d_mdct_all = (int32_t *)s.d_enc; dev.d_ix = (int16_t *)(s.d_enc + b_mdct);
     dev.d_out = (mp3s_gr_out *)(s.d_enc + b_mdct + b_ix); dev.d_en = (int32_t *)(s.d_enc + b_mdct + b_ix + b_out); dev.d_agg = d_agg;
     dev.d_mp3 = s.d_mp3; dev.d_sc = (int32_t *)(s.d_enc + b_mdct + b_ix + b_out + b_en);
     dev.d_small = s.d_small;
     if (!enc_variant_buffers(c, L, dev)) return fail(MP3S_E_NOMEM, "hipMalloc failed for %d variant entries", L.n_entries);
-    const int rc = enc_issue(c, L, dev, P->s_tail, s.e_rate, P->s_tail && P->last_tail >= 0 && getenv("MP3S_PIPE_TAIL_THROTTLE") ? P->slots[(size_t)P->last_tail].e_comp : nullptr);
+    const int rc = enc_issue(c, L, dev, P->s_tail, s.e_rate, P->s_tail && P->last_tail >= 0 && P->tail_throttle ? P->slots[(size_t)P->last_tail].e_comp : nullptr);
     if (rc) return rc;
     HIPCHK(hipEventRecord(s.e_comp, P->s_tail ? P->s_tail : c->stream));
     P->last_tail = (int)(&s - P->slots.data());
     HIPCHK(hipStreamWaitEvent(P->s_down, s.e_comp, 0));
     const size_t total = j.segs.back().mp3_off + j.segs.back().mp3_len;
     HIPCHK(hipMemcpyAsync(j.res->big[2].data(), s.d_small, small_bytes(L.n_segs), hipMemcpyDeviceToHost, P->s_down));
-    if (total) HIPCHK(hipMemcpyAsync(j.res->mp3, s.d_mp3, total, hipMemcpyDeviceToHost, P->s_down));
+    if (total) HIPCHK(hipMemcpyAsync(ck.on ? ck.dst : j.res->mp3, s.d_mp3, total, hipMemcpyDeviceToHost, P->s_down));
     HIPCHK(hipEventRecord(s.e_down, P->s_down));
     return MP3S_OK;
+}
+
+void sync_all(mp3s_pipe *P)
+{
+    (void)hipStreamSynchronize(P->s_up); (void)hipStreamSynchronize(P->s_huff); (void)hipStreamSynchronize(P->c->stream);
+    if (P->s_tail) (void)hipStreamSynchronize(P->s_tail);
+    (void)hipStreamSynchronize(P->s_down);
 }
 
 void run_slow(mp3s_pipe *P, Job &j)   // mu_issue held
@@ -321,6 +588,9 @@ void run_slow(mp3s_pipe *P, Job &j)   // mu_issue held
     j.slow_out.assign((size_t)nf, mp3s_file());
     j.slow_st.assign((size_t)nf, 0);
     j.res.reset();
+    // (the context's own pipe is not entered from here: this pipe owns the context)
+    const int64_t keep = P->c->opt[MP3S_OPT_FILE_PIPELINE];
+    P->c->opt[MP3S_OPT_FILE_PIPELINE] = 0;
     if (j.decode) {
         // file by file through mp3s_decode_file; the owners travel in one
         std::unique_ptr<mp3s_buf> top(new mp3s_buf());
@@ -332,16 +602,27 @@ void run_slow(mp3s_pipe *P, Job &j)   // mu_issue held
         }
         j.slow_rc = MP3S_OK;
         j.slow_owner = top.release();
-        return;
+    } else {
+        j.slow_rc = mp3s_hide_messages(P->c, fp.data(), fl.data(), nf, j.clear_all ? nullptr : mp.data(), ml.data(), &j.slow_owner, j.slow_out.data(),
+                                       j.slow_st.data());
+        j.slow_err = mp3s_last_error();
     }
-    j.slow_rc = mp3s_hide_messages(P->c, fp.data(), fl.data(), nf, j.clear_all ? nullptr : mp.data(), ml.data(), &j.slow_owner, j.slow_out.data(),
-                                   j.slow_st.data());
-    j.slow_err = mp3s_last_error();
+    P->c->opt[MP3S_OPT_FILE_PIPELINE] = keep;
+}
+
+void bind_to(const std::vector<int> &cpus)
+{
+    if (cpus.empty()) return;
+    cpu_set_t set;
+    CPU_ZERO(&set);
+    for (int cpu : cpus) if (cpu >= 0 && cpu < CPU_SETSIZE) CPU_SET(cpu, &set);
+    (void)sched_setaffinity(0, sizeof set, &set);
 }
 
 void worker(mp3s_pipe *P, int me)
 {
     (void)hipSetDevice(P->c->device);
+    bind_to(P->node_cpus);   // the slot's page-locked staging lives on the GPU's NUMA node: so does the thread that fills it
     ParsedStream scratch;   // per worker, capacity kept from job to job
     for (;;) {
         Job *j = nullptr;
@@ -356,16 +637,16 @@ void worker(mp3s_pipe *P, int me)
         const double t0 = now_ms(), c0 = thread_cpu_ms();
         size_t blob_len = 0;
         int max_p23 = 0;
-        bool fast = prepare_fast(P, *j, s, scratch, &blob_len, &max_p23);
+        bool fast = P->c->opt[MP3S_OPT_DEVICE_PARSE] && prepare_walk(P, *j, s);
+        if (fast) max_p23 = j->max_p23;
+        else fast = prepare_fast(P, *j, s, scratch, &blob_len, &max_p23);
         const double t1 = now_ms(), c1 = thread_cpu_ms();
-        if (trace_on()) fprintf(stderr, "mp3s: pipe job %lld slot %d on cpu %d: scan + layout %.3f ms (cpu %.3f)%s\n", (long long)j->ticket, j->slot, sched_getcpu(), t1 - t0, c1 - c0, fast ? "" : " -> synchronous path");
+        if (trace_on()) fprintf(stderr, "mp3s: pipe job %lld slot %d on cpu %d: %s + layout %.3f ms (cpu %.3f)%s\n", (long long)j->ticket, j->slot, sched_getcpu(), j->walked ? "walk" : "scan", t1 - t0, c1 - c0, fast ? "" : " -> synchronous path");
         Job::State st;
         {
             std::lock_guard<std::mutex> gi(P->mu_issue);
             if (fast && issue_fast(P, *j, s, blob_len, max_p23) != MP3S_OK) {
-                (void)hipStreamSynchronize(P->s_up); (void)hipStreamSynchronize(P->s_huff); (void)hipStreamSynchronize(P->c->stream);
-                if (P->s_tail) (void)hipStreamSynchronize(P->s_tail);
-                (void)hipStreamSynchronize(P->s_down);
+                sync_all(P);
                 fast = false;
             }
             if (!fast) run_slow(P, *j);
@@ -385,7 +666,9 @@ void worker(mp3s_pipe *P, int me)
 void free_slot(Slot &s)
 {
     if (s.h_stage) (void)hipHostFree(s.h_stage);
+    if (s.h_image) (void)hipHostFree(s.h_image);
     if (s.d_stage) (void)hipFree(s.d_stage);
+    if (s.d_image) (void)hipFree(s.d_image);
     if (s.d_mp3) (void)hipFree(s.d_mp3);
     if (s.d_small) (void)hipFree(s.d_small);
     if (s.d_enc) (void)hipFree(s.d_enc);
@@ -393,18 +676,12 @@ void free_slot(Slot &s)
     s = Slot();
 }
 
-}  // namespace
-
-extern "C" {
-
-int mp3s_pipe_create(mp3s_ctx *c, int depth, size_t max_job_bytes, int scan_threads, mp3s_pipe **out)
+int pipe_create(mp3s_ctx *c, int depth, size_t max_job_bytes, int scan_threads, bool internal, mp3s_pipe **out)
 {
-    if (!c || !out || depth < 1 || depth > 64 || scan_threads < 1 || scan_threads > 64 || max_job_bytes < 4096)
-        return fail(MP3S_E_ARG, "bad argument (1 <= depth, scan_threads <= 64; max_job_bytes >= 4096)");
     *out = nullptr;
     HIPCHK(hipSetDevice(c->device));
     std::unique_ptr<mp3s_pipe> P(new mp3s_pipe());
-    P->c = c; P->depth = depth;
+    P->c = c; P->depth = depth; P->internal = internal; P->max_job_bytes = max_job_bytes;
     auto destroy = [&](int code, const char *what) {
         for (auto &s : P->slots) free_slot(s);
         if (P->s_up) (void)hipStreamDestroy(P->s_up);
@@ -431,17 +708,24 @@ int mp3s_pipe_create(mp3s_ctx *c, int depth, size_t max_job_bytes, int scan_thre
         hipEventCreateWithFlags(&P->e_dec[0], hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&P->e_dec[1], hipEventDisableTiming) != hipSuccess)
         return destroy(MP3S_E_HIP, "stream creation failed");
-    // The tail stream is OFF unless MP3S_PIPE_TAIL=1.  On a resident batch fed through three contexts the arrangement is
-    // worth 5 % (bench.py, region (i): 0.829 -> 0.787 ms per step); in this pipe it measured slower at every priority, with
-    // and without making the next rate loop wait for the tail in front of it (0.89 - 1.25 against 0.83 ms per batch: with
-    // the copy streams and the front end there are then five streams at work, and every kernel of the two overlapping jobs
-    // stretches by half; tools/two_pipes_probe.py with MP3S_PIPE_TAIL / MP3S_PIPE_TAIL_PRIO / MP3S_PIPE_TAIL_THROTTLE).
+    // The tail stream is OFF unless MP3S_OPT_PIPE_TAIL is set.  On a resident batch fed through three contexts the
+    // arrangement is worth 5 % (bench.py, region (i): 0.829 -> 0.787 ms per step); in this pipe it measured slower at every
+    // priority, with and without making the next rate loop wait for the tail in front of it (0.89 - 1.25 against 0.83 ms
+    // per batch: with the copy streams and the front end there are then five streams at work, and every kernel of the two
+    // overlapping jobs stretches by half; tools/two_pipes_probe.py with MP3S_PIPE_TAIL / MP3S_PIPE_TAIL_PRIO / MP3S_PIPE_TAIL_THROTTLE).
     const char *tp = getenv("MP3S_PIPE_TAIL_PRIO");
     const int tail_prio = tp ? atoi(tp) : 0;
-    if (getenv("MP3S_PIPE_TAIL") && atoi(getenv("MP3S_PIPE_TAIL")) == 1 &&
-        hipStreamCreateWithPriority(&P->s_tail, hipStreamNonBlocking, tail_prio) != hipSuccess)
+    P->tail_throttle = getenv("MP3S_PIPE_TAIL_THROTTLE") != nullptr;
+    if (c->opt[MP3S_OPT_PIPE_TAIL] && hipStreamCreateWithPriority(&P->s_tail, hipStreamNonBlocking, tail_prio) != hipSuccess)
         return destroy(MP3S_E_HIP, "stream creation failed");
+    // the page-locked staging of the slots is allocated by a thread that runs on the GPU's NUMA node (first touch), and the
+    // workers that fill it stay there
+    P->node_cpus = gpu_node_cpus(c->device);
+    cpu_set_t before;
+    const bool rebind = !P->node_cpus.empty() && sched_getaffinity(0, sizeof before, &before) == 0;
+    if (rebind) bind_to(P->node_cpus);
     P->slots.resize((size_t)depth);
+    bool ok = true;
     for (auto &s : P->slots) {
         // main data: the file minus headers plus alignment and 8 zero bytes per frame; frames: 96 bytes is the smallest
         // Layer III frame (32 kbit/s at 48 kHz); anything denser (false syncs) overflows the sink and takes the other path
@@ -451,23 +735,44 @@ int mp3s_pipe_create(mp3s_ctx *c, int depth, size_t max_job_bytes, int scan_thre
         s.o_side = s.blob_cap;
         s.o_in = (s.o_side + s.side_cap * sizeof(mp3s_frame_side) + 15) & ~(size_t)15;
         s.fix_cap = std::min<size_t>(kMaxFastFiles, s.side_cap);
-        s.o_fix = s.o_in + s.in_cap;
-        s.stage_bytes = s.o_fix + s.fix_cap * kPlaceEntry;
+        s.pack_cap = (s.in_cap + s.fix_cap * kPlaceEntry + s.side_cap * sizeof(FrameRef) + (size_t)kMaxFastFiles * sizeof(StreamRef) + 256 + 15) & ~(size_t)15;
+        s.stage_bytes = s.o_in + s.pack_cap;
+        s.o_dechdr = s.stage_bytes;
+        s.o_tsel = (s.o_dechdr + s.side_cap * sizeof(mp3s_frame_hdr) + 15) & ~(size_t)15;
+        s.image_cap = max_job_bytes + 2 * kImageLead + (size_t)kMaxFastFiles * 16 + 4096;
         s.mp3_cap = max_job_bytes + s.side_cap + 4096;
-        if (hipHostMalloc((void **)&s.h_stage, s.stage_bytes, hipHostMallocDefault) != hipSuccess || hipMalloc((void **)&s.d_stage, s.stage_bytes) != hipSuccess ||
+        if (hipHostMalloc((void **)&s.h_stage, s.stage_bytes, hipHostMallocDefault) != hipSuccess ||
+            hipMalloc((void **)&s.d_stage, s.o_tsel + s.side_cap * 8 + 64) != hipSuccess || hipMalloc((void **)&s.d_image, s.image_cap) != hipSuccess ||
             hipMalloc((void **)&s.d_mp3, s.mp3_cap) != hipSuccess || hipMalloc((void **)&s.d_small, small_bytes(kMaxFastFiles)) != hipSuccess ||
             // (only e_start and e_down are read as times; the ordering events carry no time stamps: 1 % per job)
             hipEventCreate(&s.e_start) != hipSuccess || hipEventCreateWithFlags(&s.e_up, hipEventDisableTiming) != hipSuccess ||
             hipEventCreateWithFlags(&s.e_huff, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&s.e_comp, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&s.e_rate, hipEventDisableTiming) != hipSuccess ||
             // the collecting thread sleeps on this one instead of spinning: with one process per GPU on a shared host the
-            // cores are needed by the scan workers (the wake-up latency disappears behind the jobs in flight)
-            hipEventCreateWithFlags(&s.e_down, getenv("MP3S_PIPE_SPIN") ? hipEventDefault : hipEventBlockingSync) != hipSuccess)
-            return destroy(MP3S_E_NOMEM, "slot allocation failed");
+            // cores are needed by the scan workers (the wake-up latency disappears behind the jobs in flight); the
+            // context's own pipe has no job behind the one it waits for and spins
+            hipEventCreateWithFlags(&s.e_down, internal || getenv("MP3S_PIPE_SPIN") ? hipEventDefault : hipEventBlockingSync) != hipSuccess) {
+            ok = false;
+            break;
+        }
     }
-    P->todo.resize((size_t)scan_threads);
+    if (rebind) (void)sched_setaffinity(0, sizeof before, &before);
+    if (!ok) return destroy(MP3S_E_NOMEM, "slot allocation failed");
+    P->todo.resize((size_t)std::max(scan_threads, 1));
     for (int t = 0; t < scan_threads; t++) P->workers.emplace_back(worker, P.get(), t);
     *out = P.release();
     return MP3S_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int mp3s_pipe_create(mp3s_ctx *c, int depth, size_t max_job_bytes, int scan_threads, mp3s_pipe **out)
+{
+    if (!c || !out || depth < 1 || depth > 64 || scan_threads < 0 || scan_threads > 64 || max_job_bytes < 4096)
+        return fail(MP3S_E_ARG, "bad argument (1 <= depth <= 64; 0 <= scan_threads <= 64, 0 = as many as this rank's share of the host's cores allows; max_job_bytes >= 4096)");
+    if (scan_threads == 0) scan_threads = default_scan_threads(c);
+    return pipe_create(c, depth, max_job_bytes, scan_threads, false, out);
 }
 
 void mp3s_pipe_destroy(mp3s_pipe *P)
@@ -481,9 +786,7 @@ void mp3s_pipe_destroy(mp3s_pipe *P)
     P->cv_work.notify_all();
     for (auto &t : P->workers) t.join();
     (void)hipSetDevice(P->c->device);
-    (void)hipStreamSynchronize(P->s_up); (void)hipStreamSynchronize(P->s_huff); (void)hipStreamSynchronize(P->c->stream);
-    if (P->s_tail) (void)hipStreamSynchronize(P->s_tail);
-    (void)hipStreamSynchronize(P->s_down);
+    sync_all(P);
     for (auto &j : P->inflight) if (j->slow_owner) mp3s_buf_free(j->slow_owner);
     for (auto &s : P->slots) free_slot(s);
     (void)hipStreamDestroy(P->s_up); (void)hipStreamDestroy(P->s_down); (void)hipStreamDestroy(P->s_huff);
@@ -492,10 +795,28 @@ void mp3s_pipe_destroy(mp3s_pipe *P)
     delete P;
 }
 
+static int submit_job(mp3s_pipe *P, std::unique_ptr<Job> j, int64_t *ticket)
+{
+    {
+        std::lock_guard<std::mutex> g(P->mu);
+        int slot = -1;
+        for (int k = 0; k < P->depth; k++) if (!P->slots[(size_t)k].busy) { slot = k; break; }
+        if (slot < 0) return fail(MP3S_E_BUSY, "all %d slots are taken: collect a result first", P->depth);
+        P->slots[(size_t)slot].busy = true;
+        j->slot = slot; j->ticket = P->next_ticket++;
+        if (ticket) *ticket = j->ticket;
+        P->todo[(size_t)slot % P->todo.size()].push_back(j.get());
+        P->inflight.push_back(std::move(j));
+        P->st.submitted++;
+    }
+    P->cv_work.notify_all();
+    return MP3S_OK;
+}
+
 int mp3s_pipe_submit(mp3s_pipe *P, const uint8_t *const *mp3s, const size_t *lens, int n_files, const uint8_t *const *msgs,
                      const size_t *msg_lens, int64_t *ticket)
 {
-    if (!P || !mp3s || !lens || n_files <= 0 || (msgs && !msg_lens)) return fail(MP3S_E_ARG, "bad argument");
+    if (!P || P->internal || !mp3s || !lens || n_files <= 0 || (msgs && !msg_lens)) return fail(MP3S_E_ARG, "bad argument");
     std::unique_ptr<Job> j(new Job());
     j->files.resize((size_t)n_files); j->msgs.assign((size_t)n_files, {nullptr, 0});
     j->clear_all = msgs == nullptr;
@@ -506,53 +827,51 @@ int mp3s_pipe_submit(mp3s_pipe *P, const uint8_t *const *mp3s, const size_t *len
             j->msgs[i] = {msgs[i], msg_lens[i]};
         }
     }
-    {
-        std::lock_guard<std::mutex> g(P->mu);
-        int slot = -1;
-        for (int k = 0; k < P->depth; k++) if (!P->slots[(size_t)k].busy) { slot = k; break; }
-        if (slot < 0) return fail(MP3S_E_BUSY, "all %d slots are taken: collect a result first", P->depth);
-        P->slots[(size_t)slot].busy = true;
-        j->slot = slot; j->ticket = P->next_ticket++;
-        if (ticket) *ticket = j->ticket;
-        P->todo[(size_t)slot % P->todo.size()].push_back(j.get());
-        P->inflight.push_back(std::move(j));
-        P->st.submitted++;
-    }
-    P->cv_work.notify_all();
-    return MP3S_OK;
+    return submit_job(P, std::move(j), ticket);
 }
 
 int mp3s_pipe_submit_decode(mp3s_pipe *P, const uint8_t *const *mp3s, const size_t *lens, int n_files, int64_t *ticket)
 {
-    if (!P || !mp3s || !lens || n_files <= 0) return fail(MP3S_E_ARG, "bad argument");
+    if (!P || P->internal || !mp3s || !lens || n_files <= 0) return fail(MP3S_E_ARG, "bad argument");
     std::unique_ptr<Job> j(new Job());
     j->decode = true; j->clear_all = true;
     j->files.resize((size_t)n_files); j->msgs.assign((size_t)n_files, {nullptr, 0});
     for (int i = 0; i < n_files; i++) j->files[i] = {mp3s[i], lens[i]};
-    {
-        std::lock_guard<std::mutex> g(P->mu);
-        int slot = -1;
-        for (int k = 0; k < P->depth; k++) if (!P->slots[(size_t)k].busy) { slot = k; break; }
-        if (slot < 0) return fail(MP3S_E_BUSY, "all %d slots are taken: collect a result first", P->depth);
-        P->slots[(size_t)slot].busy = true;
-        j->slot = slot; j->ticket = P->next_ticket++;
-        if (ticket) *ticket = j->ticket;
-        P->todo[(size_t)slot % P->todo.size()].push_back(j.get());
-        P->inflight.push_back(std::move(j));
-        P->st.submitted++;
+    return submit_job(P, std::move(j), ticket);
+}
+
+// the job's results are on the host: are they final?  *resolved: the host had to resolve the chains (on the job's own buffers)
+static bool finish_fast(mp3s_pipe *P, Job *j, Slot &s, bool *resolved)
+{
+    const int32_t *small = (const int32_t *)j->res->big[2].data();
+    const bool parse_ok = !j->walked || (small[4] & kParseMismatch) == 0;
+    bool fast_ok = parse_ok && (j->decode ? small[3] == 0 : (small[0] == 0 && small[1] == 0 && small[2] == 0 && small[3] == 0));
+    *resolved = false;
+    if (!fast_ok) {
+        if (trace_on()) fprintf(stderr, "mp3s: pipe job %lld: verdict %d units to redo, step range %d, packer %d, Huffman status 0x%x, parse status 0x%x\n",
+                                (long long)j->ticket, small[0], small[1], small[2], small[3], small[4]);
+        // only the cursor / address guesses failed (a long message, a start the input's tables did not predict):
+        // the host resolves the chains on the job's own device buffers -- scan, decode and transforms stand
+        if (P->s_tail) (void)hipStreamSynchronize(P->s_tail);   // (later jobs' tails: the resolve below packs through the same context)
+        if (parse_ok && !j->decode && small[0] != 0 && small[1] == 0 && small[3] == 0) {
+            int passes = 0;
+            *resolved = enc_resolve(P->c, j->L, j->segs, s.h_stage + j->o_encblk, j->dev, j->res.get(), false, &passes) == MP3S_OK;
+            if (hipStreamSynchronize(P->c->stream) != hipSuccess) *resolved = false;
+        }
     }
-    P->cv_work.notify_all();
-    return MP3S_OK;
+    return fast_ok;
 }
 
 int mp3s_pipe_collect(mp3s_pipe *P, int64_t *ticket, mp3s_buf **owner, mp3s_file *out, int32_t *status, int max_files, int *n_files)
 {
-    if (!P || !owner || !out || !status) return fail(MP3S_E_ARG, "null pointer");
+    if (!P || P->internal || !owner || !out || !status) return fail(MP3S_E_ARG, "null pointer");
     Job *j = nullptr;
     {
         std::unique_lock<std::mutex> g(P->mu);
         if (P->inflight.empty()) return fail(MP3S_E_BUSY, "nothing in flight");
         j = P->inflight.front().get();
+        if (ticket) *ticket = j->ticket;   // (also when the call fails: the caller learns which job it is stuck on)
+        if (n_files) *n_files = (int)j->files.size();
         if ((int)j->files.size() > max_files) return fail(MP3S_E_ARG, "the next job has %zu files, room for %d", j->files.size(), max_files);
         P->cv_done.wait(g, [&] { return j->state != Job::QUEUED; });
     }
@@ -560,34 +879,35 @@ int mp3s_pipe_collect(mp3s_pipe *P, int64_t *ticket, mp3s_buf **owner, mp3s_file
     const int nf = (int)j->files.size();
     int rc = MP3S_OK;
     bool fast_ok = false, resolved = false;
+    double span_ms = -1;
     if (j->state == Job::ISSUED) {
         (void)hipSetDevice(P->c->device);
         if (hipEventSynchronize(s.e_down) != hipSuccess) rc = fail(MP3S_E_HIP, "waiting for the job's results failed");
         else {
-            const int32_t *small = (const int32_t *)j->res->big[2].data();
-            fast_ok = j->decode ? small[3] == 0 : (small[0] == 0 && small[1] == 0 && small[2] == 0 && small[3] == 0);
             float ms = 0;
-            if (hipEventElapsedTime(&ms, s.e_start, s.e_down) == hipSuccess) P->st.last_device_span_ms = ms;
-            if (!fast_ok) {
-                if (trace_on()) fprintf(stderr, "mp3s: pipe job %lld: verdict %d units to redo, step range %d, packer %d, Huffman status 0x%x\n",
-                                        (long long)j->ticket, small[0], small[1], small[2], small[3]);
-                std::lock_guard<std::mutex> gi(P->mu_issue);
-                // only the cursor / address guesses failed (a long message, a start the input's tables did not predict):
-                // the host resolves the chains on the job's own device buffers -- scan, decode and transforms stand
-                if (P->s_tail) (void)hipStreamSynchronize(P->s_tail);   // (later jobs' tails: the resolve below packs through the same context)
-                if (!j->decode && small[0] != 0 && small[1] == 0 && small[3] == 0) {
-                    int passes = 0;
-                    resolved = enc_resolve(P->c, j->L, j->segs, s.h_stage + s.o_in + (((size_t)j->n_total * sizeof(mp3s_frame_hdr) + 15) & ~(size_t)15),
-                                           j->dev, j->res.get(), false, &passes) == MP3S_OK;
-                    if (hipStreamSynchronize(P->c->stream) != hipSuccess) resolved = false;
-                }
-                // damaged Huffman data, a quantiser step out of range, a failed resolve: the synchronous path decides, file by file
-                if (!resolved) run_slow(P, *j);
-            }
+            if (hipEventElapsedTime(&ms, s.e_start, s.e_down) == hipSuccess) span_ms = ms;
+            std::unique_lock<std::mutex> gi(P->mu_issue, std::defer_lock);
+            const int32_t *small = (const int32_t *)j->res->big[2].data();
+            if (!(small[0] == 0 && small[1] == 0 && small[2] == 0 && small[3] == 0 && (small[4] & kParseMismatch) == 0)) gi.lock();
+            fast_ok = finish_fast(P, j, s, &resolved);
+            // damaged Huffman data, a quantiser step out of range, a failed resolve: the synchronous path decides, file by file
+            if (!fast_ok && !resolved) { if (!gi.owns_lock()) gi.lock(); run_slow(P, *j); }
         }
     }
     if (!rc) {
         if (fast_ok && j->decode) {
+            if (j->walked) {
+                // the stego bits: a serial pass over the table-index words the device left
+                const uint64_t *tsel = (const uint64_t *)j->res->big[1].data();
+                std::vector<uint8_t> &bits = j->res->bits;
+                bits.clear();
+                for (auto &d : j->dec) {
+                    uint8_t carry[4] = {0, 0, 0, 0};
+                    d.bits_off = bits.size();
+                    stego_bits_from_tsel(tsel + d.first, d.n_frames, d.nch, carry, bits);
+                    d.n_bits = bits.size() - d.bits_off;
+                }
+            }
             for (int i = 0; i < nf; i++) {
                 const Job::DecFile &d = j->dec[(size_t)i];
                 std::memset(&out[i], 0, sizeof out[i]);
@@ -619,11 +939,10 @@ int mp3s_pipe_collect(mp3s_pipe *P, int64_t *ticket, mp3s_buf **owner, mp3s_file
             }
         }
     }
-    if (ticket) *ticket = j->ticket;
-    if (n_files) *n_files = nf;
     {
         std::lock_guard<std::mutex> g(P->mu);
         P->st.collected++;
+        if (span_ms >= 0) P->st.last_device_span_ms = span_ms;
         if (fast_ok) P->st.fast++; else if (resolved) P->st.resolved++; else P->st.slow++;
         s.busy = false;
         P->inflight.pop_front();
@@ -640,3 +959,264 @@ int mp3s_pipe_get_stats(mp3s_pipe *P, mp3s_pipe_stats *out)
 }
 
 }  // extern "C"
+
+// ------------------------------------------------------------------------------------------------ one file as chunks
+// The reference's call shape is one file per call (steganography.py:137-162: decode loop MP3_Parser.py:68-80, then encode
+// loop MP3_Encoder.py:607-609).  run_file gives that call the overlap the pipe gives a stream of jobs: the calling thread
+// walks the frame headers a chunk at a time and queues each chunk on the stages above -- walk(k+1) || upload || front end ||
+// kernels(k) || download(k-1) -- and the chunks' bytes land side by side in ONE result block.  What crosses a chunk
+// boundary is what crosses a block boundary of a sharded stream: a frame of decoder state and a frame of
+// PCM in front of the chunk are recomputed and dropped; the padding recurrence is replayed from the frame index; the message
+// cursor and the inherited addresses (17 integers) are GUESSED -- "the message is hidden, nothing is inherited" -- and every
+// chunk reports whether it looked at them: only a chunk that did, on a guess that was wrong, is run again on the real carry.
+namespace {
+
+bool same_effect(const mp3s_carry &a, const mp3s_carry &b, int64_t n_hide)
+{
+    return std::memcmp(a.chain, b.chain, sizeof a.chain) == 0 && std::min<int64_t>(a.cursor, n_hide) == std::min<int64_t>(b.cursor, n_hide);
+}
+
+struct RunChunk {
+    std::unique_ptr<Job> job;
+    long first = 0, count = 0;
+    bool last = false;
+    mp3s_carry guess = {}, out = {};
+    bool carry_used = false;
+    int64_t out_off = 0, out_len = 0;
+    bool done = false;
+};
+
+}  // namespace
+
+int ensure_own_pipe(mp3s_ctx *c, size_t chunk_bytes)
+{
+    if (c->own_pipe && c->own_pipe->max_job_bytes >= chunk_bytes) return MP3S_OK;
+    if (c->own_pipe) { mp3s_pipe_destroy(c->own_pipe); c->own_pipe = nullptr; }
+    const size_t want = std::max<size_t>(chunk_bytes + chunk_bytes / 4, (size_t)1 << 20);
+    return pipe_create(c, kRunDepth, want, 0, true, &c->own_pipe);
+}
+
+void destroy_own_pipe(mp3s_ctx *c)
+{
+    if (c->own_pipe) { mp3s_pipe_destroy(c->own_pipe); c->own_pipe = nullptr; }
+}
+
+int run_file(mp3s_ctx *c, const uint8_t *mp3, size_t len, int mode, const uint8_t *utf8, size_t n_msg, int out_format, mp3s_buf **owner, RunResult *out)
+{
+    if (!c->opt[MP3S_OPT_FILE_PIPELINE] || !c->opt[MP3S_OPT_DEVICE_PARSE]) return kRunFallback;
+    const bool decode = mode == kRunDecode;
+    FrameWalker w;
+    // (errors and empty streams: the synchronous path words them)
+    if (len < 8 || len > 0xffff0000ull || w.open(mp3, len) || w.ended || w.hd.version != 1 || w.hd.layer != 3 || w.frame_size <= 0) {
+        c->run_stats.fallbacks++;
+        return kRunFallback;
+    }
+    const long fs0 = w.frame_size;
+    const long n_est = (long)((len - (size_t)w.offset) / (size_t)std::max<long>(fs0 - 1, 24)) + 8;
+    std::vector<uint8_t> bits;
+    if (mode == kRunHide) {
+        message_frame(utf8, n_msg, bits);
+        if (bits.size() > 0x3fffff00) { c->run_stats.fallbacks++; return kRunFallback; }
+    }
+    const int64_t n_hide = (int64_t)bits.size();
+    // ---- the chunk plan.  Every chunk costs a dozen launches and their gaps, so few chunks; the first one small, so that
+    //      the device starts early; a message's reach inside the first chunk, where the cursor is decided (not guessed)
+    const long reach_frames = n_hide ? (long)((n_hide * 5 / 14 + 32) / 4 * 9 / 8 + 64) : 0;
+    long chunk = (long)c->opt[MP3S_OPT_CHUNK_FRAMES];
+    long first_chunk;
+    const long kMaxChunk = kDecodeChunk - 2;
+    if (chunk > 0) { chunk = std::min(chunk, kMaxChunk); first_chunk = chunk; }
+    else if (n_est <= 3000) { chunk = first_chunk = std::min(kMaxChunk, n_est + 16); }                    // one chunk: nothing to overlap with
+    else {
+        chunk = std::min<long>(kMaxChunk, std::max<long>(2560, (n_est + 3) / 4));
+        first_chunk = std::min<long>(chunk, std::max<long>(1536, n_est / 8));
+    }
+    first_chunk = std::min(kMaxChunk, std::max(first_chunk, reach_frames));
+    const long cap_frames = std::max(chunk, first_chunk) + 2;
+    // (a message that reaches further than a chunk: the synchronous path's plan over the whole file)
+    if (reach_frames > kMaxChunk || ensure_own_pipe(c, (size_t)cap_frames * (size_t)(fs0 + 2) + 4096)) { c->run_stats.fallbacks++; return kRunFallback; }
+    mp3s_pipe *P = c->own_pipe;
+    HIPCHK(hipSetDevice(c->device));
+    // ---- the stream's frame table, grown as the walk proceeds
+    std::vector<FrameRef> &refs = c->h_refs;
+    if ((long)refs.size() < n_est + 64) refs.resize((size_t)n_est + 64);
+    std::vector<uint8_t> &tables = c->h_tables;
+    if (n_hide) { w.tables_wanted = (long)n_hide + (long)n_hide / 16 + 64; tables.resize((size_t)first_chunk * 4 + 16); }
+    long n_walked = 0;
+    std::unique_ptr<mp3s_buf> res(new mp3s_buf());
+    std::vector<RunChunk> chunks;
+    uint8_t fix[kPlaceEntry];
+    bool have_fix = false;
+    int rate = 0, kbps = 0, nch = 0;
+    const size_t esz = pcm_elem(out_format);
+    size_t res_cap = 0;
+    auto fallback = [&](const char *why) {
+        if (trace_on()) fprintf(stderr, "mp3s: run_file: %s -> synchronous path\n", why);
+        c->run_stats.fallbacks++;
+        sync_all(P);
+        for (auto &s : P->slots) s.busy = false;
+        P->keep_slot[0] = P->keep_slot[1] = -1;
+        return kRunFallback;
+    };
+    // retire chunk k: wait for its results, settle its verdict and its carry
+    int64_t hide_offset = 0;
+    auto retire = [&](size_t k) -> int {
+        RunChunk &rc = chunks[k];
+        if (rc.done) return MP3S_OK;
+        Job *j = rc.job.get();
+        Slot &s = P->slots[(size_t)j->slot];
+        if (hipEventSynchronize(s.e_down) != hipSuccess) return fail(MP3S_E_HIP, "waiting for a chunk's results failed");
+        bool resolved = false;
+        const bool ok = finish_fast(P, j, s, &resolved);
+        if (!ok && !resolved) return kRunFallback;
+        if (resolved) c->run_stats.resolved++;
+        const int32_t *small = (const int32_t *)j->res->big[2].data();
+        if (j->walked && (small[4] & kParseInherits) && chunks.size() + (w.ended ? 0 : 1) > 1) return kRunFallback;   // scalefactors inherited across frames: the stream in one piece
+        if (!decode) {
+            EncSeg &sg = j->segs[0];
+            if (resolved) {
+                std::memcpy(j->ck.dst, j->res->mp3 + sg.mp3_off, sg.mp3_len);
+                rc.out = sg.carry_out; rc.carry_used = sg.carry_used;
+            } else {
+                const mp3s_chain_seg_out *so = (const mp3s_chain_seg_out *)(j->res->big[2].data() + kSmallHead);
+                rc.out.cursor = so[0].cursor - sg.hide_base;
+                std::memcpy(rc.out.chain, so[0].chain, sizeof rc.out.chain);
+                rc.carry_used = so[0].carry_used != 0;
+            }
+            rc.out_len = (int64_t)sg.mp3_len;
+        }
+        rc.done = true;
+        return MP3S_OK;
+    };
+    // issue frames [first, first + count) of the stream as a chunk on slot `slot`
+    auto issue = [&](size_t k, const mp3s_carry *carry) -> int {
+        RunChunk &rc = chunks[k];
+        rc.job.reset(new Job());
+        Job &j = *rc.job;
+        j.slot = (int)(k % (size_t)P->depth);
+        j.ticket = (int64_t)k;
+        Slot &s = P->slots[(size_t)j.slot];
+        Chunk &ck = j.ck;
+        ck.on = true; ck.decode = decode; ck.refs = refs.data(); ck.first = rc.first; ck.count = rc.count; ck.last = rc.last;
+        ck.lead = !decode && rc.first > 0 ? 1 : 0;
+        ck.halo = rc.first - ck.lead > 0 ? 1 : 0;
+        ck.w0 = rc.first - ck.lead - ck.halo; ck.n_win = rc.count + ck.lead + ck.halo;
+        ck.out_format = out_format; ck.file = mp3; ck.file_len = len; ck.rate = rate; ck.kbps = kbps; ck.nch = nch;
+        const uint32_t lo = refs[(size_t)ck.w0].file_off;
+        ck.image_lo = rc.first == 0 ? 0 : (lo > kImageLead ? lo - kImageLead : 0);
+        const FrameRef &lr = refs[(size_t)(rc.first + rc.count - 1)];
+        ck.image_hi = (uint32_t)std::min<uint64_t>(len, (uint64_t)lr.file_off + lr.frame_size + 64);
+        ck.fix = rc.last && have_fix ? fix : nullptr;
+        ck.hide = bits.data(); ck.n_hide = (int)n_hide;
+        ck.has_carry = rc.first > 0;
+        if (ck.has_carry) ck.carry_in = carry ? *carry : rc.guess;
+        ck.tables = rc.first == 0 && n_hide ? tables.data() : nullptr;
+        ck.n_tables = (int)std::min<long>(w.tables_frames, rc.count) * 4;
+        ck.any_silent = w.any_silent ? 1 : 0;   // (of the frames walked so far: at worst the re-run launches are issued without need)
+        if (decode) ck.dst = res->big[0].data() + 64 + (size_t)rc.first * 1152 * (size_t)nch * esz;
+        if (!prepare_chunk(P, j, s, w.max_p23)) return kRunFallback;
+        if (!decode) {
+            rc.out_off = j.L.bytes_before;
+            if ((size_t)rc.out_off + j.L.mp3_bytes > res_cap) return kRunFallback;
+            j.ck.dst = res->big[0].data() + rc.out_off;
+        }
+        const int e = issue_fast(P, j, s, 0, w.max_p23);
+        return e ? kRunFallback : MP3S_OK;
+    };
+    // ---- walk and issue, chunk after chunk
+    long want = first_chunk;
+    for (size_t k = 0; !w.ended; k++) {
+        const long room = (long)refs.size() - n_walked - 8;
+        if (room <= 0) return fallback("more frames than the file's first frame size promised");
+        want = std::min(want, room);
+        uint8_t *tb = k == 0 && n_hide ? tables.data() : nullptr;
+        long got = 0;
+        while (got < want && !w.ended && !w.irregular) got += w.next(refs.data() + n_walked + got, want - got, tb ? tb + (size_t)got * 4 : nullptr, 0, 0);
+        if (w.irregular || got <= 0) return fallback("the walk does not take this stream");
+        if (k == 0) {
+            nch = w.nch; rate = w.sampling_rate;
+            if (nch < 1 || nch > 2) return fallback("channel count");
+            if (!decode && reencode_params(w.sampling_rate, w.bit_rate, w.nch, got, 0, &kbps)) return fallback("not a stream the encoder takes");
+            // the result block: the frames the file can hold at its first frame's size
+            res_cap = decode ? 64 + (size_t)(n_est + 64) * 1152 * (size_t)nch * esz : (size_t)(n_est + 64) * (size_t)(fs0 + 2);
+            if (!res->big[0].reserve(res_cap)) return fallback("no memory for the result");
+        } else if (w.nch != nch) return fallback("channel count changes");
+        if (w.ended) {
+            if (w.dup_last) return fallback("a repeated last frame");
+            bool alone = false;
+            have_fix = w.decode_last(reinterpret_cast<int16_t *>(fix + 16), reinterpret_cast<mp3s_granule_si *>(fix + 16 + 4608), &alone) == 0 && alone;
+            std::memset(fix, 0, 16);
+        }
+        if (k >= (size_t)P->depth) {               // the slot's previous chunk first
+            const int r = retire(k - (size_t)P->depth);
+            if (r) return r == kRunFallback ? fallback("a chunk needs the synchronous path") : r;
+        }
+        chunks.emplace_back();
+        RunChunk &rc = chunks.back();
+        rc.first = n_walked; rc.count = got; rc.last = w.ended;
+        rc.guess.cursor = MP3S_NO_CURSOR;          // "the message is hidden, nothing is inherited"
+        n_walked += got;
+        if (decode && 64 + (size_t)n_walked * 1152 * (size_t)nch * esz > res_cap) return fallback("more frames than the result block holds");
+        const int r = issue(k, nullptr);
+        if (r) return r == kRunFallback ? fallback("a chunk does not fit the stages") : r;
+        want = chunk;
+    }
+    // ---- settle the chunks in order: the carries
+    if (!decode && (w.sampling_rate != rate || w.bit_rate / 1000 != kbps)) return fallback("the last header names another rate");
+    // (first everything that needs a chunk's device buffers -- its verdict, a resolve -- then the carries: a chunk that is run
+    // again takes a slot, and with it the buffers of the chunk that had it last)
+    for (size_t k = 0; k < chunks.size(); k++) {
+        const int r = retire(k);
+        if (r) return r == kRunFallback ? fallback("a chunk needs the synchronous path") : r;
+    }
+    mp3s_carry real = {};
+    for (size_t k = 0; k < chunks.size(); k++) {
+        int r = MP3S_OK;
+        RunChunk &rc = chunks[k];
+        if (decode) continue;
+        if (k > 0) {
+            const bool live = std::min<int64_t>(real.cursor, n_hide) < n_hide;     // the message is still being hidden at this boundary
+            if (!same_effect(real, rc.guess, n_hide) && (rc.carry_used || live)) {
+                // the chunk looked at its carry and the guess was wrong: once more, on the real one (everything behind it has been issued
+                // and stays as it is unless its own carry turns out wrong in turn)
+                if (trace_on()) fprintf(stderr, "mp3s: run_file: chunk %zu depends on its carry: again\n", k);
+                sync_all(P);
+                c->run_stats.reruns++;
+                rc.done = false;
+                r = issue(k, &real);
+                if (!r) r = retire(k);
+                if (r) return r == kRunFallback ? fallback("a chunk needs the synchronous path") : r;
+                sync_all(P);
+            } else {
+                // nothing in the chunk looked at the carry: every chain entry it hands on is its own; only the count of tables
+                // seen so far moves with the real cursor
+                rc.out.cursor = real.cursor + (rc.out.cursor - rc.guess.cursor);
+            }
+        }
+        real = rc.out;
+        hide_offset = real.cursor;
+    }
+    // ---- the result
+    std::memset(out, 0, sizeof *out);
+    out->n_frames = n_walked; out->nch = nch; out->sampling_rate = w.sampling_rate; out->bit_rate = w.bit_rate;
+    if (decode) {
+        // stego bits: the serial pass over the table-index words of all chunks (their halo frames left out)
+        uint8_t carry[4] = {0, 0, 0, 0};
+        for (auto &rc : chunks) {
+            const Job &j = *rc.job;
+            stego_bits_from_tsel((const uint64_t *)j.res->big[1].data() + j.ck.halo, rc.count, nch, carry, res->bits);
+        }
+        out->pcm = res->big[0].data() + 64; out->n_rows = (int64_t)n_walked * 1152;
+        out->bits = res->bits.data(); out->n_bits = res->bits.size();
+    } else {
+        const RunChunk &lc = chunks.back();
+        out->mp3 = res->big[0].data(); out->mp3_len = (size_t)(lc.out_off + lc.out_len);
+        out->kbps = kbps;
+        out->hide_offset = hide_offset;
+        out->too_long = hide_offset < n_hide - 1 ? 1 : 0;
+    }
+    for (auto &s : P->slots) s.busy = false;
+    c->run_stats.files++; c->run_stats.chunks += (int64_t)chunks.size();
+    *owner = res.release();
+    return MP3S_OK;
+}

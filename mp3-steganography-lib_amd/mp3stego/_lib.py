@@ -178,7 +178,7 @@ SYMBOLS = ["mp3s_ctx_create", "mp3s_ctx_destroy", "mp3s_ctx_wait", "mp3s_last_er
            "mp3s_hide_message", "mp3s_clear_file", "mp3s_hide_messages", "mp3s_reencode_block", "mp3s_reveal_message",
            "mp3s_pipe_create", "mp3s_pipe_destroy", "mp3s_pipe_submit", "mp3s_pipe_submit_decode", "mp3s_pipe_collect", "mp3s_pipe_get_stats",
            "mp3s_index_stream", "mp3s_index_free", "mp3s_scan_range", "mp3s_decode_block_indexed", "mp3s_reencode_block_indexed",
-           "mp3s_hide_message_chunked"]
+           "mp3s_hide_message_chunked", "mp3s_walk_stream", "mp3s_parse_frames_dev", "mp3s_stego_bits", "mp3s_ctx_set_option", "mp3s_ctx_get_option", "mp3s_ctx_run_stats"]
 
 _lib = None
 _lock = threading.Lock()
@@ -204,6 +204,9 @@ def lib():
         L.mp3s_ctx_destroy.argtypes = [vp]
         L.mp3s_ctx_destroy.restype = None
         L.mp3s_device_name.argtypes = [vp, C.c_char_p, sz]
+        L.mp3s_ctx_run_stats.argtypes = [vp, vp]
+        L.mp3s_ctx_set_option.argtypes = [vp, i32, i64]
+        L.mp3s_ctx_get_option.argtypes = [vp, i32, C.POINTER(C.c_int64)]
         L.mp3s_sync.argtypes = [vp]
         L.mp3s_ctx_wait.argtypes = [vp, vp]
         L.mp3s_debug_tables.argtypes = [C.POINTER(sz)]
@@ -328,8 +331,30 @@ class Context:
 
     def close(self):
         if self.handle:
+            for p in list(getattr(self, "_pipes", ())):      # a pipe works on its context's stream: it goes first
+                p.close()
             lib().mp3s_ctx_destroy(self.handle)
             self.handle = None
+
+    OPTIONS = {"select": 1, "redo": 2, "fast_imdct": 3, "pipe_tail": 4, "chunk_frames": 5, "device_parse": 6, "file_pipeline": 7,
+               "scan_threads": 8}
+
+    def set_option(self, name, value):
+        """options of the context (include/mp3s.h MP3S_OPT_*); returns the value the option had"""
+        old = self.get_option(name)
+        check(lib().mp3s_ctx_set_option(self.handle, self.OPTIONS[name], int(value)))
+        return old
+
+    def run_stats(self):
+        """what became of this context's one-file calls: dict(files, chunks, reruns, resolved, fallbacks) (mp3s_ctx_run_stats)"""
+        a = (C.c_int64 * 5)()
+        check(lib().mp3s_ctx_run_stats(self.handle, a))
+        return dict(zip(("files", "chunks", "reruns", "resolved", "fallbacks"), list(a)))
+
+    def get_option(self, name):
+        v = C.c_int64()
+        check(lib().mp3s_ctx_get_option(self.handle, self.OPTIONS[name], C.byref(v)))
+        return v.value
 
     def __del__(self):
         try:
@@ -683,6 +708,9 @@ class Pipe:
         h = C.c_void_p()
         check(lib().mp3s_pipe_create(ctx.handle, int(depth), int(max_job_bytes), int(scan_threads), C.byref(h)))
         self.handle, self.ctx, self.depth = h, ctx, int(depth)
+        if not hasattr(ctx, "_pipes"):
+            ctx._pipes = []
+        ctx._pipes.append(self)                 # Context.close() closes its pipes first
         self._keep = {}                         # ticket -> the buffers the job borrows
         self._out, self._status, self._cap = (File * max_files)(), (C.c_int32 * max_files)(), max_files
 
@@ -692,6 +720,8 @@ class Pipe:
         n = len(mp3s)
         if messages is not None and n != len(messages):
             raise ValueError("one message (or None) per file")
+        if n > self._cap:
+            raise ValueError(f"{n} files in one job, the pipe was made for {self._cap} (max_files)")
         bufs = [np.frombuffer(m, dtype=np.uint8) for m in mp3s]
         files = (C.c_void_p * n)(*[b.ctypes.data for b in bufs])
         lens = (C.c_size_t * n)(*[len(b) for b in bufs])
@@ -712,6 +742,8 @@ class Pipe:
     def submit_decode(self, mp3s):
         """a decode job (MP3 -> WAV bytes + stego bits per file) -> ticket, or None when every slot is taken"""
         n = len(mp3s)
+        if n > self._cap:
+            raise ValueError(f"{n} files in one job, the pipe was made for {self._cap} (max_files)")
         bufs = [np.frombuffer(m, dtype=np.uint8) for m in mp3s]
         files = (C.c_void_p * n)(*[b.ctypes.data for b in bufs])
         lens = (C.c_size_t * n)(*[len(b) for b in bufs])
@@ -730,6 +762,8 @@ class Pipe:
         rc = lib().mp3s_pipe_collect(self.handle, C.byref(t), C.byref(owner), self._out, self._status, self._cap, C.byref(nf))
         if rc == E_BUSY:
             return None
+        if rc == E_ARG:                         # (the job stays in flight: nothing of it may be released)
+            check(rc)
         self._keep.pop(t.value, None)
         check(rc)
         own = _Owner(owner)
@@ -751,9 +785,12 @@ class Pipe:
 
     def close(self):
         if self.handle:
-            lib().mp3s_pipe_destroy(self.handle)
+            if self.ctx.handle:                 # (a context that is gone took its streams with it)
+                lib().mp3s_pipe_destroy(self.handle)
             self.handle = None
             self._keep.clear()
+            if self in getattr(self.ctx, "_pipes", ()):
+                self.ctx._pipes.remove(self)
 
     def __del__(self):
         try:

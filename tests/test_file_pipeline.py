@@ -1,0 +1,143 @@
+"""ONE file as chunks through the overlapped stages: mp3s_hide_message / mp3s_clear_file /
+mp3s_decode_file / mp3s_decode_stream walk the frame headers a chunk at a time and keep several chunks in flight; the
+result must be the bytes of the same call with the stages one after the other (MP3S_OPT_FILE_PIPELINE = 0: round 2's
+path, which tests/test_gpu_dropin.py and tests/test_gpu_parity.py pin to the reference's goldens and to the oracle).
+Reference call shape: steganography.py:137-162, decoder/MP3_Parser.py:68-80, encoder/MP3_Encoder.py:607-609."""
+import hashlib
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+class options:
+    def __init__(self, ctx, **kw):
+        self.ctx, self.kw = ctx, kw
+
+    def __enter__(self):
+        self.old = {k: self.ctx.set_option(k, v) for k, v in self.kw.items()}
+
+    def __exit__(self, *a):
+        for k, v in self.old.items():
+            self.ctx.set_option(k, v)
+
+
+def legacy(ctx, f, *a):
+    with options(ctx, file_pipeline=0):
+        return f(*a)
+
+
+def same_file(a, b):
+    return bytes(a["data"]) == bytes(b["data"]) and all(a[k] == b[k] for k in ("too_long", "hide_offset", "n_frames", "kbps", "sampling_rate"))
+
+
+def test_goldens_through_chunks(ctx, mlib, golden_dir):
+    """tests/test.mp3 (36 frames): hide / clear / decode in chunks of 4 ... 36 frames = the reference's bytes"""
+    data = open(os.path.join(golden_dir, "test.mp3"), "rb").read()
+    want_f64 = bytes(np.load(os.path.join(golden_dir, "g2_decode_testmp3.npz"))["pcm_sha256"]).decode()     # the reference's float64 PCM
+    want_hide, want_clear, want_wav = legacy(ctx, ctx.hide_message, data, "ddd"), legacy(ctx, ctx.clear_file, data), legacy(ctx, ctx.decode_file, data)
+    import json
+    facade = json.load(open(os.path.join(golden_dir, "g3_facade.json")))                                       # the reference's own outputs
+    assert hashlib.sha256(bytes(want_hide["data"])).hexdigest() == facade["hide_sha256"]
+    assert hashlib.sha256(bytes(want_wav["data"])).hexdigest() == "d6787aaab67826a07221eb6cb9d604c44bf3e7a1d79580ec7edded5dc17c6a90"
+    s0 = ctx.run_stats()
+    for chunk in (4, 5, 7, 16, 35, 36, 0):
+        with options(ctx, chunk_frames=chunk):
+            assert same_file(ctx.hide_message(data, "ddd"), want_hide), chunk
+            assert same_file(ctx.clear_file(data), want_clear), chunk
+            w = ctx.decode_file(data)
+            assert bytes(w["data"]) == bytes(want_wav["data"]) and np.array_equal(w["bits"], want_wav["bits"]), chunk
+            f64 = ctx.decode_stream(data, mlib.MP3S_PCM_F64)
+            assert hashlib.sha256(f64["pcm"].tobytes()).hexdigest() == want_f64, chunk
+    s1 = ctx.run_stats()
+    assert s1["files"] - s0["files"] == 7 * 4 and s1["fallbacks"] == s0["fallbacks"], (s0, s1)
+    assert s1["chunks"] - s0["chunks"] > 7 * 4 * 2
+
+
+def test_float_formats_in_chunks_are_bit_identical(ctx, mlib, golden_dir):
+    import frame_synth
+    streams = [open(os.path.join(golden_dir, "test.mp3"), "rb").read(),
+               frame_synth.make_stream(7, 300, block_types=(0, 1, 2, 3), use_reservoir=True),           # reservoir, all block types
+               frame_synth.make_stream(8, 200, mode=3, use_reservoir=True),                              # mono
+               frame_synth.make_stream(12, 150, mode=1, block_types=(0, 2))]                            # joint stereo, short blocks
+    for si, mp3 in enumerate(streams):
+        for fmt in (mlib.MP3S_PCM_F64, mlib.MP3S_PCM_F32, mlib.MP3S_PCM_I16):
+            want = legacy(ctx, ctx.decode_stream, mp3, fmt)
+            for chunk in (9, 64, 0):
+                with options(ctx, chunk_frames=chunk):
+                    got = ctx.decode_stream(mp3, fmt)
+                assert got["pcm"].tobytes() == want["pcm"].tobytes(), (si, fmt, chunk)
+                assert np.array_equal(got["bits"], want["bits"]) and got["n_frames"] == want["n_frames"], (si, fmt, chunk)
+                assert (got["channels"], got["sampling_rate"], got["bit_rate"]) == (want["channels"], want["sampling_rate"], want["bit_rate"])
+
+
+def test_carries_across_chunks(ctx, mlib, orc):
+    """silences at chunk boundaries (inherited addresses: SURVEY E7), messages that end inside a later chunk (the cursor is
+    live at a boundary), a truncated last frame -- chunks that depend on their carry are run again, the bytes stay"""
+    from synth_pcm import synth_pcm
+    pcm = synth_pcm(700, seed=51)
+    pcm[:40 * 1152] = 0                                      # the stream starts in silence
+    pcm[120 * 1152:136 * 1152] = 0                           # silences that straddle chunk boundaries of 64 and 128 frames
+    pcm[250 * 1152:262 * 1152] = 0
+    pcm[500 * 1152:530 * 1152, 1] = 0                        # one channel silent
+    mp3 = bytes(ctx.encode_pcm(pcm, 44100, 128, None)["mp3"])
+    s0 = ctx.run_stats()
+    for data in (mp3, mp3[:-3]):
+        for msg in ("short", "x" * 150, "y" * 400, None):
+            want = legacy(ctx, ctx.clear_file, data) if msg is None else legacy(ctx, ctx.hide_message, data, msg)
+            for chunk in (64, 128, 250, 0):
+                with options(ctx, chunk_frames=chunk):
+                    got = ctx.clear_file(data) if msg is None else ctx.hide_message(data, msg)
+                assert same_file(got, want), (len(data), msg and len(msg), chunk)
+    s1 = ctx.run_stats()
+    assert s1["files"] > s0["files"] and s1["reruns"] > s0["reruns"], (s0, s1)      # some chunk did depend on its carry
+    # against the oracle directly
+    d = orc.decode(mp3)
+    o = orc.encode(orc.pcm_to_i16(d["pcm"]), 44100, 128, np.array(mlib.message_frame("y" * 400)))
+    with options(ctx, chunk_frames=64):
+        assert bytes(ctx.hide_message(mp3, "y" * 400)["data"]) == o["mp3"]
+
+
+def test_what_the_chunks_do_not_take_falls_back(ctx, mlib, golden_dir):
+    import frame_synth
+    mixed = frame_synth.make_stream(9, 60, block_types=(0, 2), allow_mixed=True)      # scalefactors inherited across frames
+    mono = frame_synth.make_stream(8, 50, mode=3)
+    data = open(os.path.join(golden_dir, "test.mp3"), "rb").read()
+    tail = data + b"\x00" * 700                                                       # a bad header: the last frame is repeated (D12)
+    with options(ctx, chunk_frames=16):
+        s0 = ctx.run_stats()
+        assert legacy(ctx, ctx.decode_stream, mixed, mlib.MP3S_PCM_F64)["pcm"].tobytes() == ctx.decode_stream(mixed, mlib.MP3S_PCM_F64)["pcm"].tobytes()
+        assert bytes(legacy(ctx, ctx.decode_file, tail)["data"]) == bytes(ctx.decode_file(tail)["data"])
+        assert same_file(legacy(ctx, ctx.hide_message, tail, "abc"), ctx.hide_message(tail, "abc"))
+        with pytest.raises(mlib.Mp3sError) as e1:
+            ctx.hide_message(mono, "abc")
+        assert e1.value.code == mlib.E_UNSUPPORTED
+        assert ctx.decode_file(b"\x00" * 10)["n_frames"] == 0                         # no sync: an empty WAV, as the reference writes
+        s1 = ctx.run_stats()
+        assert s1["fallbacks"] - s0["fallbacks"] >= 4, (s0, s1)
+
+
+def test_long_file_automatic_chunks_and_the_facade(ctx, mlib, tmp_path):
+    """a 12 000-frame file with the automatic plan (four to five chunks in flight), through Steganography.hide_message"""
+    from synth_pcm import synth_pcm
+    from mp3stego import Steganography
+    pcm = synth_pcm(12000, seed=61)
+    mp3 = bytes(ctx.encode_pcm(pcm, 44100, 128, None)["mp3"])
+    want = legacy(ctx, ctx.hide_message, mp3, "The quick brown fox")
+    s0 = ctx.run_stats()
+    got = ctx.hide_message(mp3, "The quick brown fox")
+    s1 = ctx.run_stats()
+    assert same_file(got, want)
+    assert s1["files"] - s0["files"] == 1 and s1["chunks"] - s0["chunks"] >= 3 and s1["fallbacks"] == s0["fallbacks"], (s0, s1)
+    wav_want = legacy(ctx, ctx.decode_file, mp3)
+    wav = ctx.decode_file(mp3)
+    assert bytes(wav["data"]) == bytes(wav_want["data"]) and np.array_equal(wav["bits"], wav_want["bits"])
+    src, dst = tmp_path / "in.mp3", tmp_path / "out.mp3"
+    src.write_bytes(mp3)
+    st = Steganography(quiet=True)
+    assert st.hide_message(str(src), str(dst), "The quick brown fox") is False
+    assert dst.read_bytes() == bytes(want["data"])
+    got = ctx.hide_message_chunked(mp3, "The quick brown fox", 3000)
+    assert same_file(got, want)

@@ -89,7 +89,7 @@ def test_pipe_matches_the_synchronous_calls_and_the_oracle(mlib, orc, golden_dir
             assert st["fast"] + st["resolved"] + st["slow"] == st["collected"], st
         # without the selection on the device (the first pass as it was until r02b) the long message's verdict is "redo":
         # its chains are resolved at collect time, on the job's own buffers
-        os.environ["MP3S_NO_SELECT"] = "1"
+        keep = ctx.set_option("select", 0)
         try:
             pipe = mlib.Pipe(ctx, depth=3, max_job_bytes=1 << 20, scan_threads=2)
             try:
@@ -98,7 +98,7 @@ def test_pipe_matches_the_synchronous_calls_and_the_oracle(mlib, orc, golden_dir
             finally:
                 pipe.close()
         finally:
-            del os.environ["MP3S_NO_SELECT"]
+            ctx.set_option("select", keep)
         assert st["resolved"] >= 2 and st["collected"] == 3, st
         for res, k in zip(got, (5, 0, 5)):
             assert bytes(res[0]["data"]) == bytes(want[k][0]["data"]) and res[0]["hide_offset"] == want[k][0]["hide_offset"], k
