@@ -18,6 +18,11 @@ Three timed regions, all on the same 10 000-frame stream
         threads || upload || kernels || download, several batches in flight), >= 200 batches, steady state.  This is
         what a caller of the library gets.  `regions.bytes_to_bytes_one_at_a_time` is the synchronous call in a loop.
 
+`single_file_10k` / `single_file_100k` are ONE file per call -- the reference's call shape (steganography.py:137-162) --
+through `Context.hide_message` (one native call: the file as chunks through the overlapped stages) and through the drop-in
+`Steganography.hide_message(quiet=True)`.  `config5` is BASELINE configs[4]: streams with short / switching / mixed blocks, MS,
+mono, bit reservoir at 32 / 44.1 / 48 kHz (decode, frames/s) and re-encodes at 32 ... 320 kbps.
+
 `decode_only` is BASELINE config 2 (Huffman + decode transforms to float32 PCM, resident).  Multi-GPU: every rank owns
 its own batches (weak scaling, no collective on the data path) and runs regions (i) and (iii); torch is used only for the
 rendezvous / barrier / max-over-ranks (gloo).
@@ -64,6 +69,102 @@ def bits_of(s):
     return np.frombuffer("".join(format(b, "08b") for b in s.encode()).encode(), dtype=np.uint8) - ord("0")
 
 
+def run_config5(ctx, _lib, O, synth_pcm, n):
+    """BASELINE configs[4]: mixed bitrate / sampling-rate corpus with long / short block switching, mono and joint stereo.
+    Decode side: streams from tests/frame_synth.py (250 synthesised frames, laid end to end up to `n`: every copy starts with
+    main_data_begin = 0 and the reservoir only looks back) -> frames/s of Context.decode_stream to int16 (fast kernels behind
+    the guard) and to float32 (exact kernels), a prefix compared with the oracle.  Encode side: this encoder's own streams
+    at (sampling rate, bitrate) pairs -> frames/s of Context.hide_message, compared with the stages one after the other and,
+    on a prefix, with the oracle.  Reference: decoder/Frame.py:120-125, 186-208, 574-602."""
+    import frame_synth
+    ok = True
+    reps = max(1, n // 250)
+    nf = 250 * reps
+    mixes = [("long_blocks_44k_128", dict(seed=101, block_types=(0,), use_reservoir=False)),
+             ("all_short_44k_128", dict(seed=102, block_types=(2,), use_reservoir=False)),
+             ("switching_reservoir_44k_128", dict(seed=103, block_types=(0, 1, 2, 3), use_reservoir=True)),
+             ("mixed_blocks_44k_128", dict(seed=104, block_types=(0, 2), allow_mixed=True, use_reservoir=True)),
+             ("joint_ms_short_48k_192", dict(seed=105, sr_idx=1, bitrate_idx=11, mode=1, mode_ext=2, block_types=(0, 2), use_reservoir=True)),
+             ("mono_crc_32k_64", dict(seed=106, sr_idx=2, bitrate_idx=5, mode=3, crc=True, block_types=(0, 1, 2, 3), use_reservoir=True)),
+             ("long_reservoir_44k_320", dict(seed=107, bitrate_idx=14, block_types=(0,), use_reservoir=True)),
+             ("low_rate_32k_32", dict(seed=108, sr_idx=2, bitrate_idx=1, block_types=(0, 2), use_reservoir=True))]
+    dec = {}
+    for name, kw in mixes:
+        seed = kw.pop("seed")
+        one = frame_synth.make_stream(seed, 250, **kw)
+        data = one * reps
+        row = {"frames": nf, "bytes": len(data)}
+        od = O.decode(one)                                                   # the oracle on the 250 synthesised frames
+        rs0 = ctx.run_stats()
+        for fmt, key in ((_lib.MP3S_PCM_I16, "int16_fast"), (_lib.MP3S_PCM_F32, "float32_exact")):
+            r = ctx.decode_stream(data, fmt)
+            ok = ok and r["n_frames"] == nf
+            head = r["pcm"][:250 * 1152]
+            want = O.pcm_to_i16(od["pcm"]) if fmt == _lib.MP3S_PCM_I16 else od["pcm"].astype(np.float32)
+            ok = ok and bool(np.array_equal(head, want)) and bool(np.array_equal(r["bits"][:len(od["bits"])], od["bits"]))
+            del r
+            k = 5
+            t0 = time.perf_counter()
+            for _ in range(k):
+                r = ctx.decode_stream(data, fmt); del r
+            dt = (time.perf_counter() - t0) / k
+            row[key] = {"ms": round(dt * 1e3, 3), "frames_per_s": round(nf / dt)}
+        rs1 = ctx.run_stats()
+        row["through_the_overlapped_stages"] = rs1["files"] > rs0["files"]     # False: the stream needed the host parser (scalefactors inherited across frames)
+        if name == "all_short_44k_128":
+            # per kernel, the stages one after the other (event pairs around every launch)
+            ctx.set_option("file_pipeline", 0)
+            ctx.profile_select(None); ctx.profile_enable(True)
+            for _ in range(3):
+                r = ctx.decode_stream(data, _lib.MP3S_PCM_I16); del r
+            pr = ctx.profile_collect()
+            ctx.profile_enable(False)
+            row["kernels_ms_int16"] = {kn: round(ms / 3, 4) for kn, (ms, cnt) in pr.items() if cnt}
+            ctx.profile_enable(True)
+            for _ in range(3):
+                r = ctx.decode_stream(data, _lib.MP3S_PCM_F32); del r
+            pr = ctx.profile_collect()
+            ctx.profile_enable(False)
+            row["kernels_ms_float32"] = {kn: round(ms / 3, 4) for kn, (ms, cnt) in pr.items() if cnt}
+            ctx.set_option("file_pipeline", 1)
+        dec[name] = row
+    enc = {}
+    msg = "The quick brown fox jumps over the lazy dog, again & again, 0123"
+    pcm = synth_pcm(min(n, 2500), seed=0x5EED)
+    for rate, kbps in ((44100, 64), (44100, 320), (48000, 192), (32000, 128), (32000, 32), (48000, 320)):
+        src = bytes(ctx.encode_pcm(pcm, rate, kbps, None)["mp3"])
+        fsz = _lib.parse_stream(src)["frame_size"].astype(np.int64)
+        m = len(fsz) - 1
+        if m < 64:          # (32 kHz at 48 / 96 kbit/s: the reference's encoder sets a padding bit its own decoder does not expect, the stream ends after a frame)
+            enc["%d_Hz_%d_kbps" % (rate, kbps)] = {"frames": int(m + 1), "skipped": "the reference's decoder stops after the first frame of this encoder's stream"}
+            continue
+        whole = src[:int(fsz[:m].sum())]
+        r4 = max(1, n // m)
+        data = whole * r4
+        nfr = m * r4
+        got = ctx.hide_message(data, msg)
+        ctx.set_option("file_pipeline", 0)
+        want = ctx.hide_message(data, msg)
+        ctx.set_option("file_pipeline", 1)
+        ok = ok and same_bytes(got["data"], bytes(want["data"])) and got["hide_offset"] == want["hide_offset"]
+        # the oracle on a prefix of 64 frames
+        k = 64
+        o_dec = O.decode(data[:int(fsz[:k + 1].sum())])
+        o_enc = O.encode(O.pcm_to_i16(o_dec["pcm"])[:k * 1152], rate, kbps, bits_of("%d#%s" % (len(msg), msg)))
+        ok = ok and bytes(got["data"])[:len(o_enc["mp3"]) - 8] == o_enc["mp3"][:len(o_enc["mp3"]) - 8]
+        del got, want
+        kk = 8
+        t0 = time.perf_counter()
+        for _ in range(kk):
+            r = ctx.hide_message(data, msg); del r
+        dt = (time.perf_counter() - t0) / kk
+        enc["%d_Hz_%d_kbps" % (rate, kbps)] = {"frames": nfr, "bytes": len(data), "ms": round(dt * 1e3, 3), "frames_per_s": round(nfr / dt)}
+    slow = min(dec, key=lambda kname: dec[kname]["int16_fast"]["frames_per_s"])
+    return {"what": "BASELINE configs[4]: decode of synthesised streams (250 frames laid end to end) and re-encode (hide_message) of this encoder's streams, "
+                    "one file per call through the overlapped stages; every result compared with the oracle on a prefix",
+            "decode": dec, "reencode": enc, "slowest_decode_mix": slow}, ok
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -72,7 +173,9 @@ def main():
     ap.add_argument("--frames", type=int, default=10000, help="frames per GPU per step / per batch")
     ap.add_argument("--e2e-batches", type=int, default=400, help="batches of the host-fed steady-state region (0 = skip)")
     ap.add_argument("--pipe-depth", type=int, default=4)
-    ap.add_argument("--scan-threads", type=int, default=3)
+    ap.add_argument("--scan-threads", type=int, default=1, help="host threads of the pipe (the frame walk takes 0.27 ms of one core per 10 000-frame batch)")
+    ap.add_argument("--no-config5", action="store_true", help="skip the mixed corpus (BASELINE configs[4]): its streams take ~20 s to synthesise")
+    ap.add_argument("--no-single-file-100k", action="store_true")
     ap.add_argument("--cpu-frames", type=int, default=10000, help="frames per pass of the CPU baseline (rank 0, N=1)")
     ap.add_argument("--cpu-seconds", type=float, default=10.0, help="the CPU baseline repeats its pass until this much time has gone by")
     ap.add_argument("--cpu-seconds-all", type=float, default=6.0, help="duration of the all-cores run of the CPU baseline (0 = skip)")
@@ -180,6 +283,7 @@ def main():
     d_spans, d_eu, d_ec = ctx.to_device(spans), ctx.to_device(ent_unit), ctx.to_device(ent_cursor)
     d_ixv, d_outv, d_env = ctx.alloc(n_ent * 1152), ctx.alloc(n_ent * 72 + ((n_ent + 15) & ~15)), ctx.alloc(n_ent * 88)
     d_cur = ctx.to_device(np.full(units, _lib.NO_CURSOR, dtype=np.int32))
+    d_cur0 = ctx.to_device(np.full(units, _lib.NO_CURSOR, dtype=np.int32))   # what every step starts from (the library uploads fresh cursors with every job)
     d_verdict = ctx.alloc(16)
     d_segout = ctx.alloc(80)
 
@@ -220,6 +324,7 @@ def main():
             front_end(aux, k + 1)
         if aux2 is not None:
             ctx.wait_for(aux2)                      # the packer of batch k-1 has read what the rate loop is about to overwrite
+        _lib.check(L.mp3s_dev_copy(ctx.handle, d_cur, d_cur0, units * 4))   # "behind every message" for every unit: nothing of the step before is reused
         _lib.check(L.mp3s_rate_variants_dev(ctx.handle, d_mdct, d_rf, n, d_hide, len(hide_all), d_cur, d_eu, d_ec, n_ent, d_ix, d_out, d_en,
                                             d_ixv, d_outv, d_env))
         pk = ctx
@@ -347,20 +452,85 @@ def main():
     # ---------------------------------------------------------------- regions (ii) and (iii): host-fed
     regions, e2e_steady, short_files, long_message = {}, None, None, None
     if not args.resident_only:
-        # (iii) one at a time: the synchronous bytes -> bytes call in a loop (scan, upload, kernels, download, nothing overlapped)
+        # ONE file per call (the reference's call shape): the file goes through the overlapped stages as chunks
         hid = ctx.hide_message(mp3_in, payload)
         same = same and bytes(hid["data"]) == bytes(final["mp3"])
         ref_out = bytes(hid["data"])
         del hid
         k1 = 30
+        rs0 = ctx.run_stats()
         t0 = time.perf_counter()
         for _ in range(k1):
             r = ctx.hide_message(mp3_in, payload)
         t_one = (time.perf_counter() - t0) / k1
+        rs1 = ctx.run_stats()
+        same = same and bytes(r["data"]) == ref_out and rs1["files"] - rs0["files"] == k1
+        del r
+        # ... and through the drop-in facade: Steganography.hide_message(quiet=True), files on a RAM disk where there is one
+        import shutil
+        import tempfile
+        from mp3stego import Steganography
+        tdir = tempfile.mkdtemp(dir="/dev/shm" if os.path.isdir("/dev/shm") and os.access("/dev/shm", os.W_OK) else None)
+        t_fac = None
+        try:
+            src, dst = os.path.join(tdir, "in.mp3"), os.path.join(tdir, "out.mp3")
+            open(src, "wb").write(mp3_in)
+            st = Steganography(quiet=True)
+            st.hide_message(src, dst, payload)
+            t0 = time.perf_counter()
+            for _ in range(10):
+                st.hide_message(src, dst, payload)
+            t_fac = (time.perf_counter() - t0) / 10
+            same = same and open(dst, "rb").read() == ref_out
+        finally:
+            shutil.rmtree(tdir, ignore_errors=True)
+        regions["single_file_10k"] = {"ms_per_batch": round(t_one * 1e3, 4), "frames_per_s": round(n / t_one, 1), "batches": k1,
+                                      "chunks_per_file": round((rs1["chunks"] - rs0["chunks"]) / k1, 2),
+                                      "facade_ms_per_file": round(t_fac * 1e3, 4) if t_fac else None,
+                                      "what": "Context.hide_message(bytes) = ONE mp3s_hide_message call per file, a loop of them: the file's chunks through walk || upload || "
+                                              "parse + Huffman || kernels || download; facade_ms_per_file = Steganography.hide_message(quiet=True) on files (read + the same call + write)"}
+        # the same file with the stages one after the other (round 2's path, kept as the fallback)
+        ctx.set_option("file_pipeline", 0)
+        r = ctx.hide_message(mp3_in, payload)
+        t0 = time.perf_counter()
+        for _ in range(k1):
+            r = ctx.hide_message(mp3_in, payload)
+        t_seq = (time.perf_counter() - t0) / k1
         same = same and bytes(r["data"]) == ref_out
         del r
-        regions["bytes_to_bytes_one_at_a_time"] = {"ms_per_batch": round(t_one * 1e3, 4), "frames_per_s": round(n / t_one, 1), "batches": k1,
-                                                   "what": "mp3s_hide_message in a loop: host scan + upload + kernels + download, nothing overlapped"}
+        ctx.set_option("file_pipeline", 1)
+        regions["bytes_to_bytes_one_at_a_time"] = {"ms_per_batch": round(t_seq * 1e3, 4), "frames_per_s": round(n / t_seq, 1), "batches": k1,
+                                                   "what": "mp3s_hide_message with MP3S_OPT_FILE_PIPELINE = 0: host scan + upload + kernels + download, nothing overlapped (round 2's path)"}
+        if not args.no_single_file_100k and n >= 1000:
+            # a 100 000-frame file: the stream's complete frames ten times over (every frame of this encoder stands alone: main_data_begin = 0)
+            fsz = parsed["frame_size"].astype(np.int64)
+            reps = max(1, 100000 // (n - 1))
+            big = mp3_in[:int(fsz[:n - 1].sum())] * reps
+            nbig = (n - 1) * reps
+            ctx.set_option("file_pipeline", 0)
+            big_ref = ctx.hide_message(big, payload)
+            big_out = bytes(big_ref["data"]); del big_ref
+            ctx.set_option("file_pipeline", 1)
+            r = ctx.hide_message(big, payload)
+            rs0 = ctx.run_stats()
+            kb = 8
+            t0 = time.perf_counter()
+            for _ in range(kb):
+                r = ctx.hide_message(big, payload)
+            t_big = (time.perf_counter() - t0) / kb
+            rs1 = ctx.run_stats()
+            same = same and same_bytes(r["data"], big_out) and rs1["files"] - rs0["files"] == kb
+            del r
+            t0 = time.perf_counter()
+            for _ in range(3):
+                r = ctx.decode_file(big); del r
+            t_bigdec = (time.perf_counter() - t0) / 3
+            regions["single_file_100k"] = {"ms_per_batch": round(t_big * 1e3, 3), "frames_per_s": round(nbig / t_big, 1), "batches": kb, "frames": nbig,
+                                           "bytes": len(big), "chunks_per_file": round((rs1["chunks"] - rs0["chunks"]) / kb, 2),
+                                           "decode_file_ms": round(t_bigdec * 1e3, 3), "decode_file_frames_per_s": round(nbig / t_bigdec, 1),
+                                           "what": "one mp3s_hide_message call on a 42 MB file, bytes -> bytes (compared with the stages-one-after-the-other result); "
+                                                   "decode_file = MP3 -> WAV of the same file (460 MB of PCM down)"}
+            del big, big_out
         kd = 10
         r = ctx.decode_stream(mp3_in, _lib.MP3S_PCM_I16); del r
         t0 = time.perf_counter()
@@ -505,6 +675,20 @@ def main():
             same = same and all(not isinstance(b, Exception) and b["data"] == l["data"] for b, l in zip(batch_out, loop_out))
             short_files = {"files": len(shorts), "frames_each": 40, "hide_messages_one_batch_s": round(t_batch, 4),
                            "hide_message_per_file_loop_s": round(t_loop, 4), "batch_files_per_s": round(len(shorts) / t_batch, 1)}
+    # ---------------------------------------------------------------- BASELINE configs[4]: the mixed corpus
+    config5 = None
+    if not args.resident_only and not args.no_config5 and rank == 0 and world == 1:
+        config5, ok5 = run_config5(ctx, _lib, O, synth_pcm, min(n, 10000))
+        same = same and ok5
+    # ---------------------------------------------------------------- the ranks of one host side by side
+    host = {"rank": rank, "cpus_allowed": len(os.sched_getaffinity(0)), "scan_threads": args.scan_threads,
+            "host_walk_ms_per_batch": e2e_steady["host_scan_ms_per_batch"] if e2e_steady else None,
+            "host_issue_ms_per_batch": e2e_steady["host_issue_ms_per_batch"] if e2e_steady else None,
+            "pcie_gb_s": round((e2e_steady["bytes_in_per_batch"] + e2e_steady["bytes_out_per_batch"]) / (e2e_steady["ms_per_batch"] * 1e-3) / 1e9, 2) if e2e_steady else None}
+    hosts = [host]
+    if dist is not None:
+        hosts = [None] * world
+        dist.all_gather_object(hosts, host)
     same = reduce_all_ok(same and oracle_ok)
 
     # ---------------------------------------------------------------- rooflines of the dominant kernel
@@ -623,6 +807,8 @@ def main():
             "front_end_overlap": aux is not None, "tail_stream": aux2 is not None,
             "parity_checked": bool(same),
             "short_files": short_files,
+            "config5": config5,
+            "ranks_on_this_host": hosts,
             "prep_s": round(prep_s, 2),
             "device": ctx.device_name(),
         }

@@ -151,6 +151,8 @@ int mp3s_dev_free(mp3s_ctx *ctx, void *dptr);
 int mp3s_dev_upload(mp3s_ctx *ctx, void *dptr, const void *host, size_t bytes);
 int mp3s_dev_download(mp3s_ctx *ctx, void *host, const void *dptr, size_t bytes);
 int mp3s_dev_memset(mp3s_ctx *ctx, void *dptr, int value, size_t bytes);
+/* device to device on the context's stream, asynchronous (e.g. a template of assumed cursors into place at the top of a step) */
+int mp3s_dev_copy(mp3s_ctx *ctx, void *d_dst, const void *d_src, size_t bytes);
 /* HIP-event timer on the context's stream (the stream every kernel below is launched on) */
 int mp3s_timer_start(mp3s_ctx *ctx);
 int mp3s_timer_stop(mp3s_ctx *ctx, float *ms);

@@ -157,12 +157,14 @@ template <int WAVES, int LANES>
 __global__ __launch_bounds__(WAVES * 64) void k_dec_huffman(
     const uint8_t *__restrict__ blob, const mp3s_frame_side *__restrict__ side, int n_frames, int nch, int W, int max_bits,
     int16_t *__restrict__ is, mp3s_granule_si *__restrict__ si_out, int32_t *__restrict__ status, int per_frame,
-    int32_t *__restrict__ sync /* {finished workgroups, error bits}: zero between launches, owned by the context */)
+    int32_t *__restrict__ sync /* {finished workgroups, error bits}: zero between launches, owned by the context; null: status[0] was
+                                  zeroed by the caller and takes the error bits directly */)
 {
     __shared__ uint16_t fast[15][HUFF_L1_N];
     __shared__ uint16_t lut2[HUFF_L2_N];    // second-level tables for the codes longer than the first-level index
     __shared__ uint16_t quad[64];
     __shared__ uint16_t tinfo[32];        // table_select -> first-level table id | linbits << 8
+    __shared__ int wg_err;                // the group's error bits
     extern __shared__ uint32_t words[];   // [W][COLS]
     constexpr int T = WAVES * 64, COLS = WAVES * LANES;
     {
@@ -183,6 +185,7 @@ __global__ __launch_bounds__(WAVES * 64) void k_dec_huffman(
             reinterpret_cast<uint32_t *>(lut2)[i] = reinterpret_cast<const uint32_t *>(c_tab.huff_l2)[i];
         if (threadIdx.x < 64) quad[threadIdx.x] = c_tab.quad_fast[threadIdx.x];
         if (threadIdx.x < 32) tinfo[threadIdx.x] = (uint16_t)(c_tab.huff_lut_id[threadIdx.x] | (c_tab.linbits[threadIdx.x] << 8));
+        if (threadIdx.x == 0) wg_err = 0;
     }
     __syncthreads();
     const int lane = threadIdx.x & 63, col = (int)(threadIdx.x >> 6) * LANES + lane;
@@ -409,11 +412,20 @@ __global__ __launch_bounds__(WAVES * 64) void k_dec_huffman(
     e4 |= __shfl_xor(e4, 2, 64);
     if (lane < LANES && tid < (long)n_frames * 4 && (tid & 3) == 0) {
         if (per_frame) status[1 + (tid >> 2)] = e4;
-        if (e4) atomicOr(&sync[1], e4);
+        if (e4) atomicOr(&wg_err, e4);                   // (LDS)
     }
     __syncthreads();
-    __threadfence();   // the group's error atomics (other lanes, possibly another L2 channel) are visible device-wide before its arrival is counted
-    if (threadIdx.x == 0 && atomicAdd(&sync[0], 1) == (int)gridDim.x - 1) {
+    // One thread speaks for the group, and what it has to say goes out in program order: the group's error bits first, its
+    // arrival after them -- two device-scope atomics of one lane on neighbouring words, so the last group to arrive finds
+    // every group's bits (no fence: an agent-scope release writes the L2 back, which two thousand groups cannot afford).
+    if (threadIdx.x != 0) return;
+    const int g = wg_err;
+    if (!sync) {          // the caller has zeroed status[0] itself (the overlapped stages: the word travels with the job's inputs)
+        if (g) atomicOr(&status[0], g);
+        return;
+    }
+    if (g) atomicOr(&sync[1], g);
+    if (atomicAdd(&sync[0], 1) == (int)gridDim.x - 1) {
         status[0] = atomicExch(&sync[1], 0);
         atomicExch(&sync[0], 0);
     }

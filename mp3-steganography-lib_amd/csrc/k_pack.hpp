@@ -38,6 +38,7 @@ __global__ __launch_bounds__(256) void k_enc_pack(
     __shared__ uint32_t hc[4][256];
     __shared__ uint8_t hl[4][256];
     __shared__ uint8_t c1code[16], c1len[16];
+    __shared__ int wg_err;                 // the group's error bits
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
     for (int i = threadIdx.x; i < 1024; i += 256) {
         (&hc[0][0])[i] = (&c_tab.hcod[0][0])[i];
@@ -45,6 +46,7 @@ __global__ __launch_bounds__(256) void k_enc_pack(
     }
     for (int i = threadIdx.x; i < 3 * PACK_DW; i += 256) (&fb3[0][0])[i] = 0;
     if (threadIdx.x < 16) { c1code[threadIdx.x] = c_tab.hcod_c1a[threadIdx.x]; c1len[threadIdx.x] = c_tab.hlen_c1a[threadIdx.x]; }
+    if (threadIdx.x == 0) wg_err = 0;
     __syncthreads();
     int rot = 0;
     for (int f = blockIdx.x; f < n_frames; f += gridDim.x) {
@@ -228,7 +230,7 @@ __global__ __launch_bounds__(256) void k_enc_pack(
     }
     // stuffing with ones up to part2_3_length (:1433-1446)
     const int p23 = e == 0 ? p23v[0] : (e == 1 ? p23v[1] : (e == 2 ? p23v[2] : p23v[3]));
-    if (huff_bits > p23 || any_bad) { if (lane == 0) atomicOr(&sync[1], any_bad ? MP3S_PS_BAD_TABLE : MP3S_PS_OVERFLOW); }
+    if (huff_bits > p23 || any_bad) { if (lane == 0) atomicOr(&wg_err, any_bad ? MP3S_PS_BAD_TABLE : MP3S_PS_OVERFLOW); }   // (LDS)
     else
         for (uint32_t s = ustart + huff_bits + 32u * lane; s < ustart + (uint32_t)p23; s += 64u * 32u) {
             const uint32_t n = (ustart + p23 - s) < 32u ? (ustart + p23 - s) : 32u;
@@ -255,9 +257,19 @@ __global__ __launch_bounds__(256) void k_enc_pack(
     // launch on this context.  No fill kernel in front of every launch: one dispatch (and its stream gap) less per step.
     // (Only device-scope atomics touch the pair, so no cache write-back is needed: the barrier waits for this group's
     // error atomics to be acknowledged before its arrival is counted.)
+    // One thread speaks for the group, and in program order: the group's error bits first, its arrival after them -- two
+    // device-scope atomics of one lane on neighbouring words (no fence: an agent-scope release writes the L2 back).
+    // sync == null: the caller has zeroed *status itself (the overlapped stages, where the word travels with the job's inputs): two
+    // thousand arrivals on one counter are 0.1 ms of serialised atomics when the groups finish together, as they do on a short batch.
     __syncthreads();
-    __threadfence();   // the group's error atomics (other lanes, possibly another L2 channel) are visible device-wide before its arrival is counted
-    if (threadIdx.x == 0 && atomicAdd(&sync[0], 1) == (int)gridDim.x - 1) {
+    if (threadIdx.x != 0) return;
+    const int g = wg_err;
+    if (!sync) {
+        if (g) atomicOr(status, g);
+        return;
+    }
+    if (g) atomicOr(&sync[1], g);
+    if (atomicAdd(&sync[0], 1) == (int)gridDim.x - 1) {
         *status = atomicExch(&sync[1], 0);
         atomicExch(&sync[0], 0);
     }

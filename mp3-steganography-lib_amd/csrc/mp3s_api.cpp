@@ -214,6 +214,12 @@ int mp3s_dev_memset(mp3s_ctx *c, void *dptr, int value, size_t bytes)
     HIPCHK(hipMemsetAsync(dptr, value, bytes, c->stream));
     return MP3S_OK;
 }
+int mp3s_dev_copy(mp3s_ctx *c, void *d_dst, const void *d_src, size_t bytes)
+{
+    if (!c || !d_dst || !d_src) return fail(MP3S_E_ARG, "bad argument");
+    if (bytes) HIPCHK(hipMemcpyAsync(d_dst, d_src, bytes, hipMemcpyDeviceToDevice, c->stream));
+    return MP3S_OK;
+}
 int mp3s_timer_start(mp3s_ctx *c)
 {
     if (!c) return fail(MP3S_E_ARG, "ctx is null");

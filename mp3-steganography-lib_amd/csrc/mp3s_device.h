@@ -97,6 +97,9 @@ int launch_parse(hipStream_t stream, const uint8_t *d_image, uint32_t image_base
 constexpr size_t kPlaceEntry = 4912;   // [int32 frame, pad to 16 | int16 is[2304] | mp3s_granule_si si[4]]
 int launch_place_frames(hipStream_t stream, const uint8_t *d_entries, int n_entries, int16_t *d_is, mp3s_granule_si *d_si);
 int launch_copy(hipStream_t stream, const void *d_src, void *d_dst, size_t bytes);
+// one wave that occupies its hardware queue for about `microseconds`; a kernel that does nothing
+int launch_spin(hipStream_t stream, int microseconds);
+int launch_noop(hipStream_t stream);
 
 // bit-level stages on the device
 int launch_huffman(hipStream_t stream, const uint8_t *d_blob, const mp3s_frame_side *d_side, int n_frames, int nch, int max_bits,

@@ -272,6 +272,27 @@ int launch_place_frames(hipStream_t stream, const uint8_t *d_entries, int n_entr
     return (int)hipGetLastError();
 }
 
+// One wave that keeps its hardware queue busy for `ticks` of the 100 MHz wall clock (bounded), and a kernel that does nothing:
+// the pipe finds out with them which of its candidate streams run beside a context's compute stream (mp3s_pipe.cpp, pick_lanes)
+__global__ void k_spin(long long ticks, int *sink)
+{
+    const long long t0 = wall_clock64();
+    int it = 0;
+    while (wall_clock64() - t0 < ticks && it < (1 << 22)) it++;
+    if (sink && it < 0) *sink = it;
+}
+__global__ void k_noop() {}
+int launch_spin(hipStream_t stream, int microseconds)
+{
+    hipLaunchKernelGGL(k_spin, dim3(1), dim3(64), 0, stream, (long long)microseconds * 100, (int *)nullptr);
+    return (int)hipGetLastError();
+}
+int launch_noop(hipStream_t stream)
+{
+    hipLaunchKernelGGL(k_noop, dim3(1), dim3(64), 0, stream);
+    return (int)hipGetLastError();
+}
+
 // plain device copy, 16 bytes per lane and step: what HBM gives a streaming kernel on this box (BASELINE.md section 4 asks
 // for the achievable figure beside the 8 TB/s of the data sheet)
 __global__ __launch_bounds__(256) void k_copy16(const uint4 *__restrict__ src, uint4 *__restrict__ dst, size_t n16)
@@ -290,7 +311,9 @@ int launch_pack(hipStream_t stream, const int16_t *d_ix, const mp3s_gr_out *d_gr
                 int32_t *d_scfsi, int32_t *d_status, int32_t *d_sync, Profiler *prof)
 {
     const int pp = prof ? prof->begin(stream, K_ENC_PACK) : -1;
-    hipLaunchKernelGGL(k_enc_pack, dim3(n_frames < 2048 ? n_frames : 2048), dim3(256), 0, stream,   // persistent: 8 groups per CU
+    // persistent: 8 groups per CU; a short batch in fewer groups of at least four frames each (the tables are staged per group)
+    const int groups = n_frames >= 8192 ? 2048 : (n_frames + 3) / 4;
+    hipLaunchKernelGGL(k_enc_pack, dim3(groups), dim3(256), 0, stream,
                        d_ix, d_gr, d_en, n_frames, sri, bri, whole_slots,
                        d_frame_off, d_padding, d_mp3, d_scfsi, d_status, d_sync);
     if (prof) prof->end(stream, pp);

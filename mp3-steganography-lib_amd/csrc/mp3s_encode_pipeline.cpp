@@ -216,7 +216,7 @@ int enc_issue(mp3s_ctx *c, const EncLayout &L, const EncDev &d, hipStream_t tail
     // packed on the assumption that the verdict is "nothing to redo" (the common case); the caller discards it otherwise
     if (!rc) {
         const int e = launch_pack(ts, d.d_ix, d.d_out, d.d_en, L.n, L.sri, L.bri, L.whole, (const uint32_t *)(d.d_in + L.o_off), d.d_in + L.o_pad, d.d_mp3,
-                                  d.d_sc, d.d_small + 2, c->d_sync, &c->prof);
+                                  d.d_sc, d.d_small + 2, d.direct_status ? nullptr : c->d_sync, &c->prof);
         if (e) rc = fail(MP3S_E_HIP, "pack launch: %s", hipGetErrorString((hipError_t)e));
     }
     return rc;

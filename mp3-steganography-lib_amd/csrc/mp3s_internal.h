@@ -274,6 +274,7 @@ struct EncDev {
     void *d_agg = nullptr;               // chain_agg_bytes(n)
     uint8_t *d_mp3 = nullptr; int32_t *d_sc = nullptr;
     int32_t *d_small = nullptr;          // small_bytes(n_segs)
+    bool direct_status = false;          // d_small's status words were zeroed with the job's inputs: the kernels OR into them directly
     // results of the variant entries (L.n_entries of them; read by the selection right behind the rate loop)
     int16_t *d_ixv = nullptr; mp3s_gr_out *d_outv = nullptr; int32_t *d_env = nullptr;
 };

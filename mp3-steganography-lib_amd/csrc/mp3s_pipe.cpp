@@ -83,7 +83,7 @@ struct Job {
     // fast path
     bool walked = false;                 // side info and main data are taken apart on the device (k_dec_parse)
     std::vector<Upload> ups;
-    size_t o_encblk = 0, o_fix = 0, o_refs = 0, o_streams = 0, pack_end = 0;   // packed inputs inside the slot's stage (from its start)
+    size_t o_small = 0, o_encblk = 0, o_fix = 0, o_refs = 0, o_streams = 0, pack_end = 0;   // packed inputs inside the slot's stage (from its start)
     uint32_t image_base = 0, md_base = 0;
     std::vector<uint32_t> stream_first;  // first frame of every stream of the batch
     std::vector<std::vector<uint8_t>> bits, guess;
@@ -117,6 +117,7 @@ struct mp3s_pipe {
     size_t max_job_bytes = 0;
     std::vector<Slot> slots;
     hipStream_t s_up = nullptr, s_down = nullptr;
+    hipStream_t s_comp = nullptr, s_ctx = nullptr;   // a compute stream of the pipe's own (pick_lanes), and the context's while the pipe has put its own in its place
     // The Huffman kernel is a latency chain that leaves the vector units mostly idle; the rate loop is bound by them.  The
     // front end of job k+1 therefore runs on a stream of its own, under the encode half of job k, with two sets of
     // Huffman outputs (is / side records) taken in turn; e_dec[x] = the decode transforms that read set x last are done.
@@ -126,6 +127,7 @@ struct mp3s_pipe {
     hipStream_t s_tail = nullptr;
     int last_tail = -1;                  // slot of the job whose tail was issued last
     bool tail_throttle = false;
+    size_t direct_upload = kDirectUpload;
     hipEvent_t e_dec[2] = {nullptr, nullptr};
     bool dec_used[2] = {false, false};
     unsigned issued = 0;
@@ -133,7 +135,8 @@ struct mp3s_pipe {
     // next job computes: keep_slot[x] = slot of the job whose download reads buffer x last (-1: none)
     int keep_slot[2] = {-1, -1};
     std::mutex mu;                       // queue, job states, slots, statistics
-    std::condition_variable cv_work, cv_done;
+    std::condition_variable cv_work, cv_done, cv_turn;
+    int64_t next_issue = 0;              // ticket of the job whose turn it is to be issued
     std::mutex mu_issue;                 // everything that touches the context (its stream, pool, profiler)
     std::deque<std::unique_ptr<Job>> inflight;   // ticket order; front = next to collect
     // One queue per worker, and a slot always goes to the same worker (slot % workers): the staging of a slot stays in
@@ -279,7 +282,7 @@ bool prepare_walk(mp3s_pipe *P, Job &j, Slot &s)
             j.segs[i].any_silent = w.any_silent ? 1 : 0;
         }
         // the file's bytes: long files go up from where they lie, short ones are laid end to end in page-locked staging first
-        if (len >= kDirectUpload) {
+        if (len >= P->direct_upload) {
             if (run_hi > run_lo) { j.ups.push_back({run_lo, s.h_image + run_lo, run_hi - run_lo}); run_lo = run_hi = 0; }
             j.ups.push_back({img, file, len});
         } else {
@@ -298,17 +301,20 @@ bool prepare_walk(mp3s_pipe *P, Job &j, Slot &s)
     j.L = EncLayout();
     j.max_p23 = max_p23;
     size_t enc_bytes = 0;
+    // pack: [small results, zeroed | encoder inputs | host-decoded frames | refs | streams], one copy up
+    j.o_small = s.o_in;
+    const size_t small_room = (small_bytes(j.decode ? 1 : nf) + 15) & ~(size_t)15;
+    std::memset(s.h_stage + j.o_small, 0, kSmallHead);
+    j.o_encblk = j.o_small + small_room;
     if (j.decode) {
         if (!decode_result(j)) return false;
     } else {
-        if (!encode_inputs(j, s, s.h_stage + s.o_in, s.in_cap, P->c->opt[MP3S_OPT_SELECT] != 0)) return false;
+        if (small_room >= s.in_cap || !encode_inputs(j, s, s.h_stage + j.o_encblk, s.in_cap - small_room, P->c->opt[MP3S_OPT_SELECT] != 0)) return false;
         enc_bytes = j.L.bytes;
         j.res.reset(new mp3s_buf());
         if (!j.res->big[0].reserve(j.L.mp3_bytes) || !j.res->big[2].reserve(small_bytes(j.L.n_segs))) return false;
         j.res->mp3 = j.res->big[0].data();
     }
-    // pack: [encoder inputs | host-decoded frames | refs | streams], one copy up
-    j.o_encblk = s.o_in;
     j.o_fix = (j.o_encblk + enc_bytes + 15) & ~(size_t)15;
     if (j.o_fix != s.o_in + s.in_cap) std::memmove(s.h_stage + j.o_fix, fix, (size_t)j.n_fix * kPlaceEntry);
     j.o_refs = (j.o_fix + (size_t)j.n_fix * kPlaceEntry + 15) & ~(size_t)15;
@@ -336,18 +342,20 @@ bool prepare_chunk(mp3s_pipe *P, Job &j, Slot &s, int max_p23)
     j.ups.push_back({0, k.file + k.image_lo, (size_t)(k.image_hi - k.image_lo)});
     size_t enc_bytes = 0;
     j.L = EncLayout();
+    j.o_small = s.o_in;
+    std::memset(s.h_stage + j.o_small, 0, kSmallHead);
+    j.o_encblk = j.o_small + ((small_bytes(1) + 15) & ~(size_t)15);
     if (!k.decode) {
         EncSeg &sg = j.segs[0];
         sg.n_frames = (int)k.count; sg.hide = k.hide; sg.n_hide = k.n_hide;
         sg.lead = k.lead; sg.first_frame = k.first; sg.last = k.last; sg.carry_in = k.has_carry ? &k.carry_in : nullptr;
         sg.tables_guess = k.tables; sg.n_guess = k.tables ? k.n_tables : -1; sg.any_silent = k.any_silent;
-        if (!encode_inputs(j, s, s.h_stage + s.o_in, s.in_cap, P->c->opt[MP3S_OPT_SELECT] != 0)) return false;
+        if (!encode_inputs(j, s, s.h_stage + j.o_encblk, s.in_cap - (j.o_encblk - s.o_in), P->c->opt[MP3S_OPT_SELECT] != 0)) return false;
         enc_bytes = j.L.bytes;
     }
     j.res.reset(new mp3s_buf());
     if (!j.res->big[2].reserve(small_bytes(1))) return false;
     if (k.decode && !j.res->big[1].reserve((size_t)k.n_win * 8 + 16)) return false;
-    j.o_encblk = s.o_in;
     j.o_fix = (j.o_encblk + enc_bytes + 15) & ~(size_t)15;
     if (k.fix) {
         if (s.fix_cap < 1) return false;
@@ -459,6 +467,7 @@ bool prepare_fast(mp3s_pipe *P, Job &j, Slot &s, ParsedStream &p, size_t *blob_l
 int issue_fast(mp3s_pipe *P, Job &j, Slot &s, size_t blob_len, int max_p23)
 {
     mp3s_ctx *c = P->c;
+    const double t_issue0 = trace_on() ? now_ms() : 0;
     const EncLayout &L = j.L;
     const Chunk &ck = j.ck;
     const int n = j.n_total, nch = j.decode ? j.nch : 2;
@@ -473,7 +482,7 @@ int issue_fast(mp3s_pipe *P, Job &j, Slot &s, size_t blob_len, int max_p23)
     HIPCHK(hipEventRecord(s.e_start, P->s_up));
     if (j.walked) {
         for (const Upload &u : j.ups) HIPCHK(hipMemcpyAsync(s.d_image + u.dst, u.src, u.bytes, hipMemcpyHostToDevice, P->s_up));
-        HIPCHK(hipMemcpyAsync(s.d_stage + j.o_encblk, s.h_stage + j.o_encblk, j.pack_end - j.o_encblk, hipMemcpyHostToDevice, P->s_up));
+        HIPCHK(hipMemcpyAsync(s.d_stage + j.o_small, s.h_stage + j.o_small, j.pack_end - j.o_small, hipMemcpyHostToDevice, P->s_up));
         d_dechdr = (const mp3s_frame_hdr *)(s.d_stage + s.o_dechdr);
     } else {
         const size_t o_enc = j.o_encblk - s.o_in, in_bytes = j.decode ? ((size_t)n * sizeof(mp3s_frame_hdr) + 15) & ~(size_t)15 : o_enc + L.bytes;
@@ -484,17 +493,20 @@ int issue_fast(mp3s_pipe *P, Job &j, Slot &s, size_t blob_len, int max_p23)
         d_dechdr = (const mp3s_frame_hdr *)(s.d_stage + s.o_in);
     }
     HIPCHK(hipEventRecord(s.e_up, P->s_up));
+    if (trace_on()) fprintf(stderr, "mp3s:   uploads queued %.3f ms after the job's start\n", now_ms() - t_issue0);
     HIPCHK(hipStreamWaitEvent(P->s_huff, s.e_up, 0));
     if (P->dec_used[set]) HIPCHK(hipStreamWaitEvent(P->s_huff, P->e_dec[set], 0));
-    HIPCHK(hipMemsetAsync(s.d_small + 4, 0, 4, P->s_huff));
+    // the small results: a walked job brings its block, status words zeroed, with its inputs (the kernels OR into them directly);
+    // a scanned one uses the slot's, written by the last workgroup of each kernel
+    int32_t *const d_small = j.walked ? (int32_t *)(s.d_stage + j.o_small) : s.d_small;
     if (j.walked) {
         uint64_t *d_tsel = j.decode ? (uint64_t *)(s.d_stage + s.o_tsel) : nullptr;
         const int e = launch_parse(P->s_huff, s.d_image, j.image_base, (const FrameRef *)(s.d_stage + j.o_refs), (const StreamRef *)(s.d_stage + j.o_streams), n,
-                                   j.md_base, (mp3s_frame_side *)d_side, (mp3s_frame_hdr *)(s.d_stage + s.o_dechdr), d_blob, d_tsel, s.d_small + 4);
+                                   j.md_base, (mp3s_frame_side *)d_side, (mp3s_frame_hdr *)(s.d_stage + s.o_dechdr), d_blob, d_tsel, d_small + 4);
         if (e) return fail(MP3S_E_HIP, "parse launch: %s", hipGetErrorString((hipError_t)e));
     }
     const int e = launch_huffman(P->s_huff, d_blob, (const mp3s_frame_side *)d_side, n, nch, max_p23, (int16_t *)d_is, (mp3s_granule_si *)d_si,
-                                 s.d_small + 3, c->d_sync + 4, &c->prof, false);
+                                 d_small + 3, j.walked ? nullptr : c->d_sync + 4, &c->prof, false);
     if (e) return fail(MP3S_E_HIP, "huffman launch: %s", hipGetErrorString((hipError_t)e));
     if (launch_place_frames(P->s_huff, s.d_stage + j.o_fix, j.n_fix, (int16_t *)d_is, (mp3s_granule_si *)d_si))
         return fail(MP3S_E_HIP, "placing the host-decoded frames failed");
@@ -521,7 +533,7 @@ int issue_fast(mp3s_pipe *P, Job &j, Slot &s, size_t blob_len, int max_p23)
     if (j.decode) {
         HIPCHK(hipEventRecord(s.e_comp, c->stream));
         HIPCHK(hipStreamWaitEvent(P->s_down, s.e_comp, 0));
-        HIPCHK(hipMemcpyAsync(j.res->big[2].data(), s.d_small, kSmallHead, hipMemcpyDeviceToHost, P->s_down));
+        HIPCHK(hipMemcpyAsync(j.res->big[2].data(), d_small, kSmallHead, hipMemcpyDeviceToHost, P->s_down));
         if (j.walked) HIPCHK(hipMemcpyAsync(j.res->big[1].data(), s.d_stage + s.o_tsel, (size_t)n * 8, hipMemcpyDeviceToHost, P->s_down));
         if (ck.on) {
             HIPCHK(hipMemcpyAsync(ck.dst, d_keep, (size_t)ck.count * frame_elems * esz, hipMemcpyDeviceToHost, P->s_down));
@@ -552,7 +564,7 @@ int issue_fast(mp3s_pipe *P, Job &j, Slot &s, size_t blob_len, int max_p23)
     dev.d_pcm = (const int16_t *)d_keep; dev.d_in = s.d_stage + j.o_encblk; dev.d_mdct_all = (int32_t *)s.d_enc; dev.d_ix = (int16_t *)(s.d_enc + b_mdct);
     dev.d_out = (mp3s_gr_out *)(s.d_enc + b_mdct + b_ix); dev.d_en = (int32_t *)(s.d_enc + b_mdct + b_ix + b_out); dev.d_agg = d_agg;
     dev.d_mp3 = s.d_mp3; dev.d_sc = (int32_t *)(s.d_enc + b_mdct + b_ix + b_out + b_en);
-    dev.d_small = s.d_small;
+    dev.d_small = d_small; dev.direct_status = j.walked;
     if (!enc_variant_buffers(c, L, dev)) return fail(MP3S_E_NOMEM, "hipMalloc failed for %d variant entries", L.n_entries);
     const int rc = enc_issue(c, L, dev, P->s_tail, s.e_rate, P->s_tail && P->last_tail >= 0 && P->tail_throttle ? P->slots[(size_t)P->last_tail].e_comp : nullptr);
     if (rc) return rc;
@@ -560,7 +572,7 @@ int issue_fast(mp3s_pipe *P, Job &j, Slot &s, size_t blob_len, int max_p23)
     P->last_tail = (int)(&s - P->slots.data());
     HIPCHK(hipStreamWaitEvent(P->s_down, s.e_comp, 0));
     const size_t total = j.segs.back().mp3_off + j.segs.back().mp3_len;
-    HIPCHK(hipMemcpyAsync(j.res->big[2].data(), s.d_small, small_bytes(L.n_segs), hipMemcpyDeviceToHost, P->s_down));
+    HIPCHK(hipMemcpyAsync(j.res->big[2].data(), d_small, small_bytes(L.n_segs), hipMemcpyDeviceToHost, P->s_down));
     if (total) HIPCHK(hipMemcpyAsync(ck.on ? ck.dst : j.res->mp3, s.d_mp3, total, hipMemcpyDeviceToHost, P->s_down));
     HIPCHK(hipEventRecord(s.e_down, P->s_down));
     return MP3S_OK;
@@ -644,6 +656,13 @@ void worker(mp3s_pipe *P, int me)
         if (trace_on()) fprintf(stderr, "mp3s: pipe job %lld slot %d on cpu %d: %s + layout %.3f ms (cpu %.3f)%s\n", (long long)j->ticket, j->slot, sched_getcpu(), j->walked ? "walk" : "scan", t1 - t0, c1 - c0, fast ? "" : " -> synchronous path");
         Job::State st;
         {
+            // Jobs go to the device in the order they were submitted: the streams are queues and results are collected in
+            // ticket order, so a job that overtakes the one in front of it makes that one's collector wait a whole job longer
+            // (two workers on four slots: 1.36 instead of 0.82 ms per batch).  Walks and scans still run side by side.
+            std::unique_lock<std::mutex> g(P->mu);
+            P->cv_turn.wait(g, [&] { return P->next_issue == j->ticket; });
+        }
+        {
             std::lock_guard<std::mutex> gi(P->mu_issue);
             if (fast && issue_fast(P, *j, s, blob_len, max_p23) != MP3S_OK) {
                 sync_all(P);
@@ -655,10 +674,12 @@ void worker(mp3s_pipe *P, int me)
         const double t2 = now_ms();
         {
             std::lock_guard<std::mutex> g(P->mu);
-            j->scan_ms = t1 - t0; j->issue_ms = t2 - t1;
+            j->scan_ms = t1 - t0; j->issue_ms = t2 - t1;   // (with the wait for its turn)
             j->state = st;
+            P->next_issue = j->ticket + 1;
             P->st.scan_ms += t1 - t0; P->st.issue_ms += t2 - t1; P->st.scan_cpu_ms += c1 - c0;
         }
+        P->cv_turn.notify_all();
         P->cv_done.notify_all();
     }
 }
@@ -676,6 +697,96 @@ void free_slot(Slot &s)
     s = Slot();
 }
 
+// Candidate streams of a device, made once per process: four of the highest priority (copies) and four of the lowest (the
+// front end: its workgroups fill in beside the compute stream's instead of competing with them).  The runtime multiplexes
+// streams onto a few hardware queues; which queue a stream gets depends on everything the process has created before it
+// (round 2 believed priorities chose the set of queues; a context's own pipe in front of a user's pipe showed otherwise:
+// 0.97 - 1.25 instead of 0.81 ms per batch, tools/pipe_queue_probe.py; the first of three contexts ran its one-file calls at
+// half speed, tools/bench_queue_probe4.py), and a pipeline whose streams share queues with its compute stream loses its
+// overlap -- every kernel of it takes longer, not only the ones that wait.  The runtime does not tell which stream sits
+// where, and a spin kernel beside an empty one or beside a small copy does not show it either (all eight candidates passed
+// that test on a context that then ran at half speed).  So the pipe REHEARSES: four miniature jobs -- a copy up, a spin on
+// the front-end stream, two spins on the compute stream, a copy down, chained by events exactly as issue_fast chains a
+// job's stages -- through each rotation of the candidates, and keeps the rotation that got them through fastest
+// (about 1 ms per rotation when a pipe is made).
+struct LanePool {
+    hipStream_t hi[4] = {nullptr, nullptr, nullptr, nullptr}, lo[4] = {nullptr, nullptr, nullptr, nullptr}, cs[4] = {nullptr, nullptr, nullptr, nullptr};
+    hipEvent_t ev[4][4] = {};
+    hipEvent_t t0 = nullptr, t1 = nullptr;
+    uint8_t *d_buf = nullptr, *h_buf = nullptr;
+    bool ok = false;
+};
+constexpr size_t kRehearseBytes = (size_t)256 << 10;
+
+float rehearse(LanePool &lp, hipStream_t comp, hipStream_t up, hipStream_t down, hipStream_t huff)
+{
+    float ms = 1e9f;
+    bool ok = hipEventRecord(lp.t0, up) == hipSuccess;
+    for (int k = 0; k < 4 && ok; k++) {
+        ok = hipMemcpyAsync(lp.d_buf + k * kRehearseBytes, lp.h_buf + k * kRehearseBytes, kRehearseBytes, hipMemcpyHostToDevice, up) == hipSuccess &&
+             hipEventRecord(lp.ev[k][0], up) == hipSuccess && hipStreamWaitEvent(huff, lp.ev[k][0], 0) == hipSuccess && launch_spin(huff, 60) == 0 &&
+             hipEventRecord(lp.ev[k][1], huff) == hipSuccess && hipStreamWaitEvent(comp, lp.ev[k][1], 0) == hipSuccess && launch_spin(comp, 50) == 0 &&
+             launch_spin(comp, 50) == 0 && launch_noop(comp) == 0 && hipEventRecord(lp.ev[k][2], comp) == hipSuccess && hipStreamWaitEvent(down, lp.ev[k][2], 0) == hipSuccess &&
+             hipMemcpyAsync(lp.h_buf + (4 + k) * kRehearseBytes, lp.d_buf + k * kRehearseBytes, kRehearseBytes, hipMemcpyDeviceToHost, down) == hipSuccess &&
+             hipEventRecord(lp.ev[k][3], down) == hipSuccess;
+    }
+    ok = ok && hipEventRecord(lp.t1, down) == hipSuccess;
+    (void)hipStreamSynchronize(up); (void)hipStreamSynchronize(huff); (void)hipStreamSynchronize(comp); (void)hipStreamSynchronize(down);
+    if (!ok || hipEventElapsedTime(&ms, lp.t0, lp.t1) != hipSuccess) return 1e9f;
+    return ms;
+}
+
+int pick_lanes(mp3s_ctx *c, hipStream_t *up, hipStream_t *down, hipStream_t *huff, hipStream_t *comp /* a stream to compute on instead of the context's, or null */)
+{
+    static std::mutex mu;
+    static std::vector<LanePool> pools;
+    std::lock_guard<std::mutex> g(mu);
+    if ((size_t)c->device >= pools.size()) pools.resize((size_t)c->device + 1);
+    LanePool &lp = pools[(size_t)c->device];
+    if (!lp.ok) {
+        int prio_low = 0, prio_high = 0;
+        (void)hipDeviceGetStreamPriorityRange(&prio_low, &prio_high);
+        const char *hp = getenv("MP3S_PIPE_HUFF_PRIO");
+        const int huff_prio = hp ? atoi(hp) : prio_low;
+        bool ok = hipEventCreate(&lp.t0) == hipSuccess && hipEventCreate(&lp.t1) == hipSuccess && hipMalloc((void **)&lp.d_buf, 4 * kRehearseBytes) == hipSuccess &&
+                  hipHostMalloc((void **)&lp.h_buf, 8 * kRehearseBytes, hipHostMallocDefault) == hipSuccess;
+        for (int k = 0; k < 4 && ok; k++)
+            for (int q = 0; q < 4 && ok; q++) ok = hipEventCreateWithFlags(&lp.ev[k][q], hipEventDisableTiming) == hipSuccess;
+        for (int i = 0; i < 4 && ok; i++) ok = hipStreamCreateWithPriority(&lp.hi[i], hipStreamNonBlocking, prio_high) == hipSuccess;
+        for (int i = 0; i < 4 && ok; i++) ok = hipStreamCreateWithPriority(&lp.lo[i], hipStreamNonBlocking, huff_prio) == hipSuccess;
+        for (int i = 0; i < 4 && ok; i++) ok = hipStreamCreateWithFlags(&lp.cs[i], hipStreamNonBlocking) == hipSuccess;
+        if (!ok) return 1;   // (what was created stays with the process)
+        std::memset(lp.h_buf, 0, 8 * kRehearseBytes);
+        lp.ok = true;
+    }
+    (void)hipStreamSynchronize(c->stream);
+    (void)rehearse(lp, c->stream, lp.hi[0], lp.hi[1], lp.lo[0]);      // (first launches: not a measurement)
+    // the context's own stream with every rotation of the lanes; if none of them gets the rehearsal through as fast as a
+    // pipeline without shared queues does, the compute candidates too (the pipe then computes on one of those)
+    int best = 0, best_cs = -1;
+    float best_ms = 1e9f;
+    std::string seen;
+    auto tryout = [&](int ci, int r) {
+        hipStream_t comp_s = ci < 0 ? c->stream : lp.cs[ci];
+        const float ms = std::min(rehearse(lp, comp_s, lp.hi[r], lp.hi[(r + 1) & 3], lp.lo[r]), rehearse(lp, comp_s, lp.hi[r], lp.hi[(r + 1) & 3], lp.lo[r]));
+        if (trace_on()) { char b[32]; snprintf(b, sizeof b, " %.3f", ms); seen += b; }
+        if (ms < best_ms * 0.97f) { best_ms = ms; best = r; best_cs = ci; }
+    };
+    for (int r = 0; r < 4; r++) tryout(-1, r);
+    const float own_ms = best_ms;
+    const int own_best = best;
+    if (comp && best_ms > 0.64f)          // (4 x (60 + 2 x 50) us of spinning never take less than 0.58 ms: this one lost its overlap somewhere)
+        for (int ci = 0; ci < 4 && best_ms > 0.62f; ci++) {
+            if (trace_on()) seen += " |";
+            for (int r = 0; r < 4; r++) tryout(ci, r);
+        }
+    if (best_cs >= 0 && best_ms > own_ms * 0.93f) { best_cs = -1; best_ms = own_ms; best = own_best; }   // (not worth leaving the context's stream for)
+    if (trace_on()) fprintf(stderr, "mp3s: pipe lanes rehearsed:%s ms -> compute stream %d, rotation %d (%.3f ms)\n", seen.c_str(), best_cs, best, best_ms);
+    if (comp) *comp = best_cs >= 0 ? lp.cs[best_cs] : nullptr;
+    *up = lp.hi[best]; *down = lp.hi[(best + 1) & 3]; *huff = lp.lo[best];
+    return 0;
+}
+
 int pipe_create(mp3s_ctx *c, int depth, size_t max_job_bytes, int scan_threads, bool internal, mp3s_pipe **out)
 {
     *out = nullptr;
@@ -684,28 +795,13 @@ int pipe_create(mp3s_ctx *c, int depth, size_t max_job_bytes, int scan_threads, 
     P->c = c; P->depth = depth; P->internal = internal; P->max_job_bytes = max_job_bytes;
     auto destroy = [&](int code, const char *what) {
         for (auto &s : P->slots) free_slot(s);
-        if (P->s_up) (void)hipStreamDestroy(P->s_up);
-        if (P->s_down) (void)hipStreamDestroy(P->s_down);
-        if (P->s_huff) (void)hipStreamDestroy(P->s_huff);
-        if (P->s_tail) (void)hipStreamDestroy(P->s_tail);
+        if (P->s_tail) (void)hipStreamDestroy(P->s_tail);   // (the other three belong to the device: pick_lanes)
         for (hipEvent_t e : P->e_dec) if (e) (void)hipEventDestroy(e);
         return fail(code, "%s", what);
     };
-    // The runtime multiplexes streams onto a few hardware queues (round robin, four by default), and work of two streams
-    // that share a queue runs in order: a copy stream that lands on the compute stream's queue stops overlapping with the
-    // kernels (measured: every second pipe of a process, 1.35 instead of 1.10 ms per 10 000-frame batch).  Streams of
-    // another priority come from another set of queues, so the copy streams are created with the highest one.
-    int prio_low = 0, prio_high = 0;
-    (void)hipDeviceGetStreamPriorityRange(&prio_low, &prio_high);
-    if (hipStreamCreateWithPriority(&P->s_up, hipStreamNonBlocking, prio_high) != hipSuccess ||
-        hipStreamCreateWithPriority(&P->s_down, hipStreamNonBlocking, prio_high) != hipSuccess)
-        return destroy(MP3S_E_HIP, "stream creation failed");
-    // the front-end stream takes the lowest priority: another set of queues again, and its workgroups fill in beside the
-    // compute stream's instead of competing with them
-    const char *hp = getenv("MP3S_PIPE_HUFF_PRIO");
-    const int huff_prio = hp ? atoi(hp) : prio_low;
-    if (hipStreamCreateWithPriority(&P->s_huff, hipStreamNonBlocking, huff_prio) != hipSuccess ||
-        hipEventCreateWithFlags(&P->e_dec[0], hipEventDisableTiming) != hipSuccess ||
+    // copy-up, copy-down and front-end streams that run beside this context's compute stream (pick_lanes above)
+    if (pick_lanes(c, &P->s_up, &P->s_down, &P->s_huff, &P->s_comp)) return destroy(MP3S_E_HIP, "stream creation failed");
+    if (hipEventCreateWithFlags(&P->e_dec[0], hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&P->e_dec[1], hipEventDisableTiming) != hipSuccess)
         return destroy(MP3S_E_HIP, "stream creation failed");
     // The tail stream is OFF unless MP3S_OPT_PIPE_TAIL is set.  On a resident batch fed through three contexts the
@@ -716,6 +812,7 @@ int pipe_create(mp3s_ctx *c, int depth, size_t max_job_bytes, int scan_threads, 
     const char *tp = getenv("MP3S_PIPE_TAIL_PRIO");
     const int tail_prio = tp ? atoi(tp) : 0;
     P->tail_throttle = getenv("MP3S_PIPE_TAIL_THROTTLE") != nullptr;
+    if (const char *du = getenv("MP3S_PIPE_DIRECT_UPLOAD")) P->direct_upload = (size_t)atoll(du);
     if (c->opt[MP3S_OPT_PIPE_TAIL] && hipStreamCreateWithPriority(&P->s_tail, hipStreamNonBlocking, tail_prio) != hipSuccess)
         return destroy(MP3S_E_HIP, "stream creation failed");
     // the page-locked staging of the slots is allocated by a thread that runs on the GPU's NUMA node (first touch), and the
@@ -757,6 +854,10 @@ int pipe_create(mp3s_ctx *c, int depth, size_t max_job_bytes, int scan_threads, 
     }
     if (rebind) (void)sched_setaffinity(0, sizeof before, &before);
     if (!ok) return destroy(MP3S_E_NOMEM, "slot allocation failed");
+    if (P->s_comp && !internal) {   // a user's pipe owns its context: the context computes on the pipe's stream until the pipe is gone
+        (void)hipStreamSynchronize(c->stream);
+        P->s_ctx = c->stream; c->stream = P->s_comp;
+    }
     P->todo.resize((size_t)std::max(scan_threads, 1));
     for (int t = 0; t < scan_threads; t++) P->workers.emplace_back(worker, P.get(), t);
     *out = P.release();
@@ -787,9 +888,9 @@ void mp3s_pipe_destroy(mp3s_pipe *P)
     for (auto &t : P->workers) t.join();
     (void)hipSetDevice(P->c->device);
     sync_all(P);
+    if (P->s_ctx) { P->c->stream = P->s_ctx; P->s_ctx = nullptr; }
     for (auto &j : P->inflight) if (j->slow_owner) mp3s_buf_free(j->slow_owner);
     for (auto &s : P->slots) free_slot(s);
-    (void)hipStreamDestroy(P->s_up); (void)hipStreamDestroy(P->s_down); (void)hipStreamDestroy(P->s_huff);
     if (P->s_tail) (void)hipStreamDestroy(P->s_tail);
     for (hipEvent_t e : P->e_dec) (void)hipEventDestroy(e);
     delete P;
@@ -1028,8 +1129,12 @@ int run_file(mp3s_ctx *c, const uint8_t *mp3, size_t len, int mode, const uint8_
     if (chunk > 0) { chunk = std::min(chunk, kMaxChunk); first_chunk = chunk; }
     else if (n_est <= 3000) { chunk = first_chunk = std::min(kMaxChunk, n_est + 16); }                    // one chunk: nothing to overlap with
     else {
-        chunk = std::min<long>(kMaxChunk, std::max<long>(2560, (n_est + 3) / 4));
-        first_chunk = std::min<long>(chunk, std::max<long>(1536, n_est / 8));
+        // m chunks of about a quarter of the file (at least 2 560 frames: below that the kernels' fixed costs show), the first
+        // one half as long, the rest of the file split evenly over the others
+        const long target = std::min<long>(kMaxChunk, std::max<long>(2560, (n_est + 3) / 4));
+        const long m = std::max<long>(2, (n_est + target - 1) / target);
+        first_chunk = std::max<long>(1536, n_est / m / 2);
+        chunk = std::min<long>(kMaxChunk, (n_est - first_chunk + (m - 1) - 1) / (m - 1) + 8);
     }
     first_chunk = std::min(kMaxChunk, std::max(first_chunk, reach_frames));
     const long cap_frames = std::max(chunk, first_chunk) + 2;
@@ -1037,6 +1142,12 @@ int run_file(mp3s_ctx *c, const uint8_t *mp3, size_t len, int mode, const uint8_
     if (reach_frames > kMaxChunk || ensure_own_pipe(c, (size_t)cap_frames * (size_t)(fs0 + 2) + 4096)) { c->run_stats.fallbacks++; return kRunFallback; }
     mp3s_pipe *P = c->own_pipe;
     HIPCHK(hipSetDevice(c->device));
+    // (for the duration of the call the context computes on the stream its pipe rehearsed best with, if that is not its own)
+    struct StreamSwap {
+        mp3s_ctx *c; hipStream_t keep;
+        StreamSwap(mp3s_ctx *c_, hipStream_t s) : c(c_), keep(c_->stream) { if (s) c->stream = s; }
+        ~StreamSwap() { if (c->stream != keep) { (void)hipStreamSynchronize(c->stream); c->stream = keep; } }
+    } swap(c, P->s_comp);
     // ---- the stream's frame table, grown as the walk proceeds
     std::vector<FrameRef> &refs = c->h_refs;
     if ((long)refs.size() < n_est + 64) refs.resize((size_t)n_est + 64);
@@ -1120,12 +1231,15 @@ int run_file(mp3s_ctx *c, const uint8_t *mp3, size_t len, int mode, const uint8_
             if ((size_t)rc.out_off + j.L.mp3_bytes > res_cap) return kRunFallback;
             j.ck.dst = res->big[0].data() + rc.out_off;
         }
+        const double t_i = trace_on() ? now_ms() : 0;
         const int e = issue_fast(P, j, s, 0, w.max_p23);
+        if (trace_on()) fprintf(stderr, "mp3s:   issue_fast %.3f ms\n", now_ms() - t_i);
         return e ? kRunFallback : MP3S_OK;
     };
     // ---- walk and issue, chunk after chunk
     long want = first_chunk;
     for (size_t k = 0; !w.ended; k++) {
+        const double t_walk0 = trace_on() ? now_ms() : 0;
         const long room = (long)refs.size() - n_walked - 8;
         if (room <= 0) return fallback("more frames than the file's first frame size promised");
         want = std::min(want, room);
@@ -1147,10 +1261,12 @@ int run_file(mp3s_ctx *c, const uint8_t *mp3, size_t len, int mode, const uint8_
             have_fix = w.decode_last(reinterpret_cast<int16_t *>(fix + 16), reinterpret_cast<mp3s_granule_si *>(fix + 16 + 4608), &alone) == 0 && alone;
             std::memset(fix, 0, 16);
         }
+        const double t_walk1 = trace_on() ? now_ms() : 0;
         if (k >= (size_t)P->depth) {               // the slot's previous chunk first
             const int r = retire(k - (size_t)P->depth);
             if (r) return r == kRunFallback ? fallback("a chunk needs the synchronous path") : r;
         }
+        const double t_ret = trace_on() ? now_ms() : 0;
         chunks.emplace_back();
         RunChunk &rc = chunks.back();
         rc.first = n_walked; rc.count = got; rc.last = w.ended;
@@ -1158,6 +1274,7 @@ int run_file(mp3s_ctx *c, const uint8_t *mp3, size_t len, int mode, const uint8_
         n_walked += got;
         if (decode && 64 + (size_t)n_walked * 1152 * (size_t)nch * esz > res_cap) return fallback("more frames than the result block holds");
         const int r = issue(k, nullptr);
+        if (trace_on()) fprintf(stderr, "mp3s: run_file chunk %zu (%ld frames): walk %.3f ms, wait for the slot %.3f ms, prepare + issue %.3f ms\n", k, got, t_walk1 - t_walk0, t_ret - t_walk1, now_ms() - t_ret);
         if (r) return r == kRunFallback ? fallback("a chunk does not fit the stages") : r;
         want = chunk;
     }

@@ -178,7 +178,7 @@ SYMBOLS = ["mp3s_ctx_create", "mp3s_ctx_destroy", "mp3s_ctx_wait", "mp3s_last_er
            "mp3s_hide_message", "mp3s_clear_file", "mp3s_hide_messages", "mp3s_reencode_block", "mp3s_reveal_message",
            "mp3s_pipe_create", "mp3s_pipe_destroy", "mp3s_pipe_submit", "mp3s_pipe_submit_decode", "mp3s_pipe_collect", "mp3s_pipe_get_stats",
            "mp3s_index_stream", "mp3s_index_free", "mp3s_scan_range", "mp3s_decode_block_indexed", "mp3s_reencode_block_indexed",
-           "mp3s_hide_message_chunked", "mp3s_walk_stream", "mp3s_parse_frames_dev", "mp3s_stego_bits", "mp3s_ctx_set_option", "mp3s_ctx_get_option", "mp3s_ctx_run_stats"]
+           "mp3s_hide_message_chunked", "mp3s_walk_stream", "mp3s_parse_frames_dev", "mp3s_stego_bits", "mp3s_ctx_set_option", "mp3s_ctx_get_option", "mp3s_ctx_run_stats", "mp3s_dev_copy"]
 
 _lib = None
 _lock = threading.Lock()
@@ -217,6 +217,7 @@ def lib():
         L.mp3s_dev_upload.argtypes = [vp, vp, vp, sz]
         L.mp3s_dev_download.argtypes = [vp, vp, vp, sz]
         L.mp3s_dev_memset.argtypes = [vp, vp, i32, sz]
+        L.mp3s_dev_copy.argtypes = [vp, vp, vp, sz]
         L.mp3s_timer_start.argtypes = [vp]
         L.mp3s_timer_stop.argtypes = [vp, C.POINTER(C.c_float)]
         L.mp3s_bench_copy.argtypes = [vp, sz, i32, C.POINTER(C.c_double)]
