@@ -676,6 +676,16 @@ int mp3s_pipe_submit_decode(mp3s_pipe *pipe, const uint8_t *const *mp3s, const s
  * (max_files = room in both arrays), *n_files = files of that job.  MP3S_E_BUSY: nothing in flight. */
 int mp3s_pipe_collect(mp3s_pipe *pipe, int64_t *ticket, mp3s_buf **owner, mp3s_file *out, int32_t *status, int max_files,
                       int *n_files);
+/* a block job: the share of rank `rank` of `world` in hiding a message in (utf8 != NULL) or clearing ONE stream -- the
+ * arguments and the result of mp3s_reencode_block (carry_in NULL for rank 0; the carry is copied at submission) -- through
+ * the overlapped stages beside the other jobs, so that the blocks a rank holds of streams that straddle its boundaries do
+ * not interrupt the flow of the whole streams in front of and behind them (BASELINE configs[3]).  The result comes through
+ * mp3s_pipe_collect_block when the job is the oldest in flight (mp3s_pipe_collect refuses a block job with MP3S_E_ARG). */
+int mp3s_pipe_submit_block(mp3s_pipe *pipe, const uint8_t *mp3, size_t len, const uint8_t *utf8, size_t n_msg, int rank, int world,
+                           const mp3s_carry *carry_in, int64_t *ticket);
+int mp3s_pipe_collect_block(mp3s_pipe *pipe, int64_t *ticket, mp3s_buf **owner, mp3s_block *out);
+/* 1: the oldest job in flight is a block job (collect it with mp3s_pipe_collect_block), 0: another job, MP3S_E_BUSY: none */
+int mp3s_pipe_next_is_block(mp3s_pipe *pipe);
 int mp3s_pipe_get_stats(mp3s_pipe *pipe, mp3s_pipe_stats *out);
 
 #ifdef __cplusplus

@@ -106,6 +106,14 @@ struct Job {
     std::vector<uint8_t> res_bits;
     int nch = 2, n_total = 0, max_p23 = 0;
     Chunk ck;
+    // block jobs (mp3s_pipe_submit_block): one rank's share of a stream
+    bool block = false;
+    int rank = 0, world = 1;
+    bool has_carry = false; mp3s_carry carry = {};
+    std::vector<FrameRef> refs;          // the stream's frames as walked (ck.refs points here)
+    std::vector<uint8_t> fix;            // its last frame decoded on the host (kPlaceEntry bytes), if that is needed
+    mp3s_block blk = {};                 // what the caller gets
+    mp3s_buf *blk_owner = nullptr;       // ... from the synchronous path
 };
 
 }  // namespace
@@ -379,6 +387,57 @@ bool prepare_chunk(mp3s_pipe *P, Job &j, Slot &s, int max_p23)
     return true;
 }
 
+// ---- a block job: walk the stream, cut out the rank's share (as mp3s_reencode_block cuts it), and queue it as a chunk
+bool prepare_block(mp3s_pipe *P, Job &j, Slot &s)
+{
+    const uint8_t *file = j.files[0].first;
+    const size_t len = j.files[0].second;
+    if (!file || len > 0xffff0000ull) return false;
+    FrameWalker w;
+    if (w.open(file, len) || w.ended) return false;
+    j.refs.resize(len / 24 + 16);
+    j.bits.assign(1, {});
+    if (j.msgs[0].first) {
+        message_frame(j.msgs[0].first, j.msgs[0].second, j.bits[0]);
+        if (j.bits[0].size() > 0x3fffff00) return false;
+    }
+    long n = 0;
+    while (!w.ended && !w.irregular && (size_t)n < j.refs.size()) n += w.next(j.refs.data() + n, (long)j.refs.size() - n, nullptr, 0, 0);
+    if (w.irregular || !w.ended || n <= 0 || w.dup_last) return false;
+    int kbps = 0;
+    if (reencode_params(w.sampling_rate, w.bit_rate, w.nch, n, 0, &kbps)) return false;
+    const long base = n / j.world, rem = n % j.world;
+    const long first = j.rank * base + std::min<long>(j.rank, rem), count = base + (j.rank < rem ? 1 : 0);
+    std::memset(&j.blk, 0, sizeof j.blk);
+    j.blk.total_frames = n; j.blk.first_frame = first; j.blk.n_frames = count; j.blk.is_last = first + count == n;
+    j.blk.file.kbps = kbps; j.blk.file.sampling_rate = w.sampling_rate; j.blk.file.channels = 2;
+    if (count <= 0 || count > kDecodeChunk - 2) return false;    // (an empty share, or one longer than a transform group: the synchronous path)
+    if ((first == 0) != !j.has_carry) return false;
+    Chunk &k = j.ck;
+    k = Chunk();
+    k.on = true; k.decode = false; k.refs = j.refs.data(); k.first = first; k.count = count; k.last = j.blk.is_last != 0;
+    k.lead = first > 0 ? 1 : 0; k.halo = first - k.lead > 0 ? 1 : 0;
+    k.w0 = first - k.lead - k.halo; k.n_win = count + k.lead + k.halo;
+    k.file = file; k.file_len = len; k.rate = w.sampling_rate; k.kbps = kbps; k.nch = 2;
+    const uint32_t lo = j.refs[(size_t)k.w0].file_off;
+    k.image_lo = first == 0 ? 0 : (lo > kImageLead ? lo - kImageLead : 0);
+    const FrameRef &lr = j.refs[(size_t)(first + count - 1)];
+    k.image_hi = (uint32_t)std::min<uint64_t>(len, (uint64_t)lr.file_off + lr.frame_size + 64);
+    if (k.last) {
+        j.fix.assign(kPlaceEntry, 0);
+        bool alone = false;
+        if (w.decode_last(reinterpret_cast<int16_t *>(j.fix.data() + 16), reinterpret_cast<mp3s_granule_si *>(j.fix.data() + 16 + 4608), &alone) == 0 && alone) k.fix = j.fix.data();
+    }
+    k.hide = j.bits[0].data(); k.n_hide = (int)j.bits[0].size();
+    k.has_carry = j.has_carry; k.carry_in = j.carry;
+    k.any_silent = w.any_silent ? 1 : 0;
+    if (!prepare_chunk(P, j, s, w.max_p23)) return false;
+    if (!j.res->big[0].reserve(j.L.mp3_bytes + 16)) return false;
+    j.res->mp3 = j.res->big[0].data();
+    j.ck.dst = j.res->mp3;
+    return true;
+}
+
 // scan the job's files into the slot's staging (round 2's byte-level scan) and lay out the encoder's inputs; false = this
 // job takes the synchronous path
 bool prepare_fast(mp3s_pipe *P, Job &j, Slot &s, ParsedStream &p, size_t *blob_len, int *max_p23)
@@ -603,7 +662,10 @@ void run_slow(mp3s_pipe *P, Job &j)   // mu_issue held
     // (the context's own pipe is not entered from here: this pipe owns the context)
     const int64_t keep = P->c->opt[MP3S_OPT_FILE_PIPELINE];
     P->c->opt[MP3S_OPT_FILE_PIPELINE] = 0;
-    if (j.decode) {
+    if (j.block) {
+        j.slow_rc = mp3s_reencode_block(P->c, fp[0], fl[0], mp[0], ml[0], j.rank, j.world, j.has_carry ? &j.carry : nullptr, &j.blk_owner, &j.blk);
+        j.slow_err = mp3s_last_error();
+    } else if (j.decode) {
         // file by file through mp3s_decode_file; the owners travel in one
         std::unique_ptr<mp3s_buf> top(new mp3s_buf());
         for (int i = 0; i < nf; i++) {
@@ -649,9 +711,15 @@ void worker(mp3s_pipe *P, int me)
         const double t0 = now_ms(), c0 = thread_cpu_ms();
         size_t blob_len = 0;
         int max_p23 = 0;
-        bool fast = P->c->opt[MP3S_OPT_DEVICE_PARSE] && prepare_walk(P, *j, s);
-        if (fast) max_p23 = j->max_p23;
-        else fast = prepare_fast(P, *j, s, scratch, &blob_len, &max_p23);
+        bool fast;
+        if (j->block) {
+            fast = P->c->opt[MP3S_OPT_DEVICE_PARSE] && prepare_block(P, *j, s);
+            max_p23 = j->max_p23;
+        } else {
+            fast = P->c->opt[MP3S_OPT_DEVICE_PARSE] && prepare_walk(P, *j, s);
+            if (fast) max_p23 = j->max_p23;
+            else fast = prepare_fast(P, *j, s, scratch, &blob_len, &max_p23);
+        }
         const double t1 = now_ms(), c1 = thread_cpu_ms();
         if (trace_on()) fprintf(stderr, "mp3s: pipe job %lld slot %d on cpu %d: %s + layout %.3f ms (cpu %.3f)%s\n", (long long)j->ticket, j->slot, sched_getcpu(), j->walked ? "walk" : "scan", t1 - t0, c1 - c0, fast ? "" : " -> synchronous path");
         Job::State st;
@@ -889,7 +957,7 @@ void mp3s_pipe_destroy(mp3s_pipe *P)
     (void)hipSetDevice(P->c->device);
     sync_all(P);
     if (P->s_ctx) { P->c->stream = P->s_ctx; P->s_ctx = nullptr; }
-    for (auto &j : P->inflight) if (j->slow_owner) mp3s_buf_free(j->slow_owner);
+    for (auto &j : P->inflight) { if (j->slow_owner) mp3s_buf_free(j->slow_owner); if (j->blk_owner) mp3s_buf_free(j->blk_owner); }
     for (auto &s : P->slots) free_slot(s);
     if (P->s_tail) (void)hipStreamDestroy(P->s_tail);
     for (hipEvent_t e : P->e_dec) (void)hipEventDestroy(e);
@@ -974,6 +1042,7 @@ int mp3s_pipe_collect(mp3s_pipe *P, int64_t *ticket, mp3s_buf **owner, mp3s_file
         if (ticket) *ticket = j->ticket;   // (also when the call fails: the caller learns which job it is stuck on)
         if (n_files) *n_files = (int)j->files.size();
         if ((int)j->files.size() > max_files) return fail(MP3S_E_ARG, "the next job has %zu files, room for %d", j->files.size(), max_files);
+        if (j->block) return fail(MP3S_E_ARG, "the next job is a block job: mp3s_pipe_collect_block");
         P->cv_done.wait(g, [&] { return j->state != Job::QUEUED; });
     }
     Slot &s = P->slots[(size_t)j->slot];
@@ -1044,6 +1113,85 @@ int mp3s_pipe_collect(mp3s_pipe *P, int64_t *ticket, mp3s_buf **owner, mp3s_file
         std::lock_guard<std::mutex> g(P->mu);
         P->st.collected++;
         if (span_ms >= 0) P->st.last_device_span_ms = span_ms;
+        if (fast_ok) P->st.fast++; else if (resolved) P->st.resolved++; else P->st.slow++;
+        s.busy = false;
+        P->inflight.pop_front();
+    }
+    return rc;
+}
+
+int mp3s_pipe_submit_block(mp3s_pipe *P, const uint8_t *mp3, size_t len, const uint8_t *utf8, size_t n_msg, int rank, int world,
+                           const mp3s_carry *carry_in, int64_t *ticket)
+{
+    if (!P || P->internal || !mp3 || world <= 0 || rank < 0 || rank >= world || (rank == 0 && carry_in) || (rank > 0 && !carry_in) || (!utf8 && n_msg))
+        return fail(MP3S_E_ARG, "bad argument (rank 0 has no carry, every other rank has one)");
+    std::unique_ptr<Job> j(new Job());
+    j->block = true; j->rank = rank; j->world = world;
+    j->files.assign(1, {mp3, len}); j->msgs.assign(1, {utf8, n_msg});
+    j->clear_all = utf8 == nullptr;
+    if (carry_in) { j->has_carry = true; j->carry = *carry_in; }
+    return submit_job(P, std::move(j), ticket);
+}
+
+int mp3s_pipe_next_is_block(mp3s_pipe *P)
+{
+    if (!P) return fail(MP3S_E_ARG, "null pointer");
+    std::lock_guard<std::mutex> g(P->mu);
+    if (P->inflight.empty()) return fail(MP3S_E_BUSY, "nothing in flight");
+    return P->inflight.front()->block ? 1 : 0;
+}
+
+int mp3s_pipe_collect_block(mp3s_pipe *P, int64_t *ticket, mp3s_buf **owner, mp3s_block *out)
+{
+    if (!P || P->internal || !owner || !out) return fail(MP3S_E_ARG, "null pointer");
+    Job *j = nullptr;
+    {
+        std::unique_lock<std::mutex> g(P->mu);
+        if (P->inflight.empty()) return fail(MP3S_E_BUSY, "nothing in flight");
+        j = P->inflight.front().get();
+        if (ticket) *ticket = j->ticket;
+        if (!j->block) return fail(MP3S_E_ARG, "the next job is not a block job: mp3s_pipe_collect");
+        P->cv_done.wait(g, [&] { return j->state != Job::QUEUED; });
+    }
+    Slot &s = P->slots[(size_t)j->slot];
+    int rc = MP3S_OK;
+    bool fast_ok = false, resolved = false;
+    if (j->state == Job::ISSUED) {
+        (void)hipSetDevice(P->c->device);
+        if (hipEventSynchronize(s.e_down) != hipSuccess) rc = fail(MP3S_E_HIP, "waiting for the job's results failed");
+        else {
+            std::lock_guard<std::mutex> gi(P->mu_issue);
+            fast_ok = finish_fast(P, j, s, &resolved);
+            const int32_t *small = (const int32_t *)j->res->big[2].data();
+            // (a share of a stream that inherits scalefactors across frames cannot look back on the device)
+            if ((fast_ok || resolved) && (small[4] & kParseInherits) && j->world > 1) fast_ok = resolved = false;
+            if (!fast_ok && !resolved) run_slow(P, *j);
+        }
+    }
+    if (!rc) {
+        if (fast_ok || resolved) {
+            const EncSeg &sg = j->segs[0];
+            const mp3s_chain_seg_out *so = (const mp3s_chain_seg_out *)(j->res->big[2].data() + kSmallHead);
+            if (resolved) { j->blk.carry_out = sg.carry_out; j->blk.carry_used = sg.carry_used ? 1 : 0; }
+            else {
+                j->blk.carry_out.cursor = so[0].cursor - sg.hide_base;
+                std::memcpy(j->blk.carry_out.chain, so[0].chain, sizeof j->blk.carry_out.chain);
+                j->blk.carry_used = so[0].carry_used != 0;
+            }
+            j->blk.file.data = j->res->mp3 + sg.mp3_off; j->blk.file.len = sg.mp3_len; j->blk.file.n_frames = (int32_t)j->blk.n_frames;
+            j->blk.file.hide_offset = j->blk.carry_out.cursor;
+            j->blk.file.too_long = j->blk.file.hide_offset < (int64_t)sg.n_hide - 1 ? 1 : 0;
+            *out = j->blk;
+            *owner = j->res.release();
+        } else {
+            rc = j->slow_rc;
+            if (rc) fail(rc, "%s", j->slow_err.c_str());
+            else { *out = j->blk; *owner = j->blk_owner; j->blk_owner = nullptr; }
+        }
+    }
+    {
+        std::lock_guard<std::mutex> g(P->mu);
+        P->st.collected++;
         if (fast_ok) P->st.fast++; else if (resolved) P->st.resolved++; else P->st.slow++;
         s.busy = false;
         P->inflight.pop_front();

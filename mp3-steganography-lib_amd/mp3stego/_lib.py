@@ -178,7 +178,7 @@ SYMBOLS = ["mp3s_ctx_create", "mp3s_ctx_destroy", "mp3s_ctx_wait", "mp3s_last_er
            "mp3s_hide_message", "mp3s_clear_file", "mp3s_hide_messages", "mp3s_reencode_block", "mp3s_reveal_message",
            "mp3s_pipe_create", "mp3s_pipe_destroy", "mp3s_pipe_submit", "mp3s_pipe_submit_decode", "mp3s_pipe_collect", "mp3s_pipe_get_stats",
            "mp3s_index_stream", "mp3s_index_free", "mp3s_scan_range", "mp3s_decode_block_indexed", "mp3s_reencode_block_indexed",
-           "mp3s_hide_message_chunked", "mp3s_walk_stream", "mp3s_parse_frames_dev", "mp3s_stego_bits", "mp3s_ctx_set_option", "mp3s_ctx_get_option", "mp3s_ctx_run_stats", "mp3s_dev_copy"]
+           "mp3s_hide_message_chunked", "mp3s_walk_stream", "mp3s_parse_frames_dev", "mp3s_stego_bits", "mp3s_ctx_set_option", "mp3s_ctx_get_option", "mp3s_ctx_run_stats", "mp3s_dev_copy", "mp3s_pipe_submit_block", "mp3s_pipe_collect_block", "mp3s_pipe_next_is_block"]
 
 _lib = None
 _lock = threading.Lock()
@@ -282,6 +282,9 @@ def lib():
         L.mp3s_pipe_submit_decode.argtypes = [vp, vp, vp, i32, C.POINTER(C.c_int64)]
         L.mp3s_pipe_collect.argtypes = [vp, C.POINTER(C.c_int64), pvp, vp, vp, i32, C.POINTER(C.c_int32)]
         L.mp3s_pipe_get_stats.argtypes = [vp, C.POINTER(PipeStats)]
+        L.mp3s_pipe_submit_block.argtypes = [vp, vp, sz, vp, sz, i32, i32, C.POINTER(Carry), C.POINTER(C.c_int64)]
+        L.mp3s_pipe_collect_block.argtypes = [vp, C.POINTER(C.c_int64), pvp, C.POINTER(Block)]
+        L.mp3s_pipe_next_is_block.argtypes = [vp]
         _lib = L
     return _lib
 
@@ -756,9 +759,40 @@ class Pipe:
         self._keep[t.value] = (mp3s, bufs, files, lens)
         return t.value
 
+    def submit_block(self, mp3, message, rank, world, carry_in=None):
+        """a block job: rank `rank` of `world`'s share of hide_message (message: str) / clear_file (None) on one stream (the
+        arguments of Context.reencode_block) -> ticket, or None when every slot is taken.  collect() hands out the dict
+        Context.reencode_block returns."""
+        buf = np.frombuffer(mp3, dtype=np.uint8)
+        enc = None if message is None else message.encode("utf-8")
+        mb = None if enc is None else np.frombuffer(enc or b"\0", dtype=np.uint8)
+        cin = Carry.from_array(carry_in) if carry_in is not None else None
+        t = C.c_int64()
+        rc = lib().mp3s_pipe_submit_block(self.handle, buf.ctypes.data, len(mp3), None if mb is None else mb.ctypes.data, 0 if enc is None else len(enc),
+                                          int(rank), int(world), C.byref(cin) if cin is not None else None, C.byref(t))
+        if rc == E_BUSY:
+            return None
+        check(rc)
+        self._keep[t.value] = (mp3, buf, mb)
+        return t.value
+
     def collect(self):
         """-> (ticket, [per file: the dict Context.hide_message returns, or the Mp3sError that file alone would raise]);
-        None when nothing is in flight.  "data" is a read-only view of the library's page-locked result block."""
+        None when nothing is in flight.  "data" is a read-only view of the library's page-locked result block.
+        For a block job: (ticket, the dict Context.reencode_block returns, "mp3" being such a view)."""
+        kind = lib().mp3s_pipe_next_is_block(self.handle)
+        if kind == E_BUSY:
+            return None
+        if kind == 1:
+            t, owner, b = C.c_int64(), C.c_void_p(), Block()
+            rc = lib().mp3s_pipe_collect_block(self.handle, C.byref(t), C.byref(owner), C.byref(b))
+            self._keep.pop(t.value, None)
+            check(rc)
+            own, f = _Owner(owner), b.file
+            return t.value, {"total_frames": b.total_frames, "first_frame": b.first_frame, "n_frames": b.n_frames, "is_last": bool(b.is_last),
+                             "carry_used": bool(b.carry_used), "carry_out": b.carry_out.to_array(),
+                             "mp3": Context._owned_bytes(f.data, f.len, own) if f.len else b"", "kbps": f.kbps, "sampling_rate": f.sampling_rate,
+                             "too_long": bool(f.too_long), "hide_offset": f.hide_offset}
         t, owner, nf = C.c_int64(), C.c_void_p(), C.c_int32()
         rc = lib().mp3s_pipe_collect(self.handle, C.byref(t), C.byref(owner), self._out, self._status, self._cap, C.byref(nf))
         if rc == E_BUSY:

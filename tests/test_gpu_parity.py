@@ -334,3 +334,21 @@ def test_long_messages_take_the_variant_path(ctx, mlib, orc):
         pcm2 = synth_pcm(300, rate=rate, seed=5)
         msg = rng.integers(0, 2, size=2500).astype(np.uint8)
         assert ctx.encode_pcm(pcm2, rate, kbps, msg)["mp3"] == orc.encode(pcm2, rate, kbps, msg)["mp3"], (rate, kbps)
+
+
+@pytest.mark.gpu
+def test_config4_one_million_frames_as_eight_blocks():
+    """BASELINE configs[3] at size: 1 000 000 frames = 100 streams x 10 000 frames cut into 8 contiguous blocks of 125 000
+    frames (the ranks of an 8-GPU node, played one after another on this device; block boundaries inside streams 12, 37, 62,
+    87 pass the 136-byte carry).  Every stream reassembled from the blocks equals mp3s_hide_message on the whole stream, the
+    oracle agrees byte for byte on a 1 % sample (tools/config4.py, a process of its own: it forks workers for the PCM)."""
+    import json
+    import subprocess
+    import sys
+    tool = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "config4.py")
+    r = subprocess.run([sys.executable, tool, "100", "10000", "8"], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-2000:])
+    res = json.loads(r.stdout.strip().splitlines()[-1])
+    assert res["ok"] and res["frames"] == 1000000 and res["streams_equal_to_single_call"] == 100
+    assert res["oracle_sample_streams_equal"] == res["oracle_sample_streams"] == 8 and res["oracle_sample_frames"] >= 10000
+    assert res["pipe"]["slow"] == 0

@@ -302,3 +302,43 @@ def test_pipe_decode_jobs(mlib, golden_dir):
             assert st["fast"] >= 2 * 7, st
     finally:
         ctx.close()
+
+
+@pytest.mark.gpu
+def test_block_jobs_beside_whole_files(ctx, mlib):
+    """mp3s_pipe_submit_block: a rank's share of a stream as a job of the pipe, between jobs of whole files; the result is
+    mp3s_reencode_block's (bytes, carry, carry_used), the halves put together are the one-call file"""
+    from synth_pcm import synth_pcm
+    pcm = synth_pcm(400, seed=91)
+    pcm[190 * 1152:215 * 1152] = 0                           # silence across the middle: the second half looks at its carry
+    mp3 = bytes(ctx.encode_pcm(pcm, 44100, 128, None)["mp3"])
+    other = bytes(ctx.encode_pcm(synth_pcm(150, seed=92), 44100, 128, None)["mp3"])
+    for msg in ("hello block jobs", "z" * 300, None):
+        whole = ctx.clear_file(mp3) if msg is None else ctx.hide_message(mp3, msg)
+        want_other = ctx.hide_message(other, "x")
+        for world in (2, 3):
+            want = []
+            carry = None
+            for r in range(world):
+                want.append(ctx.reencode_block(mp3, msg, r, world, carry))
+                carry = want[-1]["carry_out"]
+            pipe = mlib.Pipe(ctx, depth=3, max_job_bytes=1 << 20, scan_threads=2)
+            try:
+                got, carry = [], None
+                for r in range(world):
+                    assert pipe.submit([other], ["x"]) is not None
+                    assert pipe.submit_block(mp3, msg, r, world, carry) is not None
+                    _t, res = pipe.collect()
+                    assert bytes(res[0]["data"]) == bytes(want_other["data"])
+                    _t, blk = pipe.collect()
+                    assert isinstance(blk, dict) and blk["first_frame"] == want[r]["first_frame"] and blk["n_frames"] == want[r]["n_frames"]
+                    assert bytes(blk["mp3"]) == want[r]["mp3"], (msg and len(msg), world, r)
+                    assert np.array_equal(blk["carry_out"], want[r]["carry_out"]) and blk["is_last"] == want[r]["is_last"]
+                    assert blk["hide_offset"] == want[r]["hide_offset"] and blk["too_long"] == want[r]["too_long"]
+                    got.append(bytes(blk["mp3"]))
+                    carry = blk["carry_out"]
+                st = pipe.stats()
+            finally:
+                pipe.close()
+            assert b"".join(got) == bytes(whole["data"])
+            assert st["slow"] == 0, st
