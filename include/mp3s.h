@@ -145,6 +145,11 @@ int mp3s_debug_scfsi_energies(const int32_t *xr576, int sr_idx, int32_t *en22);
  * record, blob = the stream's blob; is2304 = int16 [2][2][576], si4 = mp3s_granule_si [2][2] */
 int mp3s_debug_parse_scanned_frame(const void *frame_side, const uint8_t *blob, int16_t *is2304, mp3s_granule_si *si4);
 
+/* the host's share of a job of the overlapped stages, alone: the frame walk of `file` over and over for about `seconds`
+ * (the frame table written into one reused buffer, table counts for the first 1 000 code books as a hide job asks for them);
+ * *frames_per_s = what one thread sustains.  No device involved: tools/host_scale_probe.py runs it in N processes side by side. */
+int mp3s_debug_walk_rate(const uint8_t *file, size_t len, double seconds, double *frames_per_s, int64_t *frames_per_pass);
+
 /* device memory owned by the caller through the context (for resident pipelines / benchmarks) */
 int mp3s_dev_alloc(mp3s_ctx *ctx, size_t bytes, void **dptr);
 int mp3s_dev_free(mp3s_ctx *ctx, void *dptr);

@@ -66,6 +66,29 @@ int mp3s_debug_parse_scanned_frame(const void *frame_side, const uint8_t *blob, 
     return rc ? fail(rc, "malformed main data") : MP3S_OK;
 }
 
+int mp3s_debug_walk_rate(const uint8_t *file, size_t len, double seconds, double *frames_per_s, int64_t *frames_per_pass)
+{
+    if (!file || !frames_per_s || seconds <= 0) return fail(MP3S_E_ARG, "bad argument");
+    std::vector<FrameRef> refs(len / 24 + 16);
+    std::vector<uint8_t> tables(refs.size() * 4);
+    const double t0 = now_ms();
+    int64_t frames = 0, per_pass = 0;
+    double t = t0;
+    do {
+        FrameWalker w;
+        if (w.open(file, len)) return fail(MP3S_E_MALFORMED, "malformed or unsupported MP3 stream");
+        w.tables_wanted = 1000;
+        long n = 0;
+        while (!w.ended && !w.irregular && (size_t)n < refs.size()) n += w.next(refs.data() + n, (long)refs.size() - n, tables.data() + (size_t)n * 4, 0, 0);
+        if (w.irregular) return fail(MP3S_E_UNSUPPORTED, "not a stream the walk takes");
+        frames += n; per_pass = n;
+        t = now_ms();
+    } while (t - t0 < seconds * 1e3);
+    *frames_per_s = (double)frames / ((t - t0) * 1e-3);
+    if (frames_per_pass) *frames_per_pass = per_pass;
+    return MP3S_OK;
+}
+
 int mp3s_ctx_create(int device, mp3s_ctx **out)
 {
     if (!out) return fail(MP3S_E_ARG, "out is null");

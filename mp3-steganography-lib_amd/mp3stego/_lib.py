@@ -178,7 +178,7 @@ SYMBOLS = ["mp3s_ctx_create", "mp3s_ctx_destroy", "mp3s_ctx_wait", "mp3s_last_er
            "mp3s_hide_message", "mp3s_clear_file", "mp3s_hide_messages", "mp3s_reencode_block", "mp3s_reveal_message",
            "mp3s_pipe_create", "mp3s_pipe_destroy", "mp3s_pipe_submit", "mp3s_pipe_submit_decode", "mp3s_pipe_collect", "mp3s_pipe_get_stats",
            "mp3s_index_stream", "mp3s_index_free", "mp3s_scan_range", "mp3s_decode_block_indexed", "mp3s_reencode_block_indexed",
-           "mp3s_hide_message_chunked", "mp3s_walk_stream", "mp3s_parse_frames_dev", "mp3s_stego_bits", "mp3s_ctx_set_option", "mp3s_ctx_get_option", "mp3s_ctx_run_stats", "mp3s_dev_copy", "mp3s_pipe_submit_block", "mp3s_pipe_collect_block", "mp3s_pipe_next_is_block"]
+           "mp3s_hide_message_chunked", "mp3s_walk_stream", "mp3s_parse_frames_dev", "mp3s_stego_bits", "mp3s_ctx_set_option", "mp3s_ctx_get_option", "mp3s_ctx_run_stats", "mp3s_dev_copy", "mp3s_pipe_submit_block", "mp3s_pipe_collect_block", "mp3s_pipe_next_is_block", "mp3s_debug_walk_rate"]
 
 _lib = None
 _lock = threading.Lock()
@@ -285,6 +285,7 @@ def lib():
         L.mp3s_pipe_submit_block.argtypes = [vp, vp, sz, vp, sz, i32, i32, C.POINTER(Carry), C.POINTER(C.c_int64)]
         L.mp3s_pipe_collect_block.argtypes = [vp, C.POINTER(C.c_int64), pvp, C.POINTER(Block)]
         L.mp3s_pipe_next_is_block.argtypes = [vp]
+        L.mp3s_debug_walk_rate.argtypes = [vp, sz, C.c_double, C.POINTER(C.c_double), C.POINTER(C.c_int64)]
         _lib = L
     return _lib
 
@@ -974,6 +975,14 @@ def walk_stream(data: bytes):
                 "tables": _view(w.tables, np.uint8, (n, 4))}
     finally:
         lib().mp3s_buf_free(owner)
+
+
+def walk_rate(data: bytes, seconds=1.0):
+    """frames per second one host thread walks `data` at (mp3s_debug_walk_rate: the host's share of a pipe job, no device)"""
+    buf = np.frombuffer(data, dtype=np.uint8)
+    r, n = C.c_double(), C.c_int64()
+    check(lib().mp3s_debug_walk_rate(buf.ctypes.data, len(data), float(seconds), C.byref(r), C.byref(n)))
+    return r.value, n.value
 
 
 def stego_bits(tsel, nch, carry=None):
