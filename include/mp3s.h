@@ -116,7 +116,9 @@ int mp3s_ctx_wait(mp3s_ctx *ctx, mp3s_ctx *other);
                                     * checked and resolved afterwards [MP3S_NO_SELECT=1 -> 0] */
 #define MP3S_OPT_REDO 2            /* 1: the chain check's re-runs on the device (mp3s_chain_redo_dev) [MP3S_NO_REDO=1 -> 0] */
 #define MP3S_OPT_FAST_IMDCT 3      /* 1: int16 decode through the mirrored, fused IMDCT behind the guard [MP3S_FAST_IMDCT=0 -> 0] */
-#define MP3S_OPT_PIPE_TAIL 4       /* 1: a pipe created on this context puts a job's tail on a stream of its own [MP3S_PIPE_TAIL=1] */
+#define MP3S_OPT_PIPE_TAIL 4       /* a pipe created on this context puts a job's tail (selection, chain check, bit packing) on a stream of its own:
+                                    * 0 never, 1 (default) the candidate its rehearsal likes best unless that clearly loses, 2 only if
+                                    * the rehearsal is faster with one [MP3S_PIPE_TAIL] */
 #define MP3S_OPT_CHUNK_FRAMES 5    /* frames per chunk when ONE file goes through the overlapped stages (mp3s_hide_message, mp3s_clear_file,
                                     * mp3s_decode_file, mp3s_decode_stream); 0 = chosen from the file's length [MP3S_CHUNK_FRAMES] */
 #define MP3S_OPT_DEVICE_PARSE 6    /* 1: side info and main-data gather on the device (mp3s_parse_frames_dev) wherever the stream is

@@ -109,7 +109,7 @@ int mp3s_ctx_create(int device, mp3s_ctx **out)
         c->opt[MP3S_OPT_SELECT] = getenv("MP3S_NO_SELECT") ? 0 : 1;
         c->opt[MP3S_OPT_REDO] = getenv("MP3S_NO_REDO") ? 0 : 1;
         c->opt[MP3S_OPT_FAST_IMDCT] = env("MP3S_FAST_IMDCT", 1) != 0;
-        c->opt[MP3S_OPT_PIPE_TAIL] = env("MP3S_PIPE_TAIL", 0) == 1;
+        c->opt[MP3S_OPT_PIPE_TAIL] = std::min<int64_t>(2, std::max<int64_t>(0, env("MP3S_PIPE_TAIL", 1)));
         c->opt[MP3S_OPT_CHUNK_FRAMES] = std::max<int64_t>(0, env("MP3S_CHUNK_FRAMES", 0));
         c->opt[MP3S_OPT_DEVICE_PARSE] = env("MP3S_DEVICE_PARSE", 1) != 0;
         c->opt[MP3S_OPT_FILE_PIPELINE] = env("MP3S_FILE_PIPELINE", 1) != 0;
@@ -157,7 +157,7 @@ int mp3s_ctx_set_option(mp3s_ctx *c, int option, int64_t value)
     if (!c || option <= 0 || option >= MP3S_OPT_COUNT) return fail(MP3S_E_ARG, "unknown option %d", option);
     if (value < 0 || (option == MP3S_OPT_CHUNK_FRAMES && value != 0 && value < 4) || (option == MP3S_OPT_SCAN_THREADS && value > 64))
         return fail(MP3S_E_ARG, "option %d: value %lld out of range", option, (long long)value);
-    c->opt[option] = option == MP3S_OPT_CHUNK_FRAMES || option == MP3S_OPT_SCAN_THREADS ? value : (value != 0);
+    c->opt[option] = option == MP3S_OPT_CHUNK_FRAMES || option == MP3S_OPT_SCAN_THREADS ? value : (option == MP3S_OPT_PIPE_TAIL ? std::min<int64_t>(value, 2) : (value != 0));
     return MP3S_OK;
 }
 

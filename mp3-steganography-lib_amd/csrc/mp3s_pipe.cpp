@@ -779,32 +779,40 @@ void free_slot(Slot &s)
 // (about 1 ms per rotation when a pipe is made).
 struct LanePool {
     hipStream_t hi[4] = {nullptr, nullptr, nullptr, nullptr}, lo[4] = {nullptr, nullptr, nullptr, nullptr}, cs[4] = {nullptr, nullptr, nullptr, nullptr};
-    hipEvent_t ev[4][4] = {};
+    hipEvent_t ev[4][5] = {};
     hipEvent_t t0 = nullptr, t1 = nullptr;
     uint8_t *d_buf = nullptr, *h_buf = nullptr;
     bool ok = false;
 };
 constexpr size_t kRehearseBytes = (size_t)256 << 10;
 
-float rehearse(LanePool &lp, hipStream_t comp, hipStream_t up, hipStream_t down, hipStream_t huff)
+// tail: the stream a job's last stage (three short spins: selection, chain check, packing) runs on, behind the job's compute
+// stage and beside the next job's; null: on the compute stream itself
+float rehearse(LanePool &lp, hipStream_t comp, hipStream_t up, hipStream_t down, hipStream_t huff, hipStream_t tail = nullptr)
 {
     float ms = 1e9f;
+    hipStream_t ts = tail ? tail : comp;
     bool ok = hipEventRecord(lp.t0, up) == hipSuccess;
     for (int k = 0; k < 4 && ok; k++) {
         ok = hipMemcpyAsync(lp.d_buf + k * kRehearseBytes, lp.h_buf + k * kRehearseBytes, kRehearseBytes, hipMemcpyHostToDevice, up) == hipSuccess &&
              hipEventRecord(lp.ev[k][0], up) == hipSuccess && hipStreamWaitEvent(huff, lp.ev[k][0], 0) == hipSuccess && launch_spin(huff, 60) == 0 &&
              hipEventRecord(lp.ev[k][1], huff) == hipSuccess && hipStreamWaitEvent(comp, lp.ev[k][1], 0) == hipSuccess && launch_spin(comp, 50) == 0 &&
-             launch_spin(comp, 50) == 0 && launch_noop(comp) == 0 && hipEventRecord(lp.ev[k][2], comp) == hipSuccess && hipStreamWaitEvent(down, lp.ev[k][2], 0) == hipSuccess &&
+             launch_spin(comp, 50) == 0 && launch_noop(comp) == 0 && hipEventRecord(lp.ev[k][2], comp) == hipSuccess;
+        if (ok && tail) ok = hipStreamWaitEvent(tail, lp.ev[k][2], 0) == hipSuccess;
+        ok = ok && launch_spin(ts, 10) == 0 && launch_spin(ts, 10) == 0 && launch_spin(ts, 20) == 0 && hipEventRecord(lp.ev[k][4], ts) == hipSuccess &&
+             hipStreamWaitEvent(down, lp.ev[k][4], 0) == hipSuccess &&
              hipMemcpyAsync(lp.h_buf + (4 + k) * kRehearseBytes, lp.d_buf + k * kRehearseBytes, kRehearseBytes, hipMemcpyDeviceToHost, down) == hipSuccess &&
              hipEventRecord(lp.ev[k][3], down) == hipSuccess;
     }
     ok = ok && hipEventRecord(lp.t1, down) == hipSuccess;
     (void)hipStreamSynchronize(up); (void)hipStreamSynchronize(huff); (void)hipStreamSynchronize(comp); (void)hipStreamSynchronize(down);
+    if (tail) (void)hipStreamSynchronize(tail);
     if (!ok || hipEventElapsedTime(&ms, lp.t0, lp.t1) != hipSuccess) return 1e9f;
     return ms;
 }
 
-int pick_lanes(mp3s_ctx *c, hipStream_t *up, hipStream_t *down, hipStream_t *huff, hipStream_t *comp /* a stream to compute on instead of the context's, or null */)
+int pick_lanes(mp3s_ctx *c, hipStream_t *up, hipStream_t *down, hipStream_t *huff, hipStream_t *comp /* a stream to compute on instead of the context's, or null */,
+               hipStream_t *tail /* a stream for the tail of a job, or null */, int want_tail /* 0: none, 1: always, 2: if the rehearsal is faster with it */)
 {
     static std::mutex mu;
     static std::vector<LanePool> pools;
@@ -819,7 +827,7 @@ int pick_lanes(mp3s_ctx *c, hipStream_t *up, hipStream_t *down, hipStream_t *huf
         bool ok = hipEventCreate(&lp.t0) == hipSuccess && hipEventCreate(&lp.t1) == hipSuccess && hipMalloc((void **)&lp.d_buf, 4 * kRehearseBytes) == hipSuccess &&
                   hipHostMalloc((void **)&lp.h_buf, 8 * kRehearseBytes, hipHostMallocDefault) == hipSuccess;
         for (int k = 0; k < 4 && ok; k++)
-            for (int q = 0; q < 4 && ok; q++) ok = hipEventCreateWithFlags(&lp.ev[k][q], hipEventDisableTiming) == hipSuccess;
+            for (int q = 0; q < 5 && ok; q++) ok = hipEventCreateWithFlags(&lp.ev[k][q], hipEventDisableTiming) == hipSuccess;
         for (int i = 0; i < 4 && ok; i++) ok = hipStreamCreateWithPriority(&lp.hi[i], hipStreamNonBlocking, prio_high) == hipSuccess;
         for (int i = 0; i < 4 && ok; i++) ok = hipStreamCreateWithPriority(&lp.lo[i], hipStreamNonBlocking, huff_prio) == hipSuccess;
         for (int i = 0; i < 4 && ok; i++) ok = hipStreamCreateWithFlags(&lp.cs[i], hipStreamNonBlocking) == hipSuccess;
@@ -843,13 +851,29 @@ int pick_lanes(mp3s_ctx *c, hipStream_t *up, hipStream_t *down, hipStream_t *huf
     for (int r = 0; r < 4; r++) tryout(-1, r);
     const float own_ms = best_ms;
     const int own_best = best;
-    if (comp && best_ms > 0.64f)          // (4 x (60 + 2 x 50) us of spinning never take less than 0.58 ms: this one lost its overlap somewhere)
-        for (int ci = 0; ci < 4 && best_ms > 0.62f; ci++) {
+    if (comp && best_ms > 0.80f)          // (4 x (2 x 50 + 40) us on the compute stream behind one front-end spin never take less than 0.72 ms: this one lost its overlap somewhere)
+        for (int ci = 0; ci < 4 && best_ms > 0.78f; ci++) {
             if (trace_on()) seen += " |";
             for (int r = 0; r < 4; r++) tryout(ci, r);
         }
     if (best_cs >= 0 && best_ms > own_ms * 0.93f) { best_cs = -1; best_ms = own_ms; best = own_best; }   // (not worth leaving the context's stream for)
-    if (trace_on()) fprintf(stderr, "mp3s: pipe lanes rehearsed:%s ms -> compute stream %d, rotation %d (%.3f ms)\n", seen.c_str(), best_cs, best, best_ms);
+    // a stream for the tail of a job (MP3S_OPT_PIPE_TAIL): the candidate, other than the compute stream, that gets the
+    // rehearsal through fastest -- kept if that is faster than the tail on the compute stream itself
+    int best_tail = -1;
+    if (tail) {
+        *tail = nullptr;
+        hipStream_t comp_s = best_cs < 0 ? c->stream : lp.cs[best_cs];
+        float tail_ms = best_ms * (want_tail == 1 ? 1.05f : 0.97f);   // (1: unless it clearly loses -- the real kernels gain more from it than spins do)
+        if (trace_on()) seen += " | tail:";
+        for (int ti = 0; ti < 4 && want_tail; ti++) {
+            if (ti == best_cs) continue;
+            const float ms = std::min(rehearse(lp, comp_s, lp.hi[best], lp.hi[(best + 1) & 3], lp.lo[best], lp.cs[ti]), rehearse(lp, comp_s, lp.hi[best], lp.hi[(best + 1) & 3], lp.lo[best], lp.cs[ti]));
+            if (trace_on()) { char b[32]; snprintf(b, sizeof b, " %.3f", ms); seen += b; }
+            if (ms < tail_ms) { tail_ms = ms; best_tail = ti; }
+        }
+        if (best_tail >= 0) *tail = lp.cs[best_tail];
+    }
+    if (trace_on()) fprintf(stderr, "mp3s: pipe lanes rehearsed:%s ms -> compute stream %d, rotation %d (%.3f ms), tail stream %d\n", seen.c_str(), best_cs, best, best_ms, best_tail);
     if (comp) *comp = best_cs >= 0 ? lp.cs[best_cs] : nullptr;
     *up = lp.hi[best]; *down = lp.hi[(best + 1) & 3]; *huff = lp.lo[best];
     return 0;
@@ -862,27 +886,21 @@ int pipe_create(mp3s_ctx *c, int depth, size_t max_job_bytes, int scan_threads, 
     std::unique_ptr<mp3s_pipe> P(new mp3s_pipe());
     P->c = c; P->depth = depth; P->internal = internal; P->max_job_bytes = max_job_bytes;
     auto destroy = [&](int code, const char *what) {
-        for (auto &s : P->slots) free_slot(s);
-        if (P->s_tail) (void)hipStreamDestroy(P->s_tail);   // (the other three belong to the device: pick_lanes)
+        for (auto &s : P->slots) free_slot(s);                // (the streams belong to the device: pick_lanes)
         for (hipEvent_t e : P->e_dec) if (e) (void)hipEventDestroy(e);
         return fail(code, "%s", what);
     };
     // copy-up, copy-down and front-end streams that run beside this context's compute stream (pick_lanes above)
-    if (pick_lanes(c, &P->s_up, &P->s_down, &P->s_huff, &P->s_comp)) return destroy(MP3S_E_HIP, "stream creation failed");
+    if (pick_lanes(c, &P->s_up, &P->s_down, &P->s_huff, &P->s_comp, &P->s_tail, internal ? 0 : (int)c->opt[MP3S_OPT_PIPE_TAIL])) return destroy(MP3S_E_HIP, "stream creation failed");
     if (hipEventCreateWithFlags(&P->e_dec[0], hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&P->e_dec[1], hipEventDisableTiming) != hipSuccess)
         return destroy(MP3S_E_HIP, "stream creation failed");
-    // The tail stream is OFF unless MP3S_OPT_PIPE_TAIL is set.  On a resident batch fed through three contexts the
-    // arrangement is worth 5 % (bench.py, region (i): 0.829 -> 0.787 ms per step); in this pipe it measured slower at every
-    // priority, with and without making the next rate loop wait for the tail in front of it (0.89 - 1.25 against 0.83 ms
-    // per batch: with the copy streams and the front end there are then five streams at work, and every kernel of the two
-    // overlapping jobs stretches by half; tools/two_pipes_probe.py with MP3S_PIPE_TAIL / MP3S_PIPE_TAIL_PRIO / MP3S_PIPE_TAIL_THROTTLE).
-    const char *tp = getenv("MP3S_PIPE_TAIL_PRIO");
-    const int tail_prio = tp ? atoi(tp) : 0;
+    // The tail of a job (selection, chain check, bit packing) on a stream of its own, under the decode transforms of the next job:
+    // worth 5 % on a resident batch fed through three contexts (bench.py, region (i)); in this pipe round 2 measured it slower
+    // at every priority -- that was the lanes sharing queues, not the arrangement: with a tail stream the rehearsal vouches for
+    // a batch takes 0.79 instead of 0.82 ms (tools/pipe_tail_probe.py).  MP3S_OPT_PIPE_TAIL: 0 off, 1 on, 2 if the rehearsal gains.
     P->tail_throttle = getenv("MP3S_PIPE_TAIL_THROTTLE") != nullptr;
     if (const char *du = getenv("MP3S_PIPE_DIRECT_UPLOAD")) P->direct_upload = (size_t)atoll(du);
-    if (c->opt[MP3S_OPT_PIPE_TAIL] && hipStreamCreateWithPriority(&P->s_tail, hipStreamNonBlocking, tail_prio) != hipSuccess)
-        return destroy(MP3S_E_HIP, "stream creation failed");
     // the page-locked staging of the slots is allocated by a thread that runs on the GPU's NUMA node (first touch), and the
     // workers that fill it stay there
     P->node_cpus = gpu_node_cpus(c->device);
@@ -959,7 +977,6 @@ void mp3s_pipe_destroy(mp3s_pipe *P)
     if (P->s_ctx) { P->c->stream = P->s_ctx; P->s_ctx = nullptr; }
     for (auto &j : P->inflight) { if (j->slow_owner) mp3s_buf_free(j->slow_owner); if (j->blk_owner) mp3s_buf_free(j->blk_owner); }
     for (auto &s : P->slots) free_slot(s);
-    if (P->s_tail) (void)hipStreamDestroy(P->s_tail);
     for (hipEvent_t e : P->e_dec) (void)hipEventDestroy(e);
     delete P;
 }
