@@ -891,7 +891,7 @@ int pipe_create(mp3s_ctx *c, int depth, size_t max_job_bytes, int scan_threads, 
         return fail(code, "%s", what);
     };
     // copy-up, copy-down and front-end streams that run beside this context's compute stream (pick_lanes above)
-    if (pick_lanes(c, &P->s_up, &P->s_down, &P->s_huff, &P->s_comp, &P->s_tail, internal ? 0 : (int)c->opt[MP3S_OPT_PIPE_TAIL])) return destroy(MP3S_E_HIP, "stream creation failed");
+    if (pick_lanes(c, &P->s_up, &P->s_down, &P->s_huff, &P->s_comp, &P->s_tail, (int)c->opt[MP3S_OPT_PIPE_TAIL])) return destroy(MP3S_E_HIP, "stream creation failed");
     if (hipEventCreateWithFlags(&P->e_dec[0], hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&P->e_dec[1], hipEventDisableTiming) != hipSuccess)
         return destroy(MP3S_E_HIP, "stream creation failed");
