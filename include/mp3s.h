@@ -127,7 +127,9 @@ int mp3s_ctx_wait(mp3s_ctx *ctx, mp3s_ctx *other);
                                     * download one after the other as in round 2 [MP3S_FILE_PIPELINE=0 -> 0] */
 #define MP3S_OPT_SCAN_THREADS 8    /* host threads a multi-file call may use for its front end; 0 = from the CPUs this process may
                                     * run on (sched_getaffinity, cgroup quota) divided by the ranks on this host [MP3S_SCAN_THREADS] */
-#define MP3S_OPT_COUNT 9
+#define MP3S_OPT_FIRST_CHUNK_FRAMES 9 /* frames of the first chunk of a one-file call (the device starts when it has been walked); 0 = chosen
+                                       * from the file's length; never shorter than what the message can reach [MP3S_FIRST_CHUNK_FRAMES] */
+#define MP3S_OPT_COUNT 10
 /* what became of the one-file calls of this context (mp3s_hide_message, mp3s_clear_file, mp3s_decode_file, mp3s_decode_stream,
  * mp3s_hide_message_chunked): files that went through the overlapped stages as chunks, their chunks, chunks that were run
  * again because they depended on a carry the guess got wrong, chunks whose chains the host resolved, and files that took

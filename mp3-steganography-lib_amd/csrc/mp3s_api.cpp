@@ -114,6 +114,7 @@ int mp3s_ctx_create(int device, mp3s_ctx **out)
         c->opt[MP3S_OPT_DEVICE_PARSE] = env("MP3S_DEVICE_PARSE", 1) != 0;
         c->opt[MP3S_OPT_FILE_PIPELINE] = env("MP3S_FILE_PIPELINE", 1) != 0;
         c->opt[MP3S_OPT_SCAN_THREADS] = std::max<int64_t>(0, env("MP3S_SCAN_THREADS", 0));
+        c->opt[MP3S_OPT_FIRST_CHUNK_FRAMES] = std::max<int64_t>(0, env("MP3S_FIRST_CHUNK_FRAMES", 0));
     }
     if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess ||
         hipEventCreate(&c->ev0) != hipSuccess || hipEventCreate(&c->ev1) != hipSuccess ||
@@ -155,9 +156,9 @@ void mp3s_ctx_destroy(mp3s_ctx *c)
 int mp3s_ctx_set_option(mp3s_ctx *c, int option, int64_t value)
 {
     if (!c || option <= 0 || option >= MP3S_OPT_COUNT) return fail(MP3S_E_ARG, "unknown option %d", option);
-    if (value < 0 || (option == MP3S_OPT_CHUNK_FRAMES && value != 0 && value < 4) || (option == MP3S_OPT_SCAN_THREADS && value > 64))
+    if (value < 0 || ((option == MP3S_OPT_CHUNK_FRAMES || option == MP3S_OPT_FIRST_CHUNK_FRAMES) && value != 0 && value < 4) || (option == MP3S_OPT_SCAN_THREADS && value > 64))
         return fail(MP3S_E_ARG, "option %d: value %lld out of range", option, (long long)value);
-    c->opt[option] = option == MP3S_OPT_CHUNK_FRAMES || option == MP3S_OPT_SCAN_THREADS ? value : (option == MP3S_OPT_PIPE_TAIL ? std::min<int64_t>(value, 2) : (value != 0));
+    c->opt[option] = option == MP3S_OPT_CHUNK_FRAMES || option == MP3S_OPT_SCAN_THREADS || option == MP3S_OPT_FIRST_CHUNK_FRAMES ? value : (option == MP3S_OPT_PIPE_TAIL ? std::min<int64_t>(value, 2) : (value != 0));
     return MP3S_OK;
 }
 

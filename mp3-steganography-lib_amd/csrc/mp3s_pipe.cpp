@@ -1294,13 +1294,14 @@ int run_file(mp3s_ctx *c, const uint8_t *mp3, size_t len, int mode, const uint8_
     if (chunk > 0) { chunk = std::min(chunk, kMaxChunk); first_chunk = chunk; }
     else if (n_est <= 3000) { chunk = first_chunk = std::min(kMaxChunk, n_est + 16); }                    // one chunk: nothing to overlap with
     else {
-        // m chunks of about a quarter of the file (at least 2 560 frames: below that the kernels' fixed costs show), the first
-        // one half as long, the rest of the file split evenly over the others
-        const long target = std::min<long>(kMaxChunk, std::max<long>(2560, (n_est + 3) / 4));
-        const long m = std::max<long>(2, (n_est + target - 1) / target);
-        first_chunk = std::max<long>(1536, n_est / m / 2);
-        chunk = std::min<long>(kMaxChunk, (n_est - first_chunk + (m - 1) - 1) / (m - 1) + 8);
+        // A short first chunk, so that the device starts early, then chunks as long as a transform group takes: every chunk
+        // costs the host 0.15 ms of walking, laying out and queueing (two dozen runtime calls), which four chunks of a
+        // 10 000-frame file do not win back (tools/chunk_plan_probe.py: 2 048 + the rest 1.41 ms, four chunks 1.49, one 1.57;
+        // a 100 000-frame file: 8 192 + 16 000s 8.1 ms)
+        first_chunk = std::min<long>(8192, std::max<long>(2048, n_est / 12));
+        chunk = kMaxChunk;
     }
+    if (c->opt[MP3S_OPT_FIRST_CHUNK_FRAMES] > 0) first_chunk = (long)std::min<int64_t>(c->opt[MP3S_OPT_FIRST_CHUNK_FRAMES], kMaxChunk);
     first_chunk = std::min(kMaxChunk, std::max(first_chunk, reach_frames));
     const long cap_frames = std::max(chunk, first_chunk) + 2;
     // (a message that reaches further than a chunk: the synchronous path's plan over the whole file)
