@@ -229,6 +229,7 @@ def main():
 
     # ---------------------------------------------------------------- build the resident batch (untimed)
     t_prep = time.time()
+    ctx.set_option("file_pipeline", 0)     # (the preparation's one-file calls as full-size launches: the profiles of a --resident-only run hold nothing else)
     pcm_src = synth_pcm(n, seed=0x9E3779B97F4A7C15 + rank)
     hide = bits_of(MESSAGE)
     payload = MESSAGE.split("#", 1)[1]
@@ -293,6 +294,7 @@ def main():
     gr = final["gr"]
     active = (gr["flags"] & _lib.RF_ACTIVE) != 0
     prep_s = time.time() - t_prep
+    ctx.set_option("file_pipeline", 1)
 
     state = {"k": 0}
 

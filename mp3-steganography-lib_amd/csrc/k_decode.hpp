@@ -61,7 +61,8 @@ __device__ __forceinline__ Row18 load_row18(const double (*C36)[18], const doubl
 struct DecShared {
     double pow2q[POW2Q_N];                 // copies of the small exponent tables: random per-lane reads go to LDS
     double pow2h[POW2H_N];
-    double buf[DEC_A_WAVES][2][576];       // per wave: spectrum exchange for reorder / alias reduction
+    double buf[DEC_A_WAVES][2][32 * 19];   // per wave: spectrum exchange for reorder / alias reduction; a subband's 18 lines at a stride of 19
+                                           // doubles (38 dwords: the 32 lanes of a channel hit 32 different bank pairs; at 18 they hit 16, twice)
     uint32_t side[DEC_A_WAVES][2][18];     // per wave: the two 72-byte side records of the current granule
     double exp2f[DEC_A_WAVES][2][64];      // per wave and channel: 2^(-exp2) per scalefactor slot of the current granule
     double exp1f[DEC_A_WAVES][2][4];       // ... and 2^(exp1/4) per gain selector
@@ -147,23 +148,23 @@ __device__ __forceinline__ void dec_prepare(const DevTables &tab, DecShared &sh,
     // ---- reorder (short / mixed) or alias reduction (long) through the wave's LDS slice
     double *buf = sh.buf[wave][ch];
 #pragma unroll
-    for (int k = 0; k < 18; k++) buf[sb * 18 + k] = v[k];
+    for (int k = 0; k < 18; k++) buf[sb * 19 + k] = v[k];
     __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0): the wave's own LDS writes have landed
     __builtin_amdgcn_wave_barrier();
     if (cse != 0) {
         const int16_t *src = tab.reorder_src[sr];
 #pragma unroll
         for (int k = 0; k < 18; k++) {
-            const int s = src[sb * 18 + k];
-            v[k] = s >= 0 ? buf[s] : 0.0;
+            const int s = src[sb * 18 + k];                       // a line of the spectrum, or -1
+            v[k] = s >= 0 ? buf[s + ((s * 3641) >> 16)] : 0.0;     // line s sits at s + s / 18 (s < 576)
         }
     } else {
 #pragma unroll
         for (int i = 0; i < 8; i++) {
             // butterfly with subband sb-1 (lower line, Frame.py:622: s2*cs + s1*ca) and with subband sb+1 (upper line,
             // :621: s1*cs - s2*ca); branch-free: every lane evaluates both and the edge subbands keep their value
-            const int ilo = 18 * sb - 1 - i, ihi = 18 * (sb + 1) + i;
-            const double nlo = buf[ilo < 0 ? 0 : ilo], nhi = buf[ihi > 575 ? 575 : ihi];
+            const int ilo = 19 * sb - 2 - i, ihi = 19 * (sb + 1) + i;      // line 17 - i of subband sb - 1, line i of subband sb + 1
+            const double nlo = buf[ilo < 0 ? 0 : ilo], nhi = buf[ihi > 607 ? 607 : ihi];
             const double cs = tab.alias_cs[i], ca = tab.alias_ca[i];
             const double lo = v[i] * cs + nlo * ca;
             const double hi = v[17 - i] * cs - nhi * ca;

@@ -120,7 +120,7 @@ def test_what_the_chunks_do_not_take_falls_back(ctx, mlib, golden_dir):
 
 
 def test_long_file_automatic_chunks_and_the_facade(ctx, mlib, tmp_path):
-    """a 12 000-frame file with the automatic plan (four to five chunks in flight), through Steganography.hide_message"""
+    """a 12 000-frame file with the automatic plan (a short first chunk, then the rest), through Steganography.hide_message"""
     from synth_pcm import synth_pcm
     from mp3stego import Steganography
     pcm = synth_pcm(12000, seed=61)
@@ -130,7 +130,7 @@ def test_long_file_automatic_chunks_and_the_facade(ctx, mlib, tmp_path):
     got = ctx.hide_message(mp3, "The quick brown fox")
     s1 = ctx.run_stats()
     assert same_file(got, want)
-    assert s1["files"] - s0["files"] == 1 and s1["chunks"] - s0["chunks"] >= 3 and s1["fallbacks"] == s0["fallbacks"], (s0, s1)
+    assert s1["files"] - s0["files"] == 1 and s1["chunks"] - s0["chunks"] >= 2 and s1["fallbacks"] == s0["fallbacks"], (s0, s1)
     wav_want = legacy(ctx, ctx.decode_file, mp3)
     wav = ctx.decode_file(mp3)
     assert bytes(wav["data"]) == bytes(wav_want["data"]) and np.array_equal(wav["bits"], wav_want["bits"])
