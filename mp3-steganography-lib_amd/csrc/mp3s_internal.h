@@ -143,7 +143,7 @@ private:
         static auto *v = new std::vector<std::pair<uint8_t *, size_t>>();
         return *v;
     }
-    static constexpr size_t kMaxPinned = (size_t)1 << 30;
+    static constexpr size_t kMaxPinned = (size_t)4 << 30;   // (a 100 000-frame file decodes to 460 MB of PCM: two such results and the MP3 results beside them stay pooled)
     uint8_t *p_ = nullptr;
     size_t cap_ = 0;
     bool pinned_ = true;

@@ -777,7 +777,9 @@ void free_slot(Slot &s)
 // the front-end stream, two spins on the compute stream, a copy down, chained by events exactly as issue_fast chains a
 // job's stages -- through each rotation of the candidates, and keeps the rotation that got them through fastest
 // (about 1 ms per rotation when a pipe is made).
+struct LaneChoice { hipStream_t ctx_stream; int want_tail; hipStream_t up, down, huff, comp, tail; };
 struct LanePool {
+    std::vector<LaneChoice> chosen;       // what the rehearsal decided for a context's stream (asked again only by another context)
     hipStream_t hi[4] = {nullptr, nullptr, nullptr, nullptr}, lo[4] = {nullptr, nullptr, nullptr, nullptr}, cs[4] = {nullptr, nullptr, nullptr, nullptr};
     hipEvent_t ev[4][5] = {};
     hipEvent_t t0 = nullptr, t1 = nullptr;
@@ -811,12 +813,14 @@ float rehearse(LanePool &lp, hipStream_t comp, hipStream_t up, hipStream_t down,
     return ms;
 }
 
+std::mutex &lane_mu() { static std::mutex *m = new std::mutex(); return *m; }
+std::vector<LanePool> &lane_pools() { static auto *v = new std::vector<LanePool>(); return *v; }
+
 int pick_lanes(mp3s_ctx *c, hipStream_t *up, hipStream_t *down, hipStream_t *huff, hipStream_t *comp /* a stream to compute on instead of the context's, or null */,
                hipStream_t *tail /* a stream for the tail of a job, or null */, int want_tail /* 0: none, 1: always, 2: if the rehearsal is faster with it */)
 {
-    static std::mutex mu;
-    static std::vector<LanePool> pools;
-    std::lock_guard<std::mutex> g(mu);
+    std::lock_guard<std::mutex> g(lane_mu());
+    auto &pools = lane_pools();
     if ((size_t)c->device >= pools.size()) pools.resize((size_t)c->device + 1);
     LanePool &lp = pools[(size_t)c->device];
     if (!lp.ok) {
@@ -835,6 +839,13 @@ int pick_lanes(mp3s_ctx *c, hipStream_t *up, hipStream_t *down, hipStream_t *huf
         std::memset(lp.h_buf, 0, 8 * kRehearseBytes);
         lp.ok = true;
     }
+    for (const LaneChoice &k : lp.chosen)
+        if (k.ctx_stream == c->stream && k.want_tail == want_tail) {
+            *up = k.up; *down = k.down; *huff = k.huff;
+            if (comp) *comp = k.comp;
+            if (tail) *tail = k.tail;
+            return 0;
+        }
     (void)hipStreamSynchronize(c->stream);
     (void)rehearse(lp, c->stream, lp.hi[0], lp.hi[1], lp.lo[0]);      // (first launches: not a measurement)
     // the context's own stream with every rotation of the lanes; if none of them gets the rehearsal through as fast as a
@@ -876,7 +887,18 @@ int pick_lanes(mp3s_ctx *c, hipStream_t *up, hipStream_t *down, hipStream_t *huf
     if (trace_on()) fprintf(stderr, "mp3s: pipe lanes rehearsed:%s ms -> compute stream %d, rotation %d (%.3f ms), tail stream %d\n", seen.c_str(), best_cs, best, best_ms, best_tail);
     if (comp) *comp = best_cs >= 0 ? lp.cs[best_cs] : nullptr;
     *up = lp.hi[best]; *down = lp.hi[(best + 1) & 3]; *huff = lp.lo[best];
+    lp.chosen.push_back({c->stream, want_tail, *up, *down, *huff, comp ? *comp : nullptr, tail ? *tail : nullptr});
     return 0;
+}
+
+// a context is going away: its stream's address may come back as another context's
+void forget_lanes(mp3s_ctx *c)
+{
+    std::lock_guard<std::mutex> g(lane_mu());
+    auto &pools = lane_pools();
+    if ((size_t)c->device >= pools.size()) return;
+    auto &v = pools[(size_t)c->device].chosen;
+    v.erase(std::remove_if(v.begin(), v.end(), [&](const LaneChoice &k) { return k.ctx_stream == c->stream; }), v.end());
 }
 
 int pipe_create(mp3s_ctx *c, int depth, size_t max_job_bytes, int scan_threads, bool internal, mp3s_pipe **out)
@@ -1262,9 +1284,10 @@ int ensure_own_pipe(mp3s_ctx *c, size_t chunk_bytes)
     return pipe_create(c, kRunDepth, want, 0, true, &c->own_pipe);
 }
 
-void destroy_own_pipe(mp3s_ctx *c)
+void destroy_own_pipe(mp3s_ctx *c)   // (the context is being destroyed)
 {
     if (c->own_pipe) { mp3s_pipe_destroy(c->own_pipe); c->own_pipe = nullptr; }
+    forget_lanes(c);
 }
 
 int run_file(mp3s_ctx *c, const uint8_t *mp3, size_t len, int mode, const uint8_t *utf8, size_t n_msg, int out_format, mp3s_buf **owner, RunResult *out)
