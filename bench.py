@@ -200,6 +200,8 @@ def main():
     ap.add_argument("--pack-overlap", action="store_true", help="(default since r02e; kept for old command lines)")
     ap.add_argument("--no-tail-stream", action="store_true", help="chain check and bit packing of batch k on the main stream instead of a third one")
     ap.add_argument("--resident-only", action="store_true", help="region (i) only (profiling runs)")
+    ap.add_argument("--decode-stream", choices=("on", "off"), default="off",
+                    help="the decode transforms of batch k+1 on a context of their own, under the encode transforms and the rate loop of batch k")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -258,6 +260,10 @@ def main():
     # transforms of batch k+1, as in the library's pipe (mp3s_pipe.cpp: s_tail) -- the small launches and their gaps are 5 %
     # of a step when they sit in front of the next batch (0.829 -> 0.785 ms per step)
     aux2 = _lib.Context(ctx.device) if not (args.no_tail_stream or args.no_overlap) else None
+    # fourth stream: the int16 decode transforms wait for scalar operands half of the time (45 % of their issue slots busy), the
+    # encode transforms and the rate loop are bound by them (75 - 85 %): the decode transforms of batch k+1 under the encode side of batch k
+    dctx = _lib.Context(ctx.device) if (args.decode_stream == "on" and aux is not None) else None
+    d_pcm2 = [ctx.alloc(n * 2304 * 2), ctx.alloc(n * 2304 * 2)] if dctx is not None else None
     d_hdr = ctx.to_device(parsed["hdr"])
     rf, _pad = _lib.rate_frames(44100, 128, 2, n)
     # the message array of a batch: the eight 3-bit patterns the variants read, then the message
@@ -311,7 +317,42 @@ def main():
         _lib.check(L.mp3s_huffman_decode_dev(c.handle, d_blob, d_side, n, 2, scanned["max_part2_3_length"],
                                              d_is2[b], d_si2[b], d_hst2[b]))
 
+    def decode_side(k):
+        b = k & 1
+        dctx.wait_for(aux)                          # Huffman(k) done
+        _lib.check(L.mp3s_decode_transform_dev(dctx.handle, d_is2[b], d_si2[b], d_hdr, n, 2, 0, _lib.MP3S_PCM_I16, d_pcm2[b]))
+
+    def step4():
+        # the same step with the decode transforms on a context of their own, one batch ahead of the encode side
+        k = state["k"]; state["k"] = k + 1
+        b = k & 1
+        if k == 0 or state.get("restart"):
+            front_end(aux, k); state["restart"] = False
+            decode_side(k)
+        ctx.wait_for(dctx)                          # decode(k) done: its PCM is there
+        if not state.get("last"):
+            aux.wait_for(dctx)                      # decode(k-1) has read the Huffman outputs batch k+1 overwrites
+            front_end(aux, k + 1)
+            dctx.wait_for(ctx)                      # the encode transforms of batch k-1 have read the PCM buffer batch k+1 writes
+            decode_side(k + 1)
+        d_mdct = d_mdct2[b]
+        _lib.check(L.mp3s_encode_transform_dev(ctx.handle, d_pcm2[b], d_hdr, n, d_mdct))
+        if aux2 is not None:
+            ctx.wait_for(aux2)
+        _lib.check(L.mp3s_dev_copy(ctx.handle, d_cur, d_cur0, units * 4))
+        _lib.check(L.mp3s_rate_variants_dev(ctx.handle, d_mdct, d_rf, n, d_hide, len(hide_all), d_cur, d_eu, d_ec, n_ent, d_ix, d_out, d_en,
+                                            d_ixv, d_outv, d_env))
+        pk = ctx
+        if aux2 is not None:
+            aux2.wait_for(ctx)
+            pk = aux2
+        _lib.check(L.mp3s_select_dev(pk.handle, d_hide, d_cur, d_seg, d_spans, 1, max_reach, d_eu, d_ec, n_ent, d_ix, d_out, d_en, d_ixv, d_outv, d_env))
+        _lib.check(L.mp3s_chain_redo_dev(pk.handle, d_mdct, d_rf, n, d_hide, len(hide_all), d_cur, d_seg, 1, d_ix, d_out, d_en, d_verdict, d_segout))
+        _lib.check(L.mp3s_pack_frames_dev(pk.handle, d_ix, d_out, d_en, n, 44100, 128, d_off, d_pad, d_mp3, d_sc, d_pst))
+
     def step():
+        if dctx is not None:
+            return step4()
         # One step = one batch through the whole device pipeline.  With the second stream the batches are software
         # pipelined: the latency-bound Huffman decode of batch k+1 runs under the encode half of batch k.  Every
         # batch still gets its own Huffman launch inside the timed region (the first one is issued by the first step).
@@ -351,6 +392,8 @@ def main():
             aux.sync()
         if aux2 is not None:
             aux2.sync()
+        if dctx is not None:
+            dctx.sync()
         if dist is not None:
             dist.barrier()
 
@@ -366,7 +409,7 @@ def main():
     def collect():
         pr = ctx.profile_collect()
         on_main = {kname for kname, (ms, cnt) in pr.items() if cnt}          # launched on the main stream
-        for c in (aux, aux2):
+        for c in (aux, aux2, dctx):
             if c is not None:
                 for kname, (ms, cnt) in c.profile_collect().items():
                     pr[kname] = (pr[kname][0] + ms, pr[kname][1] + cnt)
@@ -375,7 +418,7 @@ def main():
     # ---- untimed pass with an event pair around every kernel: the per-kernel table and the choice of the dominant one.
     #      (An event pair costs stream time -- about 0.05 ms per step for all kernels -- so the timed region below
     #      carries them only around the dominant kernel, whose duration the roofline is computed from.)
-    for c in (ctx, aux, aux2):
+    for c in (ctx, aux, aux2, dctx):
         if c is not None:
             c.profile_select(None)
             c.profile_enable(True)
@@ -388,7 +431,7 @@ def main():
     # them (its own duration is stretched by sharing the CUs and is not what bounds the step)
     dom = max((kname for kname in per_step if kname in main_kernels), key=per_step.get)
     # ---- timed region (i): K steps, HIP events around the dominant kernel only
-    for c in (ctx, aux, aux2):
+    for c in (ctx, aux, aux2, dctx):
         if c is not None:
             c.profile_select([dom])
             c.profile_enable(True)
@@ -400,7 +443,7 @@ def main():
     barrier()
     wall = time.perf_counter() - t0
     prof, _ = collect()
-    for c in (ctx, aux, aux2):
+    for c in (ctx, aux, aux2, dctx):
         if c is not None:
             c.profile_enable(False)
             c.profile_select(None)
@@ -411,7 +454,7 @@ def main():
     segout = ctx.download(d_segout, _lib.CHAIN_SEG_OUT_DTYPE, (1,))
     got_gr = ctx.download(d_out, _lib.GR_OUT_DTYPE, (units,))
     got_ix = ctx.download(d_ix, np.int16, (n, 2, 2, 576))
-    got_pcm = ctx.download(d_pcm, np.int16, (n * 1152, 2))
+    got_pcm = ctx.download(d_pcm if dctx is None else d_pcm2[(state["k"] - 1) & 1], np.int16, (n * 1152, 2))
     got_mp3 = ctx.download(d_mp3, np.uint8, (int(frame_off[-1]),)).tobytes()
     same = int(verdict[0]) == 0 and int(verdict[1]) == 0          # the chain check agrees: the step was the whole job
     same = same and int(segout["cursor"][0]) - 32 == int(final["hide_offset"])
@@ -434,6 +477,32 @@ def main():
 
     max_step = reduce_max(wall / args.steps)
     value = n * world / max_step
+
+    # ---------------------------------------------------------------- the same step on FOUR streams (reported beside `value`, not as it)
+    four = None
+    if dctx is None and aux is not None and aux2 is not None and not args.resident_only:
+        dctx = _lib.Context(ctx.device)
+        d_pcm2 = [ctx.alloc(n * 2304 * 2), ctx.alloc(n * 2304 * 2)]
+        dctx.profile_select([dom]); ctx.profile_select([dom])
+        run(args.warmup + 2)
+        barrier()
+        dctx.profile_enable(True); ctx.profile_enable(True)
+        t0 = time.perf_counter()
+        run(args.steps)
+        barrier()
+        w4 = time.perf_counter() - t0
+        p4 = ctx.profile_collect()
+        for c in (ctx, dctx):
+            c.profile_enable(False); c.profile_select(None)
+        ok4 = int(ctx.download(d_verdict, np.int32, (2,))[0]) == 0 and ctx.download(d_mp3, np.uint8, (int(frame_off[-1]),)).tobytes() == got_mp3
+        same = same and ok4
+        t4 = reduce_max(w4 / args.steps)
+        four = {"frames_per_s": round(n * world / t4, 1), "ms_per_step": round(t4 * 1e3, 4), "steps": args.steps,
+                "dominant_kernel_ms_per_launch": round(p4[dom][0] / max(p4[dom][1], 1), 4),
+                "what": "the same step with the decode transforms of batch k+1 on a fourth context, under the encode transforms and the rate loop of batch k "
+                        "(they wait for scalar operands half of the time, the encode side is bound by the vector units): more frames per second, and every "
+                        "kernel -- the rate loop too -- takes longer beside the others, which is why `value` and the roofline stay with three streams"}
+        dctx.close(); dctx = None
 
     # ---------------------------------------------------------------- decode only (BASELINE config 2), resident, kernel-only
     decode_only = None
@@ -531,6 +600,7 @@ def main():
             rs1 = ctx.run_stats()
             same = same and same_bytes(r["data"], big_out) and rs1["files"] - rs0["files"] == kb
             del r
+            r = ctx.decode_file(big); del r                      # (the first call pins its 460 MB result block)
             t0 = time.perf_counter()
             for _ in range(3):
                 r = ctx.decode_file(big); del r
@@ -803,6 +873,7 @@ def main():
             "roofline": roofline,
             "roofline_alu": roofline_alu,
             "cpu_baseline": cpu,
+            "value_four_streams": four,
             "e2e_steady": e2e_steady,
             "regions": regions,
             "decode_only": decode_only,
@@ -823,7 +894,7 @@ def main():
             "device": ctx.device_name(),
         }
         print(json.dumps(out))
-    for c in (aux, aux2):
+    for c in (aux, aux2, dctx):
         if c is not None:
             c.close()
     ctx.close()

@@ -144,6 +144,7 @@ void mp3s_ctx_destroy(mp3s_ctx *c)
     destroy_own_pipe(c);
     if (c->stream) hipStreamSynchronize(c->stream);
     if (c->scratch) hipFree(c->scratch);
+    if (c->scratch_enc) hipFree(c->scratch_enc);
     if (c->d_sync) hipFree(c->d_sync);
     for (void *q : c->pool) if (q) hipFree(q);
     if (c->ev0) hipEventDestroy(c->ev0);
@@ -388,9 +389,9 @@ int mp3s_encode_transform_dev(mp3s_ctx *c, const int16_t *d_pcm, const mp3s_fram
 {
     if (!c || !d_pcm || !d_hdr || !d_mdct) return fail(MP3S_E_ARG, "null pointer");
     if (n_frames <= 0) return fail(MP3S_E_ARG, "n_frames=%d", n_frames);
-    int rc = c->ensure_scratch(enc_scratch_bytes(n_frames));
+    int rc = c->ensure_scratch_enc(enc_scratch_bytes(n_frames));
     if (rc) return rc;
-    const int e = launch_encode(c->stream, d_pcm, d_hdr, n_frames, d_mdct, c->scratch, &c->prof);
+    const int e = launch_encode(c->stream, d_pcm, d_hdr, n_frames, d_mdct, c->scratch_enc, &c->prof);
     if (e) return fail(MP3S_E_HIP, "encode launch: %s", hipGetErrorString((hipError_t)e));
     return MP3S_OK;
 }

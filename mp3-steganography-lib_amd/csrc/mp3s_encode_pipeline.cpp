@@ -177,7 +177,7 @@ void tables_guess_of(const mp3s_frame_side *side, long n_frames, int extra, std:
     }
 }
 
-int enc_issue(mp3s_ctx *c, const EncLayout &L, const EncDev &d, hipStream_t tail, hipEvent_t tail_from, hipEvent_t rate_after)
+int enc_issue(mp3s_ctx *c, const EncLayout &L, const EncDev &d, hipStream_t tail, hipEvent_t tail_from, hipEvent_t rate_after, hipEvent_t pcm_read)
 {
     const mp3s_frame_hdr *d_hdr = (const mp3s_frame_hdr *)d.d_in;
     const mp3s_rate_frame *d_rf = (const mp3s_rate_frame *)(d.d_in + L.o_rf);
@@ -186,6 +186,7 @@ int enc_issue(mp3s_ctx *c, const EncLayout &L, const EncDev &d, hipStream_t tail
     const mp3s_chain_seg *d_segs = (const mp3s_chain_seg *)(d.d_in + L.o_segs);
     const int32_t *d_mdct = d.d_mdct_all + (size_t)L.lead * 2304;   // the block's own frames
     int rc = mp3s_encode_transform_dev(c, d.d_pcm, d_hdr, L.n_all, d.d_mdct_all);
+    if (!rc && pcm_read && hipEventRecord(pcm_read, c->stream) != hipSuccess) rc = fail(MP3S_E_HIP, "event record failed");   // the PCM buffer may be written again
     // (the tail of the job in front is through before this job's rate loop starts: tails do not queue up behind one another)
     if (!rc && rate_after && hipStreamWaitEvent(c->stream, rate_after, 0) != hipSuccess) rc = fail(MP3S_E_HIP, "ordering behind the previous tail failed");
     if (!rc && L.n_entries > 0) {

@@ -83,6 +83,18 @@ struct mp3s_ctx {
         scratch_bytes = bytes;
         return 0;
     }
+    // the encode transforms' scratch (subband samples between analysis and MDCT) is a buffer of its own: in the pipe the decode
+    // transforms of the next job run on another stream beside them
+    void *scratch_enc = nullptr; size_t scratch_enc_bytes = 0;
+    int ensure_scratch_enc(size_t bytes)
+    {
+        if (bytes <= scratch_enc_bytes) return 0;
+        if (scratch_enc) { hipFree(scratch_enc); scratch_enc = nullptr; scratch_enc_bytes = 0; }
+        hipError_t e = hipMalloc(&scratch_enc, bytes);
+        if (e != hipSuccess) return fail(MP3S_E_NOMEM, "hipMalloc(%zu) for scratch: %s", bytes, hipGetErrorString(e));
+        scratch_enc_bytes = bytes;
+        return 0;
+    }
 };
 
 // Page-locked host memory for large results (decoded PCM): the device writes it at PCIe speed, no bounce buffer, no
@@ -212,7 +224,7 @@ void cut_window(ParsedStream &p, ScannedStream &sc, long first, long count);
 // host front end of stream i of m (scan; full host parse where the device cannot decode), cut to the stream's window
 int front_end(mp3s_multi &m, int i);
 int decode_transform_chunk(mp3s_ctx *c, const int16_t *d_is, const mp3s_granule_si *d_si, const mp3s_frame_hdr *d_hdr, long first, int cnt,
-                           int nch, int halo, int out_format, void *d_pcm);
+                           int nch, int halo, int out_format, void *d_pcm, hipStream_t stream = nullptr /* null: the context's */);
 // decode the streams `idx` of m (one channel count) as one batch; d_keep: int16 PCM stays on the device there
 int decode_group(mp3s_ctx *c, mp3s_multi &m, const std::vector<int> &idx, int nch, int out_format, void *d_keep = nullptr);
 
@@ -285,7 +297,8 @@ bool enc_variant_buffers(mp3s_ctx *c, const EncLayout &L, EncDev &d);
 // transforms -> rate loop on the guessed cursors -> chain check -> bit packing, all on c->stream, nothing waited for.
 // The packed bytes are final iff verdict[0] == 0 and verdict[1] == 0 (d_small[0], d_small[1]).
 int enc_issue(mp3s_ctx *c, const EncLayout &L, const EncDev &d, hipStream_t tail = nullptr /* chain check + packing on this stream, ordered behind the rate loop through tail_from */,
-              hipEvent_t tail_from = nullptr, hipEvent_t rate_after = nullptr /* the rate loop waits for this event (the previous job's tail) */);
+              hipEvent_t tail_from = nullptr, hipEvent_t rate_after = nullptr /* the rate loop waits for this event (the previous job's tail) */,
+              hipEvent_t pcm_read = nullptr /* recorded behind the encode transforms: the PCM they read may be overwritten */);
 // verdict != 0: the host resolves the chains on the first pass's device buffers (walk, message variants, exact re-runs,
 // packing again); `in` = the host copy of the block.  Pool slots of its own: the entries of the exact re-runs, the variants.
 constexpr int kSlotRedo = 11, kSlotVariants = 19;

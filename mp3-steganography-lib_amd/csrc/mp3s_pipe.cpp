@@ -125,6 +125,8 @@ struct mp3s_pipe {
     size_t max_job_bytes = 0;
     std::vector<Slot> slots;
     hipStream_t s_up = nullptr, s_down = nullptr;
+    hipStream_t s_dec = nullptr;         // the decode transforms of job k+1 under the encode transforms and the rate loop of job k (null: on the compute stream)
+    hipEvent_t e_enc[2] = {nullptr, nullptr}; bool enc_used[2] = {false, false};   // the encode transforms that read PCM buffer x last are done
     hipStream_t s_comp = nullptr, s_ctx = nullptr;   // a compute stream of the pipe's own (pick_lanes), and the context's while the pipe has put its own in its place
     // The Huffman kernel is a latency chain that leaves the vector units mostly idle; the rate loop is bound by them.  The
     // front end of job k+1 therefore runs on a stream of its own, under the encode half of job k, with two sets of
@@ -570,10 +572,15 @@ int issue_fast(mp3s_pipe *P, Job &j, Slot &s, size_t blob_len, int max_p23)
     if (launch_place_frames(P->s_huff, s.d_stage + j.o_fix, j.n_fix, (int16_t *)d_is, (mp3s_granule_si *)d_si))
         return fail(MP3S_E_HIP, "placing the host-decoded frames failed");
     HIPCHK(hipEventRecord(s.e_huff, P->s_huff));
-    HIPCHK(hipStreamWaitEvent(c->stream, s.e_huff, 0));
-    // the PCM buffer of this set may still be read by the download of the decode job that used it last
-    if (P->keep_slot[set] >= 0) HIPCHK(hipStreamWaitEvent(c->stream, P->slots[(size_t)P->keep_slot[set]].e_down, 0));
+    // the decode transforms: on a stream of their own where the pipe has one (they wait for scalar operands half of the time, the
+    // encode transforms and the rate loop of the job in front are bound by the vector units: side by side a batch takes 4 % less)
+    hipStream_t ds = P->s_dec ? P->s_dec : c->stream;
+    HIPCHK(hipStreamWaitEvent(ds, s.e_huff, 0));
+    // the PCM buffer of this set may still be read by the download of the decode job that used it last ...
+    if (P->keep_slot[set] >= 0) HIPCHK(hipStreamWaitEvent(ds, P->slots[(size_t)P->keep_slot[set]].e_down, 0));
     P->keep_slot[set] = j.decode ? j.slot : -1;
+    // ... or by the encode transforms of the job before last (on the compute stream)
+    if (P->s_dec && P->enc_used[set]) HIPCHK(hipStreamWaitEvent(ds, P->e_enc[set], 0));
     // a transform group that starts inside a stream re-runs one frame of it for the state (the chunk's own halo comes first)
     auto inside_stream = [&](long f) {
         size_t k = std::upper_bound(j.stream_first.begin(), j.stream_first.end(), (uint32_t)f) - j.stream_first.begin();
@@ -584,13 +591,14 @@ int issue_fast(mp3s_pipe *P, Job &j, Slot &s, size_t blob_len, int max_p23)
         const int halo = start == halo0 ? halo0 : (inside_stream(start) ? 1 : 0);
         const int cnt = (int)std::min<long>(kDecodeChunk, n - start) + halo;
         const int rc = decode_transform_chunk(c, (const int16_t *)d_is, (const mp3s_granule_si *)d_si, d_dechdr, start - halo, cnt, nch, halo,
-                                              out_format, (uint8_t *)d_keep + (size_t)(start - halo0) * frame_elems * esz);
+                                              out_format, (uint8_t *)d_keep + (size_t)(start - halo0) * frame_elems * esz, ds);
         if (rc) return rc;
     }
-    HIPCHK(hipEventRecord(P->e_dec[set], c->stream));
+    HIPCHK(hipEventRecord(P->e_dec[set], ds));
     P->dec_used[set] = true;
+    if (P->s_dec && !j.decode) HIPCHK(hipStreamWaitEvent(c->stream, P->e_dec[set], 0));   // the encode side starts when the PCM is there
     if (j.decode) {
-        HIPCHK(hipEventRecord(s.e_comp, c->stream));
+        HIPCHK(hipEventRecord(s.e_comp, ds));
         HIPCHK(hipStreamWaitEvent(P->s_down, s.e_comp, 0));
         HIPCHK(hipMemcpyAsync(j.res->big[2].data(), d_small, kSmallHead, hipMemcpyDeviceToHost, P->s_down));
         if (j.walked) HIPCHK(hipMemcpyAsync(j.res->big[1].data(), s.d_stage + s.o_tsel, (size_t)n * 8, hipMemcpyDeviceToHost, P->s_down));
@@ -625,8 +633,10 @@ int issue_fast(mp3s_pipe *P, Job &j, Slot &s, size_t blob_len, int max_p23)
     dev.d_mp3 = s.d_mp3; dev.d_sc = (int32_t *)(s.d_enc + b_mdct + b_ix + b_out + b_en);
     dev.d_small = d_small; dev.direct_status = j.walked;
     if (!enc_variant_buffers(c, L, dev)) return fail(MP3S_E_NOMEM, "hipMalloc failed for %d variant entries", L.n_entries);
-    const int rc = enc_issue(c, L, dev, P->s_tail, s.e_rate, P->s_tail && P->last_tail >= 0 && P->tail_throttle ? P->slots[(size_t)P->last_tail].e_comp : nullptr);
+    const int rc = enc_issue(c, L, dev, P->s_tail, s.e_rate, P->s_tail && P->last_tail >= 0 && P->tail_throttle ? P->slots[(size_t)P->last_tail].e_comp : nullptr,
+                             P->s_dec ? P->e_enc[set] : nullptr);
     if (rc) return rc;
+    if (P->s_dec) P->enc_used[set] = true;
     HIPCHK(hipEventRecord(s.e_comp, P->s_tail ? P->s_tail : c->stream));
     P->last_tail = (int)(&s - P->slots.data());
     HIPCHK(hipStreamWaitEvent(P->s_down, s.e_comp, 0));
@@ -639,7 +649,9 @@ int issue_fast(mp3s_pipe *P, Job &j, Slot &s, size_t blob_len, int max_p23)
 
 void sync_all(mp3s_pipe *P)
 {
-    (void)hipStreamSynchronize(P->s_up); (void)hipStreamSynchronize(P->s_huff); (void)hipStreamSynchronize(P->c->stream);
+    (void)hipStreamSynchronize(P->s_up); (void)hipStreamSynchronize(P->s_huff);
+    if (P->s_dec) (void)hipStreamSynchronize(P->s_dec);
+    (void)hipStreamSynchronize(P->c->stream);
     if (P->s_tail) (void)hipStreamSynchronize(P->s_tail);
     (void)hipStreamSynchronize(P->s_down);
 }
@@ -654,6 +666,7 @@ void run_slow(mp3s_pipe *P, Job &j)   // mu_issue held
         mp[i] = j.clear_all ? nullptr : j.msgs[i].first; ml[i] = j.clear_all ? 0 : j.msgs[i].second;
     }
     (void)hipStreamSynchronize(P->s_huff);   // the synchronous path uses the same Huffman output buffers
+    if (P->s_dec) (void)hipStreamSynchronize(P->s_dec);   // ... and the decode scratch
     (void)hipStreamSynchronize(P->s_down);   // ... and the PCM buffer a download may still be reading
     if (P->s_tail) (void)hipStreamSynchronize(P->s_tail);   // ... and the context's chain scratch and packer words
     j.slow_out.assign((size_t)nf, mp3s_file());
@@ -777,11 +790,11 @@ void free_slot(Slot &s)
 // the front-end stream, two spins on the compute stream, a copy down, chained by events exactly as issue_fast chains a
 // job's stages -- through each rotation of the candidates, and keeps the rotation that got them through fastest
 // (about 1 ms per rotation when a pipe is made).
-struct LaneChoice { hipStream_t ctx_stream; int want_tail; hipStream_t up, down, huff, comp, tail; };
+struct LaneChoice { hipStream_t ctx_stream; int want_tail; hipStream_t up, down, huff, comp, tail, dec; };
 struct LanePool {
     std::vector<LaneChoice> chosen;       // what the rehearsal decided for a context's stream (asked again only by another context)
     hipStream_t hi[4] = {nullptr, nullptr, nullptr, nullptr}, lo[4] = {nullptr, nullptr, nullptr, nullptr}, cs[4] = {nullptr, nullptr, nullptr, nullptr};
-    hipEvent_t ev[4][5] = {};
+    hipEvent_t ev[4][6] = {};
     hipEvent_t t0 = nullptr, t1 = nullptr;
     uint8_t *d_buf = nullptr, *h_buf = nullptr;
     bool ok = false;
@@ -790,16 +803,19 @@ constexpr size_t kRehearseBytes = (size_t)256 << 10;
 
 // tail: the stream a job's last stage (three short spins: selection, chain check, packing) runs on, behind the job's compute
 // stage and beside the next job's; null: on the compute stream itself
-float rehearse(LanePool &lp, hipStream_t comp, hipStream_t up, hipStream_t down, hipStream_t huff, hipStream_t tail = nullptr)
+// dec: the stream a job's decode stage (the first of the two compute spins) runs on, ahead of the compute stage of the job in front
+float rehearse(LanePool &lp, hipStream_t comp, hipStream_t up, hipStream_t down, hipStream_t huff, hipStream_t tail = nullptr, hipStream_t dec = nullptr)
 {
     float ms = 1e9f;
     hipStream_t ts = tail ? tail : comp;
+    hipStream_t dst = dec ? dec : comp;
     bool ok = hipEventRecord(lp.t0, up) == hipSuccess;
     for (int k = 0; k < 4 && ok; k++) {
         ok = hipMemcpyAsync(lp.d_buf + k * kRehearseBytes, lp.h_buf + k * kRehearseBytes, kRehearseBytes, hipMemcpyHostToDevice, up) == hipSuccess &&
              hipEventRecord(lp.ev[k][0], up) == hipSuccess && hipStreamWaitEvent(huff, lp.ev[k][0], 0) == hipSuccess && launch_spin(huff, 60) == 0 &&
-             hipEventRecord(lp.ev[k][1], huff) == hipSuccess && hipStreamWaitEvent(comp, lp.ev[k][1], 0) == hipSuccess && launch_spin(comp, 50) == 0 &&
-             launch_spin(comp, 50) == 0 && launch_noop(comp) == 0 && hipEventRecord(lp.ev[k][2], comp) == hipSuccess;
+             hipEventRecord(lp.ev[k][1], huff) == hipSuccess && hipStreamWaitEvent(dst, lp.ev[k][1], 0) == hipSuccess && launch_spin(dst, 50) == 0;
+        if (ok && dec) ok = hipEventRecord(lp.ev[k][5], dec) == hipSuccess && hipStreamWaitEvent(comp, lp.ev[k][5], 0) == hipSuccess;
+        ok = ok && launch_spin(comp, 50) == 0 && launch_noop(comp) == 0 && hipEventRecord(lp.ev[k][2], comp) == hipSuccess;
         if (ok && tail) ok = hipStreamWaitEvent(tail, lp.ev[k][2], 0) == hipSuccess;
         ok = ok && launch_spin(ts, 10) == 0 && launch_spin(ts, 10) == 0 && launch_spin(ts, 20) == 0 && hipEventRecord(lp.ev[k][4], ts) == hipSuccess &&
              hipStreamWaitEvent(down, lp.ev[k][4], 0) == hipSuccess &&
@@ -809,6 +825,7 @@ float rehearse(LanePool &lp, hipStream_t comp, hipStream_t up, hipStream_t down,
     ok = ok && hipEventRecord(lp.t1, down) == hipSuccess;
     (void)hipStreamSynchronize(up); (void)hipStreamSynchronize(huff); (void)hipStreamSynchronize(comp); (void)hipStreamSynchronize(down);
     if (tail) (void)hipStreamSynchronize(tail);
+    if (dec) (void)hipStreamSynchronize(dec);
     if (!ok || hipEventElapsedTime(&ms, lp.t0, lp.t1) != hipSuccess) return 1e9f;
     return ms;
 }
@@ -817,7 +834,8 @@ std::mutex &lane_mu() { static std::mutex *m = new std::mutex(); return *m; }
 std::vector<LanePool> &lane_pools() { static auto *v = new std::vector<LanePool>(); return *v; }
 
 int pick_lanes(mp3s_ctx *c, hipStream_t *up, hipStream_t *down, hipStream_t *huff, hipStream_t *comp /* a stream to compute on instead of the context's, or null */,
-               hipStream_t *tail /* a stream for the tail of a job, or null */, int want_tail /* 0: none, 1: always, 2: if the rehearsal is faster with it */)
+               hipStream_t *tail /* a stream for the tail of a job, or null */, int want_tail /* 0: none, 1: always, 2: if the rehearsal is faster with it */,
+               hipStream_t *dec = nullptr /* a stream for the decode transforms, or null */, int want_dec = 1)
 {
     std::lock_guard<std::mutex> g(lane_mu());
     auto &pools = lane_pools();
@@ -831,7 +849,7 @@ int pick_lanes(mp3s_ctx *c, hipStream_t *up, hipStream_t *down, hipStream_t *huf
         bool ok = hipEventCreate(&lp.t0) == hipSuccess && hipEventCreate(&lp.t1) == hipSuccess && hipMalloc((void **)&lp.d_buf, 4 * kRehearseBytes) == hipSuccess &&
                   hipHostMalloc((void **)&lp.h_buf, 8 * kRehearseBytes, hipHostMallocDefault) == hipSuccess;
         for (int k = 0; k < 4 && ok; k++)
-            for (int q = 0; q < 5 && ok; q++) ok = hipEventCreateWithFlags(&lp.ev[k][q], hipEventDisableTiming) == hipSuccess;
+            for (int q = 0; q < 6 && ok; q++) ok = hipEventCreateWithFlags(&lp.ev[k][q], hipEventDisableTiming) == hipSuccess;
         for (int i = 0; i < 4 && ok; i++) ok = hipStreamCreateWithPriority(&lp.hi[i], hipStreamNonBlocking, prio_high) == hipSuccess;
         for (int i = 0; i < 4 && ok; i++) ok = hipStreamCreateWithPriority(&lp.lo[i], hipStreamNonBlocking, huff_prio) == hipSuccess;
         for (int i = 0; i < 4 && ok; i++) ok = hipStreamCreateWithFlags(&lp.cs[i], hipStreamNonBlocking) == hipSuccess;
@@ -844,6 +862,7 @@ int pick_lanes(mp3s_ctx *c, hipStream_t *up, hipStream_t *down, hipStream_t *huf
             *up = k.up; *down = k.down; *huff = k.huff;
             if (comp) *comp = k.comp;
             if (tail) *tail = k.tail;
+            if (dec) *dec = k.dec;
             return 0;
         }
     (void)hipStreamSynchronize(c->stream);
@@ -884,10 +903,27 @@ int pick_lanes(mp3s_ctx *c, hipStream_t *up, hipStream_t *down, hipStream_t *huf
         }
         if (best_tail >= 0) *tail = lp.cs[best_tail];
     }
-    if (trace_on()) fprintf(stderr, "mp3s: pipe lanes rehearsed:%s ms -> compute stream %d, rotation %d (%.3f ms), tail stream %d\n", seen.c_str(), best_cs, best, best_ms, best_tail);
+    // a stream for the decode transforms: the candidate (other than the compute and tail streams) that does best, if it gains
+    int best_dec = -1;
+    if (dec) {
+        *dec = nullptr;
+        hipStream_t comp_s = best_cs < 0 ? c->stream : lp.cs[best_cs];
+        hipStream_t tail_s = best_tail >= 0 ? lp.cs[best_tail] : nullptr;
+        float ref_ms = std::min(rehearse(lp, comp_s, lp.hi[best], lp.hi[(best + 1) & 3], lp.lo[best], tail_s), rehearse(lp, comp_s, lp.hi[best], lp.hi[(best + 1) & 3], lp.lo[best], tail_s));
+        float dec_ms = ref_ms * (want_dec == 2 ? 10.f : 0.95f);
+        if (trace_on()) { char b[48]; snprintf(b, sizeof b, " | dec (%.3f):", ref_ms); seen += b; }
+        for (int di = 0; di < 4 && want_dec; di++) {
+            if (di == best_cs || di == best_tail) continue;
+            const float ms = std::min(rehearse(lp, comp_s, lp.hi[best], lp.hi[(best + 1) & 3], lp.lo[best], tail_s, lp.cs[di]), rehearse(lp, comp_s, lp.hi[best], lp.hi[(best + 1) & 3], lp.lo[best], tail_s, lp.cs[di]));
+            if (trace_on()) { char b[32]; snprintf(b, sizeof b, " %.3f", ms); seen += b; }
+            if (ms < dec_ms) { dec_ms = ms; best_dec = di; }
+        }
+        if (best_dec >= 0) *dec = lp.cs[best_dec];
+    }
+    if (trace_on()) fprintf(stderr, "mp3s: pipe lanes rehearsed:%s ms -> compute stream %d, rotation %d (%.3f ms), tail stream %d, decode stream %d\n", seen.c_str(), best_cs, best, best_ms, best_tail, best_dec);
     if (comp) *comp = best_cs >= 0 ? lp.cs[best_cs] : nullptr;
     *up = lp.hi[best]; *down = lp.hi[(best + 1) & 3]; *huff = lp.lo[best];
-    lp.chosen.push_back({c->stream, want_tail, *up, *down, *huff, comp ? *comp : nullptr, tail ? *tail : nullptr});
+    lp.chosen.push_back({c->stream, want_tail, *up, *down, *huff, comp ? *comp : nullptr, tail ? *tail : nullptr, dec ? *dec : nullptr});
     return 0;
 }
 
@@ -910,12 +946,17 @@ int pipe_create(mp3s_ctx *c, int depth, size_t max_job_bytes, int scan_threads, 
     auto destroy = [&](int code, const char *what) {
         for (auto &s : P->slots) free_slot(s);                // (the streams belong to the device: pick_lanes)
         for (hipEvent_t e : P->e_dec) if (e) (void)hipEventDestroy(e);
+        for (hipEvent_t e : P->e_enc) if (e) (void)hipEventDestroy(e);
         return fail(code, "%s", what);
     };
     // copy-up, copy-down and front-end streams that run beside this context's compute stream (pick_lanes above)
-    if (pick_lanes(c, &P->s_up, &P->s_down, &P->s_huff, &P->s_comp, &P->s_tail, (int)c->opt[MP3S_OPT_PIPE_TAIL])) return destroy(MP3S_E_HIP, "stream creation failed");
+    if (pick_lanes(c, &P->s_up, &P->s_down, &P->s_huff, &P->s_comp, &P->s_tail, (int)c->opt[MP3S_OPT_PIPE_TAIL], &P->s_dec, getenv("MP3S_PIPE_DEC") ? atoi(getenv("MP3S_PIPE_DEC")) : 0))   // (a stream of their own for the decode transforms: +4 % on a resident batch
+                                                                                   // fed through four contexts (bench.py --decode-stream on), nothing in this pipe: off)
+        return destroy(MP3S_E_HIP, "stream creation failed");
     if (hipEventCreateWithFlags(&P->e_dec[0], hipEventDisableTiming) != hipSuccess ||
-        hipEventCreateWithFlags(&P->e_dec[1], hipEventDisableTiming) != hipSuccess)
+        hipEventCreateWithFlags(&P->e_dec[1], hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&P->e_enc[0], hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&P->e_enc[1], hipEventDisableTiming) != hipSuccess)
         return destroy(MP3S_E_HIP, "stream creation failed");
     // The tail of a job (selection, chain check, bit packing) on a stream of its own, under the decode transforms of the next job:
     // worth 5 % on a resident batch fed through three contexts (bench.py, region (i)); in this pipe round 2 measured it slower
@@ -1000,6 +1041,7 @@ void mp3s_pipe_destroy(mp3s_pipe *P)
     for (auto &j : P->inflight) { if (j->slow_owner) mp3s_buf_free(j->slow_owner); if (j->blk_owner) mp3s_buf_free(j->blk_owner); }
     for (auto &s : P->slots) free_slot(s);
     for (hipEvent_t e : P->e_dec) (void)hipEventDestroy(e);
+    for (hipEvent_t e : P->e_enc) (void)hipEventDestroy(e);
     delete P;
 }
 
