@@ -405,7 +405,7 @@ typedef struct {
     int32_t regular;              /* 0: use mp3s_scan_stream for this stream (nothing else below is meaningful) */
     int32_t n_frames, nch, sampling_rate, bit_rate, dup_last_frame;
     int32_t max_part2_3_length;   /* over all granules: the bound mp3s_huffman_decode_dev wants */
-    int32_t any_silent;           /* some granule has no big values */
+    int32_t any_silent;           /* some granule has no code book in use (no big values, or book 0 in all its regions) */
     size_t blob_len;              /* bytes of blob the frames take */
     const mp3s_frame_ref *refs;   /* [n_frames]: file_off counted from the start of the file, md_off from 0, stream 0 */
     mp3s_stream_ref stream;       /* base 0, end = len, first_frame 0 */

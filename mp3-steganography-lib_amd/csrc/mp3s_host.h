@@ -105,7 +105,7 @@ struct FrameWalker {
     int error = 0;                       // the code parse_stream returns for this stream (set together with irregular)
     int nch = 0, sampling_rate = 0, bit_rate = 0;   // channel count of the first frame; rate / bitrate of the LAST header walked
     int max_p23 = 0;                     // largest part2_3_length so far
-    bool any_silent = false;             // some granule without big values so far
+    bool any_silent = false;             // some granule without a code book in use so far
     long n_frames = 0;                   // frames emitted so far
     uint32_t md_cursor = 0;              // the next frame's md_off
     long tables_wanted = 0;              // tables4 is filled until this many code books have been counted (0: never)

@@ -741,7 +741,10 @@ long FrameWalker::next(FrameRef *refs, long cap, uint8_t *tables4, uint32_t imag
         for (int u = 0; u < 2 * nch_f; u++) {
             const int b = ubase + 59 * u;
             max_p23 = std::max(max_p23, (int)bits_at(sb, b, 12));
-            if (bits_at(sb, b + 12, 9) == 0) any_silent = true;
+            // a granule without a code book in use (no big values, or book 0 in every region it has): what tables_guess_of calls 0
+            const uint32_t wt = bits_at(sb, b + 33, 16);            // window_switching | the 15 bits behind it
+            const uint32_t books = (wt & 0x8000u) ? (wt >> 2) & 0x3ffu : wt & 0x7fffu;
+            if (bits_at(sb, b + 12, 9) == 0 || books == 0) any_silent = true;
         }
         if (tables4 && nch_f == 2 && tables_frames == n_frames && tables_seen < tables_wanted) {
             for (int gr = 0; gr < 2; gr++)

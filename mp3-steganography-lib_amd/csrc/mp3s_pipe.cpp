@@ -242,7 +242,7 @@ bool prepare_walk(mp3s_pipe *P, Job &j, Slot &s)
             message_frame(j.msgs[i].first, j.msgs[i].second, j.bits[i]);
             if (j.bits[i].size() > 0x7fffffff) return false;
             w.tables_wanted = (long)j.bits[i].size() + (long)j.bits[i].size() / 16 + 64;
-            j.guess[i].resize((size_t)std::min<long>((long)(len / 96 + 16), w.tables_wanted + 8) * 4);
+            j.guess[i].resize((len / 96 + 16) * 4);     // (a silence offers no tables: the counting may go on for the whole file)
         }
         long got = 0;
         while (!w.ended && !w.irregular) {
@@ -325,6 +325,8 @@ bool prepare_walk(mp3s_pipe *P, Job &j, Slot &s)
         if (!j.res->big[0].reserve(j.L.mp3_bytes) || !j.res->big[2].reserve(small_bytes(j.L.n_segs))) return false;
         j.res->mp3 = j.res->big[0].data();
     }
+    if (trace_on() && !j.decode) fprintf(stderr, "mp3s:   walk job %lld: %d stream(s), redo launches %d, variant entries %d, first stream: any_silent %d, tables known for %d units, reach %d\n",
+                                         (long long)j.ticket, nf, (int)j.L.redo, j.L.n_entries, j.segs[0].any_silent, j.segs[0].n_guess, j.segs[0].reach);
     j.o_fix = (j.o_encblk + enc_bytes + 15) & ~(size_t)15;
     if (j.o_fix != s.o_in + s.in_cap) std::memmove(s.h_stage + j.o_fix, fix, (size_t)j.n_fix * kPlaceEntry);
     j.o_refs = (j.o_fix + (size_t)j.n_fix * kPlaceEntry + 15) & ~(size_t)15;
@@ -1332,7 +1334,23 @@ void destroy_own_pipe(mp3s_ctx *c)   // (the context is being destroyed)
     forget_lanes(c);
 }
 
+constexpr int kRunWhole = 2;             // run_file_impl: the stream inherits scalefactors across frames -- once more, as one piece
+constexpr long kWholeFrames = 4 * kDecodeChunk;   // ... if it is not longer than this (the slots are sized for the piece)
+
+static int run_file_impl(mp3s_ctx *c, const uint8_t *mp3, size_t len, int mode, const uint8_t *utf8, size_t n_msg, int out_format, mp3s_buf **owner, RunResult *out, bool whole);
+
 int run_file(mp3s_ctx *c, const uint8_t *mp3, size_t len, int mode, const uint8_t *utf8, size_t n_msg, int out_format, mp3s_buf **owner, RunResult *out)
+{
+    int rc = run_file_impl(c, mp3, len, mode, utf8, n_msg, out_format, owner, out, false);
+    // A granule of a mixed block (or one behind a short granule 0 with scfsi set) reads scalefactors written many frames earlier
+    // (SURVEY D10); the Huffman kernel finds them by walking back through the stream's side records, which a chunk that
+    // starts in the middle of the stream cannot.  Such a file goes through the same stages in ONE piece (the transforms still
+    // in groups): 1.7 instead of 4.4 ms for 10 000 frames, which the synchronous path spends in the host parser.
+    if (rc == kRunWhole) rc = run_file_impl(c, mp3, len, mode, utf8, n_msg, out_format, owner, out, true);
+    return rc == kRunWhole ? kRunFallback : rc;
+}
+
+static int run_file_impl(mp3s_ctx *c, const uint8_t *mp3, size_t len, int mode, const uint8_t *utf8, size_t n_msg, int out_format, mp3s_buf **owner, RunResult *out, bool whole)
 {
     if (!c->opt[MP3S_OPT_FILE_PIPELINE] || !c->opt[MP3S_OPT_DEVICE_PARSE]) return kRunFallback;
     const bool decode = mode == kRunDecode;
@@ -1368,6 +1386,10 @@ int run_file(mp3s_ctx *c, const uint8_t *mp3, size_t len, int mode, const uint8_
     }
     if (c->opt[MP3S_OPT_FIRST_CHUNK_FRAMES] > 0) first_chunk = (long)std::min<int64_t>(c->opt[MP3S_OPT_FIRST_CHUNK_FRAMES], kMaxChunk);
     first_chunk = std::min(kMaxChunk, std::max(first_chunk, reach_frames));
+    if (whole) {
+        if (n_est > kWholeFrames) { c->run_stats.fallbacks++; return kRunFallback; }
+        first_chunk = chunk = n_est + 64;          // one piece
+    }
     const long cap_frames = std::max(chunk, first_chunk) + 2;
     // (a message that reaches further than a chunk: the synchronous path's plan over the whole file)
     if (reach_frames > kMaxChunk || ensure_own_pipe(c, (size_t)cap_frames * (size_t)(fs0 + 2) + 4096)) { c->run_stats.fallbacks++; return kRunFallback; }
@@ -1392,13 +1414,13 @@ int run_file(mp3s_ctx *c, const uint8_t *mp3, size_t len, int mode, const uint8_
     int rate = 0, kbps = 0, nch = 0;
     const size_t esz = pcm_elem(out_format);
     size_t res_cap = 0;
-    auto fallback = [&](const char *why) {
-        if (trace_on()) fprintf(stderr, "mp3s: run_file: %s -> synchronous path\n", why);
-        c->run_stats.fallbacks++;
+    auto fallback = [&](const char *why, int code = kRunFallback) {
+        if (trace_on()) fprintf(stderr, "mp3s: run_file: %s -> %s\n", why, code == kRunWhole ? "once more, in one piece" : "synchronous path");
+        if (code == kRunFallback) c->run_stats.fallbacks++;
         sync_all(P);
         for (auto &s : P->slots) s.busy = false;
         P->keep_slot[0] = P->keep_slot[1] = -1;
-        return kRunFallback;
+        return code;
     };
     // retire chunk k: wait for its results, settle its verdict and its carry
     int64_t hide_offset = 0;
@@ -1413,7 +1435,7 @@ int run_file(mp3s_ctx *c, const uint8_t *mp3, size_t len, int mode, const uint8_
         if (!ok && !resolved) return kRunFallback;
         if (resolved) c->run_stats.resolved++;
         const int32_t *small = (const int32_t *)j->res->big[2].data();
-        if (j->walked && (small[4] & kParseInherits) && chunks.size() + (w.ended ? 0 : 1) > 1) return kRunFallback;   // scalefactors inherited across frames: the stream in one piece
+        if (j->walked && (small[4] & kParseInherits) && chunks.size() + (w.ended ? 0 : 1) > 1) return kRunWhole;   // scalefactors inherited across frames: the stream in one piece
         if (!decode) {
             EncSeg &sg = j->segs[0];
             if (resolved) {
@@ -1495,7 +1517,7 @@ int run_file(mp3s_ctx *c, const uint8_t *mp3, size_t len, int mode, const uint8_
         const double t_walk1 = trace_on() ? now_ms() : 0;
         if (k >= (size_t)P->depth) {               // the slot's previous chunk first
             const int r = retire(k - (size_t)P->depth);
-            if (r) return r == kRunFallback ? fallback("a chunk needs the synchronous path") : r;
+            if (r) return r == kRunFallback || r == kRunWhole ? fallback("a chunk needs another path", r) : r;
         }
         const double t_ret = trace_on() ? now_ms() : 0;
         chunks.emplace_back();
@@ -1515,7 +1537,7 @@ int run_file(mp3s_ctx *c, const uint8_t *mp3, size_t len, int mode, const uint8_
     // again takes a slot, and with it the buffers of the chunk that had it last)
     for (size_t k = 0; k < chunks.size(); k++) {
         const int r = retire(k);
-        if (r) return r == kRunFallback ? fallback("a chunk needs the synchronous path") : r;
+        if (r) return r == kRunFallback || r == kRunWhole ? fallback("a chunk needs another path", r) : r;
     }
     mp3s_carry real = {};
     for (size_t k = 0; k < chunks.size(); k++) {
@@ -1533,7 +1555,7 @@ int run_file(mp3s_ctx *c, const uint8_t *mp3, size_t len, int mode, const uint8_
                 rc.done = false;
                 r = issue(k, &real);
                 if (!r) r = retire(k);
-                if (r) return r == kRunFallback ? fallback("a chunk needs the synchronous path") : r;
+                if (r) return r == kRunFallback || r == kRunWhole ? fallback("a chunk needs another path", r) : r;
                 sync_all(P);
             } else {
                 // nothing in the chunk looked at the carry: every chain entry it hands on is its own; only the count of tables

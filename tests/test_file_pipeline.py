@@ -107,8 +107,14 @@ def test_what_the_chunks_do_not_take_falls_back(ctx, mlib, golden_dir):
     data = open(os.path.join(golden_dir, "test.mp3"), "rb").read()
     tail = data + b"\x00" * 700                                                       # a bad header: the last frame is repeated (D12)
     with options(ctx, chunk_frames=16):
+        # scalefactors inherited across frames: the chunks give up, the file goes through the stages in one piece (not the host parser)
         s0 = ctx.run_stats()
         assert legacy(ctx, ctx.decode_stream, mixed, mlib.MP3S_PCM_F64)["pcm"].tobytes() == ctx.decode_stream(mixed, mlib.MP3S_PCM_F64)["pcm"].tobytes()
+        s1 = ctx.run_stats()
+        assert s1["files"] - s0["files"] == 1 and s1["chunks"] - s0["chunks"] == 1 and s1["fallbacks"] == s0["fallbacks"], (s0, s1)
+        joint = frame_synth.make_stream(10, 80, mode=1, mode_ext=2, block_types=(0, 2), allow_mixed=True)      # the same for a re-encode
+        assert same_file(legacy(ctx, ctx.hide_message, joint, "mixed blocks"), ctx.hide_message(joint, "mixed blocks"))
+        s0 = ctx.run_stats()
         assert bytes(legacy(ctx, ctx.decode_file, tail)["data"]) == bytes(ctx.decode_file(tail)["data"])
         assert same_file(legacy(ctx, ctx.hide_message, tail, "abc"), ctx.hide_message(tail, "abc"))
         with pytest.raises(mlib.Mp3sError) as e1:
@@ -116,7 +122,7 @@ def test_what_the_chunks_do_not_take_falls_back(ctx, mlib, golden_dir):
         assert e1.value.code == mlib.E_UNSUPPORTED
         assert ctx.decode_file(b"\x00" * 10)["n_frames"] == 0                         # no sync: an empty WAV, as the reference writes
         s1 = ctx.run_stats()
-        assert s1["fallbacks"] - s0["fallbacks"] >= 4, (s0, s1)
+        assert s1["fallbacks"] - s0["fallbacks"] >= 3, (s0, s1)
 
 
 def test_long_file_automatic_chunks_and_the_facade(ctx, mlib, tmp_path):
