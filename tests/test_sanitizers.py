@@ -39,5 +39,6 @@ def test_host_code_under_asan_ubsan(mlib, golden_dir, tmp_path):
     env.pop("LD_PRELOAD", None)
     r = subprocess.run([str(out / "parse_mutants"), str(indir)], capture_output=True, text=True, env=env, timeout=600)
     assert r.returncode == 0 and "files" in r.stdout, (r.stdout + r.stderr)[-3000:]
+    assert int(r.stdout.split("walked")[1].split()[0]) > 100, r.stdout           # the frame walk took (and matched the scan on) many of them
     r = subprocess.run([str(out / "files_messages"), "10"], capture_output=True, text=True, env=env, timeout=600)
     assert r.returncode == 0 and "reveal bytes" in r.stdout, (r.stdout + r.stderr)[-3000:]

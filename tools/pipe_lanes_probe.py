@@ -13,7 +13,7 @@ msg = "The quick brown fox jumps over the lazy dog, again & again, 0123"
 ctxs = [_lib.Context(0) for _ in range(int(sys.argv[1]) if len(sys.argv) > 1 else 4)]
 for rep in range(2):
     for i, pctx in enumerate(ctxs):
-        pipe = _lib.Pipe(pctx, depth=4, max_job_bytes=len(mp3) + (1 << 16), scan_threads=2)
+        pipe = _lib.Pipe(pctx, depth=4, max_job_bytes=len(mp3) + (1 << 16), scan_threads=1)
         sub = got = 0
         t0 = None
         while got < nb + 20:
