@@ -4,11 +4,17 @@
 //                   granule*channel of the batch.  The bit stream of a granule is serial, but granule boundaries
 //                   come from the side info (part2_3_length), so one THREAD decodes one granule*channel (granule 1
 //                   re-reads the scalefactors scfsi lets it share with granule 0 from granule 0's own bits): a
-//                   10 000-frame batch gives 40 000 independent threads.  Code books: 9-bit first-level table and second-level
-//                   tables for the rare longer codes, both in LDS (same prefix codes the reference searches
-//                   linearly, so the same symbol and length come out).  Quirks kept: D1 (count1 stops at line 572,
+//                   10 000-frame batch gives 40 000 independent threads.  Code books: a first-level table per book indexed
+//                   by up to 10 bits and second-level tables for the longer codes, both in LDS (same prefix codes the
+//                   reference searches linearly, so the same symbol and length come out).  A lane is a chain of dependent
+//                   look-ups: the loop is written so that between two of them lie the shift of the bit window and the index
+//                   arithmetic only -- signs, stores and the refill of the window run while the next look-up is in flight.
+//                   Quirks kept: D1 (count1 stops at line 572,
 //                   no overrun discard), D2 (books 4/14 read no bits), bits past the buffer read as 0.
 #pragma once
+#ifndef MP3S_HUF_CUT
+#define MP3S_HUF_CUT 0
+#endif
 
 namespace mp3s {
 
@@ -46,6 +52,20 @@ struct BitStream {
             nxt = lds[idx * T];
         }
     }
+    // the same without a branch, for the symbol loops (every lane refills at its own pace: as a branch it is taken by some
+    // lane almost every time, and the look-up behind it would wait for the branch); re-reads the staged word when nothing
+    // was appended
+    __device__ __forceinline__ void refill_always()
+    {
+        const bool need = valid <= 32;
+        const uint64_t add = (uint64_t)nxt << ((32 - valid) & 31);
+        win |= need ? add : 0ull;
+        valid += need ? 32 : 0;
+        const uint32_t up = idx < last ? idx + 1 : last;
+        idx = need ? up : idx;
+        nxt = lds[idx * T];
+    }
+    __device__ __forceinline__ uint32_t hi() const { return (uint32_t)(win >> 32); }
     __device__ __forceinline__ uint32_t top(int n) const { return (uint32_t)(win >> (64 - n)); }   // 1 <= n <= 32
     __device__ __forceinline__ void skip(int n) { win <<= n; valid -= n; }
     __device__ __forceinline__ uint32_t get(int n)   // n <= 4 (scalefactors)
@@ -160,34 +180,31 @@ __global__ __launch_bounds__(WAVES * 64) void k_dec_huffman(
     int32_t *__restrict__ sync /* {finished workgroups, error bits}: zero between launches, owned by the context; null: status[0] was
                                   zeroed by the caller and takes the error bits directly */)
 {
-    __shared__ uint16_t fast[15][HUFF_L1_N];
-    __shared__ uint16_t lut2[HUFF_L2_N];    // second-level tables for the codes longer than the first-level index
-    __shared__ uint16_t quad[64];
-    __shared__ uint16_t tinfo[32];        // table_select -> first-level table id | linbits << 8
+#if MP3S_HUF_CUT == 9
+    const unsigned long long clk0 = __builtin_readcyclecounter();
+#endif
+    __shared__ __attribute__((aligned(16))) uint16_t tab[HUF_TAB_N];   // first level | second level | count1 (mp3s_tables.h)
+    __shared__ uint32_t tinfo[32];        // table_select -> byte offset of the first level << 16 | (32 - w) % 32 << 8 | linbits << 4 | w
     __shared__ int wg_err;                // the group's error bits
-    extern __shared__ uint32_t words[];   // [W][COLS]
+    extern __shared__ uint32_t words[];   // [W][COLS] staged bits, [WAVES][LANES][17] output tiles
     constexpr int T = WAVES * 64, COLS = WAVES * LANES;
     {
-        const uint4 *src = reinterpret_cast<const uint4 *>(&c_tab.huff_fast[0][0]);
-        uint4 *dst = reinterpret_cast<uint4 *>(&fast[0][0]);
-        constexpr int N16 = 15 * HUFF_L1_N * 2 / 16, ROUNDS = (N16 + T - 1) / T;
-        uint4 v[ROUNDS <= 8 ? ROUNDS : 8];
-        if constexpr (ROUNDS <= 8) {      // every load in flight before the first LDS write
+        const uint4 *src = reinterpret_cast<const uint4 *>(c_tab.huf_tab);
+        uint4 *dst = reinterpret_cast<uint4 *>(tab);
+        constexpr int N16 = HUF_TAB_N * 2 / 16, ROUNDS = (N16 + T - 1) / T;
+        static_assert(HUF_TAB_N % 8 == 0, "16-byte copies");
+        uint4 v[ROUNDS];
 #pragma unroll
-            for (int r = 0; r < ROUNDS; r++) { const int i = threadIdx.x + r * T; v[r] = src[i < N16 ? i : N16 - 1]; }
+        for (int r = 0; r < ROUNDS; r++) { const int i = threadIdx.x + r * T; v[r] = src[i < N16 ? i : N16 - 1]; }   // every load in flight before the first LDS write
 #pragma unroll
-            for (int r = 0; r < ROUNDS; r++) { const int i = threadIdx.x + r * T; if (i < N16) dst[i] = v[r]; }
-        } else {
-#pragma unroll 6
-            for (int i = threadIdx.x; i < N16; i += T) dst[i] = src[i];
-        }
-        for (int i = threadIdx.x; i < HUFF_L2_N / 2; i += T)
-            reinterpret_cast<uint32_t *>(lut2)[i] = reinterpret_cast<const uint32_t *>(c_tab.huff_l2)[i];
-        if (threadIdx.x < 64) quad[threadIdx.x] = c_tab.quad_fast[threadIdx.x];
-        if (threadIdx.x < 32) tinfo[threadIdx.x] = (uint16_t)(c_tab.huff_lut_id[threadIdx.x] | (c_tab.linbits[threadIdx.x] << 8));
+        for (int r = 0; r < ROUNDS; r++) { const int i = threadIdx.x + r * T; if (i < N16) dst[i] = v[r]; }
+        if (threadIdx.x < 32) tinfo[threadIdx.x] = c_tab.huf_tinfo[threadIdx.x];
         if (threadIdx.x == 0) wg_err = 0;
     }
     __syncthreads();
+#if MP3S_HUF_CUT == 9
+    const unsigned long long clk1 = __builtin_readcyclecounter();
+#endif
     const int lane = threadIdx.x & 63, col = (int)(threadIdx.x >> 6) * LANES + lane;
     const long tid = (long)blockIdx.x * COLS + col;
     bool worker = lane < LANES && tid < (long)n_frames * 4 && (int)(tid & 1) < nch;
@@ -197,12 +214,17 @@ __global__ __launch_bounds__(WAVES * 64) void k_dec_huffman(
     int err = 0;
     // Nothing is cleared in front of this kernel: every unit writes all of its 288 sample pairs and its whole side record
     // (the second channel's unit of a mono stream: zeros), and the status words are plain stores.
-    if (!worker && !host_frame && lane < LANES && tid < (long)n_frames * 4) {
-        uint32_t *z = reinterpret_cast<uint32_t *>(is) + tid * 288;
-        for (int j = 0; j < 288; j++) z[j] = 0;
+    const bool has_row = lane < LANES && tid < (long)n_frames * 4 && !host_frame;   // this lane's 288 sample pairs are written here
+    if (!worker && has_row) {
         uint32_t *zr = reinterpret_cast<uint32_t *>(si_out + tid);
         for (int j = 0; j < 18; j++) zr[j] = 0;
     }
+    // what the symbol loop below needs of a lane (a lane without a unit: nothing to decode, zeros if it has a row)
+    BitStream<COLS> br;
+    br.lds = words + (lane < LANES ? col : (int)(threadIdx.x >> 6) * LANES); br.last = 0; br.idx = 0; br.nxt = 0; br.win = 0; br.valid = 64;
+    uint32_t bit = 0, max_bit = 0, ti0 = 0, ti1 = 0, ti2 = 0, tic1a = 0, tic1b = 0;
+    int r0p = 0, r1p = 0, bvp = 0;         // region bounds and big values in pairs
+    bool c1_open = false;
     if (worker) {
     const int f = (int)(tid >> 2), k = (int)(tid & 3), gr = k >> 1, ch = k & 1;
     SideRegs fs;
@@ -214,7 +236,7 @@ __global__ __launch_bounds__(WAVES * 64) void k_dec_huffman(
     // bit offset of this unit and (for scfsi) of granule 0 of the same channel: units are laid out gr-major
     const uint32_t l0 = fs.p23(0), l1 = nch > 1 ? fs.p23(1) : 0u, l2 = fs.p23(2);
     const uint32_t bit_g0 = ch ? l0 : 0u;
-    uint32_t bit = (k >= 1 ? l0 : 0u) + (k >= 2 ? l1 : 0u) + (k >= 3 ? l2 : 0u);
+    bit = (k >= 1 ? l0 : 0u) + (k >= 2 ? l1 : 0u) + (k >= 3 ? l2 : 0u);
     if (nch == 1) bit = gr ? l0 : 0u;
     const uint32_t u0 = fs.unit_dw(k, 0), u1 = fs.unit_dw(k, 1), u2 = fs.unit_dw(k, 2), u3 = fs.unit_dw(k, 3), u4 = fs.unit_dw(k, 4);
     const uint32_t part2_3_length = u0 & 0xffffu, big_values = u0 >> 16;
@@ -223,10 +245,9 @@ __global__ __launch_bounds__(WAVES * 64) void k_dec_huffman(
     const uint32_t region0_count = u3 & 0xff, region1_count = (u3 >> 8) & 0xff;
     const uint32_t count1table_select = u4 & 0xff;
     const uint32_t scfsi = ch ? fs.d[4] : fs.d[3];   // one byte per band
-    const uint32_t max_bit = bit + part2_3_length;
+    max_bit = bit + part2_3_length;
     const uint32_t *mdw = reinterpret_cast<const uint32_t *>(blob + md_off);
     if ((int)part2_3_length > max_bits) err |= MP3S_HS_HINT;   // the caller's bound on part2_3_length does not hold
-    BitStream<COLS> br;
     {
         // stage the words covering this granule: loads first (clamped to a word inside the zero bytes that follow the
         // frame), then the big-endian swap, the masking of bytes past md_len (decoder/util.py:41-43) and the LDS writes
@@ -316,9 +337,7 @@ __global__ __launch_bounds__(WAVES * 64) void k_dec_huffman(
         for (int s = 8; s < 12; s++)
             for (int w = 0; w < 3; w++) sf_s[w * 13 + s] = (uint8_t)huf_inherit_short(blob, side, f, stream_first, gr, ch, nch, w, s);
     }
-    // ---- big values (Frame.py:458-518).  One flat loop over the pairs: the region (and with it the code book) is
-    //      looked up per pair, so a wave runs for its longest granule, not for the longest region 0 + region 1 + region 2.
-    uint32_t *smp = reinterpret_cast<uint32_t *>(is) + tid * 288;   // pair j
+    // ---- big values and count1: set up here, decoded below by all lanes of the wave in step
     int region0, region1;
     bool ok = true;
     if (short_win) { region0 = 36; region1 = 576; }
@@ -329,82 +348,141 @@ __global__ __launch_bounds__(WAVES * 64) void k_dec_huffman(
     }
     const int bv2 = (int)big_values * 2;
     if (bv2 > 576) err |= MP3S_HS_BIG_VALUES;                     // the reference runs off its sample array (IndexError)
-    int sample = 0;
     if (ok && !err) {
-        const uint32_t ti0 = tinfo[(u2 >> 8) & 31], ti1 = tinfo[(u2 >> 16) & 31], ti2 = tinfo[(u2 >> 24) & 31];
-        while (sample < bv2) {
-            // big values that run past part2_3_length read on into the data that follows (the reference has one bit
-            // cursor per frame); the staged window covers one code word of that, a second one is reported
-            if (bit > max_bit) { err |= MP3S_HS_OVERRUN; break; }
-            const uint32_t ti = sample < region0 ? ti0 : (sample < region1 ? ti1 : ti2);
-            const int lut = (int)(ti & 0xff), lb = (int)(ti >> 8);
-            if (lut == 255) {                                     // books 0, 4, 14: zeros, no bits (D2): skip the region
-                const int rend = sample < region0 ? region0 : (sample < region1 ? region1 : bv2);
-                const int to = rend < bv2 ? rend : bv2;           // region bounds are even
-                for (int j = sample >> 1; j < (to >> 1); j++) smp[j] = 0;
-                sample = to;
-                continue;
+        ti0 = tinfo[(u2 >> 8) & 31]; ti1 = tinfo[(u2 >> 16) & 31]; ti2 = tinfo[(u2 >> 24) & 31];
+        // count1: book A on ten bits, book B on eight; (v, w) and (x, y) of a quadruple are two look-ups of the same bits
+        constexpr uint32_t C1 = (uint32_t)(HUF_L1_N + HUF_L2_N) * 2;
+        tic1b = count1table_select ? ((C1 + 4096 + 512) << 16) | (24u << 8) | 8u : ((C1 + 2048) << 16) | (22u << 8) | 10u;
+        tic1a = (tic1b - ((count1table_select ? 512u : 2048u) << 16)) | (1u << 13);   // bit 13: the window stays where it is
+        r0p = region0 >> 1; r1p = region1 >> 1; bvp = (int)big_values;
+        c1_open = true;
+        br.refill();
+    }
+    }   // worker
+    // ---- big values (Frame.py:458-518) and count1 quadruples (:521-554, D1).  The lanes of a wave go through the 288 pairs of
+    //      their units in step: in iteration p a lane emits pair p -- a big-values symbol, half of a count1 quadruple, or zero --
+    //      into the wave's tile in LDS, and every 16 iterations the wave writes the tile out as whole 64-byte pieces of the
+    //      rows.  A wave is a chain of dependent look-ups and runs as fast as it issues instructions, so an iteration is
+    //      one look-up and as little around it as the formats allow: the three kinds of pairs share ONE entry format (count1:
+    //      two entries per quadruple, the second moves the window; zeros: entry 0), the window shift and the index of the
+    //      NEXT look-up come first, signs, values and the refill of the window follow while it is in flight.
+    {
+#if MP3S_HUF_CUT == 9
+        const unsigned long long clk2 = __builtin_readcyclecounter();
+#endif
+        typedef short s16x2 __attribute__((ext_vector_type(2)));
+        uint32_t *tile = words + (size_t)W * COLS + (threadIdx.x >> 6) * ((LANES + 1) * 17);
+        uint32_t *const my_tile = tile + (lane < LANES ? lane : LANES) * 17;   // (a lane without a row: the spare one)
+        const unsigned long long rows = __ballot(has_row);
+        const long tid0 = (long)blockIdx.x * COLS + (long)(threadIdx.x >> 6) * LANES;   // the wave's first unit
+        uint32_t *const is32 = reinterpret_cast<uint32_t *>(is);
+        const char *tabb = reinterpret_cast<const char *>(tab);
+        // The books of a lane, pair by pair: region 0 / 1 / 2 up to `bve`, then the two count1 entries in turn (c1n: the next
+        // one, tog: what turns one into the other), zeros (book 0) once count1 has ended.  What ends a phase early is an EVENT:
+        // big values or a quadruple that start at or behind the unit's last bit (mb), looked for with one compare.
+        int bve = bvp;
+        uint32_t c1n = c1_open ? tic1a : 0u, tog = c1_open ? tic1a ^ tic1b : 0u;
+        uint32_t mb = c1_open ? max_bit : 0xffffffffu;
+        uint32_t ti = 0 < r0p ? ti0 : (0 < r1p ? ti1 : ti2);
+        if (!(0 < bve)) { ti = c1n; c1n ^= tog; }
+        uint32_t e = *reinterpret_cast<const uint16_t *>(tabb + (ti >> 16) + 2 * __builtin_amdgcn_ubfe(br.hi(), (ti >> 8) & 31, ti & 15));
+        int p = 0;
+        for (;; p++) {
+            // -- what does not depend on the look-up in flight
+            const uint32_t chk = (ti >> 13) & 1;                  // 1: (v, w) of a quadruple -- the entry does not move the window
+            const uint32_t am = chk ? 0u : 31u;                   // (code words of up to 19 bits + 2 signs)
+            // big values that run past part2_3_length read on into the data that follows (the reference has one bit cursor per
+            // frame; the staged window covers one code word of that, a second one is reported); a quadruple is only started
+            // in front of the last bit and of line 572 (D1)
+            if (__any(bit + chk > mb) || p >= 286) {
+                if (bit + chk > mb || (p >= 286 && chk)) {
+                    if (!chk) err |= MP3S_HS_OVERRUN;
+                    bve = 0; c1n = 0; tog = 0; mb = 0xffffffffu;
+                    e = 0;                                        // entry 0: nothing
+                }
             }
-            br.refill();
-            const uint32_t window = br.top(32);
-            const uint32_t e = fast[lut][window >> (32 - HUFF_FAST_BITS)];
-            int len = 0, sym = -1;
-            uint32_t leaf = e;
-            if (e & 0x8000u) {                                    // longer than the index: the next k bits pick the leaf
-                const uint32_t k = (e >> 11) & 15;
-                leaf = lut2[2 * (e & 0x7ffu) + ((window << HUFF_FAST_BITS) >> (32 - k))];
-            }
-            if (leaf) { sym = (int)(leaf & 0xff); len = (int)(leaf >> 8); }
-            if (sym >= 0) {
-                // linbits and sign bits follow the code word: x linbits, x sign, y linbits, y sign (:499-513)
-                int v0 = sym >> 4, v1 = sym & 15;
-                br.skip(len);
-                int used = len;
-                if (lb && (v0 == 15 || v1 == 15)) {               // escape values: up to 2 x (13 + 1) more bits
+            const int pn = p + 1;
+            const bool more_bv = pn < bve;
+            const uint32_t tn = more_bv ? (pn < r0p ? ti0 : (pn < r1p ? ti1 : ti2)) : c1n;
+            c1n ^= more_bv ? 0u : tog;
+            const uint32_t hi_old = br.hi();
+            // -- the entry
+            uint32_t adv = (e >> 8) & 15;          // code word + sign bits (books 0, 4, 14 -- entry 0: nothing, D2)
+            uint32_t out_esc = 0;
+            bool escaped = false;
+            if (e & 0xc000u) {                     // (big-values books only)
+                if (e & 0x8000u) {                 // longer than the index: the next k bits pick the leaf
+                    const uint32_t k = (e >> 11) & 15, w = ti & 15;
+                    e = tab[HUF_L1_N + 2 * (e & 0x7ffu) + ((hi_old << w) >> (32 - k))];
+                    adv = w + ((e >> 8) & 15);
+                }
+                if (e & 0x4000u) {                 // escape values: x linbits, x sign, y linbits, y sign (:499-513), up to 2 x (13 + 1) more bits
+                    int v0 = (int)((e >> 4) & 15), v1 = (int)(e & 15);
+                    const int lb = (int)((ti >> 4) & 15), len = (int)adv - (v0 != 0) - (v1 != 0);
+                    int used = len;
+                    br.skip(len);
                     br.refill();
                     if (v0 == 15) { v0 += (int)br.top(lb); br.skip(lb); used += lb; }
                     if (v0) { if (br.top(1)) v0 = -v0; br.skip(1); used += 1; }
                     if (v1 == 15) { v1 += (int)br.top(lb); br.skip(lb); used += lb; }
                     if (v1) { if (br.top(1)) v1 = -v1; br.skip(1); used += 1; }
-                } else {
-                    const uint32_t sg = br.top(2);
-                    const int n0 = v0 != 0, n1 = v1 != 0;
-                    if (n0 && (sg >> 1)) v0 = -v0;
-                    if (n1 && ((n0 ? sg : sg >> 1) & 1)) v1 = -v1;
-                    br.skip(n0 + n1); used += n0 + n1;
+                    br.refill();
+                    bit += (uint32_t)used;
+                    out_esc = (uint32_t)(uint16_t)v0 | ((uint32_t)(uint16_t)v1 << 16);
+                    escaped = true;
                 }
-                bit += used;
-                smp[sample >> 1] = (uint32_t)(uint16_t)v0 | ((uint32_t)(uint16_t)v1 << 16);
-            } else smp[sample >> 1] = 0;                          // no code word matches: the reference leaves the pair at zero
-            sample += 2;
-        }
-        // ---- count1 quadruples (Frame.py:521-554, D1)
-        while (!err && bit < max_bit && sample + 4 < 576) {
-            br.refill();
-            uint32_t window = br.top(32);
-            int val, used;
-            if (count1table_select) { val = (int)((window >> 28) ^ 15u); used = 4; }
-            else {
-                const uint32_t s = quad[window >> 26];
-                val = s ? (int)(s & 15) : 0;
-                used = (int)(s >> 4);
             }
-            window <<= used;
-            int q[4];
+            const uint32_t step = escaped ? 0u : adv & am;
+            br.win <<= step;
+            // the next pair's look-up goes out before this pair's values are put together
+            const uint32_t en = *reinterpret_cast<const uint16_t *>(tabb + (tn >> 16) + 2 * __builtin_amdgcn_ubfe(br.hi(), (tn >> 8) & 31, tn & 15));
+            __builtin_amdgcn_sched_barrier(0);
+            br.valid -= (int)step; bit += step;
+            // signs: two bits of the window, x's above y's (where they are: the entry); negating a zero changes nothing, so a
+            // bit that is no sign may land on a zero
+            const uint32_t sg = __builtin_amdgcn_ubfe(hi_old, 30 + ((e >> 12) & 3) - adv, 2);
+            const uint32_t mag = ((e >> 4) & 15) | ((e & 15) << 16);
+            const uint32_t neg = ((uint32_t)__builtin_amdgcn_sbfe(sg, 1, 1) & 0xffffu) | ((uint32_t)__builtin_amdgcn_sbfe(sg, 0, 1) & 0xffff0000u);
+            const uint32_t val = __builtin_bit_cast(uint32_t, __builtin_bit_cast(s16x2, mag ^ neg) - __builtin_bit_cast(s16x2, neg));
+            my_tile[p & 15] = escaped ? out_esc : val;
+            br.refill_always();
+            ti = tn; e = en;
+            if ((p & 15) == 15) {
+                // the tile: 16 pairs of every row, 64 bytes each, four lanes per row
+                __builtin_amdgcn_wave_barrier();
 #pragma unroll
-            for (int i = 0; i < 4; i++) {
-                q[i] = (val >> (3 - i)) & 1;
-                if (q[i]) { if (window >> 31) q[i] = -1; window <<= 1; used += 1; }
+                for (int item = lane; item < LANES * 4; item += 64) {
+                    const int r = item >> 2, q = item & 3;
+                    if ((rows >> r) & 1) {
+                        const uint32_t *t4 = tile + r * 17 + 4 * q;
+                        const uint4 v = make_uint4(t4[0], t4[1], t4[2], t4[3]);
+                        *reinterpret_cast<uint4 *>(is32 + (tid0 + r) * 288 + (p - 15) + 4 * q) = v;
+                    }
+                }
+                __builtin_amdgcn_wave_barrier();
+                if (p == 287 || !__any(p + 1 < bve || tog != 0)) break;
             }
-            br.skip(used);
-            bit += used;
-            smp[sample >> 1] = (uint32_t)(uint16_t)q[0] | ((uint32_t)(uint16_t)q[1] << 16);
-            smp[(sample >> 1) + 1] = (uint32_t)(uint16_t)q[2] | ((uint32_t)(uint16_t)q[3] << 16);
-            sample += 4;
         }
+#if MP3S_HUF_CUT == 9
+        const unsigned long long clk3 = __builtin_readcyclecounter();
+#endif
+        // what no code word reached: zeros, row by row (p + 1 is a multiple of 16)
+        const int rest16 = (288 - (p + 1)) >> 2;          // 16-byte pieces per row
+        if (rest16 > 0)
+            for (int r = 0; r < LANES; r++) {
+                if (!((rows >> r) & 1)) continue;
+                uint4 *z = reinterpret_cast<uint4 *>(is32 + (tid0 + r) * 288 + (p + 1));
+                for (int i = lane; i < rest16; i += 64) z[i] = make_uint4(0, 0, 0, 0);
+            }
+#if MP3S_HUF_CUT == 9
+        const unsigned long long clk4 = __builtin_readcyclecounter();
+        if (has_row) {
+            uint32_t *d = is32 + tid * 288 + 280;
+            d[0] = (uint32_t)(clk1 - clk0); d[1] = (uint32_t)(clk2 - clk1); d[2] = (uint32_t)(clk3 - clk2); d[3] = (uint32_t)(clk4 - clk3); d[4] = (uint32_t)p;
+            d[5] = (uint32_t)__builtin_amdgcn_s_memrealtime();
+        }
+#endif
     }
-    for (int j = sample >> 1; j < 288; j++) smp[j] = 0;   // what no code word reached (everything, when the unit was rejected)
-    }   // worker
     // ---- status: the four units of a frame sit in four neighbouring lanes; the first of them stores the frame's word
     //      (which frame: the caller re-parses only the streams that hold one), errors of the whole launch are collected
     //      in the context's pair and handed out by the workgroup that finishes last (no fill launch in front of the kernel)

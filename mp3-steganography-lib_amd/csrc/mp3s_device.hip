@@ -219,20 +219,38 @@ int launch_huffman(hipStream_t stream, const uint8_t *d_blob, const mp3s_frame_s
                    int16_t *d_is, mp3s_granule_si *d_si, int32_t *d_status, int32_t *d_sync, Profiler *prof, bool per_frame)
 {
     // (no fills in front of the kernel: it writes every sample pair, every side record and every status word itself)
-    // LDS per workgroup = 30.8 KB of tables + W words per decoding lane, at most 64 KB.  Widest waves that still give
+    // LDS per workgroup = 27 KB of tables + W words per decoding lane, at most 64 KB.  Widest waves that still give
     // every SIMD about three waves to interleave; narrower ones otherwise (and for long granules, whose staging is big).
     const long units = (long)n_frames * 4;
     const int W = huf_words_for(max_bits);
-    auto fits = [&](int cols) { return (size_t)W * cols * 4 + 15 * HUFF_L1_N * 2 + HUFF_L2_N * 2 + 256 <= 64 * 1024; };
-    int lanes = 16;
-    if (fits(256) && units / 64 >= 3072) lanes = 64;   // measured: 64 = 32 from 60k frames up, 32 best below (10k: 0.149 vs 0.165 ms)
-    else if (fits(128)) lanes = 32;
-    if (const char *ev = getenv("MP3S_HUF_LANES")) { const int a = atoi(ev); if ((a == 64 && fits(256)) || (a == 32 && fits(128)) || a == 16 || a == 8) lanes = a; }
+    // (static 27 KB + dynamic: a workgroup of this chip may take more than the 64 KB a launch gets by default)
+    constexpr size_t kLdsMax = 128 * 1024;
+    auto dyn = [&](int cols, int wv) { return ((size_t)(W + 17) * cols + 17 * wv) * 4; };
+    auto fits = [&](int cols) { return dyn(cols, 8) + HUF_TAB_N * 2 + 256 <= kLdsMax; };
+    int lanes = 16, waves = 4;
+    // one wave per SIMD runs as fast as a wave can (1 024 SIMDs): 32 lanes per wave up to 8 192 frames, 64 beyond
+    if (fits(128)) { lanes = 32; waves = 4; }
+    if (fits(256) && units > 32 * 1024) { lanes = 64; waves = 4; }
+    if (const char *ev = getenv("MP3S_HUF_LANES")) {
+        const int a = atoi(ev);
+        if (a == 64 && fits(256)) { lanes = 64; waves = 4; }
+        if (a == 62 && fits(128)) { lanes = 64; waves = 2; }
+        if (a == 32 && fits(128)) { lanes = 32; waves = 4; }
+        if (a == 16) { lanes = 16; waves = 4; }
+        if (a == 8) { lanes = 8; waves = 8; }
+    }
+    if (getenv("MP3S_TRACE")) fprintf(stderr, "[mp3s] huffman launch: %ld units, W %d, %d waves x %d lanes, %zu bytes of dynamic LDS\n", units, W, waves, lanes, dyn(waves * lanes, waves));
     const int pp = prof ? prof->begin(stream, K_DEC_HUFFMAN) : -1;
 #define MP3S_HUF_LAUNCH(WV, LN)                                                                                         \
-    hipLaunchKernelGGL((k_dec_huffman<WV, LN>), dim3((unsigned)((units + WV * LN - 1) / (WV * LN))), dim3(WV * 64),    \
-                       (size_t)W * WV * LN * 4, stream, d_blob, d_side, n_frames, nch, W, max_bits, d_is, d_si, d_status, per_frame ? 1 : 0, d_sync)
-    if (lanes == 64) MP3S_HUF_LAUNCH(4, 64);
+    do {                                                                                                                \
+        static const hipError_t once = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_dec_huffman<WV, LN>),      \
+                                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)(kLdsMax - HUF_TAB_N * 2 - 256)); \
+        (void)once;                                                                                                     \
+        hipLaunchKernelGGL((k_dec_huffman<WV, LN>), dim3((unsigned)((units + WV * LN - 1) / (WV * LN))), dim3(WV * 64), \
+                           dyn(WV * LN, WV), stream, d_blob, d_side, n_frames, nch, W, max_bits, d_is, d_si, d_status, per_frame ? 1 : 0, d_sync); \
+    } while (0)
+    if (lanes == 64 && waves == 4) MP3S_HUF_LAUNCH(4, 64);
+    else if (lanes == 64) MP3S_HUF_LAUNCH(2, 64);
     else if (lanes == 32) MP3S_HUF_LAUNCH(4, 32);
     else if (lanes == 8) MP3S_HUF_LAUNCH(8, 8);
     else MP3S_HUF_LAUNCH(4, 16);

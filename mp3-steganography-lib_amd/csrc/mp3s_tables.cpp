@@ -297,22 +297,22 @@ void build()
     static const int kDecMax[32] = {1, 2, 3, 3, 0, 4, 4, 6, 6, 6, 8, 8, 8, 16, 0, 16,
                                     16, 16, 16, 16, 16, 16, 16, 16, 16, 16, 16, 16, 16, 16, 16, 16};
     static const int kBooks[15] = {1, 2, 3, 5, 6, 7, 8, 9, 10, 11, 12, 13, 15, 16, 24};
-    for (int t = 0; t < 32; t++) { T.huff_lut_id[t] = 255; T.dec_max[t] = (uint8_t)kDecMax[t]; }
-    int l2_used = 0;
+    for (int t = 0; t < 32; t++) T.dec_max[t] = (uint8_t)kDecMax[t];
+    uint16_t *L1 = T.huf_tab, *L2 = T.huf_tab + HUF_L1_N, *C1 = T.huf_tab + HUF_L1_N + HUF_L2_N;
+    int l1_used = 1, l2_used = 0;                     // entry 0: the books without code words (zeros, no bits: SURVEY D2)
+    for (int t = 0; t < 32; t++) T.huf_tinfo[t] = (uint32_t)H.huff[t].linbits << 4;   // w = 0: entry 0
     for (int b = 0; b < 15; b++) {
         const int t = kBooks[b];
-        T.huff_lut_id[t] = (uint8_t)b;
-        if (t == 16) for (int k = 16; k < 24; k++) T.huff_lut_id[k] = (uint8_t)b;
-        if (t == 24) for (int k = 24; k < 32; k++) T.huff_lut_id[k] = (uint8_t)b;
         const HostHuff &h = H.huff[t];
         // binary trie of the book: child per bit, 0x8000 | (x << 4) | y = leaf, else node index, 0 = no code
         static uint16_t tree[512][2];
         std::memset(tree, 0, sizeof tree);
-        int n_nodes = 1;   // node 0 = root
+        int n_nodes = 1, longest = 0;   // node 0 = root
         for (int x = 0; x < kDecMax[t]; x++)
             for (int y = 0; y < kDecMax[t]; y++) {
                 const int len = h.hlen[x * h.ylen + y];
                 const uint32_t code = h.hcod[x * h.ylen + y];
+                longest = std::max(longest, len);
                 int node = 0;
                 for (int d = 0; d < len; d++) {
                     const int bit = (code >> (len - 1 - d)) & 1;
@@ -334,43 +334,74 @@ void build()
             }
             return m;
         };
-        for (uint32_t w = 0; w < (uint32_t)HUFF_L1_N; w++) {
+        const int w = std::min(longest, HUF_W_MAX), base = l1_used;
+        const bool has_linbits = t >= 16;
+        auto leaf = [&](int len_total, int rel, uint16_t sym) {   // rel: what adv is counted from (0, or w for the second level)
+            const int x = (sym >> 4) & 15, y = sym & 15, nsig = (x != 0) + (y != 0), adv = len_total + nsig - rel;
+            const int c = nsig + (x == 0 && y != 0);   // the two bits at (30 + c - adv) of the window: x's sign above y's
+            if (adv < 0 || adv > 15) abort();
+            return (uint16_t)(((has_linbits && (x == 15 || y == 15)) ? 0x4000 : 0) | (c << 12) | (adv << 8) | (x << 4) | y);
+        };
+        if (l1_used + (1 << w) > HUF_L1_N) abort();
+        l1_used += 1 << w;
+        const uint32_t info = ((uint32_t)(base * 2) << 16) | ((uint32_t)((32 - w) & 31) << 8) | (uint32_t)w;
+        for (int k = (t == 16 || t == 24 ? t : t), k_end = (t == 16 || t == 24 ? t + 8 : t + 1); k < k_end; k++)
+            T.huf_tinfo[k] = info | ((uint32_t)H.huff[k].linbits << 4);
+        for (uint32_t v = 0; v < (1u << w); v++) {
             int node = 0;
             uint16_t e = 0;
-            for (int d = 0; d < HUFF_FAST_BITS; d++) {
-                const uint16_t nxt = tree[node][(w >> (HUFF_FAST_BITS - 1 - d)) & 1];
+            for (int d = 0; d < w; d++) {
+                const uint16_t nxt = tree[node][(v >> (w - 1 - d)) & 1];
                 if (!nxt) { e = 0; node = -1; break; }
-                if (nxt & 0x8000) { e = (uint16_t)(((d + 1) << 8) | (nxt & 0xff)); node = -1; break; }
+                if (nxt & 0x8000) { e = leaf(d + 1, 0, nxt); node = -1; break; }
                 node = nxt;
             }
-            if (node > 0) {   // codes longer than 10 bits share this prefix: one second-level table for the subtree
+            if (node > 0) {   // codes longer than w bits share this prefix: one second-level table for the subtree
                 const int k = depth(node), off = l2_used;
-                if (k > 15 || (off & 1) || off + (1 << k) > HUFF_L2_N || (off >> 1) >= 2048) abort();
+                if (k > 15 || (off & 1) || off + (1 << k) > HUF_L2_N || (off >> 1) >= 2048) abort();
                 l2_used += (1 << k) + ((1 << k) & 1);          // keep the next table on an even offset
-                for (uint32_t v = 0; v < (1u << k); v++) {
+                for (uint32_t u = 0; u < (1u << k); u++) {
                     int nd = node;
                     uint16_t le = 0;
                     for (int d = 0; d < k; d++) {
-                        const uint16_t nxt = tree[nd][(v >> (k - 1 - d)) & 1];
+                        const uint16_t nxt = tree[nd][(u >> (k - 1 - d)) & 1];
                         if (!nxt) break;
-                        if (nxt & 0x8000) { le = (uint16_t)(((HUFF_FAST_BITS + d + 1) << 8) | (nxt & 0xff)); break; }
+                        if (nxt & 0x8000) { le = leaf(w + d + 1, w, nxt); break; }
                         nd = nxt;
                     }
-                    T.huff_l2[off + v] = le;
+                    L2[off + u] = le;
                 }
                 e = (uint16_t)(0x8000 | (k << 11) | (off >> 1));
             }
-            T.huff_fast[b][w] = e;
+            L1[base + v] = e;
         }
     }
     {
+        // count1: book A (ISO table 32, code words of 1..6 bits) and book B (four bits, inverted), each followed by one sign
+        // bit per non-zero value in the order v, w, x, y (reference decoder/Frame.py:521-554)
         const HostHuff &q = H.huff[32];
+        uint16_t qa[64] = {0};
         for (int e = 0; e < 16; e++) {
             const int len = q.hlen[e];
             const uint32_t base = (uint32_t)q.hcod[e] << (6 - len);
             for (uint32_t f = 0; f < (1u << (6 - len)); f++)
-                if (!T.quad_fast[base + f]) T.quad_fast[base + f] = (uint16_t)((len << 4) | e);
+                if (!qa[base + f]) qa[base + f] = (uint16_t)((len << 4) | e);
             T.hcod_c1a[e] = (uint8_t)q.hcod[e];
+        }
+        // two entries per quadruple, in the format of the big-values leaves: (v, w) with adv = code word + their sign bits, then
+        // (x, y) with adv = code word + all sign bits -- the decoder looks the same bits up twice and moves on after the second
+        for (int book = 0; book < 2; book++) {
+            const int w = book ? 8 : 10;
+            uint16_t *half0 = C1 + (book ? 2048 : 0), *half1 = half0 + (1 << w);
+            for (uint32_t v = 0; v < (1u << w); v++) {
+                int val, len;
+                if (book) { val = (int)((v >> 4) ^ 15u); len = 4; }
+                else { const uint16_t s = qa[v >> 4]; val = s ? (s & 15) : 0; len = s >> 4; }
+                const int q0 = (val >> 3) & 1, q1 = (val >> 2) & 1, q2 = (val >> 1) & 1, q3 = val & 1;
+                const int n01 = q0 + q1, n23 = q2 + q3;
+                half0[v] = (uint16_t)(((n01 + (!q0 && q1)) << 12) | ((len + n01) << 8) | (q0 << 4) | q1);
+                half1[v] = (uint16_t)(((n23 + (!q2 && q3)) << 12) | ((len + n01 + n23) << 8) | (q2 << 4) | q3);
+            }
         }
         for (int i = 0; i < 256; i++) {
             T.hcod[0][i] = ISO_HCOD_13[i]; T.hcod[1][i] = ISO_HCOD_15[i];

@@ -11,12 +11,17 @@ constexpr int POW43_N = 8207;       // |is| <= 15 + 8191 (linbits 13)
 constexpr int POW2Q_MIN = -266;     // exp1 = global_gain - 210 - 8*sub_block_gain  in [-266, 45]
 constexpr int POW2Q_N = 312;
 constexpr int POW2H_N = 40;         // 2*exp2 in [0, 36]
-// First-level index width of the device Huffman tables.  9 bits: 15.4 KB + 4.4 KB of second-level tables.  With 10 bits
-// (30.7 + 2.4 KB) the kernel alone is 8 % faster, but its workgroups no longer fit into the LDS the rate loop leaves free
-// on a CU, and running under the rate loop is how the pipeline uses it (bench.py: 0.993 -> 0.967 ms per step).
-constexpr int HUFF_FAST_BITS = 9;
-constexpr int HUFF_L1_N = 1 << HUFF_FAST_BITS;
-constexpr int HUFF_L2_N = 2240;     // second-level entries (tables start on even offsets)
+// Device Huffman decode tables (k_dec_huffman).  Every book has a first-level table indexed by the next w bits of the
+// stream, w = min(longest code of the book, HUF_W_MAX): 8 + 64 + 64 + 256 + 128 + 512 entries for books 1, 2, 3, 5, 6, 9 and
+// 2^HUF_W_MAX for the other nine, one zero entry in front for the books without code words (0, 4, 14); codes longer than w
+// go through a second-level table per first-level prefix.  10 bits: 20.5 KB + 1.6 KB; a look-up is the one thing a decoding
+// lane waits for, and a second level doubles it: 6-9 % of the symbols of books 13 / 15 / 16 / 24 with 9 bits, 2-4 % with 10.
+constexpr int HUF_W_MAX = 10;
+constexpr int HUF_L1_N = 1 + 8 + 64 + 64 + 256 + 128 + 512 + 9 * (1 << HUF_W_MAX) + 7;   // (multiple of 8)
+constexpr int HUF_L2_N = 1200;      // second-level entries (tables start on even offsets)
+constexpr int HUF_C1_N = 2560;      // count1 book A on 10 bits, book B on 8: code word + sign bits, two entries per index
+constexpr int HUF_TAB_N = HUF_L1_N + HUF_L2_N + HUF_C1_N;
+static_assert(HUF_L1_N % 8 == 0 && HUF_L2_N % 8 == 0, "the kernel copies the tables 16 bytes at a time");
 
 // requantisation line map: one byte per spectral line, (is_short << 7) | (window << 5) | sfb
 // case 0 = long path, 1 = block_type 2, 2 = mixed flag with block_type != 2 (reference Frame.py:185-208)
@@ -67,13 +72,17 @@ struct DevTables {
     uint8_t linbits[32];
     int32_t linmax[32];
     uint8_t transform[32][2];      // reference MP3_Encoder.py:419-449
-    // ---- Huffman decode on the device (k_dec_huffman): first-level table (HUFF_FAST_BITS) + second-level tables for longer codes
-    uint8_t huff_lut_id[32];       // table_select -> 0..14, 255 = no code book (tables 0, 4, 14)
+    // ---- Huffman decode on the device (k_dec_huffman)
     uint8_t dec_max[32];           // symbols per axis (reference decoder/tables.py:426)
-    uint16_t huff_fast[15][HUFF_L1_N];  // leaf: (len << 8) | (x << 4) | y;  0x8000 | (k << 11) | off / 2: the next k bits
-                                        // index huff_l2[off ..];  0: no code
-    uint16_t huff_l2[HUFF_L2_N];   // leaf: (total len << 8) | (x << 4) | y;  0: no code
-    uint16_t quad_fast[64];        // count1 book A on 6 bits: (len << 4) | value
+    // table_select -> byte offset of the book's first-level table << 16 | (32 - w) % 32 << 8 | linbits << 4 | w
+    uint32_t huf_tinfo[32];
+    // [first level, all books | second level | count1 A, count1 B], copied to LDS in one piece.
+    // first / second level leaf: esc << 14 | c << 12 | adv << 8 | x << 4 | y -- adv = code length + the sign bits that follow
+    //   it, (x != 0) + (y != 0) (second level: minus the book's w); the two bits at offset 30 + c - adv of the 32-bit window
+    //   are x's sign above y's (a bit that is no sign lands on a zero); esc = x or y is 15 in a book with linbits;
+    //   first-level entry of a longer prefix: 0x8000 | k << 11 | off / 2: the next k bits index second level [off ..]
+    // count1: [A (v, w) | A (x, y) | B (v, w) | B (x, y)], 1024 + 1024 + 256 + 256 entries of the same leaf format
+    alignas(16) uint16_t huf_tab[HUF_TAB_N];
     // ---- Huffman code words for the device bit packer (k_enc_pack): books 13, 15, 16.., 24.. and count1 A
     uint32_t hcod[4][256];
     uint8_t hcod_c1a[16];

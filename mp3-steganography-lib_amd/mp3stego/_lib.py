@@ -1028,8 +1028,8 @@ DEV_TABLES_DTYPE = np.dtype([
     ("mdct_ca", "<i4", (8,)), ("steptab", "<f8", (128,)), ("steptabi", "<i4", (128,)), ("_pad_int2idx", "u1", (8,)), ("int2idx", "<u2", (10000,)),   # (int2idx is alignas(16))
     ("sfb_long", "<i4", (3, 23)), ("en_base", "<i4", (32,)), ("en_step", "<i4", (32,)), ("subdv", "<i4", (23, 2)), ("subdiv_lut", "<u4", (3, 289)), ("hlen13", "u1", (256,)), ("hlen15", "u1", (256,)),
     ("hlen16", "u1", (256,)), ("hlen24", "u1", (256,)), ("hlen_c1a", "u1", (16,)), ("linbits", "u1", (32,)),
-    ("linmax", "<i4", (32,)), ("transform", "u1", (32, 2)), ("huff_lut_id", "u1", (32,)), ("dec_max", "u1", (32,)),
-    ("huff_fast", "<u2", (15, 512)), ("huff_l2", "<u2", (2240,)), ("quad_fast", "<u2", (64,)),
+    ("linmax", "<i4", (32,)), ("transform", "u1", (32, 2)), ("dec_max", "u1", (32,)),
+    ("huf_tinfo", "<u4", (32,)), ("huf_tab", "<u2", (10256 + 1200 + 2560,)),
     ("hcod", "<u4", (4, 256)), ("hcod_c1a", "u1", (16,)), ("_pad_end", "u1", (8,))], align=True)   # (the struct is 16-byte aligned)
 
 
