@@ -12,8 +12,8 @@
 //                   Quirks kept: D1 (count1 stops at line 572,
 //                   no overrun discard), D2 (books 4/14 read no bits), bits past the buffer read as 0.
 #pragma once
-#ifndef MP3S_HUF_CUT
-#define MP3S_HUF_CUT 0
+#ifndef MP3S_HUF_CLOCKS
+#define MP3S_HUF_CLOCKS 0   // 1: shader-clock deltas of the phases into sample pairs 280..285 of every row (tools/huf_clk_probe.py)
 #endif
 
 namespace mp3s {
@@ -180,7 +180,7 @@ __global__ __launch_bounds__(WAVES * 64) void k_dec_huffman(
     int32_t *__restrict__ sync /* {finished workgroups, error bits}: zero between launches, owned by the context; null: status[0] was
                                   zeroed by the caller and takes the error bits directly */)
 {
-#if MP3S_HUF_CUT == 9
+#if MP3S_HUF_CLOCKS
     const unsigned long long clk0 = __builtin_readcyclecounter();
 #endif
     __shared__ __attribute__((aligned(16))) uint16_t tab[HUF_TAB_N];   // first level | second level | count1 (mp3s_tables.h)
@@ -202,7 +202,7 @@ __global__ __launch_bounds__(WAVES * 64) void k_dec_huffman(
         if (threadIdx.x == 0) wg_err = 0;
     }
     __syncthreads();
-#if MP3S_HUF_CUT == 9
+#if MP3S_HUF_CLOCKS
     const unsigned long long clk1 = __builtin_readcyclecounter();
 #endif
     const int lane = threadIdx.x & 63, col = (int)(threadIdx.x >> 6) * LANES + lane;
@@ -367,7 +367,7 @@ __global__ __launch_bounds__(WAVES * 64) void k_dec_huffman(
     //      two entries per quadruple, the second moves the window; zeros: entry 0), the window shift and the index of the
     //      NEXT look-up come first, signs, values and the refill of the window follow while it is in flight.
     {
-#if MP3S_HUF_CUT == 9
+#if MP3S_HUF_CLOCKS
         const unsigned long long clk2 = __builtin_readcyclecounter();
 #endif
         typedef short s16x2 __attribute__((ext_vector_type(2)));
@@ -463,7 +463,7 @@ __global__ __launch_bounds__(WAVES * 64) void k_dec_huffman(
                 if (p == 287 || !__any(p + 1 < bve || tog != 0)) break;
             }
         }
-#if MP3S_HUF_CUT == 9
+#if MP3S_HUF_CLOCKS
         const unsigned long long clk3 = __builtin_readcyclecounter();
 #endif
         // what no code word reached: zeros, row by row (p + 1 is a multiple of 16)
@@ -474,7 +474,7 @@ __global__ __launch_bounds__(WAVES * 64) void k_dec_huffman(
                 uint4 *z = reinterpret_cast<uint4 *>(is32 + (tid0 + r) * 288 + (p + 1));
                 for (int i = lane; i < rest16; i += 64) z[i] = make_uint4(0, 0, 0, 0);
             }
-#if MP3S_HUF_CUT == 9
+#if MP3S_HUF_CLOCKS
         const unsigned long long clk4 = __builtin_readcyclecounter();
         if (has_row) {
             uint32_t *d = is32 + tid * 288 + 280;

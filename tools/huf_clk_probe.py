@@ -1,4 +1,4 @@
-"""Phase clocks of k_dec_huffman from a -DMP3S_HUF_CUT=9 build (tools/ubench/build/libclk.so copied over the library): the
+"""Phase clocks of k_dec_huffman from a -DMP3S_HUF_CLOCKS=1 build (tools/ubench/build/libclk.so copied over the library): the
 kernel leaves shader-clock deltas in sample pairs 280..285 of every row."""
 import os, sys, time
 import numpy as np
