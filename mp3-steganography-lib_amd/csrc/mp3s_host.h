@@ -118,6 +118,9 @@ struct FrameWalker {
     long offset = 0;
     // ... and the same in front of the frame emitted last
     WalkHeader last_hd; int last_frame_size = 0, last_prev[9] = {0}; long last_offset = 0; int last_first_nch = 0;
+    bool last_valid = false;             // ... (kept for the frames inside the stream's last 4 096 bytes only)
+    // the header fields as the last full parse left them, and what it was a parse of
+    uint32_t hd_key = 0; bool hd_key_ok = false; int fs_base = 0;
 };
 // stego bits of a stream from what the device parser leaves per frame (tsel[f]: the twelve table indices of the frame, five
 // bits each in the order the reference walks them -- channel, granule, region -- and above them the four window-switching

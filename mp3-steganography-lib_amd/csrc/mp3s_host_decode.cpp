@@ -706,29 +706,52 @@ int FrameWalker::open(const uint8_t *f, size_t len)
     return 0;
 }
 
+// eight bytes from p as one big-endian word: the fields of a side-info unit lie inside 56 bits of it
+static inline uint64_t be64_at(const uint8_t *p) { uint64_t v; std::memcpy(&v, p, 8); return __builtin_bswap64(v); }
+
 long FrameWalker::next(FrameRef *refs, long cap, uint8_t *tables4, uint32_t image_base, uint16_t stream)
 {
     long n = 0;
+    // (the loop's state in locals: the stores into refs[] may alias any member as far as the compiler can tell)
+    long off = offset, nf = n_frames;
+    int fsz = frame_size, maxp = max_p23, pv[9];
+    uint32_t mdc = md_cursor;
+    bool silent = any_silent;
+    std::memcpy(pv, prev, sizeof pv);
+    // what a parsed header leaves for the frames that repeat it
+    int nch_f = hd.channels, sstart = hd.crc == 0 ? 6 : 4, constant = (hd.mode == 3 ? 21 : 36) + (hd.crc == 0 ? 2 : 0), ubase = nch_f == 2 ? 20 : 18;
     while (n < cap && !ended && !irregular) {
-        const uint8_t *buffer = file + offset;
-        const long buflen = flen - offset;
-        // the state in front of this frame (decode_last resumes the byte-level scan from it)
-        last_hd = hd; last_frame_size = frame_size; std::memcpy(last_prev, prev, sizeof prev); last_offset = offset; last_first_nch = first_nch;
-        int rc = parse_header(hd, buffer);   // (the sync was checked when the frame before was passed)
-        if (rc) { irregular = true; error = rc; break; }
-        // anything but MPEG-1 Layer III with a sampling rate of its own: header fields would carry over from earlier
-        // frames (FrameHeader.py:125-143), false syncs are taken apart as whatever they claim -- the byte-level scan's business
-        if (hd.version != 1 || hd.layer != 3 || ((buffer[2] >> 2) & 3) == 3 || hd.sr_idx < 0) { irregular = true; break; }
-        for (int i = 8; i > 0; i--) prev[i] = prev[i - 1];
-        prev[0] = frame_size;
-        frame_size = (int)(((1152.0 / 8) * hd.bit_rate) / hd.sampling_rate);
-        if (hd.padding == 1) frame_size += 1;
-        if (frame_size <= 0) { irregular = true; error = MP3S_E_MALFORMED; break; }
-        if (first_nch == 0) first_nch = hd.channels;
-        else if (hd.channels != first_nch) { irregular = true; error = MP3S_E_UNSUPPORTED; break; }
-        const int nch_f = hd.channels;
+        const uint8_t *buffer = file + off;
+        const long buflen = flen - off;
+        // the state in front of this frame (decode_last resumes the byte-level scan from it): kept for the frames a stream can end
+        // with regularly -- the ones inside its last bytes; a stream that ends at a bad header repeats its last frame (D12),
+        // which no caller decodes here
+        last_valid = buflen <= 4096;
+        if (last_valid) { last_hd = hd; last_frame_size = fsz; std::memcpy(last_prev, pv, sizeof pv); last_offset = off; last_first_nch = first_nch; }
+        else { __builtin_prefetch(buffer + 8 * fsz); __builtin_prefetch(buffer + 8 * fsz + 40); }   // (headers a few frames on: 38 bytes every few hundred)
+        // a header that names what the one before named (everything but the padding and private bits and the second mode-extension
+        // bit) leaves every field where it is: nothing to take apart
+        const uint32_t key = ((uint32_t)buffer[1] << 16) | ((uint32_t)(buffer[2] & 0xfc) << 8) | (uint32_t)(buffer[3] & 0xe0);
+        int padding = (buffer[2] >> 1) & 1;
+        if (key != hd_key || !hd_key_ok) {
+            hd_key_ok = false;
+            int rc = parse_header(hd, buffer);   // (the sync was checked when the frame before was passed)
+            if (rc) { irregular = true; error = rc; break; }
+            // anything but MPEG-1 Layer III with a sampling rate of its own: header fields would carry over from earlier
+            // frames (FrameHeader.py:125-143), false syncs are taken apart as whatever they claim -- the byte-level scan's business
+            if (hd.version != 1 || hd.layer != 3 || ((buffer[2] >> 2) & 3) == 3 || hd.sr_idx < 0) { irregular = true; break; }
+            fs_base = (int)(((1152.0 / 8) * hd.bit_rate) / hd.sampling_rate);
+            if (fs_base + padding <= 0) { irregular = true; error = MP3S_E_MALFORMED; break; }
+            if (first_nch == 0) first_nch = hd.channels;
+            else if (hd.channels != first_nch) { irregular = true; error = MP3S_E_UNSUPPORTED; break; }
+            hd_key = key; hd_key_ok = fs_base > 0;
+            nch_f = hd.channels; sstart = hd.crc == 0 ? 6 : 4; constant = (hd.mode == 3 ? 21 : 36) + (hd.crc == 0 ? 2 : 0); ubase = nch_f == 2 ? 20 : 18;
+            padding = hd.padding;
+        }
+        std::memmove(pv + 1, pv, 8 * sizeof pv[0]);
+        pv[0] = fsz;
+        fsz = fs_base + padding;
         // ---- side info: the fields the host needs, read where they lie (fixed positions: both layouts of a granule take 59 bits)
-        const long sstart = hd.crc == 0 ? 6 : 4;
         uint8_t sbuf[48];
         const uint8_t *sb = buffer + sstart;
         if (buflen < sstart + 40) {          // the stream ends inside the side info: bits past the end read as 0
@@ -736,17 +759,17 @@ long FrameWalker::next(FrameRef *refs, long cap, uint8_t *tables4, uint32_t imag
             if (buflen > sstart) std::memcpy(sbuf, buffer + sstart, (size_t)std::min<long>(buflen - sstart, 40));
             sb = sbuf;
         }
-        const int mdb = (int)bits_at(sb, 0, 9);
-        const int ubase = nch_f == 2 ? 20 : 18;
+        const int mdb = (int)(((uint32_t)sb[0] << 1) | (sb[1] >> 7));
         for (int u = 0; u < 2 * nch_f; u++) {
             const int b = ubase + 59 * u;
-            max_p23 = std::max(max_p23, (int)bits_at(sb, b, 12));
+            const uint64_t x = be64_at(sb + (b >> 3)) << (b & 7);   // part2_3_length (12) | big_values (9) | 12 bits | window_switching + 15
+            maxp = std::max(maxp, (int)(x >> 52));
             // a granule without a code book in use (no big values, or book 0 in every region it has): what tables_guess_of calls 0
-            const uint32_t wt = bits_at(sb, b + 33, 16);            // window_switching | the 15 bits behind it
+            const uint32_t wt = (uint32_t)(x >> 15) & 0xffffu;      // window_switching | the 15 bits behind it
             const uint32_t books = (wt & 0x8000u) ? (wt >> 2) & 0x3ffu : wt & 0x7fffu;
-            if (bits_at(sb, b + 12, 9) == 0 || books == 0) any_silent = true;
+            if (((x >> 43) & 0x1ff) == 0 || books == 0) silent = true;
         }
-        if (tables4 && nch_f == 2 && tables_frames == n_frames && tables_seen < tables_wanted) {
+        if (tables4 && nch_f == 2 && tables_frames == nf && tables_seen < tables_wanted) {
             for (int gr = 0; gr < 2; gr++)
                 for (int ch = 0; ch < 2; ch++) {
                     const int b = ubase + 59 * (gr * 2 + ch);
@@ -761,34 +784,36 @@ long FrameWalker::next(FrameRef *refs, long cap, uint8_t *tables4, uint32_t imag
             tables_frames++;
         }
         // ---- main data: how long it is (Frame.py:318-363); every part must lie inside the file where the pointers say
-        const int constant = (hd.mode == 3 ? 21 : 36) + (hd.crc == 0 ? 2 : 0);
-        long md_len = std::max<long>(0, std::min<long>(frame_size, buflen) - constant);
+        long md_len = std::max<long>(0, std::min<long>(fsz, buflen) - constant);
         if (mdb != 0) {
             long bound = 0;
             int fr = 0;
             for (; fr < 9; fr++) {
-                const long part = (long)prev[fr] - constant;
+                const long part = (long)pv[fr] - constant;
                 if (mdb < bound + part) break;
                 if (part < 0) { fr = 9; break; }
                 bound += part;
             }
             // not found: the reference goes on with the main data of the frame before; a pointer in front of the file wraps
             // around (Python slices) -- both are the byte-level scan's business
-            if (fr >= 9 || offset - mdb - (long)fr * constant < 0) { irregular = true; break; }
+            if (fr >= 9 || off - mdb - (long)fr * constant < 0) { irregular = true; break; }
             md_len += mdb;
         }
-        if (md_len > 0xffff || frame_size > 0xffff || (uint64_t)offset + image_base > 0xffffffffull || (uint64_t)md_cursor + (uint64_t)md_len + 16 > 0xffffffffull) {
+        if (md_len > 0xffff || fsz > 0xffff || (uint64_t)off + image_base > 0xffffffffull || (uint64_t)mdc + (uint64_t)md_len + 16 > 0xffffffffull) {
             irregular = true; break;
         }
         FrameRef &r = refs[n];
-        r.file_off = (uint32_t)offset + image_base; r.md_off = md_cursor; r.md_len = (uint16_t)md_len; r.frame_size = (uint16_t)frame_size;
+        r.file_off = (uint32_t)off + image_base; r.md_off = mdc; r.md_len = (uint16_t)md_len; r.frame_size = (uint16_t)fsz;
         r.stream = stream; r.flags = 0;
-        md_cursor = (uint32_t)((md_cursor + md_len + 8 + 3) & ~(uint32_t)3);
-        n++; n_frames++;
-        offset += frame_size;
-        if (!(flen > offset + 4)) ended = true;
-        else if (!(file[offset] == 0xFF && file[offset + 1] >= 0xE0)) { ended = true; dup_last = true; }   // D12
+        mdc = (uint32_t)((mdc + md_len + 8 + 3) & ~(uint32_t)3);
+        n++; nf++;
+        off += fsz;
+        if (!(flen > off + 4)) ended = true;
+        else if (!(file[off] == 0xFF && file[off + 1] >= 0xE0)) { ended = true; dup_last = true; }   // D12
     }
+    // (a frame that made the walk give up has moved nothing: its predecessor's state stands, as before)
+    offset = off; n_frames = nf; md_cursor = mdc; max_p23 = maxp; any_silent = silent;
+    if (!irregular) { frame_size = fsz; std::memcpy(prev, pv, sizeof pv); hd.padding = fsz - fs_base; }
     nch = first_nch ? first_nch : hd.channels;
     sampling_rate = hd.sampling_rate; bit_rate = hd.bit_rate;
     return n;
@@ -805,7 +830,7 @@ void FrameWalker::history(const FrameRef *stream_refs, long f, uint16_t out[9])
 
 int FrameWalker::decode_last(int16_t *is2304, mp3s_granule_si *si4, bool *alone)
 {
-    if (n_frames <= 0) return MP3S_E_ARG;
+    if (n_frames <= 0 || !last_valid) return MP3S_E_ARG;
     ScanState st;
     st.hd = last_hd; st.frame_size = last_frame_size; st.first_nch = last_first_nch; st.offset = last_offset;
     for (int i = 0; i < 9; i++) st.prev_frame_size[i] = last_prev[i];
