@@ -223,8 +223,12 @@ int launch_huffman(hipStream_t stream, const uint8_t *d_blob, const mp3s_frame_s
     // every SIMD about three waves to interleave; narrower ones otherwise (and for long granules, whose staging is big).
     const long units = (long)n_frames * 4;
     const int W = huf_words_for(max_bits);
-    // (static 27 KB + dynamic: a workgroup of this chip may take more than the 64 KB a launch gets by default)
-    constexpr size_t kLdsMax = 128 * 1024;
+    // (static 27 KB + dynamic: a workgroup of this chip may take more than the 64 KB a launch gets by default -- all 160 KB of a CU)
+    static const size_t kLdsMax = [] {
+        int dev = 0, v = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&v, hipDeviceAttributeMaxSharedMemoryPerBlock, dev) != hipSuccess || v < 64 * 1024) v = 64 * 1024;
+        return (size_t)v;
+    }();
     auto dyn = [&](int cols, int wv) { return ((size_t)(W + 17) * cols + 17 * wv) * 4; };
     auto fits = [&](int cols) { return dyn(cols, 8) + HUF_TAB_N * 2 + 256 <= kLdsMax; };
     int lanes = 16, waves = 4;

@@ -10,8 +10,13 @@ from synth_pcm import synth_pcm
 ctx = m.Context()
 L = m.lib()
 sizes = [int(a) for a in sys.argv[1:]] or [8, 64, 256, 1024, 2048, 2560, 4096, 5000, 8192, 10000]
-pcm = synth_pcm(max(sizes), seed=0x9E3779B97F4A7C15)
-mp3 = bytes(ctx.encode_pcm(pcm, 44100, 128, None)["mp3"])
+if os.environ.get("HUF_PROBE_STREAM"):      # a mix of tests/frame_synth.py instead of this encoder's own stream: long | short | switching | 320
+    import frame_synth
+    kw = {"long": dict(block_types=(0,)), "short": dict(block_types=(2,)), "switching": dict(block_types=(0, 1, 2, 3)), "320": dict(bitrate_idx=14, block_types=(0,))}[os.environ["HUF_PROBE_STREAM"]]
+    mp3 = frame_synth.make_stream(101, 250, use_reservoir=True, **kw) * ((max(sizes) + 249) // 250)
+else:
+    pcm = synth_pcm(max(sizes), seed=0x9E3779B97F4A7C15)
+    mp3 = bytes(ctx.encode_pcm(pcm, 44100, 128, None)["mp3"])
 w = m.walk_stream(mp3)
 res = {}
 for n in sizes:
