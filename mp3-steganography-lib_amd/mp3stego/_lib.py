@@ -1029,8 +1029,8 @@ DEV_TABLES_DTYPE = np.dtype([
     ("sfb_long", "<i4", (3, 23)), ("en_base", "<i4", (32,)), ("en_step", "<i4", (32,)), ("subdv", "<i4", (23, 2)), ("subdiv_lut", "<u4", (3, 289)), ("hlen13", "u1", (256,)), ("hlen15", "u1", (256,)),
     ("hlen16", "u1", (256,)), ("hlen24", "u1", (256,)), ("hlen_c1a", "u1", (16,)), ("linbits", "u1", (32,)),
     ("linmax", "<i4", (32,)), ("transform", "u1", (32, 2)), ("dec_max", "u1", (32,)),
-    ("huf_tinfo", "<u4", (32,)), ("huf_tab", "<u2", (10256 + 1200 + 2560,)),
-    ("hcod", "<u4", (4, 256)), ("hcod_c1a", "u1", (16,)), ("_pad_end", "u1", (8,))], align=True)   # (the struct is 16-byte aligned)
+    ("huf_tinfo", "<u4", (32,)), ("_pad_huf_tab", "u1", (8,)), ("huf_tab", "<u2", (10256 + 1200 + 2560,)),   # (huf_tab is alignas(16))
+    ("hcod", "<u4", (4, 256)), ("hcod_c1a", "u1", (16,))], align=True)   # (the struct is 16-byte aligned)
 
 
 def debug_tables():

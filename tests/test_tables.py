@@ -146,3 +146,83 @@ def test_guard_constants_of_the_fast_int16_decode(mlib):
     assert abs(float(t["synth_eps_g"]) / (2.0 * 32767.0 * dsum * 2.0002 * kappa) - 1) < 1e-12
     # the older terms stay what they were: eps_a scales with the slot's sum |S|, eps_x with the sample itself
     assert 1e-9 < float(t["synth_eps_a"]) < 1e-8 and float(t["synth_eps_x"]) == 4 * u
+
+
+def test_device_huffman_tables_decode_every_code_word(mlib, golden_dir):
+    """k_dec_huffman's look-up tables (first level per book, second level behind the longer prefixes, the two count1 entries per
+    quadruple: DevTables.huf_tinfo / huf_tab, one 16-bit leaf format) against the reference's code books (decoder/tables.py via
+    g1_tables.npz): every code word of every book, with every combination of sign bits and random bits behind it, comes out as
+    the reference's linear search finds it -- values, signs, bits consumed (Frame.py:458-554).  The kernel's arithmetic restated."""
+    g = np.load(os.path.join(golden_dir, "g1_tables.npz"))
+    t = mlib.debug_tables()
+    tab, tinfo = t["huf_tab"].astype(np.int64), t["huf_tinfo"].astype(np.int64)
+    L1, L2, C1 = 10256, 1200, 2560
+    assert len(tab) == L1 + L2 + C1
+    rng = np.random.default_rng(5)
+
+    def ubfe(v, off, w):
+        return (v >> (off & 31)) & ((1 << w) - 1) if w else 0
+
+    def pair(e, adv, hi):
+        sg = ubfe(hi, 30 + ((e >> 12) & 3) - adv, 2)
+        v0, v1 = (e >> 4) & 15, e & 15
+        return (-v0 if sg & 2 else v0), (-v1 if sg & 1 else v1)
+
+    checked = 0
+    meta = g["enc_huff_meta"]
+    for book in range(1, 32):
+        n, linbits = int(meta[book][0]), int(meta[book][2])
+        ti = int(tinfo[book])
+        assert (ti >> 4) & 15 == linbits
+        if n == 0:
+            assert ti >> 16 == 0 and ti & 15 == 0 and tab[0] == 0       # books 4, 14 (and 0): entry 0, nothing (D2)
+            continue
+        src = book if book < 16 else (16 if book < 24 else 24)
+        hcod, hlen = g[f"enc_hcod_{src}"].astype(np.int64), g[f"enc_hlen_{src}"].astype(np.int64)
+        w = ti & 15
+        for x in range(n):
+            for y in range(n):
+                code, ln = int(hcod[x * n + y]), int(hlen[x * n + y])
+                for sx in range(2 if x else 1):
+                    for sy in range(2 if y else 1):
+                        bits, nb = code, ln
+                        if x:
+                            bits, nb = (bits << 1) | sx, nb + 1
+                        if y:
+                            bits, nb = (bits << 1) | sy, nb + 1
+                        hi = ((bits << (32 - nb)) | int(rng.integers(0, 1 << (32 - nb)))) & 0xffffffff
+                        e = int(tab[(ti >> 17) + ubfe(hi, (ti >> 8) & 31, w)])
+                        adv = (e >> 8) & 15
+                        if e & 0x8000:
+                            k = (e >> 11) & 15
+                            e = int(tab[L1 + 2 * (e & 0x7ff) + (((hi << w) & 0xffffffff) >> (32 - k))])
+                            adv = w + ((e >> 8) & 15)
+                        assert bool(e & 0x4000) == bool(linbits and (x == 15 or y == 15)), (book, x, y)
+                        if e & 0x4000:                     # escapes: the kernel takes the code word's length and goes on bit by bit
+                            assert adv - (x != 0) - (y != 0) == ln and ((e >> 4) & 15, e & 15) == (x, y)
+                        else:
+                            assert adv == nb and pair(e, adv, hi) == (-x if sx else x, -y if sy else y), (book, x, y, sx, sy)
+                        checked += 1
+    # count1: book A (quad code book of the reference) and B (four bits, inverted)
+    qc, ql = g["enc_hcod_32"].astype(np.int64), g["enc_hlen_32"].astype(np.int64)
+    for bookb in range(2):
+        w = 8 if bookb else 10
+        half0 = L1 + L2 + (2048 if bookb else 0)
+        half1 = half0 + (1 << w)
+        for val in range(16):
+            code, ln = (val ^ 15, 4) if bookb else (int(qc[val]), int(ql[val]))
+            for signs in range(16):
+                bits, nb, want, s = code, ln, [], signs
+                for i in range(4):
+                    if (val >> (3 - i)) & 1:
+                        neg, s = s & 1, s >> 1
+                        bits, nb = (bits << 1) | neg, nb + 1
+                        want.append(-1 if neg else 1)
+                    else:
+                        want.append(0)
+                hi = ((bits << (32 - nb)) | int(rng.integers(0, 1 << (32 - nb)))) & 0xffffffff
+                ea, eb = int(tab[half0 + (hi >> (32 - w))]), int(tab[half1 + (hi >> (32 - w))])
+                assert (eb >> 8) & 15 == nb and not (ea | eb) & 0xc000
+                assert list(pair(ea, (ea >> 8) & 15, hi) + pair(eb, (eb >> 8) & 15, hi)) == want, (bookb, val, signs)
+                checked += 1
+    assert checked > 18000
