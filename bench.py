@@ -249,7 +249,17 @@ def main():
     if world > 1:
         import torch.distributed as dist  # control plane only (barrier + max); no tensors on the data path
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="gloo", rank=rank, world_size=world)
+        # (the gloo transport announces its connections on stdout, which belongs to the ONE json line of rank 0: stderr for the time being)
+        sys.stdout.flush()
+        keep_out = os.dup(1)
+        os.dup2(2, 1)
+        try:
+            dist.init_process_group(backend="gloo", rank=rank, world_size=world)
+            dist.barrier()
+        finally:
+            sys.stdout.flush()
+            os.dup2(keep_out, 1)
+            os.close(keep_out)
 
     def reduce_max(x):
         if dist is None:
