@@ -1,6 +1,7 @@
 // Single device translation unit: the constant-table symbol, the three kernel groups and their
 // launchers.  Compiled for gfx950 only (hipcc --offload-arch=gfx950 -ffp-contract=off).
 #include <hip/hip_runtime.h>
+#include <atomic>
 #include <stdint.h>
 #include <stdlib.h>
 
@@ -223,12 +224,18 @@ int launch_huffman(hipStream_t stream, const uint8_t *d_blob, const mp3s_frame_s
     // every SIMD about three waves to interleave; narrower ones otherwise (and for long granules, whose staging is big).
     const long units = (long)n_frames * 4;
     const int W = huf_words_for(max_bits);
-    // (static 27 KB + dynamic: a workgroup of this chip may take more than the 64 KB a launch gets by default -- all 160 KB of a CU)
-    static const size_t kLdsMax = [] {
-        int dev = 0, v = 0;
-        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&v, hipDeviceAttributeMaxSharedMemoryPerBlock, dev) != hipSuccess || v < 64 * 1024) v = 64 * 1024;
-        return (size_t)v;
-    }();
+    // (static 27 KB + dynamic: a workgroup of this chip may take more than the 64 KB a launch gets by default -- all 160 KB of a CU;
+    // asked for once per device and kernel instance)
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    const int dslot = dev >= 0 && dev < 64 ? dev : 0;
+    static std::atomic<int> lds_of_device[64];
+    int lds_max = lds_of_device[dslot].load(std::memory_order_relaxed);
+    if (lds_max == 0) {
+        if (hipDeviceGetAttribute(&lds_max, hipDeviceAttributeMaxSharedMemoryPerBlock, dev) != hipSuccess || lds_max < 64 * 1024) lds_max = 64 * 1024;
+        lds_of_device[dslot].store(lds_max, std::memory_order_relaxed);
+    }
+    const size_t kLdsMax = (size_t)lds_max;
     auto dyn = [&](int cols, int wv) { return ((size_t)(W + 17) * cols + 17 * wv) * 4; };
     auto fits = [&](int cols) { return dyn(cols, 8) + HUF_TAB_N * 2 + 256 <= kLdsMax; };
     int lanes = 16, waves = 4;
@@ -247,9 +254,12 @@ int launch_huffman(hipStream_t stream, const uint8_t *d_blob, const mp3s_frame_s
     const int pp = prof ? prof->begin(stream, K_DEC_HUFFMAN) : -1;
 #define MP3S_HUF_LAUNCH(WV, LN)                                                                                         \
     do {                                                                                                                \
-        static const hipError_t once = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_dec_huffman<WV, LN>),      \
-                                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)(kLdsMax - HUF_TAB_N * 2 - 256)); \
-        (void)once;                                                                                                     \
+        static std::atomic<unsigned long long> asked{0};                                                              \
+        if (!(asked.load(std::memory_order_relaxed) & (1ull << dslot))) {                                               \
+            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_dec_huffman<WV, LN>), hipFuncAttributeMaxDynamicSharedMemorySize, \
+                                      (int)(kLdsMax - HUF_TAB_N * 2 - 256));                                            \
+            asked.fetch_or(1ull << dslot, std::memory_order_relaxed);                                                   \
+        }                                                                                                               \
         hipLaunchKernelGGL((k_dec_huffman<WV, LN>), dim3((unsigned)((units + WV * LN - 1) / (WV * LN))), dim3(WV * 64), \
                            dyn(WV * LN, WV), stream, d_blob, d_side, n_frames, nch, W, max_bits, d_is, d_si, d_status, per_frame ? 1 : 0, d_sync); \
     } while (0)
