@@ -164,3 +164,51 @@ def test_two_contexts_ordered_by_ctx_wait(ctx, mlib, orc, golden_dir):
             ctx.free(q)
     finally:
         aux.close()
+
+
+@pytest.mark.gpu
+def test_device_huffman_every_launch_shape(ctx, mlib, golden_dir):
+    """k_dec_huffman as 8 waves x 8 lanes, 4 x 16, 4 x 32, 2 x 64 and 4 x 64 (MP3S_HUF_LANES: the launcher picks by the number of
+    frames and the LDS the staging needs): the lanes of a wave walk their pairs in step and leave them through a tile in LDS, so
+    every shape has its own indexing -- same samples and side records as the host parser on streams of every kind, with staging
+    sized for the stream and for the format's limit (decoder/Frame.py:365-559)."""
+    import frame_synth
+    L = mlib.lib()
+    g = np.load(os.path.join(golden_dir, "g7_decode_corpus.npz"))
+    streams = [g[k].tobytes() for k in g.files if k.endswith("__mp3")][:6]
+    streams.append(frame_synth.make_stream(31, 70, mode=3, block_types=(0, 1, 2, 3), use_reservoir=True))     # mono: every second row is zeros
+    streams.append(frame_synth.make_stream(32, 90, bitrate_idx=14, block_types=(0, 2), use_reservoir=True))   # 320 kbit/s: long granules
+    old = os.environ.get("MP3S_HUF_LANES")
+    try:
+        for data in streams:
+            p = mlib.parse_stream(data)
+            s = mlib.scan_stream(data)
+            if not s["gpu_ok"]:
+                continue
+            n, nch = s["n_frames"], s["channels"]
+            d_blob, d_side = ctx.to_device(s["blob"]), ctx.to_device(s["side"])
+            d_is, d_si, d_st = ctx.alloc(n * 2304 * 2), ctx.alloc(n * 4 * 72), ctx.alloc(4)
+            first_si = None
+            for lanes in ("32", "8", "16", "62", "64"):
+                for bound in (s["max_part2_3_length"], 0):
+                    os.environ["MP3S_HUF_LANES"] = lanes
+                    ctx.upload(d_is, np.full(n * 2304, 0x5a5a, dtype=np.int16))
+                    mlib.check(L.mp3s_huffman_decode_dev(ctx.handle, d_blob, d_side, n, nch, bound, d_is, d_si, d_st))
+                    assert int(ctx.download(d_st, np.int32, (1,))[0]) == 0
+                    got = ctx.download(d_is, np.int16, (n, 2, 2, 576))
+                    assert np.array_equal(got[:, :, :nch], p["is"][:, :, :nch]) and not got[:, :, nch:].any(), (lanes, bound)
+                    si = ctx.download(d_si, mlib.GRANULE_SI_DTYPE, (n, 2, 2))
+                    for k in ("global_gain", "block_type", "mixed_block_flag", "preflag"):
+                        assert np.array_equal(si[k][:, :, :nch], p["si"][k][:, :, :nch]), (lanes, k)
+                    # (the scalefactor arrays: the host parser keeps what earlier frames left in entries a granule does not set, D10;
+                    # tests/test_decode_corpus.py compares the PCM) -- every shape leaves the same bytes
+                    if first_si is None:
+                        first_si = si.tobytes()
+                    assert si.tobytes() == first_si, (lanes, bound)
+            for q in (d_blob, d_side, d_is, d_si, d_st):
+                ctx.free(q)
+    finally:
+        if old is None:
+            os.environ.pop("MP3S_HUF_LANES", None)
+        else:
+            os.environ["MP3S_HUF_LANES"] = old

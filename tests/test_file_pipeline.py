@@ -147,3 +147,28 @@ def test_long_file_automatic_chunks_and_the_facade(ctx, mlib, tmp_path):
     assert dst.read_bytes() == bytes(want["data"])
     got = ctx.hide_message_chunked(mp3, "The quick brown fox", 3000)
     assert same_file(got, want)
+
+
+def test_file_from_the_helper_thread_or_chunk_by_chunk(ctx, mlib, golden_dir):
+    """the whole file uploaded in pieces by the context's helper thread (the default) or every chunk's piece by the calling
+    thread (MP3S_NO_FILE_UP=1: the path of files above 1 GB): same bytes, on files of one chunk and of several, cut files, and
+    a decode; steganography.py:137-162"""
+    from synth_pcm import synth_pcm
+    mp3 = bytes(ctx.encode_pcm(synth_pcm(5000, seed=71), 44100, 128, None)["mp3"])
+    small = open(os.path.join(golden_dir, "test.mp3"), "rb").read()
+    old = os.environ.get("MP3S_NO_FILE_UP")
+    try:
+        for data in (mp3, mp3[:-777], small, small[:-5]):
+            for chunk in (0, 700):
+                with options(ctx, chunk_frames=chunk):
+                    os.environ.pop("MP3S_NO_FILE_UP", None)
+                    a, ca, wa = ctx.hide_message(data, "helper thread"), ctx.clear_file(data), ctx.decode_file(data)
+                    os.environ["MP3S_NO_FILE_UP"] = "1"
+                    b, cb, wb = ctx.hide_message(data, "helper thread"), ctx.clear_file(data), ctx.decode_file(data)
+                assert same_file(a, b) and same_file(ca, cb) and bytes(wa["data"]) == bytes(wb["data"]), (len(data), chunk)
+                assert same_file(a, legacy(ctx, ctx.hide_message, data, "helper thread"))
+    finally:
+        if old is None:
+            os.environ.pop("MP3S_NO_FILE_UP", None)
+        else:
+            os.environ["MP3S_NO_FILE_UP"] = old
