@@ -427,7 +427,10 @@ bool file_up_begin(mp3s_pipe *P, const uint8_t *file, size_t len, size_t first_b
     u.recorded.store(0); u.err.store(0);
     {
         std::lock_guard<std::mutex> g(u.mu);
-        if (!u.th.joinable()) u.th = std::thread(file_up_thread, P);
+        if (!u.th.joinable()) {
+            try { u.th = std::thread(file_up_thread, P); }
+            catch (const std::exception &) { return false; }     // (no thread to be had: every chunk's piece from the caller, as for a file above 1 GB)
+        }
         u.src = file; u.busy = true; u.started = false;
     }
     u.cv.notify_all();
