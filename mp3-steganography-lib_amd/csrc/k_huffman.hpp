@@ -58,11 +58,11 @@ struct BitStream {
     __device__ __forceinline__ void refill_always()
     {
         const bool need = valid <= 32;
-        const uint64_t add = (uint64_t)nxt << ((32 - valid) & 31);
-        win |= need ? add : 0ull;
+        const uint64_t add = (uint64_t)(need ? nxt : 0u) << ((32 - valid) & 31);
+        win |= add;
         valid += need ? 32 : 0;
-        const uint32_t up = idx < last ? idx + 1 : last;
-        idx = need ? up : idx;
+        const uint32_t up = idx + (need ? 1u : 0u);
+        idx = up < last ? up : last;
         nxt = lds[idx * T];
     }
     __device__ __forceinline__ uint32_t hi() const { return (uint32_t)(win >> 32); }
@@ -390,12 +390,13 @@ __global__ __launch_bounds__(WAVES * 64) void k_dec_huffman(
         for (;; p++) {
             // -- what does not depend on the look-up in flight
             const uint32_t chk = (ti >> 13) & 1;                  // 1: (v, w) of a quadruple -- the entry does not move the window
-            const uint32_t am = chk ? 0u : 31u;                   // (code words of up to 19 bits + 2 signs)
+            const uint32_t am = (chk - 1) & 31u;                  // ... (0; 31 otherwise: code words of up to 19 bits + 2 signs)
             // big values that run past part2_3_length read on into the data that follows (the reference has one bit cursor per
             // frame; the staged window covers one code word of that, a second one is reported); a quadruple is only started
-            // in front of the last bit and of line 572 (D1)
-            if (__any(bit + chk > mb) || p >= 286) {
-                if (bit + chk > mb || (p >= 286 && chk)) {
+            // in front of the last bit and of line 572 (D1: from pair 286 on the compare is lost for every (v, w))
+            const uint32_t lim = bit + (chk << (p >= 286 ? 30 : 0));
+            if (__any(lim > mb)) {
+                if (lim > mb) {
                     if (!chk) err |= MP3S_HS_OVERRUN;
                     bve = 0; c1n = 0; tog = 0; mb = 0xffffffffu;
                     e = 0;                                        // entry 0: nothing
