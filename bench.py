@@ -387,7 +387,6 @@ def main():
         _lib.check(L.mp3s_encode_transform_dev(ctx.handle, d_pcm2[b], d_hdr, n, d_mdct))
         if aux2 is not None:
             ctx.wait_for(aux2)
-        _lib.check(L.mp3s_dev_copy(ctx.handle, d_cur, d_cur0, units * 4))
         _lib.check(L.mp3s_rate_variants_dev(ctx.handle, d_mdct, d_rf, n, d_hide, len(hide_all), d_cur, d_eu, d_ec, n_ent, d_ix, d_out, d_en,
                                             d_ixv, d_outv, d_env))
         pk = ctx
@@ -397,6 +396,7 @@ def main():
         _lib.check(L.mp3s_select_dev(pk.handle, d_hide, d_cur, d_seg, d_spans, 1, max_reach, d_eu, d_ec, n_ent, d_ix, d_out, d_en, d_ixv, d_outv, d_env))
         _lib.check(L.mp3s_chain_redo_dev(pk.handle, d_mdct, d_rf, n, d_hide, len(hide_all), d_cur, d_seg, 1, d_ix, d_out, d_en, d_verdict, d_segout))
         _lib.check(L.mp3s_pack_frames_dev(pk.handle, d_ix, d_out, d_en, n, 44100, 128, d_off, d_pad, d_mp3, d_sc, d_pst))
+        _lib.check(L.mp3s_dev_copy(pk.handle, d_cur, d_cur0, units * 4))     # (see step)
 
     def step():
         if dctx is not None:
@@ -423,7 +423,6 @@ def main():
             front_end(aux, k + 1)
         if aux2 is not None:
             ctx.wait_for(aux2)                      # the packer of batch k-1 has read what the rate loop is about to overwrite
-        _lib.check(L.mp3s_dev_copy(ctx.handle, d_cur, d_cur0, units * 4))   # "behind every message" for every unit: nothing of the step before is reused
         _lib.check(L.mp3s_rate_variants_dev(ctx.handle, d_mdct, d_rf, n, d_hide, len(hide_all), d_cur, d_eu, d_ec, n_ent, d_ix, d_out, d_en,
                                             d_ixv, d_outv, d_env))
         pk = ctx
@@ -433,6 +432,9 @@ def main():
         _lib.check(L.mp3s_select_dev(pk.handle, d_hide, d_cur, d_seg, d_spans, 1, max_reach, d_eu, d_ec, n_ent, d_ix, d_out, d_en, d_ixv, d_outv, d_env))
         _lib.check(L.mp3s_chain_redo_dev(pk.handle, d_mdct, d_rf, n, d_hide, len(hide_all), d_cur, d_seg, 1, d_ix, d_out, d_en, d_verdict, d_segout))
         _lib.check(L.mp3s_pack_frames_dev(pk.handle, d_ix, d_out, d_en, n, 44100, 128, d_off, d_pad, d_mp3, d_sc, d_pst))
+        # "behind every message" for every unit again: nothing of this step's cursors is reused by the next one (the array starts
+        # out that way; the copy rides at the end of the tail, whose stream the next rate loop waits for, not in front of that loop)
+        _lib.check(L.mp3s_dev_copy(pk.handle, d_cur, d_cur0, units * 4))
 
     def barrier():
         ctx.sync()

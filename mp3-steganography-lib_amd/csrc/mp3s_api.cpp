@@ -150,6 +150,7 @@ void mp3s_ctx_destroy(mp3s_ctx *c)
     if (c->ev0) hipEventDestroy(c->ev0);
     if (c->ev1) hipEventDestroy(c->ev1);
     if (c->ev_order) hipEventDestroy(c->ev_order);
+    if (c->ev_sel) hipEventDestroy(c->ev_sel);
     if (c->stream) hipStreamDestroy(c->stream);
     delete c;
 }
@@ -476,6 +477,9 @@ int mp3s_rate_variants_dev(mp3s_ctx *c, const int32_t *d_mdct, const mp3s_rate_f
         !d_outv || !d_env)
         return fail(MP3S_E_ARG, "null pointer");
     if (n_frames <= 0 || n_hide < 32 || n_entries <= 0) return fail(MP3S_E_ARG, "bad sizes");
+    // (a pipe runs the selection of the job in front on its tail stream: that one reads the variant buffers this launch writes)
+    if (c->sel_pending && hipStreamWaitEvent(c->stream, c->ev_sel, 0) != hipSuccess) return fail(MP3S_E_HIP, "ordering behind the previous selection failed");
+    c->sel_pending = false;
     const RateVariantArgs va = {d_ent_unit, d_ent_cursor, n_entries, d_ixv, d_outv, d_env, (uint8_t *)(d_outv + n_entries)};
     const int e = launch_rate(c->stream, d_mdct, d_frames, n_frames, d_hide_bits, n_hide, d_cursor, nullptr, nullptr, 0, d_ix, d_out, d_en,
                               &c->prof, 0, 0, &va);

@@ -189,15 +189,23 @@ int enc_issue(mp3s_ctx *c, const EncLayout &L, const EncDev &d, hipStream_t tail
     if (!rc && pcm_read && hipEventRecord(pcm_read, c->stream) != hipSuccess) rc = fail(MP3S_E_HIP, "event record failed");   // the PCM buffer may be written again
     // (the tail of the job in front is through before this job's rate loop starts: tails do not queue up behind one another)
     if (!rc && rate_after && hipStreamWaitEvent(c->stream, rate_after, 0) != hipSuccess) rc = fail(MP3S_E_HIP, "ordering behind the previous tail failed");
+    static const bool sel_on_compute = getenv("MP3S_SELECT_ON_COMPUTE") != nullptr;   // (development: the selection in front of the tail, as until r03c)
+    const bool select_on_tail = tail && L.n_entries > 0 && !sel_on_compute;
     if (!rc && L.n_entries > 0) {
-        // short messages: their variants run in the same launch and the device decides the cursor chain (no guess)
+        // short messages: their variants run in the same launch and the device decides the cursor chain (no guess).  With a tail
+        // stream the selection (two small launches) belongs to the tail: the compute stream is free for the next job's decode
+        // transforms 25 us earlier.  The variant buffers are the context's: a rate loop that writes them waits for the selection in front of it (mp3s_rate_variants_dev).
         const int32_t *d_ent = (const int32_t *)(d.d_in + L.o_ent);
-        rc = mp3s_rate_select_dev(c, d_mdct, d_rf, L.n, d_hide, L.n_hide, const_cast<int32_t *>(d_cur), d_segs,
-                                  (const mp3s_select_span *)(d.d_in + L.o_spans), L.n_segs, L.max_reach, d_ent, d_ent + L.n_entries,
-                                  L.n_entries, d.d_ix, d.d_out, d.d_en, d.d_ixv, d.d_outv, d.d_env);
+        if (!rc && !select_on_tail)
+            rc = mp3s_rate_select_dev(c, d_mdct, d_rf, L.n, d_hide, L.n_hide, const_cast<int32_t *>(d_cur), d_segs,
+                                      (const mp3s_select_span *)(d.d_in + L.o_spans), L.n_segs, L.max_reach, d_ent, d_ent + L.n_entries,
+                                      L.n_entries, d.d_ix, d.d_out, d.d_en, d.d_ixv, d.d_outv, d.d_env);
+        else if (!rc)
+            rc = mp3s_rate_variants_dev(c, d_mdct, d_rf, L.n, d_hide, L.n_hide, d_cur, d_ent, d_ent + L.n_entries, L.n_entries, d.d_ix, d.d_out, d.d_en,
+                                        d.d_ixv, d.d_outv, d.d_env);
     } else if (!rc)
         rc = mp3s_rate_loop_dev(c, d_mdct, d_rf, L.n, d_hide, L.n_hide, d_cur, nullptr, nullptr, 0, d.d_ix, d.d_out, d.d_en);
-    // The tail of a job -- chain check (two small launches) and bit packing -- reads only the job's own buffers: the pipe
+    // The tail of a job -- selection, chain check (two small launches each) and bit packing -- reads only the job's own buffers: the pipe
     // gives it a stream of its own, so that the small launches and their gaps lie under the decode transforms of the next
     // job instead of in front of them (bench.py --pack-overlap: 0.829 -> 0.785 ms per step).  Every tail goes through the
     // same stream, so the context's chain scratch and the packer's sync words are still used by one launch at a time.
@@ -206,6 +214,17 @@ int enc_issue(mp3s_ctx *c, const EncLayout &L, const EncDev &d, hipStream_t tail
         if (hipEventRecord(tail_from, c->stream) != hipSuccess || hipStreamWaitEvent(tail, tail_from, 0) != hipSuccess)
             rc = fail(MP3S_E_HIP, "ordering the tail stream failed");
         ts = tail;
+    }
+    if (!rc && select_on_tail) {
+        const int32_t *d_ent = (const int32_t *)(d.d_in + L.o_ent);
+        hipStream_t keep = c->stream;
+        c->stream = ts;                       // (the entry point launches on the context's stream)
+        rc = mp3s_select_dev(c, d_hide, const_cast<int32_t *>(d_cur), d_segs, (const mp3s_select_span *)(d.d_in + L.o_spans), L.n_segs, L.max_reach,
+                             d_ent, d_ent + L.n_entries, L.n_entries, d.d_ix, d.d_out, d.d_en, d.d_ixv, d.d_outv, d.d_env);
+        c->stream = keep;
+        if (!rc && !c->ev_sel && hipEventCreateWithFlags(&c->ev_sel, hipEventDisableTiming) != hipSuccess) rc = fail(MP3S_E_HIP, "event creation failed");
+        if (!rc && hipEventRecord(c->ev_sel, ts) != hipSuccess) rc = fail(MP3S_E_HIP, "event record failed");
+        if (!rc) c->sel_pending = true;
     }
     if (!rc) {
         // (with the device's own re-runs of the units that inherited other addresses than the zeros they were given)

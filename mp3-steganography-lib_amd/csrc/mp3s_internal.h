@@ -42,6 +42,7 @@ struct mp3s_ctx {
     mp3s_pipe *own_pipe = nullptr;       // the overlapped stages the one-file calls run their chunks through (made on first use)
     hipStream_t stream = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr, ev_order = nullptr;
+    hipEvent_t ev_sel = nullptr; bool sel_pending = false;   // a selection on a tail stream has read the variant buffers (enc_issue)
     int32_t *d_sync = nullptr;        // {finished workgroups, error bits} of the pack kernel in flight: self-clearing;
                                       // [2] counts the samples the fast synthesis computed again in the exact order
     double synth_eps_scale = 1.0;     // int16 decode: scale of the fast synthesis guard (0 = always the exact kernel)
