@@ -86,6 +86,7 @@ struct Job {
     size_t o_small = 0, o_encblk = 0, o_fix = 0, o_refs = 0, o_streams = 0, pack_end = 0;   // packed inputs inside the slot's stage (from its start)
     size_t front_end = 0;                // a chunk of a one-file call: [o_small, front_end) is what the front end needs, the encoder's inputs lie behind
     int set = 0;                         // which of the two sets of Huffman outputs / PCM buffers the job has
+    bool down_pending = false;           // the copies of its results are not queued yet (issue_down)
     uint32_t image_base = 0, md_base = 0;
     const uint8_t *d_file = nullptr; size_t file_need = 0;   // the whole file on the device (FileUp) instead of a piece in the slot's d_image: bytes [0, file_need) are read
     std::vector<uint32_t> stream_first;  // first frame of every stream of the batch
@@ -720,8 +721,12 @@ int issue_front(mp3s_pipe *P, Job &j, Slot &s, size_t blob_len, int max_p23, boo
     return MP3S_OK;
 }
 
-// ... and everything behind it: decode transforms, encode side, tail, download
-int issue_back(mp3s_pipe *P, Job &j, Slot &s, bool inputs_later)
+int issue_down(mp3s_pipe *P, Job &j, Slot &s);
+
+// ... and everything behind it: decode transforms, encode side, tail, download (defer_down: the download is queued by issue_down
+// later -- a copy that waits for its job's kernels holds up every copy queued behind it, in either direction, on engines the
+// runtime shares between the copy streams: the inputs of the next chunk of a one-file call must not queue behind it)
+int issue_back(mp3s_pipe *P, Job &j, Slot &s, bool inputs_later, bool defer_down = false)
 {
     mp3s_ctx *c = P->c;
     const double t_issue0 = trace_on() ? now_ms() : 0;
@@ -769,21 +774,8 @@ int issue_back(mp3s_pipe *P, Job &j, Slot &s, bool inputs_later)
     if (inputs_later && j.pack_end > j.front_end && !j.decode) HIPCHK(hipStreamWaitEvent(c->stream, s.e_in, 0));   // ... and its own inputs
     if (j.decode) {
         HIPCHK(hipEventRecord(s.e_comp, ds));
-        HIPCHK(hipStreamWaitEvent(P->s_down, s.e_comp, 0));
-        HIPCHK(hipMemcpyAsync(j.res->big[2].data(), d_small, kSmallHead, hipMemcpyDeviceToHost, P->s_down));
-        if (j.walked) HIPCHK(hipMemcpyAsync(j.res->big[1].data(), s.d_stage + s.o_tsel, (size_t)n * 8, hipMemcpyDeviceToHost, P->s_down));
-        if (ck.on) {
-            HIPCHK(hipMemcpyAsync(ck.dst, d_keep, (size_t)ck.count * frame_elems * esz, hipMemcpyDeviceToHost, P->s_down));
-        } else {
-            size_t first = 0;
-            for (const auto &d : j.dec) {
-                const size_t bytes = (size_t)d.n_frames * frame_elems * 2;
-                HIPCHK(hipMemcpyAsync(j.res->mp3 + d.wav_off + 44, (const int16_t *)d_keep + first * frame_elems, bytes, hipMemcpyDeviceToHost, P->s_down));
-                first += (size_t)d.n_frames;
-            }
-        }
-        HIPCHK(hipEventRecord(s.e_down, P->s_down));
-        return MP3S_OK;
+        j.down_pending = true;
+        return defer_down ? MP3S_OK : issue_down(P, j, s);
     }
     const int units = L.units;
     const size_t b_mdct = (size_t)L.n_all * 2304 * 4, b_ix = (size_t)L.n * 2304 * 2, b_out = (size_t)units * sizeof(mp3s_gr_out),
@@ -810,10 +802,42 @@ int issue_back(mp3s_pipe *P, Job &j, Slot &s, bool inputs_later)
     if (P->s_dec) P->enc_used[set] = true;
     HIPCHK(hipEventRecord(s.e_comp, P->s_tail ? P->s_tail : c->stream));
     P->last_tail = (int)(&s - P->slots.data());
+    j.down_pending = true;
+    return defer_down ? MP3S_OK : issue_down(P, j, s);
+}
+
+// the copies of a job's results to the host, behind its last kernel (e_comp)
+int issue_down(mp3s_pipe *P, Job &j, Slot &s)
+{
+    if (!j.down_pending) return MP3S_OK;
+    j.down_pending = false;
+    mp3s_ctx *c = P->c;
+    const Chunk &ck = j.ck;
+    const int n = j.n_total, nch = j.decode ? j.nch : 2;
+    const int out_format = ck.on && j.decode ? ck.out_format : MP3S_PCM_I16;
+    const size_t esz = pcm_elem(out_format), frame_elems = (size_t)1152 * nch;
+    int32_t *const d_small = j.walked ? (int32_t *)(s.d_stage + j.o_small) : s.d_small;
     HIPCHK(hipStreamWaitEvent(P->s_down, s.e_comp, 0));
-    const size_t total = j.segs.back().mp3_off + j.segs.back().mp3_len;
-    HIPCHK(hipMemcpyAsync(j.res->big[2].data(), d_small, small_bytes(L.n_segs), hipMemcpyDeviceToHost, P->s_down));
-    if (total) HIPCHK(hipMemcpyAsync(ck.on ? ck.dst : j.res->mp3, s.d_mp3, total, hipMemcpyDeviceToHost, P->s_down));
+    if (j.decode) {
+        void *d_keep = c->grab(j.set ? 26 : 7, (size_t)n * frame_elems * esz);
+        if (!d_keep) return fail(MP3S_E_NOMEM, "hipMalloc failed for a %d-frame job", n);
+        HIPCHK(hipMemcpyAsync(j.res->big[2].data(), d_small, kSmallHead, hipMemcpyDeviceToHost, P->s_down));
+        if (j.walked) HIPCHK(hipMemcpyAsync(j.res->big[1].data(), s.d_stage + s.o_tsel, (size_t)n * 8, hipMemcpyDeviceToHost, P->s_down));
+        if (ck.on) {
+            HIPCHK(hipMemcpyAsync(ck.dst, d_keep, (size_t)ck.count * frame_elems * esz, hipMemcpyDeviceToHost, P->s_down));
+        } else {
+            size_t first = 0;
+            for (const auto &d : j.dec) {
+                const size_t bytes = (size_t)d.n_frames * frame_elems * 2;
+                HIPCHK(hipMemcpyAsync(j.res->mp3 + d.wav_off + 44, (const int16_t *)d_keep + first * frame_elems, bytes, hipMemcpyDeviceToHost, P->s_down));
+                first += (size_t)d.n_frames;
+            }
+        }
+    } else {
+        const size_t total = j.segs.back().mp3_off + j.segs.back().mp3_len;
+        HIPCHK(hipMemcpyAsync(j.res->big[2].data(), d_small, small_bytes(j.L.n_segs), hipMemcpyDeviceToHost, P->s_down));
+        if (total) HIPCHK(hipMemcpyAsync(ck.on ? ck.dst : j.res->mp3, s.d_mp3, total, hipMemcpyDeviceToHost, P->s_down));
+    }
     HIPCHK(hipEventRecord(s.e_down, P->s_down));
     return MP3S_OK;
 }
@@ -1623,6 +1647,7 @@ static int run_file_impl(mp3s_ctx *c, const uint8_t *mp3, size_t len, int mode, 
         if (rc.done) return MP3S_OK;
         Job *j = rc.job.get();
         Slot &s = P->slots[(size_t)j->slot];
+        if (issue_down(P, *j, s)) return kRunFallback;
         if (hipEventSynchronize(s.e_down) != hipSuccess) return fail(MP3S_E_HIP, "waiting for a chunk's results failed");
         if (trace_on()) {
             float up = 0, huff = 0, rate = 0, comp = 0, down = 0;
@@ -1687,13 +1712,15 @@ static int run_file_impl(mp3s_ctx *c, const uint8_t *mp3, size_t len, int mode, 
         if (!prepare_chunk(P, j, s, wv.max_p23)) return kRunFallback;
         const double t_i = trace_on() ? now_ms() : 0;
         if (issue_front(P, j, s, 0, wv.max_p23, true)) return kRunFallback;
+        // (the results of the chunk in front come down behind this chunk's inputs, not in front of them)
+        if (k > 0 && chunks[k - 1].job && issue_down(P, *chunks[k - 1].job, P->slots[(size_t)chunks[k - 1].job->slot])) return kRunFallback;
         if (!prepare_chunk_encode(P, j, s)) { sync_all(P); return kRunFallback; }
         if (!decode) {
             rc.out_off = j.L.bytes_before;
             if ((size_t)rc.out_off + j.L.mp3_bytes > res_cap) { sync_all(P); return kRunFallback; }
             j.ck.dst = res->big[0].data() + rc.out_off;
         }
-        const int e = issue_back(P, j, s, true);
+        const int e = issue_back(P, j, s, true, true);
         if (trace_on()) fprintf(stderr, "mp3s:   front + inputs + back %.3f ms\n", now_ms() - t_i);
         return e ? kRunFallback : MP3S_OK;
     };
