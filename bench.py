@@ -2,7 +2,8 @@
 """Benchmark of the hot path: MP3 frames/s for decode + re-encode at 44.1 kHz stereo 128 kbps.
 
     python bench.py --gpus N --steps K --warmup W
-    (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
+    (N > 1: either under python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ..., or on its own:
+     with WORLD_SIZE unset bench.py starts its N ranks itself as child processes, tools/launch_ranks.py)
 
 Three timed regions, all on the same 10 000-frame stream and the same 67-byte message:
 
@@ -242,8 +243,16 @@ def main():
                     help="the decode transforms of batch k+1 on a context of their own, under the encode transforms and the rate loop of batch k")
     args = ap.parse_args()
 
+    # `python bench.py --gpus N` on its own (no torch.distributed.run in front): start the N ranks from here.  The parent
+    # makes no GPU call and never exec()s; it relays rank 0's one json line and returns the worst exit code.
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.path.insert(0, os.path.join(ROOT, "tools"))
+        import launch_ranks
+        sys.exit(launch_ranks.launch([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], args.gpus))
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != max(args.gpus, 1) and rank == 0:
+        print(f"bench.py: --gpus {args.gpus} but the launcher set WORLD_SIZE={world}: running {world} rank(s)", file=sys.stderr)
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     dist = None
     if world > 1:

@@ -100,6 +100,9 @@ typedef struct {
 
 /* ---------------------------------------------------------------- context */
 int mp3s_ctx_create(int device, mp3s_ctx **out);
+/* how many HIP devices this process can open (what a launcher of one process per GPU sizes itself by); 0 and MP3S_OK
+ * on a host without one */
+int mp3s_device_count(int *n);
 void mp3s_ctx_destroy(mp3s_ctx *ctx);
 const char *mp3s_last_error(void);
 const char *mp3s_version(void);

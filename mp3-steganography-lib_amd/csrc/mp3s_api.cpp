@@ -89,6 +89,14 @@ int mp3s_debug_walk_rate(const uint8_t *file, size_t len, double seconds, double
     return MP3S_OK;
 }
 
+int mp3s_device_count(int *n)
+{
+    if (!n) return fail(MP3S_E_ARG, "n is null");
+    int k = 0;
+    *n = hipGetDeviceCount(&k) == hipSuccess && k > 0 ? k : 0;
+    return MP3S_OK;
+}
+
 int mp3s_ctx_create(int device, mp3s_ctx **out)
 {
     if (!out) return fail(MP3S_E_ARG, "out is null");

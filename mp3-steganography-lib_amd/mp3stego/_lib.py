@@ -178,7 +178,7 @@ SYMBOLS = ["mp3s_ctx_create", "mp3s_ctx_destroy", "mp3s_ctx_wait", "mp3s_last_er
            "mp3s_hide_message", "mp3s_clear_file", "mp3s_hide_messages", "mp3s_reencode_block", "mp3s_reveal_message",
            "mp3s_pipe_create", "mp3s_pipe_destroy", "mp3s_pipe_submit", "mp3s_pipe_submit_decode", "mp3s_pipe_collect", "mp3s_pipe_get_stats",
            "mp3s_index_stream", "mp3s_index_free", "mp3s_scan_range", "mp3s_decode_block_indexed", "mp3s_reencode_block_indexed",
-           "mp3s_hide_message_chunked", "mp3s_walk_stream", "mp3s_parse_frames_dev", "mp3s_stego_bits", "mp3s_ctx_set_option", "mp3s_ctx_get_option", "mp3s_ctx_run_stats", "mp3s_dev_copy", "mp3s_pipe_submit_block", "mp3s_pipe_collect_block", "mp3s_pipe_next_is_block", "mp3s_debug_walk_rate"]
+           "mp3s_hide_message_chunked", "mp3s_walk_stream", "mp3s_parse_frames_dev", "mp3s_stego_bits", "mp3s_ctx_set_option", "mp3s_ctx_get_option", "mp3s_ctx_run_stats", "mp3s_dev_copy", "mp3s_pipe_submit_block", "mp3s_pipe_collect_block", "mp3s_pipe_next_is_block", "mp3s_debug_walk_rate", "mp3s_device_count"]
 
 _lib = None
 _lock = threading.Lock()
@@ -201,6 +201,7 @@ def lib():
         L.mp3s_last_error.restype = C.c_char_p
         L.mp3s_version.restype = C.c_char_p
         L.mp3s_ctx_create.argtypes = [i32, pvp]
+        L.mp3s_device_count.argtypes = [C.POINTER(C.c_int)]
         L.mp3s_ctx_destroy.argtypes = [vp]
         L.mp3s_ctx_destroy.restype = None
         L.mp3s_device_name.argtypes = [vp, C.c_char_p, sz]
@@ -288,6 +289,13 @@ def lib():
         L.mp3s_debug_walk_rate.argtypes = [vp, sz, C.c_double, C.POINTER(C.c_double), C.POINTER(C.c_int64)]
         _lib = L
     return _lib
+
+
+def device_count():
+    """HIP devices this process can open (mp3s_device_count); touches the HIP runtime"""
+    n = C.c_int()
+    check(lib().mp3s_device_count(C.byref(n)))
+    return n.value
 
 
 def check(rc):

@@ -224,3 +224,43 @@ def test_two_processes_one_stream(ctx, mlib, tmp_path):
     whole = ctx.hide_message(mp3, "two ranks, one stream")
     assert res["mp3"] == hashlib.sha256(whole["data"]).hexdigest() and res["too_long"] == whole["too_long"]
     assert res["pcm"] == hashlib.sha256(ctx.decode_stream(mp3, mlib.MP3S_PCM_I16)["pcm"].tobytes()).hexdigest()
+
+
+def _json_line(text):
+    return json.loads([l for l in text.splitlines() if l.startswith("{")][-1])
+
+
+@pytest.mark.gpu
+def test_bench_gpus2_starts_its_own_ranks():
+    """`python bench.py --gpus 2` with WORLD_SIZE unset (the shape of the driver's N=1 command): the parent starts two rank
+    processes (tools/launch_ranks.py), both pinned to the test box's one GPU, and relays rank 0's one json line"""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    env["MP3STEGO_DEVICE"] = "0"
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "5", "--no-config5", "--no-cpu-baseline",
+                        "--no-single-file-100k", "--e2e-batches", "40", "--frames", "2000"], env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, r.stdout[-2000:]
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["parity_checked"] is True and out["scaling"] == "weak"
+    assert len(out["ranks_on_this_host"]) == 2 and sorted(h["rank"] for h in out["ranks_on_this_host"]) == [0, 1]
+    assert out["config"]["parallelism"].startswith("frames sharded over 2 GPU")
+
+
+@pytest.mark.gpu
+def test_config4_as_processes_equals_config4_in_one_process():
+    """BASELINE configs[3] in small: 5 streams x 400 frames as 2 blocks (the boundary halves stream 2).  One process playing
+    both ranks and two processes (own context + pipe each, the carry over gloo) must print the same CRC per rank, and both
+    must agree with the single call on every stream and with the oracle on the sample"""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    env["MP3STEGO_DEVICE"] = "0"
+    tool = os.path.join(ROOT, "tools", "config4.py")
+    one = subprocess.run([sys.executable, tool, "5", "400", "2"], env=env, capture_output=True, text=True, timeout=900)
+    assert one.returncode == 0, one.stderr[-3000:]
+    a = _json_line(one.stdout)
+    two = subprocess.run([sys.executable, tool, "5", "400", "2", "--procs", "2"], env=env, capture_output=True, text=True, timeout=900)
+    assert two.returncode == 0, two.stderr[-3000:]
+    b = _json_line(two.stdout)
+    assert a["ok"] and b["ok"] and b["procs"] == 2 and len(b["rank_ms"]) == 2
+    assert a["rank_crc32"] == b["rank_crc32"]
+    assert b["pieces"] == 6 and b["pieces_equal_to_single_call"] == 6 and b["halves_fit"]

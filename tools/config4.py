@@ -12,6 +12,14 @@ frames); (2) CRC32 of every rank's output; (3) the oracle (CPU restatement) on a
 stream per rank, decode + encode, byte for byte.
 
 usage (GPU box): python tools/config4.py [streams=100] [frames=10000] [ranks=8] > profiles/r02_config4.json
+
+`--procs N` (round 4): the same job as N PROCESSES, one per rank (one per GPU; MP3STEGO_DEVICE=k puts them all on device k):
+every rank builds only the streams its block touches, owns its own context and pipe, and runs its block on its own clock
+between two barriers.  The rank that holds the SECOND half of a stream starts it on the guess "message hidden, nothing
+inherited" and receives the real 136-byte carry from the rank in front over gloo (dist.isend / irecv, exactly
+mp3stego/sharded.py's rule: run again only if the block looked at its carry and the guess was wrong).  Nothing else passes
+between ranks.  Rank 0 prints the per-rank times, the aggregate frames/s (all frames / slowest rank) and the same CRCs the
+one-process run prints.  With WORLD_SIZE unset the ranks are started from here (tools/launch_ranks.py).
 """
 import json
 import multiprocessing as mp
@@ -35,9 +43,22 @@ def _pcm(args):
 
 
 def main():
-    n_streams = int(sys.argv[1]) if len(sys.argv) > 1 else 100
-    frames = int(sys.argv[2]) if len(sys.argv) > 2 else 10000
-    ranks = int(sys.argv[3]) if len(sys.argv) > 3 else 8
+    argv = [a for a in sys.argv[1:]]
+    procs = 0
+    if "--procs" in argv:
+        k = argv.index("--procs")
+        procs = int(argv[k + 1])
+        del argv[k:k + 2]
+    n_streams = int(argv[0]) if len(argv) > 0 else 100
+    frames = int(argv[1]) if len(argv) > 1 else 10000
+    ranks = int(argv[2]) if len(argv) > 2 else (procs or 8)
+    if procs:
+        assert procs == ranks, "--procs N = N ranks, one process each"
+        if "WORLD_SIZE" not in os.environ:
+            sys.path.insert(0, os.path.join(ROOT, "tools"))
+            import launch_ranks
+            sys.exit(launch_ranks.launch([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], procs))
+        return rank_main(n_streams, frames, ranks)
     total = n_streams * frames
     assert total % ranks == 0 and (2 * total // ranks) % frames == 0, "block boundaries fall on stream starts or stream middles"
     per_rank = total // ranks
@@ -147,6 +168,186 @@ def main():
            "ok": same == n_streams and oracle_same == ranks}
     print(json.dumps(res))
     sys.exit(0 if res["ok"] else 3)
+
+
+def rank_main(n_streams, frames, ranks):
+    """one rank of `--procs N` (RANK / WORLD_SIZE / MASTER_* from the launcher)"""
+    rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+    assert world == ranks
+    total = n_streams * frames
+    assert total % ranks == 0 and (2 * total // ranks) % frames == 0, "block boundaries fall on stream starts or stream middles"
+    per_rank = total // ranks
+    g0, g1 = rank * per_rank, (rank + 1) * per_rank
+    t_all = time.time()
+    # the block's pieces in stream order: (stream, kind) with kind "whole" | "first" (frames [0, n/2) of it) | "second"
+    plan, pos, i = [], g0, g0 // frames
+    while pos < g1:
+        a, b = pos - i * frames, min(g1 - i * frames, frames)
+        plan.append((i, "whole" if (a == 0 and b == frames) else ("first" if a == 0 else "second")))
+        pos = i * frames + b
+        i += 1
+    mine = sorted({i for i, _ in plan})
+    pool = mp.get_context("fork").Pool(max(1, min(len(mine), (os.cpu_count() or 8) // world, 12)))   # forked before torch / the GPU
+    it = pool.imap_unordered(_pcm, [(i, frames) for i in mine])
+    import torch
+    import torch.distributed as dist
+    sys.stdout.flush()
+    keep_out = os.dup(1)
+    os.dup2(2, 1)                                   # (the gloo transport announces its connections on stdout)
+    try:
+        dist.init_process_group(backend="gloo", rank=rank, world_size=world)
+        dist.barrier()
+    finally:
+        sys.stdout.flush()
+        os.dup2(keep_out, 1)
+        os.close(keep_out)
+    from mp3stego import _lib
+    from mp3stego.sharded import CARRY_WORDS, _PAST_MESSAGE, _same_effect
+    ctx = _lib.Context(int(os.environ.get("MP3STEGO_DEVICE", os.environ.get("LOCAL_RANK", "0"))))
+    streams = {}
+    for i, pcm in it:
+        streams[i] = bytes(ctx.encode_pcm(pcm, 44100, 128, None)["mp3"])
+    pool.close(); pool.join()
+    msgs = {i: "stream %03d: the quick brown fox jumps over the lazy dog, again!" % i for i in mine}
+    t_inputs = time.time() - t_all
+    pipe = _lib.Pipe(ctx, depth=4, max_job_bytes=max(len(s) for s in streams.values()) + 65536,
+                     scan_threads=int(os.environ.get("CONFIG4_SCAN_THREADS", "2")))
+    w = mine[0]
+    for _ in range(4):
+        assert pipe.submit([streams[w]], [msgs[w]]) is not None
+    while pipe.collect() is not None:
+        pass
+    assert pipe.submit_block(streams[w], msgs[w], 0, 2, None) is not None
+    _t, _w = pipe.collect()
+    assert pipe.submit_block(streams[w], msgs[w], 1, 2, _w["carry_out"]) is not None
+    pipe.collect()
+    del _w
+    ARENA["buf"] = np.zeros(2 * sum(len(x) for x in streams.values()) + (1 << 20), dtype=np.uint8)
+    guess = np.zeros(CARRY_WORDS, dtype=np.int64)
+    guess[0] = _PAST_MESSAGE
+    has_second = any(k == "second" for _, k in plan)
+    has_first = any(k == "first" for _, k in plan)
+    # the order of submission is free (results are put in place by piece): the first half at the block's END goes first, so that
+    # its carry reaches the next rank early; then the second half at the block's start, on the guess; then the whole streams
+    todo = sorted(range(len(plan)), key=lambda k: {"first": 0, "second": 1, "whole": 2}[plan[k][1]])
+    data = [None] * len(plan)
+    real_t = torch.zeros(CARRY_WORDS, dtype=torch.int64)
+    dist.barrier()
+    t0 = time.perf_counter()
+    rreq = dist.irecv(real_t, rank - 1) if has_second else None
+    sreq, reruns, carry_wait_ms = None, 0, 0.0
+    flight = {}                                     # ticket -> (piece, carry it ran on)
+
+    def submit(k, carry):
+        i, kind = plan[k]
+        if kind == "whole":
+            t = pipe.submit([streams[i]], [msgs[i]])
+        else:
+            t = pipe.submit_block(streams[i], msgs[i], 0 if kind == "first" else 1, 2, carry)
+        if t is not None:
+            flight[t] = (k, carry)
+        return t is not None
+
+    queue = [(k, guess if plan[k][1] == "second" else None) for k in todo]
+    while queue or flight:
+        while queue and submit(*queue[0]):
+            queue.pop(0)
+        got = pipe.collect()
+        if got is None:
+            continue
+        t, res = got
+        k, carry = flight.pop(t)
+        i, kind = plan[k]
+        if kind == "whole":
+            data[k] = keep(res[0]["data"])
+            continue
+        if kind == "first":
+            sreq = dist.isend(torch.from_numpy(np.asarray(res["carry_out"], dtype=np.int64).copy()), rank + 1)
+            data[k] = keep(res["mp3"])
+            continue
+        if carry is guess:                          # the second half came back from its run on the guess: what was the real carry?
+            tw = time.perf_counter()
+            rreq.wait()
+            carry_wait_ms += (time.perf_counter() - tw) * 1e3
+            real = real_t.numpy().copy()
+            n_hide = len(_lib.message_frame(msgs[i]))
+            live = min(int(real[0]), n_hide) < n_hide
+            if not _same_effect(real, guess, n_hide) and (res["carry_used"] or live):
+                reruns += 1
+                queue.insert(0, (k, real))
+                continue
+        data[k] = keep(res["mp3"])
+    dt = time.perf_counter() - t0
+    if sreq is not None:
+        sreq.wait()
+    dist.barrier()
+    t_job = time.perf_counter() - t0
+    st = pipe.stats()
+    pipe.close()
+    crc = 0
+    for d in data:
+        crc = zlib.crc32(d.tobytes(), crc)
+    # ---- check 1: every piece against the single call on its whole stream
+    same, half_lens = 0, {}
+    for k, (i, kind) in enumerate(plan):
+        whole = ctx.hide_message(streams[i], msgs[i])
+        wb, mine_b = bytes(whole["data"]), data[k].tobytes()
+        if kind == "whole":
+            ok = mine_b == wb
+        elif kind == "first":
+            ok = wb[:len(mine_b)] == mine_b
+        else:
+            ok = wb[len(wb) - len(mine_b):] == mine_b
+        if kind != "whole":
+            half_lens[(i, kind)] = (len(mine_b), len(wb))
+        same += int(ok and not whole["too_long"])
+    # ---- check 3: the oracle on a 1 % sample (the first stream that starts inside the block, its first k frames)
+    import oracle_lib as O
+    kf = max(8, (total // 100) // ranks)
+    i = (rank * per_rank + frames - 1) // frames
+    oracle_same, oracle_frames = 0, 0
+    if i in streams:
+        p = _lib.parse_stream(streams[i])
+        prefix = streams[i][:int(p["frame_size"][:kf + 1].sum())]
+        d = O.decode(prefix)
+        o = O.encode(O.pcm_to_i16(d["pcm"])[:kf * 1152], 44100, 128, np.array(_lib.message_frame(msgs[i])))
+        mine_b = data[[k for k, (j, kind) in enumerate(plan) if j == i][0]].tobytes()
+        m = len(o["mp3"]) - 8
+        oracle_same, oracle_frames = int(o["rc"] == 0 and mine_b[:m] == o["mp3"][:m]), kf
+    ctx.close()
+    part = {"rank": rank, "ms": round(dt * 1e3, 3), "crc": "%08x" % crc, "pieces": len(plan), "pieces_equal": same, "half_lens": half_lens,
+            "oracle_same": oracle_same, "oracle_frames": oracle_frames, "reruns": reruns, "carry_wait_ms": round(carry_wait_ms, 3),
+            "job_ms": round(t_job * 1e3, 3), "pipe": {"fast": st["fast"], "resolved": st["resolved"], "slow": st["slow"]},
+            "inputs_s": round(t_inputs, 1), "device": ctx.device}
+    parts = [None] * world if rank == 0 else None
+    dist.gather_object(part, parts, dst=0)
+    ok = True
+    if rank == 0:
+        halves = {}
+        for pt in parts:
+            halves.update(pt["half_lens"])
+        halves_fit = all(halves[(i, "first")][0] + halves[(i, "second")][0] == halves[(i, "first")][1]
+                         for (i, kind) in halves if kind == "first")
+        rank_ms = [pt["ms"] for pt in parts]
+        n_pieces = sum(pt["pieces"] for pt in parts)
+        res = {"config": "BASELINE configs[3] as %d PROCESSES: %d frames = %d streams x %d, one contiguous block of %d frames per rank, "
+                         "each rank with its own context and pipe, carries over gloo" % (world, total, n_streams, frames, per_rank),
+               "frames": total, "procs": world, "devices": [pt["device"] for pt in parts], "rank_ms": rank_ms,
+               "rank_crc32": [pt["crc"] for pt in parts], "slowest_rank_ms": max(rank_ms),
+               "job_ms_between_barriers": max(pt["job_ms"] for pt in parts),
+               "frames_per_s": round(total / (max(pt["job_ms"] for pt in parts) / 1e3), 1),
+               "pieces": n_pieces, "pieces_equal_to_single_call": sum(pt["pieces_equal"] for pt in parts), "halves_fit": halves_fit,
+               "oracle_sample_frames": sum(pt["oracle_frames"] for pt in parts), "oracle_sample_streams_equal": sum(pt["oracle_same"] for pt in parts),
+               "oracle_sample_streams": sum(1 for pt in parts if pt["oracle_frames"]),
+               "second_half_reruns": [pt["reruns"] for pt in parts], "carry_wait_ms": [pt["carry_wait_ms"] for pt in parts],
+               "pipe": [pt["pipe"] for pt in parts], "inputs_s": max(pt["inputs_s"] for pt in parts), "total_s": round(time.time() - t_all, 1)}
+        res["ok"] = ok = (res["pieces_equal_to_single_call"] == n_pieces and halves_fit and
+                          res["oracle_sample_streams_equal"] == res["oracle_sample_streams"])
+        print(json.dumps(res))
+    flag = torch.tensor([1.0 if ok else 0.0])
+    dist.broadcast(flag, 0)
+    dist.destroy_process_group()
+    sys.exit(0 if flag[0] > 0.5 else 3)
 
 
 def _idx(pieces, ticket):
