@@ -314,7 +314,7 @@ def main():
     d_hst2 = [ctx.alloc(16), ctx.alloc(16)]
     aux = None if args.no_overlap else _lib.Context(ctx.device)   # second stream on the same device
     # third stream: the tail of batch k (selection, scatter, chain check: four small launches, and the bit packer) runs under the decode
-    # transforms of batch k+1, as in the library's pipe (mp3s_pipe.cpp: s_tail) -- the small launches and their gaps are 5 %
+    # transforms of batch k+1, as in the library's pipe (csrc/pipe_jobs.cpp: s_tail) -- the small launches and their gaps are 5 %
     # of a step when they sit in front of the next batch (0.829 -> 0.785 ms per step)
     aux2 = _lib.Context(ctx.device) if not (args.no_tail_stream or args.no_overlap) else None
     # fourth stream: the int16 decode transforms wait for scalar operands half of the time (45 % of their issue slots busy), the

@@ -305,7 +305,7 @@ int launch_place_frames(hipStream_t stream, const uint8_t *d_entries, int n_entr
 }
 
 // One wave that keeps its hardware queue busy for `ticks` of the 100 MHz wall clock (bounded), and a kernel that does nothing:
-// the pipe finds out with them which of its candidate streams run beside a context's compute stream (mp3s_pipe.cpp, pick_lanes)
+// the pipe finds out with them which of its candidate streams run beside a context's compute stream (pipe_lanes.cpp, pick_lanes)
 __global__ void k_spin(long long ticks, int *sink)
 {
     const long long t0 = wall_clock64();

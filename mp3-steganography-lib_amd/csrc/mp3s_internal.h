@@ -314,7 +314,7 @@ int select_plan(const mp3s_chain_seg *segs, int n_segs, mp3s_select_span *spans,
                 const int32_t *min_reach);
 void tables_guess_of(const mp3s_frame_side *side, long n_frames, int extra, std::vector<uint8_t> &out);
 
-// ---------------------------------------------------------------- one file as chunks through the overlapped stages (mp3s_pipe.cpp)
+// ---------------------------------------------------------------- one file as chunks through the overlapped stages (run_file.cpp)
 constexpr int kRunFallback = 1;          // run_file: not for this path -- the caller takes the synchronous one (same bytes)
 constexpr int kRunHide = 0, kRunClear = 1, kRunDecode = 2;
 struct RunResult {

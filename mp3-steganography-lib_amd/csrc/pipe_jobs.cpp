@@ -19,176 +19,7 @@
 // (mono re-encode, a repeated last frame, unsupported rates, staging too small), or whose verdict says the Huffman data is
 // damaged, is redone by the synchronous path -- same bytes, by construction of that path; the fast path is an
 // optimisation, never a different answer.
-#include <sched.h>
-#include <time.h>
-
-#include <condition_variable>
-#include <deque>
-
-#include "mp3s_internal.h"
-
-namespace {
-
-constexpr int kMaxFastFiles = 1024;
-constexpr size_t kDirectUpload = (size_t)256 << 10;   // a file at least this long goes up from the caller's memory in a copy of its own
-constexpr uint32_t kImageLead = 1024;                 // bytes in front of a chunk's first frame its reservoir pointers can name (511 + 8 x 38)
-constexpr int kRunDepth = 3;                          // chunks of one file in flight
-
-struct Slot {
-    uint8_t *h_stage = nullptr;          // page-locked: [blob | side records | packed inputs]; the walk uses the last part only
-    uint8_t *d_stage = nullptr;          // the same layout on the device, + [decoder frame headers | table-index words]
-    size_t blob_cap = 0, side_cap = 0 /* frames */, in_cap = 0, fix_cap = 0 /* entries */, pack_cap = 0, o_side = 0, o_in = 0, o_dechdr = 0, o_tsel = 0,
-           stage_bytes = 0;
-    uint8_t *d_image = nullptr; size_t image_cap = 0;   // the file bytes of a walked job
-    uint8_t *h_image = nullptr;                          // page-locked, made on first need: short files are laid end to end here first
-    uint8_t *d_mp3 = nullptr; size_t mp3_cap = 0;
-    int32_t *d_small = nullptr;
-    // the encoder's intermediates of the slot's job (mdct, quantised lines, GrInfo, energies, scfsi): the slot's own, so
-    // that a job whose cursor guess failed is resolved on them at collect time while later jobs have long been issued
-    uint8_t *d_enc = nullptr; size_t enc_cap = 0;
-    hipEvent_t e_start = nullptr, e_up = nullptr, e_in = nullptr, e_huff = nullptr, e_rate = nullptr, e_comp = nullptr, e_down = nullptr;
-    bool busy = false;
-};
-
-struct Upload { size_t dst; const uint8_t *src; size_t bytes; };   // into the slot's d_image
-
-// a chunk of one file (run_file): frames [w0, w0 + n_win) of the stream go to the device, of which the first `halo` only
-// rebuild decoder state (IMDCT overlap, synthesis fifo: < 1 frame, Frame.py:151-153, 81-92) and the next `lead` only
-// encoder state (filter bank + MDCT history: 1 056 samples, MP3_Encoder.py:356, 685, 747)
-struct Chunk {
-    bool on = false;
-    const FrameRef *refs = nullptr;      // the stream's frames as walked (file / blob offsets of the whole stream)
-    long w0 = 0, n_win = 0, first = 0, count = 0;
-    int halo = 0, lead = 0;
-    bool last = false;
-    bool has_carry = false; mp3s_carry carry_in = {};
-    int out_format = MP3S_PCM_I16;
-    uint8_t *dst = nullptr;              // where the chunk's bytes go on the host (MP3 frames; PCM of a decode)
-    const uint8_t *file = nullptr; size_t file_len = 0;
-    uint32_t image_lo = 0, image_hi = 0; // the piece of the file that goes up
-    const uint8_t *fix = nullptr;        // kPlaceEntry bytes: the stream's last frame decoded on the host (index in the window filled in here), or null
-    const uint8_t *tables = nullptr; int n_tables = 0; int any_silent = -1;   // the walk's table counts for the chunk's own units
-    const uint8_t *hide = nullptr; int n_hide = 0;
-    int rate = 0, kbps = 0, nch = 2;
-    bool decode = false;
-};
-
-struct Job {
-    int64_t ticket = 0;
-    int slot = -1;
-    std::vector<std::pair<const uint8_t *, size_t>> files, msgs;   // borrowed until the job is collected
-    bool clear_all = false;
-    bool decode = false;                 // MP3 -> WAV (int16) instead of hide / clear
-    enum State { QUEUED, ISSUED, SLOW_DONE } state = QUEUED;
-    // fast path
-    bool walked = false;                 // side info and main data are taken apart on the device (k_dec_parse)
-    std::vector<Upload> ups;
-    size_t o_small = 0, o_encblk = 0, o_fix = 0, o_refs = 0, o_streams = 0, pack_end = 0;   // packed inputs inside the slot's stage (from its start)
-    size_t front_end = 0;                // a chunk of a one-file call: [o_small, front_end) is what the front end needs, the encoder's inputs lie behind
-    int set = 0;                         // which of the two sets of Huffman outputs / PCM buffers the job has
-    bool down_pending = false;           // the copies of its results are not queued yet (issue_down)
-    uint32_t image_base = 0, md_base = 0;
-    const uint8_t *d_file = nullptr; size_t file_need = 0;   // the whole file on the device (FileUp) instead of a piece in the slot's d_image: bytes [0, file_need) are read
-    std::vector<uint32_t> stream_first;  // first frame of every stream of the batch
-    std::vector<std::vector<uint8_t>> bits, guess;
-    std::vector<EncSeg> segs;
-    EncLayout L;
-    EncDev dev;
-    int rate = 0, kbps = 0;
-    std::unique_ptr<mp3s_buf> res;
-    // synchronous path
-    mp3s_buf *slow_owner = nullptr;
-    std::vector<mp3s_file> slow_out;
-    std::vector<int32_t> slow_st;
-    int slow_rc = 0;
-    std::string slow_err;
-    double scan_ms = 0, issue_ms = 0;
-    int n_fix = 0;
-    // decode jobs: per file the frames, rows, header fields, where its WAV starts in the result block, its stego bits
-    struct DecFile { int n_frames, nch, rate, bit_rate; size_t wav_off, bits_off, n_bits; long first; };
-    std::vector<DecFile> dec;
-    std::vector<uint8_t> res_bits;
-    int nch = 2, n_total = 0, max_p23 = 0;
-    Chunk ck;
-    // block jobs (mp3s_pipe_submit_block): one rank's share of a stream
-    bool block = false;
-    int rank = 0, world = 1;
-    bool has_carry = false; mp3s_carry carry = {};
-    std::vector<FrameRef> refs;          // the stream's frames as walked (ck.refs points here)
-    std::vector<uint8_t> fix;            // its last frame decoded on the host (kPlaceEntry bytes), if that is needed
-    mp3s_block blk = {};                 // what the caller gets
-    mp3s_buf *blk_owner = nullptr;       // ... from the synchronous path
-};
-
-}  // namespace
-
-// One-file calls (the context's own pipe): the whole file goes to the device in pieces that a helper thread queues while the
-// caller walks the frame headers -- a copy from ordinary memory occupies the thread that queues it for as long as the copy
-// takes (0.09 ms per 4 MB), and the chunk whose bytes are on the way is exactly the one the caller is busy preparing.
-struct FileUp {
-    std::thread th;
-    std::mutex mu;
-    std::condition_variable cv;
-    bool stop = false, busy = false, started = false;
-    const uint8_t *src = nullptr;
-    std::vector<size_t> ends;            // piece i = bytes [ends[i - 1], ends[i])
-    std::vector<hipEvent_t> ev;          // ... is on the device when ev[i] has passed (recorded on s_img)
-    std::atomic<long> recorded{0};       // pieces whose copy and event are queued
-    std::atomic<int> err{0};
-    uint8_t *d_file = nullptr; size_t cap = 0;
-    bool active = false;                 // the call in progress reads its file from d_file
-};
-
-struct WalkOut {                         // the walker's state behind a chunk of a one-file call
-    long got = 0;
-    bool ended = false, irregular = false, dup_last = false, any_silent = false, have_fix = false;
-    int nch = 0, sampling_rate = 0, bit_rate = 0, max_p23 = 0;
-    long tables_frames = 0;
-};
-
-struct mp3s_pipe {
-    mp3s_ctx *c = nullptr;
-    int depth = 0;
-    hipStream_t s_img = nullptr;         // the file pieces' own copy stream (the packed inputs of a chunk must not queue behind them)
-    FileUp up;
-    bool internal = false;               // the context's own (run_file): no worker threads, jobs issued by the caller
-    size_t max_job_bytes = 0;
-    std::vector<Slot> slots;
-    hipStream_t s_up = nullptr, s_down = nullptr;
-    hipStream_t s_dec = nullptr;         // the decode transforms of job k+1 under the encode transforms and the rate loop of job k (null: on the compute stream)
-    hipEvent_t e_enc[2] = {nullptr, nullptr}; bool enc_used[2] = {false, false};   // the encode transforms that read PCM buffer x last are done
-    hipStream_t s_comp = nullptr, s_ctx = nullptr;   // a compute stream of the pipe's own (pick_lanes), and the context's while the pipe has put its own in its place
-    // The Huffman kernel is a latency chain that leaves the vector units mostly idle; the rate loop is bound by them.  The
-    // front end of job k+1 therefore runs on a stream of its own, under the encode half of job k, with two sets of
-    // Huffman outputs (is / side records) taken in turn; e_dec[x] = the decode transforms that read set x last are done.
-    hipStream_t s_huff = nullptr;
-    // ... and, optionally (MP3S_OPT_PIPE_TAIL; measured slower here, see mp3s_pipe_create), the tail of a job (chain check +
-    // bit packing) on another one, under the decode transforms of the next job; e_rate orders it behind the job's rate loop
-    hipStream_t s_tail = nullptr;
-    int last_tail = -1;                  // slot of the job whose tail was issued last
-    bool tail_throttle = false;
-    size_t direct_upload = kDirectUpload;
-    hipEvent_t e_dec[2] = {nullptr, nullptr};
-    bool dec_used[2] = {false, false};
-    unsigned issued = 0;
-    // the PCM of a batch lives in one of two device buffers taken in turn; a decode job downloads from it while the
-    // next job computes: keep_slot[x] = slot of the job whose download reads buffer x last (-1: none)
-    int keep_slot[2] = {-1, -1};
-    std::mutex mu;                       // queue, job states, slots, statistics
-    std::condition_variable cv_work, cv_done, cv_turn;
-    int64_t next_issue = 0;              // ticket of the job whose turn it is to be issued
-    std::mutex mu_issue;                 // everything that touches the context (its stream, pool, profiler)
-    std::deque<std::unique_ptr<Job>> inflight;   // ticket order; front = next to collect
-    // One queue per worker, and a slot always goes to the same worker (slot % workers): the staging of a slot stays in
-    // the cache hierarchy of the core that wrote it last, and a scan from another core complex would fetch every line it
-    // overwrites from there (measured: 0.75 ms per 10 000 frames on the slot's own worker, 2.5 ms on changing ones).
-    std::vector<std::deque<Job *>> todo;
-    std::vector<std::thread> workers;
-    std::vector<int> node_cpus;          // CPUs of the GPU's NUMA node this process may run on (empty: unknown / no binding)
-    bool stop = false;
-    int64_t next_ticket = 0;
-    mp3s_pipe_stats st = {};
-};
+#include "pipe_internal.h"
 
 namespace {
 
@@ -198,6 +29,8 @@ double thread_cpu_ms()
     clock_gettime(CLOCK_THREAD_CPUTIME_ID, &ts);
     return ts.tv_sec * 1e3 + ts.tv_nsec * 1e-6;
 }
+
+}  // namespace
 
 int reencode_params(int sampling_rate, int bit_rate, int nch, long n_frames, int dup_last, int *kbps_out)
 {
@@ -209,6 +42,8 @@ int reencode_params(int sampling_rate, int bit_rate, int nch, long n_frames, int
     *kbps_out = kbps;
     return 0;
 }
+
+namespace {
 
 // the result block of a decode job: per file a WAV image, its PCM 64 bytes into an aligned region, the 44-byte header right
 // in front of it (what mp3s_decode_file hands out)
@@ -368,107 +203,7 @@ bool prepare_walk(mp3s_pipe *P, Job &j, Slot &s)
     return true;
 }
 
-// ---- a chunk of one file: the same packed inputs for frames [w0, w0 + n_win) of a stream that run_file has walked
-void bind_to(const std::vector<int> &cpus);
-
-// ---- the whole file of a one-file call on the device (FileUp)
-constexpr size_t kFileOnDevice = (size_t)1 << 30;       // longer files: chunk by chunk through the slots' own image buffers
-constexpr size_t kFilePiece = (size_t)4 << 20;
-
-void file_up_thread(mp3s_pipe *P)
-{
-    FileUp &u = P->up;
-    (void)hipSetDevice(P->c->device);
-    if (!P->node_cpus.empty()) bind_to(P->node_cpus);
-    std::unique_lock<std::mutex> lk(u.mu);
-    for (;;) {
-        u.cv.wait(lk, [&] { return u.stop || (u.busy && !u.started); });
-        if (u.stop) return;
-        u.started = true;
-        lk.unlock();
-        // (piece 0 is the caller's own: it needs it first, and this thread takes longer to wake up than the copy takes)
-        while (u.recorded.load(std::memory_order_acquire) < 1 && !u.err.load()) std::this_thread::yield();
-        size_t from = u.ends[0];
-        for (size_t i = 1; i < u.ends.size() && !u.err.load(); i++) {
-            if (hipMemcpyAsync(u.d_file + from, u.src + from, u.ends[i] - from, hipMemcpyHostToDevice, P->s_img) != hipSuccess ||
-                hipEventRecord(u.ev[i], P->s_img) != hipSuccess) { u.err.store(1); break; }
-            from = u.ends[i];
-            u.recorded.store((long)i + 1, std::memory_order_release);
-        }
-        lk.lock();
-        u.busy = false;
-        u.cv.notify_all();
-    }
-}
-
-void file_up_end(mp3s_pipe *P);
-
-// queue the upload of file[0, len): a first piece of first_bytes (the first chunk's), then kFilePiece at a time
-bool file_up_begin(mp3s_pipe *P, const uint8_t *file, size_t len, size_t first_bytes)
-{
-    FileUp &u = P->up;
-    u.active = false;
-    if (!P->internal || !P->s_img || len > kFileOnDevice || getenv("MP3S_NO_FILE_UP")) return false;
-    if (len + 256 > u.cap) {
-        if (u.d_file) (void)hipFree(u.d_file);
-        u.d_file = nullptr; u.cap = 0;
-        const size_t want = std::max<size_t>(len + len / 4 + 4096, (size_t)8 << 20);
-        if (hipMalloc((void **)&u.d_file, want) != hipSuccess) { (void)hipGetLastError(); return false; }
-        u.cap = want;
-    }
-    u.ends.clear();
-    size_t at = std::min(len, std::max<size_t>(first_bytes, 4096));
-    u.ends.push_back(at);
-    while (at < len) { at = std::min(len, at + kFilePiece); u.ends.push_back(at); }
-    while (u.ev.size() < u.ends.size()) {
-        hipEvent_t e = nullptr;
-        if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) return false;
-        u.ev.push_back(e);
-    }
-    u.recorded.store(0); u.err.store(0);
-    {
-        std::lock_guard<std::mutex> g(u.mu);
-        if (!u.th.joinable()) {
-            try { u.th = std::thread(file_up_thread, P); }
-            catch (const std::exception &) { return false; }     // (no thread to be had: every chunk's piece from the caller, as for a file above 1 GB)
-        }
-        u.src = file; u.busy = true; u.started = false;
-    }
-    u.cv.notify_all();
-    u.active = true;
-    if (hipMemcpyAsync(u.d_file, file, u.ends[0], hipMemcpyHostToDevice, P->s_img) != hipSuccess || hipEventRecord(u.ev[0], P->s_img) != hipSuccess) {
-        (void)hipGetLastError();
-        u.err.store(1);
-        file_up_end(P);
-        return false;
-    }
-    u.recorded.store(1, std::memory_order_release);
-    return true;
-}
-
-// `stream` waits until file[0, need) is on the device
-int file_up_wait(mp3s_pipe *P, size_t need, hipStream_t stream)
-{
-    FileUp &u = P->up;
-    size_t i = 0;
-    while (i + 1 < u.ends.size() && u.ends[i] < need) i++;
-    while (u.recorded.load(std::memory_order_acquire) <= (long)i) {
-        if (u.err.load()) return fail(MP3S_E_HIP, "uploading the file failed");
-        std::this_thread::yield();
-    }
-    HIPCHK(hipStreamWaitEvent(stream, u.ev[i], 0));
-    return MP3S_OK;
-}
-
-// the call is over: the helper is done with the caller's memory
-void file_up_end(mp3s_pipe *P)
-{
-    FileUp &u = P->up;
-    if (!u.active) return;
-    std::unique_lock<std::mutex> lk(u.mu);
-    u.cv.wait(lk, [&] { return !u.busy; });
-    u.active = false;
-}
+}  // namespace
 
 bool prepare_chunk(mp3s_pipe *P, Job &j, Slot &s, int max_p23)
 {
@@ -530,6 +265,8 @@ bool prepare_chunk_encode(mp3s_pipe *P, Job &j, Slot &s)
     j.pack_end = j.o_encblk + j.L.bytes;
     return j.pack_end <= s.o_in + s.pack_cap;
 }
+
+namespace {
 
 // ---- a block job: walk the stream, cut out the rank's share (as mp3s_reencode_block cuts it), and queue it as a chunk
 bool prepare_block(mp3s_pipe *P, Job &j, Slot &s)
@@ -666,6 +403,8 @@ bool prepare_fast(mp3s_pipe *P, Job &j, Slot &s, ParsedStream &p, size_t *blob_l
     return true;
 }
 
+}  // namespace
+
 // everything a fast job does on the device, queued on the streams; nothing is waited for
 // the front end of a job: uploads, side-info parse, Huffman decode (on the copy-up and front-end streams).  inputs_later: only
 // [o_small, front_end) of the packed inputs goes up here, the rest with issue_back
@@ -683,19 +422,16 @@ int issue_front(mp3s_pipe *P, Job &j, Slot &s, size_t blob_len, int max_p23, boo
          *d_keep = c->grab(set ? 26 : 7, (size_t)n * frame_elems * esz);
     if (!d_is || !d_si || !d_keep) return fail(MP3S_E_NOMEM, "hipMalloc failed for a %d-frame job", n);
     uint8_t *d_blob = s.d_stage, *d_side = s.d_stage + s.o_side;
-    const mp3s_frame_hdr *d_dechdr;
     HIPCHK(hipEventRecord(s.e_start, P->s_up));
     if (j.walked) {
         for (const Upload &u : j.ups) HIPCHK(hipMemcpyAsync(s.d_image + u.dst, u.src, u.bytes, hipMemcpyHostToDevice, P->s_up));
         HIPCHK(hipMemcpyAsync(s.d_stage + j.o_small, s.h_stage + j.o_small, (inputs_later ? j.front_end : j.pack_end) - j.o_small, hipMemcpyHostToDevice, P->s_up));
-        d_dechdr = (const mp3s_frame_hdr *)(s.d_stage + s.o_dechdr);
     } else {
         const size_t o_enc = j.o_encblk - s.o_in, in_bytes = j.decode ? ((size_t)n * sizeof(mp3s_frame_hdr) + 15) & ~(size_t)15 : o_enc + L.bytes;
         HIPCHK(hipMemcpyAsync(d_blob, s.h_stage, blob_len, hipMemcpyHostToDevice, P->s_up));
         HIPCHK(hipMemcpyAsync(d_side, s.h_stage + s.o_side, (size_t)n * sizeof(mp3s_frame_side), hipMemcpyHostToDevice, P->s_up));
         HIPCHK(hipMemcpyAsync(s.d_stage + s.o_in, s.h_stage + s.o_in, in_bytes, hipMemcpyHostToDevice, P->s_up));
         HIPCHK(hipMemcpyAsync(s.d_stage + j.o_fix, s.h_stage + j.o_fix, (size_t)j.n_fix * kPlaceEntry, hipMemcpyHostToDevice, P->s_up));
-        d_dechdr = (const mp3s_frame_hdr *)(s.d_stage + s.o_in);
     }
     HIPCHK(hipEventRecord(s.e_up, P->s_up));
     if (trace_on()) fprintf(stderr, "mp3s:   uploads queued %.3f ms after the job's start\n", now_ms() - t_issue0);
@@ -721,12 +457,10 @@ int issue_front(mp3s_pipe *P, Job &j, Slot &s, size_t blob_len, int max_p23, boo
     return MP3S_OK;
 }
 
-int issue_down(mp3s_pipe *P, Job &j, Slot &s);
-
 // ... and everything behind it: decode transforms, encode side, tail, download (defer_down: the download is queued by issue_down
 // later -- a copy that waits for its job's kernels holds up every copy queued behind it, in either direction, on engines the
 // runtime shares between the copy streams: the inputs of the next chunk of a one-file call must not queue behind it)
-int issue_back(mp3s_pipe *P, Job &j, Slot &s, bool inputs_later, bool defer_down = false)
+int issue_back(mp3s_pipe *P, Job &j, Slot &s, bool inputs_later, bool defer_down)
 {
     mp3s_ctx *c = P->c;
     const double t_issue0 = trace_on() ? now_ms() : 0;
@@ -842,12 +576,15 @@ int issue_down(mp3s_pipe *P, Job &j, Slot &s)
     return MP3S_OK;
 }
 
+namespace {
 
 int issue_fast(mp3s_pipe *P, Job &j, Slot &s, size_t blob_len, int max_p23)
 {
     const int rc = issue_front(P, j, s, blob_len, max_p23, false);
     return rc ? rc : issue_back(P, j, s, false);
 }
+
+}  // namespace
 
 void sync_all(mp3s_pipe *P)
 {
@@ -857,6 +594,8 @@ void sync_all(mp3s_pipe *P)
     if (P->s_tail) (void)hipStreamSynchronize(P->s_tail);
     (void)hipStreamSynchronize(P->s_down);
 }
+
+namespace {
 
 void run_slow(mp3s_pipe *P, Job &j)   // mu_issue held
 {
@@ -899,6 +638,8 @@ void run_slow(mp3s_pipe *P, Job &j)   // mu_issue held
     P->c->opt[MP3S_OPT_FILE_PIPELINE] = keep;
 }
 
+}  // namespace
+
 void bind_to(const std::vector<int> &cpus)
 {
     if (cpus.empty()) return;
@@ -907,6 +648,8 @@ void bind_to(const std::vector<int> &cpus)
     for (int cpu : cpus) if (cpu >= 0 && cpu < CPU_SETSIZE) CPU_SET(cpu, &set);
     (void)sched_setaffinity(0, sizeof set, &set);
 }
+
+namespace {
 
 void worker(mp3s_pipe *P, int me)
 {
@@ -980,167 +723,7 @@ void free_slot(Slot &s)
     s = Slot();
 }
 
-// Candidate streams of a device, made once per process: four of the highest priority (copies) and four of the lowest (the
-// front end: its workgroups fill in beside the compute stream's instead of competing with them).  The runtime multiplexes
-// streams onto a few hardware queues; which queue a stream gets depends on everything the process has created before it
-// (round 2 believed priorities chose the set of queues; a context's own pipe in front of a user's pipe showed otherwise:
-// 0.97 - 1.25 instead of 0.81 ms per batch, tools/pipe_queue_probe.py; the first of three contexts ran its one-file calls at
-// half speed, tools/bench_queue_probe4.py), and a pipeline whose streams share queues with its compute stream loses its
-// overlap -- every kernel of it takes longer, not only the ones that wait.  The runtime does not tell which stream sits
-// where, and a spin kernel beside an empty one or beside a small copy does not show it either (all eight candidates passed
-// that test on a context that then ran at half speed).  So the pipe REHEARSES: four miniature jobs -- a copy up, a spin on
-// the front-end stream, two spins on the compute stream, a copy down, chained by events exactly as issue_fast chains a
-// job's stages -- through each rotation of the candidates, and keeps the rotation that got them through fastest
-// (about 1 ms per rotation when a pipe is made).
-struct LaneChoice { hipStream_t ctx_stream; int want_tail; hipStream_t up, down, huff, comp, tail, dec, img; };
-struct LanePool {
-    std::vector<LaneChoice> chosen;       // what the rehearsal decided for a context's stream (asked again only by another context)
-    hipStream_t hi[4] = {nullptr, nullptr, nullptr, nullptr}, lo[4] = {nullptr, nullptr, nullptr, nullptr}, cs[4] = {nullptr, nullptr, nullptr, nullptr};
-    hipEvent_t ev[4][6] = {};
-    hipEvent_t t0 = nullptr, t1 = nullptr;
-    uint8_t *d_buf = nullptr, *h_buf = nullptr;
-    bool ok = false;
-};
-constexpr size_t kRehearseBytes = (size_t)256 << 10;
-
-// tail: the stream a job's last stage (three short spins: selection, chain check, packing) runs on, behind the job's compute
-// stage and beside the next job's; null: on the compute stream itself
-// dec: the stream a job's decode stage (the first of the two compute spins) runs on, ahead of the compute stage of the job in front
-float rehearse(LanePool &lp, hipStream_t comp, hipStream_t up, hipStream_t down, hipStream_t huff, hipStream_t tail = nullptr, hipStream_t dec = nullptr)
-{
-    float ms = 1e9f;
-    hipStream_t ts = tail ? tail : comp;
-    hipStream_t dst = dec ? dec : comp;
-    bool ok = hipEventRecord(lp.t0, up) == hipSuccess;
-    for (int k = 0; k < 4 && ok; k++) {
-        ok = hipMemcpyAsync(lp.d_buf + k * kRehearseBytes, lp.h_buf + k * kRehearseBytes, kRehearseBytes, hipMemcpyHostToDevice, up) == hipSuccess &&
-             hipEventRecord(lp.ev[k][0], up) == hipSuccess && hipStreamWaitEvent(huff, lp.ev[k][0], 0) == hipSuccess && launch_spin(huff, 60) == 0 &&
-             hipEventRecord(lp.ev[k][1], huff) == hipSuccess && hipStreamWaitEvent(dst, lp.ev[k][1], 0) == hipSuccess && launch_spin(dst, 50) == 0;
-        if (ok && dec) ok = hipEventRecord(lp.ev[k][5], dec) == hipSuccess && hipStreamWaitEvent(comp, lp.ev[k][5], 0) == hipSuccess;
-        ok = ok && launch_spin(comp, 50) == 0 && launch_noop(comp) == 0 && hipEventRecord(lp.ev[k][2], comp) == hipSuccess;
-        if (ok && tail) ok = hipStreamWaitEvent(tail, lp.ev[k][2], 0) == hipSuccess;
-        ok = ok && launch_spin(ts, 10) == 0 && launch_spin(ts, 10) == 0 && launch_spin(ts, 20) == 0 && hipEventRecord(lp.ev[k][4], ts) == hipSuccess &&
-             hipStreamWaitEvent(down, lp.ev[k][4], 0) == hipSuccess &&
-             hipMemcpyAsync(lp.h_buf + (4 + k) * kRehearseBytes, lp.d_buf + k * kRehearseBytes, kRehearseBytes, hipMemcpyDeviceToHost, down) == hipSuccess &&
-             hipEventRecord(lp.ev[k][3], down) == hipSuccess;
-    }
-    ok = ok && hipEventRecord(lp.t1, down) == hipSuccess;
-    (void)hipStreamSynchronize(up); (void)hipStreamSynchronize(huff); (void)hipStreamSynchronize(comp); (void)hipStreamSynchronize(down);
-    if (tail) (void)hipStreamSynchronize(tail);
-    if (dec) (void)hipStreamSynchronize(dec);
-    if (!ok || hipEventElapsedTime(&ms, lp.t0, lp.t1) != hipSuccess) return 1e9f;
-    return ms;
-}
-
-std::mutex &lane_mu() { static std::mutex *m = new std::mutex(); return *m; }
-std::vector<LanePool> &lane_pools() { static auto *v = new std::vector<LanePool>(); return *v; }
-
-int pick_lanes(mp3s_ctx *c, hipStream_t *up, hipStream_t *down, hipStream_t *huff, hipStream_t *comp /* a stream to compute on instead of the context's, or null */,
-               hipStream_t *tail /* a stream for the tail of a job, or null */, int want_tail /* 0: none, 1: always, 2: if the rehearsal is faster with it */,
-               hipStream_t *dec = nullptr /* a stream for the decode transforms, or null */, int want_dec = 1,
-               hipStream_t *img = nullptr /* a second copy-up stream (the file pieces of a one-file call), or null */)
-{
-    std::lock_guard<std::mutex> g(lane_mu());
-    auto &pools = lane_pools();
-    if ((size_t)c->device >= pools.size()) pools.resize((size_t)c->device + 1);
-    LanePool &lp = pools[(size_t)c->device];
-    if (!lp.ok) {
-        int prio_low = 0, prio_high = 0;
-        (void)hipDeviceGetStreamPriorityRange(&prio_low, &prio_high);
-        const char *hp = getenv("MP3S_PIPE_HUFF_PRIO");
-        const int huff_prio = hp ? atoi(hp) : prio_low;
-        bool ok = hipEventCreate(&lp.t0) == hipSuccess && hipEventCreate(&lp.t1) == hipSuccess && hipMalloc((void **)&lp.d_buf, 4 * kRehearseBytes) == hipSuccess &&
-                  hipHostMalloc((void **)&lp.h_buf, 8 * kRehearseBytes, hipHostMallocDefault) == hipSuccess;
-        for (int k = 0; k < 4 && ok; k++)
-            for (int q = 0; q < 6 && ok; q++) ok = hipEventCreateWithFlags(&lp.ev[k][q], hipEventDisableTiming) == hipSuccess;
-        for (int i = 0; i < 4 && ok; i++) ok = hipStreamCreateWithPriority(&lp.hi[i], hipStreamNonBlocking, prio_high) == hipSuccess;
-        for (int i = 0; i < 4 && ok; i++) ok = hipStreamCreateWithPriority(&lp.lo[i], hipStreamNonBlocking, huff_prio) == hipSuccess;
-        for (int i = 0; i < 4 && ok; i++) ok = hipStreamCreateWithFlags(&lp.cs[i], hipStreamNonBlocking) == hipSuccess;
-        if (!ok) return 1;   // (what was created stays with the process)
-        std::memset(lp.h_buf, 0, 8 * kRehearseBytes);
-        lp.ok = true;
-    }
-    for (const LaneChoice &k : lp.chosen)
-        if (k.ctx_stream == c->stream && k.want_tail == want_tail) {
-            *up = k.up; *down = k.down; *huff = k.huff;
-            if (comp) *comp = k.comp;
-            if (tail) *tail = k.tail;
-            if (dec) *dec = k.dec;
-            if (img) *img = k.img;
-            return 0;
-        }
-    (void)hipStreamSynchronize(c->stream);
-    (void)rehearse(lp, c->stream, lp.hi[0], lp.hi[1], lp.lo[0]);      // (first launches: not a measurement)
-    // the context's own stream with every rotation of the lanes; if none of them gets the rehearsal through as fast as a
-    // pipeline without shared queues does, the compute candidates too (the pipe then computes on one of those)
-    int best = 0, best_cs = -1;
-    float best_ms = 1e9f;
-    std::string seen;
-    auto tryout = [&](int ci, int r) {
-        hipStream_t comp_s = ci < 0 ? c->stream : lp.cs[ci];
-        const float ms = std::min(rehearse(lp, comp_s, lp.hi[r], lp.hi[(r + 1) & 3], lp.lo[r]), rehearse(lp, comp_s, lp.hi[r], lp.hi[(r + 1) & 3], lp.lo[r]));
-        if (trace_on()) { char b[32]; snprintf(b, sizeof b, " %.3f", ms); seen += b; }
-        if (ms < best_ms * 0.97f) { best_ms = ms; best = r; best_cs = ci; }
-    };
-    for (int r = 0; r < 4; r++) tryout(-1, r);
-    const float own_ms = best_ms;
-    const int own_best = best;
-    if (comp && best_ms > 0.80f)          // (4 x (2 x 50 + 40) us on the compute stream behind one front-end spin never take less than 0.72 ms: this one lost its overlap somewhere)
-        for (int ci = 0; ci < 4 && best_ms > 0.78f; ci++) {
-            if (trace_on()) seen += " |";
-            for (int r = 0; r < 4; r++) tryout(ci, r);
-        }
-    if (best_cs >= 0 && best_ms > own_ms * 0.93f) { best_cs = -1; best_ms = own_ms; best = own_best; }   // (not worth leaving the context's stream for)
-    // a stream for the tail of a job (MP3S_OPT_PIPE_TAIL): the candidate, other than the compute stream, that gets the
-    // rehearsal through fastest -- kept if that is faster than the tail on the compute stream itself
-    int best_tail = -1;
-    if (tail) {
-        *tail = nullptr;
-        hipStream_t comp_s = best_cs < 0 ? c->stream : lp.cs[best_cs];
-        float tail_ms = best_ms * (want_tail == 1 ? 1.05f : 0.97f);   // (1: unless it clearly loses -- the real kernels gain more from it than spins do)
-        if (trace_on()) seen += " | tail:";
-        for (int ti = 0; ti < 4 && want_tail; ti++) {
-            if (ti == best_cs) continue;
-            const float ms = std::min(rehearse(lp, comp_s, lp.hi[best], lp.hi[(best + 1) & 3], lp.lo[best], lp.cs[ti]), rehearse(lp, comp_s, lp.hi[best], lp.hi[(best + 1) & 3], lp.lo[best], lp.cs[ti]));
-            if (trace_on()) { char b[32]; snprintf(b, sizeof b, " %.3f", ms); seen += b; }
-            if (ms < tail_ms) { tail_ms = ms; best_tail = ti; }
-        }
-        if (best_tail >= 0) *tail = lp.cs[best_tail];
-    }
-    // a stream for the decode transforms: the candidate (other than the compute and tail streams) that does best, if it gains
-    int best_dec = -1;
-    if (dec) {
-        *dec = nullptr;
-        hipStream_t comp_s = best_cs < 0 ? c->stream : lp.cs[best_cs];
-        hipStream_t tail_s = best_tail >= 0 ? lp.cs[best_tail] : nullptr;
-        float ref_ms = std::min(rehearse(lp, comp_s, lp.hi[best], lp.hi[(best + 1) & 3], lp.lo[best], tail_s), rehearse(lp, comp_s, lp.hi[best], lp.hi[(best + 1) & 3], lp.lo[best], tail_s));
-        float dec_ms = ref_ms * (want_dec == 2 ? 10.f : 0.95f);
-        if (trace_on()) { char b[48]; snprintf(b, sizeof b, " | dec (%.3f):", ref_ms); seen += b; }
-        for (int di = 0; di < 4 && want_dec; di++) {
-            if (di == best_cs || di == best_tail) continue;
-            const float ms = std::min(rehearse(lp, comp_s, lp.hi[best], lp.hi[(best + 1) & 3], lp.lo[best], tail_s, lp.cs[di]), rehearse(lp, comp_s, lp.hi[best], lp.hi[(best + 1) & 3], lp.lo[best], tail_s, lp.cs[di]));
-            if (trace_on()) { char b[32]; snprintf(b, sizeof b, " %.3f", ms); seen += b; }
-            if (ms < dec_ms) { dec_ms = ms; best_dec = di; }
-        }
-        if (best_dec >= 0) *dec = lp.cs[best_dec];
-    }
-    if (trace_on()) fprintf(stderr, "mp3s: pipe lanes rehearsed:%s ms -> compute stream %d, rotation %d (%.3f ms), tail stream %d, decode stream %d\n", seen.c_str(), best_cs, best, best_ms, best_tail, best_dec);
-    if (comp) *comp = best_cs >= 0 ? lp.cs[best_cs] : nullptr;
-    *up = lp.hi[best]; *down = lp.hi[(best + 1) & 3]; *huff = lp.lo[best];
-    if (img) *img = lp.hi[(best + 2) & 3];
-    lp.chosen.push_back({c->stream, want_tail, *up, *down, *huff, comp ? *comp : nullptr, tail ? *tail : nullptr, dec ? *dec : nullptr, lp.hi[(best + 2) & 3]});
-    return 0;
-}
-
-// a context is going away: its stream's address may come back as another context's
-void forget_lanes(mp3s_ctx *c)
-{
-    std::lock_guard<std::mutex> g(lane_mu());
-    auto &pools = lane_pools();
-    if ((size_t)c->device >= pools.size()) return;
-    auto &v = pools[(size_t)c->device].chosen;
-    v.erase(std::remove_if(v.begin(), v.end(), [&](const LaneChoice &k) { return k.ctx_stream == c->stream; }), v.end());
-}
+}  // namespace
 
 int pipe_create(mp3s_ctx *c, int depth, size_t max_job_bytes, int scan_threads, bool internal, mp3s_pipe **out)
 {
@@ -1219,7 +802,27 @@ int pipe_create(mp3s_ctx *c, int depth, size_t max_job_bytes, int scan_threads, 
     return MP3S_OK;
 }
 
-}  // namespace
+// the job's results are on the host: are they final?  *resolved: the host had to resolve the chains (on the job's own buffers)
+bool finish_fast(mp3s_pipe *P, Job *j, Slot &s, bool *resolved)
+{
+    const int32_t *small = (const int32_t *)j->res->big[2].data();
+    const bool parse_ok = !j->walked || (small[4] & kParseMismatch) == 0;
+    bool fast_ok = parse_ok && (j->decode ? small[3] == 0 : (small[0] == 0 && small[1] == 0 && small[2] == 0 && small[3] == 0));
+    *resolved = false;
+    if (!fast_ok) {
+        if (trace_on()) fprintf(stderr, "mp3s: pipe job %lld: verdict %d units to redo, step range %d, packer %d, Huffman status 0x%x, parse status 0x%x\n",
+                                (long long)j->ticket, small[0], small[1], small[2], small[3], small[4]);
+        // only the cursor / address guesses failed (a long message, a start the input's tables did not predict):
+        // the host resolves the chains on the job's own device buffers -- scan, decode and transforms stand
+        if (P->s_tail) (void)hipStreamSynchronize(P->s_tail);   // (later jobs' tails: the resolve below packs through the same context)
+        if (parse_ok && !j->decode && small[0] != 0 && small[1] == 0 && small[3] == 0) {
+            int passes = 0;
+            *resolved = enc_resolve(P->c, j->L, j->segs, s.h_stage + j->o_encblk, j->dev, j->res.get(), false, &passes) == MP3S_OK;
+            if (hipStreamSynchronize(P->c->stream) != hipSuccess) *resolved = false;
+        }
+    }
+    return fast_ok;
+}
 
 extern "C" {
 
@@ -1303,28 +906,6 @@ int mp3s_pipe_submit_decode(mp3s_pipe *P, const uint8_t *const *mp3s, const size
     j->files.resize((size_t)n_files); j->msgs.assign((size_t)n_files, {nullptr, 0});
     for (int i = 0; i < n_files; i++) j->files[i] = {mp3s[i], lens[i]};
     return submit_job(P, std::move(j), ticket);
-}
-
-// the job's results are on the host: are they final?  *resolved: the host had to resolve the chains (on the job's own buffers)
-static bool finish_fast(mp3s_pipe *P, Job *j, Slot &s, bool *resolved)
-{
-    const int32_t *small = (const int32_t *)j->res->big[2].data();
-    const bool parse_ok = !j->walked || (small[4] & kParseMismatch) == 0;
-    bool fast_ok = parse_ok && (j->decode ? small[3] == 0 : (small[0] == 0 && small[1] == 0 && small[2] == 0 && small[3] == 0));
-    *resolved = false;
-    if (!fast_ok) {
-        if (trace_on()) fprintf(stderr, "mp3s: pipe job %lld: verdict %d units to redo, step range %d, packer %d, Huffman status 0x%x, parse status 0x%x\n",
-                                (long long)j->ticket, small[0], small[1], small[2], small[3], small[4]);
-        // only the cursor / address guesses failed (a long message, a start the input's tables did not predict):
-        // the host resolves the chains on the job's own device buffers -- scan, decode and transforms stand
-        if (P->s_tail) (void)hipStreamSynchronize(P->s_tail);   // (later jobs' tails: the resolve below packs through the same context)
-        if (parse_ok && !j->decode && small[0] != 0 && small[1] == 0 && small[3] == 0) {
-            int passes = 0;
-            *resolved = enc_resolve(P->c, j->L, j->segs, s.h_stage + j->o_encblk, j->dev, j->res.get(), false, &passes) == MP3S_OK;
-            if (hipStreamSynchronize(P->c->stream) != hipSuccess) *resolved = false;
-        }
-    }
-    return fast_ok;
 }
 
 int mp3s_pipe_collect(mp3s_pipe *P, int64_t *ticket, mp3s_buf **owner, mp3s_file *out, int32_t *status, int max_files, int *n_files)
@@ -1504,333 +1085,3 @@ int mp3s_pipe_get_stats(mp3s_pipe *P, mp3s_pipe_stats *out)
 }
 
 }  // extern "C"
-
-// ------------------------------------------------------------------------------------------------ one file as chunks
-// The reference's call shape is one file per call (steganography.py:137-162: decode loop MP3_Parser.py:68-80, then encode
-// loop MP3_Encoder.py:607-609).  run_file gives that call the overlap the pipe gives a stream of jobs: the calling thread
-// walks the frame headers a chunk at a time and queues each chunk on the stages above -- walk(k+1) || upload || front end ||
-// kernels(k) || download(k-1) -- and the chunks' bytes land side by side in ONE result block.  What crosses a chunk
-// boundary is what crosses a block boundary of a sharded stream: a frame of decoder state and a frame of
-// PCM in front of the chunk are recomputed and dropped; the padding recurrence is replayed from the frame index; the message
-// cursor and the inherited addresses (17 integers) are GUESSED -- "the message is hidden, nothing is inherited" -- and every
-// chunk reports whether it looked at them: only a chunk that did, on a guess that was wrong, is run again on the real carry.
-namespace {
-
-bool same_effect(const mp3s_carry &a, const mp3s_carry &b, int64_t n_hide)
-{
-    return std::memcmp(a.chain, b.chain, sizeof a.chain) == 0 && std::min<int64_t>(a.cursor, n_hide) == std::min<int64_t>(b.cursor, n_hide);
-}
-
-struct RunChunk {
-    std::unique_ptr<Job> job;
-    long first = 0, count = 0;
-    bool last = false;
-    mp3s_carry guess = {}, out = {};
-    bool carry_used = false;
-    int64_t out_off = 0, out_len = 0;
-    bool done = false;
-};
-
-}  // namespace
-
-int ensure_own_pipe(mp3s_ctx *c, size_t chunk_bytes)
-{
-    if (c->own_pipe && c->own_pipe->max_job_bytes >= chunk_bytes) return MP3S_OK;
-    if (c->own_pipe) { mp3s_pipe_destroy(c->own_pipe); c->own_pipe = nullptr; }
-    const size_t want = std::max<size_t>(chunk_bytes + chunk_bytes / 4, (size_t)1 << 20);
-    return pipe_create(c, kRunDepth, want, 0, true, &c->own_pipe);
-}
-
-void destroy_own_pipe(mp3s_ctx *c)   // (the context is being destroyed)
-{
-    if (c->own_pipe) { mp3s_pipe_destroy(c->own_pipe); c->own_pipe = nullptr; }
-    forget_lanes(c);
-}
-
-constexpr int kRunWhole = 2;             // run_file_impl: the stream inherits scalefactors across frames -- once more, as one piece
-constexpr long kWholeFrames = 4 * kDecodeChunk;   // ... if it is not longer than this (the slots are sized for the piece)
-
-static int run_file_impl(mp3s_ctx *c, const uint8_t *mp3, size_t len, int mode, const uint8_t *utf8, size_t n_msg, int out_format, mp3s_buf **owner, RunResult *out, bool whole);
-
-int run_file(mp3s_ctx *c, const uint8_t *mp3, size_t len, int mode, const uint8_t *utf8, size_t n_msg, int out_format, mp3s_buf **owner, RunResult *out)
-{
-    int rc = run_file_impl(c, mp3, len, mode, utf8, n_msg, out_format, owner, out, false);
-    // A granule of a mixed block (or one behind a short granule 0 with scfsi set) reads scalefactors written many frames earlier
-    // (SURVEY D10); the Huffman kernel finds them by walking back through the stream's side records, which a chunk that
-    // starts in the middle of the stream cannot.  Such a file goes through the same stages in ONE piece (the transforms still
-    // in groups): 1.7 instead of 4.4 ms for 10 000 frames, which the synchronous path spends in the host parser.
-    if (rc == kRunWhole) rc = run_file_impl(c, mp3, len, mode, utf8, n_msg, out_format, owner, out, true);
-    return rc == kRunWhole ? kRunFallback : rc;
-}
-
-static int run_file_impl(mp3s_ctx *c, const uint8_t *mp3, size_t len, int mode, const uint8_t *utf8, size_t n_msg, int out_format, mp3s_buf **owner, RunResult *out, bool whole)
-{
-    if (!c->opt[MP3S_OPT_FILE_PIPELINE] || !c->opt[MP3S_OPT_DEVICE_PARSE]) return kRunFallback;
-    const bool decode = mode == kRunDecode;
-    const double t_call0 = trace_on() ? now_ms() : 0;
-    FrameWalker w;
-    // (errors and empty streams: the synchronous path words them)
-    if (len < 8 || len > 0xffff0000ull || w.open(mp3, len) || w.ended || w.hd.version != 1 || w.hd.layer != 3 || w.frame_size <= 0) {
-        c->run_stats.fallbacks++;
-        return kRunFallback;
-    }
-    const long fs0 = w.frame_size;
-    const long n_est = (long)((len - (size_t)w.offset) / (size_t)std::max<long>(fs0 - 1, 24)) + 8;
-    std::vector<uint8_t> bits;
-    if (mode == kRunHide) {
-        message_frame(utf8, n_msg, bits);
-        if (bits.size() > 0x3fffff00) { c->run_stats.fallbacks++; return kRunFallback; }
-    }
-    const int64_t n_hide = (int64_t)bits.size();
-    // ---- the chunk plan.  Every chunk costs a dozen launches and their gaps, so few chunks; the first one small, so that
-    //      the device starts early; a message's reach inside the first chunk, where the cursor is decided (not guessed)
-    const long reach_frames = n_hide ? (long)((n_hide * 5 / 14 + 32) / 4 * 9 / 8 + 64) : 0;
-    long chunk = (long)c->opt[MP3S_OPT_CHUNK_FRAMES];
-    long first_chunk;
-    const long kMaxChunk = kDecodeChunk - 2;
-    if (chunk > 0) { chunk = std::min(chunk, kMaxChunk); first_chunk = chunk; }
-    else if (n_est <= 3000) { chunk = first_chunk = std::min(kMaxChunk, n_est + 16); }                    // one chunk: nothing to overlap with
-    else {
-        // A short first chunk, so that the device starts early, then chunks as long as a transform group takes: every chunk
-        // costs the host 0.15 ms of walking, laying out and queueing (two dozen runtime calls), which four chunks of a
-        // 10 000-frame file do not win back (tools/chunk_plan_probe.py: 2 048 + the rest 1.41 ms, four chunks 1.49, one 1.57;
-        // a 100 000-frame file: 8 192 + 16 000s 8.1 ms)
-        first_chunk = std::min<long>(8192, std::max<long>(2048, n_est / 12));
-        chunk = kMaxChunk;
-    }
-    if (c->opt[MP3S_OPT_FIRST_CHUNK_FRAMES] > 0) first_chunk = (long)std::min<int64_t>(c->opt[MP3S_OPT_FIRST_CHUNK_FRAMES], kMaxChunk);
-    first_chunk = std::min(kMaxChunk, std::max(first_chunk, reach_frames));
-    if (whole) {
-        if (n_est > kWholeFrames) { c->run_stats.fallbacks++; return kRunFallback; }
-        first_chunk = chunk = n_est + 64;          // one piece
-    }
-    const long cap_frames = std::max(chunk, first_chunk) + 2;
-    // (a message that reaches further than a chunk: the synchronous path's plan over the whole file)
-    if (reach_frames > kMaxChunk || ensure_own_pipe(c, (size_t)cap_frames * (size_t)(fs0 + 2) + 4096)) { c->run_stats.fallbacks++; return kRunFallback; }
-    mp3s_pipe *P = c->own_pipe;
-    HIPCHK(hipSetDevice(c->device));
-    // (for the duration of the call the context computes on the stream its pipe rehearsed best with, if that is not its own)
-    struct StreamSwap {
-        mp3s_ctx *c; hipStream_t keep;
-        StreamSwap(mp3s_ctx *c_, hipStream_t s) : c(c_), keep(c_->stream) { if (s) c->stream = s; }
-        ~StreamSwap() { if (c->stream != keep) { (void)hipStreamSynchronize(c->stream); c->stream = keep; } }
-    } swap(c, P->s_comp);
-    // the file's bytes set off for the device now (the first chunk's first), the walk follows
-    struct FileUpGuard { mp3s_pipe *P; ~FileUpGuard() { file_up_end(P); } } up_guard{P};
-    file_up_begin(P, mp3, len, (size_t)w.offset + (size_t)std::min<long>(first_chunk, n_est) * (size_t)(fs0 + 1) + 2048);
-    // ---- the stream's frame table, grown as the walk proceeds
-    std::vector<FrameRef> &refs = c->h_refs;
-    if ((long)refs.size() < n_est + 64) refs.resize((size_t)n_est + 64);
-    std::vector<uint8_t> &tables = c->h_tables;
-    if (n_hide) { w.tables_wanted = (long)n_hide + (long)n_hide / 16 + 64; tables.resize((size_t)first_chunk * 4 + 16); }
-    long n_walked = 0;
-    WalkOut wv;                                  // the walker's state behind the chunk in hand
-    std::unique_ptr<mp3s_buf> res(new mp3s_buf());
-    std::vector<RunChunk> chunks;
-    uint8_t fix[kPlaceEntry];
-    bool have_fix = false;
-    int rate = 0, kbps = 0, nch = 0;
-    const size_t esz = pcm_elem(out_format);
-    size_t res_cap = 0;
-    auto fallback = [&](const char *why, int code = kRunFallback) {
-        if (trace_on()) fprintf(stderr, "mp3s: run_file: %s -> %s\n", why, code == kRunWhole ? "once more, in one piece" : "synchronous path");
-        if (code == kRunFallback) c->run_stats.fallbacks++;
-        sync_all(P);
-        for (auto &s : P->slots) s.busy = false;
-        P->keep_slot[0] = P->keep_slot[1] = -1;
-        return code;
-    };
-    // retire chunk k: wait for its results, settle its verdict and its carry
-    int64_t hide_offset = 0;
-    auto retire = [&](size_t k) -> int {
-        RunChunk &rc = chunks[k];
-        if (rc.done) return MP3S_OK;
-        Job *j = rc.job.get();
-        Slot &s = P->slots[(size_t)j->slot];
-        if (issue_down(P, *j, s)) return kRunFallback;
-        if (hipEventSynchronize(s.e_down) != hipSuccess) return fail(MP3S_E_HIP, "waiting for a chunk's results failed");
-        if (trace_on()) {
-            float up = 0, huff = 0, rate = 0, comp = 0, down = 0;
-            hipEvent_t e0 = P->slots[(size_t)chunks[0].job->slot].e_start;
-            if (k >= (size_t)P->depth) e0 = s.e_start;
-            (void)hipEventElapsedTime(&up, e0, s.e_up); (void)hipEventElapsedTime(&huff, e0, s.e_huff); (void)hipEventElapsedTime(&rate, e0, s.e_rate);
-            (void)hipEventElapsedTime(&comp, e0, s.e_comp); (void)hipEventElapsedTime(&down, e0, s.e_down);
-            (void)hipGetLastError();
-            fprintf(stderr, "mp3s: run_file: chunk %zu's results are here %.3f ms after the call's start; on the device, from the first chunk's start: inputs up %.3f, "
-                            "front end done %.3f, rate loop done %.3f, tail done %.3f, results down %.3f ms\n", k, now_ms() - t_call0, up, huff, rate, comp, down);
-        }
-        bool resolved = false;
-        const bool ok = finish_fast(P, j, s, &resolved);
-        if (!ok && !resolved) return kRunFallback;
-        if (resolved) c->run_stats.resolved++;
-        const int32_t *small = (const int32_t *)j->res->big[2].data();
-        if (j->walked && (small[4] & kParseInherits) && chunks.size() + (wv.ended ? 0 : 1) > 1) return kRunWhole;   // scalefactors inherited across frames: the stream in one piece
-        if (!decode) {
-            EncSeg &sg = j->segs[0];
-            if (resolved) {
-                std::memcpy(j->ck.dst, j->res->mp3 + sg.mp3_off, sg.mp3_len);
-                rc.out = sg.carry_out; rc.carry_used = sg.carry_used;
-            } else {
-                const mp3s_chain_seg_out *so = (const mp3s_chain_seg_out *)(j->res->big[2].data() + kSmallHead);
-                rc.out.cursor = so[0].cursor - sg.hide_base;
-                std::memcpy(rc.out.chain, so[0].chain, sizeof rc.out.chain);
-                rc.carry_used = so[0].carry_used != 0;
-            }
-            rc.out_len = (int64_t)sg.mp3_len;
-        }
-        rc.done = true;
-        return MP3S_OK;
-    };
-    // issue frames [first, first + count) of the stream as a chunk on slot `slot`
-    auto issue = [&](size_t k, const mp3s_carry *carry) -> int {
-        RunChunk &rc = chunks[k];
-        rc.job.reset(new Job());
-        Job &j = *rc.job;
-        j.slot = (int)(k % (size_t)P->depth);
-        j.ticket = (int64_t)k;
-        Slot &s = P->slots[(size_t)j.slot];
-        Chunk &ck = j.ck;
-        ck.on = true; ck.decode = decode; ck.refs = refs.data(); ck.first = rc.first; ck.count = rc.count; ck.last = rc.last;
-        ck.lead = !decode && rc.first > 0 ? 1 : 0;
-        ck.halo = rc.first - ck.lead > 0 ? 1 : 0;
-        ck.w0 = rc.first - ck.lead - ck.halo; ck.n_win = rc.count + ck.lead + ck.halo;
-        ck.out_format = out_format; ck.file = mp3; ck.file_len = len; ck.rate = rate; ck.kbps = kbps; ck.nch = nch;
-        const uint32_t lo = refs[(size_t)ck.w0].file_off;
-        ck.image_lo = rc.first == 0 ? 0 : (lo > kImageLead ? lo - kImageLead : 0);
-        const FrameRef &lr = refs[(size_t)(rc.first + rc.count - 1)];
-        ck.image_hi = (uint32_t)std::min<uint64_t>(len, (uint64_t)lr.file_off + lr.frame_size + 64);
-        ck.fix = rc.last && have_fix ? fix : nullptr;
-        ck.hide = bits.data(); ck.n_hide = (int)n_hide;
-        ck.has_carry = rc.first > 0;
-        if (ck.has_carry) ck.carry_in = carry ? *carry : rc.guess;
-        ck.tables = rc.first == 0 && n_hide ? tables.data() : nullptr;
-        ck.n_tables = (int)std::min<long>(wv.tables_frames, rc.count) * 4;
-        ck.any_silent = wv.any_silent ? 1 : 0;   // (of the frames walked so far: at worst the re-run launches are issued without need)
-        if (decode) ck.dst = res->big[0].data() + 64 + (size_t)rc.first * 1152 * (size_t)nch * esz;
-        // the front end first (parse and Huffman kernels are a latency chain of 0.1 ms whatever the chunk's size), the encoder's
-        // inputs are laid out while it runs
-        if (!prepare_chunk(P, j, s, wv.max_p23)) return kRunFallback;
-        const double t_i = trace_on() ? now_ms() : 0;
-        if (issue_front(P, j, s, 0, wv.max_p23, true)) return kRunFallback;
-        // (the results of the chunk in front come down behind this chunk's inputs, not in front of them)
-        if (k > 0 && chunks[k - 1].job && issue_down(P, *chunks[k - 1].job, P->slots[(size_t)chunks[k - 1].job->slot])) return kRunFallback;
-        if (!prepare_chunk_encode(P, j, s)) { sync_all(P); return kRunFallback; }
-        if (!decode) {
-            rc.out_off = j.L.bytes_before;
-            if ((size_t)rc.out_off + j.L.mp3_bytes > res_cap) { sync_all(P); return kRunFallback; }
-            j.ck.dst = res->big[0].data() + rc.out_off;
-        }
-        const int e = issue_back(P, j, s, true, true);
-        if (trace_on()) fprintf(stderr, "mp3s:   front + inputs + back %.3f ms\n", now_ms() - t_i);
-        return e ? kRunFallback : MP3S_OK;
-    };
-    // ---- walk and issue, chunk after chunk
-    long want = first_chunk;
-    // (a helper thread that walks the chunks behind the first while this one queues was tried: it wakes up later than the walk takes --
-    // 1.56 instead of 1.38 ms per 10 000-frame file)
-    for (size_t k = 0; !wv.ended; k++) {
-        const double t_walk0 = trace_on() ? now_ms() : 0;
-        long got = 0;
-        const long room = (long)refs.size() - n_walked - 8;
-        if (room <= 0) return fallback("more frames than the file's first frame size promised");
-        want = std::min(want, room);
-        uint8_t *tb = k == 0 && n_hide ? tables.data() : nullptr;
-        while (got < want && !w.ended && !w.irregular) got += w.next(refs.data() + n_walked + got, want - got, tb ? tb + (size_t)got * 4 : nullptr, 0, 0);
-        wv.got = got; wv.ended = w.ended; wv.irregular = w.irregular || got <= 0; wv.dup_last = w.dup_last; wv.any_silent = w.any_silent;
-        wv.nch = w.nch; wv.sampling_rate = w.sampling_rate; wv.bit_rate = w.bit_rate; wv.max_p23 = w.max_p23; wv.tables_frames = w.tables_frames;
-        if (wv.ended && !wv.irregular && !wv.dup_last) {
-            bool alone = false;
-            wv.have_fix = w.decode_last(reinterpret_cast<int16_t *>(fix + 16), reinterpret_cast<mp3s_granule_si *>(fix + 16 + 4608), &alone) == 0 && alone;
-            std::memset(fix, 0, 16);
-        }
-        if (wv.irregular || got <= 0) return fallback("the walk does not take this stream");
-        if (k == 0) {
-            nch = wv.nch; rate = wv.sampling_rate;
-            if (nch < 1 || nch > 2) return fallback("channel count");
-            if (!decode && reencode_params(wv.sampling_rate, wv.bit_rate, wv.nch, got, 0, &kbps)) return fallback("not a stream the encoder takes");
-            // the result block: the frames the file can hold at its first frame's size
-            res_cap = decode ? 64 + (size_t)(n_est + 64) * 1152 * (size_t)nch * esz : (size_t)(n_est + 64) * (size_t)(fs0 + 2);
-            if (!res->big[0].reserve(res_cap)) return fallback("no memory for the result");
-        } else if (wv.nch != nch) return fallback("channel count changes");
-        if (wv.ended) {
-            if (wv.dup_last) return fallback("a repeated last frame");
-            have_fix = wv.have_fix;
-        }
-        const double t_walk1 = trace_on() ? now_ms() : 0;
-        if (k >= (size_t)P->depth) {               // the slot's previous chunk first
-            const int r = retire(k - (size_t)P->depth);
-            if (r) return r == kRunFallback || r == kRunWhole ? fallback("a chunk needs another path", r) : r;
-        }
-        const double t_ret = trace_on() ? now_ms() : 0;
-        chunks.emplace_back();
-        RunChunk &rc = chunks.back();
-        rc.first = n_walked; rc.count = got; rc.last = wv.ended;
-        rc.guess.cursor = MP3S_NO_CURSOR;          // "the message is hidden, nothing is inherited"
-        n_walked += got;
-        if (decode && 64 + (size_t)n_walked * 1152 * (size_t)nch * esz > res_cap) return fallback("more frames than the result block holds");
-        const int r = issue(k, nullptr);
-        if (trace_on()) fprintf(stderr, "mp3s: run_file chunk %zu (%ld frames): walk %.3f ms, wait for the slot %.3f ms, prepare + issue %.3f ms\n", k, got, t_walk1 - t_walk0, t_ret - t_walk1, now_ms() - t_ret);
-        if (r) return r == kRunFallback ? fallback("a chunk does not fit the stages") : r;
-        want = chunk;
-    }
-    if (trace_on()) fprintf(stderr, "mp3s: run_file: all chunks queued %.3f ms after the call's start\n", now_ms() - t_call0);
-    // ---- settle the chunks in order: the carries
-    if (!decode && (wv.sampling_rate != rate || wv.bit_rate / 1000 != kbps)) return fallback("the last header names another rate");
-    // (first everything that needs a chunk's device buffers -- its verdict, a resolve -- then the carries: a chunk that is run
-    // again takes a slot, and with it the buffers of the chunk that had it last)
-    for (size_t k = 0; k < chunks.size(); k++) {
-        const int r = retire(k);
-        if (r) return r == kRunFallback || r == kRunWhole ? fallback("a chunk needs another path", r) : r;
-    }
-    mp3s_carry real = {};
-    for (size_t k = 0; k < chunks.size(); k++) {
-        int r = MP3S_OK;
-        RunChunk &rc = chunks[k];
-        if (decode) continue;
-        if (k > 0) {
-            const bool live = std::min<int64_t>(real.cursor, n_hide) < n_hide;     // the message is still being hidden at this boundary
-            if (!same_effect(real, rc.guess, n_hide) && (rc.carry_used || live)) {
-                // the chunk looked at its carry and the guess was wrong: once more, on the real one (everything behind it has been issued
-                // and stays as it is unless its own carry turns out wrong in turn)
-                if (trace_on()) fprintf(stderr, "mp3s: run_file: chunk %zu depends on its carry: again\n", k);
-                sync_all(P);
-                c->run_stats.reruns++;
-                rc.done = false;
-                r = issue(k, &real);
-                if (!r) r = retire(k);
-                if (r) return r == kRunFallback || r == kRunWhole ? fallback("a chunk needs another path", r) : r;
-                sync_all(P);
-            } else {
-                // nothing in the chunk looked at the carry: every chain entry it hands on is its own; only the count of tables
-                // seen so far moves with the real cursor
-                rc.out.cursor = real.cursor + (rc.out.cursor - rc.guess.cursor);
-            }
-        }
-        real = rc.out;
-        hide_offset = real.cursor;
-    }
-    // ---- the result
-    std::memset(out, 0, sizeof *out);
-    out->n_frames = n_walked; out->nch = nch; out->sampling_rate = wv.sampling_rate; out->bit_rate = wv.bit_rate;
-    if (decode) {
-        // stego bits: the serial pass over the table-index words of all chunks (their halo frames left out)
-        uint8_t carry[4] = {0, 0, 0, 0};
-        for (auto &rc : chunks) {
-            const Job &j = *rc.job;
-            stego_bits_from_tsel((const uint64_t *)j.res->big[1].data() + j.ck.halo, rc.count, nch, carry, res->bits);
-        }
-        out->pcm = res->big[0].data() + 64; out->n_rows = (int64_t)n_walked * 1152;
-        out->bits = res->bits.data(); out->n_bits = res->bits.size();
-    } else {
-        const RunChunk &lc = chunks.back();
-        out->mp3 = res->big[0].data(); out->mp3_len = (size_t)(lc.out_off + lc.out_len);
-        out->kbps = kbps;
-        out->hide_offset = hide_offset;
-        out->too_long = hide_offset < n_hide - 1 ? 1 : 0;
-    }
-    for (auto &s : P->slots) s.busy = false;
-    c->run_stats.files++; c->run_stats.chunks += (int64_t)chunks.size();
-    *owner = res.release();
-    if (trace_on()) fprintf(stderr, "mp3s: run_file: done %.3f ms after the call's start\n", now_ms() - t_call0);
-    return MP3S_OK;
-}
