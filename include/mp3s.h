@@ -132,7 +132,17 @@ int mp3s_ctx_wait(mp3s_ctx *ctx, mp3s_ctx *other);
                                     * run on (sched_getaffinity, cgroup quota) divided by the ranks on this host [MP3S_SCAN_THREADS] */
 #define MP3S_OPT_FIRST_CHUNK_FRAMES 9 /* frames of the first chunk of a one-file call (the device starts when it has been walked); 0 = chosen
                                        * from the file's length; never shorter than what the message can reach [MP3S_FIRST_CHUNK_FRAMES] */
-#define MP3S_OPT_COUNT 10
+#define MP3S_OPT_FILE_UP 10        /* 1: a one-file call uploads the whole file from the context's helper thread; 0: each chunk's piece from the
+                                    * calling thread, as files above 1 GB go [MP3S_NO_FILE_UP=1 -> 0] */
+#define MP3S_OPT_HUF_LANES 11      /* decoding lanes per wave of the Huffman kernel: 0 = picked from the launch's size (32 up to 8 192 frames,
+                                    * 64 beyond), or 8 | 16 | 32 | 62 (64 lanes in workgroups of two waves) | 64 [MP3S_HUF_LANES] */
+#define MP3S_OPT_NUMA 12           /* 1: a pipe's workers and page-locked staging are bound to the CPUs of the GPU's NUMA node [MP3S_NO_NUMA=1 -> 0] */
+#define MP3S_OPT_FLOAT_FAST 13     /* 1: float32 output may take the mirrored, fused IMDCT and the split synthesis of the int16 path (no guard:
+                                    * the error is below 1e-9 of full scale, the contract's tolerance is 1e-5 relative); 0 (default): the float
+                                    * formats are bit-identical to the reference [MP3S_FLOAT_FAST=1 -> 1] */
+#define MP3S_OPT_FAIL_CHUNK 14     /* test aid: the k-th chunk (k = value, counted from 1) of the next one-file call fails with MP3S_E_HIP after
+                                    * its front end has been queued; the option clears itself when it fires */
+#define MP3S_OPT_COUNT 15
 /* what became of the one-file calls of this context (mp3s_hide_message, mp3s_clear_file, mp3s_decode_file, mp3s_decode_stream,
  * mp3s_hide_message_chunked): files that went through the overlapped stages as chunks, their chunks, chunks that were run
  * again because they depended on a carry the guess got wrong, chunks whose chains the host resolved, and files that took

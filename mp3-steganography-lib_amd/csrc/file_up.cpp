@@ -37,7 +37,7 @@ bool file_up_begin(mp3s_pipe *P, const uint8_t *file, size_t len, size_t first_b
 {
     FileUp &u = P->up;
     u.active = false;
-    if (!P->internal || !P->s_img || len > kFileOnDevice || getenv("MP3S_NO_FILE_UP")) return false;
+    if (!P->internal || !P->s_img || len > kFileOnDevice || !P->c->opt[MP3S_OPT_FILE_UP]) return false;
     if (len + 256 > u.cap) {
         if (u.d_file) (void)hipFree(u.d_file);
         u.d_file = nullptr; u.cap = 0;

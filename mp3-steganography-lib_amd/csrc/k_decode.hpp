@@ -29,6 +29,15 @@ __device__ __forceinline__ int xcd_tile()
 }
 
 
+// a lane permutation of the ALU (DPP) on both halves of a double
+template <int CTRL>
+__device__ __forceinline__ double dpp_f64(double v)
+{
+    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, 0xf, 0xf, false);
+    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, 0xf, 0xf, false);
+    return __hiloint2double(hi, lo);
+}
+
 __device__ __forceinline__ double shfl_xor_f64(double v, int mask)
 {
     int lo = __double2loint(v), hi = __double2hiint(v);
@@ -78,15 +87,29 @@ __device__ __forceinline__ void dec_stage_tables(DecShared &sh)
 }
 
 // requantise .. alias/reorder of granule g for this lane's subband; v[18] = IMDCT input
-__device__ __forceinline__ void dec_prepare(const DevTables &tab, DecShared &sh, int wave, double (&v)[18],
-                                            const int16_t *__restrict__ is, const mp3s_granule_si *__restrict__ si, int g,
+// what a lane reads from memory for a granule: its dword of the two 72-byte side records (lanes 0..35) and the 18 int16 lines
+// of its subband (9 dwords).  Asked for one granule ahead (imdct_run): under the 18 rows of the granule in front.
+struct GranIn { uint32_t side; uint32_t xw[9]; };
+__device__ __forceinline__ GranIn dec_fetch(const int16_t *__restrict__ is, const mp3s_granule_si *__restrict__ si, int g, int nch, int lane)
+{
+    const int ch = lane >> 5, sb = lane & 31;
+    const bool live = ch < nch;
+    GranIn in;
+    in.side = lane < 36 ? reinterpret_cast<const uint32_t *>(si + (long)g * 2)[lane] : 0u;
+    const uint32_t *xp = reinterpret_cast<const uint32_t *>(is + ((long)g * 2 + (live ? ch : 0)) * 576 + sb * 18);
+#pragma unroll
+    for (int k = 0; k < 9; k++) in.xw[k] = live ? xp[k] : 0u;
+    return in;
+}
+
+__device__ __forceinline__ void dec_prepare(const DevTables &tab, DecShared &sh, int wave, double (&v)[18], const GranIn &in,
                                             int sr, bool ms, int nch, int lane, int &bt_out)
 {
     const int ch = lane >> 5, sb = lane & 31;
     const bool live = ch < nch;
     // ---- side records of both channels -> LDS (36 dwords), then byte reads from there
     __builtin_amdgcn_wave_barrier();
-    if (lane < 36) (&sh.side[wave][0][0])[lane] = reinterpret_cast<const uint32_t *>(si + (long)g * 2)[lane];
+    if (lane < 36) (&sh.side[wave][0][0])[lane] = in.side;
     __builtin_amdgcn_s_waitcnt(0xc07f);
     __builtin_amdgcn_wave_barrier();
     const uint8_t *gb = reinterpret_cast<const uint8_t *>(sh.side[wave][live ? ch : 0]);
@@ -95,11 +118,9 @@ __device__ __forceinline__ void dec_prepare(const DevTables &tab, DecShared &sh,
     const int cse = bt == 2 ? 1 : (mixed ? 2 : 0);
     bt_out = bt;
     // ---- 18 int16 spectrum values (9 dwords) and 18 line-map bytes (5 dwords) of this subband
-    uint32_t xw[9], mw[5];
+    uint32_t mw[5];
+    const uint32_t (&xw)[9] = in.xw;
     {
-        const uint32_t *xp = reinterpret_cast<const uint32_t *>(is + ((long)g * 2 + (live ? ch : 0)) * 576 + sb * 18);
-#pragma unroll
-        for (int k = 0; k < 9; k++) xw[k] = live ? xp[k] : 0u;
         const uint32_t *mp = reinterpret_cast<const uint32_t *>(tab.rq_map[sr][cse][sb]);
 #pragma unroll
         for (int k = 0; k < 5; k++) mw[k] = mp[k];
@@ -152,11 +173,17 @@ __device__ __forceinline__ void dec_prepare(const DevTables &tab, DecShared &sh,
     __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0): the wave's own LDS writes have landed
     __builtin_amdgcn_wave_barrier();
     if (cse != 0) {
-        const int16_t *src = tab.reorder_src[sr];
+        // (the subband's 18 source lines as 9 dwords, all requested before the first is used: loaded one by one the compiler
+        // waited for each in turn -- 18 memory latencies per short granule)
+        const uint32_t *src = reinterpret_cast<const uint32_t *>(tab.reorder_src[sr] + sb * 18);
+        uint32_t sw[9];
+#pragma unroll
+        for (int k = 0; k < 9; k++) sw[k] = src[k];
 #pragma unroll
         for (int k = 0; k < 18; k++) {
-            const int s = src[sb * 18 + k];                       // a line of the spectrum, or -1
-            v[k] = s >= 0 ? buf[s + ((s * 3641) >> 16)] : 0.0;     // line s sits at s + s / 18 (s < 576)
+            const int s = (int)(int16_t)(sw[k >> 1] >> ((k & 1) * 16));   // a line of the spectrum, or -1
+            const double x = buf[s >= 0 ? s + ((s * 3641) >> 16) : 0];    // line s sits at s + s / 18 (s < 576)
+            v[k] = s >= 0 ? x : 0.0;
         }
     } else {
 #pragma unroll
@@ -198,7 +225,7 @@ __device__ __forceinline__ Row18s load_row18s(const double (*C36)[18], int i)
 // mp3s_tables.cpp); the wave leaves G = sum of B over the subbands of each channel behind, the synthesis guard adds
 // kappa-scaled G to its bound, and a sample the guard cannot vouch for is recomputed from `is` in the reference's order
 // (k_dec_fixup, which runs this function with FAST = false).  Short blocks keep the reference's order in both modes.
-template <bool FAST>
+template <bool FAST, bool ALLWR = false /* stereo, every lane stores its rows: no exec mask around the stores */>
 __device__ __forceinline__ void imdct_run(DecShared &sh, int wave, int lane, const int16_t *__restrict__ is,
                                           const mp3s_granule_si *__restrict__ si, const mp3s_frame_hdr *__restrict__ hdr,
                                           int n_granules, int nch, int g0, int run, double *S, long T, long slot0,
@@ -208,10 +235,17 @@ __device__ __forceinline__ void imdct_run(DecShared &sh, int wave, int lane, con
     const bool live = ch < nch;
     const bool wr = live && (only_ch < 0 || ch == only_ch);   // (the fix-up kernel keeps one channel's rows)
     const bool neg_odd = (sb & 1) != 0;
+    constexpr bool all_wr = ALLWR;
+    // frequency inversion (Frame.py:629-631): odd lines of odd subbands change sign -- a per-lane sign word for the high dword
+    // (a select per row would keep a lane mask in two scalar registers this loop does not have)
+    const uint32_t sgn_odd = neg_odd ? 0x80000000u : 0u;
+    auto flip = [&](double x) { return __hiloint2double(__double2hiint(x) ^ (int)sgn_odd, __double2loint(x)); };
     double tail[18];
 #pragma unroll
     for (int i = 0; i < 18; i++) tail[i] = 0.0;
 
+    GranIn next_in = {};
+    bool have_next = false;
     // gi = -1 primes the overlap with the second half of granule g0-1 (when it belongs to the same stream)
     for (int gi = -1; gi < run; gi++) {
         const int g = g0 + gi;
@@ -235,15 +269,27 @@ __device__ __forceinline__ void imdct_run(DecShared &sh, int wave, int lane, con
         const double(*C12)[6] = tab.imdct_cos12;
         double v[18];
         int bt;
-        dec_prepare(tab, sh, wave, v, is, si, g, sr, fh.ms_stereo != 0, nch, lane, bt);
+        // this granule's lines and side records: asked for under the rows of the granule in front (below), or here for the
+        // first one; the next granule's set off behind this granule's own loads (table look-ups of the requantisation), so that
+        // a whole granule of arithmetic lies between the request and the first use
+        const GranIn in = have_next ? next_in : dec_fetch(is, si, g, nch, lane);
+        dec_prepare(tab, sh, wave, v, in, sr, fh.ms_stereo != 0, nch, lane, bt);
+        have_next = gi + 1 < run && g + 1 < n_granules;
+        if (have_next) next_in = dec_fetch(is, si, g + 1, nch, lane);
         if (FAST && gi >= 0 && G) {
-            // G[g][ch] = sum over the channel's 32 subbands of sum_k |v[k]| (what the guard of the synthesis scales kappa with)
+            // G[g][ch] = sum over the channel's 32 subbands of sum_k |v[k]| (what the guard of the synthesis scales kappa with):
+            // inside a row of 16 lanes by lane permutations of the ALU (quad, half row, row), the two rows of a channel through
+            // one scalar read -- five round trips through the LDS crossbar (ds_bpermute) were a twentieth of a granule
             double b = 0.0;
 #pragma unroll
             for (int k = 0; k < 18; k++) b += fabs(v[k]);
-#pragma unroll
-            for (int d = 16; d >= 1; d >>= 1) b += shfl_xor_f64(b, d);
-            if (sb == 0 && live) G[(long)g * 2 + ch] = b;
+            b += dpp_f64<0xB1>(b);        // quad_perm [1, 0, 3, 2]
+            b += dpp_f64<0x4E>(b);        // quad_perm [2, 3, 0, 1]
+            b += dpp_f64<0x141>(b);       // row_half_mirror
+            b += dpp_f64<0x140>(b);       // row_mirror
+            const double r1 = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(b), 16), __builtin_amdgcn_readlane(__double2loint(b), 16));
+            const double r3 = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(b), 48), __builtin_amdgcn_readlane(__double2loint(b), 48));
+            if (sb == 0 && live) G[(long)g * 2 + ch] = b + (ch ? r3 : r1);
         }
         // window rows of the two channel halves as scalar pointers; lanes pick theirs with a select
         const int bt0 = __builtin_amdgcn_readlane(bt, 0), bt1 = __builtin_amdgcn_readlane(bt, 32);
@@ -253,31 +299,47 @@ __device__ __forceinline__ void imdct_run(DecShared &sh, int wave, int lane, con
         double *row = S + ((long)(live ? ch : 0) * T + ((long)g * 18 - slot0)) * 32 + sb;
         if (bt != 2) {
             if (FAST) {
-                // rows 0..8 and their mirrors 17..9, then rows 18..26 and their mirrors 35..27; window factors from LDS
+                // rows 0..8 and their mirrors 17..9, then rows 18..26 and their mirrors 35..27; window factors from LDS.
+                // A row's twiddles (scalar cache) and its two window factors (LDS) are asked for one row ahead, and the wait for
+                // them is spelled out at the TOP of a row, in front of the next request: scalar loads and LDS reads share one
+                // counter that can only be waited to zero while both kinds are in flight, and wherever the compiler places that
+                // wait itself -- at the first use, or (round 3) in front of the next LDS read, whose destination registers the
+                // skipped branch of a store may have left pending -- it lands behind the request and exposes its whole latency.
                 const double *wl = sh.win[bt];
                 Row18s cur = load_row18s(C36, gi >= 0 ? 0 : 18);
+                double wa = wl[gi >= 0 ? 0 : 18], wb = wl[gi >= 0 ? 17 : 35];
                 if (gi >= 0) {
 #pragma unroll
                     for (int i = 0; i < 9; i++) {
-                        const Row18s nxt = load_row18s(C36, i < 8 ? i + 1 : 18);
-                        const double wa = wl[i], wb = wl[17 - i];
+                        __builtin_amdgcn_s_waitcnt(0xc07f);
+                        __builtin_amdgcn_sched_barrier(0);
+                        const int in = i < 8 ? i + 1 : 18;
+                        const Row18s nxt = load_row18s(C36, in);
+                        const double nwa = wl[in], nwb = wl[in < 18 ? 17 - in : 53 - in];
                         __builtin_amdgcn_sched_barrier(0);
                         double y = 0.0;
 #pragma unroll
                         for (int k = 0; k < 18; k++) y = __builtin_fma(v[k], k < 8 ? cur.a[k & 7] : (k < 16 ? cur.b[k & 7] : cur.c[k & 1]), y);
+                        // (the sum is used by the stores alone: left to itself the compiler sinks the whole chain into their branch and asks
+                        // for the row again THERE -- request, wait a full scalar-cache latency, 18 multiply-adds, row after row)
+                        asm volatile("" : "+v"(y));
                         double xa = y * wa + tail[i];
                         double xb = -y * wb + tail[17 - i];
-                        if (neg_odd && (i & 1)) xa = -xa;
-                        if (neg_odd && ((17 - i) & 1)) xb = -xb;
-                        if (wr) { row[(long)i * 32] = xa; row[(long)(17 - i) * 32] = xb; }
+                        if (i & 1) xa = flip(xa);
+                        if ((17 - i) & 1) xb = flip(xb);
+                        if (all_wr) { row[(long)i * 32] = xa; row[(long)(17 - i) * 32] = xb; }
+                        else if (wr) { row[(long)i * 32] = xa; row[(long)(17 - i) * 32] = xb; }
                         __builtin_amdgcn_sched_barrier(0);
-                        cur = nxt;
+                        cur = nxt; wa = nwa; wb = nwb;
                     }
                 }
 #pragma unroll
                 for (int i = 18; i < 27; i++) {
-                    const Row18s nxt = load_row18s(C36, i < 26 ? i + 1 : 26);
-                    const double wa = wl[i], wb = wl[53 - i];
+                    __builtin_amdgcn_s_waitcnt(0xc07f);
+                    __builtin_amdgcn_sched_barrier(0);
+                    const int in = i < 26 ? i + 1 : 26;
+                    const Row18s nxt = load_row18s(C36, in);
+                    const double nwa = wl[in], nwb = wl[53 - in];
                     __builtin_amdgcn_sched_barrier(0);
                     double y = 0.0;
 #pragma unroll
@@ -285,7 +347,7 @@ __device__ __forceinline__ void imdct_run(DecShared &sh, int wave, int lane, con
                     tail[i - 18] = y * wa;
                     tail[35 - i] = y * wb;
                     __builtin_amdgcn_sched_barrier(0);
-                    cur = nxt;
+                    cur = nxt; wa = nwa; wb = nwb;
                 }
             } else {
             // One row of twiddles (18 doubles) + its two window factors per scalar batch.  Scalar loads can only be
@@ -300,9 +362,11 @@ __device__ __forceinline__ void imdct_run(DecShared &sh, int wave, int lane, con
                     double x = 0.0;
 #pragma unroll
                     for (int k = 0; k < 18; k++) x += v[k] * (k < 8 ? cur.a[k & 7] : (k < 16 ? cur.b[k & 7] : cur.c[k & 1]));
+                    asm volatile("" : "+v"(x));      // (as in the fast path: the sum stays in front of the store's branch)
                     x = x * (ch == 0 ? cur.w0 : cur.w1) + tail[i];
-                    if (neg_odd && (i & 1)) x = -x;
-                    if (wr) row[(long)i * 32] = x;
+                    if ((i) & 1) x = flip(x);
+                    if (all_wr) row[(long)i * 32] = x;
+                    else if (wr) row[(long)i * 32] = x;
                     __builtin_amdgcn_sched_barrier(0);
                     cur = nxt;
                 }
@@ -320,43 +384,62 @@ __device__ __forceinline__ void imdct_run(DecShared &sh, int wave, int lane, con
             }
             }
         } else {
-            // three 12-point windows placed at 6/12/18 (Frame.py:135-148); computed one window at a time
-            double w0[12], w1[12];
-#pragma unroll
-            for (int i = 0; i < 12; i++) {
-                double x = 0.0;
-#pragma unroll
-                for (int k = 0; k < 6; k++) x += v[k] * C12[i][k];
-                w0[i] = x * tab.sine_block[2][i];
-            }
-#pragma unroll
-            for (int i = 0; i < 12; i++) {
-                double x = 0.0;
-#pragma unroll
-                for (int k = 0; k < 6; k++) x += v[6 + k] * C12[i][k];
-                w1[i] = x * tab.sine_block[2][i];
-            }
+            // three 12-point windows placed at 6/12/18 (Frame.py:135-148).  The three windows share their coefficients, so the
+            // walk is over the 12 ROWS: row j gives t[j] (window 0, to sample_block[6 + j]), t[12 + j] (window 1, to [12 + j]) and
+            // t[24 + j] (window 2, to [18 + j]), each used exactly once -- six sums are kept (window 1's first half, until rows
+            // 6..11 bring window 0's second half), the rest goes where it belongs at once.  Same sums, same order, same roundings
+            // as the reference's; 14 scalar words per row instead of the whole 12 x 6 table in flight (which was most of the
+            // kernel's scalar spills) and 12 instead of 48 registers for the windows.
+            typedef double dvec4 __attribute__((ext_vector_type(4)));
+            struct Row6 { dvec4 a; dvec2 b; double s; };
+            auto load_row6 = [&](int j) { Row6 r; r.a = *reinterpret_cast<const dvec4 *>(C12[j]); r.b = *reinterpret_cast<const dvec2 *>(C12[j] + 4); r.s = tab.sine_block[2][j]; return r; };
+            double *row_s = row;
             if (gi >= 0) {
 #pragma unroll
-                for (int i = 0; i < 18; i++) {
-                    // sample_block[0..5] = 0, [6..11] = t[0..5], [12..17] = t[6..11] + t[12..17]
-                    const double blk = i < 6 ? 0.0 : (i < 12 ? w0[i - 6] : w0[i - 6] + w1[i - 12]);
-                    double x = blk + tail[i];
-                    if (neg_odd && (i & 1)) x = -x;
-                    if (wr) row[(long)i * 32] = x;
+                for (int i = 0; i < 6; i++) {                       // sample_block[0..5] = 0
+                    double x = 0.0 + tail[i];
+                    if ((i) & 1) x = flip(x);
+                    if (all_wr) row_s[(long)i * 32] = x;
+                    else if (wr) row_s[(long)i * 32] = x;
                 }
             }
+            double hold[6];
+            Row6 cur = load_row6(0);
 #pragma unroll
-            for (int i = 0; i < 12; i++) {
-                double x = 0.0;
+            for (int j = 0; j < 12; j++) {
+                const Row6 nxt = load_row6(j < 11 ? j + 1 : 11);
+                __builtin_amdgcn_sched_barrier(0);
+                double a0 = 0.0, a1 = 0.0, a2 = 0.0;
 #pragma unroll
-                for (int k = 0; k < 6; k++) x += v[12 + k] * C12[i][k];
-                x = x * tab.sine_block[2][i];
-                if (i < 6) tail[i] = w1[6 + i] + x;        // sample_block[18..23] = t[18..23] + t[24..29]
-                else tail[i] = x;                          // sample_block[24..29] = t[30..35]
+                for (int k = 0; k < 6; k++) {
+                    const double c = k < 4 ? cur.a[k] : cur.b[k - 4];
+                    a0 += v[k] * c; a1 += v[6 + k] * c; a2 += v[12 + k] * c;
+                }
+                a0 = a0 * cur.s; a1 = a1 * cur.s; a2 = a2 * cur.s;
+                asm volatile("" : "+v"(a0));
+                if (j < 6) {
+                    if (gi >= 0) {                                  // sample_block[6..11] = t[0..5]
+                        double x = a0 + tail[6 + j];
+                        if ((6 + j) & 1) x = flip(x);
+                        if (all_wr) row_s[(long)(6 + j) * 32] = x;
+                        else if (wr) row_s[(long)(6 + j) * 32] = x;
+                    }
+                    hold[j] = a1;                                   // t[12..17], for sample_block[12..17]
+                    tail[j] = a2;                                   // t[24..29], half of sample_block[18..23]
+                } else {
+                    if (gi >= 0) {                                  // sample_block[12..17] = t[6..11] + t[12..17]
+                        double x = (a0 + hold[j - 6]) + tail[6 + j];
+                        if ((6 + j) & 1) x = flip(x);
+                        if (all_wr) row_s[(long)(6 + j) * 32] = x;
+                        else if (wr) row_s[(long)(6 + j) * 32] = x;
+                    }
+                    tail[j - 6] = a1 + tail[j - 6];                 // sample_block[18..23] = t[18..23] + t[24..29]
+                    tail[j] = a2;                                   // sample_block[24..29] = t[30..35]
+                    tail[6 + j] = 0.0;                              // sample_block[30..35]
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                cur = nxt;
             }
-#pragma unroll
-            for (int i = 12; i < 18; i++) tail[i] = 0.0;   // sample_block[30..35]
         }
     }
 }
@@ -371,7 +454,8 @@ __global__ __launch_bounds__(DEC_A_WAVES * 64, 3) void k_dec_imdct(
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
     const int g0 = (xcd_tile() * DEC_A_WAVES + wave) * run;
     if (g0 >= n_granules) return;  // whole wave exits together
-    imdct_run<FAST>(sh, wave, lane, is, si, hdr, n_granules, nch, g0, run, S, T, 0, sf_base, G);
+    if (nch == 2) imdct_run<FAST, true>(sh, wave, lane, is, si, hdr, n_granules, 2, g0, run, S, T, 0, sf_base, G);
+    else imdct_run<FAST, false>(sh, wave, lane, is, si, hdr, n_granules, nch, g0, run, S, T, 0, sf_base, G);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -563,7 +647,7 @@ __global__ __launch_bounds__(TW * 64 * 2, TW == 4 ? 2 : 4) void k_dec_synth_fast
     constexpr int TL_LANES = TW * 64, OUT = TL_LANES - 15;
     constexpr int OROW = 33;
     __shared__ double ex[2][2][4][TL_LANES];
-    __shared__ uint32_t otile[OUT * OROW];
+    __shared__ uint32_t otile[(OUT + 1) * OROW];               // (+ one row nobody reads: where the lanes that do not emit put their samples)
     __shared__ double amax_w[TW * 2];
     __shared__ double gmax_s;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
@@ -641,108 +725,150 @@ __global__ __launch_bounds__(TW * 64 * 2, TW == 4 ? 2 : 4) void k_dec_synth_fast
     // code of an interval (which level, how many terms) is the same for h = 0 and h = 1 and only the table row differs.
     // Stages of an interval: odd-k sums A1, B1 (16 terms), even-k sums A0, B0 (8 / 4 / 2 terms), barrier, the two window
     // sums W0, W1 (16 taps); each stage requests the scalar operands of the next one before it computes.
-    auto window = [&](int io, int s, const SynthRow<16> &w) {
-        if (tl < 15) return;
-        double sum = 0.0;
-        if (full_hist) {
+    // ---- the window sums.  Two rules shape this loop:
+    //  * Scalar loads (matrix rows, window taps) and LDS reads (the V values of 16 slots) share ONE counter, and while both
+    //    kinds are in flight it can only be waited to zero.  So no scalar load is in flight while a window's LDS reads are
+    //    waited for: a stage waits for everything asked for so far, THEN asks for the operands of the stage behind it, then
+    //    computes (round 3 asked first; every wait of the compiler's then landed behind the request and took its whole latency).
+    //  * No branch per output: every lane sums (lanes 0..14 of the tile, which only rebuild history, from the slots of lane 15),
+    //    the guard is mask arithmetic, and a lane that does not emit writes its sample to a row of the tile nobody reads --
+    //    round 3's four exec-mask branches per output cost more instructions than its 16 multiply-adds.
+    const int tlc = tl >= 15 ? tl : 15;
+    const int orow = emit ? tl - 15 : OUT;
+    uint16_t *const oslot = ot16 + orow * OROW * 2 + ch;
+    const uint32_t emit_m = emit ? 0xffffffffu : 0u;
+    auto window_read = [&](int s, double (&u)[16]) {
+        const double *e0 = &ex[p][ch][2 * s][tlc], *e1 = &ex[p][ch][2 * s + 1][tlc];
 #pragma unroll
-            for (int jj = 0; jj < 16; jj++) sum = __builtin_fma(ex[p][ch][2 * s + (jj & 1)][tl - jj], w.c[jj >> 3][jj & 7], sum);
-        } else {
+        for (int jj = 0; jj < 16; jj++) u[jj] = (jj & 1 ? e1 : e0)[-jj];
+        if (!full_hist) {                                   // (wave-uniform, rare: a stream starts inside the tile)
 #pragma unroll
-            for (int jj = 0; jj < 16; jj++) {
-                double u = ex[p][ch][2 * s + (jj & 1)][tl - jj];
-                if (jj > lim) u = 0.0;
-                sum = __builtin_fma(u, w.c[jj >> 3][jj & 7], sum);
-            }
-        }
-        if (emit) {
-            // the guard: is the truncation of sum * 32767 beyond doubt?  (Truncation is toward zero: every x in (-1, 1) gives
-            // 0, so the integer 0 is not a boundary.)
-            const double x = sum * 32767, xi = rint(x);
-            const double r = fabs(x - xi);
-            if ((xi != 0.0 && !(r > eps_a + eps_x * fabs(x))) || !(fabs(x) < 2147483000.0)) redo |= 1u << io;
-            ot16[(tl - 15) * OROW * 2 + io * nch + ch] = (uint16_t)pcm_to_i16(sum);
+            for (int jj = 0; jj < 16; jj++) if (jj > lim) u[jj] = 0.0;      // before the stream started the fifo holds zeros
         }
     };
+    auto window_emit = [&](int io, double sum) {
+        // the guard: is the truncation of sum * 32767 beyond doubt?  (Truncation is toward zero: every x in (-1, 1) gives
+        // 0, so the integer 0 is not a boundary.)
+        const double x = sum * 32767, xi = rint(x), ax = fabs(x);
+        const double r = fabs(x - xi);
+        const bool doubt = ((xi != 0.0) & !(r > __builtin_fma(eps_x, ax, eps_a))) | !(ax < 2147483000.0);
+        redo |= (doubt ? 1u << io : 0u) & emit_m;
+        asm volatile("" : "+v"(redo));      // (decided HERE: the bits are read behind the loop, and the compiler would otherwise carry all 32 x there)
+        // (pcm_to_i16: x86's cvttsd2si gives "indefinite", low half 0, beyond int32)
+        const int q = ax < 2147483648.0 ? (int)x : 0;
+        oslot[io * nch] = (uint16_t)q;
+    };
     const double *Wtab = &c_tab.synth_window_t[0][0];
-    SynthRow<16> rA1 = synth_row<16>(C32 + (17 >> 1) * 16);          // interval (h = 0, t = 0): k = 17
+    // Scalar operands travel in pieces of eight doubles (16 scalar registers, one s_load_dwordx16): a step waits for the piece
+    // it multiplies with, asks for the next one, and multiplies -- two pieces live at any time (round 3 kept whole rows: two
+    // 16-term rows, two 8-term rows and a row of taps were 112 scalar registers at the peak, and the allocator spilled 65 of
+    // them into vector lanes, to be read back lane by lane in the middle of the sums).
+    typedef double d8 __attribute__((ext_vector_type(8)));
+    typedef double d4t __attribute__((ext_vector_type(4)));
+    typedef double d2t __attribute__((ext_vector_type(2)));
+    auto ld8 = [](const double *q) { return *reinterpret_cast<const d8 *>(q); };
+    auto dot8 = [](const double *d, const d8 &c, double a) {
+#pragma unroll
+        for (int j = 0; j < 8; j++) a = __builtin_fma(d[j], c[j], a);
+        return a;
+    };
+#define MP3S_ARRIVED() do { __builtin_amdgcn_s_waitcnt(0xc07f); __builtin_amdgcn_sched_barrier(0); } while (0)
+#define MP3S_GO() __builtin_amdgcn_sched_barrier(0)
+    d8 cur = ld8(C32 + (17 >> 1) * 16);                             // interval (h = 0, t = 0): k = 17, first half of its row
 #pragma unroll 1
     for (int h = 0; h < 2; h++) {
 #pragma unroll
         for (int tt = 0; tt < 8; tt++) {
             const int i = 16 * h + 2 * tt;
             // odd k: V[i+1] = X[17+2t] | -X[31-2t],  V[32+i+1] = -X[15-2t] | -X[2t+1];  row of odd k: (k-1)/2
-            const int kb1 = h ? 2 * tt + 1 : 15 - 2 * tt;
+            const int ka1 = h ? 31 - 2 * tt : 17 + 2 * tt, kb1 = h ? 2 * tt + 1 : 15 - 2 * tt;
             // even k: V[i] = X[16+2t] | -X[32-2t],  V[32+i] = -X[16-2t] | -X[2t]
             const int ka0 = h ? 32 - 2 * tt : 16 + 2 * tt, kb0 = h ? 2 * tt : 16 - 2 * tt;
-            constexpr int dummy = 0; (void)dummy;
-            const SynthRow<16> rB1 = synth_row<16>(C32 + (kb1 >> 1) * 16);
-            __builtin_amdgcn_sched_barrier(0);
-            double va1 = synth_dot<16>(d16, rA1);
+            const double *rowA1 = C32 + (ka1 >> 1) * 16, *rowB1 = C32 + (kb1 >> 1) * 16;
+            // ---- the odd-k sums: four pieces
+            MP3S_ARRIVED(); d8 nxt = ld8(rowA1 + 8); MP3S_GO();
+            double va1 = dot8(d16, cur, 0.0); MP3S_GO();
+            cur = nxt;
+            MP3S_ARRIVED(); nxt = ld8(rowB1); MP3S_GO();
+            va1 = dot8(d16 + 8, cur, va1); MP3S_GO();
             if (h) va1 = -va1;
-            __builtin_amdgcn_sched_barrier(0);
-            double va0, vb0, vb1;
-            SynthRow<16> w0;
-            if (tt == 0) {                              // k = 16 | 32 (X[32] = 0) and k = 16 | 0: nothing to multiply
-                w0 = synth_row<16>(Wtab + i * 16);
-                __builtin_amdgcn_sched_barrier(0);
-                vb1 = -synth_dot<16>(d16, rB1);
+            cur = nxt;
+            MP3S_ARRIVED(); nxt = ld8(rowB1 + 8); MP3S_GO();
+            double vb1 = dot8(d16, cur, 0.0); MP3S_GO();
+            cur = nxt;
+            // ---- the even-k sums (8 / 4 / 2 terms, or none), then the first half of the taps of window i
+            double va0, vb0;
+            if (tt == 0) {                                          // k = 16 | 32 (X[32] = 0) and k = 16 | 0: nothing to multiply
+                MP3S_ARRIVED(); nxt = ld8(Wtab + i * 16); MP3S_GO();
+                vb1 = -dot8(d16 + 8, cur, vb1); MP3S_GO();
                 va0 = h ? 0.0 : x16; vb0 = h ? -x0 : -x16;
-                __builtin_amdgcn_sched_barrier(0);
+                cur = nxt;
             } else if (tt & 1) {
-                const SynthRow<8> rA0 = synth_row<8>(C16 + ((ka0 - 2) >> 2) * 8);
-                __builtin_amdgcn_sched_barrier(0);
-                vb1 = -synth_dot<16>(d16, rB1);
-                __builtin_amdgcn_sched_barrier(0);
-                const SynthRow<8> rB0 = synth_row<8>(C16 + ((kb0 - 2) >> 2) * 8);
-                __builtin_amdgcn_sched_barrier(0);
-                va0 = synth_dot<8>(d8v, rA0);
-                __builtin_amdgcn_sched_barrier(0);
-                w0 = synth_row<16>(Wtab + i * 16);
-                __builtin_amdgcn_sched_barrier(0);
-                vb0 = -synth_dot<8>(d8v, rB0);
-                __builtin_amdgcn_sched_barrier(0);
-            } else if (tt & 2) {
-                const SynthRow<4> rA0 = synth_row<4>(C8 + ((ka0 - 4) >> 3) * 4), rB0 = synth_row<4>(C8 + ((kb0 - 4) >> 3) * 4);
-                __builtin_amdgcn_sched_barrier(0);
-                vb1 = -synth_dot<16>(d16, rB1);
-                __builtin_amdgcn_sched_barrier(0);
-                w0 = synth_row<16>(Wtab + i * 16);
-                __builtin_amdgcn_sched_barrier(0);
-                va0 = synth_dot<4>(d4, rA0); vb0 = -synth_dot<4>(d4, rB0);
-                __builtin_amdgcn_sched_barrier(0);
+                MP3S_ARRIVED(); nxt = ld8(C16 + ((ka0 - 2) >> 2) * 8); MP3S_GO();
+                vb1 = -dot8(d16 + 8, cur, vb1); MP3S_GO();
+                cur = nxt;
+                MP3S_ARRIVED(); nxt = ld8(C16 + ((kb0 - 2) >> 2) * 8); MP3S_GO();
+                va0 = dot8(d8v, cur, 0.0); MP3S_GO();
+                cur = nxt;
+                MP3S_ARRIVED(); nxt = ld8(Wtab + i * 16); MP3S_GO();
+                vb0 = -dot8(d8v, cur, 0.0); MP3S_GO();
+                cur = nxt;
             } else {
-                const SynthRow<2> rA0 = synth_row<2>(C4 + ((ka0 - 8) >> 4) * 2), rB0 = synth_row<2>(C4 + ((kb0 - 8) >> 4) * 2);
-                __builtin_amdgcn_sched_barrier(0);
-                vb1 = -synth_dot<16>(d16, rB1);
-                __builtin_amdgcn_sched_barrier(0);
-                w0 = synth_row<16>(Wtab + i * 16);
-                __builtin_amdgcn_sched_barrier(0);
-                va0 = synth_dot<2>(d2, rA0); vb0 = -synth_dot<2>(d2, rB0);
-                __builtin_amdgcn_sched_barrier(0);
+                // 4- and 2-term rows: both rows of the interval in one request
+                d4t a4, b4; d2t a2, b2;
+                MP3S_ARRIVED();
+                if (tt & 2) { a4 = *reinterpret_cast<const d4t *>(C8 + ((ka0 - 4) >> 3) * 4); b4 = *reinterpret_cast<const d4t *>(C8 + ((kb0 - 4) >> 3) * 4); }
+                else { a2 = *reinterpret_cast<const d2t *>(C4 + ((ka0 - 8) >> 4) * 2); b2 = *reinterpret_cast<const d2t *>(C4 + ((kb0 - 8) >> 4) * 2); }
+                MP3S_GO();
+                vb1 = -dot8(d16 + 8, cur, vb1); MP3S_GO();
+                MP3S_ARRIVED(); nxt = ld8(Wtab + i * 16); MP3S_GO();
+                va0 = 0.0; vb0 = 0.0;
+                if (tt & 2) {
+#pragma unroll
+                    for (int j = 0; j < 4; j++) { va0 = __builtin_fma(d4[j], a4[j], va0); vb0 = __builtin_fma(d4[j], b4[j], vb0); }
+                } else {
+#pragma unroll
+                    for (int j = 0; j < 2; j++) { va0 = __builtin_fma(d2[j], a2[j], va0); vb0 = __builtin_fma(d2[j], b2[j], vb0); }
+                }
+                vb0 = -vb0; MP3S_GO();
+                cur = nxt;
             }
             if (h && tt) va0 = -va0;
             ex[p][ch][0][tl] = va0;
             ex[p][ch][1][tl] = vb0;
             ex[p][ch][2][tl] = va1;
             ex[p][ch][3][tl] = vb1;
-            __syncthreads();
-            const SynthRow<16> w1 = synth_row<16>(Wtab + (i + 1) * 16);
-            __builtin_amdgcn_sched_barrier(0);
-            window(i, 0, w0);
-            __builtin_amdgcn_sched_barrier(0);
+            __syncthreads();                                        // (its wait covers the taps asked for above)
+            double u[16];
+            // ---- window i: its V values from LDS, alone in flight; then the sum, its second half of the taps under the first
+            window_read(0, u);
+            MP3S_ARRIVED(); nxt = ld8(Wtab + i * 16 + 8); MP3S_GO();
+            double sum = dot8(u, cur, 0.0); MP3S_GO();
+            cur = nxt;
+            MP3S_ARRIVED(); nxt = ld8(Wtab + (i + 1) * 16); MP3S_GO();
+            sum = dot8(u + 8, cur, sum);
+            window_emit(i, sum); MP3S_GO();
+            cur = nxt;
+            // ---- window i + 1; under its second half the first piece of the next interval: (h, t + 1), or (1, 0) behind (0, 7);
+            //      behind the last one: any row
+            MP3S_ARRIVED();
+            window_read(1, u);
+            MP3S_ARRIVED(); nxt = ld8(Wtab + (i + 1) * 16 + 8); MP3S_GO();
+            sum = dot8(u, cur, 0.0); MP3S_GO();
+            cur = nxt;
             {
-                // the first row of the next interval: (h, t + 1), or (1, 0) behind (0, 7); behind the last one: any row
                 const int hn = tt == 7 ? 1 : h, tn = tt == 7 ? 0 : tt + 1;
                 const int kn = hn ? 31 - 2 * tn : 17 + 2 * tn;
-                rA1 = synth_row<16>(C32 + (kn >> 1) * 16);
+                MP3S_ARRIVED(); nxt = ld8(C32 + (kn >> 1) * 16); MP3S_GO();
             }
-            __builtin_amdgcn_sched_barrier(0);
-            window(i + 1, 1, w1);
-            __builtin_amdgcn_sched_barrier(0);
+            sum = dot8(u + 8, cur, sum);
+            window_emit(i + 1, sum); MP3S_GO();
+            cur = nxt;
             p ^= 1;
         }
     }
+#undef MP3S_ARRIVED
+#undef MP3S_GO
     // ---- the samples the guard could not vouch for go on the fix-up list: slot | channel << 31, mask of output indices
     //      (k_dec_fixup recomputes them from `is` in the reference's order and overwrites what is stored below)
     if (redo) {

@@ -167,17 +167,17 @@ struct SideRegs {
 };
 
 // One thread per granule*channel; unit index = (frame*2 + gr)*2 + ch (same order as the si / is arrays).
-// LDS = the shared first-level tables (30.8 KB) + W words of staged bits per thread.  A wave is a chain of dependent LDS
-// look-ups, so throughput comes from resident waves: W is sized by the launcher from the longest granule of the batch
-// (30 words at 128 kbps instead of the worst-case 132), which lets 8 waves share a CU instead of 2.
-// WAVES x 64 threads per workgroup of which LANES per wave decode: every lane walks its own bit stream, so a wave is a
-// latency chain that runs as long as its slowest lane.  Small batches use narrow waves (more waves per SIMD to
-// interleave, less waiting for the slowest lane), large batches full ones (more granules in flight per CU).
+// LDS = the shared first-level tables + W words of staged bits per thread (W is sized by the launcher from the longest
+// granule of the batch: 30 words at 128 kbps instead of the worst-case 132).
+// WAVES x 64 threads per workgroup of which LANES per wave decode.  The lanes of a wave walk their 288 pairs in step, so
+// the kernel lasts as long as ONE wave's chain of dependent look-ups as long as every SIMD has at most one wave (a second
+// wave on a SIMD costs +20 %: DESIGN.md section 4): the launcher picks LANES so that the batch spreads over as many SIMDs
+// as there are (32 lanes per wave up to 8 192 frames, 64 beyond) -- the kernel's time is a latency, not a throughput.
 template <int WAVES, int LANES>
 __global__ __launch_bounds__(WAVES * 64) void k_dec_huffman(
     const uint8_t *__restrict__ blob, const mp3s_frame_side *__restrict__ side, int n_frames, int nch, int W, int max_bits,
     int16_t *__restrict__ is, mp3s_granule_si *__restrict__ si_out, int32_t *__restrict__ status, int per_frame,
-    int32_t *__restrict__ sync /* {finished workgroups, error bits}: zero between launches, owned by the context; null: status[0] was
+    int32_t *__restrict__ sync /* {finished workgroups | error bits}, one 8-byte aligned 64-bit word (k_sync.hpp): zero between launches, owned by the context; null: status[0] was
                                   zeroed by the caller and takes the error bits directly */)
 {
 #if MP3S_HUF_CLOCKS
@@ -494,20 +494,16 @@ __global__ __launch_bounds__(WAVES * 64) void k_dec_huffman(
         if (e4) atomicOr(&wg_err, e4);                   // (LDS)
     }
     __syncthreads();
-    // One thread speaks for the group, and what it has to say goes out in program order: the group's error bits first, its
-    // arrival after them -- two device-scope atomics of one lane on neighbouring words, so the last group to arrive finds
-    // every group's bits (no fence: an agent-scope release writes the L2 back, which two thousand groups cannot afford).
+    // One thread speaks for the group, once: its arrival and its error bits in ONE atomic on the context's 64-bit word
+    // (k_sync.hpp); the group that arrives last hands out every group's bits.
     if (threadIdx.x != 0) return;
     const int g = wg_err;
     if (!sync) {          // the caller has zeroed status[0] itself (the overlapped stages: the word travels with the job's inputs)
         if (g) atomicOr(&status[0], g);
         return;
     }
-    if (g) atomicOr(&sync[1], g);
-    if (atomicAdd(&sync[0], 1) == (int)gridDim.x - 1) {
-        status[0] = atomicExch(&sync[1], 0);
-        atomicExch(&sync[0], 0);
-    }
+    unsigned all;
+    if (arrive_with_bits(sync, (unsigned)g, gridDim.x, &all)) status[0] = (int32_t)all;
 }
 
 }  // namespace mp3s

@@ -252,13 +252,8 @@ __global__ __launch_bounds__(256) void k_enc_pack(
     if ((int)threadIdx.x < nbytes - tail0) mp3[off + tail0 + threadIdx.x] = (uint8_t)byte_at(tail0 + threadIdx.x);
     rot = rot == 2 ? 0 : rot + 1;
     }   // frames
-    // The caller's status word is written once, by the workgroup that finishes last, from the error bits collected in the
-    // context's scratch pair sync[0] = finished groups, sync[1] = errors; that group also clears the pair for the next
-    // launch on this context.  No fill kernel in front of every launch: one dispatch (and its stream gap) less per step.
-    // (Only device-scope atomics touch the pair, so no cache write-back is needed: the barrier waits for this group's
-    // error atomics to be acknowledged before its arrival is counted.)
-    // One thread speaks for the group, and in program order: the group's error bits first, its arrival after them -- two
-    // device-scope atomics of one lane on neighbouring words (no fence: an agent-scope release writes the L2 back).
+    // The caller's status word is written once, by the workgroup that finishes last, from the context's 64-bit word {finished
+    // groups | error bits} (k_sync.hpp: one atomic per group, no fill kernel in front of every launch).
     // sync == null: the caller has zeroed *status itself (the overlapped stages, where the word travels with the job's inputs): two
     // thousand arrivals on one counter are 0.1 ms of serialised atomics when the groups finish together, as they do on a short batch.
     __syncthreads();
@@ -268,11 +263,8 @@ __global__ __launch_bounds__(256) void k_enc_pack(
         if (g) atomicOr(status, g);
         return;
     }
-    if (g) atomicOr(&sync[1], g);
-    if (atomicAdd(&sync[0], 1) == (int)gridDim.x - 1) {
-        *status = atomicExch(&sync[1], 0);
-        atomicExch(&sync[0], 0);
-    }
+    unsigned all;
+    if (arrive_with_bits(sync, (unsigned)g, gridDim.x, &all)) *status = (int32_t)all;
 }
 
 }  // namespace mp3s

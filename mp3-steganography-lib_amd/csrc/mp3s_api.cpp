@@ -123,6 +123,11 @@ int mp3s_ctx_create(int device, mp3s_ctx **out)
         c->opt[MP3S_OPT_FILE_PIPELINE] = env("MP3S_FILE_PIPELINE", 1) != 0;
         c->opt[MP3S_OPT_SCAN_THREADS] = std::max<int64_t>(0, env("MP3S_SCAN_THREADS", 0));
         c->opt[MP3S_OPT_FIRST_CHUNK_FRAMES] = std::max<int64_t>(0, env("MP3S_FIRST_CHUNK_FRAMES", 0));
+        c->opt[MP3S_OPT_FILE_UP] = getenv("MP3S_NO_FILE_UP") ? 0 : 1;
+        c->opt[MP3S_OPT_HUF_LANES] = std::max<int64_t>(0, env("MP3S_HUF_LANES", 0));
+        c->opt[MP3S_OPT_NUMA] = getenv("MP3S_NO_NUMA") ? 0 : 1;
+        c->opt[MP3S_OPT_FLOAT_FAST] = env("MP3S_FLOAT_FAST", 0) != 0;
+        c->opt[MP3S_OPT_FAIL_CHUNK] = 0;
     }
     if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess ||
         hipEventCreate(&c->ev0) != hipSuccess || hipEventCreate(&c->ev1) != hipSuccess ||
@@ -168,7 +173,9 @@ int mp3s_ctx_set_option(mp3s_ctx *c, int option, int64_t value)
     if (!c || option <= 0 || option >= MP3S_OPT_COUNT) return fail(MP3S_E_ARG, "unknown option %d", option);
     if (value < 0 || ((option == MP3S_OPT_CHUNK_FRAMES || option == MP3S_OPT_FIRST_CHUNK_FRAMES) && value != 0 && value < 4) || (option == MP3S_OPT_SCAN_THREADS && value > 64))
         return fail(MP3S_E_ARG, "option %d: value %lld out of range", option, (long long)value);
-    c->opt[option] = option == MP3S_OPT_CHUNK_FRAMES || option == MP3S_OPT_SCAN_THREADS || option == MP3S_OPT_FIRST_CHUNK_FRAMES ? value : (option == MP3S_OPT_PIPE_TAIL ? std::min<int64_t>(value, 2) : (value != 0));
+    const bool number = option == MP3S_OPT_CHUNK_FRAMES || option == MP3S_OPT_SCAN_THREADS || option == MP3S_OPT_FIRST_CHUNK_FRAMES ||
+                        option == MP3S_OPT_HUF_LANES || option == MP3S_OPT_FAIL_CHUNK;
+    c->opt[option] = number ? value : (option == MP3S_OPT_PIPE_TAIL ? std::min<int64_t>(value, 2) : (value != 0));
     return MP3S_OK;
 }
 
@@ -558,7 +565,7 @@ int mp3s_huffman_decode_dev(mp3s_ctx *c, const uint8_t *d_blob, const mp3s_frame
     if (!c || !d_blob || !d_side || !d_is || !d_si || !d_status) return fail(MP3S_E_ARG, "null pointer");
     if (n_frames <= 0 || nch < 1 || nch > 2 || max_part2_3_length < 0) return fail(MP3S_E_ARG, "bad sizes");
     if (max_part2_3_length == 0 || max_part2_3_length > 4095) max_part2_3_length = 4095;
-    const int e = launch_huffman(c->stream, d_blob, d_side, n_frames, nch, max_part2_3_length, d_is, d_si, d_status, c->d_sync + 4, &c->prof);
+    const int e = launch_huffman(c->stream, d_blob, d_side, n_frames, nch, max_part2_3_length, d_is, d_si, d_status, c->d_sync + 4, &c->prof, false, (int)c->opt[MP3S_OPT_HUF_LANES]);
     if (e) return fail(MP3S_E_HIP, "huffman launch: %s", hipGetErrorString((hipError_t)e));
     return MP3S_OK;
 }

@@ -131,7 +131,7 @@ int decode_group(mp3s_ctx *c, mp3s_multi &m, const std::vector<int> &idx, int nc
         if (!rc) rc = mp3s_dev_upload(c, d_side, side, (size_t)n * sizeof(mp3s_frame_side));
         if (!rc) {
             const int e = launch_huffman(c->stream, (const uint8_t *)d_blob, (const mp3s_frame_side *)d_side, (int)n, nch,
-                                         max_part2_3(side, n), (int16_t *)d_is, (mp3s_granule_si *)d_si, (int32_t *)d_st, c->d_sync + 4, &c->prof, true);
+                                         max_part2_3(side, n), (int16_t *)d_is, (mp3s_granule_si *)d_si, (int32_t *)d_st, c->d_sync + 4, &c->prof, true, (int)c->opt[MP3S_OPT_HUF_LANES]);
             if (e) rc = fail(MP3S_E_HIP, "huffman launch: %s", hipGetErrorString((hipError_t)e));
         }
         const double t_up1 = trace_on() ? now_ms() : 0;

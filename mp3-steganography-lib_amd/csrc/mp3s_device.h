@@ -103,9 +103,10 @@ int launch_noop(hipStream_t stream);
 
 // bit-level stages on the device
 int launch_huffman(hipStream_t stream, const uint8_t *d_blob, const mp3s_frame_side *d_side, int n_frames, int nch, int max_bits,
-                   int16_t *d_is, mp3s_granule_si *d_si, int32_t *d_status, int32_t *d_sync /* 2 zeroed words owned by the context */,
+                   int16_t *d_is, mp3s_granule_si *d_si, int32_t *d_status, int32_t *d_sync /* one zeroed 64-bit word owned by the context (k_sync.hpp) */,
                    Profiler *prof,
-                   bool per_frame = false /* d_status holds 1 + n_frames words: [0] = all, [1 + f] = frame f */);
+                   bool per_frame = false /* d_status holds 1 + n_frames words: [0] = all, [1 + f] = frame f */,
+                   int lanes_opt = 0 /* MP3S_OPT_HUF_LANES: 0 = from the launch's size */);
 // the tables every entry of a compact == 2 launch took, one byte each
 int launch_gather_tables(hipStream_t stream, const mp3s_gr_out *d_outv, int n, uint8_t *d_tables);
 // pairs: int32 [n][2] = (entry, unit): entry's ix / energies / GrInfo (compact == 2 arrays) -> the unit's place
@@ -113,6 +114,6 @@ int launch_scatter(hipStream_t stream, const int32_t *d_pairs, int n_pairs, cons
                    const mp3s_gr_out *d_outv, int16_t *d_ix, int32_t *d_en, mp3s_gr_out *d_out);
 int launch_pack(hipStream_t stream, const int16_t *d_ix, const mp3s_gr_out *d_gr, const int32_t *d_en, int n_frames, int sri,
                 int bri, int whole_slots, const uint32_t *d_frame_off, const uint8_t *d_padding, uint8_t *d_mp3,
-                int32_t *d_scfsi, int32_t *d_status, int32_t *d_sync /* 2 zeroed words owned by the context */, Profiler *prof);
+                int32_t *d_scfsi, int32_t *d_status, int32_t *d_sync /* one zeroed 64-bit word owned by the context (k_sync.hpp) */, Profiler *prof);
 
 }  // namespace mp3s

@@ -14,6 +14,7 @@ namespace mp3s {
 __constant__ DevTables c_tab;
 }
 
+#include "k_sync.hpp"
 #include "k_decode.hpp"
 #include "k_encode.hpp"
 #include "k_rate.hpp"
@@ -93,14 +94,12 @@ int launch_decode(hipStream_t stream, const int16_t *d_is, const mp3s_granule_si
     constexpr int TW = DEC_SYNTH_TW;
     pp = prof ? prof->begin(stream, K_DEC_SYNTH) : -1;
     if (fast) {
-        static const int ftw = getenv("MP3S_FAST_TW") ? atoi(getenv("MP3S_FAST_TW")) : DEC_SYNTH_FAST_TW;
+        constexpr int ftw = DEC_SYNTH_FAST_TW;
         const double *Gk = fast_imdct ? G : nullptr;
 #define MP3S_FAST_LAUNCH(W)                                                                                                        \
         hipLaunchKernelGGL(k_dec_synth_fast<W>, dim3((unsigned)((T + (W * 64 - 15) - 1) / (W * 64 - 15))), dim3(W * 64 * nch), 0, stream, \
                            (const double *)S, T, d_hdr, nch, n_halo, (int16_t *)d_pcm, sf_base, synth_eps_scale, Gk, n_gran, fix_list, d_sync + 6)
-        if (ftw == 1) MP3S_FAST_LAUNCH(1);
-        else if (ftw == 4) MP3S_FAST_LAUNCH(4);
-        else MP3S_FAST_LAUNCH(2);
+        MP3S_FAST_LAUNCH(ftw);
 #undef MP3S_FAST_LAUNCH
         // the samples the guard could not vouch for, again from `is` in the reference's order (a handful per batch)
         const int fix_groups = (int)((T * nch + DEC_A_WAVES - 1) / DEC_A_WAVES) < 128 ? (int)((T * nch + DEC_A_WAVES - 1) / DEC_A_WAVES) : 128;
@@ -217,7 +216,7 @@ int launch_scatter(hipStream_t stream, const int32_t *d_pairs, int n_pairs, cons
 }
 
 int launch_huffman(hipStream_t stream, const uint8_t *d_blob, const mp3s_frame_side *d_side, int n_frames, int nch, int max_bits,
-                   int16_t *d_is, mp3s_granule_si *d_si, int32_t *d_status, int32_t *d_sync, Profiler *prof, bool per_frame)
+                   int16_t *d_is, mp3s_granule_si *d_si, int32_t *d_status, int32_t *d_sync, Profiler *prof, bool per_frame, int lanes_opt)
 {
     // (no fills in front of the kernel: it writes every sample pair, every side record and every status word itself)
     // LDS per workgroup = 27 KB of tables + W words per decoding lane, at most 64 KB.  Widest waves that still give
@@ -242,15 +241,16 @@ int launch_huffman(hipStream_t stream, const uint8_t *d_blob, const mp3s_frame_s
     // one wave per SIMD runs as fast as a wave can (1 024 SIMDs): 32 lanes per wave up to 8 192 frames, 64 beyond
     if (fits(128)) { lanes = 32; waves = 4; }
     if (fits(256) && units > 32 * 1024) { lanes = 64; waves = 4; }
-    if (const char *ev = getenv("MP3S_HUF_LANES")) {
-        const int a = atoi(ev);
+    if (lanes_opt > 0) {          // MP3S_OPT_HUF_LANES
+        const int a = lanes_opt;
         if (a == 64 && fits(256)) { lanes = 64; waves = 4; }
         if (a == 62 && fits(128)) { lanes = 64; waves = 2; }
         if (a == 32 && fits(128)) { lanes = 32; waves = 4; }
         if (a == 16) { lanes = 16; waves = 4; }
         if (a == 8) { lanes = 8; waves = 8; }
     }
-    if (getenv("MP3S_TRACE")) fprintf(stderr, "[mp3s] huffman launch: %ld units, W %d, %d waves x %d lanes, %zu bytes of dynamic LDS\n", units, W, waves, lanes, dyn(waves * lanes, waves));
+    static const bool trace = getenv("MP3S_TRACE") != nullptr;
+    if (trace) fprintf(stderr, "[mp3s] huffman launch: %ld units, W %d, %d waves x %d lanes, %zu bytes of dynamic LDS\n", units, W, waves, lanes, dyn(waves * lanes, waves));
     const int pp = prof ? prof->begin(stream, K_DEC_HUFFMAN) : -1;
 #define MP3S_HUF_LAUNCH(WV, LN)                                                                                         \
     do {                                                                                                                \

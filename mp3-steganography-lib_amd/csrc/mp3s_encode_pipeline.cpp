@@ -189,8 +189,7 @@ int enc_issue(mp3s_ctx *c, const EncLayout &L, const EncDev &d, hipStream_t tail
     if (!rc && pcm_read && hipEventRecord(pcm_read, c->stream) != hipSuccess) rc = fail(MP3S_E_HIP, "event record failed");   // the PCM buffer may be written again
     // (the tail of the job in front is through before this job's rate loop starts: tails do not queue up behind one another)
     if (!rc && rate_after && hipStreamWaitEvent(c->stream, rate_after, 0) != hipSuccess) rc = fail(MP3S_E_HIP, "ordering behind the previous tail failed");
-    static const bool sel_on_compute = getenv("MP3S_SELECT_ON_COMPUTE") != nullptr;   // (development: the selection in front of the tail, as until r03c)
-    const bool select_on_tail = tail && L.n_entries > 0 && !sel_on_compute;
+    const bool select_on_tail = tail && L.n_entries > 0;
     if (!rc && L.n_entries > 0) {
         // short messages: their variants run in the same launch and the device decides the cursor chain (no guess).  With a tail
         // stream the selection (two small launches) belongs to the tail: the compute stream is free for the next job's decode

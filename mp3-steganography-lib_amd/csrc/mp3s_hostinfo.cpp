@@ -60,7 +60,6 @@ int default_scan_threads(const mp3s_ctx *c)
 std::vector<int> gpu_node_cpus(int device)
 {
     std::vector<int> out;
-    if (getenv("MP3S_NO_NUMA")) return out;
     char bus[64] = {0};
     if (hipDeviceGetPCIBusId(bus, (int)sizeof bus, device) != hipSuccess) return out;
     for (char *p = bus; *p; p++) *p = (char)tolower(*p);

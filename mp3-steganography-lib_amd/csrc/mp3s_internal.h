@@ -43,7 +43,7 @@ struct mp3s_ctx {
     hipStream_t stream = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr, ev_order = nullptr;
     hipEvent_t ev_sel = nullptr; bool sel_pending = false;   // a selection on a tail stream has read the variant buffers (enc_issue)
-    int32_t *d_sync = nullptr;        // {finished workgroups, error bits} of the pack kernel in flight: self-clearing;
+    int32_t *d_sync = nullptr;        // 64-bit word {finished workgroups | error bits} of the pack kernel in flight (k_sync.hpp): self-clearing;
                                       // [2] counts the samples the fast synthesis computed again in the exact order
     double synth_eps_scale = 1.0;     // int16 decode: scale of the fast synthesis guard (0 = always the exact kernel)
     void *scratch = nullptr; size_t scratch_bytes = 0;
@@ -101,6 +101,8 @@ struct mp3s_ctx {
 // Page-locked host memory for large results (decoded PCM): the device writes it at PCIe speed, no bounce buffer, no
 // page faults.  Pinning costs more than the copy it saves, so blocks are kept and reused: process-wide, because a
 // result may outlive the context that produced it.  (Blocks still cached at exit are left to the OS.)
+int local_world_size();   // mp3s_hostinfo.cpp: LOCAL_WORLD_SIZE of the launcher (1 without one)
+
 class PinnedBlock {
 public:
     PinnedBlock() = default;
@@ -146,7 +148,7 @@ private:
         auto &fl = free_list();
         size_t held = 0;
         for (auto &e : fl) held += e.second;
-        if (fl.size() < 48 && held + cap_ <= kMaxPinned) fl.emplace_back(p_, cap_);
+        if (fl.size() < 48 && held + cap_ <= pool_cap()) fl.emplace_back(p_, cap_);
         else hipHostFree(p_);
         p_ = nullptr; cap_ = 0;
     }
@@ -157,6 +159,13 @@ private:
         return *v;
     }
     static constexpr size_t kMaxPinned = (size_t)4 << 30;   // (a 100 000-frame file decodes to 460 MB of PCM: two such results and the MP3 results beside them stay pooled)
+    // what stays pooled between calls: the ranks of one host share its page-locked memory (memlock / cgroup limits), so eight ranks
+    // keep 1 GB each where a lone process keeps 4; a block that does not fit goes back to the system when it is released
+    static size_t pool_cap()
+    {
+        static const size_t cap = std::max<size_t>((size_t)1 << 30, kMaxPinned / (size_t)local_world_size());
+        return cap;
+    }
     uint8_t *p_ = nullptr;
     size_t cap_ = 0;
     bool pinned_ = true;

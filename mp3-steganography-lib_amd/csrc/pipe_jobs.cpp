@@ -157,7 +157,7 @@ bool prepare_walk(mp3s_pipe *P, Job &j, Slot &s)
             j.segs[i].any_silent = w.any_silent ? 1 : 0;
         }
         // the file's bytes: long files go up from where they lie, short ones are laid end to end in page-locked staging first
-        if (len >= P->direct_upload) {
+        if (len >= kDirectUpload) {
             if (run_hi > run_lo) { j.ups.push_back({run_lo, s.h_image + run_lo, run_hi - run_lo}); run_lo = run_hi = 0; }
             j.ups.push_back({img, file, len});
         } else {
@@ -448,7 +448,7 @@ int issue_front(mp3s_pipe *P, Job &j, Slot &s, size_t blob_len, int max_p23, boo
         if (e) return fail(MP3S_E_HIP, "parse launch: %s", hipGetErrorString((hipError_t)e));
     }
     const int e = launch_huffman(P->s_huff, d_blob, (const mp3s_frame_side *)d_side, n, nch, max_p23, (int16_t *)d_is, (mp3s_granule_si *)d_si,
-                                 d_small + 3, j.walked ? nullptr : c->d_sync + 4, &c->prof, false);
+                                 d_small + 3, j.walked ? nullptr : c->d_sync + 4, &c->prof, false, (int)c->opt[MP3S_OPT_HUF_LANES]);
     if (e) return fail(MP3S_E_HIP, "huffman launch: %s", hipGetErrorString((hipError_t)e));
     if (launch_place_frames(P->s_huff, s.d_stage + j.o_fix, j.n_fix, (int16_t *)d_is, (mp3s_granule_si *)d_si))
         return fail(MP3S_E_HIP, "placing the host-decoded frames failed");
@@ -529,7 +529,7 @@ int issue_back(mp3s_pipe *P, Job &j, Slot &s, bool inputs_later, bool defer_down
     dev.d_mp3 = s.d_mp3; dev.d_sc = (int32_t *)(s.d_enc + b_mdct + b_ix + b_out + b_en);
     dev.d_small = d_small; dev.direct_status = j.walked;
     if (!enc_variant_buffers(c, L, dev)) return fail(MP3S_E_NOMEM, "hipMalloc failed for %d variant entries", L.n_entries);
-    const int rc = enc_issue(c, L, dev, P->s_tail, s.e_rate, P->s_tail && P->last_tail >= 0 && P->tail_throttle ? P->slots[(size_t)P->last_tail].e_comp : nullptr,
+    const int rc = enc_issue(c, L, dev, P->s_tail, s.e_rate, nullptr,
                              P->s_dec ? P->e_enc[set] : nullptr);
     if (rc) return rc;
     if (trace_on()) fprintf(stderr, "mp3s:   encode side queued %.3f ms after the job's start\n", now_ms() - t_issue0);
@@ -681,14 +681,20 @@ void worker(mp3s_pipe *P, int me)
         const double t1 = now_ms(), c1 = thread_cpu_ms();
         if (trace_on()) fprintf(stderr, "mp3s: pipe job %lld slot %d on cpu %d: %s + layout %.3f ms (cpu %.3f)%s\n", (long long)j->ticket, j->slot, sched_getcpu(), j->walked ? "walk" : "scan", t1 - t0, c1 - c0, fast ? "" : " -> synchronous path");
         Job::State st;
+        bool cancelled = false;
         {
             // Jobs go to the device in the order they were submitted: the streams are queues and results are collected in
             // ticket order, so a job that overtakes the one in front of it makes that one's collector wait a whole job longer
             // (two workers on four slots: 1.36 instead of 0.82 ms per batch).  Walks and scans still run side by side.
+            // (a pipe that is being destroyed drops its queued jobs: the ticket in front of this one may never be issued)
             std::unique_lock<std::mutex> g(P->mu);
-            P->cv_turn.wait(g, [&] { return P->next_issue == j->ticket; });
+            P->cv_turn.wait(g, [&] { return P->stop || P->next_issue == j->ticket; });
+            cancelled = P->stop;
         }
-        {
+        if (cancelled) {
+            j->slow_rc = MP3S_E_BUSY; j->slow_err = "the pipe was destroyed with this job in flight";
+            st = Job::SLOW_DONE;
+        } else {
             std::lock_guard<std::mutex> gi(P->mu_issue);
             if (fast && issue_fast(P, *j, s, blob_len, max_p23) != MP3S_OK) {
                 sync_all(P);
@@ -738,7 +744,7 @@ int pipe_create(mp3s_ctx *c, int depth, size_t max_job_bytes, int scan_threads, 
         return fail(code, "%s", what);
     };
     // copy-up, copy-down and front-end streams that run beside this context's compute stream (pick_lanes above)
-    if (pick_lanes(c, &P->s_up, &P->s_down, &P->s_huff, &P->s_comp, &P->s_tail, (int)c->opt[MP3S_OPT_PIPE_TAIL], &P->s_dec, getenv("MP3S_PIPE_DEC") ? atoi(getenv("MP3S_PIPE_DEC")) : 0, &P->s_img))   // (a stream of their own for the decode transforms: +4 % on a resident batch
+    if (pick_lanes(c, &P->s_up, &P->s_down, &P->s_huff, &P->s_comp, &P->s_tail, (int)c->opt[MP3S_OPT_PIPE_TAIL], &P->s_dec, 0, &P->s_img))   // (a stream of their own for the decode transforms: +4 % on a resident batch
                                                                                    // fed through four contexts (bench.py --decode-stream on), nothing in this pipe: off)
         return destroy(MP3S_E_HIP, "stream creation failed");
     if (hipEventCreateWithFlags(&P->e_dec[0], hipEventDisableTiming) != hipSuccess ||
@@ -750,11 +756,9 @@ int pipe_create(mp3s_ctx *c, int depth, size_t max_job_bytes, int scan_threads, 
     // worth 5 % on a resident batch fed through three contexts (bench.py, region (i)); in this pipe round 2 measured it slower
     // at every priority -- that was the lanes sharing queues, not the arrangement: with a tail stream the rehearsal vouches for
     // a batch takes 0.79 instead of 0.82 ms (tools/pipe_tail_probe.py).  MP3S_OPT_PIPE_TAIL: 0 off, 1 on, 2 if the rehearsal gains.
-    P->tail_throttle = getenv("MP3S_PIPE_TAIL_THROTTLE") != nullptr;
-    if (const char *du = getenv("MP3S_PIPE_DIRECT_UPLOAD")) P->direct_upload = (size_t)atoll(du);
     // the page-locked staging of the slots is allocated by a thread that runs on the GPU's NUMA node (first touch), and the
     // workers that fill it stay there
-    P->node_cpus = gpu_node_cpus(c->device);
+    if (c->opt[MP3S_OPT_NUMA]) P->node_cpus = gpu_node_cpus(c->device);
     cpu_set_t before;
     const bool rebind = !P->node_cpus.empty() && sched_getaffinity(0, sizeof before, &before) == 0;
     if (rebind) bind_to(P->node_cpus);
@@ -785,7 +789,7 @@ int pipe_create(mp3s_ctx *c, int depth, size_t max_job_bytes, int scan_threads, 
             // the collecting thread sleeps on this one instead of spinning: with one process per GPU on a shared host the
             // cores are needed by the scan workers (the wake-up latency disappears behind the jobs in flight); the
             // context's own pipe has no job behind the one it waits for and spins
-            hipEventCreateWithFlags(&s.e_down, internal || getenv("MP3S_PIPE_SPIN") ? hipEventDefault : hipEventBlockingSync) != hipSuccess) {
+            hipEventCreateWithFlags(&s.e_down, internal ? hipEventDefault : hipEventBlockingSync) != hipSuccess) {
             ok = false;
             break;
         }
@@ -843,6 +847,7 @@ void mp3s_pipe_destroy(mp3s_pipe *P)
         for (auto &q : P->todo) q.clear();
     }
     P->cv_work.notify_all();
+    P->cv_turn.notify_all();      // (a worker that waits for its turn behind a dropped ticket)
     for (auto &t : P->workers) t.join();
     {
         std::lock_guard<std::mutex> g(P->up.mu);

@@ -73,8 +73,7 @@ int pick_lanes(mp3s_ctx *c, hipStream_t *up, hipStream_t *down, hipStream_t *huf
     if (!lp.ok) {
         int prio_low = 0, prio_high = 0;
         (void)hipDeviceGetStreamPriorityRange(&prio_low, &prio_high);
-        const char *hp = getenv("MP3S_PIPE_HUFF_PRIO");
-        const int huff_prio = hp ? atoi(hp) : prio_low;
+        const int huff_prio = prio_low;
         bool ok = hipEventCreate(&lp.t0) == hipSuccess && hipEventCreate(&lp.t1) == hipSuccess && hipMalloc((void **)&lp.d_buf, 4 * kRehearseBytes) == hipSuccess &&
                   hipHostMalloc((void **)&lp.h_buf, 8 * kRehearseBytes, hipHostMallocDefault) == hipSuccess;
         for (int k = 0; k < 4 && ok; k++)

@@ -127,10 +127,15 @@ static int run_file_impl(mp3s_ctx *c, const uint8_t *mp3, size_t len, int mode, 
     int rate = 0, kbps = 0, nch = 0;
     const size_t esz = pcm_elem(out_format);
     size_t res_cap = 0;
+    // EVERY way out of the call after the first chunk has been queued goes through here (another path takes the file, or a hard
+    // error such as MP3S_E_HIP): nothing of this call may still be in flight when its result block, its jobs and the slots are
+    // let go -- a queued download would otherwise write into page-locked memory the pool hands to the next call
     auto fallback = [&](const char *why, int code = kRunFallback) {
-        if (trace_on()) fprintf(stderr, "mp3s: run_file: %s -> %s\n", why, code == kRunWhole ? "once more, in one piece" : "synchronous path");
+        if (trace_on()) fprintf(stderr, "mp3s: run_file: %s -> %s\n", why, code == kRunWhole ? "once more, in one piece" : code == kRunFallback ? "synchronous path" : "error");
         if (code == kRunFallback) c->run_stats.fallbacks++;
         sync_all(P);
+        if (P->s_img) (void)hipStreamSynchronize(P->s_img);
+        (void)hipGetLastError();
         for (auto &s : P->slots) s.busy = false;
         P->keep_slot[0] = P->keep_slot[1] = -1;
         return code;
@@ -207,6 +212,10 @@ static int run_file_impl(mp3s_ctx *c, const uint8_t *mp3, size_t len, int mode, 
         if (!prepare_chunk(P, j, s, wv.max_p23)) return kRunFallback;
         const double t_i = trace_on() ? now_ms() : 0;
         if (issue_front(P, j, s, 0, wv.max_p23, true)) return kRunFallback;
+        if (c->opt[MP3S_OPT_FAIL_CHUNK] == (int64_t)k + 1) {      // (test aid: a hard error with this chunk's front end and the chunks in front of it in flight)
+            c->opt[MP3S_OPT_FAIL_CHUNK] = 0;
+            return fail(MP3S_E_HIP, "chunk %zu: failure injected by MP3S_OPT_FAIL_CHUNK", k);
+        }
         // (the results of the chunk in front come down behind this chunk's inputs, not in front of them)
         if (k > 0 && chunks[k - 1].job && issue_down(P, *chunks[k - 1].job, P->slots[(size_t)chunks[k - 1].job->slot])) return kRunFallback;
         if (!prepare_chunk_encode(P, j, s)) { sync_all(P); return kRunFallback; }
@@ -254,7 +263,7 @@ static int run_file_impl(mp3s_ctx *c, const uint8_t *mp3, size_t len, int mode, 
         const double t_walk1 = trace_on() ? now_ms() : 0;
         if (k >= (size_t)P->depth) {               // the slot's previous chunk first
             const int r = retire(k - (size_t)P->depth);
-            if (r) return r == kRunFallback || r == kRunWhole ? fallback("a chunk needs another path", r) : r;
+            if (r) return fallback("a chunk needs another path", r);
         }
         const double t_ret = trace_on() ? now_ms() : 0;
         chunks.emplace_back();
@@ -265,7 +274,7 @@ static int run_file_impl(mp3s_ctx *c, const uint8_t *mp3, size_t len, int mode, 
         if (decode && 64 + (size_t)n_walked * 1152 * (size_t)nch * esz > res_cap) return fallback("more frames than the result block holds");
         const int r = issue(k, nullptr);
         if (trace_on()) fprintf(stderr, "mp3s: run_file chunk %zu (%ld frames): walk %.3f ms, wait for the slot %.3f ms, prepare + issue %.3f ms\n", k, got, t_walk1 - t_walk0, t_ret - t_walk1, now_ms() - t_ret);
-        if (r) return r == kRunFallback ? fallback("a chunk does not fit the stages") : r;
+        if (r) return fallback("a chunk does not fit the stages", r);
         want = chunk;
     }
     if (trace_on()) fprintf(stderr, "mp3s: run_file: all chunks queued %.3f ms after the call's start\n", now_ms() - t_call0);
@@ -275,7 +284,7 @@ static int run_file_impl(mp3s_ctx *c, const uint8_t *mp3, size_t len, int mode, 
     // again takes a slot, and with it the buffers of the chunk that had it last)
     for (size_t k = 0; k < chunks.size(); k++) {
         const int r = retire(k);
-        if (r) return r == kRunFallback || r == kRunWhole ? fallback("a chunk needs another path", r) : r;
+        if (r) return fallback("a chunk needs another path", r);
     }
     mp3s_carry real = {};
     for (size_t k = 0; k < chunks.size(); k++) {
@@ -293,7 +302,7 @@ static int run_file_impl(mp3s_ctx *c, const uint8_t *mp3, size_t len, int mode, 
                 rc.done = false;
                 r = issue(k, &real);
                 if (!r) r = retire(k);
-                if (r) return r == kRunFallback || r == kRunWhole ? fallback("a chunk needs another path", r) : r;
+                if (r) return fallback("a chunk needs another path", r);
                 sync_all(P);
             } else {
                 // nothing in the chunk looked at the carry: every chain entry it hands on is its own; only the count of tables

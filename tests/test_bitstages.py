@@ -168,7 +168,7 @@ def test_two_contexts_ordered_by_ctx_wait(ctx, mlib, orc, golden_dir):
 
 @pytest.mark.gpu
 def test_device_huffman_every_launch_shape(ctx, mlib, golden_dir):
-    """k_dec_huffman as 8 waves x 8 lanes, 4 x 16, 4 x 32, 2 x 64 and 4 x 64 (MP3S_HUF_LANES: the launcher picks by the number of
+    """k_dec_huffman as 8 waves x 8 lanes, 4 x 16, 4 x 32, 2 x 64 and 4 x 64 (MP3S_OPT_HUF_LANES: the launcher picks by the number of
     frames and the LDS the staging needs): the lanes of a wave walk their pairs in step and leave them through a tile in LDS, so
     every shape has its own indexing -- same samples and side records as the host parser on streams of every kind, with staging
     sized for the stream and for the format's limit (decoder/Frame.py:365-559)."""
@@ -178,7 +178,7 @@ def test_device_huffman_every_launch_shape(ctx, mlib, golden_dir):
     streams = [g[k].tobytes() for k in g.files if k.endswith("__mp3")][:6]
     streams.append(frame_synth.make_stream(31, 70, mode=3, block_types=(0, 1, 2, 3), use_reservoir=True))     # mono: every second row is zeros
     streams.append(frame_synth.make_stream(32, 90, bitrate_idx=14, block_types=(0, 2), use_reservoir=True))   # 320 kbit/s: long granules
-    old = os.environ.get("MP3S_HUF_LANES")
+    old = ctx.get_option("huf_lanes")
     try:
         for data in streams:
             p = mlib.parse_stream(data)
@@ -191,7 +191,7 @@ def test_device_huffman_every_launch_shape(ctx, mlib, golden_dir):
             first_si = None
             for lanes in ("32", "8", "16", "62", "64"):
                 for bound in (s["max_part2_3_length"], 0):
-                    os.environ["MP3S_HUF_LANES"] = lanes
+                    ctx.set_option("huf_lanes", int(lanes))
                     ctx.upload(d_is, np.full(n * 2304, 0x5a5a, dtype=np.int16))
                     mlib.check(L.mp3s_huffman_decode_dev(ctx.handle, d_blob, d_side, n, nch, bound, d_is, d_si, d_st))
                     assert int(ctx.download(d_st, np.int32, (1,))[0]) == 0
@@ -208,7 +208,4 @@ def test_device_huffman_every_launch_shape(ctx, mlib, golden_dir):
             for q in (d_blob, d_side, d_is, d_si, d_st):
                 ctx.free(q)
     finally:
-        if old is None:
-            os.environ.pop("MP3S_HUF_LANES", None)
-        else:
-            os.environ["MP3S_HUF_LANES"] = old
+        ctx.set_option("huf_lanes", old)

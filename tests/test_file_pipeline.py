@@ -151,24 +151,45 @@ def test_long_file_automatic_chunks_and_the_facade(ctx, mlib, tmp_path):
 
 def test_file_from_the_helper_thread_or_chunk_by_chunk(ctx, mlib, golden_dir):
     """the whole file uploaded in pieces by the context's helper thread (the default) or every chunk's piece by the calling
-    thread (MP3S_NO_FILE_UP=1: the path of files above 1 GB): same bytes, on files of one chunk and of several, cut files, and
+    thread (MP3S_OPT_FILE_UP = 0: the path of files above 1 GB): same bytes, on files of one chunk and of several, cut files, and
     a decode; steganography.py:137-162"""
     from synth_pcm import synth_pcm
     mp3 = bytes(ctx.encode_pcm(synth_pcm(5000, seed=71), 44100, 128, None)["mp3"])
     small = open(os.path.join(golden_dir, "test.mp3"), "rb").read()
-    old = os.environ.get("MP3S_NO_FILE_UP")
-    try:
-        for data in (mp3, mp3[:-777], small, small[:-5]):
-            for chunk in (0, 700):
-                with options(ctx, chunk_frames=chunk):
-                    os.environ.pop("MP3S_NO_FILE_UP", None)
+    for data in (mp3, mp3[:-777], small, small[:-5]):
+        for chunk in (0, 700):
+            with options(ctx, chunk_frames=chunk):
+                with options(ctx, file_up=1):
                     a, ca, wa = ctx.hide_message(data, "helper thread"), ctx.clear_file(data), ctx.decode_file(data)
-                    os.environ["MP3S_NO_FILE_UP"] = "1"
+                with options(ctx, file_up=0):
                     b, cb, wb = ctx.hide_message(data, "helper thread"), ctx.clear_file(data), ctx.decode_file(data)
-                assert same_file(a, b) and same_file(ca, cb) and bytes(wa["data"]) == bytes(wb["data"]), (len(data), chunk)
-                assert same_file(a, legacy(ctx, ctx.hide_message, data, "helper thread"))
-    finally:
-        if old is None:
-            os.environ.pop("MP3S_NO_FILE_UP", None)
-        else:
-            os.environ["MP3S_NO_FILE_UP"] = old
+            assert same_file(a, b) and same_file(ca, cb) and bytes(wa["data"]) == bytes(wb["data"]), (len(data), chunk)
+            assert same_file(a, legacy(ctx, ctx.hide_message, data, "helper thread"))
+
+
+@pytest.mark.gpu
+def test_a_failing_chunk_leaves_the_context_usable(ctx, mlib):
+    """a hard error in the middle of a one-file call (MP3S_OPT_FAIL_CHUNK: chunk k fails with MP3S_E_HIP while its front end and
+    the chunks in front of it are in flight) must leave nothing queued and no slot taken: the error comes back, and the next
+    calls on the same context -- hide, clear, decode, in chunks -- give the bytes they always give (run_file's one cleanup
+    path; steganography.py:137-162)"""
+    from synth_pcm import synth_pcm
+    mp3 = bytes(ctx.encode_pcm(synth_pcm(3000, seed=72), 44100, 128, None)["mp3"])
+    ref = legacy(ctx, ctx.hide_message, mp3, "after the failure")
+    ref_clear = legacy(ctx, ctx.clear_file, mp3)
+    ref_wav = bytes(legacy(ctx, ctx.decode_file, mp3)["data"])
+    with options(ctx, chunk_frames=500):
+        for k in (1, 2, 4, 6):
+            for call in (lambda: ctx.hide_message(mp3, "after the failure"), lambda: ctx.decode_file(mp3)):
+                s0 = ctx.run_stats()
+                ctx.set_option("fail_chunk", k)
+                with pytest.raises(mlib.Mp3sError) as e:
+                    call()
+                assert e.value.code == mlib.E_HIP and "MP3S_OPT_FAIL_CHUNK" in str(e.value)
+                assert ctx.get_option("fail_chunk") == 0                  # it fires once
+                s1 = ctx.run_stats()
+                assert s1["files"] == s0["files"] and s1["fallbacks"] == s0["fallbacks"]
+                assert same_file(ctx.hide_message(mp3, "after the failure"), ref)
+                assert same_file(ctx.clear_file(mp3), ref_clear)
+                assert bytes(ctx.decode_file(mp3)["data"]) == ref_wav
+                assert ctx.run_stats()["files"] == s1["files"] + 3
