@@ -367,7 +367,8 @@ typedef struct {
     uint8_t nch, sr_idx, ms_stereo, flags;
     uint8_t scfsi[2][4];
     mp3s_unit_side unit[2][2]; /* [gr][ch] */
-    uint32_t reserved;         /* index (in the batch) of the first frame of this frame's stream; the scan writes 0 */
+    int32_t reserved;          /* index (in the batch) of the first frame of this frame's stream; the scan writes 0.  Negative when the
+                                * side array holds records of the stream in FRONT of the batch (mp3s_stream_ref.side_back) */
 } mp3s_frame_side; /* 104 bytes */
 
 /* replaces: __unpack_scale_fac + __unpack_samples for every granule*channel of the batch -- reference
@@ -376,9 +377,10 @@ typedef struct {
  * bytes; is / si as consumed by mp3s_decode_transform_dev; status: int32, OR of MP3S_HS_* on malformed input.
  * Streams whose scalefactors are inherited across frames (mixed blocks, scfsi behind a short granule 0: SURVEY D10;
  * mp3s_scan_stream reports them with gpu_ok = 0): the kernel walks back through the stream's side records to the granule
- * that wrote the entry last and reads it from that granule's bits, so the batch must hold such a stream from its first
- * frame on and frame_side.reserved must name that frame's index in the batch (0 for a single stream).  Blocks of such a
- * stream are parsed on the host. */
+ * that wrote the entry last and reads it from that granule's bits, so d_side / d_blob must hold such a stream from its first
+ * frame on and frame_side.reserved must name that frame's index relative to d_side[0] (0 for a single stream; negative for a
+ * chunk whose predecessors' records lie in front of d_side in one file-wide array: the one-file calls, round 4).  Blocks of
+ * such a stream that a rank decodes on its own are parsed on the host. */
 #define MP3S_HS_BAD_REGION 1
 #define MP3S_HS_BIG_VALUES 2
 #define MP3S_HS_HINT 4 /* some part2_3_length exceeds max_part2_3_length: call again with a larger bound (or 0) */
@@ -412,7 +414,11 @@ typedef struct {
     uint32_t first_frame;      /* its first frame in the batch (mp3s_frame_side.reserved, mp3s_frame_hdr.stream_first) */
     uint32_t n_frames;
     uint16_t prev_size[9];     /* what Frame.__prev_frame_size holds in front of first_frame's gather (SURVEY D11 at a stream's start) */
-    uint16_t reserved[3];
+    uint16_t side_back[2];     /* lo, hi: frames of this stream whose side records and main data lie in FRONT of d_side[first_frame] /
+                                * below d_blob's offsets of this batch -- a chunk of a file whose earlier chunks left theirs in one
+                                * file-wide array (round 4).  mp3s_frame_side.reserved becomes first_frame - side_back, and the
+                                * Huffman kernel's walk for scalefactors inherited across frames goes back that far */
+    uint16_t reserved;
 } mp3s_stream_ref; /* 40 bytes */
 typedef struct {
     int32_t regular;              /* 0: use mp3s_scan_stream for this stream (nothing else below is meaningful) */

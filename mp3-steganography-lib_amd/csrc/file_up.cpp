@@ -33,7 +33,7 @@ void file_up_thread(mp3s_pipe *P)
 }  // namespace
 
 // queue the upload of file[0, len): a first piece of first_bytes (the first chunk's), then kFilePiece at a time
-bool file_up_begin(mp3s_pipe *P, const uint8_t *file, size_t len, size_t first_bytes)
+bool file_up_begin(mp3s_pipe *P, const uint8_t *file, size_t len, size_t first_bytes, long n_est)
 {
     FileUp &u = P->up;
     u.active = false;
@@ -44,6 +44,20 @@ bool file_up_begin(mp3s_pipe *P, const uint8_t *file, size_t len, size_t first_b
         const size_t want = std::max<size_t>(len + len / 4 + 4096, (size_t)8 << 20);
         if (hipMalloc((void **)&u.d_file, want) != hipSuccess) { (void)hipGetLastError(); return false; }
         u.cap = want;
+    }
+    // the file-wide side records and main data (a frame's main data: at most its own bytes + 511 of reservoir; 8 zero bytes and
+    // up to 3 of alignment behind each)
+    const size_t want_frames = (size_t)n_est + 64, want_blob = len + (size_t)(n_est + 64) * 12 + 4096;
+    if (want_frames > u.side_cap || want_blob > u.blob_cap) {
+        if (u.d_side) (void)hipFree(u.d_side);
+        if (u.d_blob) (void)hipFree(u.d_blob);
+        u.d_side = nullptr; u.d_blob = nullptr; u.side_cap = u.blob_cap = 0;
+        const size_t nf = want_frames + want_frames / 4, nb = want_blob + want_blob / 4;
+        if (hipMalloc((void **)&u.d_side, nf * sizeof(mp3s_frame_side)) != hipSuccess || hipMalloc((void **)&u.d_blob, nb) != hipSuccess) {
+            (void)hipGetLastError();
+            if (u.d_side) (void)hipFree(u.d_side);
+            u.d_side = nullptr; u.d_blob = nullptr;
+        } else { u.side_cap = nf; u.blob_cap = nb; }
     }
     u.ends.clear();
     size_t at = std::min(len, std::max<size_t>(first_bytes, 4096));

@@ -280,7 +280,7 @@ __global__ __launch_bounds__(WAVES * 64) void k_dec_huffman(
     const int sl0 = kSlen[scalefac_compress & 15][0], sl1 = kSlen[scalefac_compress & 15][1];
     const bool short_win = block_type == 2 && window_switching;
     // ---- scalefactors (Frame.py:365-441)
-    const long stream_first = (long)fs.d[25];           // frame_side.reserved: first frame of this stream in the batch
+    const long stream_first = (long)(int32_t)fs.d[25];  // frame_side.reserved: first frame of this stream, relative to side[0] (negative: earlier chunks' records in front)
     if (gr == 1 && !short_win && scfsi) {
         // bands flagged by scfsi are copied from granule 0 (:423-437): decode them from granule 0's own bits, which the
         // lane two columns to the left (same frame, same wave) has staged

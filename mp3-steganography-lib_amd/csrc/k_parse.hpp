@@ -23,7 +23,7 @@ constexpr int PARSE_INHERITS = 1;   // some frame inherits scalefactors across f
 constexpr int PARSE_MISMATCH = 2;   // the gather came out another length than the walk said: the host's scan decides
 
 struct ParseFrameRef { uint32_t file_off, md_off; uint16_t md_len, frame_size, stream, flags; };
-struct ParseStreamRef { uint32_t base, end, first_frame, n_frames; uint16_t prev_size[9]; uint16_t reserved[3]; };
+struct ParseStreamRef { uint32_t base, end, first_frame, n_frames; uint16_t prev_size[9]; uint16_t side_back[2]; uint16_t reserved; };
 
 __global__ __launch_bounds__(PARSE_WAVES * 64) void k_dec_parse(
     const uint8_t *__restrict__ image, uint32_t image_base /* image[0] is byte `image_base` of what file_off / base / end count in */,
@@ -103,7 +103,7 @@ __global__ __launch_bounds__(PARSE_WAVES * 64) void k_dec_parse(
     if (lane == 0) {
         d[0] = ref.md_off - md_base; d[1] = ref.md_len;
         d[2] = nch | (sr_idx << 8) | (ms << 16) | ((uint32_t)(ref.flags & 0xff) << 24);
-        d[25] = s_first;
+        d[25] = s_first - ((uint32_t)st->side_back[0] | ((uint32_t)st->side_back[1] << 16));   // (int32: negative when records of the stream lie in front of side[0])
         uint32_t *hd = reinterpret_cast<uint32_t *>(hdr + f);
         hd[0] = sr_idx | (nch << 8) | (ms << 16);
         hd[1] = s_first;

@@ -68,6 +68,7 @@ struct Job {
     int set = 0;                         // which of the two sets of Huffman outputs / PCM buffers the job has
     bool down_pending = false;           // the copies of its results are not queued yet (issue_down)
     uint32_t image_base = 0, md_base = 0;
+    bool file_wide = false;              // side records and main data go to the file-wide arrays of FileUp (a chunk of a one-file call)
     const uint8_t *d_file = nullptr; size_t file_need = 0;   // the whole file on the device (FileUp) instead of a piece in the slot's d_image: bytes [0, file_need) are read
     std::vector<uint32_t> stream_first;  // first frame of every stream of the batch
     std::vector<std::vector<uint8_t>> bits, guess;
@@ -114,6 +115,10 @@ struct FileUp {
     std::atomic<long> recorded{0};       // pieces whose copy and event are queued
     std::atomic<int> err{0};
     uint8_t *d_file = nullptr; size_t cap = 0;
+    // ... and what the chunks' parse kernels make of it, file-wide: side records (frame index) and gathered main data (md_off from the
+    // file's start), so that a granule of chunk k that inherits scalefactors from a frame of chunk k - 3 finds them
+    mp3s_frame_side *d_side = nullptr; size_t side_cap = 0 /* frames */;
+    uint8_t *d_blob = nullptr; size_t blob_cap = 0;
     bool active = false;                 // the call in progress reads its file from d_file
 };
 
@@ -186,6 +191,6 @@ void forget_lanes(mp3s_ctx *c);
 // ---- file_up.cpp
 constexpr size_t kFileOnDevice = (size_t)1 << 30;       // longer files: chunk by chunk through the slots' own image buffers
 constexpr size_t kFilePiece = (size_t)4 << 20;
-bool file_up_begin(mp3s_pipe *P, const uint8_t *file, size_t len, size_t first_bytes);
+bool file_up_begin(mp3s_pipe *P, const uint8_t *file, size_t len, size_t first_bytes, long n_est);
 int file_up_wait(mp3s_pipe *P, size_t need, hipStream_t stream);
 void file_up_end(mp3s_pipe *P);

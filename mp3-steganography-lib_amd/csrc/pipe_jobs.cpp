@@ -215,10 +215,13 @@ bool prepare_chunk(mp3s_pipe *P, Job &j, Slot &s, int max_p23)
     j.n_total = (int)k.n_win; j.nch = k.nch; j.rate = k.rate; j.kbps = k.kbps;
     const bool on_device = P->up.active;
     if ((size_t)k.n_win > s.side_cap || (!on_device && k.image_hi - k.image_lo + 64 > s.image_cap)) return false;
-    j.image_base = on_device ? 0 : k.image_lo; j.md_base = k.refs[k.w0].md_off;
-    j.d_file = on_device ? P->up.d_file : nullptr; j.file_need = k.image_hi;
     const FrameRef &lastr = k.refs[k.w0 + k.n_win - 1];
-    if ((size_t)lastr.md_off - j.md_base + lastr.md_len + 64 > s.blob_cap) return false;
+    // the whole file is on the device: the chunk's side records and main data go where the file's frames have their places (FileUp),
+    // and what a granule inherits from a frame of an earlier chunk is there for the Huffman kernel's walk back
+    j.file_wide = on_device && P->up.d_side && (size_t)(k.w0 + k.n_win) <= P->up.side_cap && (size_t)lastr.md_off + lastr.md_len + 64 <= P->up.blob_cap;
+    j.image_base = on_device ? 0 : k.image_lo; j.md_base = j.file_wide ? 0 : k.refs[k.w0].md_off;
+    j.d_file = on_device ? P->up.d_file : nullptr; j.file_need = k.image_hi;
+    if (!j.file_wide && (size_t)lastr.md_off - j.md_base + lastr.md_len + 64 > s.blob_cap) return false;
     if (!on_device) j.ups.push_back({0, k.file + k.image_lo, (size_t)(k.image_hi - k.image_lo)});
     j.L = EncLayout();
     // packed [small results | host-decoded frame | refs | stream | encoder inputs]: what the front end reads comes first and goes
@@ -244,6 +247,7 @@ bool prepare_chunk(mp3s_pipe *P, Job &j, Slot &s, int max_p23)
     StreamRef *sr = reinterpret_cast<StreamRef *>(s.h_stage + j.o_streams);
     std::memset(sr, 0, sizeof *sr);
     sr->base = 0; sr->end = (uint32_t)k.file_len; sr->first_frame = 0; sr->n_frames = (uint32_t)k.n_win;
+    if (j.file_wide) { sr->side_back[0] = (uint16_t)((uint32_t)k.w0 & 0xffffu); sr->side_back[1] = (uint16_t)((uint32_t)k.w0 >> 16); }
     FrameWalker::history(k.refs, k.w0, sr->prev_size);
     j.o_encblk = (j.o_streams + sizeof(StreamRef) + 15) & ~(size_t)15;
     j.front_end = j.pack_end = j.o_encblk;
@@ -422,6 +426,7 @@ int issue_front(mp3s_pipe *P, Job &j, Slot &s, size_t blob_len, int max_p23, boo
          *d_keep = c->grab(set ? 26 : 7, (size_t)n * frame_elems * esz);
     if (!d_is || !d_si || !d_keep) return fail(MP3S_E_NOMEM, "hipMalloc failed for a %d-frame job", n);
     uint8_t *d_blob = s.d_stage, *d_side = s.d_stage + s.o_side;
+    if (j.file_wide) { d_blob = P->up.d_blob; d_side = reinterpret_cast<uint8_t *>(P->up.d_side + ck.w0); }
     HIPCHK(hipEventRecord(s.e_start, P->s_up));
     if (j.walked) {
         for (const Upload &u : j.ups) HIPCHK(hipMemcpyAsync(s.d_image + u.dst, u.src, u.bytes, hipMemcpyHostToDevice, P->s_up));
@@ -860,6 +865,8 @@ void mp3s_pipe_destroy(mp3s_pipe *P)
     if (P->s_img) (void)hipStreamSynchronize(P->s_img);
     for (hipEvent_t e : P->up.ev) (void)hipEventDestroy(e);
     if (P->up.d_file) (void)hipFree(P->up.d_file);
+    if (P->up.d_side) (void)hipFree(P->up.d_side);
+    if (P->up.d_blob) (void)hipFree(P->up.d_blob);
     if (P->s_ctx) { P->c->stream = P->s_ctx; P->s_ctx = nullptr; }
     for (auto &j : P->inflight) { if (j->slow_owner) mp3s_buf_free(j->slow_owner); if (j->blk_owner) mp3s_buf_free(j->blk_owner); }
     for (auto &s : P->slots) free_slot(s);

@@ -112,7 +112,7 @@ static int run_file_impl(mp3s_ctx *c, const uint8_t *mp3, size_t len, int mode, 
     } swap(c, P->s_comp);
     // the file's bytes set off for the device now (the first chunk's first), the walk follows
     struct FileUpGuard { mp3s_pipe *P; ~FileUpGuard() { file_up_end(P); } } up_guard{P};
-    file_up_begin(P, mp3, len, (size_t)w.offset + (size_t)std::min<long>(first_chunk, n_est) * (size_t)(fs0 + 1) + 2048);
+    file_up_begin(P, mp3, len, (size_t)w.offset + (size_t)std::min<long>(first_chunk, n_est) * (size_t)(fs0 + 1) + 2048, n_est);
     // ---- the stream's frame table, grown as the walk proceeds
     std::vector<FrameRef> &refs = c->h_refs;
     if ((long)refs.size() < n_est + 64) refs.resize((size_t)n_est + 64);
@@ -164,7 +164,10 @@ static int run_file_impl(mp3s_ctx *c, const uint8_t *mp3, size_t len, int mode, 
         if (!ok && !resolved) return kRunFallback;
         if (resolved) c->run_stats.resolved++;
         const int32_t *small = (const int32_t *)j->res->big[2].data();
-        if (j->walked && (small[4] & kParseInherits) && chunks.size() + (wv.ended ? 0 : 1) > 1) return kRunWhole;   // scalefactors inherited across frames: the stream in one piece
+        // scalefactors inherited across frames: the Huffman kernel walks back to the granule that wrote them.  With the
+        // file's side records and main data in file-wide arrays it finds them across chunk boundaries (round 4); without them
+        // (a file above 1 GB, no memory) the stream goes through the stages once more, in one piece
+        if (j->walked && !j->file_wide && (small[4] & kParseInherits) && chunks.size() + (wv.ended ? 0 : 1) > 1) return kRunWhole;
         if (!decode) {
             EncSeg &sg = j->segs[0];
             if (resolved) {

@@ -107,11 +107,19 @@ def test_what_the_chunks_do_not_take_falls_back(ctx, mlib, golden_dir):
     data = open(os.path.join(golden_dir, "test.mp3"), "rb").read()
     tail = data + b"\x00" * 700                                                       # a bad header: the last frame is repeated (D12)
     with options(ctx, chunk_frames=16):
-        # scalefactors inherited across frames: the chunks give up, the file goes through the stages in one piece (not the host parser)
+        # scalefactors inherited across frames: the file goes through the chunks all the same (round 4: its side records and main
+        # data lie in file-wide arrays, the Huffman kernel's walk back crosses the chunk boundaries) ...
         s0 = ctx.run_stats()
         assert legacy(ctx, ctx.decode_stream, mixed, mlib.MP3S_PCM_F64)["pcm"].tobytes() == ctx.decode_stream(mixed, mlib.MP3S_PCM_F64)["pcm"].tobytes()
         s1 = ctx.run_stats()
-        assert s1["files"] - s0["files"] == 1 and s1["chunks"] - s0["chunks"] == 1 and s1["fallbacks"] == s0["fallbacks"], (s0, s1)
+        assert s1["files"] - s0["files"] == 1 and s1["chunks"] - s0["chunks"] == 4 and s1["fallbacks"] == s0["fallbacks"], (s0, s1)
+        # ... and without those arrays (each chunk's piece of the file uploaded by the caller, as for files above 1 GB) once more
+        # in one piece -- not through the host parser
+        with options(ctx, file_up=0):
+            s0 = ctx.run_stats()
+            assert legacy(ctx, ctx.decode_stream, mixed, mlib.MP3S_PCM_F64)["pcm"].tobytes() == ctx.decode_stream(mixed, mlib.MP3S_PCM_F64)["pcm"].tobytes()
+            s1 = ctx.run_stats()
+            assert s1["files"] - s0["files"] == 1 and s1["chunks"] - s0["chunks"] == 1 and s1["fallbacks"] == s0["fallbacks"], (s0, s1)
         joint = frame_synth.make_stream(10, 80, mode=1, mode_ext=2, block_types=(0, 2), allow_mixed=True)      # the same for a re-encode
         assert same_file(legacy(ctx, ctx.hide_message, joint, "mixed blocks"), ctx.hide_message(joint, "mixed blocks"))
         s0 = ctx.run_stats()
@@ -193,3 +201,40 @@ def test_a_failing_chunk_leaves_the_context_usable(ctx, mlib):
                 assert same_file(ctx.clear_file(mp3), ref_clear)
                 assert bytes(ctx.decode_file(mp3)["data"]) == ref_wav
                 assert ctx.run_stats()["files"] == s1["files"] + 3
+
+
+@pytest.mark.gpu
+def test_inherited_scalefactors_across_chunks(ctx, mlib, orc, golden_dir):
+    """streams whose granules read scalefactors written many frames earlier (mixed blocks, scfsi behind a short granule 0:
+    decoder/FrameSideInformation.py:11-37, decoder/Frame.py:392-405, 423-437) as chunks of 9 and 64 frames: the granule that wrote an
+    entry last may lie several chunks back.  float64 PCM = the oracle's (and the reference's, for the g7 streams), stego bits
+    and re-encodes = the one-piece call's; every file really went through several chunks"""
+    import frame_synth
+    g = np.load(os.path.join(golden_dir, "g7_decode_corpus.npz"))
+    names = sorted({k.split("__")[0] for k in g.files})
+    streams = [(n, g[n + "__mp3"].tobytes()) for n in names if g[n + "__si_mixed_block_flag"].any()]
+    assert streams
+    # long ones: short / long switches and mixed blocks, mono / joint stereo, the inherited entries up to dozens of frames back
+    for i in range(4):
+        streams.append(("synth%d" % i, frame_synth.make_stream(50 + i, 200 + 37 * i, block_types=(0, 1, 2, 3), allow_mixed=True, mode=(0, 1, 3, 0)[i],
+                                                              mode_ext=2 if i == 1 else 0, use_reservoir=i >= 2)))
+    for name, data in streams:
+        want = orc.decode(data)
+        whole_bits = legacy(ctx, ctx.decode_stream, data, mlib.MP3S_PCM_F64)["bits"]
+        n = want["n_frames"]
+        for chunk in (9, 64):
+            if n <= chunk:
+                continue
+            with options(ctx, chunk_frames=chunk):
+                s0 = ctx.run_stats()
+                got = ctx.decode_stream(data, mlib.MP3S_PCM_F64)
+                s1 = ctx.run_stats()
+                assert got["pcm"].tobytes() == want["pcm"].tobytes(), (name, chunk)
+                assert np.array_equal(got["bits"], whole_bits), (name, chunk)
+                assert s1["files"] - s0["files"] == 1 and s1["chunks"] - s0["chunks"] == -(-n // chunk) and s1["fallbacks"] == s0["fallbacks"], (name, chunk, s0, s1)
+                if want["channels"] == 2 and want["sampling_rate"] in (32000, 44100, 48000):
+                    try:
+                        ref = legacy(ctx, ctx.hide_message, data, "across the chunks")
+                    except mlib.Mp3sError:
+                        continue                                # (a bit rate the encoder does not take: refused by both paths)
+                    assert same_file(ctx.hide_message(data, "across the chunks"), ref), (name, chunk)

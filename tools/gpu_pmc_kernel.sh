@@ -11,5 +11,5 @@ run_pass () {
 EXTRA="$*"
 run_pass sq1 SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY
 run_pass sq2 SQ_INSTS_SMEM SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_SCA SQ_INSTS_SALU SQ_WAIT_INST_LDS SQ_INSTS_VMEM
-python3 tools/pmc_summary.py gpurun_out $TAG 2>/dev/null | grep -A18 "^$KER"
+python3 tools/pmc_summary.py gpurun_out $TAG 2>/dev/null | grep -A40 "^per wave"
 rm -rf gpurun_out/pmc_${TAG}_sq1 gpurun_out/pmc_${TAG}_sq2

@@ -32,3 +32,16 @@ json.dump(traffic, open(os.path.join(root, f"pmc_{tag}_traffic.json"), "w"), ind
 latest = {k: v["hbm_bytes_per_launch"] for k, v in traffic.items()}
 latest["frames"] = 10000
 json.dump(latest, open(os.path.join(root, "traffic_latest.json"), "w"), indent=1)
+
+# one line per kernel, per wave (the shape the kernels are tuned by)
+print("\nper wave:")
+for k, v in out.items():
+    w = v.get("SQ_WAVES", 0)
+    if not w or "SQ_INSTS_SALU" not in v:
+        continue
+    wc = max(v.get("SQ_WAVE_CYCLES", 0), 1)
+    print("%-20s waves %6d | VALU %6.0f SALU %5.0f SMEM %4.0f LDS %5.0f VMEM %4.0f | wave cycles %7.0f, waiting %2.0f%% (at a waitcnt %2.0f%%), "
+          "LDS conflict cycles / LDS instr %.2f | VALU per launch %.1f M" %
+          (k[:20], w, v["SQ_INSTS_VALU"] / w, v["SQ_INSTS_SALU"] / w, v["SQ_INSTS_SMEM"] / w, v["SQ_INSTS_LDS"] / w, v["SQ_INSTS_VMEM"] / w, wc / w,
+           100 * v.get("SQ_WAIT_ANY", 0) / wc, 100 * v.get("SQ_WAIT_INST_ANY", 0) / wc, v.get("SQ_LDS_BANK_CONFLICT", 0) / max(v["SQ_INSTS_LDS"], 1),
+           v["SQ_INSTS_VALU"] / 1e6))
