@@ -32,7 +32,9 @@ __device__ __forceinline__ int pack_wave_sum(int v, bool on) { return (int)wave_
 __global__ __launch_bounds__(256) void k_enc_pack(
     const int16_t *__restrict__ ix, const mp3s_gr_out *__restrict__ gr, const int32_t *__restrict__ en, int n_frames,
     int sri, int bri, int whole_slots, const uint32_t *__restrict__ frame_off, const uint8_t *__restrict__ padding,
-    uint8_t *__restrict__ mp3, int32_t *__restrict__ scfsi_out, int32_t *__restrict__ status, int32_t *__restrict__ sync)
+    uint8_t *__restrict__ mp3, int32_t *__restrict__ scfsi_out, int32_t *__restrict__ status, int32_t *__restrict__ sync,
+    int f_begin /* frames [f_begin, n_frames) of the batch: a one-file call packs its last chunk in two launches, the first half on its way
+                   down while the second is packed */)
 {
     __shared__ uint32_t fb3[3][PACK_DW];   // frame images, rotating: written / being copied out / being cleared
     __shared__ uint32_t hc[4][256];
@@ -49,7 +51,7 @@ __global__ __launch_bounds__(256) void k_enc_pack(
     if (threadIdx.x == 0) wg_err = 0;
     __syncthreads();
     int rot = 0;
-    for (int f = blockIdx.x; f < n_frames; f += gridDim.x) {
+    for (int f = f_begin + blockIdx.x; f < n_frames; f += gridDim.x) {
     // One barrier per frame.  This frame's image is fb3[rot]; the image of the frame before last -- every thread
     // finished copying it out before the previous barrier -- is cleared now and is ready after this frame's barrier.
     uint32_t *fb = fb3[rot];

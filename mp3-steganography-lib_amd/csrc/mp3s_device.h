@@ -114,6 +114,8 @@ int launch_scatter(hipStream_t stream, const int32_t *d_pairs, int n_pairs, cons
                    const mp3s_gr_out *d_outv, int16_t *d_ix, int32_t *d_en, mp3s_gr_out *d_out);
 int launch_pack(hipStream_t stream, const int16_t *d_ix, const mp3s_gr_out *d_gr, const int32_t *d_en, int n_frames, int sri,
                 int bri, int whole_slots, const uint32_t *d_frame_off, const uint8_t *d_padding, uint8_t *d_mp3,
-                int32_t *d_scfsi, int32_t *d_status, int32_t *d_sync /* one zeroed 64-bit word owned by the context (k_sync.hpp) */, Profiler *prof);
+                int32_t *d_scfsi, int32_t *d_status, int32_t *d_sync /* one zeroed 64-bit word owned by the context (k_sync.hpp) */, Profiler *prof,
+                int f_begin = 0, int f_end = -1 /* frames [f_begin, f_end) only (f_end < 0: to the end); with d_sync == null only:
+                                                   the arrival counter hands out ONE launch's bits */);
 
 }  // namespace mp3s

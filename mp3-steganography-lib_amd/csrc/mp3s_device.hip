@@ -340,14 +340,17 @@ int launch_copy(hipStream_t stream, const void *d_src, void *d_dst, size_t bytes
 
 int launch_pack(hipStream_t stream, const int16_t *d_ix, const mp3s_gr_out *d_gr, const int32_t *d_en, int n_frames, int sri,
                 int bri, int whole_slots, const uint32_t *d_frame_off, const uint8_t *d_padding, uint8_t *d_mp3,
-                int32_t *d_scfsi, int32_t *d_status, int32_t *d_sync, Profiler *prof)
+                int32_t *d_scfsi, int32_t *d_status, int32_t *d_sync, Profiler *prof, int f_begin, int f_end)
 {
     const int pp = prof ? prof->begin(stream, K_ENC_PACK) : -1;
+    if (f_end < 0 || f_end > n_frames) f_end = n_frames;
+    const int count = f_end - f_begin;
     // persistent: 8 groups per CU; a short batch in fewer groups of at least four frames each (the tables are staged per group)
-    const int groups = n_frames >= 8192 ? 2048 : (n_frames + 3) / 4;
-    hipLaunchKernelGGL(k_enc_pack, dim3(groups), dim3(256), 0, stream,
-                       d_ix, d_gr, d_en, n_frames, sri, bri, whole_slots,
-                       d_frame_off, d_padding, d_mp3, d_scfsi, d_status, d_sync);
+    const int groups = count >= 8192 ? 2048 : (count + 3) / 4;
+    if (count > 0)
+        hipLaunchKernelGGL(k_enc_pack, dim3(groups), dim3(256), 0, stream,
+                           d_ix, d_gr, d_en, f_end, sri, bri, whole_slots,
+                           d_frame_off, d_padding, d_mp3, d_scfsi, d_status, d_sync, f_begin);
     if (prof) prof->end(stream, pp);
     return (int)hipGetLastError();
 }

@@ -234,8 +234,14 @@ int enc_issue(mp3s_ctx *c, const EncLayout &L, const EncDev &d, hipStream_t tail
     }
     // packed on the assumption that the verdict is "nothing to redo" (the common case); the caller discards it otherwise
     if (!rc) {
-        const int e = launch_pack(ts, d.d_ix, d.d_out, d.d_en, L.n, L.sri, L.bri, L.whole, (const uint32_t *)(d.d_in + L.o_off), d.d_in + L.o_pad, d.d_mp3,
-                                  d.d_sc, d.d_small + 2, d.direct_status ? nullptr : c->d_sync, &c->prof);
+        const bool halves = d.direct_status && d.pack_half && d.pack_split > 0 && d.pack_split < L.n;
+        int e = launch_pack(ts, d.d_ix, d.d_out, d.d_en, L.n, L.sri, L.bri, L.whole, (const uint32_t *)(d.d_in + L.o_off), d.d_in + L.o_pad, d.d_mp3,
+                            d.d_sc, d.d_small + 2, d.direct_status ? nullptr : c->d_sync, &c->prof, 0, halves ? d.pack_split : -1);
+        if (!e && halves) {
+            if (hipEventRecord(d.pack_half, ts) != hipSuccess) e = (int)hipErrorUnknown;
+            else e = launch_pack(ts, d.d_ix, d.d_out, d.d_en, L.n, L.sri, L.bri, L.whole, (const uint32_t *)(d.d_in + L.o_off), d.d_in + L.o_pad, d.d_mp3,
+                                 d.d_sc, d.d_small + 2, nullptr, &c->prof, d.pack_split, -1);
+        }
         if (e) rc = fail(MP3S_E_HIP, "pack launch: %s", hipGetErrorString((hipError_t)e));
     }
     return rc;

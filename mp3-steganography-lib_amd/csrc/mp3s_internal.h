@@ -297,6 +297,9 @@ struct EncDev {
     uint8_t *d_mp3 = nullptr; int32_t *d_sc = nullptr;
     int32_t *d_small = nullptr;          // small_bytes(n_segs)
     bool direct_status = false;          // d_small's status words were zeroed with the job's inputs: the kernels OR into them directly
+    // the bit packer in two launches, frames [0, pack_split) and the rest, pack_half recorded between them (the last chunk of a
+    // one-file call: its first half comes down while the second is packed); 0: one launch
+    int pack_split = 0; hipEvent_t pack_half = nullptr;
     // results of the variant entries (L.n_entries of them; read by the selection right behind the rate loop)
     int16_t *d_ixv = nullptr; mp3s_gr_out *d_outv = nullptr; int32_t *d_env = nullptr;
 };

@@ -27,6 +27,7 @@ struct Slot {
     // that a job whose cursor guess failed is resolved on them at collect time while later jobs have long been issued
     uint8_t *d_enc = nullptr; size_t enc_cap = 0;
     hipEvent_t e_start = nullptr, e_up = nullptr, e_in = nullptr, e_huff = nullptr, e_rate = nullptr, e_comp = nullptr, e_down = nullptr;
+    hipEvent_t e_half = nullptr;         // the first of the bit packer's two launches is through (the last chunk of a one-file call)
     bool busy = false;
 };
 
@@ -66,8 +67,10 @@ struct Job {
     size_t o_small = 0, o_encblk = 0, o_fix = 0, o_refs = 0, o_streams = 0, pack_end = 0;   // packed inputs inside the slot's stage (from its start)
     size_t front_end = 0;                // a chunk of a one-file call: [o_small, front_end) is what the front end needs, the encoder's inputs lie behind
     int set = 0;                         // which of the two sets of Huffman outputs / PCM buffers the job has
+    size_t down_split = 0;               // bytes of the result the first of the packer's two launches wrote (0: one launch, one copy)
     bool down_pending = false;           // the copies of its results are not queued yet (issue_down)
     uint32_t image_base = 0, md_base = 0;
+    int grab_frames = 0;                 // the context's per-set buffers are asked for at this many frames at least (the chunks of one call: all alike)
     bool file_wide = false;              // side records and main data go to the file-wide arrays of FileUp (a chunk of a one-file call)
     const uint8_t *d_file = nullptr; size_t file_need = 0;   // the whole file on the device (FileUp) instead of a piece in the slot's d_image: bytes [0, file_need) are read
     std::vector<uint32_t> stream_first;  // first frame of every stream of the batch

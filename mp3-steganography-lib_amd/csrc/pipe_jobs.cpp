@@ -422,8 +422,9 @@ int issue_front(mp3s_pipe *P, Job &j, Slot &s, size_t blob_len, int max_p23, boo
     const int out_format = ck.on && j.decode ? ck.out_format : MP3S_PCM_I16;
     const size_t esz = pcm_elem(out_format), frame_elems = (size_t)1152 * nch;
     const int set = j.set = (int)(P->issued++ & 1u);
-    void *d_is = c->grab(set ? 24 : 0, (size_t)n * 2304 * 2), *d_si = c->grab(set ? 25 : 1, (size_t)n * 4 * sizeof(mp3s_granule_si)),
-         *d_keep = c->grab(set ? 26 : 7, (size_t)n * frame_elems * esz);
+    const size_t ng = (size_t)std::max(n, j.grab_frames);
+    void *d_is = c->grab(set ? 24 : 0, ng * 2304 * 2), *d_si = c->grab(set ? 25 : 1, ng * 4 * sizeof(mp3s_granule_si)),
+         *d_keep = c->grab(set ? 26 : 7, ng * frame_elems * esz);
     if (!d_is || !d_si || !d_keep) return fail(MP3S_E_NOMEM, "hipMalloc failed for a %d-frame job", n);
     uint8_t *d_blob = s.d_stage, *d_side = s.d_stage + s.o_side;
     if (j.file_wide) { d_blob = P->up.d_blob; d_side = reinterpret_cast<uint8_t *>(P->up.d_side + ck.w0); }
@@ -475,8 +476,9 @@ int issue_back(mp3s_pipe *P, Job &j, Slot &s, bool inputs_later, bool defer_down
     const int out_format = ck.on && j.decode ? ck.out_format : MP3S_PCM_I16;
     const size_t esz = pcm_elem(out_format), frame_elems = (size_t)1152 * nch;
     const int set = j.set;
-    void *d_is = c->grab(set ? 24 : 0, (size_t)n * 2304 * 2), *d_si = c->grab(set ? 25 : 1, (size_t)n * 4 * sizeof(mp3s_granule_si)),
-         *d_keep = c->grab(set ? 26 : 7, (size_t)n * frame_elems * esz);
+    const size_t ng = (size_t)std::max(n, j.grab_frames);
+    void *d_is = c->grab(set ? 24 : 0, ng * 2304 * 2), *d_si = c->grab(set ? 25 : 1, ng * 4 * sizeof(mp3s_granule_si)),
+         *d_keep = c->grab(set ? 26 : 7, ng * frame_elems * esz);
     if (!d_is || !d_si || !d_keep) return fail(MP3S_E_NOMEM, "hipMalloc failed for a %d-frame job", n);
     const mp3s_frame_hdr *d_dechdr = j.walked ? (const mp3s_frame_hdr *)(s.d_stage + s.o_dechdr) : (const mp3s_frame_hdr *)(s.d_stage + s.o_in);
     int32_t *const d_small = j.walked ? (int32_t *)(s.d_stage + j.o_small) : s.d_small;
@@ -533,6 +535,13 @@ int issue_back(mp3s_pipe *P, Job &j, Slot &s, bool inputs_later, bool defer_down
     dev.d_out = (mp3s_gr_out *)(s.d_enc + b_mdct + b_ix); dev.d_en = (int32_t *)(s.d_enc + b_mdct + b_ix + b_out); dev.d_agg = d_agg;
     dev.d_mp3 = s.d_mp3; dev.d_sc = (int32_t *)(s.d_enc + b_mdct + b_ix + b_out + b_en);
     dev.d_small = d_small; dev.direct_status = j.walked;
+    // the last chunk of a one-file call: nothing behind it hides its tail and its copy down, so the packer runs as two launches and
+    // the first half of the bytes comes down under the second (the frame offsets are the host's own: enc_fill wrote them)
+    dev.pack_split = 0; dev.pack_half = nullptr; j.down_split = 0;
+    if (ck.on && ck.last && j.walked && L.n >= 1024 && s.e_half && P->internal) {
+        dev.pack_split = L.n / 2; dev.pack_half = s.e_half;
+        j.down_split = reinterpret_cast<const uint32_t *>(s.h_stage + j.o_encblk + L.o_off)[dev.pack_split];
+    }
     if (!enc_variant_buffers(c, L, dev)) return fail(MP3S_E_NOMEM, "hipMalloc failed for %d variant entries", L.n_entries);
     const int rc = enc_issue(c, L, dev, P->s_tail, s.e_rate, nullptr,
                              P->s_dec ? P->e_enc[set] : nullptr);
@@ -556,9 +565,16 @@ int issue_down(mp3s_pipe *P, Job &j, Slot &s)
     const int out_format = ck.on && j.decode ? ck.out_format : MP3S_PCM_I16;
     const size_t esz = pcm_elem(out_format), frame_elems = (size_t)1152 * nch;
     int32_t *const d_small = j.walked ? (int32_t *)(s.d_stage + j.o_small) : s.d_small;
+    size_t done_bytes = 0;
+    if (!j.decode && j.down_split > 0) {      // the bytes of the packer's first launch: behind ITS event, not the job's last kernel
+        const size_t total = j.segs.back().mp3_off + j.segs.back().mp3_len;
+        done_bytes = std::min(j.down_split & ~(size_t)3, total);
+        HIPCHK(hipStreamWaitEvent(P->s_down, s.e_half, 0));
+        if (done_bytes) HIPCHK(hipMemcpyAsync((ck.on ? ck.dst : j.res->mp3), s.d_mp3, done_bytes, hipMemcpyDeviceToHost, P->s_down));
+    }
     HIPCHK(hipStreamWaitEvent(P->s_down, s.e_comp, 0));
     if (j.decode) {
-        void *d_keep = c->grab(j.set ? 26 : 7, (size_t)n * frame_elems * esz);
+        void *d_keep = c->grab(j.set ? 26 : 7, (size_t)std::max(n, j.grab_frames) * frame_elems * esz);
         if (!d_keep) return fail(MP3S_E_NOMEM, "hipMalloc failed for a %d-frame job", n);
         HIPCHK(hipMemcpyAsync(j.res->big[2].data(), d_small, kSmallHead, hipMemcpyDeviceToHost, P->s_down));
         if (j.walked) HIPCHK(hipMemcpyAsync(j.res->big[1].data(), s.d_stage + s.o_tsel, (size_t)n * 8, hipMemcpyDeviceToHost, P->s_down));
@@ -575,7 +591,8 @@ int issue_down(mp3s_pipe *P, Job &j, Slot &s)
     } else {
         const size_t total = j.segs.back().mp3_off + j.segs.back().mp3_len;
         HIPCHK(hipMemcpyAsync(j.res->big[2].data(), d_small, small_bytes(j.L.n_segs), hipMemcpyDeviceToHost, P->s_down));
-        if (total) HIPCHK(hipMemcpyAsync(ck.on ? ck.dst : j.res->mp3, s.d_mp3, total, hipMemcpyDeviceToHost, P->s_down));
+        uint8_t *dst = ck.on ? ck.dst : j.res->mp3;
+        if (total) HIPCHK(hipMemcpyAsync(dst + done_bytes, s.d_mp3 + done_bytes, total - done_bytes, hipMemcpyDeviceToHost, P->s_down));
     }
     HIPCHK(hipEventRecord(s.e_down, P->s_down));
     return MP3S_OK;
@@ -730,7 +747,7 @@ void free_slot(Slot &s)
     if (s.d_mp3) (void)hipFree(s.d_mp3);
     if (s.d_small) (void)hipFree(s.d_small);
     if (s.d_enc) (void)hipFree(s.d_enc);
-    for (hipEvent_t e : {s.e_start, s.e_up, s.e_in, s.e_huff, s.e_rate, s.e_comp, s.e_down}) if (e) (void)hipEventDestroy(e);
+    for (hipEvent_t e : {s.e_start, s.e_up, s.e_in, s.e_huff, s.e_rate, s.e_comp, s.e_down, s.e_half}) if (e) (void)hipEventDestroy(e);
     s = Slot();
 }
 
@@ -790,7 +807,7 @@ int pipe_create(mp3s_ctx *c, int depth, size_t max_job_bytes, int scan_threads, 
             hipMalloc((void **)&s.d_mp3, s.mp3_cap) != hipSuccess || hipMalloc((void **)&s.d_small, small_bytes(kMaxFastFiles)) != hipSuccess ||
             // (only e_start and e_down are read as times; the ordering events carry no time stamps: 1 % per job)
             hipEventCreate(&s.e_start) != hipSuccess || hipEventCreateWithFlags(&s.e_up, ord_flags) != hipSuccess || hipEventCreateWithFlags(&s.e_in, ord_flags) != hipSuccess ||
-            hipEventCreateWithFlags(&s.e_huff, ord_flags) != hipSuccess || hipEventCreateWithFlags(&s.e_comp, ord_flags) != hipSuccess || hipEventCreateWithFlags(&s.e_rate, ord_flags) != hipSuccess ||
+            hipEventCreateWithFlags(&s.e_huff, ord_flags) != hipSuccess || hipEventCreateWithFlags(&s.e_half, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&s.e_comp, ord_flags) != hipSuccess || hipEventCreateWithFlags(&s.e_rate, ord_flags) != hipSuccess ||
             // the collecting thread sleeps on this one instead of spinning: with one process per GPU on a shared host the
             // cores are needed by the scan workers (the wake-up latency disappears behind the jobs in flight); the
             // context's own pipe has no job behind the one it waits for and spins

@@ -185,12 +185,21 @@ static int run_file_impl(mp3s_ctx *c, const uint8_t *mp3, size_t len, int mode, 
         return MP3S_OK;
     };
     // issue frames [first, first + count) of the stream as a chunk on slot `slot`
-    auto issue = [&](size_t k, const mp3s_carry *carry) -> int {
+    // A chunk is queued in two steps.  issue_a: its front end (file piece, parse, Huffman -- a latency chain of 0.1 ms whatever the
+    // chunk's size).  issue_b: the results of the chunk in front, this chunk's encoder inputs (laid out here, 0.1 ms of host time
+    // for 8 000 frames) and everything behind the front end.  The main loop runs issue_a(k + 1) BEFORE issue_b(k) (round 4): the next
+    // chunk's front end is then on the device while this chunk's kernels still run -- queued behind issue_b(k) it started 0.1 ms
+    // later, ended behind the chunk's rate loop, and the compute stream sat idle for 0.05 ms between two chunks.
+    auto issue_a = [&](size_t k, const mp3s_carry *carry) -> int {
         RunChunk &rc = chunks[k];
         rc.job.reset(new Job());
         Job &j = *rc.job;
         j.slot = (int)(k % (size_t)P->depth);
         j.ticket = (int64_t)k;
+        // (the context's buffers the chunks take turns with -- Huffman outputs, PCM -- are asked for at the size of the call's largest
+        // chunk: a chunk that asked for more than the one before it in the same set would have the buffer replaced while that
+        // chunk's results still wait in it to be copied out, now that their copy is queued behind the next front end)
+        j.grab_frames = (int)cap_frames;
         Slot &s = P->slots[(size_t)j.slot];
         Chunk &ck = j.ck;
         ck.on = true; ck.decode = decode; ck.refs = refs.data(); ck.first = rc.first; ck.count = rc.count; ck.last = rc.last;
@@ -210,15 +219,19 @@ static int run_file_impl(mp3s_ctx *c, const uint8_t *mp3, size_t len, int mode, 
         ck.n_tables = (int)std::min<long>(wv.tables_frames, rc.count) * 4;
         ck.any_silent = wv.any_silent ? 1 : 0;   // (of the frames walked so far: at worst the re-run launches are issued without need)
         if (decode) ck.dst = res->big[0].data() + 64 + (size_t)rc.first * 1152 * (size_t)nch * esz;
-        // the front end first (parse and Huffman kernels are a latency chain of 0.1 ms whatever the chunk's size), the encoder's
-        // inputs are laid out while it runs
         if (!prepare_chunk(P, j, s, wv.max_p23)) return kRunFallback;
-        const double t_i = trace_on() ? now_ms() : 0;
         if (issue_front(P, j, s, 0, wv.max_p23, true)) return kRunFallback;
         if (c->opt[MP3S_OPT_FAIL_CHUNK] == (int64_t)k + 1) {      // (test aid: a hard error with this chunk's front end and the chunks in front of it in flight)
             c->opt[MP3S_OPT_FAIL_CHUNK] = 0;
             return fail(MP3S_E_HIP, "chunk %zu: failure injected by MP3S_OPT_FAIL_CHUNK", k);
         }
+        return MP3S_OK;
+    };
+    auto issue_b = [&](size_t k) -> int {
+        RunChunk &rc = chunks[k];
+        Job &j = *rc.job;
+        Slot &s = P->slots[(size_t)j.slot];
+        const double t_i = trace_on() ? now_ms() : 0;
         // (the results of the chunk in front come down behind this chunk's inputs, not in front of them)
         if (k > 0 && chunks[k - 1].job && issue_down(P, *chunks[k - 1].job, P->slots[(size_t)chunks[k - 1].job->slot])) return kRunFallback;
         if (!prepare_chunk_encode(P, j, s)) { sync_all(P); return kRunFallback; }
@@ -228,8 +241,12 @@ static int run_file_impl(mp3s_ctx *c, const uint8_t *mp3, size_t len, int mode, 
             j.ck.dst = res->big[0].data() + rc.out_off;
         }
         const int e = issue_back(P, j, s, true, true);
-        if (trace_on()) fprintf(stderr, "mp3s:   front + inputs + back %.3f ms\n", now_ms() - t_i);
+        if (trace_on()) fprintf(stderr, "mp3s:   inputs + back of chunk %zu %.3f ms\n", k, now_ms() - t_i);
         return e ? kRunFallback : MP3S_OK;
+    };
+    auto issue = [&](size_t k, const mp3s_carry *carry) -> int {
+        const int r = issue_a(k, carry);
+        return r ? r : issue_b(k);
     };
     // ---- walk and issue, chunk after chunk
     long want = first_chunk;
@@ -275,10 +292,15 @@ static int run_file_impl(mp3s_ctx *c, const uint8_t *mp3, size_t len, int mode, 
         rc.guess.cursor = MP3S_NO_CURSOR;          // "the message is hidden, nothing is inherited"
         n_walked += got;
         if (decode && 64 + (size_t)n_walked * 1152 * (size_t)nch * esz > res_cap) return fallback("more frames than the result block holds");
-        const int r = issue(k, nullptr);
+        int r = issue_a(k, nullptr);
+        if (!r && k > 0) r = issue_b(k - 1);
         if (trace_on()) fprintf(stderr, "mp3s: run_file chunk %zu (%ld frames): walk %.3f ms, wait for the slot %.3f ms, prepare + issue %.3f ms\n", k, got, t_walk1 - t_walk0, t_ret - t_walk1, now_ms() - t_ret);
         if (r) return fallback("a chunk does not fit the stages", r);
         want = chunk;
+    }
+    {
+        const int r = issue_b(chunks.size() - 1);
+        if (r) return fallback("a chunk does not fit the stages", r);
     }
     if (trace_on()) fprintf(stderr, "mp3s: run_file: all chunks queued %.3f ms after the call's start\n", now_ms() - t_call0);
     // ---- settle the chunks in order: the carries
