@@ -107,6 +107,9 @@ void mp3s_ctx_destroy(mp3s_ctx *ctx);
 const char *mp3s_last_error(void);
 const char *mp3s_version(void);
 int mp3s_device_name(mp3s_ctx *ctx, char *buf, size_t n);
+/* the device's PCI address as sysfs spells it ("0000:c5:00.0"): what a monitor thread that must not touch the GPU reads clocks and
+ * power by (/sys/bus/pci/devices/<address>/...; bench.py's `sustained` region) */
+int mp3s_device_pci(mp3s_ctx *ctx, char *buf, size_t n);
 int mp3s_sync(mp3s_ctx *ctx);
 /* Stream order between two contexts of one device: work submitted to ctx after this call starts only when everything
  * submitted to other before it has finished.  This is how a second context runs the bit-level front end of the next
@@ -147,7 +150,12 @@ int mp3s_ctx_wait(mp3s_ctx *ctx, mp3s_ctx *other);
  * mp3s_hide_message_chunked): files that went through the overlapped stages as chunks, their chunks, chunks that were run
  * again because they depended on a carry the guess got wrong, chunks whose chains the host resolved, and files that took
  * the stages one after the other instead (streams the frame walk does not take, mono re-encodes, ...) */
-typedef struct { int64_t files, chunks, reruns, resolved, fallbacks; } mp3s_run_stats;
+typedef struct {
+    int64_t files, chunks, reruns, resolved, fallbacks;
+    /* the context's own pipe (made by its first one-file call): what choosing its streams took (microseconds; part of that first
+     * call's time), the miniature jobs rehearsed, the choice and whether stages seem to share hardware queues -- mp3s_pipe_stats */
+    int64_t rehearsal_us, rehearsals, lanes, queue_shared;
+} mp3s_run_stats;
 int mp3s_ctx_run_stats(mp3s_ctx *ctx, mp3s_run_stats *out);
 int mp3s_ctx_set_option(mp3s_ctx *ctx, int option, int64_t value);
 int mp3s_ctx_get_option(mp3s_ctx *ctx, int option, int64_t *value);
@@ -688,6 +696,13 @@ typedef struct {
     double scan_cpu_ms;               /* CPU time of the scan threads inside scan_ms (less than scan_ms: the threads were not running) */
     int64_t resolved;                 /* collected jobs whose cursor / address guess failed and whose chains the host resolved on the job's
                                        * own device buffers (scan, decode and transforms kept); fast + resolved + slow = collected */
+    /* how the pipe's streams were chosen when it was made (the runtime maps streams onto a few hardware queues; a pipeline whose
+     * stages share queues loses its overlap): `rehearsals` miniature jobs of about 1 ms each, at most 12 and 15 ms in all (0: a
+     * pipe made earlier on this context's stream decided), judged against the same miniature on ONE stream */
+    double rehearsal_ms;
+    int64_t rehearsals;
+    int64_t lanes;                    /* rotation of the copy / front-end candidates | (compute candidate + 1) << 8 | (tail candidate + 1) << 16 */
+    int64_t queue_shared;             /* 1: no choice got the miniature through in 0.94 x the one-stream time (side by side: 0.86 - 0.89; on one queue: 1.1 - 1.4): stages share hardware queues */
 } mp3s_pipe_stats;
 /* depth: jobs in flight (= staging slots); max_job_bytes: MP3 bytes per job the staging is sized for (larger jobs still
  * work, through the synchronous path); scan_threads: host workers */

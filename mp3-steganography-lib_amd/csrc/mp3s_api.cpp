@@ -183,6 +183,7 @@ int mp3s_ctx_run_stats(mp3s_ctx *c, mp3s_run_stats *out)
 {
     if (!c || !out) return fail(MP3S_E_ARG, "null pointer");
     *out = c->run_stats;
+    own_pipe_lanes(c, out);
     return MP3S_OK;
 }
 
@@ -199,6 +200,14 @@ int mp3s_device_name(mp3s_ctx *c, char *buf, size_t n)
     hipDeviceProp_t p;
     HIPCHK(hipGetDeviceProperties(&p, c->device));
     snprintf(buf, n, "%s (%s, %d CUs)", p.name, p.gcnArchName, p.multiProcessorCount);
+    return MP3S_OK;
+}
+
+int mp3s_device_pci(mp3s_ctx *c, char *buf, size_t n)
+{
+    if (!c || !buf || n < 16) return fail(MP3S_E_ARG, "bad argument");
+    HIPCHK(hipDeviceGetPCIBusId(buf, (int)n, c->device));
+    for (char *p = buf; *p; p++) *p = (char)tolower(*p);
     return MP3S_OK;
 }
 

@@ -340,6 +340,7 @@ struct RunResult {
 // mode: kRunHide (utf8 / n_msg = the message) / kRunClear / kRunDecode (out_format).  MP3S_OK, kRunFallback, or an error.
 int run_file(mp3s_ctx *c, const uint8_t *mp3, size_t len, int mode, const uint8_t *utf8, size_t n_msg, int out_format, mp3s_buf **owner, RunResult *out);
 void destroy_own_pipe(mp3s_ctx *c);
+void own_pipe_lanes(const mp3s_ctx *c, mp3s_run_stats *out);
 
 // ---------------------------------------------------------------- what this process may use of the host (mp3s_hostinfo.cpp)
 // CPUs the process may run on: sched_getaffinity, cut down to the cgroup's CPU quota

@@ -132,6 +132,9 @@ struct WalkOut {                         // the walker's state behind a chunk of
     long tables_frames = 0;
 };
 
+// what choosing a pipe's streams took and found (mp3s_pipe_stats / mp3s_run_stats hand it out)
+struct LaneReport { double rehearsal_ms = 0; int64_t rehearsals = 0, lanes = 0, queue_shared = 0; float serial_ms = 0, best_ms = 0; };
+
 struct mp3s_pipe {
     mp3s_ctx *c = nullptr;
     int depth = 0;
@@ -172,6 +175,7 @@ struct mp3s_pipe {
     bool stop = false;
     int64_t next_ticket = 0;
     mp3s_pipe_stats st = {};
+    LaneReport lanes;                    // how its streams were chosen
 };
 
 // ---- pipe_jobs.cpp
@@ -189,7 +193,7 @@ int pipe_create(mp3s_ctx *c, int depth, size_t max_job_bytes, int scan_threads, 
 int pick_lanes(mp3s_ctx *c, hipStream_t *up, hipStream_t *down, hipStream_t *huff, hipStream_t *comp /* a stream to compute on instead of the context's, or null */,
                hipStream_t *tail /* a stream for the tail of a job, or null */, int want_tail /* 0: none, 1: always, 2: if the rehearsal is faster with it */,
                hipStream_t *dec = nullptr /* a stream for the decode transforms, or null */, int want_dec = 1,
-               hipStream_t *img = nullptr /* a second copy-up stream (the file pieces of a one-file call), or null */);
+               hipStream_t *img = nullptr /* a second copy-up stream (the file pieces of a one-file call), or null */, LaneReport *report = nullptr);
 void forget_lanes(mp3s_ctx *c);
 // ---- file_up.cpp
 constexpr size_t kFileOnDevice = (size_t)1 << 30;       // longer files: chunk by chunk through the slots' own image buffers

@@ -36,6 +36,14 @@ int ensure_own_pipe(mp3s_ctx *c, size_t chunk_bytes)
     return pipe_create(c, kRunDepth, want, 0, true, &c->own_pipe);
 }
 
+// how the streams of the context's own pipe were chosen (mp3s_ctx_run_stats)
+void own_pipe_lanes(const mp3s_ctx *c, mp3s_run_stats *out)
+{
+    if (!c->own_pipe) return;
+    const LaneReport &r = c->own_pipe->lanes;
+    out->rehearsal_us = (int64_t)(r.rehearsal_ms * 1e3); out->rehearsals = r.rehearsals; out->lanes = r.lanes; out->queue_shared = r.queue_shared;
+}
+
 void destroy_own_pipe(mp3s_ctx *c)   // (the context is being destroyed)
 {
     if (c->own_pipe) { mp3s_pipe_destroy(c->own_pipe); c->own_pipe = nullptr; }

@@ -160,7 +160,7 @@ def select_plan(segs, cap):
 class PipeStats(C.Structure):
     _fields_ = [("submitted", C.c_int64), ("collected", C.c_int64), ("fast", C.c_int64), ("slow", C.c_int64),
                 ("scan_ms", C.c_double), ("issue_ms", C.c_double), ("last_device_span_ms", C.c_double), ("scan_cpu_ms", C.c_double),
-                ("resolved", C.c_int64)]
+                ("resolved", C.c_int64), ("rehearsal_ms", C.c_double), ("rehearsals", C.c_int64), ("lanes", C.c_int64), ("queue_shared", C.c_int64)]
 
 
 class Block(C.Structure):
@@ -178,7 +178,7 @@ SYMBOLS = ["mp3s_ctx_create", "mp3s_ctx_destroy", "mp3s_ctx_wait", "mp3s_last_er
            "mp3s_hide_message", "mp3s_clear_file", "mp3s_hide_messages", "mp3s_reencode_block", "mp3s_reveal_message",
            "mp3s_pipe_create", "mp3s_pipe_destroy", "mp3s_pipe_submit", "mp3s_pipe_submit_decode", "mp3s_pipe_collect", "mp3s_pipe_get_stats",
            "mp3s_index_stream", "mp3s_index_free", "mp3s_scan_range", "mp3s_decode_block_indexed", "mp3s_reencode_block_indexed",
-           "mp3s_hide_message_chunked", "mp3s_walk_stream", "mp3s_parse_frames_dev", "mp3s_stego_bits", "mp3s_ctx_set_option", "mp3s_ctx_get_option", "mp3s_ctx_run_stats", "mp3s_dev_copy", "mp3s_pipe_submit_block", "mp3s_pipe_collect_block", "mp3s_pipe_next_is_block", "mp3s_debug_walk_rate", "mp3s_device_count"]
+           "mp3s_hide_message_chunked", "mp3s_walk_stream", "mp3s_parse_frames_dev", "mp3s_stego_bits", "mp3s_ctx_set_option", "mp3s_ctx_get_option", "mp3s_ctx_run_stats", "mp3s_dev_copy", "mp3s_pipe_submit_block", "mp3s_pipe_collect_block", "mp3s_pipe_next_is_block", "mp3s_debug_walk_rate", "mp3s_device_count", "mp3s_device_pci"]
 
 _lib = None
 _lock = threading.Lock()
@@ -205,6 +205,7 @@ def lib():
         L.mp3s_ctx_destroy.argtypes = [vp]
         L.mp3s_ctx_destroy.restype = None
         L.mp3s_device_name.argtypes = [vp, C.c_char_p, sz]
+        L.mp3s_device_pci.argtypes = [vp, C.c_char_p, sz]
         L.mp3s_ctx_run_stats.argtypes = [vp, vp]
         L.mp3s_ctx_set_option.argtypes = [vp, i32, i64]
         L.mp3s_ctx_get_option.argtypes = [vp, i32, C.POINTER(C.c_int64)]
@@ -359,10 +360,11 @@ class Context:
         return old
 
     def run_stats(self):
-        """what became of this context's one-file calls: dict(files, chunks, reruns, resolved, fallbacks) (mp3s_ctx_run_stats)"""
-        a = (C.c_int64 * 5)()
+        """what became of this context's one-file calls: dict(files, chunks, reruns, resolved, fallbacks) + how the streams of its
+        own pipe were chosen: rehearsal_us, rehearsals, lanes, queue_shared (mp3s_ctx_run_stats)"""
+        a = (C.c_int64 * 9)()
         check(lib().mp3s_ctx_run_stats(self.handle, a))
-        return dict(zip(("files", "chunks", "reruns", "resolved", "fallbacks"), list(a)))
+        return dict(zip(("files", "chunks", "reruns", "resolved", "fallbacks", "rehearsal_us", "rehearsals", "lanes", "queue_shared"), list(a)))
 
     def get_option(self, name):
         v = C.c_int64()
@@ -378,6 +380,12 @@ class Context:
     def device_name(self):
         buf = C.create_string_buffer(256)
         check(lib().mp3s_device_name(self.handle, buf, 256))
+        return buf.value.decode()
+
+    def device_pci(self):
+        """the device's PCI address as sysfs spells it (mp3s_device_pci)"""
+        buf = C.create_string_buffer(64)
+        check(lib().mp3s_device_pci(self.handle, buf, 64))
         return buf.value.decode()
 
     def sync(self):

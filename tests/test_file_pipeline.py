@@ -238,3 +238,40 @@ def test_inherited_scalefactors_across_chunks(ctx, mlib, orc, golden_dir):
                     except mlib.Mp3sError:
                         continue                                # (a bit rate the encoder does not take: refused by both paths)
                     assert same_file(ctx.hide_message(data, "across the chunks"), ref), (name, chunk)
+
+
+@pytest.mark.gpu
+def test_every_context_of_a_process_gets_its_overlap(mlib):
+    """three contexts in one process, each with its own pipe (made by its first one-file call): the streams of a pipe are chosen by
+    a rehearsal judged against the same miniature on ONE stream -- at most 12 miniatures and 15 ms, reported in
+    mp3s_ctx_run_stats -- and no context may end up on lanes that share hardware queues: the same 2 500-frame call takes the same
+    time on all three (within 10 %; round 3's first context of three ran at half speed before the rehearsal existed)"""
+    import time
+    from synth_pcm import synth_pcm
+    ctxs = [mlib.Context(0) for _ in range(3)]
+    try:
+        mp3 = bytes(ctxs[0].encode_pcm(synth_pcm(2500, seed=73), 44100, 128, None)["mp3"])
+        ref = None
+        med = []
+        for c in ctxs:
+            out = bytes(c.hide_message(mp3, "three contexts")["data"])          # the first call makes the pipe
+            ref = ref or out
+            assert out == ref
+            st = c.run_stats()
+            assert 3 <= st["rehearsals"] <= 12 and 0 < st["rehearsal_us"] < 40000, st    # (15 ms of budget + one miniature that started inside it + allocation)
+            assert st["queue_shared"] == 0, st
+            ts = []
+            for _ in range(15):
+                t0 = time.perf_counter()
+                r = c.hide_message(mp3, "three contexts"); del r
+                ts.append(time.perf_counter() - t0)
+            med.append(sorted(ts)[len(ts) // 2])
+        assert max(med) <= 1.10 * min(med), [round(m * 1e3, 3) for m in med]
+        # a user's pipe on the first context: its own rehearsal (the context's stream is the same: decided earlier, nothing rehearsed)
+        p = mlib.Pipe(ctxs[0], depth=2, max_job_bytes=len(mp3) + 65536, scan_threads=1)
+        ps = p.stats()
+        assert ps["rehearsals"] <= 12 and ps["queue_shared"] == 0, ps
+        p.close()
+    finally:
+        for c in ctxs:
+            c.close()
