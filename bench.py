@@ -212,6 +212,55 @@ def run_config5(ctx, _lib, O, synth_pcm, n):
             "decode": dec, "reencode": enc, "band_limited_music_44k_320": music, "slowest_decode_mix": slow}, ok
 
 
+def live_pmc(frames, timeout_s=150):
+    """HBM bytes and VALU wave instructions per launch of every kernel of the resident step, measured NOW: separate rocprofv3 --pmc
+    passes (FETCH_SIZE / WRITE_SIZE / SQ_INSTS_VALU + SQ_INSTS_SALU + SQ_WAVES; never combined with --stats or other traces) over a
+    short --resident-only run of this script as a CHILD process -- this process has not touched the GPU yet when it is called and
+    never execs.  Bytes as MI355X_MICROARCH.md (HBM section) prescribes for gfx950: 2 x FETCH_SIZE + WRITE_SIZE, both converted
+    from the counters' KB.  -> {kernel: {"hbm_bytes": ..., "SQ_INSTS_VALU": ...}} or None (no rocprofv3, a pass failed or timed out)."""
+    import csv
+    import glob
+    import shutil
+    import subprocess
+    import tempfile
+    prof = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(prof):
+        return None, "rocprofv3 not found"
+    td = tempfile.mkdtemp(prefix="mp3s_pmc_", dir="/tmp")
+    env = dict(os.environ, TMPDIR="/tmp")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+        env.pop(k, None)
+    res, t_begin = {}, time.time()
+    try:
+        for name, counters in (("fetch", ["FETCH_SIZE"]), ("write", ["WRITE_SIZE"]), ("sq", ["SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_WAVES"])):
+            left = timeout_s - (time.time() - t_begin)
+            if left < 10:
+                return None, "time budget spent"
+            out = os.path.join(td, name)
+            cmd = [prof, "--kernel-trace", "--pmc"] + counters + ["--output-format", "csv", "-d", out, "--", sys.executable, os.path.abspath(__file__),
+                   "--resident-only", "--steps", "3", "--warmup", "1", "--no-cpu-baseline", "--no-live-pmc", "--frames", str(frames)]
+            r = subprocess.run(cmd, cwd="/tmp", env=env, capture_output=True, text=True, timeout=left)
+            if r.returncode != 0:
+                return None, f"pass {name}: exit {r.returncode}: {(r.stderr or r.stdout)[-200:]}"
+            vals = {}
+            for f in glob.glob(os.path.join(out, "**", "*counter_collection.csv"), recursive=True):
+                for row in csv.DictReader(open(f)):
+                    k = row["Kernel_Name"].split("(")[0].replace("void ", "").replace("mp3s::", "").split("<")[0]
+                    vals.setdefault((k, row["Counter_Name"]), []).append(float(row["Counter_Value"]))
+            if not vals:
+                return None, f"pass {name}: no counters in the output"
+            for (k, c), v in vals.items():
+                res.setdefault(k, {})[c] = sum(v) / len(v)
+    except Exception as e:                                   # noqa: BLE001
+        return None, f"{type(e).__name__}: {e}"[:200]
+    finally:
+        shutil.rmtree(td, ignore_errors=True)
+    for k, c in res.items():
+        if "FETCH_SIZE" in c and "WRITE_SIZE" in c:
+            c["hbm_bytes"] = c["FETCH_SIZE"] * 2048 + c["WRITE_SIZE"] * 1024
+    return res, f"live: 3 rocprofv3 --pmc passes of bench.py --resident-only --steps 3 ({time.time() - t_begin:.0f} s)"
+
+
 class GpuMonitor:
     """clocks / power / busy of one device read from sysfs by a side thread that makes no GPU call (the `sustained` region):
     /sys/bus/pci/devices/<address>/pp_dpm_sclk, pp_dpm_mclk (the line with the star), gpu_busy_percent, hwmon/*/power1_average"""
@@ -303,6 +352,8 @@ def main():
     ap.add_argument("--pack-overlap", action="store_true", help="(default since r02e; kept for old command lines)")
     ap.add_argument("--no-tail-stream", action="store_true", help="chain check and bit packing of batch k on the main stream instead of a third one")
     ap.add_argument("--resident-only", action="store_true", help="region (i) only (profiling runs)")
+    ap.add_argument("--no-live-pmc", action="store_true", help="roofline.traffic / roofline_alu from the committed profiles/*_latest.json instead of three "
+                    "rocprofv3 --pmc passes run as child processes before this one touches the GPU (rank 0, one GPU, full runs only)")
     ap.add_argument("--decode-stream", choices=("on", "off"), default="off",
                     help="the decode transforms of batch k+1 on a context of their own, under the encode transforms and the rate loop of batch k")
     args = ap.parse_args()
@@ -350,6 +401,10 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MIN)
         return bool(t[0] > 0.5)
 
+    # the counters behind roofline.traffic and roofline_alu, measured in THIS run (child processes, before the GPU is touched here)
+    pmc_live, pmc_note = None, "committed profile (--no-live-pmc, --resident-only, or more than one rank)"
+    if world == 1 and rank == 0 and not args.no_live_pmc and not args.resident_only:
+        pmc_live, pmc_note = live_pmc(args.frames)
     from mp3stego import _lib
     from synth_pcm import synth_pcm
     L = _lib.lib()
@@ -966,9 +1021,12 @@ def main():
     # duration of the dominant kernel per batch, from the event pairs of the TIMED region
     dom_ms_launch = prof[dom][0] / args.steps
     achieved = B_PIPE * n / (dom_ms_launch * 1e-3) / 1e9
-    traffic = None
+    traffic, traffic_source = None, None
+    if pmc_live and dom in pmc_live and "hbm_bytes" in pmc_live[dom]:
+        traffic, traffic_source = round(pmc_live[dom]["hbm_bytes"]), pmc_note
     tj = os.path.join(ROOT, "profiles", "traffic_latest.json")
-    if os.path.exists(tj):
+    if traffic is None and os.path.exists(tj):
+        traffic_source = "profiles/traffic_latest.json (committed; live measurement: %s)" % pmc_note
         try:
             tr = json.load(open(tj))
             # PMC bytes per launch (2 x FETCH_SIZE + WRITE_SIZE, separate rocprofv3 --pmc passes) measured on the
@@ -984,9 +1042,11 @@ def main():
     except Exception:
         copy_gbs = None
     roofline = {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
+                "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic, "traffic_source": traffic_source,
                 "algorithmic_bytes_per_launch": B_PIPE * n, "kernel_ms_per_launch": round(dom_ms_launch, 4),
                 "copy_kernel_gbs": copy_gbs,
+                "hbm_bytes_per_launch_by_kernel": ({k: round(v["hbm_bytes"]) for k, v in sorted(pmc_live.items()) if k.startswith("k_") and k != "k_copy16" and "hbm_bytes" in v}
+                                                   if pmc_live else None),
                 "note": "fixed-size fp64/int32 transforms in the reference's exact operation order are ALU-bound, "
                         "not HBM-bound (see DESIGN.md and roofline_alu); frac is reported as the contract defines it; "
                         "copy_kernel_gbs = what a plain device copy achieves on this device (read + write)"}
@@ -994,9 +1054,12 @@ def main():
     # (SQ_INSTS_VALU, same passes as `traffic`), against the rate the SIMDs can issue them at
     roofline_alu = None
     pj = os.path.join(ROOT, "profiles", "pmc_latest.json")
-    if os.path.exists(pj):
+    if (pmc_live and dom in pmc_live and "SQ_INSTS_VALU" in pmc_live[dom]) or os.path.exists(pj):
         try:
-            pm = json.load(open(pj))
+            if pmc_live and dom in pmc_live and "SQ_INSTS_VALU" in pmc_live[dom]:
+                pm = dict(pmc_live, frames=n, source=pmc_note)
+            else:
+                pm = json.load(open(pj))
             insts = pm[dom]["SQ_INSTS_VALU"] * n / pm.get("frames", 10000)
             peak = N_SIMD * CLOCK_GHZ / CLK_PER_VALU                      # G wave-instructions / s
             ach = insts / (dom_ms_launch * 1e-3) / 1e9
