@@ -710,7 +710,28 @@ def main():
         f64 = ctx.decode_stream(mp3_in, _lib.MP3S_PCM_F64)["pcm"]
         same = same and bool(np.array_equal(f32, f64.astype(np.float32)))
         del f64
+        # ... and with MP3S_OPT_FLOAT_FAST: float32 through the mirrored, fused IMDCT and the split synthesis (within 1e-5, not bit-identical)
+        ctx.set_option("float_fast", 1)
+        for _ in range(3):
+            dec_step()
+        ctx.sync()
+        t0 = time.perf_counter()
+        for _ in range(kd):
+            dec_step()
+        ctx.sync()
+        dms_fast = (time.perf_counter() - t0) / kd * 1e3
+        f32f = ctx.download(d_pcm32, np.float32, (n * 1152, 2))
+        ctx.set_option("float_fast", 0)
+        f64r = f32.astype(np.float64)        # (the exact kernels' float32 = the reference's float64 rounded once: the comparison is against that)
+        dd = np.abs(f32f.astype(np.float64) - f64r)
+        bigm = np.abs(f64r) > 1e-6
+        fast_err = {"max_abs": float(dd.max()), "max_rel_where_abs_above_1e-6": float((dd[bigm] / np.abs(f64r[bigm])).max()),
+                    "samples_that_differ": int((f32f != f32).sum()), "samples": int(f32.size)}
+        same = same and bool(np.allclose(f32f, f64r, rtol=1e-5, atol=1e-9))
+        del f32f, f64r, dd, bigm
         decode_only = {"workload": f"{n} frames, Huffman decode + decode transforms -> float32 PCM, resident (BASELINE configs[1])",
+                       "float_fast": {"ms_per_step": round(dms_fast, 4), "frames_per_s": round(n / (dms_fast * 1e-3), 1), "error_vs_exact_float32": fast_err,
+                                      "what": "MP3S_OPT_FLOAT_FAST = 1: the same step through the fast sums, unguarded; default (the numbers beside this) = bit-identical to the reference"},
                        "frames_per_s": round(n / (dms * 1e-3), 1), "ms_per_step": round(dms, 4), "steps": kd,
                        "hbm_gbs_algorithmic": round(B_DEC * n / (dms * 1e-3) / 1e9, 2),
                        "hbm_frac": round(B_DEC * n / (dms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5)}

@@ -94,13 +94,18 @@ __global__ __launch_bounds__(CH_THREADS) void k_chain_sum(const mp3s_gr_out *__r
                                                           const int32_t *__restrict__ only_after)
 {
     __shared__ ChainEl wave_tot[CH_THREADS / 64];
-    if (only_after && only_after[0] == 0) return;   // the check behind the re-runs: nothing was run again, the first verdict stands
+    if (only_after && only_after[0] == 0) {          // the check behind the re-runs: nothing was run again, the verdict in front stands
+        if (redo && blockIdx.x == 0 && threadIdx.x == 0) redo[0] = 0;   // (... and the round after this one finds an empty list, not the one before last's)
+        return;
+    }
     const int f = blockIdx.x * CH_THREADS + threadIdx.x;
     // what pass 2 accumulates into starts from zero (no fill launches in front of the pair)
     if (f == 0) { verdict[0] = 0; verdict[1] = 0; }
     if (redo) {
         if (f == 0) redo[0] = 0;
-        for (int i = f; i < REDO_CAP; i += (int)gridDim.x * CH_THREADS) redo[REDO_HEAD + i] = -1;
+        // (the first check of a launch sequence also empties the second list: a later round that is skipped -- nothing was run
+        // again in front of it -- must leave an empty list behind for the round after it)
+        if (f == 0 && !only_after) redo[REDO_WORDS] = 0;
     }
     if (f < n_frames && segs[rf[f].stream].first_frame == f) seg_out[rf[f].stream].carry_used = 0;
     ChainEl total;

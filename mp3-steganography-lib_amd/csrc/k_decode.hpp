@@ -638,7 +638,10 @@ __device__ __forceinline__ double synth_dot(const double (&d)[N], const SynthRow
     return a;                                                                      // (the guard's bound covers either; half the instructions)
 }
 
-template <int TW>
+// F32 (MP3S_OPT_FLOAT_FAST): float32 output of the same sums, no guard and no fix-up -- the fast sums differ from the reference's
+// by a few 1e-14 of the slot's magnitude, the format's own rounding is 6e-8 of the sample and the contract's tolerance 1e-5;
+// a sample goes straight to its place (no tile: 64 floats per slot would double the kernel's LDS).
+template <int TW, bool F32 = false>
 __global__ __launch_bounds__(TW * 64 * 2, TW == 4 ? 2 : 4) void k_dec_synth_fast(
     const double *__restrict__ S, long T, const mp3s_frame_hdr *__restrict__ hdr, int nch, int n_halo,
     int16_t *__restrict__ pcm_out, int sf_base, double eps_scale, const double *__restrict__ G, int n_granules,
@@ -746,7 +749,12 @@ __global__ __launch_bounds__(TW * 64 * 2, TW == 4 ? 2 : 4) void k_dec_synth_fast
             for (int jj = 0; jj < 16; jj++) if (jj > lim) u[jj] = 0.0;      // before the stream started the fifo holds zeros
         }
     };
+    float *const fslot = reinterpret_cast<float *>(pcm_out) + ((valid ? t - (long)n_halo * 36 : 0) * 32) * nch + ch;
     auto window_emit = [&](int io, double sum) {
+        if (F32) {
+            if (emit) fslot[io * nch] = (float)sum;
+            return;
+        }
         // the guard: is the truncation of sum * 32767 beyond doubt?  (Truncation is toward zero: every x in (-1, 1) gives
         // 0, so the integer 0 is not a boundary.)
         const double x = sum * 32767, xi = rint(x), ax = fabs(x);
@@ -871,6 +879,7 @@ __global__ __launch_bounds__(TW * 64 * 2, TW == 4 ? 2 : 4) void k_dec_synth_fast
 #undef MP3S_GO
     // ---- the samples the guard could not vouch for go on the fix-up list: slot | channel << 31, mask of output indices
     //      (k_dec_fixup recomputes them from `is` in the reference's order and overwrites what is stored below)
+    if (F32) return;
     if (redo) {
         const int at = atomicAdd(fix_count, 1);
         fix_list[at] = make_uint2((uint32_t)t | ((uint32_t)ch << 31), redo);

@@ -13,7 +13,7 @@
 //                   no overrun discard), D2 (books 4/14 read no bits), bits past the buffer read as 0.
 #pragma once
 #ifndef MP3S_HUF_CLOCKS
-#define MP3S_HUF_CLOCKS 0   // 1: shader-clock deltas of the phases into sample pairs 280..285 of every row (tools/huf_clk_probe.py)
+#define MP3S_HUF_CLOCKS 0   // 1: shader-clock deltas of the phases into sample pairs 280..285 of every row (a round-3 probe)
 #endif
 
 namespace mp3s {

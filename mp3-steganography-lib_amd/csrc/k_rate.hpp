@@ -71,7 +71,9 @@ __device__ __forceinline__ uint32_t mulr_u(uint32_t a, uint32_t b) { return (uin
 
 // the device's list of units to run again (written by k_chain_apply, read by k_rate_redo), int32: [0] = entries wanted,
 // then from REDO_HEAD: unit[REDO_CAP] (-1 behind the end), cursor[REDO_CAP], inherited state[REDO_CAP][4]
-constexpr int REDO_CAP = 1024, REDO_HEAD = 4, REDO_WORDS = REDO_HEAD + 6 * REDO_CAP;
+constexpr int REDO_CAP = 4096, REDO_HEAD = 4, REDO_WORDS = REDO_HEAD + 6 * REDO_CAP;
+constexpr int REDO_GROUPS = 256;          // workgroups of k_rate_redo (persistent: a group takes entries g, g + REDO_GROUPS * RL_WAVES, ...)
+constexpr int REDO_CHAIN_MAX = 64;        // units a re-run may follow its chain through (the units behind it that inherit what it leaves)
 constexpr int RL_WAVES = 4;   // 4 waves share one copy of the lookup tables: 33 KB LDS -> 4 workgroups = 16 waves per CU (a fifth wave
                               // per SIMD at 96 VGPRs was measured: 0.351 instead of 0.305 ms, and the Huffman kernel no longer fits beside it)
 constexpr int RL_NP = 5;      // pairs per lane: lane l holds the CONSECUTIVE pairs 5l .. 5l+4 (lines 10l .. 10l+9); lanes 0..57 hold
@@ -342,12 +344,20 @@ struct RateVariants {
     uint8_t *tables;   // the entries' table counts once more, one byte each (what the selection's walk reads)
 };
 
+// CHAIN (k_rate_redo): the workgroup is persistent over the list (`n_list` entries are there, read from the device), and a wave
+// that has run its entry again FOLLOWS THE CHAIN behind it: the unit of the same (gr, ch) in the next frame inherits the
+// addresses and the quantiser step this one leaves (encoder/MP3_Encoder.py:1004-1006, 788-803) -- if it is silent it
+// only passes them on, if it read them (MP3S_RF_USED_ADDR_IN) and was given others it is run again on the spot, and so on until
+// a unit stands on its own.  One re-run used to settle only the listed unit itself; what it changed for the units behind
+// it went to the host (2.3 % of the long-stream jobs of tools/soak_select_long.py).  `cursor_all`: the cursors by unit, for
+// the units a chain reaches (k_chain_apply keeps them current).
+template <bool CHAIN = false>
 __device__ __forceinline__ void rate_units(
     const int32_t *__restrict__ mdct, const mp3s_rate_frame *__restrict__ frames, int n_units,
-    const uint8_t *__restrict__ hide, int n_hide, const int32_t *__restrict__ cursor_in,
+    const uint8_t *__restrict__ hide, int n_hide_all, const int32_t *__restrict__ cursor_in,
     const int32_t *__restrict__ state_in, const int32_t *__restrict__ unit_list, int n_list,
     int16_t *__restrict__ ix_out, mp3s_gr_out *__restrict__ out, int32_t *__restrict__ en_out, int out_base, int compact,
-    RateVariants var)
+    RateVariants var, const int32_t *__restrict__ cursor_all = nullptr)
 {
     // compact (re-runs of a unit list): cursor_in / state_in / out are indexed by the position in the list, so that a
     // pass moves a few bytes per listed unit over PCIe instead of whole-batch arrays; ix / en still land in place.
@@ -381,8 +391,13 @@ __device__ __forceinline__ void rate_units(
     __syncthreads();
 
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
-    int li = blockIdx.x * RL_WAVES + wave;
-    if (li >= n_list + var.n) return;
+    uint32_t *pre = pre_all[wave];
+    int32_t *esq = esq_all[wave];
+    const int p0 = 5 * lane;                      // the lane's first pair
+    int li0 = blockIdx.x * RL_WAVES + wave;
+    if (li0 >= n_list + var.n) return;
+    do {                                          // (one trip unless CHAIN: the plain rate loop keeps its straight-line shape)
+    int li = li0;
     uint8_t *tables_out = nullptr;
     if (li >= n_list) {                           // a variant entry: by entry position throughout (as compact == 2)
         li -= n_list;
@@ -391,17 +406,19 @@ __device__ __forceinline__ void rate_units(
         ix_out = var.ix; out = var.out; en_out = var.en;
         compact = 2;
     }
-    const int u = __builtin_amdgcn_readfirstlane(unit_list ? unit_list[li] : li);
-    if (u < 0 || u >= n_units) return;
-    uint32_t *pre = pre_all[wave];
-    int32_t *esq = esq_all[wave];
+    int u = __builtin_amdgcn_readfirstlane(unit_list ? unit_list[li] : li);
+    if (u < 0 || u >= n_units) { if (CHAIN) continue; return; }
+    // what the unit runs on: from the arrays (by unit, or by list position), or -- a unit reached through a chain -- from the run in front
+    bool chained = false;
+    int ch_cursor = 0, ch_state[4] = {0, 0, 0, 0};
+    for (int steps = 0; ; steps++) {
+    if (CHAIN) __builtin_amdgcn_wave_barrier();   // (the wave's LDS scratch of the unit before is no longer read)
     const mp3s_rate_frame fr = frames[u >> 2];
     const int sr = sr_wg;
     const int max_bits = fr.max_bits;
     const int ci = compact ? li : u;
-    const int cursor = (n_hide > 0 && cursor_in) ? cursor_in[ci] : 0;
-    n_hide = min(n_hide, fr.hide_end);            // streams of a batch keep their messages back to back in `hide`
-    const int p0 = 5 * lane;                      // the lane's first pair
+    const int cursor = chained ? ch_cursor : ((n_hide_all > 0 && cursor_in) ? cursor_in[ci] : 0);
+    const int n_hide = min(n_hide_all, fr.hide_end);   // streams of a batch keep their messages back to back in `hide`
 
     // ---- load xr, |xr|, xrsq >> 10 (:770-776, :837-838)
     const int32_t *xr = mdct + (long)u * 576;
@@ -462,10 +479,11 @@ __device__ __forceinline__ void rate_units(
         if (lane < 22) en_out[(long)(compact == 2 ? li : u - out_base) * 22 + lane] = en;
         RlState st;
         st.big_values = st.count1 = st.c1sel = st.r0c = st.r1c = 0;
-        st.a1 = state_in ? state_in[(long)ci * 4 + 0] : 0;
-        st.a2 = state_in ? state_in[(long)ci * 4 + 1] : 0;
-        st.a3 = state_in ? state_in[(long)ci * 4 + 2] : 0;
-        int qstep = state_in ? state_in[(long)ci * 4 + 3] : 0;
+        const int in_a1 = chained ? ch_state[0] : (state_in ? state_in[(long)ci * 4 + 0] : 0);
+        const int in_a2 = chained ? ch_state[1] : (state_in ? state_in[(long)ci * 4 + 1] : 0);
+        const int in_a3 = chained ? ch_state[2] : (state_in ? state_in[(long)ci * 4 + 2] : 0);
+        st.a1 = in_a1; st.a2 = in_a2; st.a3 = in_a3;
+        int qstep = chained ? ch_state[3] : (state_in ? state_in[(long)ci * 4 + 3] : 0);
         st.ts0 = st.ts1 = st.ts2 = 0;
         st.addr_fresh = false; st.used_addr_in = false;
         int32_t ix[2 * RL_NP];
@@ -553,13 +571,33 @@ __device__ __forceinline__ void rate_units(
             o.n_tables = act ? (st.ts0 > 0) + (st.ts1 > 0) + (st.ts2 > 0) : 0;
             o.flags = flags;
             // the inherited addresses the unit was given (each < 1024): what k_chain_apply compares with the true chain
-            o.reserved0 = state_in ? state_in[(long)ci * 4 + 0] | (state_in[(long)ci * 4 + 1] << 10) | (state_in[(long)ci * 4 + 2] << 20) : 0;
+            o.reserved0 = (state_in || chained) ? in_a1 | (in_a2 << 10) | (in_a3 << 20) : 0;
             o.xrmax = (int32_t)xrmax;
             o.reserved = 0;
             out[compact == 1 || compact == 2 ? li : u - out_base] = o;
             if (tables_out) tables_out[li] = (uint8_t)o.n_tables;
         }
+        if (!CHAIN) break;
+        // ---- the chain behind this unit: what it leaves (an active unit: its own addresses and step; a silent one passes on what it got)
+        ch_state[0] = __builtin_amdgcn_readfirstlane(st.a1); ch_state[1] = __builtin_amdgcn_readfirstlane(st.a2);
+        ch_state[2] = __builtin_amdgcn_readfirstlane(st.a3); ch_state[3] = __builtin_amdgcn_readfirstlane(qstep);
+        bool go = false;
+        int un = u;
+        for (;;) {
+            un += 4;                                               // the same (gr, ch) of the next frame
+            if (++steps >= REDO_CHAIN_MAX || un >= n_units || frames[un >> 2].stream != fr.stream) break;
+            const int f2 = __builtin_amdgcn_readfirstlane(__hip_atomic_load(&out[un - out_base].flags, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+            if (!(f2 & MP3S_RF_ACTIVE)) continue;                  // silent: it inherits and passes on (k_chain_apply writes its record)
+            const int given = __builtin_amdgcn_readfirstlane(__hip_atomic_load(&out[un - out_base].reserved0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+            go = (f2 & MP3S_RF_USED_ADDR_IN) && given != (ch_state[0] | (ch_state[1] << 10) | (ch_state[2] << 20));
+            break;                                                 // (an active unit that did not look at what it inherited: the chain ends)
+        }
+        if (!go) break;
+        u = un; chained = true;
+        ch_cursor = (n_hide_all > 0 && cursor_all) ? cursor_all[u] : 0;
     }
+    }   // the unit and its chain
+    } while (CHAIN && (li0 += (int)gridDim.x * RL_WAVES) < n_list + var.n);   // list entries
 }
 
 __global__ __launch_bounds__(RL_WAVES * 64, 4) void k_rate_loop(
@@ -574,18 +612,19 @@ __global__ __launch_bounds__(RL_WAVES * 64, 4) void k_rate_loop(
 
 // The units k_chain_apply listed (they ran on inherited addresses or a cursor that turned out different: k_chain.hpp) once
 // more, on what it found, results in place.  The list lives on the device and is short or empty: its length is not a
-// launch parameter, entries behind its end hold -1 (it is filled from the front, so a workgroup whose first entry is
-// empty has nothing to do).
+// launch parameter: redo[0] entries are there (at most REDO_CAP are kept; what the check finds beyond them stays with the
+// verdict), REDO_GROUPS persistent workgroups share them, and each re-run follows its chain (rate_units<true>).
 __global__ __launch_bounds__(RL_WAVES * 64, 4) void k_rate_redo(
     const int32_t *__restrict__ mdct, const mp3s_rate_frame *__restrict__ frames, int n_units,
     const uint8_t *__restrict__ hide, int n_hide, const int32_t *__restrict__ redo, int16_t *__restrict__ ix_out,
-    mp3s_gr_out *__restrict__ out, int32_t *__restrict__ en_out)
+    mp3s_gr_out *__restrict__ out, int32_t *__restrict__ en_out, const int32_t *__restrict__ cursor_all)
 {
     const int32_t *unit_list = redo + REDO_HEAD;
-    if (unit_list[blockIdx.x * RL_WAVES] < 0) return;
+    const int n_list = min(__builtin_amdgcn_readfirstlane(__hip_atomic_load(&redo[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)), REDO_CAP);
+    if ((int)blockIdx.x * RL_WAVES >= n_list) return;              // (most launches find an empty list: nothing staged)
     const RateVariants none = {nullptr, nullptr, 0, nullptr, nullptr, nullptr, nullptr};
-    rate_units(mdct, frames, n_units, hide, n_hide, unit_list + REDO_CAP, unit_list + 2 * REDO_CAP, unit_list, REDO_CAP, ix_out, out, en_out,
-               0, 3, none);
+    rate_units<true>(mdct, frames, n_units, hide, n_hide, unit_list + REDO_CAP, unit_list + 2 * REDO_CAP, unit_list, n_list, ix_out, out, en_out,
+                     0, 3, none, cursor_all);
 }
 
 // Message variants (enc_resolve): a unit's result depends on the message only through the <= 3 bits at its cursor, so

@@ -60,7 +60,7 @@ size_t dec_scratch_bytes(int n_frames, int nch)
 
 int launch_decode(hipStream_t stream, const int16_t *d_is, const mp3s_granule_si *d_si, const mp3s_frame_hdr *d_hdr,
                   int n_frames, int nch, int n_halo, int out_format, void *d_pcm, void *d_scratch, Profiler *prof, int sf_base,
-                  double synth_eps_scale, int32_t *d_sync, bool fast_imdct)
+                  double synth_eps_scale, int32_t *d_sync, bool fast_imdct, bool float_fast)
 {
     const long T = (long)n_frames * 36;
     double *S = (double *)d_scratch;
@@ -69,6 +69,8 @@ int launch_decode(hipStream_t stream, const int16_t *d_is, const mp3s_granule_si
     const int n_gran = n_frames * 2;
     // int16 output through the fast kernels (guarded; needs the context's counters), everything else in the reference's order
     const bool fast = out_format == MP3S_PCM_I16 && synth_eps_scale > 0 && d_sync;
+    // float32 output through the same fast sums, unguarded (MP3S_OPT_FLOAT_FAST: within 1e-5 of the reference, not bit-identical)
+    const bool fast32 = out_format == MP3S_PCM_F32 && float_fast;
     // granules per wave: each wave also primes itself with half an IMDCT of the granule before its run, so longer
     // runs waste less; pick the run length (2..8) that fills whole rounds of the chip's wave slots best (168 VGPRs ->
     // 3 waves per SIMD -> 256 CUs x 12 = 3072 slots)
@@ -84,16 +86,20 @@ int launch_decode(hipStream_t stream, const int16_t *d_is, const mp3s_granule_si
     }
     const int runs = (n_gran + run - 1) / run;
     int pp = prof ? prof->begin(stream, K_DEC_IMDCT) : -1;
-    if (fast && fast_imdct)
+    if ((fast && fast_imdct) || fast32)
         hipLaunchKernelGGL(k_dec_imdct<true>, dim3((runs + DEC_A_WAVES - 1) / DEC_A_WAVES), dim3(DEC_A_WAVES * 64), 0, stream,
-                           d_is, d_si, d_hdr, n_gran, nch, run, S, T, sf_base, G);
+                           d_is, d_si, d_hdr, n_gran, nch, run, S, T, sf_base, fast32 ? (double *)nullptr : G);
     else
         hipLaunchKernelGGL(k_dec_imdct<false>, dim3((runs + DEC_A_WAVES - 1) / DEC_A_WAVES), dim3(DEC_A_WAVES * 64), 0, stream,
                            d_is, d_si, d_hdr, n_gran, nch, run, S, T, sf_base, (double *)nullptr);
     if (prof) prof->end(stream, pp);
     constexpr int TW = DEC_SYNTH_TW;
     pp = prof ? prof->begin(stream, K_DEC_SYNTH) : -1;
-    if (fast) {
+    if (fast32) {
+        constexpr int W = DEC_SYNTH_FAST_TW;
+        hipLaunchKernelGGL((k_dec_synth_fast<W, true>), dim3((unsigned)((T + (W * 64 - 15) - 1) / (W * 64 - 15))), dim3(W * 64 * nch), 0, stream,
+                           (const double *)S, T, d_hdr, nch, n_halo, (int16_t *)d_pcm, sf_base, 1.0, (const double *)nullptr, n_gran, (uint2 *)nullptr, (int32_t *)nullptr);
+    } else if (fast) {
         constexpr int ftw = DEC_SYNTH_FAST_TW;
         const double *Gk = fast_imdct ? G : nullptr;
 #define MP3S_FAST_LAUNCH(W)                                                                                                        \
@@ -156,7 +162,13 @@ int launch_rate(hipStream_t stream, const int32_t *d_mdct, const mp3s_rate_frame
 }
 
 static size_t chain_scan_bytes(int n_frames) { return ((size_t)((n_frames + CH_THREADS - 1) / CH_THREADS) * sizeof(ChainEl) + 31) & ~(size_t)15; }
-size_t chain_agg_bytes(int n_frames) { return chain_scan_bytes(n_frames) + (size_t)REDO_WORDS * 4; }   // (+ the list of units to run again)
+// rounds of re-runs behind the first check.  Measured with 3 (round 4): the jobs of tools/soak_select_long.py that one round leaves to
+// the host -- raw PCM with silences inside a long message's reach, 20 - 160 units behind the plan whose cursors move with every
+// re-run that takes another number of tables -- went from 2.7 % to 2.0 %, and the six more launches, empty on every other job,
+// cost the resident step 0.03 ms.  One round it stays; what a re-run changes for the units that INHERIT from it is followed
+// inside the round (k_rate_redo).
+constexpr int kRedoRounds = 1;
+size_t chain_agg_bytes(int n_frames) { return chain_scan_bytes(n_frames) + (size_t)2 * REDO_WORDS * 4; }   // (+ the two lists of units to run again, taking turns)
 
 int launch_chain(hipStream_t stream, mp3s_gr_out *d_gr, const mp3s_rate_frame *d_frames, int n_frames, const mp3s_chain_seg *d_segs,
                  const int32_t *d_cursor, const int32_t *d_state, void *d_agg, int32_t *d_verdict, mp3s_chain_seg_out *d_seg_out,
@@ -172,12 +184,22 @@ int launch_chain(hipStream_t stream, mp3s_gr_out *d_gr, const mp3s_rate_frame *d
     hipLaunchKernelGGL(k_chain_apply, dim3(blocks), dim3(CH_THREADS), 0, stream, d_gr, d_frames, d_segs, n_frames,
                        (const ChainEl *)d_agg, cursor, d_state, d_verdict, d_seg_out, d_redo, (const int32_t *)nullptr);
     if (redo) {
-        hipLaunchKernelGGL(k_rate_redo, dim3(REDO_CAP / RL_WAVES), dim3(RL_WAVES * 64), 0, stream, redo->d_mdct, d_frames, n_frames * 4,
-                           redo->d_hide, redo->n_hide, (const int32_t *)d_redo, redo->d_ix, d_gr, redo->d_en);
-        hipLaunchKernelGGL(k_chain_sum, dim3(blocks), dim3(CH_THREADS), 0, stream, (const mp3s_gr_out *)d_gr, d_frames, d_segs, n_frames,
-                           (ChainEl *)d_agg, d_verdict, d_seg_out, (int32_t *)nullptr, (const int32_t *)d_redo);
-        hipLaunchKernelGGL(k_chain_apply, dim3(blocks), dim3(CH_THREADS), 0, stream, d_gr, d_frames, d_segs, n_frames,
-                           (const ChainEl *)d_agg, cursor, d_state, d_verdict, d_seg_out, (int32_t *)nullptr, (const int32_t *)d_redo);
+        // The units the check listed run again (each following its chain of inheriting units), and the check is made again -- up to
+        // kRedoRounds times, the lists taking turns: a re-run that takes another number of tables than the unit's first run moved
+        // the cursor of every unit behind it as long as the message is live, so one round settles the units up to the first
+        // such change, the next round the stretch behind it (tools/soak_select_long.py: the jobs one round left to the host had
+        // 20 - 160 units still to redo, a few such changes apart).  A round whose list is empty returns at once, kernel by kernel.
+        int32_t *lists[2] = {d_redo, d_redo + REDO_WORDS};
+        for (int round = 0; round < kRedoRounds; round++) {
+            const int32_t *cur = lists[round & 1];
+            int32_t *nxt = round + 1 < kRedoRounds ? lists[(round + 1) & 1] : nullptr;
+            hipLaunchKernelGGL(k_rate_redo, dim3(REDO_GROUPS), dim3(RL_WAVES * 64), 0, stream, redo->d_mdct, d_frames, n_frames * 4,
+                               redo->d_hide, redo->n_hide, cur, redo->d_ix, d_gr, redo->d_en, (const int32_t *)d_cursor);
+            hipLaunchKernelGGL(k_chain_sum, dim3(blocks), dim3(CH_THREADS), 0, stream, (const mp3s_gr_out *)d_gr, d_frames, d_segs, n_frames,
+                               (ChainEl *)d_agg, d_verdict, d_seg_out, nxt, cur);
+            hipLaunchKernelGGL(k_chain_apply, dim3(blocks), dim3(CH_THREADS), 0, stream, d_gr, d_frames, d_segs, n_frames,
+                               (const ChainEl *)d_agg, cursor, d_state, d_verdict, d_seg_out, nxt, cur);
+        }
     }
     if (prof) prof->end(stream, pp);
     return (int)hipGetLastError();

@@ -563,6 +563,7 @@ int encode_batch(mp3s_ctx *c, const int16_t *pcm, const int16_t *pcm_dev, std::v
         return MP3S_OK;
     }
     // ---- the guesses did not hold: resolve the chains on the host, as round 1 did
+    if (trace_on()) fprintf(stderr, "mp3s: encode of %d frames: %d units still to redo behind the device's re-runs (step range %d), %d variant entries, redo launches %d -> the host resolves\n", n, small[0], small[1], L.n_entries, (int)L.redo);
     EncDev devr = dev;
     rc = enc_resolve(c, L, segs, in.data(), devr, b, want_gr, passes_out);
     cleanup();

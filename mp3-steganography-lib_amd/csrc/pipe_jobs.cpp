@@ -777,7 +777,7 @@ int pipe_create(mp3s_ctx *c, int depth, size_t max_job_bytes, int scan_threads, 
     // The tail of a job (selection, chain check, bit packing) on a stream of its own, under the decode transforms of the next job:
     // worth 5 % on a resident batch fed through three contexts (bench.py, region (i)); in this pipe round 2 measured it slower
     // at every priority -- that was the lanes sharing queues, not the arrangement: with a tail stream the rehearsal vouches for
-    // a batch takes 0.79 instead of 0.82 ms (tools/pipe_tail_probe.py).  MP3S_OPT_PIPE_TAIL: 0 off, 1 on, 2 if the rehearsal gains.
+    // a batch takes 0.79 instead of 0.82 ms (round 3).  MP3S_OPT_PIPE_TAIL: 0 off, 1 on, 2 if the rehearsal gains.
     // the page-locked staging of the slots is allocated by a thread that runs on the GPU's NUMA node (first touch), and the
     // workers that fill it stay there
     if (c->opt[MP3S_OPT_NUMA]) P->node_cpus = gpu_node_cpus(c->device);

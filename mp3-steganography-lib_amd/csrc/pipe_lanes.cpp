@@ -8,8 +8,8 @@ namespace {
 // front end: its workgroups fill in beside the compute stream's instead of competing with them).  The runtime multiplexes
 // streams onto a few hardware queues; which queue a stream gets depends on everything the process has created before it
 // (round 2 believed priorities chose the set of queues; a context's own pipe in front of a user's pipe showed otherwise:
-// 0.97 - 1.25 instead of 0.81 ms per batch, tools/pipe_queue_probe.py; the first of three contexts ran its one-file calls at
-// half speed, tools/bench_queue_probe4.py), and a pipeline whose streams share queues with its compute stream loses its
+// 0.97 - 1.25 instead of 0.81 ms per batch, round 3; the first of three contexts ran its one-file calls at
+// half speed), and a pipeline whose streams share queues with its compute stream loses its
 // overlap -- every kernel of it takes longer, not only the ones that wait.  The runtime does not tell which stream sits
 // where, and a spin kernel beside an empty one or beside a small copy does not show it either (all eight candidates passed
 // that test on a context that then ran at half speed).  So the pipe REHEARSES: four miniature jobs -- a copy up, a spin on

@@ -96,7 +96,7 @@ static int run_file_impl(mp3s_ctx *c, const uint8_t *mp3, size_t len, int mode, 
     else {
         // A short first chunk, so that the device starts early, then chunks as long as a transform group takes: every chunk
         // costs the host 0.15 ms of walking, laying out and queueing (two dozen runtime calls), which four chunks of a
-        // 10 000-frame file do not win back (tools/chunk_plan_probe.py: 2 048 + the rest 1.41 ms, four chunks 1.49, one 1.57;
+        // 10 000-frame file do not win back (round 3, profiles/r03a_chunk_plans.json: 2 048 + the rest 1.41 ms, four chunks 1.49, one 1.57;
         // a 100 000-frame file: 8 192 + 16 000s 8.1 ms)
         first_chunk = std::min<long>(8192, std::max<long>(2048, n_est / 12));
         chunk = kMaxChunk;

@@ -67,3 +67,47 @@ def test_fast_decode_across_transform_chunks(mlib):
         del exact, fast
     finally:
         ctx.close()
+
+
+@pytest.mark.gpu
+def test_float32_through_the_fast_sums_is_an_option_within_the_contract(ctx, mlib, orc, golden_dir):
+    """MP3S_OPT_FLOAT_FAST: float32 output through the mirrored, fused IMDCT and the split synthesis, without guard or fix-up
+    (decoder/Frame.py:65-154).  Off (the default) the float formats stay bit-identical to the reference; on, every sample is within
+    the contract's 1e-5 relative tolerance (measured: a few float32 last places) on the reference's own file, the decode corpus
+    (short / mixed blocks, MS, mono, reservoir), a stream that starts inside tiles, and the chunked calls"""
+    import frame_synth
+    from synth_pcm import synth_pcm
+    g = np.load(os.path.join(golden_dir, "g7_decode_corpus.npz"))
+    streams = [open(os.path.join(golden_dir, "test.mp3"), "rb").read()]
+    streams += [g[k].tobytes() for k in g.files if k.endswith("__mp3")]
+    streams.append(bytes(ctx.encode_pcm(synth_pcm(700, seed=81), 44100, 128, None)["mp3"]))
+    streams.append(frame_synth.make_stream(61, 300, block_types=(0, 1, 2, 3), allow_mixed=True, use_reservoir=True))
+    worst_rel, worst_abs, differing = 0.0, 0.0, 0
+    keep = ctx.get_option("float_fast")
+    try:
+        for data in streams:
+            ref64 = orc.decode(data)["pcm"]
+            ctx.set_option("float_fast", 0)
+            exact = ctx.decode_stream(data, mlib.MP3S_PCM_F32)["pcm"]
+            assert np.array_equal(exact, ref64.astype(np.float32))                       # the default: the reference's samples, rounded once
+            ctx.set_option("float_fast", 1)
+            for chunk in (0, 37):
+                ctx.set_option("chunk_frames", chunk)
+                fast = ctx.decode_stream(data, mlib.MP3S_PCM_F32)["pcm"]
+                assert fast.shape == exact.shape
+                assert np.allclose(fast, ref64, rtol=1e-5, atol=1e-9), len(data)
+                d = np.abs(fast.astype(np.float64) - ref64)
+                big = np.abs(ref64) > 1e-6
+                worst_abs = max(worst_abs, float(d.max()) if d.size else 0.0)
+                if big.any():
+                    worst_rel = max(worst_rel, float((d[big] / np.abs(ref64[big])).max()))
+                differing += int((fast != exact).sum())
+            ctx.set_option("chunk_frames", 0)
+            # the other formats do not change with the option
+            assert ctx.decode_stream(data, mlib.MP3S_PCM_F64)["pcm"].tobytes() == ref64.tobytes()
+            assert np.array_equal(ctx.decode_stream(data, mlib.MP3S_PCM_I16)["pcm"], orc.pcm_to_i16(ref64))
+    finally:
+        ctx.set_option("float_fast", keep)
+        ctx.set_option("chunk_frames", 0)
+    assert worst_rel < 1e-6, (worst_rel, worst_abs)          # (measured 6e-8: float32's own rounding; the corpus holds samples up to +-1340)
+    assert differing > 0            # (the fast sums are not the reference's: if nothing differs the option did not take)

@@ -147,11 +147,18 @@ def test_silence_inside_the_reach_and_uncovered_start(ctx, mlib, orc):
     finally:
         ctx.set_option("redo", keep)
     assert r["mp3"] == o["mp3"] and r["hide_offset"] == o["hide_offset"] and r["rate_passes"] > 1
-    # ... and a message far behind the plan, more units than the list holds: the host again
+    # ... and a message far behind the plan: 2 100 units to run again (the list holds 4 096 since round 4; 1 024 before, and the
+    # host took this one)
     long_msg = rng.integers(0, 2, size=6000).astype(np.uint8)
     pcm = synth_pcm(1500, seed=36)
     pcm[:700 * 1152] = 0
     r, o = ctx.encode_pcm(pcm, 44100, 128, long_msg), orc.encode(pcm, 44100, 128, long_msg)
+    assert r["mp3"] == o["mp3"] and r["hide_offset"] == o["hide_offset"]
+    # more units than the list holds: the host again
+    longer = rng.integers(0, 2, size=14000).astype(np.uint8)
+    pcm = synth_pcm(2600, seed=37)
+    pcm[:700 * 1152] = 0
+    r, o = ctx.encode_pcm(pcm, 44100, 128, longer), orc.encode(pcm, 44100, 128, longer)
     assert r["mp3"] == o["mp3"] and r["hide_offset"] == o["hide_offset"] and r["rate_passes"] > 1
     # a stream shorter than the message's reach, message longer than the stream can hold
     pcm = synth_pcm(9, seed=34)
@@ -265,3 +272,26 @@ def test_rate_select_entry_point(ctx, mlib):
             ctx.free(p)
         if "ctx2" in locals():
             ctx2.close()
+
+
+@pytest.mark.gpu
+def test_chains_of_inheriting_units_are_followed_on_the_device(ctx, mlib, orc):
+    """behind a silence, granules so quiet that they take no big values keep the addresses they inherit and hand them on
+    (encoder/MP3_Encoder.py:1004-1006, 788-803): the unit behind such a unit inherits what THAT one was given.  The
+    first pass gives everybody zeros; the check can only fault the first of the row (the others were given what their
+    predecessor -- wrongly -- left); its re-run then follows the chain from unit to unit (k_rate_redo, round 4) where one re-run
+    per check used to leave the rest to the host.  Same bytes as the oracle, final after the first pass."""
+    from synth_pcm import synth_pcm
+    rng = np.random.default_rng(23)
+    passes = []
+    for seed, quiet_frames, amp in ((51, 6, 1), (52, 12, 2), (53, 25, 1), (54, 40, 3)):
+        pcm = synth_pcm(160, seed=seed)
+        pcm[40 * 1152:60 * 1152] = 0                                  # silence ...
+        q = rng.integers(-amp, amp + 1, size=(quiet_frames * 1152, 2)).astype(np.int16)
+        pcm[60 * 1152:(60 + quiet_frames) * 1152] = q                 # ... then a row of frames that are active but take no (or hardly any) big values
+        for nbits in (0, 64):
+            msg = rng.integers(0, 2, size=nbits).astype(np.uint8) if nbits else None
+            r, o = ctx.encode_pcm(pcm, 44100, 128, msg), orc.encode(pcm, 44100, 128, msg)
+            assert o["rc"] == 0 and r["mp3"] == o["mp3"] and r["hide_offset"] == o["hide_offset"], (seed, nbits)
+            passes.append(r["rate_passes"])
+    assert passes == [1] * len(passes), passes

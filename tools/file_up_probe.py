@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""A/B inside one process: one-file calls with the whole file uploaded by the helper thread (default) and with MP3S_NO_FILE_UP=1
+"""A/B inside one process: one-file calls with the whole file uploaded by the helper thread (default) and with MP3S_OPT_FILE_UP = 0
 (each chunk's bytes by the calling thread), alternating, medians.  usage: file_up_probe.py [frames ...]"""
 import os, sys, time, statistics
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -17,8 +17,7 @@ for frames in [int(a) for a in sys.argv[1:]] or [10000, 100000]:
         ctx.hide_message(mp3, "hello")
     for rep in range(30 if frames <= 10000 else 10):
         for mode in ("file_up", "per_chunk"):
-            if mode == "per_chunk": os.environ["MP3S_NO_FILE_UP"] = "1"
-            else: os.environ.pop("MP3S_NO_FILE_UP", None)
+            ctx.set_option("file_up", 0 if mode == "per_chunk" else 1)
             t0 = time.perf_counter(); ctx.hide_message(mp3, "hello"); t[mode].append((time.perf_counter() - t0) * 1e3)
-    os.environ.pop("MP3S_NO_FILE_UP", None)
+    ctx.set_option("file_up", 1)
     print(frames, "frames:", {k: (round(statistics.median(v), 3), round(min(v), 3)) for k, v in t.items()}, "(median, min) ms")
