@@ -43,7 +43,7 @@ float rehearse(LanePool &lp, hipStream_t comp, hipStream_t up, hipStream_t down,
         if (ok && dec) ok = hipEventRecord(lp.ev[k][5], dec) == hipSuccess && hipStreamWaitEvent(comp, lp.ev[k][5], 0) == hipSuccess;
         ok = ok && launch_spin(comp, 50) == 0 && launch_noop(comp) == 0 && hipEventRecord(lp.ev[k][2], comp) == hipSuccess;
         if (ok && tail) ok = hipStreamWaitEvent(tail, lp.ev[k][2], 0) == hipSuccess;
-        ok = ok && launch_spin(ts, 10) == 0 && launch_spin(ts, 10) == 0 && launch_spin(ts, 20) == 0 && hipEventRecord(lp.ev[k][4], ts) == hipSuccess &&
+        ok = ok && launch_spin(ts, 25) == 0 && launch_spin(ts, 25) == 0 && launch_spin(ts, 30) == 0 && hipEventRecord(lp.ev[k][4], ts) == hipSuccess &&
              hipStreamWaitEvent(down, lp.ev[k][4], 0) == hipSuccess &&
              hipMemcpyAsync(lp.h_buf + (4 + k) * kRehearseBytes, lp.d_buf + k * kRehearseBytes, kRehearseBytes, hipMemcpyDeviceToHost, down) == hipSuccess &&
              hipEventRecord(lp.ev[k][3], down) == hipSuccess;
@@ -62,14 +62,14 @@ std::vector<LanePool> &lane_pools() { static auto *v = new std::vector<LanePool>
 }  // namespace
 
 // What the rehearsal decides by (round 4: relative to a baseline measured in the same process, no absolute times).  The
-// miniature on ONE stream, stage after stage, is the unshared baseline `serial`: 4 x (copy + 60 + 100 + 40 us + copy) and the
-// gaps between them, 1.03 ms on the boxes seen.  On streams that really run side by side the four jobs take 0.86 - 0.89 of that
-// (0.75 - 0.83 with the tail on a stream of its own; the hand-overs between streams cost about 50 us per job, so the ideal
-// "first job + 3 x the longest stage" = 0.66 is not reached); with a stage on the compute stream's hardware queue they take
-// 1.1 - 1.4 x serial -- the event ping-pong inside one queue is slower than no overlap at all.  A choice of lanes is good when it
-// gets the miniature through in kOverlapOk x serial; the search stops at the first good one, never runs more than kMaxRehearsals
-// miniatures (~1 ms each) or longer than kMaxRehearsalMs, and what it measured is kept with the choice (mp3s_pipe_stats /
-// mp3s_ctx_run_stats: rehearsal_ms, rehearsals, lanes, queue_shared).
+// miniature on ONE stream, stage after stage, is the unshared baseline `serial`: 4 x (copy + 60 + 100 + 80 us + copy) and the
+// gaps between them, 1.19 ms on the boxes seen.  On streams that really run side by side the four jobs take 0.95 - 1.03 ms
+// (0.69 - 0.78 with the tail on a stream of its own); with a stage on the compute stream's hardware queue 1.2 - 2.7 ms -- the event
+// ping-pong inside one queue is slower than no overlap at all.  EVERY rotation and every tail candidate is tried once and the
+// fastest taken: "the first good one" picked arrangements whose real jobs then ran 15 - 30 % slower than another's (the
+// miniature's good and better are 5 % apart, the pipeline's are not).  That is 9 miniatures, 10 - 12.5 ms; never more than
+// kMaxRehearsals or kMaxRehearsalMs.  `queue_shared` = not even the fastest got under kOverlapOk x serial; what was measured is kept
+// with the choice (mp3s_pipe_stats / mp3s_ctx_run_stats: rehearsal_ms, rehearsals, lanes, queue_shared).
 constexpr float kOverlapOk = 0.94f;
 constexpr int kMaxRehearsals = 12;
 constexpr double kMaxRehearsalMs = 15.0;
@@ -136,7 +136,9 @@ int pick_lanes(mp3s_ctx *c, hipStream_t *up, hipStream_t *down, hipStream_t *huf
     // the context's own stream with the rotations of the lanes, until one gets the miniature through as an unshared pipeline does
     int best = 0, best_cs = -1;
     float best_ms = 1e9f;
-    for (int r = 0; r < 4 && best_ms > good && may_run(); r++) {
+    // (all four, and the fastest of them: "the first good one" took rotations whose real jobs then ran 15 - 30 % slower than
+    // another rotation's -- good and better are 5 % apart in the miniature and more in the pipeline)
+    for (int r = 0; r < 4 && may_run(); r++) {
         const float ms = run(c->stream, lp.hi[r], lp.hi[(r + 1) & 3], lp.lo[r]);
         if (ms < best_ms) { best_ms = ms; best = r; }
     }
@@ -164,11 +166,10 @@ int pick_lanes(mp3s_ctx *c, hipStream_t *up, hipStream_t *down, hipStream_t *huf
         const float accept = best_ms * (want_tail == 1 ? 1.05f : 0.97f);
         float tail_ms = 1e9f;
         if (trace_on()) seen += " | tail:";
-        for (int ti = 0; ti < 4 && want_tail && may_run(); ti++) {
+        for (int ti = 0; ti < 4 && want_tail && may_run(); ti++) {      // (every candidate: see the rotations)
             if (ti == best_cs) continue;
             const float ms = run(comp_s, lp.hi[best], lp.hi[(best + 1) & 3], lp.lo[best], lp.cs[ti]);
             if (ms < tail_ms) { tail_ms = ms; best_tail = ti; }
-            if (ms <= best_ms * 0.90f) break;      // as good as a tail stream gets
         }
         if (best_tail >= 0 && tail_ms > accept) best_tail = -1;
         if (best_tail >= 0) *tail = lp.cs[best_tail];

@@ -42,3 +42,13 @@ def test_latest_bench_line_has_the_contract_fields():
         for k in ("h2d_kernels_d2h", "bytes_to_bytes_one_at_a_time", "decode_steady"):
             assert line["regions"][k]["batches"] >= 10 and line["regions"][k]["ms_per_batch"] > 0, k
         assert line["decode_only"]["steps"] >= 10 and line["config"]["chain_verdict_units_to_redo"] == 0
+    # round 4: where the traffic and instruction counts come from, the sustained region, what a context's first call costs
+    if "sustained" in line and line["sustained"]:
+        u = line["sustained"]
+        assert u["seconds"] >= 4.5 and u["batches"] > 1000 and 0.9 < u["last_over_first"] < 1.1
+        assert abs(u["frames_per_s"] - line["config"]["frames_per_gpu"] * line["n_gpus"] * u["batches"] / u["seconds"]) / u["frames_per_s"] < 0.01
+        assert "device" in u and "sclk_mhz" in u["device"]
+        assert r["traffic_source"] and line["roofline_alu"]["pmc_source"]
+        fc = line["regions"]["single_file_10k"]["first_call"]
+        assert fc["rehearsals"] <= 12 and fc["ms"] > fc["rehearsal_ms"] >= 0
+
