@@ -740,13 +740,15 @@ __global__ __launch_bounds__(TW * 64 * 2, TW == 4 ? 2 : 4) void k_dec_synth_fast
     const int orow = emit ? tl - 15 : OUT;
     uint16_t *const oslot = ot16 + orow * OROW * 2 + ch;
     const uint32_t emit_m = emit ? 0xffffffffu : 0u;
-    auto window_read = [&](int s, double (&u)[16]) {
+    // the V values of taps 8 half .. 8 half + 7 of window s: eight at a time (16 registers; all sixteen at once put the kernel at 123
+    // VGPRs, one SIMD's whole register file for its four waves, with no room for a wave of the neighbouring batches' kernels)
+    auto window_read = [&](int s, int half, double (&u)[8]) {
         const double *e0 = &ex[p][ch][2 * s][tlc], *e1 = &ex[p][ch][2 * s + 1][tlc];
 #pragma unroll
-        for (int jj = 0; jj < 16; jj++) u[jj] = (jj & 1 ? e1 : e0)[-jj];
+        for (int j = 0; j < 8; j++) { const int jj = 8 * half + j; u[j] = (jj & 1 ? e1 : e0)[-jj]; }
         if (!full_hist) {                                   // (wave-uniform, rare: a stream starts inside the tile)
 #pragma unroll
-            for (int jj = 0; jj < 16; jj++) if (jj > lim) u[jj] = 0.0;      // before the stream started the fifo holds zeros
+            for (int j = 0; j < 8; j++) if (8 * half + j > lim) u[j] = 0.0;      // before the stream started the fifo holds zeros
         }
     };
     float *const fslot = reinterpret_cast<float *>(pcm_out) + ((valid ? t - (long)n_halo * 36 : 0) * 32) * nch + ch;
@@ -847,29 +849,31 @@ __global__ __launch_bounds__(TW * 64 * 2, TW == 4 ? 2 : 4) void k_dec_synth_fast
             ex[p][ch][2][tl] = va1;
             ex[p][ch][3][tl] = vb1;
             __syncthreads();                                        // (its wait covers the taps asked for above)
-            double u[16];
-            // ---- window i: its V values from LDS, alone in flight; then the sum, its second half of the taps under the first
-            window_read(0, u);
+            double u[8];
+            // ---- window i, eight taps at a time: V values from LDS, wait (for them and for the piece asked for a step earlier), ask for
+            //      the next piece, multiply
+            window_read(0, 0, u);
             MP3S_ARRIVED(); nxt = ld8(Wtab + i * 16 + 8); MP3S_GO();
             double sum = dot8(u, cur, 0.0); MP3S_GO();
             cur = nxt;
+            window_read(0, 1, u);
             MP3S_ARRIVED(); nxt = ld8(Wtab + (i + 1) * 16); MP3S_GO();
-            sum = dot8(u + 8, cur, sum);
+            sum = dot8(u, cur, sum);
             window_emit(i, sum); MP3S_GO();
             cur = nxt;
             // ---- window i + 1; under its second half the first piece of the next interval: (h, t + 1), or (1, 0) behind (0, 7);
             //      behind the last one: any row
-            MP3S_ARRIVED();
-            window_read(1, u);
+            window_read(1, 0, u);
             MP3S_ARRIVED(); nxt = ld8(Wtab + (i + 1) * 16 + 8); MP3S_GO();
             sum = dot8(u, cur, 0.0); MP3S_GO();
             cur = nxt;
+            window_read(1, 1, u);
             {
                 const int hn = tt == 7 ? 1 : h, tn = tt == 7 ? 0 : tt + 1;
                 const int kn = hn ? 31 - 2 * tn : 17 + 2 * tn;
                 MP3S_ARRIVED(); nxt = ld8(C32 + (kn >> 1) * 16); MP3S_GO();
             }
-            sum = dot8(u + 8, cur, sum);
+            sum = dot8(u, cur, sum);
             window_emit(i + 1, sum); MP3S_GO();
             cur = nxt;
             p ^= 1;
