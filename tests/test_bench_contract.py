@@ -10,9 +10,13 @@ HBM_PEAK = 8000.0
 
 
 def test_latest_bench_line_has_the_contract_fields():
-    base = json.load(open(os.path.join(ROOT, "BASELINE.json")))
     latest = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_bench.json")))[-1]
-    line = json.loads(open(latest).read().strip().splitlines()[-1])
+    check_line(json.loads(open(latest).read().strip().splitlines()[-1]))
+
+
+def check_line(line, full=True):
+    """`full`: a default run (every region, 200+ batches of the steady state); otherwise a shortened run of the same script"""
+    base = json.load(open(os.path.join(ROOT, "BASELINE.json")))
     assert line["metric"] == base["metric"]
     if base.get("unit"):
         assert line["unit"] in base["unit"] or base["unit"] in line["unit"]
@@ -27,6 +31,9 @@ def test_latest_bench_line_has_the_contract_fields():
     assert abs(r["achieved"] - r["algorithmic_bytes_per_launch"] / (r["kernel_ms_per_launch"] * 1e-3) / 1e9) / r["achieved"] < 0.01
     c = line["cpu_baseline"]
     assert c["kind"] in ("reference", "port") and c["cores"] >= 1 and c["value"] > 0 and c["sample"]
+    if not full:
+        assert line["parity_checked"] is True and line["e2e_steady"]["frames_per_s"] > 0 and line["regions"]["single_file_10k"]["ms_per_batch"] > 0
+        return
     # whole-job value = frames of all ranks / step time
     assert abs(line["value"] - line["config"]["frames_per_gpu"] * line["n_gpus"] / (line["ms_per_step"] * 1e-3)) / line["value"] < 0.01
     assert line["parity_checked"] is True
@@ -51,4 +58,32 @@ def test_latest_bench_line_has_the_contract_fields():
         assert r["traffic_source"] and line["roofline_alu"]["pmc_source"]
         fc = line["regions"]["single_file_10k"]["first_call"]
         assert fc["rehearsals"] <= 12 and fc["ms"] > fc["rehearsal_ms"] >= 0
+
+
+import subprocess
+import sys
+
+import pytest
+
+
+@pytest.mark.gpu
+def test_a_live_run_keeps_the_contract():
+    """bench.py itself, shortened (2 000 frames, 5 steps, 1 s of `sustained`, 1 s of CPU baseline), on the test box's GPU: one json line
+    on stdout, every field the driver reads, roofline and cpu_baseline consistent, traffic and instruction counts measured in the
+    run (the committed line above is checked for the full-size numbers; this catches a bench.py that no longer runs)"""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "5", "--warmup", "2", "--frames", "2000", "--no-config5",
+                        "--no-single-file-100k", "--e2e-batches", "40", "--sustained-seconds", "1", "--cpu-seconds", "1", "--cpu-seconds-all", "0"],
+                       env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, r.stdout[-2000:]
+    line = json.loads(lines[0])
+    check_line(line, full=False)
+    assert line["n_gpus"] == 1 and line["steps"] == 5 and line["config"]["frames_per_gpu"] == 2000
+    assert line["sustained"]["batches"] > 100 and "sclk_mhz" in line["sustained"]["device"]
+    # (where rocprofv3 is installed the counters are this run's own)
+    if os.path.exists("/opt/rocm/bin/rocprofv3"):
+        assert line["roofline"]["traffic_source"].startswith("live") and line["roofline"]["traffic"] > 0, line["roofline"]
+        assert line["roofline_alu"]["pmc_source"].startswith("live")
 
