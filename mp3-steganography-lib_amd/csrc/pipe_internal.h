@@ -155,6 +155,7 @@ struct mp3s_pipe {
     // bit packing) on another one, under the decode transforms of the next job; e_rate orders it behind the job's rate loop
     hipStream_t s_tail = nullptr;
     int last_tail = -1;                  // slot of the job whose tail was issued last
+    Job *pending_down = nullptr;         // (depth 1 - 2) the job issued last, whose copy down is queued behind the next job's issue or by its collector
     hipEvent_t e_dec[2] = {nullptr, nullptr};
     bool dec_used[2] = {false, false};
     unsigned issued = 0;

@@ -600,10 +600,33 @@ int issue_down(mp3s_pipe *P, Job &j, Slot &s)
 
 namespace {
 
+// A pipe of depth 1 or 2 has no job queued far enough ahead to hide this: the copy of a job's results waits for the job's last
+// kernel, and queued at once it holds up the copy of the NEXT job's inputs (queued behind it on another stream, on engines the
+// runtime shares between the copy streams) until then -- the device sits idle for that job's front end.  There the copy down is
+// queued behind the next job's issue instead, or by the collector if that comes first (as the one-file calls do since round 3;
+// deeper pipes have their jobs' inputs up long before the job in front asks for its results).
 int issue_fast(mp3s_pipe *P, Job &j, Slot &s, size_t blob_len, int max_p23)
 {
-    const int rc = issue_front(P, j, s, blob_len, max_p23, false);
-    return rc ? rc : issue_back(P, j, s, false);
+    const bool defer = P->depth <= 2 && !P->internal;
+    int rc = issue_front(P, j, s, blob_len, max_p23, false);
+    if (!rc) rc = issue_back(P, j, s, false, defer);
+    if (P->pending_down && P->pending_down != &j) {           // the job in front: its results may come down now
+        Job *q = P->pending_down;
+        P->pending_down = nullptr;
+        const int rd = issue_down(P, *q, P->slots[(size_t)q->slot]);
+        if (!rc) rc = rd;
+    }
+    if (!rc && defer && j.down_pending) P->pending_down = &j;
+    return rc;
+}
+
+// the collector's half of the above: the job's copy down, if nobody has queued it yet (mu_issue taken here)
+void down_now(mp3s_pipe *P, Job &j, Slot &s)
+{
+    if (P->depth > 2 || P->internal) return;
+    std::lock_guard<std::mutex> gi(P->mu_issue);
+    if (P->pending_down == &j) P->pending_down = nullptr;
+    if (j.down_pending) (void)issue_down(P, j, s);
 }
 
 }  // namespace
@@ -958,6 +981,7 @@ int mp3s_pipe_collect(mp3s_pipe *P, int64_t *ticket, mp3s_buf **owner, mp3s_file
     double span_ms = -1;
     if (j->state == Job::ISSUED) {
         (void)hipSetDevice(P->c->device);
+        down_now(P, *j, s);
         if (hipEventSynchronize(s.e_down) != hipSuccess) rc = fail(MP3S_E_HIP, "waiting for the job's results failed");
         else {
             float ms = 0;
@@ -1064,6 +1088,7 @@ int mp3s_pipe_collect_block(mp3s_pipe *P, int64_t *ticket, mp3s_buf **owner, mp3
     bool fast_ok = false, resolved = false;
     if (j->state == Job::ISSUED) {
         (void)hipSetDevice(P->c->device);
+        down_now(P, *j, s);
         if (hipEventSynchronize(s.e_down) != hipSuccess) rc = fail(MP3S_E_HIP, "waiting for the job's results failed");
         else {
             std::lock_guard<std::mutex> gi(P->mu_issue);
