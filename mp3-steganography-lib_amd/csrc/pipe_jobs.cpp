@@ -651,6 +651,13 @@ void run_slow(mp3s_pipe *P, Job &j)   // mu_issue held
         fp[i] = j.files[i].first; fl[i] = j.files[i].second;
         mp[i] = j.clear_all ? nullptr : j.msgs[i].first; ml[i] = j.clear_all ? 0 : j.msgs[i].second;
     }
+    // (a shallow pipe's last issued job may still wait for its copy down to be queued: the synchronous path below writes the PCM and
+    // Huffman buffers it would read)
+    if (P->pending_down && P->pending_down != &j) {
+        Job *q = P->pending_down;
+        P->pending_down = nullptr;
+        (void)issue_down(P, *q, P->slots[(size_t)q->slot]);
+    }
     (void)hipStreamSynchronize(P->s_huff);   // the synchronous path uses the same Huffman output buffers
     if (P->s_dec) (void)hipStreamSynchronize(P->s_dec);   // ... and the decode scratch
     (void)hipStreamSynchronize(P->s_down);   // ... and the PCM buffer a download may still be reading

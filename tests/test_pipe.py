@@ -342,3 +342,42 @@ def test_block_jobs_beside_whole_files(ctx, mlib):
                 pipe.close()
             assert b"".join(got) == bytes(whole["data"])
             assert st["slow"] == 0, st
+
+
+def test_shallow_pipes_keep_a_job_whose_copy_down_is_still_to_come(mlib):
+    """pipes of depth 1 and 2 queue a job's copy down behind the NEXT job's issue (round 4).  If that next job takes the synchronous
+    path -- which decodes into the context's PCM buffer -- the copy has to be queued first: a decode job followed by a hide job the
+    stages do not take (files of two sampling rates: two device batches) and by ordinary ones, results = the one-call results, for every
+    depth (tools/soak_pipe.py found this: 51 wrong decode jobs in 55 000)"""
+    import time
+    from synth_pcm import synth_pcm
+    ctx = mlib.Context(0)
+    try:
+        a44 = [bytes(ctx.encode_pcm(synth_pcm(n, seed=90 + n), 44100, 128, None)["mp3"]) for n in (300, 500, 120)]
+        b48 = bytes(ctx.encode_pcm(synth_pcm(400, rate=48000, seed=95), 48000, 192, None)["mp3"])
+        want = {id(f): bytes(ctx.decode_file(f)["data"]) for f in a44 + [b48]}
+        hid = {id(f): bytes(ctx.hide_message(f, "after")["data"]) for f in a44 + [b48]}
+        for depth in (1, 2, 3):
+            for rep in range(3):
+                pipe = mlib.Pipe(ctx, depth=depth, max_job_bytes=1 << 21, scan_threads=2)
+                try:
+                    jobs = [("d", [a44[0]]), ("h", [a44[1], b48]), ("d", [a44[1]]), ("h", [b48, a44[2]]), ("d", [a44[2]]), ("h", [a44[1]]), ("d", [a44[0], a44[1]])]
+                    got, nxt = [], 0
+                    while len(got) < len(jobs):
+                        while nxt < len(jobs):
+                            k, files = jobs[nxt]
+                            t = pipe.submit_decode(files) if k == "d" else pipe.submit(files, ["after"] * len(files))
+                            if t is None:
+                                break
+                            nxt += 1
+                        time.sleep(0.03)                  # (the workers issue what was submitted before the oldest job is asked for)
+                        got.append(pipe.collect()[1])
+                    for (k, files), res in zip(jobs, got):
+                        for f, r in zip(files, res):
+                            assert not isinstance(r, Exception)
+                            assert bytes(r["data"]) == (want if k == "d" else hid)[id(f)], (depth, rep, k, len(f))
+                    assert pipe.stats()["slow"] >= 2
+                finally:
+                    pipe.close()
+    finally:
+        ctx.close()
