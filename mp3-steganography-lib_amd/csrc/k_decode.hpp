@@ -723,11 +723,15 @@ __global__ __launch_bounds__(TW * 64 * 2, TW == 4 ? 2 : 4) void k_dec_synth_fast
     const double *C32 = c_tab.synth_fast, *C16 = c_tab.synth_fast + 256, *C8 = c_tab.synth_fast + 320, *C4 = c_tab.synth_fast + 336;
     uint32_t redo = 0;
     int p = 0;
-    // Outputs i = 16 h + 2 t and i + 1 per barrier interval.  V[i] = X[16+i] (h = 0) or -X[48-i] (h = 1), V[32+i] = -X[16-i]
-    // or -X[i-16]: in both halves the k of V[i] and of V[32+i] have the same number of trailing zero bits as 2t, so the
-    // code of an interval (which level, how many terms) is the same for h = 0 and h = 1 and only the table row differs.
-    // Stages of an interval: odd-k sums A1, B1 (16 terms), even-k sums A0, B0 (8 / 4 / 2 terms), barrier, the two window
-    // sums W0, W1 (16 taps); each stage requests the scalar operands of the next one before it computes.
+    // Outputs 2t, 32 - 2t, 2t + 1 and 31 - 2t per barrier interval (t = 0: outputs 0, 16, 1 and 31).  Outputs i and 32 - i read
+    // the same two X of every slot: V[i] = X[16+i], V[32+i] = -X[16-i] for i <= 16, and V[32-i] = -X[16+i], V[64-i] = -X[16-i]
+    // -- so an interval computes A0 = X[16+2t], B0 = X[16-2t] (8 / 4 / 2 terms, nothing to multiply for t = 0), A1 = X[17+2t],
+    // B1 = X[15-2t] (16 terms each) ONCE, exchanges (A0, -B0, A1, -B1), and every set of sixteen V values read back from the
+    // other lanes feeds two window sums; the signs of the mirrored output live in its taps (DevTables::synth_window_f:
+    // (-a) * w and a * (-w) are the same double, so the sums are what round 3's kernel, which computed every X twice, got).
+    // 853 instead of 1 192 multiply-adds and 256 instead of 512 LDS reads per slot, 8 instead of 16 barriers.
+    // Stages of an interval: odd-k sums A1, B1, even-k sums A0, B0, barrier, four window sums; each stage requests the scalar
+    // operands of the next one before it computes.
     // ---- the window sums.  Two rules shape this loop:
     //  * Scalar loads (matrix rows, window taps) and LDS reads (the V values of 16 slots) share ONE counter, and while both
     //    kinds are in flight it can only be waited to zero.  So no scalar load is in flight while a window's LDS reads are
@@ -740,10 +744,11 @@ __global__ __launch_bounds__(TW * 64 * 2, TW == 4 ? 2 : 4) void k_dec_synth_fast
     const int orow = emit ? tl - 15 : OUT;
     uint16_t *const oslot = ot16 + orow * OROW * 2 + ch;
     const uint32_t emit_m = emit ? 0xffffffffu : 0u;
-    // the V values of taps 8 half .. 8 half + 7 of window s: eight at a time (16 registers; all sixteen at once put the kernel at 123
-    // VGPRs, one SIMD's whole register file for its four waves, with no room for a wave of the neighbouring batches' kernels)
-    auto window_read = [&](int s, int half, double (&u)[8]) {
-        const double *e0 = &ex[p][ch][2 * s][tlc], *e1 = &ex[p][ch][2 * s + 1][tlc];
+    // the V values of taps 8 half .. 8 half + 7: even taps from exchange slot se, odd taps from slot so; eight at a time (16
+    // registers; all sixteen at once put the kernel at 123 VGPRs, one SIMD's whole register file for its four waves, with no
+    // room for a wave of the neighbouring batches' kernels)
+    auto window_read = [&](int se, int so, int half, double (&u)[8]) {
+        const double *e0 = &ex[p][ch][se][tlc], *e1 = &ex[p][ch][so][tlc];
 #pragma unroll
         for (int j = 0; j < 8; j++) { const int jj = 8 * half + j; u[j] = (jj & 1 ? e1 : e0)[-jj]; }
         if (!full_hist) {                                   // (wave-uniform, rare: a stream starts inside the tile)
@@ -768,7 +773,7 @@ __global__ __launch_bounds__(TW * 64 * 2, TW == 4 ? 2 : 4) void k_dec_synth_fast
         const int q = ax < 2147483648.0 ? (int)x : 0;
         oslot[io * nch] = (uint16_t)q;
     };
-    const double *Wtab = &c_tab.synth_window_t[0][0];
+    const double *Wtab = &c_tab.synth_window_f[0][0];
     // Scalar operands travel in pieces of eight doubles (16 scalar registers, one s_load_dwordx16): a step waits for the piece
     // it multiplies with, asks for the next one, and multiplies -- two pieces live at any time (round 3 kept whole rows: two
     // 16-term rows, two 8-term rows and a row of taps were 112 scalar registers at the peak, and the allocator spilled 65 of
@@ -784,100 +789,132 @@ __global__ __launch_bounds__(TW * 64 * 2, TW == 4 ? 2 : 4) void k_dec_synth_fast
     };
 #define MP3S_ARRIVED() do { __builtin_amdgcn_s_waitcnt(0xc07f); __builtin_amdgcn_sched_barrier(0); } while (0)
 #define MP3S_GO() __builtin_amdgcn_sched_barrier(0)
-    d8 cur = ld8(C32 + (17 >> 1) * 16);                             // interval (h = 0, t = 0): k = 17, first half of its row
-#pragma unroll 1
-    for (int h = 0; h < 2; h++) {
+    d8 cur = ld8(C32 + (17 >> 1) * 16);                             // interval t = 0: k = 17, first half of its row
 #pragma unroll
-        for (int tt = 0; tt < 8; tt++) {
-            const int i = 16 * h + 2 * tt;
-            // odd k: V[i+1] = X[17+2t] | -X[31-2t],  V[32+i+1] = -X[15-2t] | -X[2t+1];  row of odd k: (k-1)/2
-            const int ka1 = h ? 31 - 2 * tt : 17 + 2 * tt, kb1 = h ? 2 * tt + 1 : 15 - 2 * tt;
-            // even k: V[i] = X[16+2t] | -X[32-2t],  V[32+i] = -X[16-2t] | -X[2t]
-            const int ka0 = h ? 32 - 2 * tt : 16 + 2 * tt, kb0 = h ? 2 * tt : 16 - 2 * tt;
-            const double *rowA1 = C32 + (ka1 >> 1) * 16, *rowB1 = C32 + (kb1 >> 1) * 16;
-            // ---- the odd-k sums: four pieces
-            MP3S_ARRIVED(); d8 nxt = ld8(rowA1 + 8); MP3S_GO();
-            double va1 = dot8(d16, cur, 0.0); MP3S_GO();
+    for (int tt = 0; tt < 8; tt++) {
+        // odd k: A1 = X[17+2t], B1 = X[15-2t]; row of odd k: (k-1)/2.  even k: A0 = X[16+2t], B0 = X[16-2t]
+        const int ka1 = 17 + 2 * tt, kb1 = 15 - 2 * tt, ka0 = 16 + 2 * tt, kb0 = 16 - 2 * tt;
+        const double *rowA1 = C32 + (ka1 >> 1) * 16, *rowB1 = C32 + (kb1 >> 1) * 16;
+        // outputs of the interval and the rows of their taps
+        const int oa = 2 * tt, ob = tt ? 32 - 2 * tt : 16, oc = 2 * tt + 1, od = 31 - 2 * tt;
+        const double *Wa = Wtab + oa * 16, *Wb = Wtab + ob * 16, *Wc = Wtab + oc * 16, *Wd = Wtab + od * 16;
+        d8 nxt;
+        // ---- the odd-k sums: four pieces
+        MP3S_ARRIVED(); nxt = ld8(rowA1 + 8); MP3S_GO();
+        double va1 = dot8(d16, cur, 0.0); MP3S_GO();
+        cur = nxt;
+        MP3S_ARRIVED(); nxt = ld8(rowB1); MP3S_GO();
+        va1 = dot8(d16 + 8, cur, va1); MP3S_GO();
+        cur = nxt;
+        MP3S_ARRIVED(); nxt = ld8(rowB1 + 8); MP3S_GO();
+        double vb1 = dot8(d16, cur, 0.0); MP3S_GO();
+        cur = nxt;
+        // ---- the even-k sums (8 / 4 / 2 terms, or none), then the first half of the taps of output 2t
+        double va0, vb0;
+        if (tt == 0) {                                          // A0 = B0 = X[16] for output 0, X[32] = 0 and X[0] for output 16
+            MP3S_ARRIVED(); nxt = ld8(Wa); MP3S_GO();
+            vb1 = -dot8(d16 + 8, cur, vb1); MP3S_GO();
+            va0 = x16; vb0 = -x0;
             cur = nxt;
-            MP3S_ARRIVED(); nxt = ld8(rowB1); MP3S_GO();
-            va1 = dot8(d16 + 8, cur, va1); MP3S_GO();
-            if (h) va1 = -va1;
+        } else if (tt & 1) {
+            MP3S_ARRIVED(); nxt = ld8(C16 + ((ka0 - 2) >> 2) * 8); MP3S_GO();
+            vb1 = -dot8(d16 + 8, cur, vb1); MP3S_GO();
             cur = nxt;
-            MP3S_ARRIVED(); nxt = ld8(rowB1 + 8); MP3S_GO();
-            double vb1 = dot8(d16, cur, 0.0); MP3S_GO();
+            MP3S_ARRIVED(); nxt = ld8(C16 + ((kb0 - 2) >> 2) * 8); MP3S_GO();
+            va0 = dot8(d8v, cur, 0.0); MP3S_GO();
             cur = nxt;
-            // ---- the even-k sums (8 / 4 / 2 terms, or none), then the first half of the taps of window i
-            double va0, vb0;
-            if (tt == 0) {                                          // k = 16 | 32 (X[32] = 0) and k = 16 | 0: nothing to multiply
-                MP3S_ARRIVED(); nxt = ld8(Wtab + i * 16); MP3S_GO();
-                vb1 = -dot8(d16 + 8, cur, vb1); MP3S_GO();
-                va0 = h ? 0.0 : x16; vb0 = h ? -x0 : -x16;
-                cur = nxt;
-            } else if (tt & 1) {
-                MP3S_ARRIVED(); nxt = ld8(C16 + ((ka0 - 2) >> 2) * 8); MP3S_GO();
-                vb1 = -dot8(d16 + 8, cur, vb1); MP3S_GO();
-                cur = nxt;
-                MP3S_ARRIVED(); nxt = ld8(C16 + ((kb0 - 2) >> 2) * 8); MP3S_GO();
-                va0 = dot8(d8v, cur, 0.0); MP3S_GO();
-                cur = nxt;
-                MP3S_ARRIVED(); nxt = ld8(Wtab + i * 16); MP3S_GO();
-                vb0 = -dot8(d8v, cur, 0.0); MP3S_GO();
-                cur = nxt;
+            MP3S_ARRIVED(); nxt = ld8(Wa); MP3S_GO();
+            vb0 = -dot8(d8v, cur, 0.0); MP3S_GO();
+            cur = nxt;
+        } else {
+            // 4- and 2-term rows: both rows of the interval in one request
+            d4t a4, b4; d2t a2, b2;
+            MP3S_ARRIVED();
+            if (tt & 2) { a4 = *reinterpret_cast<const d4t *>(C8 + ((ka0 - 4) >> 3) * 4); b4 = *reinterpret_cast<const d4t *>(C8 + ((kb0 - 4) >> 3) * 4); }
+            else { a2 = *reinterpret_cast<const d2t *>(C4 + ((ka0 - 8) >> 4) * 2); b2 = *reinterpret_cast<const d2t *>(C4 + ((kb0 - 8) >> 4) * 2); }
+            MP3S_GO();
+            vb1 = -dot8(d16 + 8, cur, vb1); MP3S_GO();
+            MP3S_ARRIVED(); nxt = ld8(Wa); MP3S_GO();
+            va0 = 0.0; vb0 = 0.0;
+            if (tt & 2) {
+#pragma unroll
+                for (int j = 0; j < 4; j++) { va0 = __builtin_fma(d4[j], a4[j], va0); vb0 = __builtin_fma(d4[j], b4[j], vb0); }
             } else {
-                // 4- and 2-term rows: both rows of the interval in one request
-                d4t a4, b4; d2t a2, b2;
-                MP3S_ARRIVED();
-                if (tt & 2) { a4 = *reinterpret_cast<const d4t *>(C8 + ((ka0 - 4) >> 3) * 4); b4 = *reinterpret_cast<const d4t *>(C8 + ((kb0 - 4) >> 3) * 4); }
-                else { a2 = *reinterpret_cast<const d2t *>(C4 + ((ka0 - 8) >> 4) * 2); b2 = *reinterpret_cast<const d2t *>(C4 + ((kb0 - 8) >> 4) * 2); }
-                MP3S_GO();
-                vb1 = -dot8(d16 + 8, cur, vb1); MP3S_GO();
-                MP3S_ARRIVED(); nxt = ld8(Wtab + i * 16); MP3S_GO();
-                va0 = 0.0; vb0 = 0.0;
-                if (tt & 2) {
 #pragma unroll
-                    for (int j = 0; j < 4; j++) { va0 = __builtin_fma(d4[j], a4[j], va0); vb0 = __builtin_fma(d4[j], b4[j], vb0); }
-                } else {
-#pragma unroll
-                    for (int j = 0; j < 2; j++) { va0 = __builtin_fma(d2[j], a2[j], va0); vb0 = __builtin_fma(d2[j], b2[j], vb0); }
-                }
-                vb0 = -vb0; MP3S_GO();
-                cur = nxt;
+                for (int j = 0; j < 2; j++) { va0 = __builtin_fma(d2[j], a2[j], va0); vb0 = __builtin_fma(d2[j], b2[j], vb0); }
             }
-            if (h && tt) va0 = -va0;
-            ex[p][ch][0][tl] = va0;
-            ex[p][ch][1][tl] = vb0;
-            ex[p][ch][2][tl] = va1;
-            ex[p][ch][3][tl] = vb1;
-            __syncthreads();                                        // (its wait covers the taps asked for above)
-            double u[8];
-            // ---- window i, eight taps at a time: V values from LDS, wait (for them and for the piece asked for a step earlier), ask for
-            //      the next piece, multiply
-            window_read(0, 0, u);
-            MP3S_ARRIVED(); nxt = ld8(Wtab + i * 16 + 8); MP3S_GO();
+            vb0 = -vb0; MP3S_GO();
+            cur = nxt;
+        }
+        ex[p][ch][0][tl] = va0;
+        ex[p][ch][1][tl] = vb0;
+        ex[p][ch][2][tl] = va1;
+        ex[p][ch][3][tl] = vb1;
+        __syncthreads();                                        // (its wait covers the taps asked for above)
+        double u[8];
+        // ---- eight taps at a time: V values from LDS, wait (for them and for the piece asked for a step earlier), ask for the next
+        //      piece, multiply
+        if (tt == 0) {
+            // output 0: every tap reads X[16] (slot 0); output 16: X[0] (slot 1) under taps that are zero where V[16] stands
+            window_read(0, 0, 0, u);
+            MP3S_ARRIVED(); nxt = ld8(Wa + 8); MP3S_GO();
             double sum = dot8(u, cur, 0.0); MP3S_GO();
             cur = nxt;
-            window_read(0, 1, u);
-            MP3S_ARRIVED(); nxt = ld8(Wtab + (i + 1) * 16); MP3S_GO();
+            window_read(0, 0, 1, u);
+            MP3S_ARRIVED(); nxt = ld8(Wb); MP3S_GO();
             sum = dot8(u, cur, sum);
-            window_emit(i, sum); MP3S_GO();
+            window_emit(oa, sum); MP3S_GO();
             cur = nxt;
-            // ---- window i + 1; under its second half the first piece of the next interval: (h, t + 1), or (1, 0) behind (0, 7);
-            //      behind the last one: any row
-            window_read(1, 0, u);
-            MP3S_ARRIVED(); nxt = ld8(Wtab + (i + 1) * 16 + 8); MP3S_GO();
+            window_read(1, 1, 0, u);
+            MP3S_ARRIVED(); nxt = ld8(Wb + 8); MP3S_GO();
             sum = dot8(u, cur, 0.0); MP3S_GO();
             cur = nxt;
-            window_read(1, 1, u);
-            {
-                const int hn = tt == 7 ? 1 : h, tn = tt == 7 ? 0 : tt + 1;
-                const int kn = hn ? 31 - 2 * tn : 17 + 2 * tn;
-                MP3S_ARRIVED(); nxt = ld8(C32 + (kn >> 1) * 16); MP3S_GO();
-            }
+            window_read(1, 1, 1, u);
+            MP3S_ARRIVED(); nxt = ld8(Wc); MP3S_GO();
             sum = dot8(u, cur, sum);
-            window_emit(i + 1, sum); MP3S_GO();
+            window_emit(ob, sum); MP3S_GO();
             cur = nxt;
-            p ^= 1;
+        } else {
+            window_read(0, 1, 0, u);
+            MP3S_ARRIVED(); nxt = ld8(Wb); MP3S_GO();
+            double sa = dot8(u, cur, 0.0); MP3S_GO();
+            cur = nxt;
+            MP3S_ARRIVED(); nxt = ld8(Wa + 8); MP3S_GO();
+            double sb = dot8(u, cur, 0.0); MP3S_GO();
+            cur = nxt;
+            window_read(0, 1, 1, u);
+            MP3S_ARRIVED(); nxt = ld8(Wb + 8); MP3S_GO();
+            sa = dot8(u, cur, sa);
+            window_emit(oa, sa); MP3S_GO();
+            cur = nxt;
+            MP3S_ARRIVED(); nxt = ld8(Wc); MP3S_GO();
+            sb = dot8(u, cur, sb);
+            window_emit(ob, sb); MP3S_GO();
+            cur = nxt;
         }
+        // ---- outputs 2t + 1 and 31 - 2t; under the last piece the first piece of the next interval (behind the last one: any row)
+        {
+            window_read(2, 3, 0, u);
+            MP3S_ARRIVED(); nxt = ld8(Wd); MP3S_GO();
+            double sc = dot8(u, cur, 0.0); MP3S_GO();
+            cur = nxt;
+            MP3S_ARRIVED(); nxt = ld8(Wc + 8); MP3S_GO();
+            double sd = dot8(u, cur, 0.0); MP3S_GO();
+            cur = nxt;
+            window_read(2, 3, 1, u);
+            MP3S_ARRIVED(); nxt = ld8(Wd + 8); MP3S_GO();
+            sc = dot8(u, cur, sc);
+            window_emit(oc, sc); MP3S_GO();
+            cur = nxt;
+            {
+                const int tn = tt == 7 ? 0 : tt + 1;
+                MP3S_ARRIVED(); nxt = ld8(C32 + ((17 + 2 * tn) >> 1) * 16); MP3S_GO();
+            }
+            sd = dot8(u, cur, sd);
+            window_emit(od, sd); MP3S_GO();
+            cur = nxt;
+        }
+        p ^= 1;
     }
 #undef MP3S_ARRIVED
 #undef MP3S_GO

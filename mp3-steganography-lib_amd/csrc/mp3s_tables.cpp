@@ -185,6 +185,14 @@ void build()
         T.imdct_kappa = 2 * g18 + (double)dT + 4.2 * u;
         T.synth_eps_g = 2.0 * 32767.0 * dsum * 2.0002 * T.imdct_kappa;
         T.synth_eps_x = 2.0 * 2 * u;
+        for (int i = 0; i < 32; i++)
+            for (int k = 0; k < 16; k++) {
+                double w = T.synth_window_t[i][k];
+                if (i == 0 && (k & 1)) w = -w;
+                if (i == 16 && !(k & 1)) w = 0.0;
+                if (i > 16 && !(k & 1)) w = -w;
+                T.synth_window_f[i][k] = w;
+            }
     }
     for (int sr = 0; sr < 3; sr++) {
         for (int c = 0; c < 3; c++) {

@@ -49,6 +49,11 @@ struct DevTables {
     // leaves rows that differ from the reference's by at most imdct_kappa * (sum of |IMDCT input| of the subband in this
     // and the previous granule); G is that sum over the 32 subbands of a granule and channel
     double synth_eps_g, imdct_kappa;
+    // the window taps as k_dec_synth_fast multiplies them: outputs i and 32 - i read the same V values (V[32 - i] = -V[i],
+    // V[64 - i] = V[32 + i]), so one interval of the kernel sums both from one set of LDS reads and the signs move into the
+    // taps: row i < 16 = synth_window_t[i]; rows 17..31 with their even taps negated; row 0 with its odd taps negated (both
+    // halves of its V pair are +-X[16]); row 16 with its even taps zero (V[16] = X[32] = 0)
+    double synth_window_f[32][16];
     uint8_t rq_map[3][3][32][20];  // [sr][case][subband][18 lines + 2 pad]: five aligned dwords per lane;
                                    // byte = gain selector << 6 | scalefactor slot (see build_rq_map)
     int16_t reorder_src[3][576];   // [sr][dst line] -> src line or -1 (zero)  Frame.py:574-602
