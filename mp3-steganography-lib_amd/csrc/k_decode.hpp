@@ -38,6 +38,19 @@ __device__ __forceinline__ double dpp_f64(double v)
     return __hiloint2double(hi, lo);
 }
 
+// A bound on the largest of a wave's non-negative doubles (NaN counts as the largest): the high words compared as integers
+// (six DPP steps on 32 bits instead of six 64-bit permutes, compares and selects), one unit in the 20th mantissa bit added
+// on the way back.  Only for scales of guards.
+__device__ __forceinline__ double wave_max_bound_f64(double a)
+{
+    uint32_t v = (uint32_t)__double2hiint(a);
+#define MP3S_DPP_MAX(ctrl, rm) v = max(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, ctrl, rm, 0xf, false))
+    MP3S_DPP_MAX(0x111, 0xf); MP3S_DPP_MAX(0x112, 0xf); MP3S_DPP_MAX(0x114, 0xf); MP3S_DPP_MAX(0x118, 0xf);   // row_shr:1, 2, 4, 8
+    MP3S_DPP_MAX(0x142, 0xa); MP3S_DPP_MAX(0x143, 0xc);                                                       // row_bcast:15, 31
+#undef MP3S_DPP_MAX
+    return __hiloint2double(__builtin_amdgcn_readlane((int)v, 63) + 1, 0);
+}
+
 __device__ __forceinline__ double shfl_xor_f64(double v, int mask)
 {
     int lo = __double2loint(v), hi = __double2hiint(v);
@@ -665,8 +678,7 @@ __global__ __launch_bounds__(TW * 64 * 2, TW == 4 ? 2 : 4) void k_dec_synth_fast
         const int g = ga + (lane >> 1), c = lane & 1;
         double gm = 0.0;
         if (G && g <= gb && g < n_granules && c < nch) gm = G[(long)g * 2 + c];
-#pragma unroll
-        for (int d = 32; d >= 1; d >>= 1) { const double o = shfl_xor_f64(gm, d); gm = gm > o ? gm : o; }
+        gm = wave_max_bound_f64(gm);
         if (lane == 0) gmax_s = gm;
     }
     const long t = tile0 - 15 + tl;
@@ -706,22 +718,25 @@ __global__ __launch_bounds__(TW * 64 * 2, TW == 4 ? 2 : 4) void k_dec_synth_fast
     }
     // ---- the largest sum |S| of a slot in this tile (both channels): the scale of the guard
     {
-        double a = asum;
-#pragma unroll
-        for (int d = 32; d >= 1; d >>= 1) { const double o = shfl_xor_f64(a, d); a = a > o ? a : o; }
+        const double a = wave_max_bound_f64(asum);
         if (lane == 0) amax_w[wave] = a;
     }
     __syncthreads();
     double amax = amax_w[0];
 #pragma unroll
     for (int w = 1; w < TW * 2; w++) if (w < TW * nch) amax = amax > amax_w[w] ? amax : amax_w[w];
-    const double eps_a = (c_tab.synth_eps_a * amax + c_tab.synth_eps_g * gmax_s) * eps_scale, eps_x = c_tab.synth_eps_x * eps_scale;
+    // The guard's width for the whole tile, a scalar: synth_xbound * amax bounds every |sample * 32767| of the tile, so the term
+    // that grows with the sample (eps_x |x|: 3 % of the other at most) is taken at that bound instead of per sample; a tile
+    // whose bound leaves int32 (noise from a damaged file; NaN) goes to the exact path as a whole.
+    const double xb_v = c_tab.synth_xbound * amax;
+    const double eg_v = (c_tab.synth_eps_a * amax + c_tab.synth_eps_g * gmax_s + c_tab.synth_eps_x * xb_v) * eps_scale;
+    const double eps_t = __hiloint2double(__builtin_amdgcn_readfirstlane(__double2hiint(eg_v)), __builtin_amdgcn_readfirstlane(__double2loint(eg_v)));
+    const bool safe = __builtin_amdgcn_readfirstlane((int)(xb_v < 2147483000.0)) != 0;
     const long halo_slots = (long)n_halo * 36;
     const bool emit = valid && tl >= 15 && t >= halo_slots;
     const bool full_hist = __ballot(tl >= 15 && lim < 15) == 0;
     uint16_t *ot16 = reinterpret_cast<uint16_t *>(otile);
-    const double *C32 = c_tab.synth_fast, *C16 = c_tab.synth_fast + 256, *C8 = c_tab.synth_fast + 320, *C4 = c_tab.synth_fast + 336;
-    uint32_t redo = 0;
+    unsigned long long dmask = 0;                               // lanes with a sample the guard cannot vouch for
     int p = 0;
     // Outputs 2t, 32 - 2t, 2t + 1 and 31 - 2t per barrier interval (t = 0: outputs 0, 16, 1 and 31).  Outputs i and 32 - i read
     // the same two X of every slot: V[i] = X[16+i], V[32+i] = -X[16-i] for i <= 16, and V[32-i] = -X[16+i], V[64-i] = -X[16-i]
@@ -738,22 +753,25 @@ __global__ __launch_bounds__(TW * 64 * 2, TW == 4 ? 2 : 4) void k_dec_synth_fast
     //    waited for: a stage waits for everything asked for so far, THEN asks for the operands of the stage behind it, then
     //    computes (round 3 asked first; every wait of the compiler's then landed behind the request and took its whole latency).
     //  * No branch per output: every lane sums (lanes 0..14 of the tile, which only rebuild history, from the slots of lane 15),
-    //    the guard is mask arithmetic, and a lane that does not emit writes its sample to a row of the tile nobody reads --
-    //    round 3's four exec-mask branches per output cost more instructions than its 16 multiply-adds.
+    //    the guard is one comparison into a wave mask, and a lane that does not emit writes its sample to a row of the tile
+    //    nobody reads -- round 3's four exec-mask branches per output cost more instructions than its 16 multiply-adds.
     const int tlc = tl >= 15 ? tl : 15;
     const int orow = emit ? tl - 15 : OUT;
-    uint16_t *const oslot = ot16 + orow * OROW * 2 + ch;
-    const uint32_t emit_m = emit ? 0xffffffffu : 0u;
+    uint16_t *const oslot = ot16 + orow * OROW * 2 + ch;       // a slot's row: [output][channel], two channels wide also for mono
     // the V values of taps 8 half .. 8 half + 7: even taps from exchange slot se, odd taps from slot so; eight at a time (16
     // registers; all sixteen at once put the kernel at 123 VGPRs, one SIMD's whole register file for its four waves, with no
     // room for a wave of the neighbouring batches' kernels)
+    const double *const exb = &ex[0][ch][0][tlc - 15];
     auto window_read = [&](int se, int so, int half, double (&u)[8]) {
-        const double *e0 = &ex[p][ch][se][tlc], *e1 = &ex[p][ch][so][tlc];
+        // (one base register, fifteen slots back: every read is base + a non-negative immediate)
+        const double *e0 = exb + (p * 8 + se) * TL_LANES, *e1 = exb + (p * 8 + so) * TL_LANES;
 #pragma unroll
-        for (int j = 0; j < 8; j++) { const int jj = 8 * half + j; u[j] = (jj & 1 ? e1 : e0)[-jj]; }
+        for (int j = 0; j < 8; j++) { const int jj = 8 * half + j; u[j] = (jj & 1 ? e1 : e0)[15 - jj]; }
         if (!full_hist) {                                   // (wave-uniform, rare: a stream starts inside the tile)
+            int lim_here = lim;
+            asm volatile("" : "+v"(lim_here));              // (compared HERE: sixteen lane masks kept across the loop were scalar spills)
 #pragma unroll
-            for (int j = 0; j < 8; j++) if (8 * half + j > lim) u[j] = 0.0;      // before the stream started the fifo holds zeros
+            for (int j = 0; j < 8; j++) if (8 * half + j > lim_here) u[j] = 0.0;      // before the stream started the fifo holds zeros
         }
     };
     float *const fslot = reinterpret_cast<float *>(pcm_out) + ((valid ? t - (long)n_halo * 36 : 0) * 32) * nch + ch;
@@ -762,18 +780,23 @@ __global__ __launch_bounds__(TW * 64 * 2, TW == 4 ? 2 : 4) void k_dec_synth_fast
             if (emit) fslot[io * nch] = (float)sum;
             return;
         }
-        // the guard: is the truncation of sum * 32767 beyond doubt?  (Truncation is toward zero: every x in (-1, 1) gives
-        // 0, so the integer 0 is not a boundary.)
-        const double x = sum * 32767, xi = rint(x), ax = fabs(x);
-        const double r = fabs(x - xi);
-        const bool doubt = ((xi != 0.0) & !(r > __builtin_fma(eps_x, ax, eps_a))) | !(ax < 2147483000.0);
-        redo |= (doubt ? 1u << io : 0u) & emit_m;
-        asm volatile("" : "+v"(redo));      // (decided HERE: the bits are read behind the loop, and the compiler would otherwise carry all 32 x there)
-        // (pcm_to_i16: x86's cvttsd2si gives "indefinite", low half 0, beyond int32)
-        const int q = ax < 2147483648.0 ? (int)x : 0;
-        oslot[io * nch] = (uint16_t)q;
+        // the guard: is the truncation of x = sample * 32767 (the taps carry the factor) beyond doubt?  Truncation is toward
+        // zero: every x in (-1, 1) gives 0, so the integer 0 is not a boundary -- the distance is taken to the nearest integer
+        // that is not zero.  One comparison into the wave's mask (round 3: per sample its own bit, thirteen instructions; the
+        // fix-up kernel recomputes the slot's 32 samples, which costs it nothing: they are its lanes)
+        const double x = sum, xi = rint(x);
+        const double dist = fabs(x) - fmax(fabs(xi), 1.0);
+        dmask |= __ballot(!(fabs(dist) > eps_t));
+        asm volatile("" : "+s"(dmask));                   // (merged HERE: the compiler kept the 32 masks for a tree behind the loop, as scalar spills)
+        oslot[io * 2] = (uint16_t)(int)x;                   // (beyond int32 only in a tile that is not `safe`: recomputed as a whole)
     };
-    const double *Wtab = &c_tab.synth_window_f[0][0];
+    // the tables of the loop behind ONE base address the compiler cannot see through: every scalar load is base + immediate
+    // (it rebuilt a pc-relative address, three scalar instructions, in front of each of the 105 loads)
+    typedef const double __attribute__((address_space(4))) *ctab_ptr;   // (the constant segment: what makes the loads scalar ones)
+    ctab_ptr ct = (ctab_ptr)c_tab.synth_fast;
+    asm volatile("" : "+s"(ct));
+    ctab_ptr C32 = ct, C16 = ct + 256, C8 = ct + 320, C4 = ct + 336;
+    ctab_ptr Wtab = ct + (long)((F32 ? offsetof(DevTables, synth_window_f) : offsetof(DevTables, synth_window_fs)) - offsetof(DevTables, synth_fast)) / 8;
     // Scalar operands travel in pieces of eight doubles (16 scalar registers, one s_load_dwordx16): a step waits for the piece
     // it multiplies with, asks for the next one, and multiplies -- two pieces live at any time (round 3 kept whole rows: two
     // 16-term rows, two 8-term rows and a row of taps were 112 scalar registers at the peak, and the allocator spilled 65 of
@@ -781,7 +804,7 @@ __global__ __launch_bounds__(TW * 64 * 2, TW == 4 ? 2 : 4) void k_dec_synth_fast
     typedef double d8 __attribute__((ext_vector_type(8)));
     typedef double d4t __attribute__((ext_vector_type(4)));
     typedef double d2t __attribute__((ext_vector_type(2)));
-    auto ld8 = [](const double *q) { return *reinterpret_cast<const d8 *>(q); };
+    auto ld8 = [](ctab_ptr q) { return *(const d8 __attribute__((address_space(4))) *)q; };
     auto dot8 = [](const double *d, const d8 &c, double a) {
 #pragma unroll
         for (int j = 0; j < 8; j++) a = __builtin_fma(d[j], c[j], a);
@@ -794,10 +817,10 @@ __global__ __launch_bounds__(TW * 64 * 2, TW == 4 ? 2 : 4) void k_dec_synth_fast
     for (int tt = 0; tt < 8; tt++) {
         // odd k: A1 = X[17+2t], B1 = X[15-2t]; row of odd k: (k-1)/2.  even k: A0 = X[16+2t], B0 = X[16-2t]
         const int ka1 = 17 + 2 * tt, kb1 = 15 - 2 * tt, ka0 = 16 + 2 * tt, kb0 = 16 - 2 * tt;
-        const double *rowA1 = C32 + (ka1 >> 1) * 16, *rowB1 = C32 + (kb1 >> 1) * 16;
+        ctab_ptr rowA1 = C32 + (ka1 >> 1) * 16, rowB1 = C32 + (kb1 >> 1) * 16;
         // outputs of the interval and the rows of their taps
         const int oa = 2 * tt, ob = tt ? 32 - 2 * tt : 16, oc = 2 * tt + 1, od = 31 - 2 * tt;
-        const double *Wa = Wtab + oa * 16, *Wb = Wtab + ob * 16, *Wc = Wtab + oc * 16, *Wd = Wtab + od * 16;
+        ctab_ptr Wa = Wtab + oa * 16, Wb = Wtab + ob * 16, Wc = Wtab + oc * 16, Wd = Wtab + od * 16;
         d8 nxt;
         // ---- the odd-k sums: four pieces
         MP3S_ARRIVED(); nxt = ld8(rowA1 + 8); MP3S_GO();
@@ -830,8 +853,8 @@ __global__ __launch_bounds__(TW * 64 * 2, TW == 4 ? 2 : 4) void k_dec_synth_fast
             // 4- and 2-term rows: both rows of the interval in one request
             d4t a4, b4; d2t a2, b2;
             MP3S_ARRIVED();
-            if (tt & 2) { a4 = *reinterpret_cast<const d4t *>(C8 + ((ka0 - 4) >> 3) * 4); b4 = *reinterpret_cast<const d4t *>(C8 + ((kb0 - 4) >> 3) * 4); }
-            else { a2 = *reinterpret_cast<const d2t *>(C4 + ((ka0 - 8) >> 4) * 2); b2 = *reinterpret_cast<const d2t *>(C4 + ((kb0 - 8) >> 4) * 2); }
+            if (tt & 2) { a4 = *(const d4t __attribute__((address_space(4))) *)(C8 + ((ka0 - 4) >> 3) * 4); b4 = *(const d4t __attribute__((address_space(4))) *)(C8 + ((kb0 - 4) >> 3) * 4); }
+            else { a2 = *(const d2t __attribute__((address_space(4))) *)(C4 + ((ka0 - 8) >> 4) * 2); b2 = *(const d2t __attribute__((address_space(4))) *)(C4 + ((kb0 - 8) >> 4) * 2); }
             MP3S_GO();
             vb1 = -dot8(d16 + 8, cur, vb1); MP3S_GO();
             MP3S_ARRIVED(); nxt = ld8(Wa); MP3S_GO();
@@ -921,19 +944,30 @@ __global__ __launch_bounds__(TW * 64 * 2, TW == 4 ? 2 : 4) void k_dec_synth_fast
     // ---- the samples the guard could not vouch for go on the fix-up list: slot | channel << 31, mask of output indices
     //      (k_dec_fixup recomputes them from `is` in the reference's order and overwrites what is stored below)
     if (F32) return;
-    if (redo) {
-        const int at = atomicAdd(fix_count, 1);
-        fix_list[at] = make_uint2((uint32_t)t | ((uint32_t)ch << 31), redo);
+    {
+        const unsigned long long em = __ballot(emit);
+        const unsigned long long mine = safe ? dmask & em : em;
+        if ((mine >> lane) & 1ull) {
+            const int at = atomicAdd(fix_count, 1);
+            fix_list[at] = make_uint2((uint32_t)t | ((uint32_t)ch << 31), 0xffffffffu);
+        }
     }
     __syncthreads();
-    const int dw_per_slot = 16 * nch;
-    const int n_dw = OUT * dw_per_slot;
-    uint32_t *outp = (uint32_t *)pcm_out;
-    for (int c = threadIdx.x; c < n_dw; c += blockDim.x) {
-        const int sl = c / dw_per_slot, w = c - sl * dw_per_slot;
-        const long slot = tile0 + sl;
-        if (slot < halo_slots || slot >= T) continue;
-        outp[(slot - halo_slots) * dw_per_slot + w] = otile[sl * OROW + w];
+    {
+        // the tile's slots are one contiguous piece of the output: dword c of the tile goes to dword c of the piece (round 3
+        // divided by the run-time row length and compared 64-bit slot numbers per dword: a third of the kernel's vector instructions)
+        const int sh = nch == 2 ? 5 : 4;                                     // log2 of a slot's dwords
+        const long lo_l = halo_slots - tile0, hi_l = T - tile0;             // (hi_l > 0: the tile starts inside the batch)
+        const int sl_lo = lo_l > 0 ? (lo_l < OUT ? (int)lo_l : OUT) : 0, sl_hi = hi_l < OUT ? (int)hi_l : OUT;
+        uint32_t *const outp = (uint32_t *)pcm_out;
+        const long obase = (tile0 - halo_slots) << sh;
+        for (int c = (sl_lo << sh) + (int)threadIdx.x; c < (sl_hi << sh); c += (int)blockDim.x) {
+            const int sl = c >> sh, w = c & ((1 << sh) - 1);
+            uint32_t v;
+            if (nch == 2) v = otile[sl * OROW + w];
+            else v = (otile[sl * OROW + 2 * w] & 0xffffu) | (otile[sl * OROW + 2 * w + 1] << 16);   // mono: every other half word of the row
+            outp[obase + c] = v;
+        }
     }
 }
 

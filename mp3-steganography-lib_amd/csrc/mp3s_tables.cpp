@@ -135,8 +135,9 @@ void build()
         //   fast:       |V_fast - V_true| <= g24 A:  at most 5 additions in front of a product, a factor that is off by at
         //               most 2u, 16 products summed one after the other
         //   window:     both paths run the same 16-tap sum on their V; the results differ by at most
-        //               Dsum (dV + 2 g17 (1 + dV)) Amax,  Dsum = max_i sum_taps |D|,  dV = dN + g33 + g24
-        //   * 32767:    two roundings of one multiplication: 2u |x|
+        //               Dsum (dV + 2 g18 (1 + dV)) Amax,  Dsum = max_i sum_taps |D|,  dV = dN + g33 + g24
+        //               (g18, not g17: the fast path's taps carry the factor 32767 and are rounded once more for it)
+        //   * 32767:    two roundings of one multiplication: 2u |x|  (the fast path has none since round 4: kept)
         // and twice that, against slips in the algebra above.
         const double u = 1.1102230246251565e-16;
         long double dN = 0;
@@ -153,9 +154,9 @@ void build()
             for (int k = 0; k < 16; k++) a += std::fabs(T.synth_window[32 * k + i]);
             if (a > dsum) dsum = a;
         }
-        const double g33 = 33 * u / (1 - 33 * u), g24 = 24 * u / (1 - 24 * u), g17 = 17 * u / (1 - 17 * u);
+        const double g33 = 33 * u / (1 - 33 * u), g24 = 24 * u / (1 - 24 * u), g18s = 18 * u / (1 - 18 * u);
         const double dV = (double)dN + 1e-19 + g33 + g24;
-        T.synth_eps_a = 2.0 * 32767.0 * dsum * (dV + 2 * g17 * (1 + dV));
+        T.synth_eps_a = 2.0 * 32767.0 * dsum * (dV + 2 * g18s * (1 + dV));
         // The fast IMDCT (imdct_run<true>).  Inputs v[k] of a subband are the same in both paths (requantisation .. alias
         // reduction are not touched); B = sum_k |v[k]|, |C| <= 1, |window| <= 1.
         //   reference:  X[i] = the 18 products summed one after the other:            |X[i] - sum v C[i]| <= g18 B
@@ -192,7 +193,9 @@ void build()
                 if (i == 16 && !(k & 1)) w = 0.0;
                 if (i > 16 && !(k & 1)) w = -w;
                 T.synth_window_f[i][k] = w;
+                T.synth_window_fs[i][k] = w * 32767.0;
             }
+        T.synth_xbound = 32767.0 * dsum * (1.0 + 1e-6);
     }
     for (int sr = 0; sr < 3; sr++) {
         for (int c = 0; c < 3; c++) {

@@ -54,6 +54,11 @@ struct DevTables {
     // taps: row i < 16 = synth_window_t[i]; rows 17..31 with their even taps negated; row 0 with its odd taps negated (both
     // halves of its V pair are +-X[16]); row 16 with its even taps zero (V[16] = X[32] = 0)
     double synth_window_f[32][16];
+    // ... and times 32767 for the int16 path (each tap rounded once: one more rounding per term in the guard's bound), so
+    // that a window sum IS the sample's scaled value; synth_xbound * (largest sum |S| of a slot in the tile) bounds every
+    // |sample * 32767| of the tile (32767 * Dsum and a little)
+    double synth_window_fs[32][16];
+    double synth_xbound;
     uint8_t rq_map[3][3][32][20];  // [sr][case][subband][18 lines + 2 pad]: five aligned dwords per lane;
                                    // byte = gain selector << 6 | scalefactor slot (see build_rq_map)
     int16_t reorder_src[3][576];   // [sr][dst line] -> src line or -1 (zero)  Frame.py:574-602

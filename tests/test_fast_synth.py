@@ -35,9 +35,10 @@ def test_fast_synthesis_equals_exact_kernel(mlib, golden_dir, orc):
             for k in range(len(streams)):
                 assert np.array_equal(fast[k], exact[k]), (scale, k)
                 assert np.array_equal(batch[k], exact_batch[k]), (scale, k)
-        # the guard's share: next to nothing at the proven bound, a large share when inflated a billion times
+        # the guard's share: next to nothing at the proven bound (a flagged sample takes the 32 of its slot and channel with it),
+        # a large share when inflated a billion times
         total = 2 * sum(e.size for e in exact)
-        assert counts[1.0] < total * 1e-5 and counts[1e9] > total * 0.5, counts
+        assert counts[1.0] < total * 1e-3 and counts[1e9] > total * 0.5, counts
         assert counts[1.0] <= counts[1e3] <= counts[1e6] <= counts[1e9]
         # the float formats do not take the fast path
         ctx.synth_mode(1.0)
