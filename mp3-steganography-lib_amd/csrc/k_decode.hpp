@@ -790,21 +790,18 @@ __global__ __launch_bounds__(TW * 64 * 2, TW == 4 ? 2 : 4) void k_dec_synth_fast
         asm volatile("" : "+s"(dmask));                   // (merged HERE: the compiler kept the 32 masks for a tree behind the loop, as scalar spills)
         oslot[io * 2] = (uint16_t)(int)x;                   // (beyond int32 only in a tile that is not `safe`: recomputed as a whole)
     };
-    // the tables of the loop behind ONE base address the compiler cannot see through: every scalar load is base + immediate
-    // (it rebuilt a pc-relative address, three scalar instructions, in front of each of the 105 loads)
+    // The loop's constants come as ONE stream in the order of their use (DevTables::synth_stream), sixteen doubles per step behind
+    // one base address the compiler cannot see through: a scalar load is base + immediate (it rebuilt a pc-relative address, three
+    // scalar instructions, in front of each), and a step is: wait for the piece asked for a step earlier (and for the step's LDS
+    // reads), ask for the next piece, sixteen multiply-adds -- two pieces live at any time, 64 scalar registers.  (Round 3 kept
+    // whole rows, 112 scalar registers at the peak, 65 of them spilled into vector lanes; pieces of eight doubles, until r04c,
+    // waited twice as often: the kernel issued a third of the vector instructions its SIMDs had slots for.)
     typedef const double __attribute__((address_space(4))) *ctab_ptr;   // (the constant segment: what makes the loads scalar ones)
-    ctab_ptr ct = (ctab_ptr)c_tab.synth_fast;
+    ctab_ptr ct = (ctab_ptr)&c_tab.synth_stream[F32 ? 0 : 1][0][0];
     asm volatile("" : "+s"(ct));
-    ctab_ptr C32 = ct, C16 = ct + 256, C8 = ct + 320, C4 = ct + 336;
-    ctab_ptr Wtab = ct + (long)((F32 ? offsetof(DevTables, synth_window_f) : offsetof(DevTables, synth_window_fs)) - offsetof(DevTables, synth_fast)) / 8;
-    // Scalar operands travel in pieces of eight doubles (16 scalar registers, one s_load_dwordx16): a step waits for the piece
-    // it multiplies with, asks for the next one, and multiplies -- two pieces live at any time (round 3 kept whole rows: two
-    // 16-term rows, two 8-term rows and a row of taps were 112 scalar registers at the peak, and the allocator spilled 65 of
-    // them into vector lanes, to be read back lane by lane in the middle of the sums).
     typedef double d8 __attribute__((ext_vector_type(8)));
-    typedef double d4t __attribute__((ext_vector_type(4)));
-    typedef double d2t __attribute__((ext_vector_type(2)));
-    auto ld8 = [](ctab_ptr q) { return *(const d8 __attribute__((address_space(4))) *)q; };
+    struct Piece { d8 lo, hi; };
+    auto ld16 = [](ctab_ptr q) { Piece r; r.lo = *(const d8 __attribute__((address_space(4))) *)q; r.hi = *(const d8 __attribute__((address_space(4))) *)(q + 8); return r; };
     auto dot8 = [](const double *d, const d8 &c, double a) {
 #pragma unroll
         for (int j = 0; j < 8; j++) a = __builtin_fma(d[j], c[j], a);
@@ -812,61 +809,36 @@ __global__ __launch_bounds__(TW * 64 * 2, TW == 4 ? 2 : 4) void k_dec_synth_fast
     };
 #define MP3S_ARRIVED() do { __builtin_amdgcn_s_waitcnt(0xc07f); __builtin_amdgcn_sched_barrier(0); } while (0)
 #define MP3S_GO() __builtin_amdgcn_sched_barrier(0)
-    d8 cur = ld8(C32 + (17 >> 1) * 16);                             // interval t = 0: k = 17, first half of its row
+    Piece cur = ld16(ct);                                           // interval t = 0: the row of X[17]
 #pragma unroll
     for (int tt = 0; tt < 8; tt++) {
-        // odd k: A1 = X[17+2t], B1 = X[15-2t]; row of odd k: (k-1)/2.  even k: A0 = X[16+2t], B0 = X[16-2t]
-        const int ka1 = 17 + 2 * tt, kb1 = 15 - 2 * tt, ka0 = 16 + 2 * tt, kb0 = 16 - 2 * tt;
-        ctab_ptr rowA1 = C32 + (ka1 >> 1) * 16, rowB1 = C32 + (kb1 >> 1) * 16;
-        // outputs of the interval and the rows of their taps
-        const int oa = 2 * tt, ob = tt ? 32 - 2 * tt : 16, oc = 2 * tt + 1, od = 31 - 2 * tt;
-        ctab_ptr Wa = Wtab + oa * 16, Wb = Wtab + ob * 16, Wc = Wtab + oc * 16, Wd = Wtab + od * 16;
-        d8 nxt;
-        // ---- the odd-k sums: four pieces
-        MP3S_ARRIVED(); nxt = ld8(rowA1 + 8); MP3S_GO();
-        double va1 = dot8(d16, cur, 0.0); MP3S_GO();
+        // odd k: A1 = X[17+2t], B1 = X[15-2t].  even k: A0 = X[16+2t], B0 = X[16-2t]
+        ctab_ptr q = ct + tt * 112;
+        const int oa = 2 * tt, ob = tt ? 32 - 2 * tt : 16, oc = 2 * tt + 1, od = 31 - 2 * tt;   // outputs of the interval
+        Piece nxt;
+        // ---- the odd-k sums
+        MP3S_ARRIVED(); nxt = ld16(q + 16); MP3S_GO();
+        double va1 = dot8(d16 + 8, cur.hi, dot8(d16, cur.lo, 0.0)); MP3S_GO();
         cur = nxt;
-        MP3S_ARRIVED(); nxt = ld8(rowB1); MP3S_GO();
-        va1 = dot8(d16 + 8, cur, va1); MP3S_GO();
+        MP3S_ARRIVED(); nxt = ld16(q + (tt ? 32 : 48)); MP3S_GO();
+        double vb1 = -dot8(d16 + 8, cur.hi, dot8(d16, cur.lo, 0.0)); MP3S_GO();
         cur = nxt;
-        MP3S_ARRIVED(); nxt = ld8(rowB1 + 8); MP3S_GO();
-        double vb1 = dot8(d16, cur, 0.0); MP3S_GO();
-        cur = nxt;
-        // ---- the even-k sums (8 / 4 / 2 terms, or none), then the first half of the taps of output 2t
+        // ---- the even-k sums (8 / 4 / 2 terms; t = 0: A0 = B0 = X[16] for output 0, X[32] = 0 and X[0] for output 16)
         double va0, vb0;
-        if (tt == 0) {                                          // A0 = B0 = X[16] for output 0, X[32] = 0 and X[0] for output 16
-            MP3S_ARRIVED(); nxt = ld8(Wa); MP3S_GO();
-            vb1 = -dot8(d16 + 8, cur, vb1); MP3S_GO();
-            va0 = x16; vb0 = -x0;
-            cur = nxt;
-        } else if (tt & 1) {
-            MP3S_ARRIVED(); nxt = ld8(C16 + ((ka0 - 2) >> 2) * 8); MP3S_GO();
-            vb1 = -dot8(d16 + 8, cur, vb1); MP3S_GO();
-            cur = nxt;
-            MP3S_ARRIVED(); nxt = ld8(C16 + ((kb0 - 2) >> 2) * 8); MP3S_GO();
-            va0 = dot8(d8v, cur, 0.0); MP3S_GO();
-            cur = nxt;
-            MP3S_ARRIVED(); nxt = ld8(Wa); MP3S_GO();
-            vb0 = -dot8(d8v, cur, 0.0); MP3S_GO();
-            cur = nxt;
-        } else {
-            // 4- and 2-term rows: both rows of the interval in one request
-            d4t a4, b4; d2t a2, b2;
-            MP3S_ARRIVED();
-            if (tt & 2) { a4 = *(const d4t __attribute__((address_space(4))) *)(C8 + ((ka0 - 4) >> 3) * 4); b4 = *(const d4t __attribute__((address_space(4))) *)(C8 + ((kb0 - 4) >> 3) * 4); }
-            else { a2 = *(const d2t __attribute__((address_space(4))) *)(C4 + ((ka0 - 8) >> 4) * 2); b2 = *(const d2t __attribute__((address_space(4))) *)(C4 + ((kb0 - 8) >> 4) * 2); }
-            MP3S_GO();
-            vb1 = -dot8(d16 + 8, cur, vb1); MP3S_GO();
-            MP3S_ARRIVED(); nxt = ld8(Wa); MP3S_GO();
-            va0 = 0.0; vb0 = 0.0;
-            if (tt & 2) {
+        if (tt == 0) { va0 = x16; vb0 = -x0; }
+        else {
+            MP3S_ARRIVED(); nxt = ld16(q + 48); MP3S_GO();
+            if (tt & 1) { va0 = dot8(d8v, cur.lo, 0.0); vb0 = -dot8(d8v, cur.hi, 0.0); }
+            else {
+                va0 = 0.0; vb0 = 0.0;
 #pragma unroll
-                for (int j = 0; j < 4; j++) { va0 = __builtin_fma(d4[j], a4[j], va0); vb0 = __builtin_fma(d4[j], b4[j], vb0); }
-            } else {
-#pragma unroll
-                for (int j = 0; j < 2; j++) { va0 = __builtin_fma(d2[j], a2[j], va0); vb0 = __builtin_fma(d2[j], b2[j], vb0); }
+                for (int j = 0; j < ((tt & 2) ? 4 : 2); j++) {
+                    va0 = __builtin_fma((tt & 2) ? d4[j] : d2[j], cur.lo[j], va0);
+                    vb0 = __builtin_fma((tt & 2) ? d4[j] : d2[j], cur.hi[j], vb0);
+                }
+                vb0 = -vb0;
             }
-            vb0 = -vb0; MP3S_GO();
+            MP3S_GO();
             cur = nxt;
         }
         ex[p][ch][0][tl] = va0;
@@ -875,65 +847,50 @@ __global__ __launch_bounds__(TW * 64 * 2, TW == 4 ? 2 : 4) void k_dec_synth_fast
         ex[p][ch][3][tl] = vb1;
         __syncthreads();                                        // (its wait covers the taps asked for above)
         double u[8];
-        // ---- eight taps at a time: V values from LDS, wait (for them and for the piece asked for a step earlier), ask for the next
-        //      piece, multiply
+        // ---- eight taps of two outputs at a time: V values from LDS, wait (for them and for the piece asked for a step earlier), ask
+        //      for the next piece, multiply
         if (tt == 0) {
             // output 0: every tap reads X[16] (slot 0); output 16: X[0] (slot 1) under taps that are zero where V[16] stands
             window_read(0, 0, 0, u);
-            MP3S_ARRIVED(); nxt = ld8(Wa + 8); MP3S_GO();
-            double sum = dot8(u, cur, 0.0); MP3S_GO();
-            cur = nxt;
+            MP3S_ARRIVED(); nxt = ld16(q + 64); MP3S_GO();
+            double sum = dot8(u, cur.lo, 0.0); MP3S_GO();
             window_read(0, 0, 1, u);
-            MP3S_ARRIVED(); nxt = ld8(Wb); MP3S_GO();
-            sum = dot8(u, cur, sum);
+            MP3S_ARRIVED(); MP3S_GO();                          // (the next piece is in flight under this wait: one interval in eight)
+            sum = dot8(u, cur.hi, sum);
             window_emit(oa, sum); MP3S_GO();
             cur = nxt;
             window_read(1, 1, 0, u);
-            MP3S_ARRIVED(); nxt = ld8(Wb + 8); MP3S_GO();
-            sum = dot8(u, cur, 0.0); MP3S_GO();
-            cur = nxt;
+            MP3S_ARRIVED(); nxt = ld16(q + 80); MP3S_GO();
+            sum = dot8(u, cur.lo, 0.0); MP3S_GO();
             window_read(1, 1, 1, u);
-            MP3S_ARRIVED(); nxt = ld8(Wc); MP3S_GO();
-            sum = dot8(u, cur, sum);
+            MP3S_ARRIVED(); MP3S_GO();
+            sum = dot8(u, cur.hi, sum);
             window_emit(ob, sum); MP3S_GO();
             cur = nxt;
         } else {
             window_read(0, 1, 0, u);
-            MP3S_ARRIVED(); nxt = ld8(Wb); MP3S_GO();
-            double sa = dot8(u, cur, 0.0); MP3S_GO();
-            cur = nxt;
-            MP3S_ARRIVED(); nxt = ld8(Wa + 8); MP3S_GO();
-            double sb = dot8(u, cur, 0.0); MP3S_GO();
+            MP3S_ARRIVED(); nxt = ld16(q + 64); MP3S_GO();
+            double sa = dot8(u, cur.lo, 0.0), sb = dot8(u, cur.hi, 0.0); MP3S_GO();
             cur = nxt;
             window_read(0, 1, 1, u);
-            MP3S_ARRIVED(); nxt = ld8(Wb + 8); MP3S_GO();
-            sa = dot8(u, cur, sa);
-            window_emit(oa, sa); MP3S_GO();
-            cur = nxt;
-            MP3S_ARRIVED(); nxt = ld8(Wc); MP3S_GO();
-            sb = dot8(u, cur, sb);
+            MP3S_ARRIVED(); nxt = ld16(q + 80); MP3S_GO();
+            sa = dot8(u, cur.lo, sa);
+            window_emit(oa, sa);
+            sb = dot8(u, cur.hi, sb);
             window_emit(ob, sb); MP3S_GO();
             cur = nxt;
         }
         // ---- outputs 2t + 1 and 31 - 2t; under the last piece the first piece of the next interval (behind the last one: any row)
         {
             window_read(2, 3, 0, u);
-            MP3S_ARRIVED(); nxt = ld8(Wd); MP3S_GO();
-            double sc = dot8(u, cur, 0.0); MP3S_GO();
-            cur = nxt;
-            MP3S_ARRIVED(); nxt = ld8(Wc + 8); MP3S_GO();
-            double sd = dot8(u, cur, 0.0); MP3S_GO();
+            MP3S_ARRIVED(); nxt = ld16(q + 96); MP3S_GO();
+            double sc = dot8(u, cur.lo, 0.0), sd = dot8(u, cur.hi, 0.0); MP3S_GO();
             cur = nxt;
             window_read(2, 3, 1, u);
-            MP3S_ARRIVED(); nxt = ld8(Wd + 8); MP3S_GO();
-            sc = dot8(u, cur, sc);
-            window_emit(oc, sc); MP3S_GO();
-            cur = nxt;
-            {
-                const int tn = tt == 7 ? 0 : tt + 1;
-                MP3S_ARRIVED(); nxt = ld8(C32 + ((17 + 2 * tn) >> 1) * 16); MP3S_GO();
-            }
-            sd = dot8(u, cur, sd);
+            MP3S_ARRIVED(); nxt = ld16(ct + (tt == 7 ? 0 : tt + 1) * 112); MP3S_GO();
+            sc = dot8(u, cur.lo, sc);
+            window_emit(oc, sc);
+            sd = dot8(u, cur.hi, sd);
             window_emit(od, sd); MP3S_GO();
             cur = nxt;
         }

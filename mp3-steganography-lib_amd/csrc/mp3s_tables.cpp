@@ -196,6 +196,21 @@ void build()
                 T.synth_window_fs[i][k] = w * 32767.0;
             }
         T.synth_xbound = 32767.0 * dsum * (1.0 + 1e-6);
+        for (int v = 0; v < 2; v++)
+            for (int t = 0; t < 8; t++) {
+                double *q = T.synth_stream[v][t];
+                const double (*W)[16] = v ? T.synth_window_fs : T.synth_window_f;
+                const double *C32 = T.synth_fast, *C16 = T.synth_fast + 256, *C8 = T.synth_fast + 320, *C4 = T.synth_fast + 336;
+                const int ka1 = 17 + 2 * t, kb1 = 15 - 2 * t, ka0 = 16 + 2 * t, kb0 = 16 - 2 * t;
+                for (int j = 0; j < 16; j++) { q[j] = C32[(ka1 >> 1) * 16 + j]; q[16 + j] = C32[(kb1 >> 1) * 16 + j]; }
+                if (t & 1) for (int j = 0; j < 8; j++) { q[32 + j] = C16[((ka0 - 2) >> 2) * 8 + j]; q[40 + j] = C16[((kb0 - 2) >> 2) * 8 + j]; }
+                else if (t & 2) for (int j = 0; j < 4; j++) { q[32 + j] = C8[((ka0 - 4) >> 3) * 4 + j]; q[40 + j] = C8[((kb0 - 4) >> 3) * 4 + j]; }
+                else if (t) for (int j = 0; j < 2; j++) { q[32 + j] = C4[((ka0 - 8) >> 4) * 2 + j]; q[40 + j] = C4[((kb0 - 8) >> 4) * 2 + j]; }
+                const int oa = 2 * t, ob = t ? 32 - 2 * t : 16, oc = 2 * t + 1, od = 31 - 2 * t;
+                if (t) for (int j = 0; j < 8; j++) { q[48 + j] = W[oa][j]; q[56 + j] = W[ob][j]; q[64 + j] = W[oa][8 + j]; q[72 + j] = W[ob][8 + j]; }
+                else for (int j = 0; j < 16; j++) { q[48 + j] = W[oa][j]; q[64 + j] = W[ob][j]; }
+                for (int j = 0; j < 8; j++) { q[80 + j] = W[oc][j]; q[88 + j] = W[od][j]; q[96 + j] = W[oc][8 + j]; q[104 + j] = W[od][8 + j]; }
+            }
     }
     for (int sr = 0; sr < 3; sr++) {
         for (int c = 0; c < 3; c++) {

@@ -59,6 +59,12 @@ struct DevTables {
     // |sample * 32767| of the tile (32767 * Dsum and a little)
     double synth_window_fs[32][16];
     double synth_xbound;
+    // k_dec_synth_fast's constants in the order it uses them, sixteen doubles (one scalar request, two cache lines) per step:
+    // per interval t = 0..7  [row of X[17+2t]] [row of X[15-2t]] [rows of X[16+2t], X[16-2t]: 8 + 8, or 4 + 4, or 2 + 2 doubles
+    // at 0 and 8, nothing for t = 0] then the taps (synth_window_f; [1]: synth_window_fs) of outputs a = 2t, b = 32 - 2t,
+    // c = 2t + 1, d = 31 - 2t as [a 0..7 | b 0..7] [a 8..15 | b 8..15] [c 0..7 | d 0..7] [c 8..15 | d 8..15]
+    // (t = 0: outputs 0 and 16 read different slots: [row 0] [row 16] in their places)
+    double synth_stream[2][8][112];
     uint8_t rq_map[3][3][32][20];  // [sr][case][subband][18 lines + 2 pad]: five aligned dwords per lane;
                                    // byte = gain selector << 6 | scalefactor slot (see build_rq_map)
     int16_t reorder_src[3][576];   // [sr][dst line] -> src line or -1 (zero)  Frame.py:574-602
