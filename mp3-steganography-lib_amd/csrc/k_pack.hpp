@@ -41,7 +41,7 @@ __global__ __launch_bounds__(256) void k_enc_pack(
     __shared__ uint8_t hl[4][256];
     __shared__ uint8_t c1code[16], c1len[16];
     __shared__ int wg_err;                 // the group's error bits
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+    const int wave0 = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane0 = threadIdx.x & 63;
     for (int i = threadIdx.x; i < 1024; i += 256) {
         (&hc[0][0])[i] = (&c_tab.hcod[0][0])[i];
         (&hl[0][0])[i] = i < 256 ? c_tab.hlen13[i] : (i < 512 ? c_tab.hlen15[i - 256] : (i < 768 ? c_tab.hlen16[i - 512] : c_tab.hlen24[i - 768]));
@@ -52,12 +52,17 @@ __global__ __launch_bounds__(256) void k_enc_pack(
     __syncthreads();
     int rot = 0;
     for (int f = f_begin + blockIdx.x; f < n_frames; f += gridDim.x) {
+    // The lane number is made opaque once per frame: every predicate of it (lane < 22, lane >= d, lane == 0 ...) is loop-invariant, and
+    // the compiler kept them all across the frame loop as lane masks -- 38 pairs of scalar registers, 76 spills, a v_readlane pair in
+    // front of every use: a fifth of the kernel's vector instructions.  Recomputed where they are used they are one comparison each.
+    int lane = lane0, tid = (int)threadIdx.x, wave = wave0;
+    asm volatile("" : "+v"(lane), "+v"(tid), "+s"(wave));      // (what follows from the wave number likewise: scalar arithmetic per frame instead of spills)
     // One barrier per frame.  This frame's image is fb3[rot]; the image of the frame before last -- every thread
     // finished copying it out before the previous barrier -- is cleared now and is ready after this frame's barrier.
     uint32_t *fb = fb3[rot];
     {
         uint32_t *cl = fb3[rot == 2 ? 0 : rot + 1];
-        for (int i = threadIdx.x; i < PACK_DW; i += 256) cl[i] = 0;
+        for (int i = tid; i < PACK_DW; i += 256) cl[i] = 0;
     }
     const int pad = padding[f];
     // ---- __resv_frame_end (:1097-1145): all slack of the frame becomes stuffing; emission order e = gr*2 + ch
@@ -204,6 +209,8 @@ __global__ __launch_bounds__(256) void k_enc_pack(
         code1[k] = (in_bv || in_c1) ? ext : 0u;
         n1[k] = (in_bv || in_c1) ? xb : 0;
         tot += n0[k] + n1[k];
+        __builtin_amdgcn_sched_barrier(0);   // one pair at a time: every lane predicate above is a pair of scalar registers, and the five
+                                             // pairs' worth interleaved were 76 scalar spills (a fifth of the kernel's vector instructions)
     }
     // exclusive prefix of the lanes' bit counts
     int incl = tot;
@@ -245,13 +252,19 @@ __global__ __launch_bounds__(256) void k_enc_pack(
     auto byte_at = [&](int k) -> uint32_t { return (fb[k >> 2] >> (24 - 8 * (k & 3))) & 0xffu; };
     const int head = (int)((4u - (off & 3u)) & 3u) < nbytes ? (int)((4u - (off & 3u)) & 3u) : nbytes;
     const int n_dw = (nbytes - head) >> 2, tail0 = head + 4 * n_dw;
-    if ((int)threadIdx.x < head) mp3[off + threadIdx.x] = (uint8_t)byte_at(threadIdx.x);
+    if (tid < head) mp3[off + tid] = (uint8_t)byte_at(tid);
     uint32_t *outw = reinterpret_cast<uint32_t *>(mp3 + off + head);
-    for (int j = threadIdx.x; j < n_dw; j += 256) {
-        const int k = head + 4 * j;
-        outw[j] = byte_at(k) | (byte_at(k + 1) << 8) | (byte_at(k + 2) << 16) | (byte_at(k + 3) << 24);
+    {
+        // bytes head + 4j .. + 3 of the image (big-endian in its dwords) as one little-endian dword: a funnel shift over two image
+        // dwords and a byte swap (byte by byte it was two dozen instructions per dword)
+        const int hq = head >> 2, hs = 8 * (head & 3);               // (wave-uniform)
+        for (int j = tid; j < n_dw; j += 256) {
+            const uint32_t hi = fb[hq + j], lo = fb[hq + j + 1];     // (PACK_DW leaves slack behind the last byte)
+            const uint32_t be = hs ? __builtin_amdgcn_alignbit(hi, lo, 32 - hs) : hi;
+            outw[j] = __builtin_bswap32(be);
+        }
     }
-    if ((int)threadIdx.x < nbytes - tail0) mp3[off + tail0 + threadIdx.x] = (uint8_t)byte_at(tail0 + threadIdx.x);
+    if (tid < nbytes - tail0) mp3[off + tail0 + tid] = (uint8_t)byte_at(tail0 + tid);
     rot = rot == 2 ? 0 : rot + 1;
     }   // frames
     // The caller's status word is written once, by the workgroup that finishes last, from the context's 64-bit word {finished
