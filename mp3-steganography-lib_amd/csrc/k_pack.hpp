@@ -52,11 +52,7 @@ __global__ __launch_bounds__(256) void k_enc_pack(
     __syncthreads();
     int rot = 0;
     for (int f = f_begin + blockIdx.x; f < n_frames; f += gridDim.x) {
-    // The lane number is made opaque once per frame: every predicate of it (lane < 22, lane >= d, lane == 0 ...) is loop-invariant, and
-    // the compiler kept them all across the frame loop as lane masks -- 38 pairs of scalar registers, 76 spills, a v_readlane pair in
-    // front of every use: a fifth of the kernel's vector instructions.  Recomputed where they are used they are one comparison each.
-    int lane = lane0, tid = (int)threadIdx.x, wave = wave0;
-    asm volatile("" : "+v"(lane), "+v"(tid), "+s"(wave));      // (what follows from the wave number likewise: scalar arithmetic per frame instead of spills)
+    const int lane = lane0, tid = (int)threadIdx.x, wave = wave0;
     // One barrier per frame.  This frame's image is fb3[rot]; the image of the frame before last -- every thread
     // finished copying it out before the previous barrier -- is cleared now and is ready after this frame's barrier.
     uint32_t *fb = fb3[rot];
@@ -209,8 +205,6 @@ __global__ __launch_bounds__(256) void k_enc_pack(
         code1[k] = (in_bv || in_c1) ? ext : 0u;
         n1[k] = (in_bv || in_c1) ? xb : 0;
         tot += n0[k] + n1[k];
-        __builtin_amdgcn_sched_barrier(0);   // one pair at a time: every lane predicate above is a pair of scalar registers, and the five
-                                             // pairs' worth interleaved were 76 scalar spills (a fifth of the kernel's vector instructions)
     }
     // exclusive prefix of the lanes' bit counts
     int incl = tot;
