@@ -48,6 +48,38 @@ def test_fast_synthesis_equals_exact_kernel(mlib, golden_dir, orc):
         ctx.close()
 
 
+def test_tiles_that_could_leave_int32_go_to_the_exact_order_as_a_whole(mlib):
+    """k_dec_synth_fast vouches for a tile's truncations only when synth_xbound * (largest sum |S| of a slot) stays inside int32
+    (its per-sample conversion saturates where the reference's wraps, MP3_Parser.py:91); a tile beyond that is put on the
+    fix-up list whole.  A mono stream with escape values up to 8 206: samples far beyond int32, int16 output equal to the
+    exact kernel's, and a large share of the samples recomputed at the guard's own width"""
+    import frame_synth
+    ctx = mlib.Context(0)
+    try:
+        mp3 = bytearray(frame_synth.make_stream(32, 90, mode=3, max_lin=8191))
+        # global_gain = 255 in every granule (mono side info: 9 + 5 + 4 bits, then per granule 12 + 9 in front of its 8 bits, 59 in all)
+        pos = 0
+        for size in mlib.parse_stream(bytes(mp3))["frame_size"]:
+            for gr in range(2):
+                bit = (pos + 4) * 8 + 18 + 59 * gr + 21
+                for b in range(bit, bit + 8):
+                    mp3[b >> 3] |= 0x80 >> (b & 7)
+            pos += int(size)
+        mp3 = bytes(mp3)
+        f64 = np.array(ctx.decode_stream(mp3, mlib.MP3S_PCM_F64)["pcm"])
+        beyond = int(np.count_nonzero(np.abs(f64) * 32767 >= 2147483648.0))
+        assert beyond > 0, "the stream no longer reaches beyond int32: pick another seed"
+        ctx.synth_mode(0.0)
+        exact = np.array(ctx.decode_stream(mp3, mlib.MP3S_PCM_I16)["pcm"])
+        ctx.synth_mode(1.0)
+        fast = np.array(ctx.decode_stream(mp3, mlib.MP3S_PCM_I16)["pcm"])
+        n_exact = ctx.synth_mode(1.0)
+        assert np.array_equal(fast, exact)
+        assert n_exact >= beyond and n_exact > exact.size // 20, (n_exact, beyond, exact.size)
+    finally:
+        ctx.close()
+
+
 def test_fast_decode_across_transform_chunks(mlib):
     """A stream longer than one transform chunk (16 384 frames, one frame of halo in front of the second chunk) with the
     guard inflated: the fix-up kernel recomputes flagged samples of both chunks from `is`, with the halo frame as priming."""
