@@ -160,15 +160,26 @@ __device__ __forceinline__ void dec_prepare(const DevTables &tab, DecShared &sh,
         __builtin_amdgcn_s_waitcnt(0xc07f);
         __builtin_amdgcn_wave_barrier();
         // ---- requantise (Frame.py:210-215): ((sign * |is|^(4/3)) * 2^(exp1/4)) * 2^(-exp2)
+        // (|is|^(4/3) from a scalar base + a 32-bit lane offset: behind the table's 29 KB offset in DevTables the compiler built a 64-bit
+        // address per value, three vector instructions more; the map byte's two fields by bit-field extracts)
+        typedef const double __attribute__((address_space(1))) *gtab_ptr;
+        gtab_ptr p43 = (gtab_ptr)tab.pow43;
+        asm volatile("" : "+s"(p43));
 #pragma unroll
         for (int k = 0; k < 18; k++) {
             const int x = (int)(int16_t)(xw[k >> 1] >> ((k & 1) * 16));
-            const int m = (int)((mw[k >> 2] >> ((k & 3) * 8)) & 0xff);
-            int ax = x < 0 ? -x : x;
-            ax = ax < POW43_N ? ax : POW43_N - 1;
-            const double a = tab.pow43[ax];
-            const double sa = x < 0 ? -a : a;   // sign * a is exact
-            v[k] = (sa * e1[m >> 6]) * e2[m & 63];
+            const uint32_t mwk = mw[k >> 2];
+            // (spelled out: the compiler turns a bit-field extract + scaled add back into shift, mask and add)
+            uint32_t i1, i2;
+            asm("v_bfe_u32 %0, %1, %2, 2" : "=v"(i1) : "v"(mwk), "n"((k & 3) * 8 + 6));
+            asm("v_bfe_u32 %0, %1, %2, 6" : "=v"(i2) : "v"(mwk), "n"((k & 3) * 8));
+            uint32_t ax = (uint32_t)(x < 0 ? -x : x);
+            ax = ax < (uint32_t)POW43_N ? ax : (uint32_t)(POW43_N - 1);
+            const double a = p43[ax];
+            // sign * a is exact: the sign bit of the 16-bit value goes straight into the high word (a >= 0)
+            const uint32_t sgn = (k & 1) ? xw[k >> 1] : xw[k >> 1] << 16;
+            const double sa = __hiloint2double((int)(((uint32_t)__double2hiint(a) & 0x7fffffffu) | (sgn & 0x80000000u)), __double2loint(a));
+            v[k] = (sa * e1[i1]) * e2[i2];
         }
     }
     // ---- MS stereo (Frame.py:568-572): L = (M + S) / sqrt2, R = (M - S) / sqrt2
