@@ -70,29 +70,33 @@ __global__ __launch_bounds__(256, 4) void k_enc_analysis(
     // the usual case reads the tile without the per-row masks.
     const bool starts_inside = __ballot(valid && (t - 15) < s0) != 0;
     auto window_sums = [&](auto masked) {
+    // two k steps per trip: every y gets two products at a time, added by ONE v_add3_u32 (a product per trip cost an add each)
 #pragma unroll 1
-    for (int k = 0; k < 8; k++) {
-        const i32x16 *ewv = reinterpret_cast<const i32x16 *>(c_tab.enwindow + 64 * k);
+    for (int k = 0; k < 8; k += 2) {
+        const i32x16 *ewa = reinterpret_cast<const i32x16 *>(c_tab.enwindow + 64 * k), *ewb = ewa + 4;   // enwindow[64 (k + 1) ..]
 #pragma unroll
         for (int h = 0; h < 2; h++) {
-            const i32x16 e0 = ewv[2 * h], e1 = ewv[2 * h + 1];   // enwindow[64k + 32h .. +31]
-            const int back = 2 * k + h;                  // rows back from the lane's own row
-            const bool in_stream = (t - back) >= s0;     // ring x starts zeroed (MP3_Encoder.py:532-534)
-            const int16_t *rp = tw + (lane + 15 - back) * ENC_ROW;
+            const i32x16 a0 = ewa[2 * h], a1 = ewa[2 * h + 1];   // enwindow[64k + 32h .. +31]
+            const i32x16 b0 = ewb[2 * h], b1 = ewb[2 * h + 1];   // enwindow[64(k+1) + 32h .. +31]
+            const int back_a = 2 * k + h, back_b = back_a + 2;  // rows back from the lane's own row
+            const bool in_a = (t - back_a) >= s0, in_b = (t - back_b) >= s0;     // ring x starts zeroed (MP3_Encoder.py:532-534)
+            const int16_t *ra = tw + (lane + 15 - back_a) * ENC_ROW, *rb = ra - 2 * ENC_ROW;
 #pragma unroll
             for (int cb = 0; cb < 4; cb++) {
-                uint4 q = *reinterpret_cast<const uint4 *>(rp + cb * 8);
-                if (decltype(masked)::value && !in_stream) q = make_uint4(0, 0, 0, 0);
-                const uint32_t d[4] = {q.x, q.y, q.z, q.w};
+                uint4 qa = *reinterpret_cast<const uint4 *>(ra + cb * 8), qb = *reinterpret_cast<const uint4 *>(rb + cb * 8);
+                if (decltype(masked)::value && !in_a) qa = make_uint4(0, 0, 0, 0);
+                if (decltype(masked)::value && !in_b) qb = make_uint4(0, 0, 0, 0);
+                const uint32_t da[4] = {qa.x, qa.y, qa.z, qa.w}, db[4] = {qb.x, qb.y, qb.z, qb.w};
 #pragma unroll
                 for (int e = 0; e < 4; e++) {
                     const int col_lo = cb * 8 + 2 * e, col_hi = col_lo + 1;
                     const int c_lo = 31 - col_lo, c_hi = 31 - col_hi;          // coefficient within this half
-                    const int32_t x_lo = (int32_t)(d[e] << 16), x_hi = (int32_t)(d[e] & 0xffff0000u);
-                    y[h * 32 + c_lo] += mulhi_vs(x_lo, c_lo < 16 ? e0[c_lo & 15] : e1[c_lo & 15]);
-                    y[h * 32 + c_hi] += mulhi_vs(x_hi, c_hi < 16 ? e0[c_hi & 15] : e1[c_hi & 15]);
+                    const int32_t xa_lo = (int32_t)(da[e] << 16), xa_hi = (int32_t)(da[e] & 0xffff0000u);
+                    const int32_t xb_lo = (int32_t)(db[e] << 16), xb_hi = (int32_t)(db[e] & 0xffff0000u);
+                    y[h * 32 + c_lo] += mulhi_vs(xa_lo, c_lo < 16 ? a0[c_lo & 15] : a1[c_lo & 15]) + mulhi_vs(xb_lo, c_lo < 16 ? b0[c_lo & 15] : b1[c_lo & 15]);
+                    y[h * 32 + c_hi] += mulhi_vs(xa_hi, c_hi < 16 ? a0[c_hi & 15] : a1[c_hi & 15]) + mulhi_vs(xb_hi, c_hi < 16 ? b0[c_hi & 15] : b1[c_hi & 15]);
                 }
-                __builtin_amdgcn_sched_barrier(0);   // eight products at a time: bounds the scheduler's hoisting
+                __builtin_amdgcn_sched_barrier(0);   // sixteen products at a time: bounds the scheduler's hoisting
             }
         }
     }
