@@ -150,10 +150,14 @@ __global__ __launch_bounds__(256, 4) void k_enc_analysis(
     __builtin_amdgcn_s_waitcnt(0xc07f);
     __builtin_amdgcn_wave_barrier();
     uint32_t *out = reinterpret_cast<uint32_t *>(SB) + ((long)ch * Ts + t0) * 32;
+    // 16 bytes per lane and trip: eight lanes per 128-byte row, eight rows per trip (the scratch is 256-byte aligned, rows 128)
+    const int rows = (Ts - t0) < 64 ? (int)(Ts - t0) : 64;
 #pragma unroll 4
-    for (int e = lane; e < 64 * 32; e += 64) {
-        const int r = e >> 5, c = e & 31;
-        if (t0 + r < Ts) out[e] = ot[r * 33 + c];
+    for (int r = lane >> 3; r < 64; r += 8) {
+        const int c = (lane & 7) * 4;
+        const uint32_t *src = ot + r * 33 + c;
+        const uint4 v = make_uint4(src[0], src[1], src[2], src[3]);
+        if (r < rows) *reinterpret_cast<uint4 *>(out + r * 32 + c) = v;
     }
 }
 
