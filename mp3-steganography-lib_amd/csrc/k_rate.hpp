@@ -370,30 +370,42 @@ __device__ __forceinline__ void rate_units(
     __shared__ int32_t esq_all[RL_WAVES][580];
     const int sr0 = frames[0].sr_idx;             // one sample rate per launch (the host splits batches otherwise)
     const int sr_wg = sr0 >= 0 && sr0 < 3 ? sr0 : 0;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+    const int p0 = 5 * lane;                      // the lane's first pair
+    // The wave's own lines are asked for BEFORE the tables are staged (plain launches: one unit per wave): their latency passes
+    // under the staging and its barrier instead of behind it (staging measured at 7 % of the kernel, this wait at half as much again).
+    int2 xpre[RL_NP];
+    int u_pre = -1;
+    if (!CHAIN) {
+        const int li = blockIdx.x * RL_WAVES + wave;
+        if (li < n_list + var.n) {
+            const int32_t *ul = li >= n_list ? var.unit : unit_list;
+            const int lj = li >= n_list ? li - n_list : li;
+            u_pre = __builtin_amdgcn_readfirstlane(ul ? ul[lj] : lj);
+            if (u_pre >= 0 && u_pre < n_units) {
+                const int32_t *xr = mdct + (long)u_pre * 576;
+#pragma unroll
+                for (int m = 0; m < RL_NP; m++) {
+                    xpre[m] = make_int2(0, 0);
+                    if (p0 + m < 288) xpre[m] = *reinterpret_cast<const int2 *>(xr + 2 * (p0 + m));
+                }
+            }
+        }
+    }
     {
         static_assert(sizeof(tb.int2idx) % 16 == 0 && sizeof(c_tab.int2idx) == sizeof(tb.int2idx), "int2idx is staged 16 bytes at a time");
         const uint4 *src = reinterpret_cast<const uint4 *>(c_tab.int2idx);
         uint4 *dst = reinterpret_cast<uint4 *>(tb.int2idx);
         for (int i = threadIdx.x; i < (int)(sizeof(tb.int2idx) / 16); i += blockDim.x) dst[i] = src[i];
     }
-    for (int i = threadIdx.x; i < 256; i += blockDim.x) {
-        const uint32_t x = (uint32_t)i >> 4, y = (uint32_t)i & 15u;
-        tb.hl[i].x = (uint32_t)c_tab.hlen13[i] | ((uint32_t)c_tab.hlen15[i] << 5) | ((uint32_t)c_tab.hlen16[i] << 10) |
-                   ((uint32_t)c_tab.hlen24[i] << 15) | (((x != 0) + (y != 0)) << 20) | (((x == 15) + (y == 15)) << 22);
-        const uint32_t shortest = min(min((uint32_t)c_tab.hlen13[i], (uint32_t)c_tab.hlen15[i]), min((uint32_t)c_tab.hlen16[i], (uint32_t)c_tab.hlen24[i]));
-        if (i) tb.hl[i].x |= (shortest + (x != 0) + (y != 0)) << 25;
-        const uint32_t longest = max(max((uint32_t)c_tab.hlen13[i], (uint32_t)c_tab.hlen15[i]), max((uint32_t)c_tab.hlen16[i], (uint32_t)c_tab.hlen24[i]));
-        tb.hl[i].y = (i ? shortest + (x != 0) + (y != 0) : 0u) | ((longest + (x != 0) + (y != 0) + 13u * ((x == 15) + (y == 15))) << 16);
-    }
-    if (threadIdx.x < 16) tb.c1w[threadIdx.x] = (uint32_t)c_tab.hlen_c1a[threadIdx.x] | ((uint32_t)__popc(threadIdx.x & 3u) << 16);
+    for (int i = threadIdx.x; i < 256; i += blockDim.x) tb.hl[i] = make_uint2(c_tab.rl_hl[i][0], c_tab.rl_hl[i][1]);   // (built on the host: mp3s_tables.cpp)
+    if (threadIdx.x < 16) tb.c1w[threadIdx.x] = c_tab.rl_c1w[threadIdx.x];
     if (threadIdx.x < 64) tb.transform[threadIdx.x] = c_tab.transform[threadIdx.x >> 1][threadIdx.x & 1];
     for (int i = threadIdx.x; i < 289; i += blockDim.x) tb.subdiv[i] = c_tab.subdiv_lut[sr_wg][i];
     __syncthreads();
 
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
     uint32_t *pre = pre_all[wave];
     int32_t *esq = esq_all[wave];
-    const int p0 = 5 * lane;                      // the lane's first pair
     int li0 = blockIdx.x * RL_WAVES + wave;
     if (li0 >= n_list + var.n) return;
     do {                                          // (one trip unless CHAIN: the plain rate loop keeps its straight-line shape)
@@ -406,7 +418,7 @@ __device__ __forceinline__ void rate_units(
         ix_out = var.ix; out = var.out; en_out = var.en;
         compact = 2;
     }
-    int u = __builtin_amdgcn_readfirstlane(unit_list ? unit_list[li] : li);
+    int u = CHAIN ? __builtin_amdgcn_readfirstlane(unit_list ? unit_list[li] : li) : u_pre;
     if (u < 0 || u >= n_units) { if (CHAIN) continue; return; }
     // what the unit runs on: from the arrays (by unit, or by list position), or -- a unit reached through a chain -- from the run in front
     bool chained = false;
@@ -428,7 +440,8 @@ __device__ __forceinline__ void rate_units(
     for (int m = 0; m < RL_NP; m++) {
         const int p = p0 + m;
         int2 v = make_int2(0, 0);
-        if (p < 288) v = *reinterpret_cast<const int2 *>(xr + 2 * p);
+        if (!CHAIN) v = xpre[m];
+        else if (p < 288) v = *reinterpret_cast<const int2 *>(xr + 2 * p);
         const int32_t vv[2] = {v.x, v.y};
 #pragma unroll
         for (int e = 0; e < 2; e++) {

@@ -318,6 +318,16 @@ void build()
         T.hlen16[i] = ISO_HLEN_16[i]; T.hlen24[i] = ISO_HLEN_24[i];
     }
     for (int i = 0; i < 16; i++) T.hlen_c1a[i] = ISO_HLEN_32[i];
+    for (int i = 0; i < 256; i++) {
+        // (k_rate.hpp, RlTables::hl) .x: code length in books 13 | 15 << 5 | 16.. << 10 | 24.. << 15 | non-zero values << 20 | values > 14 << 22
+        // | (shortest of the four + non-zero values; 0 for the pair (0,0)) << 25;  .y: that shortest field | (longest + non-zero + 13 per escape) << 16
+        const uint32_t x = (uint32_t)i >> 4, y = (uint32_t)i & 15u, nz = (x != 0) + (y != 0), esc = (x == 15) + (y == 15);
+        const uint32_t l13 = T.hlen13[i], l15 = T.hlen15[i], l16 = T.hlen16[i], l24 = T.hlen24[i];
+        const uint32_t shortest = std::min(std::min(l13, l15), std::min(l16, l24)), longest = std::max(std::max(l13, l15), std::max(l16, l24));
+        T.rl_hl[i][0] = l13 | (l15 << 5) | (l16 << 10) | (l24 << 15) | (nz << 20) | (esc << 22) | (i ? (shortest + nz) << 25 : 0u);
+        T.rl_hl[i][1] = (i ? shortest + nz : 0u) | ((longest + nz + 13u * esc) << 16);
+    }
+    for (int i = 0; i < 16; i++) T.rl_c1w[i] = (uint32_t)T.hlen_c1a[i] | ((uint32_t)__builtin_popcount(i & 3) << 16);
     for (int i = 0; i < 32; i++) { T.linbits[i] = (uint8_t)H.huff[i].linbits; T.linmax[i] = H.huff[i].linmax; }
     // ---- device Huffman decode tables
     static const int kDecMax[32] = {1, 2, 3, 3, 0, 4, 4, 6, 6, 6, 8, 8, 8, 16, 0, 16,

@@ -58,7 +58,7 @@ struct DevTables {
     // that a window sum IS the sample's scaled value; synth_xbound * (largest sum |S| of a slot in the tile) bounds every
     // |sample * 32767| of the tile (32767 * Dsum and a little)
     double synth_window_fs[32][16];
-    double synth_xbound;
+    double synth_xbound, synth_reserved;   // (two doubles: what follows keeps its offset modulo 16, and the 16-byte aligned tables their padding)
     // k_dec_synth_fast's constants in the order it uses them, sixteen doubles (one scalar request, two cache lines) per step:
     // per interval t = 0..7  [row of X[17+2t]] [row of X[15-2t]] [rows of X[16+2t], X[16-2t]: 8 + 8, or 4 + 4, or 2 + 2 doubles
     // at 0 and 8, nothing for t = 0] then the taps (synth_window_f; [1]: synth_window_fs) of outputs a = 2t, b = 32 - 2t,
@@ -102,6 +102,10 @@ struct DevTables {
     // ---- Huffman code words for the device bit packer (k_enc_pack): books 13, 15, 16.., 24.. and count1 A
     uint32_t hcod[4][256];
     uint8_t hcod_c1a[16];
+    // ---- k_rate_loop's pair words as it keeps them in LDS (RlTables::hl, ::c1w in k_rate.hpp), built here once instead of by
+    //      every workgroup from the four code-length tables
+    uint32_t rl_hl[256][2];     // (lands on a 16-byte boundary: huf_tab is aligned, what lies between is 4 096 + 16 bytes)
+    uint32_t rl_c1w[16];
 };
 
 struct HostHuff {

@@ -226,3 +226,50 @@ def test_device_huffman_tables_decode_every_code_word(mlib, golden_dir):
                 assert list(pair(ea, (ea >> 8) & 15, hi) + pair(eb, (eb >> 8) & 15, hi)) == want, (bookb, val, signs)
                 checked += 1
     assert checked > 18000
+
+
+def test_tables_of_the_fast_synthesis_and_the_rate_loop_follow_from_the_reference_tables(mlib):
+    """Round 4's host-built kernel tables are rearrangements of tables pinned above: the window taps as k_dec_synth_fast multiplies them
+    (signs of the mirrored outputs moved into the taps, decoder/tables.py:429-514), their stream in the order of use, and the rate loop's
+    pair words (code lengths of books 13 / 15 / 16.. / 24.., encoder/tables.py)."""
+    t = mlib.debug_tables()
+    wt = np.array(t["synth_window_t"])
+    f = np.array(t["synth_window_f"]); fs = np.array(t["synth_window_fs"])
+    want = wt.copy()
+    want[0, 1::2] *= -1
+    want[16, 0::2] = 0
+    want[17:, 0::2] *= -1
+    assert np.array_equal(f, want) and np.array_equal(fs, want * 32767.0)
+    sf = np.array(t["synth_fast"]); st = np.array(t["synth_stream"])
+    C32, C16, C8, C4 = sf[:256].reshape(16, 16), sf[256:320].reshape(8, 8), sf[320:336].reshape(4, 4), sf[336:340].reshape(2, 2)
+    for v, W in ((0, f), (1, fs)):
+        for tt in range(8):
+            q = st[v, tt]
+            ka1, kb1, ka0, kb0 = 17 + 2 * tt, 15 - 2 * tt, 16 + 2 * tt, 16 - 2 * tt
+            assert np.array_equal(q[:16], C32[ka1 >> 1]) and np.array_equal(q[16:32], C32[kb1 >> 1])
+            if tt & 1:
+                assert np.array_equal(q[32:40], C16[(ka0 - 2) >> 2]) and np.array_equal(q[40:48], C16[(kb0 - 2) >> 2])
+            elif tt & 2:
+                assert np.array_equal(q[32:36], C8[(ka0 - 4) >> 3]) and np.array_equal(q[40:44], C8[(kb0 - 4) >> 3])
+            elif tt:
+                assert np.array_equal(q[32:34], C4[(ka0 - 8) >> 4]) and np.array_equal(q[40:42], C4[(kb0 - 8) >> 4])
+            oa, ob, oc, od = 2 * tt, (32 - 2 * tt if tt else 16), 2 * tt + 1, 31 - 2 * tt
+            if tt:
+                assert np.array_equal(q[48:56], W[oa, :8]) and np.array_equal(q[56:64], W[ob, :8])
+                assert np.array_equal(q[64:72], W[oa, 8:]) and np.array_equal(q[72:80], W[ob, 8:])
+            else:
+                assert np.array_equal(q[48:64], W[oa]) and np.array_equal(q[64:80], W[ob])
+            assert np.array_equal(q[80:88], W[oc, :8]) and np.array_equal(q[88:96], W[od, :8])
+            assert np.array_equal(q[96:104], W[oc, 8:]) and np.array_equal(q[104:112], W[od, 8:])
+    l = np.stack([np.array(t[k]).astype(np.uint32) for k in ("hlen13", "hlen15", "hlen16", "hlen24")])
+    i = np.arange(256, dtype=np.uint32)
+    x, y = i >> 4, i & 15
+    nz, esc = (x != 0).astype(np.uint32) + (y != 0), (x == 15).astype(np.uint32) + (y == 15)
+    shortest, longest = l.min(axis=0), l.max(axis=0)
+    hl = np.array(t["rl_hl"])
+    w0 = l[0] | (l[1] << 5) | (l[2] << 10) | (l[3] << 15) | (nz << 20) | (esc << 22) | np.where(i > 0, (shortest + nz) << 25, 0).astype(np.uint32)
+    w1 = np.where(i > 0, shortest + nz, 0).astype(np.uint32) | ((longest + nz + 13 * esc) << 16)
+    assert np.array_equal(hl[:, 0], w0) and np.array_equal(hl[:, 1], w1)
+    c1 = np.array(t["hlen_c1a"]).astype(np.uint32)
+    assert np.array_equal(np.array(t["rl_c1w"]), c1 | (np.array([bin(k & 3).count("1") for k in range(16)], dtype=np.uint32) << 16))
+    assert float(t["synth_xbound"]) >= 32767.0 * np.abs(wt).sum(axis=1).max()
