@@ -30,7 +30,8 @@ __device__ __forceinline__ int32_t mulhi_vs(int32_t v, int32_t s)
 typedef int32_t i32x4 __attribute__((ext_vector_type(4)));
 typedef int32_t i32x16 __attribute__((ext_vector_type(16)));
 
-constexpr int ENC_ROW = 40;   // int16 per LDS row: 32 samples + 8 pad (80-byte stride)
+constexpr int ENC_ROW = 34;   // int16 per LDS row: 32 samples + 2 pad: 17 dwords, so the 64 lanes' rows start in 32 different banks twice over
+                              // (the window sums read one sample per lane and instruction)
 constexpr int ENC_LDS_DW = 64 * 33;   // per-wave LDS in dwords: PCM tile (79 rows * 20 dw) first, then the 64 x 32 output tile (+1 pad)
 
 // SB layout: int32 [ch][Ts][32 bands] with Ts = n_frames * 36 slots (a 128-byte row per slot)
@@ -60,7 +61,8 @@ __global__ __launch_bounds__(256, 4) void k_enc_analysis(
             uint2 o;
             o.x = __builtin_amdgcn_perm(q.y, q.x, sel);
             o.y = __builtin_amdgcn_perm(q.w, q.z, sel);
-            *reinterpret_cast<uint2 *>(tw + (c >> 3) * ENC_ROW + (c & 7) * 4) = o;
+            uint32_t *dst = reinterpret_cast<uint32_t *>(tw + (c >> 3) * ENC_ROW + (c & 7) * 4);   // (rows are 4-byte aligned)
+            dst[0] = o.x; dst[1] = o.y;
         }
     } else {                                                    // (a caller's PCM that does not start on a 16-byte boundary)
         for (int e = lane; e < 79 * 32; e += 64) {
@@ -86,6 +88,16 @@ __global__ __launch_bounds__(256, 4) void k_enc_analysis(
     // A stream that starts inside the wave's window (its first slots see zeros where the ring x was still empty) is rare:
     // the usual case reads the tile without the per-row masks.
     const bool starts_inside = __ballot(valid && (t - 15) < s0) != 0;
+    // A sample reaches its multiplier as (sample << 16) (MP3_Encoder.py:341: the ring holds the PCM in the high half).  It is READ that way:
+    // ds_read_u16_d16_hi puts the 16 bits into the high half of a register and leaves the low half (zero throughout) alone -- one LDS
+    // instruction per sample instead of a 16-byte read per eight samples plus a shift or a mask for each: a ninth of the kernel's vector
+    // instructions moved to the LDS port, which the kernel hardly used.  The loads are inline assembly (the compiler has no pattern for
+    // them that keeps the low half): they, the wait behind a group of sixteen and the products are chained through the registers.
+    const uint32_t tw_lds = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const int16_t *)tw;
+    uint32_t xs[16];
+#pragma unroll
+    for (int i = 0; i < 16; i++) xs[i] = 0;
+#define MP3S_LDS_HI16(reg, addr, off) asm volatile("ds_read_u16_d16_hi %0, %1 offset:%2" : "+v"(reg) : "v"(addr), "n"(off))
     auto window_sums = [&](auto masked) {
     // two k steps per trip: every y gets two products at a time, added by ONE v_add3_u32 (a product per trip cost an add each)
 #pragma unroll 1
@@ -97,21 +109,24 @@ __global__ __launch_bounds__(256, 4) void k_enc_analysis(
             const i32x16 b0 = ewb[2 * h], b1 = ewb[2 * h + 1];   // enwindow[64(k+1) + 32h .. +31]
             const int back_a = 2 * k + h, back_b = back_a + 2;  // rows back from the lane's own row
             const bool in_a = (t - back_a) >= s0, in_b = (t - back_b) >= s0;     // ring x starts zeroed (MP3_Encoder.py:532-534)
-            const int16_t *ra = tw + (lane + 15 - back_a) * ENC_ROW, *rb = ra - 2 * ENC_ROW;
+            // sample 32t+31-m sits `m>>5` rows back at column 31-(m&31); one k step = rows 2k and 2k+1 back
+            const uint32_t ra = tw_lds + (uint32_t)((lane + 15 - back_a) * ENC_ROW * 2), rb = ra - 2 * ENC_ROW * 2;
 #pragma unroll
             for (int cb = 0; cb < 4; cb++) {
-                uint4 qa = *reinterpret_cast<const uint4 *>(ra + cb * 8), qb = *reinterpret_cast<const uint4 *>(rb + cb * 8);
-                if (decltype(masked)::value && !in_a) qa = make_uint4(0, 0, 0, 0);
-                if (decltype(masked)::value && !in_b) qb = make_uint4(0, 0, 0, 0);
-                const uint32_t da[4] = {qa.x, qa.y, qa.z, qa.w}, db[4] = {qb.x, qb.y, qb.z, qb.w};
 #pragma unroll
-                for (int e = 0; e < 4; e++) {
-                    const int col_lo = cb * 8 + 2 * e, col_hi = col_lo + 1;
-                    const int c_lo = 31 - col_lo, c_hi = 31 - col_hi;          // coefficient within this half
-                    const int32_t xa_lo = (int32_t)(da[e] << 16), xa_hi = (int32_t)(da[e] & 0xffff0000u);
-                    const int32_t xb_lo = (int32_t)(db[e] << 16), xb_hi = (int32_t)(db[e] & 0xffff0000u);
-                    y[h * 32 + c_lo] += mulhi_vs(xa_lo, c_lo < 16 ? a0[c_lo & 15] : a1[c_lo & 15]) + mulhi_vs(xb_lo, c_lo < 16 ? b0[c_lo & 15] : b1[c_lo & 15]);
-                    y[h * 32 + c_hi] += mulhi_vs(xa_hi, c_hi < 16 ? a0[c_hi & 15] : a1[c_hi & 15]) + mulhi_vs(xb_hi, c_hi < 16 ? b0[c_hi & 15] : b1[c_hi & 15]);
+                for (int e = 0; e < 8; e++) {                   // columns 8 cb .. 8 cb + 7 of both rows
+                    MP3S_LDS_HI16(xs[e], ra, (cb * 8 + e) * 2);
+                    MP3S_LDS_HI16(xs[8 + e], rb, (cb * 8 + e) * 2);
+                }
+                asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(xs[0]), "+v"(xs[1]), "+v"(xs[2]), "+v"(xs[3]), "+v"(xs[4]), "+v"(xs[5]), "+v"(xs[6]), "+v"(xs[7]),
+                             "+v"(xs[8]), "+v"(xs[9]), "+v"(xs[10]), "+v"(xs[11]), "+v"(xs[12]), "+v"(xs[13]), "+v"(xs[14]), "+v"(xs[15]));
+#pragma unroll
+                for (int e = 0; e < 8; e++) {
+                    const int col = cb * 8 + e, c = 31 - col;                 // coefficient within this half
+                    int32_t xa = (int32_t)xs[e], xb = (int32_t)xs[8 + e];
+                    if (decltype(masked)::value && !in_a) xa = 0;
+                    if (decltype(masked)::value && !in_b) xb = 0;
+                    y[h * 32 + c] += mulhi_vs(xa, c < 16 ? a0[c & 15] : a1[c & 15]) + mulhi_vs(xb, c < 16 ? b0[c & 15] : b1[c & 15]);
                 }
                 __builtin_amdgcn_sched_barrier(0);   // sixteen products at a time: bounds the scheduler's hoisting
             }
@@ -119,6 +134,7 @@ __global__ __launch_bounds__(256, 4) void k_enc_analysis(
     }
     };
     if (starts_inside) window_sums(std::true_type{}); else window_sums(std::false_type{});
+#undef MP3S_LDS_HI16
     // ---- s[sb] = sum_j mul(fl[sb][j], y[j])   (MP3_Encoder.py:358-368); four bands per pass for ILP.
     // Results are staged in the wave's LDS region as [slot][band] (33-dword rows) and written out as rows.
     const bool odd_slot = (t & 1) != 0;      // slot-in-granule parity == slot parity (18 is even)
