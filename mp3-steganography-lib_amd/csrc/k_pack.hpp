@@ -120,14 +120,17 @@ __global__ __launch_bounds__(256) void k_enc_pack(
             }
         }
     }
-    if (lane == 0) {
-        // ---- side info of this wave's granule*channel (:1305-1337), 59 bits at 52 + 59 e
-        uint32_t pos = 52 + 59 * (uint32_t)e;
-        auto put = [&](uint32_t v, int n) { lds_put(fb, pos, v, n); pos += n; };
-        put(((uint32_t)p23v[e] << 9) | (uint32_t)g.big_values, 21);
-        put((((uint32_t)(g.quantizer_step + 210) & 0xff) << 5), 13);            // global_gain 8, scalefac_compress 4, window_switching 1
-        put(((uint32_t)g.table_select[0] << 10) | ((uint32_t)g.table_select[1] << 5) | (uint32_t)g.table_select[2], 15);
-        put(((uint32_t)g.region0_count << 6) | ((uint32_t)g.region1_count << 3) | (uint32_t)g.count1table_select, 10);   // + preflag, scalefac_scale = 0
+    if (lane < 4) {
+        // ---- side info of this wave's granule*channel (:1305-1337), 59 bits at 52 + 59 e: its four fields by four lanes, one put each
+        //      (one lane putting them one after the other had the whole wave step through four times the instructions)
+        const uint32_t f0 = ((uint32_t)p23v[e] << 9) | (uint32_t)g.big_values;                                            // 21 bits
+        const uint32_t f1 = (((uint32_t)(g.quantizer_step + 210) & 0xff) << 5);                                           // 13: global_gain 8, scalefac_compress 4, window_switching 1
+        const uint32_t f2 = ((uint32_t)g.table_select[0] << 10) | ((uint32_t)g.table_select[1] << 5) | (uint32_t)g.table_select[2];   // 15
+        const uint32_t f3 = ((uint32_t)g.region0_count << 6) | ((uint32_t)g.region1_count << 3) | (uint32_t)g.count1table_select;     // 10: + preflag, scalefac_scale = 0
+        const uint32_t v = lane == 0 ? f0 : (lane == 1 ? f1 : (lane == 2 ? f2 : f3));
+        const int n = lane == 0 ? 21 : (lane == 1 ? 13 : (lane == 2 ? 15 : 10));
+        const uint32_t at = lane == 0 ? 0u : (lane == 1 ? 21u : (lane == 2 ? 34u : 49u));
+        lds_put(fb, 52 + 59 * (uint32_t)e + at, v, n);
     }
 
     // ---- main data of this wave's granule*channel (:1394-1446)
