@@ -214,22 +214,27 @@ __device__ __forceinline__ int rl_body(const RlTables &tb, const int32_t (&ix)[2
         // inside the count1 region every value is 0 or 1, so x + 2y is the pair's code there; elsewhere the sum is only
         // kept inside the table (& 15) and its result dropped
 #pragma unroll
-        for (int m = 0; m < RL_NP; m++) c2[m] = (uint32_t)(ix[2 * m] + 2 * ix[2 * m + 1]);
-        c2[RL_NP] = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)c2[0], 0x130, 0xf, 0xf, false);   // wave_shl:1 = lane + 1's
-        const uint32_t c1n = (uint32_t)(2 * count1);
-        const uint32_t rel0 = (uint32_t)(p0 - bv);
-        // a pair at an even distance from big_values starts a quad (code length + its ones), the others add their ones only
-        const uint32_t keep_even = (rel0 & 1u) ? 0xffff0000u : 0xffffffffu, keep_odd = (rel0 & 1u) ? 0xffffffffu : 0xffff0000u;
-#pragma unroll
         for (int m = 0; m < RL_NP; m++) {
             const int x = ix[2 * m], y = ix[2 * m + 1];
             const uint2 hh = tb.hl[(x > 14 ? 15 : x) * 16 + (y > 14 ? 15 : y)];
-            const uint32_t quad = tb.c1w[(c2[m] | (c2[m + 1] << 2)) & 15u];
             h[m] = hh.x;
             bnd += (p0 + m) < bv ? hh.y : (2 * (p0 + m) < reach ? hh.y & 0xffff0000u : 0u);
-            acc += rel0 + (uint32_t)m < c1n ? quad & ((m & 1) ? keep_odd : keep_even) : 0u;
         }
-        wave_add2(bnd, acc);
+        if (count1 > 0) {                                   // (wave-uniform: a probe whose values are all above 1 up to the last non-zero pair has no quads)
+#pragma unroll
+            for (int m = 0; m < RL_NP; m++) c2[m] = (uint32_t)(ix[2 * m] + 2 * ix[2 * m + 1]);
+            c2[RL_NP] = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)c2[0], 0x130, 0xf, 0xf, false);   // wave_shl:1 = lane + 1's
+            const uint32_t c1n = (uint32_t)(2 * count1);
+            const uint32_t rel0 = (uint32_t)(p0 - bv);
+            // a pair at an even distance from big_values starts a quad (code length + its ones), the others add their ones only
+            const uint32_t keep_even = (rel0 & 1u) ? 0xffff0000u : 0xffffffffu, keep_odd = (rel0 & 1u) ? 0xffffffffu : 0xffff0000u;
+#pragma unroll
+            for (int m = 0; m < RL_NP; m++) {
+                const uint32_t quad = tb.c1w[(c2[m] | (c2[m + 1] << 2)) & 15u];
+                acc += rel0 + (uint32_t)m < c1n ? quad & ((m & 1) ? keep_odd : keep_even) : 0u;
+            }
+            wave_add2(bnd, acc);
+        } else bnd = wave_add_u32(bnd);
     }
     const int signs = (int)(acc >> 16), sum0 = signs + (int)(acc & 0xffff), sum1 = signs + 4 * count1;
     int bits;
