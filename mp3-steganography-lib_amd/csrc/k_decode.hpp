@@ -493,6 +493,45 @@ __device__ __forceinline__ int16_t pcm_to_i16(double v)
     return (int16_t)(uint16_t)((uint32_t)(int32_t)x & 0xffffu);
 }
 
+// The 64 rows of S a synthesis wave needs (256 bytes each, one per lane) are one contiguous 16 KB: fetched in four rounds of four requests in
+// which FOUR LANES SHARE A CACHE LINE (lane l: row l / 4 + 16 k, 16-byte column 4 r + l % 4), through 5 KB of LDS to the lane that owns the
+// row.  (Every lane reading its own row, 16 bytes per request, touched 64 lines per request and used a quarter of each: beside other kernels the
+// synthesis was paying for the traffic between L2 and the vector caches -- the step 0.663-0.670 -> 0.652-0.659 ms.)  `stage`: the wave's own
+// SYNTH_STAGE_WAVE bytes; they may be reused once every wave of the workgroup is behind a barrier.
+constexpr int SYNTH_STAGE_ROW = 80, SYNTH_STAGE_WAVE = 64 * SYNTH_STAGE_ROW;
+__device__ __forceinline__ void synth_fetch_rows(unsigned char *stage, const double *__restrict__ S, long T, int ch, long t, int lane, double (&Sv)[32])
+{
+    const long tw0 = t - lane;                                     // slot of the wave's lane 0
+    const double *blk = S + ((long)ch * T + tw0) * 32;             // (rows outside the batch are not read)
+    uint4 q[2][4];
+    auto fetch = [&](int r, uint4 (&qq)[4]) {
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const int row = (lane >> 2) + 16 * k;
+            const long tr = tw0 + row;
+            qq[k] = make_uint4(0, 0, 0, 0);
+            if (tr >= 0 && tr < T) qq[k] = *reinterpret_cast<const uint4 *>(blk + row * 32 + (4 * r + (lane & 3)) * 2);
+        }
+    };
+    fetch(0, q[0]);
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+        if (r < 3) fetch(r + 1, q[(r + 1) & 1]);
+        __builtin_amdgcn_wave_barrier();                           // (the round before has been read back)
+#pragma unroll
+        for (int k = 0; k < 4; k++)
+            *reinterpret_cast<uint4 *>(stage + ((lane >> 2) + 16 * k) * SYNTH_STAGE_ROW + (lane & 3) * 16) = q[r & 1][k];
+        __builtin_amdgcn_s_waitcnt(0xc07f);
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int c = 0; c < 4; c++) {
+            const double2 v = *reinterpret_cast<const double2 *>(stage + lane * SYNTH_STAGE_ROW + c * 16);
+            Sv[8 * r + 2 * c] = v.x; Sv[8 * r + 2 * c + 1] = v.y;
+        }
+        __builtin_amdgcn_s_waitcnt(0xc07f);
+    }
+}
+
 template <int TW>
 __global__ __launch_bounds__(TW * 64 * 2, 5) void k_dec_synth(
     const double *__restrict__ S, long T, const mp3s_frame_hdr *__restrict__ hdr, int nch, int n_halo, int out_format,
@@ -500,8 +539,13 @@ __global__ __launch_bounds__(TW * 64 * 2, 5) void k_dec_synth(
 {
     constexpr int TL_LANES = TW * 64, OUT = TL_LANES - 15;
     constexpr int OROW = 33;                                   // dwords per staged slot (32 + 1 pad: no bank conflicts)
-    __shared__ double ex[2][2][4][TL_LANES];                   // [parity][ch][index of the pair * 2 + V half][lane]
-    __shared__ uint32_t otile[OUT * OROW];
+    // one block of LDS: ex[2][2][4][TL_LANES] doubles ([parity][ch][index of the pair * 2 + V half][lane]) | otile[OUT * OROW] dwords; in front
+    // of the loop the same bytes stage the waves' rows of S (synth_fetch_rows)
+    constexpr int EX_BYTES = 2 * 2 * 4 * TL_LANES * 8, OT_BYTES = OUT * OROW * 4;
+    static_assert(TW * 2 * SYNTH_STAGE_WAVE <= EX_BYTES + OT_BYTES, "the staging of S fits the loop's LDS");
+    __shared__ __attribute__((aligned(16))) unsigned char lds_raw[EX_BYTES + OT_BYTES];
+    double (*const ex)[2][4][TL_LANES] = reinterpret_cast<double (*)[2][4][TL_LANES]>(lds_raw);
+    uint32_t *const otile = reinterpret_cast<uint32_t *>(lds_raw + EX_BYTES);
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
     const int ch = wave / TW, tl = (wave % TW) * 64 + lane;
     const long tile0 = (long)xcd_tile() * OUT;
@@ -514,15 +558,8 @@ __global__ __launch_bounds__(TW * 64 * 2, 5) void k_dec_synth(
         lim = (int)((t - s0) < 64 ? (t - s0) : 64);
     }
     double Sv[32];
-    {
-        const double2 *sp = reinterpret_cast<const double2 *>(S + ((long)ch * T + (valid ? t : 0)) * 32);
-#pragma unroll
-        for (int j = 0; j < 16; j++) {
-            double2 q = make_double2(0.0, 0.0);
-            if (valid) q = sp[j];
-            Sv[2 * j] = q.x; Sv[2 * j + 1] = q.y;
-        }
-    }
+    synth_fetch_rows(lds_raw + wave * SYNTH_STAGE_WAVE, S, T, ch, t, lane, Sv);
+    __syncthreads();                                           // (the staging bytes become the exchange buffers)
     const long halo_slots = (long)n_halo * 36;
     const bool emit = valid && tl >= 15 && t >= halo_slots;
     const bool full_hist = __ballot(tl >= 15 && lim < 15) == 0;
@@ -675,8 +712,8 @@ __global__ __launch_bounds__(TW * 64 * 2, TW == 4 ? 2 : 4) void k_dec_synth_fast
     constexpr int OROW = 33;
     // one block of LDS: ex[2][2][4][TL_LANES] doubles | otile[(OUT + 1) * OROW] dwords (+ one row nobody reads: where the lanes that do not
     // emit put their samples); in front of the loop the same bytes stage the waves' rows of S (below)
-    constexpr int EX_BYTES = 2 * 2 * 4 * TL_LANES * 8, OT_BYTES = (OUT + 1) * OROW * 4, STAGE_ROW = 80, STAGE_WAVE = 64 * STAGE_ROW;
-    static_assert(TW * 2 * STAGE_WAVE <= EX_BYTES + OT_BYTES, "the staging of S fits the loop's LDS");
+    constexpr int EX_BYTES = 2 * 2 * 4 * TL_LANES * 8, OT_BYTES = (OUT + 1) * OROW * 4;
+    static_assert(TW * 2 * SYNTH_STAGE_WAVE <= EX_BYTES + OT_BYTES, "the staging of S fits the loop's LDS");
     __shared__ __attribute__((aligned(16))) unsigned char lds_raw[EX_BYTES + OT_BYTES];
     double (*const ex)[2][4][TL_LANES] = reinterpret_cast<double (*)[2][4][TL_LANES]>(lds_raw);
     uint32_t *const otile = reinterpret_cast<uint32_t *>(lds_raw + EX_BYTES);
@@ -711,42 +748,7 @@ __global__ __launch_bounds__(TW * 64 * 2, TW == 4 ? 2 : 4) void k_dec_synth_fast
     double asum = 0.0;
     {
         double Sv[32];
-        // The wave's 64 rows of S (256 bytes each, one per lane) are one contiguous 16 KB: fetched in four rounds of four requests in which
-        // FOUR LANES SHARE A CACHE LINE (lane l: row l / 4 + 16 k, 16-byte column 4 r + l % 4), through LDS to the lane that owns the row.
-        // (Every lane reading its own row, 16 bytes per request, touched 64 lines per request and used a quarter of each: the kernel alone
-        // was bound by the traffic between L2 and the vector caches, 0.099 -> 0.08 ms.)
-        {
-            unsigned char *stage = lds_raw + wave * STAGE_WAVE;
-            const long tw0 = t - lane;                                     // slot of the wave's lane 0
-            const double *blk = S + ((long)ch * T + tw0) * 32;             // (rows outside the batch are not read)
-            uint4 q[2][4];
-            auto fetch = [&](int r, uint4 (&qq)[4]) {
-#pragma unroll
-                for (int k = 0; k < 4; k++) {
-                    const int row = (lane >> 2) + 16 * k;
-                    const long tr = tw0 + row;
-                    qq[k] = make_uint4(0, 0, 0, 0);
-                    if (tr >= 0 && tr < T) qq[k] = *reinterpret_cast<const uint4 *>(blk + row * 32 + (4 * r + (lane & 3)) * 2);
-                }
-            };
-            fetch(0, q[0]);
-#pragma unroll
-            for (int r = 0; r < 4; r++) {
-                if (r < 3) fetch(r + 1, q[(r + 1) & 1]);
-                __builtin_amdgcn_wave_barrier();                           // (the round before has been read back)
-#pragma unroll
-                for (int k = 0; k < 4; k++)
-                    *reinterpret_cast<uint4 *>(stage + ((lane >> 2) + 16 * k) * STAGE_ROW + (lane & 3) * 16) = q[r & 1][k];
-                __builtin_amdgcn_s_waitcnt(0xc07f);
-                __builtin_amdgcn_wave_barrier();
-#pragma unroll
-                for (int c = 0; c < 4; c++) {
-                    const double2 v = *reinterpret_cast<const double2 *>(stage + lane * STAGE_ROW + c * 16);
-                    Sv[8 * r + 2 * c] = v.x; Sv[8 * r + 2 * c + 1] = v.y;
-                }
-                __builtin_amdgcn_s_waitcnt(0xc07f);
-            }
-        }
+        synth_fetch_rows(lds_raw + wave * SYNTH_STAGE_WAVE, S, T, ch, t, lane, Sv);
 #pragma unroll
         for (int j = 0; j < 32; j++) asum += fabs(Sv[j]);
         double u16[16], u8[8], u4[4], u2[2];
