@@ -397,22 +397,41 @@ __device__ __forceinline__ void rate_units(
             }
         }
     }
+    // The tables: asked for HERE, put into LDS and waited for (the workgroup's one barrier) where a wave first needs them -- in a plain launch
+    // behind its unit's own front (lines, energies, scfsi logs: nothing of it reads a table), so that the tables' way through the caches passes
+    // under that arithmetic; a re-run launch (CHAIN) stages them at once.
+    static_assert(sizeof(tb.int2idx) % 16 == 0 && sizeof(c_tab.int2idx) == sizeof(tb.int2idx), "int2idx is staged 16 bytes at a time");
+    constexpr int I2I_CHUNKS = (int)(sizeof(tb.int2idx) / 16), I2I_ROUNDS = (I2I_CHUNKS + RL_WAVES * 64 - 1) / (RL_WAVES * 64);
+    uint4 t_i2i[I2I_ROUNDS];
+    uint2 t_hl;
+    uint32_t t_c1w = 0, t_tr = 0, t_sd[2];
     {
-        static_assert(sizeof(tb.int2idx) % 16 == 0 && sizeof(c_tab.int2idx) == sizeof(tb.int2idx), "int2idx is staged 16 bytes at a time");
         const uint4 *src = reinterpret_cast<const uint4 *>(c_tab.int2idx);
-        uint4 *dst = reinterpret_cast<uint4 *>(tb.int2idx);
-        for (int i = threadIdx.x; i < (int)(sizeof(tb.int2idx) / 16); i += blockDim.x) dst[i] = src[i];
+#pragma unroll
+        for (int r = 0; r < I2I_ROUNDS; r++) { const int i = (int)threadIdx.x + r * RL_WAVES * 64; t_i2i[r] = src[i < I2I_CHUNKS ? i : I2I_CHUNKS - 1]; }
+        t_hl = make_uint2(c_tab.rl_hl[threadIdx.x & 255][0], c_tab.rl_hl[threadIdx.x & 255][1]);   // (built on the host: mp3s_tables.cpp)
+        if (threadIdx.x < 16) t_c1w = c_tab.rl_c1w[threadIdx.x];
+        if (threadIdx.x < 64) t_tr = c_tab.transform[threadIdx.x >> 1][threadIdx.x & 1];
+#pragma unroll
+        for (int r = 0; r < 2; r++) { const int i = (int)threadIdx.x + r * RL_WAVES * 64; t_sd[r] = c_tab.subdiv_lut[sr_wg][i < 289 ? i : 288]; }
     }
-    for (int i = threadIdx.x; i < 256; i += blockDim.x) tb.hl[i] = make_uint2(c_tab.rl_hl[i][0], c_tab.rl_hl[i][1]);   // (built on the host: mp3s_tables.cpp)
-    if (threadIdx.x < 16) tb.c1w[threadIdx.x] = c_tab.rl_c1w[threadIdx.x];
-    if (threadIdx.x < 64) tb.transform[threadIdx.x] = c_tab.transform[threadIdx.x >> 1][threadIdx.x & 1];
-    for (int i = threadIdx.x; i < 289; i += blockDim.x) tb.subdiv[i] = c_tab.subdiv_lut[sr_wg][i];
-    __syncthreads();
+    auto tables_in = [&]() {
+        uint4 *dst = reinterpret_cast<uint4 *>(tb.int2idx);
+#pragma unroll
+        for (int r = 0; r < I2I_ROUNDS; r++) { const int i = (int)threadIdx.x + r * RL_WAVES * 64; if (i < I2I_CHUNKS) dst[i] = t_i2i[r]; }
+        tb.hl[threadIdx.x & 255] = t_hl;
+        if (threadIdx.x < 16) tb.c1w[threadIdx.x] = t_c1w;
+        if (threadIdx.x < 64) tb.transform[threadIdx.x] = (uint8_t)t_tr;
+#pragma unroll
+        for (int r = 0; r < 2; r++) { const int i = (int)threadIdx.x + r * RL_WAVES * 64; if (i < 289) tb.subdiv[i] = t_sd[r]; }
+        __syncthreads();
+    };
+    if (CHAIN) tables_in();
 
     uint32_t *pre = pre_all[wave];
     int32_t *esq = esq_all[wave];
     int li0 = blockIdx.x * RL_WAVES + wave;
-    if (li0 >= n_list + var.n) return;
+    if (li0 >= n_list + var.n) { if (!CHAIN) tables_in(); return; }
     do {                                          // (one trip unless CHAIN: the plain rate loop keeps its straight-line shape)
     int li = li0;
     uint8_t *tables_out = nullptr;
@@ -424,7 +443,7 @@ __device__ __forceinline__ void rate_units(
         compact = 2;
     }
     int u = CHAIN ? __builtin_amdgcn_readfirstlane(unit_list ? unit_list[li] : li) : u_pre;
-    if (u < 0 || u >= n_units) { if (CHAIN) continue; return; }
+    if (u < 0 || u >= n_units) { if (CHAIN) continue; tables_in(); return; }
     // what the unit runs on: from the arrays (by unit, or by list position), or -- a unit reached through a chain -- from the run in front
     bool chained = false;
     int ch_cursor = 0, ch_state[4] = {0, 0, 0, 0};
@@ -510,6 +529,7 @@ __device__ __forceinline__ void rate_units(
         int bits = 0, flags = 0;
         bool err = false;
 
+        if (!CHAIN) tables_in();               // (every wave of the workgroup comes by here, or by one of the two returns above, exactly once)
         if (xrmax) {
             flags |= MP3S_RF_ACTIVE;
             // ---- __bin_search_step_size (:958-996)
