@@ -697,7 +697,7 @@ typedef struct {
     int64_t resolved;                 /* collected jobs whose cursor / address guess failed and whose chains the host resolved on the job's
                                        * own device buffers (scan, decode and transforms kept); fast + resolved + slow = collected */
     /* how the pipe's streams were chosen when it was made (the runtime maps streams onto a few hardware queues; a pipeline whose
-     * stages share queues loses its overlap): `rehearsals` miniature jobs of about 1 ms each, at most 12 and 15 ms in all (0: a
+     * stages share queues loses its overlap): `rehearsals` miniature jobs of about 1 ms each, at most 12 and 15 ms in all -- 13 x the one-stream miniature, within 60 ms, where that is more (0: a
      * pipe made earlier on this context's stream decided), judged against the same miniature on ONE stream */
     double rehearsal_ms;
     int64_t rehearsals;

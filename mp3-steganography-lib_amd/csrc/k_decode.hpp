@@ -501,31 +501,39 @@ __device__ __forceinline__ int16_t pcm_to_i16(double v)
 constexpr int SYNTH_STAGE_ROW = 80, SYNTH_STAGE_WAVE = 64 * SYNTH_STAGE_ROW;
 __device__ __forceinline__ void synth_fetch_rows(unsigned char *stage, const double *__restrict__ S, long T, int ch, long t, int lane, double (&Sv)[32])
 {
-    const long tw0 = t - lane;                                     // slot of the wave's lane 0
-    const double *blk = S + ((long)ch * T + tw0) * 32;             // (rows outside the batch are not read)
+    const long tw0 = __builtin_amdgcn_readfirstlane((int)((t - lane) >> 32)) * 0x100000000l + (uint32_t)__builtin_amdgcn_readfirstlane((int)(t - lane));   // slot of the wave's lane 0 (a scalar)
+    // the wave's block behind a scalar base + a 32-bit lane offset (global address space spelled out: the loads take the base as it is)
+    typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+    typedef const u32x4 __attribute__((address_space(1))) *gq_ptr;
+    gq_ptr blk = (gq_ptr)(S + ((long)ch * T + tw0) * 32);                 // (rows outside the batch are not read)
+    const uint32_t voff = (uint32_t)((lane >> 2) * 16 + (lane & 3));      // in 16-byte units: row lane / 4, column lane % 4
+    const bool inside = tw0 >= 0 && tw0 + 64 <= T;                        // (wave-uniform: all but a batch's first and last tiles)
+    const int rlo = tw0 < 0 ? (int)-tw0 : 0, rhi = T - tw0 < 64 ? (int)(T - tw0) : 64;
     uint4 q[2][4];
     auto fetch = [&](int r, uint4 (&qq)[4]) {
 #pragma unroll
         for (int k = 0; k < 4; k++) {
             const int row = (lane >> 2) + 16 * k;
-            const long tr = tw0 + row;
-            qq[k] = make_uint4(0, 0, 0, 0);
-            if (tr >= 0 && tr < T) qq[k] = *reinterpret_cast<const uint4 *>(blk + row * 32 + (4 * r + (lane & 3)) * 2);
+            if (inside) { const u32x4 v = blk[voff + (uint32_t)(k * 256 + r * 4)]; qq[k] = make_uint4(v.x, v.y, v.z, v.w); }
+            else {
+                qq[k] = make_uint4(0, 0, 0, 0);
+                if (row >= rlo && row < rhi) { const u32x4 v = blk[voff + (uint32_t)(k * 256 + r * 4)]; qq[k] = make_uint4(v.x, v.y, v.z, v.w); }
+            }
         }
     };
+    const uint32_t wr = (uint32_t)((lane >> 2) * SYNTH_STAGE_ROW + (lane & 3) * 16), rd = (uint32_t)(lane * SYNTH_STAGE_ROW);
     fetch(0, q[0]);
 #pragma unroll
     for (int r = 0; r < 4; r++) {
         if (r < 3) fetch(r + 1, q[(r + 1) & 1]);
         __builtin_amdgcn_wave_barrier();                           // (the round before has been read back)
 #pragma unroll
-        for (int k = 0; k < 4; k++)
-            *reinterpret_cast<uint4 *>(stage + ((lane >> 2) + 16 * k) * SYNTH_STAGE_ROW + (lane & 3) * 16) = q[r & 1][k];
+        for (int k = 0; k < 4; k++) *reinterpret_cast<uint4 *>(stage + wr + k * 16 * SYNTH_STAGE_ROW) = q[r & 1][k];
         __builtin_amdgcn_s_waitcnt(0xc07f);
         __builtin_amdgcn_wave_barrier();
 #pragma unroll
         for (int c = 0; c < 4; c++) {
-            const double2 v = *reinterpret_cast<const double2 *>(stage + lane * SYNTH_STAGE_ROW + c * 16);
+            const double2 v = *reinterpret_cast<const double2 *>(stage + rd + c * 16);
             Sv[8 * r + 2 * c] = v.x; Sv[8 * r + 2 * c + 1] = v.y;
         }
         __builtin_amdgcn_s_waitcnt(0xc07f);

@@ -72,7 +72,7 @@ std::vector<LanePool> &lane_pools() { static auto *v = new std::vector<LanePool>
 // with the choice (mp3s_pipe_stats / mp3s_ctx_run_stats: rehearsal_ms, rehearsals, lanes, queue_shared).
 constexpr float kOverlapOk = 0.94f;
 constexpr int kMaxRehearsals = 12;
-constexpr double kMaxRehearsalMs = 15.0;
+constexpr double kMaxRehearsalMs = 15.0, kMaxRehearsalMsSlow = 60.0;
 
 int pick_lanes(mp3s_ctx *c, hipStream_t *up, hipStream_t *down, hipStream_t *huff, hipStream_t *comp /* a stream to compute on instead of the context's, or null */,
                hipStream_t *tail /* a stream for the tail of a job, or null */, int want_tail /* 0: none, 1: always, 2: if the rehearsal is faster with it */,
@@ -121,7 +121,11 @@ int pick_lanes(mp3s_ctx *c, hipStream_t *up, hipStream_t *down, hipStream_t *huf
     const double t_begin = now_ms();
     int runs = 0;
     std::string seen;
-    auto may_run = [&] { return runs < kMaxRehearsals && now_ms() - t_begin < kMaxRehearsalMs; };
+    // (the time limit follows the process's own pace: where a miniature takes 4 ms instead of 1.2 -- seen once, in a bench run on one box:
+    // four miniatures in 15.9 ms, the tail candidates never tried, one-file calls at 1.83 instead of 1.19 ms for the life of the
+    // context -- thirteen of them are allowed their time, within kMaxRehearsalMsSlow)
+    double budget_ms = kMaxRehearsalMs;
+    auto may_run = [&] { return runs < kMaxRehearsals && now_ms() - t_begin < budget_ms; };
     auto run = [&](hipStream_t comp_s, hipStream_t u, hipStream_t d, hipStream_t h, hipStream_t t = nullptr) {
         runs++;
         const float ms = rehearse(lp, comp_s, u, d, h, t);
@@ -132,6 +136,7 @@ int pick_lanes(mp3s_ctx *c, hipStream_t *up, hipStream_t *down, hipStream_t *huf
     (void)hipStreamSynchronize(c->stream);
     const float serial = run(c->stream, c->stream, c->stream, c->stream);   // the unshared baseline: every stage on ONE stream
     const float good = serial * kOverlapOk;
+    if (serial < 1e8f) budget_ms = std::min(kMaxRehearsalMsSlow, std::max(kMaxRehearsalMs, 13.0 * (double)serial));
     if (trace_on()) seen += " (serial) |";
     // the context's own stream with the rotations of the lanes, until one gets the miniature through as an unshared pipeline does
     int best = 0, best_cs = -1;

@@ -258,7 +258,7 @@ def test_every_context_of_a_process_gets_its_overlap(mlib):
             ref = ref or out
             assert out == ref
             st = c.run_stats()
-            assert 3 <= st["rehearsals"] <= 12 and 0 < st["rehearsal_us"] < 40000, st    # (15 ms of budget + one miniature that started inside it + allocation)
+            assert 3 <= st["rehearsals"] <= 12 and 0 < st["rehearsal_us"] < 70000, st    # (15 ms of budget, or 13 one-stream miniatures within 60 ms where the process is slow, + the miniature that started inside it + allocation)
             assert st["queue_shared"] == 0, st
             ts = []
             for _ in range(15):
