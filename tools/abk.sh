@@ -5,7 +5,7 @@ PAT=${1:-synth|fixup|imdct}
 cd "$GRAFT_REPO_ROOT"
 L=mp3-steganography-lib_amd/mp3stego/libmp3s_hip.so
 cp $L /tmp/keep.so
-for v in A B; do
+for v in ${ABK_SET:-A B}; do
   cp mp3-steganography-lib_amd/build/ab/$v.so $L; echo "== $v"
   cd /tmp; export TMPDIR=/tmp; cd "$GRAFT_REPO_ROOT"
   timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_ab$v -- python3 bench.py --steps 20 --warmup 2 --no-cpu-baseline --resident-only --no-overlap > /dev/null 2> /dev/null
