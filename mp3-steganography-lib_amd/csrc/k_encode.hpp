@@ -83,8 +83,6 @@ __global__ __launch_bounds__(256, 4) void k_enc_analysis(
     // ---- y[i] = sum_k mul(x[(off + i + 64k) & 511], enwindow[i + 64k])   (MP3_Encoder.py:336-354)
     // sample 32t+31-m sits `m>>5` rows back at column 31-(m&31); one k step = rows 2k and 2k+1 back
     int32_t y[64];
-#pragma unroll
-    for (int i = 0; i < 64; i++) y[i] = 0;
     // A stream that starts inside the wave's window (its first slots see zeros where the ring x was still empty) is rare:
     // the usual case reads the tile without the per-row masks.
     const bool starts_inside = __ballot(valid && (t - 15) < s0) != 0;
@@ -100,8 +98,7 @@ __global__ __launch_bounds__(256, 4) void k_enc_analysis(
 #define MP3S_LDS_HI16(reg, addr, off) asm volatile("ds_read_u16_d16_hi %0, %1 offset:%2" : "+v"(reg) : "v"(addr), "n"(off))
     auto window_sums = [&](auto masked) {
     // two k steps per trip: every y gets two products at a time, added by ONE v_add3_u32 (a product per trip cost an add each)
-#pragma unroll 1
-    for (int k = 0; k < 8; k += 2) {
+    auto trip = [&](int k, auto first) {                   // (the first trip sets the sums: no 64 registers to clear in front of the loop)
         const i32x16 *ewa = reinterpret_cast<const i32x16 *>(c_tab.enwindow + 64 * k), *ewb = ewa + 4;   // enwindow[64 (k + 1) ..]
 #pragma unroll
         for (int h = 0; h < 2; h++) {
@@ -126,12 +123,16 @@ __global__ __launch_bounds__(256, 4) void k_enc_analysis(
                     int32_t xa = (int32_t)xs[e], xb = (int32_t)xs[8 + e];
                     if (decltype(masked)::value && !in_a) xa = 0;
                     if (decltype(masked)::value && !in_b) xb = 0;
-                    y[h * 32 + c] += mulhi_vs(xa, c < 16 ? a0[c & 15] : a1[c & 15]) + mulhi_vs(xb, c < 16 ? b0[c & 15] : b1[c & 15]);
+                    const int32_t two = mulhi_vs(xa, c < 16 ? a0[c & 15] : a1[c & 15]) + mulhi_vs(xb, c < 16 ? b0[c & 15] : b1[c & 15]);
+                    if (decltype(first)::value) y[h * 32 + c] = two; else y[h * 32 + c] += two;
                 }
                 __builtin_amdgcn_sched_barrier(0);   // sixteen products at a time: bounds the scheduler's hoisting
             }
         }
-    }
+    };
+    trip(0, std::true_type{});
+#pragma unroll 1
+    for (int k = 2; k < 8; k += 2) trip(k, std::false_type{});
     };
     if (starts_inside) window_sums(std::true_type{}); else window_sums(std::false_type{});
 #undef MP3S_LDS_HI16

@@ -96,15 +96,24 @@ __global__ __launch_bounds__(256) void k_enc_pack(
             a = a < 0 ? -a : a;
         }
         tot21 = __builtin_amdgcn_readlane(a, 21);
-        const int tp = pack_wave_sum(a, lane < 21);
+        // the five sums over lanes (all 21 bands; bands 0-5, 6-10, 11-15, 16-20) from ONE inclusive scan of the rows' 16 lanes + the row in
+        // front: five wave reductions before
+        int sc = lane < 21 ? a : 0;
+        sc += __builtin_amdgcn_update_dpp(0, sc, 0x111, 0xf, 0xf, false);   // row_shr:1
+        sc += __builtin_amdgcn_update_dpp(0, sc, 0x112, 0xf, 0xf, false);   // row_shr:2
+        sc += __builtin_amdgcn_update_dpp(0, sc, 0x114, 0xf, 0xf, false);   // row_shr:4
+        sc += __builtin_amdgcn_update_dpp(0, sc, 0x118, 0xf, 0xf, false);   // row_shr:8  (lane l: sum of its row's lanes up to l)
+        const int row0 = __builtin_amdgcn_readlane(sc, 15);                 // bands 0..15
+        const int p5 = __builtin_amdgcn_readlane(sc, 5), p10 = __builtin_amdgcn_readlane(sc, 10), q20 = __builtin_amdgcn_readlane(sc, 20);   // (q20: bands 16..20)
+        const int tp = row0 + q20;
         int cond = 2 + (gr[u0].xrmax != 0) + (gr[u1].xrmax != 0);
         if (tot21 < 10) cond++;
         if (tp < 100) cond++;
+        const int band_sum[4] = {p5, p10 - p5, row0 - p10, q20};
         uint32_t scbits = 0;
 #pragma unroll
         for (int b = 0; b < 4; b++) {
-            const int lo = b == 0 ? 0 : 1 + 5 * b, hi = 6 + 5 * b;
-            const int s0 = pack_wave_sum(a, lane >= lo && lane < hi);
+            const int s0 = band_sum[b];
             const int v = (cond == 6 && s0 < 10) ? 1 : 0;
             scbits = (scbits << 1) | (uint32_t)v;
             if (lane == 0) scfsi_out[((long)f * 2 + wave) * 4 + b] = v;
