@@ -660,10 +660,11 @@ __global__ __launch_bounds__(TW * 64 * 2, 5) void k_dec_synth(
 // (17 <= i <= 47), -X[i-48] (i >= 48).  The result is NOT the reference's float64 bit pattern: it differs from it by a few
 // 1e-14 of the slot's sum |S| (mostly because the reference's own matrix is that far from the true cosines).  What the
 // int16 format promises -- (pcm * 32767) truncated exactly as the reference truncates it -- is kept by a guard: a sample
-// whose scaled value lies closer to an integer than the proven bound on that difference (DevTables::synth_eps_a / _x,
-// derivation in mp3s_tables.cpp and DESIGN.md) is put on the fix-up list and computed again in the reference's order from
-// `is` (k_dec_fixup; the rows in S are the fast IMDCT's, not the reference's).  About one sample in a million takes that
-// path.  eps_scale (tests): inflates the guard so that the exact path is exercised.
+// whose scaled value lies closer to a non-zero integer than the proven bound on that difference (DevTables::synth_eps_a / _x / _g,
+// derivation in mp3s_tables.cpp and DESIGN.md; one width per tile since round 4) puts its slot and channel on the fix-up list,
+// whose 32 samples are computed again in the reference's order from `is` (k_dec_fixup; the rows in S are the fast IMDCT's, not
+// the reference's).  About two samples in ten thousand take that path.  eps_scale (tests): inflates the guard so that the exact
+// path is exercised.
 // ---------------------------------------------------------------------------------------------
 __device__ __noinline__ double synth_exact_sample(const double *S, long T, int ch, long t, int i, int lim)
 {
