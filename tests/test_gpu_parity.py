@@ -352,3 +352,30 @@ def test_config4_one_million_frames_as_eight_blocks():
     assert res["ok"] and res["frames"] == 1000000 and res["streams_equal_to_single_call"] == 100
     assert res["oracle_sample_streams_equal"] == res["oracle_sample_streams"] == 8 and res["oracle_sample_frames"] >= 10000
     assert res["pipe"]["slow"] == 0
+
+
+@pytest.mark.gpu
+def test_encode_transform_takes_pcm_from_any_int16_address(ctx, mlib):
+    """k_enc_analysis stages its PCM tile 16 bytes per lane when the caller's device pointer allows it and sample by sample when it
+    does not (`mp3s_encode_transform_dev` is C-ABI: any int16-aligned address): the same MDCT lines either way
+    (encoder/MP3_Encoder.py:321-370, 652-758)."""
+    import ctypes as C
+    from synth_pcm import synth_pcm
+    n = 40
+    pcm = np.ascontiguousarray(synth_pcm(n, seed=23), dtype=np.int16)
+    hdr = np.zeros(n, dtype=mlib.FRAME_HDR_DTYPE)
+    hdr["nch"] = 2
+    want = ctx.encode_transform(pcm, hdr)
+    d_hdr = ctx.to_device(hdr)
+    d_mdct = ctx.alloc(want.nbytes)
+    d_pcm = ctx.alloc(pcm.nbytes + 64)
+    try:
+        for shift in (0, 4, 6, 18):                          # bytes: 16-byte aligned, and three addresses that are not
+            at = C.c_void_p(d_pcm.value + shift)
+            ctx.upload(at, pcm)
+            mlib.check(mlib.lib().mp3s_encode_transform_dev(ctx.handle, at, d_hdr, n, d_mdct))
+            ctx.sync()
+            got = ctx.download(d_mdct, np.int32, want.shape)
+            assert np.array_equal(got, want), shift
+    finally:
+        ctx.free(d_pcm); ctx.free(d_mdct); ctx.free(d_hdr)
