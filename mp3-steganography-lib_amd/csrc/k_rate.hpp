@@ -372,7 +372,6 @@ __device__ __forceinline__ void rate_units(
     // whose arrays hold one chunk of units)
     __shared__ __attribute__((aligned(16))) RlTables tb;
     __shared__ uint32_t pre_all[RL_WAVES][64];
-    __shared__ int32_t esq_all[RL_WAVES][580];
     const int sr0 = frames[0].sr_idx;             // one sample rate per launch (the host splits batches otherwise)
     const int sr_wg = sr0 >= 0 && sr0 < 3 ? sr0 : 0;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
@@ -429,7 +428,6 @@ __device__ __forceinline__ void rate_units(
     if (CHAIN) tables_in();
 
     uint32_t *pre = pre_all[wave];
-    int32_t *esq = esq_all[wave];
     int li0 = blockIdx.x * RL_WAVES + wave;
     if (li0 >= n_list + var.n) { if (!CHAIN) tables_in(); return; }
     do {                                          // (one trip unless CHAIN: the plain rate loop keeps its straight-line shape)
@@ -475,7 +473,6 @@ __device__ __forceinline__ void rate_units(
             lmax = max(lmax, a);
             const int32_t sq = (int32_t)(((uint64_t)a * a + (1ull << 30)) >> 31);   // util.mulsr(xr, xr)
             const int32_t e10 = sq >> 10;
-            if (p < 288) esq[2 * p + e] = e10;
             esum += (uint32_t)e10;
         }
     }
@@ -501,8 +498,11 @@ __device__ __forceinline__ void rate_units(
             const int b0 = c_tab.sfb_long[sr][lane], b1 = c_tab.sfb_long[sr][lane + 1];
             const int q0 = (b0 * 6554) >> 16, q1 = (b1 * 6554) >> 16;        // x / 10 for x <= 576
             uint32_t s0 = pre[q0], s1 = pre[q1];                             // (q <= 57)
-            for (int i = 10 * q0; i < b0; i++) s0 += (uint32_t)esq[i];
-            for (int i = 10 * q1; i < b1; i++) s1 += (uint32_t)esq[i];
+            // (the at most nine lines between a lane's start and a band's bound: read again from the unit's lines -- they are in the vector
+            // cache -- and squared again; a copy of all 576 squares in LDS was 9 KB per workgroup and the fifth wave per SIMD)
+            auto e10_of = [&](int i) { const int32_t v = xr[i]; const uint32_t a = v < 0 ? 0u - (uint32_t)v : (uint32_t)v; return (uint32_t)((int32_t)(((uint64_t)a * a + (1ull << 30)) >> 31) >> 10); };
+            for (int i = 10 * q0; i < b0; i++) s0 += e10_of(i);
+            for (int i = 10 * q1; i < b1; i++) s1 += e10_of(i);
             temp = (int32_t)(s1 - s0);
         } else if (lane == 21) temp = (int32_t)etot;
         __builtin_amdgcn_wave_barrier();
@@ -638,7 +638,7 @@ __device__ __forceinline__ void rate_units(
     } while (CHAIN && (li0 += (int)gridDim.x * RL_WAVES) < n_list + var.n);   // list entries
 }
 
-__global__ __launch_bounds__(RL_WAVES * 64, 4) void k_rate_loop(
+__global__ __launch_bounds__(RL_WAVES * 64, 5) void k_rate_loop(
     const int32_t *__restrict__ mdct, const mp3s_rate_frame *__restrict__ frames, int n_units,
     const uint8_t *__restrict__ hide, int n_hide, const int32_t *__restrict__ cursor_in,
     const int32_t *__restrict__ state_in, const int32_t *__restrict__ unit_list, int n_list,
