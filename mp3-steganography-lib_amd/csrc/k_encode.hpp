@@ -32,10 +32,11 @@ typedef int32_t i32x16 __attribute__((ext_vector_type(16)));
 
 constexpr int ENC_ROW = 34;   // int16 per LDS row: 32 samples + 2 pad: 17 dwords, so the 64 lanes' rows start in 32 different banks twice over
                               // (the window sums read one sample per lane and instruction)
-constexpr int ENC_LDS_DW = 64 * 33;   // per-wave LDS in dwords: PCM tile (79 rows * 20 dw) first, then the 64 x 32 output tile (+1 pad)
+constexpr int ENC_LDS_DW = 79 * 17 + 1;   // per-wave LDS in dwords: the PCM tile (79 rows of 17 dwords), then -- twice -- a 64 x 16 half of the output tile (rows of 17):
+                                      // 5.4 KB per wave, 21.5 per workgroup: five workgroups = five waves per SIMD fit a CU's LDS (8.4 KB per wave and four until round 4)
 
 // SB layout: int32 [ch][Ts][32 bands] with Ts = n_frames * 36 slots (a 128-byte row per slot)
-__global__ __launch_bounds__(256, 4) void k_enc_analysis(
+__global__ __launch_bounds__(256, 5) void k_enc_analysis(
     const int16_t *__restrict__ pcm, const mp3s_frame_hdr *__restrict__ hdr, int n_frames,
     int32_t *__restrict__ SB, long Ts)
 {
@@ -141,6 +142,8 @@ __global__ __launch_bounds__(256, 4) void k_enc_analysis(
     const bool odd_slot = (t & 1) != 0;      // slot-in-granule parity == slot parity (18 is even)
     __builtin_amdgcn_wave_barrier();         // every lane is done reading the PCM tile
     uint32_t *ot = lds_all[wave];
+    uint32_t *out = reinterpret_cast<uint32_t *>(SB) + ((long)ch * Ts + t0) * 32;
+    const int rows = (Ts - t0) < 64 ? (int)(Ts - t0) : 64;
 #pragma unroll 1
     for (int sb = 0; sb < 32; sb += 4) {
         int32_t a0 = 0, a1 = 0, a2 = 0, a3 = 0;
@@ -159,22 +162,25 @@ __global__ __launch_bounds__(256, 4) void k_enc_analysis(
             }
         }
         if (odd_slot) { a1 = (int32_t)(0u - (uint32_t)a1); a3 = (int32_t)(0u - (uint32_t)a3); }   // odd bands
-        ot[lane * 33 + sb] = (uint32_t)a0;
-        ot[lane * 33 + sb + 1] = (uint32_t)a1;
-        ot[lane * 33 + sb + 2] = (uint32_t)a2;
-        ot[lane * 33 + sb + 3] = (uint32_t)a3;
-    }
-    __builtin_amdgcn_s_waitcnt(0xc07f);
-    __builtin_amdgcn_wave_barrier();
-    uint32_t *out = reinterpret_cast<uint32_t *>(SB) + ((long)ch * Ts + t0) * 32;
-    // 16 bytes per lane and trip: eight lanes per 128-byte row, eight rows per trip (the scratch is 256-byte aligned, rows 128)
-    const int rows = (Ts - t0) < 64 ? (int)(Ts - t0) : 64;
-#pragma unroll 4
-    for (int r = lane >> 3; r < 64; r += 8) {
-        const int c = (lane & 7) * 4;
-        const uint32_t *src = ot + r * 33 + c;
-        const uint4 v = make_uint4(src[0], src[1], src[2], src[3]);
-        if (r < rows) *reinterpret_cast<uint4 *>(out + r * 32 + c) = v;
+        const int sbh = sb & 15;
+        ot[lane * 17 + sbh] = (uint32_t)a0;
+        ot[lane * 17 + sbh + 1] = (uint32_t)a1;
+        ot[lane * 17 + sbh + 2] = (uint32_t)a2;
+        ot[lane * 17 + sbh + 3] = (uint32_t)a3;
+        if (sbh == 12) {
+            // ---- sixteen bands of the 64 slots are complete: out 16 bytes per lane, four lanes per 64-byte half row, sixteen rows per trip
+            __builtin_amdgcn_s_waitcnt(0xc07f);
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int r = lane >> 2; r < 64; r += 16) {
+                const int c = (lane & 3) * 4;
+                const uint32_t *src = ot + r * 17 + c;
+                const uint4 v = make_uint4(src[0], src[1], src[2], src[3]);
+                if (r < rows) *reinterpret_cast<uint4 *>(out + r * 32 + (sb - 12) + c) = v;
+            }
+            __builtin_amdgcn_s_waitcnt(0xc07f);
+            __builtin_amdgcn_wave_barrier();         // (the tile is free for the other sixteen bands)
+        }
     }
 }
 
