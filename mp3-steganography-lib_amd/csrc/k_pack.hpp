@@ -219,13 +219,8 @@ __global__ __launch_bounds__(256) void k_enc_pack(
         tot += n0[k] + n1[k];
     }
     // exclusive prefix of the lanes' bit counts
-    int incl = tot;
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-        const int o = __shfl_up(incl, d, 64);
-        if (lane >= d) incl += o;
-    }
-    const int huff_bits = __shfl(incl, 63, 64);
+    const int incl = (int)wave_scan_u32((uint32_t)tot);
+    const int huff_bits = __builtin_amdgcn_readlane(incl, 63);
     // The lane's code words are consecutive in the stream: they are gathered in a 64-bit register (in front of them as many
     // zero bits as the lane's start lies behind a dword boundary) and leave as whole dwords of the frame image -- two or
     // three LDS atomics per lane instead of one or two per code word.  A word has at most 28 bits and fewer than 32 are

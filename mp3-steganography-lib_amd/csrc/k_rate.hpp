@@ -37,6 +37,19 @@ __device__ __forceinline__ uint32_t wave_add_u32(uint32_t v)
     v += RL_DPP(v, 0x143, 0xc);
     return (uint32_t)__builtin_amdgcn_readlane((int)v, 63);
 }
+// inclusive prefix sums over the lanes, the same six DPP steps: within the rows of 16 by shifts of 1, 2, 4, 8, then the last lane of
+// rows 0 and 2 into rows 1 and 3, then lane 31 into rows 2 and 3 (six additions; through __shfl_up a step was an LDS permute, a compare,
+// a select and an addition with the address arithmetic of the permute on top)
+__device__ __forceinline__ uint32_t wave_scan_u32(uint32_t v)
+{
+    v += RL_DPP(v, 0x111, 0xf);
+    v += RL_DPP(v, 0x112, 0xf);
+    v += RL_DPP(v, 0x114, 0xf);
+    v += RL_DPP(v, 0x118, 0xf);
+    v += RL_DPP(v, 0x142, 0xa);
+    v += RL_DPP(v, 0x143, 0xc);
+    return v;
+}
 // Several reductions at once: a DPP step has to wait two issue slots for the VALU write in front of it, so independent
 // chains are written step by step side by side -- the second and third fill the slots the first would idle in.
 __device__ __forceinline__ void wave_add2(uint32_t &a, uint32_t &b)
@@ -482,12 +495,7 @@ __device__ __forceinline__ void rate_units(
         // Band sums through prefix sums: lane l holds the sum of lines 10l .. 10l+9 already; a wave scan turns the lane sums
         // into the sums of everything in front of each lane, and a band lane completes its two bounds with at most 9 lines
         // each.  Sums stay below 2^31 (576 x 2^21).
-        uint32_t incl = esum;
-#pragma unroll
-        for (int d = 1; d < 64; d <<= 1) {
-            const uint32_t o = (uint32_t)__shfl_up((int)incl, d, 64);
-            if (lane >= d) incl += o;
-        }
+        const uint32_t incl = wave_scan_u32(esum);
         etot = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
         xrmax = wave_max_u32(lmax);
         pre[lane] = incl - esum;
