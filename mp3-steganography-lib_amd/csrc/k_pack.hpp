@@ -52,7 +52,15 @@ __global__ __launch_bounds__(256) void k_enc_pack(
     __syncthreads();
     int rot = 0;
     for (int f = f_begin + blockIdx.x; f < n_frames; f += gridDim.x) {
-    const int lane = lane0, tid = (int)threadIdx.x, wave = wave0;
+    // The wave number and a copy of the lane number used ONLY in comparisons are made opaque once per frame: what follows from them is
+    // invariant over the frame loop, and kept across it every lane predicate (lane < 22, lane == 0 ...) is a mask in two scalar
+    // registers and every wave-derived scalar one more -- 71 scalar spills, read back lane by lane (v_readlane) in front of each use, a
+    // fifth of the kernel's vector instructions.  A predicate recomputed is one comparison, a scalar recomputed is scalar arithmetic;
+    // the lane number's ARITHMETIC (addresses, pair numbers) stays invariant and hoisted (made opaque too, round 4's first try, it cost
+    // more than the spills).
+    const int lane = lane0, tid = (int)threadIdx.x;
+    int lane_p = lane0, wave = wave0;
+    asm volatile("" : "+v"(lane_p), "+s"(wave));
     // One barrier per frame.  This frame's image is fb3[rot]; the image of the frame before last -- every thread
     // finished copying it out before the previous barrier -- is cleared now and is ready after this frame's barrier.
     uint32_t *fb = fb3[rot];
@@ -91,14 +99,14 @@ __global__ __launch_bounds__(256) void k_enc_pack(
         // ---- scfsi of channel `wave` (:861-892) from the band energies of its two granules: lane s holds band s
         const long u0 = ((long)f * 2 + wave) * 2, u1 = u0 + 1;
         int a = 0, tot21 = 0;
-        if (lane < 22) {
+        if (lane_p < 22) {
             a = en[u0 * 22 + lane] - en[u1 * 22 + lane];
             a = a < 0 ? -a : a;
         }
         tot21 = __builtin_amdgcn_readlane(a, 21);
         // the five sums over lanes (all 21 bands; bands 0-5, 6-10, 11-15, 16-20) from ONE inclusive scan of the rows' 16 lanes + the row in
         // front: five wave reductions before
-        int sc = lane < 21 ? a : 0;
+        int sc = lane_p < 21 ? a : 0;
         sc += __builtin_amdgcn_update_dpp(0, sc, 0x111, 0xf, 0xf, false);   // row_shr:1
         sc += __builtin_amdgcn_update_dpp(0, sc, 0x112, 0xf, 0xf, false);   // row_shr:2
         sc += __builtin_amdgcn_update_dpp(0, sc, 0x114, 0xf, 0xf, false);   // row_shr:4
@@ -116,9 +124,9 @@ __global__ __launch_bounds__(256) void k_enc_pack(
             const int s0 = band_sum[b];
             const int v = (cond == 6 && s0 < 10) ? 1 : 0;
             scbits = (scbits << 1) | (uint32_t)v;
-            if (lane == 0) scfsi_out[((long)f * 2 + wave) * 4 + b] = v;
+            if (lane_p == 0) scfsi_out[((long)f * 2 + wave) * 4 + b] = v;
         }
-        if (lane == 0) {
+        if (lane_p == 0) {
             lds_put(fb, 44 + 4 * wave, scbits, 4);
             if (wave == 0) {
                 // ---- frame header (:1281-1300): sync 11, version 2, layer 2, no CRC 1, bitrate 4, rate 2, padding 1, ext 1,
@@ -129,16 +137,16 @@ __global__ __launch_bounds__(256) void k_enc_pack(
             }
         }
     }
-    if (lane < 4) {
+    if (lane_p < 4) {
         // ---- side info of this wave's granule*channel (:1305-1337), 59 bits at 52 + 59 e: its four fields by four lanes, one put each
         //      (one lane putting them one after the other had the whole wave step through four times the instructions)
         const uint32_t f0 = ((uint32_t)p23v[e] << 9) | (uint32_t)g.big_values;                                            // 21 bits
         const uint32_t f1 = (((uint32_t)(g.quantizer_step + 210) & 0xff) << 5);                                           // 13: global_gain 8, scalefac_compress 4, window_switching 1
         const uint32_t f2 = ((uint32_t)g.table_select[0] << 10) | ((uint32_t)g.table_select[1] << 5) | (uint32_t)g.table_select[2];   // 15
         const uint32_t f3 = ((uint32_t)g.region0_count << 6) | ((uint32_t)g.region1_count << 3) | (uint32_t)g.count1table_select;     // 10: + preflag, scalefac_scale = 0
-        const uint32_t v = lane == 0 ? f0 : (lane == 1 ? f1 : (lane == 2 ? f2 : f3));
-        const int n = lane == 0 ? 21 : (lane == 1 ? 13 : (lane == 2 ? 15 : 10));
-        const uint32_t at = lane == 0 ? 0u : (lane == 1 ? 21u : (lane == 2 ? 34u : 49u));
+        const uint32_t v = lane_p == 0 ? f0 : (lane_p == 1 ? f1 : (lane_p == 2 ? f2 : f3));
+        const int n = lane_p == 0 ? 21 : (lane_p == 1 ? 13 : (lane_p == 2 ? 15 : 10));
+        const uint32_t at = lane_p == 0 ? 0u : (lane_p == 1 ? 21u : (lane_p == 2 ? 34u : 49u));
         lds_put(fb, 52 + 59 * (uint32_t)e + at, v, n);
     }
 
@@ -155,7 +163,7 @@ __global__ __launch_bounds__(256) void k_enc_pack(
         const uint32_t *xp = reinterpret_cast<const uint32_t *>(ix + u * 576 + lane * 10);
 #pragma unroll
         for (int k = 0; k < 5; k++) {
-            const uint32_t w = (lane * 5 + k) < 288 ? xp[k] : 0u;
+            const uint32_t w = (lane_p * 5 + k) < 288 ? xp[k] : 0u;
             xv[2 * k] = (int)(int16_t)(w & 0xffff); xv[2 * k + 1] = (int)(int16_t)(w >> 16);
         }
     }
@@ -240,7 +248,7 @@ __global__ __launch_bounds__(256) void k_enc_pack(
     }
     // stuffing with ones up to part2_3_length (:1433-1446)
     const int p23 = e == 0 ? p23v[0] : (e == 1 ? p23v[1] : (e == 2 ? p23v[2] : p23v[3]));
-    if (huff_bits > p23 || any_bad) { if (lane == 0) atomicOr(&wg_err, any_bad ? MP3S_PS_BAD_TABLE : MP3S_PS_OVERFLOW); }   // (LDS)
+    if (huff_bits > p23 || any_bad) { if (lane_p == 0) atomicOr(&wg_err, any_bad ? MP3S_PS_BAD_TABLE : MP3S_PS_OVERFLOW); }   // (LDS)
     else
         for (uint32_t s = ustart + huff_bits + 32u * lane; s < ustart + (uint32_t)p23; s += 64u * 32u) {
             const uint32_t n = (ustart + p23 - s) < 32u ? (ustart + p23 - s) : 32u;
