@@ -413,6 +413,7 @@ __device__ __forceinline__ void rate_units(
     // behind its unit's own front (lines, energies, scfsi logs: nothing of it reads a table), so that the tables' way through the caches passes
     // under that arithmetic; a re-run launch (CHAIN) stages them at once.
     static_assert(sizeof(tb.int2idx) % 16 == 0 && sizeof(c_tab.int2idx) == sizeof(tb.int2idx), "int2idx is staged 16 bytes at a time");
+    static_assert(RL_WAVES * 64 >= 256, "one thread per pair word (tb.hl) when the tables are put into LDS");
     constexpr int I2I_CHUNKS = (int)(sizeof(tb.int2idx) / 16), I2I_ROUNDS = (I2I_CHUNKS + RL_WAVES * 64 - 1) / (RL_WAVES * 64);
     uint4 t_i2i[I2I_ROUNDS];
     uint2 t_hl;
