@@ -384,7 +384,6 @@ __device__ __forceinline__ void rate_units(
     // results of unit u go to element u - out_base of the three output arrays (0 except for the message variants,
     // whose arrays hold one chunk of units)
     __shared__ __attribute__((aligned(16))) RlTables tb;
-    __shared__ uint32_t pre_all[RL_WAVES][64];
     const int sr0 = frames[0].sr_idx;             // one sample rate per launch (the host splits batches otherwise)
     const int sr_wg = sr0 >= 0 && sr0 < 3 ? sr0 : 0;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
@@ -441,7 +440,6 @@ __device__ __forceinline__ void rate_units(
     };
     if (CHAIN) tables_in();
 
-    uint32_t *pre = pre_all[wave];
     int li0 = blockIdx.x * RL_WAVES + wave;
     if (li0 >= n_list + var.n) { if (!CHAIN) tables_in(); return; }
     do {                                          // (one trip unless CHAIN: the plain rate loop keeps its straight-line shape)
@@ -472,6 +470,7 @@ __device__ __forceinline__ void rate_units(
     const int32_t *xr = mdct + (long)u * 576;
     uint32_t xa[2 * RL_NP];
     uint32_t negmask = 0, lmax = 0, esum = 0;
+    uint32_t pk[2 * RL_NP - 1];                   // the lane's own running sums: pk[k] = its lines 0..k
 #pragma unroll
     for (int m = 0; m < RL_NP; m++) {
         const int p = p0 + m;
@@ -488,33 +487,34 @@ __device__ __forceinline__ void rate_units(
             const int32_t sq = (int32_t)(((uint64_t)a * a + (1ull << 30)) >> 31);   // util.mulsr(xr, xr)
             const int32_t e10 = sq >> 10;
             esum += (uint32_t)e10;
+            if (2 * m + e < 2 * RL_NP - 1) pk[2 * m + e] = esum;
         }
     }
     uint32_t xrmax = lmax, etot = 0;
     // ---- scalefactor-band energies for __calc_scfsi (:840-857); lane b < 21 sums band b, lane 21 = total
     {
         // Band sums through prefix sums: lane l holds the sum of lines 10l .. 10l+9 already; a wave scan turns the lane sums
-        // into the sums of everything in front of each lane, and a band lane completes its two bounds with at most 9 lines
-        // each.  Sums stay below 2^31 (576 x 2^21).
+        // into the sums of everything in front of each lane.  Lane j < 22 then builds S(j), the sum of all lines in front of
+        // band bound j = 10 q + r: what lies in front of lane q, plus lane q's own running sum over r lines -- both fetched
+        // from lane q by ds_bpermute (nine running sums are offered, the one with k + 1 == r is kept), and a band is
+        // S(j + 1) - S(j) with the neighbour's S through DPP.  Sums stay below 2^31 (576 x 2^21).  (Round 3 had the band
+        // lanes walk their up to nine lines through a copy of all squares in LDS -- 9 KB per workgroup and the fifth wave
+        // per SIMD --, round 4 first through the unit's lines in memory: two divergent loops of dependent loads, 8 % of the
+        // kernel's vector instructions.)
         const uint32_t incl = wave_scan_u32(esum);
         etot = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
         xrmax = wave_max_u32(lmax);
-        pre[lane] = incl - esum;
-        __builtin_amdgcn_s_waitcnt(0xc07f);
-        __builtin_amdgcn_wave_barrier();
-        int32_t temp = 0;
-        if (lane < 21) {
-            const int b0 = c_tab.sfb_long[sr][lane], b1 = c_tab.sfb_long[sr][lane + 1];
-            const int q0 = (b0 * 6554) >> 16, q1 = (b1 * 6554) >> 16;        // x / 10 for x <= 576
-            uint32_t s0 = pre[q0], s1 = pre[q1];                             // (q <= 57)
-            // (the at most nine lines between a lane's start and a band's bound: read again from the unit's lines -- they are in the vector
-            // cache -- and squared again; a copy of all 576 squares in LDS was 9 KB per workgroup and the fifth wave per SIMD)
-            auto e10_of = [&](int i) { const int32_t v = xr[i]; const uint32_t a = v < 0 ? 0u - (uint32_t)v : (uint32_t)v; return (uint32_t)((int32_t)(((uint64_t)a * a + (1ull << 30)) >> 31) >> 10); };
-            for (int i = 10 * q0; i < b0; i++) s0 += e10_of(i);
-            for (int i = 10 * q1; i < b1; i++) s1 += e10_of(i);
-            temp = (int32_t)(s1 - s0);
-        } else if (lane == 21) temp = (int32_t)etot;
-        __builtin_amdgcn_wave_barrier();
+        const int bj = c_tab.sfb_long[sr][lane < 22 ? lane : 22];
+        const int qj = (bj * 6554) >> 16, rj = bj - 10 * qj;                 // x / 10 for x <= 576; q <= 57
+        uint32_t S = (uint32_t)__builtin_amdgcn_ds_bpermute(qj << 2, (int)(incl - esum)), part = 0;
+#pragma unroll
+        for (int k = 0; k < 2 * RL_NP - 1; k++) {
+            const uint32_t v = (uint32_t)__builtin_amdgcn_ds_bpermute(qj << 2, (int)pk[k]);
+            part = rj == k + 1 ? v : part;
+        }
+        S += part;
+        const uint32_t Sn = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)S, 0x130, 0xf, 0xf, false);   // wave_shl:1 = lane + 1's
+        const int32_t temp = lane < 21 ? (int32_t)(Sn - S) : (lane == 21 ? (int32_t)etot : 0);
         // en = int32(log(temp * 4.768371584e-7) / 0.69314718): tabulated with the host's libm per octave of temp (value at
         // 2^k, and the argument from which on it is one more), so no device log and nothing to guard
         int32_t en = 0;
