@@ -352,6 +352,9 @@ def main():
     ap.add_argument("--pack-overlap", action="store_true", help="(default since r02e; kept for old command lines)")
     ap.add_argument("--no-tail-stream", action="store_true", help="chain check and bit packing of batch k on the main stream instead of a third one")
     ap.add_argument("--resident-only", action="store_true", help="region (i) only (profiling runs)")
+    ap.add_argument("--dom-events-every", type=int, default=4, help="the timed region's HIP event pair around the dominant kernel on every N-th step: "
+                    "a pair costs 0.009 ms of stream time (on every step 0.613-0.616 ms per step, on every fourth 0.606, on the first only 0.604-0.605: "
+                    "DESIGN.md §5)")
     ap.add_argument("--no-live-pmc", action="store_true", help="roofline.traffic / roofline_alu from the committed profiles/*_latest.json instead of three "
                     "rocprofv3 --pmc passes run as child processes before this one touches the GPU (rank 0, one GPU, full runs only)")
     ap.add_argument("--decode-stream", choices=("on", "off"), default="off",
@@ -575,10 +578,16 @@ def main():
         if dist is not None:
             dist.barrier()
 
-    def run(steps):
+    dom = None
+
+    def run(steps, events_every=0):
         state["restart"] = True                      # the first step of a run issues its own front end
         for i in range(steps):
             state["last"] = i == steps - 1           # ... and the last one does not start a batch nobody finishes
+            if events_every > 1:                     # (the timed region: event pairs on a sample of its steps; a mask, nothing is waited for)
+                for c in (ctx, aux, aux2, dctx):
+                    if c is not None:
+                        c.profile_select([dom] if i % events_every == 0 else [])
             step()
 
     run(args.warmup)
@@ -616,7 +625,7 @@ def main():
     barrier()
     t0 = time.perf_counter()
     ctx.timer_start()
-    run(args.steps)
+    run(args.steps, max(1, args.dom_events_every))
     gpu_ms = ctx.timer_stop()
     barrier()
     wall = time.perf_counter() - t0
@@ -1040,7 +1049,7 @@ def main():
 
     # ---------------------------------------------------------------- rooflines of the dominant kernel
     # duration of the dominant kernel per batch, from the event pairs of the TIMED region
-    dom_ms_launch = prof[dom][0] / args.steps
+    dom_ms_launch = prof[dom][0] / max(prof[dom][1], 1)
     achieved = B_PIPE * n / (dom_ms_launch * 1e-3) / 1e9
     traffic, traffic_source = None, None
     if pmc_live and dom in pmc_live and "hbm_bytes" in pmc_live[dom]:
@@ -1156,7 +1165,9 @@ def main():
             "long_message": long_message,
             "kernels_ms_per_step": {k: round(v, 4) for k, v in per_step.items()},
             "kernels_ms_note": f"event pairs around every kernel, separate untimed pass of {n_prof} steps; the timed region "
-                               "carries them around the dominant kernel only (they cost about 0.05 ms per step)",
+                               f"carries them around the dominant kernel only, on every {max(1, args.dom_events_every)}. step "
+                               "(all kernels: about 0.05 ms per step; the one pair 0.009 ms)",
+            "dominant_kernel_launches_timed": int(prof[dom][1]),
             "hot_path_value": round(n * world / (sum(v for k, v in per_step.items()
                                                        if k not in ("k_dec_huffman", "k_enc_pack")) * 1e-3), 1),
             "gpu_event_ms_per_step": round(gpu_ms / args.steps, 4),
