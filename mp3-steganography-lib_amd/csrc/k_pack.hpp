@@ -11,6 +11,7 @@
 namespace mp3s {
 
 constexpr int PACK_DW = 372;          // LDS image of one frame: 1441 bytes max (320 kbps @ 32 kHz) + slack
+constexpr int PACK_PT_QUAD = 1024, PACK_PT_NONE = 1056, PACK_PT = 1057;   // the code-word table of k_enc_pack
 #define MP3S_PS_OVERFLOW 1            // Huffman bits exceed part2_3_length (cannot happen for rate-loop output)
 #define MP3S_PS_BAD_TABLE 2           // a code book this encoder never selects
 
@@ -37,17 +38,22 @@ __global__ __launch_bounds__(256) void k_enc_pack(
                    down while the second is packed */)
 {
     __shared__ uint32_t fb3[3][PACK_DW];   // frame images, rotating: written / being copied out / being cleared
-    __shared__ uint32_t hc[4][256];
-    __shared__ uint8_t hl[4][256];
-    __shared__ uint8_t c1code[16], c1len[16];
+    // code words of every kind in ONE table, code | length << 24 (a code has at most 19 bits): [book family][min(x,15)][min(y,15)] for the four
+    // families of big-value books (13, 15, 16.., 24..), then the quadruples of count1 table A and B, then an empty word -- a pair picks its INDEX
+    // (big value / first pair of a quadruple / nothing) and reads once; code and length used to come from two to four reads and as many selects
+    __shared__ uint32_t pt[PACK_PT];
     __shared__ int wg_err;                 // the group's error bits
     const int wave0 = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane0 = threadIdx.x & 63;
     for (int i = threadIdx.x; i < 1024; i += 256) {
-        (&hc[0][0])[i] = (&c_tab.hcod[0][0])[i];
-        (&hl[0][0])[i] = i < 256 ? c_tab.hlen13[i] : (i < 512 ? c_tab.hlen15[i - 256] : (i < 768 ? c_tab.hlen16[i - 512] : c_tab.hlen24[i - 768]));
+        const uint32_t len = i < 256 ? c_tab.hlen13[i] : (i < 512 ? c_tab.hlen15[i - 256] : (i < 768 ? c_tab.hlen16[i - 512] : c_tab.hlen24[i - 768]));
+        pt[i] = (&c_tab.hcod[0][0])[i] | (len << 24);
     }
+    if (threadIdx.x < 16) {
+        pt[PACK_PT_QUAD + threadIdx.x] = (uint32_t)c_tab.hcod_c1a[threadIdx.x] | ((uint32_t)c_tab.hlen_c1a[threadIdx.x] << 24);
+        pt[PACK_PT_QUAD + 16 + threadIdx.x] = (15u - threadIdx.x) | (4u << 24);      // table B: four bits, the complement
+    }
+    if (threadIdx.x == 0) pt[PACK_PT_NONE] = 0;
     for (int i = threadIdx.x; i < 3 * PACK_DW; i += 256) (&fb3[0][0])[i] = 0;
-    if (threadIdx.x < 16) { c1code[threadIdx.x] = c_tab.hcod_c1a[threadIdx.x]; c1len[threadIdx.x] = c_tab.hlen_c1a[threadIdx.x]; }
     if (threadIdx.x == 0) wg_err = 0;
     __syncthreads();
     int rot = 0;
@@ -177,9 +183,10 @@ __global__ __launch_bounds__(256) void k_enc_pack(
     int tot = 0;
     // What differs between the regions is wave-uniform: one scalar word per region -- Huffman-length family (books 13, 15,
     // 16.., 24..) | linbits << 2 | "book in use" << 6 -- picked per lane; everything else is the same arithmetic for every
-    // pair, without a branch: the table word of (min(x,15), min(y,15)), the escape and sign bits (MP3_Encoder.py:1452-1500;
-    // books 13 and 15 have no linbits, so their value 15 emits none), and for a count1 pair the quadruple's code with its first
-    // pair (E13) and the signs of its own two values (:1502-1547).
+    // pair, without a branch and (round 4) nearly without selects: the escape and sign bits (MP3_Encoder.py:1452-1500;
+    // books 13 and 15 have no linbits, so their value 15 emits none) are field extractions of a width that is zero where
+    // nothing is emitted, and the pair's own code word -- its book's, or the quadruple's with the first pair of a quad (E13;
+    // :1502-1547), or none -- is one read of `pt`.
     uint32_t Kr[3];
     bool any_bad = false;
     {
@@ -194,57 +201,63 @@ __global__ __launch_bounds__(256) void k_enc_pack(
             any_bad |= ti != 0 && ti != 13 && ti != 15 && ti < 16 && lo < 2 * bv && lo < hi;
         }
     }
+    const uint32_t quad_base = (uint32_t)(PACK_PT_QUAD + (c1sel ? 16 : 0));
 #pragma unroll
     for (int k = 0; k < 5; k++) {
         const int p = lane * 5 + k;
-        int x = xv[2 * k], y = xv[2 * k + 1];
-        const uint32_t sx = x > 0 ? 0 : 1, sy = y > 0 ? 0 : 1;     // util.abs_and_sign: "sign" of 0 is 1, never emitted
-        x = x < 0 ? -x : x; y = y < 0 ? -y : y;
+        const int vx = xv[2 * k], vy = xv[2 * k + 1];
+        const uint32_t x = (uint32_t)(vx < 0 ? -vx : vx), y = (uint32_t)(vy < 0 ? -vy : vy);
         const int i = 2 * p;
         const uint32_t K = i >= r2s ? Kr[2] : (i >= r1s ? Kr[1] : Kr[0]);
-        const bool in_bv = p < bv && (K >> 6) != 0;
-        const bool in_c1 = p >= bv && p < bv + 2 * c1;
-        const int lb = in_bv ? (int)((K >> 2) & 15u) : 0;
-        // escape and sign bits: [x - 15 in lb bits] [sign of x] [y - 15 in lb bits] [sign of y]
-        const bool ex = x > 14 && lb > 0, ey = y > 14 && lb > 0;
-        uint32_t ext = ex ? (uint32_t)(x - 15) : 0u;
-        int xb = ex ? lb : 0;
-        ext = x != 0 ? (ext << 1) | sx : ext; xb += x != 0 ? 1 : 0;
-        ext = ey ? (ext << lb) | (uint32_t)(y - 15) : ext; xb += ey ? lb : 0;
-        ext = y != 0 ? (ext << 1) | sy : ext; xb += y != 0 ? 1 : 0;
-        // the pair's own code word: big-value book, or the quadruple's code with the first pair of a quad
-        const int xx = x > 14 ? 15 : x, yy = y > 14 ? 15 : y;
-        const uint32_t tix = ((K & 3u) << 8) + (uint32_t)(xx * 16 + yy);
-        const uint32_t bc = (&hc[0][0])[tix]; const int bn = (&hl[0][0])[tix];
-        const int q = (int)((c2[k] | (c2[k + 1] << 2)) & 15u);
-        const uint32_t qc = c1sel ? (uint32_t)(15 - q) : (uint32_t)c1code[q];
-        const int qn = c1sel ? 4 : (int)c1len[q];
+        const uint32_t Ke = p < bv ? K : 0u;                              // != 0: a big-value pair of a book in use
+        const bool in_c1 = (uint32_t)(p - bv) < (uint32_t)(2 * c1);
+        const uint32_t lb = __builtin_amdgcn_ubfe(Ke, 2, 4);
+        // escape and sign bits: [x - 15 in lb bits] [sign of x] [y - 15 in lb bits] [sign of y]; a value of 0 has no sign bit,
+        // a value below 15 (or a book without linbits) no escape bits: fields of width 0
+        const uint32_t lbx = x > 14 ? lb : 0u, lby = y > 14 ? lb : 0u;
+        const uint32_t nzx = x < 1 ? x : 1u, nzy = y < 1 ? y : 1u;
+        uint32_t ext = __builtin_amdgcn_ubfe(x - 15u, 0, lbx);
+        ext = (ext << nzx) | ((uint32_t)vx >> 31);
+        ext = (ext << lby) | __builtin_amdgcn_ubfe(y - 15u, 0, lby);
+        ext = (ext << nzy) | ((uint32_t)vy >> 31);
+        const uint32_t xb = lbx + nzx + lby + nzy;
+        const bool inside = Ke != 0 || in_c1;
+        // the pair's own code word
+        const uint32_t xx = x > 14 ? 15u : x, yy = y > 14 ? 15u : y;
+        const uint32_t q = (c2[k] | (c2[k + 1] << 2)) & 15u;
         const bool quad = in_c1 && !((p - bv) & 1);
-        code0[k] = in_bv ? bc : (quad ? qc : 0u);
-        n0[k] = in_bv ? bn : (quad ? qn : 0);
-        code1[k] = (in_bv || in_c1) ? ext : 0u;
-        n1[k] = (in_bv || in_c1) ? xb : 0;
+        const uint32_t tix = Ke != 0 ? ((Ke & 3u) << 8) + xx * 16u + yy : (quad ? quad_base + q : (uint32_t)PACK_PT_NONE);
+        const uint32_t word = pt[tix];
+        code0[k] = word & 0xffffffu;
+        n0[k] = (int)(word >> 24);
+        code1[k] = inside ? ext : 0u;
+        n1[k] = inside ? (int)xb : 0;
         tot += n0[k] + n1[k];
     }
     // exclusive prefix of the lanes' bit counts
     const int incl = (int)wave_scan_u32((uint32_t)tot);
     const int huff_bits = __builtin_amdgcn_readlane(incl, 63);
     // The lane's code words are consecutive in the stream: they are gathered in a 64-bit register (in front of them as many
-    // zero bits as the lane's start lies behind a dword boundary) and leave as whole dwords of the frame image -- two or
-    // three LDS atomics per lane instead of one or two per code word.  A word has at most 28 bits and fewer than 32 are
-    // pending in front of it, so one flush per word suffices.
+    // zero bits as the lane's start lies behind a dword boundary) and leave as dwords of the frame image.  A word has at most
+    // 28 bits and fewer than 32 are pending in front of it.  Round 4: after EVERY word the dword the pending bits begin in is
+    // OR-ed into the image, finished or not (an unfinished one is OR-ed again, with more bits, by the next word: the same
+    // bits twice do no harm), and position and count move on by arithmetic -- the flush used to be a per-lane branch, ten
+    // of them per frame.
     {
         const uint32_t pos0 = ustart + (uint32_t)(incl - tot);
         uint32_t d = pos0 >> 5;
-        int cnt = (int)(pos0 & 31u);
-        uint64_t acc = 0;
+        uint32_t cnt = pos0 & 31u;
+        uint64_t top = 0;                                                       // the pending bits, from bit 63 down: cnt of them behind the dword boundary
         auto append = [&](uint32_t v, int n) {
-            acc = (acc << n) | v; cnt += n;
-            if (cnt >= 32) { atomicOr(&fb[d], (uint32_t)(acc >> (cnt - 32))); d++; cnt -= 32; }
+            top |= (uint64_t)v << ((64u - cnt - (uint32_t)n) & 63u);             // cnt + n <= 59; (n == 0: v == 0)
+            cnt += (uint32_t)n;
+            atomicOr(&fb[d], (uint32_t)(top >> 32));
+            const uint32_t adv = cnt >> 5;                                      // 0 or 1
+            top <<= 32u * adv; d += adv; cnt &= 31u;
         };
 #pragma unroll
         for (int k = 0; k < 5; k++) { append(code0[k], n0[k]); append(code1[k], n1[k]); }
-        if (cnt > 0) atomicOr(&fb[d], (uint32_t)(acc << (32 - cnt)));
+        atomicOr(&fb[d], (uint32_t)(top >> 32));                                // what the last word left behind a dword boundary
     }
     // stuffing with ones up to part2_3_length (:1433-1446)
     const int p23 = e == 0 ? p23v[0] : (e == 1 ? p23v[1] : (e == 2 ? p23v[2] : p23v[3]));
