@@ -14,6 +14,7 @@
 // product is floored on its own exactly as the reference does.
 #pragma once
 #include <type_traits>
+#include "analysis_plan.h"
 
 namespace mp3s {
 
@@ -29,6 +30,13 @@ __device__ __forceinline__ int32_t mulhi_vs(int32_t v, int32_t s)
 }
 typedef int32_t i32x4 __attribute__((ext_vector_type(4)));
 typedef int32_t i32x16 __attribute__((ext_vector_type(16)));
+typedef int32_t i32x8 __attribute__((ext_vector_type(8)));
+// f(integral_constant<int, N>) for N = B .. E - 1, unrolled at compile time
+template <int B, int E, class F>
+__device__ __forceinline__ void static_for(F &&f)
+{
+    if constexpr (B < E) { f(std::integral_constant<int, B>{}); static_for<B + 1, E>(f); }
+}
 
 constexpr int ENC_ROW = 34;   // int16 per LDS row: 32 samples + 2 pad: 17 dwords, so the 64 lanes' rows start in 32 different banks twice over
                               // (the window sums read one sample per lane and instruction)
@@ -137,51 +145,100 @@ __global__ __launch_bounds__(256, 5) void k_enc_analysis(
     };
     if (starts_inside) window_sums(std::true_type{}); else window_sums(std::false_type{});
 #undef MP3S_LDS_HI16
-    // ---- s[sb] = sum_j mul(fl[sb][j], y[j])   (MP3_Encoder.py:358-368); four bands per pass for ILP.
-    // Results are staged in the wave's LDS region as [slot][band] (33-dword rows) and written out as rows.
+    // ---- s[sb] = sum_j mul(fl[sb][j], y[j])   (MP3_Encoder.py:358-368); four bands per pass: {p, 15 - p, 16 + p, 31 - p}.  The filter is
+    // cos((2 sb + 1)(16 - j) pi / 64): within such a set the coefficients of a column repeat themselves (16 - j = 2 mod 4: in two pairs; a multiple
+    // of 4: all four; j = 48: zeros) wherever the table's rounding has not pulled them two units apart -- and a product with the same coefficient
+    // is the same product: computed once (analysis_plan.h: 1 516 products per slot instead of 2 048; each product still floored on its own, the
+    // sums wrap -- bit for bit the reference's).  The plan is compiled in, so the passes are unrolled; the host checks its table against it.
+    // Results are staged in the wave's LDS region as [slot][16 bands] (17-dword rows) and written out as 16-byte pieces of the rows: passes
+    // 0..3 complete bands 0-3, 12-15, 16-19, 28-31, passes 4..7 the other four pieces.
     const bool odd_slot = (t & 1) != 0;      // slot-in-granule parity == slot parity (18 is even)
     __builtin_amdgcn_wave_barrier();         // every lane is done reading the PCM tile
     uint32_t *ot = lds_all[wave];
     uint32_t *out = reinterpret_cast<uint32_t *>(SB) + ((long)ch * Ts + t0) * 32;
     const int rows = (Ts - t0) < 64 ? (int)(Ts - t0) : 64;
-#pragma unroll 1
-    for (int sb = 0; sb < 32; sb += 4) {
-        int32_t a0 = 0, a1 = 0, a2 = 0, a3 = 0;
-        const i32x16 *f0 = reinterpret_cast<const i32x16 *>(c_tab.fl[sb]), *f1 = reinterpret_cast<const i32x16 *>(c_tab.fl[sb + 1]),
-                     *f2 = reinterpret_cast<const i32x16 *>(c_tab.fl[sb + 2]), *f3 = reinterpret_cast<const i32x16 *>(c_tab.fl[sb + 3]);
+    // The coefficients reach the multiplier as scalar operands, eight columns of the pass's four rows at a time (4 x s_load_dwordx8), and the NEXT
+    // block's are asked for before this block's products start: every block begins by waiting for its own (asked for a block ago; scalar loads
+    // return out of order, so the wait is for everything outstanding and comes BEFORE the next request goes out).  Until round 4's last change a
+    // block asked for its coefficients and waited for them on the spot, 32 times per wave: 45 % of the kernel's wave cycles stood at a wait.
+    int32_t a[4] = {0, 0, 0, 0};
+    i32x8 cur[4], nxt[4];
+    // (the table's address once, in a scalar pair the compiler cannot re-derive: every request is then base + immediate offset -- it built the
+    // address of each of the 256 requests from the program counter, three scalar instructions apiece)
+    typedef const int32_t __attribute__((address_space(4))) *fl_ptr;
+    fl_ptr flp = (fl_ptr)&c_tab.fl[0][0];
+    asm volatile("" : "+s"(flp));
+    auto load_block = [&](auto nc, i32x8 (&c)[4]) {
+        constexpr int N = decltype(nc)::value, P = N >> 3, B = N & 7;
+        constexpr int O[4] = {P, 15 - P, 16 + P, 31 - P};
 #pragma unroll
-        for (int jb = 0; jb < 4; jb++) {
-            const i32x16 c0 = f0[jb], c1 = f1[jb], c2 = f2[jb], c3 = f3[jb];   // 4 x s_load_dwordx16
+        for (int o = 0; o < 4; o++) c[o] = *(const i32x8 __attribute__((address_space(4))) *)(flp + O[o] * 64 + 8 * B);
+    };
+    load_block(std::integral_constant<int, 0>{}, cur);
+    static_for<0, 64>([&](auto nc) {
+        constexpr int N = decltype(nc)::value, P = N >> 3, B = N & 7;
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_waitcnt(0xc07f);      // this block's coefficients are here; nothing else is outstanding
+        __builtin_amdgcn_sched_barrier(0);       // (the next request does not move in front of the wait)
+        if constexpr (N < 63) load_block(std::integral_constant<int, N + 1>{}, nxt);
+        __builtin_amdgcn_sched_barrier(0);       // (the request stays in front of the products; nothing of the next block is started under this one)
 #pragma unroll
-            for (int j = 0; j < 16; j++) {
-                a0 += mulhi_vs(y[jb * 16 + j], c0[j]);
-                a1 += mulhi_vs(y[jb * 16 + j], c1[j]);
-                a2 += mulhi_vs(y[jb * 16 + j], c2[j]);
-                a3 += mulhi_vs(y[jb * 16 + j], c3[j]);
-                if ((j & 3) == 3) __builtin_amdgcn_sched_barrier(0);
+        for (int j = 0; j < 8; j += 2) {                        // two columns at a time: an output's two products leave in one v_add3_u32
+            int32_t m[2][4];
+#pragma unroll
+            for (int e = 0; e < 2; e++) {
+                const int k = B * 8 + j + e;
+                const unsigned plan = ANALYSIS_PLAN[P][k];
+                const int32_t cj[4] = {cur[0][j + e], cur[1][j + e], cur[2][j + e], cur[3][j + e]};
+#pragma unroll
+                for (int o = 0; o < 4; o++) {
+                    const unsigned rep = (plan >> (2 * o)) & 3u;
+                    if ((plan >> (8 + o)) & 1u) m[e][o] = 0;
+                    else if (rep == (unsigned)o) m[e][o] = mulhi_vs(y[k], cj[o]);
+                    else m[e][o] = m[e][rep];
+                }
+            }
+#pragma unroll
+            for (int o = 0; o < 4; o++) {
+                a[o] += m[0][o] + m[1][o];
+                asm("" : "+v"(a[o]));                           // (sums are not re-associated across outputs: shared partial sums lived long enough to spill)
+            }
+            if (j == 2) __builtin_amdgcn_sched_barrier(0);
+        }
+        if constexpr (B == 7) {
+            // ---- the pass's four bands are complete.  Odd bands of odd slots change sign (:365-368): bands P and 16 + P are odd with P, 15 - P and 31 - P with P even
+            if (odd_slot) {
+                if (P & 1) { a[0] = (int32_t)(0u - (uint32_t)a[0]); a[2] = (int32_t)(0u - (uint32_t)a[2]); }
+                else       { a[1] = (int32_t)(0u - (uint32_t)a[1]); a[3] = (int32_t)(0u - (uint32_t)a[3]); }
+            }
+            constexpr int q = P & 3;
+            ot[lane * 17 + q] = (uint32_t)a[0];               // piece 0: bands 4g .. 4g + 3 (g = P >> 2)
+            ot[lane * 17 + 4 + 3 - q] = (uint32_t)a[1];       // piece 1: bands 12 - 4g .. 15 - 4g
+            ot[lane * 17 + 8 + q] = (uint32_t)a[2];           // piece 2: bands 16 + 4g ..
+            ot[lane * 17 + 12 + 3 - q] = (uint32_t)a[3];      // piece 3: bands 28 - 4g ..
+            a[0] = a[1] = a[2] = a[3] = 0;
+            if constexpr (q == 3) {
+                // ---- sixteen bands of the 64 slots are complete: out 16 bytes per lane, four lanes (= four pieces) per row, sixteen rows per trip
+                constexpr int g = P >> 2;
+                __builtin_amdgcn_s_waitcnt(0xc07f);
+                __builtin_amdgcn_wave_barrier();
+                const int piece = lane & 3;
+                const int band0 = piece == 0 ? 4 * g : (piece == 1 ? 12 - 4 * g : (piece == 2 ? 16 + 4 * g : 28 - 4 * g));
+#pragma unroll
+                for (int r = lane >> 2; r < 64; r += 16) {
+                    const uint32_t *src = ot + r * 17 + piece * 4;
+                    const uint4 v = make_uint4(src[0], src[1], src[2], src[3]);
+                    if (r < rows) *reinterpret_cast<uint4 *>(out + r * 32 + band0) = v;
+                }
+                __builtin_amdgcn_s_waitcnt(0xc07f);
+                __builtin_amdgcn_wave_barrier();         // (the tile is free for the other sixteen bands)
             }
         }
-        if (odd_slot) { a1 = (int32_t)(0u - (uint32_t)a1); a3 = (int32_t)(0u - (uint32_t)a3); }   // odd bands
-        const int sbh = sb & 15;
-        ot[lane * 17 + sbh] = (uint32_t)a0;
-        ot[lane * 17 + sbh + 1] = (uint32_t)a1;
-        ot[lane * 17 + sbh + 2] = (uint32_t)a2;
-        ot[lane * 17 + sbh + 3] = (uint32_t)a3;
-        if (sbh == 12) {
-            // ---- sixteen bands of the 64 slots are complete: out 16 bytes per lane, four lanes per 64-byte half row, sixteen rows per trip
-            __builtin_amdgcn_s_waitcnt(0xc07f);
-            __builtin_amdgcn_wave_barrier();
+        if constexpr (N < 63) {
 #pragma unroll
-            for (int r = lane >> 2; r < 64; r += 16) {
-                const int c = (lane & 3) * 4;
-                const uint32_t *src = ot + r * 17 + c;
-                const uint4 v = make_uint4(src[0], src[1], src[2], src[3]);
-                if (r < rows) *reinterpret_cast<uint4 *>(out + r * 32 + (sb - 12) + c) = v;
-            }
-            __builtin_amdgcn_s_waitcnt(0xc07f);
-            __builtin_amdgcn_wave_barrier();         // (the tile is free for the other sixteen bands)
+            for (int o = 0; o < 4; o++) cur[o] = nxt[o];
         }
-    }
+    });
 }
 
 // mdct layout: int32 [frame][ch][gr][576]  (reference __mdct_freq)

@@ -140,6 +140,11 @@ int mp3s_ctx_create(int device, mp3s_ctx **out)
         mp3s_ctx_destroy(c);
         return fail(MP3S_E_NO_DEVICE, "device scratch allocation failed");
     }
+    if (!host_tables().analysis_plan_ok) {
+        mp3s_ctx_destroy(c);
+        return fail(MP3S_E_NO_DEVICE, "the analysis filter table built on this host does not repeat itself where the kernel shares products "
+                                      "(csrc/analysis_plan.h: run tools/gen_analysis_plan.py here and rebuild)");
+    }
     const int rc = dev_upload_tables(c->stream);
     if (rc) {
         mp3s_ctx_destroy(c);

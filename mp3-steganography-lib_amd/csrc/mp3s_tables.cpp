@@ -3,6 +3,7 @@
 // sees bit-identical constants; tests/test_tables.py checks them against the reference's dump.
 #include "mp3s_tables.h"
 #include "iso_tables.h"
+#include "analysis_plan.h"
 
 #include <algorithm>
 #include <cmath>
@@ -262,6 +263,21 @@ void build()
             double f = 1e9 * std::cos((double)((2 * i + 1) * (16 - j)) * 0.049087385212), ip;
             if (f >= 0) std::modf(f + 0.5, &ip); else std::modf(f - 0.5, &ip);
             T.fl[i][j] = (int32_t)(ip * 2147483647.0 * 1e-9);
+        }
+    // k_enc_analysis computes a product once where two outputs of a pass hold the same coefficient (analysis_plan.h, generated from this
+    // formula by tools/gen_analysis_plan.py): the table built HERE, with this machine's libm, must repeat itself in exactly those places
+    H.analysis_plan_ok = true;
+    for (int p = 0; p < 8; p++)
+        for (int k = 0; k < 64; k++) {
+            const int o[4] = {p, 15 - p, 16 + p, 31 - p};
+            unsigned word = 0;
+            for (int j = 0; j < 4; j++) {
+                int rep = j;
+                for (int q = j - 1; q >= 0; q--) if (T.fl[o[q]][k] == T.fl[o[j]][k]) rep = q;
+                word |= (unsigned)rep << (2 * j);
+                if (T.fl[o[j]][k] == 0) word |= 1u << (8 + j);
+            }
+            if (word != ANALYSIS_PLAN[p][k]) H.analysis_plan_ok = false;
         }
     for (int m = 0; m < 18; m++)
         for (int k = 0; k < 36; k++)

@@ -120,6 +120,7 @@ struct HostTables {
     int sfb_short_width[3][12];
     int slen[16][2];
     uint8_t in_h0[32];
+    bool analysis_plan_ok;   // the filter table built here repeats itself exactly where k_enc_analysis was compiled to share products (analysis_plan.h)
 };
 
 const HostTables &host_tables();   // built on first use, thread-safe

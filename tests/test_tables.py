@@ -273,3 +273,35 @@ def test_tables_of_the_fast_synthesis_and_the_rate_loop_follow_from_the_referenc
     c1 = np.array(t["hlen_c1a"]).astype(np.uint32)
     assert np.array_equal(np.array(t["rl_c1w"]), c1 | (np.array([bin(k & 3).count("1") for k in range(16)], dtype=np.uint32) << 16))
     assert float(t["synth_xbound"]) >= 32767.0 * np.abs(wt).sum(axis=1).max()
+
+
+def test_analysis_plan_matches_the_filter_table(mlib, golden_dir):
+    """k_enc_analysis computes a product once where two outputs of a pass ({p, 15-p, 16+p, 31-p}) hold the same filter coefficient
+    (csrc/analysis_plan.h, generated by tools/gen_analysis_plan.py).  The committed header is what the generator writes today, and
+    it describes the table the library builds -- which is the reference's (enc_fl, encoder/MP3_Encoder.py:536-544)."""
+    import re
+    import subprocess
+    import sys
+    root = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "gen_analysis_plan.py"), "--check"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout + r.stderr
+    text = open(os.path.join(root, "mp3-steganography-lib_amd", "csrc", "analysis_plan.h")).read()
+    words = [int(w, 16) for w in re.findall(r"0x[0-9a-f]{3}", text.split("ANALYSIS_PLAN[8][64]")[1])]
+    plan = np.array(words, dtype=np.int64).reshape(8, 64)
+    fl = mlib.debug_tables()["fl"].reshape(32, 64)
+    assert np.array_equal(fl, np.load(os.path.join(golden_dir, "g1_tables.npz"))["enc_fl"])
+    products = 0
+    for p in range(8):
+        o = [p, 15 - p, 16 + p, 31 - p]
+        for k in range(64):
+            v = [int(fl[i][k]) for i in o]
+            word = 0
+            for j in range(4):
+                rep = min(q for q in range(j + 1) if v[q] == v[j])
+                word |= rep << (2 * j)
+                if v[j] == 0:
+                    word |= 1 << (8 + j)
+                elif rep == j:
+                    products += 1
+            assert word == plan[p][k], (p, k)
+    assert products == int(re.search(r"ANALYSIS_PRODUCTS = (\d+)", text).group(1)) == 1516
