@@ -379,3 +379,27 @@ def test_encode_transform_takes_pcm_from_any_int16_address(ctx, mlib):
             assert np.array_equal(got, want), shift
     finally:
         ctx.free(d_pcm); ctx.free(d_mdct); ctx.free(d_hdr)
+
+
+@pytest.mark.gpu
+def test_pure_tones_reach_the_longest_escapes(ctx, mlib, orc):
+    """A full-scale sine in one channel and a full-scale square wave in the other put nearly all of a granule's bits into a few lines:
+    quantised values of up to 8 000 (books 23 / 31, 13 linbits; the quantiser's float branch on every probe) -- the far end of the
+    bit packer's escape fields and of the rate loop's tables (encoder/MP3_Encoder.py:389-415, 1452-1500).  Bytes, cursor, scfsi and
+    the decode of the result against the oracle; with and without a message."""
+    n = 24
+    t = np.arange(n * 1152) / 44100.0
+    left = np.rint(32767 * np.sin(2 * np.pi * 1000 * t)).astype(np.int16)
+    right = np.where(np.sin(2 * np.pi * 220 * t) >= 0, 32767, -32768).astype(np.int16)
+    pcm = np.ascontiguousarray(np.stack([left, right], axis=1))
+    seen = 0
+    for kbps, msg in ((320, None), (128, bits_of("6#tones.")), (64, None)):
+        o = orc.encode(pcm, 44100, kbps, msg)
+        r = ctx.encode_pcm(pcm, 44100, kbps, msg)
+        assert o["rc"] == 0 and r["mp3"] == o["mp3"], kbps
+        assert r["hide_offset"] == o["hide_offset"]
+        assert np.array_equal(r["scfsi"], o["frames"]["scfsi"]), kbps
+        d, od = ctx.decode_stream(r["mp3"], mlib.MP3S_PCM_F64), orc.decode(r["mp3"])   # ... and back: the decoder's escapes
+        assert np.array_equal(d["pcm"], od["pcm"]) and np.array_equal(d["bits"], od["bits"]), kbps
+        seen = max(seen, int(np.abs(np.asarray(o["ix"])).max()))
+    assert seen > 4096                                                  # (the premise: 13-bit escapes were in the streams)
