@@ -634,6 +634,13 @@ int mp3s_encode_file(mp3s_ctx *ctx, const uint8_t *wav, size_t len, int bitrate_
 int mp3s_hide_message(mp3s_ctx *ctx, const uint8_t *mp3, size_t len, const uint8_t *utf8, size_t n_msg, mp3s_buf **owner,
                       mp3s_file *out);
 int mp3s_clear_file(mp3s_ctx *ctx, const uint8_t *mp3, size_t len, mp3s_buf **owner, mp3s_file *out);
+/* The same two calls with the result written to an open file instead of handed back (the reference's hide_message / clear_file write
+ * a file: steganography.py:137-162, 164-182 -- the last step of both is Encoder(...).encode() writing output_file_path,
+ * encoder/encoder.py:53-57): bytes [0, out->len) of `fd` are the result (pwrite: the descriptor's position is not used or moved), the
+ * file is cut to that length at the end; out->data is NULL.  A file that goes through the stages as chunks is written chunk by chunk, a
+ * chunk's bytes while the next chunk is on the device.  After an error the file's content is unspecified. */
+int mp3s_hide_message_fd(mp3s_ctx *ctx, const uint8_t *mp3, size_t len, const uint8_t *utf8, size_t n_msg, int fd, mp3s_file *out);
+int mp3s_clear_file_fd(mp3s_ctx *ctx, const uint8_t *mp3, size_t len, int fd, mp3s_file *out);
 /* replaces: a loop of Steganography.hide_message / clear_file over a list of files.  All files with the
  * same sampling rate and bitrate go through the device as ONE batch (decode, transforms, rate loop, bit packing: the
  * streams' frames back to back, every serial chain restarting at a stream's first frame), so many short files cost

@@ -1,5 +1,7 @@
 // C-ABI of the library (include/mp3s.h), part 3: PCM in (from the host, or left in HBM by the decode pipeline), MP3 out
 // -- the encoder's device batch with its serial chains, and the file / message / block entry points built on it.
+#include <unistd.h>
+#include <cerrno>
 #include "mp3s_internal.h"
 
 static inline size_t up16(size_t x) { return (x + 15) & ~(size_t)15; }
@@ -937,8 +939,31 @@ static int reencode(mp3s_ctx *c, const uint8_t *mp3, size_t len, const uint8_t *
         out->n_frames = (int32_t)r.n_frames; out->too_long = r.too_long; out->hide_offset = r.hide_offset;
         return MP3S_OK;
     }
+    c->sink_done = 0;                                  // (mp3s_*_fd: what the chunks wrote is written again from the result of the other path)
     const uint8_t *const no_msg = nullptr;
     return mp3s_hide_messages(c, &mp3, &len, 1, hide ? &msg : &no_msg, &n_msg, owner, out, nullptr);
+}
+
+// mp3s_hide_message_fd / mp3s_clear_file_fd: reencode() with the context's sink set -- run_file writes the chunks it can as they become
+// final --, then whatever is missing, the cut to length, and the result block goes back
+static int reencode_fd(mp3s_ctx *c, const uint8_t *mp3, size_t len, const uint8_t *msg, size_t n_msg, bool hide, int fd, mp3s_file *out)
+{
+    mp3s_buf *owner = nullptr;
+    c->sink_fd = fd; c->sink_done = 0;
+    int rc = reencode(c, mp3, len, msg, n_msg, hide, &owner, out);
+    c->sink_fd = -1;
+    if (rc == MP3S_OK) {
+        size_t at = std::min(c->sink_done, out->len);
+        while (at < out->len) {
+            const ssize_t w = pwrite(fd, out->data + at, out->len - at, (off_t)at);
+            if (w <= 0) { rc = fail(MP3S_E_ARG, "writing the result to the file descriptor failed (errno %d)", errno); break; }
+            at += (size_t)w;
+        }
+        if (rc == MP3S_OK && ftruncate(fd, (off_t)out->len) != 0) rc = fail(MP3S_E_ARG, "cutting the output file to length failed (errno %d)", errno);
+    }
+    if (owner) mp3s_buf_free(owner);
+    out->data = nullptr;
+    return rc;
 }
 
 int mp3s_hide_message(mp3s_ctx *c, const uint8_t *mp3, size_t len, const uint8_t *utf8, size_t n_msg, mp3s_buf **owner, mp3s_file *out)
@@ -952,6 +977,19 @@ int mp3s_clear_file(mp3s_ctx *c, const uint8_t *mp3, size_t len, mp3s_buf **owne
 {
     if (!c || !mp3 || !owner || !out) return fail(MP3S_E_ARG, "null pointer");
     return reencode(c, mp3, len, nullptr, 0, false, owner, out);
+}
+
+int mp3s_hide_message_fd(mp3s_ctx *c, const uint8_t *mp3, size_t len, const uint8_t *utf8, size_t n_msg, int fd, mp3s_file *out)
+{
+    if (!c || !mp3 || (!utf8 && n_msg) || !out || fd < 0) return fail(MP3S_E_ARG, "bad argument");
+    static const uint8_t empty = 0;
+    return reencode_fd(c, mp3, len, utf8 ? utf8 : &empty, n_msg, true, fd, out);
+}
+
+int mp3s_clear_file_fd(mp3s_ctx *c, const uint8_t *mp3, size_t len, int fd, mp3s_file *out)
+{
+    if (!c || !mp3 || !out || fd < 0) return fail(MP3S_E_ARG, "bad argument");
+    return reencode_fd(c, mp3, len, nullptr, 0, false, fd, out);
 }
 
 }  // extern "C"

@@ -7,6 +7,7 @@
 // PCM in front of the chunk are recomputed and dropped; the padding recurrence is replayed from the frame index; the message
 // cursor and the inherited addresses (17 integers) are GUESSED -- "the message is hidden, nothing is inherited" -- and every
 // chunk reports whether it looked at them: only a chunk that did, on a guess that was wrong, is run again on the real carry.
+#include <unistd.h>
 #include "pipe_internal.h"
 
 namespace {
@@ -68,6 +69,7 @@ int run_file(mp3s_ctx *c, const uint8_t *mp3, size_t len, int mode, const uint8_
 
 static int run_file_impl(mp3s_ctx *c, const uint8_t *mp3, size_t len, int mode, const uint8_t *utf8, size_t n_msg, int out_format, mp3s_buf **owner, RunResult *out, bool whole)
 {
+    c->sink_done = 0;                                                // (mp3s_*_fd: nothing of THIS attempt's result is in the file yet)
     if (!c->opt[MP3S_OPT_FILE_PIPELINE] || !c->opt[MP3S_OPT_DEVICE_PARSE]) return kRunFallback;
     const bool decode = mode == kRunDecode;
     const double t_call0 = trace_on() ? now_ms() : 0;
@@ -192,6 +194,34 @@ static int run_file_impl(mp3s_ctx *c, const uint8_t *mp3, size_t len, int mode, 
         rc.done = true;
         return MP3S_OK;
     };
+    // (mp3s_*_fd: a chunk's bytes go to the file as soon as they are final -- while the chunks behind it are still on the device.  Final =
+    // the chunk will not be run again on its real carry: the test of the settling loop at the end, on a copy of the carries, nothing
+    // settled here.  Chunks 0 .. k have been retired.)
+    bool sink_on = !decode && c->sink_fd >= 0;
+    size_t sink_next = 0;
+    mp3s_carry sink_real = {};
+    auto sink_upto = [&](size_t k) {
+        for (; sink_on && sink_next <= k && sink_next < chunks.size(); sink_next++) {
+            const RunChunk &rc = chunks[sink_next];
+            mp3s_carry mine = rc.out;
+            if (sink_next > 0) {
+                const bool live = std::min<int64_t>(sink_real.cursor, n_hide) < n_hide;
+                if (!same_effect(sink_real, rc.guess, n_hide) && (rc.carry_used || live)) { sink_on = false; break; }   // (it will be run again: its bytes change)
+                mine.cursor = sink_real.cursor + (rc.out.cursor - rc.guess.cursor);
+            }
+            if ((size_t)rc.out_off != c->sink_done) { sink_on = false; break; }
+            const uint8_t *src = res->big[0].data() + rc.out_off;
+            size_t left = (size_t)rc.out_len, at = (size_t)rc.out_off;
+            while (left) {
+                const ssize_t w = pwrite(c->sink_fd, src, left, (off_t)at);
+                if (w <= 0) { sink_on = false; break; }                     // (the caller writes what is missing, and reports what fails there)
+                src += w; at += (size_t)w; left -= (size_t)w;
+            }
+            if (!sink_on) break;
+            c->sink_done = at;
+            sink_real = mine;
+        }
+    };
     // issue frames [first, first + count) of the stream as a chunk on slot `slot`
     // A chunk is queued in two steps.  issue_a: its front end (file piece, parse, Huffman -- a latency chain of 0.1 ms whatever the
     // chunk's size).  issue_b: the results of the chunk in front, this chunk's encoder inputs (laid out here, 0.1 ms of host time
@@ -292,6 +322,7 @@ static int run_file_impl(mp3s_ctx *c, const uint8_t *mp3, size_t len, int mode, 
         if (k >= (size_t)P->depth) {               // the slot's previous chunk first
             const int r = retire(k - (size_t)P->depth);
             if (r) return fallback("a chunk needs another path", r);
+            sink_upto(k - (size_t)P->depth);
         }
         const double t_ret = trace_on() ? now_ms() : 0;
         chunks.emplace_back();
@@ -318,6 +349,7 @@ static int run_file_impl(mp3s_ctx *c, const uint8_t *mp3, size_t len, int mode, 
     for (size_t k = 0; k < chunks.size(); k++) {
         const int r = retire(k);
         if (r) return fallback("a chunk needs another path", r);
+        sink_upto(k);
     }
     mp3s_carry real = {};
     for (size_t k = 0; k < chunks.size(); k++) {

@@ -277,3 +277,72 @@ def test_every_context_of_a_process_gets_its_overlap(mlib):
     finally:
         for c in ctxs:
             c.close()
+
+
+@pytest.mark.gpu
+def test_result_written_to_a_file_descriptor_chunk_by_chunk(ctx, mlib, orc, golden_dir, tmp_path):
+    """mp3s_hide_message_fd / mp3s_clear_file_fd (what Steganography.hide_message / clear_file end in, reference steganography.py:137-182,
+    encoder/encoder.py:53-57): the file holds exactly the bytes the call returns otherwise -- over a longer file that was there, with chunks
+    that depend on their carry (run again: written at the end), through the paths the chunks do not take, in place through the facade, and
+    a stream the call refuses leaves the output as it was."""
+    import frame_synth
+    from synth_pcm import synth_pcm
+    from mp3stego import Steganography
+    pcm = synth_pcm(700, seed=51)
+    pcm[:40 * 1152] = 0
+    pcm[120 * 1152:136 * 1152] = 0                           # silences that straddle chunk boundaries (inherited addresses: chunks run again)
+    pcm[250 * 1152:262 * 1152] = 0
+    mp3 = bytes(ctx.encode_pcm(pcm, 44100, 128, None)["mp3"])
+    out = tmp_path / "out.mp3"
+
+    def through_fd(data, msg):
+        out.write_bytes(b"\xaa" * (len(data) + 5000))        # something longer is there: it is overwritten and cut to length
+        fd = os.open(str(out), os.O_WRONLY)
+        try:
+            r = ctx.recode_to_fd(data, msg, fd)
+            assert os.lseek(fd, 0, os.SEEK_CUR) == 0         # pwrite: the descriptor's position is not moved
+        finally:
+            os.close(fd)
+        got = out.read_bytes()
+        assert len(got) == r["len"]
+        return got, r
+
+    s0 = ctx.run_stats()
+    for data in (mp3, mp3[:-3]):
+        for msg in ("short", "y" * 400, None):
+            want = ctx.clear_file(data) if msg is None else ctx.hide_message(data, msg)
+            for chunk in (64, 250, 0):
+                with options(ctx, chunk_frames=chunk):
+                    got, r = through_fd(data, msg)
+                assert got == bytes(want["data"]), (len(data), msg and len(msg), chunk)
+                assert r["too_long"] == want["too_long"] and r["hide_offset"] == want["hide_offset"] and r["n_frames"] == want["n_frames"]
+    s1 = ctx.run_stats()
+    assert s1["reruns"] > s0["reruns"]                                               # some chunk was run again on its real carry
+    assert through_fd(mp3, "y" * 400)[0] == orc.encode(orc.pcm_to_i16(orc.decode(mp3)["pcm"]), 44100, 128, np.array(mlib.message_frame("y" * 400)))["mp3"]
+    # what the chunks do not take (a repeated last frame; mixed blocks without the file-wide arrays)
+    tail = open(os.path.join(golden_dir, "test.mp3"), "rb").read() + b"\x00" * 700
+    assert through_fd(tail, "abc")[0] == bytes(ctx.hide_message(tail, "abc")["data"])
+    joint = frame_synth.make_stream(10, 80, mode=1, mode_ext=2, block_types=(0, 2), allow_mixed=True)
+    with options(ctx, chunk_frames=16, file_up=0):
+        assert through_fd(joint, None)[0] == bytes(ctx.clear_file(joint)["data"])
+    # a stream the call refuses: the error of the other entry point, and through the facade the output file is as it was
+    mono = frame_synth.make_stream(8, 50, mode=3)
+    fd = os.open(str(out), os.O_WRONLY)
+    try:
+        with pytest.raises(mlib.Mp3sError) as e1:
+            ctx.recode_to_fd(mono, "abc", fd)
+        assert e1.value.code == mlib.E_UNSUPPORTED
+    finally:
+        os.close(fd)
+    # the facade: in place (the result replaces the input only when the input has been read), and into a new file
+    st = Steganography(quiet=True)
+    src = tmp_path / "in.mp3"
+    src.write_bytes(mp3)
+    want = bytes(ctx.hide_message(mp3, "in place")["data"])
+    with options(ctx, chunk_frames=64):
+        assert st.hide_message(str(src), str(src), "in place") is False
+    assert src.read_bytes() == want
+    src.write_bytes(mp3)
+    new = tmp_path / "new.mp3"
+    st.clear_file(str(src), str(new))
+    assert new.read_bytes() == bytes(ctx.clear_file(mp3)["data"])
