@@ -18,6 +18,20 @@ gd = os.path.join(ROOT, 'tests', 'golden')
 data = open(os.path.join(gd, "test.mp3"), "rb").read()
 g = np.load(os.path.join(gd, "g7_decode_corpus.npz"))
 names = sorted({k.split("__")[0] for k in g.files})
+import contextlib
+import tempfile
+sink_fd = os.open(os.path.join(tempfile.mkdtemp(dir="/dev/shm" if os.path.isdir("/dev/shm") else None), "sink.mp3"), os.O_RDWR | os.O_CREAT, 0o600)
+
+
+@contextlib.contextmanager
+def mlib_options(c, chunk_frames):
+    old = c.set_option("chunk_frames", chunk_frames)
+    try:
+        yield
+    finally:
+        c.set_option("chunk_frames", old)
+
+
 t_end = time.time() + budget
 stats = {"ok": 0, "both_reject": 0, "bad": 0}
 seed = 30000
@@ -45,6 +59,19 @@ while time.time() < t_end:
             single = ctx.clear_file(f) if msg is None else ctx.hide_message(f, msg)
         except (mlib.Mp3sError, SystemExit):
             single = None
+        # ... and the same call with its result written to a file descriptor (mp3s_*_fd: chunk by chunk), over something longer
+        try:
+            os.lseek(sink_fd, 0, os.SEEK_SET); os.write(sink_fd, b"\xaa" * (len(f) + 4096))
+            with mlib_options(ctx, 64 if seed % 5 == 0 else 0):
+                rf = ctx.recode_to_fd(f, msg, sink_fd)
+            os.lseek(sink_fd, 0, os.SEEK_SET)
+            to_fd = os.read(sink_fd, rf["len"] + 1)
+        except (mlib.Mp3sError, SystemExit):
+            to_fd = None
+        if (single is None) != (to_fd is None) or (single is not None and bytes(single["data"]) != to_fd):
+            stats["bad"] += 1
+            print("FD MISMATCH seed", seed, "file", i, single is None, to_fd is None, flush=True)
+            continue
         if want is None:
             if isinstance(r, Exception) and single is None:
                 stats["both_reject"] += 1
