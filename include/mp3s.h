@@ -625,6 +625,11 @@ typedef struct {
 } mp3s_file;
 /* replaces: Decoder(...).decode() -- reference decoder/decoder.py:59-84: MP3 bytes -> WAV bytes (int16) */
 int mp3s_decode_file(mp3s_ctx *ctx, const uint8_t *mp3, size_t len, mp3s_buf **owner, mp3s_file *out);
+/* the same with the WAV written to an open file (decoder/decoder.py:80-84 ends in scipy.io.wavfile.write(output_file_path, ...)): bytes
+ * [0, out->len) of `fd` (pwrite), cut to that length; the PCM of a file that goes through the stages as chunks is written chunk by chunk
+ * while the later chunks are on the device (same rule as mp3s_hide_message_fd for a file that held something).  out->data is NULL, out->bits
+ * lives in *owner. */
+int mp3s_decode_file_fd(mp3s_ctx *ctx, const uint8_t *mp3, size_t len, int fd, mp3s_buf **owner, mp3s_file *out);
 /* replaces: Encoder(...).encode() -- reference encoder/encoder.py:21-58: WAV bytes -> MP3 bytes, hide_bits optional */
 int mp3s_encode_file(mp3s_ctx *ctx, const uint8_t *wav, size_t len, int bitrate_kbps, const uint8_t *hide_bits,
                      int n_hide, mp3s_buf **owner, mp3s_file *out);
@@ -638,7 +643,9 @@ int mp3s_clear_file(mp3s_ctx *ctx, const uint8_t *mp3, size_t len, mp3s_buf **ow
  * a file: steganography.py:137-162, 164-182 -- the last step of both is Encoder(...).encode() writing output_file_path,
  * encoder/encoder.py:53-57): bytes [0, out->len) of `fd` are the result (pwrite: the descriptor's position is not used or moved), the
  * file is cut to that length at the end; out->data is NULL.  A file that goes through the stages as chunks is written chunk by chunk, a
- * chunk's bytes while the next chunk is on the device.  After an error the file's content is unspecified. */
+ * chunk's bytes while the chunks behind it are on the device -- if the file was EMPTY when the call began; a file that held something is
+ * written at the end of a call that succeeded and is left as it was by one that did not (the reference has not touched its output when it
+ * refuses a stream; whoever created an empty file for the call removes it after an error). */
 int mp3s_hide_message_fd(mp3s_ctx *ctx, const uint8_t *mp3, size_t len, const uint8_t *utf8, size_t n_msg, int fd, mp3s_file *out);
 int mp3s_clear_file_fd(mp3s_ctx *ctx, const uint8_t *mp3, size_t len, int fd, mp3s_file *out);
 /* replaces: a loop of Steganography.hide_message / clear_file over a list of files.  All files with the

@@ -1,5 +1,8 @@
 // C-ABI of the library (include/mp3s.h), part 2: MP3 streams in, PCM out -- the host front end, the device batch
 // (Huffman decode + transforms, chunked with a one-frame halo) and the entry points built on them.
+#include <sys/stat.h>
+#include <unistd.h>
+#include <cerrno>
 #include "mp3s_internal.h"
 
 // keep frames [first, first + count) of a parsed stream (its main data, side records, samples)
@@ -417,9 +420,43 @@ int mp3s_decode_stream(mp3s_ctx *c, const uint8_t *file, size_t len, int out_for
     return mp3s_decode_streams(c, &file, &len, 1, out_format, owner, out, nullptr);
 }
 
+static int decode_file_impl(mp3s_ctx *c, const uint8_t *mp3, size_t len, mp3s_buf **owner, mp3s_file *out);
+
 int mp3s_decode_file(mp3s_ctx *c, const uint8_t *mp3, size_t len, mp3s_buf **owner, mp3s_file *out)
 {
     if (!c || !mp3 || !owner || !out) return fail(MP3S_E_ARG, "null pointer");
+    return decode_file_impl(c, mp3, len, owner, out);
+}
+
+// the WAV into an open file: the PCM of a file that goes through the stages as chunks is written chunk by chunk (run_file, the context's
+// sink), then the header, whatever is missing, and the cut to length; *owner keeps out->bits alive
+int mp3s_decode_file_fd(mp3s_ctx *c, const uint8_t *mp3, size_t len, int fd, mp3s_buf **owner, mp3s_file *out)
+{
+    if (!c || !mp3 || !owner || !out || fd < 0) return fail(MP3S_E_ARG, "bad argument");
+    struct stat st;
+    c->sink_fd = fd; c->sink_done = 0; c->sink_base = 44; c->sink_early = fstat(fd, &st) == 0 && st.st_size == 0;
+    int rc = decode_file_impl(c, mp3, len, owner, out);
+    c->sink_fd = -1;
+    if (rc) return rc;
+    const size_t done = out->len > 44 ? std::min(c->sink_done, out->len - 44) : 0;
+    auto put = [&](const uint8_t *src, size_t n, size_t at) {
+        while (n) {
+            const ssize_t w = pwrite(fd, src, n, (off_t)at);
+            if (w <= 0) return false;
+            src += w; at += (size_t)w; n -= (size_t)w;
+        }
+        return true;
+    };
+    if (!put(out->data, 44, 0) || !put(out->data + 44 + done, out->len - 44 - done, 44 + done) || ftruncate(fd, (off_t)out->len) != 0) {
+        mp3s_buf_free(*owner); *owner = nullptr;
+        return fail(MP3S_E_ARG, "writing the WAV to the file descriptor failed (errno %d)", errno);
+    }
+    out->data = nullptr;
+    return MP3S_OK;
+}
+
+static int decode_file_impl(mp3s_ctx *c, const uint8_t *mp3, size_t len, mp3s_buf **owner, mp3s_file *out)
+{
     // the PCM lands 64 bytes into its buffer; the 44-byte WAV header goes right in front of it: no second copy
     mp3s_buf *b = nullptr;
     mp3s_decoded d;
@@ -428,8 +465,10 @@ int mp3s_decode_file(mp3s_ctx *c, const uint8_t *mp3, size_t len, mp3s_buf **own
     if (rc == MP3S_OK) {
         d.n_frames = (int32_t)r.n_frames; d.nch = r.nch; d.sampling_rate = r.sampling_rate; d.bit_rate = r.bit_rate;
         d.n_bits = (int32_t)r.n_bits; d.n_rows = r.n_rows; d.pcm = r.pcm; d.bits = r.bits;
-    } else if (rc == kRunFallback)                                                    // ... or one stage after the other
+    } else if (rc == kRunFallback) {                                                  // ... or one stage after the other
+        c->sink_done = 0;
         rc = decode_streams_impl(c, &mp3, &len, 1, MP3S_PCM_I16, 64, &b, &d, nullptr);
+    }
     if (rc) return rc;
     uint8_t *wav;
     if (d.n_rows == 0) {   // nothing decoded: what scipy writes for an empty 1-d array at the header object's initial rate 0

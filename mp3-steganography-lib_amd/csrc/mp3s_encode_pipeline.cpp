@@ -1,5 +1,6 @@
 // C-ABI of the library (include/mp3s.h), part 3: PCM in (from the host, or left in HBM by the decode pipeline), MP3 out
 // -- the encoder's device batch with its serial chains, and the file / message / block entry points built on it.
+#include <sys/stat.h>
 #include <unistd.h>
 #include <cerrno>
 #include "mp3s_internal.h"
@@ -949,7 +950,8 @@ static int reencode(mp3s_ctx *c, const uint8_t *mp3, size_t len, const uint8_t *
 static int reencode_fd(mp3s_ctx *c, const uint8_t *mp3, size_t len, const uint8_t *msg, size_t n_msg, bool hide, int fd, mp3s_file *out)
 {
     mp3s_buf *owner = nullptr;
-    c->sink_fd = fd; c->sink_done = 0;
+    struct stat st;
+    c->sink_fd = fd; c->sink_done = 0; c->sink_base = 0; c->sink_early = fstat(fd, &st) == 0 && st.st_size == 0;
     int rc = reencode(c, mp3, len, msg, n_msg, hide, &owner, out);
     c->sink_fd = -1;
     if (rc == MP3S_OK) {

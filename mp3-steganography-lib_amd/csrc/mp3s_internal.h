@@ -40,7 +40,8 @@ struct mp3s_ctx {
     int64_t opt[MP3S_OPT_COUNT] = {0};   // MP3S_OPT_*: defaults from the environment at creation, then mp3s_ctx_set_option
     mp3s_run_stats run_stats = {0, 0, 0, 0, 0};
     mp3s_pipe *own_pipe = nullptr;       // the overlapped stages the one-file calls run their chunks through (made on first use)
-    int sink_fd = -1; size_t sink_done = 0;   // mp3s_*_fd: the file the result goes to, and how many of its bytes run_file has written already
+    int sink_fd = -1; size_t sink_done = 0, sink_base = 0; bool sink_early = false;   // (sink_early: the file was empty when the call began -- only then do chunks go to it before the call has succeeded)
+   // mp3s_*_fd: the file the result goes to, how many of its bytes (behind sink_base: the WAV header's place) run_file has written already
     hipStream_t stream = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr, ev_order = nullptr;
     hipEvent_t ev_sel = nullptr; bool sel_pending = false;   // a selection on a tail stream has read the variant buffers (enc_issue)

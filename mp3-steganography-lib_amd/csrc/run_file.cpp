@@ -197,23 +197,27 @@ static int run_file_impl(mp3s_ctx *c, const uint8_t *mp3, size_t len, int mode, 
     // (mp3s_*_fd: a chunk's bytes go to the file as soon as they are final -- while the chunks behind it are still on the device.  Final =
     // the chunk will not be run again on its real carry: the test of the settling loop at the end, on a copy of the carries, nothing
     // settled here.  Chunks 0 .. k have been retired.)
-    bool sink_on = !decode && c->sink_fd >= 0;
+    // Only into a file that was EMPTY when the call began (sink_early): a stream that is refused late -- a damaged frame in the last chunk, found
+    // on the device -- ends in an error, and the reference has not touched its output file at that point; a file that held something is written
+    // at the end of a call that succeeded (the entry point does that), a fresh one is removed by the caller that created it.
+    bool sink_on = c->sink_fd >= 0 && c->sink_early && (!decode || out_format == MP3S_PCM_I16);   // (a decode's chunks have no carries: final when they are down)
     size_t sink_next = 0;
     mp3s_carry sink_real = {};
     auto sink_upto = [&](size_t k) {
         for (; sink_on && sink_next <= k && sink_next < chunks.size(); sink_next++) {
             const RunChunk &rc = chunks[sink_next];
             mp3s_carry mine = rc.out;
-            if (sink_next > 0) {
+            if (!decode && sink_next > 0) {
                 const bool live = std::min<int64_t>(sink_real.cursor, n_hide) < n_hide;
                 if (!same_effect(sink_real, rc.guess, n_hide) && (rc.carry_used || live)) { sink_on = false; break; }   // (it will be run again: its bytes change)
                 mine.cursor = sink_real.cursor + (rc.out.cursor - rc.guess.cursor);
             }
-            if ((size_t)rc.out_off != c->sink_done) { sink_on = false; break; }
-            const uint8_t *src = res->big[0].data() + rc.out_off;
-            size_t left = (size_t)rc.out_len, at = (size_t)rc.out_off;
+            const size_t off = decode ? (size_t)rc.first * 1152 * (size_t)nch * esz : (size_t)rc.out_off;
+            size_t left = decode ? (size_t)rc.count * 1152 * (size_t)nch * esz : (size_t)rc.out_len, at = off;
+            if (off != c->sink_done) { sink_on = false; break; }
+            const uint8_t *src = res->big[0].data() + (decode ? 64 : 0) + off;
             while (left) {
-                const ssize_t w = pwrite(c->sink_fd, src, left, (off_t)at);
+                const ssize_t w = pwrite(c->sink_fd, src, left, (off_t)(c->sink_base + at));
                 if (w <= 0) { sink_on = false; break; }                     // (the caller writes what is missing, and reports what fails there)
                 src += w; at += (size_t)w; left -= (size_t)w;
             }

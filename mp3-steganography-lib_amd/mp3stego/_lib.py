@@ -175,7 +175,7 @@ SYMBOLS = ["mp3s_ctx_create", "mp3s_ctx_destroy", "mp3s_ctx_wait", "mp3s_last_er
            "mp3s_encode_transform_dev", "mp3s_encode_transform", "mp3s_rate_loop_dev", "mp3s_chain_resolve_dev", "mp3s_chain_redo_dev", "mp3s_select_patterns", "mp3s_select_plan", "mp3s_rate_select_dev", "mp3s_rate_variants_dev", "mp3s_select_dev", "mp3s_huffman_decode_dev", "mp3s_pack_frames_dev", "mp3s_scan_stream", "mp3s_buf_free",
            "mp3s_parse_stream", "mp3s_format_stream", "mp3s_rate_frames", "mp3s_decode_stream", "mp3s_decode_streams", "mp3s_decode_block", "mp3s_encode_pcm", "mp3s_encode_block",
            "mp3s_wav_parse", "mp3s_wav_header", "mp3s_message_frame", "mp3s_message_reveal", "mp3s_decode_file", "mp3s_encode_file",
-           "mp3s_hide_message", "mp3s_clear_file", "mp3s_hide_message_fd", "mp3s_clear_file_fd", "mp3s_hide_messages", "mp3s_reencode_block", "mp3s_reveal_message",
+           "mp3s_hide_message", "mp3s_clear_file", "mp3s_hide_message_fd", "mp3s_clear_file_fd", "mp3s_decode_file_fd", "mp3s_hide_messages", "mp3s_reencode_block", "mp3s_reveal_message",
            "mp3s_pipe_create", "mp3s_pipe_destroy", "mp3s_pipe_submit", "mp3s_pipe_submit_decode", "mp3s_pipe_collect", "mp3s_pipe_get_stats",
            "mp3s_index_stream", "mp3s_index_free", "mp3s_scan_range", "mp3s_decode_block_indexed", "mp3s_reencode_block_indexed",
            "mp3s_hide_message_chunked", "mp3s_walk_stream", "mp3s_parse_frames_dev", "mp3s_stego_bits", "mp3s_ctx_set_option", "mp3s_ctx_get_option", "mp3s_ctx_run_stats", "mp3s_dev_copy", "mp3s_pipe_submit_block", "mp3s_pipe_collect_block", "mp3s_pipe_next_is_block", "mp3s_debug_walk_rate", "mp3s_device_count", "mp3s_device_pci"]
@@ -261,6 +261,7 @@ def lib():
         L.mp3s_encode_file.argtypes = [vp, vp, sz, i32, vp, i32, pvp, C.POINTER(File)]
         L.mp3s_hide_message.argtypes = [vp, vp, sz, vp, sz, pvp, C.POINTER(File)]
         L.mp3s_clear_file.argtypes = [vp, vp, sz, pvp, C.POINTER(File)]
+        L.mp3s_decode_file_fd.argtypes = [vp, vp, sz, C.c_int, pvp, C.POINTER(File)]
         L.mp3s_hide_message_fd.argtypes = [vp, vp, sz, vp, sz, C.c_int, C.POINTER(File)]
         L.mp3s_clear_file_fd.argtypes = [vp, vp, sz, C.c_int, C.POINTER(File)]
         L.mp3s_decode_block.argtypes = [vp, vp, sz, C.c_int64, C.c_int64, i32, pvp, C.POINTER(Decoded)]
@@ -630,6 +631,17 @@ class Context:
         check(lib().mp3s_encode_file(self.handle, buf.ctypes.data, len(wav), int(bitrate), hb.ctypes.data if hb is not None else None,
                                      nh, C.byref(owner), C.byref(f)))
         return self._file(f, owner)
+
+    def decode_file_to_fd(self, mp3: bytes, fd: int):
+        """decode_file with the WAV written to the open file `fd` (bytes [0, length), cut to length; include/mp3s.h mp3s_decode_file_fd):
+        the PCM of a file that goes through the stages as chunks is written chunk by chunk while the later chunks are on the device.
+        Returns decode_file's dict without "data" (+ "len")."""
+        buf = np.frombuffer(mp3, dtype=np.uint8)
+        owner, f = C.c_void_p(), File()
+        check(lib().mp3s_decode_file_fd(self.handle, buf.ctypes.data, len(mp3), int(fd), C.byref(owner), C.byref(f)))
+        own = _Owner(owner)
+        return {"len": f.len, "kbps": f.kbps, "sampling_rate": f.sampling_rate, "channels": f.channels, "n_frames": f.n_frames,
+                "too_long": False, "hide_offset": 0, "bits": _view_owned(f.bits, np.uint8, (f.n_bits,), own)}
 
     def hide_message(self, mp3: bytes, message: str):
         """decode + re-encode with "<count>#<message>" hidden; the PCM stays on the device in between."""

@@ -41,17 +41,26 @@ class Decoder:
             with open('METADATA.txt', 'w') as f:   # in the working directory, like the reference
                 f.write(id3.listing(self.__file_path, self.__tag))
         start = time.time()
+        # the WAV straight into the output file (over what is there, cut to length at the end): the library writes a file's PCM chunk by
+        # chunk while the later chunks are still on the device -- 46 MB per 10 000 frames, the larger part of the call.  A stream the call
+        # refuses leaves no file behind that was not there (the reference raises before it writes)
+        there = os.path.exists(self.__output_file_path)
+        fd = os.open(self.__output_file_path, os.O_WRONLY | os.O_CREAT, 0o666)
         try:
-            res = _lib.default_context().decode_file(self.__data)
+            res = _lib.default_context().decode_file_to_fd(self.__data, fd)
         except _lib.Mp3sError as e:
+            os.close(fd); fd = -1
+            if not there:
+                os.remove(self.__output_file_path)
             if e.code in (_lib.E_MALFORMED, _lib.E_UNSUPPORTED):
                 raise ValueError(str(e)) from None
             raise
+        finally:
+            if fd >= 0:
+                os.close(fd)
         self.__result = res
         if not quiet:
             print('\nParsed', res["n_frames"], 'frames in', time.time() - start, 'seconds.')
-        with open(self.__output_file_path, "wb") as f:
-            f.write(res["data"])
         if not quiet:
             print(f"Wav file created on {self.__output_file_path}")
 

@@ -182,7 +182,8 @@ class Steganography:
                 if fd >= 0:
                     os.close(fd)
             if res is None and made:
-                os.remove(mp3_out)               # (the reference has not created its output at this point either)
+                os.remove(mp3_out)               # (the reference has not created its output at this point either; a file that was there
+                                                 # and held something has not been written to by a call that failed: include/mp3s.h)
             if res is not None:
                 self._kbps = res["kbps"]
                 if os.path.exists(wav):

@@ -267,8 +267,9 @@ def test_every_context_of_a_process_gets_its_overlap(mlib):
                 ts.append(time.perf_counter() - t0)
             med.append(sorted(ts)[len(ts) // 2])
         # (what the rehearsal guards against is a context at HALF speed -- 1.08 - 1.18 ms against 0.70 in round 3; from run to run the
-        # contexts of a process differ by up to 20 %: the first stream a process makes is not like the others)
-        assert max(med) <= 1.30 * min(med), [round(m * 1e3, 3) for m in med]
+        # contexts of a process differ by up to 20 %: the first stream a process makes is not like the others -- and by 35 % on two boxes
+        # of round 4's last day: 0.61 / 0.58 / 0.79 ms; the bound stays below the 1.54 the half-speed case had at its best)
+        assert max(med) <= 1.45 * min(med), [round(m * 1e3, 3) for m in med]
         # a user's pipe on the first context: its own rehearsal (the context's stream is the same: decided earlier, nothing rehearsed)
         p = mlib.Pipe(ctxs[0], depth=2, max_job_bytes=len(mp3) + 65536, scan_threads=1)
         ps = p.stats()
@@ -295,8 +296,9 @@ def test_result_written_to_a_file_descriptor_chunk_by_chunk(ctx, mlib, orc, gold
     mp3 = bytes(ctx.encode_pcm(pcm, 44100, 128, None)["mp3"])
     out = tmp_path / "out.mp3"
 
-    def through_fd(data, msg):
-        out.write_bytes(b"\xaa" * (len(data) + 5000))        # something longer is there: it is overwritten and cut to length
+    def through_fd(data, msg, fresh=False):
+        # something longer is there: it is overwritten and cut to length at the end of the call -- or nothing: then chunk by chunk
+        out.write_bytes(b"" if fresh else b"\xaa" * (len(data) + 5000))
         fd = os.open(str(out), os.O_WRONLY)
         try:
             r = ctx.recode_to_fd(data, msg, fd)
@@ -312,19 +314,53 @@ def test_result_written_to_a_file_descriptor_chunk_by_chunk(ctx, mlib, orc, gold
         for msg in ("short", "y" * 400, None):
             want = ctx.clear_file(data) if msg is None else ctx.hide_message(data, msg)
             for chunk in (64, 250, 0):
-                with options(ctx, chunk_frames=chunk):
-                    got, r = through_fd(data, msg)
-                assert got == bytes(want["data"]), (len(data), msg and len(msg), chunk)
+                for fresh in (False, True):
+                    with options(ctx, chunk_frames=chunk):
+                        got, r = through_fd(data, msg, fresh)
+                    assert got == bytes(want["data"]), (len(data), msg and len(msg), chunk, fresh)
                 assert r["too_long"] == want["too_long"] and r["hide_offset"] == want["hide_offset"] and r["n_frames"] == want["n_frames"]
     s1 = ctx.run_stats()
     assert s1["reruns"] > s0["reruns"]                                               # some chunk was run again on its real carry
     assert through_fd(mp3, "y" * 400)[0] == orc.encode(orc.pcm_to_i16(orc.decode(mp3)["pcm"]), 44100, 128, np.array(mlib.message_frame("y" * 400)))["mp3"]
     # what the chunks do not take (a repeated last frame; mixed blocks without the file-wide arrays)
     tail = open(os.path.join(golden_dir, "test.mp3"), "rb").read() + b"\x00" * 700
-    assert through_fd(tail, "abc")[0] == bytes(ctx.hide_message(tail, "abc")["data"])
+    assert through_fd(tail, "abc", True)[0] == bytes(ctx.hide_message(tail, "abc")["data"])
     joint = frame_synth.make_stream(10, 80, mode=1, mode_ext=2, block_types=(0, 2), allow_mixed=True)
     with options(ctx, chunk_frames=16, file_up=0):
-        assert through_fd(joint, None)[0] == bytes(ctx.clear_file(joint)["data"])
+        assert through_fd(joint, None, True)[0] == bytes(ctx.clear_file(joint)["data"])
+    # a frame damaged in the last chunk: found on the device when that chunk comes down -- a file that held something is as it was
+    bad = bytearray(mp3)
+    refs = mlib.walk_stream(mp3)["refs"]
+    at = int(refs["file_off"][-3]) + 40
+    bad[at:at + 60] = b"\xff" * 60
+    bad = bytes(bad)
+    try:
+        want_bad = bytes(ctx.hide_message(bad, "abc")["data"])
+    except mlib.Mp3sError:
+        want_bad = None
+    out.write_bytes(b"kept" * 1000)
+    fd = os.open(str(out), os.O_WRONLY)
+    try:
+        with options(ctx, chunk_frames=64):
+            try:
+                r = ctx.recode_to_fd(bad, "abc", fd)
+                assert want_bad is not None and out.read_bytes() == want_bad and r["len"] == len(want_bad)
+            except mlib.Mp3sError:
+                assert want_bad is None and out.read_bytes() == b"kept" * 1000
+    finally:
+        os.close(fd)
+    # decode: the WAV into a file, fresh (chunk by chunk) or over something longer
+    wav_want = ctx.decode_file(mp3)
+    for fresh in (False, True):
+        out.write_bytes(b"" if fresh else b"\xbb" * (len(wav_want["data"]) + 999))
+        fd = os.open(str(out), os.O_WRONLY)
+        try:
+            with options(ctx, chunk_frames=64):
+                r = ctx.decode_file_to_fd(mp3, fd)
+        finally:
+            os.close(fd)
+        assert out.read_bytes() == bytes(wav_want["data"]) and np.array_equal(r["bits"], wav_want["bits"]) and r["kbps"] == wav_want["kbps"]
+    assert ctx.decode_file_to_fd(b"\x00" * 10, os.open(str(out), os.O_WRONLY))["n_frames"] == 0 and len(out.read_bytes()) == 44
     # a stream the call refuses: the error of the other entry point, and through the facade the output file is as it was
     mono = frame_synth.make_stream(8, 50, mode=3)
     fd = os.open(str(out), os.O_WRONLY)
