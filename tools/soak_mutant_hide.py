@@ -61,7 +61,9 @@ while time.time() < t_end:
             single = None
         # ... and the same call with its result written to a file descriptor (mp3s_*_fd: chunk by chunk), over something longer
         try:
-            os.lseek(sink_fd, 0, os.SEEK_SET); os.write(sink_fd, b"\xaa" * (len(f) + 4096))
+            os.ftruncate(sink_fd, 0)                                   # (an empty file is written chunk by chunk, one that holds something at the end)
+            if (seed + i) % 2:
+                os.lseek(sink_fd, 0, os.SEEK_SET); os.write(sink_fd, b"\xaa" * (len(f) + 4096))
             with mlib_options(ctx, 64 if seed % 5 == 0 else 0):
                 rf = ctx.recode_to_fd(f, msg, sink_fd)
             os.lseek(sink_fd, 0, os.SEEK_SET)
