@@ -259,10 +259,14 @@ __global__ __launch_bounds__(256, 4) void k_enc_mdct(
     const int ch = lane >> 5, band = lane & 31;
     const bool has_prev = f > (int)hdr[f].stream_first;   // l3_sb_sample[ch][0] starts zeroed
     const int32_t *row = SB + ((long)ch * Ts + (long)f * 36) * 32 + band;
+    // (the rows of the frame in front through an address that exists either way: compiled as an unconditional load + select -- as a
+    // fully unrolled variant of this kernel was in round 4 -- `row - 18 * 32` of a batch's first frame lies in front of the buffer)
+    const int32_t *prow = has_prev ? row - 18 * 32 : row;
     int32_t in[54];
 #pragma unroll
     for (int j = 0; j < 18; j++) {
-        in[j] = has_prev ? row[(j - 18) * 32] : 0;
+        const int32_t pv = prow[j * 32];
+        in[j] = has_prev ? pv : 0;
         in[18 + j] = row[j * 32];
         in[36 + j] = row[(18 + j) * 32];
     }
