@@ -145,7 +145,9 @@ int mp3s_ctx_wait(mp3s_ctx *ctx, mp3s_ctx *other);
                                     * formats are bit-identical to the reference [MP3S_FLOAT_FAST=1 -> 1] */
 #define MP3S_OPT_FAIL_CHUNK 14     /* test aid: the k-th chunk (k = value, counted from 1) of the next one-file call fails with MP3S_E_HIP after
                                     * its front end has been queued; the option clears itself when it fires */
-#define MP3S_OPT_COUNT 15
+#define MP3S_OPT_FUSED_DECODE 15   /* 1 (default): the fast decode paths (int16; float32 under MP3S_OPT_FLOAT_FAST) run IMDCT and synthesis as ONE kernel, the
+                                    * subband samples between them staying in LDS; 0: two kernels with the samples in device memory [MP3S_FUSED_DECODE=0 -> 0] */
+#define MP3S_OPT_COUNT 16
 /* what became of the one-file calls of this context (mp3s_hide_message, mp3s_clear_file, mp3s_decode_file, mp3s_decode_stream,
  * mp3s_hide_message_chunked): files that went through the overlapped stages as chunks, their chunks, chunks that were run
  * again because they depended on a carry the guess got wrong, chunks whose chains the host resolved, and files that took

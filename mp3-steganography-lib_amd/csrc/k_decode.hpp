@@ -99,7 +99,6 @@ __device__ __forceinline__ void dec_stage_tables(DecShared &sh)
     __syncthreads();
 }
 
-// requantise .. alias/reorder of granule g for this lane's subband; v[18] = IMDCT input
 // what a lane reads from memory for a granule: its dword of the two 72-byte side records (lanes 0..35) and the 18 int16 lines
 // of its subband (9 dwords).  Asked for one granule ahead (imdct_run): under the 18 rows of the granule in front.
 struct GranIn { uint32_t side; uint32_t xw[9]; };
@@ -115,8 +114,11 @@ __device__ __forceinline__ GranIn dec_fetch(const int16_t *__restrict__ is, cons
     return in;
 }
 
-__device__ __forceinline__ void dec_prepare(const DevTables &tab, DecShared &sh, int wave, double (&v)[18], const GranIn &in,
-                                            int sr, bool ms, int nch, int lane, int &bt_out)
+// requantise (Frame.py:157-218) and MS stereo (:561-572) of granule `in` for this lane's subband, lines in spectrum order.
+// SH: the kernel's shared block (side, exp2f, exp1f, pow2q, pow2h: DecShared here, FuShared in k_decode_fused.hpp)
+template <class SH>
+__device__ __forceinline__ void dec_requant_ms(const DevTables &tab, SH &sh, int wave, double (&v)[18], const GranIn &in,
+                                               int sr, bool ms, int nch, int lane, int &bt_out, int &cse_out)
 {
     const int ch = lane >> 5, sb = lane & 31;
     const bool live = ch < nch;
@@ -129,7 +131,7 @@ __device__ __forceinline__ void dec_prepare(const DevTables &tab, DecShared &sh,
     const int gg = gb[0], bt = gb[2] & 3, mixed = gb[3] ? 1 : 0;
     const int mult2 = gb[1] ? 2 : 1, preflag = gb[4] ? 1 : 0;
     const int cse = bt == 2 ? 1 : (mixed ? 2 : 0);
-    bt_out = bt;
+    bt_out = bt; cse_out = cse;
     // ---- 18 int16 spectrum values (9 dwords) and 18 line-map bytes (5 dwords) of this subband
     uint32_t mw[5];
     const uint32_t (&xw)[9] = in.xw;
@@ -190,6 +192,15 @@ __device__ __forceinline__ void dec_prepare(const DevTables &tab, DecShared &sh,
             v[k] = ch == 0 ? (v[k] + o) / tab.sqrt2 : (o - v[k]) / tab.sqrt2;
         }
     }
+}
+
+// requantise .. alias/reorder of granule g for this lane's subband; v[18] = IMDCT input
+__device__ __forceinline__ void dec_prepare(const DevTables &tab, DecShared &sh, int wave, double (&v)[18], const GranIn &in,
+                                            int sr, bool ms, int nch, int lane, int &bt_out)
+{
+    const int ch = lane >> 5, sb = lane & 31;
+    int cse;
+    dec_requant_ms(tab, sh, wave, v, in, sr, ms, nch, lane, bt_out, cse);
     // ---- reorder (short / mixed) or alias reduction (long) through the wave's LDS slice
     double *buf = sh.buf[wave][ch];
 #pragma unroll
@@ -711,53 +722,32 @@ __device__ __forceinline__ double synth_dot(const double (&d)[N], const SynthRow
 // F32 (MP3S_OPT_FLOAT_FAST): float32 output of the same sums, no guard and no fix-up -- the fast sums differ from the reference's
 // by a few 1e-14 of the slot's magnitude, the format's own rounding is 6e-8 of the sample and the contract's tolerance 1e-5;
 // a sample goes straight to its place (no tile: 64 floats per slot would double the kernel's LDS).
-template <int TW, bool F32 = false>
-__global__ __launch_bounds__(TW * 64 * 2, TW == 4 ? 2 : 4) void k_dec_synth_fast(
-    const double *__restrict__ S, long T, const mp3s_frame_hdr *__restrict__ hdr, int nch, int n_halo,
-    int16_t *__restrict__ pcm_out, int sf_base, double eps_scale, const double *__restrict__ G, int n_granules,
-    uint2 *__restrict__ fix_list, int32_t *__restrict__ fix_count)
+//
+// synth_fast_tile: a workgroup's tile of TW * 64 slot lanes per channel (the first 15 rebuild V history, OUT of the others emit) from the
+// lanes' rows Sv[32] on -- shared by k_dec_synth_fast (rows from S in HBM) and k_dec_fused (rows from the workgroup's own IMDCT in LDS).
+//   lds_raw : SynthFastLds<TW, OUT>::BYTES of LDS that nothing else uses from this call's first barrier on (ex | otile)
+//   amax_w  : TW * 2 doubles of LDS;  gmax_s: the largest G of the granules the tile reads, written in front of this call
+template <int TW, int OUT>
+struct SynthFastLds {
+    static constexpr int TL_LANES = TW * 64, OROW = 33;
+    // ex[2][2][4][TL_LANES] doubles | otile[(OUT + 1) * OROW] dwords (+ one row nobody reads: where the lanes that do not emit put their samples)
+    static constexpr int EX_BYTES = 2 * 2 * 4 * TL_LANES * 8, OT_BYTES = (OUT + 1) * OROW * 4, BYTES = EX_BYTES + OT_BYTES;
+};
+template <int TW, bool F32, int OUT, bool DEEP = false>
+__device__ __forceinline__ void synth_fast_tile(unsigned char *lds_raw, double *amax_w, const double *gmax_p, double (&Sv)[32], long T, long tile0,
+                                                long t, int tl, int ch, int wave, int lane, bool valid, int lim, int nch, int n_halo,
+                                                int16_t *__restrict__ pcm_out, double eps_scale, uint2 *__restrict__ fix_list,
+                                                int32_t *__restrict__ fix_count)
 {
-    constexpr int TL_LANES = TW * 64, OUT = TL_LANES - 15;
-    constexpr int OROW = 33;
-    // one block of LDS: ex[2][2][4][TL_LANES] doubles | otile[(OUT + 1) * OROW] dwords (+ one row nobody reads: where the lanes that do not
-    // emit put their samples); in front of the loop the same bytes stage the waves' rows of S (below)
-    constexpr int EX_BYTES = 2 * 2 * 4 * TL_LANES * 8, OT_BYTES = (OUT + 1) * OROW * 4;
-    static_assert(TW * 2 * SYNTH_STAGE_WAVE <= EX_BYTES + OT_BYTES, "the staging of S fits the loop's LDS");
-    __shared__ __attribute__((aligned(16))) unsigned char lds_raw[EX_BYTES + OT_BYTES];
+    constexpr int TL_LANES = TW * 64, OROW = SynthFastLds<TW, OUT>::OROW, EX_BYTES = SynthFastLds<TW, OUT>::EX_BYTES;
+    static_assert(OUT <= TL_LANES - 15, "the first 15 lanes of a tile only rebuild V history");
     double (*const ex)[2][4][TL_LANES] = reinterpret_cast<double (*)[2][4][TL_LANES]>(lds_raw);
     uint32_t *const otile = reinterpret_cast<uint32_t *>(lds_raw + EX_BYTES);
-    __shared__ double amax_w[TW * 2];
-    __shared__ double gmax_s;
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
-    const int ch = wave / TW, tl = (wave % TW) * 64 + lane;
-    const long tile0 = (long)xcd_tile() * OUT;
-    if (wave == 0) {
-        // the largest G (sum of |IMDCT input| of a granule and channel, left behind by the fast IMDCT) among the granules
-        // whose rows this tile reads and the granule in front of them (its overlap tail is part of their rows)
-        const long tlo = tile0 - 15 > 0 ? tile0 - 15 : 0, thi = tile0 + OUT - 1 < T - 1 ? tile0 + OUT - 1 : T - 1;
-        const int ga = (int)(tlo / 18) > 0 ? (int)(tlo / 18) - 1 : 0, gb = (int)(thi / 18);
-        static_assert((TW * 64 + 17) / 18 + 2 <= 32, "one lane pair per granule of the tile");
-        const int g = ga + (lane >> 1), c = lane & 1;
-        double gm = 0.0;
-        if (G && g <= gb && g < n_granules && c < nch) gm = G[(long)g * 2 + c];
-        gm = wave_max_bound_f64(gm);
-        if (lane == 0) gmax_s = gm;
-    }
-    const long t = tile0 - 15 + tl;
-    const bool valid = t >= 0 && t < T;
-    int lim = -1;
-    if (valid) {
-        const uint32_t sf = hdr[t / 36].stream_first;
-        const long s0 = sf > (uint32_t)sf_base ? (long)(sf - (uint32_t)sf_base) * 36 : 0;
-        lim = (int)((t - s0) < 64 ? (t - s0) : 64);
-    }
     // ---- the differences of the splitting, level by level: X[k] of odd k is a 16-term sum over d16, of k = 2 mod 4 an
     //      8-term sum over d8, k = 4 mod 8: d4, k = 8 mod 16: d2, and X[16] = (u2[0] - u2[1]) cos(pi/4), X[0] = u2[0] + u2[1]
     double d16[16], d8v[8], d4[4], d2[2], x0, x16;
     double asum = 0.0;
     {
-        double Sv[32];
-        synth_fetch_rows(lds_raw + wave * SYNTH_STAGE_WAVE, S, T, ch, t, lane, Sv);
 #pragma unroll
         for (int j = 0; j < 32; j++) asum += fabs(Sv[j]);
         double u16[16], u8[8], u4[4], u2[2];
@@ -785,12 +775,12 @@ __global__ __launch_bounds__(TW * 64 * 2, TW == 4 ? 2 : 4) void k_dec_synth_fast
     // that grows with the sample (eps_x |x|: 3 % of the other at most) is taken at that bound instead of per sample; a tile
     // whose bound leaves int32 (noise from a damaged file; NaN) goes to the exact path as a whole.
     const double xb_v = c_tab.synth_xbound * amax;
-    const double eg_v = (c_tab.synth_eps_a * amax + c_tab.synth_eps_g * gmax_s + c_tab.synth_eps_x * xb_v) * eps_scale;
+    const double eg_v = (c_tab.synth_eps_a * amax + c_tab.synth_eps_g * *gmax_p + c_tab.synth_eps_x * xb_v) * eps_scale;
     const double eps_t = __hiloint2double(__builtin_amdgcn_readfirstlane(__double2hiint(eg_v)), __builtin_amdgcn_readfirstlane(__double2loint(eg_v)));
     const bool safe = __builtin_amdgcn_readfirstlane((int)(xb_v < 2147483000.0)) != 0;
     const long halo_slots = (long)n_halo * 36;
-    const bool emit = valid && tl >= 15 && t >= halo_slots;
-    const bool full_hist = __ballot(tl >= 15 && lim < 15) == 0;
+    const bool emit = valid && tl >= 15 && tl < 15 + OUT && t >= halo_slots;
+    const bool full_hist = __ballot(tl >= 15 && tl < 15 + OUT && lim < 15) == 0;
     uint16_t *ot16 = reinterpret_cast<uint16_t *>(otile);
     unsigned long long dmask = 0;                               // lanes with a sample the guard cannot vouch for
     int p = 0;
@@ -902,6 +892,48 @@ __global__ __launch_bounds__(TW * 64 * 2, TW == 4 ? 2 : 4) void k_dec_synth_fast
         ex[p][ch][2][tl] = va1;
         ex[p][ch][3][tl] = vb1;
         __syncthreads();                                        // (its wait covers the taps asked for above)
+        if constexpr (DEEP) {
+            // (k_dec_fused: two waves per SIMD, nobody to run under a wait.)  The V values of a step are asked for a step AHEAD, with
+            // the next piece of constants: what a step's wait at its top is for has had the step in front of it, sixteen
+            // multiply-adds, to arrive -- only the first read of an interval, which cannot go out in front of the barrier, is waited
+            // for in full.  Two sets of eight V values, 32 registers (this kernel has them).
+            double ua[8], ub[8];
+            if (tt == 0) {
+                window_read(0, 0, 0, ua);
+                MP3S_ARRIVED(); nxt = ld16(q + 64); window_read(0, 0, 1, ub); MP3S_GO();
+                double sum = dot8(ua, cur.lo, 0.0); MP3S_GO();
+                MP3S_ARRIVED(); window_read(1, 1, 0, ua); MP3S_GO();
+                sum = dot8(ub, cur.hi, sum);
+                window_emit(oa, sum); MP3S_GO();
+                cur = nxt;
+                MP3S_ARRIVED(); nxt = ld16(q + 80); window_read(1, 1, 1, ub); MP3S_GO();
+                sum = dot8(ua, cur.lo, 0.0); MP3S_GO();
+                MP3S_ARRIVED(); window_read(2, 3, 0, ua); MP3S_GO();
+                sum = dot8(ub, cur.hi, sum);
+                window_emit(ob, sum); MP3S_GO();
+                cur = nxt;
+            } else {
+                window_read(0, 1, 0, ua);
+                MP3S_ARRIVED(); nxt = ld16(q + 64); window_read(0, 1, 1, ub); MP3S_GO();
+                double sa = dot8(ua, cur.lo, 0.0), sb = dot8(ua, cur.hi, 0.0); MP3S_GO();
+                cur = nxt;
+                MP3S_ARRIVED(); nxt = ld16(q + 80); window_read(2, 3, 0, ua); MP3S_GO();
+                sa = dot8(ub, cur.lo, sa);
+                window_emit(oa, sa);
+                sb = dot8(ub, cur.hi, sb);
+                window_emit(ob, sb); MP3S_GO();
+                cur = nxt;
+            }
+            MP3S_ARRIVED(); nxt = ld16(q + 96); window_read(2, 3, 1, ub); MP3S_GO();
+            double sc = dot8(ua, cur.lo, 0.0), sd = dot8(ua, cur.hi, 0.0); MP3S_GO();
+            cur = nxt;
+            MP3S_ARRIVED(); nxt = ld16(ct + (tt == 7 ? 0 : tt + 1) * 112); MP3S_GO();
+            sc = dot8(ub, cur.lo, sc);
+            window_emit(oc, sc);
+            sd = dot8(ub, cur.hi, sd);
+            window_emit(od, sd); MP3S_GO();
+            cur = nxt;
+        } else {
         double u[8];
         // ---- eight taps of two outputs at a time: V values from LDS, wait (for them and for the piece asked for a step earlier), ask
         //      for the next piece, multiply
@@ -950,6 +982,7 @@ __global__ __launch_bounds__(TW * 64 * 2, TW == 4 ? 2 : 4) void k_dec_synth_fast
             window_emit(od, sd); MP3S_GO();
             cur = nxt;
         }
+        }
         p ^= 1;
     }
 #undef MP3S_ARRIVED
@@ -982,6 +1015,47 @@ __global__ __launch_bounds__(TW * 64 * 2, TW == 4 ? 2 : 4) void k_dec_synth_fast
             outp[obase + c] = v;
         }
     }
+}
+
+template <int TW, bool F32 = false>
+__global__ __launch_bounds__(TW * 64 * 2, TW == 4 ? 2 : 4) void k_dec_synth_fast(
+    const double *__restrict__ S, long T, const mp3s_frame_hdr *__restrict__ hdr, int nch, int n_halo,
+    int16_t *__restrict__ pcm_out, int sf_base, double eps_scale, const double *__restrict__ G, int n_granules,
+    uint2 *__restrict__ fix_list, int32_t *__restrict__ fix_count)
+{
+    constexpr int TL_LANES = TW * 64, OUT = TL_LANES - 15;
+    // in front of the tile's loop its LDS stages the waves' rows of S (synth_fetch_rows)
+    static_assert(TW * 2 * SYNTH_STAGE_WAVE <= SynthFastLds<TW, OUT>::BYTES, "the staging of S fits the loop's LDS");
+    __shared__ __attribute__((aligned(16))) unsigned char lds_raw[SynthFastLds<TW, OUT>::BYTES];
+    __shared__ double amax_w[TW * 2];
+    __shared__ double gmax_s;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+    const int ch = wave / TW, tl = (wave % TW) * 64 + lane;
+    const long tile0 = (long)xcd_tile() * OUT;
+    if (wave == 0) {
+        // the largest G (sum of |IMDCT input| of a granule and channel, left behind by the fast IMDCT) among the granules
+        // whose rows this tile reads and the granule in front of them (its overlap tail is part of their rows)
+        const long tlo = tile0 - 15 > 0 ? tile0 - 15 : 0, thi = tile0 + OUT - 1 < T - 1 ? tile0 + OUT - 1 : T - 1;
+        const int ga = (int)(tlo / 18) > 0 ? (int)(tlo / 18) - 1 : 0, gb = (int)(thi / 18);
+        static_assert((TW * 64 + 17) / 18 + 2 <= 32, "one lane pair per granule of the tile");
+        const int g = ga + (lane >> 1), c = lane & 1;
+        double gm = 0.0;
+        if (G && g <= gb && g < n_granules && c < nch) gm = G[(long)g * 2 + c];
+        gm = wave_max_bound_f64(gm);
+        if (lane == 0) gmax_s = gm;
+    }
+    const long t = tile0 - 15 + tl;
+    const bool valid = t >= 0 && t < T;
+    int lim = -1;
+    if (valid) {
+        const uint32_t sf = hdr[t / 36].stream_first;
+        const long s0 = sf > (uint32_t)sf_base ? (long)(sf - (uint32_t)sf_base) * 36 : 0;
+        lim = (int)((t - s0) < 64 ? (t - s0) : 64);
+    }
+    double Sv[32];
+    synth_fetch_rows(lds_raw + wave * SYNTH_STAGE_WAVE, S, T, ch, t, lane, Sv);
+    synth_fast_tile<TW, F32, OUT>(lds_raw, amax_w, &gmax_s, Sv, T, tile0, t, tl, ch, wave, lane, valid, lim, nch, n_halo, pcm_out, eps_scale,
+                                  fix_list, fix_count);
 }
 
 

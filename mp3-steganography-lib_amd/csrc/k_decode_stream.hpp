@@ -1,0 +1,382 @@
+// The fast decode transform as ONE wave-local stream (int16 output behind the guard; float32 with MP3S_OPT_FLOAT_FAST):
+// requantise -> MS stereo -> reorder | alias reduction -> IMDCT + window + overlap-add -> frequency inversion -> polyphase synthesis ->
+// PCM, reference decoder/Frame.py:157-218, 561-631, 106-154, 65-103, 633-640 and MP3_Parser.py:91.  Included by mp3s_device.hip behind
+// k_decode.hpp (dec_fetch, dec_requant_ms, load_row18s, dpp_f64, xcd_tile).
+//
+// The reference runs imdct -> __frequency_inversion -> synth_filter_bank on one array (Frame.py:282-284).  Here that array never exists:
+// a wave walks `run` consecutive granules with lane = (channel, subband) from the first stage to the last, and what the stages hand to
+// each other stays in the wave's registers.
+//   * IMDCT as in k_dec_imdct<true>: 18 lines per lane, twiddle rows as scalar operands, the mirrored rows by sign, fused multiply-adds;
+//     the overlap tail of a granule waits for the next one in the wave's own 9 KB of LDS.  Its 18 outputs are the subband's samples of
+//     the granule's 18 time slots: S[p], one register pair per slot.
+//   * Matrixing of slot p ACROSS the lanes: X[k] = sum_j S[j] cos((2j+1) k pi/64) = sum_{j<16} (S[j] -+ S[31-j]) cos(..) (k odd: the
+//     differences, k even: the sums).  A lane gets its mirror subband's sample by ds_swizzle (xor 31), forms its difference (subbands
+//     0..15: DPP row 0 / 2 of the wave) or sum (16..31: row 1 / 3), and every lane of a row sums 16 products of ITS row's 16 values with
+//     its own 16 cosines: v_fmac_f64 with DPP row_newbcast:j takes the value of lane j of the row as the multiplicand -- sixteen
+//     instructions give the 32 X of both channels.  (tools/ubench/dpp64.hip: the DPP form issues at the plain v_fma_f64's rate.)
+//   * V[i] = X[16+i] (i <= 16, X[32] = 0), -X[48-i] (17..47), -X[i-48] (48..63): lane (ch, i) fetches A = V[i] and B = V[32+i] from the
+//     lanes that hold them (ds_bpermute), signs and the zero live in its taps.
+//   * Window: output i of slot t is sum_jj D[i + 32 jj] * (jj even ? A : B)(slot t - jj) (Frame.py:89-101).  Instead of keeping 16 slots of
+//     V history, a slot's A and B are added into the sums of the 16 outputs they belong to as they arrive: 18 running sums per lane, indexed
+//     by the slot's place in its granule (p + jj) mod 18 -- compile-time indices, since a granule is 18 slots; the sum of slot p is complete
+//     when slot p adds its own term and leaves as the PCM sample of (slot, channel, i): a wave stores 128 contiguous bytes per slot.
+// Nothing is exchanged between waves: no workgroup barrier behind the staging of the small tables, no LDS for data beyond the tail, no
+// device-memory scratch.  A run is primed with the granule in front of it (IMDCT + synthesis without output: the 15 slots of history)
+// and the tail of the one before that.
+//
+// The sums are not the reference's bit patterns (mirrored, fused, other order): the int16 format keeps its promise -- (pcm * 32767)
+// truncated exactly as the reference truncates it -- through the guard of DESIGN.md section 2, whose bound covers these sums (at most one
+// addition in front of a product, a cosine off by <= 2u, 16 products summed in turn: below the gamma_24 the bound grants the matrixing;
+// the 16-tap sum in any order).  The guard's scale A_max (largest sum |S| of a slot) is taken from above here: a slot's sum |S| is at
+// most G(its granule) + G(the granule in front), G = sum of |IMDCT input| per granule and channel, so 2 max(G of the three granules a
+// window sum can reach) stands for A_max and the same maximum for G_max.  A sample the guard cannot vouch for puts (slot, channel, bit i)
+// on the fix-up list; k_dec_fixup computes it again from `is` in the reference's order.
+#pragma once
+
+namespace mp3s {
+
+constexpr int ST_WAVES = 4;                 // waves per workgroup; they share the staged tables and nothing else
+
+struct StShared {
+    double pow2q[POW2Q_N];                  // (as DecShared: random per-lane reads go to LDS)
+    double pow2h[POW2H_N];
+    uint32_t side[ST_WAVES][2][18];         // per wave: the two 72-byte side records of the current granule
+    double exp2f[ST_WAVES][2][64];          // per wave and channel: 2^(-exp2) per scalefactor slot of the current granule
+    double exp1f[ST_WAVES][2][4];           // ... and 2^(exp1/4) per gain selector
+    double win[4][36];                      // sine_block
+    double tail[ST_WAVES][18][64];          // per wave: the overlap tail of the granule before, [row][lane]
+};
+
+// One line of channel c of granule g, requantised as dec_requant_ms does it (Frame.py:210-215), for a lane that needs it out of order
+// (the reordered lines of a short / mixed granule): is and the line map from memory, the exponent factors of channel c from the wave's tables.
+__device__ __forceinline__ double st_requant_line(const DevTables &tab, StShared &sh, int wave, const int16_t *__restrict__ is, int g, int c, int sr, int s)
+{
+    const uint8_t *gb = reinterpret_cast<const uint8_t *>(sh.side[wave][c]);
+    const int bt = gb[2] & 3, mixed = gb[3] ? 1 : 0;
+    const int cse = bt == 2 ? 1 : (mixed ? 2 : 0);
+    const int sbs = (s * 3641) >> 16;                                   // s / 18 (s < 576)
+    const uint32_t m = tab.rq_map[sr][cse][sbs][s - 18 * sbs];
+    const int x = is[((long)g * 2 + c) * 576 + s];
+    uint32_t ax = (uint32_t)(x < 0 ? -x : x);
+    ax = ax < (uint32_t)POW43_N ? ax : (uint32_t)(POW43_N - 1);
+    const double a = tab.pow43[ax];
+    const double sa = x < 0 ? -a : a;
+    return (sa * sh.exp1f[wave][c][m >> 6]) * sh.exp2f[wave][c][m & 63];
+}
+
+// X of this lane: sum_j (value of lane j of this lane's DPP row) * c[j], fused multiply-adds in turn.  One block: the compiler does not
+// know the DPP hazard (a vector write of `t` needs two wait states before a DPP read, a write of EXEC five) behind inline assembly, so the s_nop is in it.
+__device__ __forceinline__ double st_row_dot16(double t, const double (&c)[16])
+{
+    double x = 0.0;
+    asm("s_nop 4\n\t"
+        "v_fmac_f64_dpp %0, %1, %2 row_newbcast:0 row_mask:0xf bank_mask:0xf\n\t"
+        "v_fmac_f64_dpp %0, %1, %3 row_newbcast:1 row_mask:0xf bank_mask:0xf\n\t"
+        "v_fmac_f64_dpp %0, %1, %4 row_newbcast:2 row_mask:0xf bank_mask:0xf\n\t"
+        "v_fmac_f64_dpp %0, %1, %5 row_newbcast:3 row_mask:0xf bank_mask:0xf\n\t"
+        "v_fmac_f64_dpp %0, %1, %6 row_newbcast:4 row_mask:0xf bank_mask:0xf\n\t"
+        "v_fmac_f64_dpp %0, %1, %7 row_newbcast:5 row_mask:0xf bank_mask:0xf\n\t"
+        "v_fmac_f64_dpp %0, %1, %8 row_newbcast:6 row_mask:0xf bank_mask:0xf\n\t"
+        "v_fmac_f64_dpp %0, %1, %9 row_newbcast:7 row_mask:0xf bank_mask:0xf\n\t"
+        "v_fmac_f64_dpp %0, %1, %10 row_newbcast:8 row_mask:0xf bank_mask:0xf\n\t"
+        "v_fmac_f64_dpp %0, %1, %11 row_newbcast:9 row_mask:0xf bank_mask:0xf\n\t"
+        "v_fmac_f64_dpp %0, %1, %12 row_newbcast:10 row_mask:0xf bank_mask:0xf\n\t"
+        "v_fmac_f64_dpp %0, %1, %13 row_newbcast:11 row_mask:0xf bank_mask:0xf\n\t"
+        "v_fmac_f64_dpp %0, %1, %14 row_newbcast:12 row_mask:0xf bank_mask:0xf\n\t"
+        "v_fmac_f64_dpp %0, %1, %15 row_newbcast:13 row_mask:0xf bank_mask:0xf\n\t"
+        "v_fmac_f64_dpp %0, %1, %16 row_newbcast:14 row_mask:0xf bank_mask:0xf\n\t"
+        "v_fmac_f64_dpp %0, %1, %17 row_newbcast:15 row_mask:0xf bank_mask:0xf"
+        : "+v"(x)
+        : "v"(t), "v"(c[0]), "v"(c[1]), "v"(c[2]), "v"(c[3]), "v"(c[4]), "v"(c[5]), "v"(c[6]), "v"(c[7]), "v"(c[8]), "v"(c[9]), "v"(c[10]),
+          "v"(c[11]), "v"(c[12]), "v"(c[13]), "v"(c[14]), "v"(c[15]));
+    return x;
+}
+
+template <int NCH, bool F32>
+__global__ __launch_bounds__(ST_WAVES * 64, 2) void k_dec_stream(
+    const int16_t *__restrict__ is, const mp3s_granule_si *__restrict__ si, const mp3s_frame_hdr *__restrict__ hdr,
+    int n_granules, int run, int n_halo, void *__restrict__ pcm_out, int sf_base, double eps_scale,
+    uint2 *__restrict__ fix_list, int32_t *__restrict__ fix_count)
+{
+    __shared__ StShared sh;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+    for (int i = threadIdx.x; i < POW2Q_N; i += blockDim.x) sh.pow2q[i] = c_tab.pow2q[i];
+    if (threadIdx.x < POW2H_N) sh.pow2h[threadIdx.x] = c_tab.pow2h[threadIdx.x];
+    if (threadIdx.x < 144) (&sh.win[0][0])[threadIdx.x] = (&c_tab.sine_block[0][0])[threadIdx.x];
+    __syncthreads();
+    const int ga = (xcd_tile() * ST_WAVES + wave) * run;       // this wave's granules: ga .. ga + run - 1
+    if (ga >= n_granules) return;                                // (whole waves; no barrier behind this line)
+
+    const int ch = lane >> 5, sb = lane & 31;
+    const bool live = ch < NCH;
+    const uint32_t sgn_odd = (sb & 1) ? 0x80000000u : 0u;       // frequency inversion (Frame.py:629-631): odd slots of odd subbands
+    auto flip = [&](double x) { return __hiloint2double(__double2hiint(x) ^ (int)sgn_odd, __double2loint(x)); };
+    // ---- the lane's constants of the synthesis: its 16 cosines (as the holder of X[k]: k = 2 (sb & 15) + 1 in the rows of the
+    //      differences, 2 (sb & 15) in the rows of the sums), its 16 taps (as output i = sb), where its A and B come from
+    double cx[16], wt[16];
+#pragma unroll
+    for (int j = 0; j < 16; j++) { cx[j] = c_tab.stream_cx[sb][j]; wt[j] = c_tab.stream_taps[F32 ? 0 : 1][sb][j]; }
+    int addr_a, addr_b;
+    {
+        const int ka = sb <= 15 ? 16 + sb : (sb == 16 ? 0 : 48 - sb);        // A = V[i]: X[16+i] | 0 (tap) | -X[48-i]
+        const int kb = sb <= 15 ? 16 - sb : sb - 16;                         // B = V[32+i]: -X[16-i] | -X[i-16]
+        auto holder = [&](int k) { return (ch << 5) + ((k & 1) ? (k >> 1) : 16 + (k >> 1)); };
+        addr_a = holder(ka) * 4; addr_b = holder(kb) * 4;
+    }
+    const uint32_t sgn_lo = sb < 16 ? 0x80000000u : 0u;         // subbands 0..15 form S - mirror, 16..31 S + mirror
+    // the guard's width per unit of the largest G in reach (header comment); F32 has no guard
+    const double eps_k = (2.0 * c_tab.synth_eps_a + c_tab.synth_eps_g + 2.0 * c_tab.synth_eps_x * c_tab.synth_xbound) * eps_scale;
+    const double xb_k = 2.0 * c_tab.synth_xbound;
+    const long halo_slots = (long)n_halo * 36;
+    typedef double __attribute__((address_space(3))) lds_f64;
+    lds_f64 *const tl = (lds_f64 *)reinterpret_cast<double *>(&sh.tail[wave][0][lane]);   // row r of the tail at tl[r * 64]
+
+    double acc[18];
+#pragma unroll
+    for (int i = 0; i < 18; i++) acc[i] = 0.0;
+    double gm1 = 0.0, gm2 = 0.0;                                // G of the two granules in front (this lane's channel)
+    // the stream the run starts in begins at granule s_a of the launch: nothing in front of it primes the run
+    const int s_a = [&] { const uint32_t sf = hdr[ga >> 1].stream_first; return sf > (uint32_t)sf_base ? (int)(sf - (uint32_t)sf_base) * 2 : 0; }();
+    bool fresh = true;                                          // the tail in LDS and the running sums are to be cleared before the next granule
+    GranIn next_in = {};
+    bool have_next = false;
+
+#pragma unroll 1
+    for (int gi = -2; gi < run; gi++) {
+        const int g = ga + gi;
+        if (g >= n_granules) break;
+        if (g < 0 || (gi < 0 && g < s_a)) continue;
+        const mp3s_frame_hdr fh = hdr[g >> 1];
+        const int first_gran = fh.stream_first > (uint32_t)sf_base ? (int)(fh.stream_first - (uint32_t)sf_base) * 2 : 0;
+        if (g == first_gran) fresh = true;                      // Frame.py:234-235: prev_samples and the fifo start as zeros
+        if (fresh) {
+#pragma unroll
+            for (int i = 0; i < 18; i++) { tl[i * 64] = 0.0; acc[i] = 0.0; }
+            gm1 = gm2 = 0.0;
+            fresh = false;
+        }
+        const bool tail_only = gi == -2;                        // two granules in front of the run: only its overlap tail is needed
+        const bool emit = gi >= 0;
+        const int sr = fh.sr_idx < 3 ? fh.sr_idx : 0;
+        const bool ms = fh.ms_stereo != 0;
+        // the twiddle tables are invariant over this loop: an opaque zero offset per granule keeps their scalar loads inside it (k_dec_imdct)
+        int zoff = 0;
+        asm volatile("" : "+s"(zoff));
+        const DevTables &tab = *reinterpret_cast<const DevTables *>(reinterpret_cast<const char *>(&c_tab) + zoff);
+        const double(*C36)[18] = tab.imdct_cos36;
+        const double(*C12)[6] = tab.imdct_cos12;
+
+        // ---- requantise, MS stereo (dec_requant_ms), then reorder | alias reduction without an exchange buffer
+        double v[18];
+        int bt, cse;
+        const GranIn in = have_next ? next_in : dec_fetch(is, si, g, NCH, lane);
+        dec_requant_ms(tab, sh, wave, v, in, sr, ms, NCH, lane, bt, cse);
+        have_next = gi + 1 < run && g + 1 < n_granules;
+        if (have_next) next_in = dec_fetch(is, si, g + 1, NCH, lane);
+        if (cse != 0) {
+            // reorder (Frame.py:574-602) of a short / mixed granule: line k of this subband is line src of the spectrum (or nothing),
+            // computed again from `is` -- requantised and, under MS stereo, combined with the other channel's line src
+            const uint32_t *srcw = reinterpret_cast<const uint32_t *>(tab.reorder_src[sr] + sb * 18);
+            uint32_t sw[9];
+#pragma unroll
+            for (int k = 0; k < 9; k++) sw[k] = srcw[k];
+#pragma unroll
+            for (int k = 0; k < 18; k++) {
+                const int s = (int)(int16_t)(sw[k >> 1] >> ((k & 1) * 16));
+                double x = 0.0;
+                if (s >= 0 && live) {
+                    x = st_requant_line(tab, sh, wave, is, g, ch, sr, s);
+                    if (ms && NCH == 2) {
+                        const double o = st_requant_line(tab, sh, wave, is, g, ch ^ 1, sr, s);
+                        x = ch == 0 ? (x + o) / tab.sqrt2 : (o - x) / tab.sqrt2;
+                    }
+                }
+                v[k] = x;
+            }
+        } else {
+            // alias reduction (Frame.py:604-622): butterflies with line 17 - i of subband sb - 1 and line i of subband sb + 1, the
+            // neighbours' lines by DPP wave shifts (both read before either is changed); the edge subbands keep their value
+#pragma unroll
+            for (int i = 0; i < 8; i++) {
+                const double nlo = dpp_f64<0x138>(v[17 - i]);   // wave_shr:1 = lane - 1's
+                const double nhi = dpp_f64<0x130>(v[i]);        // wave_shl:1 = lane + 1's
+                const double cs = tab.alias_cs[i], ca = tab.alias_ca[i];
+                const double lo = v[i] * cs + nlo * ca;
+                const double hi = v[17 - i] * cs - nhi * ca;
+                v[i] = sb >= 1 ? lo : v[i];
+                v[17 - i] = sb <= 30 ? hi : v[17 - i];
+            }
+        }
+        // ---- G of this granule and channel: sum over the channel's subbands of sum_k |v[k]|; the guard's width for its slots
+        double eps_t = 0.0;
+        bool safe = true;
+        if (!F32) {
+            double s = 0.0;
+#pragma unroll
+            for (int k = 0; k < 18; k++) s += fabs(v[k]);
+            s += dpp_f64<0xB1>(s);                              // quad_perm [1, 0, 3, 2]
+            s += dpp_f64<0x4E>(s);                              // quad_perm [2, 3, 0, 1]
+            s += dpp_f64<0x141>(s);                             // row_half_mirror
+            s += dpp_f64<0x140>(s);                             // row_mirror: the sum of the lane's row of 16
+            const double o = __hiloint2double(__builtin_amdgcn_ds_swizzle(__double2hiint(s), 0x401f), __builtin_amdgcn_ds_swizzle(__double2loint(s), 0x401f));   // xor 16: the channel's other row
+            const double gc = s + o;
+            double gx = gc > gm1 ? gc : gm1;
+            gx = gx > gm2 ? gx : gm2;
+            if (!(gx >= 0.0)) gx = __builtin_inf();             // NaN: nothing is safe
+            eps_t = eps_k * gx;
+            safe = __ballot(!(xb_k * gx < 2147483000.0)) == 0;  // (beyond int32 the kernel's conversion and the reference's wrapping one differ)
+            gm2 = gm1; gm1 = gc;
+        }
+
+        double S[18];
+        if (bt != 2) {
+            // ---- long windows: rows 0..8 and their mirrors 17..9 (x[17-i] = -x[i]), then rows 18..26 and their mirrors 35..27; a row's
+            //      twiddles (scalar cache), window factors and tail values (LDS) are asked for one row ahead, the wait for them at the
+            //      TOP of a row, in front of the next request (k_dec_imdct)
+            const double *wl = sh.win[bt];
+            Row18s cur;
+            double wa, wb;
+            if (!tail_only) {
+                cur = load_row18s(C36, 0);
+                wa = wl[0]; wb = wl[17];
+                double ta = tl[0], tb = tl[17 * 64];
+#pragma unroll
+                for (int i = 0; i < 9; i++) {
+                    __builtin_amdgcn_s_waitcnt(0xc07f);
+                    __builtin_amdgcn_sched_barrier(0);
+                    const int in2 = i < 8 ? i + 1 : 18;                         // (behind row 8: the first row of the second half)
+                    const Row18s nxt = load_row18s(C36, in2);
+                    const double nwa = wl[in2], nwb = wl[in2 < 18 ? 17 - in2 : 35];
+                    const double nta = in2 < 18 ? (double)tl[in2 * 64] : 0.0, ntb = in2 < 18 ? (double)tl[(17 - in2) * 64] : 0.0;
+                    __builtin_amdgcn_sched_barrier(0);
+                    double y = 0.0;
+#pragma unroll
+                    for (int k = 0; k < 18; k++) y = __builtin_fma(v[k], k < 8 ? cur.a[k & 7] : (k < 16 ? cur.b[k & 7] : cur.c[k & 1]), y);
+                    double xa = y * wa + ta;
+                    double xb = -y * wb + tb;
+                    if (i & 1) xa = flip(xa);
+                    if ((17 - i) & 1) xb = flip(xb);
+                    S[i] = xa; S[17 - i] = xb;
+                    __builtin_amdgcn_sched_barrier(0);
+                    cur = nxt; wa = nwa; wb = nwb; ta = nta; tb = ntb;
+                }
+            } else {
+                cur = load_row18s(C36, 18);
+                wa = wl[18]; wb = wl[35];
+            }
+#pragma unroll
+            for (int i = 18; i < 27; i++) {
+                __builtin_amdgcn_s_waitcnt(0xc07f);
+                __builtin_amdgcn_sched_barrier(0);
+                const int in2 = i < 26 ? i + 1 : 26;
+                const Row18s nxt = load_row18s(C36, in2);
+                const double nwa = wl[in2], nwb = wl[53 - in2];
+                __builtin_amdgcn_sched_barrier(0);
+                double y = 0.0;
+#pragma unroll
+                for (int k = 0; k < 18; k++) y = __builtin_fma(v[k], k < 8 ? cur.a[k & 7] : (k < 16 ? cur.b[k & 7] : cur.c[k & 1]), y);
+                tl[(i - 18) * 64] = y * wa;
+                tl[(35 - i) * 64] = y * wb;
+                __builtin_amdgcn_sched_barrier(0);
+                cur = nxt; wa = nwa; wb = nwb;
+            }
+        } else {
+            // ---- three 12-point windows placed at 6 / 12 / 18 (Frame.py:135-148), the reference's order, walked over the 12 rows as
+            //      k_dec_imdct does
+            typedef double dvec4 __attribute__((ext_vector_type(4)));
+            struct Row6 { dvec4 a; dvec2 b; double s; };
+            auto load_row6 = [&](int j) { Row6 r; r.a = *reinterpret_cast<const dvec4 *>(C12[j]); r.b = *reinterpret_cast<const dvec2 *>(C12[j] + 4); r.s = tab.sine_block[2][j]; return r; };
+            double pt[18], hold[6], tn[18];
+#pragma unroll
+            for (int i = 0; i < 18; i++) pt[i] = tl[i * 64];
+#pragma unroll
+            for (int i = 0; i < 6; i++) { double x = 0.0 + pt[i]; if (i & 1) x = flip(x); S[i] = x; }    // sample_block[0..5] = 0
+            Row6 cur = load_row6(0);
+#pragma unroll
+            for (int j = 0; j < 12; j++) {
+                const Row6 nxt = load_row6(j < 11 ? j + 1 : 11);
+                __builtin_amdgcn_sched_barrier(0);
+                double a0 = 0.0, a1 = 0.0, a2 = 0.0;
+#pragma unroll
+                for (int k = 0; k < 6; k++) {
+                    const double c = k < 4 ? cur.a[k] : cur.b[k - 4];
+                    a0 += v[k] * c; a1 += v[6 + k] * c; a2 += v[12 + k] * c;
+                }
+                a0 = a0 * cur.s; a1 = a1 * cur.s; a2 = a2 * cur.s;
+                if (j < 6) {
+                    double x = a0 + pt[6 + j];                          // sample_block[6..11] = t[0..5]
+                    if ((6 + j) & 1) x = flip(x);
+                    S[6 + j] = x;
+                    hold[j] = a1;                                       // t[12..17]
+                    tn[j] = a2;                                         // t[24..29], half of sample_block[18..23]
+                } else {
+                    double x = (a0 + hold[j - 6]) + pt[6 + j];          // sample_block[12..17] = t[6..11] + t[12..17]
+                    if ((6 + j) & 1) x = flip(x);
+                    S[6 + j] = x;
+                    tn[j - 6] = a1 + tn[j - 6];                         // sample_block[18..23] = t[18..23] + t[24..29]
+                    tn[j] = a2;                                         // sample_block[24..29] = t[30..35]
+                    tn[6 + j] = 0.0;                                    // sample_block[30..35]
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                cur = nxt;
+            }
+#pragma unroll
+            for (int i = 0; i < 18; i++) tl[i * 64] = tn[i];
+        }
+        if (tail_only) continue;
+
+        // ---- synthesis of the granule's 18 slots, in time order
+        const long t0 = (long)g * 18;                                           // the granule's first slot
+        const bool store = emit && t0 >= halo_slots;                            // (a halo is whole frames)
+        int16_t *const o16 = reinterpret_cast<int16_t *>(pcm_out) + ((t0 - halo_slots) * 32 + sb) * NCH + ch;
+        float *const o32 = reinterpret_cast<float *>(pcm_out) + ((t0 - halo_slots) * 32 + sb) * NCH + ch;
+        // slot p's X: mirror subband by swizzle, difference | sum, the row's 16 x 16 products
+        auto mirror = [&](double s) { return __hiloint2double(__builtin_amdgcn_ds_swizzle(__double2hiint(s), 0x7c1f), __builtin_amdgcn_ds_swizzle(__double2loint(s), 0x7c1f)); };
+        auto xsum = [&](double s, double m) {
+            const double ms2 = __hiloint2double(__double2hiint(m) ^ (int)sgn_lo, __double2loint(m));
+            return st_row_dot16(s + ms2, cx);
+        };
+        double mir = mirror(S[0]);
+        double X = xsum(S[0], mir);
+#pragma unroll
+        for (int p = 0; p < 18; p++) {
+            // A and B of slot p from the lanes that hold them; the mirror of slot p + 1 with them, one wait for all
+            const int a_lo = __builtin_amdgcn_ds_bpermute(addr_a, __double2loint(X)), a_hi = __builtin_amdgcn_ds_bpermute(addr_a, __double2hiint(X));
+            const int b_lo = __builtin_amdgcn_ds_bpermute(addr_b, __double2loint(X)), b_hi = __builtin_amdgcn_ds_bpermute(addr_b, __double2hiint(X));
+            if (p < 17) mir = mirror(S[p + 1]);
+            const double A = __hiloint2double(a_hi, a_lo), B = __hiloint2double(b_hi, b_lo);
+            if (p < 17) X = xsum(S[p + 1], mir);
+            // the 16 sums this slot belongs to: lag jj ahead, its even lags take A, the odd ones B; lag 15 opens a sum
+#pragma unroll
+            for (int jj = 0; jj < 16; jj++) {
+                const int q = (p + jj) % 18;
+                const double val = (jj & 1) ? B : A;
+                acc[q] = jj == 15 ? wt[15] * val : __builtin_fma(wt[jj], val, acc[q]);
+            }
+            const double x = acc[p];                                            // complete: this slot's own term was its last
+            if (F32) {
+                if (store && live) o32[p * 32 * NCH] = (float)x;
+            } else {
+                // the guard (k_dec_synth_fast): is the truncation of x = sample * 32767 beyond doubt?  distance to the nearest non-zero integer
+                const double xi = rint(x);
+                const double dist = fabs(x) - fmax(fabs(xi), 1.0);
+                if (store) {
+                    if (live) o16[p * 32 * NCH] = (int16_t)(int)x;
+                    unsigned long long m = safe ? __ballot(!(fabs(dist) > eps_t)) : ~0ull;
+                    if (NCH == 1) m &= 0xffffffffull;
+                    if (m) {                                                    // (wave-uniform, rare)
+                        if (lane == 0) {
+                            const uint32_t m0 = (uint32_t)m, m1 = (uint32_t)(m >> 32);
+                            const int n = (m0 != 0) + (m1 != 0);
+                            int at = atomicAdd(fix_count, n);
+                            if (m0) fix_list[at++] = make_uint2((uint32_t)(t0 + p), m0);
+                            if (m1) fix_list[at] = make_uint2((uint32_t)(t0 + p) | 0x80000000u, m1);
+                        }
+                    }
+                }
+            }
+        }
+    }
+}
+
+}  // namespace mp3s

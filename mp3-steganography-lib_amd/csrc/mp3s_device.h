@@ -43,7 +43,8 @@ int launch_decode(hipStream_t stream, const int16_t *d_is, const mp3s_granule_si
                                                through the exact order, [6..7] belong to the fix-up list; without them the
                                                exact kernels run */,
                   bool fast_imdct = true /* MP3S_OPT_FAST_IMDCT: the mirrored, fused IMDCT under the fast synthesis */,
-                  bool float_fast = false /* MP3S_OPT_FLOAT_FAST: float32 output through the fast sums, unguarded (within 1e-5, not bit-identical) */);
+                  bool float_fast = false /* MP3S_OPT_FLOAT_FAST: float32 output through the fast sums, unguarded (within 1e-5, not bit-identical) */,
+                  bool fused = true /* MP3S_OPT_FUSED_DECODE: the fast paths as one kernel, S in LDS (k_decode_fused.hpp) */);
 
 // scratch: subband samples int32 [2][32][36 n]
 size_t enc_scratch_bytes(int n_frames);

@@ -16,6 +16,7 @@ __constant__ DevTables c_tab;
 
 #include "k_sync.hpp"
 #include "k_decode.hpp"
+#include "k_decode_stream.hpp"
 #include "k_encode.hpp"
 #include "k_rate.hpp"
 #include "k_huffman.hpp"
@@ -60,7 +61,7 @@ size_t dec_scratch_bytes(int n_frames, int nch)
 
 int launch_decode(hipStream_t stream, const int16_t *d_is, const mp3s_granule_si *d_si, const mp3s_frame_hdr *d_hdr,
                   int n_frames, int nch, int n_halo, int out_format, void *d_pcm, void *d_scratch, Profiler *prof, int sf_base,
-                  double synth_eps_scale, int32_t *d_sync, bool fast_imdct, bool float_fast)
+                  double synth_eps_scale, int32_t *d_sync, bool fast_imdct, bool float_fast, bool fused)
 {
     const long T = (long)n_frames * 36;
     double *S = (double *)d_scratch;
@@ -71,6 +72,36 @@ int launch_decode(hipStream_t stream, const int16_t *d_is, const mp3s_granule_si
     const bool fast = out_format == MP3S_PCM_I16 && synth_eps_scale > 0 && d_sync;
     // float32 output through the same fast sums, unguarded (MP3S_OPT_FLOAT_FAST: within 1e-5 of the reference, not bit-identical)
     const bool fast32 = out_format == MP3S_PCM_F32 && float_fast;
+    // the fast paths as ONE kernel, a wave-local stream with no intermediate array (k_decode_stream.hpp); timed as the synthesis
+    if (fused && ((fast && fast_imdct) || fast32)) {
+        // granules per wave: a run is primed with a granule and a half of work in front of it, so longer runs waste less; short enough that
+        // the waves fill the chip's slots (two waves per SIMD: 2 048) in whole rounds
+        int run = 16;
+        {
+            double best = 1e30;
+            for (int r = 4; r <= 16; r++) {
+                const long waves = (n_gran + r - 1) / r;
+                const long rounds = (waves + 2047) / 2048;
+                const double cost = (double)rounds * (r + 1.6);
+                if (cost < best) { best = cost; run = r; }
+            }
+        }
+        const int runs = (n_gran + run - 1) / run;
+        const dim3 grid((runs + ST_WAVES - 1) / ST_WAVES), block(ST_WAVES * 64);
+        const int pf = prof ? prof->begin(stream, K_DEC_SYNTH) : -1;
+        if (fast32) {
+            if (nch == 2) hipLaunchKernelGGL((k_dec_stream<2, true>), grid, block, 0, stream, d_is, d_si, d_hdr, n_gran, run, n_halo, d_pcm, sf_base, 1.0, (uint2 *)nullptr, (int32_t *)nullptr);
+            else hipLaunchKernelGGL((k_dec_stream<1, true>), grid, block, 0, stream, d_is, d_si, d_hdr, n_gran, run, n_halo, d_pcm, sf_base, 1.0, (uint2 *)nullptr, (int32_t *)nullptr);
+        } else {
+            if (nch == 2) hipLaunchKernelGGL((k_dec_stream<2, false>), grid, block, 0, stream, d_is, d_si, d_hdr, n_gran, run, n_halo, d_pcm, sf_base, synth_eps_scale, fix_list, d_sync + 6);
+            else hipLaunchKernelGGL((k_dec_stream<1, false>), grid, block, 0, stream, d_is, d_si, d_hdr, n_gran, run, n_halo, d_pcm, sf_base, synth_eps_scale, fix_list, d_sync + 6);
+            const int fix_groups = (int)((T * nch + DEC_A_WAVES - 1) / DEC_A_WAVES) < 128 ? (int)((T * nch + DEC_A_WAVES - 1) / DEC_A_WAVES) : 128;
+            hipLaunchKernelGGL(k_dec_fixup, dim3(fix_groups), dim3(DEC_A_WAVES * 64), 0, stream, d_is, d_si, d_hdr, n_gran, nch, T, n_halo,
+                               sf_base, (int16_t *)d_pcm, (const uint2 *)fix_list, d_sync + 6, d_sync + 2);
+        }
+        if (prof) prof->end(stream, pf);
+        return (int)hipGetLastError();
+    }
     // granules per wave: each wave also primes itself with half an IMDCT of the granule before its run, so longer
     // runs waste less; pick the run length (2..8) that fills whole rounds of the chip's wave slots best (168 VGPRs ->
     // 3 waves per SIMD -> 256 CUs x 12 = 3072 slots)

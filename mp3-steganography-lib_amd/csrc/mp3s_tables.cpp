@@ -213,6 +213,17 @@ void build()
                 for (int j = 0; j < 8; j++) { q[80 + j] = W[oc][j]; q[88 + j] = W[od][j]; q[96 + j] = W[oc][8 + j]; q[104 + j] = W[od][8 + j]; }
             }
     }
+    for (int sb = 0; sb < 32; sb++)
+        for (int j = 0; j < 16; j++) {
+            const int k = sb < 16 ? 2 * sb + 1 : 2 * (sb - 16);
+            // (true cosines rounded once: the multiple of pi/64 reduced modulo its period in integers, the cosine taken in long double)
+            const int n = ((sb < 16 ? 2 * j + 1 : 31 - 2 * j) * k) % 128;
+            T.stream_cx[sb][j] = (double)cosl((long double)n * 3.14159265358979323846264338327950288L / 64.0L);
+            const double d = T.synth_window_t[sb][j];
+            const double w = (j & 1) ? -d : (sb <= 15 ? d : (sb == 16 ? 0.0 : -d));
+            T.stream_taps[0][sb][j] = w;
+            T.stream_taps[1][sb][j] = w * 32767.0;
+        }
     for (int sr = 0; sr < 3; sr++) {
         for (int c = 0; c < 3; c++) {
             uint8_t flat[576];

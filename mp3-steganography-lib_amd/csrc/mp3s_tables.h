@@ -65,6 +65,14 @@ struct DevTables {
     // c = 2t + 1, d = 31 - 2t as [a 0..7 | b 0..7] [a 8..15 | b 8..15] [c 0..7 | d 0..7] [c 8..15 | d 8..15]
     // (t = 0: outputs 0 and 16 read different slots: [row 0] [row 16] in their places)
     double synth_stream[2][8][112];
+    // k_dec_stream (k_decode_stream.hpp), lane = (channel, subband sb):
+    //   stream_cx[sb][j]: the lane's 16 cosines as the holder of X[k].  sb < 16: k = 2 sb + 1, the j-th value of its DPP row is the
+    //   difference S[j] - S[31-j]: cos((2j+1) k pi/64); sb >= 16: k = 2 (sb - 16), the j-th value of its row is the sum
+    //   S[15-j] + S[16+j]: cos((31-2j) k pi/64)
+    //   stream_taps[v][i][jj]: the 16 taps of output i = sb, D[i + 32 jj] times the sign of the V value it multiplies -- even jj: V[i]
+    //   = +X[16+i] (i <= 15), 0 (i = 16), -X[48-i]; odd jj: V[32+i] = -X[16-i] (i <= 15), -X[i-16] -- and, v = 1, times 32767
+    double stream_cx[32][16];
+    double stream_taps[2][32][16];
     uint8_t rq_map[3][3][32][20];  // [sr][case][subband][18 lines + 2 pad]: five aligned dwords per lane;
                                    // byte = gain selector << 6 | scalefactor slot (see build_rq_map)
     int16_t reorder_src[3][576];   // [sr][dst line] -> src line or -1 (zero)  Frame.py:574-602
