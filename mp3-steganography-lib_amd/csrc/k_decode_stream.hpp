@@ -36,6 +36,7 @@
 namespace mp3s {
 
 constexpr int ST_WAVES = 4;                 // waves per workgroup; they share the staged tables and nothing else
+constexpr int ST_P43_N = 512;
 
 struct StShared {
     double pow2q[POW2Q_N];                  // (as DecShared: random per-lane reads go to LDS)
@@ -45,6 +46,7 @@ struct StShared {
     double exp1f[ST_WAVES][2][4];           // ... and 2^(exp1/4) per gain selector
     double win[4][36];                      // sine_block
     double tail[ST_WAVES][18][64];          // per wave: the overlap tail of the granule before, [row][lane]
+    double p43[ST_P43_N];                   // |is|^(4/3) of the small values (most of a stream): an LDS look-up where the whole table is a trip to L2
 };
 
 // One line of channel c of granule g, requantised as dec_requant_ms does it (Frame.py:210-215), for a lane that needs it out of order
@@ -103,6 +105,7 @@ __global__ __launch_bounds__(ST_WAVES * 64, 2) void k_dec_stream(
     for (int i = threadIdx.x; i < POW2Q_N; i += blockDim.x) sh.pow2q[i] = c_tab.pow2q[i];
     if (threadIdx.x < POW2H_N) sh.pow2h[threadIdx.x] = c_tab.pow2h[threadIdx.x];
     if (threadIdx.x < 144) (&sh.win[0][0])[threadIdx.x] = (&c_tab.sine_block[0][0])[threadIdx.x];
+    for (int i = threadIdx.x; i < ST_P43_N; i += blockDim.x) sh.p43[i] = c_tab.pow43[i];
     __syncthreads();
     const int ga = (xcd_tile() * ST_WAVES + wave) * run;       // this wave's granules: ga .. ga + run - 1
     if (ga >= n_granules) return;                                // (whole waves; no barrier behind this line)
@@ -141,13 +144,23 @@ __global__ __launch_bounds__(ST_WAVES * 64, 2) void k_dec_stream(
     GranIn next_in = {};
     bool have_next = false;
 
+    // priming: the granule in front of the run (history of the synthesis) and the tail of the one before, as far as they belong to the stream
+    const int gi0 = ga - 2 >= s_a ? -2 : (ga - 1 >= s_a ? -1 : 0);
+    mp3s_frame_hdr fh = hdr[(ga + gi0) >> 1];
+    // the line map of long blocks (scalefactor band of each of the lane's 18 lines) depends on the sample rate alone: kept across granules
+    int sr_map = fh.sr_idx < 3 ? fh.sr_idx : 0;
+    uint32_t mwl[5];
+#pragma unroll
+    for (int k = 0; k < 5; k++) mwl[k] = reinterpret_cast<const uint32_t *>(c_tab.rq_map[sr_map][0][sb])[k];
 #pragma unroll 1
-    for (int gi = -2; gi < run; gi++) {
+    for (int gi = gi0; gi < run; gi++) {
         const int g = ga + gi;
         if (g >= n_granules) break;
-        if (g < 0 || (gi < 0 && g < s_a)) continue;
-        const mp3s_frame_hdr fh = hdr[g >> 1];
         const int first_gran = fh.stream_first > (uint32_t)sf_base ? (int)(fh.stream_first - (uint32_t)sf_base) * 2 : 0;
+        const int sr = fh.sr_idx < 3 ? fh.sr_idx : 0;
+        const bool ms = fh.ms_stereo != 0;
+        // (the next granule's frame header: a scalar load whose latency passes under this granule)
+        fh = hdr[(g + 1 < n_granules ? g + 1 : g) >> 1];
         if (g == first_gran) fresh = true;                      // Frame.py:234-235: prev_samples and the fifo start as zeros
         if (fresh) {
 #pragma unroll
@@ -157,8 +170,6 @@ __global__ __launch_bounds__(ST_WAVES * 64, 2) void k_dec_stream(
         }
         const bool tail_only = gi == -2;                        // two granules in front of the run: only its overlap tail is needed
         const bool emit = gi >= 0;
-        const int sr = fh.sr_idx < 3 ? fh.sr_idx : 0;
-        const bool ms = fh.ms_stereo != 0;
         // the twiddle tables are invariant over this loop: an opaque zero offset per granule keeps their scalar loads inside it (k_dec_imdct)
         int zoff = 0;
         asm volatile("" : "+s"(zoff));
@@ -170,9 +181,69 @@ __global__ __launch_bounds__(ST_WAVES * 64, 2) void k_dec_stream(
         double v[18];
         int bt, cse;
         const GranIn in = have_next ? next_in : dec_fetch(is, si, g, NCH, lane);
-        dec_requant_ms(tab, sh, wave, v, in, sr, ms, NCH, lane, bt, cse);
         have_next = gi + 1 < run && g + 1 < n_granules;
         if (have_next) next_in = dec_fetch(is, si, g + 1, NCH, lane);
+        // The common granule -- long blocks in every channel, no value beyond the small |is|^(4/3) table -- without a trip to memory: the
+        // side records' fields from the registers they arrived in (lane d of the first 36 holds dword d: v_readlane for the two
+        // head dwords of a channel, one ds_bpermute for a lane's scalefactor byte), the line map kept from the granule before,
+        // |is|^(4/3) from LDS.  Same products in the same order as dec_requant_ms, which takes everything else.
+        bool quick;
+        uint32_t w0, w1;
+        {
+            const uint32_t d0a = (uint32_t)__builtin_amdgcn_readlane((int)in.side, 0), d1a = (uint32_t)__builtin_amdgcn_readlane((int)in.side, 1);
+            const uint32_t d0b = (uint32_t)__builtin_amdgcn_readlane((int)in.side, 18), d1b = (uint32_t)__builtin_amdgcn_readlane((int)in.side, 19);
+            auto is_long = [](uint32_t d0) { return ((d0 >> 16) & 3u) != 2u && (d0 >> 24) == 0u; };     // block_type != 2, mixed_block_flag == 0
+            quick = is_long(d0a) && (NCH == 1 || is_long(d0b));
+            w0 = ch ? d0b : d0a; w1 = ch ? d1b : d1a;
+            uint32_t mx = 0;
+#pragma unroll
+            for (int k = 0; k < 9; k++) {
+                const int lo16 = (int)(int16_t)in.xw[k], hi16 = (int)in.xw[k] >> 16;
+                mx = max(mx, max((uint32_t)(lo16 < 0 ? -lo16 : lo16), (uint32_t)(hi16 < 0 ? -hi16 : hi16)));
+            }
+            quick = quick && __ballot(mx >= (uint32_t)ST_P43_N) == 0;
+        }
+        if (quick && sr != sr_map) {
+            sr_map = sr;
+#pragma unroll
+            for (int k = 0; k < 5; k++) mwl[k] = reinterpret_cast<const uint32_t *>(tab.rq_map[sr][0][sb])[k];
+        }
+        if (quick) {
+            bt = (int)((w0 >> 16) & 3u); cse = 0;
+            const int gg = (int)(w0 & 0xffu), mult2 = ((w0 >> 8) & 0xffu) ? 2 : 1, preflag = (w1 & 0xffu) ? 1 : 0;
+            // 2^(-exp2) per scalefactor band: lane sb < 22 of a channel takes band sb (Frame.py:201-208; byte 8 + sb of the record)
+            double *e2 = sh.exp2f[wave][ch];
+            const int bsrc = ((ch ? 18 : 0) + 2 + (sb >> 2)) * 4;
+            const uint32_t sfw = (uint32_t)__builtin_amdgcn_ds_bpermute(bsrc, (int)in.side);
+            if (sb < 22) {
+                const int pt = sb < 11 || sb > 20 ? 0 : (int)((0x2333221111ull >> ((sb - 11) * 4)) & 15);   // pre_tab[11..20]
+                const int k2 = mult2 * ((int)((sfw >> ((sb & 3) * 8)) & 15u) + preflag * pt);
+                e2[sb] = sh.pow2h[k2 < POW2H_N ? k2 : POW2H_N - 1];
+            }
+            const double e1 = sh.pow2q[gg - 210 - POW2Q_MIN];
+            __builtin_amdgcn_s_waitcnt(0xc07f);
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int k = 0; k < 18; k++) {
+                const uint32_t xwk = in.xw[k >> 1];
+                const int x = (int)(int16_t)(xwk >> ((k & 1) * 16));
+                const uint32_t ax = (uint32_t)(x < 0 ? -x : x);
+                const double a = sh.p43[ax];
+                uint32_t i2;
+                asm("v_bfe_u32 %0, %1, %2, 6" : "=v"(i2) : "v"(mwl[k >> 2]), "n"((k & 3) * 8));
+                const uint32_t sgn = (k & 1) ? xwk : xwk << 16;
+                const double sa = __hiloint2double((int)(((uint32_t)__double2hiint(a) & 0x7fffffffu) | (sgn & 0x80000000u)), __double2loint(a));
+                v[k] = (sa * e1) * e2[i2];
+            }
+            if (ms && NCH == 2) {
+#pragma unroll
+                for (int k = 0; k < 18; k++) {
+                    const double o = shfl_xor_f64(v[k], 32);
+                    v[k] = ch == 0 ? (v[k] + o) / tab.sqrt2 : (o - v[k]) / tab.sqrt2;
+                }
+            }
+        } else
+            dec_requant_ms(tab, sh, wave, v, in, sr, ms, NCH, lane, bt, cse);
         if (cse != 0) {
             // reorder (Frame.py:574-602) of a short / mixed granule: line k of this subband is line src of the spectrum (or nothing),
             // computed again from `is` -- requantised and, under MS stereo, combined with the other channel's line src
@@ -286,15 +357,17 @@ __global__ __launch_bounds__(ST_WAVES * 64, 2) void k_dec_stream(
             typedef double dvec4 __attribute__((ext_vector_type(4)));
             struct Row6 { dvec4 a; dvec2 b; double s; };
             auto load_row6 = [&](int j) { Row6 r; r.a = *reinterpret_cast<const dvec4 *>(C12[j]); r.b = *reinterpret_cast<const dvec2 *>(C12[j] + 4); r.s = tab.sine_block[2][j]; return r; };
-            double pt[18], hold[6], tn[18];
+            // (the tail of the granule before is read row by row where it is used and the new one written where it is complete: a row of
+            // the new tail never lands on a row of the old one that is still to be read -- rows 0..5 are read first, row 6 + j at step j,
+            // and step j writes rows j >= 6 and 6 + j; six sums wait in registers.  Eighteen registers instead of eighty.)
+            double hold[6], tn[6];
 #pragma unroll
-            for (int i = 0; i < 18; i++) pt[i] = tl[i * 64];
-#pragma unroll
-            for (int i = 0; i < 6; i++) { double x = 0.0 + pt[i]; if (i & 1) x = flip(x); S[i] = x; }    // sample_block[0..5] = 0
+            for (int i = 0; i < 6; i++) { double x = 0.0 + (double)tl[i * 64]; if (i & 1) x = flip(x); S[i] = x; }    // sample_block[0..5] = 0
             Row6 cur = load_row6(0);
 #pragma unroll
             for (int j = 0; j < 12; j++) {
                 const Row6 nxt = load_row6(j < 11 ? j + 1 : 11);
+                const double pj = tl[(6 + j) * 64];
                 __builtin_amdgcn_sched_barrier(0);
                 double a0 = 0.0, a1 = 0.0, a2 = 0.0;
 #pragma unroll
@@ -304,24 +377,24 @@ __global__ __launch_bounds__(ST_WAVES * 64, 2) void k_dec_stream(
                 }
                 a0 = a0 * cur.s; a1 = a1 * cur.s; a2 = a2 * cur.s;
                 if (j < 6) {
-                    double x = a0 + pt[6 + j];                          // sample_block[6..11] = t[0..5]
+                    double x = a0 + pj;                                 // sample_block[6..11] = t[0..5]
                     if ((6 + j) & 1) x = flip(x);
                     S[6 + j] = x;
                     hold[j] = a1;                                       // t[12..17]
                     tn[j] = a2;                                         // t[24..29], half of sample_block[18..23]
                 } else {
-                    double x = (a0 + hold[j - 6]) + pt[6 + j];          // sample_block[12..17] = t[6..11] + t[12..17]
+                    double x = (a0 + hold[j - 6]) + pj;                 // sample_block[12..17] = t[6..11] + t[12..17]
                     if ((6 + j) & 1) x = flip(x);
                     S[6 + j] = x;
                     tn[j - 6] = a1 + tn[j - 6];                         // sample_block[18..23] = t[18..23] + t[24..29]
-                    tn[j] = a2;                                         // sample_block[24..29] = t[30..35]
-                    tn[6 + j] = 0.0;                                    // sample_block[30..35]
+                    tl[j * 64] = a2;                                    // sample_block[24..29] = t[30..35]
+                    tl[(6 + j) * 64] = 0.0;                             // sample_block[30..35]
                 }
                 __builtin_amdgcn_sched_barrier(0);
                 cur = nxt;
             }
 #pragma unroll
-            for (int i = 0; i < 18; i++) tl[i * 64] = tn[i];
+            for (int i = 0; i < 6; i++) tl[i * 64] = tn[i];
         }
         if (tail_only) continue;
 
@@ -336,16 +409,22 @@ __global__ __launch_bounds__(ST_WAVES * 64, 2) void k_dec_stream(
             const double ms2 = __hiloint2double(__double2hiint(m) ^ (int)sgn_lo, __double2loint(m));
             return st_row_dot16(s + ms2, cx);
         };
+        // Slot p's A and B and slot p + 1's mirror are asked for one slot AHEAD: under the sixteen multiply-adds of the slot in front
+        // (LDS operations of a wave complete in order: when the mirror a slot's X needs is here, so are the A and B asked for before it)
         double mir = mirror(S[0]);
         double X = xsum(S[0], mir);
+        int a_lo = __builtin_amdgcn_ds_bpermute(addr_a, __double2loint(X)), a_hi = __builtin_amdgcn_ds_bpermute(addr_a, __double2hiint(X));
+        int b_lo = __builtin_amdgcn_ds_bpermute(addr_b, __double2loint(X)), b_hi = __builtin_amdgcn_ds_bpermute(addr_b, __double2hiint(X));
+        mir = mirror(S[1]);
 #pragma unroll
         for (int p = 0; p < 18; p++) {
-            // A and B of slot p from the lanes that hold them; the mirror of slot p + 1 with them, one wait for all
-            const int a_lo = __builtin_amdgcn_ds_bpermute(addr_a, __double2loint(X)), a_hi = __builtin_amdgcn_ds_bpermute(addr_a, __double2hiint(X));
-            const int b_lo = __builtin_amdgcn_ds_bpermute(addr_b, __double2loint(X)), b_hi = __builtin_amdgcn_ds_bpermute(addr_b, __double2hiint(X));
-            if (p < 17) mir = mirror(S[p + 1]);
             const double A = __hiloint2double(a_hi, a_lo), B = __hiloint2double(b_hi, b_lo);
-            if (p < 17) X = xsum(S[p + 1], mir);
+            if (p < 17) {
+                X = xsum(S[p + 1], mir);
+                a_lo = __builtin_amdgcn_ds_bpermute(addr_a, __double2loint(X)); a_hi = __builtin_amdgcn_ds_bpermute(addr_a, __double2hiint(X));
+                b_lo = __builtin_amdgcn_ds_bpermute(addr_b, __double2loint(X)); b_hi = __builtin_amdgcn_ds_bpermute(addr_b, __double2hiint(X));
+                if (p < 16) mir = mirror(S[p + 2]);
+            }
             // the 16 sums this slot belongs to: lag jj ahead, its even lags take A, the odd ones B; lag 15 opens a sum
 #pragma unroll
             for (int jj = 0; jj < 16; jj++) {
