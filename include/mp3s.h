@@ -40,6 +40,8 @@ extern "C" {
 #define MP3S_E_NOMEM (-7)
 #define MP3S_E_EXIT (-8)        /* the reference calls sys.exit(text) here; the text is in mp3s_last_error() */
 #define MP3S_E_BUSY (-9)        /* mp3s_pipe_submit: every slot is taken, collect a result first; mp3s_pipe_collect: nothing pending */
+#define MP3S_E_TABLES (-10)     /* a constant table built with this host's libm is not the one a kernel was compiled for (the encoder's analysis
+                                 * filter: csrc/analysis_plan.h); the encode entry points refuse, decoding works */
 
 #define MP3S_PCM_I16 0 /* (pcm*32767) truncated toward zero, low 16 bits: reference decoder/MP3_Parser.py:91 */
 #define MP3S_PCM_F32 1
@@ -97,6 +99,8 @@ typedef struct {
 #define MP3S_RF_USED_ADDR_IN 2 /* the incoming address1/2/3 were read before being overwritten */
 #define MP3S_RF_STEP_RANGE 4  /* quantizer step left the table */
 #define MP3S_RF_LOG_GUARD 8   /* reserved: never set since the band energies come from a table built with the host's libm */
+#define MP3S_RF_LISTED 16     /* the device's chain check has put the unit on its list of re-runs (mp3s_chain_redo_dev): the list entry's wave is the
+                               * unit's one writer in that launch, a re-run that follows its chain of inheriting units stops in front of it */
 
 /* ---------------------------------------------------------------- context */
 int mp3s_ctx_create(int device, mp3s_ctx **out);

@@ -188,6 +188,7 @@ __global__ __launch_bounds__(CH_THREADS) void k_chain_apply(mp3s_gr_out *__restr
                 if (at < REDO_CAP) {
                     const int32_t c = (int32_t)(cur < (long)MP3S_NO_CURSOR ? cur : (long)MP3S_NO_CURSOR);
                     redo_list[REDO_HEAD + at] = (int32_t)u;
+                    g.flags = flags | MP3S_RF_LISTED;     // one writer per unit in k_rate_redo: a chain that reaches this unit leaves it to its entry
                     redo_list[REDO_HEAD + REDO_CAP + at] = hiding ? c : (cursor_in ? cursor_in[u] : 0);
                     if (hiding) cursor_in[u] = c;
 #pragma unroll

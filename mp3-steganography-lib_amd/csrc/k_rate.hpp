@@ -588,6 +588,7 @@ __device__ __forceinline__ void rate_units(
             if (err) flags |= MP3S_RF_STEP_RANGE;
         }
         if (st.used_addr_in) flags |= MP3S_RF_USED_ADDR_IN;
+        if (CHAIN && !chained) flags |= MP3S_RF_LISTED;    // (a list entry's unit stays marked: see the chain walk below)
 
         // ---- signed ix (format_bitstream :1272-1276) as int16 pairs
         int16_t *ixo = ix_out + (long)(compact == 2 ? li : u - out_base) * 576;
@@ -634,6 +635,10 @@ __device__ __forceinline__ void rate_units(
             un += 4;                                               // the same (gr, ch) of the next frame
             if (++steps >= REDO_CHAIN_MAX || un >= n_units || frames[un >> 2].stream != fr.stream) break;
             const int f2 = __builtin_amdgcn_readfirstlane(__hip_atomic_load(&out[un - out_base].flags, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+            // A unit that is itself an entry of the list has its own wave in this launch -- possibly at work right now, and it may
+            // have written its record already or not: the mark k_chain_apply gave it stays set either way.  The chain stops here;
+            // the entry runs on what the check derived from the first pass, and the check behind this launch judges the result.
+            if (f2 & MP3S_RF_LISTED) break;
             if (!(f2 & MP3S_RF_ACTIVE)) continue;                  // silent: it inherits and passes on (k_chain_apply writes its record)
             const int given = __builtin_amdgcn_readfirstlane(__hip_atomic_load(&out[un - out_base].reserved0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
             go = (f2 & MP3S_RF_USED_ADDR_IN) && given != (ch_state[0] | (ch_state[1] << 10) | (ch_state[2] << 20));

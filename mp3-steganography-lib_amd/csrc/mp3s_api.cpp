@@ -141,11 +141,6 @@ int mp3s_ctx_create(int device, mp3s_ctx **out)
         mp3s_ctx_destroy(c);
         return fail(MP3S_E_NO_DEVICE, "device scratch allocation failed");
     }
-    if (!host_tables().analysis_plan_ok) {
-        mp3s_ctx_destroy(c);
-        return fail(MP3S_E_NO_DEVICE, "the analysis filter table built on this host does not repeat itself where the kernel shares products "
-                                      "(csrc/analysis_plan.h: run tools/gen_analysis_plan.py here and rebuild)");
-    }
     const int rc = dev_upload_tables(c->stream);
     if (rc) {
         mp3s_ctx_destroy(c);
@@ -421,6 +416,11 @@ int mp3s_encode_transform_dev(mp3s_ctx *c, const int16_t *d_pcm, const mp3s_fram
 {
     if (!c || !d_pcm || !d_hdr || !d_mdct) return fail(MP3S_E_ARG, "null pointer");
     if (n_frames <= 0) return fail(MP3S_E_ARG, "n_frames=%d", n_frames);
+    // k_enc_analysis computes a product once where the filter table repeats itself (analysis_plan.h, generated from the table's values): a
+    // host whose libm rounds the table differently gets no wrong subband samples -- the encode entry points refuse, decoding is not affected
+    if (!host_tables().analysis_plan_ok)
+        return fail(MP3S_E_TABLES, "the analysis filter table built on this host does not repeat itself where the kernel shares products "
+                                   "(csrc/analysis_plan.h: run tools/gen_analysis_plan.py here and rebuild)");
     int rc = c->ensure_scratch_enc(enc_scratch_bytes(n_frames));
     if (rc) return rc;
     const int e = launch_encode(c->stream, d_pcm, d_hdr, n_frames, d_mdct, c->scratch_enc, &c->prof);

@@ -48,11 +48,15 @@ class Decoder:
         fd = os.open(self.__output_file_path, os.O_WRONLY | os.O_CREAT, 0o666)
         try:
             res = _lib.default_context().decode_file_to_fd(self.__data, fd)
-        except _lib.Mp3sError as e:
+        except BaseException as e:
+            # whatever ends the call (the library's refusal, an interrupt, no memory): no output is left behind that was not there,
+            # and one that was there is not left half written
             os.close(fd); fd = -1
             if not there:
                 os.remove(self.__output_file_path)
-            if e.code in (_lib.E_MALFORMED, _lib.E_UNSUPPORTED):
+            else:
+                os.truncate(self.__output_file_path, 0)
+            if isinstance(e, _lib.Mp3sError) and e.code in (_lib.E_MALFORMED, _lib.E_UNSUPPORTED):
                 raise ValueError(str(e)) from None
             raise
         finally:

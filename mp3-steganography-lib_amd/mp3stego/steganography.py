@@ -27,15 +27,38 @@ def _must_exist(path: str):
 
 
 _helper = None
+_pending = []          # what the helper thread was given and nobody has looked at yet
+
+
+def _reset_helper():
+    """a forked child starts without the parent's helper thread (its executor would wait for a thread that is not there)"""
+    global _helper
+    _helper = None
+    _pending.clear()
+
+
+if hasattr(os, "register_at_fork"):
+    os.register_at_fork(after_in_child=_reset_helper)
+
+
+def _settle():
+    """what the helper thread has finished: its exceptions surface here (at the start of the next call, or at exit) instead of nowhere"""
+    for fut in [f for f in _pending if f.done()]:
+        _pending.remove(fut)
+        fut.result()
 
 
 def _later(fn):
-    """run `fn` on the module's helper thread (made on first use)"""
+    """run `fn` on the module's helper thread (made on first use); the result is looked at by the next call's _settle()"""
     global _helper
     if _helper is None:
+        import atexit
         from concurrent.futures import ThreadPoolExecutor
         _helper = ThreadPoolExecutor(max_workers=1, thread_name_prefix="mp3stego-aux")
-    return _helper.submit(fn)
+        atexit.register(lambda: (_helper.shutdown(wait=True) if _helper is not None else None))
+    fut = _helper.submit(fn)
+    _pending.append(fut)
+    return fut
 
 
 def _store(path: str, out):
@@ -147,6 +170,7 @@ class Steganography:
         if self.quiet and _ends(mp3_out, ".mp3"):
             from mp3stego import _lib
             import mmap
+            _settle()
             # the input mapped instead of read (0.4 ms per 4 MB less; the library's uploads take the pages as they come), the output
             # written over what is there and cut to length at the end (truncating first gives every page back and takes it again)
             mapped = None
@@ -174,11 +198,24 @@ class Steganography:
                     res = ctx.recode_to_fd(data, message, fd)
             except _lib.Mp3sError:
                 res = None                       # the step-by-step path decides what this looks like to the caller
+            except BaseException:
+                # (an interrupt, no memory: nothing half written stays behind, as after a refusal)
+                if fd >= 0:
+                    os.close(fd); fd = -1
+                    if made:
+                        os.remove(mp3_out)
+                    else:
+                        os.truncate(mp3_out, 0)
+                raise
             finally:
                 if mapped is not None:
                     # (the runtime registers the pages of a mapping it uploads from with the device; taking the mapping down undoes that in
-                    # the driver: 0.34 ms per 4 MB -- on the helper thread, beside the write of the result)
-                    _later(mapped.close)
+                    # the driver: 0.34 ms per 4 MB -- on the helper thread, beside the write of the result.  When the output IS the input
+                    # the mapping goes first: the caller may rewrite the file the moment this call returns)
+                    if os.path.abspath(mp3_out) == os.path.abspath(mp3_in):
+                        mapped.close()
+                    else:
+                        _later(mapped.close)
                 if fd >= 0:
                     os.close(fd)
             if res is None and fd >= 0:

@@ -67,16 +67,37 @@ def child_env(env, rank, n, port):
 
 def launch(argv, n, env=None, timeout=None, grace=30.0, n_devices=None, out=None, err=None):
     """start `argv` (a full command line, e.g. [sys.executable, "bench.py", ...]) N times, one rank each.
-    -> worst exit code (E_USAGE without starting anything if the ranks do not fit the devices)."""
+    -> worst exit code (E_USAGE without starting anything if the ranks do not fit the devices).
+    timeout None = MP3STEGO_LAUNCH_TIMEOUT seconds (default 3600): a rank that hangs without exiting -- a rendezvous or a
+    barrier that never completes -- ends the job with E_TIMEOUT instead of keeping the parent polling for ever.  A job whose
+    ranks die within seconds without a line from rank 0 (the port taken between free_port() and the ranks' bind: the socket
+    is closed before they start) is started once more, fresh children on a new port; nothing is ever re-executed."""
     env = dict(os.environ if env is None else env)
+    if timeout is None:
+        try:
+            timeout = float(env.get("MP3STEGO_LAUNCH_TIMEOUT", "3600"))
+        except ValueError:
+            timeout = 3600.0
     out = sys.stdout if out is None else out
     err = sys.stderr if err is None else err
+    for attempt in range(2):
+        t_start = time.time()
+        code, said = _launch_once(argv, n, env, timeout, grace, n_devices, out, err)
+        if code in (0, E_USAGE, E_TIMEOUT) or said or time.time() - t_start > 20.0 or attempt == 1:
+            return code
+        print(f"[launch_ranks] the ranks ended with {code} within {time.time() - t_start:.1f} s and rank 0 said nothing: once more on a new port",
+              file=err, flush=True)
+    return code
+
+
+def _launch_once(argv, n, env, timeout, grace, n_devices, out, err):
+    """-> (worst exit code, rank 0 printed something)"""
     if n_devices is None:
         n_devices = -1 if env.get("MP3STEGO_DEVICE", "") != "" else visible_devices()
     ok, msg = plan(n, env, n_devices)
     print(f"[launch_ranks] {msg}", file=err, flush=True)
     if not ok:
-        return E_USAGE
+        return E_USAGE, False
     port = free_port()
     procs = []
     for r in range(n):
@@ -129,4 +150,4 @@ def launch(argv, n, env=None, timeout=None, grace=30.0, n_devices=None, out=None
         c = 0 if c is None else c
         if c != 0 and (worst == 0 or abs(c) > abs(worst)):
             worst = c
-    return worst if worst >= 0 else 128 - worst          # (a rank killed by signal s: 128 + s, as a shell reports it)
+    return (worst if worst >= 0 else 128 - worst), bool(relay)          # (a rank killed by signal s: 128 + s, as a shell reports it)
