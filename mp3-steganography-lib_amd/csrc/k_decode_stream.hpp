@@ -47,6 +47,8 @@ struct StShared {
     double win[4][36];                      // sine_block
     double tail[ST_WAVES][18][64];          // per wave: the overlap tail of the granule before, [row][lane]
     double p43[ST_P43_N];                   // |is|^(4/3) of the small values (most of a stream): an LDS look-up where the whole table is a trip to L2
+    double cx[16][32], wt[16][32];          // the synthesis' per-lane constants, [term][subband]: read into registers in front of a granule's 18 slots and
+                                            // dead again behind them (64 registers that requantisation and IMDCT have better use for)
 };
 
 // One line of channel c of granule g, requantised as dec_requant_ms does it (Frame.py:210-215), for a lane that needs it out of order
@@ -106,6 +108,12 @@ __global__ __launch_bounds__(ST_WAVES * 64, 2) void k_dec_stream(
     if (threadIdx.x < POW2H_N) sh.pow2h[threadIdx.x] = c_tab.pow2h[threadIdx.x];
     if (threadIdx.x < 144) (&sh.win[0][0])[threadIdx.x] = (&c_tab.sine_block[0][0])[threadIdx.x];
     for (int i = threadIdx.x; i < ST_P43_N; i += blockDim.x) sh.p43[i] = c_tab.pow43[i];
+    // the lanes' constants of the synthesis: 16 cosines (as the holder of X[k]: k = 2 (sb & 15) + 1 in the rows of the differences, 2 (sb & 15)
+    // in the rows of the sums) and 16 taps (as output i = sb)
+    for (int i = threadIdx.x; i < 512; i += blockDim.x) {
+        sh.cx[i >> 5][i & 31] = c_tab.stream_cx[i & 31][i >> 5];
+        sh.wt[i >> 5][i & 31] = c_tab.stream_taps[F32 ? 0 : 1][i & 31][i >> 5];
+    }
     __syncthreads();
     const int ga = (xcd_tile() * ST_WAVES + wave) * run;       // this wave's granules: ga .. ga + run - 1
     if (ga >= n_granules) return;                                // (whole waves; no barrier behind this line)
@@ -114,11 +122,7 @@ __global__ __launch_bounds__(ST_WAVES * 64, 2) void k_dec_stream(
     const bool live = ch < NCH;
     const uint32_t sgn_odd = (sb & 1) ? 0x80000000u : 0u;       // frequency inversion (Frame.py:629-631): odd slots of odd subbands
     auto flip = [&](double x) { return __hiloint2double(__double2hiint(x) ^ (int)sgn_odd, __double2loint(x)); };
-    // ---- the lane's constants of the synthesis: its 16 cosines (as the holder of X[k]: k = 2 (sb & 15) + 1 in the rows of the
-    //      differences, 2 (sb & 15) in the rows of the sums), its 16 taps (as output i = sb), where its A and B come from
-    double cx[16], wt[16];
-#pragma unroll
-    for (int j = 0; j < 16; j++) { cx[j] = c_tab.stream_cx[sb][j]; wt[j] = c_tab.stream_taps[F32 ? 0 : 1][sb][j]; }
+    // ---- where the lane's A and B come from (as output i = sb)
     int addr_a, addr_b;
     {
         const int ka = sb <= 15 ? 16 + sb : (sb == 16 ? 0 : 48 - sb);        // A = V[i]: X[16+i] | 0 (tap) | -X[48-i]
@@ -181,8 +185,6 @@ __global__ __launch_bounds__(ST_WAVES * 64, 2) void k_dec_stream(
         double v[18];
         int bt, cse;
         const GranIn in = have_next ? next_in : dec_fetch(is, si, g, NCH, lane);
-        have_next = gi + 1 < run && g + 1 < n_granules;
-        if (have_next) next_in = dec_fetch(is, si, g + 1, NCH, lane);
         // The common granule -- long blocks in every channel, no value beyond the small |is|^(4/3) table -- without a trip to memory: the
         // side records' fields from the registers they arrived in (lane d of the first 36 holds dword d: v_readlane for the two
         // head dwords of a channel, one ds_bpermute for a lane's scalefactor byte), the line map kept from the granule before,
@@ -396,6 +398,9 @@ __global__ __launch_bounds__(ST_WAVES * 64, 2) void k_dec_stream(
 #pragma unroll
             for (int i = 0; i < 6; i++) tl[i * 64] = tn[i];
         }
+        // the next granule's lines and side records: asked for here, behind the rows (their registers are wanted there), under the synthesis
+        have_next = gi + 1 < run && g + 1 < n_granules;
+        if (have_next) next_in = dec_fetch(is, si, g + 1, NCH, lane);
         if (tail_only) continue;
 
         // ---- synthesis of the granule's 18 slots, in time order
@@ -403,6 +408,9 @@ __global__ __launch_bounds__(ST_WAVES * 64, 2) void k_dec_stream(
         const bool store = emit && t0 >= halo_slots;                            // (a halo is whole frames)
         int16_t *const o16 = reinterpret_cast<int16_t *>(pcm_out) + ((t0 - halo_slots) * 32 + sb) * NCH + ch;
         float *const o32 = reinterpret_cast<float *>(pcm_out) + ((t0 - halo_slots) * 32 + sb) * NCH + ch;
+        double cx[16], wt[16];
+#pragma unroll
+        for (int j = 0; j < 16; j++) { cx[j] = sh.cx[j][sb]; wt[j] = sh.wt[j][sb]; }
         // slot p's X: mirror subband by swizzle, difference | sum, the row's 16 x 16 products
         auto mirror = [&](double s) { return __hiloint2double(__builtin_amdgcn_ds_swizzle(__double2hiint(s), 0x7c1f), __builtin_amdgcn_ds_swizzle(__double2loint(s), 0x7c1f)); };
         auto xsum = [&](double s, double m) {

@@ -170,6 +170,66 @@ __device__ __forceinline__ int rl_quantize(const RlTables &tb, const uint32_t (&
     return __ballot(big) ? 8193 : 0;
 }
 
+// calc_run_len (MP3_Encoder.py:266-291) and __subdivide (:998-1036) from what every lane knows about its own pairs: k0 = its highest
+// slot (+ 1) holding a non-zero value, k1 = its highest slot (+ 1) holding a value > 1.  Everything with a side effect that the reference's
+// loop body has in front of its bit counts: count1, big_values, region counts and addresses (left untouched when big_values == 0: E7).
+__device__ __forceinline__ void rl_run_lengths(const RlTables &tb, int k0, int k1, RlState &st)
+{
+    // per lane the highest slot (+1), then the highest lane: two ballots and two readlanes
+    const unsigned long long nzm = __ballot(k0 != 0), bgm = __ballot(k1 != 0);
+    const int L0 = 63 - (nzm ? __builtin_clzll(nzm) : 0), L1 = 63 - (bgm ? __builtin_clzll(bgm) : 0);
+    const int r0 = __builtin_amdgcn_readlane(k0, L0), r1 = __builtin_amdgcn_readlane(k1, L1);
+    const int P0 = nzm ? 5 * L0 + r0 - 1 : -1, P1 = bgm ? 5 * L1 + r1 - 1 : -1;
+    const int count1 = (P0 - P1) >> 1;
+    const int bv = (P0 + 1) - 2 * count1;
+    st.count1 = count1;
+    st.big_values = bv;
+    // ---- __subdivide (addresses are left untouched when big_values == 0: E7)
+    if (bv == 0) {
+        st.r0c = 0; st.r1c = 0;
+        if (!st.addr_fresh) st.used_addr_in = true;
+    } else {
+        // __subdivide (:1008-1036) depends on big_values only: looked up in the per-rate table built on the host
+        const uint32_t e = tb.subdiv[bv < 289 ? bv : 288];
+        st.r0c = (int)(e & 15); st.r1c = (int)((e >> 4) & 7);
+        st.a1 = (int)((e >> 8) & 1023); st.a2 = (int)((e >> 18) & 1023);
+        st.a3 = 2 * bv;
+        st.addr_fresh = true;
+    }
+}
+
+// A probe of the binary search decided WITHOUT quantising it (MP3_Encoder.py:958-996 with :373-415, :266-291, :998-1036 inside).
+// The early probes sit at steps far too fine for the budget: all the search wants from them is "the bits reach max_bits" and
+// the side effects of the loop body.  quantize is monotone in |xr| (DevTables::rl_t1 / _t2 / _t8: the smallest |xr| of the step
+// whose quantised value is >= 1, >= 2, > 8192), so which of its three ways out the probe takes and, if the body runs, its run
+// lengths -- hence count1, big_values and the region addresses, exactly -- come from ten comparisons per lane; and every
+// non-zero value costs a sign bit, every big-value pair and every count1 quadruple at least one bit of code: when that sum
+// alone reaches the limit the decision stands.  Returns the probe's `bit` (100000 as the caller sets it for quantize's two
+// refusals, else that lower bound) or -1: undecided, the caller runs the probe in full (the side effects applied here are
+// the ones it applies again).  q_early: quantize's early out (:394-395), which leaves the kept quantisation valid.
+__device__ __forceinline__ int rl_precheck(const RlTables &tb, const uint32_t (&xa)[2 * RL_NP], RlState &st, int step, uint32_t scalei,
+                                           uint32_t xrmax, int limit, bool &q_early)
+{
+    q_early = false;
+    const int idx = step + 127;
+    if (idx < 0 || idx > 127) return -1;
+    if (mulr_u(xrmax, scalei) > 165140u) { q_early = true; return 100000; }
+    const uint32_t t1 = (uint32_t)c_tab.rl_t1[idx], t2 = (uint32_t)c_tab.rl_t2[idx], t8 = (uint32_t)c_tab.rl_t8[idx];
+    if (xrmax >= t8) return 100000;
+    int k0 = 0, k1 = 0;
+    uint32_t nnz = 0;
+#pragma unroll
+    for (int m = 0; m < RL_NP; m++) {
+        const uint32_t pm = max(xa[2 * m], xa[2 * m + 1]);
+        k0 = pm >= t1 ? m + 1 : k0;
+        k1 = pm >= t2 ? m + 1 : k1;
+        nnz += (xa[2 * m] >= t1 ? 1u : 0u) + (xa[2 * m + 1] >= t1 ? 1u : 0u);
+    }
+    rl_run_lengths(tb, k0, k1, st);
+    const int lb = (int)wave_add_u32(nnz) + st.big_values + st.count1;
+    return lb >= limit ? lb : -1;
+}
+
 // calc_run_len + count1_bit_count + __subdivide + __big_v_tab_select + big_v_bit_count
 // `limit`: the caller only wants to know whether the bit count reaches it (binary search: max_bits; inner loop:
 // max_bits + 1).  A lower bound -- exact count1 bits + per big-value pair the shortest code any candidate book has for it
@@ -182,38 +242,17 @@ __device__ __forceinline__ int rl_body(const RlTables &tb, const int32_t (&ix)[2
                                        RlState &st, const uint8_t *__restrict__ hide, int n_hide, int cursor,
                                        int limit, bool ub_ok, bool &full)
 {
-    // ---- calc_run_len: highest non-zero pair P0, highest pair holding a value > 1 P1.  Values are >= 0 here, so "some value
-    //      of the pair > 1" is (x | y) > 1.  Per lane the highest slot (+1), then the highest lane.
-    uint32_t o[RL_NP];
+    // ---- calc_run_len: highest non-zero pair, highest pair holding a value > 1.  Values are >= 0 here, so "some value
+    //      of the pair > 1" is (x | y) > 1.
     int k0 = 0, k1 = 0;
 #pragma unroll
     for (int m = 0; m < RL_NP; m++) {
-        o[m] = (uint32_t)(ix[2 * m] | ix[2 * m + 1]);
-        k0 = o[m] != 0 ? m + 1 : k0;
-        k1 = o[m] > 1 ? m + 1 : k1;
+        const uint32_t o = (uint32_t)(ix[2 * m] | ix[2 * m + 1]);
+        k0 = o != 0 ? m + 1 : k0;
+        k1 = o > 1 ? m + 1 : k1;
     }
-    const unsigned long long nzm = __ballot(k0 != 0), bgm = __ballot(k1 != 0);
-    const int L0 = 63 - (nzm ? __builtin_clzll(nzm) : 0), L1 = 63 - (bgm ? __builtin_clzll(bgm) : 0);
-    const int r0 = __builtin_amdgcn_readlane(k0, L0), r1 = __builtin_amdgcn_readlane(k1, L1);
-    const int P0 = nzm ? 5 * L0 + r0 - 1 : -1, P1 = bgm ? 5 * L1 + r1 - 1 : -1;
-    const int count1 = (P0 - P1) >> 1;
-    const int bv = (P0 + 1) - 2 * count1;
-    st.count1 = count1;
-    st.big_values = bv;
-
-    // ---- __subdivide (addresses are left untouched when big_values == 0: E7)
-    const int bvr = 2 * bv;
-    if (bv == 0) {
-        st.r0c = 0; st.r1c = 0;
-        if (!st.addr_fresh) st.used_addr_in = true;
-    } else {
-        // __subdivide (:1008-1036) depends on big_values only: looked up in the per-rate table built on the host
-        const uint32_t e = tb.subdiv[bv < 289 ? bv : 288];
-        st.r0c = (int)(e & 15); st.r1c = (int)((e >> 4) & 7);
-        st.a1 = (int)((e >> 8) & 1023); st.a2 = (int)((e >> 18) & 1023);
-        st.a3 = bvr;
-        st.addr_fresh = true;
-    }
+    rl_run_lengths(tb, k0, k1, st);
+    const int count1 = st.count1, bv = st.big_values, bvr = 2 * bv;
 
     // ---- one pass over the lane's pairs: table word of the pair (lower / upper bound of the big-value bits: pairs below
     //      big_values at their shortest code; every pair the regions can reach -- with big_values == 0 the stale address2
@@ -546,6 +585,18 @@ __device__ __forceinline__ void rate_units(
             int body_step = 1 << 20, body_bits = 0;   // step whose quantisation + rl_body results are still in ix / st
             uint32_t sc = rl_scale_of(next + count / 2);
             asm volatile("s_mov_b32 %0, %0" : "+s"(sc));   // arrived before the loop: inside it no use of `sc` has to wait for the loads issued at its top
+            {
+                // the first probe (step -60) is decided from thresholds where that can be done (rl_precheck): in front of the loop, whose
+                // registers it then does not share
+                const uint32_t sc_lo = rl_scale_of(next + 30), sc_hi = rl_scale_of(next + 90);
+                bool q_early;
+                const int bit = rl_precheck(tb, xa, st, next + 60, sc, xrmax, max_bits, q_early);
+                if (bit >= 0) {
+                    if (bit < max_bits) { count = 60; sc = sc_lo; }
+                    else { next += 60; count -= 60; sc = sc_hi; }
+                    asm volatile("s_mov_b32 %0, %0" : "+s"(sc));
+                }
+            }
             do {
                 const int half = count / 2;
                 // the scales of the two steps the search may probe next, asked for now

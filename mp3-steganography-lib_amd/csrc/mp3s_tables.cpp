@@ -301,6 +301,36 @@ void build()
     }
     for (int i = 0; i < 10000; i++)
         T.int2idx[i] = (uint16_t)(int32_t)(std::sqrt(std::sqrt((double)i) * (double)i) - 0.0946 + 0.5);
+    {
+        // thresholds of rl_precheck.  ln = mulr(|xr|, steptabi) = (|xr| * scalei + 2^31) >> 32 is monotone in |xr|, int2idx in ln, the float
+        // branch's int(sqrt(sqrt(d) * d)), d = |xr| * steptab * 4.656612875e-10, in |xr|: "quantised value >= v" is "|xr| >= T".
+        int l1 = 0, l2 = 0;                              // smallest ln with int2idx[ln] >= 1, >= 2
+        while (l1 < 9999 && T.int2idx[l1] < 1) l1++;
+        while (l2 < 9999 && T.int2idx[l2] < 2) l2++;
+        auto at_least = [](int ln, uint32_t scalei) -> uint32_t {   // smallest a with (a * scalei + 2^31) >> 32 >= ln
+            if (scalei == 0) return 0xffffffffu;
+            const unsigned __int128 need = ((unsigned __int128)(uint32_t)ln << 32) - (1ull << 31);
+            const unsigned __int128 a = (need + scalei - 1) / scalei;
+            return a > 0x80000000ull ? 0xffffffffu : (uint32_t)a;     // (|xr| <= 2^31)
+        };
+        for (int i = 0; i < 128; i++) {
+            const uint32_t sc = (uint32_t)T.steptabi[i];
+            T.rl_t1[i] = at_least(l1, sc);
+            T.rl_t2[i] = at_least(l2, sc);
+            // float branch (values whose ln >= 10000): the kernel's own expression, correctly rounded square roots on both sides
+            auto big = [&](uint64_t a) {
+                const double dbl = (double)(uint32_t)a * T.steptab[i] * 4.656612875e-10;
+                return (int32_t)std::sqrt(std::sqrt(dbl) * dbl) > 8192;
+            };
+            const uint64_t lo_ln = at_least(10000, sc);    // below it a value takes the table branch (<= 1000)
+            uint64_t lo = lo_ln, hi = 0x80000000ull;
+            if (lo_ln == 0xffffffffu || !big(hi)) T.rl_t8[i] = 0xffffffffu;
+            else {
+                while (lo < hi) { const uint64_t mid = (lo + hi) / 2; if (big(mid)) hi = mid; else lo = mid + 1; }
+                T.rl_t8[i] = (uint32_t)lo;
+            }
+        }
+    }
 
     set_huff(0, 0, 0, 0, 0, nullptr, nullptr);
     set_huff(1, 2, 2, 0, 0, ISO_HCOD_1, ISO_HLEN_1);

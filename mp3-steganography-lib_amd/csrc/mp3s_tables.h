@@ -114,6 +114,10 @@ struct DevTables {
     //      every workgroup from the four code-length tables
     uint32_t rl_hl[256][2];     // (lands on a 16-byte boundary: huf_tab is aligned, what lies between is 4 096 + 16 bytes)
     uint32_t rl_c1w[16];
+    // ---- k_rate_loop's look at a probe of the binary search WITHOUT quantising it (rl_precheck): per quantiser step (index step + 127)
+    //      the smallest |xr| whose quantised value is >= 1, >= 2, and -- through quantize's float branch -- > 8192 (0xffffffff: none).
+    //      quantize is monotone in |xr|: ix >= v  <=>  |xr| >= threshold (MP3_Encoder.py:396-409)
+    uint32_t rl_t1[128], rl_t2[128], rl_t8[128];
 };
 
 struct HostHuff {

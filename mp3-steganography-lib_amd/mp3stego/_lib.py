@@ -1076,7 +1076,7 @@ DEV_TABLES_DTYPE = np.dtype([
     ("hlen16", "u1", (256,)), ("hlen24", "u1", (256,)), ("hlen_c1a", "u1", (16,)), ("linbits", "u1", (32,)),
     ("linmax", "<i4", (32,)), ("transform", "u1", (32, 2)), ("dec_max", "u1", (32,)),
     ("huf_tinfo", "<u4", (32,)), ("_pad_huf_tab", "u1", (8,)), ("huf_tab", "<u2", (10256 + 1200 + 2560,)),   # (huf_tab is alignas(16))
-    ("hcod", "<u4", (4, 256)), ("hcod_c1a", "u1", (16,)), ("rl_hl", "<u4", (256, 2)), ("rl_c1w", "<u4", (16,))], align=True)   # (the struct is 16-byte aligned)
+    ("hcod", "<u4", (4, 256)), ("hcod_c1a", "u1", (16,)), ("rl_hl", "<u4", (256, 2)), ("rl_c1w", "<u4", (16,)), ("rl_t1", "<u4", (128,)), ("rl_t2", "<u4", (128,)), ("rl_t8", "<u4", (128,))], align=True)   # (the struct is 16-byte aligned)
 
 
 def debug_tables():
