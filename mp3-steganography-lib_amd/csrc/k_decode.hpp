@@ -552,7 +552,7 @@ __device__ __forceinline__ void synth_fetch_rows(unsigned char *stage, const dou
 }
 
 template <int TW>
-__global__ __launch_bounds__(TW * 64 * 2, 5) void k_dec_synth(
+__global__ __launch_bounds__(TW * 64 * 2, 4) void k_dec_synth(
     const double *__restrict__ S, long T, const mp3s_frame_hdr *__restrict__ hdr, int nch, int n_halo, int out_format,
     void *__restrict__ pcm_out, int sf_base)
 {

@@ -1,4 +1,4 @@
-"""The fast int16 synthesis (k_dec_synth_fast) behind its guard: int16 PCM equal to the exact kernel's -- which is the
+"""The fast int16 decode (k_dec_stream; k_dec_imdct<true> + k_dec_synth_fast with MP3S_OPT_FUSED_DECODE = 0) behind its guard: int16 PCM equal to the exact kernel's -- which is the
 reference's, bit for bit (tests/test_gpu_parity.py, tests/test_decode_corpus.py) -- also when the guard is made so wide that
 most samples take the exact path, and on streams that start and stop inside a tile."""
 import os
@@ -26,15 +26,18 @@ def test_fast_synthesis_equals_exact_kernel(mlib, golden_dir, orc):
         exact = [np.array(ctx.decode_stream(s, mlib.MP3S_PCM_I16)["pcm"]) for s in streams]
         exact_batch = [np.array(r["pcm"]) for r in ctx.decode_streams(streams, mlib.MP3S_PCM_I16)]
         assert np.array_equal(exact[4], orc.pcm_to_i16(orc.decode(streams[4])["pcm"]))
-        counts = {}
-        for scale in (1.0, 1e3, 1e6, 1e9):
-            ctx.synth_mode(scale)
-            fast = [np.array(ctx.decode_stream(s, mlib.MP3S_PCM_I16)["pcm"]) for s in streams]
-            batch = [np.array(r["pcm"]) for r in ctx.decode_streams(streams, mlib.MP3S_PCM_I16)]
-            counts[scale] = ctx.synth_mode(scale)
-            for k in range(len(streams)):
-                assert np.array_equal(fast[k], exact[k]), (scale, k)
-                assert np.array_equal(batch[k], exact_batch[k]), (scale, k)
+        # both fast paths: the one-kernel stream (k_dec_stream, the default) and the two kernels with S in device memory
+        for fused in (0, 1):
+            ctx.set_option("fused_decode", fused)
+            counts = {}
+            for scale in (1.0, 1e3, 1e6, 1e9):
+                ctx.synth_mode(scale)
+                fast = [np.array(ctx.decode_stream(s, mlib.MP3S_PCM_I16)["pcm"]) for s in streams]
+                batch = [np.array(r["pcm"]) for r in ctx.decode_streams(streams, mlib.MP3S_PCM_I16)]
+                counts[scale] = ctx.synth_mode(scale)
+                for k in range(len(streams)):
+                    assert np.array_equal(fast[k], exact[k]), (fused, scale, k)
+                    assert np.array_equal(batch[k], exact_batch[k]), (fused, scale, k)
         # the guard's share: next to nothing at the proven bound (a flagged sample takes the 32 of its slot and channel with it),
         # a large share when inflated a billion times
         total = 2 * sum(e.size for e in exact)
