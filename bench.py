@@ -743,7 +743,11 @@ def main():
                                       "what": "MP3S_OPT_FLOAT_FAST = 1: the same step through the fast sums, unguarded; default (the numbers beside this) = bit-identical to the reference"},
                        "frames_per_s": round(n / (dms * 1e-3), 1), "ms_per_step": round(dms, 4), "steps": kd,
                        "hbm_gbs_algorithmic": round(B_DEC * n / (dms * 1e-3) / 1e9, 2),
-                       "hbm_frac": round(B_DEC * n / (dms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5)}
+                       "hbm_frac": round(B_DEC * n / (dms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),
+                       "headline": "the config-2 number is frames_per_s / ms_per_step / hbm_frac on THIS level: the default, float32 bit-identical to the "
+                                   "reference's float64 rounded once (the exact kernels); float_fast is the option within north_star's 1e-5",
+                       }
+        decode_only["float_fast"]["hbm_frac"] = round(B_DEC * n / (dms_fast * 1e-3) / 1e9 / HBM_PEAK_GBS, 5)
 
     # ---------------------------------------------------------------- regions (ii) and (iii): host-fed
     regions, e2e_steady, short_files, long_message, sustained, octx = {}, None, None, None, None, None
@@ -1041,6 +1045,10 @@ def main():
             "host_walk_ms_per_batch": e2e_steady["host_scan_ms_per_batch"] if e2e_steady else None,
             "host_issue_ms_per_batch": e2e_steady["host_issue_ms_per_batch"] if e2e_steady else None,
             "pcie_gb_s": round((e2e_steady["bytes_in_per_batch"] + e2e_steady["bytes_out_per_batch"]) / (e2e_steady["ms_per_batch"] * 1e-3) / 1e9, 2) if e2e_steady else None}
+    try:
+        host.update(ctx.host_share())            # page-locked bytes pooled / cap, the ranks it believes share the host, CPUs on the GPU's NUMA node
+    except Exception:                             # noqa: BLE001
+        pass
     hosts = [host]
     if dist is not None:
         hosts = [None] * world
@@ -1101,6 +1109,21 @@ def main():
                             "peak_is": f"{N_SIMD} SIMDs x {CLOCK_GHZ} GHz / {CLK_PER_VALU} clk per wave instruction (fp64 and 32-bit "
                                        "multiplies issue at >= 4 clk per wave64 on a SIMD-32: tools/ubench/valu_rates.hip measures 4.5)",
                             "pmc_source": pm.get("source", "profiles/pmc_latest.json")}
+            # ... and against the rate its OWN instruction mix can issue at: the listing's vector instructions by class (tools/kernel_mix.py)
+            # times the measured cost of each class (tools/ubench/issue_rates.hip: plain 32-bit VOP1/VOP2 1.2 ns per wave instruction and SIMD,
+            # VOP3 / DPP / compares / multiplies / fp64 1.9, v_mad_u64_u32 2.3, lane reads 2.4 -- five waves per SIMD, whatever the clock was)
+            try:
+                rates = json.load(open(os.path.join(ROOT, "profiles", "r05_issue_rates.json")))
+                mix = json.load(open(os.path.join(ROOT, "profiles", "r05_kernel_mix.json")))[dom]
+                ns = {"full": rates["v_add_u32"]["ns_5"], "half": rates["v_bfe_u32"]["ns_5"], "mad64": rates["v_mad_u64_u32"]["ns_5"], "lane": rates["v_readlane_b32"]["ns_5"]}
+                mean_ns = sum(mix.get(c, 0) * ns[c] for c in ns) / max(1, sum(mix.get(c, 0) for c in ns))
+                peak_mix = N_SIMD / mean_ns                                   # G wave-instructions / s
+                roofline_alu.update({"peak_of_its_mix": round(peak_mix, 1), "frac_of_its_mix": round(ach / peak_mix, 4),
+                                     "mix": {c: mix.get(c, 0) for c in ns}, "ns_per_wave_instruction_by_class": {c: round(v, 3) for c, v in ns.items()},
+                                     "mean_ns_per_wave_instruction": round(mean_ns, 3),
+                                     "mix_source": "profiles/r05_kernel_mix.json (listing) x profiles/r05_issue_rates.json (measured)"})
+            except Exception:
+                pass
         except Exception:
             roofline_alu = None
 
@@ -1154,14 +1177,14 @@ def main():
                        "sample_rate": 44100, "channels": 2, "bitrate_kbps": 128, "message_bits": int(len(hide)),
                        "chain_verdict_units_to_redo": int(verdict[0]), "message_variant_entries": n_ent, "pipeline_rate_passes": int(final["rate_passes"]),
                        "parallelism": f"frames sharded over {world} GPU(s), no collective"},
+            "sustained": sustained,
             "roofline": roofline,
             "roofline_alu": roofline_alu,
             "cpu_baseline": cpu,
-            "value_four_streams": four,
             "e2e_steady": e2e_steady,
-            "sustained": sustained,
-            "regions": regions,
             "decode_only": decode_only,
+            "value_four_streams": four,
+            "regions": regions,
             "long_message": long_message,
             "kernels_ms_per_step": {k: round(v, 4) for k, v in per_step.items()},
             "kernels_ms_note": f"event pairs around every kernel, separate untimed pass of {n_prof} steps; the timed region "

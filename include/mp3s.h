@@ -149,8 +149,9 @@ int mp3s_ctx_wait(mp3s_ctx *ctx, mp3s_ctx *other);
                                     * formats are bit-identical to the reference [MP3S_FLOAT_FAST=1 -> 1] */
 #define MP3S_OPT_FAIL_CHUNK 14     /* test aid: the k-th chunk (k = value, counted from 1) of the next one-file call fails with MP3S_E_HIP after
                                     * its front end has been queued; the option clears itself when it fires */
-#define MP3S_OPT_FUSED_DECODE 15   /* 1 (default): the fast decode paths (int16; float32 under MP3S_OPT_FLOAT_FAST) run IMDCT and synthesis as ONE kernel, the
-                                    * subband samples between them staying in LDS; 0: two kernels with the samples in device memory [MP3S_FUSED_DECODE=0 -> 0] */
+#define MP3S_OPT_FUSED_DECODE 15   /* 1 (default): the fast decode paths (int16; float32 under MP3S_OPT_FLOAT_FAST) run requantisation .. synthesis as ONE
+                                    * kernel, a wave-local stream with no array between IMDCT and synthesis (k_decode_stream.hpp; timed as dec_synth);
+                                    * 0: two kernels with the subband samples in device memory [MP3S_FUSED_DECODE=0 -> 0] */
 #define MP3S_OPT_COUNT 16
 /* what became of the one-file calls of this context (mp3s_hide_message, mp3s_clear_file, mp3s_decode_file, mp3s_decode_stream,
  * mp3s_hide_message_chunked): files that went through the overlapped stages as chunks, their chunks, chunks that were run
@@ -163,6 +164,15 @@ typedef struct {
     int64_t rehearsal_us, rehearsals, lanes, queue_shared;
 } mp3s_run_stats;
 int mp3s_ctx_run_stats(mp3s_ctx *ctx, mp3s_run_stats *out);
+/* What a rank of a multi-process launch holds of the host (all optional): page-locked bytes this PROCESS keeps pooled between calls and the
+ * cap it keeps them under (the ranks of a host share its lockable memory: 4 GB / LOCAL_WORLD_SIZE, at least 1 GB), the ranks it believes
+ * share the host, the CPUs it may run on, and how many of those lie on the NUMA node of the context's GPU (what a pipe's workers and
+ * staging are bound to with MP3S_OPT_NUMA; 0 = unknown, nothing is bound). */
+typedef struct {
+    uint64_t pinned_pooled_bytes, pinned_pool_cap_bytes;
+    int32_t local_world_size, cpus_allowed, gpu_node_cpus, reserved;
+} mp3s_host_share;
+int mp3s_ctx_host_share(mp3s_ctx *ctx, mp3s_host_share *out);
 int mp3s_ctx_set_option(mp3s_ctx *ctx, int option, int64_t value);
 int mp3s_ctx_get_option(mp3s_ctx *ctx, int option, int64_t *value);
 /* host copy of the constant tables uploaded to the device (struct DevTables of csrc/mp3s_tables.h), for tests */

@@ -140,6 +140,14 @@ public:
         return true;
     }
     uint8_t *data() const { return p_; }
+    // what the process keeps pooled right now, and the cap (mp3s_ctx_host_share)
+    static void pool_state(size_t *held, size_t *cap)
+    {
+        std::lock_guard<std::mutex> g(mu());
+        size_t h = 0;
+        for (auto &e : free_list()) h += e.second;
+        *held = h; *cap = pool_cap();
+    }
 
 private:
     void release()

@@ -178,7 +178,7 @@ SYMBOLS = ["mp3s_ctx_create", "mp3s_ctx_destroy", "mp3s_ctx_wait", "mp3s_last_er
            "mp3s_hide_message", "mp3s_clear_file", "mp3s_hide_message_fd", "mp3s_clear_file_fd", "mp3s_decode_file_fd", "mp3s_hide_messages", "mp3s_reencode_block", "mp3s_reveal_message",
            "mp3s_pipe_create", "mp3s_pipe_destroy", "mp3s_pipe_submit", "mp3s_pipe_submit_decode", "mp3s_pipe_collect", "mp3s_pipe_get_stats",
            "mp3s_index_stream", "mp3s_index_free", "mp3s_scan_range", "mp3s_decode_block_indexed", "mp3s_reencode_block_indexed",
-           "mp3s_hide_message_chunked", "mp3s_walk_stream", "mp3s_parse_frames_dev", "mp3s_stego_bits", "mp3s_ctx_set_option", "mp3s_ctx_get_option", "mp3s_ctx_run_stats", "mp3s_dev_copy", "mp3s_pipe_submit_block", "mp3s_pipe_collect_block", "mp3s_pipe_next_is_block", "mp3s_debug_walk_rate", "mp3s_device_count", "mp3s_device_pci"]
+           "mp3s_hide_message_chunked", "mp3s_walk_stream", "mp3s_parse_frames_dev", "mp3s_stego_bits", "mp3s_ctx_set_option", "mp3s_ctx_get_option", "mp3s_ctx_run_stats", "mp3s_ctx_host_share", "mp3s_dev_copy", "mp3s_pipe_submit_block", "mp3s_pipe_collect_block", "mp3s_pipe_next_is_block", "mp3s_debug_walk_rate", "mp3s_device_count", "mp3s_device_pci"]
 
 _lib = None
 _lock = threading.Lock()
@@ -368,6 +368,16 @@ class Context:
         a = (C.c_int64 * 9)()
         check(lib().mp3s_ctx_run_stats(self.handle, a))
         return dict(zip(("files", "chunks", "reruns", "resolved", "fallbacks", "rehearsal_us", "rehearsals", "lanes", "queue_shared"), list(a)))
+
+    def host_share(self):
+        """what this rank holds of the host: dict(pinned_pooled_bytes, pinned_pool_cap_bytes, local_world_size, cpus_allowed,
+        gpu_node_cpus) (mp3s_ctx_host_share)"""
+        class S(C.Structure):
+            _fields_ = [("pinned_pooled_bytes", C.c_uint64), ("pinned_pool_cap_bytes", C.c_uint64), ("local_world_size", C.c_int32),
+                        ("cpus_allowed", C.c_int32), ("gpu_node_cpus", C.c_int32), ("reserved", C.c_int32)]
+        st = S()
+        check(lib().mp3s_ctx_host_share(self.handle, C.byref(st)))
+        return {k: int(getattr(st, k)) for k, _ in S._fields_ if k != "reserved"}
 
     def get_option(self, name):
         v = C.c_int64()

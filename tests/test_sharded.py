@@ -2,6 +2,7 @@
 frames with a one-frame halo / lead and the 17-integer carry between them must reproduce, bit for bit, what one GPU
 makes of the whole stream -- which the other tests pin to the oracle."""
 import json
+import time
 import os
 import socket
 import subprocess
@@ -245,6 +246,37 @@ def test_bench_gpus2_starts_its_own_ranks():
     assert out["n_gpus"] == 2 and out["parity_checked"] is True and out["scaling"] == "weak"
     assert len(out["ranks_on_this_host"]) == 2 and sorted(h["rank"] for h in out["ranks_on_this_host"]) == [0, 1]
     assert out["config"]["parallelism"].startswith("frames sharded over 2 GPU")
+
+
+@pytest.mark.gpu
+def test_five_ranks_side_by_side_on_one_device():
+    """The launch shape of the driver's multi-GPU run before the hardware sees it: five rank processes (a test box lets one user open its card from six processes at once, and
+    the test runner is one of them; the driver's node takes eight ranks) with a context, a pipe and a rehearsal each, all on device 0.  Every rank reports what it
+    holds of the host: its share of the page-locked pool (4 GB / ranks, at least 1 GB), the CPUs it may use and those on the GPU's node."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    env["MP3STEGO_DEVICE"] = "0"
+    t0 = time.time()
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "5", "--steps", "3", "--no-config5", "--no-cpu-baseline",
+                        "--no-single-file-100k", "--no-short-files", "--e2e-batches", "20", "--sustained-seconds", "0", "--frames", "2000"],
+                       env=env, capture_output=True, text=True, timeout=900)
+    wall = time.time() - t0
+    assert r.returncode == 0, r.stderr[-3000:]
+    out = json.loads([l for l in r.stdout.splitlines() if l.strip()][-1])
+    assert out["n_gpus"] == 5 and out["parity_checked"] is True
+    hosts = out["ranks_on_this_host"]
+    assert sorted(h["rank"] for h in hosts) == list(range(5))
+    for h in hosts:
+        assert h["local_world_size"] == 5 and h["cpus_allowed"] >= 1
+        assert h["pinned_pool_cap_bytes"] == max(1 << 30, (4 << 30) // 5) and h["pinned_pooled_bytes"] <= h["pinned_pool_cap_bytes"]
+    assert sum(h["pinned_pooled_bytes"] for h in hosts) <= 5 << 30
+    assert wall < 240, wall
+    tool = os.path.join(ROOT, "tools", "config4.py")
+    one = subprocess.run([sys.executable, tool, "5", "300", "5"], env=env, capture_output=True, text=True, timeout=900)
+    assert one.returncode == 0, one.stderr[-3000:]
+    five = subprocess.run([sys.executable, tool, "5", "300", "5", "--procs", "5"], env=env, capture_output=True, text=True, timeout=900)
+    assert five.returncode == 0, five.stderr[-3000:]
+    a, b = _json_line(one.stdout), _json_line(five.stdout)
+    assert a["ok"] and b["ok"] and b["procs"] == 5 and a["rank_crc32"] == b["rank_crc32"]
 
 
 @pytest.mark.gpu

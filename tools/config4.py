@@ -161,7 +161,7 @@ def main():
                      (total, n_streams, frames, ranks, per_rank),
            "frames": total, "ranks": ranks, "rank_ms": rank_ms, "rank_crc32": ["%08x" % c for c in crc],
            "one_device_all_ranks_s": round(sum(rank_ms) / 1e3, 4), "one_device_frames_per_s": round(total / (sum(rank_ms) / 1e3), 1),
-           "slowest_rank_ms": max(rank_ms), "frames_per_s_if_ranks_ran_side_by_side": round(total / (max(rank_ms) / 1e3), 1),
+           "slowest_rank_ms": max(rank_ms), "extrapolated_not_measured_frames_per_s_if_ranks_ran_side_by_side": round(total / (max(rank_ms) / 1e3), 1),
            "streams_equal_to_single_call": same, "streams": n_streams, "single_call_loop_s": round(t_single, 3),
            "oracle_sample_frames": oracle_frames, "oracle_sample_streams_equal": oracle_same, "oracle_sample_streams": ranks,
            "pipe": {"fast": st["fast"], "resolved": st["resolved"], "slow": st["slow"]}, "inputs_s": round(t_inputs, 1), "total_s": round(time.time() - t_all, 1),
