@@ -43,19 +43,17 @@ constexpr int ENC_ROW = 34;   // int16 per LDS row: 32 samples + 2 pad: 17 dword
 constexpr int ENC_LDS_DW = 79 * 17 + 1;   // per-wave LDS in dwords: the PCM tile (79 rows of 17 dwords), then -- twice -- a 64 x 16 half of the output tile (rows of 17):
                                       // 5.4 KB per wave, 21.5 per workgroup: five workgroups = five waves per SIMD fit a CU's LDS (8.4 KB per wave and four until round 4)
 
-// SB layout: int32 [ch][Ts][32 bands] with Ts = n_frames * 36 slots (a 128-byte row per slot)
-__global__ __launch_bounds__(256, 5) void k_enc_analysis(
-    const int16_t *__restrict__ pcm, const mp3s_frame_hdr *__restrict__ hdr, int n_frames,
-    int32_t *__restrict__ SB, long Ts)
+// The analysis of 64 consecutive slots t0 .. t0 + 63 of channel ch by one wave (lane = slot).  `lds`: ENC_LDS_DW dwords of the wave's own.
+// TILE == false (k_enc_analysis): the subband samples go to SB in device memory, int32 [ch][Ts][32 bands] (a 128-byte row per slot), staged
+// through `lds` so that they leave as 16-byte pieces of the rows.  TILE == true (k_enc_fused): they go to `rows` in LDS, row r of the
+// workgroup's tile at rows + r * ENC_TROW with r = the lane's slot - tile_t0, for the slots [lo, hi) only; `between`() runs once when the
+// wave has read the last sample of its PCM staging (the fused kernel's workgroup barrier: the staging lies inside the tile).
+constexpr int ENC_TROW = 33;  // dwords per row of the fused kernel's tile (32 bands + 1: the slot lanes' writes and the band lanes' reads are conflict free)
+template <bool TILE, class Between>
+__device__ __forceinline__ void enc_analysis_wave(const int16_t *__restrict__ pcm, const mp3s_frame_hdr *__restrict__ hdr, long Ts, int ch, long t0, int lane,
+                                                  uint32_t *lds, int32_t *__restrict__ SB, uint32_t *rows, long tile_t0, long lo, long hi, Between between)
 {
-    __shared__ __attribute__((aligned(16))) uint32_t lds_all[4][ENC_LDS_DW];
-    static_assert(79 * ENC_ROW * 2 <= ENC_LDS_DW * 4, "PCM tile must fit");
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
-    const long wid = (long)xcd_tile() * 4 + wave;
-    const int ch = (int)(wid & 1);
-    const long t0 = (wid >> 1) * 64;          // first slot of this wave
-    if (t0 >= Ts) return;
-    int16_t *tw = reinterpret_cast<int16_t *>(lds_all[wave]);
+    int16_t *tw = reinterpret_cast<int16_t *>(lds);
     // stage rows t0-15 .. t0+63 of channel ch (zeros outside the batch): the tile is one contiguous piece of the interleaved PCM,
     // read 16 bytes (four samples of both channels) per lane and trip, the wave's channel picked out by two byte permutes
     // (sample by sample it was forty trips of a dozen instructions: a tenth of the kernel's vector instructions)
@@ -85,7 +83,7 @@ __global__ __launch_bounds__(256, 5) void k_enc_analysis(
     __builtin_amdgcn_s_waitcnt(0xc07f);
     __builtin_amdgcn_wave_barrier();
     const long t = t0 + lane;
-    const bool valid = t < Ts;
+    const bool valid = t >= 0 && t < Ts;
     long s0 = 0;
     if (valid) s0 = (long)hdr[t / 36].stream_first * 36;
 
@@ -154,9 +152,12 @@ __global__ __launch_bounds__(256, 5) void k_enc_analysis(
     // 0..3 complete bands 0-3, 12-15, 16-19, 28-31, passes 4..7 the other four pieces.
     const bool odd_slot = (t & 1) != 0;      // slot-in-granule parity == slot parity (18 is even)
     __builtin_amdgcn_wave_barrier();         // every lane is done reading the PCM tile
-    uint32_t *ot = lds_all[wave];
-    uint32_t *out = reinterpret_cast<uint32_t *>(SB) + ((long)ch * Ts + t0) * 32;
-    const int rows = (Ts - t0) < 64 ? (int)(Ts - t0) : 64;
+    between();
+    uint32_t *ot = lds;
+    uint32_t *out = TILE ? nullptr : reinterpret_cast<uint32_t *>(SB) + ((long)ch * Ts + t0) * 32;
+    const int n_rows = (Ts - t0) < 64 ? (int)(Ts - t0) : 64;
+    // (TILE) the lane's row of the tile; a lane outside [lo, hi) writes a row nobody reads (the tile's spare row)
+    uint32_t *trow = TILE ? rows + (valid && t >= lo && t < hi ? (t - tile_t0) : -1) * ENC_TROW : nullptr;
     // The coefficients reach the multiplier as scalar operands, eight columns of the pass's four rows at a time (4 x s_load_dwordx8), and the NEXT
     // block's are asked for before this block's products start: every block begins by waiting for its own (asked for a block ago; scalar loads
     // return out of order, so the wait is for everything outstanding and comes BEFORE the next request goes out).  Until round 4's last change a
@@ -212,12 +213,16 @@ __global__ __launch_bounds__(256, 5) void k_enc_analysis(
                 else       { a[1] = (int32_t)(0u - (uint32_t)a[1]); a[3] = (int32_t)(0u - (uint32_t)a[3]); }
             }
             constexpr int q = P & 3;
+            if constexpr (TILE) {
+                trow[P] = (uint32_t)a[0]; trow[15 - P] = (uint32_t)a[1]; trow[16 + P] = (uint32_t)a[2]; trow[31 - P] = (uint32_t)a[3];
+            } else {
             ot[lane * 17 + q] = (uint32_t)a[0];               // piece 0: bands 4g .. 4g + 3 (g = P >> 2)
             ot[lane * 17 + 4 + 3 - q] = (uint32_t)a[1];       // piece 1: bands 12 - 4g .. 15 - 4g
             ot[lane * 17 + 8 + q] = (uint32_t)a[2];           // piece 2: bands 16 + 4g ..
             ot[lane * 17 + 12 + 3 - q] = (uint32_t)a[3];      // piece 3: bands 28 - 4g ..
+            }
             a[0] = a[1] = a[2] = a[3] = 0;
-            if constexpr (q == 3) {
+            if constexpr (q == 3 && !TILE) {
                 // ---- sixteen bands of the 64 slots are complete: out 16 bytes per lane, four lanes (= four pieces) per row, sixteen rows per trip
                 constexpr int g = P >> 2;
                 __builtin_amdgcn_s_waitcnt(0xc07f);
@@ -228,7 +233,7 @@ __global__ __launch_bounds__(256, 5) void k_enc_analysis(
                 for (int r = lane >> 2; r < 64; r += 16) {
                     const uint32_t *src = ot + r * 17 + piece * 4;
                     const uint4 v = make_uint4(src[0], src[1], src[2], src[3]);
-                    if (r < rows) *reinterpret_cast<uint4 *>(out + r * 32 + band0) = v;
+                    if (r < n_rows) *reinterpret_cast<uint4 *>(out + r * 32 + band0) = v;
                 }
                 __builtin_amdgcn_s_waitcnt(0xc07f);
                 __builtin_amdgcn_wave_barrier();         // (the tile is free for the other sixteen bands)
@@ -241,35 +246,34 @@ __global__ __launch_bounds__(256, 5) void k_enc_analysis(
     });
 }
 
+// SB layout: int32 [ch][Ts][32 bands] with Ts = n_frames * 36 slots (a 128-byte row per slot)
+__global__ __launch_bounds__(256, 5) void k_enc_analysis(
+    const int16_t *__restrict__ pcm, const mp3s_frame_hdr *__restrict__ hdr, int n_frames,
+    int32_t *__restrict__ SB, long Ts)
+{
+    __shared__ __attribute__((aligned(16))) uint32_t lds_all[4][ENC_LDS_DW];
+    static_assert(79 * ENC_ROW * 2 <= ENC_LDS_DW * 4, "PCM tile must fit");
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+    const long wid = (long)xcd_tile() * 4 + wave;
+    const int ch = (int)(wid & 1);
+    const long t0 = (wid >> 1) * 64;          // first slot of this wave
+    if (t0 >= Ts) return;
+    enc_analysis_wave<false>(pcm, hdr, Ts, ch, t0, lane, lds_all[wave], SB, nullptr, 0, 0, 0, [] {});
+}
+
 // mdct layout: int32 [frame][ch][gr][576]  (reference __mdct_freq)
 // One wave per FRAME: lane = (channel, band) transforms both granules, which share 18 of their 36 input rows and every
 // cos_l coefficient (a scalar operand loaded once for two multiply-adds).  Results go to an LDS tile [granule][channel]
 // [line k][band] (rows padded to 33), where the alias butterflies between neighbouring bands are applied
 // (MP3_Encoder.py:704-744, util.cmuls :143-155) and from where the four 576-line blocks leave as full rows.
 constexpr int MD_ROW = 33, MD_BLK = 18 * MD_ROW;
-__global__ __launch_bounds__(256, 4) void k_enc_mdct(
-    const int32_t *__restrict__ SB, long Ts, const mp3s_frame_hdr *__restrict__ hdr, int n_frames,
-    int32_t *__restrict__ mdct)
+
+// Two consecutive granules ga, ga + 1 of both channels from their 54 rows of subband samples in[] (18 of the granule in front, 18 + 18 of
+// their own), lane = (channel, band): the MDCT sums, the alias butterflies through the wave's tile xs (4 * MD_BLK dwords, block = granule
+// in the pair * 2 + channel), and the blocks of the granules g_lo <= g < g_hi out as full rows.  (MP3_Encoder.py:681-744)
+__device__ __forceinline__ void enc_mdct_pair(const int32_t (&in)[54], int32_t *xs, int lane, int32_t *__restrict__ mdct, long ga, long g_lo, long g_hi)
 {
-    __shared__ int32_t xs_all[4][4 * MD_BLK];
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
-    const int f = xcd_tile() * 4 + wave;
-    if (f >= n_frames) return;
-    int32_t *xs = xs_all[wave];
     const int ch = lane >> 5, band = lane & 31;
-    const bool has_prev = f > (int)hdr[f].stream_first;   // l3_sb_sample[ch][0] starts zeroed
-    const int32_t *row = SB + ((long)ch * Ts + (long)f * 36) * 32 + band;
-    // (the rows of the frame in front through an address that exists either way: compiled as an unconditional load + select -- as a
-    // fully unrolled variant of this kernel was in round 4 -- `row - 18 * 32` of a batch's first frame lies in front of the buffer)
-    const int32_t *prow = has_prev ? row - 18 * 32 : row;
-    int32_t in[54];
-#pragma unroll
-    for (int j = 0; j < 18; j++) {
-        const int32_t pv = prow[j * 32];
-        in[j] = has_prev ? pv : 0;
-        in[18 + j] = row[j * 32];
-        in[36 + j] = row[(18 + j) * 32];
-    }
     int32_t *x0 = xs + ch * MD_BLK + band, *x1 = x0 + 2 * MD_BLK;   // block index = granule * 2 + channel
     // The 36 coefficients of output k are one scalar batch (9 x s_load_dwordx4).  All scalar loads of a wave share one counter
     // that can only be waited to zero, and the compiler waits where a value is first used: the batch of output k + 1 is
@@ -320,16 +324,105 @@ __global__ __launch_bounds__(256, 4) void k_enc_mdct(
     }
     __builtin_amdgcn_s_waitcnt(0xc07f);
     __builtin_amdgcn_wave_barrier();
-    int32_t *o = mdct + (long)f * 4 * 576;
 #pragma unroll
-    for (int q = 0; q < 4; q++) {            // output block (channel, granule), tile block (granule, channel)
-        const int32_t *src = xs + ((q & 1) * 2 + (q >> 1)) * MD_BLK;
+    for (int q = 0; q < 4; q++) {            // tile block q = (granule in the pair, channel) -> the reference's [frame][ch][gr][576]
+        const long g = ga + (q >> 1);
+        if (g < g_lo || g >= g_hi) continue;
+        const int32_t *src = xs + q * MD_BLK;
+        int32_t *o = mdct + (((g >> 1) * 2 + (q & 1)) * 2 + (g & 1)) * 576;
 #pragma unroll
         for (int t = 0; t < 9; t++) {
             const int e = lane + 64 * t, b = (e * 3641) >> 16, k = e - 18 * b;   // e = band * 18 + k
-            o[q * 576 + e] = src[k * MD_ROW + b];
+            o[e] = src[k * MD_ROW + b];
         }
     }
+}
+
+__global__ __launch_bounds__(256, 4) void k_enc_mdct(
+    const int32_t *__restrict__ SB, long Ts, const mp3s_frame_hdr *__restrict__ hdr, int n_frames,
+    int32_t *__restrict__ mdct)
+{
+    __shared__ int32_t xs_all[4][4 * MD_BLK];
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+    const int f = xcd_tile() * 4 + wave;
+    if (f >= n_frames) return;
+    const int ch = lane >> 5, band = lane & 31;
+    const bool has_prev = f > (int)hdr[f].stream_first;   // l3_sb_sample[ch][0] starts zeroed
+    const int32_t *row = SB + ((long)ch * Ts + (long)f * 36) * 32 + band;
+    // (the rows of the frame in front through an address that exists either way: compiled as an unconditional load + select -- as a
+    // fully unrolled variant of this kernel was in round 4 -- `row - 18 * 32` of a batch's first frame lies in front of the buffer)
+    const int32_t *prow = has_prev ? row - 18 * 32 : row;
+    int32_t in[54];
+#pragma unroll
+    for (int j = 0; j < 18; j++) {
+        const int32_t pv = prow[j * 32];
+        in[j] = has_prev ? pv : 0;
+        in[18 + j] = row[j * 32];
+        in[36 + j] = row[(18 + j) * 32];
+    }
+    enc_mdct_pair(in, xs_all[wave], lane, mdct, 2l * f, 2l * f, 2l * f + 2);
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------
+// Analysis and MDCT in ONE kernel: the subband samples between them (the reference's l3_sb_sample, MP3_Encoder.py:652-749: the filter
+// bank is called from inside __mdct_sub) stay in LDS.
+// A workgroup of eight waves owns EF_GR consecutive granules of both channels.
+//   phase 1, lane = slot: its waves analyse the granules' 18 EF_GR slots and the 18 of the granule in front (what the first MDCT
+//     overlaps with: computed again rather than carried) -- 4 waves x 64 lanes per channel, 252 of 256 lanes at work -- exactly as
+//     k_enc_analysis does (enc_analysis_wave), into a tile of rows [channel][slot][32 bands + 1] in LDS.  The waves' PCM staging
+//     lies INSIDE the tile: a barrier separates the last read of a sample from the first row written.
+//   phase 2, lane = (channel, band): seven of the waves take two consecutive granules each (the seventh one), read their 54 rows
+//     from the tile, and -- behind a barrier, after which the tile is dead -- run enc_mdct_pair with their butterfly tile where
+//     the rows were (7 x 4 blocks are the tile's size to the byte).
+// No SB array, one launch; the analysis of one granule in thirteen is done twice.
+// ---------------------------------------------------------------------------------------------------------------------------
+constexpr int EF_GR = 13, EF_SLOTS = 18 * (EF_GR + 1), EF_WAVES = 8;
+constexpr int EF_TILE_DW = 2 * (EF_SLOTS + 1) * ENC_TROW;          // per channel one spare row in front (what lanes outside the tile write)
+static_assert(EF_SLOTS <= 4 * 64, "four analysis waves per channel");
+static_assert(EF_WAVES * ENC_LDS_DW <= EF_TILE_DW, "the waves' PCM staging fits the tile");
+static_assert(((EF_GR + 1) / 2) * 4 * MD_BLK <= EF_TILE_DW, "the MDCT waves' butterfly tiles fit the tile");
+
+__global__ __launch_bounds__(EF_WAVES * 64, 4) void k_enc_fused(
+    const int16_t *__restrict__ pcm, const mp3s_frame_hdr *__restrict__ hdr, int n_frames, int32_t *__restrict__ mdct)
+{
+    __shared__ __attribute__((aligned(16))) uint32_t tile[EF_TILE_DW];
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+    const long Ts = (long)n_frames * 36, n_gran = (long)n_frames * 2;
+    const long g0 = (long)xcd_tile() * EF_GR;                      // the workgroup's granules g0 .. g0 + EF_GR - 1
+    const long s0 = g0 * 18, t_first = s0 - 18;                    // ... their slots, and the tile's first row
+    // ---- phase 1
+    {
+        const int ch = wave >> 2;
+        const long t0 = t_first + 64 * (wave & 3);
+        uint32_t *rows = tile + ((long)ch * (EF_SLOTS + 1) + 1) * ENC_TROW;
+        enc_analysis_wave<true>(pcm, hdr, Ts, ch, t0, lane, tile + wave * ENC_LDS_DW, nullptr, rows, t_first, t_first, t_first + EF_SLOTS,
+                                [] { __syncthreads(); });
+    }
+    __syncthreads();                                               // every row of the tile is written
+    // ---- phase 2: the granules in pairs (even, odd) = the two of a frame, so that the second one never starts a stream; a pair that reaches
+    //      out of the workgroup's range on either side computes that granule too and drops it
+    const long ga = g0 - (g0 & 1) + 2 * wave;                      // this wave's granules ga, ga + 1
+    const long g_hi = g0 + EF_GR < n_gran ? g0 + EF_GR : n_gran;
+    const bool unit = ga < g_hi;                                   // (seven of the eight waves; fewer at the end of the batch)
+    int32_t in[54];
+    if (unit) {
+        const int ch = lane >> 5, band = lane & 31;
+        // l3_sb_sample[ch][0] starts zeroed (MP3_Encoder.py:528-534): a stream's first granule overlaps with zeros
+        const bool has_prev = ga >= g0 && ga > (long)hdr[ga >> 1].stream_first * 2;      // (ga == g0 - 1: its result is dropped)
+        // row 0 of the tile is slot 18 (g0 - 1); rows of the granule in front of ga from r_prev on (not there for ga == g0 - 1)
+        const long r_prev = (ga - g0) * 18;
+        const uint32_t *row = tile + ((long)ch * (EF_SLOTS + 1) + 1 + (r_prev >= 0 ? r_prev : 0)) * ENC_TROW + band;
+        const long r_own = r_prev >= 0 ? 18 : 0;                   // the granule's own rows from here
+#pragma unroll
+        for (int j = 0; j < 18; j++) {
+            const int32_t pv = (int32_t)row[j * ENC_TROW];
+            in[j] = has_prev ? pv : 0;
+            in[18 + j] = (int32_t)row[(r_own + j) * ENC_TROW];
+            in[36 + j] = ga + 1 < g_hi ? (int32_t)row[(r_own + 18 + j) * ENC_TROW] : 0;
+        }
+    }
+    __syncthreads();                                               // every wave has its rows: the tile is free
+    if (unit) enc_mdct_pair(in, reinterpret_cast<int32_t *>(tile) + wave * 4 * MD_BLK, lane, mdct, ga, g0, g_hi);
 }
 
 }  // namespace mp3s

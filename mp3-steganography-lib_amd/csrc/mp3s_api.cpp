@@ -129,6 +129,7 @@ int mp3s_ctx_create(int device, mp3s_ctx **out)
         c->opt[MP3S_OPT_FLOAT_FAST] = env("MP3S_FLOAT_FAST", 0) != 0;
         c->opt[MP3S_OPT_FAIL_CHUNK] = 0;
         c->opt[MP3S_OPT_FUSED_DECODE] = env("MP3S_FUSED_DECODE", 1) != 0;
+        c->opt[MP3S_OPT_FUSED_ENCODE] = env("MP3S_FUSED_ENCODE", 0) != 0;
     }
     if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess ||
         hipEventCreate(&c->ev0) != hipSuccess || hipEventCreate(&c->ev1) != hipSuccess ||
@@ -434,9 +435,10 @@ int mp3s_encode_transform_dev(mp3s_ctx *c, const int16_t *d_pcm, const mp3s_fram
     if (!host_tables().analysis_plan_ok)
         return fail(MP3S_E_TABLES, "the analysis filter table built on this host does not repeat itself where the kernel shares products "
                                    "(csrc/analysis_plan.h: run tools/gen_analysis_plan.py here and rebuild)");
-    int rc = c->ensure_scratch_enc(enc_scratch_bytes(n_frames));
+    const bool fused = c->opt[MP3S_OPT_FUSED_ENCODE] != 0;
+    int rc = fused ? MP3S_OK : c->ensure_scratch_enc(enc_scratch_bytes(n_frames));   // (the fused kernel keeps the subband samples in LDS)
     if (rc) return rc;
-    const int e = launch_encode(c->stream, d_pcm, d_hdr, n_frames, d_mdct, c->scratch_enc, &c->prof);
+    const int e = launch_encode(c->stream, d_pcm, d_hdr, n_frames, d_mdct, c->scratch_enc, &c->prof, fused);
     if (e) return fail(MP3S_E_HIP, "encode launch: %s", hipGetErrorString((hipError_t)e));
     return MP3S_OK;
 }

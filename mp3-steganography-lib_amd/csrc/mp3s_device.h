@@ -49,7 +49,7 @@ int launch_decode(hipStream_t stream, const int16_t *d_is, const mp3s_granule_si
 // scratch: subband samples int32 [2][32][36 n]
 size_t enc_scratch_bytes(int n_frames);
 int launch_encode(hipStream_t stream, const int16_t *d_pcm, const mp3s_frame_hdr *d_hdr, int n_frames, int32_t *d_mdct,
-                  void *d_scratch, Profiler *prof);
+                  void *d_scratch, Profiler *prof, bool fused = false /* MP3S_OPT_FUSED_ENCODE: one kernel, no scratch (d_scratch may be null) */);
 
 // entries behind the launch's own units: unit d_unit[e] once more with cursor d_cursor[e] and no inherited state, results
 // to element e of d_ix / d_out / d_en (the message variants the device chooses from, launch_select)

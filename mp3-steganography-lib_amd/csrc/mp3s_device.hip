@@ -158,8 +158,16 @@ size_t enc_scratch_bytes(int n_frames)
 }
 
 int launch_encode(hipStream_t stream, const int16_t *d_pcm, const mp3s_frame_hdr *d_hdr, int n_frames, int32_t *d_mdct,
-                  void *d_scratch, Profiler *prof)
+                  void *d_scratch, Profiler *prof, bool fused)
 {
+    if (fused) {
+        // analysis and MDCT as one kernel, the subband samples in LDS (k_enc_fused); timed as the analysis
+        const long n_gran = (long)n_frames * 2;
+        const int pf = prof ? prof->begin(stream, K_ENC_ANALYSIS) : -1;
+        hipLaunchKernelGGL(k_enc_fused, dim3((unsigned)((n_gran + EF_GR - 1) / EF_GR)), dim3(EF_WAVES * 64), 0, stream, d_pcm, d_hdr, n_frames, d_mdct);
+        if (prof) prof->end(stream, pf);
+        return (int)hipGetLastError();
+    }
     const long Ts = (long)n_frames * 36;
     int32_t *SB = (int32_t *)d_scratch;
     const long waves = 2 * ((Ts + 63) / 64);

@@ -117,7 +117,20 @@ def test_encode_transform_golden(ctx, mlib, orc, golden_dir):
     # extreme samples
     rng = np.random.default_rng(7)
     hard = rng.choice(np.array([-32768, 32767, 0, 1, -1], dtype=np.int16), size=(8 * 1152, 2))
-    assert np.array_equal(ctx.encode_transform(hard), orc.encode(hard, 44100, 320)["mdct_freq"])
+    want_hard = orc.encode(hard, 44100, 320)["mdct_freq"]
+    assert np.array_equal(ctx.encode_transform(hard), want_hard)
+    # the same through the one-kernel form (MP3S_OPT_FUSED_ENCODE: analysis and MDCT in one launch, the subband samples in LDS): tiles of 13
+    # granules, so 60 frames make ten workgroups whose first granule is even and odd in turn
+    long_pcm = np.concatenate([pcm, hard, pcm[:16 * 1152]])
+    want_long = ctx.encode_transform(long_pcm)
+    assert np.array_equal(want_long, orc.encode(long_pcm, 44100, 320)["mdct_freq"])
+    old = ctx.set_option("fused_encode", 1)
+    try:
+        assert np.array_equal(ctx.encode_transform(pcm), mdct)
+        assert np.array_equal(ctx.encode_transform(hard), want_hard)
+        assert np.array_equal(ctx.encode_transform(long_pcm), want_long)
+    finally:
+        ctx.set_option("fused_encode", old)
 
 
 @pytest.mark.parametrize("name", ["plain320", "hide_ddd320"])
