@@ -142,6 +142,7 @@ struct mp3s_pipe {
     FileUp up;
     bool internal = false;               // the context's own (run_file): no worker threads, jobs issued by the caller
     size_t max_job_bytes = 0;
+    size_t max_frames = 0;               // frames a job can have at most (the context's own pipe cuts its chunks by frames); 0: from the bytes, 96 per frame
     std::vector<Slot> slots;
     hipStream_t s_up = nullptr, s_down = nullptr;
     hipStream_t s_dec = nullptr;         // the decode transforms of job k+1 under the encode transforms and the rate loop of job k (null: on the compute stream)
@@ -189,7 +190,9 @@ int issue_down(mp3s_pipe *P, Job &j, Slot &s);
 void sync_all(mp3s_pipe *P);
 void bind_to(const std::vector<int> &cpus);
 bool finish_fast(mp3s_pipe *P, Job *j, Slot &s, bool *resolved);
-int pipe_create(mp3s_ctx *c, int depth, size_t max_job_bytes, int scan_threads, bool internal, mp3s_pipe **out);
+int pipe_create(mp3s_ctx *c, int depth, size_t max_job_bytes, int scan_threads, bool internal, mp3s_pipe **out, size_t max_frames = 0);
+// the slot's buffers exist (made on first need in the context's own pipe); false: out of memory
+bool pipe_slot_ready(mp3s_pipe *P, Slot &s);
 // ---- pipe_lanes.cpp
 int pick_lanes(mp3s_ctx *c, hipStream_t *up, hipStream_t *down, hipStream_t *huff, hipStream_t *comp /* a stream to compute on instead of the context's, or null */,
                hipStream_t *tail /* a stream for the tail of a job, or null */, int want_tail /* 0: none, 1: always, 2: if the rehearsal is faster with it */,

@@ -783,7 +783,53 @@ void free_slot(Slot &s)
 
 }  // namespace
 
-int pipe_create(mp3s_ctx *c, int depth, size_t max_job_bytes, int scan_threads, bool internal, mp3s_pipe **out)
+// a slot's staging and device buffers (sizes from the pipe's): 20 - 60 MB of page-locked memory and as much on the device, milliseconds
+// to pin -- a user's pipe takes all its slots when it is made, the context's own pipe takes a slot when a chunk first needs it
+// (a two-chunk file never pays for the third)
+bool pipe_slot_ready(mp3s_pipe *P, Slot &s)
+{
+    if (s.h_stage) return true;
+    const size_t max_job_bytes = P->max_job_bytes;
+    const bool internal = P->internal;
+    cpu_set_t before;
+    const bool rebind = !P->node_cpus.empty() && sched_getaffinity(0, sizeof before, &before) == 0;
+    if (rebind) bind_to(P->node_cpus);           // (first touch of the page-locked staging on the GPU's NUMA node)
+    const unsigned ord_flags = trace_on() ? hipEventDefault : hipEventDisableTiming;   // (a traced run prints when each stage of a chunk ended)
+    bool ok = true;
+    {
+        // main data: the file minus headers plus alignment and 8 zero bytes per frame; frames: 96 bytes is the smallest
+        // Layer III frame (32 kbit/s at 48 kHz); anything denser (false syncs) overflows the sink and takes the other path.
+        // (The context's own pipe cuts its chunks by FRAMES and says how many a chunk can have: max_frames.)
+        s.blob_cap = (max_job_bytes + max_job_bytes / 8 + 4096 + 15) & ~(size_t)15;
+        s.side_cap = P->max_frames > 0 ? P->max_frames + 16 : max_job_bytes / 96 + 16;
+        s.in_cap = (s.side_cap * (72 + 16) + max_job_bytes / 4 + (size_t)kMaxFastFiles * (sizeof(mp3s_chain_seg) + sizeof(mp3s_select_span)) + s.side_cap * 4 * MP3S_SELECT_VARIANTS * 8 + 4096 + 15) & ~(size_t)15;   // (+ variant entries: at most 10 per unit, 8 bytes each)
+        s.o_side = s.blob_cap;
+        s.o_in = (s.o_side + s.side_cap * sizeof(mp3s_frame_side) + 15) & ~(size_t)15;
+        s.fix_cap = internal ? 8 : std::min<size_t>(kMaxFastFiles, s.side_cap);     // (host-decoded last frames: one per file of a job; the context's own pipe runs ONE file's chunks)
+        s.pack_cap = (s.in_cap + s.fix_cap * kPlaceEntry + s.side_cap * sizeof(FrameRef) + (size_t)kMaxFastFiles * sizeof(StreamRef) + 256 + 15) & ~(size_t)15;
+        s.stage_bytes = s.o_in + s.pack_cap;
+        s.o_dechdr = s.stage_bytes;
+        s.o_tsel = (s.o_dechdr + s.side_cap * sizeof(mp3s_frame_hdr) + 15) & ~(size_t)15;
+        s.image_cap = max_job_bytes + 2 * kImageLead + (size_t)kMaxFastFiles * 16 + 4096;
+        s.mp3_cap = max_job_bytes + s.side_cap + 4096;
+        if (hipHostMalloc((void **)&s.h_stage, s.stage_bytes, hipHostMallocDefault) != hipSuccess ||
+            hipMalloc((void **)&s.d_stage, s.o_tsel + s.side_cap * 8 + 64) != hipSuccess || hipMalloc((void **)&s.d_image, s.image_cap) != hipSuccess ||
+            hipMalloc((void **)&s.d_mp3, s.mp3_cap) != hipSuccess || hipMalloc((void **)&s.d_small, small_bytes(kMaxFastFiles)) != hipSuccess ||
+            // (only e_start and e_down are read as times; the ordering events carry no time stamps: 1 % per job)
+            hipEventCreate(&s.e_start) != hipSuccess || hipEventCreateWithFlags(&s.e_up, ord_flags) != hipSuccess || hipEventCreateWithFlags(&s.e_in, ord_flags) != hipSuccess ||
+            hipEventCreateWithFlags(&s.e_huff, ord_flags) != hipSuccess || hipEventCreateWithFlags(&s.e_half, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&s.e_comp, ord_flags) != hipSuccess || hipEventCreateWithFlags(&s.e_rate, ord_flags) != hipSuccess ||
+            // the collecting thread sleeps on this one instead of spinning: with one process per GPU on a shared host the
+            // cores are needed by the scan workers (the wake-up latency disappears behind the jobs in flight); the
+            // context's own pipe has no job behind the one it waits for and spins
+            hipEventCreateWithFlags(&s.e_down, internal ? hipEventDefault : hipEventBlockingSync) != hipSuccess)
+            ok = false;
+    }
+    if (rebind) (void)sched_setaffinity(0, sizeof before, &before);
+    if (!ok) { (void)hipGetLastError(); free_slot(s); }
+    return ok;
+}
+
+int pipe_create(mp3s_ctx *c, int depth, size_t max_job_bytes, int scan_threads, bool internal, mp3s_pipe **out, size_t max_frames)
 {
     *out = nullptr;
     HIPCHK(hipSetDevice(c->device));
@@ -811,43 +857,11 @@ int pipe_create(mp3s_ctx *c, int depth, size_t max_job_bytes, int scan_threads, 
     // the page-locked staging of the slots is allocated by a thread that runs on the GPU's NUMA node (first touch), and the
     // workers that fill it stay there
     if (c->opt[MP3S_OPT_NUMA]) P->node_cpus = gpu_node_cpus(c->device);
-    cpu_set_t before;
-    const bool rebind = !P->node_cpus.empty() && sched_getaffinity(0, sizeof before, &before) == 0;
-    if (rebind) bind_to(P->node_cpus);
+    P->max_frames = max_frames;
     P->slots.resize((size_t)depth);
-    bool ok = true;
-    const unsigned ord_flags = trace_on() ? hipEventDefault : hipEventDisableTiming;   // (a traced run prints when each stage of a chunk ended)
-    for (auto &s : P->slots) {
-        // main data: the file minus headers plus alignment and 8 zero bytes per frame; frames: 96 bytes is the smallest
-        // Layer III frame (32 kbit/s at 48 kHz); anything denser (false syncs) overflows the sink and takes the other path
-        s.blob_cap = (max_job_bytes + max_job_bytes / 8 + 4096 + 15) & ~(size_t)15;
-        s.side_cap = max_job_bytes / 96 + 16;
-        s.in_cap = (s.side_cap * (72 + 16) + max_job_bytes / 4 + (size_t)kMaxFastFiles * (sizeof(mp3s_chain_seg) + sizeof(mp3s_select_span)) + s.side_cap * 4 * MP3S_SELECT_VARIANTS * 8 + 4096 + 15) & ~(size_t)15;   // (+ variant entries: at most 10 per unit, 8 bytes each)
-        s.o_side = s.blob_cap;
-        s.o_in = (s.o_side + s.side_cap * sizeof(mp3s_frame_side) + 15) & ~(size_t)15;
-        s.fix_cap = std::min<size_t>(kMaxFastFiles, s.side_cap);
-        s.pack_cap = (s.in_cap + s.fix_cap * kPlaceEntry + s.side_cap * sizeof(FrameRef) + (size_t)kMaxFastFiles * sizeof(StreamRef) + 256 + 15) & ~(size_t)15;
-        s.stage_bytes = s.o_in + s.pack_cap;
-        s.o_dechdr = s.stage_bytes;
-        s.o_tsel = (s.o_dechdr + s.side_cap * sizeof(mp3s_frame_hdr) + 15) & ~(size_t)15;
-        s.image_cap = max_job_bytes + 2 * kImageLead + (size_t)kMaxFastFiles * 16 + 4096;
-        s.mp3_cap = max_job_bytes + s.side_cap + 4096;
-        if (hipHostMalloc((void **)&s.h_stage, s.stage_bytes, hipHostMallocDefault) != hipSuccess ||
-            hipMalloc((void **)&s.d_stage, s.o_tsel + s.side_cap * 8 + 64) != hipSuccess || hipMalloc((void **)&s.d_image, s.image_cap) != hipSuccess ||
-            hipMalloc((void **)&s.d_mp3, s.mp3_cap) != hipSuccess || hipMalloc((void **)&s.d_small, small_bytes(kMaxFastFiles)) != hipSuccess ||
-            // (only e_start and e_down are read as times; the ordering events carry no time stamps: 1 % per job)
-            hipEventCreate(&s.e_start) != hipSuccess || hipEventCreateWithFlags(&s.e_up, ord_flags) != hipSuccess || hipEventCreateWithFlags(&s.e_in, ord_flags) != hipSuccess ||
-            hipEventCreateWithFlags(&s.e_huff, ord_flags) != hipSuccess || hipEventCreateWithFlags(&s.e_half, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&s.e_comp, ord_flags) != hipSuccess || hipEventCreateWithFlags(&s.e_rate, ord_flags) != hipSuccess ||
-            // the collecting thread sleeps on this one instead of spinning: with one process per GPU on a shared host the
-            // cores are needed by the scan workers (the wake-up latency disappears behind the jobs in flight); the
-            // context's own pipe has no job behind the one it waits for and spins
-            hipEventCreateWithFlags(&s.e_down, internal ? hipEventDefault : hipEventBlockingSync) != hipSuccess) {
-            ok = false;
-            break;
-        }
-    }
-    if (rebind) (void)sched_setaffinity(0, sizeof before, &before);
-    if (!ok) return destroy(MP3S_E_NOMEM, "slot allocation failed");
+    // (the context's own pipe: the first slot now, the others when a chunk first lands on them -- pipe_slot_ready)
+    for (size_t k = 0; k < P->slots.size(); k++)
+        if ((!internal || k == 0) && !pipe_slot_ready(P.get(), P->slots[k])) return destroy(MP3S_E_NOMEM, "slot allocation failed");
     if (P->s_comp && !internal) {   // a user's pipe owns its context: the context computes on the pipe's stream until the pipe is gone
         (void)hipStreamSynchronize(c->stream);
         P->s_ctx = c->stream; c->stream = P->s_comp;
@@ -887,7 +901,7 @@ int mp3s_pipe_create(mp3s_ctx *c, int depth, size_t max_job_bytes, int scan_thre
     if (!c || !out || depth < 1 || depth > 64 || scan_threads < 0 || scan_threads > 64 || max_job_bytes < 4096)
         return fail(MP3S_E_ARG, "bad argument (1 <= depth <= 64; 0 <= scan_threads <= 64, 0 = as many as this rank's share of the host's cores allows; max_job_bytes >= 4096)");
     if (scan_threads == 0) scan_threads = default_scan_threads(c);
-    return pipe_create(c, depth, max_job_bytes, scan_threads, false, out);
+    return pipe_create(c, depth, max_job_bytes, scan_threads, false, out, 0);
 }
 
 void mp3s_pipe_destroy(mp3s_pipe *P)

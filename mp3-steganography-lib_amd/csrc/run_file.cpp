@@ -29,12 +29,13 @@ struct RunChunk {
 
 }  // namespace
 
-int ensure_own_pipe(mp3s_ctx *c, size_t chunk_bytes)
+int ensure_own_pipe(mp3s_ctx *c, size_t chunk_bytes, size_t chunk_frames)
 {
-    if (c->own_pipe && c->own_pipe->max_job_bytes >= chunk_bytes) return MP3S_OK;
+    if (c->own_pipe && c->own_pipe->max_job_bytes >= chunk_bytes && c->own_pipe->max_frames >= chunk_frames) return MP3S_OK;
     if (c->own_pipe) { mp3s_pipe_destroy(c->own_pipe); c->own_pipe = nullptr; }
     const size_t want = std::max<size_t>(chunk_bytes + chunk_bytes / 4, (size_t)1 << 20);
-    return pipe_create(c, kRunDepth, want, 0, true, &c->own_pipe);
+    // (chunks are cut by frames: the slots' per-frame arrays are sized by what a chunk can hold, not by the 96-byte frames its bytes could be)
+    return pipe_create(c, kRunDepth, want, 0, true, &c->own_pipe, std::max<size_t>(chunk_frames + chunk_frames / 4, 4096));
 }
 
 // how the streams of the context's own pipe were chosen (mp3s_ctx_run_stats)
@@ -111,7 +112,7 @@ static int run_file_impl(mp3s_ctx *c, const uint8_t *mp3, size_t len, int mode, 
     }
     const long cap_frames = std::max(chunk, first_chunk) + 2;
     // (a message that reaches further than a chunk: the synchronous path's plan over the whole file)
-    if (reach_frames > kMaxChunk || ensure_own_pipe(c, (size_t)cap_frames * (size_t)(fs0 + 2) + 4096)) { c->run_stats.fallbacks++; return kRunFallback; }
+    if (reach_frames > kMaxChunk || ensure_own_pipe(c, (size_t)cap_frames * (size_t)(fs0 + 2) + 4096, (size_t)cap_frames)) { c->run_stats.fallbacks++; return kRunFallback; }
     mp3s_pipe *P = c->own_pipe;
     HIPCHK(hipSetDevice(c->device));
     // (for the duration of the call the context computes on the stream its pipe rehearsed best with, if that is not its own)
@@ -243,6 +244,7 @@ static int run_file_impl(mp3s_ctx *c, const uint8_t *mp3, size_t len, int mode, 
         // chunk's results still wait in it to be copied out, now that their copy is queued behind the next front end)
         j.grab_frames = (int)cap_frames;
         Slot &s = P->slots[(size_t)j.slot];
+        if (!pipe_slot_ready(P, s)) return kRunFallback;
         Chunk &ck = j.ck;
         ck.on = true; ck.decode = decode; ck.refs = refs.data(); ck.first = rc.first; ck.count = rc.count; ck.last = rc.last;
         ck.lead = !decode && rc.first > 0 ? 1 : 0;
