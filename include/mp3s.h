@@ -155,7 +155,7 @@ int mp3s_ctx_wait(mp3s_ctx *ctx, mp3s_ctx *other);
 #define MP3S_OPT_FUSED_ENCODE 16   /* 1: analysis filter bank and MDCT as ONE kernel, the subband samples between them in LDS (k_enc_fused; timed as enc_analysis,
                                     * no encode scratch, 221 MB less traffic per 10 000 frames); 0 (default): two kernels with the samples in device memory --
                                     * measured faster: the one kernel's workgroup barriers and its 67 KB of LDS per workgroup cost more than the round trip
-                                    * through memory (DESIGN.md section 8) [MP3S_FUSED_ENCODE=1 -> 1] */
+                                    * through memory (DESIGN.md section 4.2) [MP3S_FUSED_ENCODE=1 -> 1] */
 #define MP3S_OPT_COUNT 17
 /* what became of the one-file calls of this context (mp3s_hide_message, mp3s_clear_file, mp3s_decode_file, mp3s_decode_stream,
  * mp3s_hide_message_chunked): files that went through the overlapped stages as chunks, their chunks, chunks that were run
