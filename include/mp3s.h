@@ -156,7 +156,9 @@ int mp3s_ctx_wait(mp3s_ctx *ctx, mp3s_ctx *other);
                                     * no encode scratch, 221 MB less traffic per 10 000 frames); 0 (default): two kernels with the samples in device memory --
                                     * measured faster: the one kernel's workgroup barriers and its 67 KB of LDS per workgroup cost more than the round trip
                                     * through memory [MP3S_FUSED_ENCODE=1 -> 1] */
-#define MP3S_OPT_COUNT 17
+#define MP3S_OPT_PIPE_DEC 17       /* 1: a pipe created on this context runs the decode transform of job k + 1 on a stream of its own, under the encode
+                                    * transforms and the rate loop of job k [MP3S_PIPE_DEC=0|1] */
+#define MP3S_OPT_COUNT 18
 /* what became of the one-file calls of this context (mp3s_hide_message, mp3s_clear_file, mp3s_decode_file, mp3s_decode_stream,
  * mp3s_hide_message_chunked): files that went through the overlapped stages as chunks, their chunks, chunks that were run
  * again because they depended on a carry the guess got wrong, chunks whose chains the host resolved, and files that took

@@ -130,6 +130,7 @@ int mp3s_ctx_create(int device, mp3s_ctx **out)
         c->opt[MP3S_OPT_FAIL_CHUNK] = 0;
         c->opt[MP3S_OPT_FUSED_DECODE] = env("MP3S_FUSED_DECODE", 1) != 0;
         c->opt[MP3S_OPT_FUSED_ENCODE] = env("MP3S_FUSED_ENCODE", 0) != 0;
+        c->opt[MP3S_OPT_PIPE_DEC] = env("MP3S_PIPE_DEC", 0) != 0;
     }
     if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess ||
         hipEventCreate(&c->ev0) != hipSuccess || hipEventCreate(&c->ev1) != hipSuccess ||

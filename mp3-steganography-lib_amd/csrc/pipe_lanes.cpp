@@ -16,7 +16,7 @@ namespace {
 // the front-end stream, two spins on the compute stream, a copy down, chained by events exactly as issue_fast chains a
 // job's stages -- through each rotation of the candidates, and keeps the rotation that got them through fastest
 // (about 1 ms per rotation when a pipe is made).
-struct LaneChoice { hipStream_t ctx_stream; int want_tail; hipStream_t up, down, huff, comp, tail, dec, img; LaneReport report; };
+struct LaneChoice { hipStream_t ctx_stream; int want_tail; hipStream_t up, down, huff, comp, tail, dec, img; LaneReport report; int want_dec; };
 struct LanePool {
     std::vector<LaneChoice> chosen;       // what the rehearsal decided for a context's stream (asked again only by another context)
     hipStream_t hi[4] = {nullptr, nullptr, nullptr, nullptr}, lo[4] = {nullptr, nullptr, nullptr, nullptr}, cs[4] = {nullptr, nullptr, nullptr, nullptr};
@@ -108,7 +108,7 @@ int pick_lanes(mp3s_ctx *c, hipStream_t *up, hipStream_t *down, hipStream_t *huf
         lp.ok = true;
     }
     for (const LaneChoice &k : lp.chosen)
-        if (k.ctx_stream == c->stream && k.want_tail == want_tail) {
+        if (k.ctx_stream == c->stream && k.want_tail == want_tail && k.want_dec == want_dec) {
             *up = k.up; *down = k.down; *huff = k.huff;
             if (comp) *comp = k.comp;
             if (tail) *tail = k.tail;
@@ -181,8 +181,15 @@ int pick_lanes(mp3s_ctx *c, hipStream_t *up, hipStream_t *down, hipStream_t *huf
     }
     // (a stream of their own for the decode transforms gained nothing in this pipe -- bench.py's resident step on four contexts
     // does: +4 % -- and is not rehearsed)
-    if (dec) *dec = nullptr;
-    (void)want_dec;
+    // ... and, MP3S_OPT_PIPE_DEC, a stream for the decode transforms of job k + 1 under the encode side of job k: the first compute candidate
+    // that is neither the compute nor the tail stream (not rehearsed: what the miniature's spins say about two compute-heavy kernels side
+    // by side is nothing; bench.py's sustained region is the judge)
+    int best_dec = -1;
+    if (dec) {
+        *dec = nullptr;
+        for (int di = 3; di >= 0 && want_dec && best_dec < 0; di--) if (di != best_cs && di != best_tail) best_dec = di;
+        if (best_dec >= 0) *dec = lp.cs[best_dec];
+    }
     LaneReport rep;
     rep.rehearsal_ms = now_ms() - t_begin; rep.rehearsals = runs;
     rep.lanes = (int64_t)best | ((int64_t)(best_cs + 1) << 8) | ((int64_t)(best_tail + 1) << 16);
@@ -194,7 +201,7 @@ int pick_lanes(mp3s_ctx *c, hipStream_t *up, hipStream_t *down, hipStream_t *huf
     *up = lp.hi[best]; *down = lp.hi[(best + 1) & 3]; *huff = lp.lo[best];
     if (img) *img = lp.hi[(best + 2) & 3];
     if (report) *report = rep;
-    lp.chosen.push_back({c->stream, want_tail, *up, *down, *huff, comp ? *comp : nullptr, tail ? *tail : nullptr, nullptr, lp.hi[(best + 2) & 3], rep});
+    lp.chosen.push_back({c->stream, want_tail, *up, *down, *huff, comp ? *comp : nullptr, tail ? *tail : nullptr, dec ? *dec : nullptr, lp.hi[(best + 2) & 3], rep, want_dec});
     return 0;
 }
 
