@@ -47,7 +47,9 @@ bool file_up_begin(mp3s_pipe *P, const uint8_t *file, size_t len, size_t first_b
     }
     // the file-wide side records and main data (a frame's main data: at most its own bytes + 511 of reservoir; 8 zero bytes and
     // up to 3 of alignment behind each)
-    const size_t want_frames = (size_t)n_est + 64, want_blob = len + (size_t)(n_est + 64) * 12 + 4096;
+    // (every frame's share counted in full: 511 bytes of reservoir + 8 zero bytes + 3 of alignment -- with 12 per frame, as until round 5, a stream
+    // that uses its reservoir to the full did not fit, its chunks were not file-wide and a mixed-block file went through the stages twice)
+    const size_t want_frames = (size_t)n_est + 64, want_blob = len + (size_t)(n_est + 64) * (511 + 12) + 4096;
     if (want_frames > u.side_cap || want_blob > u.blob_cap) {
         if (u.d_side) (void)hipFree(u.d_side);
         if (u.d_blob) (void)hipFree(u.d_blob);

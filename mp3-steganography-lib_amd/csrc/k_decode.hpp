@@ -114,11 +114,12 @@ __device__ __forceinline__ GranIn dec_fetch(const int16_t *__restrict__ is, cons
     return in;
 }
 
-// requantise (Frame.py:157-218) and MS stereo (:561-572) of granule `in` for this lane's subband, lines in spectrum order.
-// SH: the kernel's shared block (side, exp2f, exp1f, pow2q, pow2h: DecShared here, FuShared in k_decode_fused.hpp)
+// The side records of a granule's channels into the wave's LDS slice and, from them, the two exponent factors of requantisation per
+// scalefactor slot / gain selector (Frame.py:185-213): what every line's requantisation reads.  SH: the kernel's shared block (side, exp2f,
+// exp1f, pow2q, pow2h: DecShared here, StShared in k_decode_stream.hpp).  bt / cse: this lane's channel's block type and case (0 long,
+// 1 block_type 2, 2 mixed flag with another block type).
 template <class SH>
-__device__ __forceinline__ void dec_requant_ms(const DevTables &tab, SH &sh, int wave, double (&v)[18], const GranIn &in,
-                                               int sr, bool ms, int nch, int lane, int &bt_out, int &cse_out)
+__device__ __forceinline__ void dec_requant_tables(SH &sh, int wave, const GranIn &in, int nch, int lane, int &bt_out, int &cse_out)
 {
     const int ch = lane >> 5, sb = lane & 31;
     const bool live = ch < nch;
@@ -130,8 +131,37 @@ __device__ __forceinline__ void dec_requant_ms(const DevTables &tab, SH &sh, int
     const uint8_t *gb = reinterpret_cast<const uint8_t *>(sh.side[wave][live ? ch : 0]);
     const int gg = gb[0], bt = gb[2] & 3, mixed = gb[3] ? 1 : 0;
     const int mult2 = gb[1] ? 2 : 1, preflag = gb[4] ? 1 : 0;
-    const int cse = bt == 2 ? 1 : (mixed ? 2 : 0);
-    bt_out = bt; cse_out = cse;
+    bt_out = bt; cse_out = bt == 2 ? 1 : (mixed ? 2 : 0);
+    // ---- the two exponent factors depend on the line only through its scalefactor band / window: 61 + 4 values per
+    //      granule and channel, worked out once by the wave (two slots per lane) instead of once per line
+    //      long slot s:  exp2 = mult * (sf_l[s] + preflag * pretab[s]);  short slot 22 + 13 w + s:  exp2 = mult * sf_s[w][s]
+    //      selector 0:   exp1 = gg - 210;  selector 1 + w:  exp1 = gg - 210 - 8 * sub_block_gain[w]
+    double *e2 = sh.exp2f[wave][ch], *e1 = sh.exp1f[wave][ch];
+#pragma unroll
+    for (int h = 0; h < 2; h++) {
+        const int slot = sb + 32 * h;
+        if (slot < 61) {
+            int k2;
+            if (slot < 22) {
+                const int pt = slot < 11 || slot > 20 ? 0 : (int)((0x2333221111ull >> ((slot - 11) * 4)) & 15);   // pre_tab[11..20]
+                k2 = mult2 * ((gb[8 + slot] & 15) + preflag * pt);
+            } else k2 = mult2 * (gb[30 + (slot - 22)] & 15);
+            e2[slot] = sh.pow2h[k2 < POW2H_N ? k2 : POW2H_N - 1];
+        }
+    }
+    if (sb < 4) e1[sb] = sh.pow2q[gg - 210 - (sb ? 8 * (gb[5 + sb - 1] & 7) : 0) - POW2Q_MIN];
+    __builtin_amdgcn_s_waitcnt(0xc07f);
+    __builtin_amdgcn_wave_barrier();
+}
+
+// requantise (Frame.py:157-218) and MS stereo (:561-572) of granule `in` for this lane's subband, lines in spectrum order.
+template <class SH>
+__device__ __forceinline__ void dec_requant_ms(const DevTables &tab, SH &sh, int wave, double (&v)[18], const GranIn &in,
+                                               int sr, bool ms, int nch, int lane, int &bt_out, int &cse_out)
+{
+    const int ch = lane >> 5, sb = lane & 31;
+    dec_requant_tables(sh, wave, in, nch, lane, bt_out, cse_out);
+    const int cse = cse_out;
     // ---- 18 int16 spectrum values (9 dwords) and 18 line-map bytes (5 dwords) of this subband
     uint32_t mw[5];
     const uint32_t (&xw)[9] = in.xw;
@@ -140,27 +170,8 @@ __device__ __forceinline__ void dec_requant_ms(const DevTables &tab, SH &sh, int
 #pragma unroll
         for (int k = 0; k < 5; k++) mw[k] = mp[k];
     }
-    // ---- the two exponent factors depend on the line only through its scalefactor band / window: 61 + 4 values per
-    //      granule and channel, worked out once by the wave (two slots per lane) instead of once per line
-    //      long slot s:  exp2 = mult * (sf_l[s] + preflag * pretab[s]);  short slot 22 + 13 w + s:  exp2 = mult * sf_s[w][s]
-    //      selector 0:   exp1 = gg - 210;  selector 1 + w:  exp1 = gg - 210 - 8 * sub_block_gain[w]
     {
-        double *e2 = sh.exp2f[wave][ch], *e1 = sh.exp1f[wave][ch];
-#pragma unroll
-        for (int h = 0; h < 2; h++) {
-            const int slot = sb + 32 * h;
-            if (slot < 61) {
-                int k2;
-                if (slot < 22) {
-                    const int pt = slot < 11 || slot > 20 ? 0 : (int)((0x2333221111ull >> ((slot - 11) * 4)) & 15);   // pre_tab[11..20]
-                    k2 = mult2 * ((gb[8 + slot] & 15) + preflag * pt);
-                } else k2 = mult2 * (gb[30 + (slot - 22)] & 15);
-                e2[slot] = sh.pow2h[k2 < POW2H_N ? k2 : POW2H_N - 1];
-            }
-        }
-        if (sb < 4) e1[sb] = sh.pow2q[gg - 210 - (sb ? 8 * (gb[5 + sb - 1] & 7) : 0) - POW2Q_MIN];
-        __builtin_amdgcn_s_waitcnt(0xc07f);
-        __builtin_amdgcn_wave_barrier();
+        const double *e2 = sh.exp2f[wave][ch], *e1 = sh.exp1f[wave][ch];
         // ---- requantise (Frame.py:210-215): ((sign * |is|^(4/3)) * 2^(exp1/4)) * 2^(-exp2)
         // (|is|^(4/3) from a scalar base + a 32-bit lane offset: behind the table's 29 KB offset in DevTables the compiler built a 64-bit
         // address per value, three vector instructions more; the map byte's two fields by bit-field extracts)

@@ -244,11 +244,40 @@ __global__ __launch_bounds__(ST_WAVES * 64, 2) void k_dec_stream(
                     v[k] = ch == 0 ? (v[k] + o) / tab.sqrt2 : (o - v[k]) / tab.sqrt2;
                 }
             }
-        } else
-            dec_requant_ms(tab, sh, wave, v, in, sr, ms, NCH, lane, bt, cse);
-        if (cse != 0) {
-            // reorder (Frame.py:574-602) of a short / mixed granule: line k of this subband is line src of the spectrum (or nothing),
-            // computed again from `is` -- requantised and, under MS stereo, combined with the other channel's line src
+        } else {
+            // Everything else.  Both channels in the same short / mixed case (the usual shape of such a granule, and every mono one): a lane
+            // requantises the 18 lines its subband holds AFTER the reorder (Frame.py:574-602: line k of subband sb is line src of the
+            // spectrum, or nothing) straight from `is` -- the other channel's lane of the same subband does the same line, so MS stereo is
+            // the ordinary exchange.  Channels in different cases (rare): in spectrum order first (dec_requant_ms, MS included), then a short /
+            // mixed lane computes its reordered lines again, both channels' values of each (below).
+            const uint32_t sd0a = (uint32_t)__builtin_amdgcn_readlane((int)in.side, 0), sd0b = (uint32_t)__builtin_amdgcn_readlane((int)in.side, 18);
+            auto case_of = [](uint32_t d0) { return ((d0 >> 16) & 3u) == 2u ? 1 : ((d0 >> 24) ? 2 : 0); };
+            const int cse_a = case_of(sd0a), cse_b = NCH == 2 ? case_of(sd0b) : cse_a;
+            if (cse_a == cse_b && cse_a != 0) {
+                dec_requant_tables(sh, wave, in, NCH, lane, bt, cse);
+                const uint32_t *srcw = reinterpret_cast<const uint32_t *>(tab.reorder_src[sr] + sb * 18);
+                uint32_t sw[9];
+#pragma unroll
+                for (int k = 0; k < 9; k++) sw[k] = srcw[k];
+#pragma unroll
+                for (int k = 0; k < 18; k++) {
+                    const int s = (int)(int16_t)(sw[k >> 1] >> ((k & 1) * 16));
+                    v[k] = s >= 0 && live ? st_requant_line(tab, sh, wave, is, g, ch, sr, s) : 0.0;
+                }
+                if (ms && NCH == 2) {
+#pragma unroll
+                    for (int k = 0; k < 18; k++) {
+                        const double o = shfl_xor_f64(v[k], 32);
+                        v[k] = ch == 0 ? (v[k] + o) / tab.sqrt2 : (o - v[k]) / tab.sqrt2;
+                    }
+                }
+                cse = -1;                                           // (its lines are in place)
+            } else
+                dec_requant_ms(tab, sh, wave, v, in, sr, ms, NCH, lane, bt, cse);
+        }
+        if (cse > 0) {
+            // reorder of a short / mixed lane whose other channel is in another case: line k of this subband is line src of the spectrum
+            // (or nothing), computed again from `is` -- requantised and, under MS stereo, combined with the other channel's line src
             const uint32_t *srcw = reinterpret_cast<const uint32_t *>(tab.reorder_src[sr] + sb * 18);
             uint32_t sw[9];
 #pragma unroll
@@ -266,7 +295,7 @@ __global__ __launch_bounds__(ST_WAVES * 64, 2) void k_dec_stream(
                 }
                 v[k] = x;
             }
-        } else {
+        } else if (cse == 0) {
             // alias reduction (Frame.py:604-622): butterflies with line 17 - i of subband sb - 1 and line i of subband sb + 1, the
             // neighbours' lines by DPP wave shifts (both read before either is changed); the edge subbands keep their value
 #pragma unroll
