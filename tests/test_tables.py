@@ -305,3 +305,56 @@ def test_analysis_plan_matches_the_filter_table(mlib, golden_dir):
                     products += 1
             assert word == plan[p][k], (p, k)
     assert products == int(re.search(r"ANALYSIS_PRODUCTS = (\d+)", text).group(1)) == 1516
+
+
+def test_tables_of_the_stream_decode_and_the_first_probe(mlib):
+    """Round 5's tables from their definitions.  k_dec_stream: a lane's 16 cosines as the holder of X[k] and its 16 taps as output i, against
+    the synthesis matrix N[i][j] = cos((16+i)(2j+1)pi/64) and the window D -- V = N S must come out of X = sum_j (S[j] -+ S[31-j]) cx[j], fetched
+    and signed as the kernel does it.  rl_precheck: the thresholds are the smallest |xr| whose quantised value (the reference's quantize,
+    MP3_Encoder.py:373-415, in Python integers) reaches 1, 2 and leaves 8192."""
+    t = mlib.debug_tables()
+    cx, taps = np.array(t["stream_cx"], dtype=np.float64), np.array(t["stream_taps"], dtype=np.float64)
+    rng = np.random.default_rng(5)
+    S = rng.standard_normal(32)
+    # the rows' values: subbands 0..15 hold S[j] - S[31-j] (row-lane j), subbands 16..31 hold S[16+m] + S[15-m] (row-lane m)
+    d = np.array([S[j] - S[31 - j] for j in range(16)])
+    u_rev = np.array([S[16 + m] + S[15 - m] for m in range(16)])
+    X = np.zeros(33)
+    for sb in range(32):
+        k = 2 * sb + 1 if sb < 16 else 2 * (sb - 16)
+        X[k] = float(np.dot(d if sb < 16 else u_rev, cx[sb]))
+    Xt = np.array([sum(S[j] * np.cos((2 * j + 1) * k * np.pi / 64) for j in range(32)) for k in range(33)])
+    assert np.allclose(X[:32], Xt[:32], rtol=0, atol=1e-13)
+    V = np.array(t["synth_matrix"], dtype=np.float64) @ S                       # the reference's V, 64 values
+    win = np.array(t["synth_window"], dtype=np.float64)
+    for i in range(32):
+        ka = 16 + i if i <= 15 else (0 if i == 16 else 48 - i)
+        kb = 16 - i if i <= 15 else i - 16
+        for jj in range(16):
+            want = win[i + 32 * jj] * (V[i] if jj % 2 == 0 else V[32 + i])       # the term of Frame.py:89-101 this slot contributes at lag jj
+            got = taps[0][i][jj] * (Xt[ka] if jj % 2 == 0 else Xt[kb])
+            assert abs(got - want) < 1e-12, (i, jj)
+            assert taps[1][i][jj] == taps[0][i][jj] * 32767.0
+    # ---- thresholds of the first probe
+    steptabi = np.array(t["steptabi"], dtype=np.int64)
+    steptab = np.array(t["steptab"], dtype=np.float64)
+    int2idx = np.array(t["int2idx"], dtype=np.int64)
+    t1, t2, t8 = (np.array(t[k], dtype=np.int64) for k in ("rl_t1", "rl_t2", "rl_t8"))
+
+    def quant(a, i):
+        ln = (int(a) * int(steptabi[i]) + (1 << 31)) >> 32
+        if ln < 10000:
+            return int(int2idx[ln])
+        dbl = np.float64(int(a)) * steptab[i] * np.float64(4.656612875e-10)
+        return int(np.sqrt(np.sqrt(dbl) * dbl))
+    for i in range(128):
+        for thr, v in ((t1[i], 1), (t2[i], 2)):
+            if thr == 0xffffffff:
+                assert quant(1 << 31, i) < v
+            else:
+                assert quant(thr, i) >= v and (thr == 0 or quant(thr - 1, i) < v), (i, v, thr)
+        if t8[i] == 0xffffffff:
+            assert quant(1 << 31, i) <= 8192
+        else:
+            assert quant(t8[i], i) > 8192 and quant(t8[i] - 1, i) <= 8192, (i, t8[i])
+    assert any(t8 != 0xffffffff) and t1[67] == 32768          # (step -60: ln = |xr| / 65536 rounded)
