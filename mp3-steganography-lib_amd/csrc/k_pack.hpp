@@ -11,7 +11,8 @@
 namespace mp3s {
 
 constexpr int PACK_DW = 372;          // LDS image of one frame: 1441 bytes max (320 kbps @ 32 kHz) + slack
-constexpr int PACK_PT_QUAD = 1024, PACK_PT_NONE = 1056, PACK_PT = 1057;   // the code-word table of k_enc_pack
+constexpr int PACK_FAM = 260;         // a book family's 256 words + 4: small values of different families (what a wave mostly reads at once) in different banks
+constexpr int PACK_PT_QUAD = 4 * PACK_FAM, PACK_PT_NONE = PACK_PT_QUAD + 32, PACK_PT = PACK_PT_NONE + 1;   // the code-word table of k_enc_pack
 #define MP3S_PS_OVERFLOW 1            // Huffman bits exceed part2_3_length (cannot happen for rate-loop output)
 #define MP3S_PS_BAD_TABLE 2           // a code book this encoder never selects
 
@@ -46,7 +47,7 @@ __global__ __launch_bounds__(256) void k_enc_pack(
     const int wave0 = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane0 = threadIdx.x & 63;
     for (int i = threadIdx.x; i < 1024; i += 256) {
         const uint32_t len = i < 256 ? c_tab.hlen13[i] : (i < 512 ? c_tab.hlen15[i - 256] : (i < 768 ? c_tab.hlen16[i - 512] : c_tab.hlen24[i - 768]));
-        pt[i] = (&c_tab.hcod[0][0])[i] | (len << 24);
+        pt[(i >> 8) * PACK_FAM + (i & 255)] = (&c_tab.hcod[0][0])[i] | (len << 24);
     }
     if (threadIdx.x < 16) {
         pt[PACK_PT_QUAD + threadIdx.x] = (uint32_t)c_tab.hcod_c1a[threadIdx.x] | ((uint32_t)c_tab.hlen_c1a[threadIdx.x] << 24);
@@ -226,7 +227,7 @@ __global__ __launch_bounds__(256) void k_enc_pack(
         const uint32_t xx = x > 14 ? 15u : x, yy = y > 14 ? 15u : y;
         const uint32_t q = (c2[k] | (c2[k + 1] << 2)) & 15u;
         const bool quad = in_c1 && !((p - bv) & 1);
-        const uint32_t tix = Ke != 0 ? ((Ke & 3u) << 8) + xx * 16u + yy : (quad ? quad_base + q : (uint32_t)PACK_PT_NONE);
+        const uint32_t tix = Ke != 0 ? (Ke & 3u) * (uint32_t)PACK_FAM + xx * 16u + yy : (quad ? quad_base + q : (uint32_t)PACK_PT_NONE);
         const uint32_t word = pt[tix];
         code0[k] = word & 0xffffffu;
         n0[k] = (int)(word >> 24);
@@ -243,7 +244,7 @@ __global__ __launch_bounds__(256) void k_enc_pack(
     // OR-ed into the image, finished or not (an unfinished one is OR-ed again, with more bits, by the next word: the same
     // bits twice do no harm), and position and count move on by arithmetic -- the flush used to be a per-lane branch, ten
     // of them per frame.
-    {
+    if (tot) {   // (the lanes behind the last value hold nothing and all stand on ONE dword: 64 ORs of zero into one address, eleven times)
         const uint32_t pos0 = ustart + (uint32_t)(incl - tot);
         uint32_t d = pos0 >> 5;
         uint32_t cnt = pos0 & 31u;
