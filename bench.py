@@ -706,13 +706,14 @@ def main():
         # as in region (i): the Huffman decode of batch k + 1 on a second context's stream, under the transforms of batch k, two sets of
         # `is` / side records taken in turn (every batch gets its own Huffman launch inside the timed loop); `serial_ms_per_step` = both on one stream
         hctx = None if args.no_overlap else _lib.Context(ctx.device)
-        dstate = {"i": 0}
+        dstate = {"i": 0, "fmt": _lib.MP3S_PCM_F32, "out": d_pcm32}
 
         def dec_step():
+            fmt, d_out = dstate["fmt"], dstate["out"]
             i = dstate["i"]; dstate["i"] = i + 1
             if hctx is None:
                 _lib.check(L.mp3s_huffman_decode_dev(ctx.handle, d_blob, d_side, n, 2, scanned["max_part2_3_length"], d_is2[0], d_si2[0], d_hst2[0]))
-                _lib.check(L.mp3s_decode_transform_dev(ctx.handle, d_is2[0], d_si2[0], d_hdr, n, 2, 0, _lib.MP3S_PCM_F32, d_pcm32))
+                _lib.check(L.mp3s_decode_transform_dev(ctx.handle, d_is2[0], d_si2[0], d_hdr, n, 2, 0, fmt, d_out))
                 return
             cur, nxt = i & 1, (i + 1) & 1
             if i == 0:
@@ -720,7 +721,7 @@ def main():
             ctx.wait_for(hctx)                      # batch i's Huffman output is there
             hctx.wait_for(ctx)                      # ... and the transforms that read the other set are through
             _lib.check(L.mp3s_huffman_decode_dev(hctx.handle, d_blob, d_side, n, 2, scanned["max_part2_3_length"], d_is2[nxt], d_si2[nxt], d_hst2[nxt]))
-            _lib.check(L.mp3s_decode_transform_dev(ctx.handle, d_is2[cur], d_si2[cur], d_hdr, n, 2, 0, _lib.MP3S_PCM_F32, d_pcm32))
+            _lib.check(L.mp3s_decode_transform_dev(ctx.handle, d_is2[cur], d_si2[cur], d_hdr, n, 2, 0, fmt, d_out))
 
         def dec_sync():
             ctx.sync()
@@ -731,7 +732,7 @@ def main():
             t0 = time.perf_counter()
             for _ in range(k):
                 _lib.check(L.mp3s_huffman_decode_dev(ctx.handle, d_blob, d_side, n, 2, scanned["max_part2_3_length"], d_is2[0], d_si2[0], d_hst2[0]))
-                _lib.check(L.mp3s_decode_transform_dev(ctx.handle, d_is2[0], d_si2[0], d_hdr, n, 2, 0, _lib.MP3S_PCM_F32, d_pcm32))
+                _lib.check(L.mp3s_decode_transform_dev(ctx.handle, d_is2[0], d_si2[0], d_hdr, n, 2, 0, dstate["fmt"], dstate["out"]))
             ctx.sync()
             return (time.perf_counter() - t0) / k * 1e3
         for _ in range(3):
@@ -766,6 +767,22 @@ def main():
         dms_fast = min(dms_fast_overlap, dms_fast_serial)
         f32f = ctx.download(d_pcm32, np.float32, (n * 1152, 2))
         ctx.set_option("float_fast", 0)
+        # ... and to int16, the reference's own decode product (MP3_Parser.py:91: the WAV it writes is (pcm * 32767).astype(int16)): the stream
+        # kernel behind its guard + the fix-up kernel, bit-identical
+        dstate.update(i=0, fmt=_lib.MP3S_PCM_I16, out=d_pcm)
+        for _ in range(3):
+            dec_step()
+        dec_sync()
+        dms_i16_serial = dec_serial(kd)
+        dstate["i"] = 0
+        t0 = time.perf_counter()
+        for _ in range(kd):
+            dec_step()
+        dec_sync()
+        dms_i16_overlap = (time.perf_counter() - t0) / kd * 1e3
+        dms_i16 = min(dms_i16_overlap, dms_i16_serial)
+        same = same and bool(np.array_equal(ctx.download(d_pcm, np.int16, (n * 1152, 2)), np.asarray(pcm16).reshape(-1, 2)))
+        dstate.update(i=0, fmt=_lib.MP3S_PCM_F32, out=d_pcm32)
         f64r = f32.astype(np.float64)        # (the exact kernels' float32 = the reference's float64 rounded once: the comparison is against that)
         dd = np.abs(f32f.astype(np.float64) - f64r)
         bigm = np.abs(f64r) > 1e-6
@@ -783,9 +800,14 @@ def main():
                        "hbm_gbs_algorithmic": round(B_DEC * n / (dms * 1e-3) / 1e9, 2),
                        "hbm_frac": round(B_DEC * n / (dms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),
                        "headline": "the config-2 number is frames_per_s / ms_per_step / hbm_frac on THIS level: the default, float32 bit-identical to the "
-                                   "reference's float64 rounded once (the exact kernels); float_fast is the option within north_star's 1e-5",
+                                   "reference's float64 rounded once (the exact kernels); float_fast is the option within north_star's 1e-5; `int16` is the same step to the "
+                                   "samples the reference's decoder actually writes (its WAV), bit-identical through the guarded stream kernel",
                        }
         decode_only["float_fast"]["hbm_frac"] = round(B_DEC * n / (dms_fast * 1e-3) / 1e9 / HBM_PEAK_GBS, 5)
+        decode_only["int16"] = {"ms_per_step": round(dms_i16, 4), "frames_per_s": round(n / (dms_i16 * 1e-3), 1), "serial_ms_per_step": round(dms_i16_serial, 4),
+                                "overlapped_ms_per_step": round(dms_i16_overlap, 4), "hbm_frac": round(9520 * n / (dms_i16 * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),
+                                "what": "the same step to int16 PCM -- the reference's own decode product (MP3_Parser.py:91 writes (pcm * 32767).astype(int16) as the WAV): "
+                                        "k_dec_stream behind its guard + k_dec_fixup, bit-identical; 9 520 algorithmic bytes per frame (4 912 in + 4 608 out)"}
         if hctx is not None:
             hctx.close()
 
