@@ -63,6 +63,9 @@ struct BitStream {
         valid += need ? 32 : 0;
         const uint32_t up = idx + (need ? 1u : 0u);
         idx = up < last ? up : last;
+        // (the staged word is read AFTER the old one was used -- the address is made to depend on the window: one register, no copy and so
+        //  no wait for the word at the loop's back edge)
+        asm volatile("" : "+v"(idx) : "v"((uint32_t)win));
         nxt = lds[idx * T];
     }
     __device__ __forceinline__ uint32_t hi() const { return (uint32_t)(win >> 32); }
@@ -386,8 +389,12 @@ __global__ __launch_bounds__(WAVES * 64) void k_dec_huffman(
         uint32_t ti = 0 < r0p ? ti0 : (0 < r1p ? ti1 : ti2);
         if (!(0 < bve)) { ti = c1n; c1n ^= tog; }
         uint32_t e = *reinterpret_cast<const uint16_t *>(tabb + (ti >> 16) + 2 * __builtin_amdgcn_ubfe(br.hi(), (ti >> 8) & 31, ti & 15));
+        // Eighteen tiles of sixteen pairs: the inner loop is counted and has no way out (as one loop with the write-out and the `break` inside
+        // an `if` the compiler kept two flags and seven scalar instructions per pair alive for them).
         int p = 0;
-        for (;; p++) {
+        for (int tile_no = 0; tile_no < 18; tile_no++) {
+#pragma unroll 4
+        for (int q16 = 0; q16 < 16; q16++, p++) {
             // -- what does not depend on the look-up in flight
             const uint32_t chk = (ti >> 13) & 1;                  // 1: (v, w) of a quadruple -- the entry does not move the window
             const uint32_t am = (chk - 1) & 31u;                  // ... (0; 31 otherwise: code words of up to 19 bits + 2 signs)
@@ -395,7 +402,7 @@ __global__ __launch_bounds__(WAVES * 64) void k_dec_huffman(
             // frame; the staged window covers one code word of that, a second one is reported); a quadruple is only started
             // in front of the last bit and of line 572 (D1: from pair 286 on the compare is lost for every (v, w))
             const uint32_t lim = bit + (chk << (p >= 286 ? 30 : 0));
-            if (__any(lim > mb)) {
+            if (__builtin_expect(__any(lim > mb), 0)) {   // (unlikely: a wave alone on its SIMD pays every TAKEN branch with an empty instruction buffer)
                 if (lim > mb) {
                     if (!chk) err |= MP3S_HS_OVERRUN;
                     bve = 0; c1n = 0; tog = 0; mb = 0xffffffffu;
@@ -411,7 +418,7 @@ __global__ __launch_bounds__(WAVES * 64) void k_dec_huffman(
             uint32_t adv = (e >> 8) & 15;          // code word + sign bits (books 0, 4, 14 -- entry 0: nothing, D2)
             uint32_t out_esc = 0;
             bool escaped = false;
-            if (e & 0xc000u) {                     // (big-values books only)
+            if (__builtin_expect((e & 0xc000u) != 0, 0)) {   // (big-values books only)
                 if (e & 0x8000u) {                 // longer than the index: the next k bits pick the leaf
                     const uint32_t k = (e >> 11) & 15, w = ti & 15;
                     e = tab[HUF_L1_N + 2 * (e & 0x7ffu) + ((hi_old << w) >> (32 - k))];
@@ -439,40 +446,47 @@ __global__ __launch_bounds__(WAVES * 64) void k_dec_huffman(
             const uint32_t en = *reinterpret_cast<const uint16_t *>(tabb + (tn >> 16) + 2 * __builtin_amdgcn_ubfe(br.hi(), (tn >> 8) & 31, tn & 15));
             __builtin_amdgcn_sched_barrier(0);
             br.valid -= (int)step; bit += step;
+            // the window's refill comes FIRST behind the look-up: the staged word it asks for is then old by the time the top of the loop waits
+            // for everything outstanding (it stood last, a dozen instructions in front of that wait)
+            br.refill_always();
+            __builtin_amdgcn_sched_barrier(0);
             // signs: two bits of the window, x's above y's (where they are: the entry); negating a zero changes nothing, so a
             // bit that is no sign may land on a zero
             const uint32_t sg = __builtin_amdgcn_ubfe(hi_old, 30 + ((e >> 12) & 3) - adv, 2);
             const uint32_t mag = ((e >> 4) & 15) | ((e & 15) << 16);
             const uint32_t neg = ((uint32_t)__builtin_amdgcn_sbfe(sg, 1, 1) & 0xffffu) | ((uint32_t)__builtin_amdgcn_sbfe(sg, 0, 1) & 0xffff0000u);
             const uint32_t val = __builtin_bit_cast(uint32_t, __builtin_bit_cast(s16x2, mag ^ neg) - __builtin_bit_cast(s16x2, neg));
-            my_tile[p & 15] = escaped ? out_esc : val;
-            br.refill_always();
+            my_tile[q16] = escaped ? out_esc : val;
             ti = tn; e = en;
-            if ((p & 15) == 15) {
+        }
+            {
                 // the tile: 16 pairs of every row, 64 bytes each, four lanes per row
                 __builtin_amdgcn_wave_barrier();
+                // (the pair counter as the write-out sees it is made opaque: the compiler otherwise keeps the three row addresses as induction
+                //  variables and steps them in EVERY iteration -- five instructions of a chain that issues one every five clocks)
+                const int p0 = __builtin_amdgcn_readfirstlane(p - 16);
 #pragma unroll
                 for (int item = lane; item < LANES * 4; item += 64) {
                     const int r = item >> 2, q = item & 3;
                     if ((rows >> r) & 1) {
                         const uint32_t *t4 = tile + r * 17 + 4 * q;
                         const uint4 v = make_uint4(t4[0], t4[1], t4[2], t4[3]);
-                        *reinterpret_cast<uint4 *>(is32 + (tid0 + r) * 288 + (p - 15) + 4 * q) = v;
+                        *reinterpret_cast<uint4 *>(is32 + (tid0 + r) * 288 + p0 + 4 * q) = v;
                     }
                 }
                 __builtin_amdgcn_wave_barrier();
-                if (p == 287 || !__any(p + 1 < bve || tog != 0)) break;
+                if (!__any(p < bve || tog != 0)) break;      // (p: the pairs done, a multiple of 16)
             }
         }
 #if MP3S_HUF_CLOCKS
         const unsigned long long clk3 = __builtin_readcyclecounter();
 #endif
-        // what no code word reached: zeros, row by row (p + 1 is a multiple of 16)
-        const int rest16 = (288 - (p + 1)) >> 2;          // 16-byte pieces per row
+        // what no code word reached: zeros, row by row
+        const int rest16 = (288 - p) >> 2;          // 16-byte pieces per row
         if (rest16 > 0)
             for (int r = 0; r < LANES; r++) {
                 if (!((rows >> r) & 1)) continue;
-                uint4 *z = reinterpret_cast<uint4 *>(is32 + (tid0 + r) * 288 + (p + 1));
+                uint4 *z = reinterpret_cast<uint4 *>(is32 + (tid0 + r) * 288 + p);
                 for (int i = lane; i < rest16; i += 64) z[i] = make_uint4(0, 0, 0, 0);
             }
 #if MP3S_HUF_CLOCKS
