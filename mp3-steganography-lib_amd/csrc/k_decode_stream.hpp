@@ -480,7 +480,7 @@ __global__ __launch_bounds__(ST_WAVES * 64, 2) void k_dec_stream(
                     if (live) o16[p * 32 * NCH] = (int16_t)(int)x;
                     unsigned long long m = safe ? __ballot(!(fabs(dist) > eps_t)) : ~0ull;
                     if (NCH == 1) m &= 0xffffffffull;
-                    if (m) {                                                    // (wave-uniform, rare)
+                    if (__builtin_expect(m != 0, 0)) {                          // (wave-uniform, rare: out of line)
                         if (lane == 0) {
                             const uint32_t m0 = (uint32_t)m, m1 = (uint32_t)(m >> 32);
                             const int n = (m0 != 0) + (m1 != 0);
