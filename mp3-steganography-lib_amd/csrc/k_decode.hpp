@@ -68,18 +68,6 @@ constexpr int DEC_A_WAVES = 4;
 
 typedef double dvec8 __attribute__((ext_vector_type(8)));
 typedef double dvec2 __attribute__((ext_vector_type(2)));
-struct Row18 { dvec8 a, b; dvec2 c; double w0, w1; };   // IMDCT twiddle row + the window factor of each channel half
-__device__ __forceinline__ Row18 load_row18(const double (*C36)[18], const double *win0, const double *win1, int i)
-{
-    Row18 r;
-    const double *p = C36[i];
-    r.a = *reinterpret_cast<const dvec8 *>(p);
-    r.b = *reinterpret_cast<const dvec8 *>(p + 8);
-    r.c = *reinterpret_cast<const dvec2 *>(p + 16);
-    r.w0 = win0[i]; r.w1 = win1[i];
-    return r;
-}
-
 struct DecShared {
     double pow2q[POW2Q_N];                 // copies of the small exponent tables: random per-lane reads go to LDS
     double pow2h[POW2H_N];
@@ -337,10 +325,6 @@ __device__ __forceinline__ void imdct_run(DecShared &sh, int wave, int lane, con
             const double r3 = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(b), 48), __builtin_amdgcn_readlane(__double2loint(b), 48));
             if (sb == 0 && live) G[(long)g * 2 + ch] = b + (ch ? r3 : r1);
         }
-        // window rows of the two channel halves as scalar pointers; lanes pick theirs with a select
-        const int bt0 = __builtin_amdgcn_readlane(bt, 0), bt1 = __builtin_amdgcn_readlane(bt, 32);
-        const double *win0 = tab.sine_block[bt0], *win1 = tab.sine_block[bt1];
-
         // ---- IMDCT + window (Frame.py:124-148), overlap (:151-153), frequency inversion (:629-631) in the sign
         double *row = S + ((long)(live ? ch : 0) * T + ((long)g * 18 - slot0)) * 32 + sb;
         if (bt != 2) {
@@ -396,37 +380,47 @@ __device__ __forceinline__ void imdct_run(DecShared &sh, int wave, int lane, con
                     cur = nxt; wa = nwa; wb = nwb;
                 }
             } else {
-            // One row of twiddles (18 doubles) + its two window factors per scalar batch.  Scalar loads can only be
-            // waited for all at once, so the row after the one being multiplied is requested first: its latency
-            // passes under 18 multiply-adds per lane.
-            Row18 cur = load_row18(C36, win0, win1, gi >= 0 ? 0 : 18);
+            // One row of twiddles (18 doubles) per scalar batch, the row after the one being multiplied requested first: its latency
+            // passes under 18 multiply-adds per lane.  The window factor is the lane's own read of the staged copy in LDS (as in
+            // the fast rows): with the two channel halves' factors in the scalar batch two rows in flight were 80 scalar registers --
+            // most of this kernel's 400 scalar spills, a read-lane per five products in the rows.  Same doubles, same products.
+            const double *wl = sh.win[bt];
+            Row18s cur = load_row18s(C36, gi >= 0 ? 0 : 18);
+            double wc = wl[gi >= 0 ? 0 : 18];
             if (gi >= 0) {
 #pragma unroll
                 for (int i = 0; i < 18; i++) {
-                    const Row18 nxt = load_row18(C36, win0, win1, i + 1);
+                    __builtin_amdgcn_s_waitcnt(0xc07f);
+                    __builtin_amdgcn_sched_barrier(0);
+                    const Row18s nxt = load_row18s(C36, i + 1);
+                    const double wn = wl[i + 1];
                     __builtin_amdgcn_sched_barrier(0);
                     double x = 0.0;
 #pragma unroll
                     for (int k = 0; k < 18; k++) x += v[k] * (k < 8 ? cur.a[k & 7] : (k < 16 ? cur.b[k & 7] : cur.c[k & 1]));
                     asm volatile("" : "+v"(x));      // (as in the fast path: the sum stays in front of the store's branch)
-                    x = x * (ch == 0 ? cur.w0 : cur.w1) + tail[i];
+                    x = x * wc + tail[i];
                     if ((i) & 1) x = flip(x);
                     if (all_wr) row[(long)i * 32] = x;
                     else if (wr) row[(long)i * 32] = x;
                     __builtin_amdgcn_sched_barrier(0);
-                    cur = nxt;
+                    cur = nxt; wc = wn;
                 }
             }
 #pragma unroll
             for (int i = 18; i < 36; i++) {
-                const Row18 nxt = load_row18(C36, win0, win1, i < 35 ? i + 1 : 35);
+                __builtin_amdgcn_s_waitcnt(0xc07f);
+                __builtin_amdgcn_sched_barrier(0);
+                const int in = i < 35 ? i + 1 : 35;
+                const Row18s nxt = load_row18s(C36, in);
+                const double wn = wl[in];
                 __builtin_amdgcn_sched_barrier(0);
                 double x = 0.0;
 #pragma unroll
                 for (int k = 0; k < 18; k++) x += v[k] * (k < 8 ? cur.a[k & 7] : (k < 16 ? cur.b[k & 7] : cur.c[k & 1]));
-                tail[i - 18] = x * (ch == 0 ? cur.w0 : cur.w1);
+                tail[i - 18] = x * wc;
                 __builtin_amdgcn_sched_barrier(0);
-                cur = nxt;
+                cur = nxt; wc = wn;
             }
             }
         } else {
