@@ -32,6 +32,17 @@
 // window sum can reach) stands for A_max and the same maximum for G_max.  A sample the guard cannot vouch for puts (slot, channel, bit i)
 // on the fix-up list; k_dec_fixup computes it again from `is` in the reference's order.
 #pragma once
+#ifndef MP3S_ST_CLOCKS
+#define MP3S_ST_CLOCKS 0   // 1: shader-clock sums of a wave's phases into g_st_clocks, read by mp3s_debug_st_clocks (a probe: tools/st_clocks.py)
+#endif
+#if MP3S_ST_CLOCKS
+__device__ uint32_t g_st_clocks[4096 * 8];
+extern "C" __attribute__((visibility("default"))) int mp3s_debug_st_clocks(uint32_t *out)
+{
+    (void)hipDeviceSynchronize();
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_st_clocks), sizeof(uint32_t) * 4096 * 8);
+}
+#endif
 
 namespace mp3s {
 
@@ -104,6 +115,10 @@ __global__ __launch_bounds__(ST_WAVES * 64, 2) void k_dec_stream(
 {
     __shared__ StShared sh;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+#if MP3S_ST_CLOCKS
+    const unsigned long long ck_start = __builtin_readcyclecounter();
+    unsigned long long ck_req = 0, ck_rows = 0, ck_syn = 0, ck_setup = 0;
+#endif
     for (int i = threadIdx.x; i < POW2Q_N; i += blockDim.x) sh.pow2q[i] = c_tab.pow2q[i];
     if (threadIdx.x < POW2H_N) sh.pow2h[threadIdx.x] = c_tab.pow2h[threadIdx.x];
     if (threadIdx.x < 144) (&sh.win[0][0])[threadIdx.x] = (&c_tab.sine_block[0][0])[threadIdx.x];
@@ -156,10 +171,16 @@ __global__ __launch_bounds__(ST_WAVES * 64, 2) void k_dec_stream(
     uint32_t mwl[5];
 #pragma unroll
     for (int k = 0; k < 5; k++) mwl[k] = reinterpret_cast<const uint32_t *>(c_tab.rq_map[sr_map][0][sb])[k];
+#if MP3S_ST_CLOCKS
+    ck_setup = __builtin_readcyclecounter() - ck_start;
+#endif
 #pragma unroll 1
     for (int gi = gi0; gi < run; gi++) {
         const int g = ga + gi;
         if (g >= n_granules) break;
+#if MP3S_ST_CLOCKS
+        const unsigned long long ck_a = __builtin_readcyclecounter();
+#endif
         const int first_gran = fh.stream_first > (uint32_t)sf_base ? (int)(fh.stream_first - (uint32_t)sf_base) * 2 : 0;
         const int sr = fh.sr_idx < 3 ? fh.sr_idx : 0;
         const bool ms = fh.ms_stereo != 0;
@@ -330,6 +351,10 @@ __global__ __launch_bounds__(ST_WAVES * 64, 2) void k_dec_stream(
             gm2 = gm1; gm1 = gc;
         }
 
+#if MP3S_ST_CLOCKS
+        const unsigned long long ck_b = __builtin_readcyclecounter();
+        ck_req += ck_b - ck_a;
+#endif
         double S[18];
         if (bt != 2) {
             // ---- long windows: rows 0..8 and their mirrors 17..9 (x[17-i] = -x[i]), then rows 18..26 and their mirrors 35..27; a row's
@@ -430,6 +455,10 @@ __global__ __launch_bounds__(ST_WAVES * 64, 2) void k_dec_stream(
         // the next granule's lines and side records: asked for here, behind the rows (their registers are wanted there), under the synthesis
         have_next = gi + 1 < run && g + 1 < n_granules;
         if (have_next) next_in = dec_fetch(is, si, g + 1, NCH, lane);
+#if MP3S_ST_CLOCKS
+        const unsigned long long ck_c = __builtin_readcyclecounter();
+        ck_rows += ck_c - ck_b;
+#endif
         if (tail_only) continue;
 
         // ---- synthesis of the granule's 18 slots, in time order
@@ -492,7 +521,17 @@ __global__ __launch_bounds__(ST_WAVES * 64, 2) void k_dec_stream(
                 }
             }
         }
+#if MP3S_ST_CLOCKS
+        ck_syn += __builtin_readcyclecounter() - ck_c;
+#endif
     }
+#if MP3S_ST_CLOCKS
+    if (lane == 0) {
+        uint32_t *d = g_st_clocks + ((size_t)(xcd_tile() * ST_WAVES + wave) & 4095) * 8;
+        d[0] = (uint32_t)ck_setup; d[1] = (uint32_t)ck_req; d[2] = (uint32_t)ck_rows; d[3] = (uint32_t)ck_syn;
+        d[4] = (uint32_t)(__builtin_readcyclecounter() - ck_start);
+    }
+#endif
 }
 
 }  // namespace mp3s
