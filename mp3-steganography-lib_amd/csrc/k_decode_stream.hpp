@@ -57,7 +57,8 @@ struct StShared {
     double exp1f[ST_WAVES][2][4];           // ... and 2^(exp1/4) per gain selector
     double win[4][36];                      // sine_block
     double tail[ST_WAVES][18][64];          // per wave: the overlap tail of the granule before, [row][lane]
-    double p43[ST_P43_N];                   // |is|^(4/3) of the small values (most of a stream): an LDS look-up where the whole table is a trip to L2
+    double p43[2 * ST_P43_N];               // sign(is) |is|^(4/3) of the small values (most of a stream), entry is + 512 for -512 <= is < 512: an LDS look-up where
+                                            // the whole table is a trip to L2 -- signed, so that a line needs neither its absolute value nor its sign put back
     double cx[16][32], wt[16][32];          // the synthesis' per-lane constants, [term][subband]: read into registers in front of a granule's 18 slots and
                                             // dead again behind them (64 registers that requantisation and IMDCT have better use for)
 };
@@ -122,7 +123,10 @@ __global__ __launch_bounds__(ST_WAVES * 64, 2) void k_dec_stream(
     for (int i = threadIdx.x; i < POW2Q_N; i += blockDim.x) sh.pow2q[i] = c_tab.pow2q[i];
     if (threadIdx.x < POW2H_N) sh.pow2h[threadIdx.x] = c_tab.pow2h[threadIdx.x];
     if (threadIdx.x < 144) (&sh.win[0][0])[threadIdx.x] = (&c_tab.sine_block[0][0])[threadIdx.x];
-    for (int i = threadIdx.x; i < ST_P43_N; i += blockDim.x) sh.p43[i] = c_tab.pow43[i];
+    for (int i = threadIdx.x; i < 2 * ST_P43_N; i += blockDim.x) {
+        const int x = i - ST_P43_N;
+        sh.p43[i] = x < 0 ? -c_tab.pow43[-x] : c_tab.pow43[x];
+    }
     // the lanes' constants of the synthesis: 16 cosines (as the holder of X[k]: k = 2 (sb & 15) + 1 in the rows of the differences, 2 (sb & 15)
     // in the rows of the sums) and 16 taps (as output i = sb)
     for (int i = threadIdx.x; i < 512; i += blockDim.x) {
@@ -218,13 +222,15 @@ __global__ __launch_bounds__(ST_WAVES * 64, 2) void k_dec_stream(
             auto is_long = [](uint32_t d0) { return ((d0 >> 16) & 3u) != 2u && (d0 >> 24) == 0u; };     // block_type != 2, mixed_block_flag == 0
             quick = is_long(d0a) && (NCH == 1 || is_long(d0b));
             w0 = ch ? d0b : d0a; w1 = ch ? d1b : d1a;
-            uint32_t mx = 0;
+            // every line inside the table: -512 <= is < 512  <=>  (is + 512) has no bit above the tenth, for both halves of a dword at once
+            uint32_t hi_bits = 0;
 #pragma unroll
             for (int k = 0; k < 9; k++) {
-                const int lo16 = (int)(int16_t)in.xw[k], hi16 = (int)in.xw[k] >> 16;
-                mx = max(mx, max((uint32_t)(lo16 < 0 ? -lo16 : lo16), (uint32_t)(hi16 < 0 ? -hi16 : hi16)));
+                uint32_t t;
+                asm("v_pk_add_u16 %0, %1, %2" : "=v"(t) : "v"(in.xw[k]), "v"(0x02000200u));
+                hi_bits |= t;
             }
-            quick = quick && __ballot(mx >= (uint32_t)ST_P43_N) == 0;
+            quick = quick && __ballot((hi_bits & 0xfc00fc00u) != 0) == 0;
         }
         if (quick && sr != sr_map) {
             sr_map = sr;
@@ -249,13 +255,10 @@ __global__ __launch_bounds__(ST_WAVES * 64, 2) void k_dec_stream(
 #pragma unroll
             for (int k = 0; k < 18; k++) {
                 const uint32_t xwk = in.xw[k >> 1];
-                const int x = (int)(int16_t)(xwk >> ((k & 1) * 16));
-                const uint32_t ax = (uint32_t)(x < 0 ? -x : x);
-                const double a = sh.p43[ax];
+                const int x = (k & 1) ? (int)xwk >> 16 : (int)(int16_t)xwk;
+                const double sa = sh.p43[x + ST_P43_N];
                 uint32_t i2;
                 asm("v_bfe_u32 %0, %1, %2, 6" : "=v"(i2) : "v"(mwl[k >> 2]), "n"((k & 3) * 8));
-                const uint32_t sgn = (k & 1) ? xwk : xwk << 16;
-                const double sa = __hiloint2double((int)(((uint32_t)__double2hiint(a) & 0x7fffffffu) | (sgn & 0x80000000u)), __double2loint(a));
                 v[k] = (sa * e1) * e2[i2];
             }
             if (ms && NCH == 2) {
