@@ -203,7 +203,6 @@ __global__ __launch_bounds__(ST_WAVES * 64, 2) void k_dec_stream(
         int zoff = 0;
         asm volatile("" : "+s"(zoff));
         const DevTables &tab = *reinterpret_cast<const DevTables *>(reinterpret_cast<const char *>(&c_tab) + zoff);
-        const double(*C36)[18] = tab.imdct_cos36;
         const double(*C12)[6] = tab.imdct_cos12;
 
         // ---- requantise, MS stereo (dec_requant_ms), then reorder | alias reduction without an exchange buffer
@@ -360,56 +359,95 @@ __global__ __launch_bounds__(ST_WAVES * 64, 2) void k_dec_stream(
 #endif
         double S[18];
         if (bt != 2) {
-            // ---- long windows: rows 0..8 and their mirrors 17..9 (x[17-i] = -x[i]), then rows 18..26 and their mirrors 35..27; a row's
-            //      twiddles (scalar cache), window factors and tail values (LDS) are asked for one row ahead, the wait for them at the
-            //      TOP of a row, in front of the next request (k_dec_imdct)
+            // ---- long windows.  The 36 outputs are 18 values and their mirror images (x[17-i] = -x[i], x[53-i] = x[i]), and the 18 are a
+            //      DCT-IV of the 18 lines: y[n] = sum_k v[k] cos((2n+1)(2k+1) pi/72), rows 0..8 = y[9..17], rows 18..26 = -y[8..0].  In two
+            //      halves (DevTables::imdct_rot / imdct_pq, derivation and error bound in mp3s_tables.cpp): nine rotations of the pairs
+            //      (v[k], v[17-k]) into (p, q), then ten stages m of two nine-term sums P[m], Q[m] that give y[2m] = P + Q and
+            //      y[2m-1] = P - Q -- 236 multiply-adds where the mirrored rows took 324.  Stages 9..5 give the rows that read the old tail,
+            //      stages 4..0 the rows that write the new one.  A stage's 18 factors (scalar cache), its rows' window factors and tail
+            //      values (LDS) are asked for one stage ahead, the wait for them at the TOP of a stage (k_dec_imdct).
             const double *wl = sh.win[bt];
-            Row18s cur;
-            double wa, wb;
-            if (!tail_only) {
-                cur = load_row18s(C36, 0);
-                wa = wl[0]; wb = wl[17];
-                double ta = tl[0], tb = tl[17 * 64];
+            double p[9], q[9];
+            {
+                const Row18s r = load_row18s(tab.imdct_rot, 0);
 #pragma unroll
-                for (int i = 0; i < 9; i++) {
-                    __builtin_amdgcn_s_waitcnt(0xc07f);
-                    __builtin_amdgcn_sched_barrier(0);
-                    const int in2 = i < 8 ? i + 1 : 18;                         // (behind row 8: the first row of the second half)
-                    const Row18s nxt = load_row18s(C36, in2);
-                    const double nwa = wl[in2], nwb = wl[in2 < 18 ? 17 - in2 : 35];
-                    const double nta = in2 < 18 ? (double)tl[in2 * 64] : 0.0, ntb = in2 < 18 ? (double)tl[(17 - in2) * 64] : 0.0;
-                    __builtin_amdgcn_sched_barrier(0);
-                    double y = 0.0;
-#pragma unroll
-                    for (int k = 0; k < 18; k++) y = __builtin_fma(v[k], k < 8 ? cur.a[k & 7] : (k < 16 ? cur.b[k & 7] : cur.c[k & 1]), y);
-                    double xa = y * wa + ta;
-                    double xb = -y * wb + tb;
-                    if (i & 1) xa = flip(xa);
-                    if ((17 - i) & 1) xb = flip(xb);
-                    S[i] = xa; S[17 - i] = xb;
-                    __builtin_amdgcn_sched_barrier(0);
-                    cur = nxt; wa = nwa; wb = nwb; ta = nta; tb = ntb;
+                for (int k = 0; k < 9; k++) {
+                    const double c = 2 * k < 8 ? r.a[2 * k] : (2 * k < 16 ? r.b[2 * k - 8] : r.c[2 * k - 16]);
+                    const double sn = 2 * k + 1 < 8 ? r.a[2 * k + 1] : (2 * k + 1 < 16 ? r.b[2 * k + 1 - 8] : r.c[2 * k + 1 - 16]);
+                    p[k] = __builtin_fma(v[17 - k], sn, v[k] * c);
+                    q[k] = __builtin_fma(v[17 - k], c, -(v[k] * sn));
                 }
-            } else {
-                cur = load_row18s(C36, 18);
-                wa = wl[18]; wb = wl[35];
             }
+            struct StageIn { Row18s c; double w[4], t[4]; };
+            // rows of stage m: the one of y[2m] first (none for m = 9), then the one of y[2m-1] (none for m = 0)
+            auto stage_in = [&](auto mc) {
+                constexpr int m = decltype(mc)::value;
+                StageIn in;
+                in.c = load_row18s(tab.imdct_pq, m);
 #pragma unroll
-            for (int i = 18; i < 27; i++) {
-                __builtin_amdgcn_s_waitcnt(0xc07f);
-                __builtin_amdgcn_sched_barrier(0);
-                const int in2 = i < 26 ? i + 1 : 26;
-                const Row18s nxt = load_row18s(C36, in2);
-                const double nwa = wl[in2], nwb = wl[53 - in2];
-                __builtin_amdgcn_sched_barrier(0);
-                double y = 0.0;
+                for (int h = 0; h < 2; h++) {
+                    const int n = h == 0 ? 2 * m : 2 * m - 1;
+                    in.w[2 * h] = in.w[2 * h + 1] = in.t[2 * h] = in.t[2 * h + 1] = 0.0;
+                    if (n < 0 || n > 17) continue;
+                    if (n >= 9) {                                               // row i = n - 9 and its mirror 17 - i
+                        const int i = n - 9;
+                        in.w[2 * h] = wl[i]; in.w[2 * h + 1] = wl[17 - i];
+                        in.t[2 * h] = tl[i * 64]; in.t[2 * h + 1] = tl[(17 - i) * 64];
+                    } else {                                                    // row i = 26 - n and its mirror 53 - i
+                        const int i = 26 - n;
+                        in.w[2 * h] = wl[i]; in.w[2 * h + 1] = wl[53 - i];
+                    }
+                }
+                return in;
+            };
+            auto stage = [&](auto mc, const StageIn &in) {
+                constexpr int m = decltype(mc)::value;
+                double P = 0.0, Q = 0.0;
 #pragma unroll
-                for (int k = 0; k < 18; k++) y = __builtin_fma(v[k], k < 8 ? cur.a[k & 7] : (k < 16 ? cur.b[k & 7] : cur.c[k & 1]), y);
-                tl[(i - 18) * 64] = y * wa;
-                tl[(35 - i) * 64] = y * wb;
-                __builtin_amdgcn_sched_barrier(0);
-                cur = nxt; wa = nwa; wb = nwb;
+                for (int k = 0; k < 9; k++) {
+                    const double cp = k < 8 ? in.c.a[k] : in.c.b[0];
+                    const double cq = k < 7 ? in.c.b[1 + k] : in.c.c[k - 7];
+                    if (m != 9) P = __builtin_fma(p[k], cp, P);          // (P[9] = 0: its factors are zeros)
+                    if (m != 0) Q = __builtin_fma(q[k], cq, Q);          // (Q[0] = 0)
+                }
+#pragma unroll
+                for (int h = 0; h < 2; h++) {
+                    const int n = h == 0 ? 2 * m : 2 * m - 1;
+                    if (n < 0 || n > 17) continue;
+                    const double y = h == 0 ? P + Q : P - Q;
+                    if (n >= 9) {
+                        const int i = n - 9;
+                        double xa = y * in.w[2 * h] + in.t[2 * h];
+                        double xb = -y * in.w[2 * h + 1] + in.t[2 * h + 1];
+                        if (i & 1) xa = flip(xa);
+                        if ((17 - i) & 1) xb = flip(xb);
+                        S[i] = xa; S[17 - i] = xb;
+                    } else {
+                        const int i = 26 - n;
+                        tl[(i - 18) * 64] = -y * in.w[2 * h];
+                        tl[(35 - i) * 64] = -y * in.w[2 * h + 1];
+                    }
+                }
+            };
+            // (stage by stage, written out: the stage number is a compile-time constant of every one)
+#define MP3S_ST_STAGE(M, MNEXT)                                                                 \
+            {                                                                                   \
+                __builtin_amdgcn_s_waitcnt(0xc07f);                                             \
+                __builtin_amdgcn_sched_barrier(0);                                              \
+                const StageIn nxt = stage_in(std::integral_constant<int, MNEXT>{});             \
+                __builtin_amdgcn_sched_barrier(0);                                              \
+                stage(std::integral_constant<int, M>{}, cur);                                   \
+                __builtin_amdgcn_sched_barrier(0);                                              \
+                cur = nxt;                                                                      \
             }
+            StageIn cur;
+            if (!tail_only) {
+                cur = stage_in(std::integral_constant<int, 9>{});
+                MP3S_ST_STAGE(9, 8) MP3S_ST_STAGE(8, 7) MP3S_ST_STAGE(7, 6) MP3S_ST_STAGE(6, 5) MP3S_ST_STAGE(5, 4)
+            } else
+                cur = stage_in(std::integral_constant<int, 4>{});
+            MP3S_ST_STAGE(4, 3) MP3S_ST_STAGE(3, 2) MP3S_ST_STAGE(2, 1) MP3S_ST_STAGE(1, 0) MP3S_ST_STAGE(0, 0)
+#undef MP3S_ST_STAGE
         } else {
             // ---- three 12-point windows placed at 6 / 12 / 18 (Frame.py:135-148), the reference's order, walked over the 12 rows as
             //      k_dec_imdct does

@@ -184,7 +184,40 @@ void build()
                 if (b > dT) dT = b;
             }
         const double g18 = 18 * u / (1 - 18 * u);
-        T.imdct_kappa = 2 * g18 + (double)dT + 4.2 * u;
+        // The stream kernel's rows (k_dec_stream) are the same 18 independent values by another route: y[n] = sum_k v[k] cos((2n+1)(2k+1) pi/72),
+        // a DCT-IV of 18 points, rows 0..8 = y[9..17], rows 18..26 = -y[8..0] (the other rows by the mirror signs, as above).  With
+        // a = (2k+1) pi/72 and the pairs x = v[k], x' = v[17-k], k < 9:
+        //     p[k] = x cos a + x' sin a,   q[k] = -x sin a + x' cos a                                   (9 rotations)
+        //     P[m] = sum_k p[k] cos(m (2k+1) pi/18),   Q[m] = sum_k q[k] sin(m (2k+1) pi/18),  m = 0..9  (P[9] = Q[0] = 0)
+        //     y[2m] = P[m] + Q[m],   y[2m-1] = P[m] - Q[m]
+        // (the angle-addition formulas for (4m +- 1) a; checked against the direct sums in tests/test_tables.py): 236 instead of 324
+        // multiply-adds per subband.  Its distance from the TRUE sums, factors rounded once (<= u each), a product and a fused
+        // multiply-add per rotation, nine fused multiply-adds per sum, one addition:
+        //     |dp| <= 3.01 u (|x| + |x'|),  sum_k (|p| + |q|) <= sqrt2 B (1 + 4u),
+        //     |dP| <= (g9 + u) sum |p| + sum |dp|,  |dy| <= |dP| + |dQ| + u (sum |p| + sum |q|)  <=  ((g9 + 2u) sqrt2 + 6.02 u) B  <  22 u B
+        // and the reference's X from the true sums: g18 B for its own additions + dC B, dC = max |C[i][k] - cos((2i+19)(2k+1) pi/72)| of
+        // its table (arguments rounded before the cosine: measured in long double).  So |Y - X| <= (g18 + dC + 22u) B; window factor and
+        // overlap-add as above.  kappa covers both routes (k_dec_imdct<true>, k_dec_fixup's callers keep the mirrored sums).
+        long double dC = 0;
+        for (int i = 0; i < 36; i++)
+            for (int k = 0; k < 18; k++) {
+                const long double c = cosl((long double)((2 * i + 19) * (2 * k + 1)) * pil / 72.0L);
+                const long double d = fabsl((long double)T.imdct_cos36[i][k] - c);
+                if (d > dC) dC = d;
+            }
+        const double kappa_mirror = 2 * g18 + (double)dT + 4.2 * u, kappa_dct4 = g18 + (double)dC + 1e-19 + 22 * u + 4.2 * u;
+        T.imdct_kappa = kappa_mirror > kappa_dct4 ? kappa_mirror : kappa_dct4;
+        for (int k = 0; k < 9; k++) {
+            T.imdct_rot[0][2 * k] = (double)cosl((long double)(2 * k + 1) * pil / 72.0L);
+            T.imdct_rot[0][2 * k + 1] = (double)sinl((long double)(2 * k + 1) * pil / 72.0L);
+        }
+        for (int m = 0; m < 10; m++)
+            for (int k = 0; k < 9; k++) {
+                // (the argument reduced mod 36 in integers first: m (2k+1) pi/18 has the period 36)
+                const int r = (m * (2 * k + 1)) % 36;
+                T.imdct_pq[m][k] = m == 9 ? 0.0 : (double)cosl((long double)r * pil / 18.0L);       // (cos((2k+1) pi/2) = 0)
+                T.imdct_pq[m][9 + k] = m == 0 ? 0.0 : (double)sinl((long double)r * pil / 18.0L);
+            }
         T.synth_eps_g = 2.0 * 32767.0 * dsum * 2.0002 * T.imdct_kappa;
         T.synth_eps_x = 2.0 * 2 * u;
         for (int i = 0; i < 32; i++)

@@ -73,6 +73,11 @@ struct DevTables {
     //   = +X[16+i] (i <= 15), 0 (i = 16), -X[48-i]; odd jj: V[32+i] = -X[16-i] (i <= 15), -X[i-16] -- and, v = 1, times 32767
     double stream_cx[32][16];
     double stream_taps[2][32][16];
+    // the stream kernel's long-block IMDCT as a DCT-IV of 18 points in two halves (mp3s_tables.cpp, k_decode_stream.hpp):
+    //   imdct_rot[2k], [2k+1] = cos, sin((2k+1) pi/72): the rotation of the pair (v[k], v[17-k]) into (p[k], q[k]);
+    //   imdct_pq[m][k] = cos(m (2k+1) pi/18), imdct_pq[m][9+k] = sin(m (2k+1) pi/18), m = 0..9, k = 0..8: stage m's two rows
+    double imdct_rot[1][18];
+    double imdct_pq[10][18];
     uint8_t rq_map[3][3][32][20];  // [sr][case][subband][18 lines + 2 pad]: five aligned dwords per lane;
                                    // byte = gain selector << 6 | scalefactor slot (see build_rq_map)
     int16_t reorder_src[3][576];   // [sr][dst line] -> src line or -1 (zero)  Frame.py:574-602

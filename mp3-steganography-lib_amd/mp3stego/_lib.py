@@ -1078,7 +1078,7 @@ DEV_TABLES_DTYPE = np.dtype([
     ("synth_matrix", "<f8", (64, 32)), ("synth_window", "<f8", (512,)), ("synth_window_t", "<f8", (32, 16)), ("imdct_cos36", "<f8", (36, 18)),
     ("imdct_cos12", "<f8", (12, 6)), ("sine_block", "<f8", (4, 36)), ("alias_cs", "<f8", (8,)), ("alias_ca", "<f8", (8,)),
     ("pow43", "<f8", (8207,)), ("pow2q", "<f8", (312,)), ("pow2h", "<f8", (40,)), ("sqrt2", "<f8"),
-    ("synth_fast", "<f8", (344,)), ("synth_eps_a", "<f8"), ("synth_eps_x", "<f8"), ("synth_eps_g", "<f8"), ("imdct_kappa", "<f8"), ("synth_window_f", "<f8", (32, 16)), ("synth_window_fs", "<f8", (32, 16)), ("synth_xbound", "<f8"), ("synth_reserved", "<f8"), ("synth_stream", "<f8", (2, 8, 112)), ("stream_cx", "<f8", (32, 16)), ("stream_taps", "<f8", (2, 32, 16)),
+    ("synth_fast", "<f8", (344,)), ("synth_eps_a", "<f8"), ("synth_eps_x", "<f8"), ("synth_eps_g", "<f8"), ("imdct_kappa", "<f8"), ("synth_window_f", "<f8", (32, 16)), ("synth_window_fs", "<f8", (32, 16)), ("synth_xbound", "<f8"), ("synth_reserved", "<f8"), ("synth_stream", "<f8", (2, 8, 112)), ("stream_cx", "<f8", (32, 16)), ("stream_taps", "<f8", (2, 32, 16)), ("imdct_rot", "<f8", (1, 18)), ("imdct_pq", "<f8", (10, 18)),
     ("rq_map", "u1", (3, 3, 32, 20)), ("reorder_src", "<i2", (3, 576)), ("pre_tab", "u1", (24,)),
     ("enwindow", "<i4", (512,)), ("fl", "<i4", (32, 64)), ("cos_l", "<i4", (18, 36)), ("mdct_cs", "<i4", (8,)),
     ("mdct_ca", "<i4", (8,)), ("steptab", "<f8", (128,)), ("steptabi", "<i4", (128,)), ("_pad_int2idx", "u1", (8,)), ("int2idx", "<u2", (10000,)),   # (int2idx is alignas(16))

@@ -140,8 +140,35 @@ def test_guard_constants_of_the_fast_int16_decode(mlib):
     assert 0 < d_t < 1e-13
     u = 2.0 ** -53
     g18 = 18 * u / (1 - 18 * u)
-    kappa = 2 * g18 + d_t + 4.2 * u
-    assert abs(float(t["imdct_kappa"]) - kappa) <= 1e-18
+    # ... and the other route to the same rows (k_dec_stream: a DCT-IV of 18 points in two halves), measured against the TRUE cosines
+    i36, k18 = np.arange(36, dtype=np.longdouble)[:, None], np.arange(18, dtype=np.longdouble)[None, :]
+    d_c = float(np.abs(c - np.cos((2 * i36 + 19) * (2 * k18 + 1) * np.longdouble(np.pi) / 72)).max())
+    assert 0 < d_c < 1e-13
+    kappa = max(2 * g18 + d_t + 4.2 * u, g18 + d_c + 1e-19 + 22 * u + 4.2 * u)
+    assert abs(float(t["imdct_kappa"]) - kappa) <= 2e-17          # (numpy's long double pi is a double: d_c to ~1e-17)
+    # its tables and its algebra: rotations, ten stages of two nine-term sums, y[2m] = P + Q, y[2m-1] = P - Q, rows 0..8 = y[9..17],
+    # rows 18..26 = -y[8..0] -- against the reference's own matrix on random lines
+    rot, pq = np.array(t["imdct_rot"], dtype=np.float64)[0], np.array(t["imdct_pq"], dtype=np.float64)
+    kk = np.arange(9)
+    assert np.allclose(rot[0::2], np.cos((2 * kk + 1) * np.pi / 72), rtol=0, atol=2e-16) and np.allclose(rot[1::2], np.sin((2 * kk + 1) * np.pi / 72), rtol=0, atol=2e-16)
+    for m in range(10):
+        assert np.allclose(pq[m, :9], np.cos(m * (2 * kk + 1) * np.pi / 18), rtol=0, atol=1e-14) and np.allclose(pq[m, 9:], np.sin(m * (2 * kk + 1) * np.pi / 18), rtol=0, atol=1e-14)   # (numpy rounds the argument first)
+    assert not pq[9, :9].any() and not pq[0, 9:].any()
+    rng = np.random.default_rng(36)
+    for _ in range(20):
+        v = rng.standard_normal(18) * 10.0 ** rng.integers(-6, 6)
+        x, xm = v[:9], v[::-1][:9]
+        pp, qq = x * rot[0::2] + xm * rot[1::2], -x * rot[1::2] + xm * rot[0::2]
+        y = np.zeros(18)
+        for m in range(10):
+            P, Q = float(pp @ pq[m, :9]), float(qq @ pq[m, 9:])
+            if m <= 8:
+                y[2 * m] = P + Q
+            if m >= 1:
+                y[2 * m - 1] = P - Q
+        want = np.array(t["imdct_cos36"], dtype=np.float64) @ v
+        rows = np.concatenate([y[9:18], -y[9:18][::-1], -y[8::-1], -y[0:9]])
+        assert np.abs(rows - want).max() <= float(t["imdct_kappa"]) * np.abs(v).sum()
     dsum = max(float(np.abs(t["synth_window"][i::32]).sum()) for i in range(32))
     assert abs(float(t["synth_eps_g"]) / (2.0 * 32767.0 * dsum * 2.0002 * kappa) - 1) < 1e-12
     # the older terms stay what they were: eps_a scales with the slot's sum |S|, eps_x with the sample itself
