@@ -350,6 +350,8 @@ def main():
                          "tail of batch k-1 on the third stream the step takes the same time either way, and the rate loop -- the kernel the "
                          "roofline is computed from -- runs undisturbed), or under its rate loop (r02d and before)")
     ap.add_argument("--pack-overlap", action="store_true", help="(default since r02e; kept for old command lines)")
+    ap.add_argument("--lean-sync", choices=("on", "off"), default="on", help="region (i): the rate loop's dispatch signals the side streams itself and the main "
+                    "stream's waits stand together in front of it (MP3S_OPT_RATE_SIGNALS, mp3s_ctx_wait_last)")
     ap.add_argument("--no-tail-stream", action="store_true", help="chain check and bit packing of batch k on the main stream instead of a third one")
     ap.add_argument("--resident-only", action="store_true", help="region (i) only (profiling runs)")
     ap.add_argument("--dom-events-every", type=int, default=4, help="the timed region's HIP event pair around the dominant kernel on every N-th step: "
@@ -489,7 +491,9 @@ def main():
     prep_s = time.time() - t_prep
     ctx.set_option("file_pipeline", 1)
 
-    state = {"k": 0}
+    state = {"k": 0, "lean": args.lean_sync == "on" and aux is not None and aux2 is not None and dctx is None and args.huffman_under == "decode"}
+    if state["lean"]:
+        ctx.set_option("rate_signals", 1)
 
     def front_end(c, k):
         b = k & 1
@@ -537,28 +541,45 @@ def main():
         # batch still gets its own Huffman launch inside the timed region (the first one is issued by the first step).
         k = state["k"]; state["k"] = k + 1
         b = k & 1
+        # `lean`: the rate loop's dispatch signals the order event itself (MP3S_OPT_RATE_SIGNALS) and both side streams wait for THAT
+        # (wait_last: no record packet on the main stream), and the main stream's wait for the Huffman decode of batch k + 1 stands in
+        # front of the rate loop of batch k, beside its wait for the tail of batch k - 1: nothing lies between the rate loop and the decode
+        # behind it.  (A record or a wait is a packet of its own in the queue and costs the stream 7-8 us: tools/timeline.sh.)
+        lean = state["lean"]
         if aux is None:
             front_end(ctx, k)
         else:
             if k == 0 or state.get("restart"):
                 front_end(aux, k); state["restart"] = False
-            ctx.wait_for(aux)                       # Huffman(k) done
+                ctx.wait_for(aux)                   # Huffman(k) done
+            elif not lean:
+                ctx.wait_for(aux)                   # Huffman(k) done
         if aux is not None and not state.get("last") and args.huffman_under == "decode":
-            aux.wait_for(ctx)                       # batch k-1 is through: its Huffman outputs may be overwritten
+            if lean:
+                aux.wait_last(ctx)                  # batch k-1 is through (its rate loop's own signal): its Huffman outputs may be overwritten
+            else:
+                aux.wait_for(ctx)                   # batch k-1 is through: its Huffman outputs may be overwritten
             front_end(aux, k + 1)
+            if lean:
+                aux.wait_for(aux2)                  # ... and behind it the front stream waits for the tail of batch k-1: the main stream's ONE wait (below) is for both
         _lib.check(L.mp3s_decode_transform_dev(ctx.handle, d_is2[b], d_si2[b], d_hdr, n, 2, 0, _lib.MP3S_PCM_I16, d_pcm))
         d_mdct = d_mdct2[b]
         _lib.check(L.mp3s_encode_transform_dev(ctx.handle, d_pcm, d_hdr, n, d_mdct))
         if aux is not None and not state.get("last") and args.huffman_under == "rate":
             aux.wait_for(ctx)                       # decode(k-1) has read its inputs; start under the rate loop, the longest kernel
             front_end(aux, k + 1)
-        if aux2 is not None:
+        if aux2 is not None and (not lean or state.get("last")):
             ctx.wait_for(aux2)                      # the packer of batch k-1 has read what the rate loop is about to overwrite
+        if lean and not state.get("last"):
+            ctx.wait_for(aux)                       # Huffman(k+1) done AND the tail of batch k-1 through: the decode of batch k+1 follows this rate loop directly
         _lib.check(L.mp3s_rate_variants_dev(ctx.handle, d_mdct, d_rf, n, d_hide, len(hide_all), d_cur, d_eu, d_ec, n_ent, d_ix, d_out, d_en,
                                             d_ixv, d_outv, d_env))
         pk = ctx
         if aux2 is not None:
-            aux2.wait_for(ctx)                      # the rate loop of batch k is through: its tail goes on the third stream
+            if lean:
+                aux2.wait_last(ctx)                 # the rate loop of batch k is through: its tail goes on the third stream
+            else:
+                aux2.wait_for(ctx)                  # the rate loop of batch k is through: its tail goes on the third stream
             pk = aux2
         _lib.check(L.mp3s_select_dev(pk.handle, d_hide, d_cur, d_seg, d_spans, 1, max_reach, d_eu, d_ec, n_ent, d_ix, d_out, d_en, d_ixv, d_outv, d_env))
         _lib.check(L.mp3s_chain_redo_dev(pk.handle, d_mdct, d_rf, n, d_hide, len(hide_all), d_cur, d_seg, 1, d_ix, d_out, d_en, d_verdict, d_segout))

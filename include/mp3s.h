@@ -119,6 +119,10 @@ int mp3s_sync(mp3s_ctx *ctx);
  * submitted to other before it has finished.  This is how a second context runs the bit-level front end of the next
  * batch (mp3s_huffman_decode_dev) under the transform kernels of the current one. */
 int mp3s_ctx_wait(mp3s_ctx *ctx, mp3s_ctx *other);
+/* The same without a new record on other: work submitted to ctx after this call starts when what other's order event was LAST
+ * recorded behind has finished -- the previous mp3s_ctx_wait(.., other), or, with MP3S_OPT_RATE_SIGNALS, other's last rate loop.
+ * (Never recorded: no wait.)  Several contexts can wait for one point of another's stream for the price of one packet there, or none. */
+int mp3s_ctx_wait_last(mp3s_ctx *ctx, mp3s_ctx *other);
 /* Options of a context (what used to be MP3S_* environment switches read in the middle of a job: the environment now only
  * provides the DEFAULTS, read once by mp3s_ctx_create -- the names in brackets -- so two contexts of one process can differ
  * and no job path calls getenv).  Set them while nothing is in flight on the context. */
@@ -158,7 +162,11 @@ int mp3s_ctx_wait(mp3s_ctx *ctx, mp3s_ctx *other);
                                     * through memory [MP3S_FUSED_ENCODE=1 -> 1] */
 #define MP3S_OPT_PIPE_DEC 17       /* 1: a pipe created on this context runs the decode transform of job k + 1 on a stream of its own, under the encode
                                     * transforms and the rate loop of job k [MP3S_PIPE_DEC=0|1] */
-#define MP3S_OPT_COUNT 18
+#define MP3S_OPT_RATE_SIGNALS 18   /* 1: the dispatch of the rate loop (mp3s_rate_variants_dev, mp3s_rate_loop_dev) carries the context's order event as its
+                                    * completion signal: another context's mp3s_ctx_wait_last(other, this) then waits for the rate loop without a
+                                    * record packet of its own in this context's queue (a record or a wait between two kernels costs the stream 7-8 us
+                                    * of nothing: tools/timeline.sh) [MP3S_RATE_SIGNALS=0|1, default 0] */
+#define MP3S_OPT_COUNT 19
 /* what became of the one-file calls of this context (mp3s_hide_message, mp3s_clear_file, mp3s_decode_file, mp3s_decode_stream,
  * mp3s_hide_message_chunked): files that went through the overlapped stages as chunks, their chunks, chunks that were run
  * again because they depended on a carry the guess got wrong, chunks whose chains the host resolved, and files that took

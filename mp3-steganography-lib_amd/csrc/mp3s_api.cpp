@@ -131,6 +131,7 @@ int mp3s_ctx_create(int device, mp3s_ctx **out)
         c->opt[MP3S_OPT_FUSED_DECODE] = env("MP3S_FUSED_DECODE", 1) != 0;
         c->opt[MP3S_OPT_FUSED_ENCODE] = env("MP3S_FUSED_ENCODE", 0) != 0;
         c->opt[MP3S_OPT_PIPE_DEC] = env("MP3S_PIPE_DEC", 0) != 0;
+        c->opt[MP3S_OPT_RATE_SIGNALS] = env("MP3S_RATE_SIGNALS", 0) != 0;
     }
     if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess ||
         hipEventCreate(&c->ev0) != hipSuccess || hipEventCreate(&c->ev1) != hipSuccess ||
@@ -240,6 +241,15 @@ int mp3s_ctx_wait(mp3s_ctx *c, mp3s_ctx *other)
     if (c == other) return MP3S_OK;
     if (c->device != other->device) return fail(MP3S_E_ARG, "contexts on different devices");
     HIPCHK(hipEventRecord(other->ev_order, other->stream));
+    HIPCHK(hipStreamWaitEvent(c->stream, other->ev_order, 0));
+    return MP3S_OK;
+}
+
+int mp3s_ctx_wait_last(mp3s_ctx *c, mp3s_ctx *other)
+{
+    if (!c || !other) return fail(MP3S_E_ARG, "ctx is null");
+    if (c == other) return MP3S_OK;
+    if (c->device != other->device) return fail(MP3S_E_ARG, "contexts on different devices");
     HIPCHK(hipStreamWaitEvent(c->stream, other->ev_order, 0));
     return MP3S_OK;
 }
@@ -474,7 +484,8 @@ int mp3s_rate_loop_dev(mp3s_ctx *c, const int32_t *d_mdct, const mp3s_rate_frame
     if (n_frames <= 0 || n_hide < 0 || (n_hide > 0 && (!d_hide_bits || !d_cursor_in)))
         return fail(MP3S_E_ARG, "bad sizes / missing hide inputs");
     const int e = launch_rate(c->stream, d_mdct, d_frames, n_frames, d_hide_bits, n_hide, d_cursor_in, d_state_in,
-                              d_unit_list, n_list, d_ix, d_out, d_en, &c->prof);
+                              d_unit_list, n_list, d_ix, d_out, d_en, &c->prof, 0, 0, nullptr,
+                              c->rate_done ? c->rate_done : (c->opt[MP3S_OPT_RATE_SIGNALS] ? c->ev_order : nullptr));
     if (e) return fail(MP3S_E_HIP, "rate launch: %s", hipGetErrorString((hipError_t)e));
     return MP3S_OK;
 }
@@ -529,7 +540,7 @@ int mp3s_rate_variants_dev(mp3s_ctx *c, const int32_t *d_mdct, const mp3s_rate_f
     c->sel_pending = false;
     const RateVariantArgs va = {d_ent_unit, d_ent_cursor, n_entries, d_ixv, d_outv, d_env, (uint8_t *)(d_outv + n_entries)};
     const int e = launch_rate(c->stream, d_mdct, d_frames, n_frames, d_hide_bits, n_hide, d_cursor, nullptr, nullptr, 0, d_ix, d_out, d_en,
-                              &c->prof, 0, 0, &va);
+                              &c->prof, 0, 0, &va, c->rate_done ? c->rate_done : (c->opt[MP3S_OPT_RATE_SIGNALS] ? c->ev_order : nullptr));
     if (e) return fail(MP3S_E_HIP, "rate launch: %s", hipGetErrorString((hipError_t)e));
     return MP3S_OK;
 }

@@ -65,13 +65,13 @@ int front_end(mp3s_multi &m, int i)
 // transforms of frames [first, first + cnt) of a resident batch (arrays indexed by batch frame; stream_first counts from
 // frame 0 of the batch); the PCM of all but the first `halo` of them goes to d_pcm
 int decode_transform_chunk(mp3s_ctx *c, const int16_t *d_is, const mp3s_granule_si *d_si, const mp3s_frame_hdr *d_hdr, long first, int cnt,
-                           int nch, int halo, int out_format, void *d_pcm, hipStream_t stream)
+                           int nch, int halo, int out_format, void *d_pcm, hipStream_t stream, hipEvent_t done)
 {
     int rc = c->ensure_scratch(dec_scratch_bytes(cnt, nch));
     if (rc) return rc;
     const int e = launch_decode(stream ? stream : c->stream, d_is + (size_t)first * 2304, d_si + (size_t)first * 4, d_hdr + first, cnt, nch, halo, out_format,
                                 d_pcm, c->scratch, &c->prof, (int)first, c->synth_eps_scale, c->d_sync, c->opt[MP3S_OPT_FAST_IMDCT] != 0, c->opt[MP3S_OPT_FLOAT_FAST] != 0,
-                                c->opt[MP3S_OPT_FUSED_DECODE] != 0);
+                                c->opt[MP3S_OPT_FUSED_DECODE] != 0, done);
     if (e) return fail(MP3S_E_HIP, "decode launch: %s", hipGetErrorString((hipError_t)e));
     return MP3S_OK;
 }

@@ -44,7 +44,9 @@ int launch_decode(hipStream_t stream, const int16_t *d_is, const mp3s_granule_si
                                                exact kernels run */,
                   bool fast_imdct = true /* MP3S_OPT_FAST_IMDCT: the mirrored, fused IMDCT under the fast synthesis */,
                   bool float_fast = false /* MP3S_OPT_FLOAT_FAST: float32 output through the fast sums, unguarded (within 1e-5, not bit-identical) */,
-                  bool fused = true /* MP3S_OPT_FUSED_DECODE: the fast paths as one kernel, S in LDS (k_decode_fused.hpp) */);
+                  bool fused = true /* MP3S_OPT_FUSED_DECODE: the fast paths as one kernel, S in LDS (k_decode_fused.hpp) */,
+                  hipEvent_t done = nullptr /* recorded behind the transforms: as the last dispatch's own completion signal where the path has one
+                                               (the fused int16 path: no record packet in the queue), by a record otherwise */);
 
 // scratch: subband samples int32 [2][32][36 n]
 size_t enc_scratch_bytes(int n_frames);
@@ -67,7 +69,8 @@ int launch_rate(hipStream_t stream, const int32_t *d_mdct, const mp3s_rate_frame
                 const int32_t *d_list, int n_list, int16_t *d_ix, mp3s_gr_out *d_out, int32_t *d_en, Profiler *prof,
                 int out_base = 0 /* unit whose results land on element 0 of d_ix / d_out / d_en */,
                 int compact = 0 /* 1: d_cursor / d_state / d_out are indexed by the position in d_list; 2: d_ix / d_en too */,
-                const RateVariantArgs *variants = nullptr);
+                const RateVariantArgs *variants = nullptr,
+                hipEvent_t done = nullptr /* the dispatch's own completion signal: no record packet behind it (MP3S_OPT_RATE_SIGNALS) */);
 
 // the serial chains of the rate loop (k_chain.hpp): two small launches; d_agg: chain_agg_bytes(n_frames) of scratch.
 // With `redo` (the rate loop's other operands) the units the check finds wrong -- they read inherited addresses that were

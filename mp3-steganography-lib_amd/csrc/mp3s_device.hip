@@ -1,6 +1,7 @@
 // Single device translation unit: the constant-table symbol, the three kernel groups and their
 // launchers.  Compiled for gfx950 only (hipcc --offload-arch=gfx950 -ffp-contract=off).
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 #include <atomic>
 #include <stdint.h>
 #include <stdlib.h>
@@ -61,7 +62,7 @@ size_t dec_scratch_bytes(int n_frames, int nch)
 
 int launch_decode(hipStream_t stream, const int16_t *d_is, const mp3s_granule_si *d_si, const mp3s_frame_hdr *d_hdr,
                   int n_frames, int nch, int n_halo, int out_format, void *d_pcm, void *d_scratch, Profiler *prof, int sf_base,
-                  double synth_eps_scale, int32_t *d_sync, bool fast_imdct, bool float_fast, bool fused)
+                  double synth_eps_scale, int32_t *d_sync, bool fast_imdct, bool float_fast, bool fused, hipEvent_t done)
 {
     const long T = (long)n_frames * 36;
     double *S = (double *)d_scratch;
@@ -96,10 +97,16 @@ int launch_decode(hipStream_t stream, const int16_t *d_is, const mp3s_granule_si
             if (nch == 2) hipLaunchKernelGGL((k_dec_stream<2, false>), grid, block, 0, stream, d_is, d_si, d_hdr, n_gran, run, n_halo, d_pcm, sf_base, synth_eps_scale, fix_list, d_sync + 6);
             else hipLaunchKernelGGL((k_dec_stream<1, false>), grid, block, 0, stream, d_is, d_si, d_hdr, n_gran, run, n_halo, d_pcm, sf_base, synth_eps_scale, fix_list, d_sync + 6);
             const int fix_groups = (int)((T * nch + DEC_A_WAVES - 1) / DEC_A_WAVES) < 128 ? (int)((T * nch + DEC_A_WAVES - 1) / DEC_A_WAVES) : 128;
-            hipLaunchKernelGGL(k_dec_fixup, dim3(fix_groups), dim3(DEC_A_WAVES * 64), 0, stream, d_is, d_si, d_hdr, n_gran, nch, T, n_halo,
-                               sf_base, (int16_t *)d_pcm, (const uint2 *)fix_list, d_sync + 6, d_sync + 2);
+            if (done)
+                hipExtLaunchKernelGGL(k_dec_fixup, dim3(fix_groups), dim3(DEC_A_WAVES * 64), 0, stream, nullptr, done, 0, d_is, d_si, d_hdr, n_gran, nch, T, n_halo,
+                                      sf_base, (int16_t *)d_pcm, (const uint2 *)fix_list, d_sync + 6, d_sync + 2);
+            else
+                hipLaunchKernelGGL(k_dec_fixup, dim3(fix_groups), dim3(DEC_A_WAVES * 64), 0, stream, d_is, d_si, d_hdr, n_gran, nch, T, n_halo,
+                                   sf_base, (int16_t *)d_pcm, (const uint2 *)fix_list, d_sync + 6, d_sync + 2);
+            done = nullptr;                                  // (signalled by the dispatch itself)
         }
         if (prof) prof->end(stream, pf);
+        if (done && hipEventRecord(done, stream) != hipSuccess) return (int)hipErrorUnknown;
         return (int)hipGetLastError();
     }
     // granules per wave: each wave also primes itself with half an IMDCT of the granule before its run, so longer
@@ -149,6 +156,7 @@ int launch_decode(hipStream_t stream, const int16_t *d_is, const mp3s_granule_si
                            n_halo, out_format, d_pcm, sf_base);
     }
     if (prof) prof->end(stream, pp);
+    if (done && hipEventRecord(done, stream) != hipSuccess) return (int)hipErrorUnknown;
     return (int)hipGetLastError();
 }
 
@@ -185,17 +193,21 @@ int launch_encode(hipStream_t stream, const int16_t *d_pcm, const mp3s_frame_hdr
 int launch_rate(hipStream_t stream, const int32_t *d_mdct, const mp3s_rate_frame *d_frames, int n_frames,
                 const uint8_t *d_hide, int n_hide, const int32_t *d_cursor, const int32_t *d_state,
                 const int32_t *d_list, int n_list, int16_t *d_ix, mp3s_gr_out *d_out, int32_t *d_en, Profiler *prof, int out_base, int compact,
-                const RateVariantArgs *variants)
+                const RateVariantArgs *variants, hipEvent_t done)
 {
     const int n_units = n_frames * 4;
     if (compact && !d_list) return (int)hipErrorInvalidValue;
     const int n = d_list ? n_list : n_units;
     RateVariants var = {nullptr, nullptr, 0, nullptr, nullptr, nullptr, nullptr};
     if (variants && variants->n > 0) var = RateVariants{variants->d_unit, variants->d_cursor, variants->n, variants->d_ix, variants->d_out, variants->d_en, variants->d_tables};
-    if (n + var.n <= 0) return 0;
+    if (n + var.n <= 0) return done ? (int)hipEventRecord(done, stream) : 0;
     const int pp = prof ? prof->begin(stream, K_RATE_LOOP) : -1;
-    hipLaunchKernelGGL(k_rate_loop, dim3((n + var.n + RL_WAVES - 1) / RL_WAVES), dim3(RL_WAVES * 64), 0, stream, d_mdct, d_frames,
-                       n_units, d_hide, n_hide, d_cursor, d_state, d_list, n, d_ix, d_out, d_en, out_base, compact, var);
+    if (done)
+        hipExtLaunchKernelGGL(k_rate_loop, dim3((n + var.n + RL_WAVES - 1) / RL_WAVES), dim3(RL_WAVES * 64), 0, stream, nullptr, done, 0, d_mdct, d_frames,
+                              n_units, d_hide, n_hide, d_cursor, d_state, d_list, n, d_ix, d_out, d_en, out_base, compact, var);
+    else
+        hipLaunchKernelGGL(k_rate_loop, dim3((n + var.n + RL_WAVES - 1) / RL_WAVES), dim3(RL_WAVES * 64), 0, stream, d_mdct, d_frames,
+                           n_units, d_hide, n_hide, d_cursor, d_state, d_list, n, d_ix, d_out, d_en, out_base, compact, var);
     if (prof) prof->end(stream, pp);
     return (int)hipGetLastError();
 }

@@ -193,6 +193,11 @@ int enc_issue(mp3s_ctx *c, const EncLayout &L, const EncDev &d, hipStream_t tail
     // (the tail of the job in front is through before this job's rate loop starts: tails do not queue up behind one another)
     if (!rc && rate_after && hipStreamWaitEvent(c->stream, rate_after, 0) != hipSuccess) rc = fail(MP3S_E_HIP, "ordering behind the previous tail failed");
     const bool select_on_tail = tail && L.n_entries > 0;
+    // with a tail stream the rate loop is the compute stream's last launch of the job and the tail waits for IT: its dispatch carries
+    // tail_from as its own completion signal (a record would be a packet of its own in the queue: 7-8 us of nothing in front of the
+    // next job's decode, tools/timeline.sh)
+    const bool rate_signals = tail && tail_from && (select_on_tail || L.n_entries <= 0);
+    if (rate_signals) c->rate_done = tail_from;
     if (!rc && L.n_entries > 0) {
         // short messages: their variants run in the same launch and the device decides the cursor chain (no guess).  With a tail
         // stream the selection (two small launches) belongs to the tail: the compute stream is free for the next job's decode
@@ -211,9 +216,10 @@ int enc_issue(mp3s_ctx *c, const EncLayout &L, const EncDev &d, hipStream_t tail
     // gives it a stream of its own, so that the small launches and their gaps lie under the decode transforms of the next
     // job instead of in front of them (bench.py --pack-overlap: 0.829 -> 0.785 ms per step).  Every tail goes through the
     // same stream, so the context's chain scratch and the packer's sync words are still used by one launch at a time.
+    c->rate_done = nullptr;
     hipStream_t ts = c->stream;
     if (!rc && tail) {
-        if (hipEventRecord(tail_from, c->stream) != hipSuccess || hipStreamWaitEvent(tail, tail_from, 0) != hipSuccess)
+        if ((!rate_signals && hipEventRecord(tail_from, c->stream) != hipSuccess) || hipStreamWaitEvent(tail, tail_from, 0) != hipSuccess)
             rc = fail(MP3S_E_HIP, "ordering the tail stream failed");
         ts = tail;
     }

@@ -45,6 +45,7 @@ struct mp3s_ctx {
     hipStream_t stream = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr, ev_order = nullptr;
     hipEvent_t ev_sel = nullptr; bool sel_pending = false;   // a selection on a tail stream has read the variant buffers (enc_issue)
+    hipEvent_t rate_done = nullptr;   // set by enc_issue around its call of a rate entry point: the rate loop's dispatch signals it (no record packet)
     int32_t *d_sync = nullptr;        // 64-bit word {finished workgroups | error bits} of the pack kernel in flight (k_sync.hpp): self-clearing;
                                       // [2] counts the samples the fast synthesis computed again in the exact order
     double synth_eps_scale = 1.0;     // int16 decode: scale of the fast synthesis guard (0 = always the exact kernel)
@@ -244,7 +245,8 @@ void cut_window(ParsedStream &p, ScannedStream &sc, long first, long count);
 // host front end of stream i of m (scan; full host parse where the device cannot decode), cut to the stream's window
 int front_end(mp3s_multi &m, int i);
 int decode_transform_chunk(mp3s_ctx *c, const int16_t *d_is, const mp3s_granule_si *d_si, const mp3s_frame_hdr *d_hdr, long first, int cnt,
-                           int nch, int halo, int out_format, void *d_pcm, hipStream_t stream = nullptr /* null: the context's */);
+                           int nch, int halo, int out_format, void *d_pcm, hipStream_t stream = nullptr /* null: the context's */,
+                           hipEvent_t done = nullptr /* recorded behind the chunk's transforms (launch_decode) */);
 // decode the streams `idx` of m (one channel count) as one batch; d_keep: int16 PCM stays on the device there
 int decode_group(mp3s_ctx *c, mp3s_multi &m, const std::vector<int> &idx, int nch, int out_format, void *d_keep = nullptr);
 

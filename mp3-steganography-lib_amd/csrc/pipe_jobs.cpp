@@ -504,11 +504,14 @@ int issue_back(mp3s_pipe *P, Job &j, Slot &s, bool inputs_later, bool defer_down
     for (long start = halo0; start < n; start += kDecodeChunk) {
         const int halo = start == halo0 ? halo0 : (inside_stream(start) ? 1 : 0);
         const int cnt = (int)std::min<long>(kDecodeChunk, n - start) + halo;
+        // (the last group's last dispatch signals e_dec itself where it can: a record is a packet of its own in the queue, 7-8 us of nothing
+        //  between two kernels: tools/timeline.sh)
+        const bool last_group = start + kDecodeChunk >= n;
         const int rc = decode_transform_chunk(c, (const int16_t *)d_is, (const mp3s_granule_si *)d_si, d_dechdr, start - halo, cnt, nch, halo,
-                                              out_format, (uint8_t *)d_keep + (size_t)(start - halo0) * frame_elems * esz, ds);
+                                              out_format, (uint8_t *)d_keep + (size_t)(start - halo0) * frame_elems * esz, ds, last_group ? P->e_dec[set] : nullptr);
         if (rc) return rc;
     }
-    HIPCHK(hipEventRecord(P->e_dec[set], ds));
+    if (n <= halo0) HIPCHK(hipEventRecord(P->e_dec[set], ds));     // (no group ran)
     if (trace_on()) fprintf(stderr, "mp3s:   decode transforms queued %.3f ms after the job's start\n", now_ms() - t_issue0);
     P->dec_used[set] = true;
     if (P->s_dec && !j.decode) HIPCHK(hipStreamWaitEvent(c->stream, P->e_dec[set], 0));   // the encode side starts when the PCM is there

@@ -169,7 +169,7 @@ class Block(C.Structure):
 
 
 # every symbol include/mp3s.h declares (tests/test_abi.py checks the library exports all of them)
-SYMBOLS = ["mp3s_ctx_create", "mp3s_ctx_destroy", "mp3s_ctx_wait", "mp3s_last_error", "mp3s_version", "mp3s_device_name", "mp3s_sync", "mp3s_debug_tables", "mp3s_debug_scfsi_energies", "mp3s_debug_parse_scanned_frame",
+SYMBOLS = ["mp3s_ctx_create", "mp3s_ctx_destroy", "mp3s_ctx_wait", "mp3s_ctx_wait_last", "mp3s_last_error", "mp3s_version", "mp3s_device_name", "mp3s_sync", "mp3s_debug_tables", "mp3s_debug_scfsi_energies", "mp3s_debug_parse_scanned_frame",
            "mp3s_dev_alloc", "mp3s_dev_free", "mp3s_dev_upload", "mp3s_dev_download", "mp3s_dev_memset",
            "mp3s_timer_start", "mp3s_timer_stop", "mp3s_bench_copy", "mp3s_synth_mode", "mp3s_profile_enable", "mp3s_profile_select", "mp3s_profile_collect", "mp3s_decode_transform_dev", "mp3s_decode_transform",
            "mp3s_encode_transform_dev", "mp3s_encode_transform", "mp3s_rate_loop_dev", "mp3s_chain_resolve_dev", "mp3s_chain_redo_dev", "mp3s_select_patterns", "mp3s_select_plan", "mp3s_rate_select_dev", "mp3s_rate_variants_dev", "mp3s_select_dev", "mp3s_huffman_decode_dev", "mp3s_pack_frames_dev", "mp3s_scan_stream", "mp3s_buf_free",
@@ -211,6 +211,7 @@ def lib():
         L.mp3s_ctx_get_option.argtypes = [vp, i32, C.POINTER(C.c_int64)]
         L.mp3s_sync.argtypes = [vp]
         L.mp3s_ctx_wait.argtypes = [vp, vp]
+        L.mp3s_ctx_wait_last.argtypes = [vp, vp]
         L.mp3s_debug_tables.argtypes = [C.POINTER(sz)]
         L.mp3s_debug_tables.restype = vp
         L.mp3s_debug_scfsi_energies.argtypes = [vp, i32, vp]
@@ -354,7 +355,7 @@ class Context:
             self.handle = None
 
     OPTIONS = {"select": 1, "redo": 2, "fast_imdct": 3, "pipe_tail": 4, "chunk_frames": 5, "device_parse": 6, "file_pipeline": 7,
-               "scan_threads": 8, "first_chunk_frames": 9, "file_up": 10, "huf_lanes": 11, "numa": 12, "float_fast": 13, "fail_chunk": 14, "fused_decode": 15, "fused_encode": 16, "pipe_dec": 17}
+               "scan_threads": 8, "first_chunk_frames": 9, "file_up": 10, "huf_lanes": 11, "numa": 12, "float_fast": 13, "fail_chunk": 14, "fused_decode": 15, "fused_encode": 16, "pipe_dec": 17, "rate_signals": 18}
 
     def set_option(self, name, value):
         """options of the context (include/mp3s.h MP3S_OPT_*); returns the value the option had"""
@@ -450,6 +451,11 @@ class Context:
     def wait_for(self, other):
         """work submitted to this context from now on starts after everything submitted to `other` so far"""
         check(lib().mp3s_ctx_wait(self.handle, other.handle))
+
+    def wait_last(self, other):
+        """... after what `other`'s order event was last recorded behind (the last wait_for(.., other), or other's last rate loop with the option
+        rate_signals): no new record in other's queue"""
+        check(lib().mp3s_ctx_wait_last(self.handle, other.handle))
 
     def timer_start(self):
         check(lib().mp3s_timer_start(self.handle))
