@@ -354,9 +354,9 @@ def main():
                     "stream's waits stand together in front of it (MP3S_OPT_RATE_SIGNALS, mp3s_ctx_wait_last)")
     ap.add_argument("--no-tail-stream", action="store_true", help="chain check and bit packing of batch k on the main stream instead of a third one")
     ap.add_argument("--resident-only", action="store_true", help="region (i) only (profiling runs)")
-    ap.add_argument("--dom-events-every", type=int, default=4, help="the timed region's HIP event pair around the dominant kernel on every N-th step: "
-                    "a pair costs 0.009 ms of stream time (on every step 0.613-0.616 ms per step, on every fourth 0.606, on the first only 0.604-0.605: "
-                    "DESIGN.md §5)")
+    ap.add_argument("--dom-events-every", type=int, default=8, help="the timed region's HIP event pair around the dominant kernel on every N-th step: "
+                    "a pair is two packets in the queue, 0.015 ms of stream time (round 5, 100 steps: on every fourth step 0.533-0.536 ms per step, on every "
+                    "eighth 0.524, on every sixteenth 0.526: docs/LOG.md); 25 pairs in the default 200 steps")
     ap.add_argument("--no-live-pmc", action="store_true", help="roofline.traffic / roofline_alu from the committed profiles/*_latest.json instead of three "
                     "rocprofv3 --pmc passes run as child processes before this one touches the GPU (rank 0, one GPU, full runs only)")
     ap.add_argument("--decode-stream", choices=("on", "off"), default="off",
