@@ -130,9 +130,9 @@ int mp3s_ctx_wait_last(mp3s_ctx *ctx, mp3s_ctx *other);
                                     * checked and resolved afterwards [MP3S_NO_SELECT=1 -> 0] */
 #define MP3S_OPT_REDO 2            /* 1: the chain check's re-runs on the device (mp3s_chain_redo_dev) [MP3S_NO_REDO=1 -> 0] */
 #define MP3S_OPT_FAST_IMDCT 3      /* 1: int16 decode through the mirrored, fused IMDCT behind the guard [MP3S_FAST_IMDCT=0 -> 0] */
-#define MP3S_OPT_PIPE_TAIL 4       /* a pipe created on this context puts a job's tail (selection, chain check, bit packing) on a stream of its own:
-                                    * 0 never, 1 (default) the candidate its rehearsal likes best unless that clearly loses, 2 only if
-                                    * the rehearsal is faster with one [MP3S_PIPE_TAIL] */
+#define MP3S_OPT_PIPE_TAIL 4       /* a pipe created on this context (mp3s_pipe_create; not the context's own, which runs the chunks of one file and takes
+                                    * none) puts a job's tail (selection, chain check, bit packing) on a stream of its own: 0 never, 1 (default) the
+                                    * candidate its rehearsal likes best unless that clearly loses, 2 only if the rehearsal is faster with one [MP3S_PIPE_TAIL] */
 #define MP3S_OPT_CHUNK_FRAMES 5    /* frames per chunk when ONE file goes through the overlapped stages (mp3s_hide_message, mp3s_clear_file,
                                     * mp3s_decode_file, mp3s_decode_stream); 0 = chosen from the file's length [MP3S_CHUNK_FRAMES] */
 #define MP3S_OPT_DEVICE_PARSE 6    /* 1: side info and main-data gather on the device (mp3s_parse_frames_dev) wherever the stream is
@@ -166,7 +166,11 @@ int mp3s_ctx_wait_last(mp3s_ctx *ctx, mp3s_ctx *other);
                                     * completion signal: another context's mp3s_ctx_wait_last(other, this) then waits for the rate loop without a
                                     * record packet of its own in this context's queue (a record or a wait between two kernels costs the stream 7-8 us
                                     * of nothing: tools/timeline.sh) [MP3S_RATE_SIGNALS=0|1, default 0] */
-#define MP3S_OPT_COUNT 19
+#define MP3S_OPT_PIPE_SIGNALS 19   /* bit 0: in a pipe and in the one-file calls the last decode dispatch carries the event the front end waits for as its own
+                                    * completion signal, bit 1: the rate loop the event the tail stream waits for; 0 (default): event records behind them.
+                                    * Measured (tools/pipe_signals_ab.sh): 3 gives the pipe +1.5 % (18.0 -> 18.3 M frames/s) and now and then puts a context's
+                                    * one-file calls into a slower order of its streams (1.1 -> 1.4 ms per 10 000 frames): off [MP3S_PIPE_SIGNALS=0..3] */
+#define MP3S_OPT_COUNT 20
 /* what became of the one-file calls of this context (mp3s_hide_message, mp3s_clear_file, mp3s_decode_file, mp3s_decode_stream,
  * mp3s_hide_message_chunked): files that went through the overlapped stages as chunks, their chunks, chunks that were run
  * again because they depended on a carry the guess got wrong, chunks whose chains the host resolved, and files that took

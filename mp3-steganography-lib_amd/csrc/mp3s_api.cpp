@@ -132,6 +132,7 @@ int mp3s_ctx_create(int device, mp3s_ctx **out)
         c->opt[MP3S_OPT_FUSED_ENCODE] = env("MP3S_FUSED_ENCODE", 0) != 0;
         c->opt[MP3S_OPT_PIPE_DEC] = env("MP3S_PIPE_DEC", 0) != 0;
         c->opt[MP3S_OPT_RATE_SIGNALS] = env("MP3S_RATE_SIGNALS", 0) != 0;
+        c->opt[MP3S_OPT_PIPE_SIGNALS] = env("MP3S_PIPE_SIGNALS", 0) & 3;
     }
     if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess ||
         hipEventCreate(&c->ev0) != hipSuccess || hipEventCreate(&c->ev1) != hipSuccess ||
@@ -191,7 +192,7 @@ int mp3s_ctx_set_option(mp3s_ctx *c, int option, int64_t value)
     if (value < 0 || ((option == MP3S_OPT_CHUNK_FRAMES || option == MP3S_OPT_FIRST_CHUNK_FRAMES) && value != 0 && value < 4) || (option == MP3S_OPT_SCAN_THREADS && value > 64))
         return fail(MP3S_E_ARG, "option %d: value %lld out of range", option, (long long)value);
     const bool number = option == MP3S_OPT_CHUNK_FRAMES || option == MP3S_OPT_SCAN_THREADS || option == MP3S_OPT_FIRST_CHUNK_FRAMES ||
-                        option == MP3S_OPT_HUF_LANES || option == MP3S_OPT_FAIL_CHUNK;
+                        option == MP3S_OPT_HUF_LANES || option == MP3S_OPT_FAIL_CHUNK || option == MP3S_OPT_PIPE_SIGNALS;
     c->opt[option] = number ? value : (option == MP3S_OPT_PIPE_TAIL ? std::min<int64_t>(value, 2) : (value != 0));
     return MP3S_OK;
 }

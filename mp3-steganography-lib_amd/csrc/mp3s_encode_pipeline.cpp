@@ -196,7 +196,7 @@ int enc_issue(mp3s_ctx *c, const EncLayout &L, const EncDev &d, hipStream_t tail
     // with a tail stream the rate loop is the compute stream's last launch of the job and the tail waits for IT: its dispatch carries
     // tail_from as its own completion signal (a record would be a packet of its own in the queue: 7-8 us of nothing in front of the
     // next job's decode, tools/timeline.sh)
-    const bool rate_signals = tail && tail_from && (select_on_tail || L.n_entries <= 0);
+    const bool rate_signals = tail && tail_from && (select_on_tail || L.n_entries <= 0) && (c->opt[MP3S_OPT_PIPE_SIGNALS] & 2);
     if (rate_signals) c->rate_done = tail_from;
     if (!rc && L.n_entries > 0) {
         // short messages: their variants run in the same launch and the device decides the cursor chain (no guess).  With a tail

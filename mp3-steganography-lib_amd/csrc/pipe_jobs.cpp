@@ -508,10 +508,11 @@ int issue_back(mp3s_pipe *P, Job &j, Slot &s, bool inputs_later, bool defer_down
         //  between two kernels: tools/timeline.sh)
         const bool last_group = start + kDecodeChunk >= n;
         const int rc = decode_transform_chunk(c, (const int16_t *)d_is, (const mp3s_granule_si *)d_si, d_dechdr, start - halo, cnt, nch, halo,
-                                              out_format, (uint8_t *)d_keep + (size_t)(start - halo0) * frame_elems * esz, ds, last_group ? P->e_dec[set] : nullptr);
+                                              out_format, (uint8_t *)d_keep + (size_t)(start - halo0) * frame_elems * esz, ds,
+                                              last_group && (c->opt[MP3S_OPT_PIPE_SIGNALS] & 1) ? P->e_dec[set] : nullptr);
         if (rc) return rc;
     }
-    if (n <= halo0) HIPCHK(hipEventRecord(P->e_dec[set], ds));     // (no group ran)
+    if (n <= halo0 || !(c->opt[MP3S_OPT_PIPE_SIGNALS] & 1)) HIPCHK(hipEventRecord(P->e_dec[set], ds));     // (no group ran: nothing has signalled it)
     if (trace_on()) fprintf(stderr, "mp3s:   decode transforms queued %.3f ms after the job's start\n", now_ms() - t_issue0);
     P->dec_used[set] = true;
     if (P->s_dec && !j.decode) HIPCHK(hipStreamWaitEvent(c->stream, P->e_dec[set], 0));   // the encode side starts when the PCM is there
@@ -845,7 +846,10 @@ int pipe_create(mp3s_ctx *c, int depth, size_t max_job_bytes, int scan_threads, 
         return fail(code, "%s", what);
     };
     // copy-up, copy-down and front-end streams that run beside this context's compute stream (pick_lanes above)
-    if (pick_lanes(c, &P->s_up, &P->s_down, &P->s_huff, &P->s_comp, &P->s_tail, (int)c->opt[MP3S_OPT_PIPE_TAIL], &P->s_dec, c->opt[MP3S_OPT_PIPE_DEC] != 0, &P->s_img, &P->lanes))   // (a stream of their own for the decode transforms: +4 % on a resident batch
+    // (the context's OWN pipe -- the chunks of one file -- takes no tail stream: with one its calls run at 1.06-1.12 ms per 10 000 frames or, where
+    //  the rehearsal's choice lands the tail on a hardware queue that is in somebody's way, at 1.4-1.6; without, at 1.04-1.08 every time, and the
+    //  four tail miniatures are spared its first call: tools/tail_ab.py, tools/lanes_vs_time.py)
+    if (pick_lanes(c, &P->s_up, &P->s_down, &P->s_huff, &P->s_comp, &P->s_tail, internal ? 0 : (int)c->opt[MP3S_OPT_PIPE_TAIL], &P->s_dec, c->opt[MP3S_OPT_PIPE_DEC] != 0, &P->s_img, &P->lanes))   // (a stream of their own for the decode transforms: +4 % on a resident batch
                                                                                    // fed through four contexts (bench.py --decode-stream on), nothing in this pipe: off)
         return destroy(MP3S_E_HIP, "stream creation failed");
     if (hipEventCreateWithFlags(&P->e_dec[0], hipEventDisableTiming) != hipSuccess ||

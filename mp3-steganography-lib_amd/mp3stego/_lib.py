@@ -355,7 +355,7 @@ class Context:
             self.handle = None
 
     OPTIONS = {"select": 1, "redo": 2, "fast_imdct": 3, "pipe_tail": 4, "chunk_frames": 5, "device_parse": 6, "file_pipeline": 7,
-               "scan_threads": 8, "first_chunk_frames": 9, "file_up": 10, "huf_lanes": 11, "numa": 12, "float_fast": 13, "fail_chunk": 14, "fused_decode": 15, "fused_encode": 16, "pipe_dec": 17, "rate_signals": 18}
+               "scan_threads": 8, "first_chunk_frames": 9, "file_up": 10, "huf_lanes": 11, "numa": 12, "float_fast": 13, "fail_chunk": 14, "fused_decode": 15, "fused_encode": 16, "pipe_dec": 17, "rate_signals": 18, "pipe_signals": 19}
 
     def set_option(self, name, value):
         """options of the context (include/mp3s.h MP3S_OPT_*); returns the value the option had"""

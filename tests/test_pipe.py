@@ -381,3 +381,51 @@ def test_shallow_pipes_keep_a_job_whose_copy_down_is_still_to_come(mlib):
                     pipe.close()
     finally:
         ctx.close()
+
+
+@pytest.mark.gpu
+def test_events_as_dispatch_signals_change_no_byte(mlib):
+    """MP3S_OPT_PIPE_SIGNALS (the last decode dispatch / the rate loop carry the pipe's events as their own completion signals instead of event
+    records behind them) and MP3S_OPT_RATE_SIGNALS + mp3s_ctx_wait_last (the same for a caller that orders contexts itself): stream order only --
+    one-file calls, pipe jobs and a hand-ordered device step give the bytes of the default."""
+    from synth_pcm import synth_pcm
+    base = mlib.Context(0)
+    try:
+        files = [bytes(base.encode_pcm(synth_pcm(n, seed=300 + n), 44100, 128, None)["mp3"]) for n in (2500, 700, 90)]
+        want_h = [bytes(base.hide_message(f, "signals")["data"]) for f in files]
+        want_d = [bytes(base.decode_file(f)["data"]) for f in files]
+    finally:
+        base.close()
+    for v in (1, 2, 3):
+        c = mlib.Context(0)
+        try:
+            c.set_option("pipe_signals", v)
+            for rep in range(2):
+                for f, h, d in zip(files, want_h, want_d):
+                    assert bytes(c.hide_message(f, "signals")["data"]) == h, (v, len(f))
+                    assert bytes(c.decode_file(f)["data"]) == d, (v, len(f))
+            pipe = mlib.Pipe(c, depth=3, max_job_bytes=1 << 22, scan_threads=2)
+            try:
+                assert pipe.submit(files, ["signals"] * len(files)) is not None
+                for rep in range(3):
+                    assert pipe.submit_decode(files) is not None
+                    got_h = pipe.collect()[1]
+                    assert pipe.submit(files, ["signals"] * len(files)) is not None
+                    got_d = pipe.collect()[1]
+                    assert [bytes(r["data"]) for r in got_h] == want_h and [bytes(r["data"]) for r in got_d] == want_d, v
+                pipe.collect()
+            finally:
+                pipe.close()
+        finally:
+            c.close()
+    # the rate loop's own signal for a caller's contexts: a second context's copy waits for it with wait_last
+    a, b = mlib.Context(0), mlib.Context(0)
+    try:
+        a.set_option("rate_signals", 1)
+        pcm = synth_pcm(400, seed=77)
+        r0 = a.encode_pcm(pcm, 44100, 128, None)
+        b.wait_last(a)                       # (whatever a's last rate loop was: nothing of b starts before it)
+        r1 = b.encode_pcm(pcm, 44100, 128, None)
+        assert bytes(r0["mp3"]) == bytes(r1["mp3"])
+    finally:
+        a.close(); b.close()
