@@ -1272,7 +1272,8 @@ def main():
             "kernels_ms_per_step": {k: round(v, 4) for k, v in per_step.items()},
             "kernels_ms_note": f"event pairs around every kernel, separate untimed pass of {n_prof} steps; the timed region "
                                f"carries them around the dominant kernel only, on every {max(1, args.dom_events_every)}. step "
-                               "(all kernels: about 0.05 ms per step; the one pair 0.009 ms)",
+                               "(all kernels: about 0.05 ms per step).  The rate loop's pair is the dispatch's own start and stop event "
+                               "(hipExtLaunchKernelGGL): the kernel's time stamps, no record packets around it -- it agrees with rocprofv3's kernel trace",
             "dominant_kernel_launches_timed": int(prof[dom][1]),
             "hot_path_value": round(n * world / (sum(v for k, v in per_step.items()
                                                        if k not in ("k_dec_huffman", "k_enc_pack")) * 1e-3), 1),

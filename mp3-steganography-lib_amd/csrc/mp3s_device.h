@@ -28,6 +28,8 @@ struct Profiler {
     long count[K_COUNT] = {0};
     int begin(hipStream_t s, int k);          // returns pair index or -1
     void end(hipStream_t s, int pair);
+    // the pair as the START and STOP event of one dispatch (hipExtLaunchKernelGGL): the kernel's own time stamps, no record packets around it
+    bool attach(int k, hipEvent_t *start, hipEvent_t *stop);
 };
 
 int dev_upload_tables(hipStream_t stream);
