@@ -15,7 +15,11 @@ t0 = time.time()
 base = synth_pcm(2500, seed=7).astype(np.float64)
 compared = mism = exact_samples = streams = 0
 kinds = {}
+t_say = t0
 while compared < target:
+    if time.time() - t_say > 30:        # (a run that says nothing for seven minutes is taken to be hung)
+        t_say = time.time()
+        print("... %.2e samples, %d mismatches" % (compared, mism), file=sys.stderr, flush=True)
     k = streams % 6
     if k == 0:      # the bench signal at a random gain and DC offset
         pcm = np.clip(base * rng.uniform(0.01, 1.3) + rng.uniform(-2000, 2000), -32768, 32767).astype(np.int16)
