@@ -546,15 +546,17 @@ def main():
         # front of the rate loop of batch k, beside its wait for the tail of batch k - 1: nothing lies between the rate loop and the decode
         # behind it.  (A record or a wait is a packet of its own in the queue and costs the stream 7-8 us: tools/timeline.sh.)
         lean = state["lean"]
+        first = False
         if aux is None:
             front_end(ctx, k)
         else:
             if k == 0 or state.get("restart"):
                 front_end(aux, k); state["restart"] = False
                 ctx.wait_for(aux)                   # Huffman(k) done
+                first = lean
             elif not lean:
                 ctx.wait_for(aux)                   # Huffman(k) done
-        if aux is not None and not state.get("last") and args.huffman_under == "decode":
+        if aux is not None and not state.get("last") and args.huffman_under == "decode" and not first:
             if lean:
                 aux.wait_last(ctx)                  # batch k-1 is through (its rate loop's own signal): its Huffman outputs may be overwritten
             else:
@@ -563,6 +565,12 @@ def main():
             if lean:
                 aux.wait_for(aux2)                  # ... and behind it the front stream waits for the tail of batch k-1: the main stream's ONE wait (below) is for both
         _lib.check(L.mp3s_decode_transform_dev(ctx.handle, d_is2[b], d_si2[b], d_hdr, n, 2, 0, _lib.MP3S_PCM_I16, d_pcm))
+        if first and not state.get("last"):
+            # (a run's first step: no rate loop stands in front whose end would release the next Huffman decode -- released at once it
+            #  takes its CUs before this step's decode gets there, which then runs beside it at half speed (tools/timeline_head.sh).  Behind the decode.)
+            aux.wait_for(ctx)
+            front_end(aux, k + 1)
+            aux.wait_for(aux2)
         d_mdct = d_mdct2[b]
         _lib.check(L.mp3s_encode_transform_dev(ctx.handle, d_pcm, d_hdr, n, d_mdct))
         if aux is not None and not state.get("last") and args.huffman_under == "rate":
