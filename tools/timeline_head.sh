@@ -10,25 +10,19 @@ import csv, sys
 rows = list(csv.DictReader(open(sys.argv[1])))
 ev = [(int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"].split("(")[0].replace("void ", "").replace("mp3s::", ""), r.get("Queue_Id", "?")) for r in rows]
 ev.sort()
-# regions = runs of kernels separated by idle gaps > 0.3 ms; the timed region is the one with 20 rate loops
-regions, cur = [], [ev[0]]
-for a, b in zip(ev, ev[1:]):
-    if b[0] - max(e[1] for e in cur[-40:]) > 150000:
-        regions.append(cur); cur = []
-    cur.append(b)
-regions.append(cur)
-print("regions (rate loops in each):", [sum(1 for e in reg if e[2].startswith("k_rate_loop")) for reg in regions])
-for reg in regions:
-    n_rl = sum(1 for e in reg if e[2].startswith("k_rate_loop"))
-    if n_rl != 20:
-        continue
-    t0 = reg[0][0]
-    print("timed region: %d kernels, %.1f us from first start to last end" % (len(reg), (max(e[1] for e in reg) - t0) / 1e3))
-    for s, e, n, q in reg[:26]:
-        print("%9.1f %9.1f  %7.1f  q%-3s %s" % ((s - t0) / 1e3, (e - t0) / 1e3, (e - s) / 1e3, q, n[:40]))
-    print("   ...")
-    for s, e, n, q in reg[-14:]:
-        print("%9.1f %9.1f  %7.1f  q%-3s %s" % ((s - t0) / 1e3, (e - t0) / 1e3, (e - s) / 1e3, q, n[:40]))
-    break
+# the timed region: the last 20 rate loops and everything behind the rate loop in front of them
+rl = [i for i, e in enumerate(ev) if e[2].startswith("k_rate_loop")]
+start = rl[-21] + 1 if len(rl) > 20 else 0
+while start < len(ev) and ev[start][0] < ev[rl[-21]][1] + 20000 and len(rl) > 20:   # (the tail of the step in front, the verdict's copies)
+    start += 1
+reg = ev[start:]
+t0 = reg[0][0]
+last_end = max(e[1] for e in reg if not e[2].startswith("__amd_rocclr") or e[3] != reg[0][3])
+print("timed region: %d kernels, %.1f us from the first start to the end of the last tail" % (len(reg), (max(e[1] for e in reg[:-2]) - t0) / 1e3))
+for s, e, n, q in reg[:24]:
+    print("%9.1f %9.1f  %7.1f  q%-3s %s" % ((s - t0) / 1e3, (e - t0) / 1e3, (e - s) / 1e3, q, n[:40]))
+print("   ...")
+for s, e, n, q in reg[-14:]:
+    print("%9.1f %9.1f  %7.1f  q%-3s %s" % ((s - t0) / 1e3, (e - t0) / 1e3, (e - s) / 1e3, q, n[:40]))
 PY
 rm -rf gpurun_out/tl
