@@ -202,12 +202,15 @@ __device__ __forceinline__ void rl_run_lengths(const RlTables &tb, int k0, int k
 // The early probes sit at steps far too fine for the budget: all the search wants from them is "the bits reach max_bits" and
 // the side effects of the loop body.  quantize is monotone in |xr| (DevTables::rl_t1 / _t2 / _t8: the smallest |xr| of the step
 // whose quantised value is >= 1, >= 2, > 8192), so which of its three ways out the probe takes and, if the body runs, its run
-// lengths -- hence count1, big_values and the region addresses, exactly -- come from ten comparisons per lane; and every
-// non-zero value costs a sign bit, every big-value pair and every count1 quadruple at least one bit of code: when that sum
-// alone reaches the limit the decision stands.  Returns the probe's `bit` (100000 as the caller sets it for quantize's two
-// refusals, else that lower bound) or -1: undecided, the caller runs the probe in full (the side effects applied here are
-// the ones it applies again).  q_early: quantize's early out (:394-395), which leaves the kept quantisation valid.
-__device__ __forceinline__ int rl_precheck(const RlTables &tb, const uint32_t (&xa)[2 * RL_NP], RlState &st, int step, uint32_t scalei,
+// lengths -- hence count1, big_values and the region addresses, exactly -- come from ten comparisons per lane.  The lower bound of
+// its bits: a sign bit per non-zero value, at least one bit of code per count1 quadruple (both count1 books: :171-211) and per
+// big-value pair THAT HOLDS A NON-ZERO VALUE -- the pair (0, 0) is free in a region whose maximum is 0 (__new_choose_table gives
+// such a region table 0 and count_bit(0) is 0: :1182-1184, :228-229), exactly what rl_hl's `shortest` field says, so a pair of
+// zeros below big_values counts nothing here.  When that sum alone reaches the limit the decision stands.  Returns the probe's
+// `bit` (100000 as the caller sets it for quantize's two refusals, else that lower bound) or -1: undecided, the caller runs the
+// probe in full (the side effects applied here are the ones it applies again).  q_early: quantize's early out (:394-395), which
+// leaves the kept quantisation valid.
+__device__ __forceinline__ int rl_precheck(const RlTables &tb, const uint32_t (&xa)[2 * RL_NP], int p0, RlState &st, int step, uint32_t scalei,
                                            uint32_t xrmax, int limit, bool &q_early)
 {
     q_early = false;
@@ -217,16 +220,20 @@ __device__ __forceinline__ int rl_precheck(const RlTables &tb, const uint32_t (&
     const uint32_t t1 = (uint32_t)c_tab.rl_t1[idx], t2 = (uint32_t)c_tab.rl_t2[idx], t8 = (uint32_t)c_tab.rl_t8[idx];
     if (xrmax >= t8) return 100000;
     int k0 = 0, k1 = 0;
-    uint32_t nnz = 0;
+    uint32_t nnz = 0, nzp = 0;                 // non-zero values; bit m: the lane's pair m holds one
 #pragma unroll
     for (int m = 0; m < RL_NP; m++) {
         const uint32_t pm = max(xa[2 * m], xa[2 * m + 1]);
         k0 = pm >= t1 ? m + 1 : k0;
         k1 = pm >= t2 ? m + 1 : k1;
+        nzp |= pm >= t1 ? 1u << m : 0u;
         nnz += (xa[2 * m] >= t1 ? 1u : 0u) + (xa[2 * m + 1] >= t1 ? 1u : 0u);
     }
     rl_run_lengths(tb, k0, k1, st);
-    const int lb = (int)wave_add_u32(nnz) + st.big_values + st.count1;
+    // the lane's non-zero pairs below big_values (pairs p0 .. p0 + 4)
+    const int below = min(max(st.big_values - p0, 0), RL_NP);
+    nnz += (uint32_t)__builtin_popcount(nzp & ((1u << below) - 1u));
+    const int lb = (int)wave_add_u32(nnz) + st.count1;
     return lb >= limit ? lb : -1;
 }
 
@@ -590,7 +597,7 @@ __device__ __forceinline__ void rate_units(
                 // registers it then does not share
                 const uint32_t sc_lo = rl_scale_of(next + 30), sc_hi = rl_scale_of(next + 90);
                 bool q_early;
-                const int bit = rl_precheck(tb, xa, st, next + 60, sc, xrmax, max_bits, q_early);
+                const int bit = rl_precheck(tb, xa, p0, st, next + 60, sc, xrmax, max_bits, q_early);
                 if (bit >= 0) {
                     if (bit < max_bits) { count = 60; sc = sc_lo; }
                     else { next += 60; count -= 60; sc = sc_hi; }

@@ -14,7 +14,7 @@ LIB_PATH = os.path.join(_HERE, "libmp3s_hip.so")
 
 MP3S_PCM_I16, MP3S_PCM_F32, MP3S_PCM_F64 = 0, 1, 2
 E_NO_DEVICE, E_HIP, E_ARG, E_MALFORMED, E_UNSUPPORTED, E_STEP_RANGE, E_NOMEM, E_EXIT, E_BUSY, E_TABLES = -1, -2, -3, -4, -5, -6, -7, -8, -9, -10
-RF_ACTIVE, RF_USED_ADDR_IN, RF_STEP_RANGE, RF_LOG_GUARD = 1, 2, 4, 8
+RF_ACTIVE, RF_USED_ADDR_IN, RF_STEP_RANGE, RF_LOG_GUARD, RF_LISTED = 1, 2, 4, 8, 16
 
 
 class Mp3sError(RuntimeError):

@@ -98,6 +98,11 @@ const int32_t *orc_enc_mdct_freq(const OrcEncoder *); /* [frames][2 ch][2 gr][57
 const int32_t *orc_enc_ix(const OrcEncoder *);        /* [frames][2 ch][2 gr][576] (signed, as after format_bitstream) */
 
 /* encode stages usable stand-alone */
+/* test hook: the rate loop (MP3_Encoder.py:766-813) of one granule*channel on a given spectrum, fresh GrInfo, budget max_bits */
+int orc_enc_rate_unit(OrcEncoder *e, int max_bits, const int32_t *xr576, int32_t *ix576, OrcGrInfo *out);
+/* test hook: one probe of the binary search's body (:973-990) at `step` on n spectra, fresh GrInfo; bits -1 = step outside steptab / silence */
+void orc_enc_probe_bits(OrcEncoder *e, long n, int step, const int32_t *xr, int32_t *bits, int32_t *big_values, int32_t *count1);
+void orc_enc_rate_units(OrcEncoder *e, long n, const int32_t *max_bits, const int32_t *xr, int32_t *ix, OrcGrInfo *out, int32_t *rc);
 void orc_enc_window_filter_subband(int32_t *s32, int32_t *x512, int32_t *off);
 int32_t orc_enc_quantize(int32_t *ix, int step_size, int32_t xrmax, const int32_t *xr, const int32_t *xrabs);
 

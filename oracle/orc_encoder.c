@@ -425,44 +425,95 @@ static void resv_frame_end(OrcEncoder *e)
     }
 }
 
+/* MP3_Encoder.py:766-813: the body of __iteration_loop for one (ch, gr) */
+static void iterate_unit(OrcEncoder *e, int ch, int gr)
+{
+    int32_t *ix = e->l3_enc[ch][gr];
+    e->xr = e->mdct_freq[ch][gr];
+    e->xrmax = 0;
+    for (int i = 575; i >= 0; i--) {
+        e->xrsq[i] = mulsr(e->xr[i], e->xr[i]);
+        e->xrabs[i] = labs32(e->xr[i]);
+        if (e->xrabs[i] > e->xrmax) e->xrmax = e->xrabs[i];
+    }
+    OrcGrInfo *c = &e->gi[gr][ch];
+    calc_scfsi(e, ch, gr);
+    /* :894-931: resv_max == 0 -> mean_bits // nch capped at 4095 */
+    int max_bits = e->mean_bits / e->nch;
+    if (max_bits > 4095) max_bits = 4095;
+    /* :788-803 (address1/2/3 and quantizerStepSize are NOT reset) */
+    c->part2_3_length = 0; c->big_values = 0; c->count1 = 0; c->scale_fac_compress = 0;
+    c->table_select[0] = c->table_select[1] = c->table_select[2] = 0;
+    c->region0_count = 0; c->region1_count = 0; c->part2_length = 0; c->preflag = 0;
+    c->scale_fac_scale = 0; c->count1table_select = 0;
+    if (e->xrmax) {
+        /* :933-956 outer_loop */
+        c->quantizerStepSize = bin_search_step_size(e, max_bits, ix, c);
+        if (e->error) return;
+        c->part2_length = 0; /* :1038-1062 with scale_fac_compress == 0 */
+        int huff_bits = max_bits - c->part2_length;
+        int bits = inner_loop(e, ix, huff_bits, c);
+        if (e->error) return;
+        c->part2_3_length = c->part2_length + bits;
+        e->hide_off += (c->table_select[0] > 0) + (c->table_select[1] > 0) + (c->table_select[2] > 0);
+    }
+    e->resv_size += ((double)e->mean_bits / e->nch) - c->part2_3_length;
+    c->global_gain = c->quantizerStepSize + 210;
+}
+
 /* MP3_Encoder.py:760-815 */
 static void iteration_loop(OrcEncoder *e)
 {
     for (int ch = 0; ch < e->nch; ch++)
         for (int gr = 0; gr < 2; gr++) {
-            int32_t *ix = e->l3_enc[ch][gr];
-            e->xr = e->mdct_freq[ch][gr];
-            e->xrmax = 0;
-            for (int i = 575; i >= 0; i--) {
-                e->xrsq[i] = mulsr(e->xr[i], e->xr[i]);
-                e->xrabs[i] = labs32(e->xr[i]);
-                if (e->xrabs[i] > e->xrmax) e->xrmax = e->xrabs[i];
-            }
-            OrcGrInfo *c = &e->gi[gr][ch];
-            calc_scfsi(e, ch, gr);
-            /* :894-931: resv_max == 0 -> mean_bits // nch capped at 4095 */
-            int max_bits = e->mean_bits / e->nch;
-            if (max_bits > 4095) max_bits = 4095;
-            /* :788-803 (address1/2/3 and quantizerStepSize are NOT reset) */
-            c->part2_3_length = 0; c->big_values = 0; c->count1 = 0; c->scale_fac_compress = 0;
-            c->table_select[0] = c->table_select[1] = c->table_select[2] = 0;
-            c->region0_count = 0; c->region1_count = 0; c->part2_length = 0; c->preflag = 0;
-            c->scale_fac_scale = 0; c->count1table_select = 0;
-            if (e->xrmax) {
-                /* :933-956 outer_loop */
-                c->quantizerStepSize = bin_search_step_size(e, max_bits, ix, c);
-                if (e->error) return;
-                c->part2_length = 0; /* :1038-1062 with scale_fac_compress == 0 */
-                int huff_bits = max_bits - c->part2_length;
-                int bits = inner_loop(e, ix, huff_bits, c);
-                if (e->error) return;
-                c->part2_3_length = c->part2_length + bits;
-                e->hide_off += (c->table_select[0] > 0) + (c->table_select[1] > 0) + (c->table_select[2] > 0);
-            }
-            e->resv_size += ((double)e->mean_bits / e->nch) - c->part2_3_length;
-            c->global_gain = c->quantizerStepSize + 210;
+            iterate_unit(e, ch, gr);
+            if (e->error) return;
         }
     resv_frame_end(e);
+}
+
+/* Test hook (not a function of the reference): the rate loop of ONE granule*channel on a spectrum handed in, as a stream's first frame
+ * sees it -- fresh GrInfo (addresses and quantizerStepSize 0), the message `e` was made with at its start -- for a budget of max_bits.
+ * Lets tests/ put spectra in front of the device's rate loop that PCM through the filter bank does not produce (a lone line, empty
+ * regions below the last big value).  e: orc_enc_new(samplerate, 2, any bitrate, ...). */
+int orc_enc_rate_unit(OrcEncoder *e, int max_bits, const int32_t *xr576, int32_t *ix576, OrcGrInfo *out)
+{
+    if (e->error) return e->error;
+    memcpy(e->mdct_freq[0][0], xr576, 576 * sizeof(int32_t));
+    memset(&e->gi[0][0], 0, sizeof e->gi[0][0]);
+    memset(e->l3_enc[0][0], 0, sizeof e->l3_enc[0][0]);
+    e->hide_off = 0;
+    e->mean_bits = max_bits * e->nch;
+    iterate_unit(e, 0, 0);
+    memcpy(ix576, e->l3_enc[0][0], 576 * sizeof(int32_t));
+    *out = e->gi[0][0];
+    int rc = e->error;
+    e->error = 0;
+    return rc;
+}
+
+/* Test hook: ONE probe of __bin_search_step_size's body (:973-990) on n spectra with fresh GrInfo: bits[i] = the probe's `bit` at
+ * `step` (100000 when quantize refuses), and the run lengths it leaves -- what a bound on a probe's bits is checked against. */
+void orc_enc_probe_bits(OrcEncoder *e, long n, int step, const int32_t *xr, int32_t *bits, int32_t *big_values, int32_t *count1)
+{
+    for (long i = 0; i < n; i++) {
+        int32_t *ix = e->l3_enc[0][0];
+        OrcGrInfo *c = &e->gi[0][0];
+        memset(c, 0, sizeof *c);
+        e->xr = xr + i * 576;
+        e->xrmax = 0;
+        for (int k = 0; k < 576; k++) { e->xrabs[k] = labs32(e->xr[k]); if (e->xrabs[k] > e->xrmax) e->xrmax = e->xrabs[k]; }
+        int32_t q = e->xrmax ? orc_enc_quantize(ix, step, e->xrmax, e->xr, e->xrabs) : -1;
+        if (q < 0) { bits[i] = -1; big_values[i] = count1[i] = 0; continue; }
+        bits[i] = q > 8192 ? 100000 : rate_body(e, ix, c);
+        big_values[i] = q > 8192 ? -1 : c->big_values; count1[i] = q > 8192 ? -1 : c->count1;
+    }
+}
+
+/* the same for n spectra, each with its own budget; rc[i] = 0 or ORC_ERR_STEP_RANGE */
+void orc_enc_rate_units(OrcEncoder *e, long n, const int32_t *max_bits, const int32_t *xr, int32_t *ix, OrcGrInfo *out, int32_t *rc)
+{
+    for (long i = 0; i < n; i++) rc[i] = orc_enc_rate_unit(e, max_bits[i], xr + i * 576, ix + i * 576, out + i);
 }
 
 /* MP3_Encoder.py:1362-1392 */

@@ -97,6 +97,10 @@ def lib():
     L.orc_enc_window_filter_subband.argtypes = [ip, ip, ip]
     L.orc_enc_quantize.argtypes = [ip, i32, i32, ip, ip]
     L.orc_enc_quantize.restype = i32
+    L.orc_enc_rate_units.argtypes = [vp, i64, ip, ip, ip, vp, ip]
+    L.orc_enc_rate_units.restype = None
+    L.orc_enc_probe_bits.argtypes = [vp, i64, i32, ip, ip, ip, ip]
+    L.orc_enc_probe_bits.restype = None
     _lib = L
     return L
 
@@ -174,6 +178,40 @@ def encode(pcm_i16: np.ndarray, samplerate: int, bitrate: int, hide_bits=None):
         return out
     finally:
         L.orc_enc_free(e)
+
+
+def rate_units(samplerate: int, max_bits: np.ndarray, xr: np.ndarray):
+    """The reference's rate loop (MP3_Encoder.py:766-813) on n spectra int32 [n][576], each as the first granule of a stream (fresh
+    GrInfo, no message) with its own budget.  Returns {"ix": int32 [n][576] (unsigned, before format_bitstream), "gi": GRINFO_DTYPE [n],
+    "rc": int32 [n]}."""
+    L = lib()
+    xr = np.ascontiguousarray(xr, dtype=np.int32).reshape(-1, 576)
+    n = xr.shape[0]
+    mb = np.ascontiguousarray(np.broadcast_to(np.asarray(max_bits, dtype=np.int32), (n,)))
+    e = L.orc_enc_new(samplerate, 2, 128, None, 0)
+    try:
+        ix = np.zeros((n, 576), dtype=np.int32)
+        gi = np.zeros(n, dtype=GRINFO_DTYPE)
+        rc = np.zeros(n, dtype=np.int32)
+        L.orc_enc_rate_units(e, n, mb, xr, ix, gi.ctypes.data, rc)
+    finally:
+        L.orc_enc_free(e)
+    return {"ix": ix, "gi": gi, "rc": rc}
+
+
+def probe_bits(samplerate: int, step: int, xr: np.ndarray):
+    """One probe of the reference's binary search (MP3_Encoder.py:973-990: quantize, then the loop body) at `step` on n spectra with
+    fresh GrInfo: (bits, big_values, count1); bits 100000 where quantize refuses, -1 for silence or a step outside steptab."""
+    L = lib()
+    xr = np.ascontiguousarray(xr, dtype=np.int32).reshape(-1, 576)
+    n = xr.shape[0]
+    e = L.orc_enc_new(samplerate, 2, 128, None, 0)
+    try:
+        bits, bv, c1 = (np.zeros(n, dtype=np.int32) for _ in range(3))
+        L.orc_enc_probe_bits(e, n, step, xr, bits, bv, c1)
+    finally:
+        L.orc_enc_free(e)
+    return bits, bv, c1
 
 
 def wav_bytes(pcm_i16: np.ndarray, rate: int) -> bytes:

@@ -225,6 +225,51 @@ def test_rate_loop_batch_entry_point(ctx, mlib, orc, golden_dir):
         ctx.free(p)
 
 
+@pytest.mark.parametrize("rate,kbps", [(44100, 32), (44100, 48), (48000, 56), (32000, 32), (44100, 128), (48000, 320)])
+def test_rate_loop_on_sparse_spectra(ctx, mlib, orc, rate, kbps):
+    """mp3s_rate_loop_dev on spectra with empty regions below the last big value, lone lines, everything at the first thresholds
+    (tests/spectra.py), at budgets from 32 to 320 kbit/s: every unit's step, run lengths, regions, tables, bits and quantised lines
+    against the reference's loop (oracle rate_units: MP3_Encoder.py:766-813) -- the binary search's decisions, which the pre-check
+    and the bounds take without evaluating a probe in full, must be the reference's everywhere (round-5 advisor finding:
+    tests/test_rate_bounds.py has the bound itself)."""
+    from spectra import sparse_spectra
+    t = mlib.debug_tables()
+    n = 1024                                                          # frames: 4096 spectra
+    units = 4 * n
+    parts = [sparse_spectra(rate + kbps + 7 * k, units // 4, base=max(int(t["rl_t1"][st + 127]), 1))
+             for k, st in enumerate((-60, -60, -30, -90))]           # aimed at the first probe and at both second probes
+    xr = np.ascontiguousarray(np.concatenate(parts)[np.random.default_rng(kbps).permutation(units)])
+    rf, _ = mlib.rate_frames(rate, kbps, 2, n)
+    want = orc.rate_units(rate, np.repeat(rf["max_bits"], 4), xr)
+    L = mlib.lib()
+    d_mdct, d_rf = ctx.to_device(xr), ctx.to_device(rf)
+    d_ix, d_out, d_en = ctx.alloc(units * 576 * 2), ctx.alloc(units * 72), ctx.alloc(units * 22 * 4)
+    d_state = ctx.to_device(np.zeros((units, 4), dtype=np.int32))
+    try:
+        mlib.check(L.mp3s_rate_loop_dev(ctx.handle, d_mdct, d_rf, n, None, 0, None, d_state, None, 0, d_ix, d_out, d_en))
+        ctx.sync()
+        out = ctx.download(d_out, mlib.GR_OUT_DTYPE, (units,))
+        ix = ctx.download(d_ix, np.int16, (units, 576)).astype(np.int32)
+    finally:
+        for p in (d_mdct, d_rf, d_ix, d_out, d_en, d_state):
+            ctx.free(p)
+    gi = want["gi"]
+    ok = want["rc"] == 0
+    assert ok.sum() > units * 0.9
+    assert np.array_equal(((out["flags"] & mlib.RF_STEP_RANGE) != 0), ~ok)     # the quantiser step ran out of steptab: IndexError in the reference
+    act = (np.abs(xr).max(1) > 0) & ok
+    assert np.array_equal((out["flags"] & mlib.RF_ACTIVE) != 0, np.abs(xr).max(1) > 0)
+    for a, b in (("quantizer_step", "quantizerStepSize"), ("big_values", "big_values"), ("count1", "count1"),
+                 ("part2_3_length", "part2_3_length"), ("region0_count", "region0_count"), ("region1_count", "region1_count"),
+                 ("count1table_select", "count1table_select"), ("table_select", "table_select")):
+        bad = np.nonzero(act & ~(out[a] == gi[b]).reshape(units, -1).all(1))[0]
+        assert bad.size == 0, (a, bad[:8], out[a][bad[:4]], gi[b][bad[:4]])
+    for k, fld in enumerate(("address1", "address2", "address3")):
+        assert np.array_equal(out["address"][act, k], gi[fld][act]), fld
+    assert np.array_equal(np.abs(ix[act]), want["ix"][act])
+    assert ((ix[act] == 0) | ((ix[act] < 0) == (xr[act] < 0))).all()
+
+
 def test_facade_hashes(ctx, mlib, golden_dir):
     """hide / clear / too-long through the device pipeline equal the reference facade run"""
     fac = json.load(open(os.path.join(golden_dir, "g3_facade.json")))
