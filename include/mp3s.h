@@ -199,6 +199,13 @@ const void *mp3s_debug_tables(size_t *bytes);
  * The kernel's tabulated energies are cross-checked against this in the tests. */
 int mp3s_debug_scfsi_energies(const int32_t *xr576, int sr_idx, int32_t *en22);
 
+/* A probe of the int16 decode's guard (reference decoder/MP3_Parser.py:91 truncates pcm * 32767, decoder/Frame.py:65-154 is the
+ * order of the sums it truncates): while d_x / d_eps (device arrays of `capacity` doubles) are set, the fused int16 decode (k_dec_stream)
+ * also leaves per sample of a call its fast value x -- fp64, before the truncation -- and the width eps its guard compared with (infinite
+ * for a granule it does not vouch for at all), at the sample's index in the call's PCM.  |x - 32767 * exact fp64 PCM| / eps is the margin
+ * of the bound (tests/test_guard_margin.py asserts <= 0.5).  NULL, NULL, 0 ends the probe.  Not for production calls: 16 bytes more per sample. */
+int mp3s_debug_guard_margin(mp3s_ctx *ctx, double *d_x, double *d_eps, int64_t capacity);
+
 /* host decode (scalefactors + Huffman) of ONE frame of a scanned stream: what the stream pipelines do with the frames the
  * device Huffman kernel flags (exact for streams the scan marks gpu_ok); exposed for the tests.  side = that frame's
  * record, blob = the stream's blob; is2304 = int16 [2][2][576], si4 = mp3s_granule_si [2][2] */

@@ -194,7 +194,9 @@ __global__ __launch_bounds__(CH_THREADS) void k_chain_apply(mp3s_gr_out *__restr
 #pragma unroll
                     for (int j = 0; j < 4; j++) redo_list[REDO_HEAD + 2 * REDO_CAP + 4 * at + j] = ch[j];
                 }
-            }
+            } else if (flags & MP3S_RF_LISTED) {
+                g.flags = flags & ~MP3S_RF_LISTED;        // not on THIS check's list: the mark of the list before goes (a chain of the next round may
+            }                                             // run through the unit again; and the records the caller reads carry no internal mark)
             if (flags & MP3S_RF_STEP_RANGE) err_here = 1;
             if (active) cur += g.n_tables;
             else {   // silent unit: everything is inherited (quantizerStepSize and addresses pass through)

@@ -108,11 +108,16 @@ __device__ __forceinline__ double st_row_dot16(double t, const double (&c)[16])
     return x;
 }
 
-template <int NCH, bool F32>
+// MARGIN (a probe, mp3s_debug_guard_margin: tests/test_guard_margin.py, tools/soak_fast_synth.py): the same kernel also leaves, per sample it
+// stores, the fast value x (fp64, before truncation) in mg_x and the width eps_t its guard compared with in mg_eps (infinite where the
+// granule is not vouched for at all), at the sample's index in the launch's output + mg_base -- so that the distance of x from the
+// reference-order value can be measured against the bound on the device, not only counted as equal / unequal after truncation.
+template <int NCH, bool F32, bool MARGIN = false>
 __global__ __launch_bounds__(ST_WAVES * 64, 2) void k_dec_stream(
     const int16_t *__restrict__ is, const mp3s_granule_si *__restrict__ si, const mp3s_frame_hdr *__restrict__ hdr,
     int n_granules, int run, int n_halo, void *__restrict__ pcm_out, int sf_base, double eps_scale,
-    uint2 *__restrict__ fix_list, int32_t *__restrict__ fix_count)
+    uint2 *__restrict__ fix_list, int32_t *__restrict__ fix_count,
+    double *__restrict__ mg_x = nullptr, double *__restrict__ mg_eps = nullptr, long mg_base = 0, long mg_cap = 0)
 {
     __shared__ StShared sh;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
@@ -548,6 +553,10 @@ __global__ __launch_bounds__(ST_WAVES * 64, 2) void k_dec_stream(
                 const double dist = fabs(x) - fmax(fabs(xi), 1.0);
                 if (store) {
                     if (live) o16[p * 32 * NCH] = (int16_t)(int)x;
+                    if (MARGIN && live) {
+                        const long at = mg_base + ((t0 - halo_slots + p) * 32 + sb) * NCH + ch;
+                        if (at >= 0 && at < mg_cap) { mg_x[at] = x; mg_eps[at] = safe ? eps_t : __builtin_inf(); }
+                    }
                     unsigned long long m = safe ? __ballot(!(fabs(dist) > eps_t)) : ~0ull;
                     if (NCH == 1) m &= 0xffffffffull;
                     if (__builtin_expect(m != 0, 0)) {                          // (wave-uniform, rare: out of line)

@@ -11,6 +11,27 @@
 // Integer work only (bit exact); the one float spot is quantize's ln >= 10000 path (correctly rounded fp64 sqrt).  The
 // scfsi log is a table built with the host's libm (DevTables::en_base / en_step).
 #pragma once
+#ifndef MP3S_RL_STATS
+#define MP3S_RL_STATS 0   // 1: what every probe of k_rate_loop ends on and the shader clocks of a wave's phases, summed into g_rl_stats and read by
+                          // mp3s_debug_rl_stats (a probe: tools/rl_stats.py; such a build is not the product's)
+#endif
+#ifndef MP3S_RL_OCC
+#define MP3S_RL_OCC 6     // waves per SIMD k_rate_loop is compiled for (r06: 80 VGPRs, a dozen values spilled AROUND the search loop, none inside: 0.214 -> 0.204 ms in the step)
+#endif
+#if MP3S_RL_STATS
+__device__ unsigned long long g_rl_stats[128];
+extern "C" __attribute__((visibility("default"))) int mp3s_debug_rl_stats(unsigned long long *out, int clear)
+{
+    (void)hipDeviceSynchronize();
+    int rc = (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_rl_stats), sizeof(unsigned long long) * 128);
+    if (clear) { unsigned long long z[128] = {}; rc |= (int)hipMemcpyToSymbol(HIP_SYMBOL(g_rl_stats), z, sizeof z); }
+    return rc;
+}
+#define RL_STAT(i, v) do { if ((threadIdx.x & 63) == 0) atomicAdd(&g_rl_stats[(i)], (unsigned long long)(v)); } while (0)
+#define RL_CLK() __builtin_readcyclecounter()
+#else
+#define RL_STAT(i, v) do { } while (0)
+#endif
 
 namespace mp3s {
 
@@ -104,7 +125,7 @@ struct RlTables {
                             // | (longest of the four lengths + non-zero values + 13 bits per value > 14) << 16
     uint32_t c1w[16];       // count1 book A: code length of the quad | number of ones in its first pair << 16
     uint8_t transform[64];  // [table][bit]
-    uint32_t subdiv[289];   // __subdivide result per big_values for this workgroup's sample rate (see DevTables)
+    uint32_t subdiv[292];   // __subdivide result per big_values (0..288) for this workgroup's sample rate (see DevTables); padded to 16-byte pieces
 };
 
 // linbits of table t (encoder/tables.py:287-302) without a memory lookup: nibble k of the packed constants
@@ -190,7 +211,8 @@ __device__ __forceinline__ void rl_run_lengths(const RlTables &tb, int k0, int k
         if (!st.addr_fresh) st.used_addr_in = true;
     } else {
         // __subdivide (:1008-1036) depends on big_values only: looked up in the per-rate table built on the host
-        const uint32_t e = tb.subdiv[bv < 289 ? bv : 288];
+        const uint32_t e = (uint32_t)__builtin_amdgcn_readfirstlane((int)tb.subdiv[bv < 289 ? bv : 288]);   // (wave-uniform: its fields are scalar arithmetic,
+                                                                                                                 //  not four vector registers per kept evaluation)
         st.r0c = (int)(e & 15); st.r1c = (int)((e >> 4) & 7);
         st.a1 = (int)((e >> 8) & 1023); st.a2 = (int)((e >> 18) & 1023);
         st.a3 = 2 * bv;
@@ -270,6 +292,7 @@ __device__ __forceinline__ int rl_body(const RlTables &tb, const int32_t (&ix)[2
     uint32_t bnd = 0, acc = 0;
     {
         const int reach = st.a2 > bvr ? st.a2 : bvr;
+        const int reach_p = (reach + 1) >> 1;             // pairs below `reach` (slot m of the lane: p0 < limit - m, the limit's side scalar)
         // inside the count1 region every value is 0 or 1, so x + 2y is the pair's code there; elsewhere the sum is only
         // kept inside the table (& 15) and its result dropped
 #pragma unroll
@@ -277,7 +300,7 @@ __device__ __forceinline__ int rl_body(const RlTables &tb, const int32_t (&ix)[2
             const int x = ix[2 * m], y = ix[2 * m + 1];
             const uint2 hh = tb.hl[(x > 14 ? 15 : x) * 16 + (y > 14 ? 15 : y)];
             h[m] = hh.x;
-            bnd += (p0 + m) < bv ? hh.y : (2 * (p0 + m) < reach ? hh.y & 0xffff0000u : 0u);
+            bnd += p0 < bv - m ? hh.y : (p0 < reach_p - m ? hh.y & 0xffff0000u : 0u);
         }
         if (count1 > 0) {                                   // (wave-uniform: a probe whose values are all above 1 up to the last non-zero pair has no quads)
 #pragma unroll
@@ -312,9 +335,9 @@ __device__ __forceinline__ int rl_body(const RlTables &tb, const int32_t (&ix)[2
     int rid[RL_NP];
 #pragma unroll
     for (int m = 0; m < RL_NP; m++) {
-        const int s = 2 * (p0 + m);
         const uint32_t pm = (uint32_t)max(ix[2 * m], ix[2 * m + 1]);
-        const bool in0 = s < a1, in1 = !in0 && s < a2, in2 = !in0 && !in1 && s < bvr;
+        // (line 2 (p0 + m) below a bound <=> p0 below the bound's pair count - m: the per-slot part stays on the scalar side)
+        const bool in0 = p0 < ((a1 + 1) >> 1) - m, in1 = !in0 && p0 < ((a2 + 1) >> 1) - m, in2 = !in0 && !in1 && p0 < bv - m;
         mx0 = max(mx0, in0 ? pm : 0u);
         mx1 = max(mx1, in1 ? pm : 0u);
         mx2 = max(mx2, in2 ? pm : 0u);
@@ -423,6 +446,7 @@ __device__ __forceinline__ void rate_units(
     int16_t *__restrict__ ix_out, mp3s_gr_out *__restrict__ out, int32_t *__restrict__ en_out, int out_base, int compact,
     RateVariants var, const int32_t *__restrict__ cursor_all = nullptr)
 {
+    const int n_total = n_list + var.n;
     // compact (re-runs of a unit list): cursor_in / state_in / out are indexed by the position in the list, so that a
     // pass moves a few bytes per listed unit over PCIe instead of whole-batch arrays; ix / en still land in place.
     // compact == 2 (message variants: the list names a unit once per 3-bit pattern): ix / en go by list position too
@@ -430,6 +454,9 @@ __device__ __forceinline__ void rate_units(
     // results of unit u go to element u - out_base of the three output arrays (0 except for the message variants,
     // whose arrays hold one chunk of units)
     __shared__ __attribute__((aligned(16))) RlTables tb;
+#if MP3S_RL_STATS
+    const unsigned long long clk0 = RL_CLK();
+#endif
     const int sr0 = frames[0].sr_idx;             // one sample rate per launch (the host splits batches otherwise)
     const int sr_wg = sr0 >= 0 && sr0 < 3 ? sr0 : 0;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
@@ -454,40 +481,52 @@ __device__ __forceinline__ void rate_units(
             }
         }
     }
-    // The tables: asked for HERE, put into LDS and waited for (the workgroup's one barrier) where a wave first needs them -- in a plain launch
-    // behind its unit's own front (lines, energies, scfsi logs: nothing of it reads a table), so that the tables' way through the caches passes
-    // under that arithmetic; a re-run launch (CHAIN) stages them at once.
+    // The tables: asked for HERE and waited for (the workgroup's one barrier) where a wave first needs them -- in a plain launch behind its
+    // unit's own front (lines, energies, scfsi logs: nothing of it reads a table), so that the tables' way through the caches passes under that
+    // arithmetic; a re-run launch (CHAIN) and the persistent workgroups wait at once.  The three large tables go STRAIGHT into LDS
+    // (global_load_lds_dwordx4: each lane's 16 bytes land at the wave's LDS base + 16 * lane; no register holds them -- through registers the
+    // staging kept 24 VGPRs alive across the unit's front, the kernel's peak: r06), the two of 64 bytes through a register each.
     static_assert(sizeof(tb.int2idx) % 16 == 0 && sizeof(c_tab.int2idx) == sizeof(tb.int2idx), "int2idx is staged 16 bytes at a time");
-    static_assert(RL_WAVES * 64 >= 256, "one thread per pair word (tb.hl) when the tables are put into LDS");
+    static_assert(sizeof(tb.hl) == sizeof(c_tab.rl_hl) && sizeof(tb.hl) % 1024 == 0, "the pair words are staged one wave-load (1 KB) at a time");
+    static_assert(offsetof(RlTables, hl) % 16 == 0 && offsetof(RlTables, subdiv) % 16 == 0 && sizeof(tb.subdiv) % 16 == 0, "16-byte pieces in LDS");
     constexpr int I2I_CHUNKS = (int)(sizeof(tb.int2idx) / 16), I2I_ROUNDS = (I2I_CHUNKS + RL_WAVES * 64 - 1) / (RL_WAVES * 64);
-    uint4 t_i2i[I2I_ROUNDS];
-    uint2 t_hl;
-    uint32_t t_c1w = 0, t_tr = 0, t_sd[2];
+    constexpr int HL_CHUNKS = (int)(sizeof(tb.hl) / 16), SD_CHUNKS = (int)(sizeof(tb.subdiv) / 16);
+    static_assert(HL_CHUNKS + SD_CHUNKS <= RL_WAVES * 64 && HL_CHUNKS % 64 == 0, "pair words and region table: one piece per thread");
+    uint32_t t_c1w = 0, t_tr = 0;
     {
-        const uint4 *src = reinterpret_cast<const uint4 *>(c_tab.int2idx);
+        typedef const __attribute__((address_space(1))) void *gsrc;
+        typedef __attribute__((address_space(3))) void *ldst;
+        char *const lds0 = reinterpret_cast<char *>(&tb);
+        const char *const g_i2i = reinterpret_cast<const char *>(c_tab.int2idx);
 #pragma unroll
-        for (int r = 0; r < I2I_ROUNDS; r++) { const int i = (int)threadIdx.x + r * RL_WAVES * 64; t_i2i[r] = src[i < I2I_CHUNKS ? i : I2I_CHUNKS - 1]; }
-        t_hl = make_uint2(c_tab.rl_hl[threadIdx.x & 255][0], c_tab.rl_hl[threadIdx.x & 255][1]);   // (built on the host: mp3s_tables.cpp)
+        for (int r = 0; r < I2I_ROUNDS; r++) {
+            const int base = (r * RL_WAVES + wave) * 64;                      // the wave's first piece of this round
+            if (base + lane < I2I_CHUNKS)
+                __builtin_amdgcn_global_load_lds((gsrc)(g_i2i + (size_t)(base + lane) * 16), (ldst)(lds0 + offsetof(RlTables, int2idx) + base * 16), 16, 0, 0);
+        }
+        {
+            // pieces 0 .. HL_CHUNKS-1: the pair words; behind them (a wave boundary) the region table of this sample rate, whose last piece reads a few
+            // bytes past its 289 words (still inside DevTables) into the padding of tb.subdiv
+            const int base = wave * 64;
+            const bool is_hl = base < HL_CHUNKS;
+            const char *src = is_hl ? reinterpret_cast<const char *>(c_tab.rl_hl) + (size_t)(base + lane) * 16
+                                    : reinterpret_cast<const char *>(c_tab.subdiv_lut[sr_wg]) + (size_t)(base - HL_CHUNKS + lane) * 16;
+            char *dst = is_hl ? lds0 + offsetof(RlTables, hl) + base * 16 : lds0 + offsetof(RlTables, subdiv) + (base - HL_CHUNKS) * 16;
+            if (is_hl || base - HL_CHUNKS + lane < SD_CHUNKS) __builtin_amdgcn_global_load_lds((gsrc)src, (ldst)dst, 16, 0, 0);
+        }
         if (threadIdx.x < 16) t_c1w = c_tab.rl_c1w[threadIdx.x];
         if (threadIdx.x < 64) t_tr = c_tab.transform[threadIdx.x >> 1][threadIdx.x & 1];
-#pragma unroll
-        for (int r = 0; r < 2; r++) { const int i = (int)threadIdx.x + r * RL_WAVES * 64; t_sd[r] = c_tab.subdiv_lut[sr_wg][i < 289 ? i : 288]; }
     }
     auto tables_in = [&]() {
-        uint4 *dst = reinterpret_cast<uint4 *>(tb.int2idx);
-#pragma unroll
-        for (int r = 0; r < I2I_ROUNDS; r++) { const int i = (int)threadIdx.x + r * RL_WAVES * 64; if (i < I2I_CHUNKS) dst[i] = t_i2i[r]; }
-        tb.hl[threadIdx.x & 255] = t_hl;
         if (threadIdx.x < 16) tb.c1w[threadIdx.x] = t_c1w;
         if (threadIdx.x < 64) tb.transform[threadIdx.x] = (uint8_t)t_tr;
-#pragma unroll
-        for (int r = 0; r < 2; r++) { const int i = (int)threadIdx.x + r * RL_WAVES * 64; if (i < 289) tb.subdiv[i] = t_sd[r]; }
+        __builtin_amdgcn_s_waitcnt(0);            // (this wave's pieces have landed in LDS)
         __syncthreads();
     };
     if (CHAIN) tables_in();
 
     int li0 = blockIdx.x * RL_WAVES + wave;
-    if (li0 >= n_list + var.n) { if (!CHAIN) tables_in(); return; }
+    if (li0 >= n_total) { if (!CHAIN) tables_in(); return; }
     do {                                          // (one trip unless CHAIN: the plain rate loop keeps its straight-line shape)
     int li = li0;
     uint8_t *tables_out = nullptr;
@@ -584,9 +623,19 @@ __device__ __forceinline__ void rate_units(
         int bits = 0, flags = 0;
         bool err = false;
 
+#if MP3S_RL_STATS
+        const unsigned long long clk1 = RL_CLK();
+#endif
         if (!CHAIN) tables_in();               // (every wave of the workgroup comes by here, or by one of the two returns above, exactly once)
+#if MP3S_RL_STATS
+        const unsigned long long clk2 = RL_CLK();
+        unsigned long long clk3 = clk2, clk4 = clk2, clk5 = clk2;
+        RL_STAT(54, clk1 - clk0); RL_STAT(55, clk2 - clk1); RL_STAT(60, 1);
+        int probe_j = 0;
+#endif
         if (xrmax) {
             flags |= MP3S_RF_ACTIVE;
+            RL_STAT(35, 1);
             // ---- __bin_search_step_size (:958-996)
             int next = -120, count = 120;
             int body_step = 1 << 20, body_bits = 0;   // step whose quantisation + rl_body results are still in ix / st
@@ -602,8 +651,14 @@ __device__ __forceinline__ void rate_units(
                     if (bit < max_bits) { count = 60; sc = sc_lo; }
                     else { next += 60; count -= 60; sc = sc_hi; }
                     asm volatile("s_mov_b32 %0, %0" : "+s"(sc));
+#if MP3S_RL_STATS
+                    RL_STAT(0 * 5 + 0, 1); RL_STAT(40, 1); RL_STAT(47, 1); probe_j = 1;
+#endif
                 }
             }
+#if MP3S_RL_STATS
+            clk3 = RL_CLK();
+#endif
             do {
                 const int half = count / 2;
                 // the scales of the two steps the search may probe next, asked for now
@@ -611,17 +666,32 @@ __device__ __forceinline__ void rate_units(
                 const int q = rl_quantize(tb, xa, ix, next + half, sc, xrmax);
                 int bit;
                 if (q < 0) { err = true; break; }
-                if (q > 8192) { bit = 100000; if (q != 16384) body_step = 1 << 20; }   // 16384 = early out, ix untouched
+                if (q > 8192) { bit = 100000; if (q != 16384) body_step = 1 << 20; RL_STAT(probe_j * 5 + 1, 1); }   // 16384 = early out, ix untouched
                 else {
                     bool full;
                     // the last probe (half == 1) is the one the inner loop may reuse: it is evaluated in full
                     bit = rl_body(tb, ix, p0, st, hide, n_hide, cursor, max_bits, half > 1, full);
                     if (full) { body_step = next + half; body_bits = bit; } else body_step = 1 << 20;
+#if MP3S_RL_STATS
+                    RL_STAT(probe_j * 5 + (full ? 4 : (bit >= max_bits ? 2 : 3)), 1);
+                    RL_STAT(62, 1); if (st.count1 > 0) RL_STAT(61, 1);
+#endif
                 }
+#if MP3S_RL_STATS
+                if (bit >= max_bits) {           // what the threshold pre-check would have said about this probe
+                    RlState st2 = st; bool qe;
+                    const int pb = rl_precheck(tb, xa, p0, st2, next + half, sc, xrmax, max_bits, qe);
+                    RL_STAT(40 + probe_j, 1); if (pb >= max_bits) RL_STAT(47 + probe_j, 1);
+                }
+                probe_j++;
+#endif
                 if (bit < max_bits) { count = half; sc = sc_lo; }
                 else { next += half; count -= half; sc = sc_hi; }
             } while (count > 1);
             qstep = next;
+#if MP3S_RL_STATS
+            clk4 = RL_CLK();
+#endif
             // ---- __inner_loop (:1064-1095), part2_length == 0
             if (!err) {
                 if (max_bits < 0) qstep -= 1;
@@ -633,6 +703,7 @@ __device__ __forceinline__ void rate_units(
                         qstep += 1;
                         bits = body_bits;
                         body_step = 1 << 20;
+                        RL_STAT(37, 1);
                         continue;
                     }
                     int q;
@@ -641,9 +712,16 @@ __device__ __forceinline__ void rate_units(
                     qstep += 1;
                     bool full;
                     bits = rl_body(tb, ix, p0, st, hide, n_hide, cursor, max_bits + 1, false, full);
+#if MP3S_RL_STATS
+                    RL_STAT(36, 1); RL_STAT(full ? 39 : 38, 1); RL_STAT(62, 1); if (st.count1 > 0) RL_STAT(61, 1);
+#endif
                 } while (bits > max_bits);
             }
             if (err) flags |= MP3S_RF_STEP_RANGE;
+#if MP3S_RL_STATS
+            clk5 = RL_CLK();
+            RL_STAT(56, clk3 - clk2); RL_STAT(57, clk4 - clk3); RL_STAT(58, clk5 - clk4);
+#endif
         }
         if (st.used_addr_in) flags |= MP3S_RF_USED_ADDR_IN;
         if (CHAIN && !chained) flags |= MP3S_RF_LISTED;    // (a list entry's unit stays marked: see the chain walk below)
@@ -683,6 +761,9 @@ __device__ __forceinline__ void rate_units(
             out[compact == 1 || compact == 2 ? li : u - out_base] = o;
             if (tables_out) tables_out[li] = (uint8_t)o.n_tables;
         }
+#if MP3S_RL_STATS
+        RL_STAT(59, RL_CLK() - clk5);
+#endif
         if (!CHAIN) break;
         // ---- the chain behind this unit: what it leaves (an active unit: its own addresses and step; a silent one passes on what it got)
         ch_state[0] = __builtin_amdgcn_readfirstlane(st.a1); ch_state[1] = __builtin_amdgcn_readfirstlane(st.a2);
@@ -707,10 +788,10 @@ __device__ __forceinline__ void rate_units(
         ch_cursor = (n_hide_all > 0 && cursor_all) ? cursor_all[u] : 0;
     }
     }   // the unit and its chain
-    } while (CHAIN && (li0 += (int)gridDim.x * RL_WAVES) < n_list + var.n);   // list entries
+    } while (CHAIN && (li0 += (int)gridDim.x * RL_WAVES) < n_total);   // list entries
 }
 
-__global__ __launch_bounds__(RL_WAVES * 64, 5) void k_rate_loop(
+__global__ __launch_bounds__(RL_WAVES * 64, MP3S_RL_OCC) void k_rate_loop(
     const int32_t *__restrict__ mdct, const mp3s_rate_frame *__restrict__ frames, int n_units,
     const uint8_t *__restrict__ hide, int n_hide, const int32_t *__restrict__ cursor_in,
     const int32_t *__restrict__ state_in, const int32_t *__restrict__ unit_list, int n_list,
@@ -734,7 +815,7 @@ __global__ __launch_bounds__(RL_WAVES * 64, 4) void k_rate_redo(
     if ((int)blockIdx.x * RL_WAVES >= n_list) return;              // (most launches find an empty list: nothing staged)
     const RateVariants none = {nullptr, nullptr, 0, nullptr, nullptr, nullptr, nullptr};
     rate_units<true>(mdct, frames, n_units, hide, n_hide, unit_list + REDO_CAP, unit_list + 2 * REDO_CAP, unit_list, n_list, ix_out, out, en_out,
-                     0, 3, none, cursor_all);
+                  0, 3, none, cursor_all);
 }
 
 // Message variants (enc_resolve): a unit's result depends on the message only through the <= 3 bits at its cursor, so

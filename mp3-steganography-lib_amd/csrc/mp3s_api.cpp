@@ -373,6 +373,12 @@ int mp3s_profile_collect(mp3s_ctx *c, double *total_ms, int64_t *launches, int n
         p.count[p.kid[i]] += 1;
     }
     p.n_pairs = 0;
+    if (p.dropped) {
+        // (a table that silently under-counts a kernel is worse than none: collect more often -- MAX_PAIRS launches fit between two calls)
+        const long lost = p.dropped;
+        p.dropped = 0;
+        return fail(MP3S_E_ARG, "%ld timed launches had no event pair left (collect at least every %d launches)", lost, Profiler::MAX_PAIRS);
+    }
     for (int k = 0; k < K_COUNT; k++) { total_ms[k] = p.total_ms[k]; launches[k] = p.count[k]; }
     static_assert(K_COUNT == MP3S_N_KERNELS, "kernel list out of sync with mp3s.h");
     return MP3S_OK;
@@ -389,8 +395,20 @@ int mp3s_decode_transform_dev(mp3s_ctx *c, const int16_t *d_is, const mp3s_granu
     if (rc) return rc;
     const int e = launch_decode(c->stream, d_is, d_si, d_hdr, n_frames, nch, n_halo, out_format, d_pcm, c->scratch, &c->prof, 0,
                                 c->synth_eps_scale, c->d_sync, c->opt[MP3S_OPT_FAST_IMDCT] != 0, c->opt[MP3S_OPT_FLOAT_FAST] != 0,
-                                c->opt[MP3S_OPT_FUSED_DECODE] != 0);
+                                c->opt[MP3S_OPT_FUSED_DECODE] != 0, nullptr, [&]() -> const GuardProbe * {
+                                    if (!c->guard_probe.x) return nullptr;
+                                    c->guard_probe.base = 0;
+                                    return &c->guard_probe; }());
     if (e) return fail(MP3S_E_HIP, "decode launch: %s", hipGetErrorString((hipError_t)e));
+    return MP3S_OK;
+}
+
+int mp3s_debug_guard_margin(mp3s_ctx *c, double *d_x, double *d_eps, int64_t capacity)
+{
+    if (!c) return fail(MP3S_E_ARG, "null context");
+    if ((d_x == nullptr) != (d_eps == nullptr) || (d_x && capacity <= 0)) return fail(MP3S_E_ARG, "both arrays and their capacity, or neither");
+    HIPCHK(hipStreamSynchronize(c->stream));
+    c->guard_probe = GuardProbe{d_x, d_eps, 0, d_x ? capacity : 0};
     return MP3S_OK;
 }
 

@@ -71,7 +71,10 @@ int decode_transform_chunk(mp3s_ctx *c, const int16_t *d_is, const mp3s_granule_
     if (rc) return rc;
     const int e = launch_decode(stream ? stream : c->stream, d_is + (size_t)first * 2304, d_si + (size_t)first * 4, d_hdr + first, cnt, nch, halo, out_format,
                                 d_pcm, c->scratch, &c->prof, (int)first, c->synth_eps_scale, c->d_sync, c->opt[MP3S_OPT_FAST_IMDCT] != 0, c->opt[MP3S_OPT_FLOAT_FAST] != 0,
-                                c->opt[MP3S_OPT_FUSED_DECODE] != 0, done);
+                                c->opt[MP3S_OPT_FUSED_DECODE] != 0, done, [&]() -> const GuardProbe * {
+                                    if (!c->guard_probe.x) return nullptr;
+                                    c->guard_probe.base = (int64_t)(first + halo) * 1152 * nch;   // (a batch's chunks fill the probe's arrays side by side)
+                                    return &c->guard_probe; }());
     if (e) return fail(MP3S_E_HIP, "decode launch: %s", hipGetErrorString((hipError_t)e));
     return MP3S_OK;
 }

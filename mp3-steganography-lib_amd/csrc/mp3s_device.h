@@ -22,6 +22,7 @@ struct Profiler {
     hipEvent_t ev[2 * MAX_PAIRS];
     int kid[MAX_PAIRS];
     int n_pairs = 0, n_created = 0;
+    long dropped = 0;                         // launches that asked for an event pair and got none (MAX_PAIRS reached, event creation failed): mp3s_profile_collect refuses a table that misses them
     bool enabled = false;
     unsigned mask = ~0u;                      // bit k: kernel k gets an event pair
     double total_ms[K_COUNT] = {0};
@@ -34,6 +35,9 @@ struct Profiler {
 
 int dev_upload_tables(hipStream_t stream);
 
+// mp3s_debug_guard_margin: where the fused int16 decode leaves its fast values and guard widths (device arrays of `cap` doubles; a launch's
+// sample i goes to element base + i)
+struct GuardProbe { double *x, *eps; int64_t base, cap; };
 // scratch: time-domain subband samples, float64 [nch][36 n][32], + what the fast int16 path keeps beside them
 size_t dec_scratch_bytes(int n_frames, int nch);
 int launch_decode(hipStream_t stream, const int16_t *d_is, const mp3s_granule_si *d_si, const mp3s_frame_hdr *d_hdr,
@@ -48,7 +52,8 @@ int launch_decode(hipStream_t stream, const int16_t *d_is, const mp3s_granule_si
                   bool float_fast = false /* MP3S_OPT_FLOAT_FAST: float32 output through the fast sums, unguarded (within 1e-5, not bit-identical) */,
                   bool fused = true /* MP3S_OPT_FUSED_DECODE: the fast paths as one kernel, S in LDS (k_decode_fused.hpp) */,
                   hipEvent_t done = nullptr /* recorded behind the transforms: as the last dispatch's own completion signal where the path has one
-                                               (the fused int16 path: no record packet in the queue), by a record otherwise */);
+                                               (the fused int16 path: no record packet in the queue), by a record otherwise */,
+                  const GuardProbe *probe = nullptr /* the fused int16 path also writes its fast values and guard widths there (a probe) */);
 
 // scratch: subband samples int32 [2][32][36 n]
 size_t enc_scratch_bytes(int n_frames);

@@ -29,9 +29,10 @@ namespace mp3s {
 
 int Profiler::begin(hipStream_t s, int k)
 {
-    if (!enabled || !((mask >> k) & 1u) || n_pairs >= MAX_PAIRS) return -1;
+    if (!enabled || !((mask >> k) & 1u)) return -1;
+    if (n_pairs >= MAX_PAIRS) { dropped++; return -1; }
     while (n_created < 2 * (n_pairs + 1)) {
-        if (hipEventCreate(&ev[n_created]) != hipSuccess) return -1;
+        if (hipEventCreate(&ev[n_created]) != hipSuccess) { dropped++; return -1; }
         n_created++;
     }
     kid[n_pairs] = k;
@@ -44,9 +45,10 @@ void Profiler::end(hipStream_t s, int pair)
 }
 bool Profiler::attach(int k, hipEvent_t *start, hipEvent_t *stop)
 {
-    if (!enabled || !((mask >> k) & 1u) || n_pairs >= MAX_PAIRS) return false;
+    if (!enabled || !((mask >> k) & 1u)) return false;
+    if (n_pairs >= MAX_PAIRS) { dropped++; return false; }
     while (n_created < 2 * (n_pairs + 1)) {
-        if (hipEventCreate(&ev[n_created]) != hipSuccess) return false;
+        if (hipEventCreate(&ev[n_created]) != hipSuccess) { dropped++; return false; }
         n_created++;
     }
     kid[n_pairs] = k;
@@ -74,7 +76,7 @@ size_t dec_scratch_bytes(int n_frames, int nch)
 
 int launch_decode(hipStream_t stream, const int16_t *d_is, const mp3s_granule_si *d_si, const mp3s_frame_hdr *d_hdr,
                   int n_frames, int nch, int n_halo, int out_format, void *d_pcm, void *d_scratch, Profiler *prof, int sf_base,
-                  double synth_eps_scale, int32_t *d_sync, bool fast_imdct, bool float_fast, bool fused, hipEvent_t done)
+                  double synth_eps_scale, int32_t *d_sync, bool fast_imdct, bool float_fast, bool fused, hipEvent_t done, const GuardProbe *probe)
 {
     const long T = (long)n_frames * 36;
     double *S = (double *)d_scratch;
@@ -103,11 +105,14 @@ int launch_decode(hipStream_t stream, const int16_t *d_is, const mp3s_granule_si
         const dim3 grid((runs + ST_WAVES - 1) / ST_WAVES), block(ST_WAVES * 64);
         const int pf = prof ? prof->begin(stream, K_DEC_SYNTH) : -1;
         if (fast32) {
-            if (nch == 2) hipLaunchKernelGGL((k_dec_stream<2, true>), grid, block, 0, stream, d_is, d_si, d_hdr, n_gran, run, n_halo, d_pcm, sf_base, 1.0, (uint2 *)nullptr, (int32_t *)nullptr);
-            else hipLaunchKernelGGL((k_dec_stream<1, true>), grid, block, 0, stream, d_is, d_si, d_hdr, n_gran, run, n_halo, d_pcm, sf_base, 1.0, (uint2 *)nullptr, (int32_t *)nullptr);
+            if (nch == 2) hipLaunchKernelGGL((k_dec_stream<2, true>), grid, block, 0, stream, d_is, d_si, d_hdr, n_gran, run, n_halo, d_pcm, sf_base, 1.0, (uint2 *)nullptr, (int32_t *)nullptr, (double *)nullptr, (double *)nullptr, 0L, 0L);
+            else hipLaunchKernelGGL((k_dec_stream<1, true>), grid, block, 0, stream, d_is, d_si, d_hdr, n_gran, run, n_halo, d_pcm, sf_base, 1.0, (uint2 *)nullptr, (int32_t *)nullptr, (double *)nullptr, (double *)nullptr, 0L, 0L);
         } else {
-            if (nch == 2) hipLaunchKernelGGL((k_dec_stream<2, false>), grid, block, 0, stream, d_is, d_si, d_hdr, n_gran, run, n_halo, d_pcm, sf_base, synth_eps_scale, fix_list, d_sync + 6);
-            else hipLaunchKernelGGL((k_dec_stream<1, false>), grid, block, 0, stream, d_is, d_si, d_hdr, n_gran, run, n_halo, d_pcm, sf_base, synth_eps_scale, fix_list, d_sync + 6);
+            if (probe && probe->x) {     // (mp3s_debug_guard_margin: the probe's instantiation of the same kernel)
+                if (nch == 2) hipLaunchKernelGGL((k_dec_stream<2, false, true>), grid, block, 0, stream, d_is, d_si, d_hdr, n_gran, run, n_halo, d_pcm, sf_base, synth_eps_scale, fix_list, d_sync + 6, probe->x, probe->eps, (long)probe->base, (long)probe->cap);
+                else hipLaunchKernelGGL((k_dec_stream<1, false, true>), grid, block, 0, stream, d_is, d_si, d_hdr, n_gran, run, n_halo, d_pcm, sf_base, synth_eps_scale, fix_list, d_sync + 6, probe->x, probe->eps, (long)probe->base, (long)probe->cap);
+            } else if (nch == 2) hipLaunchKernelGGL((k_dec_stream<2, false>), grid, block, 0, stream, d_is, d_si, d_hdr, n_gran, run, n_halo, d_pcm, sf_base, synth_eps_scale, fix_list, d_sync + 6, (double *)nullptr, (double *)nullptr, 0L, 0L);
+            else hipLaunchKernelGGL((k_dec_stream<1, false>), grid, block, 0, stream, d_is, d_si, d_hdr, n_gran, run, n_halo, d_pcm, sf_base, synth_eps_scale, fix_list, d_sync + 6, (double *)nullptr, (double *)nullptr, 0L, 0L);
             const int fix_groups = (int)((T * nch + DEC_A_WAVES - 1) / DEC_A_WAVES) < 128 ? (int)((T * nch + DEC_A_WAVES - 1) / DEC_A_WAVES) : 128;
             if (done)
                 hipExtLaunchKernelGGL(k_dec_fixup, dim3(fix_groups), dim3(DEC_A_WAVES * 64), 0, stream, nullptr, done, 0, d_is, d_si, d_hdr, n_gran, nch, T, n_halo,

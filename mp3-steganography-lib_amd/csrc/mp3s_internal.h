@@ -49,6 +49,7 @@ struct mp3s_ctx {
     int32_t *d_sync = nullptr;        // 64-bit word {finished workgroups | error bits} of the pack kernel in flight (k_sync.hpp): self-clearing;
                                       // [2] counts the samples the fast synthesis computed again in the exact order
     double synth_eps_scale = 1.0;     // int16 decode: scale of the fast synthesis guard (0 = always the exact kernel)
+    GuardProbe guard_probe = {nullptr, nullptr, 0, 0};   // mp3s_debug_guard_margin
     void *scratch = nullptr; size_t scratch_bytes = 0;
     Profiler prof;
     // device buffers of the stream pipelines, kept between calls (hipMalloc/hipFree cost more than a small file's work)

@@ -172,7 +172,7 @@ class Block(C.Structure):
 SYMBOLS = ["mp3s_ctx_create", "mp3s_ctx_destroy", "mp3s_ctx_wait", "mp3s_ctx_wait_last", "mp3s_last_error", "mp3s_version", "mp3s_device_name", "mp3s_sync", "mp3s_debug_tables", "mp3s_debug_scfsi_energies", "mp3s_debug_parse_scanned_frame",
            "mp3s_dev_alloc", "mp3s_dev_free", "mp3s_dev_upload", "mp3s_dev_download", "mp3s_dev_memset",
            "mp3s_timer_start", "mp3s_timer_stop", "mp3s_bench_copy", "mp3s_synth_mode", "mp3s_profile_enable", "mp3s_profile_select", "mp3s_profile_collect", "mp3s_decode_transform_dev", "mp3s_decode_transform",
-           "mp3s_encode_transform_dev", "mp3s_encode_transform", "mp3s_rate_loop_dev", "mp3s_chain_resolve_dev", "mp3s_chain_redo_dev", "mp3s_select_patterns", "mp3s_select_plan", "mp3s_rate_select_dev", "mp3s_rate_variants_dev", "mp3s_select_dev", "mp3s_huffman_decode_dev", "mp3s_pack_frames_dev", "mp3s_scan_stream", "mp3s_buf_free",
+           "mp3s_encode_transform_dev", "mp3s_encode_transform", "mp3s_debug_guard_margin", "mp3s_rate_loop_dev", "mp3s_chain_resolve_dev", "mp3s_chain_redo_dev", "mp3s_select_patterns", "mp3s_select_plan", "mp3s_rate_select_dev", "mp3s_rate_variants_dev", "mp3s_select_dev", "mp3s_huffman_decode_dev", "mp3s_pack_frames_dev", "mp3s_scan_stream", "mp3s_buf_free",
            "mp3s_parse_stream", "mp3s_format_stream", "mp3s_rate_frames", "mp3s_decode_stream", "mp3s_decode_streams", "mp3s_decode_block", "mp3s_encode_pcm", "mp3s_encode_block",
            "mp3s_wav_parse", "mp3s_wav_header", "mp3s_message_frame", "mp3s_message_reveal", "mp3s_decode_file", "mp3s_encode_file",
            "mp3s_hide_message", "mp3s_clear_file", "mp3s_hide_message_fd", "mp3s_clear_file_fd", "mp3s_decode_file_fd", "mp3s_hide_messages", "mp3s_reencode_block", "mp3s_reveal_message",
@@ -471,6 +471,32 @@ class Context:
         n = C.c_int64()
         check(lib().mp3s_synth_mode(self.handle, float(eps_scale), C.byref(n)))
         return n.value
+
+    def guard_margin(self, n_samples):
+        """probe of the int16 decode's guard (include/mp3s.h mp3s_debug_guard_margin): context manager; inside it every fused int16 decode of
+        up to n_samples samples leaves its fast values and guard widths, read with .read() -> (x, eps) float64 arrays"""
+        ctx = self
+
+        class _Probe:
+            def __enter__(self):
+                lib().mp3s_debug_guard_margin.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64]
+                self.n = int(n_samples)
+                self.d_x, self.d_eps = ctx.alloc(self.n * 8), ctx.alloc(self.n * 8)
+                check(lib().mp3s_dev_memset(ctx.handle, self.d_x, 0, self.n * 8))
+                check(lib().mp3s_dev_memset(ctx.handle, self.d_eps, 0, self.n * 8))
+                check(lib().mp3s_debug_guard_margin(ctx.handle, self.d_x, self.d_eps, self.n))
+                return self
+
+            def read(self, n=None):
+                ctx.sync()
+                n = self.n if n is None else int(n)
+                return ctx.download(self.d_x, np.float64, (n,)), ctx.download(self.d_eps, np.float64, (n,))
+
+            def __exit__(self, *exc):
+                check(lib().mp3s_debug_guard_margin(ctx.handle, None, None, 0))
+                ctx.free(self.d_x); ctx.free(self.d_eps)
+                return False
+        return _Probe()
 
     def bench_copy(self, nbytes=1 << 30, iters=20):
         """GB/s (read + write) of a plain device copy kernel"""

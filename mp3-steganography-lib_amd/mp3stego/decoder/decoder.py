@@ -46,15 +46,17 @@ class Decoder:
         # refuses leaves no file behind that was not there (the reference raises before it writes)
         there = os.path.exists(self.__output_file_path)
         fd = os.open(self.__output_file_path, os.O_WRONLY | os.O_CREAT, 0o666)
+        held = os.fstat(fd).st_size             # a file that holds something is only written when the call has succeeded (mp3s_decode_file_fd)
         try:
             res = _lib.default_context().decode_file_to_fd(self.__data, fd)
         except BaseException as e:
-            # whatever ends the call (the library's refusal, an interrupt, no memory): no output is left behind that was not there,
-            # and one that was there is not left half written
+            # whatever ends the call (the library's refusal, an interrupt, no memory): no output is left behind that was not there; one
+            # that was there and empty is empty again (chunks may have gone to it); one that held something has not been touched -- the
+            # reference raises while it parses, before write_to_wav (decoder.py:59-84), and leaves the user's file as it was
             os.close(fd); fd = -1
             if not there:
                 os.remove(self.__output_file_path)
-            else:
+            elif held == 0:
                 os.truncate(self.__output_file_path, 0)
             if isinstance(e, _lib.Mp3sError) and e.code in (_lib.E_MALFORMED, _lib.E_UNSUPPORTED):
                 raise ValueError(str(e)) from None

@@ -9,6 +9,8 @@ device memory) whenever nothing of the detour would be observable.
 import contextlib
 import os
 import sys
+import threading
+import warnings
 
 from mp3stego.decoder.decoder import Decoder
 from mp3stego.encoder.encoder import Encoder
@@ -28,12 +30,14 @@ def _must_exist(path: str):
 
 _helper = None
 _pending = []          # what the helper thread was given and nobody has looked at yet
+_pending_lock = threading.Lock()
 
 
 def _reset_helper():
     """a forked child starts without the parent's helper thread (its executor would wait for a thread that is not there)"""
-    global _helper
+    global _helper, _pending_lock
     _helper = None
+    _pending_lock = threading.Lock()     # (the parent's may have been held by a thread that does not exist here)
     _pending.clear()
 
 
@@ -42,10 +46,16 @@ if hasattr(os, "register_at_fork"):
 
 
 def _settle():
-    """what the helper thread has finished: its exceptions surface here (at the start of the next call, or at exit) instead of nowhere"""
-    for fut in [f for f in _pending if f.done()]:
-        _pending.remove(fut)
-        fut.result()
+    """what the helper thread has finished is taken off the list; a failure of such a deferred clean-up (the un-mapping of an EARLIER
+    call's input) is reported as a warning -- it is not this call's failure and must not make a valid request fail"""
+    with _pending_lock:
+        done = [f for f in _pending if f.done()]
+        for fut in done:
+            _pending.remove(fut)
+    for fut in done:
+        err = fut.exception()
+        if err is not None:
+            warnings.warn(f"mp3stego: a deferred clean-up of an earlier call failed: {err!r}", RuntimeWarning, stacklevel=3)
 
 
 def _later(fn):
@@ -57,7 +67,8 @@ def _later(fn):
         _helper = ThreadPoolExecutor(max_workers=1, thread_name_prefix="mp3stego-aux")
         atexit.register(lambda: (_helper.shutdown(wait=True) if _helper is not None else None))
     fut = _helper.submit(fn)
-    _pending.append(fut)
+    with _pending_lock:
+        _pending.append(fut)
     return fut
 
 
@@ -71,6 +82,14 @@ def _store(path: str, out):
         os.ftruncate(fd, len(out))
     finally:
         os.close(fd)
+
+
+def _same_file(a: str, b: str) -> bool:
+    """one file under two names (a symbolic or hard link to the input as the output) counts as in place"""
+    try:
+        return os.path.samefile(a, b)
+    except OSError:
+        return os.path.abspath(a) == os.path.abspath(b)
 
 
 def _ends(path: str, ext: str) -> bool:
@@ -212,7 +231,7 @@ class Steganography:
                     # (the runtime registers the pages of a mapping it uploads from with the device; taking the mapping down undoes that in
                     # the driver: 0.34 ms per 4 MB -- on the helper thread, beside the write of the result.  When the output IS the input
                     # the mapping goes first: the caller may rewrite the file the moment this call returns)
-                    if os.path.abspath(mp3_out) == os.path.abspath(mp3_in):
+                    if _same_file(mp3_in, mp3_out):
                         mapped.close()
                     else:
                         _later(mapped.close)

@@ -10,7 +10,11 @@ HBM_PEAK = 8000.0
 
 
 def test_latest_bench_line_has_the_contract_fields():
-    latest = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_bench.json")))[-1]
+    lines = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_bench.json")))
+    if not lines:
+        import pytest
+        pytest.skip("no bench line under profiles/ (a checkout without it)")
+    latest = lines[-1]
     check_line(json.loads(open(latest).read().strip().splitlines()[-1]))
 
 

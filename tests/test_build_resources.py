@@ -16,11 +16,15 @@ PKG = os.path.join(ROOT, "mp3-steganography-lib_amd")
 HIPCC = "/opt/rocm/bin/hipcc"
 
 # the kernels of the resident decode -> embed -> re-encode step (bench.py region (i)), by the start of their demangled names
-STEP_KERNELS = ["mp3s::k_dec_parse", "void mp3s::k_dec_huffman<4, 64>", "void mp3s::k_dec_stream<2, false>", "mp3s::k_dec_fixup",
+STEP_KERNELS = ["mp3s::k_dec_parse", "void mp3s::k_dec_huffman<4, 64>", "void mp3s::k_dec_stream<2, false, false>", "mp3s::k_dec_fixup",
                 "mp3s::k_enc_analysis", "mp3s::k_enc_mdct", "mp3s::k_rate_loop", "mp3s::k_enc_pack"]
 # kernels beside them that must not spill vector registers either (the float formats' exact path, mono, float32-fast)
-OTHER_KERNELS = ["void mp3s::k_dec_stream<1, false>", "void mp3s::k_dec_stream<2, true>", "void mp3s::k_dec_imdct<false>", "void mp3s::k_dec_synth<2>"]
+OTHER_KERNELS = ["void mp3s::k_dec_stream<1, false, false>", "void mp3s::k_dec_stream<2, true, false>", "void mp3s::k_dec_imdct<false>", "void mp3s::k_dec_synth<2>"]
 SGPR_SPILL_CAP = 128      # scalar spills are cheap (a lane write / read each) but not free: a kernel that needs more has lost its shape
+# k_rate_loop at six waves per SIMD (80 VGPRs) keeps a few values that live AROUND its search loop in scratch: measured faster than five waves
+# without (round 6: 0.214 -> 0.204 ms in the step); inside the loop only its rare table-swap path reloads them.  More than this is a regression.
+VGPR_SPILL_ALLOWED = {"mp3s::k_rate_loop": (8, 32)}       # kernel: (registers, scratch bytes per lane)
+TABLE = os.path.join(ROOT, "profiles", "r06_kernel_resources.json")
 
 
 def resource_usage():
@@ -57,24 +61,28 @@ def _find(usage, start):
     return usage[hits[0]]
 
 
+def resource_table(usage):
+    return {k: _find(usage, k) for k in STEP_KERNELS + OTHER_KERNELS}
+
+
 def test_step_kernels_do_not_spill_vector_registers(usage):
-    table = {}
-    for k in STEP_KERNELS + OTHER_KERNELS:
-        u = _find(usage, k)
-        table[k] = u
-        assert u["VGPRs Spill"] == 0 and u["ScratchSize [bytes/lane]"] == 0, (k, u)
+    table = resource_table(usage)
+    for k, u in table.items():
+        regs, scratch = VGPR_SPILL_ALLOWED.get(k, (0, 0))
+        assert u["VGPRs Spill"] <= regs and u["ScratchSize [bytes/lane]"] <= scratch, (k, u)
         assert u["SGPRs Spill"] <= SGPR_SPILL_CAP or k in ("mp3s::k_dec_fixup", "void mp3s::k_dec_imdct<false>"), (k, u)
-    # the table the design document cites (tracked; rewritten only when the numbers move)
-    path = os.path.join(ROOT, "profiles", "r05_kernel_resources.json")
-    new = json.dumps(table, indent=1, sort_keys=True) + "\n"
-    if not os.path.exists(path) or open(path).read() != new:
-        try:
-            open(path, "w").write(new)
-        except OSError:
-            pass
+    # the table the design document cites is a tracked file: compared here, written by `python tests/test_build_resources.py`
+    if not os.path.exists(TABLE):
+        pytest.skip("no committed table (a checkout without profiles/)")
+    assert json.load(open(TABLE)) == table, "profiles/r06_kernel_resources.json is stale: python tests/test_build_resources.py"
 
 
 def test_occupancy_is_what_the_launch_bounds_ask_for(usage):
-    want = {"mp3s::k_rate_loop": 5, "mp3s::k_enc_analysis": 5, "mp3s::k_enc_mdct": 4, "void mp3s::k_dec_stream<2, false>": 2}
+    want = {"mp3s::k_rate_loop": 6, "mp3s::k_enc_analysis": 5, "mp3s::k_enc_mdct": 4, "void mp3s::k_dec_stream<2, false, false>": 2}
     for k, occ in want.items():
         assert _find(usage, k)["Occupancy [waves/SIMD]"] >= occ, (k, _find(usage, k))
+
+
+if __name__ == "__main__":
+    open(TABLE, "w").write(json.dumps(resource_table(resource_usage()), indent=1, sort_keys=True) + "\n")
+    print("wrote", TABLE)

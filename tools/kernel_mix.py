@@ -44,5 +44,5 @@ if __name__ == "__main__":
         out[short.replace("mp3s::", "")] = dict(c, valu=sum(c.values()), instructions=len(ins))
     path = os.path.join(isa_stats.ROOT, "profiles", "r05_kernel_mix.json")
     json.dump(out, open(path, "w"), indent=1, sort_keys=True)
-    for k in ("k_rate_loop", "k_enc_analysis", "k_dec_stream<2, false>", "k_enc_mdct", "k_enc_pack", "k_dec_huffman<4, 64>"):
+    for k in ("k_rate_loop", "k_enc_analysis", "k_dec_stream<2, false, false>", "k_enc_mdct", "k_enc_pack", "k_dec_huffman<4, 64>"):
         print(k, out.get(k))
