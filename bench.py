@@ -70,6 +70,29 @@ def bits_of(s):
     return np.frombuffer("".join(format(b, "08b") for b in s.encode()).encode(), dtype=np.uint8) - ord("0")
 
 
+def rank_host_record(rank, scan_threads, e2e_steady, host_share):
+    """what one rank reports of the host it shares (the line's `ranks_on_this_host`): its CPUs, its walk / issue time per batch, its share of
+    the page-locked pool (mp3s_ctx_host_share).  `host_share`: a callable returning that dict (the context's, or the library's without a context)"""
+    host = {"rank": rank, "cpus_allowed": len(os.sched_getaffinity(0)), "scan_threads": scan_threads,
+            "host_walk_ms_per_batch": e2e_steady["host_scan_ms_per_batch"] if e2e_steady else None,
+            "host_issue_ms_per_batch": e2e_steady["host_issue_ms_per_batch"] if e2e_steady else None,
+            "pcie_gb_s": round((e2e_steady["bytes_in_per_batch"] + e2e_steady["bytes_out_per_batch"]) / (e2e_steady["ms_per_batch"] * 1e-3) / 1e9, 2) if e2e_steady else None}
+    try:
+        host.update(host_share())            # page-locked bytes pooled / cap, the ranks it believes share the host, CPUs on the GPU's NUMA node
+    except Exception:                         # noqa: BLE001
+        pass
+    return host
+
+
+def gather_rank_hosts(dist, world, host):
+    """every rank's record on every rank, in rank order (rank 0 prints them); one process: just its own"""
+    if dist is None:
+        return [host]
+    hosts = [None] * world
+    dist.all_gather_object(hosts, host)
+    return hosts
+
+
 def run_config5(ctx, _lib, O, synth_pcm, n):
     """BASELINE configs[4]: mixed bitrate / sampling-rate corpus with long / short block switching, mono and joint stereo.
     Decode side: streams from tests/frame_synth.py (250 synthesised frames, laid end to end up to `n`: every copy starts with
@@ -101,6 +124,8 @@ def run_config5(ctx, _lib, O, synth_pcm, n):
         exact_i16 = 0
         for fmt, key in ((_lib.MP3S_PCM_I16, "int16_fast"), (_lib.MP3S_PCM_F32, "float32_exact")):
             ctx.synth_mode(1.0)                                                # (reads and clears the counter of guarded samples)
+            if os.environ.get("MP3S_TRACE"):
+                sys.stderr.write("==== config5 %s %s\n" % (name, key)); sys.stderr.flush()
             r = ctx.decode_stream(data, fmt)
             ok = ok and r["n_frames"] == nf
             head = r["pcm"][:250 * 1152]
@@ -113,13 +138,18 @@ def run_config5(ctx, _lib, O, synth_pcm, n):
                 r = ctx.decode_stream(data, fmt); del r
                 ts.append(time.perf_counter() - t0)
             dt = sorted(ts)[len(ts) // 2]                                      # median of 7 calls (the first calls of a size find no page-locked block in the pool)
-            row[key] = {"ms": round(dt * 1e3, 3), "frames_per_s": round(nf / dt)}
+            row[key] = {"ms": round(dt * 1e3, 3), "frames_per_s": round(nf / dt), "calls_ms": [round(t * 1e3, 3) for t in ts]}
             if fmt == _lib.MP3S_PCM_I16:
                 exact_i16 = ctx.synth_mode(1.0)
         rs1 = ctx.run_stats()
         row["calls_through_the_overlapped_stages"] = rs1["files"] - rs0["files"]     # of 16; the others needed the host parser (scalefactors inherited
         row["calls_through_the_stages_one_after_the_other"] = rs1["fallbacks"] - rs0["fallbacks"]   # across frames, Huffman data that runs into the next granule)
         row["int16_samples_recomputed_in_exact_order_per_call"] = exact_i16 // 8
+        row["lanes"], row["queue_shared"] = rs1["lanes"], rs1["queue_shared"]
+        try:
+            row["pinned_pooled_mb"] = round(ctx.host_share()["pinned_pooled_bytes"] / 2 ** 20, 1)
+        except Exception:                                                      # noqa: BLE001
+            pass
         if name == "all_short_44k_128":
             # per kernel, the stages one after the other (event pairs around every launch)
             ctx.set_option("file_pipeline", 0)
@@ -329,6 +359,7 @@ def main():
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--frames", type=int, default=10000, help="frames per GPU per step / per batch")
+    ap.add_argument("--regions", type=int, default=3, help="timed regions of --steps steps each; `value` is the median one (value_min / value_max beside it)")
     ap.add_argument("--e2e-batches", type=int, default=400, help="batches of the host-fed steady-state region (0 = skip)")
     ap.add_argument("--sustained-seconds", type=float, default=5.0, help="wall time of the `sustained` region: the host-fed steady state for that long, "
                     "frames/s of its first and last second, clocks and power from sysfs (0 = skip)")
@@ -651,13 +682,20 @@ def main():
         if c is not None:
             c.profile_select([dom])
             c.profile_enable(True)
-    barrier()
-    t0 = time.perf_counter()
-    ctx.timer_start()
-    run(args.steps, max(1, args.dom_events_every))
-    gpu_ms = ctx.timer_stop()
-    barrier()
-    wall = time.perf_counter() - t0
+    # The contract's region -- barrier, EXACTLY K steps, barrier -- is timed `--regions` times back to back (default 3); `value` is the median
+    # region, value_min / value_max the others: one region of the driver's 20 steps is 10 ms, of which 0.3-0.4 are the three streams filling
+    # and draining, and moved between 18.2 and 19.2 M frames/s from lease to lease (round-5 verdict, item 3).
+    walls, gpu_mss = [], []
+    for _ in range(max(1, args.regions)):
+        barrier()
+        t0 = time.perf_counter()
+        ctx.timer_start()
+        run(args.steps, max(1, args.dom_events_every))
+        gpu_mss.append(ctx.timer_stop())
+        barrier()
+        walls.append(time.perf_counter() - t0)
+    order = sorted(range(len(walls)), key=lambda i: walls[i])
+    wall, gpu_ms = walls[order[len(order) // 2]], gpu_mss[order[len(order) // 2]]
     prof, _ = collect()
     for c in (ctx, aux, aux2, dctx):
         if c is not None:
@@ -693,6 +731,8 @@ def main():
 
     max_step = reduce_max(wall / args.steps)
     value = n * world / max_step
+    value_min = n * world / reduce_max(max(walls) / args.steps)
+    value_max = n * world / reduce_max(min(walls) / args.steps)
 
     # ---------------------------------------------------------------- the same step on FOUR streams (reported beside `value`, not as it)
     four = None
@@ -1132,18 +1172,7 @@ def main():
         config5, ok5 = run_config5(octx if octx is not None else ctx, _lib, O, synth_pcm, min(n, 10000))
         same = same and ok5
     # ---------------------------------------------------------------- the ranks of one host side by side
-    host = {"rank": rank, "cpus_allowed": len(os.sched_getaffinity(0)), "scan_threads": args.scan_threads,
-            "host_walk_ms_per_batch": e2e_steady["host_scan_ms_per_batch"] if e2e_steady else None,
-            "host_issue_ms_per_batch": e2e_steady["host_issue_ms_per_batch"] if e2e_steady else None,
-            "pcie_gb_s": round((e2e_steady["bytes_in_per_batch"] + e2e_steady["bytes_out_per_batch"]) / (e2e_steady["ms_per_batch"] * 1e-3) / 1e9, 2) if e2e_steady else None}
-    try:
-        host.update(ctx.host_share())            # page-locked bytes pooled / cap, the ranks it believes share the host, CPUs on the GPU's NUMA node
-    except Exception:                             # noqa: BLE001
-        pass
-    hosts = [host]
-    if dist is not None:
-        hosts = [None] * world
-        dist.all_gather_object(hosts, host)
+    hosts = gather_rank_hosts(dist, world, rank_host_record(rank, args.scan_threads, e2e_steady, ctx.host_share))
     same = reduce_all_ok(same and oracle_ok)
 
     # ---------------------------------------------------------------- rooflines of the dominant kernel
@@ -1179,6 +1208,7 @@ def main():
                 "note": "fixed-size fp64/int32 transforms in the reference's exact operation order are ALU-bound, "
                         "not HBM-bound (see DESIGN.md and roofline_alu); frac is reported as the contract defines it; "
                         "copy_kernel_gbs = what a plain device copy achieves on this device (read + write)"}
+    step_hbm_bytes = sum(roofline["hbm_bytes_per_launch_by_kernel"].values()) if roofline["hbm_bytes_per_launch_by_kernel"] else None
     # what actually binds: VALU issue.  Wave instructions of the dominant kernel per launch from the committed PMC summary
     # (SQ_INSTS_VALU, same passes as `traffic`), against the rate the SIMDs can issue them at
     roofline_alu = None
@@ -1199,7 +1229,10 @@ def main():
                             "waves_per_launch": round(pm[dom].get("SQ_WAVES", 0) * n / pm.get("frames", 10000)),
                             "peak_is": f"{N_SIMD} SIMDs x {CLOCK_GHZ} GHz / {CLK_PER_VALU} clk per wave instruction (fp64 and 32-bit "
                                        "multiplies issue at >= 4 clk per wave64 on a SIMD-32: tools/ubench/valu_rates.hip measures 4.5)",
-                            "pmc_source": pm.get("source", "profiles/pmc_latest.json")}
+                            "pmc_source": pm.get("source", "profiles/pmc_latest.json"),
+                            # the same achieved rate against the three peaks one can argue for, side by side: the guide's 2 clocks per wave
+                            # instruction (MI355X_MICROARCH.md), the flat 4 clocks above, and the kernel's own mix below
+                            "frac_at_2_clk": round(ach / (N_SIMD * CLOCK_GHZ / 2.0), 4), "frac_at_4_clk": round(ach / peak, 4)}
             # ... and against the rate its OWN instruction mix can issue at: the listing's vector instructions by class (tools/kernel_mix.py)
             # times the measured cost of each class (tools/ubench/issue_rates.hip: plain 32-bit VOP1/VOP2 1.2 ns per wave instruction and SIMD,
             # VOP3 / DPP / compares / multiplies / fp64 1.9, v_mad_u64_u32 2.3, lane reads 2.4 -- five waves per SIMD, whatever the clock was)
@@ -1212,7 +1245,12 @@ def main():
                 roofline_alu.update({"peak_of_its_mix": round(peak_mix, 1), "frac_of_its_mix": round(ach / peak_mix, 4),
                                      "mix": {c: mix.get(c, 0) for c in ns}, "ns_per_wave_instruction_by_class": {c: round(v, 3) for c, v in ns.items()},
                                      "mean_ns_per_wave_instruction": round(mean_ns, 3),
-                                     "mix_source": "profiles/r05_kernel_mix.json (listing) x profiles/r05_issue_rates.json (measured)"})
+                                     "mix_source": "profiles/r05_kernel_mix.json (the LISTING's instructions by class, not executed counts: the counters of this chip "
+                                                   "count vector instructions by data type, not by encoding -- see valu_by_type -- so the mix-weighted "
+                                                   "peak is an estimate that brackets between frac_at_4_clk and 1) x profiles/r05_issue_rates.json (measured)"})
+                bytype = {k[len("SQ_INSTS_VALU_"):]: round(v * n / pm.get("frames", 10000)) for k, v in pm[dom].items() if k.startswith("SQ_INSTS_VALU_")}
+                if bytype:
+                    roofline_alu["valu_by_type"] = bytype            # EXECUTED wave instructions per launch by the hardware's own classes
             except Exception:
                 pass
         except Exception:
@@ -1268,6 +1306,21 @@ def main():
                        "sample_rate": 44100, "channels": 2, "bitrate_kbps": 128, "message_bits": int(len(hide)),
                        "chain_verdict_units_to_redo": int(verdict[0]), "message_variant_entries": n_ent, "pipeline_rate_passes": int(final["rate_passes"]),
                        "parallelism": f"frames sharded over {world} GPU(s), no collective"},
+            "timed_regions": len(walls), "value_min": round(value_min, 1), "value_max": round(value_max, 1),
+            "value_spread": round((value_max - value_min) / value, 4),
+            # the evidence the nested objects below hold, once more as scalars (a reader that keeps scalars only sees them)
+            "sustained_frames_per_s": sustained["frames_per_s"] if sustained else None,
+            "e2e_steady_frames_per_s": e2e_steady["frames_per_s"] if e2e_steady else None,
+            "cpu_all_cores_frames_per_s": (cpu or {}).get("all_cores", {}).get("value") if cpu else None,
+            "cpu_all_cores": (cpu or {}).get("all_cores", {}).get("cores") if cpu else None,
+            "step_hbm_bytes": step_hbm_bytes,
+            "decode_only_float32_exact_ms": decode_only["ms_per_step"] if decode_only else None,
+            "decode_only_float32_fast_ms": decode_only["float_fast"]["ms_per_step"] if decode_only and "float_fast" in decode_only else None,
+            "decode_only_int16_ms": decode_only["int16"]["ms_per_step"] if decode_only and "int16" in decode_only else None,
+            "facade_ms_per_file": (regions or {}).get("single_file_10k", {}).get("facade_ms_per_file") if regions else None,
+            "c_call_ms_per_file": (regions or {}).get("single_file_10k", {}).get("ms_per_batch") if regions else None,
+            "first_call_ms": (regions or {}).get("single_file_10k", {}).get("first_call", {}).get("ms") if regions else None,
+            "dominant_kernel_ms": round(dom_ms_launch, 4),
             "sustained": sustained,
             "roofline": roofline,
             "roofline_alu": roofline_alu,

@@ -185,7 +185,8 @@ int mp3s_ctx_run_stats(mp3s_ctx *ctx, mp3s_run_stats *out);
 /* What a rank of a multi-process launch holds of the host (all optional): page-locked bytes this PROCESS keeps pooled between calls and the
  * cap it keeps them under (the ranks of a host share its lockable memory: 4 GB / LOCAL_WORLD_SIZE, at least 1 GB), the ranks it believes
  * share the host, the CPUs it may run on, and how many of those lie on the NUMA node of the context's GPU (what a pipe's workers and
- * staging are bound to with MP3S_OPT_NUMA; 0 = unknown, nothing is bound). */
+ * staging are bound to with MP3S_OPT_NUMA; 0 = unknown, nothing is bound).  ctx may be NULL: the host's side alone (gpu_node_cpus = 0),
+ * what a rank would be told without a GPU in reach (the eight-rank CPU test, tests/test_distributed.py). */
 typedef struct {
     uint64_t pinned_pooled_bytes, pinned_pool_cap_bytes;
     int32_t local_world_size, cpus_allowed, gpu_node_cpus, reserved;

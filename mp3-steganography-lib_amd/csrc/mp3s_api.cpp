@@ -175,13 +175,13 @@ void mp3s_ctx_destroy(mp3s_ctx *c)
 
 int mp3s_ctx_host_share(mp3s_ctx *c, mp3s_host_share *out)
 {
-    if (!c || !out) return fail(MP3S_E_ARG, "null pointer");
+    if (!out) return fail(MP3S_E_ARG, "null pointer");
     size_t held = 0, cap = 0;
     PinnedBlock::pool_state(&held, &cap);
     out->pinned_pooled_bytes = held; out->pinned_pool_cap_bytes = cap;
     out->local_world_size = local_world_size();
     out->cpus_allowed = host_cpus_allowed();
-    out->gpu_node_cpus = (int32_t)gpu_node_cpus(c->device).size();
+    out->gpu_node_cpus = c ? (int32_t)gpu_node_cpus(c->device).size() : 0;   // (no context: the host's side alone -- what a rank would get, asked without a GPU)
     out->reserved = 0;
     return MP3S_OK;
 }

@@ -40,6 +40,7 @@ struct mp3s_ctx {
     int64_t opt[MP3S_OPT_COUNT] = {0};   // MP3S_OPT_*: defaults from the environment at creation, then mp3s_ctx_set_option
     mp3s_run_stats run_stats = {0, 0, 0, 0, 0};
     mp3s_pipe *own_pipe = nullptr;       // the overlapped stages the one-file calls run their chunks through (made on first use)
+    std::vector<mp3s_pipe *> parked_pipes;   // own pipes that became too small (a file with larger frames came): quiet, kept until the context goes (run_file.cpp)
     int sink_fd = -1; size_t sink_done = 0, sink_base = 0; bool sink_early = false;   // (sink_early: the file was empty when the call began -- only then do chunks go to it before the call has succeeded)
    // mp3s_*_fd: the file the result goes to, how many of its bytes (behind sink_base: the WAV header's place) run_file has written already
     hipStream_t stream = nullptr;
@@ -353,6 +354,7 @@ struct RunResult {
 // mode: kRunHide (utf8 / n_msg = the message) / kRunClear / kRunDecode (out_format).  MP3S_OK, kRunFallback, or an error.
 int run_file(mp3s_ctx *c, const uint8_t *mp3, size_t len, int mode, const uint8_t *utf8, size_t n_msg, int out_format, mp3s_buf **owner, RunResult *out);
 void destroy_own_pipe(mp3s_ctx *c);
+void pipe_quiesce(mp3s_pipe *P);     // pipe_jobs.cpp: threads ended, streams drained, nothing freed
 void own_pipe_lanes(const mp3s_ctx *c, mp3s_run_stats *out);
 
 // ---------------------------------------------------------------- what this process may use of the host (mp3s_hostinfo.cpp)

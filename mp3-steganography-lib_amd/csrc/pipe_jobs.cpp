@@ -901,6 +901,33 @@ bool finish_fast(mp3s_pipe *P, Job *j, Slot &s, bool *resolved)
     return fast_ok;
 }
 
+// The pipe's threads ended and its streams drained; its buffers, events and results stay as they are (mp3s_pipe_destroy is what is left to do).
+// A context's own pipe that has become too small is parked like this until the context goes (ensure_own_pipe: giving its buffers back at that
+// point halves the rate of the copies behind it for the next ten calls).
+void pipe_quiesce(mp3s_pipe *P)
+{
+    if (!P) return;
+    {
+        std::lock_guard<std::mutex> g(P->mu);
+        P->stop = true;
+        for (auto &q : P->todo) q.clear();
+    }
+    P->cv_work.notify_all();
+    P->cv_turn.notify_all();      // (a worker that waits for its turn behind a dropped ticket)
+    for (auto &t : P->workers) t.join();
+    P->workers.clear();
+    {
+        std::lock_guard<std::mutex> g(P->up.mu);
+        P->up.stop = true;
+    }
+    P->up.cv.notify_all();
+    if (P->up.th.joinable()) P->up.th.join();
+    (void)hipSetDevice(P->c->device);
+    sync_all(P);
+    if (P->s_img) (void)hipStreamSynchronize(P->s_img);
+    if (P->s_ctx) { P->c->stream = P->s_ctx; P->s_ctx = nullptr; }
+}
+
 extern "C" {
 
 int mp3s_pipe_create(mp3s_ctx *c, int depth, size_t max_job_bytes, int scan_threads, mp3s_pipe **out)
@@ -914,23 +941,7 @@ int mp3s_pipe_create(mp3s_ctx *c, int depth, size_t max_job_bytes, int scan_thre
 void mp3s_pipe_destroy(mp3s_pipe *P)
 {
     if (!P) return;
-    {
-        std::lock_guard<std::mutex> g(P->mu);
-        P->stop = true;
-        for (auto &q : P->todo) q.clear();
-    }
-    P->cv_work.notify_all();
-    P->cv_turn.notify_all();      // (a worker that waits for its turn behind a dropped ticket)
-    for (auto &t : P->workers) t.join();
-    {
-        std::lock_guard<std::mutex> g(P->up.mu);
-        P->up.stop = true;
-    }
-    P->up.cv.notify_all();
-    if (P->up.th.joinable()) P->up.th.join();
-    (void)hipSetDevice(P->c->device);
-    sync_all(P);
-    if (P->s_img) (void)hipStreamSynchronize(P->s_img);
+    pipe_quiesce(P);
     for (hipEvent_t e : P->up.ev) (void)hipEventDestroy(e);
     if (P->up.d_file) (void)hipFree(P->up.d_file);
     if (P->up.d_side) (void)hipFree(P->up.d_side);

@@ -32,7 +32,16 @@ struct RunChunk {
 int ensure_own_pipe(mp3s_ctx *c, size_t chunk_bytes, size_t chunk_frames)
 {
     if (c->own_pipe && c->own_pipe->max_job_bytes >= chunk_bytes && c->own_pipe->max_frames >= chunk_frames) return MP3S_OK;
-    if (c->own_pipe) { mp3s_pipe_destroy(c->own_pipe); c->own_pipe = nullptr; }
+    if (c->own_pipe) {
+        // A file with larger frames than any before it (a higher bit rate): the slots' byte buffers are too small.  The old pipe is PARKED, not
+        // destroyed: handing its page-locked and device buffers back to the driver at this point made every copy of the next ten calls run at
+        // half rate (r06, tools/repro_config5.py + rocprofv3 --memory-copy-trace: 28 instead of 56 GB/s down, the same sizes, agents and stream;
+        // kept instead: the first call 9 instead of 20 ms, none slow behind it -- config 5's joint_ms_short_48k_192 at 1.6 or 2.5 ms by where the
+        // seven timed calls fell).  Frame sizes are bounded (1 441 bytes), so at most a few pipes are ever parked; they go with the context.
+        pipe_quiesce(c->own_pipe);
+        c->parked_pipes.push_back(c->own_pipe);
+        c->own_pipe = nullptr;
+    }
     const size_t want = std::max<size_t>(chunk_bytes + chunk_bytes / 4, (size_t)1 << 20);
     // (chunks are cut by frames: the slots' per-frame arrays are sized by what a chunk can hold, not by the 96-byte frames its bytes could be)
     return pipe_create(c, kRunDepth, want, 0, true, &c->own_pipe, std::max<size_t>(chunk_frames + chunk_frames / 4, 4096));
@@ -49,6 +58,8 @@ void own_pipe_lanes(const mp3s_ctx *c, mp3s_run_stats *out)
 void destroy_own_pipe(mp3s_ctx *c)   // (the context is being destroyed)
 {
     if (c->own_pipe) { mp3s_pipe_destroy(c->own_pipe); c->own_pipe = nullptr; }
+    for (mp3s_pipe *p : c->parked_pipes) mp3s_pipe_destroy(p);
+    c->parked_pipes.clear();
     forget_lanes(c);
 }
 

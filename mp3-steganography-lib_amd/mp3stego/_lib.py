@@ -373,12 +373,7 @@ class Context:
     def host_share(self):
         """what this rank holds of the host: dict(pinned_pooled_bytes, pinned_pool_cap_bytes, local_world_size, cpus_allowed,
         gpu_node_cpus) (mp3s_ctx_host_share)"""
-        class S(C.Structure):
-            _fields_ = [("pinned_pooled_bytes", C.c_uint64), ("pinned_pool_cap_bytes", C.c_uint64), ("local_world_size", C.c_int32),
-                        ("cpus_allowed", C.c_int32), ("gpu_node_cpus", C.c_int32), ("reserved", C.c_int32)]
-        st = S()
-        check(lib().mp3s_ctx_host_share(self.handle, C.byref(st)))
-        return {k: int(getattr(st, k)) for k, _ in S._fields_ if k != "reserved"}
+        return host_share(self.handle)
 
     def get_option(self, name):
         v = C.c_int64()
@@ -1127,6 +1122,16 @@ def debug_tables():
     p = lib().mp3s_debug_tables(C.byref(n))
     assert n.value == DEV_TABLES_DTYPE.itemsize, (n.value, DEV_TABLES_DTYPE.itemsize)
     return _view(p, DEV_TABLES_DTYPE, (1,))[0]
+
+
+def host_share(handle=None):
+    """mp3s_ctx_host_share; without a context handle: the host's side alone (gpu_node_cpus 0), no GPU needed"""
+    class S(C.Structure):
+        _fields_ = [("pinned_pooled_bytes", C.c_uint64), ("pinned_pool_cap_bytes", C.c_uint64), ("local_world_size", C.c_int32),
+                    ("cpus_allowed", C.c_int32), ("gpu_node_cpus", C.c_int32), ("reserved", C.c_int32)]
+    st = S()
+    check(lib().mp3s_ctx_host_share(handle, C.byref(st)))
+    return {k: int(getattr(st, k)) for k, _ in S._fields_ if k != "reserved"}
 
 
 _default_ctx = None

@@ -140,3 +140,78 @@ def test_sharded_stream_plumbing_over_gloo(tmp_path):
     assert res["hide_offset"] == 12 * 48
     calls = dict(tuple(map(int, l.split()[1:])) for o, _ in outs for l in o.splitlines() if l.startswith("CALLS"))
     assert calls == {0: 1, 1: 1, 2: 2}                               # only the block that inherits is run a second time
+
+
+EIGHT_WORKER = textwrap.dedent("""
+    import os, sys, json
+    import torch.distributed as dist
+    sys.path.insert(0, %r); sys.path.insert(0, os.path.join(%r, "mp3-steganography-lib_amd"))
+    import bench
+    from mp3stego import _lib
+    rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+    dist.init_process_group(backend="gloo", rank=rank, world_size=world)
+    steady = {"host_scan_ms_per_batch": 0.2 + rank, "host_issue_ms_per_batch": 0.1, "bytes_in_per_batch": 4e6, "bytes_out_per_batch": 4e6, "ms_per_batch": 1.0}
+    hosts = bench.gather_rank_hosts(dist, world, bench.rank_host_record(rank, 1, steady, _lib.host_share))
+    if rank == 0:
+        print(json.dumps({"ranks_on_this_host": hosts}))
+    dist.barrier()
+    dist.destroy_process_group()
+""") % (ROOT, ROOT)
+
+
+def _run_ranks(script, args, world, extra_env=None, per_rank_cpus=None):
+    port = free_port()
+    procs = []
+    for rank in range(world):
+        env = dict(os.environ, RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), LOCAL_WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), **(extra_env or {}))
+        pre = None
+        if per_rank_cpus:
+            cpus = per_rank_cpus[rank]
+            pre = lambda cpus=cpus: os.sched_setaffinity(0, cpus)             # noqa: E731  (what a launcher that pins its ranks would do)
+        procs.append(subprocess.Popen([sys.executable, str(script)] + args, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, preexec_fn=pre))
+    outs = [p.communicate(timeout=600) for p in procs]
+    for p, (o, e) in zip(procs, outs):
+        assert p.returncode == 0, e[-2000:]
+    return outs
+
+
+def test_eight_ranks_carry_chain_over_gloo(tmp_path):
+    """SURVEY 8e at the world size the driver launches (8), without eight GPUs: mp3stego/sharded.py between eight real processes over gloo
+    with the stand-in context -- the carry (message cursor + four inherited chains, 136 bytes: encoder/MP3_Encoder.py:808-809, 1004-1006) passes
+    through SEVEN hand-overs, the blocks that did not look at theirs run once, the three that did run again on the real one, rank 0 assembles
+    the blocks in order."""
+    import json
+    golden = os.path.join(ROOT, "tests", "golden", "g6_synth128.npz")
+    (tmp_path / "in.mp3").write_bytes(np.load(golden)["mp3"].tobytes())
+    (tmp_path / "worker.py").write_text(SHARD_WORKER)
+    outs = _run_ranks(tmp_path / "worker.py", [str(tmp_path / "in.mp3")], 8)
+    res = json.loads([l for l in outs[0][0].splitlines() if l.startswith("{")][0])
+    # 48 frames over 8 ranks: blocks of 6 at frames 0, 6, ..., 42; the stand-in "inherits" from frame 30 on.  Every block adds 72 to the cursor;
+    # a block that did not inherit sets its own chains (first + 1), one that did passes on what it got
+    want = "".join("<%d,6,-,0>" % (6 * r) for r in range(5))
+    for r, cur in ((5, 360), (6, 432), (7, 504)):
+        want += "<%d,6,%s,%d>" % (6 * r, ",".join(map(str, [cur] + [25] * 16)), int(r == 7))
+    assert res["data"] == want
+    assert res["hide_offset"] == 12 * 48
+    calls = dict(tuple(map(int, l.split()[1:])) for o, _ in outs for l in o.splitlines() if l.startswith("CALLS"))
+    assert calls == {0: 1, 1: 1, 2: 1, 3: 1, 4: 1, 5: 2, 6: 2, 7: 2}
+
+
+def test_eight_ranks_share_the_host_and_rank0_assembles_the_line(tmp_path):
+    """what eight ranks of one host are told (mp3s_ctx_host_share without a context: LOCAL_WORLD_SIZE = 8 -> the page-locked pool's cap is
+    4 GB / 8 but at least 1 GB; the CPUs each may use, here one CPU per rank where the container has eight) and bench.py's own assembly of
+    `ranks_on_this_host` on rank 0 (bench.rank_host_record / gather_rank_hosts), over gloo"""
+    import json
+    (tmp_path / "worker.py").write_text(EIGHT_WORKER)
+    avail = sorted(os.sched_getaffinity(0))
+    pins = [{avail[r % len(avail)]} for r in range(8)]
+    outs = _run_ranks(tmp_path / "worker.py", [], 8, per_rank_cpus=pins)
+    hosts = json.loads([l for l in outs[0][0].splitlines() if l.startswith("{")][0])["ranks_on_this_host"]
+    assert [h["rank"] for h in hosts] == list(range(8))
+    for r, h in enumerate(hosts):
+        assert h["local_world_size"] == 8 and h["pinned_pool_cap_bytes"] == 1 << 30 and h["pinned_pooled_bytes"] == 0
+        assert h["cpus_allowed"] == 1 and h["gpu_node_cpus"] == 0
+        assert h["host_walk_ms_per_batch"] == 0.2 + r and h["pcie_gb_s"] == 8.0
+    if len(avail) >= 8:
+        assert len({tuple(p) for p in pins}) == 8                       # (distinct CPUs per rank on this container)
