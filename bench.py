@@ -242,7 +242,7 @@ def run_config5(ctx, _lib, O, synth_pcm, n):
             "decode": dec, "reencode": enc, "band_limited_music_44k_320": music, "slowest_decode_mix": slow}, ok
 
 
-def live_pmc(frames, timeout_s=150):
+def live_pmc(frames, timeout_s=200):
     """HBM bytes and VALU wave instructions per launch of every kernel of the resident step, measured NOW: separate rocprofv3 --pmc
     passes (FETCH_SIZE / WRITE_SIZE / SQ_INSTS_VALU + SQ_INSTS_SALU + SQ_WAVES; never combined with --stats or other traces) over a
     short --resident-only run of this script as a CHILD process -- this process has not touched the GPU yet when it is called and
@@ -262,7 +262,10 @@ def live_pmc(frames, timeout_s=150):
         env.pop(k, None)
     res, t_begin = {}, time.time()
     try:
-        for name, counters in (("fetch", ["FETCH_SIZE"]), ("write", ["WRITE_SIZE"]), ("sq", ["SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_WAVES"])):
+        for name, counters in (("fetch", ["FETCH_SIZE"]), ("write", ["WRITE_SIZE"]), ("sq", ["SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_WAVES"]),
+                               # the vector instructions EXECUTED, by the hardware's own classes (data type, not encoding): roofline_alu.valu_by_type
+                               ("sqt", ["SQ_INSTS_VALU_INT32", "SQ_INSTS_VALU_INT64", "SQ_INSTS_VALU_CVT", "SQ_INSTS_VALU_ADD_F64", "SQ_INSTS_VALU_MUL_F64",
+                                        "SQ_INSTS_VALU_FMA_F64", "SQ_INSTS_VALU_TRANS_F64"])):
             left = timeout_s - (time.time() - t_begin)
             if left < 10:
                 return None, "time budget spent"
@@ -271,6 +274,8 @@ def live_pmc(frames, timeout_s=150):
                    "--resident-only", "--steps", "3", "--warmup", "1", "--no-cpu-baseline", "--no-live-pmc", "--frames", str(frames)]
             r = subprocess.run(cmd, cwd="/tmp", env=env, capture_output=True, text=True, timeout=left)
             if r.returncode != 0:
+                if name == "sqt":                  # (an extra: the by-type counters are not what the roofline needs)
+                    break
                 return None, f"pass {name}: exit {r.returncode}: {(r.stderr or r.stdout)[-200:]}"
             vals = {}
             for f in glob.glob(os.path.join(out, "**", "*counter_collection.csv"), recursive=True):
@@ -288,7 +293,7 @@ def live_pmc(frames, timeout_s=150):
     for k, c in res.items():
         if "FETCH_SIZE" in c and "WRITE_SIZE" in c:
             c["hbm_bytes"] = c["FETCH_SIZE"] * 2048 + c["WRITE_SIZE"] * 1024
-    return res, f"live: 3 rocprofv3 --pmc passes of bench.py --resident-only --steps 3 ({time.time() - t_begin:.0f} s)"
+    return res, f"live: rocprofv3 --pmc passes (FETCH_SIZE | WRITE_SIZE | SQ instruction counts | SQ vector instructions by type) of bench.py --resident-only --steps 3 ({time.time() - t_begin:.0f} s)"
 
 
 class GpuMonitor:

@@ -168,7 +168,7 @@ int mp3s_ctx_wait_last(mp3s_ctx *ctx, mp3s_ctx *other);
                                     * of nothing: tools/timeline.sh) [MP3S_RATE_SIGNALS=0|1, default 0] */
 #define MP3S_OPT_PIPE_SIGNALS 19   /* bit 0: in a pipe and in the one-file calls the last decode dispatch carries the event the front end waits for as its own
                                     * completion signal, bit 1: the rate loop the event the tail stream waits for; 0 (default): event records behind them.
-                                    * Measured (tools/pipe_signals_ab.sh): 3 gives the pipe +1.5 % (18.0 -> 18.3 M frames/s) and now and then puts a context's
+                                    * Measured (round 5, docs/LOG.md): 3 gives the pipe +1.5 % (18.0 -> 18.3 M frames/s) and now and then puts a context's
                                     * one-file calls into a slower order of its streams (1.1 -> 1.4 ms per 10 000 frames): off [MP3S_PIPE_SIGNALS=0..3] */
 #define MP3S_OPT_COUNT 20
 /* what became of the one-file calls of this context (mp3s_hide_message, mp3s_clear_file, mp3s_decode_file, mp3s_decode_stream,
@@ -214,7 +214,7 @@ int mp3s_debug_parse_scanned_frame(const void *frame_side, const uint8_t *blob, 
 
 /* the host's share of a job of the overlapped stages, alone: the frame walk of `file` over and over for about `seconds`
  * (the frame table written into one reused buffer, table counts for the first 1 000 code books as a hide job asks for them);
- * *frames_per_s = what one thread sustains.  No device involved: tools/host_scale_probe.py runs it in N processes side by side. */
+ * *frames_per_s = what one thread sustains.  No device involved (round 4 ran it in N processes side by side: docs/LOG.md). */
 int mp3s_debug_walk_rate(const uint8_t *file, size_t len, double seconds, double *frames_per_s, int64_t *frames_per_pass);
 
 /* device memory owned by the caller through the context (for resident pipelines / benchmarks) */

@@ -194,6 +194,7 @@ __device__ __forceinline__ int rl_quantize(const RlTables &tb, const uint32_t (&
 // calc_run_len (MP3_Encoder.py:266-291) and __subdivide (:998-1036) from what every lane knows about its own pairs: k0 = its highest
 // slot (+ 1) holding a non-zero value, k1 = its highest slot (+ 1) holding a value > 1.  Everything with a side effect that the reference's
 // loop body has in front of its bit counts: count1, big_values, region counts and addresses (left untouched when big_values == 0: E7).
+__device__ __forceinline__ void rl_run_lengths_p(const RlTables &tb, int P0, int P1, RlState &st);
 __device__ __forceinline__ void rl_run_lengths(const RlTables &tb, int k0, int k1, RlState &st)
 {
     // per lane the highest slot (+1), then the highest lane: two ballots and two readlanes
@@ -201,6 +202,11 @@ __device__ __forceinline__ void rl_run_lengths(const RlTables &tb, int k0, int k
     const int L0 = 63 - (nzm ? __builtin_clzll(nzm) : 0), L1 = 63 - (bgm ? __builtin_clzll(bgm) : 0);
     const int r0 = __builtin_amdgcn_readlane(k0, L0), r1 = __builtin_amdgcn_readlane(k1, L1);
     const int P0 = nzm ? 5 * L0 + r0 - 1 : -1, P1 = bgm ? 5 * L1 + r1 - 1 : -1;
+    rl_run_lengths_p(tb, P0, P1, st);
+}
+// ... from the highest non-zero pair P0 and the highest pair holding a value > 1, P1 (-1: none)
+__device__ __forceinline__ void rl_run_lengths_p(const RlTables &tb, int P0, int P1, RlState &st)
+{
     const int count1 = (P0 - P1) >> 1;
     const int bv = (P0 + 1) - 2 * count1;
     st.count1 = count1;
@@ -610,9 +616,12 @@ __device__ __forceinline__ void rate_units(
         if (lane < 22) en_out[(long)(compact == 2 ? li : u - out_base) * 22 + lane] = en;
         RlState st;
         st.big_values = st.count1 = st.c1sel = st.r0c = st.r1c = 0;
-        const int in_a1 = chained ? ch_state[0] : (state_in ? state_in[(long)ci * 4 + 0] : 0);
-        const int in_a2 = chained ? ch_state[1] : (state_in ? state_in[(long)ci * 4 + 1] : 0);
-        const int in_a3 = chained ? ch_state[2] : (state_in ? state_in[(long)ci * 4 + 2] : 0);
+        // (wave-uniform: read into scalar registers -- as vector loads they lived in three VGPRs across the whole search for the one word that
+        //  reports them at the end, the kernel's last scratch spills at six waves per SIMD)
+        const int in_a1 = __builtin_amdgcn_readfirstlane(chained ? ch_state[0] : (state_in ? state_in[(long)ci * 4 + 0] : 0));
+        const int in_a2 = __builtin_amdgcn_readfirstlane(chained ? ch_state[1] : (state_in ? state_in[(long)ci * 4 + 1] : 0));
+        const int in_a3 = __builtin_amdgcn_readfirstlane(chained ? ch_state[2] : (state_in ? state_in[(long)ci * 4 + 2] : 0));
+        const int in_given = in_a1 | (in_a2 << 10) | (in_a3 << 20);          // what k_chain_apply compares with the true chain (each < 1024)
         st.a1 = in_a1; st.a2 = in_a2; st.a3 = in_a3;
         int qstep = chained ? ch_state[3] : (state_in ? state_in[(long)ci * 4 + 3] : 0);
         st.ts0 = st.ts1 = st.ts2 = 0;
@@ -755,7 +764,7 @@ __device__ __forceinline__ void rate_units(
             o.n_tables = act ? (st.ts0 > 0) + (st.ts1 > 0) + (st.ts2 > 0) : 0;
             o.flags = flags;
             // the inherited addresses the unit was given (each < 1024): what k_chain_apply compares with the true chain
-            o.reserved0 = (state_in || chained) ? in_a1 | (in_a2 << 10) | (in_a3 << 20) : 0;
+            o.reserved0 = (state_in || chained) ? in_given : 0;
             o.xrmax = (int32_t)xrmax;
             o.reserved = 0;
             out[compact == 1 || compact == 2 ? li : u - out_base] = o;

@@ -848,7 +848,7 @@ int pipe_create(mp3s_ctx *c, int depth, size_t max_job_bytes, int scan_threads, 
     // copy-up, copy-down and front-end streams that run beside this context's compute stream (pick_lanes above)
     // (the context's OWN pipe -- the chunks of one file -- takes no tail stream: with one its calls run at 1.06-1.12 ms per 10 000 frames or, where
     //  the rehearsal's choice lands the tail on a hardware queue that is in somebody's way, at 1.4-1.6; without, at 1.04-1.08 every time, and the
-    //  four tail miniatures are spared its first call: tools/tail_ab.py, tools/lanes_vs_time.py)
+    //  four tail miniatures are spared its first call: round 5, docs/LOG.md)
     if (pick_lanes(c, &P->s_up, &P->s_down, &P->s_huff, &P->s_comp, &P->s_tail, internal ? 0 : (int)c->opt[MP3S_OPT_PIPE_TAIL], &P->s_dec, c->opt[MP3S_OPT_PIPE_DEC] != 0, &P->s_img, &P->lanes))   // (a stream of their own for the decode transforms: +4 % on a resident batch
                                                                                    // fed through four contexts (bench.py --decode-stream on), nothing in this pipe: off)
         return destroy(MP3S_E_HIP, "stream creation failed");

@@ -21,9 +21,7 @@ STEP_KERNELS = ["mp3s::k_dec_parse", "void mp3s::k_dec_huffman<4, 64>", "void mp
 # kernels beside them that must not spill vector registers either (the float formats' exact path, mono, float32-fast)
 OTHER_KERNELS = ["void mp3s::k_dec_stream<1, false, false>", "void mp3s::k_dec_stream<2, true, false>", "void mp3s::k_dec_imdct<false>", "void mp3s::k_dec_synth<2>"]
 SGPR_SPILL_CAP = 128      # scalar spills are cheap (a lane write / read each) but not free: a kernel that needs more has lost its shape
-# k_rate_loop at six waves per SIMD (80 VGPRs) keeps a few values that live AROUND its search loop in scratch: measured faster than five waves
-# without (round 6: 0.214 -> 0.204 ms in the step); inside the loop only its rare table-swap path reloads them.  More than this is a regression.
-VGPR_SPILL_ALLOWED = {"mp3s::k_rate_loop": (8, 32)}       # kernel: (registers, scratch bytes per lane)
+VGPR_SPILL_ALLOWED = {}       # kernel: (registers, scratch bytes per lane) -- none: k_rate_loop's last three went in round 6 (its inherited addresses read as scalars)
 TABLE = os.path.join(ROOT, "profiles", "r06_kernel_resources.json")
 
 
