@@ -248,6 +248,116 @@ __device__ __forceinline__ Row18s load_row18s(const double (*C36)[18], int i)
     return r;
 }
 
+// IMDCT + window (Frame.py:124-148), overlap (:151-153) and frequency inversion (:629-631) of ONE granule of this lane's subband in the
+// REFERENCE's order: every output a sum of separately rounded products ascending from +0.0.  v[18] = the IMDCT's input, tail = the second half of
+// the block in front (in) / of this block (out).  `rows`: the granule's 18 time samples are wanted -- out(i, x) gets sample i, in slot order --,
+// else only the tail (a granule that primes a run).  Used by the exact kernels' S rows (imdct_run), the fix-up kernel and the exact stream kernel
+// (k_decode_exact.hpp): one source for the order of the sums.
+template <class OUT>
+__device__ __forceinline__ void imdct_rows_exact(const DevTables &tab, const DecShared &sh, const double (&v)[18], int bt, double (&tail)[18], bool rows,
+                                                 uint32_t sgn_odd, OUT out)
+{
+    auto flip = [&](double x) { return __hiloint2double(__double2hiint(x) ^ (int)sgn_odd, __double2loint(x)); };
+    const double(*C36)[18] = tab.imdct_cos36;
+    const double(*C12)[6] = tab.imdct_cos12;
+    if (bt != 2) {
+        // One row of twiddles (18 doubles) per scalar batch, the row after the one being multiplied requested first: its latency
+        // passes under 18 multiply-adds per lane.  The window factor is the lane's own read of the staged copy in LDS (as in
+        // the fast rows): with the two channel halves' factors in the scalar batch two rows in flight were 80 scalar registers --
+        // most of this kernel's 400 scalar spills, a read-lane per five products in the rows.  Same doubles, same products.
+        const double *wl = sh.win[bt];
+        Row18s cur = load_row18s(C36, rows ? 0 : 18);
+        double wc = wl[rows ? 0 : 18];
+        if (rows) {
+#pragma unroll
+            for (int i = 0; i < 18; i++) {
+                __builtin_amdgcn_s_waitcnt(0xc07f);
+                __builtin_amdgcn_sched_barrier(0);
+                const Row18s nxt = load_row18s(C36, i + 1);
+                const double wn = wl[i + 1];
+                __builtin_amdgcn_sched_barrier(0);
+                double x = 0.0;
+#pragma unroll
+                for (int k = 0; k < 18; k++) x += v[k] * (k < 8 ? cur.a[k & 7] : (k < 16 ? cur.b[k & 7] : cur.c[k & 1]));
+                asm volatile("" : "+v"(x));      // (as in the fast path: the sum stays in front of the store's branch)
+                x = x * wc + tail[i];
+                if ((i) & 1) x = flip(x);
+                out(i, x);
+                __builtin_amdgcn_sched_barrier(0);
+                cur = nxt; wc = wn;
+            }
+        }
+#pragma unroll
+        for (int i = 18; i < 36; i++) {
+            __builtin_amdgcn_s_waitcnt(0xc07f);
+            __builtin_amdgcn_sched_barrier(0);
+            const int in = i < 35 ? i + 1 : 35;
+            const Row18s nxt = load_row18s(C36, in);
+            const double wn = wl[in];
+            __builtin_amdgcn_sched_barrier(0);
+            double x = 0.0;
+#pragma unroll
+            for (int k = 0; k < 18; k++) x += v[k] * (k < 8 ? cur.a[k & 7] : (k < 16 ? cur.b[k & 7] : cur.c[k & 1]));
+            tail[i - 18] = x * wc;
+            __builtin_amdgcn_sched_barrier(0);
+            cur = nxt; wc = wn;
+        }
+    } else {
+        // three 12-point windows placed at 6/12/18 (Frame.py:135-148).  The three windows share their coefficients, so the
+        // walk is over the 12 ROWS: row j gives t[j] (window 0, to sample_block[6 + j]), t[12 + j] (window 1, to [12 + j]) and
+        // t[24 + j] (window 2, to [18 + j]), each used exactly once -- six sums are kept (window 1's first half, until rows
+        // 6..11 bring window 0's second half), the rest goes where it belongs at once.  Same sums, same order, same roundings
+        // as the reference's; 14 scalar words per row instead of the whole 12 x 6 table in flight (which was most of the
+        // kernel's scalar spills) and 12 instead of 48 registers for the windows.
+        typedef double dvec4 __attribute__((ext_vector_type(4)));
+        struct Row6 { dvec4 a; dvec2 b; double s; };
+        auto load_row6 = [&](int j) { Row6 r; r.a = *reinterpret_cast<const dvec4 *>(C12[j]); r.b = *reinterpret_cast<const dvec2 *>(C12[j] + 4); r.s = tab.sine_block[2][j]; return r; };
+        if (rows) {
+#pragma unroll
+            for (int i = 0; i < 6; i++) {                       // sample_block[0..5] = 0
+                double x = 0.0 + tail[i];
+                if ((i) & 1) x = flip(x);
+                out(i, x);
+            }
+        }
+        double hold[6];
+        Row6 cur = load_row6(0);
+#pragma unroll
+        for (int j = 0; j < 12; j++) {
+            const Row6 nxt = load_row6(j < 11 ? j + 1 : 11);
+            __builtin_amdgcn_sched_barrier(0);
+            double a0 = 0.0, a1 = 0.0, a2 = 0.0;
+#pragma unroll
+            for (int k = 0; k < 6; k++) {
+                const double c = k < 4 ? cur.a[k] : cur.b[k - 4];
+                a0 += v[k] * c; a1 += v[6 + k] * c; a2 += v[12 + k] * c;
+            }
+            a0 = a0 * cur.s; a1 = a1 * cur.s; a2 = a2 * cur.s;
+            asm volatile("" : "+v"(a0));
+            if (j < 6) {
+                if (rows) {                                     // sample_block[6..11] = t[0..5]
+                    double x = a0 + tail[6 + j];
+                    if ((6 + j) & 1) x = flip(x);
+                    out(6 + j, x);
+                }
+                hold[j] = a1;                                   // t[12..17], for sample_block[12..17]
+                tail[j] = a2;                                   // t[24..29], half of sample_block[18..23]
+            } else {
+                if (rows) {                                     // sample_block[12..17] = t[6..11] + t[12..17]
+                    double x = (a0 + hold[j - 6]) + tail[6 + j];
+                    if ((6 + j) & 1) x = flip(x);
+                    out(6 + j, x);
+                }
+                tail[j - 6] = a1 + tail[j - 6];                 // sample_block[18..23] = t[18..23] + t[24..29]
+                tail[j] = a2;                                   // sample_block[24..29] = t[30..35]
+                tail[6 + j] = 0.0;                              // sample_block[30..35]
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            cur = nxt;
+        }
+    }
+}
+
 // One wave walks granules g0 .. g0 + run - 1 (lane = channel, subband), primed with the second half of granule g0 - 1.
 // Rows go to S + ((ch * T) + g * 18 + i - slot0) * 32 (slot0 = 0 for the batch's scratch; the fix-up kernel writes a
 // private window of slots).
@@ -300,7 +410,6 @@ __device__ __forceinline__ void imdct_run(DecShared &sh, int wave, int lane, con
         asm volatile("" : "+s"(zoff));
         const DevTables &tab = *reinterpret_cast<const DevTables *>(reinterpret_cast<const char *>(&c_tab) + zoff);
         const double(*C36)[18] = tab.imdct_cos36;
-        const double(*C12)[6] = tab.imdct_cos12;
         double v[18];
         int bt;
         // this granule's lines and side records: asked for under the rows of the granule in front (below), or here for the
@@ -380,106 +489,10 @@ __device__ __forceinline__ void imdct_run(DecShared &sh, int wave, int lane, con
                     cur = nxt; wa = nwa; wb = nwb;
                 }
             } else {
-            // One row of twiddles (18 doubles) per scalar batch, the row after the one being multiplied requested first: its latency
-            // passes under 18 multiply-adds per lane.  The window factor is the lane's own read of the staged copy in LDS (as in
-            // the fast rows): with the two channel halves' factors in the scalar batch two rows in flight were 80 scalar registers --
-            // most of this kernel's 400 scalar spills, a read-lane per five products in the rows.  Same doubles, same products.
-            const double *wl = sh.win[bt];
-            Row18s cur = load_row18s(C36, gi >= 0 ? 0 : 18);
-            double wc = wl[gi >= 0 ? 0 : 18];
-            if (gi >= 0) {
-#pragma unroll
-                for (int i = 0; i < 18; i++) {
-                    __builtin_amdgcn_s_waitcnt(0xc07f);
-                    __builtin_amdgcn_sched_barrier(0);
-                    const Row18s nxt = load_row18s(C36, i + 1);
-                    const double wn = wl[i + 1];
-                    __builtin_amdgcn_sched_barrier(0);
-                    double x = 0.0;
-#pragma unroll
-                    for (int k = 0; k < 18; k++) x += v[k] * (k < 8 ? cur.a[k & 7] : (k < 16 ? cur.b[k & 7] : cur.c[k & 1]));
-                    asm volatile("" : "+v"(x));      // (as in the fast path: the sum stays in front of the store's branch)
-                    x = x * wc + tail[i];
-                    if ((i) & 1) x = flip(x);
-                    if (all_wr) row[(long)i * 32] = x;
-                    else if (wr) row[(long)i * 32] = x;
-                    __builtin_amdgcn_sched_barrier(0);
-                    cur = nxt; wc = wn;
-                }
-            }
-#pragma unroll
-            for (int i = 18; i < 36; i++) {
-                __builtin_amdgcn_s_waitcnt(0xc07f);
-                __builtin_amdgcn_sched_barrier(0);
-                const int in = i < 35 ? i + 1 : 35;
-                const Row18s nxt = load_row18s(C36, in);
-                const double wn = wl[in];
-                __builtin_amdgcn_sched_barrier(0);
-                double x = 0.0;
-#pragma unroll
-                for (int k = 0; k < 18; k++) x += v[k] * (k < 8 ? cur.a[k & 7] : (k < 16 ? cur.b[k & 7] : cur.c[k & 1]));
-                tail[i - 18] = x * wc;
-                __builtin_amdgcn_sched_barrier(0);
-                cur = nxt; wc = wn;
-            }
+                imdct_rows_exact(tab, sh, v, bt, tail, gi >= 0, sgn_odd, [&](int i, double x) { if (all_wr) row[(long)i * 32] = x; else if (wr) row[(long)i * 32] = x; });
             }
         } else {
-            // three 12-point windows placed at 6/12/18 (Frame.py:135-148).  The three windows share their coefficients, so the
-            // walk is over the 12 ROWS: row j gives t[j] (window 0, to sample_block[6 + j]), t[12 + j] (window 1, to [12 + j]) and
-            // t[24 + j] (window 2, to [18 + j]), each used exactly once -- six sums are kept (window 1's first half, until rows
-            // 6..11 bring window 0's second half), the rest goes where it belongs at once.  Same sums, same order, same roundings
-            // as the reference's; 14 scalar words per row instead of the whole 12 x 6 table in flight (which was most of the
-            // kernel's scalar spills) and 12 instead of 48 registers for the windows.
-            typedef double dvec4 __attribute__((ext_vector_type(4)));
-            struct Row6 { dvec4 a; dvec2 b; double s; };
-            auto load_row6 = [&](int j) { Row6 r; r.a = *reinterpret_cast<const dvec4 *>(C12[j]); r.b = *reinterpret_cast<const dvec2 *>(C12[j] + 4); r.s = tab.sine_block[2][j]; return r; };
-            double *row_s = row;
-            if (gi >= 0) {
-#pragma unroll
-                for (int i = 0; i < 6; i++) {                       // sample_block[0..5] = 0
-                    double x = 0.0 + tail[i];
-                    if ((i) & 1) x = flip(x);
-                    if (all_wr) row_s[(long)i * 32] = x;
-                    else if (wr) row_s[(long)i * 32] = x;
-                }
-            }
-            double hold[6];
-            Row6 cur = load_row6(0);
-#pragma unroll
-            for (int j = 0; j < 12; j++) {
-                const Row6 nxt = load_row6(j < 11 ? j + 1 : 11);
-                __builtin_amdgcn_sched_barrier(0);
-                double a0 = 0.0, a1 = 0.0, a2 = 0.0;
-#pragma unroll
-                for (int k = 0; k < 6; k++) {
-                    const double c = k < 4 ? cur.a[k] : cur.b[k - 4];
-                    a0 += v[k] * c; a1 += v[6 + k] * c; a2 += v[12 + k] * c;
-                }
-                a0 = a0 * cur.s; a1 = a1 * cur.s; a2 = a2 * cur.s;
-                asm volatile("" : "+v"(a0));
-                if (j < 6) {
-                    if (gi >= 0) {                                  // sample_block[6..11] = t[0..5]
-                        double x = a0 + tail[6 + j];
-                        if ((6 + j) & 1) x = flip(x);
-                        if (all_wr) row_s[(long)(6 + j) * 32] = x;
-                        else if (wr) row_s[(long)(6 + j) * 32] = x;
-                    }
-                    hold[j] = a1;                                   // t[12..17], for sample_block[12..17]
-                    tail[j] = a2;                                   // t[24..29], half of sample_block[18..23]
-                } else {
-                    if (gi >= 0) {                                  // sample_block[12..17] = t[6..11] + t[12..17]
-                        double x = (a0 + hold[j - 6]) + tail[6 + j];
-                        if ((6 + j) & 1) x = flip(x);
-                        if (all_wr) row_s[(long)(6 + j) * 32] = x;
-                        else if (wr) row_s[(long)(6 + j) * 32] = x;
-                    }
-                    tail[j - 6] = a1 + tail[j - 6];                 // sample_block[18..23] = t[18..23] + t[24..29]
-                    tail[j] = a2;                                   // sample_block[24..29] = t[30..35]
-                    tail[6 + j] = 0.0;                              // sample_block[30..35]
-                }
-                __builtin_amdgcn_sched_barrier(0);
-                cur = nxt;
-            }
+            imdct_rows_exact(tab, sh, v, bt, tail, gi >= 0, sgn_odd, [&](int i, double x) { if (all_wr) row[(long)i * 32] = x; else if (wr) row[(long)i * 32] = x; });
         }
     }
 }
