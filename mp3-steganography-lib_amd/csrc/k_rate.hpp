@@ -376,6 +376,11 @@ __device__ __forceinline__ int rl_body(const RlTables &tb, const int32_t (&ix)[2
         const uint32_t big = (esc0 ? 5u : (10u | (lbA << 16))) | (15u << 8) | (lbB << 20);
         Kr[r] = none ? (25u | (25u << 8)) : (small ? (0u | (5u << 8)) : big);
     }
+#if MP3S_RL_STATS
+    RL_STAT(63, 1);                                                         // evaluations in full ...
+    if (rmax[0] < 15 && rmax[1] < 15 && rmax[2] < 15) RL_STAT(64, 1);       // ... whose three regions all stay below 15 (no escapes, books 13 / 15 only)
+    if (rmax[1] < 15 && rmax[2] < 15) RL_STAT(65, 1);                       // ... whose regions 1 and 2 do
+#endif
     uint32_t w0 = 0, w1 = 0, w2 = 0;
 #pragma unroll
     for (int m = 0; m < RL_NP; m++) {

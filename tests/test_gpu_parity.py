@@ -348,6 +348,46 @@ def test_encode_matrix_of_rates_and_bitrates(ctx, mlib, orc, rate):
         assert np.array_equal(d["pcm"], od["pcm"]), (rate, kbps)
 
 
+def test_pilot_tone_in_digital_silence_at_low_bit_rates(ctx, mlib, orc):
+    """The round-5 advisor's case as PCM: a low-level high-frequency tone in digital silence at 32 / 48 / 56 kbit/s -- big_values reaches far up,
+    every region below the tone is empty (table 0: free in the reference, encoder/MP3_Encoder.py:1182-1184, :228-229), and the binary search's first
+    probe has FEWER bits than max_bits although a bit per pair below big_values would say otherwise (the premise is checked on the oracle's own
+    spectra: tests/test_rate_bounds.py's model of the round-5 bound).  Bytes, cursor and every granule's side info against the oracle, with and
+    without a message; the decode of the result as well."""
+    from test_rate_bounds import precheck_model
+    t = mlib.debug_tables()
+    t1, t2 = int(t["rl_t1"][67]), int(t["rl_t2"][67])
+    n = 48
+    misfires = 0
+    for rate, freq, amp, kbps in ((44100, 19000, 5, 48), (44100, 15000, 2, 32), (44100, 20500, 20, 56), (48000, 21000, 8, 48), (32000, 14500, 6, 48)):
+        tt = np.arange(n * 1152) / rate
+        sig = np.rint(amp * np.sin(2 * np.pi * freq * tt)).astype(np.int16)
+        pcm = np.ascontiguousarray(np.stack([sig, np.roll(sig, 7)], axis=1))
+        pcm[20 * 1152:24 * 1152] = 0                                  # silent frames inside: inherited addresses (SURVEY E7)
+        for msg in (None, bits_of("12#pilot tones..")):
+            o = orc.encode(pcm, rate, kbps, msg)
+            r = ctx.encode_pcm(pcm, rate, kbps, msg)
+            assert o["rc"] == 0 and r["mp3"] == o["mp3"], (rate, freq, amp, kbps, msg is not None)
+            assert r["hide_offset"] == o["hide_offset"]
+            gi = o["frames"]["gi"]
+            gr = r["gr"].reshape(-1, 2, 2)
+            assert np.array_equal(gr["quantizer_step"].transpose(0, 2, 1), gi["quantizerStepSize"])
+            assert np.array_equal(gr["big_values"].transpose(0, 2, 1), gi["big_values"])
+            assert np.array_equal(gr["table_select"].transpose(0, 2, 1, 3), gi["table_select"])
+        d, od = ctx.decode_stream(r["mp3"], mlib.MP3S_PCM_F64), orc.decode(r["mp3"])
+        assert np.array_equal(d["pcm"], od["pcm"]) and np.array_equal(d["bits"], od["bits"])
+        # the premise: units whose first probe the round-5 bound would have decided the other way
+        md = o["mdct_freq"].reshape(-1, 576)
+        rf, _ = mlib.rate_frames(rate, kbps, 2, n)
+        mb = np.repeat(rf["max_bits"], 4)
+        bits, _, _ = orc.probe_bits(rate, -60, md)
+        _, _, lb, lb_r5 = precheck_model(md, t1, t2)
+        ran = (bits >= 0) & (bits < 100000)
+        assert (lb[ran] <= bits[ran]).all()
+        misfires += int((ran & (bits < mb) & (lb_r5 >= mb)).sum())
+    assert misfires > 100, misfires
+
+
 # ------------------------------------------------------------------------------------------------ BASELINE config 4 (shape)
 def test_many_seeded_streams_across_chunk_boundaries(ctx, mlib, orc):
     """config 4 in miniature: several seeded streams as one batch that is larger than the pipeline's transform chunk,

@@ -34,6 +34,8 @@ for j in range(7):
 out["inner"] = {"evaluations per unit": round(float(d[36]) / units, 4), "last probe reused": round(float(d[37]) / units, 4),
                 "ended on the lower bound": round(float(d[38]) / units, 4), "in full": round(float(d[39]) / units, 4)}
 out["evaluations per unit (quantised)"] = round(float(d[62]) / units, 4)
+out["evaluations in full whose three regions all stay below 15"] = round(float(d[64]) / max(int(d[63]), 1), 4)
+out["evaluations in full whose regions 1 and 2 stay below 15"] = round(float(d[65]) / max(int(d[63]), 1), 4)
 out["evaluations with quadruples"] = round(float(d[61]) / max(int(d[62]), 1), 4)
 for k, nm in enumerate(["front (lines, energies)", "tables into LDS + barrier", "first probe (pre-check)", "binary search", "inner loop", "results out"]):
     out["phase_clocks_per_wave"][nm] = round(float(d[54 + k]) / waves, 1)
