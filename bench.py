@@ -926,7 +926,7 @@ def main():
         import tempfile
         from mp3stego import Steganography
         tdir = tempfile.mkdtemp(dir="/dev/shm" if os.path.isdir("/dev/shm") and os.access("/dev/shm", os.W_OK) else None)
-        t_fac = None
+        t_fac = t_fac_new = None
         try:
             src, dst = os.path.join(tdir, "in.mp3"), os.path.join(tdir, "out.mp3")
             open(src, "wb").write(mp3_in)
@@ -937,11 +937,22 @@ def main():
                 st.hide_message(src, dst, payload)
             t_fac = (time.perf_counter() - t0) / 10
             same = same and open(dst, "rb").read() == ref_out
+            # ... into a file that is not there yet (the library writes the result chunk by chunk under the device's work; over a file that holds
+            # something -- above -- it is written when the call has succeeded, as the reference leaves such a file alone when its encode fails)
+            ts = []
+            for _ in range(10):
+                os.remove(dst)
+                t0 = time.perf_counter()
+                st.hide_message(src, dst, payload)
+                ts.append(time.perf_counter() - t0)
+            t_fac_new = sorted(ts)[len(ts) // 2]
+            same = same and open(dst, "rb").read() == ref_out
         finally:
             shutil.rmtree(tdir, ignore_errors=True)
         regions["single_file_10k"] = {"ms_per_batch": round(t_one * 1e3, 4), "frames_per_s": round(n / t_one, 1), "batches": k1, "first_call": first_call,
                                       "chunks_per_file": round((rs1["chunks"] - rs0["chunks"]) / k1, 2),
                                       "facade_ms_per_file": round(t_fac * 1e3, 4) if t_fac else None,
+                                      "facade_new_file_ms": round(t_fac_new * 1e3, 4) if t_fac else None,
                                       "what": "Context.hide_message(bytes) = ONE mp3s_hide_message call per file, a loop of them: the file's chunks through walk || upload || "
                                               "parse + Huffman || kernels || download; facade_ms_per_file = Steganography.hide_message(quiet=True) on files (read + the same call + write)"}
         # the same file with the stages one after the other (round 2's path, kept as the fallback)
@@ -1323,6 +1334,7 @@ def main():
             "decode_only_float32_fast_ms": decode_only["float_fast"]["ms_per_step"] if decode_only and "float_fast" in decode_only else None,
             "decode_only_int16_ms": decode_only["int16"]["ms_per_step"] if decode_only and "int16" in decode_only else None,
             "facade_ms_per_file": (regions or {}).get("single_file_10k", {}).get("facade_ms_per_file") if regions else None,
+            "facade_new_file_ms": (regions or {}).get("single_file_10k", {}).get("facade_new_file_ms") if regions else None,
             "c_call_ms_per_file": (regions or {}).get("single_file_10k", {}).get("ms_per_batch") if regions else None,
             "first_call_ms": (regions or {}).get("single_file_10k", {}).get("first_call", {}).get("ms") if regions else None,
             "dominant_kernel_ms": round(dom_ms_launch, 4),
