@@ -16,7 +16,7 @@
                           // mp3s_debug_rl_stats (a probe: tools/rl_stats.py; such a build is not the product's)
 #endif
 #ifndef MP3S_RL_OCC
-#define MP3S_RL_OCC 6     // waves per SIMD k_rate_loop is compiled for (r06: 80 VGPRs, a dozen values spilled AROUND the search loop, none inside: 0.214 -> 0.204 ms in the step)
+#define MP3S_RL_OCC 6     // waves per SIMD k_rate_loop is compiled for (r06: 80 VGPRs, no scratch; 0.214 -> 0.204 ms in the step against five waves and 96 VGPRs)
 #endif
 #if MP3S_RL_STATS
 __device__ unsigned long long g_rl_stats[128];
@@ -194,7 +194,6 @@ __device__ __forceinline__ int rl_quantize(const RlTables &tb, const uint32_t (&
 // calc_run_len (MP3_Encoder.py:266-291) and __subdivide (:998-1036) from what every lane knows about its own pairs: k0 = its highest
 // slot (+ 1) holding a non-zero value, k1 = its highest slot (+ 1) holding a value > 1.  Everything with a side effect that the reference's
 // loop body has in front of its bit counts: count1, big_values, region counts and addresses (left untouched when big_values == 0: E7).
-__device__ __forceinline__ void rl_run_lengths_p(const RlTables &tb, int P0, int P1, RlState &st);
 __device__ __forceinline__ void rl_run_lengths(const RlTables &tb, int k0, int k1, RlState &st)
 {
     // per lane the highest slot (+1), then the highest lane: two ballots and two readlanes
@@ -202,11 +201,6 @@ __device__ __forceinline__ void rl_run_lengths(const RlTables &tb, int k0, int k
     const int L0 = 63 - (nzm ? __builtin_clzll(nzm) : 0), L1 = 63 - (bgm ? __builtin_clzll(bgm) : 0);
     const int r0 = __builtin_amdgcn_readlane(k0, L0), r1 = __builtin_amdgcn_readlane(k1, L1);
     const int P0 = nzm ? 5 * L0 + r0 - 1 : -1, P1 = bgm ? 5 * L1 + r1 - 1 : -1;
-    rl_run_lengths_p(tb, P0, P1, st);
-}
-// ... from the highest non-zero pair P0 and the highest pair holding a value > 1, P1 (-1: none)
-__device__ __forceinline__ void rl_run_lengths_p(const RlTables &tb, int P0, int P1, RlState &st)
-{
     const int count1 = (P0 - P1) >> 1;
     const int bv = (P0 + 1) - 2 * count1;
     st.count1 = count1;
@@ -494,7 +488,7 @@ __device__ __forceinline__ void rate_units(
     }
     // The tables: asked for HERE and waited for (the workgroup's one barrier) where a wave first needs them -- in a plain launch behind its
     // unit's own front (lines, energies, scfsi logs: nothing of it reads a table), so that the tables' way through the caches passes under that
-    // arithmetic; a re-run launch (CHAIN) and the persistent workgroups wait at once.  The three large tables go STRAIGHT into LDS
+    // arithmetic; a re-run launch (CHAIN) waits at once.  The three large tables go STRAIGHT into LDS
     // (global_load_lds_dwordx4: each lane's 16 bytes land at the wave's LDS base + 16 * lane; no register holds them -- through registers the
     // staging kept 24 VGPRs alive across the unit's front, the kernel's peak: r06), the two of 64 bytes through a register each.
     static_assert(sizeof(tb.int2idx) % 16 == 0 && sizeof(c_tab.int2idx) == sizeof(tb.int2idx), "int2idx is staged 16 bytes at a time");
