@@ -44,7 +44,7 @@ constexpr int ENC_LDS_DW = 79 * 17 + 1;   // per-wave LDS in dwords: the PCM til
                                       // 5.4 KB per wave, 21.5 per workgroup: five workgroups = five waves per SIMD fit a CU's LDS (8.4 KB per wave and four until round 4)
 
 // The analysis of 64 consecutive slots t0 .. t0 + 63 of channel ch by one wave (lane = slot).  `lds`: ENC_LDS_DW dwords of the wave's own.
-// TILE == false (k_enc_analysis): the subband samples go to SB in device memory, int32 [ch][Ts][32 bands] (a 128-byte row per slot), staged
+// TILE == false (k_enc_analysis): the subband samples go to SB in device memory, int32 [ch][Ts][32] (a 128-byte row per slot, bands at sb_pos), staged
 // through `lds` so that they leave as 16-byte pieces of the rows.  TILE == true (k_enc_fused): they go to `rows` in LDS, row r of the
 // workgroup's tile at rows + r * ENC_TROW with r = the lane's slot - tile_t0, for the slots [lo, hi) only; `between`() runs once when the
 // wave has read the last sample of its PCM staging (the fused kernel's workgroup barrier: the staging lies inside the tile).
@@ -227,13 +227,14 @@ __device__ __forceinline__ void enc_analysis_wave(const int16_t *__restrict__ pc
                 constexpr int g = P >> 2;
                 __builtin_amdgcn_s_waitcnt(0xc07f);
                 __builtin_amdgcn_wave_barrier();
+                // (the trip's sixteen bands -- 4g.., 12-4g.., 16+4g.., 28-4g.. -- lie SIDE BY SIDE in the row: sb_pos, below; 64 contiguous bytes per row
+                //  and trip instead of four 16-byte pieces, each half of a 32-byte sector whose other half came a quarter of the wave's life later)
                 const int piece = lane & 3;
-                const int band0 = piece == 0 ? 4 * g : (piece == 1 ? 12 - 4 * g : (piece == 2 ? 16 + 4 * g : 28 - 4 * g));
 #pragma unroll
                 for (int r = lane >> 2; r < 64; r += 16) {
                     const uint32_t *src = ot + r * 17 + piece * 4;
                     const uint4 v = make_uint4(src[0], src[1], src[2], src[3]);
-                    if (r < n_rows) *reinterpret_cast<uint4 *>(out + r * 32 + band0) = v;
+                    if (r < n_rows) *reinterpret_cast<uint4 *>(out + r * 32 + g * 16 + piece * 4) = v;
                 }
                 __builtin_amdgcn_s_waitcnt(0xc07f);
                 __builtin_amdgcn_wave_barrier();         // (the tile is free for the other sixteen bands)
@@ -246,7 +247,11 @@ __device__ __forceinline__ void enc_analysis_wave(const int16_t *__restrict__ pc
     });
 }
 
-// SB layout: int32 [ch][Ts][32 bands] with Ts = n_frames * 36 slots (a 128-byte row per slot)
+// SB layout: int32 [ch][Ts][32] with Ts = n_frames * 36 slots (a 128-byte row per slot); band b of a slot sits at sb_pos(b) of its row -- the order in
+// which the analysis completes its bands (four at a time: b >> 2 = 0, 3, 4, 7 in its first trip, 1, 2, 5, 6 in its second), so that a trip's sixteen
+// bands are one half of the row.  (Round 6: in band order a trip wrote four 16-byte pieces per row, half a sector each; the counters showed 123 MB
+// written for the array's 92.)
+__device__ __forceinline__ int sb_pos(int band) { return (int)((0x37621540u >> (4 * (band >> 2))) & 7u) * 4 + (band & 3); }
 __global__ __launch_bounds__(256, 5) void k_enc_analysis(
     const int16_t *__restrict__ pcm, const mp3s_frame_hdr *__restrict__ hdr, int n_frames,
     int32_t *__restrict__ SB, long Ts)
@@ -348,7 +353,7 @@ __global__ __launch_bounds__(256, 4) void k_enc_mdct(
     if (f >= n_frames) return;
     const int ch = lane >> 5, band = lane & 31;
     const bool has_prev = f > (int)hdr[f].stream_first;   // l3_sb_sample[ch][0] starts zeroed
-    const int32_t *row = SB + ((long)ch * Ts + (long)f * 36) * 32 + band;
+    const int32_t *row = SB + ((long)ch * Ts + (long)f * 36) * 32 + sb_pos(band);
     // (the rows of the frame in front through an address that exists either way: compiled as an unconditional load + select -- as a
     // fully unrolled variant of this kernel was in round 4 -- `row - 18 * 32` of a batch's first frame lies in front of the buffer)
     const int32_t *prow = has_prev ? row - 18 * 32 : row;

@@ -49,3 +49,8 @@ def test_argument_checks_do_not_need_a_gpu(mlib):
     out = np.zeros(4, dtype=mlib.RATE_FRAME_DTYPE)
     assert L.mp3s_rate_frames(22050, 128, 2, 4, out.ctypes.data, None) == mlib.E_UNSUPPORTED
     assert L.mp3s_rate_frames(44100, 100, 2, 4, out.ctypes.data, None) == mlib.E_UNSUPPORTED
+    # the probes of round 6: a null context is refused; the host's share of a rank is answered without one
+    L.mp3s_debug_guard_margin.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64]
+    assert L.mp3s_debug_guard_margin(None, None, None, 0) == mlib.E_ARG
+    hs = mlib.host_share()
+    assert hs["cpus_allowed"] >= 1 and hs["local_world_size"] >= 1 and hs["gpu_node_cpus"] == 0 and hs["pinned_pool_cap_bytes"] >= 1 << 30
