@@ -292,7 +292,9 @@ __device__ __forceinline__ int rl_body(const RlTables &tb, const int32_t (&ix)[2
     uint32_t bnd = 0, acc = 0;
     {
         const int reach = st.a2 > bvr ? st.a2 : bvr;
-        const int reach_p = (reach + 1) >> 1;             // pairs below `reach` (slot m of the lane: p0 < limit - m, the limit's side scalar)
+        // pairs of this lane below big_values / below `reach`: slot m is inside when m < the distance -- one subtraction per lane and bound, then
+        // compares with the slot's number as an inline constant (no per-slot register: ten of them were hoisted out of the search loop until r06)
+        const int d_bv = bv - p0, d_reach = ((reach + 1) >> 1) - p0;
         // inside the count1 region every value is 0 or 1, so x + 2y is the pair's code there; elsewhere the sum is only
         // kept inside the table (& 15) and its result dropped
 #pragma unroll
@@ -300,7 +302,7 @@ __device__ __forceinline__ int rl_body(const RlTables &tb, const int32_t (&ix)[2
             const int x = ix[2 * m], y = ix[2 * m + 1];
             const uint2 hh = tb.hl[(x > 14 ? 15 : x) * 16 + (y > 14 ? 15 : y)];
             h[m] = hh.x;
-            bnd += p0 < bv - m ? hh.y : (p0 < reach_p - m ? hh.y & 0xffff0000u : 0u);
+            bnd += m < d_bv ? hh.y : (m < d_reach ? hh.y & 0xffff0000u : 0u);
         }
         if (count1 > 0) {                                   // (wave-uniform: a probe whose values are all above 1 up to the last non-zero pair has no quads)
 #pragma unroll
@@ -333,11 +335,11 @@ __device__ __forceinline__ int rl_body(const RlTables &tb, const int32_t (&ix)[2
     const int a1 = st.a1, a2 = st.a2;
     uint32_t mx0 = 0, mx1 = 0, mx2 = 0;
     int rid[RL_NP];
+    const int d_a1 = ((a1 + 1) >> 1) - p0, d_a2 = ((a2 + 1) >> 1) - p0, d_bv3 = bv - p0;   // (line 2 (p0 + m) below a bound <=> m below the bound's pair count - p0)
 #pragma unroll
     for (int m = 0; m < RL_NP; m++) {
         const uint32_t pm = (uint32_t)max(ix[2 * m], ix[2 * m + 1]);
-        // (line 2 (p0 + m) below a bound <=> p0 below the bound's pair count - m: the per-slot part stays on the scalar side)
-        const bool in0 = p0 < ((a1 + 1) >> 1) - m, in1 = !in0 && p0 < ((a2 + 1) >> 1) - m, in2 = !in0 && !in1 && p0 < bv - m;
+        const bool in0 = m < d_a1, in1 = !in0 && m < d_a2, in2 = !in0 && !in1 && m < d_bv3;
         mx0 = max(mx0, in0 ? pm : 0u);
         mx1 = max(mx1, in1 ? pm : 0u);
         mx2 = max(mx2, in2 ? pm : 0u);
