@@ -382,3 +382,30 @@ def test_result_written_to_a_file_descriptor_chunk_by_chunk(ctx, mlib, orc, gold
     new = tmp_path / "new.mp3"
     st.clear_file(str(src), str(new))
     assert new.read_bytes() == bytes(ctx.clear_file(mp3)["data"])
+
+
+@pytest.mark.gpu
+def test_files_with_larger_frames_park_the_pipe_and_change_nothing(mlib):
+    """A context's own pipe is sized by the largest frame it has seen; a file with larger frames (a higher bit rate) makes a new one and the old one
+    is PARKED until the context goes (csrc/run_file.cpp ensure_own_pipe: freeing its buffers at that point halved the rate of the next ten calls'
+    copies -- DESIGN 6).  Files of growing and shrinking frame sizes through one context, hide and decode: every result equals the stages one
+    after the other, none of the calls falls back, and the context can be destroyed with three pipes parked."""
+    from synth_pcm import synth_pcm
+    ctx = mlib.Context(0)
+    try:
+        pcm = {r: synth_pcm(2600, seed=0x51 + r, rate=r) for r in (32000, 44100, 48000)}
+        order = [(44100, 64), (44100, 128), (48000, 192), (44100, 128), (44100, 320), (32000, 64), (48000, 320), (44100, 64)]   # 208 .. 1 044 bytes per frame, up and down
+        files = {rk: bytes(ctx.encode_pcm(pcm[rk[0]], rk[0], rk[1], None)["mp3"]) for rk in set(order)}
+        rs0 = ctx.run_stats()
+        for i, rk in enumerate(order):
+            data = files[rk]
+            got = ctx.hide_message(data, "frames of %d bytes" % (len(data) // 2600))
+            want = legacy(ctx, ctx.hide_message, data, "frames of %d bytes" % (len(data) // 2600))
+            assert same_file(got, want), (i, rk)
+            d16, w16 = ctx.decode_stream(data, mlib.MP3S_PCM_I16), legacy(ctx, ctx.decode_stream, data, mlib.MP3S_PCM_I16)
+            assert np.array_equal(d16["pcm"], w16["pcm"]) and np.array_equal(d16["bits"], w16["bits"]), (i, rk)
+            del got, want, d16, w16
+        rs1 = ctx.run_stats()
+        assert rs1["fallbacks"] == rs0["fallbacks"] and rs1["files"] - rs0["files"] == 2 * len(order)
+    finally:
+        ctx.close()
