@@ -180,15 +180,16 @@ def encode(pcm_i16: np.ndarray, samplerate: int, bitrate: int, hide_bits=None):
         L.orc_enc_free(e)
 
 
-def rate_units(samplerate: int, max_bits: np.ndarray, xr: np.ndarray):
+def rate_units(samplerate: int, max_bits: np.ndarray, xr: np.ndarray, hide_bits=None):
     """The reference's rate loop (MP3_Encoder.py:766-813) on n spectra int32 [n][576], each as the first granule of a stream (fresh
-    GrInfo, no message) with its own budget.  Returns {"ix": int32 [n][576] (unsigned, before format_bitstream), "gi": GRINFO_DTYPE [n],
+    GrInfo; `hide_bits`: every unit sees the message from its start, cursor 0) with its own budget.  Returns {"ix": int32 [n][576] (unsigned, before format_bitstream), "gi": GRINFO_DTYPE [n],
     "rc": int32 [n]}."""
     L = lib()
     xr = np.ascontiguousarray(xr, dtype=np.int32).reshape(-1, 576)
     n = xr.shape[0]
     mb = np.ascontiguousarray(np.broadcast_to(np.asarray(max_bits, dtype=np.int32), (n,)))
-    e = L.orc_enc_new(samplerate, 2, 128, None, 0)
+    hb = None if hide_bits is None or len(hide_bits) == 0 else bytes(int(b) + 48 for b in hide_bits)
+    e = L.orc_enc_new(samplerate, 2, 128, hb, 0 if hb is None else len(hb))
     try:
         ix = np.zeros((n, 576), dtype=np.int32)
         gi = np.zeros(n, dtype=GRINFO_DTYPE)

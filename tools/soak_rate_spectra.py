@@ -34,16 +34,23 @@ while time.time() - t0 < seconds:
         parts.append(sparse_spectra(int(rng.integers(1 << 31)), units // 4, base=min(base, 1 << 27)))
     xr = np.ascontiguousarray(np.concatenate(parts)[rng.permutation(units)])
     rf, _ = mlib.rate_frames(rate, kbps, 2, n)
-    want = orc.rate_units(rate, np.repeat(rf["max_bits"], 4), xr)
+    # every other batch with a message: each unit sees it from its start (cursor 0), so its up to three tables go through the swap (MP3_Encoder.py:1257-1263)
+    hide = rng.integers(0, 2, 3).astype(np.uint8) if batches % 2 else None
+    want = orc.rate_units(rate, np.repeat(rf["max_bits"], 4), xr, hide)
+    if hide is not None:
+        rf["hide_end"] = len(hide)
     d_mdct, d_rf = ctx.to_device(xr), ctx.to_device(rf)
+    d_hide = ctx.to_device(hide) if hide is not None else None
+    d_cur = ctx.to_device(np.zeros(units, dtype=np.int32)) if hide is not None else None
     d_ix, d_out, d_en = ctx.alloc(units * 576 * 2), ctx.alloc(units * 72), ctx.alloc(units * 22 * 4)
     d_state = ctx.to_device(np.zeros((units, 4), dtype=np.int32))
-    mlib.check(L.mp3s_rate_loop_dev(ctx.handle, d_mdct, d_rf, n, None, 0, None, d_state, None, 0, d_ix, d_out, d_en))
+    mlib.check(L.mp3s_rate_loop_dev(ctx.handle, d_mdct, d_rf, n, d_hide, 0 if hide is None else len(hide), d_cur, d_state, None, 0, d_ix, d_out, d_en))
     ctx.sync()
     out = ctx.download(d_out, mlib.GR_OUT_DTYPE, (units,))
     ix = ctx.download(d_ix, np.int16, (units, 576)).astype(np.int32)
-    for p in (d_mdct, d_rf, d_ix, d_out, d_en, d_state):
-        ctx.free(p)
+    for p in (d_mdct, d_rf, d_ix, d_out, d_en, d_state, d_hide, d_cur):
+        if p is not None:
+            ctx.free(p)
     gi = want["gi"]
     ok = want["rc"] == 0
     wrong = ((out["flags"] & mlib.RF_STEP_RANGE) != 0) != ~ok
@@ -56,7 +63,7 @@ while time.time() - t0 < seconds:
     wrong |= act & ~((ix == 0) | ((ix < 0) == (xr < 0))).all(1)
     nb = int(wrong.sum())
     if nb:
-        print("MISMATCH", rate, kbps, np.nonzero(wrong)[0][:8], flush=True)
+        print("MISMATCH", rate, kbps, None if hide is None else hide.tolist(), np.nonzero(wrong)[0][:8], flush=True)
     bad += nb; units_done += units; batches += 1; step_range += int((~ok).sum())
     if time.time() - t_say > 30:
         t_say = time.time()
