@@ -11,7 +11,10 @@ namespace mp3s {
 // waves per channel in a synthesis tile (tile = TW*64 - 15 output slots).  2: 31 KB of LDS per workgroup, five groups =
 // five waves per SIMD on a CU; the kernel waits for scalar-cache misses (the 16 KB matrix is streamed once per tile), so
 // the fifth wave buys more (0.217 -> 0.207 ms) than the larger halo share (15/128 instead of 15/256) costs
-constexpr int DEC_SYNTH_TW = 2;
+#ifndef MP3S_DEC_SYNTH_TW
+#define MP3S_DEC_SYNTH_TW 2
+#endif
+constexpr int DEC_SYNTH_TW = MP3S_DEC_SYNTH_TW;
 constexpr int DEC_SYNTH_FAST_TW = 2;   // the fast int16 variant (k_dec_synth_fast)
 
 // optional per-kernel HIP-event timing: when non-null, every kernel launch is bracketed by two events
