@@ -761,8 +761,9 @@ def main():
         four = {"frames_per_s": round(n * world / t4, 1), "ms_per_step": round(t4 * 1e3, 4), "steps": args.steps,
                 "dominant_kernel_ms_per_launch": round(p4[dom][0] / max(p4[dom][1], 1), 4),
                 "what": "the same step with the decode transforms of batch k+1 on a fourth context, under the encode transforms and the rate loop of batch k "
-                        "(they wait for scalar operands half of the time, the encode side is bound by the vector units): more frames per second, and every "
-                        "kernel -- the rate loop too -- takes longer beside the others, which is why `value` and the roofline stay with three streams"}
+                        "(they wait for scalar operands half of the time, the encode side is bound by the vector units): +2-3 % frames per second over "
+                        "200 steps, less than `value` over the driver's 20 (a longer fill and drain); every kernel -- the rate loop too -- takes longer "
+                        "beside the others, which is why `value` and the roofline stay with three streams"}
         dctx.close(); dctx = None
 
     # the resident steps are over: their helper contexts (second / third / fourth stream) go now -- the host-fed regions below are what
