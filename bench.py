@@ -1266,14 +1266,14 @@ def main():
             # VOP3 / DPP / compares / multiplies / fp64 1.9, v_mad_u64_u32 2.3, lane reads 2.4 -- five waves per SIMD, whatever the clock was)
             try:
                 rates = json.load(open(os.path.join(ROOT, "profiles", "r05_issue_rates.json")))
-                mix = json.load(open(os.path.join(ROOT, "profiles", "r05_kernel_mix.json")))[dom]
+                mix = json.load(open(os.path.join(ROOT, "profiles", "r06_kernel_mix.json")))[dom]
                 ns = {"full": rates["v_add_u32"]["ns_5"], "half": rates["v_bfe_u32"]["ns_5"], "mad64": rates["v_mad_u64_u32"]["ns_5"], "lane": rates["v_readlane_b32"]["ns_5"]}
                 mean_ns = sum(mix.get(c, 0) * ns[c] for c in ns) / max(1, sum(mix.get(c, 0) for c in ns))
                 peak_mix = N_SIMD / mean_ns                                   # G wave-instructions / s
                 roofline_alu.update({"peak_of_its_mix": round(peak_mix, 1), "frac_of_its_mix": round(ach / peak_mix, 4),
                                      "mix": {c: mix.get(c, 0) for c in ns}, "ns_per_wave_instruction_by_class": {c: round(v, 3) for c, v in ns.items()},
                                      "mean_ns_per_wave_instruction": round(mean_ns, 3),
-                                     "mix_source": "profiles/r05_kernel_mix.json (the LISTING's instructions by class, not executed counts: the counters of this chip "
+                                     "mix_source": "profiles/r06_kernel_mix.json (the LISTING's instructions by class, not executed counts: the counters of this chip "
                                                    "count vector instructions by data type, not by encoding -- see valu_by_type -- so the mix-weighted "
                                                    "peak is an estimate that brackets between frac_at_4_clk and 1) x profiles/r05_issue_rates.json (measured)"})
                 bytype = {k[len("SQ_INSTS_VALU_"):]: round(v * n / pm.get("frames", 10000)) for k, v in pm[dom].items() if k.startswith("SQ_INSTS_VALU_")}

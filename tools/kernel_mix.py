@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Static instruction mix of the step kernels, by the issue-cost classes tools/ubench/issue_rates.hip measures (CPU: compiles the device code
-to assembly).  Writes profiles/r05_kernel_mix.json; bench.py weights the dominant kernel's vector instructions with the measured cost of
+to assembly).  Writes profiles/r06_kernel_mix.json; bench.py weights the dominant kernel's vector instructions with the measured cost of
 their class (profiles/r05_issue_rates.json) instead of a flat 4 clocks.  The mix is the LISTING's (every instruction counted once), which
 stands for the dynamic one: the kernels' hot loops are unrolled straight-line code that makes up most of their listing.
 usage: python tools/kernel_mix.py"""
@@ -42,7 +42,7 @@ if __name__ == "__main__":
             if k:
                 c[k] += 1
         out[short.replace("mp3s::", "")] = dict(c, valu=sum(c.values()), instructions=len(ins))
-    path = os.path.join(isa_stats.ROOT, "profiles", "r05_kernel_mix.json")
+    path = os.path.join(isa_stats.ROOT, "profiles", "r06_kernel_mix.json")
     json.dump(out, open(path, "w"), indent=1, sort_keys=True)
     for k in ("k_rate_loop", "k_enc_analysis", "k_dec_stream<2, false, false>", "k_enc_mdct", "k_enc_pack", "k_dec_huffman<4, 64>"):
         print(k, out.get(k))
