@@ -16,7 +16,8 @@ g = np.load(os.path.join(gd, "g7_decode_corpus.npz"))
 names = sorted({k.split("__")[0] for k in g.files})
 t_end = time.time() + budget
 stats = {"dec_ok": 0, "dec_err": 0, "dec_bad": 0, "enc_ok": 0, "enc_err": 0, "enc_bad": 0}
-seed = 1000
+seed = 1000 + int(os.environ.get("SOAK_SEED", "0"))     # (SOAK_SEED: other cases than the default run's)
+seed0 = seed
 rates = (32000, 44100, 48000); kb = (32, 40, 48, 56, 64, 80, 96, 112, 128, 160, 192, 224, 256, 320)
 while time.time() < t_end:
     seed += 1
@@ -57,4 +58,4 @@ while time.time() < t_end:
     same = o["rc"] == 0 and r["mp3"] == o["mp3"] and r["hide_offset"] == o["hide_offset"]
     stats["enc_ok" if same else "enc_bad"] += 1
     if not same: print("ENC mismatch seed", seed, rate, kbps, kind, len(msg))
-print(stats, "seeds", seed - 1000)
+print(stats, "seeds", seed - seed0, "from", seed0)

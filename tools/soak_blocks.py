@@ -20,7 +20,7 @@ g = np.load(os.path.join(gd, "g7_decode_corpus.npz"))
 names = sorted({k.split("__")[0] for k in g.files})
 t_end = time.time() + budget
 stats = {"ok": 0, "both_reject": 0, "bad": 0}
-seed = 9000
+seed = 9000 + int(os.environ.get("SOAK_SEED", "0"))
 while time.time() < t_end:
     seed += 1
     rng = np.random.default_rng(seed)

@@ -19,7 +19,7 @@ t_end = time.time() + budget
 stats = {"single": 0, "batch_files": 0, "sharded": 0, "bad": 0}
 rates = (32000, 44100, 48000)
 kb = (32, 48, 64, 96, 128, 192, 256, 320)
-seed = 5000
+seed = 5000 + int(os.environ.get("SOAK_SEED", "0"))
 
 
 def signal(rng, n, rate):

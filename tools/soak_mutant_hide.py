@@ -34,7 +34,7 @@ def mlib_options(c, chunk_frames):
 
 t_end = time.time() + budget
 stats = {"ok": 0, "both_reject": 0, "bad": 0}
-seed = 30000
+seed = 30000 + int(os.environ.get("SOAK_SEED", "0"))
 while time.time() < t_end:
     seed += 1
     rng = np.random.default_rng(seed)

@@ -15,7 +15,7 @@ seconds = float(sys.argv[1]) if len(sys.argv) > 1 else 300.0
 ctx = mlib.Context(0)
 L = mlib.lib()
 t = mlib.debug_tables()
-rng = np.random.default_rng(606)
+rng = np.random.default_rng(606 + int(os.environ.get("SOAK_SEED", "0")))
 t0 = t_say = time.time()
 units_done = bad = batches = step_range = 0
 FIELDS = (("quantizer_step", "quantizerStepSize"), ("big_values", "big_values"), ("count1", "count1"), ("part2_3_length", "part2_3_length"),

@@ -18,7 +18,7 @@ budget = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
 ctx = mlib.Context(0)
 t_end = time.time() + budget
 stats = {"single": 0, "first_pass_final": 0, "batch_files": 0, "bad": 0, "frames": 0}
-seed = 9000
+seed = 9000 + int(os.environ.get("SOAK_SEED", "0"))
 
 
 def signal(rng, n):
