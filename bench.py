@@ -434,6 +434,15 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         return float(t[0])
 
+    # every comparison behind `parity_checked`, by name: a false flag says in `parity_failures` whether BYTES differed ("bytes: ...") or a job took
+    # another path than the default settings give it ("path: ...": e.g. MP3S_FILE_PIPELINE=0 in the environment -- tools/option_sweep.sh)
+    parity_failures = []
+
+    def note(label, ok):
+        if not ok and label not in parity_failures:
+            parity_failures.append(label)
+        return bool(ok)
+
     def reduce_all_ok(ok):
         if dist is None:
             return bool(ok)
@@ -725,14 +734,14 @@ def main():
     got_ix = ctx.download(d_ix, np.int16, (n, 2, 2, 576))
     got_pcm = ctx.download(d_pcm if dctx is None else d_pcm2[(state["k"] - 1) & 1], np.int16, (n * 1152, 2))
     got_mp3 = ctx.download(d_mp3, np.uint8, (int(frame_off[-1]),)).tobytes()
-    same = int(verdict[0]) == 0 and int(verdict[1]) == 0          # the chain check agrees: the step was the whole job
-    same = same and int(segout["cursor"][0]) - 32 == int(final["hide_offset"])
-    same = same and bool(np.array_equal(got_pcm, pcm16)) and got_mp3[:(len(got_mp3) // 4) * 4] == final["mp3"]
-    same = same and bool(np.array_equal(ctx.download(d_is, np.int16, (n, 2, 2, 576)), parsed["is"]))
-    same = same and int(ctx.download(d_hst, np.int32, (1,))[0]) == 0 and int(ctx.download(d_pst, np.int32, (1,))[0]) == 0
+    same = note("bytes: resident step, chain verdict", int(verdict[0]) == 0 and int(verdict[1]) == 0)          # the chain check agrees: the step was the whole job
+    same = note("bytes: resident step, message cursor", int(segout["cursor"][0]) - 32 == int(final["hide_offset"])) and same
+    same = note("bytes: resident step, PCM and MP3", bool(np.array_equal(got_pcm, pcm16)) and got_mp3[:(len(got_mp3) // 4) * 4] == final["mp3"]) and same
+    same = note("bytes: resident step, Huffman values", bool(np.array_equal(ctx.download(d_is, np.int16, (n, 2, 2, 576)), parsed["is"]))) and same
+    same = note("bytes: resident step, kernel status words", int(ctx.download(d_hst, np.int32, (1,))[0]) == 0 and int(ctx.download(d_pst, np.int32, (1,))[0]) == 0) and same
     for k in ("part2_3_length", "big_values", "count1", "table_select", "count1table_select", "region0_count",
               "region1_count", "n_tables", "quantizer_step", "address"):
-        same = same and bool(np.array_equal(got_gr[k], gr[k]))
+        same = note("bytes: resident step, GrInfo." + k, bool(np.array_equal(got_gr[k], gr[k]))) and same
     mp3_final = final["mp3"]
     # oracle check on a bounded prefix (the codec is causal: the first frames of the stream depend on nothing later)
     import oracle_lib as O
@@ -767,7 +776,7 @@ def main():
         for c in (ctx, dctx):
             c.profile_enable(False); c.profile_select(None)
         ok4 = int(ctx.download(d_verdict, np.int32, (2,))[0]) == 0 and ctx.download(d_mp3, np.uint8, (int(frame_off[-1]),)).tobytes() == got_mp3
-        same = same and ok4
+        same = note("bytes: four-stream step", ok4) and same
         t4 = reduce_max(w4 / args.steps)
         four = {"frames_per_s": round(n * world / t4, 1), "ms_per_step": round(t4 * 1e3, 4), "steps": args.steps,
                 "dominant_kernel_ms_per_launch": round(p4[dom][0] / max(p4[dom][1], 1), 4),
@@ -835,7 +844,7 @@ def main():
         dms = min(dms_overlap, dms_serial)           # (the better of the two arrangements, named in the record)
         f32 = ctx.download(d_pcm32, np.float32, (n * 1152, 2))
         f64 = ctx.decode_stream(mp3_in, _lib.MP3S_PCM_F64)["pcm"]
-        same = same and bool(np.array_equal(f32, f64.astype(np.float32)))
+        same = note("bytes: decode_only float32 exact", bool(np.array_equal(f32, f64.astype(np.float32)))) and same
         del f64
         # ... and with MP3S_OPT_FLOAT_FAST: float32 through the mirrored, fused IMDCT and the split synthesis (within 1e-5, not bit-identical)
         ctx.set_option("float_fast", 1)
@@ -867,14 +876,14 @@ def main():
         dec_sync()
         dms_i16_overlap = (time.perf_counter() - t0) / kd * 1e3
         dms_i16 = min(dms_i16_overlap, dms_i16_serial)
-        same = same and bool(np.array_equal(ctx.download(d_pcm, np.int16, (n * 1152, 2)), np.asarray(pcm16).reshape(-1, 2)))
+        same = note("bytes: decode_only int16", bool(np.array_equal(ctx.download(d_pcm, np.int16, (n * 1152, 2)), np.asarray(pcm16).reshape(-1, 2)))) and same
         dstate.update(i=0, fmt=_lib.MP3S_PCM_F32, out=d_pcm32)
         f64r = f32.astype(np.float64)        # (the exact kernels' float32 = the reference's float64 rounded once: the comparison is against that)
         dd = np.abs(f32f.astype(np.float64) - f64r)
         bigm = np.abs(f64r) > 1e-6
         fast_err = {"max_abs": float(dd.max()), "max_rel_where_abs_above_1e-6": float((dd[bigm] / np.abs(f64r[bigm])).max()),
                     "samples_that_differ": int((f32f != f32).sum()), "samples": int(f32.size)}
-        same = same and bool(np.allclose(f32f, f64r, rtol=1e-5, atol=1e-9))
+        same = note("tolerance: decode_only float32 fast within 1e-5", bool(np.allclose(f32f, f64r, rtol=1e-5, atol=1e-9))) and same
         del f32f, f64r, dd, bigm
         decode_only = {"workload": f"{n} frames, Huffman decode + decode transforms -> float32 PCM, resident (BASELINE configs[1])",
                        "float_fast": {"ms_per_step": round(dms_fast, 4), "frames_per_s": round(n / (dms_fast * 1e-3), 1), "serial_ms_per_step": round(dms_fast_serial, 4),
@@ -907,7 +916,7 @@ def main():
         t0 = time.perf_counter()
         hid = octx.hide_message(mp3_in, payload)                  # the first call makes the pipe
         t_first = time.perf_counter() - t0
-        same = same and bytes(hid["data"]) == bytes(final["mp3"])
+        same = note("bytes: hide_message against the resident result", bytes(hid["data"]) == bytes(final["mp3"])) and same
         ref_out = bytes(hid["data"])
         del hid
         frs = octx.run_stats()
@@ -922,7 +931,7 @@ def main():
             r = octx.hide_message(mp3_in, payload)
         t_one = (time.perf_counter() - t0) / k1
         rs1 = octx.run_stats()
-        same = same and bytes(r["data"]) == ref_out and rs1["files"] - rs0["files"] == k1
+        same = note("bytes: one file per call", bytes(r["data"]) == ref_out) and note("path: one file per call went through the file pipeline", rs1["files"] - rs0["files"] == k1) and same
         del r
         # (the main context, whose pipe was made beside the helper contexts of the resident steps: reported, not used)
         r = ctx.hide_message(mp3_in, payload)
@@ -930,7 +939,7 @@ def main():
         for _ in range(k1):
             r = ctx.hide_message(mp3_in, payload)
         t_main = (time.perf_counter() - t0) / k1
-        same = same and bytes(r["data"]) == ref_out
+        same = note("bytes: one file per call (variant)", bytes(r["data"]) == ref_out) and same
         del r
         first_call["ms_per_call_on_the_context_of_the_resident_steps"] = round(t_main * 1e3, 4)
         # ... and through the drop-in facade: Steganography.hide_message(quiet=True), files on a RAM disk where there is one
@@ -948,7 +957,7 @@ def main():
             for _ in range(10):
                 st.hide_message(src, dst, payload)
             t_fac = (time.perf_counter() - t0) / 10
-            same = same and open(dst, "rb").read() == ref_out
+            same = note("bytes: the facade's output file", open(dst, "rb").read() == ref_out) and same
             # ... into a file that is not there yet (the library writes the result chunk by chunk under the device's work; over a file that holds
             # something -- above -- it is written when the call has succeeded, as the reference leaves such a file alone when its encode fails)
             ts = []
@@ -958,7 +967,7 @@ def main():
                 st.hide_message(src, dst, payload)
                 ts.append(time.perf_counter() - t0)
             t_fac_new = sorted(ts)[len(ts) // 2]
-            same = same and open(dst, "rb").read() == ref_out
+            same = note("bytes: the facade's output file", open(dst, "rb").read() == ref_out) and same
         finally:
             shutil.rmtree(tdir, ignore_errors=True)
         regions["single_file_10k"] = {"ms_per_batch": round(t_one * 1e3, 4), "frames_per_s": round(n / t_one, 1), "batches": k1, "first_call": first_call,
@@ -974,7 +983,7 @@ def main():
         for _ in range(k1):
             r = octx.hide_message(mp3_in, payload)
         t_seq = (time.perf_counter() - t0) / k1
-        same = same and bytes(r["data"]) == ref_out
+        same = note("bytes: one file per call (variant)", bytes(r["data"]) == ref_out) and same
         del r
         octx.set_option("file_pipeline", 1)
         regions["bytes_to_bytes_one_at_a_time"] = {"ms_per_batch": round(t_seq * 1e3, 4), "frames_per_s": round(n / t_seq, 1), "batches": k1,
@@ -997,7 +1006,7 @@ def main():
                 r = octx.hide_message(big, payload)
             t_big = (time.perf_counter() - t0) / kb
             rs1 = octx.run_stats()
-            same = same and same_bytes(r["data"], big_out) and rs1["files"] - rs0["files"] == kb
+            same = note("bytes: 100 000-frame file", same_bytes(r["data"], big_out)) and note("path: 100 000-frame file went through the file pipeline", rs1["files"] - rs0["files"] == kb) and same
             del r
             r = octx.decode_file(big); del r                      # (the first call pins its 460 MB result block)
             t0 = time.perf_counter()
@@ -1042,11 +1051,11 @@ def main():
             _t, res = pipe.collect()
             if i >= 4:
                 spans.append(pipe.stats()["last_device_span_ms"])
-            same = same and bytes(res[0]["data"]) == ref_out
+            same = note("bytes: pipe job", bytes(res[0]["data"]) == ref_out) and same
             del res
         st1 = pipe.stats()
         pipe.close()
-        same = same and st1["fast"] == 24
+        same = note("path: 24 pipe jobs final after the first pass", st1["fast"] == 24) and same
         regions["h2d_kernels_d2h"] = {"ms_per_batch": round(float(np.mean(spans)), 4), "frames_per_s": round(n / (float(np.mean(spans)) * 1e-3), 1),
                                       "batches": len(spans),
                                       "what": "one batch at a time from page-locked staging: first uploaded byte to last downloaded byte (HIP events)",
@@ -1066,7 +1075,7 @@ def main():
                     del res
                     got += 1
                 return ok
-            same = pump(12, 1) and same                                   # warm-up: result blocks, pool sizes; every batch compared
+            same = note("bytes: e2e warm-up batches", pump(12, 1)) and same                                   # warm-up: result blocks, pool sizes; every batch compared
             if dist is not None:
                 dist.barrier()
             s0 = pipe.stats()
@@ -1075,7 +1084,7 @@ def main():
             t_e2e = time.perf_counter() - t0
             s1 = pipe.stats()
             pipe.close()
-            same = same and ok and (s1["fast"] - s0["fast"]) == args.e2e_batches
+            same = note("bytes: e2e batches", ok) and note("path: every e2e batch final after the first pass", (s1["fast"] - s0["fast"]) == args.e2e_batches) and same
             t_max = reduce_max(t_e2e)
             nb = args.e2e_batches
             e2e_steady = {"frames_per_s": round(n * nb * world / t_max, 1), "ms_per_batch": round(t_max / nb * 1e3, 4), "steps": nb,
@@ -1115,7 +1124,7 @@ def main():
                 pass
             mon.stop()
             pipe.close()
-            same = same and ok
+            same = note("bytes: host-fed region", ok) and same
             st = np.asarray(stamps)
             first_n, last_n = int((st <= t0 + 1.0).sum()), int((st > t1 - 1.0).sum())
             t_sus = reduce_max(t1 - t0)
@@ -1142,13 +1151,13 @@ def main():
                     del res
                     got += 1
                 return ok
-            same = pump_dec(8, 1) and same
+            same = note("bytes: decode_steady warm-up", pump_dec(8, 1)) and same
             t0 = time.perf_counter()
             ok = pump_dec(nbd, 64)
             t_dec_steady = reduce_max(time.perf_counter() - t0)
             sd = pipe.stats()
             pipe.close()
-            same = same and ok and sd["slow"] == 0
+            same = note("bytes: decode_steady batches", ok) and note("path: no decode job through the host parser", sd["slow"] == 0) and same
             regions["decode_steady"] = {"frames_per_s": round(n * nbd * world / t_dec_steady, 1), "ms_per_batch": round(t_dec_steady / nbd * 1e3, 4), "batches": nbd,
                                         "pcm_mb_down_per_batch": round(n * 2304 * 2 / 1e6, 1), "pcie_gbs_down": round(n * 2304 * 2 * nbd / t_dec_steady / 1e9, 1),
                                         "what": "BASELINE configs[1] host-fed: MP3 bytes -> WAV bytes (int16) through mp3s_pipe_submit_decode, several batches in "
@@ -1173,7 +1182,7 @@ def main():
             t_ls = reduce_max(time.perf_counter() - t0)
             sl = pipe.stats()
             pipe.close()
-            same = same and ok
+            same = note("bytes: host-fed region", ok) and same
             long_message["steady"] = {"ms_per_batch": round(t_ls / nbl * 1e3, 4), "frames_per_s": round(n * nbl * world / t_ls, 1), "batches": nbl,
                                       "resolved": sl["resolved"], "synchronous": sl["slow"],
                                       "what": "the same message through mp3s_pipe_*: decided on the device in the overlapped stages (resolved = jobs that still needed the host at collect time)"}
@@ -1191,17 +1200,17 @@ def main():
             t_l0 = time.time()
             loop_out = [ctx.hide_message(f, m) for f, m in zip(shorts, notes)]
             t_loop = time.time() - t_l0
-            same = same and all(not isinstance(b, Exception) and b["data"] == l["data"] for b, l in zip(batch_out, loop_out))
+            same = note("bytes: short files, batch against loop", all(not isinstance(b, Exception) and b["data"] == l["data"] for b, l in zip(batch_out, loop_out))) and same
             short_files = {"files": len(shorts), "frames_each": 40, "hide_messages_one_batch_s": round(t_batch, 4),
                            "hide_message_per_file_loop_s": round(t_loop, 4), "batch_files_per_s": round(len(shorts) / t_batch, 1)}
     # ---------------------------------------------------------------- BASELINE configs[4]: the mixed corpus
     config5 = None
     if not args.resident_only and not args.no_config5 and rank == 0 and world == 1:
         config5, ok5 = run_config5(octx if octx is not None else ctx, _lib, O, synth_pcm, min(n, 10000))
-        same = same and ok5
+        same = note("bytes: config 5", ok5) and same
     # ---------------------------------------------------------------- the ranks of one host side by side
     hosts = gather_rank_hosts(dist, world, rank_host_record(rank, args.scan_threads, e2e_steady, ctx.host_share))
-    same = reduce_all_ok(same and oracle_ok)
+    same = reduce_all_ok(note("bytes: oracle on the first 64 frames", oracle_ok) and same)
 
     # ---------------------------------------------------------------- rooflines of the dominant kernel
     # duration of the dominant kernel per batch, from the event pairs of the TIMED region
@@ -1370,7 +1379,7 @@ def main():
             "gpu_event_ms_per_step": round(gpu_ms / args.steps, 4),
             "timed_region_s": round(wall, 4),
             "front_end_overlap": front_end_overlap, "tail_stream": tail_stream,
-            "parity_checked": bool(same),
+            "parity_checked": bool(same), "parity_failures": parity_failures,
             "short_files": short_files,
             "config5": config5,
             "ranks_on_this_host": hosts,

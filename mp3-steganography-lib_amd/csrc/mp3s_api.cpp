@@ -393,6 +393,7 @@ int mp3s_decode_transform_dev(mp3s_ctx *c, const int16_t *d_is, const mp3s_granu
         return fail(MP3S_E_ARG, "bad sizes: n_frames=%d nch=%d n_halo=%d fmt=%d", n_frames, nch, n_halo, out_format);
     int rc = c->ensure_scratch(dec_scratch_bytes(n_frames, nch));
     if (rc) return rc;
+    if (int pe = guard_probe_usable(c, out_format)) return pe;
     const int e = launch_decode(c->stream, d_is, d_si, d_hdr, n_frames, nch, n_halo, out_format, d_pcm, c->scratch, &c->prof, 0,
                                 c->synth_eps_scale, c->d_sync, c->opt[MP3S_OPT_FAST_IMDCT] != 0, c->opt[MP3S_OPT_FLOAT_FAST] != 0,
                                 c->opt[MP3S_OPT_FUSED_DECODE] != 0, nullptr, [&]() -> const GuardProbe * {

@@ -69,6 +69,7 @@ int decode_transform_chunk(mp3s_ctx *c, const int16_t *d_is, const mp3s_granule_
 {
     int rc = c->ensure_scratch(dec_scratch_bytes(cnt, nch));
     if (rc) return rc;
+    if (int pe = guard_probe_usable(c, out_format)) return pe;
     const int e = launch_decode(stream ? stream : c->stream, d_is + (size_t)first * 2304, d_si + (size_t)first * 4, d_hdr + first, cnt, nch, halo, out_format,
                                 d_pcm, c->scratch, &c->prof, (int)first, c->synth_eps_scale, c->d_sync, c->opt[MP3S_OPT_FAST_IMDCT] != 0, c->opt[MP3S_OPT_FLOAT_FAST] != 0,
                                 c->opt[MP3S_OPT_FUSED_DECODE] != 0, done, [&]() -> const GuardProbe * {

@@ -106,6 +106,17 @@ struct mp3s_ctx {
 // Page-locked host memory for large results (decoded PCM): the device writes it at PCIe speed, no bounce buffer, no
 // page faults.  Pinning costs more than the copy it saves, so blocks are kept and reused: process-wide, because a
 // result may outlive the context that produced it.  (Blocks still cached at exit are left to the OS.)
+// mp3s_debug_guard_margin's probe is an instantiation of the stream kernel: an int16 decode that would take another route while the probe is set
+// (MP3S_OPT_FUSED_DECODE or MP3S_OPT_FAST_IMDCT off, the guard switched off) is refused -- it would leave the probe's arrays as they were.
+// (Float formats never fill them and pass.)
+inline int guard_probe_usable(const mp3s_ctx *c, int out_format)
+{
+    if (!c->guard_probe.x || out_format != MP3S_PCM_I16) return MP3S_OK;
+    if (c->opt[MP3S_OPT_FUSED_DECODE] && c->opt[MP3S_OPT_FAST_IMDCT] && c->synth_eps_scale > 0 && c->d_sync) return MP3S_OK;
+    return fail(MP3S_E_ARG, "the guard probe is set (mp3s_debug_guard_margin) and this int16 decode would not run the stream kernel that fills it "
+                            "(MP3S_OPT_FUSED_DECODE / MP3S_OPT_FAST_IMDCT off, or the guard's scale is 0)");
+}
+
 int local_world_size();   // mp3s_hostinfo.cpp: LOCAL_WORLD_SIZE of the launcher (1 without one)
 
 class PinnedBlock {

@@ -22,6 +22,8 @@ RESULTS = {}
 
 def margin(ctx, mlib, decode, n_samples):
     """decode(fmt) -> pcm; returns the statistics of r over the call's samples"""
+    if not (ctx.get_option("fused_decode") and ctx.get_option("fast_imdct")):
+        pytest.skip("the probe is an instantiation of the stream kernel, which this context's settings switch off (tools/option_sweep.sh)")
     exact = np.asarray(decode(mlib.MP3S_PCM_F64), dtype=np.float64).reshape(-1)
     assert exact.size == n_samples
     ctx.synth_mode(1.0)
@@ -132,3 +134,22 @@ def test_margin_on_adversarial_batch(ctx, mlib, golden_dir):
     ctx.synth_mode(1.0)
     assert np.array_equal(i16, want)
     record("adversarial: single lines, samples within 1e-9 of non-zero integers", res)
+
+
+def test_probe_refuses_a_decode_that_would_not_fill_it(ctx, mlib):
+    """with the stream kernel switched off the int16 decode takes the two kernels, which carry no probe: refused while the probe is set, not left unfilled"""
+    import frame_synth
+    data = frame_synth.make_stream(5, 40)
+    n = ctx.decode_stream(data, mlib.MP3S_PCM_I16)["pcm"].size
+    fused, piped = ctx.get_option("fused_decode"), ctx.get_option("file_pipeline")
+    ctx.set_option("file_pipeline", 0)                          # (as every use of the probe: one batch per call)
+    try:
+        with ctx.guard_margin(n):
+            ctx.set_option("fused_decode", 0)
+            with pytest.raises(mlib.Mp3sError, match="guard probe"):
+                ctx.decode_stream(data, mlib.MP3S_PCM_I16)
+            ctx.decode_stream(data, mlib.MP3S_PCM_F64)          # (float formats never fill it and pass)
+    finally:
+        ctx.set_option("fused_decode", fused)
+        ctx.set_option("file_pipeline", piped)
+    ctx.decode_stream(data, mlib.MP3S_PCM_I16)                  # the probe is gone: nothing is refused
