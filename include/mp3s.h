@@ -206,7 +206,7 @@ int mp3s_debug_scfsi_energies(const int32_t *xr576, int sr_idx, int32_t *en22);
  * for a granule it does not vouch for at all), at the sample's index in the call's PCM.  |x - 32767 * exact fp64 PCM| / eps is the margin
  * of the bound (tests/test_guard_margin.py asserts <= 0.5).  NULL, NULL, 0 ends the probe.  Not for production calls: 16 bytes more per sample.
  * The probe is an instantiation of the stream kernel: while it is set, an int16 decode that would not run that kernel (MP3S_OPT_FUSED_DECODE or
- * MP3S_OPT_FAST_IMDCT off, mp3s_ctx_synth_mode 0) returns MP3S_E_ARG instead of leaving the arrays as they were; float formats never fill them. */
+ * MP3S_OPT_FAST_IMDCT off, mp3s_synth_mode with scale 0) returns MP3S_E_ARG instead of leaving the arrays as they were; float formats never fill them. */
 int mp3s_debug_guard_margin(mp3s_ctx *ctx, double *d_x, double *d_eps, int64_t capacity);
 
 /* host decode (scalefactors + Huffman) of ONE frame of a scanned stream: what the stream pipelines do with the frames the
